@@ -1,0 +1,505 @@
+// libcoper_hip.so -- C ABI (include/coper_hip.h): handle, configuration validation, parameter
+// registry, prepare, workspace, and dispatch to the kernels.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "coper_internal.h"
+
+static thread_local std::string g_create_error;
+
+namespace coper {
+
+int fail(coper_handle* h, int code, const std::string& msg) {
+  if (h) h->err = msg; else g_create_error = msg;
+  return code;
+}
+
+int hip_fail(coper_handle* h, hipError_t e, const char* what) {
+  std::string msg = std::string("HIP error '") + hipGetErrorString(e) + "' in " + what;
+  (void)hipGetLastError();
+  return fail(h, COPER_EHIP, msg);
+}
+
+ScopedKernelTimer::ScopedKernelTimer(coper_handle* h_, const char* n, hipStream_t s_) : h(h_), name(n), s(s_) {
+  if (!h->profile) return;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { e0 = e1 = nullptr; return; }
+  (void)hipEventRecord(e0, s);
+}
+
+ScopedKernelTimer::~ScopedKernelTimer() {
+  if (!e0) return;
+  (void)hipEventRecord(e1, s);
+  h->timers[name].pending.emplace_back(e0, e1);
+}
+
+static void add_spec(coper_handle* h, const std::string& name, std::vector<int64_t> shape) {
+  h->specs.push_back({name, shape});
+  h->params[name] = Param();
+}
+
+static void add_bn_specs(coper_handle* h, const std::string& prefix, int64_t n) {
+  add_spec(h, prefix + "/gamma", {n});
+  add_spec(h, prefix + "/beta", {n});
+  add_spec(h, prefix + "/moving_mean", {n});
+  add_spec(h, prefix + "/moving_variance", {n});
+}
+
+// ContextualParameterGenerator.__init__ (models.py:44-54): projections [in, n] over context_size[1:] + [num_elements]
+static void add_generator_specs(coper_handle* h, const std::string& name, int n_hidden, const int32_t* hidden,
+                                int64_t num_elements) {
+  int64_t in = h->dm.r;
+  for (int i = 0; i <= n_hidden; ++i) {
+    int64_t n = i < n_hidden ? hidden[i] : num_elements;
+    char buf[256];
+    snprintf(buf, sizeof buf, "%s/CPG/Projection%d", name.c_str(), i);
+    add_spec(h, buf, {in, n});
+    if (i < n_hidden && h->dm.ctx_bn) add_bn_specs(h, std::string(buf) + "/BatchNorm", n);
+    in = n;
+  }
+}
+
+static int64_t prod(const std::vector<int64_t>& v) {
+  int64_t p = 1;
+  for (auto x : v) p *= x;
+  return p;
+}
+
+template <typename T>
+static int dev_alloc(coper_handle* h, T** p, size_t n) {
+  if (*p) { (void)hipFree(*p); *p = nullptr; }
+  if (n == 0) n = 1;
+  hipError_t e = hipMalloc((void**)p, n * sizeof(T));
+  if (e != hipSuccess) {
+    *p = nullptr;
+    (void)hipGetLastError();
+    char buf[128];
+    snprintf(buf, sizeof buf, "hipMalloc of %zu bytes failed", n * sizeof(T));
+    return fail(h, COPER_ENOMEM, buf);
+  }
+  return COPER_OK;
+}
+
+template <typename T>
+static void dev_free(T** p) {
+  if (*p) { (void)hipFree(*p); *p = nullptr; }
+}
+
+static int ensure_workspace(coper_handle* h, int64_t B, int64_t nnz, hipStream_t s) {
+  const Dims& dm = h->dm;
+  if (nnz > h->ws_nnz) h->ws_nnz = nnz;
+  if (B <= h->ws_queries && h->perm) return COPER_OK;
+  COPER_HIP_TRY(h, hipStreamSynchronize(s));
+  int64_t cap = B < 64 ? 64 : B;
+  int rc;
+  const int KSPLIT_MAX = 8;
+  if ((rc = dev_alloc(h, &h->rel_count, dm.R + 2))) return rc;
+  if ((rc = dev_alloc(h, &h->rel_offset, dm.R + 2))) return rc;
+  if ((rc = dev_alloc(h, &h->rel_cursor, dm.R + 2))) return rc;
+  if ((rc = dev_alloc(h, &h->perm, cap))) return rc;
+  if ((rc = dev_alloc(h, &h->tiles, 4 * (cap / 16 + dm.R + 2)))) return rc;
+  if ((rc = dev_alloc(h, &h->n_tiles, 4))) return rc;
+  if ((rc = dev_alloc(h, &h->x_sorted, (size_t)cap * dm.F_pad))) return rc;
+  if ((rc = dev_alloc(h, &h->z_part, (size_t)KSPLIT_MAX * cap * dm.d_pad16))) return rc;
+  if ((rc = dev_alloc(h, &h->tgt_ws, cap))) return rc;
+  if ((rc = dev_alloc(h, &h->cnt_ws, 2 * cap))) return rc;
+  h->ws_queries = cap;
+  h->ws_ksplit = KSPLIT_MAX;
+  return COPER_OK;
+}
+
+}  // namespace coper
+
+using namespace coper;
+
+extern "C" {
+
+COPER_API int coper_abi_version(void) { return COPER_ABI_VERSION; }
+
+COPER_API const char* coper_last_error(const coper_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+COPER_API int coper_create(const coper_config* cfg, coper_handle** out) {
+  if (!cfg || !out) return fail(nullptr, COPER_EINVAL, "coper_create: null argument");
+  *out = nullptr;
+  if (cfg->abi_version != COPER_ABI_VERSION) return fail(nullptr, COPER_EINVAL, "coper_create: abi_version mismatch");
+  coper_handle* h = new coper_handle();
+  h->cfg = *cfg;
+  Dims& dm = h->dm;
+  auto bad = [&](const char* m) {
+    int rc = fail(nullptr, COPER_EINVAL, std::string("coper_create: ") + m);
+    delete h;
+    return rc;
+  };
+  dm.E = cfg->num_ent; dm.R = cfg->num_rel; dm.d = cfg->ent_emb_size; dm.r = cfg->rel_emb_size;
+  dm.emb_h = cfg->emb_h; dm.emb_w = cfg->emb_w;
+  dm.fh = cfg->conv_filter_height; dm.fw = cfg->conv_filter_width; dm.C = cfg->conv_num_channels;
+  dm.concat_rel = cfg->concat_rel != 0; dm.lookup = cfg->do_parameter_lookup != 0;
+  dm.gen_conv = cfg->n_ctx_conv >= 0; dm.gen_fc = cfg->n_ctx_out >= 0;
+  dm.ctx_bn = cfg->context_rel_use_batch_norm != 0;
+  if (dm.E <= 0 || dm.R <= 0 || dm.d <= 0 || dm.r <= 0) return bad("num_ent, num_rel, ent_emb_size, rel_emb_size must be positive");
+  if (dm.R > 0x7fffffff || dm.E > 0x7fffffffffLL) return bad("num_rel / num_ent too large");
+  if (dm.fh <= 0 || dm.fw <= 0 || dm.C <= 0) return bad("conv filter sizes must be positive");
+  if (dm.emb_h <= 0 || dm.emb_w <= 0 || dm.emb_h * dm.emb_w != dm.d) return bad("emb_h * emb_w must equal ent_emb_size (models.py:355)");
+  if (cfg->n_ctx_conv > COPER_MAX_CTX || cfg->n_ctx_out > COPER_MAX_CTX) return bad("too many generator hidden layers");
+  if (cfg->shard_lo < 0 || cfg->shard_hi > dm.E || cfg->shard_lo >= cfg->shard_hi) return bad("entity shard [lo,hi) out of range");
+  if (cfg->score_mode != COPER_SCORE_F32) return bad("score_mode: only COPER_SCORE_F32 is built in this version");
+  // models.py:360: e1 stacked on the reshaped relation only for plain ConvE
+  dm.stacked = !dm.gen_conv && !dm.gen_fc && !dm.lookup;
+  dm.in_h = dm.emb_h; dm.in_w = dm.emb_w;
+  if (dm.stacked) {
+    if (dm.r % dm.emb_h != 0 || dm.r / dm.emb_h != dm.emb_w)
+      return bad("plain ConvE stacks e1 on rel (models.py:361-362): needs rel_emb_size == ent_emb_size");
+    dm.in_h = 2 * dm.emb_h;
+  } else if (!dm.gen_conv && !dm.gen_fc) {
+    return bad("do_parameter_lookup with both contexts None is ill-formed in the reference (models.py:263-264 vs :360)");
+  }
+  if (dm.lookup && dm.concat_rel) return bad("g_lookup passes relation ids as rel_emb: cannot concat_rel (models.py:180,406)");
+  dm.Ho = dm.in_h - dm.fh + 1; dm.Wo = dm.in_w - dm.fw + 1;
+  if (dm.Ho <= 0 || dm.Wo <= 0) return bad("conv filter larger than the image");
+  dm.F_conv = (int64_t)dm.Ho * dm.Wo * dm.C;
+  dm.F = dm.F_conv + (dm.concat_rel ? dm.r : 0);
+  dm.F_pad = (dm.F + 15) / 16 * 16;
+  dm.d_pad16 = (dm.d + 15) / 16 * 16; dm.nfb = dm.d_pad16 / 16;
+  dm.d_pad8 = (dm.d + 7) / 8 * 8; dm.KS = dm.d_pad8 / 8;
+  dm.n_local = cfg->shard_hi - cfg->shard_lo;
+  dm.n_eblk = ((dm.n_local + 31) / 32 + EBLK_ALIGN - 1) / EBLK_ALIGN * EBLK_ALIGN;
+  if (dm.KS * 2 * 64 * 16 > 160 * 1024) return bad("ent_emb_size too large for the LDS query tile");
+  if ((int64_t)dm.in_h * dm.in_w + (int64_t)dm.fh * dm.fw * dm.C + 3 * dm.C > 40000) return bad("conv stage too large for LDS");
+
+  // parameter specs (models.py:203-336)
+  add_spec(h, "ent_emb", {dm.n_local, dm.d});
+  add_spec(h, "pred_bias", {dm.n_local});
+  if (!dm.lookup) add_spec(h, "rel_emb", {dm.R, dm.r});
+  int64_t nconv = (int64_t)dm.fh * dm.fw * dm.C;
+  if (dm.gen_conv) {
+    if (dm.lookup) {
+      add_spec(h, "conv1_weights", {dm.R, nconv});
+      add_spec(h, "conv1_bias", {dm.R, dm.C});
+    } else {
+      add_generator_specs(h, "conv1_weights", cfg->n_ctx_conv, cfg->ctx_conv, nconv);
+      add_generator_specs(h, "conv1_bias", cfg->n_ctx_conv, cfg->ctx_conv, dm.C);
+    }
+  } else {
+    add_spec(h, "conv1_weights", {dm.fh, dm.fw, 1, dm.C});
+    add_spec(h, "conv1_bias", {dm.C});
+  }
+  if (dm.gen_fc) {
+    if (dm.lookup) {
+      add_spec(h, "fc_weights", {dm.R, dm.F * dm.d});
+      add_spec(h, "fc_bias", {dm.R, dm.d});
+    } else {
+      add_generator_specs(h, "fc_weights", cfg->n_ctx_out, cfg->ctx_out, dm.F * dm.d);
+      add_generator_specs(h, "fc_bias", cfg->n_ctx_out, cfg->ctx_out, dm.d);
+    }
+  } else {
+    add_spec(h, "fc_weights", {dm.F, dm.d});
+    add_spec(h, "fc_bias", {dm.d});
+  }
+  add_bn_specs(h, "Conv1BN", dm.C);
+  add_bn_specs(h, "FCBN", dm.d);
+  *out = h;
+  return COPER_OK;
+}
+
+COPER_API void coper_destroy(coper_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->cfg.device);
+  (void)hipDeviceSynchronize();
+  dev_free(&h->conv_scale); dev_free(&h->conv_shift); dev_free(&h->fc_scale); dev_free(&h->fc_shift);
+  dev_free(&h->conv_w_rel); dev_free(&h->conv_b_rel); dev_free(&h->fc_b_rel); dev_free(&h->Wf);
+  dev_free(&h->Ef); dev_free(&h->bias_pad); dev_free(&h->ctx_tmp[0]); dev_free(&h->ctx_tmp[1]);
+  dev_free(&h->rel_count); dev_free(&h->rel_offset); dev_free(&h->rel_cursor); dev_free(&h->perm);
+  dev_free(&h->tiles); dev_free(&h->n_tiles); dev_free(&h->x_sorted); dev_free(&h->z_part);
+  dev_free(&h->tgt_ws); dev_free(&h->cnt_ws);
+  for (auto& kv : h->timers)
+    for (auto& p : kv.second.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+  delete h;
+}
+
+COPER_API int coper_get_dims(const coper_handle* h, int64_t* F, int32_t* Ho, int32_t* Wo, int64_t* n_local) {
+  if (!h) return COPER_EINVAL;
+  if (F) *F = h->dm.F;
+  if (Ho) *Ho = h->dm.Ho;
+  if (Wo) *Wo = h->dm.Wo;
+  if (n_local) *n_local = h->dm.n_local;
+  return COPER_OK;
+}
+
+COPER_API int coper_num_params(const coper_handle* h) { return h ? (int)h->specs.size() : 0; }
+
+COPER_API int coper_param_spec(const coper_handle* h, int index, const char** leaf_name, int64_t* shape_out, int* ndim_out) {
+  if (!h || index < 0 || index >= (int)h->specs.size()) return COPER_EINVAL;
+  const ParamSpec& sp = h->specs[index];
+  if (leaf_name) *leaf_name = sp.name.c_str();
+  if (ndim_out) *ndim_out = (int)sp.shape.size();
+  if (shape_out)
+    for (size_t i = 0; i < sp.shape.size() && i < 4; ++i) shape_out[i] = sp.shape[i];
+  return COPER_OK;
+}
+
+COPER_API int coper_set_param(coper_handle* h, const char* leaf_name, const void* dev_ptr, const int64_t* shape, int ndim) {
+  if (!h || !leaf_name || !dev_ptr || !shape || ndim <= 0) return fail(h, COPER_EINVAL, "coper_set_param: null argument");
+  auto it = h->params.find(leaf_name);
+  if (it == h->params.end())
+    return fail(h, COPER_EINVAL, std::string("coper_set_param: '") + leaf_name + "' is not a parameter of this configuration");
+  const ParamSpec* sp = nullptr;
+  for (auto& s : h->specs)
+    if (s.name == leaf_name) sp = &s;
+  std::vector<int64_t> got(shape, shape + ndim);
+  if (prod(got) != prod(sp->shape)) {
+    char buf[256];
+    snprintf(buf, sizeof buf, "coper_set_param: '%s' has %lld elements, configuration needs %lld", leaf_name,
+             (long long)prod(got), (long long)prod(sp->shape));
+    return fail(h, COPER_ESHAPE, buf);
+  }
+  it->second.ptr = (const float*)dev_ptr;
+  it->second.shape = got;
+  it->second.set = true;
+  h->prepared = false;
+  return COPER_OK;
+}
+
+// Evaluate one generator for every relation id: ctx chain through the hidden layers (BN folded, ReLU),
+// returns the final context and its width.  (models.py:56-70)
+static int run_generator_hidden(coper_handle* h, const std::string& name, int n_hidden, const int32_t* hidden,
+                                const float** ctx_out, int* K_out, hipStream_t s) {
+  const Dims& dm = h->dm;
+  const float* cur = h->params["rel_emb"].ptr;
+  int K = dm.r;
+  for (int i = 0; i < n_hidden; ++i) {
+    char buf[256];
+    snprintf(buf, sizeof buf, "%s/CPG/Projection%d", name.c_str(), i);
+    int n = hidden[i];
+    float* dst = h->ctx_tmp[i & 1];
+    const float* sc = nullptr;
+    const float* sh = nullptr;
+    float* scb = nullptr;
+    if (dm.ctx_bn) {
+      // fold this layer's BN into a scratch (scale | shift) placed after the activations
+      scb = h->ctx_tmp[i & 1] + (size_t)dm.R * n;
+      std::string bn = std::string(buf) + "/BatchNorm";
+      int rc = launch_fold_bn(h, h->params[bn + "/gamma"].ptr, h->params[bn + "/beta"].ptr,
+                              h->params[bn + "/moving_mean"].ptr, h->params[bn + "/moving_variance"].ptr, n,
+                              h->cfg.bn_epsilon, scb, scb + n, s);
+      if (rc) return rc;
+      sc = scb; sh = scb + n;
+    }
+    int rc = launch_gen_small(h, cur, dm.R, K, h->params[buf].ptr, n, sc, sh, true, dst, s);
+    if (rc) return rc;
+    cur = dst;
+    K = n;
+  }
+  *ctx_out = cur;
+  *K_out = K;
+  return COPER_OK;
+}
+
+COPER_API int coper_prepare(coper_handle* h, void* stream) {
+  if (!h) return COPER_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const Dims& dm = h->dm;
+  const coper_config& cfg = h->cfg;
+  for (auto& sp : h->specs)
+    if (!h->params[sp.name].set) return fail(h, COPER_EMISSING, "coper_prepare: parameter '" + sp.name + "' was never set");
+  COPER_HIP_TRY(h, hipSetDevice(cfg.device));
+  int rc;
+  if ((rc = dev_alloc(h, &h->conv_scale, dm.C)) || (rc = dev_alloc(h, &h->conv_shift, dm.C)) ||
+      (rc = dev_alloc(h, &h->fc_scale, dm.d)) || (rc = dev_alloc(h, &h->fc_shift, dm.d)))
+    return rc;
+  auto P = [&](const std::string& n) { return h->params[n].ptr; };
+  if ((rc = launch_fold_bn(h, P("Conv1BN/gamma"), P("Conv1BN/beta"), P("Conv1BN/moving_mean"),
+                           P("Conv1BN/moving_variance"), dm.C, cfg.bn_epsilon, h->conv_scale, h->conv_shift, s)))
+    return rc;
+  if ((rc = launch_fold_bn(h, P("FCBN/gamma"), P("FCBN/beta"), P("FCBN/moving_mean"), P("FCBN/moving_variance"),
+                           dm.d, cfg.bn_epsilon, h->fc_scale, h->fc_shift, s)))
+    return rc;
+
+  // scratch for generator hidden activations: R * max_hidden (+ 2 * max_hidden for the folded BN)
+  int max_hidden = 1;
+  for (int i = 0; i < cfg.n_ctx_conv; ++i) max_hidden = cfg.ctx_conv[i] > max_hidden ? cfg.ctx_conv[i] : max_hidden;
+  for (int i = 0; i < cfg.n_ctx_out; ++i) max_hidden = cfg.ctx_out[i] > max_hidden ? cfg.ctx_out[i] : max_hidden;
+  size_t tmp_elems = (size_t)(dm.R + 2) * max_hidden;
+  if ((rc = dev_alloc(h, &h->ctx_tmp[0], tmp_elems)) || (rc = dev_alloc(h, &h->ctx_tmp[1], tmp_elems))) return rc;
+
+  int64_t nconv = (int64_t)dm.fh * dm.fw * dm.C;
+  if (dm.gen_conv) {
+    if ((rc = dev_alloc(h, &h->conv_w_rel, (size_t)dm.R * nconv)) || (rc = dev_alloc(h, &h->conv_b_rel, (size_t)dm.R * dm.C)))
+      return rc;
+    if (dm.lookup) {  // ParameterLookup.generate (models.py:90-94): the table row IS the parameter
+      COPER_HIP_TRY(h, hipMemcpyAsync(h->conv_w_rel, P("conv1_weights"), sizeof(float) * dm.R * nconv, hipMemcpyDeviceToDevice, s));
+      COPER_HIP_TRY(h, hipMemcpyAsync(h->conv_b_rel, P("conv1_bias"), sizeof(float) * dm.R * dm.C, hipMemcpyDeviceToDevice, s));
+    } else {
+      const float* ctx; int K; char buf[256];
+      if ((rc = run_generator_hidden(h, "conv1_weights", cfg.n_ctx_conv, cfg.ctx_conv, &ctx, &K, s))) return rc;
+      snprintf(buf, sizeof buf, "conv1_weights/CPG/Projection%d", cfg.n_ctx_conv);
+      if ((rc = launch_gen_small(h, ctx, dm.R, K, P(buf), nconv, nullptr, nullptr, false, h->conv_w_rel, s))) return rc;
+      if ((rc = run_generator_hidden(h, "conv1_bias", cfg.n_ctx_conv, cfg.ctx_conv, &ctx, &K, s))) return rc;
+      snprintf(buf, sizeof buf, "conv1_bias/CPG/Projection%d", cfg.n_ctx_conv);
+      if ((rc = launch_gen_small(h, ctx, dm.R, K, P(buf), dm.C, nullptr, nullptr, false, h->conv_b_rel, s))) return rc;
+    }
+  }
+  int64_t ksteps = dm.F_pad / 16;
+  size_t per_rel = (size_t)dm.nfb * ksteps * 64 * 4;  // floats
+  h->Rw = dm.gen_fc ? dm.R : 1;
+  if ((rc = dev_alloc(h, &h->Wf, per_rel * h->Rw))) return rc;
+  if (dm.gen_fc) {
+    if ((rc = dev_alloc(h, &h->fc_b_rel, (size_t)dm.R * dm.d))) return rc;
+    if (dm.lookup) {
+      COPER_HIP_TRY(h, hipMemcpyAsync(h->fc_b_rel, P("fc_bias"), sizeof(float) * dm.R * dm.d, hipMemcpyDeviceToDevice, s));
+      if ((rc = launch_gen_dense_frag(h, nullptr, dm.R, 0, P("fc_weights"), 1, h->Wf, s))) return rc;
+    } else {
+      const float* ctx; int K; char buf[256];
+      if ((rc = run_generator_hidden(h, "fc_bias", cfg.n_ctx_out, cfg.ctx_out, &ctx, &K, s))) return rc;
+      snprintf(buf, sizeof buf, "fc_bias/CPG/Projection%d", cfg.n_ctx_out);
+      if ((rc = launch_gen_small(h, ctx, dm.R, K, P(buf), dm.d, nullptr, nullptr, false, h->fc_b_rel, s))) return rc;
+      if ((rc = run_generator_hidden(h, "fc_weights", cfg.n_ctx_out, cfg.ctx_out, &ctx, &K, s))) return rc;
+      snprintf(buf, sizeof buf, "fc_weights/CPG/Projection%d", cfg.n_ctx_out);
+      if ((rc = launch_gen_dense_frag(h, ctx, dm.R, K, P(buf), 0, h->Wf, s))) return rc;
+    }
+  } else {
+    if ((rc = launch_gen_dense_frag(h, nullptr, 1, 0, P("fc_weights"), 1, h->Wf, s))) return rc;
+  }
+  // entity table image
+  if ((rc = dev_alloc(h, &h->Ef, (size_t)dm.n_eblk * dm.KS * 64 * 4)) || (rc = dev_alloc(h, &h->bias_pad, (size_t)dm.n_eblk * 32)))
+    return rc;
+  if ((rc = launch_entity_frag(h, P("ent_emb"), P("pred_bias"), s))) return rc;
+  h->prepared = true;
+  return COPER_OK;
+}
+
+COPER_API int coper_reserve(coper_handle* h, int64_t max_queries, int64_t max_filter_nnz, void* stream) {
+  if (!h || max_queries < 0 || max_filter_nnz < 0) return fail(h, COPER_EINVAL, "coper_reserve: bad argument");
+  COPER_HIP_TRY(h, hipSetDevice(h->cfg.device));
+  return ensure_workspace(h, max_queries, max_filter_nnz, (hipStream_t)stream);
+}
+
+#define COPER_REQUIRE_PREPARED(h)                                                           \
+  do {                                                                                      \
+    if (!(h)) return COPER_EINVAL;                                                          \
+    if (!(h)->prepared) return fail((h), COPER_ESTATE, "coper_prepare has not been called"); \
+  } while (0)
+
+COPER_API int coper_gather_entities(coper_handle* h, const int64_t* ids, int64_t B, float* out, void* stream) {
+  COPER_REQUIRE_PREPARED(h);
+  if (B == 0) return COPER_OK;
+  if (!ids || !out || B < 0) return fail(h, COPER_EINVAL, "coper_gather_entities: bad argument");
+  return launch_gather_entities(h, ids, B, out, (hipStream_t)stream);
+}
+
+COPER_API int coper_encode(coper_handle* h, const int64_t* e1, const int64_t* rel, int64_t B, const float* e1_rows,
+                 float* h_out, void* stream) {
+  COPER_REQUIRE_PREPARED(h);
+  if (B == 0) return COPER_OK;  // empty batch: nothing to do (the reference's session.run on an empty batch returns [0,d])
+  if (!rel || !h_out || B < 0 || (!e1 && !e1_rows)) return fail(h, COPER_EINVAL, "coper_encode: bad argument");
+  if (B > 0x7fffffff) return fail(h, COPER_EINVAL, "coper_encode: batch too large");
+  hipStream_t s = (hipStream_t)stream;
+  const Dims& dm = h->dm;
+  int rc;
+  if ((rc = ensure_workspace(h, B, 0, s))) return rc;
+  const int tq = 32;
+  // K-split of the dense layer depends on F only, never on the batch: h[b] is then a pure function of
+  // (e1[b], rel[b]) -- bit-identical whatever batch, chunking or rank computes it.
+  int64_t ksteps = dm.F_pad / 16;
+  int ksplit = ksteps >= 64 ? 4 : 1;
+  if (ksplit > h->ws_ksplit) ksplit = h->ws_ksplit;
+  if ((rc = launch_group_by_relation(h, rel, B, tq, s))) return rc;
+  if ((rc = launch_conv(h, e1, rel, e1_rows, B, s))) return rc;
+  return launch_dense(h, rel, B, tq, ksplit, h_out, s);
+}
+
+COPER_API int coper_score_all(coper_handle* h, const float* hvec, int64_t B, float* logits, int64_t ld, void* stream) {
+  COPER_REQUIRE_PREPARED(h);
+  if (B == 0) return COPER_OK;
+  if (!hvec || !logits || B < 0 || ld < h->dm.n_local) return fail(h, COPER_EINVAL, "coper_score_all: bad argument");
+  return launch_score_all(h, hvec, B, logits, ld, (hipStream_t)stream);
+}
+
+COPER_API int coper_score_lookup(coper_handle* h, const float* hvec, const int32_t* lookup, int64_t B, int64_t L, float* out,
+                       void* stream) {
+  COPER_REQUIRE_PREPARED(h);
+  if (B == 0 || L == 0) return COPER_OK;  // eval batches carry lookup_values of shape [B, 0] (data.py:205-213)
+  if (!hvec || !lookup || !out || B < 0 || L < 0) return fail(h, COPER_EINVAL, "coper_score_lookup: bad argument");
+  return launch_score_lookup(h, hvec, lookup, B, L, out, (hipStream_t)stream);
+}
+
+COPER_API int coper_target_scores(coper_handle* h, const float* hvec, const int64_t* e2, int64_t B, float* tgt, void* stream) {
+  COPER_REQUIRE_PREPARED(h);
+  if (B == 0) return COPER_OK;
+  if (!hvec || !e2 || !tgt || B < 0) return fail(h, COPER_EINVAL, "coper_target_scores: bad argument");
+  return launch_pair_targets(h, hvec, e2, B, tgt, (hipStream_t)stream);
+}
+
+COPER_API int coper_rank_counts(coper_handle* h, const float* hvec, const float* tgt, const int64_t* e2,
+                      const int64_t* filt_indptr, const int64_t* filt_idx, int64_t filt_nnz, int64_t B, int32_t k,
+                      int32_t* n_greater, int32_t* n_equal, float* topk_val, int64_t* topk_idx, void* stream) {
+  COPER_REQUIRE_PREPARED(h);
+  if (B == 0) return COPER_OK;
+  if (!hvec || !tgt || !e2 || !filt_indptr || !n_greater || !n_equal || B < 0 || filt_nnz < 0 ||
+      (filt_nnz > 0 && !filt_idx))
+    return fail(h, COPER_EINVAL, "coper_rank_counts: bad argument");
+  if (k != 0) return fail(h, COPER_EUNSUPPORTED, "coper_rank_counts: top-k (k > 0) is not built in this version");
+  (void)topk_val; (void)topk_idx;
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  if ((rc = ensure_workspace(h, B, filt_nnz, s))) return rc;
+  COPER_HIP_TRY(h, hipMemsetAsync(n_greater, 0, sizeof(int32_t) * B, s));
+  COPER_HIP_TRY(h, hipMemsetAsync(n_equal, 0, sizeof(int32_t) * B, s));
+  if ((rc = launch_score_count(h, hvec, tgt, B, n_greater, n_equal, s))) return rc;
+  return launch_filter_correct(h, hvec, tgt, e2, filt_indptr, filt_idx, filt_nnz, B, n_greater, n_equal, s);
+}
+
+COPER_API int coper_rank(coper_handle* h, const float* hvec, const int64_t* e2, const int64_t* filt_indptr,
+               const int64_t* filt_idx, int64_t filt_nnz, int64_t B, int32_t* ranks, int32_t* n_equal, void* stream) {
+  COPER_REQUIRE_PREPARED(h);
+  if (B == 0) return COPER_OK;
+  if (!ranks || B < 0) return fail(h, COPER_EINVAL, "coper_rank: bad argument");
+  if (h->dm.n_local != h->dm.E) return fail(h, COPER_ESTATE, "coper_rank needs the whole table; sharded handles use coper_target_scores + coper_rank_counts");
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  if ((rc = ensure_workspace(h, B, filt_nnz, s))) return rc;
+  if ((rc = coper_target_scores(h, hvec, e2, B, h->tgt_ws, stream))) return rc;
+  int32_t* ng = h->cnt_ws;
+  int32_t* ne = n_equal ? n_equal : h->cnt_ws + h->ws_queries;
+  if ((rc = coper_rank_counts(h, hvec, h->tgt_ws, e2, filt_indptr, filt_idx, filt_nnz, B, 0, ng, ne, nullptr, nullptr, stream)))
+    return rc;
+  return launch_finish_ranks(h, ng, B, ranks, s);
+}
+
+COPER_API int coper_check_ids(coper_handle* h, int64_t* n_bad, void* stream) {
+  if (!h || !n_bad) return COPER_EINVAL;
+  *n_bad = 0;
+  if (!h->rel_count) return COPER_OK;
+  int32_t v = 0;
+  COPER_HIP_TRY(h, hipMemcpyAsync(&v, h->rel_count + h->dm.R + 1, sizeof v, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  COPER_HIP_TRY(h, hipStreamSynchronize((hipStream_t)stream));
+  *n_bad = v;
+  return COPER_OK;
+}
+
+COPER_API int coper_profile_enable(coper_handle* h, int enable) {
+  if (!h) return COPER_EINVAL;
+  h->profile = enable != 0;
+  return COPER_OK;
+}
+
+COPER_API int coper_profile_read(coper_handle* h, const char* kernel, double* total_ms, int64_t* launches) {
+  if (!h || !kernel) return COPER_EINVAL;
+  Timer& t = h->timers[kernel];
+  for (auto& p : t.pending) {
+    COPER_HIP_TRY(h, hipEventSynchronize(p.second));
+    float ms = 0.f;
+    COPER_HIP_TRY(h, hipEventElapsedTime(&ms, p.first, p.second));
+    t.total_ms += ms;
+    t.launches += 1;
+    (void)hipEventDestroy(p.first);
+    (void)hipEventDestroy(p.second);
+  }
+  t.pending.clear();
+  if (total_ms) *total_ms = t.total_ms;
+  if (launches) *launches = t.launches;
+  t.total_ms = 0.0;
+  t.launches = 0;
+  return COPER_OK;
+}
+
+}  // extern "C"

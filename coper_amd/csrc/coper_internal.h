@@ -1,0 +1,147 @@
+// Internal declarations shared by the libcoper_hip.so translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/coper_hip.h"
+
+namespace coper {
+
+struct Param {
+  const float* ptr = nullptr;
+  std::vector<int64_t> shape;
+  bool set = false;
+};
+
+struct ParamSpec {
+  std::string name;
+  std::vector<int64_t> shape;
+};
+
+// Derived sizes, exactly as ConvE._create_variables derives them (models.py:261-271).
+struct Dims {
+  int64_t E = 0, R = 0;
+  int d = 0, r = 0, emb_h = 0, emb_w = 0;
+  int fh = 3, fw = 3, C = 32;
+  bool concat_rel = false, lookup = false, gen_conv = false, gen_fc = false, stacked = false, ctx_bn = false;
+  int in_h = 0, in_w = 0, Ho = 0, Wo = 0;
+  int64_t F_conv = 0, F = 0;
+  // padded sizes used by the MFMA layouts
+  int64_t F_pad = 0;   // F rounded up to 16 (one 16x16x4 super-step = 16 f)
+  int d_pad16 = 0;     // d rounded up to 16 (feature blocks of the dense layer)
+  int nfb = 0;         // d_pad16 / 16
+  int d_pad8 = 0;      // d rounded up to 8 (k-steps of the score kernels)
+  int KS = 0;          // d_pad8 / 8
+  int64_t n_local = 0; // shard rows
+  int64_t n_eblk = 0;  // 32-row entity blocks (padded to a multiple of EBLK_ALIGN)
+};
+
+constexpr int EBLK_ALIGN = 8;  // entity blocks consumed per workgroup iteration in score_count
+
+struct Timer {
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+  double total_ms = 0.0;
+  int64_t launches = 0;
+};
+
+}  // namespace coper
+
+struct coper_handle {
+  coper_config cfg;
+  coper::Dims dm;
+  std::vector<coper::ParamSpec> specs;
+  std::map<std::string, coper::Param> params;
+  std::string err;
+  bool prepared = false;
+
+  // ---- derived device buffers (owned) ----
+  float* conv_scale = nullptr;  // [C]   folded Conv1BN
+  float* conv_shift = nullptr;
+  float* fc_scale = nullptr;    // [d]   folded FCBN
+  float* fc_shift = nullptr;
+  float* conv_w_rel = nullptr;  // [R, fh*fw, C] generated / looked-up conv filters (gen_conv)
+  float* conv_b_rel = nullptr;  // [R, C]
+  float* fc_b_rel = nullptr;    // [R, d]  (gen_fc)
+  float* Wf = nullptr;          // dense weights, fragment-major: [Rw][nfb][F_pad/16][64] float4
+  int64_t Rw = 0;               // R when gen_fc else 1
+  float* Ef = nullptr;          // entity table, fragment-major: [n_eblk][KS][64] float4
+  float* bias_pad = nullptr;    // [n_eblk*32], -inf padded
+  float* ctx_tmp[2] = {nullptr, nullptr};  // generator hidden activations
+  size_t ctx_tmp_elems = 0;
+
+  // ---- workspace (owned, grown lazily) ----
+  int64_t ws_queries = 0;
+  int64_t ws_nnz = 0;
+  int ws_ksplit = 0;
+  int32_t* rel_count = nullptr;   // [R+1]
+  int32_t* rel_offset = nullptr;  // [R+1]
+  int32_t* rel_cursor = nullptr;  // [R]
+  int32_t* perm = nullptr;        // [B] sorted position -> query
+  int32_t* tiles = nullptr;       // [T_max*4] (rel, start, n, pad)
+  int32_t* n_tiles = nullptr;     // [1]
+  float* x_sorted = nullptr;      // [B, F_pad]
+  float* z_part = nullptr;        // [ksplit, B, d_pad16]
+  float* tgt_ws = nullptr;        // [B]
+  int32_t* cnt_ws = nullptr;      // [2B]
+
+  bool profile = false;
+  std::map<std::string, coper::Timer> timers;
+};
+
+namespace coper {
+
+int fail(coper_handle* h, int code, const std::string& msg);
+int hip_fail(coper_handle* h, hipError_t e, const char* what);
+
+#define COPER_HIP_TRY(h, expr)                                    \
+  do {                                                            \
+    hipError_t _e = (expr);                                       \
+    if (_e != hipSuccess) return coper::hip_fail((h), _e, #expr); \
+  } while (0)
+
+// kernels_prepare.hip
+int launch_fold_bn(coper_handle* h, const float* gamma, const float* beta, const float* mean, const float* var,
+                   int n, float eps, float* scale, float* shift, hipStream_t s);
+// out[rel, n] = act( sum_k ctx[rel,k] * P[k,n] ), optional BN+ReLU epilogue (generator hidden layers,
+// conv filters/biases, dense bias): small N.
+int launch_gen_small(coper_handle* h, const float* ctx, int64_t R, int K, const float* P, int64_t N,
+                     const float* bn_scale, const float* bn_shift, bool relu, float* out, hipStream_t s);
+// dense weights into fragment-major Wf.  mode 0: sum_k ctx[rel,k]*P[k, f*d+i]; mode 1: P[rel, f*d+i] (lookup
+// and static: ctx == nullptr).
+int launch_gen_dense_frag(coper_handle* h, const float* ctx, int64_t R, int K, const float* P, int mode,
+                          float* Wf, hipStream_t s);
+int launch_entity_frag(coper_handle* h, const float* ent, const float* bias, hipStream_t s);
+
+// kernels_encode.hip
+int launch_group_by_relation(coper_handle* h, const int64_t* rel, int64_t B, int tq, hipStream_t s);
+int launch_conv(coper_handle* h, const int64_t* e1, const int64_t* rel, const float* e1_rows, int64_t B,
+                hipStream_t s);
+int launch_dense(coper_handle* h, const int64_t* rel, int64_t B, int tq, int ksplit, float* h_out, hipStream_t s);
+int launch_gather_entities(coper_handle* h, const int64_t* ids, int64_t B, float* out, hipStream_t s);
+
+// kernels_score.hip
+int launch_score_all(coper_handle* h, const float* hvec, int64_t B, float* logits, int64_t ld, hipStream_t s);
+int launch_score_count(coper_handle* h, const float* hvec, const float* tgt, int64_t B, int32_t* ng, int32_t* ne,
+                       hipStream_t s);
+int launch_pair_targets(coper_handle* h, const float* hvec, const int64_t* e2, int64_t B, float* tgt, hipStream_t s);
+int launch_filter_correct(coper_handle* h, const float* hvec, const float* tgt, const int64_t* e2,
+                          const int64_t* indptr, const int64_t* idx, int64_t nnz, int64_t B, int32_t* ng,
+                          int32_t* ne, hipStream_t s);
+int launch_score_lookup(coper_handle* h, const float* hvec, const int32_t* lookup, int64_t B, int64_t L, float* out,
+                        hipStream_t s);
+int launch_finish_ranks(coper_handle* h, const int32_t* ng, int64_t B, int32_t* ranks, hipStream_t s);
+
+// profiling helpers (hipEvents on the launch stream)
+struct ScopedKernelTimer {
+  coper_handle* h;
+  const char* name;
+  hipStream_t s;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  ScopedKernelTimer(coper_handle* h_, const char* n, hipStream_t s_);
+  ~ScopedKernelTimer();
+};
+
+}  // namespace coper

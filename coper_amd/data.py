@@ -1,0 +1,293 @@
+"""Synthetic knowledge graphs, the reference batch contract, and sparse (CSR) filters.
+
+The reference loader (`qa_cpg/data.py`) is out of scope as an engine;
+what is in scope is the *batch contract* it defines and the evaluator consumes
+(`models.py:139-152`, `data.py:168-226`):
+
+    {'e1': int64 [B], 'e2': int64 [B], 'rel': int64 [B],
+     'e2_multi': float32 [B, |E|]   (eval: dense 0/1 mask of ALL known tails of (e1, rel)),
+     'lookup_values': int32 [B, 0]}  (eval: empty)
+
+This module yields that contract with the mask kept SPARSE (`filt_indptr`, `filt_idx`: the
+int64 list the reference stores in its TFRecords before `tf.sparse_to_dense`, data.py:182-186,591)
+and a dense-mask adapter for API parity.  No real dataset exists offline
+(`/root/reference/.MISSING_LARGE_BLOBS`), so the BASELINE configurations are synthetic KGs of the
+named |E|, |R|, d.  numpy only: nothing here touches the oracle or the GPU."""
+from __future__ import annotations
+
+import math
+from typing import Dict, Iterator, Optional
+
+import numpy as np
+
+__all__ = ["CONFIGS", "model_descriptors", "synthetic_params", "synthetic_queries", "SyntheticKGLoader",
+           "dense_filter_to_csr", "csr_to_dense_filter", "param_shapes"]
+
+_COMMON = dict(use_negative_sampling=False, label_smoothing_epsilon=0.1, input_dropout=0.2, hidden_dropout=0.3,
+               output_dropout=0.2, add_loss_summaries=False, add_variable_summaries=False,
+               add_tensor_summaries=False, learning_rate=0.001, concat_rel=False, context_rel_dropout=0.2,
+               context_rel_use_batch_norm=True, batch_norm_momentum=0.99, batch_norm_train_stats=True)
+
+# BASELINE.json configs, made concrete as in BASELINE.md section 2 (R2 = 2|R|: `_reverse` relations
+# get their own ids, data.py:422-428).  `queries` = queries per evaluation pass.
+CONFIGS = {
+    # CoPER-ConvE on Nations-shaped data, plumbing (config_nations_cpg.yaml shapes with BASELINE's d=32)
+    "nations_cpg": dict(num_ent=14, num_rel=110, ent_emb_size=32, rel_emb_size=8, emb_h=4, emb_w=8,
+                        context_rel_conv=None, context_rel_out=[], queries=2000),
+    # config_FB15k-237_cpg.yaml
+    "fb15k237_cpg": dict(num_ent=14541, num_rel=474, ent_emb_size=200, rel_emb_size=32,
+                         context_rel_conv=None, context_rel_out=[], queries=20480),
+    # config_WN18RR_cpg.yaml
+    "wn18rr_cpg": dict(num_ent=40943, num_rel=22, ent_emb_size=200, rel_emb_size=8,
+                       context_rel_conv=None, context_rel_out=[], queries=3072),
+    # config_FB15k-237_plain.yaml
+    "fb15k237_plain": dict(num_ent=14541, num_rel=474, ent_emb_size=200, rel_emb_size=200,
+                           context_rel_conv=None, context_rel_out=None, queries=20480),
+    # synthetic 10M-entity KG (BASELINE.json configs[4])
+    "synth10m_cpg": dict(num_ent=10_000_000, num_rel=2000, ent_emb_size=256, rel_emb_size=32, emb_h=16, emb_w=16,
+                         context_rel_conv=None, context_rel_out=[], queries=4096),
+}
+
+
+def model_descriptors(name: str, **overrides) -> dict:
+    """The `model_descriptors` dict `run_cpg.py:115-137` builds, for a named BASELINE config."""
+    md = dict(_COMMON)
+    md.update(CONFIGS[name])
+    md.pop("queries", None)
+    md.update(overrides)
+    return md
+
+
+def _dims(md):
+    d, r = int(md["ent_emb_size"]), int(md["rel_emb_size"])
+    fh, fw, C = int(md.get("conv_filter_height", 3)), int(md.get("conv_filter_width", 3)), int(md.get("conv_num_channels", 32))
+    emb_h = int(md.get("emb_h", 10))
+    emb_w = int(md.get("emb_w", d // emb_h))
+    lookup = bool(md.get("do_parameter_lookup", False))
+    gen_conv = md.get("context_rel_conv", None) is not None
+    gen_fc = md.get("context_rel_out", None) is not None
+    stacked = (not gen_conv) and (not gen_fc) and (not lookup)
+    in_h = 2 * emb_h if stacked else emb_h
+    Ho, Wo = in_h - fh + 1, emb_w - fw + 1
+    F = Ho * Wo * C + (r if md.get("concat_rel", False) else 0)
+    return dict(d=d, r=r, fh=fh, fw=fw, C=C, emb_h=emb_h, emb_w=emb_w, lookup=lookup, gen_conv=gen_conv,
+                gen_fc=gen_fc, stacked=stacked, Ho=Ho, Wo=Wo, F=F)
+
+
+def param_shapes(md: dict) -> Dict[str, tuple]:
+    """Leaf name -> shape of every variable `ConvE._create_variables` creates (models.py:203-336),
+    plus the BN variables of `tf.layers.batch_normalization` (models.py:63-65,386-388,416-418)."""
+    dm = _dims(md)
+    E, R, d, r, C = int(md["num_ent"]), int(md["num_rel"]), dm["d"], dm["r"], dm["C"]
+    F = dm["F"]
+    sh = {"ent_emb": (E, d), "pred_bias": (E,)}
+    if not dm["lookup"]:
+        sh["rel_emb"] = (R, r)
+    ctx_bn = bool(md.get("context_rel_use_batch_norm", False))
+
+    def gen(name, hidden, n_out):
+        size_in = r
+        for i, n in enumerate(list(hidden) + [n_out]):
+            sh["%s/CPG/Projection%d" % (name, i)] = (size_in, n)
+            if i < len(hidden) and ctx_bn:
+                for leaf in ("gamma", "beta", "moving_mean", "moving_variance"):
+                    sh["%s/CPG/Projection%d/BatchNorm/%s" % (name, i, leaf)] = (n,)
+            size_in = n
+
+    nconv = dm["fh"] * dm["fw"] * C
+    if dm["gen_conv"]:
+        if dm["lookup"]:
+            sh["conv1_weights"] = (R, nconv)
+            sh["conv1_bias"] = (R, C)
+        else:
+            gen("conv1_weights", md["context_rel_conv"], nconv)
+            gen("conv1_bias", md["context_rel_conv"], C)
+    else:
+        sh["conv1_weights"] = (dm["fh"], dm["fw"], 1, C)
+        sh["conv1_bias"] = (C,)
+    if dm["gen_fc"]:
+        if dm["lookup"]:
+            sh["fc_weights"] = (R, F * d)
+            sh["fc_bias"] = (R, d)
+        else:
+            gen("fc_weights", md["context_rel_out"], F * d)
+            gen("fc_bias", md["context_rel_out"], d)
+    else:
+        sh["fc_weights"] = (F, d)
+        sh["fc_bias"] = (d,)
+    for leaf in ("gamma", "beta", "moving_mean", "moving_variance"):
+        sh["Conv1BN/" + leaf] = (C,)
+        sh["FCBN/" + leaf] = (d,)
+    return sh
+
+
+def synthetic_params(md: dict, seed: int = 0, skip=()) -> Dict[str, np.ndarray]:
+    """Random-init weights of the named architecture with O(1) activations by construction
+    (SURVEY 8(d)): entity rows ~ N(0, 0.3^2); filters / dense weights scaled so that the
+    pre-BN activations have ~unit variance; BN statistics close to the analytic moments, with
+    gamma ~ U(0.5,1.5), beta ~ N(0,0.1^2); pred_bias ~ N(0,0.1^2).  Logits come out O(1-10),
+    which makes the 1e-3 parity gate meaningful.  `skip`: leaf names not to materialise here
+    (e.g. 'ent_emb' of the 10M-entity config, generated on the device instead)."""
+    rng = np.random.default_rng(seed)
+    dm = _dims(md)
+    shapes = param_shapes(md)
+    d, r, C, F = dm["d"], dm["r"], dm["C"], dm["F"]
+    s_e, s_c = 0.3, 0.3
+    p = {}
+
+    def normal(shape, std):
+        return (rng.standard_normal(shape, dtype=np.float32) * np.float32(std)).astype(np.float32)
+
+    for name, shape in shapes.items():
+        if name in skip:
+            continue
+        leaf = name.rsplit("/", 1)[-1]
+        if name == "ent_emb":
+            p[name] = normal(shape, s_e)
+        elif name == "rel_emb":
+            p[name] = normal(shape, s_e if dm["stacked"] else s_c)
+        elif name == "pred_bias":
+            p[name] = normal(shape, 0.1)
+        elif leaf == "gamma":
+            p[name] = rng.uniform(0.5, 1.5, shape).astype(np.float32)
+        elif leaf == "beta":
+            p[name] = normal(shape, 0.1)
+        elif leaf == "moving_mean":
+            p[name] = normal(shape, 0.1)
+        elif leaf == "moving_variance":
+            p[name] = rng.uniform(0.8, 1.25, shape).astype(np.float32)
+        elif "/CPG/Projection" in name:
+            base = name.split("/", 1)[0]
+            fan_in = shape[0]
+            idx = int(name.rsplit("Projection", 1)[1])
+            hidden = md["context_rel_conv"] if base.startswith("conv1") else md["context_rel_out"]
+            last = idx == len(hidden)
+            if last:
+                ctx_std = s_c if idx == 0 else 0.6  # relu(BN(.)) hidden activations ~ 0.6 rms
+                target = {"conv1_weights": 1.0 / (s_e * 3.0), "conv1_bias": 0.1,
+                          "fc_weights": 1.0 / math.sqrt(0.5 * F), "fc_bias": 0.1}[base]
+                p[name] = normal(shape, target / (ctx_std * math.sqrt(fan_in)))
+            else:
+                ctx_std = s_c if idx == 0 else 0.6
+                p[name] = normal(shape, 1.0 / (ctx_std * math.sqrt(fan_in)))
+        elif name == "conv1_weights":
+            p[name] = normal(shape, 1.0 / (s_e * 3.0))
+        elif name == "conv1_bias":
+            p[name] = normal(shape, 0.1)
+        elif name == "fc_weights":
+            p[name] = normal(shape, 1.0 / math.sqrt(0.5 * F))
+        elif name == "fc_bias":
+            p[name] = normal(shape, 0.1)
+        else:  # pragma: no cover
+            raise KeyError(name)
+    return p
+
+
+def synthetic_queries(md: dict, Q: int, seed: int = 0, mean_filter: float = 4.0, max_filter: int = 64,
+                      order: str = "shuffled"):
+    """Evaluation queries + CSR known-answer filters: e1, e2 ~ U[0,|E|); rel ~ U[0,|R|)
+    over the FORWARD half of the R2 table (eval excludes inverse relations, run_cpg.py:156,164,172);
+    filter list = {e2} U Geometric(mean 4, cap 64) uniform entities, sorted unique.
+    order: 'shuffled' | 'sorted' (by relation -- exposes the per-relation weight reuse)."""
+    rng = np.random.default_rng(seed + 1000003)
+    E, R2 = int(md["num_ent"]), int(md["num_rel"])
+    Rf = max(1, R2 // 2)
+    e1 = rng.integers(0, E, Q, dtype=np.int64)
+    rel = rng.integers(0, Rf, Q, dtype=np.int64)
+    e2 = rng.integers(0, E, Q, dtype=np.int64)
+    if order == "sorted":
+        o = np.argsort(rel, kind="stable")
+        e1, rel, e2 = e1[o], rel[o], e2[o]
+    n_extra = np.minimum(rng.geometric(1.0 / (1.0 + mean_filter), Q) - 1, max_filter - 1)
+    n_extra = np.minimum(n_extra, E - 1)
+    indptr = np.zeros(Q + 1, dtype=np.int64)
+    rows = []
+    for i in range(Q):
+        extra = rng.integers(0, E, int(n_extra[i]), dtype=np.int64)
+        row = np.unique(np.concatenate([extra, e2[i:i + 1]]))
+        rows.append(row)
+        indptr[i + 1] = indptr[i] + len(row)
+    idx = np.concatenate(rows) if rows else np.zeros(0, np.int64)
+    return dict(e1=e1, rel=rel, e2=e2, filt_indptr=indptr, filt_idx=idx.astype(np.int64))
+
+
+def dense_filter_to_csr(e2_multi: np.ndarray):
+    """Dense 0/1 mask [B,|E|] (data.py:182-186) -> (indptr int64 [B+1], idx int64 sorted)."""
+    rows, cols = np.nonzero(np.asarray(e2_multi) == 1)
+    B = e2_multi.shape[0]
+    indptr = np.zeros(B + 1, dtype=np.int64)
+    np.add.at(indptr, rows + 1, 1)
+    return np.cumsum(indptr), cols.astype(np.int64)
+
+
+def csr_to_dense_filter(indptr, idx, num_ent: int) -> np.ndarray:
+    B = len(indptr) - 1
+    m = np.zeros((B, num_ent), dtype=np.float32)
+    for i in range(B):
+        m[i, idx[indptr[i]:indptr[i + 1]]] = 1.0
+    return m
+
+
+class SyntheticKGLoader(object):
+    """Mirror of the reference loader surface the driver touches (data.py:25-29,82-100,168-174):
+    `dataset_name`, `num_ent`, `num_rel`, `needs_test_set_cleaning`, `eval_dataset(...)`.
+    `eval_dataset` returns a re-iterable of batches in the reference batch contract with the filter
+    in CSR form (`filt_indptr`, `filt_idx`); `dense_mask=True` also materialises `e2_multi`."""
+
+    def __init__(self, config_name: str = "fb15k237_cpg", seed: int = 0, queries: Optional[int] = None,
+                 md: Optional[dict] = None):
+        self.dataset_name = config_name
+        self.md = md if md is not None else model_descriptors(config_name)
+        self.num_ent = int(self.md["num_ent"])
+        self.num_rel = int(self.md["num_rel"])
+        self.needs_test_set_cleaning = False
+        self.seed = seed
+        self.queries = queries if queries is not None else CONFIGS.get(config_name, {}).get("queries", 1024)
+        self._cache = {}
+
+    def maybe_create_tf_record_files(self, directory=None, buffer_size=None):
+        return None  # nothing to create: the KG is synthetic
+
+    def _queries(self, dataset_type):
+        if dataset_type not in self._cache:
+            salt = {"train": 1, "dev": 2, "test": 3}.get(dataset_type, 4)
+            self._cache[dataset_type] = synthetic_queries(self.md, self.queries, seed=self.seed * 7 + salt)
+        return self._cache[dataset_type]
+
+    def eval_dataset(self, directory=None, dataset_type="test", batch_size=512, include_inv_relations=False,
+                     buffer_size=None, prefetch_buffer_size=None, dense_mask=False):
+        q = self._queries(dataset_type)
+        return EvalDataset(q, batch_size, self.num_ent, dense_mask)
+
+
+class EvalDataset(object):
+    """Re-iterable batch source; exhausting it is the end-of-data signal the reference gets as
+    `tf.errors.OutOfRangeError` (metrics.py:59)."""
+
+    def __init__(self, q, batch_size, num_ent, dense_mask=False):
+        self.q, self.batch_size, self.num_ent, self.dense_mask = q, int(batch_size), num_ent, dense_mask
+
+    def __len__(self):
+        return (len(self.q["e1"]) + self.batch_size - 1) // self.batch_size
+
+    @property
+    def num_queries(self):
+        return len(self.q["e1"])
+
+    def as_single_batch(self):
+        q = self.q
+        return dict(e1=q["e1"], e2=q["e2"], rel=q["rel"], filt_indptr=q["filt_indptr"], filt_idx=q["filt_idx"],
+                    lookup_values=np.zeros((len(q["e1"]), 0), np.int32))
+
+    def __iter__(self) -> Iterator[dict]:
+        q = self.q
+        Q = len(q["e1"])
+        for s in range(0, Q, self.batch_size):
+            e = min(Q, s + self.batch_size)
+            ip = q["filt_indptr"][s:e + 1]
+            batch = dict(e1=q["e1"][s:e], e2=q["e2"][s:e], rel=q["rel"][s:e],
+                         filt_indptr=(ip - ip[0]).astype(np.int64), filt_idx=q["filt_idx"][ip[0]:ip[-1]],
+                         lookup_values=np.zeros((e - s, 0), np.int32))
+            if self.dense_mask:
+                batch["e2_multi"] = csr_to_dense_filter(batch["filt_indptr"], batch["filt_idx"], self.num_ent)
+            yield batch

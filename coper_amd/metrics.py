@@ -1,0 +1,111 @@
+"""`ranking_and_hits` -- drop-in for `qa_cpg.metrics.ranking_and_hits` (metrics.py:23-86).
+
+Same signature, same return `(mr, mrr, hits)`, same float64 means (metrics.py:65-76), same
+optional result files (metrics.py:14-20,70-83).  What changes is where the work happens: the
+reference fetches `[B,|E|]` logits and a dense `[B,|E|]` filter mask to the host every batch and
+argsorts each row in Python (metrics.py:40-57); here the batches are concatenated, encoded and
+ranked on the device (fused score + count, CSR filter), and only int32 ranks come back."""
+from __future__ import annotations
+
+import logging
+import os
+
+import numpy as np
+import torch
+
+from .data import dense_filter_to_csr
+from .sharding import EntityShardedRanker, local_rank_pass
+
+__all__ = ["ranking_and_hits", "hits_and_means", "collect_batches"]
+
+logger = logging.getLogger(__name__)
+
+
+def _write_data_to_file(file_path, data):
+    append_write = "a" if os.path.exists(file_path) else "w+"
+    with open(file_path, append_write) as handle:
+        handle.write(str(data) + "\n")
+
+
+def hits_and_means(ranks, hits_to_compute=(1, 3, 5, 10, 20)):
+    """metrics.py:53-57,65-76: per-query 1.0/0.0 hits, float64 means."""
+    ranks = np.asarray(ranks, dtype=np.int64)
+    hits = {}
+    for hits_level in hits_to_compute:
+        hits[hits_level] = np.mean(np.where(ranks <= hits_level, 1.0, 0.0)) if len(ranks) else float("nan")
+    mr = np.mean(ranks) if len(ranks) else float("nan")
+    mrr = np.mean(1. / ranks) if len(ranks) else float("nan")
+    return mr, mrr, hits
+
+
+def collect_batches(data_iterator_handle):
+    """Drains a batch source (the role of the `while not stopped` loop, metrics.py:38-60) into one set
+    of query arrays with a CSR filter.  Accepts batches carrying `filt_indptr`/`filt_idx` or the
+    reference's dense `e2_multi`."""
+    if hasattr(data_iterator_handle, "as_single_batch"):
+        return data_iterator_handle.as_single_batch()
+    e1, e2, rel, indptr, idx = [], [], [], [np.zeros(1, np.int64)], []
+    base = 0
+    for batch in data_iterator_handle:
+        n = len(batch["e1"])
+        if n == 0:
+            continue
+        e1.append(np.asarray(batch["e1"], np.int64))
+        e2.append(np.asarray(batch["e2"], np.int64))
+        rel.append(np.asarray(batch["rel"], np.int64))
+        if "filt_indptr" in batch:
+            ip, ix = np.asarray(batch["filt_indptr"], np.int64), np.asarray(batch["filt_idx"], np.int64)
+        else:
+            ip, ix = dense_filter_to_csr(np.asarray(batch["e2_multi"]))
+        indptr.append(ip[1:] + base)
+        idx.append(ix)
+        base += int(ip[-1])
+    cat = lambda xs, dt: np.concatenate(xs).astype(dt) if xs else np.zeros(0, dt)
+    return dict(e1=cat(e1, np.int64), e2=cat(e2, np.int64), rel=cat(rel, np.int64),
+                filt_indptr=np.concatenate(indptr).astype(np.int64), filt_idx=cat(idx, np.int64))
+
+
+def ranking_and_hits(model, results_dir, data_iterator_handle, name, session=None, hits_to_compute=(1, 3, 5, 10, 20),
+                     enable_write_to_file=False, max_chunk=32768, ranker=None, return_ranks=False):
+    """`session` is accepted and ignored (the model object is the session).  Extra keyword-only
+    options: `max_chunk` queries per device pass, `ranker` = an `EntityShardedRanker` for
+    entity-sharded multi-GPU evaluation, `return_ranks` to also get the int ranks."""
+    if results_dir is not None:
+        os.makedirs(results_dir, exist_ok=True)
+    logger.info("")
+    logger.info("-" * 50)
+    logger.info(name)
+    logger.info("-" * 50)
+    logger.info("")
+
+    q = collect_batches(data_iterator_handle)
+    Q = len(q["e1"])
+    ranks = []
+    for s in range(0, Q, max_chunk):
+        e = min(Q, s + max_chunk)
+        ip = q["filt_indptr"][s:e + 1]
+        chunk = dict(e1=q["e1"][s:e], e2=q["e2"][s:e], rel=q["rel"][s:e], filt_indptr=ip - ip[0],
+                     filt_idx=q["filt_idx"][ip[0]:ip[-1]])
+        if ranker is not None:
+            r, _ = ranker.rank(chunk)
+        else:
+            r, _ = local_rank_pass(model, chunk)
+        ranks.append(r)
+    ranks = torch.cat(ranks).cpu().numpy().astype(np.int64) if ranks else np.zeros(0, np.int64)
+    count = Q
+    logger.info("Evaluated %d samples." % count)
+
+    mr, mrr, hits = hits_and_means(ranks, hits_to_compute)
+    for hits_level in hits_to_compute:
+        logger.info("Hits @%d: %10.6f", hits_level, hits[hits_level])
+        if enable_write_to_file:
+            _write_data_to_file(os.path.join(results_dir, "hits_at_{}.txt".format(hits_level)), hits[hits_level])
+    logger.info("Mean rank: %10.6f", mr)
+    logger.info("Mean reciprocal rank: %10.6f", mrr)
+    if enable_write_to_file:
+        _write_data_to_file(os.path.join(results_dir, "mean_rank.txt"), mr)
+        _write_data_to_file(os.path.join(results_dir, "mrr.txt"), mrr)
+    logger.info("-" * 50)
+    if return_ranks:
+        return mr, mrr, hits, ranks
+    return mr, mrr, hits

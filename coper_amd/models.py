@@ -1,0 +1,349 @@
+"""`ConvE` -- host-side mirror of `qa_cpg.models.ConvE` (CoPER_ConvE/qa_cpg/models.py:97-201) over
+libcoper_hip.so.
+
+Same constructor contract (`ConvE(model_descriptors)`, keys of models.py:99-130), same variable
+names (`.variables[...]`, models.py:316-325), same fetch attributes the callers use
+(`.e1 .e2 .rel .e2_multi .obj_lookup_values .predicted_e2_emb .predictions_all
+.predictions_lookup .is_train .input_iterator_handle`, models.py:135-190), evaluated through a
+`session.run(fetches, feed_dict)` shim (`ConvE.session()`), so `run_cpg.py:_evaluate` /
+`metrics.ranking_and_hits` read the same.  Inference only: `.loss` / `.train_op` raise.
+
+torch is plumbing (device memory, streams); all compute is in the HIP library.  There is no CPU
+path: constructing a model without a GPU or without the built library raises."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .data import param_shapes
+
+__all__ = ["ConvE", "ContextualParameterGenerator", "ParameterLookup", "OutOfRangeError"]
+
+
+class OutOfRangeError(Exception):
+    """End of an evaluation pass (the reference sees `tf.errors.OutOfRangeError`, metrics.py:59)."""
+
+
+class ContextualParameterGenerator(object):
+    """Parameter holder mirroring models.py:32-54: `.projections` = list of [in, n] matrices named
+    '<name>/CPG/Projection<i>'.  `generate` happens on the device inside `coper_prepare`."""
+
+    def __init__(self, name, shape, projections, batch_norms):
+        self.name, self.shape, self.projections, self.batch_norms = name, list(shape), projections, batch_norms
+
+
+class ParameterLookup(object):
+    """Parameter holder mirroring models.py:79-88: `.param_lookup_matrix` [num_rel, prod(shape)]."""
+
+    def __init__(self, name, output_shape, matrix):
+        self.name, self.output_shape, self.param_lookup_matrix = name, list(output_shape), matrix
+
+
+class _Fetch(object):
+    def __init__(self, name):
+        self.name = name
+
+    def __repr__(self):
+        return "<coper fetch %s>" % self.name
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class ConvE(object):
+    def __init__(self, model_descriptors: dict, device=None, shard=None, score_mode="f32"):
+        md = dict(model_descriptors)
+        # required keys, as models.py:99-105,119-130 reads them
+        for key in ("use_negative_sampling", "label_smoothing_epsilon", "num_ent", "num_rel", "ent_emb_size",
+                    "rel_emb_size", "input_dropout", "hidden_dropout", "output_dropout", "add_loss_summaries",
+                    "add_variable_summaries", "add_tensor_summaries", "learning_rate"):
+            if key not in md:
+                raise KeyError(key)
+        self.model_descriptors = md
+        self.use_negative_sampling = md["use_negative_sampling"]
+        self.num_ent, self.num_rel = int(md["num_ent"]), int(md["num_rel"])
+        self.ent_emb_size, self.rel_emb_size = int(md["ent_emb_size"]), int(md["rel_emb_size"])
+        self.is_parameter_lookup = md.get("do_parameter_lookup", False)
+        self.context_rel_conv = md.get("context_rel_conv", None)
+        self.context_rel_out = md.get("context_rel_out", None)
+        self.concat_rel = md.get("concat_rel", False)
+
+        if not torch.cuda.is_available():
+            raise RuntimeError("coper_amd.ConvE needs a HIP device: the product path has no CPU fallback")
+        self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        self.shard = (0, self.num_ent) if shard is None else (int(shard[0]), int(shard[1]))
+        self._lib = _lib.load()
+        mode = {"f32": _lib.SCORE_F32, "bf16x3": _lib.SCORE_BF16X3, "bf16": _lib.SCORE_BF16}[score_mode]
+        self.score_mode = score_mode
+        cfg = _lib.make_config(md, device=self.device.index or 0, shard=self.shard, score_mode=mode)
+        h = C.c_void_p()
+        rc = self._lib.coper_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise _lib.CoperError(rc, (self._lib.coper_last_error(None) or b"").decode())
+        self._h = h
+        F, Ho, Wo, nl = C.c_int64(), C.c_int32(), C.c_int32(), C.c_int64()
+        self._lib.coper_get_dims(h, C.byref(F), C.byref(Ho), C.byref(Wo), C.byref(nl))
+        self.fc_input_size, self.conv_out_height, self.conv_out_width, self.n_local = F.value, Ho.value, Wo.value, nl.value
+
+        # parameter specs from the library (single source of truth for the shapes)
+        self._specs = {}
+        for i in range(self._lib.coper_num_params(h)):
+            name, shape, nd = C.c_char_p(), (C.c_int64 * 4)(), C.c_int()
+            self._lib.coper_param_spec(h, i, C.byref(name), shape, C.byref(nd))
+            self._specs[name.value.decode()] = tuple(shape[j] for j in range(nd.value))
+        self._tensors: Dict[str, torch.Tensor] = {}
+        self._prepared = False
+
+        # fetch handles (models.py:135-190)
+        self.input_iterator_handle = _Fetch("input_iterator_handle")
+        self.is_train = _Fetch("is_train")
+        self.e1, self.e2, self.rel = _Fetch("e1"), _Fetch("e2"), _Fetch("rel")
+        self.e2_multi = _Fetch("e2_multi")
+        self.obj_lookup_values = _Fetch("lookup_values") if self.use_negative_sampling else None
+        self.predicted_e2_emb = _Fetch("predicted_e2_emb")
+        self.predictions_all = _Fetch("predictions_all")
+        self.predictions_lookup = _Fetch("predictions_lookup")
+        self.summaries = None
+
+    # ---------------------------------------------------------------- parameters
+    @property
+    def parameter_specs(self) -> Dict[str, tuple]:
+        """leaf name -> LOCAL shape (ent_emb / pred_bias rows are the shard's)."""
+        return dict(self._specs)
+
+    def load_parameters(self, params: Dict[str, "np.ndarray | torch.Tensor"], global_rows=True):
+        """Sets parameters by the reference's leaf names.  `global_rows`: ent_emb / pred_bias are given
+        for all |E| entities and sliced to the shard here."""
+        lo, hi = self.shard
+        for name, want in self._specs.items():
+            if name not in params:
+                continue
+            v = params[name]
+            t = v if isinstance(v, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(v))
+            if name in ("ent_emb", "pred_bias") and global_rows and t.shape[0] == self.num_ent and (lo, hi) != (0, self.num_ent):
+                t = t[lo:hi]
+            t = t.to(device=self.device, dtype=torch.float32).contiguous()
+            if t.numel() != int(np.prod(want)):
+                raise ValueError("parameter %s: got shape %s, need %s" % (name, tuple(t.shape), want))
+            self._tensors[name] = t
+            shape = (C.c_int64 * max(1, t.dim()))(*t.shape)
+            _lib.check(self._h, self._lib.coper_set_param(self._h, name.encode(), _ptr(t), shape, t.dim()))
+        self._prepared = False
+        return self
+
+    @property
+    def variables(self):
+        """Dict with the keys of models.py:316-325; generated parameters are holder objects like the
+        reference's generator objects."""
+        T = self._tensors
+        out = {"ent_emb": T.get("ent_emb"), "pred_bias": T.get("pred_bias")}
+        if not self.is_parameter_lookup:
+            out["rel_emb"] = T.get("rel_emb")
+        C_ = int(self.model_descriptors.get("conv_num_channels", 32))
+        fh = int(self.model_descriptors.get("conv_filter_height", 3))
+        fw = int(self.model_descriptors.get("conv_filter_width", 3))
+        shapes = {"conv1_weights": [fh, fw, 1, C_], "conv1_bias": [C_],
+                  "fc_weights": [self.fc_input_size, self.ent_emb_size], "fc_bias": [self.ent_emb_size]}
+        for name, ctx in (("conv1_weights", self.context_rel_conv), ("conv1_bias", self.context_rel_conv),
+                          ("fc_weights", self.context_rel_out), ("fc_bias", self.context_rel_out)):
+            if ctx is None:
+                out[name] = T.get(name)
+            elif self.is_parameter_lookup:
+                out[name] = ParameterLookup(name, shapes[name], T.get(name))
+            else:
+                proj = [T.get("%s/CPG/Projection%d" % (name, i)) for i in range(len(ctx) + 1)]
+                bns = [{leaf: T.get("%s/CPG/Projection%d/BatchNorm/%s" % (name, i, leaf))
+                        for leaf in ("gamma", "beta", "moving_mean", "moving_variance")} for i in range(len(ctx))]
+                out[name] = ContextualParameterGenerator(name, shapes[name], proj, bns)
+        return out
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def prepare(self):
+        """coper_prepare: fold BN, evaluate the generators once per relation, build the MFMA images."""
+        missing = [n for n in self._specs if n not in self._tensors]
+        if missing:
+            raise _lib.CoperError(2, "parameters never set: %s" % ", ".join(missing))
+        with torch.cuda.device(self.device):
+            _lib.check(self._h, self._lib.coper_prepare(self._h, self._stream()))
+        self._prepared = True
+        return self
+
+    def reserve(self, max_queries, max_filter_nnz=0):
+        with torch.cuda.device(self.device):
+            _lib.check(self._h, self._lib.coper_reserve(self._h, int(max_queries), int(max_filter_nnz), self._stream()))
+        return self
+
+    # ---------------------------------------------------------------- compute
+    def _ids(self, a, dtype=torch.int64):
+        if isinstance(a, torch.Tensor):
+            return a.to(device=self.device, dtype=dtype).contiguous()
+        return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(self.device, non_blocking=True)
+
+    def _need_prepared(self):
+        if not self._prepared:
+            self.prepare()
+
+    def gather_entities(self, ids):
+        self._need_prepared()
+        ids = self._ids(ids)
+        out = torch.empty((ids.numel(), self.ent_emb_size), device=self.device, dtype=torch.float32)
+        _lib.check(self._h, self._lib.coper_gather_entities(self._h, _ptr(ids), ids.numel(), _ptr(out), self._stream()))
+        return out
+
+    def encode(self, e1, rel, e1_rows: Optional[torch.Tensor] = None):
+        """predicted_e2_emb [B, d] (models.py:183)."""
+        self._need_prepared()
+        rel = self._ids(rel)
+        e1 = self._ids(e1) if e1 is not None else None
+        B = rel.numel()
+        out = torch.empty((B, self.ent_emb_size), device=self.device, dtype=torch.float32)
+        if e1_rows is not None:
+            e1_rows = e1_rows.to(device=self.device, dtype=torch.float32).contiguous()
+        _lib.check(self._h, self._lib.coper_encode(self._h, _ptr(e1), _ptr(rel), B, _ptr(e1_rows), _ptr(out), self._stream()))
+        return out
+
+    def score_all(self, h):
+        """predictions_all [B, n_local] logits (models.py:434-437)."""
+        self._need_prepared()
+        B = h.shape[0]
+        out = torch.empty((B, self.n_local), device=self.device, dtype=torch.float32)
+        _lib.check(self._h, self._lib.coper_score_all(self._h, _ptr(h), B, _ptr(out), self.n_local, self._stream()))
+        return out
+
+    def score_lookup(self, h, lookup):
+        """predictions_lookup [B, L] (models.py:439-443)."""
+        self._need_prepared()
+        lookup = self._ids(lookup, torch.int32)
+        B, L = lookup.shape
+        out = torch.zeros((B, L), device=self.device, dtype=torch.float32)
+        _lib.check(self._h, self._lib.coper_score_lookup(self._h, _ptr(h), _ptr(lookup), B, L, _ptr(out), self._stream()))
+        return out
+
+    def target_scores(self, h, e2):
+        self._need_prepared()
+        e2 = self._ids(e2)
+        out = torch.empty((e2.numel(),), device=self.device, dtype=torch.float32)
+        _lib.check(self._h, self._lib.coper_target_scores(self._h, _ptr(h), _ptr(e2), e2.numel(), _ptr(out), self._stream()))
+        return out
+
+    def rank_counts(self, h, tgt, e2, filt_indptr, filt_idx, filt_nnz=None):
+        """(n_greater, n_equal) int32 [B] over this shard (metrics.py:44-50 without logits)."""
+        self._need_prepared()
+        e2, ip, ix = self._ids(e2), self._ids(filt_indptr), self._ids(filt_idx)
+        B = e2.numel()
+        nnz = int(ix.numel()) if filt_nnz is None else int(filt_nnz)
+        ng = torch.empty((B,), device=self.device, dtype=torch.int32)
+        ne = torch.empty((B,), device=self.device, dtype=torch.int32)
+        _lib.check(self._h, self._lib.coper_rank_counts(self._h, _ptr(h), _ptr(tgt), _ptr(e2), _ptr(ip), _ptr(ix), nnz, B, 0,
+                                                        _ptr(ng), _ptr(ne), None, None, self._stream()))
+        return ng, ne
+
+    def rank(self, h, e2, filt_indptr, filt_idx, filt_nnz=None):
+        """Filtered ranks int32 [B] (+ n_equal) on an unsharded model."""
+        self._need_prepared()
+        e2, ip, ix = self._ids(e2), self._ids(filt_indptr), self._ids(filt_idx)
+        B = e2.numel()
+        nnz = int(ix.numel()) if filt_nnz is None else int(filt_nnz)
+        ranks = torch.empty((B,), device=self.device, dtype=torch.int32)
+        ne = torch.empty((B,), device=self.device, dtype=torch.int32)
+        _lib.check(self._h, self._lib.coper_rank(self._h, _ptr(h), _ptr(e2), _ptr(ip), _ptr(ix), nnz, B, _ptr(ranks), _ptr(ne),
+                                                 self._stream()))
+        return ranks, ne
+
+    def check_ids(self):
+        n = C.c_int64()
+        _lib.check(self._h, self._lib.coper_check_ids(self._h, C.byref(n), self._stream()))
+        return n.value
+
+    def profile(self, enable=True):
+        _lib.check(self._h, self._lib.coper_profile_enable(self._h, 1 if enable else 0))
+
+    def profile_read(self, kernel):
+        ms, n = C.c_double(), C.c_int64()
+        _lib.check(self._h, self._lib.coper_profile_read(self._h, kernel.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    # ---------------------------------------------------------------- reference-style access
+    @property
+    def loss(self):
+        raise NotImplementedError("training (loss / train_op, models.py:192-200) is outside this build: SURVEY 8f-1")
+
+    train_op = loss
+
+    def session(self):
+        return Session(self)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.coper_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Session(object):
+    """`session.run(fetches, feed_dict)` shim: `feed_dict[model.input_iterator_handle]` is any iterator
+    over batches in the reference batch contract (see coper_amd.data).  Each `run` consumes one batch
+    (like one `session.run` on the TF iterator, metrics.py:40-42) and returns host NumPy arrays."""
+
+    def __init__(self, model: ConvE):
+        self.model = model
+        self._iters = {}
+
+    def run(self, fetches, feed_dict=None):
+        m = self.model
+        single = not isinstance(fetches, (tuple, list))
+        fl = [fetches] if single else list(fetches)
+        handle = (feed_dict or {}).get(m.input_iterator_handle)
+        if handle is None:
+            raise ValueError("feed_dict must map model.input_iterator_handle to a batch iterator")
+        key = id(handle)
+        if key not in self._iters:
+            self._iters[key] = iter(handle)
+        try:
+            batch = next(self._iters[key])
+        except StopIteration:
+            del self._iters[key]
+            raise OutOfRangeError()
+        if feed_dict.get(m.is_train, False):
+            raise NotImplementedError("is_train=True: training is outside this build (SURVEY 8f-1)")
+        cache = {}
+
+        def h():
+            if "h" not in cache:
+                cache["h"] = m.encode(batch["e1"], batch["rel"])
+            return cache["h"]
+
+        out = []
+        for f in fl:
+            n = f.name
+            if n in ("e1", "e2", "rel"):
+                out.append(np.asarray(batch[n]))
+            elif n == "e2_multi":
+                if "e2_multi" in batch:
+                    out.append(np.asarray(batch["e2_multi"]))
+                else:
+                    from .data import csr_to_dense_filter
+                    out.append(csr_to_dense_filter(batch["filt_indptr"], batch["filt_idx"], m.num_ent))
+            elif n == "lookup_values":
+                out.append(np.asarray(batch["lookup_values"]))
+            elif n == "predicted_e2_emb":
+                out.append(h().cpu().numpy())
+            elif n == "predictions_all":
+                out.append(m.score_all(h()).cpu().numpy())
+            elif n == "predictions_lookup":
+                out.append(m.score_lookup(h(), batch["lookup_values"]).cpu().numpy())
+            else:
+                raise KeyError(n)
+        return out[0] if single else tuple(out)

@@ -1,0 +1,126 @@
+"""Multi-GPU evaluation: one process per GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI).
+
+The reference has no distributed code at all; the path shards two ways:
+
+* `QueryShardedEvaluator` -- small KGs (FB15k-237 / WN18RR-shaped: the whole model is a few GB and is
+  replicated): the queries of a pass are split across ranks, no data-path collective; one
+  all-gather of int32 ranks at the end so every rank can form the global metrics.
+* `EntityShardedRanker` -- large KGs (the 10M-entity config): rank g owns entity rows
+  [g|E|/G, (g+1)|E|/G) of `ent_emb` / `pred_bias`.  Per chunk of B queries:
+    1. all-reduce(sum) of the shard-local gather of `ent_emb[e1]` (each row has one owner, the rest
+       contribute zeros: exact)                                                   [B, d]  f32
+    2. the encoder is split by relation (rank = rel mod G: a rank touches only its relations'
+       generated dense weights), all-reduce(sum) of the zero-padded `h`           [B, d]  f32
+    3. the owner of `e2[b]` computes the target logit; all-reduce(sum)            [B]     f32
+    4. every rank runs the fused score+count over its rows; ONE all-gather of the packed per-shard
+       record (n_greater, n_equal[, top-k]) -- the collective BASELINE.json's north_star names --
+       and every rank sums the counts: rank = 1 + sum_g n_greater_g (integers: identical to the
+       single-GPU result).
+  Payloads are <= B*d*4 bytes (<= 4 MB), i.e. latency-bound on xGMI; logits never cross GPUs.
+
+Both take a *scorer*: any object with `gather_entities / encode / target_scores / rank_counts`
+returning torch tensors on its own device.  `coper_amd.models.ConvE` is the product scorer; the
+CPU `gloo` tests (tests/test_sharding_gloo.py) plug a test-only scorer in to exercise the exchange
+logic without a GPU -- the product never routes through anything else."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+__all__ = ["local_rank_pass", "QueryShardedEvaluator", "EntityShardedRanker", "shard_bounds"]
+
+
+def shard_bounds(num_ent: int, world: int, rank: int):
+    """Rows [lo, hi) of rank `rank`: contiguous, sizes differ by at most one."""
+    base, rem = divmod(int(num_ent), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def local_rank_pass(model, chunk):
+    """Unsharded: encode + fused filtered rank for one chunk of queries.  Returns (ranks, n_equal) int32 tensors."""
+    h = model.encode(chunk["e1"], chunk["rel"])
+    return model.rank(h, chunk["e2"], chunk["filt_indptr"], chunk["filt_idx"], filt_nnz=len(chunk["filt_idx"]))
+
+
+def _slice_chunk(chunk, lo, hi):
+    ip = np.asarray(chunk["filt_indptr"])[lo:hi + 1]
+    return dict(e1=chunk["e1"][lo:hi], e2=chunk["e2"][lo:hi], rel=chunk["rel"][lo:hi],
+                filt_indptr=(ip - ip[0]).astype(np.int64), filt_idx=np.asarray(chunk["filt_idx"])[ip[0]:ip[-1]])
+
+
+class QueryShardedEvaluator(object):
+    """Replicated model, queries split contiguously across ranks."""
+
+    def __init__(self, scorer, group=None, rank_fn=local_rank_pass):
+        self.scorer, self.group, self.rank_fn = scorer, group, rank_fn
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank_id = dist.get_rank(group) if dist.is_initialized() else 0
+
+    def rank(self, chunk):
+        Q = len(chunk["e1"])
+        lo, hi = shard_bounds(Q, self.world, self.rank_id)
+        if hi > lo:
+            r, ne = self.rank_fn(self.scorer, _slice_chunk(chunk, lo, hi))
+        else:
+            dev = getattr(self.scorer, "device", "cpu")
+            r = torch.zeros(0, dtype=torch.int32, device=dev)
+            ne = torch.zeros(0, dtype=torch.int32, device=dev)
+        if self.world == 1:
+            return r, ne
+        # ragged all-gather: pad to the largest share
+        cap = shard_bounds(Q, self.world, 0)[1]
+        buf = torch.zeros((2, cap), dtype=torch.int32, device=r.device)
+        buf[0, :hi - lo] = r
+        buf[1, :hi - lo] = ne
+        out = torch.empty((self.world * 2, cap), dtype=torch.int32, device=r.device)
+        dist.all_gather_into_tensor(out, buf, group=self.group)
+        out = out.view(self.world, 2, cap)
+        rs, nes = [], []
+        for g in range(self.world):
+            glo, ghi = shard_bounds(Q, self.world, g)
+            rs.append(out[g, 0, :ghi - glo])
+            nes.append(out[g, 1, :ghi - glo])
+        return torch.cat(rs), torch.cat(nes)
+
+
+class EntityShardedRanker(object):
+    """Entity-sharded ranking; see the module docstring for the four exchange steps."""
+
+    def __init__(self, scorer, group=None, split_encoder=True):
+        self.scorer, self.group, self.split_encoder = scorer, group, split_encoder
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank_id = dist.get_rank(group) if dist.is_initialized() else 0
+
+    def _allreduce(self, t):
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def encode(self, e1, rel):
+        sc = self.scorer
+        rows = self._allreduce(sc.gather_entities(e1))                          # step 1
+        rel_np = np.asarray(rel)
+        if self.world == 1 or not self.split_encoder:
+            return sc.encode(e1, rel, e1_rows=rows)
+        mine = np.nonzero(rel_np % self.world == self.rank_id)[0]               # step 2
+        h = torch.zeros((len(rel_np), rows.shape[1]), dtype=torch.float32, device=rows.device)
+        if len(mine):
+            sel = torch.as_tensor(mine, device=rows.device)
+            h_loc = sc.encode(np.asarray(e1)[mine], rel_np[mine], e1_rows=rows.index_select(0, sel).contiguous())
+            h.index_copy_(0, sel, h_loc)
+        return self._allreduce(h)
+
+    def rank(self, chunk):
+        sc = self.scorer
+        h = self.encode(chunk["e1"], chunk["rel"])
+        tgt = self._allreduce(sc.target_scores(h, chunk["e2"]))                  # step 3
+        ng, ne = sc.rank_counts(h, tgt, chunk["e2"], chunk["filt_indptr"], chunk["filt_idx"],
+                                filt_nnz=len(chunk["filt_idx"]))
+        rec = torch.stack([ng, ne], dim=1).contiguous()                          # step 4: packed per-shard record
+        if self.world > 1:
+            out = torch.empty((self.world * rec.shape[0], rec.shape[1]), dtype=rec.dtype, device=rec.device)
+            dist.all_gather_into_tensor(out, rec, group=self.group)     # concatenated along dim 0 (gloo + nccl)
+            rec = out.view(self.world, rec.shape[0], rec.shape[1]).sum(dim=0, dtype=torch.int32)
+        return (1 + rec[:, 0]).to(torch.int32), rec[:, 1].to(torch.int32)

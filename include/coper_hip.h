@@ -1,0 +1,187 @@
+/*
+ * coper_hip.h -- C ABI of libcoper_hip.so: the MI355X (gfx950) CoPER-ConvE scoring engine.
+ *
+ * The reference (otiliastr/coper, CoPER_ConvE/qa_cpg) has NO FFI / plugin interface for this
+ * path: the seam is a Python object protocol between run_cpg.py / metrics.py and models.py.
+ * Each entry point below therefore cites the reference *Python* interface it replaces
+ * (paths relative to CoPER_ConvE/qa_cpg/).  The reference-side binding a maintainer would add
+ * is the ctypes stub shown in INTEGRATION.md (it is what coper_amd/_lib.py does).
+ *
+ * Conventions
+ *   - plain C, no C++ exceptions cross the boundary; every call returns a coper_status.
+ *   - all tensor arguments are DEVICE pointers owned by the caller (row-major, fp32 unless
+ *     stated); ids are int64 like the reference batch contract (models.py:139-152), lookup
+ *     indices int32.
+ *   - every call is asynchronous on the hipStream_t it is given (passed as void* so that the
+ *     header needs no HIP include); the handle's workspace is stream-ordered: use one handle
+ *     per (GPU, stream).  A handle is not thread-safe.
+ *   - parameters are BORROWED: the caller keeps the device buffers alive and must call
+ *     coper_prepare() again after changing their contents (it rebuilds every derived cache).
+ */
+#ifndef COPER_HIP_H_
+#define COPER_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(COPER_BUILD)
+#define COPER_API __attribute__((visibility("default")))
+#else
+#define COPER_API
+#endif
+
+#define COPER_ABI_VERSION 1
+#define COPER_MAX_CTX 4 /* max hidden layers of a g_MLP generator */
+
+typedef enum coper_status {
+  COPER_OK = 0,
+  COPER_EINVAL = 1,    /* bad argument / ill-formed model_descriptors */
+  COPER_EMISSING = 2,  /* a required parameter was never set */
+  COPER_ESHAPE = 3,    /* parameter shape does not match the configuration */
+  COPER_EHIP = 4,      /* HIP runtime error, text in coper_last_error() */
+  COPER_ESTATE = 5,    /* call order violated (e.g. encode before prepare) */
+  COPER_ENOMEM = 6,
+  COPER_EUNSUPPORTED = 7
+} coper_status;
+
+typedef enum coper_score_mode {
+  COPER_SCORE_F32 = 0,   /* entity table fp32, exact-f32 MFMA (v_mfma_f32_32x32x2_f32): parity mode */
+  COPER_SCORE_BF16X3 = 1,/* table + query split hi/lo bf16, 3 bf16 MFMAs per product: ~2^-16 rel. error */
+  COPER_SCORE_BF16 = 2   /* table + query rounded to bf16, 1 MFMA: ~2^-9 rel. error (throughput mode) */
+} coper_score_mode;
+
+/* Mirrors the `model_descriptors` dict of ConvE.__init__ (models.py:98-130) -- only the keys
+ * that influence inference -- plus what the build adds: (emb_h, emb_w) replacing the
+ * hard-coded (10, d // 10) of models.py:261-262,355; the entity shard; the score precision. */
+typedef struct coper_config {
+  int32_t abi_version;          /* = COPER_ABI_VERSION */
+  int32_t device;               /* HIP device ordinal */
+  int64_t num_ent;              /* |E| (global)                          models.py:102 */
+  int64_t num_rel;              /* R2 = 2|R| incl. _reverse relations    models.py:103 */
+  int32_t ent_emb_size;         /* d                                     models.py:104 */
+  int32_t rel_emb_size;         /* r                                     models.py:105 */
+  int32_t emb_h, emb_w;         /* image reshape, emb_h * emb_w == d     models.py:355 */
+  int32_t conv_filter_height;   /* default 3                             models.py:109 */
+  int32_t conv_filter_width;    /* default 3                             models.py:110 */
+  int32_t conv_num_channels;    /* default 32                            models.py:111 */
+  int32_t concat_rel;           /*                                       models.py:113 */
+  int32_t do_parameter_lookup;  /* g_lookup                              models.py:107 */
+  /* context_rel_conv / context_rel_out (models.py:114-115):
+   *   n = -1 -> None (static parameter), n = 0 -> [] (g_linear), n > 0 -> hidden sizes (g_MLP) */
+  int32_t n_ctx_conv;
+  int32_t ctx_conv[COPER_MAX_CTX];
+  int32_t n_ctx_out;
+  int32_t ctx_out[COPER_MAX_CTX];
+  int32_t context_rel_use_batch_norm; /*                                 models.py:117 */
+  float bn_epsilon;             /* 1e-3 = tf.layers.batch_normalization default */
+  int64_t shard_lo, shard_hi;   /* entity rows [lo, hi) held by this handle; [0, num_ent) = unsharded */
+  int32_t score_mode;           /* coper_score_mode */
+  int32_t reserved[7];
+} coper_config;
+
+typedef struct coper_handle coper_handle;
+
+/* Replaces ConvE.__init__ / _create_variables shape logic (models.py:98-130, 203-336):
+ * validates the configuration exactly as the reference derives its shapes.  No parameter
+ * memory is allocated: parameters are borrowed through coper_set_param. */
+COPER_API int coper_create(const coper_config* cfg, coper_handle** out);
+COPER_API void coper_destroy(coper_handle* h);
+
+/* Text of the last failure on this handle (never NULL).  With h == NULL: last coper_create failure. */
+COPER_API const char* coper_last_error(const coper_handle* h);
+COPER_API int coper_abi_version(void);
+
+/* Derived sizes (models.py:261-271): F = fc_input_size, Ho/Wo = conv output; n_local = shard_hi - shard_lo. */
+COPER_API int coper_get_dims(const coper_handle* h, int64_t* F, int32_t* Ho, int32_t* Wo, int64_t* n_local);
+
+/* Number of parameters the configuration requires and their leaf names / shapes, named as
+ * the reference's TF variables: ent_emb, rel_emb, pred_bias, conv1_weights,
+ * conv1_bias, fc_weights, fc_bias, "<name>/CPG/Projection<i>",
+ * "<name>/CPG/Projection<i>/BatchNorm/{gamma,beta,moving_mean,moving_variance}",
+ * "Conv1BN/...", "FCBN/...".  shape_out must hold 4 entries. */
+COPER_API int coper_num_params(const coper_handle* h);
+COPER_API int coper_param_spec(const coper_handle* h, int index, const char** leaf_name, int64_t* shape_out, int* ndim_out);
+
+/* Replaces variable assignment / Saver.restore (models.py:203-336, run_cpg.py:205-206).
+ * dev_ptr: fp32, contiguous, on cfg.device.  ent_emb / pred_bias are the LOCAL shard rows. */
+COPER_API int coper_set_param(coper_handle* h, const char* leaf_name, const void* dev_ptr,
+                    const int64_t* shape, int ndim);
+
+/* Builds everything inference derives from the parameters (re-run after any weight change):
+ *   - BN (Conv1BN, FCBN, generator BNs) folded to per-channel affine   models.py:61-65,386-388,416-418
+ *   - per-relation generated / looked-up conv filters, conv bias, dense weights, dense bias
+ *     (ContextualParameterGenerator.generate / ParameterLookup.generate, models.py:56-76,90-94,
+ *      338-352) evaluated once per relation id instead of once per sample
+ *   - dense weights and the entity table re-laid out in MFMA-fragment-major order. */
+COPER_API int coper_prepare(coper_handle* h, void* stream);
+
+/* Pre-size the workspace so later calls with B <= max_queries and nnz <= max_filter_nnz do
+ * not allocate (needed before hipGraph capture).  Optional: calls grow the workspace lazily. */
+COPER_API int coper_reserve(coper_handle* h, int64_t max_queries, int64_t max_filter_nnz, void* stream);
+
+/* Row gather tf.nn.embedding_lookup(ent_emb, ids) (models.py:176) restricted to the shard:
+ * out[b,:] = ent_emb[ids[b]] if shard_lo <= ids[b] < shard_hi else 0.  (Multi-GPU: sum over
+ * ranks = the full gather.)  out: [B, d]. */
+COPER_API int coper_gather_entities(coper_handle* h, const int64_t* ids, int64_t B, float* out, void* stream);
+
+/* Replaces ConvE._create_predictions (models.py:354-426) in inference mode:
+ * h_out[B, d] = predicted_e2_emb.  e1_rows: optional [B, d] pre-gathered ent_emb[e1] rows
+ * (required when the shard does not hold every e1; NULL = gather locally). */
+COPER_API int coper_encode(coper_handle* h, const int64_t* e1, const int64_t* rel, int64_t B,
+                 const float* e1_rows, float* h_out, void* stream);
+
+/* Replaces ConvE._compute_likelihoods(..., ent_indices=None) (models.py:428-437):
+ * logits[B, n_local] = h . ent_emb_shard^T + pred_bias_shard  (no sigmoid). ld = row stride of logits. */
+COPER_API int coper_score_all(coper_handle* h, const float* hvec, int64_t B, float* logits, int64_t ld, void* stream);
+
+/* Replaces ConvE._compute_likelihoods(..., ent_indices=lookup) (models.py:438-443):
+ * out[B, L] = h[b] . ent_emb[lookup[b,l]] + pred_bias[lookup[b,l]]; lookup holds GLOBAL ids,
+ * entries outside the shard produce 0 (sum over ranks = full result). */
+COPER_API int coper_score_lookup(coper_handle* h, const float* hvec, const int32_t* lookup, int64_t B, int64_t L,
+                       float* out, void* stream);
+
+/* Target scores: tgt[b] = logit(b, e2[b]) if e2[b] is in the shard else 0, bit-identical to
+ * the value coper_score_all writes for that element (metrics.py:44). */
+COPER_API int coper_target_scores(coper_handle* h, const float* hvec, const int64_t* e2, int64_t B, float* tgt, void* stream);
+
+/* Replaces the host ranker loop of ranking_and_hits (metrics.py:44-50) without materialising
+ * logits: for every query b over the shard's entities j, with the known-answer filter given
+ * in CSR form (filt_idx[filt_indptr[b] .. filt_indptr[b+1]) = GLOBAL ids, sorted ascending;
+ * the dense e2_multi mask of data.py:182-186 made sparse):
+ *   n_greater[b] = #{ j != e2[b], j not filtered : logit(b,j) >  tgt[b] }
+ *   n_equal[b]   = #{ j != e2[b], j not filtered : logit(b,j) == tgt[b] }
+ * so that rank = 1 + sum_over_shards(n_greater) when tie-free (any value in
+ * [1+n_greater, 1+n_greater+n_equal] under ties -- the reference's np.argsort is unstable).
+ * tgt: [B] global target scores (from coper_target_scores, summed over shards).
+ * filt_nnz = filt_indptr[B], passed from the host that built the CSR (sizes the launch).
+ * k > 0 additionally returns the shard's top-k of the FILTERED row (target kept, like
+ * metrics.py:46), order (score desc, id asc): topk_val [B,k] (-inf padded), topk_idx [B,k]
+ * global ids (-1 padded).  k == 0: both may be NULL. */
+COPER_API int coper_rank_counts(coper_handle* h, const float* hvec, const float* tgt, const int64_t* e2,
+                      const int64_t* filt_indptr, const int64_t* filt_idx, int64_t filt_nnz, int64_t B, int32_t k,
+                      int32_t* n_greater, int32_t* n_equal, float* topk_val, int64_t* topk_idx,
+                      void* stream);
+
+/* Single-shard convenience: coper_target_scores + coper_rank_counts + rank = 1 + n_greater.
+ * ranks: int32 [B]. */
+COPER_API int coper_rank(coper_handle* h, const float* hvec, const int64_t* e2, const int64_t* filt_indptr,
+               const int64_t* filt_idx, int64_t filt_nnz, int64_t B, int32_t* ranks, int32_t* n_equal,
+               void* stream);
+
+/* Timing hook used by bench.py: average device time (ms) of the dominant kernel
+ * (score_count) over the launches since the last reset, measured with hipEvents recorded on
+ * the launch stream.  enable != 0 turns per-launch event recording on. */
+/* Ids are validated on the device and clamped, never trusted: returns in *n_bad the number of
+ * out-of-range relation ids seen by coper_encode since the last call (synchronises the stream). */
+COPER_API int coper_check_ids(coper_handle* h, int64_t* n_bad, void* stream);
+
+COPER_API int coper_profile_enable(coper_handle* h, int enable);
+COPER_API int coper_profile_read(coper_handle* h, const char* kernel, double* total_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COPER_HIP_H_ */

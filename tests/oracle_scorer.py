@@ -1,0 +1,65 @@
+"""TEST-ONLY scorer: the shard-scorer protocol of coper_amd.sharding implemented with the CPU
+oracle, so the multi-rank exchange logic can run under gloo without a GPU."""
+import numpy as np
+import torch
+
+from oracle import coper_oracle as O
+
+
+class OracleShardScorer(object):
+    device = torch.device("cpu")
+
+    def __init__(self, params, md, shard):
+        self.p, self.md, (self.lo, self.hi) = params, md, shard
+        self.E = np.ascontiguousarray(params["ent_emb"][self.lo:self.hi])
+        self.b = np.ascontiguousarray(params["pred_bias"][self.lo:self.hi])
+        self.d = self.E.shape[1]
+
+    def gather_entities(self, ids):
+        ids = np.asarray(ids)
+        out = np.zeros((len(ids), self.d), np.float32)
+        own = (ids >= self.lo) & (ids < self.hi)
+        out[own] = self.E[ids[own] - self.lo]
+        return torch.from_numpy(out)
+
+    def encode(self, e1, rel, e1_rows=None):
+        rel = np.asarray(rel)
+        p = dict(self.p)
+        if e1_rows is not None:
+            p["ent_emb"] = e1_rows.numpy()
+            e1 = np.arange(len(rel))
+        st = O.forward(p, self.md, e1, rel, np.float32, materialise=False)
+        return torch.from_numpy(np.ascontiguousarray(st["h"]))
+
+    def target_scores(self, h, e2):
+        e2 = np.asarray(e2)
+        h = h.numpy()
+        out = np.zeros(len(e2), np.float32)
+        for b in np.nonzero((e2 >= self.lo) & (e2 < self.hi))[0]:
+            r = e2[b] - self.lo
+            out[b] = O.score_chain(h[b:b + 1], self.E[r:r + 1], self.b[r:r + 1])[0, 0]
+        return torch.from_numpy(out)
+
+    def rank_counts(self, h, tgt, e2, filt_indptr, filt_idx, filt_nnz=None):
+        logits = O.score_chain(h.numpy(), self.E, self.b)
+        e2, ip, ix = np.asarray(e2), np.asarray(filt_indptr), np.asarray(filt_idx)
+        t = tgt.numpy()
+        B = len(e2)
+        ng, ne = np.zeros(B, np.int32), np.zeros(B, np.int32)
+        for b in range(B):
+            keep = np.ones(self.hi - self.lo, bool)
+            f = ix[ip[b]:ip[b + 1]]
+            f = f[(f >= self.lo) & (f < self.hi)] - self.lo
+            keep[f] = False
+            if self.lo <= e2[b] < self.hi:
+                keep[e2[b] - self.lo] = False
+            row = logits[b][keep]
+            ng[b] = np.count_nonzero(row > t[b])
+            ne[b] = np.count_nonzero(row == t[b])
+        return torch.from_numpy(ng), torch.from_numpy(ne)
+
+    # unsharded convenience used by QueryShardedEvaluator's rank_fn
+    def rank(self, h, e2, filt_indptr, filt_idx, filt_nnz=None):
+        tgt = self.target_scores(h, e2)
+        ng, ne = self.rank_counts(h, tgt, e2, filt_indptr, filt_idx)
+        return (1 + ng).to(torch.int32), ne

@@ -1,0 +1,77 @@
+"""CPU: host-side logic of the drop-in (batch contract, CSR filters, metric means, shard bounds)."""
+import numpy as np
+import pytest
+
+from coper_amd import data as cdata
+from coper_amd.metrics import collect_batches, hits_and_means
+from coper_amd.sharding import shard_bounds
+
+
+def test_csr_dense_roundtrip_and_batches():
+    md = cdata.model_descriptors("nations_cpg")
+    loader = cdata.SyntheticKGLoader("nations_cpg", seed=1, queries=37)
+    ds = loader.eval_dataset(batch_size=8, dense_mask=True)
+    assert len(ds) == 5
+    whole = ds.as_single_batch()
+    n = 0
+    for b in ds:
+        B = len(b["e1"])
+        assert b["e1"].dtype == np.int64 and b["rel"].dtype == np.int64 and b["e2"].dtype == np.int64
+        assert b["lookup_values"].shape == (B, 0) and b["lookup_values"].dtype == np.int32      # data.py:205-213
+        assert b["e2_multi"].shape == (B, md["num_ent"]) and b["e2_multi"].dtype == np.float32  # data.py:182-186
+        ip, ix = cdata.dense_filter_to_csr(b["e2_multi"])
+        assert np.array_equal(ip, b["filt_indptr"]) and np.array_equal(ix, b["filt_idx"])
+        assert all(b["e2_multi"][i, b["e2"][i]] == 1.0 for i in range(B))   # the target is a known answer
+        assert np.all(b["rel"] < md["num_rel"] // 2)                         # forward relations only
+        n += B
+    assert n == 37
+    # draining batches (with dense masks only) reproduces the single-batch CSR
+    dense_only = [dict(e1=b["e1"], e2=b["e2"], rel=b["rel"], e2_multi=b["e2_multi"]) for b in ds]
+    got = collect_batches(dense_only)
+    for k in ("e1", "e2", "rel", "filt_indptr", "filt_idx"):
+        assert np.array_equal(got[k], whole[k]), k
+    got2 = collect_batches(iter(ds))
+    assert np.array_equal(got2["filt_idx"], whole["filt_idx"])
+
+
+def test_empty_and_ragged_batches():
+    got = collect_batches([])
+    assert len(got["e1"]) == 0 and got["filt_indptr"].tolist() == [0]
+    b0 = dict(e1=np.zeros(0, np.int64), e2=np.zeros(0, np.int64), rel=np.zeros(0, np.int64),
+              filt_indptr=np.zeros(1, np.int64), filt_idx=np.zeros(0, np.int64))
+    b1 = dict(e1=np.array([1, 2]), e2=np.array([3, 4]), rel=np.array([0, 1]), filt_indptr=np.array([0, 0, 2]),
+              filt_idx=np.array([4, 9]))
+    got = collect_batches([b0, b1, b0])
+    assert got["filt_indptr"].tolist() == [0, 0, 2] and got["filt_idx"].tolist() == [4, 9]
+    mr, mrr, hits = hits_and_means([], (1, 10))
+    assert np.isnan(mr) and np.isnan(mrr) and np.isnan(hits[1])
+
+
+def test_hits_and_means_reference_arithmetic():
+    ranks = [1, 2, 3, 11, 21]
+    mr, mrr, hits = hits_and_means(ranks)
+    assert mr == np.mean(ranks) and mrr == np.mean(1. / np.array(ranks))
+    assert hits == {1: 0.2, 3: 0.6, 5: 0.6, 10: 0.6, 20: 0.8}
+    assert set(hits) == {1, 3, 5, 10, 20}          # default hits_to_compute (metrics.py:23)
+
+
+@pytest.mark.parametrize("n,w", [(14, 1), (14, 4), (14541, 8), (10_000_000, 8), (5, 8)])
+def test_shard_bounds_partition(n, w):
+    cuts = [shard_bounds(n, w, r) for r in range(w)]
+    assert cuts[0][0] == 0 and cuts[-1][1] == n
+    assert all(cuts[i][1] == cuts[i + 1][0] for i in range(w - 1))
+    sizes = [hi - lo for lo, hi in cuts]
+    assert max(sizes) - min(sizes) <= 1
+
+
+def test_synthetic_params_are_seeded_and_complete():
+    md = cdata.model_descriptors("nations_cpg")
+    a, b = cdata.synthetic_params(md, 3), cdata.synthetic_params(md, 3)
+    assert set(a) == set(cdata.param_shapes(md))
+    assert all(np.array_equal(a[k], b[k]) and a[k].dtype == np.float32 for k in a)
+    c = cdata.synthetic_params(md, 4)
+    assert not np.array_equal(a["ent_emb"], c["ent_emb"])
+    q = cdata.synthetic_queries(md, 50, 0)
+    for i in range(50):
+        row = q["filt_idx"][q["filt_indptr"][i]:q["filt_indptr"][i + 1]]
+        assert np.all(np.diff(row) > 0) and q["e2"][i] in row       # sorted unique, contains the target

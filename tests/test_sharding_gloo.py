@@ -1,0 +1,71 @@
+"""CPU, world_size 2 and 3 over gloo: the N>1 exchange logic of coper_amd.sharding gives exactly the
+single-process ranks (integer counts sum exactly; float all-reduces only ever add zeros)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from coper_amd import data as cdata
+from coper_amd.sharding import EntityShardedRanker, QueryShardedEvaluator, local_rank_pass, shard_bounds
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _md():
+    return dict(cdata._COMMON, num_ent=203, num_rel=12, ent_emb_size=32, rel_emb_size=8, emb_h=4, emb_w=8,
+                conv_num_channels=4, context_rel_conv=None, context_rel_out=[])
+
+
+def _worker(rank, world, port, mode, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tests.oracle_scorer import OracleShardScorer
+        md = _md()
+        p = cdata.synthetic_params(md, seed=11)
+        q = cdata.synthetic_queries(md, 45, seed=2, mean_filter=3.0, max_filter=12)
+        if mode == "entity":
+            sc = OracleShardScorer(p, md, shard_bounds(md["num_ent"], world, rank))
+            ranks, ne = EntityShardedRanker(sc).rank(q)
+        elif mode == "entity_nosplit":
+            sc = OracleShardScorer(p, md, shard_bounds(md["num_ent"], world, rank))
+            ranks, ne = EntityShardedRanker(sc, split_encoder=False).rank(q)
+        else:
+            sc = OracleShardScorer(p, md, (0, md["num_ent"]))
+            ranks, ne = QueryShardedEvaluator(sc).rank(q)
+        np.save(os.path.join(out_dir, "ranks_%d.npy" % rank), ranks.numpy())
+        np.save(os.path.join(out_dir, "ne_%d.npy" % rank), ne.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def _expected():
+    from tests.oracle_scorer import OracleShardScorer
+    md = _md()
+    p = cdata.synthetic_params(md, seed=11)
+    q = cdata.synthetic_queries(md, 45, seed=2, mean_filter=3.0, max_filter=12)
+    sc = OracleShardScorer(p, md, (0, md["num_ent"]))
+    ranks, ne = local_rank_pass(sc, q)
+    return ranks.numpy(), ne.numpy()
+
+
+@pytest.mark.parametrize("mode,world", [("entity", 2), ("entity", 3), ("entity_nosplit", 2), ("query", 2), ("query", 3)])
+def test_sharded_ranks_equal_single_process(tmp_path, oracle_chain, mode, world):
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, mode, str(tmp_path)), nprocs=world, join=True)
+    exp_r, exp_ne = _expected()
+    assert exp_r.min() >= 1 and exp_r.max() <= 203 and len(set(exp_r.tolist())) > 5
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / ("ranks_%d.npy" % r)), exp_r), (mode, r)
+        assert np.array_equal(np.load(tmp_path / ("ne_%d.npy" % r)), exp_ne), (mode, r)
