@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py -- scored triples/sec (1-vs-all) of the CoPER-ConvE evaluation hot path on MI355X.
+
+A "step" = one pass of the hot path (encode -> 1-vs-all score -> filtered rank) over one batch of
+synthetic queries: the evaluation set of the workload (Q queries), resident in
+HBM before the timed region starts.  Default workload = BASELINE.json configs[1]
+(FB15k-237-shaped CoPER-ConvE: |E|=14541, R2=474, d=200, r=32; Q=20480), fp32-exact mode.
+
+  python bench.py --gpus N --steps K --warmup W
+  N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`
+         query-sharded (every rank holds the model and ranks its own Q queries): weak scaling.
+  --workload synth10m_cpg --mode entity : the 10M-entity config, entity-sharded (strong scaling).
+
+Prints ONE JSON line (rank 0)."""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: Peak FP32 (matrix)
+PEAK_HBM_GBS = 8000.0
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="fb15k237_cpg")
+    ap.add_argument("--mode", choices=["query", "entity"], default="query")
+    ap.add_argument("--queries", type=int, default=None)
+    ap.add_argument("--order", choices=["shuffled", "sorted"], default="shuffled")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def device_params(md, seed, device, shard=None):
+    """Random-init weights of the named architecture.  Small tensors come from the seeded numpy
+    generator; an entity table too large to build on the host is drawn on the device (same
+    N(0, 0.3^2) law), row-sharded."""
+    import torch
+    from coper_amd import data as cdata
+    big = int(md["num_ent"]) * int(md["ent_emb_size"]) > (1 << 28)
+    p = cdata.synthetic_params(md, seed, skip=("ent_emb", "pred_bias") if big else ())
+    if big:
+        lo, hi = shard if shard is not None else (0, int(md["num_ent"]))
+        g = torch.Generator(device=device)
+        g.manual_seed(seed * 1000 + lo)
+        p["ent_emb"] = torch.randn((hi - lo, int(md["ent_emb_size"])), generator=g, device=device, dtype=torch.float32) * 0.3
+        p["pred_bias"] = torch.randn((hi - lo,), generator=g, device=device, dtype=torch.float32) * 0.1
+    return p, big
+
+
+def cpu_baseline(md, params, q, seconds):
+    """Reference-semantics CPU restatement (oracle, kind "port"): forward with the generated dense
+    weights materialised [B,F,d] (models.py:70,412), logits for all entities, dense mask, per-row
+    np.argsort (metrics.py:44-57), on a bounded sample of the same workload."""
+    from oracle import coper_oracle as O
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([i.get("num_threads", 1) for i in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    bs = 256
+    done, t0 = 0, time.perf_counter()
+    Q = len(q["e1"])
+    while done + bs <= Q:
+        ip = q["filt_indptr"][done:done + bs + 1]
+        O.eval_pass_reference_semantics(params, md, q["e1"][done:done + bs], q["rel"][done:done + bs],
+                                        q["e2"][done:done + bs], ip - ip[0], q["filt_idx"][ip[0]:ip[-1]], batch_size=bs)
+        done += bs
+        if time.perf_counter() - t0 >= seconds:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "triples/s", "cores": int(threads), "kind": "port",
+            "sample": "%d queries of the same workload in batches of %d (%.1f s): NumPy forward with materialised "
+                      "[B,F,d] generated weights + dense mask + per-row argsort" % (done, bs, dt)}
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+    from coper_amd import data as cdata
+    from coper_amd.models import ConvE
+    from coper_amd.sharding import EntityShardedRanker, local_rank_pass, shard_bounds
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+
+    md = cdata.model_descriptors(args.workload)
+    Q = args.queries or cdata.CONFIGS[args.workload]["queries"]
+    entity_mode = args.mode == "entity"
+    shard = shard_bounds(md["num_ent"], world, rank) if entity_mode else None
+    params, big = device_params(md, 0, device, shard)
+    model = ConvE(md, device=device, shard=shard)
+    model.load_parameters(params, global_rows=not big)
+    t_prep0 = time.perf_counter()
+    model.prepare()
+    torch.cuda.synchronize(device)
+    prepare_ms = (time.perf_counter() - t_prep0) * 1e3
+
+    # queries: entity mode -> every rank sees the same Q queries; query mode -> Q per rank (weak scaling)
+    q = cdata.synthetic_queries(md, Q, seed=0 if entity_mode else rank, order=args.order)
+    dev_q = {k: torch.as_tensor(v).to(device) for k, v in q.items()}   # inputs resident in HBM
+    nnz = int(len(q["filt_idx"]))
+    model.reserve(Q, nnz)
+    ranker = EntityShardedRanker(model) if entity_mode else None
+    host_q = dict(q)
+
+    def step():
+        if entity_mode:
+            # ids are tiny; the host copies drive the relation split, the device copies feed the kernels
+            return ranker.rank(dict(e1=host_q["e1"], rel=host_q["rel"], e2=dev_q["e2"], filt_indptr=dev_q["filt_indptr"],
+                                    filt_idx=dev_q["filt_idx"]))
+        h = model.encode(dev_q["e1"], dev_q["rel"])
+        return model.rank(h, dev_q["e2"], dev_q["filt_indptr"], dev_q["filt_idx"], filt_nnz=nnz)
+
+    for _ in range(args.warmup):
+        step()
+    model.profile(True)
+    for k in ("score_count", "dense", "conv"):
+        model.profile_read(k)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ranks, _ = step()
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    model.profile(False)
+    if world > 1:
+        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    kern = {}
+    for k in ("score_count", "dense", "conv"):
+        ms, n = model.profile_read(k)
+        kern[k] = (ms / n) if n else None
+    ranks_np = ranks.cpu().numpy()
+
+    if rank == 0:
+        units = Q * (1 if entity_mode else world) * args.steps
+        n_local = model.n_local
+        d = int(md["ent_emb_size"])
+        out = {
+            "metric": "scored triples/sec (1-vs-all)", "value": units / dt, "unit": "triples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong" if entity_mode else "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: |E|=%d R2=%d d=%d r=%d, Q=%d queries/pass%s, %s relation order" % (
+                args.workload, md["num_ent"], md["num_rel"], d, md["rel_emb_size"], Q,
+                "" if entity_mode else " per GPU", args.order),
+                "parallelism": ("entity-sharded x%d" % world) if entity_mode else ("query-sharded x%d" % world),
+                "score_mode": "f32 (v_mfma_f32_32x32x2_f32, exact)", "prepare_ms": round(prepare_ms, 2),
+                "mean_rank": float(np.mean(ranks_np)), "mrr": float(np.mean(1.0 / ranks_np))},
+        }
+        if kern["score_count"]:
+            flops = 2.0 * Q * n_local * d          # ALGORITHMIC flops of one score_count launch
+            ach = flops / (kern["score_count"] * 1e-3) / 1e12
+            out["roofline"] = {"kernel": "k_score_count_f32", "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
+                               "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                               "avg_launch_ms": kern["score_count"],
+                               "other_kernels_ms": {k: v for k, v in kern.items() if k != "score_count"}}
+        if not args.no_cpu_baseline and world == 1:
+            host_p = {k: (v.cpu().numpy() if hasattr(v, "cpu") else v) for k, v in params.items()} if not big else None
+            if host_p is not None:
+                out["cpu_baseline"] = cpu_baseline(md, host_p, q, args.cpu_seconds)
+                out["config"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
