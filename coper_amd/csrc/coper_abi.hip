@@ -103,6 +103,7 @@ static int ensure_workspace(coper_handle* h, int64_t B, int64_t nnz, hipStream_t
   if ((rc = dev_alloc(h, &h->z_part, (size_t)KSPLIT_MAX * cap * dm.d_pad16))) return rc;
   if ((rc = dev_alloc(h, &h->tgt_ws, cap))) return rc;
   if ((rc = dev_alloc(h, &h->cnt_ws, 2 * cap))) return rc;
+  if ((rc = dev_alloc(h, &h->hfrag_ws, (size_t)((cap + 127) / 128) * 128 * dm.d_pad8))) return rc;
   h->ws_queries = cap;
   h->ws_ksplit = KSPLIT_MAX;
   return COPER_OK;
@@ -163,7 +164,7 @@ COPER_API int coper_create(const coper_config* cfg, coper_handle** out) {
   dm.d_pad8 = (dm.d + 7) / 8 * 8; dm.KS = dm.d_pad8 / 8;
   dm.n_local = cfg->shard_hi - cfg->shard_lo;
   dm.n_eblk = ((dm.n_local + 31) / 32 + EBLK_ALIGN - 1) / EBLK_ALIGN * EBLK_ALIGN;
-  if (dm.KS * 2 * 64 * 16 > 160 * 1024) return bad("ent_emb_size too large for the LDS query tile");
+  if (dm.KS * 4 * 64 * 16 > 160 * 1024) return bad("ent_emb_size too large for the LDS query tile (d <= 320)");
   if ((int64_t)dm.in_h * dm.in_w + (int64_t)dm.fh * dm.fw * dm.C + 3 * dm.C > 40000) return bad("conv stage too large for LDS");
 
   // parameter specs (models.py:203-336)
@@ -210,7 +211,7 @@ COPER_API void coper_destroy(coper_handle* h) {
   dev_free(&h->Ef); dev_free(&h->bias_pad); dev_free(&h->ctx_tmp[0]); dev_free(&h->ctx_tmp[1]);
   dev_free(&h->rel_count); dev_free(&h->rel_offset); dev_free(&h->rel_cursor); dev_free(&h->perm);
   dev_free(&h->tiles); dev_free(&h->n_tiles); dev_free(&h->x_sorted); dev_free(&h->z_part);
-  dev_free(&h->tgt_ws); dev_free(&h->cnt_ws);
+  dev_free(&h->tgt_ws); dev_free(&h->cnt_ws); dev_free(&h->hfrag_ws);
   for (auto& kv : h->timers)
     for (auto& p : kv.second.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   delete h;
@@ -363,6 +364,12 @@ COPER_API int coper_prepare(coper_handle* h, void* stream) {
   if ((rc = dev_alloc(h, &h->Ef, (size_t)dm.n_eblk * dm.KS * 64 * 4)) || (rc = dev_alloc(h, &h->bias_pad, (size_t)dm.n_eblk * 32)))
     return rc;
   if ((rc = launch_entity_frag(h, P("ent_emb"), P("pred_bias"), s))) return rc;
+  {
+    hipDeviceProp_t prop;
+    COPER_HIP_TRY(h, hipGetDeviceProperties(&prop, cfg.device));
+    h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  if ((rc = score_kernels_init(h))) return rc;
   h->prepared = true;
   return COPER_OK;
 }

@@ -86,6 +86,8 @@ struct coper_handle {
   float* z_part = nullptr;        // [ksplit, B, d_pad16]
   float* tgt_ws = nullptr;        // [B]
   int32_t* cnt_ws = nullptr;      // [2B]
+  float* hfrag_ws = nullptr;      // h re-packed in MFMA-fragment order [ceil(B/128)*4][KS][64] float4
+  int num_cus = 256;
 
   bool profile = false;
   std::map<std::string, coper::Timer> timers;
@@ -133,6 +135,7 @@ int launch_filter_correct(coper_handle* h, const float* hvec, const float* tgt, 
 int launch_score_lookup(coper_handle* h, const float* hvec, const int32_t* lookup, int64_t B, int64_t L, float* out,
                         hipStream_t s);
 int launch_finish_ranks(coper_handle* h, const int32_t* ng, int64_t B, int32_t* ranks, hipStream_t s);
+int score_kernels_init(coper_handle* h);
 
 // profiling helpers (hipEvents on the launch stream)
 struct ScopedKernelTimer {

@@ -44,105 +44,183 @@ __device__ __forceinline__ void stage_h_frag(float4* hl, const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
-// fused score + count.  grid = (query tiles of 32*NQ, entity splits); 4 waves, each wave ME entity
-// blocks per iteration.  D[i][j]: i = entity row (A operand), j = query (B operand, one per lane).
+// fused score + count (the dominant kernel).
+//
+// Persistent, statically balanced: the work is U = q_tiles x iters units, one unit = 128 queries x
+// 256 entities (8 waves x one 32-row entity block each); workgroup w of G = #CUs owns the contiguous
+// unit range [U*w/G, U*(w+1)/G) in query-tile-major order, so every workgroup does the same number of
+// MFMAs (no tail) and re-stages its query tile at most twice.  512 threads = 2 waves per SIMD sharing
+// one 128-query h tile in LDS (pre-packed in fragment order by k_pack_h: staging is a straight copy);
+// each wave streams its own entity block from Ef straight into VGPRs, software-pipelined one k-step
+// ahead.  D[i][j]: i = entity row (A operand, on the accumulator registers), j = query (B operand, one
+// per lane): counting #{s > t}, #{s == t} is lane-local.
 // ------------------------------------------------------------------------------------------------
-template <int NQ, int ME>
-__global__ __launch_bounds__(256, 2) void k_score_count_f32(const float4* __restrict__ Ef,
+constexpr int SC_NQ = 4;      // 32-query blocks per workgroup tile
+constexpr int SC_WAVES = 8;   // entity blocks per unit
+
+__global__ void k_pack_h(const float* __restrict__ hvec, int64_t B, int d, int KS, float4* __restrict__ hfrag,
+                         int64_t total) {
+  int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // ((qtile*NQ + qb)*KS + ks)*64 + l
+  if (j >= total) return;
+  int l = (int)(j & 63);
+  int64_t rest = j >> 6;
+  int ks = (int)(rest % KS);
+  int64_t qblk = rest / KS;
+  int64_t q = qblk * 32 + (l & 31);
+  int k = 8 * ks + 4 * (l >> 5);
+  float v[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) v[t] = (q < B && k + t < d) ? hvec[q * d + k + t] : 0.f;
+  hfrag[j] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+__global__ __launch_bounds__(512, 2) void k_score_count_f32(const float4* __restrict__ Ef,
                                                             const float* __restrict__ bias_pad,
-                                                            const float* __restrict__ hvec,
-                                                            const float* __restrict__ tgt, int64_t B, int d, int KS,
-                                                            int64_t n_eblk, int64_t eblk_per_split,
+                                                            const float4* __restrict__ hfrag,
+                                                            const float* __restrict__ tgt, int64_t B, int KS,
+                                                            int64_t iters, int64_t units,
                                                             int32_t* __restrict__ ng, int32_t* __restrict__ ne) {
-  extern __shared__ float4 hl[];
-  const int64_t q0 = (int64_t)blockIdx.x * (32 * NQ);
-  stage_h_frag<NQ>(hl, hvec, q0, B, d, KS);
-  __syncthreads();
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  constexpr int NQ = SC_NQ;
+  extern __shared__ float4 hl[];  // [NQ][KS][64]
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int64_t u_begin = units * blockIdx.x / gridDim.x;
+  const int64_t u_end = units * (blockIdx.x + 1) / gridDim.x;
   float t[NQ];
   int cg[NQ], ce[NQ];
-#pragma unroll
-  for (int b = 0; b < NQ; ++b) {
-    int64_t q = q0 + b * 32 + (lane & 31);
-    t[b] = q < B ? tgt[q] : INFINITY;
-    cg[b] = 0;
-    ce[b] = 0;
+  int64_t cur_tile = -1;
+
+  float4 a0, a1, b0[NQ], b1[NQ], bq[4];
+#ifdef COPER_DBG_NO_GLOADS
+#define EF_AT(ebx, ks_) Ef[lane]
+#else
+#define EF_AT(ebx, ks_) Ef[((ebx)*KS + (ks_)) * 64 + lane]
+#endif
+#ifdef COPER_DBG_NO_LDS
+#define LOAD_B(bv, ks_) \
+  { _Pragma("unroll") for (int b = 0; b < NQ; ++b) bv[b] = hl[b * 64 + lane]; }
+#else
+#define LOAD_B(bv, ks_) \
+  { _Pragma("unroll") for (int b = 0; b < NQ; ++b) bv[b] = hl[(b * KS + (ks_)) * 64 + lane]; }
+#endif
+#define LOAD_BIAS(ebx)                                                                 \
+  {                                                                                    \
+    const float4* bp = (const float4*)(bias_pad + (ebx)*32 + 4 * (lane >> 5));         \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) bq[j] = bp[2 * j];                   \
   }
-  const int64_t e_begin = (int64_t)blockIdx.y * eblk_per_split;
-  int64_t e_end = e_begin + eblk_per_split;
-  if (e_end > n_eblk) e_end = n_eblk;
-  for (int64_t eb = e_begin + wave * ME; eb < e_end; eb += 4 * ME) {
-    f32x16 acc[ME][NQ];
+#define MFMA_STEP(av, bv)                                                                                  \
+  {                                                                                                        \
+    _Pragma("unroll") for (int tt = 0; tt < 4; ++tt) _Pragma("unroll") for (int b = 0; b < NQ; ++b) acc[b] = \
+        __builtin_amdgcn_mfma_f32_32x32x2f32(F4C(av, tt), F4C(bv[b], tt), acc[b], 0, 0, 0);                 \
+  }
+#define FLUSH_COUNTS()                                                        \
+  {                                                                           \
+    _Pragma("unroll") for (int b = 0; b < NQ; ++b) {                          \
+      int g = cg[b] + __shfl_xor(cg[b], 32);                                  \
+      int e = ce[b] + __shfl_xor(ce[b], 32);                                  \
+      int64_t q = cur_tile * (32 * NQ) + b * 32 + (lane & 31);                \
+      if (lane < 32 && q < B) {                                               \
+        if (g) atomicAdd(&ng[q], g);                                          \
+        if (e) atomicAdd(&ne[q], e);                                          \
+      }                                                                       \
+    }                                                                         \
+  }
+
+  if (u_begin < u_end) {
+    int64_t eb = (u_begin % iters) * SC_WAVES + wave;
+    a0 = EF_AT(eb, 0);
+    LOAD_BIAS(eb);
+  }
+  for (int64_t u = u_begin; u < u_end; ++u) {
+    const int64_t tile = u / iters;
+    const int64_t eb = (u % iters) * SC_WAVES + wave;
+    if (tile != cur_tile) {  // workgroup-uniform
+      if (cur_tile >= 0) FLUSH_COUNTS();
+      __syncthreads();
+      const float4* src = hfrag + tile * (NQ * KS * 64);
+      for (int j = threadIdx.x; j < NQ * KS * 64; j += 512) hl[j] = src[j];
+      cur_tile = tile;
 #pragma unroll
-    for (int a = 0; a < ME; ++a) {
-      // accumulator row of reg r: (r&3) + 8(r>>2) + 4(lane>>5): start the chain from pred_bias
-      const float4* bp = (const float4*)(bias_pad + (eb + a) * 32 + 4 * (lane >> 5));
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float4 b4 = bp[2 * j];
-#pragma unroll
-        for (int b = 0; b < NQ; ++b) {
-          acc[a][b][4 * j + 0] = b4.x; acc[a][b][4 * j + 1] = b4.y;
-          acc[a][b][4 * j + 2] = b4.z; acc[a][b][4 * j + 3] = b4.w;
-        }
+      for (int b = 0; b < NQ; ++b) {
+        int64_t q = tile * (32 * NQ) + b * 32 + (lane & 31);
+        t[b] = q < B ? tgt[q] : INFINITY;
+        cg[b] = 0;
+        ce[b] = 0;
       }
+      __syncthreads();
     }
-    const float4* ep = Ef + (eb * KS) * 64 + lane;
-    for (int ks = 0; ks < KS; ++ks) {
-      float4 av[ME], bv[NQ];
+    f32x16 acc[NQ];
+    // accumulator row of reg r: (r&3) + 8(r>>2) + 4(lane>>5): the chain starts from pred_bias
 #pragma unroll
-      for (int a = 0; a < ME; ++a) av[a] = ep[((int64_t)a * KS + ks) * 64];
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int b = 0; b < NQ; ++b) bv[b] = hl[(b * KS + ks) * 64 + lane];
-#pragma unroll
-      for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-        for (int a = 0; a < ME; ++a)
-#pragma unroll
-          for (int b = 0; b < NQ; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(F4C(av[a], tt), F4C(bv[b], tt), acc[a][b], 0, 0, 0);
+      for (int b = 0; b < NQ; ++b) {
+        acc[b][4 * j + 0] = bq[j].x; acc[b][4 * j + 1] = bq[j].y;
+        acc[b][4 * j + 2] = bq[j].z; acc[b][4 * j + 3] = bq[j].w;
+      }
+    LOAD_B(b0, 0);
+    int ks = 0;
+    for (; ks + 2 <= KS; ks += 2) {
+      a1 = EF_AT(eb, ks + 1);
+      LOAD_B(b1, ks + 1);
+      __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMAs it overlaps
+      MFMA_STEP(a0, b0);
+      const int kn = ks + 2 < KS ? ks + 2 : KS - 1;
+      a0 = EF_AT(eb, kn);
+      LOAD_B(b0, kn);
+      __builtin_amdgcn_sched_barrier(0);
+      MFMA_STEP(a1, b1);
     }
+    if (ks < KS) MFMA_STEP(a0, b0);  // odd KS: a0/b0 hold k-step KS-1
+    if (u + 1 < u_end) {             // next unit's first fragment + bias rows, ahead of the compares
+      const int64_t ebn = ((u + 1) % iters) * SC_WAVES + wave;
+      a0 = EF_AT(ebn, 0);
+      LOAD_BIAS(ebn);
+    }
+#ifdef COPER_DBG_NO_EPILOGUE
 #pragma unroll
-    for (int a = 0; a < ME; ++a)
+    for (int b = 0; b < NQ; ++b) cg[b] += (acc[b][0] + acc[b][5] + acc[b][10] + acc[b][15] > t[b]) ? 1 : 0;
+#else
 #pragma unroll
-      for (int b = 0; b < NQ; ++b)
+    for (int b = 0; b < NQ; ++b)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float s = acc[a][b][r];
-          cg[b] += (s > t[b]) ? 1 : 0;
-          ce[b] += (s == t[b]) ? 1 : 0;
-        }
+      for (int r = 0; r < 16; ++r) {
+        float sc = acc[b][r];
+        cg[b] += (sc > t[b]) ? 1 : 0;
+        ce[b] += (sc == t[b]) ? 1 : 0;
+      }
+#endif
   }
-#pragma unroll
-  for (int b = 0; b < NQ; ++b) {
-    cg[b] += __shfl_xor(cg[b], 32);
-    ce[b] += __shfl_xor(ce[b], 32);
-    int64_t q = q0 + b * 32 + (lane & 31);
-    if (lane < 32 && q < B) {
-      if (cg[b]) atomicAdd(&ng[q], cg[b]);
-      if (ce[b]) atomicAdd(&ne[q], ce[b]);
-    }
-  }
+  if (cur_tile >= 0) FLUSH_COUNTS();
+#undef EF_AT
+#undef LOAD_B
+#undef LOAD_BIAS
+#undef MFMA_STEP
+#undef FLUSH_COUNTS
 }
 
 int launch_score_count(coper_handle* h, const float* hvec, const float* tgt, int64_t B, int32_t* ng, int32_t* ne,
                        hipStream_t s) {
   const Dims& dm = h->dm;
-  constexpr int NQ = 2, ME = 2;
-  int64_t q_tiles = (B + 32 * NQ - 1) / (32 * NQ);
-  int64_t iters = dm.n_eblk / (4 * ME);  // n_eblk is padded to EBLK_ALIGN = 4*ME
-  int64_t splits = (2048 + q_tiles - 1) / q_tiles;
-  if (splits > iters) splits = iters;
-  if (splits < 1) splits = 1;
-  if (splits > 65535) splits = 65535;
-  int64_t iters_per_split = (iters + splits - 1) / splits;
-  splits = (iters + iters_per_split - 1) / iters_per_split;
-  size_t lds = (size_t)NQ * dm.KS * 64 * sizeof(float4);
+  int64_t q_tiles = (B + 32 * SC_NQ - 1) / (32 * SC_NQ);
+  int64_t iters = dm.n_eblk / SC_WAVES;  // n_eblk is padded to EBLK_ALIGN = SC_WAVES
+  int64_t units = q_tiles * iters;
+  int64_t total = q_tiles * SC_NQ * dm.KS * 64;
+  hipLaunchKernelGGL(k_pack_h, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, hvec, B, dm.d, dm.KS,
+                     (float4*)h->hfrag_ws, total);
+  int64_t grid = h->num_cus;
+  if (grid > units) grid = units;
+  size_t lds = (size_t)SC_NQ * dm.KS * 64 * sizeof(float4);
   ScopedKernelTimer t(h, "score_count", s);
-  hipLaunchKernelGGL((k_score_count_f32<NQ, ME>), dim3((unsigned)q_tiles, (unsigned)splits), dim3(256), lds, s,
-                     (const float4*)h->Ef, h->bias_pad, hvec, tgt, B, dm.d, dm.KS, dm.n_eblk,
-                     iters_per_split * 4 * ME, ng, ne);
+  hipLaunchKernelGGL(k_score_count_f32, dim3((unsigned)grid), dim3(512), lds, s, (const float4*)h->Ef, h->bias_pad,
+                     (const float4*)h->hfrag_ws, tgt, B, dm.KS, iters, units, ng, ne);
   COPER_HIP_TRY(h, hipGetLastError());
+  return COPER_OK;
+}
+
+int score_kernels_init(coper_handle* h) {
+  const Dims& dm = h->dm;
+  int lds = (int)((size_t)SC_NQ * dm.KS * 64 * sizeof(float4));
+  COPER_HIP_TRY(h, hipFuncSetAttribute((const void*)k_score_count_f32, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   return COPER_OK;
 }
 
