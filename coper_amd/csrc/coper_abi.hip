@@ -97,8 +97,9 @@ static int ensure_workspace(coper_handle* h, int64_t B, int64_t nnz, hipStream_t
   if ((rc = dev_alloc(h, &h->rel_offset, dm.R + 2))) return rc;
   if ((rc = dev_alloc(h, &h->rel_cursor, dm.R + 2))) return rc;
   if ((rc = dev_alloc(h, &h->perm, cap))) return rc;
-  if ((rc = dev_alloc(h, &h->tiles, 4 * (cap / 16 + dm.R + 2)))) return rc;
+  if ((rc = dev_alloc(h, &h->tiles, 4 * (cap / 32 + dm.R + 4)))) return rc;
   if ((rc = dev_alloc(h, &h->n_tiles, 4))) return rc;
+  if ((rc = dev_alloc(h, &h->blk_off, dm.R + 2))) return rc;
   if ((rc = dev_alloc(h, &h->x_sorted, (size_t)cap * dm.F_pad))) return rc;
   if ((rc = dev_alloc(h, &h->z_part, (size_t)KSPLIT_MAX * cap * dm.d_pad16))) return rc;
   if ((rc = dev_alloc(h, &h->tgt_ws, cap))) return rc;
@@ -210,7 +211,7 @@ COPER_API void coper_destroy(coper_handle* h) {
   dev_free(&h->conv_w_rel); dev_free(&h->conv_b_rel); dev_free(&h->fc_b_rel); dev_free(&h->Wf);
   dev_free(&h->Ef); dev_free(&h->bias_pad); dev_free(&h->ctx_tmp[0]); dev_free(&h->ctx_tmp[1]);
   dev_free(&h->rel_count); dev_free(&h->rel_offset); dev_free(&h->rel_cursor); dev_free(&h->perm);
-  dev_free(&h->tiles); dev_free(&h->n_tiles); dev_free(&h->x_sorted); dev_free(&h->z_part);
+  dev_free(&h->tiles); dev_free(&h->n_tiles); dev_free(&h->blk_off); dev_free(&h->x_sorted); dev_free(&h->z_part);
   dev_free(&h->tgt_ws); dev_free(&h->cnt_ws); dev_free(&h->hfrag_ws);
   for (auto& kv : h->timers)
     for (auto& p : kv.second.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
@@ -407,7 +408,7 @@ COPER_API int coper_encode(coper_handle* h, const int64_t* e1, const int64_t* re
   // K-split of the dense layer depends on F only, never on the batch: h[b] is then a pure function of
   // (e1[b], rel[b]) -- bit-identical whatever batch, chunking or rank computes it.
   int64_t ksteps = dm.F_pad / 16;
-  int ksplit = ksteps >= 64 ? 4 : 1;
+  int ksplit = ksteps >= 64 ? 4 : 1;  // DENSE_KSLICES
   if (ksplit > h->ws_ksplit) ksplit = h->ws_ksplit;
   if ((rc = launch_group_by_relation(h, rel, B, tq, s))) return rc;
   if ((rc = launch_conv(h, e1, rel, e1_rows, B, s))) return rc;

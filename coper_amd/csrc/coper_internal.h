@@ -81,13 +81,15 @@ struct coper_handle {
   int32_t* rel_cursor = nullptr;  // [R]
   int32_t* perm = nullptr;        // [B] sorted position -> query
   int32_t* tiles = nullptr;       // [T_max*4] (rel, start, n, pad)
-  int32_t* n_tiles = nullptr;     // [1]
+  int32_t* n_tiles = nullptr;     // [2] #small tiles, #big 16-query blocks
+  int32_t* blk_off = nullptr;     // [R+1] exclusive scan of the big groups' block counts
   float* x_sorted = nullptr;      // [B, F_pad]
   float* z_part = nullptr;        // [ksplit, B, d_pad16]
   float* tgt_ws = nullptr;        // [B]
   int32_t* cnt_ws = nullptr;      // [2B]
   float* hfrag_ws = nullptr;      // h re-packed in MFMA-fragment order [ceil(B/128)*4][KS][64] float4
   int num_cus = 256;
+  bool dense_attr_done = false;
 
   bool profile = false;
   std::map<std::string, coper::Timer> timers;

@@ -30,48 +30,83 @@ __global__ void k_rel_hist(const int64_t* __restrict__ rel, int64_t B, int use_r
   atomicAdd(&count[key], 1);
 }
 
-// single block: exclusive scan of the counts -> offsets, and the tile list
-__global__ __launch_bounds__(1024) void k_rel_scan_tiles(const int32_t* __restrict__ count, int64_t R, int tq,
-                                                         int32_t* __restrict__ offset,
+// single block: exclusive scan of the counts -> offsets, and the two tile lists:
+//   small tiles: one per relation group with 1..32 queries          (k_dense_small_f32)
+//   big tiles:   groups with > 32 queries cut into ceil(c/128) balanced tiles of <= 128 (k_dense_big_f32),
+//                emitted largest-first (by 16-query block count) so the hardware dispatcher, which hands
+//                out workgroups in index order, ends the launch on the cheapest tiles.
+// tiles[] = small list at [0, 4*cap_small), big list after it; n_tiles[0] = #small, n_tiles[1] = #big.
+__global__ __launch_bounds__(1024) void k_rel_scan_tiles(const int32_t* __restrict__ count, int64_t R,
+                                                         int64_t cap_small, int32_t* __restrict__ offset,
                                                          int32_t* __restrict__ tiles,
                                                          int32_t* __restrict__ n_tiles) {
   __shared__ int s_cnt[1024];
-  __shared__ int s_til[1024];
-  __shared__ int carry_cnt, carry_til;
-  if (threadIdx.x == 0) { carry_cnt = 0; carry_til = 0; }
+  __shared__ int s_sml[1024];
+  __shared__ int carry_cnt, carry_sml;
+  __shared__ int cls_count[9], cls_base[9], cls_cursor[9];
+  if (threadIdx.x == 0) { carry_cnt = 0; carry_sml = 0; }
+  if (threadIdx.x < 9) { cls_count[threadIdx.x] = 0; cls_cursor[threadIdx.x] = 0; }
   __syncthreads();
+  int32_t* tiles_big = tiles + 4 * cap_small;
+  // pass 1: offsets, small tiles, and the number of big tiles per size class
   for (int64_t base = 0; base < R; base += 1024) {
     int64_t rid = base + threadIdx.x;
     int c = rid < R ? count[rid] : 0;
-    int nt = (c + tq - 1) / tq;
+    int ns = (c > 0 && c <= 32) ? 1 : 0;
     s_cnt[threadIdx.x] = c;
-    s_til[threadIdx.x] = nt;
+    s_sml[threadIdx.x] = ns;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {
       int a = 0, b2 = 0;
-      if ((int)threadIdx.x >= off) { a = s_cnt[threadIdx.x - off]; b2 = s_til[threadIdx.x - off]; }
+      if ((int)threadIdx.x >= off) { a = s_cnt[threadIdx.x - off]; b2 = s_sml[threadIdx.x - off]; }
       __syncthreads();
       s_cnt[threadIdx.x] += a;
-      s_til[threadIdx.x] += b2;
+      s_sml[threadIdx.x] += b2;
       __syncthreads();
     }
     int excl_c = carry_cnt + s_cnt[threadIdx.x] - c;
-    int excl_t = carry_til + s_til[threadIdx.x] - nt;
+    int excl_s = carry_sml + s_sml[threadIdx.x] - ns;
     if (rid < R) {
       offset[rid] = excl_c;
-      for (int j = 0; j < nt; ++j) {
-        int32_t* t = tiles + 4 * (int64_t)(excl_t + j);
-        t[0] = (int32_t)rid;
-        t[1] = excl_c + j * tq;
-        t[2] = (c - j * tq) < tq ? (c - j * tq) : tq;
-        t[3] = 0;
+      if (ns) {
+        int32_t* t = tiles + 4 * (int64_t)excl_s;
+        t[0] = (int32_t)rid; t[1] = excl_c; t[2] = c; t[3] = 0;
+      }
+      if (c > 32) {
+        int nb = (c + 127) / 128, bsz = c / nb, rem = c % nb;
+        if (rem) atomicAdd(&cls_count[(bsz + 1 + 15) >> 4], rem);
+        atomicAdd(&cls_count[(bsz + 15) >> 4], nb - rem);
       }
     }
     __syncthreads();
-    if (threadIdx.x == 1023) { carry_cnt += s_cnt[1023]; carry_til += s_til[1023]; }
+    if (threadIdx.x == 1023) { carry_cnt += s_cnt[1023]; carry_sml += s_sml[1023]; }
     __syncthreads();
   }
-  if (threadIdx.x == 0) { offset[R] = carry_cnt; *n_tiles = carry_til; }
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int k = 8; k >= 0; --k) { cls_base[k] = run; run += cls_count[k]; }
+    offset[R] = carry_cnt;
+    n_tiles[0] = carry_sml;
+    n_tiles[1] = run;
+  }
+  __syncthreads();
+  // pass 2: place the big tiles, class by class (order inside a class is irrelevant to the results)
+  for (int64_t rid = threadIdx.x; rid < R; rid += 1024) {
+    int c = count[rid];
+    if (c <= 32) continue;
+    int nb = (c + 127) / 128, bsz = c / nb, rem = c % nb;
+    int off = offset[rid];
+    for (int j = 0; j < nb; ++j) {
+      int sz = bsz + (j < rem ? 1 : 0);
+      int k = (sz + 15) >> 4;
+      int slot = cls_base[k] + atomicAdd(&cls_cursor[k], 1);
+      int32_t* t = tiles_big + 4 * (int64_t)slot;
+      t[0] = (int32_t)rid;
+      t[1] = off + j * bsz + (j < rem ? j : rem);
+      t[2] = sz;
+      t[3] = 0;
+    }
+  }
 }
 
 __global__ void k_rel_scatter(const int64_t* __restrict__ rel, int64_t B, int use_rel, int64_t R,
@@ -85,6 +120,9 @@ __global__ void k_rel_scatter(const int64_t* __restrict__ rel, int64_t B, int us
   perm[offset[key] + pos] = (int32_t)b;
 }
 
+// capacity of the small-tile list (one tile per relation key at most); the big list follows it
+static int64_t small_tile_cap(const coper_handle* h) { return (h->dm.gen_fc ? h->dm.R : 1) + 1; }
+
 int launch_group_by_relation(coper_handle* h, const int64_t* rel, int64_t B, int tq, hipStream_t s) {
   const Dims& dm = h->dm;
   int64_t R = dm.gen_fc ? dm.R : 1;
@@ -94,8 +132,9 @@ int launch_group_by_relation(coper_handle* h, const int64_t* rel, int64_t B, int
   // rel_count[R+1] doubles as the out-of-range counter (ids are validated on device, never trusted)
   hipLaunchKernelGGL(k_rel_hist, dim3(nb), dim3(256), 0, s, rel, B, dm.gen_fc ? 1 : 0, R, h->rel_count,
                      h->rel_count + dm.R + 1);
-  hipLaunchKernelGGL(k_rel_scan_tiles, dim3(1), dim3(1024), 0, s, h->rel_count, R, tq, h->rel_offset, h->tiles,
-                     h->n_tiles);
+  (void)tq;
+  hipLaunchKernelGGL(k_rel_scan_tiles, dim3(1), dim3(1024), 0, s, h->rel_count, R, small_tile_cap(h), h->rel_offset,
+                     h->tiles, h->n_tiles);
   hipLaunchKernelGGL(k_rel_scatter, dim3(nb), dim3(256), 0, s, rel, B, dm.gen_fc ? 1 : 0, R, h->rel_offset,
                      h->rel_cursor, h->perm);
   COPER_HIP_TRY(h, hipGetLastError());
@@ -176,28 +215,43 @@ int launch_conv(coper_handle* h, const int64_t* e1, const int64_t* rel, const fl
 }
 
 // ------------------------------------------------------------------------------------------------
-// dense: Z^T[d, TQ] = W_rel^T[d, F] . X^T[F, TQ] per tile, v_mfma_f32_16x16x4_f32
+// dense: Z^T[d, n] = W_rel^T[d, F] . X^T[F, n] per tile, v_mfma_f32_16x16x4_f32 (exact f32)
 //   A operand (features on rows):  lane l holds W[f = 16ks + 4(l>>4) + t][feat = 16fb + (l&15)]  (Wf float4, t = component)
 //   B operand (queries on columns): lane l holds x[q = l&15][f = 16ks + 4(l>>4) + t]
 //   MFMA t contracts k-group {4g + t : g = 0..3}; D: col = lane&15 (query), row = 4(lane>>4) + reg (feature).
+// K = F is cut into DENSE_KSLICES fixed slices (a function of F only); every (query, feature, slice)
+// partial is ONE accumulator chain over the slice's k-steps in order, whichever kernel produces it, and
+// k_dense_finalize adds the slices in order: h[b] does not depend on the batch it was computed in.
+//
+//   k_dense_small_f32  tiles of <= 32 queries (HBM-bound: n/2 flop per weight byte): one wave per slice,
+//                      weights stream from Wf straight into VGPRs (13 KiB per wave per k-step), no LDS.
+//   k_dense_big_f32    tiles of 33..128 queries: 4 waves x 32 queries share the weight stream through an
+//                      LDS double buffer filled by LDS-DMA (global_load_lds, 1 KiB per wave-instruction,
+//                      the fragment image is lane-linear so no swizzle is needed); the x fragments take
+//                      the same route (per-lane gather addresses).  One slice per workgroup (grid.y).
 // ------------------------------------------------------------------------------------------------
-template <int NFB, int NQ>
-__global__ __launch_bounds__(256) void k_dense_f32(const float4* __restrict__ Wf, const float* __restrict__ x_sorted,
-                                                   const int32_t* __restrict__ tiles,
-                                                   const int32_t* __restrict__ n_tiles, int nfb, int64_t ksteps,
-                                                   int64_t F_pad, int ksplit, int64_t Bcap, int d_pad16,
-                                                   float* __restrict__ z_part) {
-  extern __shared__ float4 red[];  // [2][NFB*NQ][64]
+// DENSE_KSLICES = 4 when F_pad/16 >= 64 else 1 (chosen in coper_encode from F only)
+
+#define F4T(v, t) ((t) == 0 ? (v).x : (t) == 1 ? (v).y : (t) == 2 ? (v).z : (v).w)
+
+template <int NFB>
+__global__ __launch_bounds__(256) void k_dense_small_f32(const float4* __restrict__ Wf,
+                                                         const float* __restrict__ x_sorted,
+                                                         const int32_t* __restrict__ tiles,
+                                                         const int32_t* __restrict__ n_tiles, int nfb, int64_t ksteps,
+                                                         int64_t F_pad, int nslices, int64_t Bcap, int d_pad16,
+                                                         float* __restrict__ z_part) {
+  constexpr int NQ = 2;
   int tile = blockIdx.x;
-  if (tile >= *n_tiles) return;
-  const int slice = blockIdx.y;
+  if (tile >= n_tiles[0]) return;
   const int fb0 = blockIdx.z * NFB;
-  const int64_t relw = tiles[4 * tile + 0];
-  const int start = tiles[4 * tile + 1];
-  const int n = tiles[4 * tile + 2];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int nparts = ksplit * 4, part = slice * 4 + wave;
-  const int64_t kb = ksteps * part / nparts, ke = ksteps * (part + 1) / nparts;
+  const int64_t relw = __builtin_amdgcn_readfirstlane(tiles[4 * tile + 0]);
+  const int start = __builtin_amdgcn_readfirstlane(tiles[4 * tile + 1]);
+  const int n = __builtin_amdgcn_readfirstlane(tiles[4 * tile + 2]);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int slice = blockIdx.y * 4 + wave;
+  if (slice >= nslices) return;
+  const int64_t kb = ksteps * slice / nslices, ke = ksteps * (slice + 1) / nslices;
 
   f32x4 acc[NFB][NQ];
 #pragma unroll
@@ -231,61 +285,192 @@ __global__ __launch_bounds__(256) void k_dense_f32(const float4* __restrict__ Wf
     for (int t = 0; t < 4; ++t) {
 #pragma unroll
       for (int a = 0; a < NFB; ++a) {
-        float av_t = t == 0 ? av[a].x : t == 1 ? av[a].y : t == 2 ? av[a].z : av[a].w;
-        float b0 = t == 0 ? bv[0].x : t == 1 ? bv[0].y : t == 2 ? bv[0].z : bv[0].w;
-        acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_t, b0, acc[a][0], 0, 0, 0);
-        if (NQ > 1 && second) {
-          float b1 = t == 0 ? bv[NQ - 1].x : t == 1 ? bv[NQ - 1].y : t == 2 ? bv[NQ - 1].z : bv[NQ - 1].w;
-          acc[a][NQ - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_t, b1, acc[a][NQ - 1], 0, 0, 0);
-        }
+        acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(F4T(av[a], t), F4T(bv[0], t), acc[a][0], 0, 0, 0);
+        if (second) acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(F4T(av[a], t), F4T(bv[1], t), acc[a][1], 0, 0, 0);
       }
     }
+  }
+#pragma unroll
+  for (int a = 0; a < NFB; ++a) {
+    if (fb0 + a >= nfb) continue;
+#pragma unroll
+    for (int b = 0; b < NQ; ++b) {
+      int qi = b * 16 + (lane & 15);
+      if (qi < n) {
+        float* dst = z_part + ((int64_t)slice * Bcap + start + qi) * d_pad16 + (fb0 + a) * 16 + 4 * (lane >> 4);
+        *(float4*)dst = make_float4(acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]);
+      }
+    }
+  }
+}
+
+#ifndef COPER_DENSE_NSTAGE
+#define COPER_DENSE_NSTAGE 3
+#endif
+#ifndef COPER_DENSE_GI
+#define COPER_DENSE_GI 4
+#endif
+// One tile of NB 16-query blocks: the NFB x NB (feature block, query block) accumulator tiles are dealt
+// to the 4 waves as contiguous ranges of the fb-major item list, so every wave issues the same number
+// of MFMAs (within one item) whatever the tile size.  Operands reach LDS by LDS-DMA through a 3-stage
+// ring: two stages are in flight while one is consumed; every wave issues exactly L DMAs per stage (the
+// slot list is padded with dummies) so one counted `s_waitcnt vmcnt(L)` + one raw s_barrier per k-step
+// retires a stage without draining the younger ones.
+template <int NFB, int NB>
+__device__ __forceinline__ void dense_big_body(float4* __restrict__ ldsA, const float4* __restrict__ Wf,
+                                               const float* __restrict__ x_sorted, int64_t relw, int start, int n,
+                                               int fb0, int nfb, int64_t ksteps, int64_t F_pad, int64_t kb, int64_t ke,
+                                               float* __restrict__ zdst /* z_part + slice*Bcap*d_pad16 */, int d_pad16) {
+  constexpr int L = (NFB + NB + 3) / 4;   // DMA slots per wave per stage
+  constexpr int STAGE = 4 * L * 64;       // float4 per ring stage (incl. dummy slots)
+  constexpr int NSTAGE = COPER_DENSE_NSTAGE;
+  constexpr int T = NFB * NB;
+  constexpr int MAXI = (T + 3) / 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int i0 = T * wave / 4, cnt = T * (wave + 1) / 4 - i0;
+
+  // slot s = wave + 4i: s < NFB -> weight fragment fb = s (1 KiB per k-step);
+  //                     s < NFB + NB -> x fragment of query block s - NFB (per-lane gather, 64 B per k-step);
+  //                     else dummy (re-reads slot `wave` into its own ring slot).
+  const char* src[L];
+  int stride[L];
+#pragma unroll
+  for (int i = 0; i < L; ++i) {
+    int sl = wave + 4 * i;
+    if (sl >= NFB + NB) sl = wave;
+    if (sl < NFB) {
+      int fb = fb0 + sl < nfb ? fb0 + sl : nfb - 1;
+      src[i] = (const char*)(Wf + ((relw * nfb + fb) * ksteps + kb) * 64 + lane);
+      stride[i] = 1024;
+    } else {
+      int qi = (sl - NFB) * 16 + (lane & 15);
+      if (qi > n - 1) qi = n - 1;
+      src[i] = (const char*)(x_sorted + (int64_t)(start + qi) * F_pad + 16 * kb + 4 * (lane >> 4));
+      stride[i] = 64;
+    }
+  }
+#ifdef COPER_DBG_DENSE_NO_DMA
+#define DMA_N 1
+#else
+#define DMA_N L
+#endif
+#define STAGE_ISSUE(buf, kk)                                                                                      \
+  {                                                                                                               \
+    float4* dstb = ldsA + (buf)*STAGE;                                                                            \
+    _Pragma("unroll") for (int i = 0; i < DMA_N; ++i) __builtin_amdgcn_global_load_lds(                           \
+        (const __attribute__((address_space(1))) void*)(src[i] + (int64_t)(kk)*stride[i]),                        \
+        (__attribute__((address_space(3))) void*)(dstb + (wave + 4 * i) * 64), 16, 0, 0);                         \
   }
 
-  // cross-wave reduction in fixed order: (w0 + w2) + (w1 + w3)
-  float4* slot = red + (size_t)(wave & 1) * (NFB * NQ * 64);
-  if (wave >= 2) {
+  int offA[MAXI], offB[MAXI];
 #pragma unroll
-    for (int a = 0; a < NFB; ++a)
-#pragma unroll
-      for (int b = 0; b < NQ; ++b)
-        slot[(a * NQ + b) * 64 + lane] = make_float4(acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]);
+  for (int i = 0; i < MAXI; ++i) {
+    int item = cnt > 0 ? i0 + (i < cnt ? i : cnt - 1) : 0;  // a wave short of items recomputes one (discarded)
+    offA[i] = (item / NB) * 64 + lane;
+    offB[i] = (NFB + item % NB) * 64 + lane;
   }
-  __syncthreads();
-  if (wave < 2) {
+  f32x4 acc[MAXI];
 #pragma unroll
-    for (int a = 0; a < NFB; ++a)
+  for (int i = 0; i < MAXI; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (int)(ke - kb);
 #pragma unroll
-      for (int b = 0; b < NQ; ++b) {
-        float4 o = slot[(a * NQ + b) * 64 + lane];
-        acc[a][b][0] += o.x; acc[a][b][1] += o.y; acc[a][b][2] += o.z; acc[a][b][3] += o.w;
-      }
+  for (int st = 0; st < NSTAGE - 1; ++st) STAGE_ISSUE(st, st < nk ? st : nk - 1);
+  int cur = 0, nxt = NSTAGE - 1;
+  for (int k = 0; k < nk; ++k) {
+    // stage k has landed once at most the (NSTAGE-2)*L youngest DMAs (stages k+1..) are outstanding
+#ifdef COPER_DBG_DENSE_NO_DMA
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+    {
+      constexpr int N = (NSTAGE - 2) * L;
+      static_assert(N <= 24, "vmcnt immediate");
+      if (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else if (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else if (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      else if (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+#endif
+    __builtin_amdgcn_s_barrier();  // every wave's share of stage k is in LDS; everyone is done with stage k-1
+    {
+      int kk = k + NSTAGE - 1 < nk ? k + NSTAGE - 1 : nk - 1;  // past the end: harmless re-load into the ring slot nobody reads
+      STAGE_ISSUE(nxt, kk);
+    }
+    const float4* ab = ldsA + cur * STAGE;
+    // groups of GI items: GI independent accumulators between two MFMAs of one chain (the 16x16x4 f32
+    // MFMA issues every 32 cycles but its dependent latency is 40), fragments of a group read together
+    constexpr int GI = COPER_DENSE_GI;
+#pragma unroll
+    for (int g = 0; g < MAXI; g += GI) {
+      float4 av[GI], bv[GI];
+#pragma unroll
+      for (int j = 0; j < GI; ++j)
+        if (g + j < MAXI) { av[j] = ab[offA[g + j]]; bv[j] = ab[offB[g + j]]; }
+#ifdef COPER_DBG_DENSE_NO_MFMA
+#pragma unroll
+      for (int j = 0; j < GI; ++j)
+        if (g + j < MAXI) { acc[g + j][0] += av[j].x * bv[j].x; }
+#else
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < GI; ++j)
+          if (g + j < MAXI)
+            acc[g + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(F4T(av[j], t), F4T(bv[j], t), acc[g + j], 0, 0, 0);
+#endif
+    }
+    cur = cur == NSTAGE - 1 ? 0 : cur + 1;
+    nxt = nxt == NSTAGE - 1 ? 0 : nxt + 1;
   }
-  __syncthreads();
-  if (wave == 1) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may outlive the workgroup's LDS
+#undef STAGE_ISSUE
 #pragma unroll
-    for (int a = 0; a < NFB; ++a)
-#pragma unroll
-      for (int b = 0; b < NQ; ++b)
-        red[(a * NQ + b) * 64 + lane] = make_float4(acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]);
-  }
-  __syncthreads();
-  if (wave == 0) {
-#pragma unroll
-    for (int a = 0; a < NFB; ++a) {
-      if (fb0 + a >= nfb) continue;
-#pragma unroll
-      for (int b = 0; b < NQ; ++b) {
-        float4 o = red[(a * NQ + b) * 64 + lane];
-        int qi = b * 16 + (lane & 15);
-        if (qi < n) {
-          float4 v = make_float4(acc[a][b][0] + o.x, acc[a][b][1] + o.y, acc[a][b][2] + o.z, acc[a][b][3] + o.w);
-          float* dst = z_part + ((int64_t)slice * Bcap + start + qi) * d_pad16 + (fb0 + a) * 16 + 4 * (lane >> 4);
-          *(float4*)dst = v;
-        }
-      }
+  for (int i = 0; i < MAXI; ++i) {
+    if (i >= cnt) continue;
+    int item = i0 + i;
+    int fb = fb0 + item / NB, qb = item % NB;
+    int qi = qb * 16 + (lane & 15);
+    if (fb < nfb && qi < n) {
+      float* dst = zdst + (int64_t)(start + qi) * d_pad16 + fb * 16 + 4 * (lane >> 4);
+      *(float4*)dst = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
     }
   }
+}
+
+template <int NFB>
+__global__ __launch_bounds__(256) void k_dense_big_f32(const float4* __restrict__ Wf,
+                                                       const float* __restrict__ x_sorted,
+                                                       const int32_t* __restrict__ tiles,
+                                                       const int32_t* __restrict__ n_tiles, int64_t cap_small,
+                                                       int nfb, int64_t ksteps, int64_t F_pad, int nslices,
+                                                       int64_t Bcap, int d_pad16, float* __restrict__ z_part) {
+  extern __shared__ float4 ldsA[];  // ring of [4L][64] float4 stages
+  int tile = blockIdx.x;
+  if (tile >= n_tiles[1]) return;
+  const int32_t* tl = tiles + 4 * (cap_small + tile);
+  const int slice = blockIdx.y;
+  const int fb0 = blockIdx.z * NFB;
+  const int64_t relw = __builtin_amdgcn_readfirstlane(tl[0]);
+  const int start = __builtin_amdgcn_readfirstlane(tl[1]);
+  const int n = __builtin_amdgcn_readfirstlane(tl[2]);
+  const int64_t kb = ksteps * slice / nslices, ke = ksteps * (slice + 1) / nslices;
+  float* zdst = z_part + (int64_t)slice * Bcap * d_pad16;
+  const int nb = (n + 15) >> 4;  // 3..8 (tiles hold 33..128 queries)
+#define BODY(NB_) dense_big_body<NFB, NB_>(ldsA, Wf, x_sorted, relw, start, n, fb0, nfb, ksteps, F_pad, kb, ke, zdst, d_pad16)
+  switch (nb) {
+    case 3: BODY(3); break;
+    case 4: BODY(4); break;
+    case 5: BODY(5); break;
+    case 6: BODY(6); break;
+    case 7: BODY(7); break;
+    default: BODY(8); break;
+  }
+#undef BODY
 }
 
 __global__ void k_dense_finalize(const float* __restrict__ z_part, int ksplit, int64_t Bcap, int64_t B, int d,
@@ -308,27 +493,37 @@ __global__ void k_dense_finalize(const float* __restrict__ z_part, int ksplit, i
 }
 
 template <int NFB>
-static void dense_launch(coper_handle* h, int64_t T_max, int ksplit, int zgroups, hipStream_t s) {
+static void dense_launch(coper_handle* h, int64_t B, int nslices, int zgroups, hipStream_t s) {
   const Dims& dm = h->dm;
-  constexpr int NQ = 2;
-  size_t lds = (size_t)2 * NFB * NQ * 64 * sizeof(float4);
-  hipLaunchKernelGGL((k_dense_f32<NFB, NQ>), dim3((unsigned)T_max, (unsigned)ksplit, (unsigned)zgroups), dim3(256),
-                     lds, s, (const float4*)h->Wf, h->x_sorted, h->tiles, h->n_tiles, dm.nfb, dm.F_pad / 16, dm.F_pad,
-                     ksplit, h->ws_queries, dm.d_pad16, h->z_part);
+  int64_t cap_small = small_tile_cap(h);
+  int64_t n_small_max = cap_small - 1 < B ? cap_small - 1 : B;
+  int64_t n_big_max = B / 33 + 1;
+  if (n_small_max > 0)
+    hipLaunchKernelGGL((k_dense_small_f32<NFB>), dim3((unsigned)n_small_max, (unsigned)((nslices + 3) / 4), (unsigned)zgroups),
+                       dim3(256), 0, s, (const float4*)h->Wf, h->x_sorted, h->tiles, h->n_tiles, dm.nfb, dm.F_pad / 16,
+                       dm.F_pad, nslices, h->ws_queries, dm.d_pad16, h->z_part);
+  if (B > 32) {
+    size_t lds = (size_t)COPER_DENSE_NSTAGE * (((NFB + 8 + 3) / 4) * 4) * 64 * sizeof(float4);  // ring, max NB = 8
+    if (!h->dense_attr_done) {
+      (void)hipFuncSetAttribute((const void*)k_dense_big_f32<NFB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      h->dense_attr_done = true;
+    }
+    hipLaunchKernelGGL((k_dense_big_f32<NFB>), dim3((unsigned)n_big_max, (unsigned)nslices, (unsigned)zgroups), dim3(256),
+                       lds, s, (const float4*)h->Wf, h->x_sorted, h->tiles, h->n_tiles, cap_small, dm.nfb, dm.F_pad / 16,
+                       dm.F_pad, nslices, h->ws_queries, dm.d_pad16, h->z_part);
+  }
 }
 
 int launch_dense(coper_handle* h, const int64_t* rel, int64_t B, int tq, int ksplit, float* h_out, hipStream_t s) {
   const Dims& dm = h->dm;
-  int64_t Rk = dm.gen_fc ? dm.R : 1;
-  int64_t T_max = (B + tq - 1) / tq + (Rk < B ? Rk : B);
+  (void)tq;
   {
     ScopedKernelTimer t(h, "dense", s);
     int nfb = dm.nfb;
-    if (nfb == 13) dense_launch<13>(h, T_max, ksplit, 1, s);
-    else if (nfb == 16) dense_launch<16>(h, T_max, ksplit, 1, s);
-    else if (nfb <= 2) dense_launch<2>(h, T_max, ksplit, 1, s);
-    else if (nfb <= 4) dense_launch<4>(h, T_max, ksplit, 1, s);
-    else dense_launch<8>(h, T_max, ksplit, (nfb + 7) / 8, s);
+    if (nfb == 13) dense_launch<13>(h, B, ksplit, 1, s);
+    else if (nfb <= 2) dense_launch<2>(h, B, ksplit, 1, s);
+    else if (nfb <= 4) dense_launch<4>(h, B, ksplit, 1, s);
+    else dense_launch<8>(h, B, ksplit, (nfb + 7) / 8, s);
     COPER_HIP_TRY(h, hipGetLastError());
   }
   const float* fcb = dm.gen_fc ? h->fc_b_rel : h->params["fc_bias"].ptr;

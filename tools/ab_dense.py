@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""A/B timing of the encode kernels for a given build of the library (COPER_HIP_LIB=...)."""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np, torch
+from coper_amd import data as cdata
+from coper_amd.models import ConvE
+name = sys.argv[1] if len(sys.argv) > 1 else "fb15k237_cpg"
+Q = int(sys.argv[2]) if len(sys.argv) > 2 else 20480
+md = cdata.model_descriptors(name)
+p = cdata.synthetic_params(md, 0)
+m = ConvE(md, device="cuda:0").load_parameters(p).prepare()
+q = cdata.synthetic_queries(md, Q, seed=0)
+dq = {k: torch.as_tensor(v).cuda() for k, v in q.items()}
+for _ in range(3):
+    m.encode(dq["e1"], dq["rel"])
+m.profile(True); m.profile_read("dense"); m.profile_read("conv")
+for _ in range(20):
+    m.encode(dq["e1"], dq["rel"])
+torch.cuda.synchronize()
+ms, n = m.profile_read("dense"); ms2, n2 = m.profile_read("conv")
+print("%s: dense avg %.4f ms, conv avg %.4f ms" % (os.environ.get("COPER_HIP_LIB", "default"), ms / n, ms2 / n2))

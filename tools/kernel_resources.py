@@ -6,7 +6,7 @@ CSRC = os.path.join(HERE, "..", "coper_amd", "csrc")
 files = sys.argv[1:] or sorted(f for f in os.listdir(CSRC) if f.startswith("kernels_"))
 for f in files:
     out = subprocess.run(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-c", "-DCOPER_BUILD",
-                          "-Rpass-analysis=kernel-resource-usage", os.path.join(CSRC, f), "-o", "/dev/null"],
+                          "-mllvm", "-amdgpu-mfma-vgpr-form", "-Rpass-analysis=kernel-resource-usage", os.path.join(CSRC, f), "-o", "/dev/null"],
                          capture_output=True, text=True).stderr
     cur = {}
     for line in out.splitlines():
