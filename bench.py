@@ -30,6 +30,20 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: Peak FP
 PEAK_HBM_GBS = 8000.0
 
 
+def pmc_traffic(workload, Q, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (profiles/), collected on
+    this same command in separate --pmc passes; None when no summary matches the workload."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if d.get("workload") == workload and d.get("queries") == Q and kernel in d.get("kernels", {}):
+            return d["kernels"][kernel]["hbm_bytes_per_launch"]
+    return None
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -181,7 +195,8 @@ def main():
             flops = 2.0 * Q * n_local * d          # ALGORITHMIC flops of one score_count launch
             ach = flops / (kern["score_count"] * 1e-3) / 1e12
             out["roofline"] = {"kernel": "k_score_count_f32", "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
-                               "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                               "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                               "traffic": pmc_traffic(args.workload, Q, "coper::k_score_count_f32") if world == 1 else None,
                                "avg_launch_ms": kern["score_count"],
                                "other_kernels_ms": {k: v for k, v in kern.items() if k != "score_count"}}
         if not args.no_cpu_baseline and world == 1:

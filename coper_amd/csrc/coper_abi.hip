@@ -93,9 +93,9 @@ static int ensure_workspace(coper_handle* h, int64_t B, int64_t nnz, hipStream_t
   int64_t cap = B < 64 ? 64 : B;
   int rc;
   const int KSPLIT_MAX = 8;
-  if ((rc = dev_alloc(h, &h->rel_count, dm.R + 2))) return rc;
+  if ((rc = dev_alloc(h, &h->rel_count, 2 * (dm.R + 2)))) return rc;  // counts | cursors: one memset
+  h->rel_cursor = h->rel_count + (dm.R + 2);
   if ((rc = dev_alloc(h, &h->rel_offset, dm.R + 2))) return rc;
-  if ((rc = dev_alloc(h, &h->rel_cursor, dm.R + 2))) return rc;
   if ((rc = dev_alloc(h, &h->perm, cap))) return rc;
   if ((rc = dev_alloc(h, &h->tiles, 4 * (cap / 32 + dm.R + 4)))) return rc;
   if ((rc = dev_alloc(h, &h->n_tiles, 4))) return rc;
@@ -210,9 +210,9 @@ COPER_API void coper_destroy(coper_handle* h) {
   dev_free(&h->conv_scale); dev_free(&h->conv_shift); dev_free(&h->fc_scale); dev_free(&h->fc_shift);
   dev_free(&h->conv_w_rel); dev_free(&h->conv_b_rel); dev_free(&h->fc_b_rel); dev_free(&h->Wf);
   dev_free(&h->Ef); dev_free(&h->bias_pad); dev_free(&h->ctx_tmp[0]); dev_free(&h->ctx_tmp[1]);
-  dev_free(&h->rel_count); dev_free(&h->rel_offset); dev_free(&h->rel_cursor); dev_free(&h->perm);
+  dev_free(&h->rel_count); dev_free(&h->rel_offset); h->rel_cursor = nullptr; dev_free(&h->perm);
   dev_free(&h->tiles); dev_free(&h->n_tiles); dev_free(&h->blk_off); dev_free(&h->x_sorted); dev_free(&h->z_part);
-  dev_free(&h->tgt_ws); dev_free(&h->cnt_ws); dev_free(&h->hfrag_ws);
+  dev_free(&h->tgt_ws); dev_free(&h->cnt_ws); dev_free(&h->hfrag_ws); dev_free(&h->logits_ws);
   for (auto& kv : h->timers)
     for (auto& p : kv.second.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   delete h;
@@ -445,15 +445,26 @@ COPER_API int coper_rank_counts(coper_handle* h, const float* hvec, const float*
   if (!hvec || !tgt || !e2 || !filt_indptr || !n_greater || !n_equal || B < 0 || filt_nnz < 0 ||
       (filt_nnz > 0 && !filt_idx))
     return fail(h, COPER_EINVAL, "coper_rank_counts: bad argument");
-  if (k != 0) return fail(h, COPER_EUNSUPPORTED, "coper_rank_counts: top-k (k > 0) is not built in this version");
-  (void)topk_val; (void)topk_idx;
+  if (k < 0 || k > 1024 || (k > 0 && (!topk_val || !topk_idx)))
+    return fail(h, COPER_EINVAL, "coper_rank_counts: bad top-k arguments (0 <= k <= 1024)");
   hipStream_t s = (hipStream_t)stream;
   int rc;
   if ((rc = ensure_workspace(h, B, filt_nnz, s))) return rc;
-  COPER_HIP_TRY(h, hipMemsetAsync(n_greater, 0, sizeof(int32_t) * B, s));
-  COPER_HIP_TRY(h, hipMemsetAsync(n_equal, 0, sizeof(int32_t) * B, s));
   if ((rc = launch_score_count(h, hvec, tgt, B, n_greater, n_equal, s))) return rc;
-  return launch_filter_correct(h, hvec, tgt, e2, filt_indptr, filt_idx, filt_nnz, B, n_greater, n_equal, s);
+  if ((rc = launch_filter_correct(h, hvec, tgt, e2, filt_indptr, filt_idx, filt_nnz, B, n_greater, n_equal, s))) return rc;
+  if (k > 0) {
+    // logits workspace: at most 256 MiB (or one row) at a time
+    int64_t rows = (int64_t)(256ll << 20) / (h->dm.n_local * 4);
+    if (rows < 1) rows = 1;
+    if (rows > B) rows = B;
+    if (rows > h->logits_ws_rows) {
+      COPER_HIP_TRY(h, hipStreamSynchronize(s));
+      if ((rc = dev_alloc(h, &h->logits_ws, (size_t)rows * h->dm.n_local))) return rc;
+      h->logits_ws_rows = rows;
+    }
+    return launch_topk(h, hvec, e2, filt_indptr, filt_idx, B, k, topk_val, topk_idx, h->logits_ws, h->logits_ws_rows, s);
+  }
+  return COPER_OK;
 }
 
 COPER_API int coper_rank(coper_handle* h, const float* hvec, const int64_t* e2, const int64_t* filt_indptr,

@@ -87,6 +87,8 @@ struct coper_handle {
   float* z_part = nullptr;        // [ksplit, B, d_pad16]
   float* tgt_ws = nullptr;        // [B]
   int32_t* cnt_ws = nullptr;      // [2B]
+  float* logits_ws = nullptr;     // top-k path only: [chunk_rows, n_local]
+  int64_t logits_ws_rows = 0;
   float* hfrag_ws = nullptr;      // h re-packed in MFMA-fragment order [ceil(B/128)*4][KS][64] float4
   int num_cus = 256;
   bool dense_attr_done = false;
@@ -138,6 +140,9 @@ int launch_score_lookup(coper_handle* h, const float* hvec, const int32_t* looku
                         hipStream_t s);
 int launch_finish_ranks(coper_handle* h, const int32_t* ng, int64_t B, int32_t* ranks, hipStream_t s);
 int score_kernels_init(coper_handle* h);
+int launch_topk(coper_handle* h, const float* hvec, const int64_t* e2, const int64_t* indptr, const int64_t* idx,
+                int64_t B, int k, float* topk_val, int64_t* topk_idx, float* logits_ws, int64_t chunk_rows,
+                hipStream_t s);
 
 // profiling helpers (hipEvents on the launch stream)
 struct ScopedKernelTimer {

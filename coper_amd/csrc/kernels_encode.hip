@@ -21,13 +21,31 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // ------------------------------------------------------------------------------------------------
 // grouping
 // ------------------------------------------------------------------------------------------------
-__global__ void k_rel_hist(const int64_t* __restrict__ rel, int64_t B, int use_rel, int64_t R,
-                           int32_t* __restrict__ count, int32_t* __restrict__ bad) {
-  int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
-  int64_t key = use_rel ? rel[b] : 0;
-  if (key < 0 || key >= R) { atomicAdd(bad, 1); key = 0; }  // clamped, and reported by coper_check_ids
-  atomicAdd(&count[key], 1);
+// LDS-privatised when the relation table fits (R <= 8192): one global atomic per (block, relation present)
+// instead of one per query on a few hundred hot counters.
+constexpr int HIST_LDS_MAX = 8192;
+constexpr int HIST_BLOCK = 1024;
+
+__global__ __launch_bounds__(HIST_BLOCK) void k_rel_hist(const int64_t* __restrict__ rel, int64_t B, int use_rel,
+                                                          int64_t R, int32_t* __restrict__ count,
+                                                          int32_t* __restrict__ bad) {
+  extern __shared__ int32_t sh[];
+  const bool priv = R <= HIST_LDS_MAX;
+  if (priv) {
+    for (int k = threadIdx.x; k < R; k += HIST_BLOCK) sh[k] = 0;
+    __syncthreads();
+  }
+  int64_t b = (int64_t)blockIdx.x * HIST_BLOCK + threadIdx.x;
+  if (b < B) {
+    int64_t key = use_rel ? rel[b] : 0;
+    if (key < 0 || key >= R) { atomicAdd(bad, 1); key = 0; }  // clamped, and reported by coper_check_ids
+    if (priv) atomicAdd(&sh[key], 1); else atomicAdd(&count[key], 1);
+  }
+  if (priv) {
+    __syncthreads();
+    for (int k = threadIdx.x; k < R; k += HIST_BLOCK)
+      if (sh[k]) atomicAdd(&count[k], sh[k]);
+  }
 }
 
 // single block: exclusive scan of the counts -> offsets, and the two tile lists:
@@ -109,15 +127,33 @@ __global__ __launch_bounds__(1024) void k_rel_scan_tiles(const int32_t* __restri
   }
 }
 
-__global__ void k_rel_scatter(const int64_t* __restrict__ rel, int64_t B, int use_rel, int64_t R,
-                              const int32_t* __restrict__ offset, int32_t* __restrict__ cursor,
-                              int32_t* __restrict__ perm) {
-  int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
-  int64_t key = use_rel ? rel[b] : 0;
-  if (key < 0 || key >= R) key = 0;
-  int pos = atomicAdd(&cursor[key], 1);
-  perm[offset[key] + pos] = (int32_t)b;
+__global__ __launch_bounds__(HIST_BLOCK) void k_rel_scatter(const int64_t* __restrict__ rel, int64_t B, int use_rel,
+                                                             int64_t R, const int32_t* __restrict__ offset,
+                                                             int32_t* __restrict__ cursor,
+                                                             int32_t* __restrict__ perm) {
+  extern __shared__ int32_t sh[];  // [R] block counts, then block bases
+  const bool priv = R <= HIST_LDS_MAX;
+  int64_t b = (int64_t)blockIdx.x * HIST_BLOCK + threadIdx.x;
+  int64_t key = 0;
+  if (b < B) {
+    key = use_rel ? rel[b] : 0;
+    if (key < 0 || key >= R) key = 0;
+  }
+  if (!priv) {
+    if (b < B) perm[offset[key] + atomicAdd(&cursor[key], 1)] = (int32_t)b;
+    return;
+  }
+  for (int k = threadIdx.x; k < R; k += HIST_BLOCK) sh[k] = 0;
+  __syncthreads();
+  int local = 0;
+  if (b < B) local = atomicAdd(&sh[key], 1);           // rank inside the block
+  __syncthreads();
+  for (int k = threadIdx.x; k < R; k += HIST_BLOCK) {   // reserve the block's range per relation
+    int c = sh[k];
+    sh[k] = c ? atomicAdd(&cursor[k], c) : 0;
+  }
+  __syncthreads();
+  if (b < B) perm[offset[key] + sh[key] + local] = (int32_t)b;
 }
 
 // capacity of the small-tile list (one tile per relation key at most); the big list follows it
@@ -126,16 +162,16 @@ static int64_t small_tile_cap(const coper_handle* h) { return (h->dm.gen_fc ? h-
 int launch_group_by_relation(coper_handle* h, const int64_t* rel, int64_t B, int tq, hipStream_t s) {
   const Dims& dm = h->dm;
   int64_t R = dm.gen_fc ? dm.R : 1;
-  COPER_HIP_TRY(h, hipMemsetAsync(h->rel_count, 0, sizeof(int32_t) * (dm.R + 2), s));
-  COPER_HIP_TRY(h, hipMemsetAsync(h->rel_cursor, 0, sizeof(int32_t) * (dm.R + 1), s));
-  unsigned nb = (unsigned)((B + 255) / 256);
+  COPER_HIP_TRY(h, hipMemsetAsync(h->rel_count, 0, sizeof(int32_t) * 2 * (dm.R + 2), s));  // counts | cursors
+  unsigned nb = (unsigned)((B + HIST_BLOCK - 1) / HIST_BLOCK);
+  size_t hl = R <= HIST_LDS_MAX ? sizeof(int32_t) * (size_t)R : 0;
   // rel_count[R+1] doubles as the out-of-range counter (ids are validated on device, never trusted)
-  hipLaunchKernelGGL(k_rel_hist, dim3(nb), dim3(256), 0, s, rel, B, dm.gen_fc ? 1 : 0, R, h->rel_count,
+  hipLaunchKernelGGL(k_rel_hist, dim3(nb), dim3(HIST_BLOCK), hl, s, rel, B, dm.gen_fc ? 1 : 0, R, h->rel_count,
                      h->rel_count + dm.R + 1);
   (void)tq;
   hipLaunchKernelGGL(k_rel_scan_tiles, dim3(1), dim3(1024), 0, s, h->rel_count, R, small_tile_cap(h), h->rel_offset,
                      h->tiles, h->n_tiles);
-  hipLaunchKernelGGL(k_rel_scatter, dim3(nb), dim3(256), 0, s, rel, B, dm.gen_fc ? 1 : 0, R, h->rel_offset,
+  hipLaunchKernelGGL(k_rel_scatter, dim3(nb), dim3(HIST_BLOCK), hl, s, rel, B, dm.gen_fc ? 1 : 0, R, h->rel_offset,
                      h->rel_cursor, h->perm);
   COPER_HIP_TRY(h, hipGetLastError());
   return COPER_OK;
@@ -197,19 +233,127 @@ __global__ __launch_bounds__(256) void k_conv_bn_relu(
   for (int64_t k = F + threadIdx.x; k < F_pad; k += 256) xo[k] = 0.f;
 }
 
+// 3x3 filters, C a multiple of 32 (every shipped config): lane = (channel c = lane&31, row half = lane>>5),
+// the 4 waves of a workgroup take 8 output rows per sweep; each lane slides a 3x3 register window along its
+// row (3 LDS reads -- broadcast across the 32 channels -- and 9 FMAs per output), taps/bias/BN in registers;
+// a wave-store is two 128-B runs of x.  QPB queries per workgroup amortise the tap loads.
+template <int QPB>
+__global__ __launch_bounds__(256) void k_conv3x3_bn_relu(
+    const int64_t* __restrict__ e1, const int64_t* __restrict__ rel, const float* __restrict__ e1_rows,
+    const int32_t* __restrict__ perm, const float* __restrict__ ent, int64_t shard_lo, int64_t n_local,
+    const float* __restrict__ rel_emb, const float* __restrict__ conv_w, const float* __restrict__ conv_b,
+    int per_rel_conv, const float* __restrict__ scale, const float* __restrict__ shift, int d, int r, int in_h,
+    int in_w, int stacked, int C, int Ho, int Wo, int concat_rel, int64_t F, int64_t F_pad, int64_t R, int64_t B,
+    float* __restrict__ x_sorted) {
+  extern __shared__ float lds[];  // img[QPB][in_h*in_w]
+  const int img_sz = in_h * in_w;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int cl = lane & 31, hf = lane >> 5;
+  const int64_t pos0 = (int64_t)blockIdx.x * QPB;
+  int64_t rids[QPB];
+#pragma unroll
+  for (int qq = 0; qq < QPB; ++qq) {
+    int64_t pos = pos0 + qq;
+    rids[qq] = 0;
+    if (pos >= B) continue;
+    int64_t q = perm[pos];
+    int64_t rid = rel[q];
+    if (rid < 0 || rid >= R) rid = 0;
+    rids[qq] = rid;
+    float* img = lds + qq * img_sz;
+    for (int k = threadIdx.x; k < d; k += 256) {
+      float v;
+      if (e1_rows) {
+        v = e1_rows[q * d + k];
+      } else {
+        int64_t row = e1[q] - shard_lo;
+        v = (row >= 0 && row < n_local) ? ent[row * d + k] : 0.f;
+      }
+      img[k] = v;
+    }
+    if (stacked)
+      for (int k = threadIdx.x; k < r; k += 256) img[d + k] = rel_emb[rid * r + k];
+  }
+  __syncthreads();
+  for (int c0 = 0; c0 < C; c0 += 32) {
+    const int c = c0 + cl;
+    float tap[9], kb = 0.f;
+    const float sc = scale[c], sh = shift[c];
+    int64_t tap_rid = -1;
+#pragma unroll
+    for (int qq = 0; qq < QPB; ++qq) {
+      int64_t pos = pos0 + qq;
+      if (pos >= B) break;
+      const int64_t rid = per_rel_conv ? rids[qq] : 0;
+      if (rid != tap_rid) {  // workgroup-uniform
+        const float* wsrc = per_rel_conv ? conv_w + rid * (int64_t)(9 * C) : conv_w;
+        const float* bsrc = per_rel_conv ? conv_b + rid * (int64_t)C : conv_b;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) tap[k] = wsrc[k * C + c];
+        kb = bsrc[c];
+        tap_rid = rid;
+      }
+      const float* img = lds + qq * img_sz;
+      float* xo = x_sorted + pos * F_pad;
+      for (int i0 = 0; i0 < Ho; i0 += 8) {
+        const int i = i0 + 2 * wave + hf;
+        if (i < Ho) {
+          const float* r0 = img + i * in_w;
+          const float* r1 = r0 + in_w;
+          const float* r2 = r1 + in_w;
+          float w00 = r0[0], w01 = r0[1], w10 = r1[0], w11 = r1[1], w20 = r2[0], w21 = r2[1];
+          float* dst = xo + (int64_t)i * Wo * C + c;
+          for (int j = 0; j < Wo; ++j) {
+            float w02 = r0[j + 2], w12 = r1[j + 2], w22 = r2[j + 2];
+            float y = 0.f;
+            y = fmaf(w00, tap[0], y); y = fmaf(w01, tap[1], y); y = fmaf(w02, tap[2], y);
+            y = fmaf(w10, tap[3], y); y = fmaf(w11, tap[4], y); y = fmaf(w12, tap[5], y);
+            y = fmaf(w20, tap[6], y); y = fmaf(w21, tap[7], y); y = fmaf(w22, tap[8], y);
+            y += kb;
+            y = fmaf(y, sc, sh);
+            dst[(int64_t)j * C] = fmaxf(y, 0.f);
+            w00 = w01; w01 = w02; w10 = w11; w11 = w12; w20 = w21; w21 = w22;
+          }
+        }
+      }
+    }
+  }
+  // tail of each row: concat_rel columns and the zero padding up to F_pad
+#pragma unroll
+  for (int qq = 0; qq < QPB; ++qq) {
+    int64_t pos = pos0 + qq;
+    if (pos >= B) break;
+    float* xo = x_sorted + pos * F_pad;
+    int64_t Fc = (int64_t)Ho * Wo * C;
+    if (concat_rel)
+      for (int k = threadIdx.x; k < r; k += 256) xo[Fc + k] = rel_emb[rids[qq] * r + k];
+    for (int64_t k = F + threadIdx.x; k < F_pad; k += 256) xo[k] = 0.f;
+  }
+}
+
 int launch_conv(coper_handle* h, const int64_t* e1, const int64_t* rel, const float* e1_rows, int64_t B,
                 hipStream_t s) {
   const Dims& dm = h->dm;
   const float* rel_emb = dm.lookup ? nullptr : h->params["rel_emb"].ptr;
   const float* cw = dm.gen_conv ? h->conv_w_rel : h->params["conv1_weights"].ptr;
   const float* cb = dm.gen_conv ? h->conv_b_rel : h->params["conv1_bias"].ptr;
-  size_t lds = sizeof(float) * ((size_t)dm.in_h * dm.in_w + (size_t)dm.fh * dm.fw * dm.C + 3 * (size_t)dm.C);
   ScopedKernelTimer t(h, "conv", s);
-  hipLaunchKernelGGL(k_conv_bn_relu, dim3((unsigned)B), dim3(256), lds, s, e1, rel, e1_rows, h->perm,
-                     h->params["ent_emb"].ptr, (int64_t)h->cfg.shard_lo, dm.n_local, rel_emb, cw, cb,
-                     dm.gen_conv ? 1 : 0, h->conv_scale, h->conv_shift, dm.d, dm.r, dm.emb_w, dm.in_h, dm.in_w,
-                     dm.stacked ? 1 : 0, dm.fh, dm.fw, dm.C, dm.Ho, dm.Wo, dm.concat_rel ? 1 : 0, dm.F, dm.F_pad,
-                     dm.R, h->x_sorted);
+  if (dm.fh == 3 && dm.fw == 3 && dm.C % 32 == 0) {
+    constexpr int QPB = 4;
+    size_t lds = sizeof(float) * (size_t)QPB * dm.in_h * dm.in_w;
+    hipLaunchKernelGGL((k_conv3x3_bn_relu<QPB>), dim3((unsigned)((B + QPB - 1) / QPB)), dim3(256), lds, s, e1, rel,
+                       e1_rows, h->perm, h->params["ent_emb"].ptr, (int64_t)h->cfg.shard_lo, dm.n_local, rel_emb, cw, cb,
+                       dm.gen_conv ? 1 : 0, h->conv_scale, h->conv_shift, dm.d, dm.r, dm.in_h, dm.in_w,
+                       dm.stacked ? 1 : 0, dm.C, dm.Ho, dm.Wo, dm.concat_rel ? 1 : 0, dm.F, dm.F_pad, dm.R, B,
+                       h->x_sorted);
+  } else {
+    size_t lds = sizeof(float) * ((size_t)dm.in_h * dm.in_w + (size_t)dm.fh * dm.fw * dm.C + 3 * (size_t)dm.C);
+    hipLaunchKernelGGL(k_conv_bn_relu, dim3((unsigned)B), dim3(256), lds, s, e1, rel, e1_rows, h->perm,
+                       h->params["ent_emb"].ptr, (int64_t)h->cfg.shard_lo, dm.n_local, rel_emb, cw, cb,
+                       dm.gen_conv ? 1 : 0, h->conv_scale, h->conv_shift, dm.d, dm.r, dm.emb_w, dm.in_h, dm.in_w,
+                       dm.stacked ? 1 : 0, dm.fh, dm.fw, dm.C, dm.Ho, dm.Wo, dm.concat_rel ? 1 : 0, dm.F, dm.F_pad,
+                       dm.R, h->x_sorted);
+  }
   COPER_HIP_TRY(h, hipGetLastError());
   return COPER_OK;
 }

@@ -59,8 +59,9 @@ constexpr int SC_NQ = 4;      // 32-query blocks per workgroup tile
 constexpr int SC_WAVES = 8;   // entity blocks per unit
 
 __global__ void k_pack_h(const float* __restrict__ hvec, int64_t B, int d, int KS, float4* __restrict__ hfrag,
-                         int64_t total) {
+                         int64_t total, int32_t* __restrict__ ng, int32_t* __restrict__ ne) {
   int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // ((qtile*NQ + qb)*KS + ks)*64 + l
+  if (j < B) { ng[j] = 0; ne[j] = 0; }  // the count buffers start from zero (saves two memset nodes)
   if (j >= total) return;
   int l = (int)(j & 63);
   int64_t rest = j >> 6;
@@ -206,7 +207,7 @@ int launch_score_count(coper_handle* h, const float* hvec, const float* tgt, int
   int64_t units = q_tiles * iters;
   int64_t total = q_tiles * SC_NQ * dm.KS * 64;
   hipLaunchKernelGGL(k_pack_h, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, hvec, B, dm.d, dm.KS,
-                     (float4*)h->hfrag_ws, total);
+                     (float4*)h->hfrag_ws, total, ng, ne);
   int64_t grid = h->num_cus;
   if (grid > units) grid = units;
   size_t lds = (size_t)SC_NQ * dm.KS * 64 * sizeof(float4);
@@ -296,9 +297,25 @@ int launch_score_all(coper_handle* h, const float* hvec, int64_t B, float* logit
 // ------------------------------------------------------------------------------------------------
 // VALU pair scores: the same chain on (query, entity) pairs picked by index.
 // ------------------------------------------------------------------------------------------------
+// The chain of the file header on one (entity row, query row) pair.  d % 8 == 0 (every BASELINE config):
+// two 16-B loads per operand per k-step, issued a few k-steps ahead of the dependent fma chain.
 __device__ __forceinline__ float chain_score(const float* __restrict__ erow, const float* __restrict__ hrow,
                                              float bias, int d) {
   float s = bias;
+  if ((d & 7) == 0) {
+    const float4* e4 = (const float4*)erow;
+    const float4* h4 = (const float4*)hrow;
+    const int KS = d >> 3;
+#pragma unroll 5
+    for (int ks = 0; ks < KS; ++ks) {
+      float4 a0 = e4[2 * ks], a1 = e4[2 * ks + 1], b0 = h4[2 * ks], b1 = h4[2 * ks + 1];
+      s = fmaf(a0.x, b0.x, s); s = fmaf(a1.x, b1.x, s);
+      s = fmaf(a0.y, b0.y, s); s = fmaf(a1.y, b1.y, s);
+      s = fmaf(a0.z, b0.z, s); s = fmaf(a1.z, b1.z, s);
+      s = fmaf(a0.w, b0.w, s); s = fmaf(a1.w, b1.w, s);
+    }
+    return s;
+  }
   int KS = (d + 7) >> 3;
   for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
@@ -329,46 +346,54 @@ int launch_pair_targets(coper_handle* h, const float* hvec, const int64_t* e2, i
   return COPER_OK;
 }
 
-// thread i < nnz: filter entry i;  thread nnz + b: the target of query b.
+// 16 lanes per query walk its CSR filter list (coalesced id reads, no row search); lane 0 of the group
+// also retires the target itself, which scored == tgt by construction and was counted as "equal".
 __global__ void k_filter_correct(const float* __restrict__ ent, const float* __restrict__ bias,
                                  const float* __restrict__ hvec, const float* __restrict__ tgt,
                                  const int64_t* __restrict__ e2, const int64_t* __restrict__ indptr,
                                  const int64_t* __restrict__ idx, int64_t B, int d, int64_t lo, int64_t n_local,
                                  int32_t* __restrict__ ng, int32_t* __restrict__ ne) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  int64_t nnz = indptr[B];
-  if (i >= nnz + B) return;
-  if (i >= nnz) {  // the target scores == tgt by construction and was counted as "equal"
-    int64_t b = i - nnz;
-    int64_t row = e2[b] - lo;
-    float t = tgt[b];
+  int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t b = gid >> 4;
+  int sub = (int)(gid & 15);
+  if (b >= B) return;
+  const float t = tgt[b];
+  const int64_t target = e2[b];
+  if (sub == 0) {
+    int64_t row = target - lo;
     if (row >= 0 && row < n_local && t == t) atomicSub(&ne[b], 1);
-    return;
   }
-  // largest b with indptr[b] <= i
-  int64_t lo_b = 0, hi_b = B;
-  while (hi_b - lo_b > 1) {
-    int64_t mid = (lo_b + hi_b) >> 1;
-    if (indptr[mid] <= i) lo_b = mid; else hi_b = mid;
+  const int64_t beg = indptr[b], end = indptr[b + 1];
+  int dg = 0, de = 0;
+  for (int64_t i = beg + sub; i < end; i += 16) {
+    int64_t f = idx[i];
+    if (i > beg && idx[i - 1] == f) continue;  // adjacent duplicate: the dense mask is idempotent
+    if (f == target) continue;                 // the target is restored after masking (metrics.py:46)
+    int64_t row = f - lo;
+    if (row < 0 || row >= n_local) continue;
+    float s = chain_score(ent + row * d, hvec + b * d, bias[row], d);
+    dg += s > t ? 1 : 0;
+    de += s == t ? 1 : 0;
   }
-  int64_t b = lo_b;
-  int64_t f = idx[i];
-  if (i > indptr[b] && idx[i - 1] == f) return;  // adjacent duplicate: the dense mask is idempotent
-  if (f == e2[b]) return;                        // the target is restored after masking (metrics.py:46)
-  int64_t row = f - lo;
-  if (row < 0 || row >= n_local) return;
-  float s = chain_score(ent + row * d, hvec + b * d, bias[row], d);
-  float t = tgt[b];
-  if (s > t) atomicSub(&ng[b], 1);
-  else if (s == t) atomicSub(&ne[b], 1);
+  // reduce over the 16-lane group
+#pragma unroll
+  for (int m = 8; m >= 1; m >>= 1) {
+    dg += __shfl_xor(dg, m);
+    de += __shfl_xor(de, m);
+  }
+  if (sub == 0) {
+    if (dg) atomicSub(&ng[b], dg);
+    if (de) atomicSub(&ne[b], de);
+  }
 }
 
 int launch_filter_correct(coper_handle* h, const float* hvec, const float* tgt, const int64_t* e2,
                           const int64_t* indptr, const int64_t* idx, int64_t nnz, int64_t B, int32_t* ng,
                           int32_t* ne, hipStream_t s) {
   const Dims& dm = h->dm;
-  int64_t bound = nnz + B;  // the kernel re-reads nnz = indptr[B] on the device and trusts that
-  hipLaunchKernelGGL(k_filter_correct, dim3((unsigned)((bound + 255) / 256)), dim3(256), 0, s,
+  (void)nnz;
+  int64_t threads = B * 16;
+  hipLaunchKernelGGL(k_filter_correct, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s,
                      h->params["ent_emb"].ptr, h->params["pred_bias"].ptr, hvec, tgt, e2, indptr, idx, B, dm.d,
                      (int64_t)h->cfg.shard_lo, dm.n_local, ng, ne);
   COPER_HIP_TRY(h, hipGetLastError());
@@ -393,6 +418,87 @@ int launch_score_lookup(coper_handle* h, const float* hvec, const int32_t* looku
                      h->params["ent_emb"].ptr, h->params["pred_bias"].ptr, hvec, lookup, B, L, dm.d,
                      (int64_t)h->cfg.shard_lo, dm.n_local, out);
   COPER_HIP_TRY(h, hipGetLastError());
+  return COPER_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// top-k of the filtered row (optional output of coper_rank_counts, k > 0): logits of a chunk of queries
+// are materialised by k_score_all_f32 into a workspace, known answers other than the target are set to
+// -inf (metrics.py:45-46 in sparse form), then k rounds of a block-wide arg-max per row pick the
+// candidates in (score desc, id asc) order.  Not on the ranking hot path: ranks never need it.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_mask_filtered(float* __restrict__ logits, int64_t ld, const int64_t* __restrict__ e2,
+                                const int64_t* __restrict__ indptr, const int64_t* __restrict__ idx, int64_t b0,
+                                int64_t nb, int64_t lo, int64_t n_local) {
+  int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t bl = gid >> 4;
+  int sub = (int)(gid & 15);
+  if (bl >= nb) return;
+  int64_t b = b0 + bl;
+  const int64_t target = e2[b];
+  for (int64_t i = indptr[b] + sub; i < indptr[b + 1]; i += 16) {
+    int64_t f = idx[i];
+    int64_t row = f - lo;
+    if (f == target || row < 0 || row >= n_local) continue;
+    logits[bl * ld + row] = -INFINITY;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_topk_select(float* __restrict__ logits, int64_t ld, int64_t n_local,
+                                                     int64_t lo, int k, float* __restrict__ out_val,
+                                                     int64_t* __restrict__ out_idx, int64_t b0) {
+  __shared__ float s_val[256];
+  __shared__ int s_idx[256];
+  float* row = logits + (int64_t)blockIdx.x * ld;
+  int64_t b = b0 + blockIdx.x;
+  for (int round = 0; round < k; ++round) {
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int64_t j = threadIdx.x; j < n_local; j += 256) {
+      float v = row[j];
+      if (v > best || (v == best && v > -INFINITY && (int)j < bi)) { best = v; bi = (int)j; }
+    }
+    s_val[threadIdx.x] = best;
+    s_idx[threadIdx.x] = bi;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+      if ((int)threadIdx.x < off) {
+        float v2 = s_val[threadIdx.x + off];
+        int i2 = s_idx[threadIdx.x + off];
+        if (v2 > s_val[threadIdx.x] || (v2 == s_val[threadIdx.x] && i2 < s_idx[threadIdx.x])) {
+          s_val[threadIdx.x] = v2;
+          s_idx[threadIdx.x] = i2;
+        }
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      float v = s_val[0];
+      int i = s_idx[0];
+      bool ok = i != 0x7fffffff && v > -INFINITY;
+      out_val[b * k + round] = ok ? v : -INFINITY;
+      out_idx[b * k + round] = ok ? lo + i : -1;
+      if (ok) row[i] = -INFINITY;  // taken
+    }
+    __syncthreads();
+  }
+}
+
+int launch_topk(coper_handle* h, const float* hvec, const int64_t* e2, const int64_t* indptr, const int64_t* idx,
+                int64_t B, int k, float* topk_val, int64_t* topk_idx, float* logits_ws, int64_t chunk_rows,
+                hipStream_t s) {
+  const Dims& dm = h->dm;
+  for (int64_t b0 = 0; b0 < B; b0 += chunk_rows) {
+    int64_t nb = B - b0 < chunk_rows ? B - b0 : chunk_rows;
+    int rc = launch_score_all(h, hvec + b0 * dm.d, nb, logits_ws, dm.n_local, s);
+    if (rc) return rc;
+    int64_t threads = nb * 16;
+    hipLaunchKernelGGL(k_mask_filtered, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, logits_ws, dm.n_local,
+                       e2, indptr, idx, b0, nb, (int64_t)h->cfg.shard_lo, dm.n_local);
+    hipLaunchKernelGGL(k_topk_select, dim3((unsigned)nb), dim3(256), 0, s, logits_ws, dm.n_local, dm.n_local,
+                       (int64_t)h->cfg.shard_lo, k, topk_val, topk_idx, b0);
+    COPER_HIP_TRY(h, hipGetLastError());
+  }
   return COPER_OK;
 }
 

@@ -233,16 +233,21 @@ class ConvE(object):
         _lib.check(self._h, self._lib.coper_target_scores(self._h, _ptr(h), _ptr(e2), e2.numel(), _ptr(out), self._stream()))
         return out
 
-    def rank_counts(self, h, tgt, e2, filt_indptr, filt_idx, filt_nnz=None):
-        """(n_greater, n_equal) int32 [B] over this shard (metrics.py:44-50 without logits)."""
+    def rank_counts(self, h, tgt, e2, filt_indptr, filt_idx, filt_nnz=None, k=0):
+        """(n_greater, n_equal) int32 [B] over this shard (metrics.py:44-50 without logits); with k > 0 also
+        the shard's top-k of the filtered row: (..., topk_val f32 [B,k], topk_idx int64 [B,k] global ids)."""
         self._need_prepared()
         e2, ip, ix = self._ids(e2), self._ids(filt_indptr), self._ids(filt_idx)
         B = e2.numel()
         nnz = int(ix.numel()) if filt_nnz is None else int(filt_nnz)
         ng = torch.empty((B,), device=self.device, dtype=torch.int32)
         ne = torch.empty((B,), device=self.device, dtype=torch.int32)
-        _lib.check(self._h, self._lib.coper_rank_counts(self._h, _ptr(h), _ptr(tgt), _ptr(e2), _ptr(ip), _ptr(ix), nnz, B, 0,
-                                                        _ptr(ng), _ptr(ne), None, None, self._stream()))
+        tv = torch.empty((B, k), device=self.device, dtype=torch.float32) if k > 0 else None
+        ti = torch.empty((B, k), device=self.device, dtype=torch.int64) if k > 0 else None
+        _lib.check(self._h, self._lib.coper_rank_counts(self._h, _ptr(h), _ptr(tgt), _ptr(e2), _ptr(ip), _ptr(ix), nnz, B, int(k),
+                                                        _ptr(ng), _ptr(ne), _ptr(tv), _ptr(ti), self._stream()))
+        if k > 0:
+            return ng, ne, tv, ti
         return ng, ne
 
     def rank(self, h, e2, filt_indptr, filt_idx, filt_nnz=None):

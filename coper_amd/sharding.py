@@ -28,7 +28,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-__all__ = ["local_rank_pass", "QueryShardedEvaluator", "EntityShardedRanker", "shard_bounds"]
+__all__ = ["local_rank_pass", "QueryShardedEvaluator", "EntityShardedRanker", "shard_bounds", "merge_topk"]
 
 
 def shard_bounds(num_ent: int, world: int, rank: int):
@@ -112,15 +112,44 @@ class EntityShardedRanker(object):
             h.index_copy_(0, sel, h_loc)
         return self._allreduce(h)
 
-    def rank(self, chunk):
+    def rank(self, chunk, k=0):
+        """Returns (ranks, n_equal) int32 [B]; with k > 0 also the global top-k of the filtered rows
+        (topk_val f32 [B,k], topk_idx int64 [B,k]), merged from the per-shard top-k in (score desc, id asc) order."""
         sc = self.scorer
         h = self.encode(chunk["e1"], chunk["rel"])
         tgt = self._allreduce(sc.target_scores(h, chunk["e2"]))                  # step 3
-        ng, ne = sc.rank_counts(h, tgt, chunk["e2"], chunk["filt_indptr"], chunk["filt_idx"],
-                                filt_nnz=len(chunk["filt_idx"]))
-        rec = torch.stack([ng, ne], dim=1).contiguous()                          # step 4: packed per-shard record
+        out = sc.rank_counts(h, tgt, chunk["e2"], chunk["filt_indptr"], chunk["filt_idx"],
+                             filt_nnz=len(chunk["filt_idx"]), k=k)
+        ng, ne = out[0], out[1]
+        # step 4: ONE all-gather of the packed per-shard record: [ng<<32 | ne, k score bit patterns, k ids]
+        B = ng.shape[0]
+        rec = torch.empty((B, 1 + 2 * k), dtype=torch.int64, device=ng.device)
+        rec[:, 0] = (ng.to(torch.int64) << 32) | ne.to(torch.int64)
+        if k > 0:
+            rec[:, 1:1 + k] = out[2].contiguous().view(torch.int32).to(torch.int64)
+            rec[:, 1 + k:] = out[3]
         if self.world > 1:
-            out = torch.empty((self.world * rec.shape[0], rec.shape[1]), dtype=rec.dtype, device=rec.device)
-            dist.all_gather_into_tensor(out, rec, group=self.group)     # concatenated along dim 0 (gloo + nccl)
-            rec = out.view(self.world, rec.shape[0], rec.shape[1]).sum(dim=0, dtype=torch.int32)
-        return (1 + rec[:, 0]).to(torch.int32), rec[:, 1].to(torch.int32)
+            allrec = torch.empty((self.world * B, 1 + 2 * k), dtype=torch.int64, device=rec.device)
+            dist.all_gather_into_tensor(allrec, rec, group=self.group)           # concatenated along dim 0 (gloo + nccl)
+            allrec = allrec.view(self.world, B, 1 + 2 * k)
+        else:
+            allrec = rec.view(1, B, 1 + 2 * k)
+        ng_tot = (allrec[:, :, 0] >> 32).sum(dim=0)
+        ne_tot = (allrec[:, :, 0] & 0xFFFFFFFF).sum(dim=0)
+        ranks = (1 + ng_tot).to(torch.int32)
+        if k == 0:
+            return ranks, ne_tot.to(torch.int32)
+        vals = allrec[:, :, 1:1 + k].to(torch.int32).view(torch.float32).permute(1, 0, 2).reshape(B, -1)
+        ids = allrec[:, :, 1 + k:].permute(1, 0, 2).reshape(B, -1)
+        tv, ti = merge_topk(vals, ids, k)
+        return ranks, ne_tot.to(torch.int32), tv, ti
+
+
+def merge_topk(vals, ids, k):
+    """Top-k of candidate lists [B, M] in (score desc, id asc) order; padding entries are (-inf, -1)."""
+    big = torch.iinfo(torch.int64).max
+    key_ids = torch.where(ids < 0, torch.full_like(ids, big), ids)
+    o1 = torch.argsort(key_ids, dim=1, stable=True)
+    v1, i1 = torch.gather(vals, 1, o1), torch.gather(ids, 1, o1)
+    o2 = torch.argsort(v1, dim=1, descending=True, stable=True)
+    return torch.gather(v1, 1, o2)[:, :k].contiguous(), torch.gather(i1, 1, o2)[:, :k].contiguous()

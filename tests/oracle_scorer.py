@@ -40,7 +40,7 @@ class OracleShardScorer(object):
             out[b] = O.score_chain(h[b:b + 1], self.E[r:r + 1], self.b[r:r + 1])[0, 0]
         return torch.from_numpy(out)
 
-    def rank_counts(self, h, tgt, e2, filt_indptr, filt_idx, filt_nnz=None):
+    def rank_counts(self, h, tgt, e2, filt_indptr, filt_idx, filt_nnz=None, k=0):
         logits = O.score_chain(h.numpy(), self.E, self.b)
         e2, ip, ix = np.asarray(e2), np.asarray(filt_indptr), np.asarray(filt_idx)
         t = tgt.numpy()
@@ -56,6 +56,20 @@ class OracleShardScorer(object):
             row = logits[b][keep]
             ng[b] = np.count_nonzero(row > t[b])
             ne[b] = np.count_nonzero(row == t[b])
+        if k > 0:
+            # shard-local top-k of the filtered row (target kept), global ids
+            tv = np.full((B, k), -np.inf, np.float32)
+            ti = np.full((B, k), -1, np.int64)
+            for b in range(B):
+                row = logits[b].copy()
+                f = ix[ip[b]:ip[b + 1]]
+                f = f[(f >= self.lo) & (f < self.hi) & (f != e2[b])] - self.lo
+                row[f] = -np.inf
+                order = np.lexsort((np.arange(len(row)), -row))[:k]
+                order = order[row[order] > -np.inf]
+                tv[b, :len(order)] = row[order]
+                ti[b, :len(order)] = order + self.lo
+            return torch.from_numpy(ng), torch.from_numpy(ne), torch.from_numpy(tv), torch.from_numpy(ti)
         return torch.from_numpy(ng), torch.from_numpy(ne)
 
     # unsharded convenience used by QueryShardedEvaluator's rank_fn

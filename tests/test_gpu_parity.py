@@ -291,3 +291,41 @@ def test_full_size_configs_properties(oracle_chain, name):
     assert (mr, mrr, hits[10]) == (mr2, mrr2, hits2[10])
     assert n_equal < 1e-6 * Q * md["num_ent"]
     m.close()
+
+
+def test_topk_of_filtered_rows(oracle_chain):
+    """coper_rank_counts(k > 0): top-k of the filtered row (target kept), (score desc, id asc), -inf / -1 padding;
+    two shard handles merged == unsharded."""
+    O = oracle_chain
+    from coper_amd.sharding import merge_topk
+    md = cdata.model_descriptors("fb15k237_cpg", num_ent=700, num_rel=12)
+    p = cdata.synthetic_params(md, 7)
+    q = cdata.synthetic_queries(md, 90, seed=8, mean_filter=6.0, max_filter=40)
+    m = _model(md, p)
+    h = m.encode(q["e1"], q["rel"])
+    tgt = m.target_scores(h, q["e2"])
+    logits = m.score_all(h).cpu().numpy()
+    for k in (1, 10, 33):
+        ng, ne, tv, ti = m.rank_counts(h, tgt, q["e2"], q["filt_indptr"], q["filt_idx"], k=k)
+        ev, ei = O.topk_filtered(logits, q["e2"], q["filt_indptr"], q["filt_idx"], k)
+        assert np.array_equal(tv.cpu().numpy(), ev) and np.array_equal(ti.cpu().numpy(), ei)
+        ng0, ne0 = m.rank_counts(h, tgt, q["e2"], q["filt_indptr"], q["filt_idx"])
+        assert np.array_equal(ng.cpu().numpy(), ng0.cpu().numpy())
+    # k larger than the number of unfiltered entities: padded with (-inf, -1)
+    md2 = cdata.model_descriptors("nations_cpg")
+    p2 = cdata.synthetic_params(md2, 1)
+    q2 = cdata.synthetic_queries(md2, 20, seed=1, mean_filter=3.0, max_filter=8)
+    m2 = _model(md2, p2)
+    h2 = m2.encode(q2["e1"], q2["rel"])
+    _, _, tv, ti = m2.rank_counts(h2, m2.target_scores(h2, q2["e2"]), q2["e2"], q2["filt_indptr"], q2["filt_idx"], k=16)
+    ev, ei = O.topk_filtered(m2.score_all(h2).cpu().numpy(), q2["e2"], q2["filt_indptr"], q2["filt_idx"], 16)
+    assert np.array_equal(tv.cpu().numpy(), ev) and np.array_equal(ti.cpu().numpy(), ei)
+    assert (ti.cpu().numpy() == -1).any()
+    # sharded: per-shard top-k merged == unsharded top-k
+    shards = [_model(md, p, shard=(0, 333)), _model(md, p, shard=(333, 700))]
+    parts = [s_.rank_counts(h, tgt, q["e2"], q["filt_indptr"], q["filt_idx"], k=10) for s_ in shards]
+    tv, ti = merge_topk(torch.cat([x[2] for x in parts], 1), torch.cat([x[3] for x in parts], 1), 10)
+    ev, ei = O.topk_filtered(logits, q["e2"], q["filt_indptr"], q["filt_idx"], 10)
+    assert np.array_equal(tv.cpu().numpy(), ev) and np.array_equal(ti.cpu().numpy(), ei)
+    for x in shards + [m, m2]:
+        x.close()

@@ -37,7 +37,9 @@ def _worker(rank, world, port, mode, out_dir):
         q = cdata.synthetic_queries(md, 45, seed=2, mean_filter=3.0, max_filter=12)
         if mode == "entity":
             sc = OracleShardScorer(p, md, shard_bounds(md["num_ent"], world, rank))
-            ranks, ne = EntityShardedRanker(sc).rank(q)
+            ranks, ne, tv, ti = EntityShardedRanker(sc).rank(q, k=7)
+            np.save(os.path.join(out_dir, "tv_%d.npy" % rank), tv.numpy())
+            np.save(os.path.join(out_dir, "ti_%d.npy" % rank), ti.numpy())
         elif mode == "entity_nosplit":
             sc = OracleShardScorer(p, md, shard_bounds(md["num_ent"], world, rank))
             ranks, ne = EntityShardedRanker(sc, split_encoder=False).rank(q)
@@ -69,3 +71,15 @@ def test_sharded_ranks_equal_single_process(tmp_path, oracle_chain, mode, world)
     for r in range(world):
         assert np.array_equal(np.load(tmp_path / ("ranks_%d.npy" % r)), exp_r), (mode, r)
         assert np.array_equal(np.load(tmp_path / ("ne_%d.npy" % r)), exp_ne), (mode, r)
+    if mode == "entity":
+        # merged per-shard top-k == top-k of the whole filtered row
+        from tests.oracle_scorer import OracleShardScorer
+        md = _md()
+        p = cdata.synthetic_params(md, seed=11)
+        q = cdata.synthetic_queries(md, 45, seed=2, mean_filter=3.0, max_filter=12)
+        sc = OracleShardScorer(p, md, (0, md["num_ent"]))
+        h = sc.encode(q["e1"], q["rel"])
+        _, _, tv, ti = sc.rank_counts(h, sc.target_scores(h, q["e2"]), q["e2"], q["filt_indptr"], q["filt_idx"], k=7)
+        for r in range(world):
+            assert np.array_equal(np.load(tmp_path / ("tv_%d.npy" % r)), tv.numpy())
+            assert np.array_equal(np.load(tmp_path / ("ti_%d.npy" % r)), ti.numpy())
