@@ -28,6 +28,7 @@ if ROOT not in sys.path:
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: Peak FP32 (matrix)
 PEAK_HBM_GBS = 8000.0
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA; the bf16x3 mode spends 3 hardware MFMAs per algorithmic product
 
 
 def pmc_traffic(workload, Q, kernel):
@@ -55,6 +56,7 @@ def parse_args():
     ap.add_argument("--order", choices=["shuffled", "sorted"], default="shuffled")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--score-mode", choices=["f32", "bf16x3"], default="f32")
     return ap.parse_args()
 
 
@@ -125,7 +127,7 @@ def main():
     entity_mode = args.mode == "entity"
     shard = shard_bounds(md["num_ent"], world, rank) if entity_mode else None
     params, big = device_params(md, 0, device, shard)
-    model = ConvE(md, device=device, shard=shard)
+    model = ConvE(md, device=device, shard=shard, score_mode=args.score_mode)
     model.load_parameters(params, global_rows=not big)
     t_prep0 = time.perf_counter()
     model.prepare()
@@ -183,20 +185,24 @@ def main():
             "metric": "scored triples/sec (1-vs-all)", "value": units / dt, "unit": "triples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if entity_mode else "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if args.score_mode == "f32" else "bf16x3 (split bf16 operands, fp32 accumulate; dense layer f32)",
+            "data": "synthetic",
             "config": {"workload": "%s: |E|=%d R2=%d d=%d r=%d, Q=%d queries/pass%s, %s relation order" % (
                 args.workload, md["num_ent"], md["num_rel"], d, md["rel_emb_size"], Q,
                 "" if entity_mode else " per GPU", args.order),
                 "parallelism": ("entity-sharded x%d" % world) if entity_mode else ("query-sharded x%d" % world),
-                "score_mode": "f32 (v_mfma_f32_32x32x2_f32, exact)", "prepare_ms": round(prepare_ms, 2),
+                "score_mode": "f32 (v_mfma_f32_32x32x2_f32, exact)" if args.score_mode == "f32" else
+                "bf16x3 (3 x v_mfma_f32_32x32x16_bf16 per product, ~2^-16 rel.)", "prepare_ms": round(prepare_ms, 2),
                 "mean_rank": float(np.mean(ranks_np)), "mrr": float(np.mean(1.0 / ranks_np))},
         }
         if kern["score_count"]:
             flops = 2.0 * Q * n_local * d          # ALGORITHMIC flops of one score_count launch
             ach = flops / (kern["score_count"] * 1e-3) / 1e12
-            out["roofline"] = {"kernel": "k_score_count_f32", "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
-                               "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
-                               "traffic": pmc_traffic(args.workload, Q, "coper::k_score_count_f32") if world == 1 else None,
+            peak = PEAK_F32_MFMA_TFLOPS if args.score_mode == "f32" else PEAK_BF16_MFMA_TFLOPS
+            out["roofline"] = {"kernel": "k_score_count_f32" if args.score_mode == "f32" else "k_score_count_bf16x3",
+                               "bound": "mfma", "achieved": ach, "peak": peak,
+                               "unit": "TFLOP/s", "frac": ach / peak,
+                               "traffic": pmc_traffic(args.workload, Q, "coper::k_score_count_f32") if (world == 1 and args.score_mode == "f32") else None,
                                "avg_launch_ms": kern["score_count"],
                                "other_kernels_ms": {k: v for k, v in kern.items() if k != "score_count"}}
         if not args.no_cpu_baseline and world == 1:

@@ -88,6 +88,12 @@ static void dev_free(T** p) {
 static int ensure_workspace(coper_handle* h, int64_t B, int64_t nnz, hipStream_t s) {
   const Dims& dm = h->dm;
   if (nnz > h->ws_nnz) h->ws_nnz = nnz;
+  if (h->cfg.score_mode != COPER_SCORE_F32 && nnz > h->row_of_cap) {
+    COPER_HIP_TRY(h, hipStreamSynchronize(s));
+    int rc0 = dev_alloc(h, &h->row_of_ws, (size_t)nnz);
+    if (rc0) return rc0;
+    h->row_of_cap = nnz;
+  }
   if (B <= h->ws_queries && h->perm) return COPER_OK;
   COPER_HIP_TRY(h, hipStreamSynchronize(s));
   int64_t cap = B < 64 ? 64 : B;
@@ -104,10 +110,22 @@ static int ensure_workspace(coper_handle* h, int64_t B, int64_t nnz, hipStream_t
   if ((rc = dev_alloc(h, &h->z_part, (size_t)KSPLIT_MAX * cap * dm.d_pad16))) return rc;
   if ((rc = dev_alloc(h, &h->tgt_ws, cap))) return rc;
   if ((rc = dev_alloc(h, &h->cnt_ws, 2 * cap))) return rc;
-  if ((rc = dev_alloc(h, &h->hfrag_ws, (size_t)((cap + 127) / 128) * 128 * dm.d_pad8))) return rc;
+  if (h->cfg.score_mode == COPER_SCORE_F32) {
+    if ((rc = dev_alloc(h, &h->hfrag_ws, (size_t)((cap + 127) / 128) * 128 * dm.d_pad8))) return rc;
+  } else {
+    size_t plane = (size_t)((cap + 127) / 128) * 4 * dm.KS16 * 64 * 16;
+    dev_free((char**)&h->hfrag16_hi); dev_free((char**)&h->hfrag16_lo);
+    if (hipMalloc(&h->hfrag16_hi, plane) != hipSuccess || hipMalloc(&h->hfrag16_lo, plane) != hipSuccess)
+      return fail(h, COPER_ENOMEM, "hipMalloc of the bf16 query planes failed");
+  }
   h->ws_queries = cap;
   h->ws_ksplit = KSPLIT_MAX;
   return COPER_OK;
+}
+
+int score_all_dispatch(coper_handle* h, const float* hvec, int64_t B, float* logits, int64_t ld, hipStream_t s) {
+  if (h->cfg.score_mode != COPER_SCORE_F32) return launch_score_all_bf16x3(h, hvec, B, logits, ld, s);
+  return launch_score_all(h, hvec, B, logits, ld, s);
 }
 
 }  // namespace coper
@@ -144,7 +162,8 @@ COPER_API int coper_create(const coper_config* cfg, coper_handle** out) {
   if (dm.emb_h <= 0 || dm.emb_w <= 0 || dm.emb_h * dm.emb_w != dm.d) return bad("emb_h * emb_w must equal ent_emb_size (models.py:355)");
   if (cfg->n_ctx_conv > COPER_MAX_CTX || cfg->n_ctx_out > COPER_MAX_CTX) return bad("too many generator hidden layers");
   if (cfg->shard_lo < 0 || cfg->shard_hi > dm.E || cfg->shard_lo >= cfg->shard_hi) return bad("entity shard [lo,hi) out of range");
-  if (cfg->score_mode != COPER_SCORE_F32) return bad("score_mode: only COPER_SCORE_F32 is built in this version");
+  if (cfg->score_mode != COPER_SCORE_F32 && cfg->score_mode != COPER_SCORE_BF16X3)
+    return bad("score_mode: COPER_SCORE_F32 and COPER_SCORE_BF16X3 are built; COPER_SCORE_BF16 is not");
   // models.py:360: e1 stacked on the reshaped relation only for plain ConvE
   dm.stacked = !dm.gen_conv && !dm.gen_fc && !dm.lookup;
   dm.in_h = dm.emb_h; dm.in_w = dm.emb_w;
@@ -163,6 +182,7 @@ COPER_API int coper_create(const coper_config* cfg, coper_handle** out) {
   dm.F_pad = (dm.F + 15) / 16 * 16;
   dm.d_pad16 = (dm.d + 15) / 16 * 16; dm.nfb = dm.d_pad16 / 16;
   dm.d_pad8 = (dm.d + 7) / 8 * 8; dm.KS = dm.d_pad8 / 8;
+  dm.KS16 = (dm.d + 15) / 16;
   dm.n_local = cfg->shard_hi - cfg->shard_lo;
   dm.n_eblk = ((dm.n_local + 31) / 32 + EBLK_ALIGN - 1) / EBLK_ALIGN * EBLK_ALIGN;
   if (dm.KS * 4 * 64 * 16 > 160 * 1024) return bad("ent_emb_size too large for the LDS query tile (d <= 320)");
@@ -212,7 +232,8 @@ COPER_API void coper_destroy(coper_handle* h) {
   dev_free(&h->Ef); dev_free(&h->bias_pad); dev_free(&h->ctx_tmp[0]); dev_free(&h->ctx_tmp[1]);
   dev_free(&h->rel_count); dev_free(&h->rel_offset); h->rel_cursor = nullptr; dev_free(&h->perm);
   dev_free(&h->tiles); dev_free(&h->n_tiles); dev_free(&h->blk_off); dev_free(&h->x_sorted); dev_free(&h->z_part);
-  dev_free(&h->tgt_ws); dev_free(&h->cnt_ws); dev_free(&h->hfrag_ws); dev_free(&h->logits_ws);
+  dev_free(&h->tgt_ws); dev_free(&h->cnt_ws); dev_free(&h->hfrag_ws); dev_free(&h->logits_ws); dev_free(&h->row_of_ws);
+  dev_free((char**)&h->Ef16_hi); dev_free((char**)&h->Ef16_lo); dev_free((char**)&h->hfrag16_hi); dev_free((char**)&h->hfrag16_lo);
   for (auto& kv : h->timers)
     for (auto& p : kv.second.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   delete h;
@@ -361,16 +382,29 @@ COPER_API int coper_prepare(coper_handle* h, void* stream) {
   } else {
     if ((rc = launch_gen_dense_frag(h, nullptr, 1, 0, P("fc_weights"), 1, h->Wf, s))) return rc;
   }
-  // entity table image
-  if ((rc = dev_alloc(h, &h->Ef, (size_t)dm.n_eblk * dm.KS * 64 * 4)) || (rc = dev_alloc(h, &h->bias_pad, (size_t)dm.n_eblk * 32)))
-    return rc;
-  if ((rc = launch_entity_frag(h, P("ent_emb"), P("pred_bias"), s))) return rc;
+  // entity table image(s)
+  if (cfg.score_mode == COPER_SCORE_F32) {
+    if ((rc = dev_alloc(h, &h->Ef, (size_t)dm.n_eblk * dm.KS * 64 * 4)) || (rc = dev_alloc(h, &h->bias_pad, (size_t)dm.n_eblk * 32)))
+      return rc;
+    if ((rc = launch_entity_frag(h, P("ent_emb"), P("pred_bias"), s))) return rc;
+  } else {
+    // bias_pad comes from the (tiny-KS) fp32 image builder run on a 1-k-step view; the table goes to two bf16 planes
+    size_t plane = (size_t)dm.n_eblk * dm.KS16 * 64 * 16;
+    dev_free((char**)&h->Ef16_hi); dev_free((char**)&h->Ef16_lo);
+    if (hipMalloc(&h->Ef16_hi, plane) != hipSuccess || hipMalloc(&h->Ef16_lo, plane) != hipSuccess)
+      return fail(h, COPER_ENOMEM, "hipMalloc of the bf16 entity planes failed");
+    if ((rc = dev_alloc(h, &h->bias_pad, (size_t)dm.n_eblk * 32))) return rc;
+    if ((rc = launch_bias_pad(h, P("pred_bias"), s))) return rc;
+    if ((rc = launch_rows_to_frag_bf16(h, P("ent_emb"), dm.n_local, dm.n_eblk, (uint4*)h->Ef16_hi, (uint4*)h->Ef16_lo, s)))
+      return rc;
+    if ((rc = score_bf16_kernels_init(h))) return rc;
+  }
   {
     hipDeviceProp_t prop;
     COPER_HIP_TRY(h, hipGetDeviceProperties(&prop, cfg.device));
     h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
-  if ((rc = score_kernels_init(h))) return rc;
+  if (cfg.score_mode == COPER_SCORE_F32 && (rc = score_kernels_init(h))) return rc;
   h->prepared = true;
   return COPER_OK;
 }
@@ -419,7 +453,10 @@ COPER_API int coper_score_all(coper_handle* h, const float* hvec, int64_t B, flo
   COPER_REQUIRE_PREPARED(h);
   if (B == 0) return COPER_OK;
   if (!hvec || !logits || B < 0 || ld < h->dm.n_local) return fail(h, COPER_EINVAL, "coper_score_all: bad argument");
-  return launch_score_all(h, hvec, B, logits, ld, (hipStream_t)stream);
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  if ((rc = ensure_workspace(h, B, 0, s))) return rc;
+  return score_all_dispatch(h, hvec, B, logits, ld, s);
 }
 
 COPER_API int coper_score_lookup(coper_handle* h, const float* hvec, const int32_t* lookup, int64_t B, int64_t L, float* out,
@@ -427,14 +464,22 @@ COPER_API int coper_score_lookup(coper_handle* h, const float* hvec, const int32
   COPER_REQUIRE_PREPARED(h);
   if (B == 0 || L == 0) return COPER_OK;  // eval batches carry lookup_values of shape [B, 0] (data.py:205-213)
   if (!hvec || !lookup || !out || B < 0 || L < 0) return fail(h, COPER_EINVAL, "coper_score_lookup: bad argument");
-  return launch_score_lookup(h, hvec, lookup, B, L, out, (hipStream_t)stream);
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  if ((rc = ensure_workspace(h, B, 0, s))) return rc;
+  if (h->cfg.score_mode != COPER_SCORE_F32) return launch_score_lookup_bf16x3(h, hvec, lookup, B, L, out, s);
+  return launch_score_lookup(h, hvec, lookup, B, L, out, s);
 }
 
 COPER_API int coper_target_scores(coper_handle* h, const float* hvec, const int64_t* e2, int64_t B, float* tgt, void* stream) {
   COPER_REQUIRE_PREPARED(h);
   if (B == 0) return COPER_OK;
   if (!hvec || !e2 || !tgt || B < 0) return fail(h, COPER_EINVAL, "coper_target_scores: bad argument");
-  return launch_pair_targets(h, hvec, e2, B, tgt, (hipStream_t)stream);
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  if ((rc = ensure_workspace(h, B, 0, s))) return rc;
+  if (h->cfg.score_mode != COPER_SCORE_F32) return launch_pair_targets_bf16x3(h, hvec, e2, B, tgt, s);
+  return launch_pair_targets(h, hvec, e2, B, tgt, s);
 }
 
 COPER_API int coper_rank_counts(coper_handle* h, const float* hvec, const float* tgt, const int64_t* e2,
@@ -450,8 +495,14 @@ COPER_API int coper_rank_counts(coper_handle* h, const float* hvec, const float*
   hipStream_t s = (hipStream_t)stream;
   int rc;
   if ((rc = ensure_workspace(h, B, filt_nnz, s))) return rc;
-  if ((rc = launch_score_count(h, hvec, tgt, B, n_greater, n_equal, s))) return rc;
-  if ((rc = launch_filter_correct(h, hvec, tgt, e2, filt_indptr, filt_idx, filt_nnz, B, n_greater, n_equal, s))) return rc;
+  if (h->cfg.score_mode != COPER_SCORE_F32) {
+    if ((rc = launch_pack_h_bf16(h, hvec, B, s))) return rc;
+    if ((rc = launch_score_count_bf16x3(h, hvec, tgt, B, n_greater, n_equal, s))) return rc;
+    if ((rc = launch_filter_correct_bf16x3(h, tgt, e2, filt_indptr, filt_idx, filt_nnz, B, n_greater, n_equal, s))) return rc;
+  } else {
+    if ((rc = launch_score_count(h, hvec, tgt, B, n_greater, n_equal, s))) return rc;
+    if ((rc = launch_filter_correct(h, hvec, tgt, e2, filt_indptr, filt_idx, filt_nnz, B, n_greater, n_equal, s))) return rc;
+  }
   if (k > 0) {
     // logits workspace: at most 256 MiB (or one row) at a time
     int64_t rows = (int64_t)(256ll << 20) / (h->dm.n_local * 4);

@@ -35,6 +35,7 @@ struct Dims {
   int nfb = 0;         // d_pad16 / 16
   int d_pad8 = 0;      // d rounded up to 8 (k-steps of the score kernels)
   int KS = 0;          // d_pad8 / 8
+  int KS16 = 0;        // ceil(d / 16): k-steps of the bf16 MFMA
   int64_t n_local = 0; // shard rows
   int64_t n_eblk = 0;  // 32-row entity blocks (padded to a multiple of EBLK_ALIGN)
 };
@@ -69,6 +70,8 @@ struct coper_handle {
   int64_t Rw = 0;               // R when gen_fc else 1
   float* Ef = nullptr;          // entity table, fragment-major: [n_eblk][KS][64] float4
   float* bias_pad = nullptr;    // [n_eblk*32], -inf padded
+  void* Ef16_hi = nullptr;      // COPER_SCORE_BF16X3: entity table hi / lo bf16 planes, fragment-major
+  void* Ef16_lo = nullptr;      //   [n_eblk][KS16][64] x 16 B
   float* ctx_tmp[2] = {nullptr, nullptr};  // generator hidden activations
   size_t ctx_tmp_elems = 0;
 
@@ -89,6 +92,10 @@ struct coper_handle {
   int32_t* cnt_ws = nullptr;      // [2B]
   float* logits_ws = nullptr;     // top-k path only: [chunk_rows, n_local]
   int64_t logits_ws_rows = 0;
+  void* hfrag16_hi = nullptr;     // bf16x3: h hi / lo planes in fragment order
+  void* hfrag16_lo = nullptr;
+  int32_t* row_of_ws = nullptr;   // bf16x3: CSR entry -> query row [nnz]
+  int64_t row_of_cap = 0;
   float* hfrag_ws = nullptr;      // h re-packed in MFMA-fragment order [ceil(B/128)*4][KS][64] float4
   int num_cus = 256;
   bool dense_attr_done = false;
@@ -140,6 +147,23 @@ int launch_score_lookup(coper_handle* h, const float* hvec, const int32_t* looku
                         hipStream_t s);
 int launch_finish_ranks(coper_handle* h, const int32_t* ng, int64_t B, int32_t* ranks, hipStream_t s);
 int score_kernels_init(coper_handle* h);
+// kernels_score_bf16.hip (COPER_SCORE_BF16X3)
+int launch_rows_to_frag_bf16(coper_handle* h, const float* src, int64_t n_rows, int64_t n_blk, uint4* hi, uint4* lo,
+                             hipStream_t s);
+int launch_pack_h_bf16(coper_handle* h, const float* hvec, int64_t B, hipStream_t s);
+int launch_score_count_bf16x3(coper_handle* h, const float* hvec, const float* tgt, int64_t B, int32_t* ng,
+                              int32_t* ne, hipStream_t s);
+int launch_score_all_bf16x3(coper_handle* h, const float* hvec, int64_t B, float* logits, int64_t ld, hipStream_t s);
+int launch_pair_targets_bf16x3(coper_handle* h, const float* hvec, const int64_t* e2, int64_t B, float* tgt,
+                               hipStream_t s);
+int launch_score_lookup_bf16x3(coper_handle* h, const float* hvec, const int32_t* lookup, int64_t B, int64_t L,
+                               float* out, hipStream_t s);
+int launch_filter_correct_bf16x3(coper_handle* h, const float* tgt, const int64_t* e2, const int64_t* indptr,
+                                 const int64_t* idx, int64_t nnz, int64_t B, int32_t* ng, int32_t* ne,
+                                 hipStream_t s);
+int score_bf16_kernels_init(coper_handle* h);
+int score_all_dispatch(coper_handle* h, const float* hvec, int64_t B, float* logits, int64_t ld, hipStream_t s);
+int launch_bias_pad(coper_handle* h, const float* bias, hipStream_t s);
 int launch_topk(coper_handle* h, const float* hvec, const int64_t* e2, const int64_t* indptr, const int64_t* idx,
                 int64_t B, int k, float* topk_val, int64_t* topk_idx, float* logits_ws, int64_t chunk_rows,
                 hipStream_t s);

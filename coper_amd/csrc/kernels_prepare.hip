@@ -200,4 +200,18 @@ int launch_entity_frag(coper_handle* h, const float* ent, const float* bias, hip
   return COPER_OK;
 }
 
+__global__ void k_bias_pad(const float* __restrict__ bias, int64_t n_local, int64_t n_pad, float* __restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_pad) out[i] = i < n_local ? bias[i] : -INFINITY;
+}
+
+int launch_bias_pad(coper_handle* h, const float* bias, hipStream_t s) {
+  const Dims& dm = h->dm;
+  int64_t n_pad = dm.n_eblk * 32;
+  hipLaunchKernelGGL(k_bias_pad, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, s, bias, dm.n_local, n_pad,
+                     h->bias_pad);
+  COPER_HIP_TRY(h, hipGetLastError());
+  return COPER_OK;
+}
+
 }  // namespace coper

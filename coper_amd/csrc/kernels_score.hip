@@ -490,7 +490,7 @@ int launch_topk(coper_handle* h, const float* hvec, const int64_t* e2, const int
   const Dims& dm = h->dm;
   for (int64_t b0 = 0; b0 < B; b0 += chunk_rows) {
     int64_t nb = B - b0 < chunk_rows ? B - b0 : chunk_rows;
-    int rc = launch_score_all(h, hvec + b0 * dm.d, nb, logits_ws, dm.n_local, s);
+    int rc = score_all_dispatch(h, hvec + b0 * dm.d, nb, logits_ws, dm.n_local, s);
     if (rc) return rc;
     int64_t threads = nb * 16;
     hipLaunchKernelGGL(k_mask_filtered, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, logits_ws, dm.n_local,

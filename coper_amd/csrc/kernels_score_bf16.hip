@@ -1,0 +1,456 @@
+// COPER_SCORE_BF16X3: the 1-vs-all scorer / ranker on the bf16 matrix cores at fp32-class accuracy.
+//
+// gfx950 has no TF32/xf32 path and its exact-f32 MFMA runs at 1/16 of the bf16 rate, so the fp32 mode
+// of kernels_score.hip is MFMA-bound at 157 TFLOP/s.  Here every fp32 operand is split once into two
+// bf16 terms,  x = hi + lo  (hi = rne_bf16(x), lo = rne_bf16(x - hi), |x - hi - lo| <= 2^-17 |x|), and
+// each product is formed as  lo*hi + hi*lo + hi*hi  on v_mfma_f32_32x32x16_bf16 with fp32 accumulation
+// (the dropped lo*lo term is <= 2^-16 relative): 3 MFMAs at the bf16 rate instead of 1 at the f32 rate,
+// 16/3 = 5.3x the matrix throughput, logit error ~1e-5 -- inside the 1e-3 gate of BASELINE.json.
+// Storage is two bf16 planes (same bytes as fp32).
+//
+// Every logit of this mode -- tiles of score_count / score_all and the (query, entity) pair kernel used
+// for targets, filter correction and the sampled scorer -- is produced by the SAME instruction sequence
+// with the SAME operand roles (entity rows = A, queries = B), accumulators started from pred_bias, so
+// they agree bit for bit (tests/test_gpu_parity.py checks it); an MFMA's result for element (i, j) does
+// not depend on where the row / column sits in the tile.
+#include "coper_internal.h"
+
+namespace coper {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned short bf16_rne(float x) {
+  unsigned u = __float_as_uint(x);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);  // NaN stays NaN
+  return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ float bf16_to_f32(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
+
+__device__ __forceinline__ void split8(const float* v, uint4& hi, uint4& lo) {
+  unsigned short h[8], l[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    h[j] = bf16_rne(v[j]);
+    l[j] = bf16_rne(v[j] - bf16_to_f32(h[j]));
+  }
+  hi = make_uint4(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16), h[4] | ((unsigned)h[5] << 16),
+                  h[6] | ((unsigned)h[7] << 16));
+  lo = make_uint4(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16), l[4] | ((unsigned)l[5] << 16),
+                  l[6] | ((unsigned)l[7] << 16));
+}
+
+#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&(a), *(const bf16x8*)&(b), (c), 0, 0, 0)
+// one k-step (16 k) of the split product, smallest terms first
+#define MFMA_X3(ahi, alo, bhi, blo, c) \
+  { (c) = MFMA_BF16(alo, bhi, c); (c) = MFMA_BF16(ahi, blo, c); (c) = MFMA_BF16(ahi, bhi, c); }
+
+// ------------------------------------------------------------------------------------------------
+// prepare: fragment image  X16[(blk*KS16 + ks)*64 + l] = 8 bf16 { X[32blk + (l&31)][16ks + 8(l>>5) + j] }
+// for the hi and the lo plane (the A/B operand map of v_mfma_f32_32x32x16_bf16).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rows_to_frag_bf16(const float* __restrict__ src, int64_t n_rows, int d,
+                                                           int KS16, uint4* __restrict__ hi, uint4* __restrict__ lo,
+                                                           int64_t total) {
+  int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (blk*KS16 + ks)*64 + l
+  if (j >= total) return;
+  int l = (int)(j & 63);
+  int64_t rest = j >> 6;
+  int ks = (int)(rest % KS16);
+  int64_t blk = rest / KS16;
+  int64_t row = blk * 32 + (l & 31);
+  int k = 16 * ks + 8 * (l >> 5);
+  float v[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) v[t] = (row < n_rows && k + t < d) ? src[row * d + k + t] : 0.f;
+  uint4 h4, l4;
+  split8(v, h4, l4);
+  hi[j] = h4;
+  lo[j] = l4;
+}
+
+int launch_rows_to_frag_bf16(coper_handle* h, const float* src, int64_t n_rows, int64_t n_blk, uint4* hi, uint4* lo,
+                             hipStream_t s) {
+  const Dims& dm = h->dm;
+  int64_t total = n_blk * dm.KS16 * 64;
+  hipLaunchKernelGGL(k_rows_to_frag_bf16, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, n_rows, dm.d,
+                     dm.KS16, hi, lo, total);
+  COPER_HIP_TRY(h, hipGetLastError());
+  return COPER_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused score + count: same persistent, statically balanced structure as k_score_count_f32
+// (kernels_score.hip): unit = 128 queries x 256 entities, 8 waves x one 32-row entity block.
+// ------------------------------------------------------------------------------------------------
+constexpr int BX_NQ = 4;
+constexpr int BX_WAVES = 8;
+
+__global__ void k_zero_counts(int64_t B, int32_t* __restrict__ ng, int32_t* __restrict__ ne) {
+  int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < B) { ng[j] = 0; ne[j] = 0; }
+}
+
+__global__ __launch_bounds__(512, 2) void k_score_count_bf16x3(const uint4* __restrict__ Ehi,
+                                                               const uint4* __restrict__ Elo,
+                                                               const float* __restrict__ bias_pad,
+                                                               const uint4* __restrict__ Hhi,
+                                                               const uint4* __restrict__ Hlo,
+                                                               const float* __restrict__ tgt, int64_t B, int KS,
+                                                               int64_t iters, int64_t units,
+                                                               int32_t* __restrict__ ng, int32_t* __restrict__ ne) {
+  constexpr int NQ = BX_NQ;
+  extern __shared__ uint4 hl16[];  // [2 planes][NQ][KS][64]
+  uint4* hl_hi = hl16;
+  uint4* hl_lo = hl16 + NQ * KS * 64;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int64_t u_begin = units * blockIdx.x / gridDim.x;
+  const int64_t u_end = units * (blockIdx.x + 1) / gridDim.x;
+  float t[NQ];
+  int cg[NQ], ce[NQ];
+  int64_t cur_tile = -1;
+  uint4 a0h, a0l, a1h, a1l, b0h[NQ], b0l[NQ], b1h[NQ], b1l[NQ];
+  float4 bq[4];
+
+#define LOAD_A(ah, al, ebx, ks_)                         \
+  {                                                      \
+    int64_t o_ = ((ebx)*KS + (ks_)) * 64 + lane;         \
+    ah = Ehi[o_];                                        \
+    al = Elo[o_];                                        \
+  }
+#define LOAD_B(bh, bl, ks_)                                                   \
+  {                                                                           \
+    _Pragma("unroll") for (int b = 0; b < NQ; ++b) {                          \
+      bh[b] = hl_hi[(b * KS + (ks_)) * 64 + lane];                            \
+      bl[b] = hl_lo[(b * KS + (ks_)) * 64 + lane];                            \
+    }                                                                         \
+  }
+#define LOAD_BIAS(ebx)                                                         \
+  {                                                                            \
+    const float4* bp = (const float4*)(bias_pad + (ebx)*32 + 4 * (lane >> 5)); \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) bq[j] = bp[2 * j];           \
+  }
+#define STEP(ah, al, bh, bl) \
+  { _Pragma("unroll") for (int b = 0; b < NQ; ++b) MFMA_X3(ah, al, bh[b], bl[b], acc[b]); }
+#define FLUSH_COUNTS()                                                        \
+  {                                                                           \
+    _Pragma("unroll") for (int b = 0; b < NQ; ++b) {                          \
+      int g = cg[b] + __shfl_xor(cg[b], 32);                                  \
+      int e = ce[b] + __shfl_xor(ce[b], 32);                                  \
+      int64_t q = cur_tile * (32 * NQ) + b * 32 + (lane & 31);                \
+      if (lane < 32 && q < B) {                                               \
+        if (g) atomicAdd(&ng[q], g);                                          \
+        if (e) atomicAdd(&ne[q], e);                                          \
+      }                                                                       \
+    }                                                                         \
+  }
+
+  if (u_begin < u_end) {
+    int64_t eb = (u_begin % iters) * BX_WAVES + wave;
+    LOAD_A(a0h, a0l, eb, 0);
+    LOAD_BIAS(eb);
+  }
+  for (int64_t u = u_begin; u < u_end; ++u) {
+    const int64_t tile = u / iters;
+    const int64_t eb = (u % iters) * BX_WAVES + wave;
+    if (tile != cur_tile) {  // workgroup-uniform
+      if (cur_tile >= 0) FLUSH_COUNTS();
+      __syncthreads();
+      const uint4* sh = Hhi + tile * (NQ * KS * 64);
+      const uint4* sl = Hlo + tile * (NQ * KS * 64);
+      for (int j = threadIdx.x; j < NQ * KS * 64; j += 512) { hl_hi[j] = sh[j]; hl_lo[j] = sl[j]; }
+      cur_tile = tile;
+#pragma unroll
+      for (int b = 0; b < NQ; ++b) {
+        int64_t q = tile * (32 * NQ) + b * 32 + (lane & 31);
+        t[b] = q < B ? tgt[q] : INFINITY;
+        cg[b] = 0;
+        ce[b] = 0;
+      }
+      __syncthreads();
+    }
+    f32x16 acc[NQ];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int b = 0; b < NQ; ++b) {
+        acc[b][4 * j + 0] = bq[j].x; acc[b][4 * j + 1] = bq[j].y;
+        acc[b][4 * j + 2] = bq[j].z; acc[b][4 * j + 3] = bq[j].w;
+      }
+    LOAD_B(b0h, b0l, 0);
+    int ks = 0;
+    for (; ks + 2 <= KS; ks += 2) {
+      LOAD_A(a1h, a1l, eb, ks + 1);
+      LOAD_B(b1h, b1l, ks + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      STEP(a0h, a0l, b0h, b0l);
+      const int kn = ks + 2 < KS ? ks + 2 : KS - 1;
+      LOAD_A(a0h, a0l, eb, kn);
+      LOAD_B(b0h, b0l, kn);
+      __builtin_amdgcn_sched_barrier(0);
+      STEP(a1h, a1l, b1h, b1l);
+    }
+    if (ks < KS) STEP(a0h, a0l, b0h, b0l);
+    if (u + 1 < u_end) {
+      const int64_t ebn = ((u + 1) % iters) * BX_WAVES + wave;
+      LOAD_A(a0h, a0l, ebn, 0);
+      LOAD_BIAS(ebn);
+    }
+#pragma unroll
+    for (int b = 0; b < NQ; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float sc = acc[b][r];
+        cg[b] += (sc > t[b]) ? 1 : 0;
+        ce[b] += (sc == t[b]) ? 1 : 0;
+      }
+  }
+  if (cur_tile >= 0) FLUSH_COUNTS();
+#undef LOAD_A
+#undef LOAD_B
+#undef LOAD_BIAS
+#undef STEP
+#undef FLUSH_COUNTS
+}
+
+int launch_pack_h_bf16(coper_handle* h, const float* hvec, int64_t B, hipStream_t s) {
+  int64_t n_blk = (B + 32 * BX_NQ - 1) / (32 * BX_NQ) * BX_NQ;
+  return launch_rows_to_frag_bf16(h, hvec, B, n_blk, (uint4*)h->hfrag16_hi, (uint4*)h->hfrag16_lo, s);
+}
+
+int launch_score_count_bf16x3(coper_handle* h, const float* hvec, const float* tgt, int64_t B, int32_t* ng,
+                              int32_t* ne, hipStream_t s) {
+  const Dims& dm = h->dm;
+  (void)hvec;  // already packed by launch_pack_h_bf16 (coper_rank_counts packs once per call)
+  hipLaunchKernelGGL(k_zero_counts, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, B, ng, ne);
+  int64_t q_tiles = (B + 32 * BX_NQ - 1) / (32 * BX_NQ);
+  int64_t iters = dm.n_eblk / BX_WAVES;
+  int64_t units = q_tiles * iters;
+  int64_t grid = h->num_cus;
+  if (grid > units) grid = units;
+  size_t lds = (size_t)2 * BX_NQ * dm.KS16 * 64 * sizeof(uint4);
+  ScopedKernelTimer t(h, "score_count", s);
+  hipLaunchKernelGGL(k_score_count_bf16x3, dim3((unsigned)grid), dim3(512), lds, s, (const uint4*)h->Ef16_hi,
+                     (const uint4*)h->Ef16_lo, h->bias_pad, (const uint4*)h->hfrag16_hi, (const uint4*)h->hfrag16_lo, tgt,
+                     B, dm.KS16, iters, units, ng, ne);
+  COPER_HIP_TRY(h, hipGetLastError());
+  return COPER_OK;
+}
+
+int score_bf16_kernels_init(coper_handle* h) {
+  int lds = (int)((size_t)2 * BX_NQ * h->dm.KS16 * 64 * sizeof(uint4));
+  COPER_HIP_TRY(h, hipFuncSetAttribute((const void*)k_score_count_bf16x3, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  return COPER_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// logits out (predictions_all): same operand roles as score_count (entity rows on the accumulator
+// registers, one query per lane) so the bits are the same; each lane stores 4 consecutive entities of
+// its query per register quad (16-B stores).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void k_score_all_bf16x3(const uint4* __restrict__ Ehi,
+                                                             const uint4* __restrict__ Elo,
+                                                             const float* __restrict__ bias_pad,
+                                                             const uint4* __restrict__ Hhi,
+                                                             const uint4* __restrict__ Hlo, int64_t B, int KS,
+                                                             int64_t n_eblk, int64_t n_local,
+                                                             float* __restrict__ logits, int64_t ld) {
+  constexpr int NQ = 2, ME = 2;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t qblk0 = (int64_t)blockIdx.x * NQ;  // 32-query blocks (hfrag is packed per 32-query block)
+  const int64_t eb0 = ((int64_t)blockIdx.y * 4 + wave) * ME;
+  if (eb0 >= n_eblk) return;
+  f32x16 acc[ME][NQ];
+#pragma unroll
+  for (int a = 0; a < ME; ++a) {
+    const float4* bp = (const float4*)(bias_pad + (eb0 + a) * 32 + 4 * (lane >> 5));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float4 b4 = bp[2 * j];
+#pragma unroll
+      for (int b = 0; b < NQ; ++b) {
+        acc[a][b][4 * j + 0] = b4.x; acc[a][b][4 * j + 1] = b4.y;
+        acc[a][b][4 * j + 2] = b4.z; acc[a][b][4 * j + 3] = b4.w;
+      }
+    }
+  }
+  for (int ks = 0; ks < KS; ++ks) {
+    uint4 ah[ME], al[ME], bh[NQ], bl[NQ];
+#pragma unroll
+    for (int a = 0; a < ME; ++a) {
+      int64_t o = ((eb0 + a) * KS + ks) * 64 + lane;
+      ah[a] = Ehi[o];
+      al[a] = Elo[o];
+    }
+#pragma unroll
+    for (int b = 0; b < NQ; ++b) {
+      int64_t o = ((qblk0 + b) * KS + ks) * 64 + lane;
+      bh[b] = Hhi[o];
+      bl[b] = Hlo[o];
+    }
+#pragma unroll
+    for (int a = 0; a < ME; ++a)
+#pragma unroll
+      for (int b = 0; b < NQ; ++b) MFMA_X3(ah[a], al[a], bh[b], bl[b], acc[a][b]);
+  }
+#pragma unroll
+  for (int a = 0; a < ME; ++a)
+#pragma unroll
+    for (int b = 0; b < NQ; ++b) {
+      int64_t q = (qblk0 + b) * 32 + (lane & 31);
+      if (q >= B) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int64_t e = (eb0 + a) * 32 + 8 * j + 4 * (lane >> 5);
+        float* dst = logits + q * ld + e;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (e + c < n_local) dst[c] = acc[a][b][4 * j + c];
+      }
+    }
+}
+
+int launch_score_all_bf16x3(coper_handle* h, const float* hvec, int64_t B, float* logits, int64_t ld, hipStream_t s) {
+  const Dims& dm = h->dm;
+  int rc = launch_pack_h_bf16(h, hvec, B, s);
+  if (rc) return rc;
+  int64_t q_groups = (B + 63) / 64;
+  int64_t e_groups = (dm.n_eblk + 7) / 8;
+  if (e_groups > 65535) return fail(h, COPER_EUNSUPPORTED, "score_all: shard too large to materialise logits");
+  ScopedKernelTimer t(h, "score_all", s);
+  hipLaunchKernelGGL(k_score_all_bf16x3, dim3((unsigned)q_groups, (unsigned)e_groups), dim3(256), 0, s,
+                     (const uint4*)h->Ef16_hi, (const uint4*)h->Ef16_lo, h->bias_pad, (const uint4*)h->hfrag16_hi,
+                     (const uint4*)h->hfrag16_lo, B, dm.KS16, dm.n_eblk, dm.n_local, logits, ld);
+  COPER_HIP_TRY(h, hipGetLastError());
+  return COPER_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// (query, entity) pairs through the same MFMA sequence: a wave takes 32 pairs, gathers their entity and
+// query fragments straight from the two fragment images, and reads the diagonal of the 32x32 tile.
+//   mode 0  targets:  pair p = query p with e2[p]          -> out[p] = logit (0 outside the shard)
+//   mode 1  lookup:   pair p = (b = p / L, lookup[p])      -> out[p] = logit (0 outside the shard)
+//   mode 2  filter:   pair p = CSR entry p of query row[p] -> subtract from ng / ne what score_count counted
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pair_bf16x3(const uint4* __restrict__ Ehi, const uint4* __restrict__ Elo,
+                                                     const float* __restrict__ bias_pad,
+                                                     const uint4* __restrict__ Hhi, const uint4* __restrict__ Hlo,
+                                                     int KS, int mode, int64_t n_pairs, int64_t B, int64_t L,
+                                                     const int64_t* __restrict__ e2, const int32_t* __restrict__ lookup,
+                                                     const int64_t* __restrict__ indptr, const int64_t* __restrict__ idx,
+                                                     const int32_t* __restrict__ row_of, const float* __restrict__ tgt,
+                                                     int64_t lo, int64_t n_local, float* __restrict__ out,
+                                                     int32_t* __restrict__ ng, int32_t* __restrict__ ne) {
+  __shared__ int64_t s_e[4][32];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = lane & 31, half = lane >> 5;
+  const int64_t p = ((int64_t)blockIdx.x * 4 + wave) * 32 + i;
+  int64_t q = 0, erow = -1;  // erow < 0: nothing to score for this pair
+  if (p < n_pairs) {
+    if (mode == 0) {
+      q = p;
+      erow = e2[p] - lo;
+    } else if (mode == 1) {
+      q = p / L;
+      erow = (int64_t)lookup[p] - lo;
+    } else {
+      q = row_of[p];
+      int64_t f = idx[p];
+      erow = f - lo;
+      if (p > indptr[q] && idx[p - 1] == f) erow = -1;  // adjacent duplicate: the dense mask is idempotent
+      if (f == e2[q]) erow = -1;                        // the target is restored after masking (metrics.py:46)
+    }
+    if (erow >= n_local) erow = -1;
+  }
+  if (half == 0) s_e[wave][i] = erow;
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): wave-local LDS exchange
+  __builtin_amdgcn_wave_barrier();
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    int64_t er = s_e[wave][(r & 3) + 8 * (r >> 2) + 4 * half];
+    acc[r] = er >= 0 ? bias_pad[er] : 0.f;
+  }
+  const int64_t ea = erow >= 0 ? erow : 0;
+  const uint4* pa_h = Ehi + ((ea >> 5) * KS) * 64 + half * 32 + (ea & 31);
+  const uint4* pa_l = Elo + ((ea >> 5) * KS) * 64 + half * 32 + (ea & 31);
+  const uint4* pb_h = Hhi + ((q >> 5) * KS) * 64 + half * 32 + (q & 31);
+  const uint4* pb_l = Hlo + ((q >> 5) * KS) * 64 + half * 32 + (q & 31);
+  for (int ks = 0; ks < KS; ++ks) {
+    uint4 ah = pa_h[ks * 64], al = pa_l[ks * 64], bh = pb_h[ks * 64], bl = pb_l[ks * 64];
+    MFMA_X3(ah, al, bh, bl, acc);
+  }
+  // D[i][i] sits in lane i + 32*((i>>2)&1), register (i&3) + 4*(i>>3)
+  if (((i >> 2) & 1) != half || p >= n_pairs) return;
+  const int reg = (i & 3) + 4 * (i >> 3);
+  float sc = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) sc = (r == reg) ? acc[r] : sc;
+  if (mode != 2) {
+    out[p] = erow >= 0 ? sc : 0.f;
+    return;
+  }
+  if (erow < 0) return;
+  float t = tgt[q];
+  if (sc > t) atomicSub(&ng[q], 1);
+  else if (sc == t) atomicSub(&ne[q], 1);
+}
+
+// CSR -> row id per entry, and the retirement of the target itself (scored == tgt, counted as "equal")
+__global__ void k_expand_rows_retire_target(const int64_t* __restrict__ indptr, int64_t B, const int64_t* __restrict__ e2,
+                                            const float* __restrict__ tgt, int64_t lo, int64_t n_local,
+                                            int32_t* __restrict__ row_of, int32_t* __restrict__ ne) {
+  int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t b = gid >> 4;
+  int sub = (int)(gid & 15);
+  if (b >= B) return;
+  for (int64_t i = indptr[b] + sub; i < indptr[b + 1]; i += 16) row_of[i] = (int32_t)b;
+  if (sub == 0) {
+    int64_t row = e2[b] - lo;
+    float t = tgt[b];
+    if (row >= 0 && row < n_local && t == t) atomicSub(&ne[b], 1);
+  }
+}
+
+static void pair_launch(coper_handle* h, int mode, int64_t n_pairs, int64_t B, int64_t L, const int64_t* e2,
+                        const int32_t* lookup, const int64_t* indptr, const int64_t* idx, const int32_t* row_of,
+                        const float* tgt, float* out, int32_t* ng, int32_t* ne, hipStream_t s) {
+  const Dims& dm = h->dm;
+  if (n_pairs <= 0) return;
+  hipLaunchKernelGGL(k_pair_bf16x3, dim3((unsigned)((n_pairs + 127) / 128)), dim3(256), 0, s, (const uint4*)h->Ef16_hi,
+                     (const uint4*)h->Ef16_lo, h->bias_pad, (const uint4*)h->hfrag16_hi, (const uint4*)h->hfrag16_lo,
+                     dm.KS16, mode, n_pairs, B, L, e2, lookup, indptr, idx, row_of, tgt, (int64_t)h->cfg.shard_lo,
+                     dm.n_local, out, ng, ne);
+}
+
+int launch_pair_targets_bf16x3(coper_handle* h, const float* hvec, const int64_t* e2, int64_t B, float* tgt,
+                               hipStream_t s) {
+  int rc = launch_pack_h_bf16(h, hvec, B, s);
+  if (rc) return rc;
+  pair_launch(h, 0, B, B, 1, e2, nullptr, nullptr, nullptr, nullptr, nullptr, tgt, nullptr, nullptr, s);
+  COPER_HIP_TRY(h, hipGetLastError());
+  return COPER_OK;
+}
+
+int launch_score_lookup_bf16x3(coper_handle* h, const float* hvec, const int32_t* lookup, int64_t B, int64_t L,
+                               float* out, hipStream_t s) {
+  int rc = launch_pack_h_bf16(h, hvec, B, s);
+  if (rc) return rc;
+  pair_launch(h, 1, B * L, B, L, nullptr, lookup, nullptr, nullptr, nullptr, nullptr, out, nullptr, nullptr, s);
+  COPER_HIP_TRY(h, hipGetLastError());
+  return COPER_OK;
+}
+
+int launch_filter_correct_bf16x3(coper_handle* h, const float* tgt, const int64_t* e2, const int64_t* indptr,
+                                 const int64_t* idx, int64_t nnz, int64_t B, int32_t* ng, int32_t* ne,
+                                 hipStream_t s) {
+  const Dims& dm = h->dm;
+  int64_t threads = B * 16;
+  hipLaunchKernelGGL(k_expand_rows_retire_target, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, indptr, B, e2,
+                     tgt, (int64_t)h->cfg.shard_lo, dm.n_local, h->row_of_ws, ne);
+  pair_launch(h, 2, nnz, B, 1, e2, nullptr, indptr, idx, h->row_of_ws, tgt, nullptr, ng, ne, s);
+  COPER_HIP_TRY(h, hipGetLastError());
+  return COPER_OK;
+}
+
+}  // namespace coper

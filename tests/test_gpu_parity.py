@@ -329,3 +329,72 @@ def test_topk_of_filtered_rows(oracle_chain):
     assert np.array_equal(tv.cpu().numpy(), ev) and np.array_equal(ti.cpu().numpy(), ei)
     for x in shards + [m, m2]:
         x.close()
+
+
+@pytest.mark.parametrize("name", ["plain", "cpg_fc", "cpg_conv_fc"])
+def test_bf16x3_mode_golden_fixture(golden_dir, oracle_chain, name):
+    """COPER_SCORE_BF16X3 (split-bf16 operands on the bf16 matrix cores): logits within 1e-3 of the fp64
+    oracle (measured ~1e-5); every kernel of the mode produces the same bits; fused ranks == the reference
+    ranker semantics on the mode's own logits; == the fp64 oracle's ranks outside the error band."""
+    O = oracle_chain
+    g, md, p, q = _fwd_case(golden_dir, name)
+    m = _model(md, p, score_mode="bf16x3")
+    h = m.encode(q["e1"], q["rel"])
+    assert np.abs(h.cpu().numpy() - g["f64:h"]).max() < H_TOL          # the encoder stays fp32-exact
+    logits = m.score_all(h).cpu().numpy()
+    err = np.abs(logits - g["f64:logits"]).max()
+    assert err < LOGIT_TOL and err < 2e-4
+    tgt = m.target_scores(h, q["e2"]).cpu().numpy()
+    assert np.array_equal(tgt, logits[np.arange(len(tgt)), q["e2"]])     # pair kernel == tile kernel, bit for bit
+    lookup = np.random.default_rng(1).integers(0, md["num_ent"], (len(q["e1"]), 9)).astype(np.int32)
+    assert np.array_equal(m.score_lookup(h, lookup).cpu().numpy(), np.take_along_axis(logits, lookup.astype(np.int64), axis=1))
+    ranks, ne = m.rank(h, q["e2"], q["filt_indptr"], q["filt_idx"])
+    ng_o, ne_o = O.rank_counts_c(logits, q["e2"], q["filt_indptr"], q["filt_idx"])
+    assert np.array_equal(ranks.cpu().numpy(), 1 + ng_o) and np.array_equal(ne.cpu().numpy(), ne_o)
+    safe = g["f64:min_gap"] > 2 * err + 1e-6
+    assert safe.mean() > 0.9
+    assert np.array_equal(ranks.cpu().numpy()[safe], 1 + g["f64:n_greater"][safe])
+    _, _, tv, ti = m.rank_counts(h, m.target_scores(h, q["e2"]), q["e2"], q["filt_indptr"], q["filt_idx"], k=5)
+    ev, ei = O.topk_filtered(logits, q["e2"], q["filt_indptr"], q["filt_idx"], 5)
+    assert np.array_equal(tv.cpu().numpy(), ev) and np.array_equal(ti.cpu().numpy(), ei)
+    m.close()
+
+
+def test_bf16x3_mode_full_size_and_sharded(oracle_chain):
+    """FB15k-237 full size in bf16x3: fused ranks == C restatement of the reference ranker on the mode's own
+    materialised logits; agreement with the fp32-exact mode's ranks except inside the ~1e-5 logit band;
+    two entity shards == unsharded."""
+    O = oracle_chain
+    from coper_amd.metrics import ranking_and_hits
+    md = cdata.model_descriptors("fb15k237_cpg")
+    p = cdata.synthetic_params(md, 0)
+    Q = 4096
+    q = cdata.synthetic_queries(md, Q, seed=0)
+    m = _model(md, p, score_mode="bf16x3")
+    mr, mrr, hits, ranks = ranking_and_hits(m, None, cdata.EvalDataset(q, 512, md["num_ent"]), "bf16x3", return_ranks=True)
+    h = m.encode(q["e1"], q["rel"])
+    logits = m.score_all(h).cpu().numpy()
+    ng, ne = O.rank_counts_c(logits, q["e2"], q["filt_indptr"], q["filt_idx"])
+    assert np.array_equal(ranks, 1 + ng)
+    m32 = _model(md, p)
+    _, _, _, ranks32 = ranking_and_hits(m32, None, cdata.EvalDataset(q, 512, md["num_ent"]), "f32", return_ranks=True)
+    lg32 = m32.score_all(m32.encode(q["e1"], q["rel"])).cpu().numpy()
+    err = np.abs(logits - lg32).max()
+    assert err < 2e-4
+    diff = ranks != ranks32
+    # ~1650 competitors per unit of logit around a typical target: a +-err band moves a few % of the ranks by 1
+    assert diff.mean() < 0.25 and np.abs(ranks - ranks32).max() <= 5, (diff.mean(), np.abs(ranks - ranks32).max(), err)
+    mrr32, mrr16 = np.mean(1.0 / ranks32), np.mean(1.0 / ranks)
+    assert abs(mrr32 - mrr16) < 1e-4 * max(mrr32, 1e-3) + 1e-6
+    assert abs(np.mean(ranks <= 10) - np.mean(ranks32 <= 10)) < 2e-3
+    # every disagreement is a competitor within the error band of the target
+    t32 = lg32[np.arange(Q), q["e2"]]
+    for b in np.nonzero(diff)[0]:
+        assert (np.abs(lg32[b] - t32[b]) < 2 * err).sum() >= 2
+    shards = [_model(md, p, shard=(0, 7000), score_mode="bf16x3"), _model(md, p, shard=(7000, md["num_ent"]), score_mode="bf16x3")]
+    tgt = sum(s_.target_scores(h, q["e2"]) for s_ in shards)
+    assert np.array_equal(tgt.cpu().numpy(), m.target_scores(h, q["e2"]).cpu().numpy())
+    ngs = sum(s_.rank_counts(h, tgt, q["e2"], q["filt_indptr"], q["filt_idx"])[0] for s_ in shards)
+    assert np.array_equal((1 + ngs).cpu().numpy(), ranks)
+    for x in shards + [m, m32]:
+        x.close()
