@@ -56,7 +56,7 @@ def parse_args():
     ap.add_argument("--order", choices=["shuffled", "sorted"], default="shuffled")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--score-mode", choices=["f32", "bf16x3"], default="f32")
+    ap.add_argument("--score-mode", choices=["f32", "bf16x3"], default="bf16x3")
     return ap.parse_args()
 
 
@@ -185,7 +185,7 @@ def main():
             "metric": "scored triples/sec (1-vs-all)", "value": units / dt, "unit": "triples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if entity_mode else "weak", "vs_baseline": None,
-            "dtype": "f32" if args.score_mode == "f32" else "bf16x3 (split bf16 operands, fp32 accumulate; dense layer f32)",
+            "dtype": "f32" if args.score_mode == "f32" else "bf16x3 (fp32 values split into two bf16 terms, 3 bf16 MFMAs per product, fp32 accumulate)",
             "data": "synthetic",
             "config": {"workload": "%s: |E|=%d R2=%d d=%d r=%d, Q=%d queries/pass%s, %s relation order" % (
                 args.workload, md["num_ent"], md["num_rel"], d, md["rel_emb_size"], Q,
@@ -195,16 +195,46 @@ def main():
                 "bf16x3 (3 x v_mfma_f32_32x32x16_bf16 per product, ~2^-16 rel.)", "prepare_ms": round(prepare_ms, 2),
                 "mean_rank": float(np.mean(ranks_np)), "mrr": float(np.mean(1.0 / ranks_np))},
         }
+        F = model.fc_input_size
+        kinfo = {}
         if kern["score_count"]:
-            flops = 2.0 * Q * n_local * d          # ALGORITHMIC flops of one score_count launch
-            ach = flops / (kern["score_count"] * 1e-3) / 1e12
+            fl = 2.0 * Q * n_local * d           # ALGORITHMIC flops of one score_count launch
             peak = PEAK_F32_MFMA_TFLOPS if args.score_mode == "f32" else PEAK_BF16_MFMA_TFLOPS
-            out["roofline"] = {"kernel": "k_score_count_f32" if args.score_mode == "f32" else "k_score_count_bf16x3",
-                               "bound": "mfma", "achieved": ach, "peak": peak,
-                               "unit": "TFLOP/s", "frac": ach / peak,
-                               "traffic": pmc_traffic(args.workload, Q, "coper::k_score_count_f32") if (world == 1 and args.score_mode == "f32") else None,
-                               "avg_launch_ms": kern["score_count"],
-                               "other_kernels_ms": {k: v for k, v in kern.items() if k != "score_count"}}
+            ach = fl / (kern["score_count"] * 1e-3) / 1e12
+            kname = "k_score_count_f32" if args.score_mode == "f32" else "k_score_count_bf16x3"
+            kinfo[kname] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                            "avg_launch_ms": kern["score_count"],
+                            "traffic": pmc_traffic(args.workload, Q, "coper::" + kname) if world == 1 else None}
+            if args.score_mode != "f32":
+                kinfo[kname]["note"] = "3 hardware bf16 MFMAs per algorithmic product: hardware MFMA utilisation = 3 x frac"
+        if kern["dense"]:
+            fl = 2.0 * Q * F * d                 # ALGORITHMIC flops of the dense launch pair (small + big tiles)
+            if args.score_mode == "f32":
+                ach = fl / (kern["dense"] * 1e-3) / 1e12
+                kinfo["k_dense_big_f32"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                            "frac": ach / PEAK_F32_MFMA_TFLOPS, "avg_launch_ms": kern["dense"],
+                                            "traffic": pmc_traffic(args.workload, Q, "coper::k_dense_big_f32<13>") if world == 1 else None}
+            else:
+                # ALGORITHMIC bytes (cached per-relation weights): G weight streams (one per
+                # relation tile of <= 128 queries) of F*d values in two bf16 planes + x in two bf16 planes + z out
+                cnt = np.bincount(q["rel"]) if md.get("context_rel_out", None) is not None else np.array([Q])
+                G = int(np.sum((cnt[cnt > 0] + 127) // 128))
+                by = G * F * d * 4.0 + Q * F * 4.0 + Q * d * 4.0
+                ach = by / (kern["dense"] * 1e-3) / 1e9
+                kinfo["k_dense_big_bf16x3"] = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                               "frac": ach / PEAK_HBM_GBS, "avg_launch_ms": kern["dense"],
+                                               "algorithmic_bytes": by, "algorithmic_tflops": fl / (kern["dense"] * 1e-3) / 1e12,
+                                               "traffic": pmc_traffic(args.workload, Q, "coper::k_dense_big_bf16x3<13>") if world == 1 else None}
+        if kern["conv"]:
+            by = Q * (F * 4.0 + d * 4.0)         # ALGORITHMIC bytes: x written (fp32 or two bf16 planes) + e1 row read
+            ach = by / (kern["conv"] * 1e-3) / 1e9
+            kinfo["k_conv3x3_bn_relu" if args.score_mode == "f32" else "k_conv3x3_bn_relu_bf16"] = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                          "frac": ach / PEAK_HBM_GBS, "avg_launch_ms": kern["conv"],
+                                          "traffic": pmc_traffic(args.workload, Q, "coper::k_conv3x3_bn_relu<4>" if args.score_mode == "f32" else "coper::k_conv3x3_bn_relu_bf16<4>") if world == 1 else None}
+        if kinfo:
+            dom = max(kinfo, key=lambda k: kinfo[k]["avg_launch_ms"])   # the dominant kernel of the step
+            out["roofline"] = dict(kernel=dom, **kinfo[dom])
+            out["roofline"]["all_kernels"] = {k: {kk: vv for kk, vv in v.items() if kk != "note"} for k, v in kinfo.items() if k != dom}
         if not args.no_cpu_baseline and world == 1:
             host_p = {k: (v.cpu().numpy() if hasattr(v, "cpu") else v) for k, v in params.items()} if not big else None
             if host_p is not None:

@@ -10,7 +10,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libcoper_hip.so")
-SOURCES = ["coper_abi.hip", "kernels_prepare.hip", "kernels_encode.hip", "kernels_score.hip", "kernels_score_bf16.hip"]
+SOURCES = ["coper_abi.hip", "kernels_prepare.hip", "kernels_encode.hip", "kernels_score.hip", "kernels_score_bf16.hip",
+           "kernels_encode_bf16.hip"]
 
 
 def _hipcc():

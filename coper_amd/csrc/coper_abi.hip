@@ -179,7 +179,7 @@ COPER_API int coper_create(const coper_config* cfg, coper_handle** out) {
   if (dm.Ho <= 0 || dm.Wo <= 0) return bad("conv filter larger than the image");
   dm.F_conv = (int64_t)dm.Ho * dm.Wo * dm.C;
   dm.F = dm.F_conv + (dm.concat_rel ? dm.r : 0);
-  dm.F_pad = (dm.F + 15) / 16 * 16;
+  dm.F_pad = (dm.F + 31) / 32 * 32;
   dm.d_pad16 = (dm.d + 15) / 16 * 16; dm.nfb = dm.d_pad16 / 16;
   dm.d_pad8 = (dm.d + 7) / 8 * 8; dm.KS = dm.d_pad8 / 8;
   dm.KS16 = (dm.d + 15) / 16;
@@ -233,6 +233,7 @@ COPER_API void coper_destroy(coper_handle* h) {
   dev_free(&h->rel_count); dev_free(&h->rel_offset); h->rel_cursor = nullptr; dev_free(&h->perm);
   dev_free(&h->tiles); dev_free(&h->n_tiles); dev_free(&h->blk_off); dev_free(&h->x_sorted); dev_free(&h->z_part);
   dev_free(&h->tgt_ws); dev_free(&h->cnt_ws); dev_free(&h->hfrag_ws); dev_free(&h->logits_ws); dev_free(&h->row_of_ws);
+  dev_free((char**)&h->Wf16_hi); dev_free((char**)&h->Wf16_lo);
   dev_free((char**)&h->Ef16_hi); dev_free((char**)&h->Ef16_lo); dev_free((char**)&h->hfrag16_hi); dev_free((char**)&h->hfrag16_lo);
   for (auto& kv : h->timers)
     for (auto& p : kv.second.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
@@ -382,6 +383,16 @@ COPER_API int coper_prepare(coper_handle* h, void* stream) {
   } else {
     if ((rc = launch_gen_dense_frag(h, nullptr, 1, 0, P("fc_weights"), 1, h->Wf, s))) return rc;
   }
+  h->enc_bf16 = cfg.score_mode != COPER_SCORE_F32 && conv_bf16_supported(dm);
+  if (h->enc_bf16) {
+    size_t plane = (size_t)h->Rw * dm.nfb * (dm.F_pad / 32) * 64 * 16;
+    dev_free((char**)&h->Wf16_hi); dev_free((char**)&h->Wf16_lo);
+    if (hipMalloc(&h->Wf16_hi, plane) != hipSuccess || hipMalloc(&h->Wf16_lo, plane) != hipSuccess)
+      return fail(h, COPER_ENOMEM, "hipMalloc of the bf16 weight planes failed");
+    if ((rc = launch_wfrag_to_bf16(h, h->Wf, h->Rw, h->Wf16_hi, h->Wf16_lo, s))) return rc;
+    COPER_HIP_TRY(h, hipStreamSynchronize(s));
+    dev_free(&h->Wf);  // the fp32 image was only the staging form
+  }
   // entity table image(s)
   if (cfg.score_mode == COPER_SCORE_F32) {
     if ((rc = dev_alloc(h, &h->Ef, (size_t)dm.n_eblk * dm.KS * 64 * 4)) || (rc = dev_alloc(h, &h->bias_pad, (size_t)dm.n_eblk * 32)))
@@ -445,6 +456,11 @@ COPER_API int coper_encode(coper_handle* h, const int64_t* e1, const int64_t* re
   int ksplit = ksteps >= 64 ? 4 : 1;  // DENSE_KSLICES
   if (ksplit > h->ws_ksplit) ksplit = h->ws_ksplit;
   if ((rc = launch_group_by_relation(h, rel, B, tq, s))) return rc;
+  if (h->enc_bf16) {
+    if ((rc = launch_conv_bf16(h, e1, rel, e1_rows, B, s))) return rc;
+    if ((rc = launch_dense_bf16(h, B, ksplit, s))) return rc;
+    return launch_dense_finalize(h, rel, B, ksplit, h_out, s);
+  }
   if ((rc = launch_conv(h, e1, rel, e1_rows, B, s))) return rc;
   return launch_dense(h, rel, B, tq, ksplit, h_out, s);
 }

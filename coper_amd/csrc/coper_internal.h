@@ -30,7 +30,7 @@ struct Dims {
   int in_h = 0, in_w = 0, Ho = 0, Wo = 0;
   int64_t F_conv = 0, F = 0;
   // padded sizes used by the MFMA layouts
-  int64_t F_pad = 0;   // F rounded up to 16 (one 16x16x4 super-step = 16 f)
+  int64_t F_pad = 0;   // F rounded up to 32 (two 16x16x4 f32 super-steps = one 16x16x32 bf16 k-step)
   int d_pad16 = 0;     // d rounded up to 16 (feature blocks of the dense layer)
   int nfb = 0;         // d_pad16 / 16
   int d_pad8 = 0;      // d rounded up to 8 (k-steps of the score kernels)
@@ -70,6 +70,9 @@ struct coper_handle {
   int64_t Rw = 0;               // R when gen_fc else 1
   float* Ef = nullptr;          // entity table, fragment-major: [n_eblk][KS][64] float4
   float* bias_pad = nullptr;    // [n_eblk*32], -inf padded
+  void* Wf16_hi = nullptr;      // COPER_SCORE_BF16X3: dense weights as hi / lo bf16 planes (16x16x32 fragment order)
+  void* Wf16_lo = nullptr;
+  bool enc_bf16 = false;        // encoder runs in bf16x3 (needs 3x3 filters, C % 8 == 0)
   void* Ef16_hi = nullptr;      // COPER_SCORE_BF16X3: entity table hi / lo bf16 planes, fragment-major
   void* Ef16_lo = nullptr;      //   [n_eblk][KS16][64] x 16 B
   float* ctx_tmp[2] = {nullptr, nullptr};  // generator hidden activations
@@ -162,6 +165,13 @@ int launch_filter_correct_bf16x3(coper_handle* h, const float* tgt, const int64_
                                  const int64_t* idx, int64_t nnz, int64_t B, int32_t* ng, int32_t* ne,
                                  hipStream_t s);
 int score_bf16_kernels_init(coper_handle* h);
+// kernels_encode_bf16.hip
+bool conv_bf16_supported(const Dims& dm);
+int launch_wfrag_to_bf16(coper_handle* h, const float* Wf, int64_t Rw, void* hi, void* lo, hipStream_t s);
+int launch_conv_bf16(coper_handle* h, const int64_t* e1, const int64_t* rel, const float* e1_rows, int64_t B,
+                     hipStream_t s);
+int launch_dense_bf16(coper_handle* h, int64_t B, int nslices, hipStream_t s);
+int launch_dense_finalize(coper_handle* h, const int64_t* rel, int64_t B, int ksplit, float* h_out, hipStream_t s);
 int score_all_dispatch(coper_handle* h, const float* hvec, int64_t B, float* logits, int64_t ld, hipStream_t s);
 int launch_bias_pad(coper_handle* h, const float* bias, hipStream_t s);
 int launch_topk(coper_handle* h, const float* hvec, const int64_t* e2, const int64_t* indptr, const int64_t* idx,

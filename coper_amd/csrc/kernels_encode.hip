@@ -670,6 +670,11 @@ int launch_dense(coper_handle* h, const int64_t* rel, int64_t B, int tq, int ksp
     else dense_launch<8>(h, B, ksplit, (nfb + 7) / 8, s);
     COPER_HIP_TRY(h, hipGetLastError());
   }
+  return launch_dense_finalize(h, rel, B, ksplit, h_out, s);
+}
+
+int launch_dense_finalize(coper_handle* h, const int64_t* rel, int64_t B, int ksplit, float* h_out, hipStream_t s) {
+  const Dims& dm = h->dm;
   const float* fcb = dm.gen_fc ? h->fc_b_rel : h->params["fc_bias"].ptr;
   int64_t total = B * dm.d;
   hipLaunchKernelGGL(k_dense_finalize, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, h->z_part, ksplit,

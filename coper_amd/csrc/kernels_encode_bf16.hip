@@ -1,0 +1,467 @@
+// COPER_SCORE_BF16X3 encoder: the conv stage writes x as two bf16 planes (hi / lo split of the fp32
+// activation, kernels_score_bf16.hip header), the generated-dense layer runs on v_mfma_f32_16x16x32_bf16
+// with the split product  lo*hi + hi*lo + hi*hi  (3 MFMAs per 32 k at the bf16 rate instead of 8 exact-f32
+// MFMAs: 5.3x the matrix throughput), fp32 accumulation, fp32 z / h.  With the matrix time out of the way
+// the layer is bound by the one pass over the per-relation weight cache (HBM).
+//
+// Same decomposition as kernels_encode.hip: fixed K slices (a function of F only), one accumulator chain
+// per (query, feature, slice) whichever kernel produces it, slices summed in order by k_dense_finalize:
+// h[b] stays a pure function of (e1[b], rel[b]).
+//
+//   A operand (features on rows):  lane l holds 8 bf16 W[f = 32ks + 8(l>>4) + j][feat = 16fb + (l&15)]
+//   B operand (queries on columns): lane l holds 8 bf16 x[q = l&15][f = 32ks + 8(l>>4) + j]
+//   D: col = lane&15 (query), row = 4(lane>>4) + reg (feature).
+#include "coper_internal.h"
+
+namespace coper {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned short bf16_rne_e(float x) {
+  unsigned u = __float_as_uint(x);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+  return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ float bf16_f32_e(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
+
+__device__ __forceinline__ void split8_e(const float* v, uint4& hi, uint4& lo) {
+  // plain casts: hipcc emits v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN stays NaN)
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  unsigned hw[4], lw[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    bf16x2_t hp = {(__bf16)v[2 * j], (__bf16)v[2 * j + 1]};
+    float r0 = v[2 * j] - (float)hp[0], r1 = v[2 * j + 1] - (float)hp[1];
+    bf16x2_t lp = {(__bf16)r0, (__bf16)r1};
+    hw[j] = __builtin_bit_cast(unsigned, hp);
+    lw[j] = __builtin_bit_cast(unsigned, lp);
+  }
+  hi = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+  lo = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+}
+
+#define MFMA16_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&(a), *(const bf16x8*)&(b), (c), 0, 0, 0)
+#define MFMA16_X3(ahi, alo, bhi, blo, c) \
+  { (c) = MFMA16_BF16(alo, bhi, c); (c) = MFMA16_BF16(ahi, blo, c); (c) = MFMA16_BF16(ahi, bhi, c); }
+
+// ------------------------------------------------------------------------------------------------
+// prepare: fp32 fragment image Wf (v_mfma_f32_16x16x4 layout, built by k_gen_dense_frag / k_dense_frag_copy)
+// -> two bf16 planes in the 16x16x32 layout:  W16[(rel*nfb + fb)*ks32n + ks][lane] = 8 bf16.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_wfrag_to_bf16(const float4* __restrict__ Wf, int64_t n_relfb, int64_t ks32n,
+                                                       uint4* __restrict__ hi, uint4* __restrict__ lo) {
+  int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (relfb*ks32n + ks)*64 + lane
+  if (j >= n_relfb * ks32n * 64) return;
+  int l = (int)(j & 63);
+  int64_t rest = j >> 6;
+  int64_t ks = rest % ks32n;
+  int64_t relfb = rest / ks32n;
+  // target f = 32ks + 8(l>>4) + jj  ->  source k-step 2ks + (l>>5), k-groups g = 2((l>>4)&1), g+1, feature lane l&15
+  int64_t ks16 = 2 * ks + (l >> 5);
+  int g = 2 * ((l >> 4) & 1);
+  const float4* src = Wf + (relfb * (2 * ks32n) + ks16) * 64 + (l & 15);
+  float4 a = src[16 * g], b = src[16 * (g + 1)];
+  float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  uint4 h4, l4;
+  split8_e(v, h4, l4);
+  hi[j] = h4;
+  lo[j] = l4;
+}
+
+int launch_wfrag_to_bf16(coper_handle* h, const float* Wf, int64_t Rw, void* hi, void* lo, hipStream_t s) {
+  const Dims& dm = h->dm;
+  int64_t ks32n = dm.F_pad / 32;
+  int64_t total = Rw * dm.nfb * ks32n * 64;
+  hipLaunchKernelGGL(k_wfrag_to_bf16, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float4*)Wf,
+                     Rw * dm.nfb, ks32n, (uint4*)hi, (uint4*)lo);
+  COPER_HIP_TRY(h, hipGetLastError());
+  return COPER_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv + BN + ReLU -> x planes.  3x3 filters, C a multiple of 8.  lane = (pixel of a 16-pixel group,
+// channel octet): 72 taps (9 x 8 channels) in registers, 9 LDS reads of the image per pixel (shared by the
+// octet lanes), 72 FMAs, and one 16-B store per plane; a wave-store is 16 pixels x 64 B = 1 KiB contiguous.
+// ------------------------------------------------------------------------------------------------
+template <int QPB>
+__global__ __launch_bounds__(256) void k_conv3x3_bn_relu_bf16(
+    const int64_t* __restrict__ e1, const int64_t* __restrict__ rel, const float* __restrict__ e1_rows,
+    const int32_t* __restrict__ perm, const float* __restrict__ ent, int64_t shard_lo, int64_t n_local,
+    const float* __restrict__ rel_emb, const float* __restrict__ conv_w, const float* __restrict__ conv_b,
+    int per_rel_conv, const float* __restrict__ scale, const float* __restrict__ shift, int d, int r, int in_h,
+    int in_w, int stacked, int C, int Ho, int Wo, int concat_rel, int64_t F, int64_t F_pad, int64_t R, int64_t B,
+    unsigned short* __restrict__ x_hi, unsigned short* __restrict__ x_lo) {
+  extern __shared__ float lds[];  // img[QPB][in_h*in_w]
+  const int img_sz = in_h * in_w;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t pos0 = (int64_t)blockIdx.x * QPB;
+  int64_t rids[QPB];
+#pragma unroll
+  for (int qq = 0; qq < QPB; ++qq) {
+    int64_t pos = pos0 + qq;
+    rids[qq] = 0;
+    if (pos >= B) continue;
+    int64_t q = perm[pos];
+    int64_t rid = rel[q];
+    if (rid < 0 || rid >= R) rid = 0;
+    rids[qq] = rid;
+    float* img = lds + qq * img_sz;
+    for (int k = threadIdx.x; k < d; k += 256) {
+      float v;
+      if (e1_rows) {
+        v = e1_rows[q * d + k];
+      } else {
+        int64_t row = e1[q] - shard_lo;
+        v = (row >= 0 && row < n_local) ? ent[row * d + k] : 0.f;
+      }
+      img[k] = v;
+    }
+    if (stacked)
+      for (int k = threadIdx.x; k < r; k += 256) img[d + k] = rel_emb[rid * r + k];
+  }
+  __syncthreads();
+  const int noct = C >> 3;                 // channel octets per pixel
+  const int ppg = 64 / noct;               // pixels per wave-group (16 for C = 32)
+  const int pl = lane / noct, oc = lane % noct;
+  const int npix = Ho * Wo;
+  float tap[9][8], kb[8], sc[8], sh[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) { sc[c] = scale[8 * oc + c]; sh[c] = shift[8 * oc + c]; }
+  int64_t tap_rid = -1;
+#pragma unroll
+  for (int qq = 0; qq < QPB; ++qq) {
+    int64_t pos = pos0 + qq;
+    if (pos >= B) break;
+    const int64_t rid = per_rel_conv ? rids[qq] : 0;
+    if (rid != tap_rid) {  // workgroup-uniform
+      const float* wsrc = per_rel_conv ? conv_w + rid * (int64_t)(9 * C) : conv_w;
+      const float* bsrc = per_rel_conv ? conv_b + rid * (int64_t)C : conv_b;
+#pragma unroll
+      for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) tap[k][c] = wsrc[k * C + 8 * oc + c];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) kb[c] = bsrc[8 * oc + c];
+      tap_rid = rid;
+    }
+    const float* img = lds + qq * img_sz;
+    unsigned short* xh = x_hi + pos * F_pad;
+    unsigned short* xl = x_lo + pos * F_pad;
+    int p = wave * ppg + pl;
+    int i = p / Wo, j = p - i * Wo;             // one division per query; then (i, j) advance by 4*ppg pixels
+    const int di = (4 * ppg) / Wo, dj = (4 * ppg) - di * Wo;
+    for (; p < npix; p += 4 * ppg, i += di, j += dj) {
+      if (j >= Wo) { j -= Wo; ++i; }
+      {
+        const float* r0 = img + i * in_w + j;
+        float w[9] = {r0[0], r0[1], r0[2], r0[in_w], r0[in_w + 1], r0[in_w + 2],
+                      r0[2 * in_w], r0[2 * in_w + 1], r0[2 * in_w + 2]};
+        float y[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          float a = 0.f;
+#pragma unroll
+          for (int k = 0; k < 9; ++k) a = fmaf(w[k], tap[k][c], a);
+          a += kb[c];
+          a = fmaf(a, sc[c], sh[c]);
+          y[c] = fmaxf(a, 0.f);
+        }
+        uint4 h4, l4;
+        split8_e(y, h4, l4);
+        *(uint4*)(xh + (int64_t)p * C + 8 * oc) = h4;
+        *(uint4*)(xl + (int64_t)p * C + 8 * oc) = l4;
+      }
+    }
+  }
+  // tail of each row: concat_rel columns and the zero padding up to F_pad
+#pragma unroll
+  for (int qq = 0; qq < QPB; ++qq) {
+    int64_t pos = pos0 + qq;
+    if (pos >= B) break;
+    int64_t Fc = (int64_t)npix * C;
+    unsigned short* xh = x_hi + pos * F_pad;
+    unsigned short* xl = x_lo + pos * F_pad;
+    if (concat_rel)
+      for (int k = threadIdx.x; k < r; k += 256) {
+        float v = rel_emb[rids[qq] * r + k];
+        unsigned short hb = bf16_rne_e(v);
+        xh[Fc + k] = hb;
+        xl[Fc + k] = bf16_rne_e(v - bf16_f32_e(hb));
+      }
+    for (int64_t k = F + threadIdx.x; k < F_pad; k += 256) { xh[k] = 0; xl[k] = 0; }
+  }
+}
+
+bool conv_bf16_supported(const Dims& dm) { return dm.fh == 3 && dm.fw == 3 && dm.C % 8 == 0 && 64 % (dm.C / 8) == 0; }
+
+int launch_conv_bf16(coper_handle* h, const int64_t* e1, const int64_t* rel, const float* e1_rows, int64_t B,
+                     hipStream_t s) {
+  const Dims& dm = h->dm;
+  const float* rel_emb = dm.lookup ? nullptr : h->params["rel_emb"].ptr;
+  const float* cw = dm.gen_conv ? h->conv_w_rel : h->params["conv1_weights"].ptr;
+  const float* cb = dm.gen_conv ? h->conv_b_rel : h->params["conv1_bias"].ptr;
+  constexpr int QPB = 4;
+  size_t lds = sizeof(float) * (size_t)QPB * dm.in_h * dm.in_w;
+  unsigned short* xh = (unsigned short*)h->x_sorted;
+  unsigned short* xl = xh + (size_t)h->ws_queries * dm.F_pad;
+  ScopedKernelTimer t(h, "conv", s);
+  hipLaunchKernelGGL((k_conv3x3_bn_relu_bf16<QPB>), dim3((unsigned)((B + QPB - 1) / QPB)), dim3(256), lds, s, e1, rel,
+                     e1_rows, h->perm, h->params["ent_emb"].ptr, (int64_t)h->cfg.shard_lo, dm.n_local, rel_emb, cw, cb,
+                     dm.gen_conv ? 1 : 0, h->conv_scale, h->conv_shift, dm.d, dm.r, dm.in_h, dm.in_w,
+                     dm.stacked ? 1 : 0, dm.C, dm.Ho, dm.Wo, dm.concat_rel ? 1 : 0, dm.F, dm.F_pad, dm.R, B, xh, xl);
+  COPER_HIP_TRY(h, hipGetLastError());
+  return COPER_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// dense, tiles of <= 32 queries: one wave per K slice, weights streamed from the planes into VGPRs.
+// ------------------------------------------------------------------------------------------------
+template <int NFB>
+__global__ __launch_bounds__(256) void k_dense_small_bf16x3(const uint4* __restrict__ Whi, const uint4* __restrict__ Wlo,
+                                                            const unsigned short* __restrict__ x_hi,
+                                                            const unsigned short* __restrict__ x_lo,
+                                                            const int32_t* __restrict__ tiles,
+                                                            const int32_t* __restrict__ n_tiles, int nfb, int64_t ks32n,
+                                                            int64_t F_pad, int nslices, int64_t Bcap, int d_pad16,
+                                                            float* __restrict__ z_part) {
+  constexpr int NQ = 2;
+  int tile = blockIdx.x;
+  if (tile >= n_tiles[0]) return;
+  const int fb0 = blockIdx.z * NFB;
+  const int64_t relw = __builtin_amdgcn_readfirstlane(tiles[4 * tile + 0]);
+  const int start = __builtin_amdgcn_readfirstlane(tiles[4 * tile + 1]);
+  const int n = __builtin_amdgcn_readfirstlane(tiles[4 * tile + 2]);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int slice = blockIdx.y * 4 + wave;
+  if (slice >= nslices) return;
+  const int64_t kb = ks32n * slice / nslices, ke = ks32n * (slice + 1) / nslices;
+  f32x4 acc[NFB][NQ];
+#pragma unroll
+  for (int a = 0; a < NFB; ++a)
+#pragma unroll
+    for (int b = 0; b < NQ; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int64_t woff[NFB];
+#pragma unroll
+  for (int a = 0; a < NFB; ++a) {
+    int fb = fb0 + a < nfb ? fb0 + a : nfb - 1;
+    woff[a] = ((relw * nfb + fb) * ks32n) * 64 + lane;
+  }
+  int64_t xoff[NQ];
+#pragma unroll
+  for (int b = 0; b < NQ; ++b) {
+    int qi = b * 16 + (lane & 15);
+    if (qi > n - 1) qi = n - 1;
+    xoff[b] = (int64_t)(start + qi) * F_pad + 8 * (lane >> 4);
+  }
+  const bool second = n > 16;
+  for (int64_t ks = kb; ks < ke; ++ks) {
+    uint4 ah[NFB], al[NFB], bh[NQ], bl[NQ];
+#pragma unroll
+    for (int a = 0; a < NFB; ++a) { ah[a] = Whi[woff[a] + ks * 64]; al[a] = Wlo[woff[a] + ks * 64]; }
+#pragma unroll
+    for (int b = 0; b < NQ; ++b) {
+      bh[b] = *(const uint4*)(x_hi + xoff[b] + 32 * ks);
+      bl[b] = *(const uint4*)(x_lo + xoff[b] + 32 * ks);
+    }
+#pragma unroll
+    for (int a = 0; a < NFB; ++a) {
+      MFMA16_X3(ah[a], al[a], bh[0], bl[0], acc[a][0]);
+      if (second) MFMA16_X3(ah[a], al[a], bh[1], bl[1], acc[a][1]);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < NFB; ++a) {
+    if (fb0 + a >= nfb) continue;
+#pragma unroll
+    for (int b = 0; b < NQ; ++b) {
+      int qi = b * 16 + (lane & 15);
+      if (qi < n) {
+        float* dst = z_part + ((int64_t)slice * Bcap + start + qi) * d_pad16 + (fb0 + a) * 16 + 4 * (lane >> 4);
+        *(float4*)dst = make_float4(acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dense, tiles of 33..128 queries: 4 waves share the weight and x planes through an LDS ring filled by
+// LDS-DMA (same item-balanced structure as dense_big_body in kernels_encode.hip).
+// ------------------------------------------------------------------------------------------------
+template <int NFB, int NB>
+__device__ __forceinline__ void dense_big_body_bf16(uint4* __restrict__ ring, const uint4* __restrict__ Whi,
+                                                    const uint4* __restrict__ Wlo,
+                                                    const unsigned short* __restrict__ x_hi,
+                                                    const unsigned short* __restrict__ x_lo, int64_t relw, int start,
+                                                    int n, int fb0, int nfb, int64_t ks32n, int64_t F_pad, int64_t kb,
+                                                    int64_t ke, float* __restrict__ zdst, int d_pad16) {
+  constexpr int NSLOT = 2 * NFB + 2 * NB;  // W hi | W lo | x hi | x lo
+  constexpr int L = (NSLOT + 3) / 4;
+  constexpr int STAGE = 4 * L * 64;        // uint4 per ring stage
+  constexpr int NSTAGE = 3;
+  constexpr int T = NFB * NB;
+  constexpr int MAXI = (T + 3) / 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int i0 = T * wave / 4, cnt = T * (wave + 1) / 4 - i0;
+  const char* src[L];
+  int stride[L];
+#pragma unroll
+  for (int i = 0; i < L; ++i) {
+    int sl = wave + 4 * i;
+    if (sl >= NSLOT) sl = wave;
+    if (sl < 2 * NFB) {
+      int plane = sl >= NFB;
+      int fbi = sl - plane * NFB;
+      int fb = fb0 + fbi < nfb ? fb0 + fbi : nfb - 1;
+      const uint4* base = plane ? Wlo : Whi;
+      src[i] = (const char*)(base + ((relw * nfb + fb) * ks32n + kb) * 64 + lane);
+      stride[i] = 1024;
+    } else {
+      int xs = sl - 2 * NFB;
+      int plane = xs >= NB;
+      int qb = xs - plane * NB;
+      int qi = qb * 16 + (lane & 15);
+      if (qi > n - 1) qi = n - 1;
+      const unsigned short* base = plane ? x_lo : x_hi;
+      src[i] = (const char*)(base + (int64_t)(start + qi) * F_pad + 32 * kb + 8 * (lane >> 4));
+      stride[i] = 64;
+    }
+  }
+#define STAGE_ISSUE(buf, kk)                                                                                      \
+  {                                                                                                               \
+    uint4* dstb = ring + (buf)*STAGE;                                                                             \
+    _Pragma("unroll") for (int i = 0; i < L; ++i) __builtin_amdgcn_global_load_lds(                               \
+        (const __attribute__((address_space(1))) void*)(src[i] + (int64_t)(kk)*stride[i]),                        \
+        (__attribute__((address_space(3))) void*)(dstb + (wave + 4 * i) * 64), 16, 0, 0);                         \
+  }
+  int offA[MAXI], offB[MAXI];
+#pragma unroll
+  for (int i = 0; i < MAXI; ++i) {
+    int item = cnt > 0 ? i0 + (i < cnt ? i : cnt - 1) : 0;
+    offA[i] = (item / NB) * 64 + lane;                 // W hi slot; W lo = + NFB*64
+    offB[i] = (2 * NFB + item % NB) * 64 + lane;       // x hi slot; x lo = + NB*64
+  }
+  f32x4 acc[MAXI];
+#pragma unroll
+  for (int i = 0; i < MAXI; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int nk = (int)(ke - kb);
+#pragma unroll
+  for (int st = 0; st < NSTAGE - 1; ++st) STAGE_ISSUE(st, st < nk ? st : nk - 1);
+  int cur = 0, nxt = NSTAGE - 1;
+  for (int k = 0; k < nk; ++k) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * L) : "memory");  // stage k landed; younger stages fly
+    __builtin_amdgcn_s_barrier();
+    {
+      int kk = k + NSTAGE - 1 < nk ? k + NSTAGE - 1 : nk - 1;
+      STAGE_ISSUE(nxt, kk);
+    }
+    const uint4* ab = ring + cur * STAGE;
+    constexpr int GI = 4;
+#pragma unroll
+    for (int g = 0; g < MAXI; g += GI) {
+      uint4 ah[GI], al[GI], bh[GI], bl[GI];
+#pragma unroll
+      for (int j = 0; j < GI; ++j)
+        if (g + j < MAXI) {
+          ah[j] = ab[offA[g + j]];
+          al[j] = ab[offA[g + j] + NFB * 64];
+          bh[j] = ab[offB[g + j]];
+          bl[j] = ab[offB[g + j] + NB * 64];
+        }
+#pragma unroll
+      for (int j = 0; j < GI; ++j)
+        if (g + j < MAXI) acc[g + j] = MFMA16_BF16(al[j], bh[j], acc[g + j]);
+#pragma unroll
+      for (int j = 0; j < GI; ++j)
+        if (g + j < MAXI) acc[g + j] = MFMA16_BF16(ah[j], bl[j], acc[g + j]);
+#pragma unroll
+      for (int j = 0; j < GI; ++j)
+        if (g + j < MAXI) acc[g + j] = MFMA16_BF16(ah[j], bh[j], acc[g + j]);
+    }
+    cur = cur == NSTAGE - 1 ? 0 : cur + 1;
+    nxt = nxt == NSTAGE - 1 ? 0 : nxt + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef STAGE_ISSUE
+#pragma unroll
+  for (int i = 0; i < MAXI; ++i) {
+    if (i >= cnt) continue;
+    int item = i0 + i;
+    int fb = fb0 + item / NB, qb = item % NB;
+    int qi = qb * 16 + (lane & 15);
+    if (fb < nfb && qi < n) {
+      float* dst = zdst + (int64_t)(start + qi) * d_pad16 + fb * 16 + 4 * (lane >> 4);
+      *(float4*)dst = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+    }
+  }
+}
+
+template <int NFB>
+__global__ __launch_bounds__(256) void k_dense_big_bf16x3(const uint4* __restrict__ Whi, const uint4* __restrict__ Wlo,
+                                                          const unsigned short* __restrict__ x_hi,
+                                                          const unsigned short* __restrict__ x_lo,
+                                                          const int32_t* __restrict__ tiles,
+                                                          const int32_t* __restrict__ n_tiles, int64_t cap_small,
+                                                          int nfb, int64_t ks32n, int64_t F_pad, int nslices,
+                                                          int64_t Bcap, int d_pad16, float* __restrict__ z_part) {
+  extern __shared__ uint4 ring16[];
+  int tile = blockIdx.x;
+  if (tile >= n_tiles[1]) return;
+  const int32_t* tl = tiles + 4 * (cap_small + tile);
+  const int slice = blockIdx.y;
+  const int fb0 = blockIdx.z * NFB;
+  const int64_t relw = __builtin_amdgcn_readfirstlane(tl[0]);
+  const int start = __builtin_amdgcn_readfirstlane(tl[1]);
+  const int n = __builtin_amdgcn_readfirstlane(tl[2]);
+  const int64_t kb = ks32n * slice / nslices, ke = ks32n * (slice + 1) / nslices;
+  float* zdst = z_part + (int64_t)slice * Bcap * d_pad16;
+  const int nb = (n + 15) >> 4;
+#define BODY(NB_) dense_big_body_bf16<NFB, NB_>(ring16, Whi, Wlo, x_hi, x_lo, relw, start, n, fb0, nfb, ks32n, F_pad, kb, ke, zdst, d_pad16)
+  switch (nb) {
+    case 3: BODY(3); break;
+    case 4: BODY(4); break;
+    case 5: BODY(5); break;
+    case 6: BODY(6); break;
+    case 7: BODY(7); break;
+    default: BODY(8); break;
+  }
+#undef BODY
+}
+
+template <int NFB>
+static void dense_launch_bf16(coper_handle* h, int64_t B, int nslices, int zgroups, hipStream_t s) {
+  const Dims& dm = h->dm;
+  int64_t cap_small = (dm.gen_fc ? dm.R : 1) + 1;
+  int64_t n_small_max = cap_small - 1 < B ? cap_small - 1 : B;
+  int64_t n_big_max = B / 33 + 1;
+  const unsigned short* xh = (const unsigned short*)h->x_sorted;
+  const unsigned short* xl = xh + (size_t)h->ws_queries * dm.F_pad;
+  if (n_small_max > 0)
+    hipLaunchKernelGGL((k_dense_small_bf16x3<NFB>), dim3((unsigned)n_small_max, (unsigned)((nslices + 3) / 4), (unsigned)zgroups),
+                       dim3(256), 0, s, (const uint4*)h->Wf16_hi, (const uint4*)h->Wf16_lo, xh, xl, h->tiles, h->n_tiles,
+                       dm.nfb, dm.F_pad / 32, dm.F_pad, nslices, h->ws_queries, dm.d_pad16, h->z_part);
+  if (B > 32) {
+    size_t lds = (size_t)3 * (((2 * NFB + 16 + 3) / 4) * 4) * 64 * sizeof(uint4);
+    if (!h->dense_attr_done) {
+      (void)hipFuncSetAttribute((const void*)k_dense_big_bf16x3<NFB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      h->dense_attr_done = true;
+    }
+    hipLaunchKernelGGL((k_dense_big_bf16x3<NFB>), dim3((unsigned)n_big_max, (unsigned)nslices, (unsigned)zgroups), dim3(256),
+                       lds, s, (const uint4*)h->Wf16_hi, (const uint4*)h->Wf16_lo, xh, xl, h->tiles, h->n_tiles, cap_small,
+                       dm.nfb, dm.F_pad / 32, dm.F_pad, nslices, h->ws_queries, dm.d_pad16, h->z_part);
+  }
+}
+
+int launch_dense_bf16(coper_handle* h, int64_t B, int nslices, hipStream_t s) {
+  const Dims& dm = h->dm;
+  ScopedKernelTimer t(h, "dense", s);
+  int nfb = dm.nfb;
+  if (nfb == 13) dense_launch_bf16<13>(h, B, nslices, 1, s);
+  else if (nfb <= 2) dense_launch_bf16<2>(h, B, nslices, 1, s);
+  else if (nfb <= 4) dense_launch_bf16<4>(h, B, nslices, 1, s);
+  else dense_launch_bf16<8>(h, B, nslices, (nfb + 7) / 8, s);
+  COPER_HIP_TRY(h, hipGetLastError());
+  return COPER_OK;
+}
+
+}  // namespace coper

@@ -28,16 +28,19 @@ __device__ __forceinline__ unsigned short bf16_rne(float x) {
 __device__ __forceinline__ float bf16_to_f32(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
 
 __device__ __forceinline__ void split8(const float* v, uint4& hi, uint4& lo) {
-  unsigned short h[8], l[8];
+  // plain casts: hipcc emits v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN stays NaN)
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  unsigned hw[4], lw[4];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    h[j] = bf16_rne(v[j]);
-    l[j] = bf16_rne(v[j] - bf16_to_f32(h[j]));
+  for (int j = 0; j < 4; ++j) {
+    bf16x2_t hp = {(__bf16)v[2 * j], (__bf16)v[2 * j + 1]};
+    float r0 = v[2 * j] - (float)hp[0], r1 = v[2 * j + 1] - (float)hp[1];
+    bf16x2_t lp = {(__bf16)r0, (__bf16)r1};
+    hw[j] = __builtin_bit_cast(unsigned, hp);
+    lw[j] = __builtin_bit_cast(unsigned, lp);
   }
-  hi = make_uint4(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16), h[4] | ((unsigned)h[5] << 16),
-                  h[6] | ((unsigned)h[7] << 16));
-  lo = make_uint4(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16), l[4] | ((unsigned)l[5] << 16),
-                  l[6] | ((unsigned)l[7] << 16));
+  hi = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+  lo = make_uint4(lw[0], lw[1], lw[2], lw[3]);
 }
 
 #define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&(a), *(const bf16x8*)&(b), (c), 0, 0, 0)

@@ -380,7 +380,7 @@ def test_bf16x3_mode_full_size_and_sharded(oracle_chain):
     _, _, _, ranks32 = ranking_and_hits(m32, None, cdata.EvalDataset(q, 512, md["num_ent"]), "f32", return_ranks=True)
     lg32 = m32.score_all(m32.encode(q["e1"], q["rel"])).cpu().numpy()
     err = np.abs(logits - lg32).max()
-    assert err < 2e-4
+    assert err < 5e-4      # encoder and scorer both in bf16x3; the gate is 1e-3
     diff = ranks != ranks32
     # ~1650 competitors per unit of logit around a typical target: a +-err band moves a few % of the ranks by 1
     assert diff.mean() < 0.25 and np.abs(ranks - ranks32).max() <= 5, (diff.mean(), np.abs(ranks - ranks32).max(), err)
