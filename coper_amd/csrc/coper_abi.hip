@@ -512,7 +512,7 @@ COPER_API int coper_rank_counts(coper_handle* h, const float* hvec, const float*
   int rc;
   if ((rc = ensure_workspace(h, B, filt_nnz, s))) return rc;
   if (h->cfg.score_mode != COPER_SCORE_F32) {
-    if ((rc = launch_pack_h_bf16(h, hvec, B, s))) return rc;
+    if (!(h->trust_packed && h->packed_hvec == hvec && h->packed_B == B) && (rc = launch_pack_h_bf16(h, hvec, B, s))) return rc;
     if ((rc = launch_score_count_bf16x3(h, hvec, tgt, B, n_greater, n_equal, s))) return rc;
     if ((rc = launch_filter_correct_bf16x3(h, tgt, e2, filt_indptr, filt_idx, filt_nnz, B, n_greater, n_equal, s))) return rc;
   } else {
@@ -546,8 +546,10 @@ COPER_API int coper_rank(coper_handle* h, const float* hvec, const int64_t* e2, 
   if ((rc = coper_target_scores(h, hvec, e2, B, h->tgt_ws, stream))) return rc;
   int32_t* ng = h->cnt_ws;
   int32_t* ne = n_equal ? n_equal : h->cnt_ws + h->ws_queries;
-  if ((rc = coper_rank_counts(h, hvec, h->tgt_ws, e2, filt_indptr, filt_idx, filt_nnz, B, 0, ng, ne, nullptr, nullptr, stream)))
-    return rc;
+  h->trust_packed = true;  // same hvec, same stream, no caller code in between: the packing of target_scores is valid
+  rc = coper_rank_counts(h, hvec, h->tgt_ws, e2, filt_indptr, filt_idx, filt_nnz, B, 0, ng, ne, nullptr, nullptr, stream);
+  h->trust_packed = false;
+  if (rc) return rc;
   return launch_finish_ranks(h, ng, B, ranks, s);
 }
 

@@ -97,6 +97,9 @@ struct coper_handle {
   int64_t logits_ws_rows = 0;
   void* hfrag16_hi = nullptr;     // bf16x3: h hi / lo planes in fragment order
   void* hfrag16_lo = nullptr;
+  const float* packed_hvec = nullptr;  // what hfrag16 currently holds (only trusted inside coper_rank)
+  int64_t packed_B = 0;
+  bool trust_packed = false;
   int32_t* row_of_ws = nullptr;   // bf16x3: CSR entry -> query row [nnz]
   int64_t row_of_cap = 0;
   float* hfrag_ws = nullptr;      // h re-packed in MFMA-fragment order [ceil(B/128)*4][KS][64] float4

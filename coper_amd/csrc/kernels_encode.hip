@@ -622,18 +622,32 @@ __global__ void k_dense_finalize(const float* __restrict__ z_part, int ksplit, i
                                  const float* __restrict__ fc_b, int per_rel_bias, int64_t R,
                                  const float* __restrict__ scale, const float* __restrict__ shift,
                                  float* __restrict__ h_out) {
+  // one thread per 4 consecutive features of one query (d_pad16 is a multiple of 4: 16-B partial loads)
+  const int nq4 = d_pad16 >> 2;
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= B * d) return;
-  int64_t pos = idx / d;
-  int k = (int)(idx % d);
-  float z = 0.f;
-  for (int s = 0; s < ksplit; ++s) z += z_part[((int64_t)s * Bcap + pos) * d_pad16 + k];
+  if (idx >= B * nq4) return;
+  int64_t pos = idx / nq4;
+  int k0 = (int)(idx % nq4) * 4;
+  if (k0 >= d) return;
+  float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int s = 0; s < ksplit; ++s) {
+    float4 p = *(const float4*)(z_part + ((int64_t)s * Bcap + pos) * d_pad16 + k0);
+    z.x += p.x; z.y += p.y; z.z += p.z; z.w += p.w;
+  }
   int64_t q = perm[pos];
   int64_t rid = rel[q];
   if (rid < 0 || rid >= R) rid = 0;
-  z += per_rel_bias ? fc_b[rid * d + k] : fc_b[k];
-  z = fmaf(z, scale[k], shift[k]);
-  h_out[q * d + k] = fmaxf(z, 0.f);
+  const float* bsrc = per_rel_bias ? fc_b + rid * d : fc_b;
+  float zz[4] = {z.x, z.y, z.z, z.w};
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    int k = k0 + c;
+    if (k < d) {
+      float v = zz[c] + bsrc[k];
+      v = fmaf(v, scale[k], shift[k]);
+      h_out[q * d + k] = fmaxf(v, 0.f);
+    }
+  }
 }
 
 template <int NFB>
@@ -676,7 +690,7 @@ int launch_dense(coper_handle* h, const int64_t* rel, int64_t B, int tq, int ksp
 int launch_dense_finalize(coper_handle* h, const int64_t* rel, int64_t B, int ksplit, float* h_out, hipStream_t s) {
   const Dims& dm = h->dm;
   const float* fcb = dm.gen_fc ? h->fc_b_rel : h->params["fc_bias"].ptr;
-  int64_t total = B * dm.d;
+  int64_t total = B * (dm.d_pad16 / 4);
   hipLaunchKernelGGL(k_dense_finalize, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, h->z_part, ksplit,
                      h->ws_queries, B, dm.d, dm.d_pad16, h->perm, rel, fcb, dm.gen_fc ? 1 : 0, dm.R, h->fc_scale,
                      h->fc_shift, h_out);

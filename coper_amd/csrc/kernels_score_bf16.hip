@@ -356,6 +356,8 @@ __global__ __launch_bounds__(256) void k_pair_bf16x3(const uint4* __restrict__ E
     } else if (mode == 1) {
       q = p / L;
       erow = (int64_t)lookup[p] - lo;
+    } else if (p >= indptr[B]) {
+      erow = -1;  // the launch may be sized by a capacity larger than the CSR (hipGraph replay): no query owns p
     } else {
       q = row_of[p];
       int64_t f = idx[p];
@@ -379,7 +381,19 @@ __global__ __launch_bounds__(256) void k_pair_bf16x3(const uint4* __restrict__ E
   const uint4* pa_l = Elo + ((ea >> 5) * KS) * 64 + half * 32 + (ea & 31);
   const uint4* pb_h = Hhi + ((q >> 5) * KS) * 64 + half * 32 + (q & 31);
   const uint4* pb_l = Hlo + ((q >> 5) * KS) * 64 + half * 32 + (q & 31);
-  for (int ks = 0; ks < KS; ++ks) {
+  // gathered 16-B loads, batched four k-steps deep (one wave per SIMD here: nothing else hides their latency)
+  int ks = 0;
+  for (; ks + 4 <= KS; ks += 4) {
+    uint4 ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      ah[u] = pa_h[(ks + u) * 64]; al[u] = pa_l[(ks + u) * 64];
+      bh[u] = pb_h[(ks + u) * 64]; bl[u] = pb_l[(ks + u) * 64];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) MFMA_X3(ah[u], al[u], bh[u], bl[u], acc);
+  }
+  for (; ks < KS; ++ks) {
     uint4 ah = pa_h[ks * 64], al = pa_l[ks * 64], bh = pb_h[ks * 64], bl = pb_l[ks * 64];
     MFMA_X3(ah, al, bh, bl, acc);
   }
@@ -430,6 +444,8 @@ int launch_pair_targets_bf16x3(coper_handle* h, const float* hvec, const int64_t
                                hipStream_t s) {
   int rc = launch_pack_h_bf16(h, hvec, B, s);
   if (rc) return rc;
+  h->packed_hvec = hvec;  // coper_rank reuses this packing for the count pass on the same stream
+  h->packed_B = B;
   pair_launch(h, 0, B, B, 1, e2, nullptr, nullptr, nullptr, nullptr, nullptr, tgt, nullptr, nullptr, s);
   COPER_HIP_TRY(h, hipGetLastError());
   return COPER_OK;

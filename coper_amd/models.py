@@ -262,6 +262,52 @@ class ConvE(object):
                                                  self._stream()))
         return ranks, ne
 
+    def capture_rank_pass(self, B, max_nnz):
+        """hipGraph capture of one encode -> fused-rank pass for batches of exactly B queries (the reference's
+        per-`session.run` batch, B = 512, is launch-bound: ~14 kernel launches per batch).  Returns
+        `run(e1, rel, e2, filt_indptr, filt_idx) -> (ranks, n_equal)`; the id / CSR arguments are copied into
+        static device buffers (CSR padded to `max_nnz` entries), the graph is replayed, and the outputs are
+        static tensors valid until the next replay.  Every coper_* call inside is allocation-free after
+        `reserve`, which is what makes the sequence capturable."""
+        self._need_prepared()
+        self.reserve(B, max_nnz)
+        dev = self.device
+        st = dict(e1=torch.zeros(B, dtype=torch.int64, device=dev), rel=torch.zeros(B, dtype=torch.int64, device=dev),
+                  e2=torch.zeros(B, dtype=torch.int64, device=dev), ip=torch.zeros(B + 1, dtype=torch.int64, device=dev),
+                  ix=torch.zeros(max(1, max_nnz), dtype=torch.int64, device=dev),
+                  h=torch.empty((B, self.ent_emb_size), dtype=torch.float32, device=dev),
+                  ranks=torch.empty(B, dtype=torch.int32, device=dev), ne=torch.empty(B, dtype=torch.int32, device=dev))
+
+        def body():
+            # the filter launch is sized by max_nnz; entries past indptr[B] belong to no query and are skipped
+            _lib.check(self._h, self._lib.coper_encode(self._h, _ptr(st["e1"]), _ptr(st["rel"]), B, None, _ptr(st["h"]), self._stream()))
+            _lib.check(self._h, self._lib.coper_rank(self._h, _ptr(st["h"]), _ptr(st["e2"]), _ptr(st["ip"]), _ptr(st["ix"]),
+                                                     max_nnz, B, _ptr(st["ranks"]), _ptr(st["ne"]), self._stream()))
+
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                body()                      # warm-up outside capture (lazy attribute / workspace set-up)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            body()
+
+        def run(e1, rel, e2, filt_indptr, filt_idx):
+            ix = self._ids(filt_idx)
+            n = int(ix.numel())
+            if n > max_nnz:
+                raise ValueError("filter has %d entries, graph was captured for %d" % (n, max_nnz))
+            st["e1"].copy_(self._ids(e1)); st["rel"].copy_(self._ids(rel)); st["e2"].copy_(self._ids(e2))
+            st["ip"].copy_(self._ids(filt_indptr))
+            st["ix"][:n].copy_(ix)
+            graph.replay()
+            return st["ranks"], st["ne"]
+
+        run.graph = graph
+        return run
+
     def check_ids(self):
         n = C.c_int64()
         _lib.check(self._h, self._lib.coper_check_ids(self._h, C.byref(n), self._stream()))

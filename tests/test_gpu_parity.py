@@ -398,3 +398,23 @@ def test_bf16x3_mode_full_size_and_sharded(oracle_chain):
     assert np.array_equal((1 + ngs).cpu().numpy(), ranks)
     for x in shards + [m, m32]:
         x.close()
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+def test_hipgraph_replay_equals_eager(mode):
+    """capture_rank_pass: the captured encode -> rank sequence replays bit-identically for new inputs,
+    including CSR filters shorter than the captured capacity."""
+    md = cdata.model_descriptors("fb15k237_cpg", num_ent=3001, num_rel=30)
+    p = cdata.synthetic_params(md, 2)
+    m = _model(md, p, score_mode=mode)
+    B = 512
+    qs = [cdata.synthetic_queries(md, B, seed=s_) for s_ in (1, 2, 3)]
+    cap = max(len(q["filt_idx"]) for q in qs) + 100
+    run = m.capture_rank_pass(B, cap)
+    for q in qs:
+        r_g, ne_g = run(q["e1"], q["rel"], q["e2"], q["filt_indptr"], q["filt_idx"])
+        r_g, ne_g = r_g.cpu().numpy().copy(), ne_g.cpu().numpy().copy()
+        h = m.encode(q["e1"], q["rel"])
+        r_e, ne_e = m.rank(h, q["e2"], q["filt_indptr"], q["filt_idx"])
+        assert np.array_equal(r_g, r_e.cpu().numpy()) and np.array_equal(ne_g, ne_e.cpu().numpy())
+    m.close()
