@@ -22,12 +22,16 @@ Pinning status (see DESIGN.md "Oracle"):
   * the generator / generated-dense / score sub-steps are pinned against the
     reference's PyTorch sister implementation ``CoPER_MINERVA/src/emb/fact_network.py``
     (``tests/golden/cpg_substeps.npz``);
+  * conv -> dense -> score END TO END is pinned against the OUTPUT of the reference's PyTorch
+    sister models run here on CPU (``fact_network.py`` ``ConvE.forward`` / ``CPG_ConvE.forward``
+    and ``forward_fact``; ``tests/golden/minerva_e2e.npz``, weight mapping in
+    ``tests/minerva_map.py``): sigmoid scores agree to 2e-6;
   * the TF-1.14 graph itself (``models.py``) cannot be executed here (TensorFlow is an
     un-vendored, loosely pinned dependency: ``requirements.txt:6``, "tensorflow-gpu==1.14"
-    in ``CoPER_ConvE/README.md:115-116``) and the reference ships no tests, so the conv/BN
-    stage is restated from TF-1.14 semantics and cross-checked against
-    ``torch.nn.functional.conv2d`` / ``batch_norm``: for that stage parity is UNPINNED by
-    reference-held vectors.
+    in ``CoPER_ConvE/README.md:115-116``) and the reference ships no tests, so what stays
+    restated-from-semantics only is the TF-specific residue: BN placement after the conv
+    (``Conv1BN``, the sister model has none), eps = 1e-3, and the NHWC flatten order --
+    each covered by a hand-written KAT and a ``torch.nn.functional`` cross-check.
 """
 from __future__ import annotations
 

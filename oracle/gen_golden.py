@@ -195,6 +195,73 @@ def gen_conv_torch():
     print("conv_torch: ok")
 
 
+def gen_minerva_e2e():
+    """End-to-end pin of conv -> dense -> score against the reference's PyTorch sister models
+    (CoPER_MINERVA/src/emb/fact_network.py: ConvE :116-197, CPG_ConvE :261-439) run on CPU in eval mode with
+    randomised BN statistics.  The fixture stores the reference-side tensors (torch layouts) and the
+    reference outputs; tests/minerva_map.py maps them onto the qa_cpg leaf names."""
+    import contextlib
+    import io
+    import torch
+    spec = importlib.util.spec_from_file_location("ref_fact_network2", os.path.join(REF, "CoPER_MINERVA/src/emb/fact_network.py"))
+    fn = importlib.util.module_from_spec(spec)
+    with contextlib.redirect_stdout(io.StringIO()):
+        spec.loader.exec_module(fn)
+    torch.manual_seed(123)
+    E, R, B, d1, d2, C = 60, 6, 10, 10, 4, 8
+    d = d1 * d2
+    out = {}
+
+    class KG(object):
+        def __init__(self, ent, rel):
+            self.ent, self.rel = ent, rel
+        def get_entity_embeddings(self, e):
+            return self.ent[e]
+        def get_relation_embeddings(self, r):
+            return self.rel[r]
+        def get_all_entity_embeddings(self):
+            return self.ent
+
+    def randomise_bn(bn):
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.1)
+            bn.running_mean.normal_(0, 0.1); bn.running_var.uniform_(0.6, 1.4)
+
+    for tag, r_dim, cpg in (("plain", d, False), ("cpg", 20, True)):
+        args = types.SimpleNamespace(entity_dim=d, relation_dim=r_dim, emb_2D_d1=d1, emb_2D_d2=d2, num_out_channels=C,
+                                     kernel_size=3, hidden_dropout_rate=0.3, feat_dropout_rate=0.2, cpg_conv_net=[-1],
+                                     cpg_fc_net=[], cpg_dropout=0.2, cpg_batch_norm=False, cpg_batch_norm_momentum=0.1,
+                                     cpg_use_bias=False)
+        with contextlib.redirect_stdout(io.StringIO()):
+            m = fn.CPG_ConvE(args, E) if cpg else fn.ConvE(args, E)
+        m.eval()
+        randomise_bn(m.bn0); randomise_bn(m.bn2)
+        with torch.no_grad():
+            m.b.normal_(0, 0.1)
+            m.conv1.weight.normal_(0, 1.0); m.conv1.bias.normal_(0, 0.1)
+            if cpg:
+                for g_, std in ((m.fc_weights, 0.35), (m.fc_bias, 0.3)):
+                    for lin in g_.network:
+                        if isinstance(lin, torch.nn.Linear):
+                            lin.weight.normal_(0, std)
+            else:
+                m.fc.weight.normal_(0, 0.12); m.fc.bias.normal_(0, 0.1)
+        ent = torch.randn(E, d) * 0.3
+        rel = torch.randn(R, r_dim) * 0.3
+        kg = KG(ent, rel)
+        e1 = torch.randint(0, E, (B,)); r = torch.randint(0, R, (B,)); e2 = torch.randint(0, E, (B,))
+        with torch.no_grad():
+            S = m.forward(e1, r, kg)                    # [B, E] sigmoid scores
+            Sf = m.forward_fact(e1, r, e2, kg)          # [B, 1]
+        out.update({tag + ":ent": ent.numpy(), tag + ":rel": rel.numpy(), tag + ":e1": e1.numpy(), tag + ":r": r.numpy(),
+                    tag + ":e2": e2.numpy(), tag + ":S": S.numpy(), tag + ":S_fact": Sf.numpy(),
+                    tag + ":dims": np.array([E, R, B, d1, d2, C, r_dim])})
+        for k, v in m.state_dict().items():
+            out[tag + ":sd:" + k] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, "minerva_e2e.npz"), **out)
+    print("minerva_e2e: keys", len(out), "S range", float(out["plain:S"].min()), float(out["plain:S"].max()))
+
+
 # ------------------------------------------------------------------------------------------------
 FWD_CASES = {
     # name: (model_descriptors overrides, #queries)
@@ -252,5 +319,6 @@ if __name__ == "__main__":
     gen_rank_fixtures(ref, eod)
     gen_cpg_substeps()
     gen_conv_torch()
+    gen_minerva_e2e()
     gen_fwd_fixtures()
     print("sizes:", {f: os.path.getsize(os.path.join(OUT, f)) for f in sorted(os.listdir(OUT))})

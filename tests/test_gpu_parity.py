@@ -418,3 +418,20 @@ def test_hipgraph_replay_equals_eager(mode):
         r_e, ne_e = m.rank(h, q["e2"], q["filt_indptr"], q["filt_idx"])
         assert np.array_equal(r_g, r_e.cpu().numpy()) and np.array_equal(ne_g, ne_e.cpu().numpy())
     m.close()
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+@pytest.mark.parametrize("tag", ["plain", "cpg"])
+def test_end_to_end_matches_minerva_torch_models_gpu(golden_dir, tag, mode):
+    """HIP path vs the OUTPUT of the reference's PyTorch sister models (fact_network.py forward / forward_fact)."""
+    from tests.minerva_map import load_case, sigmoid
+    g = np.load(os.path.join(golden_dir, "minerva_e2e.npz"))
+    md, p, q, S, S_fact = load_case(g, tag)
+    m = _model(md, p, score_mode=mode)
+    h = m.encode(q["e1"], q["rel"])
+    logits = m.score_all(h).cpu().numpy()
+    tol = 2e-6 if mode == "f32" else 1e-4   # logit gate 1e-3 <=> 2.5e-4 on sigmoid scores
+    assert np.abs(sigmoid(logits) - S).max() < tol
+    fact = m.score_lookup(h, q["e2"][:, None].astype(np.int32)).cpu().numpy()
+    assert np.abs(sigmoid(fact) - S_fact).max() < tol
+    m.close()

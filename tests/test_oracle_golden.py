@@ -148,3 +148,20 @@ def test_chain_oracle_close_to_blas(oracle_chain):
     s2 = O.score_chain(h[:, :13], E[:, :13], b)
     ref2 = h[:, :13].astype(np.float64) @ E[:, :13].astype(np.float64).T + b
     assert np.abs(s2 - ref2).max() < 1e-5
+
+
+@pytest.mark.parametrize("tag", ["plain", "cpg"])
+def test_end_to_end_matches_minerva_torch_models(golden_dir, tag):
+    """conv -> dense -> score of the oracle against the OUTPUT of the reference's PyTorch sister models
+    (fact_network.py ConvE.forward / CPG_ConvE.forward and forward_fact) on the mapped weights."""
+    from tests.minerva_map import load_case, sigmoid
+    g = _load(golden_dir, "minerva_e2e.npz")
+    md, p, q, S, S_fact = load_case(g, tag)
+    assert set(p) == set(cdata.param_shapes(md))
+    st = O.forward(p, md, q["e1"], q["rel"], np.float32)
+    logits = O.score_all(st["h"], p["ent_emb"], p["pred_bias"])
+    assert np.abs(sigmoid(logits) - S).max() < 2e-6
+    fact = O.score_lookup(st["h"], p["ent_emb"], p["pred_bias"], q["e2"][:, None])
+    assert np.abs(sigmoid(fact) - S_fact).max() < 2e-6
+    st64 = O.forward(p, md, q["e1"], q["rel"], np.float64)
+    assert np.abs(sigmoid(O.score_all(st64["h"], p["ent_emb"], p["pred_bias"])) - S).max() < 2e-6
