@@ -1,0 +1,174 @@
+"""TSV knowledge-graph loader: the on-disk side of the reference's data pipeline,
+`qa_cpg/data.py:401-572`, producing the batch contract of `coper_amd.data` (ids + CSR filters)
+instead of TFRecords and dense masks.
+
+What is kept exactly as the reference does it:
+  * triples `e1\\trel\\te2` per line, fields stripped (data.py:417-421);
+  * every triple also feeds the `_reverse` relation `(e2, rel_reverse) -> e1` of the FULL graph
+    (data.py:422-437), and of a split's own graph only where `add_reverse_per_filetype` says so
+    (data.py:438-439: train only for the shipped loaders);
+  * evaluation labels / filters come from the full graph (train + dev + test, both directions)
+    (data.py:464-469, 494-503): the filter of a query (e1, rel) is every known tail;
+  * `needs_test_set_cleaning`: dev/test questions whose e1, e2 or relation never occur in train are
+    dropped (data.py:445-459, 487-497);
+  * JSON lines `{"e1","e2","rel","e2_multi"}` with space-joined tails and e2 = "None" for the train
+    file (data.py:477-504), `entities.txt` / `relations.txt` id maps that, once written, define the
+    ids (data.py:506-572);
+  * eval batches exclude inverse relations unless asked (data.py:192-197, run_cpg.py:156).
+
+What differs on purpose: id assignment when no id files exist iterates sorted names instead of Python
+`set`s (the reference's ids depend on the hash seed), and nothing is downloaded."""
+from __future__ import annotations
+
+import json
+import os
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+from .data import EvalDataset
+
+__all__ = ["TSVKGLoader"]
+
+
+class TSVKGLoader(object):
+    def __init__(self, directory: str, dataset_name: str = "kg", filetypes=("train", "dev", "test"),
+                 add_reverse_per_filetype=(True, False, False), needs_test_set_cleaning: bool = False):
+        self.directory, self.dataset_name = directory, dataset_name
+        self.filetypes = list(filetypes)
+        self.add_reverse_per_filetype = list(add_reverse_per_filetype)
+        self.needs_test_set_cleaning = needs_test_set_cleaning
+        self.num_ent: Optional[int] = None
+        self.num_rel: Optional[int] = None
+        self.full_graph: Dict[Tuple[str, str], set] = {}
+        self.graphs: Dict[str, Dict[Tuple[str, str], set]] = {}
+        self.entity_ids: Dict[str, int] = {}
+        self.relation_ids: Dict[str, int] = {}
+        self._samples: Dict[str, List[dict]] = {}
+        self._loaded = False
+
+    # ---------------------------------------------------------------- data.py:401-475
+    def load_and_preprocess(self, write_json: bool = False):
+        full_graph, graphs = {}, {}
+        for i, ft in enumerate(self.filetypes):
+            g = graphs[ft] = {}
+            with open(os.path.join(self.directory, "%s.txt" % ft), "r") as handle:
+                for line in handle:
+                    if not line.strip():
+                        continue
+                    e1, rel, e2 = line.split("\t")
+                    e1, rel, e2 = e1.strip(), rel.strip(), e2.strip()
+                    rel_reverse = rel + "_reverse"
+                    full_graph.setdefault((e1, rel), set()).add(e2)
+                    full_graph.setdefault((e2, rel_reverse), set()).add(e1)
+                    g.setdefault((e1, rel), set()).add(e2)
+                    g.setdefault((e2, rel_reverse), set())
+                    if self.add_reverse_per_filetype[i]:
+                        g[(e2, rel_reverse)].add(e1)
+        self.full_graph, self.graphs = full_graph, graphs
+        allowed_entities = allowed_relations = None
+        if self.needs_test_set_cleaning:
+            allowed_entities, allowed_relations = set(), set()
+            for (e1, rel), tails in graphs[self.filetypes[0]].items():
+                allowed_entities.add(e1)
+                allowed_entities.update(tails)
+                allowed_relations.add(rel)
+        names = {"train": self.filetypes[0], "dev": self.filetypes[1], "test": self.filetypes[2]}
+        self._samples = {
+            "train": self._graph_samples(graphs[names["train"]], None, None, None),
+            "dev": self._graph_samples(graphs[names["dev"]], full_graph, allowed_entities, allowed_relations),
+            "test": self._graph_samples(graphs[names["test"]], full_graph, allowed_entities, allowed_relations),
+            "full": self._graph_samples(full_graph, full_graph, allowed_entities, allowed_relations),
+        }
+        if write_json:
+            for split, samples in self._samples.items():
+                with open(os.path.join(self.directory, "e1rel_to_e2_%s.json" % split), "w") as handle:
+                    for s in samples:
+                        handle.write(json.dumps({"e1": s["e1"], "e2": s["e2"], "rel": s["rel"],
+                                                 "e2_multi": " ".join(s["e2_multi"])}) + "\n")
+        self._loaded = True
+        return self._samples
+
+    @staticmethod
+    def _graph_samples(graph, labels, allowed_entities, allowed_relations):
+        """data.py:477-504 (`_write_graph`) as in-memory samples; tails kept sorted for determinism."""
+        out = []
+        for (e1, rel), value in graph.items():
+            if labels is None:
+                out.append({"e1": e1, "e2": "None", "rel": rel, "e2_multi": sorted(value)})
+                continue
+            if allowed_entities is not None and e1 not in allowed_entities:
+                continue
+            if allowed_relations is not None and rel not in allowed_relations:
+                continue
+            e2_multi = sorted(labels[(e1, rel)])
+            for e2 in sorted(value):
+                if allowed_entities is not None and e2 not in allowed_entities:
+                    continue
+                out.append({"e1": e1, "e2": e2, "rel": rel, "e2_multi": e2_multi})
+        return out
+
+    # ---------------------------------------------------------------- data.py:506-572
+    def assign_ids(self, write_files: bool = False):
+        if not self._loaded:
+            self.load_and_preprocess()
+        ent_file = os.path.join(self.directory, "entities.txt")
+        rel_file = os.path.join(self.directory, "relations.txt")
+        entity_ids, relation_ids = {}, {}
+        if os.path.exists(ent_file):
+            with open(ent_file) as handle:
+                for i, line in enumerate(handle):
+                    entity_ids[line.strip()] = i
+        if os.path.exists(rel_file):
+            with open(rel_file) as handle:
+                for i, line in enumerate(handle):
+                    relation_ids[line.strip()] = i
+        if not entity_ids or not relation_ids:
+            ents, rels = set(), set()
+            for s in self._samples["full"]:
+                ents.add(s["e1"]); ents.add(s["e2"]); ents.update(s["e2_multi"])
+                rels.add(s["rel"])
+            ents.discard("None"); rels.discard("None")
+            if not entity_ids:
+                entity_ids = {name: i for i, name in enumerate(sorted(ents))}
+                if write_files:
+                    with open(ent_file, "w") as handle:
+                        handle.write("".join(n + "\n" for n in sorted(ents)))
+            if not relation_ids:
+                relation_ids = {name: i for i, name in enumerate(sorted(rels))}
+                if write_files:
+                    with open(rel_file, "w") as handle:
+                        handle.write("".join(n + "\n" for n in sorted(rels)))
+        self.entity_ids, self.relation_ids = entity_ids, relation_ids
+        self.num_ent, self.num_rel = len(entity_ids), len(relation_ids)    # data.py:337-338
+        return entity_ids, relation_ids
+
+    def maybe_create_tf_record_files(self, directory=None, buffer_size=None):
+        """Name kept for the driver (run_cpg.py:108): loads, assigns ids; nothing TF is written."""
+        self.assign_ids()
+        return None
+
+    # ---------------------------------------------------------------- data.py:168-226 + 574-594
+    def encoded_split(self, dataset_type: str, include_inv_relations: bool = False):
+        """Id arrays + CSR filter of one split: what `_encode_sample_as_tf_record` + `eval_dataset` feed."""
+        if not self.entity_ids:
+            self.assign_ids()
+        E, Rm = self.entity_ids, self.relation_ids
+        e1, e2, rel, indptr, idx = [], [], [], [0], []
+        for s in self._samples[dataset_type]:
+            if s["e2"] == "None":
+                continue
+            if s["rel"].endswith("_reverse") and not include_inv_relations:
+                continue
+            e1.append(E[s["e1"]]); e2.append(E[s["e2"]]); rel.append(Rm[s["rel"]])
+            tails = sorted(set(E[t] for t in s["e2_multi"] if t != "None"))
+            idx.extend(tails)
+            indptr.append(len(idx))
+        return dict(e1=np.asarray(e1, np.int64), e2=np.asarray(e2, np.int64), rel=np.asarray(rel, np.int64),
+                    filt_indptr=np.asarray(indptr, np.int64), filt_idx=np.asarray(idx, np.int64))
+
+    def eval_dataset(self, directory=None, dataset_type="test", batch_size=512, include_inv_relations=False,
+                     buffer_size=None, prefetch_buffer_size=None, dense_mask=False):
+        if self.num_ent is None:
+            self.assign_ids()
+        return EvalDataset(self.encoded_split(dataset_type, include_inv_relations), batch_size, self.num_ent, dense_mask)

@@ -1,0 +1,90 @@
+"""Weight import: parameter dicts keyed by the reference's TF leaf names from
+  * an .npz / dict of arrays exported from a TF checkpoint (`tf.train.load_variable` per leaf),
+  * the `best_embeddings.ckpt` pickle the reference driver writes (`run_cpg.py:242-249`):
+    `[rel_emb, ent_emb]`, or `ent_emb` alone for g_lookup models,
+  * the state_dict of the reference's PyTorch sister models (`CoPER_MINERVA/src/emb/fact_network.py`
+    `ConvE` :116-197 and `CPG_ConvE` :261-439), whose tensors are re-laid out for the qa_cpg graph.
+The TF-1.14 `Saver` bundle itself (`model_weights.ckpt.index/.data`) is not parsed here."""
+from __future__ import annotations
+
+import pickle
+from typing import Dict
+
+import numpy as np
+
+__all__ = ["load_npz", "load_best_embeddings_pickle", "from_minerva_state_dict", "leaf_name"]
+
+
+def leaf_name(tf_variable_name: str) -> str:
+    """'variables/variables/fc_weights/CPG/Projection0:0' -> 'fc_weights/CPG/Projection0' (scopes
+    nest `variables/` from run_cpg.py:114 and again from models.py:169; BN layers sit one scope up)."""
+    n = tf_variable_name.split(":")[0]
+    while n.startswith("variables/"):
+        n = n[len("variables/"):]
+    return n
+
+
+def load_npz(path) -> Dict[str, np.ndarray]:
+    with np.load(path) as z:
+        return {leaf_name(k): np.asarray(z[k], np.float32) for k in z.files}
+
+
+def load_best_embeddings_pickle(path, is_parameter_lookup=False) -> Dict[str, np.ndarray]:
+    with open(path, "rb") as f:
+        obj = pickle.load(f)
+    if is_parameter_lookup:
+        return {"ent_emb": np.asarray(obj, np.float32)}
+    rel_emb, ent_emb = obj
+    return {"rel_emb": np.asarray(rel_emb, np.float32), "ent_emb": np.asarray(ent_emb, np.float32)}
+
+
+def from_minerva_state_dict(sd: Dict[str, np.ndarray], entity_emb, relation_emb, emb_2D_d1: int, emb_2D_d2: int,
+                            cpg: bool):
+    """state_dict of fact_network.ConvE / CPG_ConvE (+ the KG's embedding tables) -> (model_descriptors overrides,
+    parameters by qa_cpg leaf name).  Differences folded away (fact_network.py line numbers):
+      * bn0 on the input image (:150 / :356): a scalar affine in eval mode -> folded into the conv taps and bias
+      * no BN after the conv (`# X = self.bn1(X)` :153 / :364)               -> Conv1BN = identity
+      * NCHW flatten `X.view(-1, feat_dim)` (:156 / :368)                     -> dense-weight rows permuted to (i, j, c)
+      * BatchNorm eps 1e-5 (torch default) vs 1e-3 (TF default)               -> moving_variance shifted by the difference
+    The sister models apply a sigmoid to the scores (:166 / :389); this engine returns logits like qa_cpg."""
+    sd = {k: np.asarray(v) for k, v in sd.items()}
+    ent = np.asarray(entity_emb, np.float32)
+    rel = np.asarray(relation_emb, np.float32)
+    E, d = ent.shape
+    R, r_dim = rel.shape
+    C = sd["conv1.weight"].shape[0]
+    assert sd["conv1.weight"].shape[2:] == (3, 3) and emb_2D_d1 * emb_2D_d2 == d
+    md = dict(num_ent=E, num_rel=R, ent_emb_size=d, rel_emb_size=r_dim, emb_h=emb_2D_d1, emb_w=emb_2D_d2,
+              conv_num_channels=C, context_rel_conv=None, context_rel_out=[] if cpg else None,
+              context_rel_use_batch_norm=False, concat_rel=False)
+    in_h = emb_2D_d1 if cpg else 2 * emb_2D_d1
+    Ho, Wo = in_h - 2, emb_2D_d2 - 2
+    F = Ho * Wo * C
+    p = {"ent_emb": ent, "rel_emb": rel, "pred_bias": sd["b"].astype(np.float32)}
+    a = float(sd["bn0.weight"][0] / np.sqrt(sd["bn0.running_var"][0] + np.float32(1e-5)))
+    c = float(sd["bn0.bias"][0] - sd["bn0.running_mean"][0] * a)
+    Wc = sd["conv1.weight"]                                                      # [C, 1, 3, 3]
+    p["conv1_weights"] = (a * Wc[:, 0].transpose(1, 2, 0))[:, :, None, :].astype(np.float32)   # HWIO [3,3,1,C]
+    p["conv1_bias"] = (sd["conv1.bias"] + c * Wc[:, 0].sum(axis=(1, 2))).astype(np.float32)
+    p["Conv1BN/gamma"] = np.ones(C, np.float32)
+    p["Conv1BN/beta"] = np.zeros(C, np.float32)
+    p["Conv1BN/moving_mean"] = np.zeros(C, np.float32)
+    p["Conv1BN/moving_variance"] = np.full(C, 1.0 - 1e-3, np.float32)
+    pix, ch = np.divmod(np.arange(F), C)      # ours: f = (i*Wo + j)*C + ch ; reference: f_ref = ch*(Ho*Wo) + (i*Wo + j)
+    f_ref = ch * (Ho * Wo) + pix
+    if cpg:
+        names = sorted(k for k in sd if k.startswith("fc_weights.network.") and k.endswith(".weight"))
+        if len(names) != 1:
+            raise NotImplementedError("g_MLP generators of the sister model: map each Linear to Projection<i> the same way")
+        Wg = sd[names[0]]                                                        # [F*d, r]
+        P = Wg.T.reshape(r_dim, F, d)[:, f_ref, :].reshape(r_dim, F * d)
+        p["fc_weights/CPG/Projection0"] = np.ascontiguousarray(P, np.float32)
+        p["fc_bias/CPG/Projection0"] = np.ascontiguousarray(sd["fc_bias.network.0.weight"].T, np.float32)
+    else:
+        p["fc_weights"] = np.ascontiguousarray(sd["fc.weight"].T[f_ref, :], np.float32)   # [F, d]
+        p["fc_bias"] = sd["fc.bias"].astype(np.float32)
+    p["FCBN/gamma"] = sd["bn2.weight"].astype(np.float32)
+    p["FCBN/beta"] = sd["bn2.bias"].astype(np.float32)
+    p["FCBN/moving_mean"] = sd["bn2.running_mean"].astype(np.float32)
+    p["FCBN/moving_variance"] = (sd["bn2.running_var"].astype(np.float64) + 1e-5 - 1e-3).astype(np.float32)
+    return md, p

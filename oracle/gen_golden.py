@@ -262,6 +262,35 @@ def gen_minerva_e2e():
     print("minerva_e2e: keys", len(out), "S range", float(out["plain:S"].min()), float(out["plain:S"].max()))
 
 
+def gen_loader_fixture():
+    """TSV -> JSON -> id maps through the REFERENCE'S OWN loader code (qa_cpg/data.py load_and_preprocess,
+    _write_graph, _assign_ids), imported under the stub tensorflow module, on a small split of the
+    nell-995 dev triples the reference ships (CoPER_ConvE/data/nell-995-test/dev.txt)."""
+    import shutil
+    spec = importlib.util.spec_from_file_location("ref_data", os.path.join(REF, "CoPER_ConvE/qa_cpg/data.py"))
+    rd = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rd)
+    lines = open(os.path.join(REF, "CoPER_ConvE/data/nell-995-test/dev.txt")).read().splitlines(True)
+    tsv_dir = os.path.join(OUT, "kg_tsv")
+    os.makedirs(tsv_dir, exist_ok=True)
+    splits = {"train.txt": lines[:400], "dev.txt": lines[400:470], "test.txt": lines[470:]}
+    for name, ls in splits.items():
+        with open(os.path.join(tsv_dir, name), "w") as f:
+            f.writelines(ls)
+    for clean in (False, True):
+        with tempfile.TemporaryDirectory() as td:
+            for name in splits:
+                shutil.copy(os.path.join(tsv_dir, name), td)
+            loader = rd.NELL995Loader(is_test=True, needs_test_set_cleaning=clean)
+            json_files = loader.load_and_preprocess(td)
+            loader._assign_ids(json_files)
+            dst = os.path.join(OUT, "kg_ref_clean" if clean else "kg_ref")
+            os.makedirs(dst, exist_ok=True)
+            for fn_ in list(json_files.values()) + [os.path.join(td, "entities.txt"), os.path.join(td, "relations.txt")]:
+                shutil.copy(fn_, dst)
+            print("loader fixture (clean=%s):" % clean, {k: sum(1 for _ in open(v)) for k, v in json_files.items()})
+
+
 # ------------------------------------------------------------------------------------------------
 FWD_CASES = {
     # name: (model_descriptors overrides, #queries)
@@ -320,5 +349,6 @@ if __name__ == "__main__":
     gen_cpg_substeps()
     gen_conv_torch()
     gen_minerva_e2e()
+    gen_loader_fixture()
     gen_fwd_fixtures()
     print("sizes:", {f: os.path.getsize(os.path.join(OUT, f)) for f in sorted(os.listdir(OUT))})

@@ -435,3 +435,35 @@ def test_end_to_end_matches_minerva_torch_models_gpu(golden_dir, tag, mode):
     fact = m.score_lookup(h, q["e2"][:, None].astype(np.int32)).cpu().numpy()
     assert np.abs(sigmoid(fact) - S_fact).max() < tol
     m.close()
+
+
+def test_tsv_loader_to_ranking_end_to_end(golden_dir, tmp_path, oracle_chain):
+    """TSV triples (a split of the nell-995 dev set the reference ships) -> TSVKGLoader -> ranking_and_hits on
+    the GPU == the oracle's reference-semantics evaluation pass on the same batches."""
+    import shutil
+    O = oracle_chain
+    from coper_amd.kg_loader import TSVKGLoader
+    from coper_amd.metrics import ranking_and_hits
+    for f in ("train.txt", "dev.txt", "test.txt"):
+        shutil.copy(os.path.join(golden_dir, "kg_tsv", f), tmp_path)
+    for f in ("entities.txt", "relations.txt"):
+        shutil.copy(os.path.join(golden_dir, "kg_ref", f), tmp_path)
+    loader = TSVKGLoader(str(tmp_path), "nell-995-test")
+    loader.maybe_create_tf_record_files(str(tmp_path))
+    md = dict(cdata._COMMON, num_ent=loader.num_ent, num_rel=loader.num_rel, ent_emb_size=200, rel_emb_size=32,
+              context_rel_conv=None, context_rel_out=[])
+    p = cdata.synthetic_params(md, 9)
+    m = _model(md, p)
+    ds = loader.eval_dataset(str(tmp_path), "test", batch_size=32)
+    mr, mrr, hits, ranks = ranking_and_hits(m, str(tmp_path / "eval"), ds, "test", enable_write_to_file=True, return_ranks=True)
+    q = ds.as_single_batch()
+    h = m.encode(q["e1"], q["rel"])
+    logits = m.score_all(h).cpu().numpy()
+    e2_multi = cdata.csr_to_dense_filter(q["filt_indptr"], q["filt_idx"], loader.num_ent)
+    assert np.array_equal(O.rank_dense_literal(logits, q["e2"], e2_multi), ranks)
+    mr_o, mrr_o, hits_o = O.metrics_from_ranks(ranks)
+    assert (mr, mrr) == (mr_o, mrr_o) and hits == hits_o
+    assert os.path.exists(tmp_path / "eval" / "mrr.txt") and os.path.exists(tmp_path / "eval" / "hits_at_10.txt")   # metrics.py:70-83
+    st = O.forward(p, md, q["e1"], q["rel"], np.float64, materialise=False)
+    assert np.abs(logits - O.score_all(st["h"], p["ent_emb"].astype(np.float64), p["pred_bias"].astype(np.float64))).max() < LOGIT_TOL
+    m.close()

@@ -75,3 +75,20 @@ def test_synthetic_params_are_seeded_and_complete():
     for i in range(50):
         row = q["filt_idx"][q["filt_indptr"][i]:q["filt_indptr"][i + 1]]
         assert np.all(np.diff(row) > 0) and q["e2"][i] in row       # sorted unique, contains the target
+
+
+def test_weight_import_helpers(tmp_path):
+    import pickle
+    from coper_amd.weights import leaf_name, load_best_embeddings_pickle, load_npz
+    assert leaf_name("variables/variables/fc_weights/CPG/Projection0:0") == "fc_weights/CPG/Projection0"
+    assert leaf_name("variables/Conv1BN/moving_variance:0") == "Conv1BN/moving_variance"
+    rel, ent = np.ones((4, 3), np.float64), np.zeros((5, 2), np.float64)
+    with open(tmp_path / "best_embeddings.ckpt", "wb") as f:           # run_cpg.py:242-249
+        pickle.dump([rel, ent], f)
+    got = load_best_embeddings_pickle(tmp_path / "best_embeddings.ckpt")
+    assert got["rel_emb"].dtype == np.float32 and got["rel_emb"].shape == (4, 3) and got["ent_emb"].shape == (5, 2)
+    with open(tmp_path / "e.ckpt", "wb") as f:
+        pickle.dump(ent, f)
+    assert set(load_best_embeddings_pickle(tmp_path / "e.ckpt", is_parameter_lookup=True)) == {"ent_emb"}
+    np.savez(tmp_path / "w.npz", **{"variables/variables/pred_bias:0": np.arange(3.0)})
+    assert list(load_npz(tmp_path / "w.npz")) == ["pred_bias"]

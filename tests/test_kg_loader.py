@@ -1,0 +1,82 @@
+"""CPU: the TSV loader (coper_amd/kg_loader.py) against the outputs of the REFERENCE'S OWN loader code
+(qa_cpg/data.py load_and_preprocess / _write_graph / _assign_ids, run under a stub tensorflow module by
+oracle/gen_golden.py) on a split of the nell-995 dev triples the reference ships."""
+import json
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+from coper_amd.kg_loader import TSVKGLoader
+
+
+def _ref_samples(path):
+    out = []
+    for line in open(path):
+        s = json.loads(line)
+        out.append((s["e1"], s["rel"], s["e2"], frozenset(t for t in s["e2_multi"].split(" ") if t)))
+    return sorted(out, key=lambda x: (x[0], x[1], x[2]))
+
+
+def _my_samples(samples):
+    return sorted(((s["e1"], s["rel"], s["e2"], frozenset(s["e2_multi"])) for s in samples), key=lambda x: (x[0], x[1], x[2]))
+
+
+@pytest.mark.parametrize("clean", [False, True])
+def test_json_samples_equal_reference_loader(golden_dir, tmp_path, clean):
+    ref_dir = os.path.join(golden_dir, "kg_ref_clean" if clean else "kg_ref")
+    for f in ("train.txt", "dev.txt", "test.txt"):
+        shutil.copy(os.path.join(golden_dir, "kg_tsv", f), tmp_path)
+    loader = TSVKGLoader(str(tmp_path), "nell-995-test", needs_test_set_cleaning=clean)
+    samples = loader.load_and_preprocess(write_json=True)
+    for split in ("train", "dev", "test", "full"):
+        assert _my_samples(samples[split]) == _ref_samples(os.path.join(ref_dir, "e1rel_to_e2_%s.json" % split)), split
+        # the JSON files written here parse to the same samples as the reference's files
+        assert _ref_samples(str(tmp_path / ("e1rel_to_e2_%s.json" % split))) == _ref_samples(os.path.join(ref_dir, "e1rel_to_e2_%s.json" % split))
+
+
+@pytest.mark.parametrize("clean", [False, True])
+def test_ids_and_eval_batches_follow_reference_id_files(golden_dir, tmp_path, clean):
+    ref_dir = os.path.join(golden_dir, "kg_ref_clean" if clean else "kg_ref")
+    for f in ("train.txt", "dev.txt", "test.txt"):
+        shutil.copy(os.path.join(golden_dir, "kg_tsv", f), tmp_path)
+    for f in ("entities.txt", "relations.txt"):          # id files written by the reference define the ids
+        shutil.copy(os.path.join(ref_dir, f), tmp_path)
+    loader = TSVKGLoader(str(tmp_path), "nell-995-test", needs_test_set_cleaning=clean)
+    ent, rel = loader.assign_ids()
+    ref_ent = {l.strip(): i for i, l in enumerate(open(os.path.join(ref_dir, "entities.txt")))}
+    ref_rel = {l.strip(): i for i, l in enumerate(open(os.path.join(ref_dir, "relations.txt")))}
+    assert ent == ref_ent and rel == ref_rel
+    assert loader.num_ent == len(ref_ent) and loader.num_rel == len(ref_rel)
+    # num_rel counts the `_reverse` relations (data.py:422-428,338)
+    assert sum(1 for r in ref_rel if r.endswith("_reverse")) * 2 == len(ref_rel)
+    for split in ("dev", "test"):
+        enc = loader.encoded_split(split)
+        # expected: reference JSON lines of the split, forward relations only (run_cpg.py:156), through the id maps
+        exp = []
+        for e1, r, e2, tails in _ref_samples(os.path.join(ref_dir, "e1rel_to_e2_%s.json" % split)):
+            if r.endswith("_reverse"):
+                continue
+            exp.append((ref_ent[e1], ref_rel[r], ref_ent[e2], frozenset(ref_ent[t] for t in tails)))
+        got = []
+        for i in range(len(enc["e1"])):
+            row = enc["filt_idx"][enc["filt_indptr"][i]:enc["filt_indptr"][i + 1]]
+            assert np.all(np.diff(row) > 0)                  # CSR rows sorted unique
+            assert enc["e2"][i] in row                       # the target is a known answer (full-graph labels)
+            got.append((int(enc["e1"][i]), int(enc["rel"][i]), int(enc["e2"][i]), frozenset(int(v) for v in row)))
+        assert sorted(got, key=lambda x: x[:3]) == sorted(exp, key=lambda x: x[:3]), split
+    ds = loader.eval_dataset(dataset_type="test", batch_size=16, dense_mask=True)
+    n = 0
+    for b in ds:
+        assert b["e2_multi"].shape == (len(b["e1"]), loader.num_ent)
+        n += len(b["e1"])
+    assert n == len(loader.encoded_split("test")["e1"])
+
+
+def test_ids_are_deterministic_without_id_files(golden_dir, tmp_path):
+    for f in ("train.txt", "dev.txt", "test.txt"):
+        shutil.copy(os.path.join(golden_dir, "kg_tsv", f), tmp_path)
+    a = TSVKGLoader(str(tmp_path)).assign_ids(write_files=True)
+    b = TSVKGLoader(str(tmp_path)).assign_ids()            # now read back from the files
+    assert a == b and list(a[0]) == sorted(a[0])
