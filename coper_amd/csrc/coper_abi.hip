@@ -503,7 +503,7 @@ COPER_API int coper_rank_counts(coper_handle* h, const float* hvec, const float*
                       int32_t* n_greater, int32_t* n_equal, float* topk_val, int64_t* topk_idx, void* stream) {
   COPER_REQUIRE_PREPARED(h);
   if (B == 0) return COPER_OK;
-  if (!hvec || !tgt || !e2 || !filt_indptr || !n_greater || !n_equal || B < 0 || filt_nnz < 0 ||
+  if (!hvec || !tgt || !e2 || !filt_indptr || !n_greater || B < 0 || filt_nnz < 0 ||
       (filt_nnz > 0 && !filt_idx))
     return fail(h, COPER_EINVAL, "coper_rank_counts: bad argument");
   if (k < 0 || k > 1024 || (k > 0 && (!topk_val || !topk_idx)))
@@ -545,7 +545,7 @@ COPER_API int coper_rank(coper_handle* h, const float* hvec, const int64_t* e2, 
   if ((rc = ensure_workspace(h, B, filt_nnz, s))) return rc;
   if ((rc = coper_target_scores(h, hvec, e2, B, h->tgt_ws, stream))) return rc;
   int32_t* ng = h->cnt_ws;
-  int32_t* ne = n_equal ? n_equal : h->cnt_ws + h->ws_queries;
+  int32_t* ne = n_equal;  // NULL: ties are not counted (one compare per score instead of two)
   h->trust_packed = true;  // same hvec, same stream, no caller code in between: the packing of target_scores is valid
   rc = coper_rank_counts(h, hvec, h->tgt_ws, e2, filt_indptr, filt_idx, filt_nnz, B, 0, ng, ne, nullptr, nullptr, stream);
   h->trust_packed = false;

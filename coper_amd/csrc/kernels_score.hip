@@ -61,7 +61,7 @@ constexpr int SC_WAVES = 8;   // entity blocks per unit
 __global__ void k_pack_h(const float* __restrict__ hvec, int64_t B, int d, int KS, float4* __restrict__ hfrag,
                          int64_t total, int32_t* __restrict__ ng, int32_t* __restrict__ ne) {
   int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // ((qtile*NQ + qb)*KS + ks)*64 + l
-  if (j < B) { ng[j] = 0; ne[j] = 0; }  // the count buffers start from zero (saves two memset nodes)
+  if (j < B) { ng[j] = 0; if (ne) ne[j] = 0; }  // the count buffers start from zero (saves two memset nodes)
   if (j >= total) return;
   int l = (int)(j & 63);
   int64_t rest = j >> 6;
@@ -75,6 +75,9 @@ __global__ void k_pack_h(const float* __restrict__ hvec, int64_t B, int d, int K
   hfrag[j] = make_float4(v[0], v[1], v[2], v[3]);
 }
 
+// EQ = false: the caller does not want n_equal (ties are a diagnostic the reference never computes): the
+// epilogue is one compare per score instead of two.
+template <bool EQ>
 __global__ __launch_bounds__(512, 2) void k_score_count_f32(const float4* __restrict__ Ef,
                                                             const float* __restrict__ bias_pad,
                                                             const float4* __restrict__ hfrag,
@@ -117,11 +120,11 @@ __global__ __launch_bounds__(512, 2) void k_score_count_f32(const float4* __rest
   {                                                                           \
     _Pragma("unroll") for (int b = 0; b < NQ; ++b) {                          \
       int g = cg[b] + __shfl_xor(cg[b], 32);                                  \
-      int e = ce[b] + __shfl_xor(ce[b], 32);                                  \
+      int e = EQ ? ce[b] + __shfl_xor(ce[b], 32) : 0;                         \
       int64_t q = cur_tile * (32 * NQ) + b * 32 + (lane & 31);                \
       if (lane < 32 && q < B) {                                               \
         if (g) atomicAdd(&ng[q], g);                                          \
-        if (e) atomicAdd(&ne[q], e);                                          \
+        if (EQ && e) atomicAdd(&ne[q], e);                                    \
       }                                                                       \
     }                                                                         \
   }
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(512, 2) void k_score_count_f32(const float4* __rest
       for (int r = 0; r < 16; ++r) {
         float sc = acc[b][r];
         cg[b] += (sc > t[b]) ? 1 : 0;
-        ce[b] += (sc == t[b]) ? 1 : 0;
+        if (EQ) ce[b] += (sc == t[b]) ? 1 : 0;
       }
 #endif
   }
@@ -212,8 +215,12 @@ int launch_score_count(coper_handle* h, const float* hvec, const float* tgt, int
   if (grid > units) grid = units;
   size_t lds = (size_t)SC_NQ * dm.KS * 64 * sizeof(float4);
   ScopedKernelTimer t(h, "score_count", s);
-  hipLaunchKernelGGL(k_score_count_f32, dim3((unsigned)grid), dim3(512), lds, s, (const float4*)h->Ef, h->bias_pad,
-                     (const float4*)h->hfrag_ws, tgt, B, dm.KS, iters, units, ng, ne);
+  if (ne)
+    hipLaunchKernelGGL(k_score_count_f32<true>, dim3((unsigned)grid), dim3(512), lds, s, (const float4*)h->Ef, h->bias_pad,
+                       (const float4*)h->hfrag_ws, tgt, B, dm.KS, iters, units, ng, ne);
+  else
+    hipLaunchKernelGGL(k_score_count_f32<false>, dim3((unsigned)grid), dim3(512), lds, s, (const float4*)h->Ef, h->bias_pad,
+                       (const float4*)h->hfrag_ws, tgt, B, dm.KS, iters, units, ng, ne);
   COPER_HIP_TRY(h, hipGetLastError());
   return COPER_OK;
 }
@@ -221,7 +228,8 @@ int launch_score_count(coper_handle* h, const float* hvec, const float* tgt, int
 int score_kernels_init(coper_handle* h) {
   const Dims& dm = h->dm;
   int lds = (int)((size_t)SC_NQ * dm.KS * 64 * sizeof(float4));
-  COPER_HIP_TRY(h, hipFuncSetAttribute((const void*)k_score_count_f32, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  COPER_HIP_TRY(h, hipFuncSetAttribute((const void*)k_score_count_f32<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  COPER_HIP_TRY(h, hipFuncSetAttribute((const void*)k_score_count_f32<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   return COPER_OK;
 }
 
@@ -361,7 +369,7 @@ __global__ void k_filter_correct(const float* __restrict__ ent, const float* __r
   const int64_t target = e2[b];
   if (sub == 0) {
     int64_t row = target - lo;
-    if (row >= 0 && row < n_local && t == t) atomicSub(&ne[b], 1);
+    if (ne && row >= 0 && row < n_local && t == t) atomicSub(&ne[b], 1);
   }
   const int64_t beg = indptr[b], end = indptr[b + 1];
   int dg = 0, de = 0;
@@ -383,7 +391,7 @@ __global__ void k_filter_correct(const float* __restrict__ ent, const float* __r
   }
   if (sub == 0) {
     if (dg) atomicSub(&ng[b], dg);
-    if (de) atomicSub(&ne[b], de);
+    if (ne && de) atomicSub(&ne[b], de);
   }
 }
 

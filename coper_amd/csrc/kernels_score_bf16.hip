@@ -91,9 +91,10 @@ constexpr int BX_WAVES = 8;
 
 __global__ void k_zero_counts(int64_t B, int32_t* __restrict__ ng, int32_t* __restrict__ ne) {
   int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < B) { ng[j] = 0; ne[j] = 0; }
+  if (j < B) { ng[j] = 0; if (ne) ne[j] = 0; }
 }
 
+template <bool EQ>
 __global__ __launch_bounds__(512, 2) void k_score_count_bf16x3(const uint4* __restrict__ Ehi,
                                                                const uint4* __restrict__ Elo,
                                                                const float* __restrict__ bias_pad,
@@ -112,7 +113,6 @@ __global__ __launch_bounds__(512, 2) void k_score_count_bf16x3(const uint4* __re
   float t[NQ];
   int cg[NQ], ce[NQ];
   int64_t cur_tile = -1;
-  uint4 a0h, a0l, a1h, a1l, b0h[NQ], b0l[NQ], b1h[NQ], b1l[NQ];
   float4 bq[4];
 
 #define LOAD_A(ah, al, ebx, ks_)                         \
@@ -139,18 +139,24 @@ __global__ __launch_bounds__(512, 2) void k_score_count_bf16x3(const uint4* __re
   {                                                                           \
     _Pragma("unroll") for (int b = 0; b < NQ; ++b) {                          \
       int g = cg[b] + __shfl_xor(cg[b], 32);                                  \
-      int e = ce[b] + __shfl_xor(ce[b], 32);                                  \
+      int e = EQ ? ce[b] + __shfl_xor(ce[b], 32) : 0;                         \
       int64_t q = cur_tile * (32 * NQ) + b * 32 + (lane & 31);                \
       if (lane < 32 && q < B) {                                               \
         if (g) atomicAdd(&ng[q], g);                                          \
-        if (e) atomicAdd(&ne[q], e);                                          \
+        if (EQ && e) atomicAdd(&ne[q], e);                                    \
       }                                                                       \
     }                                                                         \
   }
 
+  // entity fragments are fetched THREE k-steps ahead (a k-step is only 12 MFMAs = 384 cycles here, shorter
+  // than an L2 round trip under load): four rotating register buffers
+  uint4 ah[4], al[4];
+#define KCL(k_) ((k_) < KS ? (k_) : KS - 1)
   if (u_begin < u_end) {
     int64_t eb = (u_begin % iters) * BX_WAVES + wave;
-    LOAD_A(a0h, a0l, eb, 0);
+    LOAD_A(ah[0], al[0], eb, 0);
+    LOAD_A(ah[1], al[1], eb, KCL(1));
+    LOAD_A(ah[2], al[2], eb, KCL(2));
     LOAD_BIAS(eb);
   }
   for (int64_t u = u_begin; u < u_end; ++u) {
@@ -180,23 +186,23 @@ __global__ __launch_bounds__(512, 2) void k_score_count_bf16x3(const uint4* __re
         acc[b][4 * j + 0] = bq[j].x; acc[b][4 * j + 1] = bq[j].y;
         acc[b][4 * j + 2] = bq[j].z; acc[b][4 * j + 3] = bq[j].w;
       }
-    LOAD_B(b0h, b0l, 0);
-    int ks = 0;
-    for (; ks + 2 <= KS; ks += 2) {
-      LOAD_A(a1h, a1l, eb, ks + 1);
-      LOAD_B(b1h, b1l, ks + 1);
-      __builtin_amdgcn_sched_barrier(0);
-      STEP(a0h, a0l, b0h, b0l);
-      const int kn = ks + 2 < KS ? ks + 2 : KS - 1;
-      LOAD_A(a0h, a0l, eb, kn);
-      LOAD_B(b0h, b0l, kn);
-      __builtin_amdgcn_sched_barrier(0);
-      STEP(a1h, a1l, b1h, b1l);
+    for (int ks = 0; ks < KS; ks += 4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (ks + j < KS) {  // wave-uniform
+          LOAD_A(ah[(j + 3) & 3], al[(j + 3) & 3], eb, KCL(ks + j + 3));
+          __builtin_amdgcn_sched_barrier(0);
+          uint4 bh[NQ], bl[NQ];
+          LOAD_B(bh, bl, ks + j);
+          STEP(ah[j], al[j], bh, bl);
+        }
+      }
     }
-    if (ks < KS) STEP(a0h, a0l, b0h, b0l);
     if (u + 1 < u_end) {
       const int64_t ebn = ((u + 1) % iters) * BX_WAVES + wave;
-      LOAD_A(a0h, a0l, ebn, 0);
+      LOAD_A(ah[0], al[0], ebn, 0);
+      LOAD_A(ah[1], al[1], ebn, KCL(1));
+      LOAD_A(ah[2], al[2], ebn, KCL(2));
       LOAD_BIAS(ebn);
     }
 #pragma unroll
@@ -205,9 +211,10 @@ __global__ __launch_bounds__(512, 2) void k_score_count_bf16x3(const uint4* __re
       for (int r = 0; r < 16; ++r) {
         float sc = acc[b][r];
         cg[b] += (sc > t[b]) ? 1 : 0;
-        ce[b] += (sc == t[b]) ? 1 : 0;
+        if (EQ) ce[b] += (sc == t[b]) ? 1 : 0;
       }
   }
+#undef KCL
   if (cur_tile >= 0) FLUSH_COUNTS();
 #undef LOAD_A
 #undef LOAD_B
@@ -233,16 +240,22 @@ int launch_score_count_bf16x3(coper_handle* h, const float* hvec, const float* t
   if (grid > units) grid = units;
   size_t lds = (size_t)2 * BX_NQ * dm.KS16 * 64 * sizeof(uint4);
   ScopedKernelTimer t(h, "score_count", s);
-  hipLaunchKernelGGL(k_score_count_bf16x3, dim3((unsigned)grid), dim3(512), lds, s, (const uint4*)h->Ef16_hi,
-                     (const uint4*)h->Ef16_lo, h->bias_pad, (const uint4*)h->hfrag16_hi, (const uint4*)h->hfrag16_lo, tgt,
-                     B, dm.KS16, iters, units, ng, ne);
+  if (ne)
+    hipLaunchKernelGGL(k_score_count_bf16x3<true>, dim3((unsigned)grid), dim3(512), lds, s, (const uint4*)h->Ef16_hi,
+                       (const uint4*)h->Ef16_lo, h->bias_pad, (const uint4*)h->hfrag16_hi, (const uint4*)h->hfrag16_lo, tgt,
+                       B, dm.KS16, iters, units, ng, ne);
+  else
+    hipLaunchKernelGGL(k_score_count_bf16x3<false>, dim3((unsigned)grid), dim3(512), lds, s, (const uint4*)h->Ef16_hi,
+                       (const uint4*)h->Ef16_lo, h->bias_pad, (const uint4*)h->hfrag16_hi, (const uint4*)h->hfrag16_lo, tgt,
+                       B, dm.KS16, iters, units, ng, ne);
   COPER_HIP_TRY(h, hipGetLastError());
   return COPER_OK;
 }
 
 int score_bf16_kernels_init(coper_handle* h) {
   int lds = (int)((size_t)2 * BX_NQ * h->dm.KS16 * 64 * sizeof(uint4));
-  COPER_HIP_TRY(h, hipFuncSetAttribute((const void*)k_score_count_bf16x3, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  COPER_HIP_TRY(h, hipFuncSetAttribute((const void*)k_score_count_bf16x3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  COPER_HIP_TRY(h, hipFuncSetAttribute((const void*)k_score_count_bf16x3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   return COPER_OK;
 }
 
@@ -410,7 +423,7 @@ __global__ __launch_bounds__(256) void k_pair_bf16x3(const uint4* __restrict__ E
   if (erow < 0) return;
   float t = tgt[q];
   if (sc > t) atomicSub(&ng[q], 1);
-  else if (sc == t) atomicSub(&ne[q], 1);
+  else if (ne && sc == t) atomicSub(&ne[q], 1);
 }
 
 // CSR -> row id per entry, and the retirement of the target itself (scored == tgt, counted as "equal")
@@ -425,7 +438,7 @@ __global__ void k_expand_rows_retire_target(const int64_t* __restrict__ indptr, 
   if (sub == 0) {
     int64_t row = e2[b] - lo;
     float t = tgt[b];
-    if (row >= 0 && row < n_local && t == t) atomicSub(&ne[b], 1);
+    if (ne && row >= 0 && row < n_local && t == t) atomicSub(&ne[b], 1);
   }
 }
 

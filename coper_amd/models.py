@@ -250,14 +250,14 @@ class ConvE(object):
             return ng, ne, tv, ti
         return ng, ne
 
-    def rank(self, h, e2, filt_indptr, filt_idx, filt_nnz=None):
-        """Filtered ranks int32 [B] (+ n_equal) on an unsharded model."""
+    def rank(self, h, e2, filt_indptr, filt_idx, filt_nnz=None, want_equal=True):
+        """Filtered ranks int32 [B] (+ n_equal, or None with want_equal=False) on an unsharded model."""
         self._need_prepared()
         e2, ip, ix = self._ids(e2), self._ids(filt_indptr), self._ids(filt_idx)
         B = e2.numel()
         nnz = int(ix.numel()) if filt_nnz is None else int(filt_nnz)
         ranks = torch.empty((B,), device=self.device, dtype=torch.int32)
-        ne = torch.empty((B,), device=self.device, dtype=torch.int32)
+        ne = torch.empty((B,), device=self.device, dtype=torch.int32) if want_equal else None
         _lib.check(self._h, self._lib.coper_rank(self._h, _ptr(h), _ptr(e2), _ptr(ip), _ptr(ix), nnz, B, _ptr(ranks), _ptr(ne),
                                                  self._stream()))
         return ranks, ne

@@ -38,10 +38,15 @@ def shard_bounds(num_ent: int, world: int, rank: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def local_rank_pass(model, chunk):
-    """Unsharded: encode + fused filtered rank for one chunk of queries.  Returns (ranks, n_equal) int32 tensors."""
+def local_rank_pass(model, chunk, want_equal=False):
+    """Unsharded: encode + fused filtered rank for one chunk of queries.  Returns (ranks, n_equal) int32 tensors;
+    n_equal is None unless asked for (ranking_and_hits, like the reference, has no use for tie counts)."""
     h = model.encode(chunk["e1"], chunk["rel"])
-    return model.rank(h, chunk["e2"], chunk["filt_indptr"], chunk["filt_idx"], filt_nnz=len(chunk["filt_idx"]))
+    try:
+        return model.rank(h, chunk["e2"], chunk["filt_indptr"], chunk["filt_idx"], filt_nnz=len(chunk["filt_idx"]),
+                          want_equal=want_equal)
+    except TypeError:   # scorers without the option
+        return model.rank(h, chunk["e2"], chunk["filt_indptr"], chunk["filt_idx"], filt_nnz=len(chunk["filt_idx"]))
 
 
 def _slice_chunk(chunk, lo, hi):
@@ -62,7 +67,7 @@ class QueryShardedEvaluator(object):
         Q = len(chunk["e1"])
         lo, hi = shard_bounds(Q, self.world, self.rank_id)
         if hi > lo:
-            r, ne = self.rank_fn(self.scorer, _slice_chunk(chunk, lo, hi))
+            r, ne = self.rank_fn(self.scorer, _slice_chunk(chunk, lo, hi), want_equal=True)
         else:
             dev = getattr(self.scorer, "device", "cpu")
             r = torch.zeros(0, dtype=torch.int32, device=dev)

@@ -155,6 +155,8 @@ COPER_API int coper_target_scores(coper_handle* h, const float* hvec, const int6
  *   n_equal[b]   = #{ j != e2[b], j not filtered : logit(b,j) == tgt[b] }
  * so that rank = 1 + sum_over_shards(n_greater) when tie-free (any value in
  * [1+n_greater, 1+n_greater+n_equal] under ties -- the reference's np.argsort is unstable).
+ * n_equal may be NULL: ties are then not counted (the reference never computes them; saves one compare per
+ * score) and rank = 1 + n_greater is the optimistic end of the band.
  * tgt: [B] global target scores (from coper_target_scores, summed over shards).
  * filt_nnz = filt_indptr[B], passed from the host that built the CSR (sizes the launch).
  * k > 0 additionally returns the shard's top-k of the FILTERED row (target kept, like

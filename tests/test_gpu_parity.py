@@ -218,6 +218,11 @@ def test_batch_invariance_determinism_and_chunking(oracle_chain):
     assert np.array_equal(hp, h1[perm])
     hs = m.encode(q["e1"][:37], q["rel"][:37]).cpu().numpy()
     assert np.array_equal(hs, h1[:37])
+    # ranks do not depend on whether tie counts are requested (n_equal = NULL: one compare per score)
+    hq = m.encode(q["e1"], q["rel"])
+    r_eq, ne = m.rank(hq, q["e2"], q["filt_indptr"], q["filt_idx"])
+    r_no, none = m.rank(hq, q["e2"], q["filt_indptr"], q["filt_idx"], want_equal=False)
+    assert none is None and np.array_equal(r_eq.cpu().numpy(), r_no.cpu().numpy())
     ds = cdata.EvalDataset(q, 128, md["num_ent"])
     a = ranking_and_hits(m, None, ds, "whole", return_ranks=True)
     b = ranking_and_hits(m, None, ds, "chunked", max_chunk=100, return_ranks=True)
