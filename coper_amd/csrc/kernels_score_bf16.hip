@@ -86,7 +86,13 @@ int launch_rows_to_frag_bf16(coper_handle* h, const float* src, int64_t n_rows, 
 // fused score + count: same persistent, statically balanced structure as k_score_count_f32
 // (kernels_score.hip): unit = 128 queries x 256 entities, 8 waves x one 32-row entity block.
 // ------------------------------------------------------------------------------------------------
-constexpr int BX_NQ = 4;
+#ifndef COPER_BX_NQ
+#define COPER_BX_NQ 4
+#endif
+#ifndef COPER_BX_WGS_PER_CU
+#define COPER_BX_WGS_PER_CU 1
+#endif
+constexpr int BX_NQ = COPER_BX_NQ;
 constexpr int BX_WAVES = 8;
 
 __global__ void k_zero_counts(int64_t B, int32_t* __restrict__ ng, int32_t* __restrict__ ne) {
@@ -236,7 +242,7 @@ int launch_score_count_bf16x3(coper_handle* h, const float* hvec, const float* t
   int64_t q_tiles = (B + 32 * BX_NQ - 1) / (32 * BX_NQ);
   int64_t iters = dm.n_eblk / BX_WAVES;
   int64_t units = q_tiles * iters;
-  int64_t grid = h->num_cus;
+  int64_t grid = (int64_t)h->num_cus * COPER_BX_WGS_PER_CU;
   if (grid > units) grid = units;
   size_t lds = (size_t)2 * BX_NQ * dm.KS16 * 64 * sizeof(uint4);
   ScopedKernelTimer t(h, "score_count", s);

@@ -9,7 +9,7 @@ name = sys.argv[1] if len(sys.argv) > 1 else "fb15k237_cpg"
 Q = int(sys.argv[2]) if len(sys.argv) > 2 else 20480
 md = cdata.model_descriptors(name)
 p = cdata.synthetic_params(md, 0)
-m = ConvE(md, device="cuda:0").load_parameters(p).prepare()
+m = ConvE(md, device="cuda:0", score_mode=os.environ.get("COPER_MODE", "bf16x3")).load_parameters(p).prepare()
 q = cdata.synthetic_queries(md, Q, seed=0)
 h = m.encode(q["e1"], q["rel"])
 tgt = m.target_scores(h, q["e2"])
@@ -17,7 +17,7 @@ dq = {k: torch.as_tensor(v).cuda() for k, v in q.items()}
 for _ in range(3):
     m.rank_counts(h, tgt, dq["e2"], dq["filt_indptr"], dq["filt_idx"])
 m.profile(True); m.profile_read("score_count")
-for _ in range(20):
+for _ in range(40):
     m.rank_counts(h, tgt, dq["e2"], dq["filt_indptr"], dq["filt_idx"])
 torch.cuda.synchronize()
 ms, n = m.profile_read("score_count")
