@@ -61,7 +61,7 @@ constexpr int SC_WAVES = 8;   // entity blocks per unit
 __global__ void k_pack_h(const float* __restrict__ hvec, int64_t B, int d, int KS, float4* __restrict__ hfrag,
                          int64_t total, int32_t* __restrict__ ng, int32_t* __restrict__ ne) {
   int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // ((qtile*NQ + qb)*KS + ks)*64 + l
-  if (j < B) { ng[j] = 0; if (ne) ne[j] = 0; }  // the count buffers start from zero (saves two memset nodes)
+  if (ng && j < B) { ng[j] = 0; if (ne) ne[j] = 0; }  // the count buffers start from zero (saves two memset nodes)
   if (j >= total) return;
   int l = (int)(j & 63);
   int64_t rest = j >> 6;
@@ -240,14 +240,13 @@ int score_kernels_init(coper_handle* h) {
 template <int NQ, int ME>
 __global__ __launch_bounds__(256, 2) void k_score_all_f32(const float4* __restrict__ Ef,
                                                           const float* __restrict__ bias_pad,
-                                                          const float* __restrict__ hvec, int64_t B, int d, int KS,
+                                                          const float4* __restrict__ hfrag, int64_t B, int KS,
                                                           int64_t n_eblk, int64_t n_local,
                                                           float* __restrict__ logits, int64_t ld) {
-  extern __shared__ float4 hl[];
-  const int64_t q0 = (int64_t)blockIdx.x * (32 * NQ);
-  stage_h_frag<NQ>(hl, hvec, q0, B, d, KS);
-  __syncthreads();
+  // both operands stream from their fragment images (h pre-packed by k_pack_h), one k-step ahead; no LDS
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t qb0 = (int64_t)blockIdx.x * NQ;  // 32-query blocks
+  const int64_t q0 = qb0 * 32;
   const int64_t eb0 = ((int64_t)blockIdx.y * 4 + wave) * ME;
   if (eb0 >= n_eblk) return;
   f32x16 acc[NQ][ME];
@@ -260,20 +259,33 @@ __global__ __launch_bounds__(256, 2) void k_score_all_f32(const float4* __restri
       for (int r = 0; r < 16; ++r) acc[b][a][r] = bv;
   }
   const float4* ep = Ef + (eb0 * KS) * 64 + lane;
-  for (int ks = 0; ks < KS; ++ks) {
-    float4 ev[ME], hv[NQ];
-#pragma unroll
-    for (int a = 0; a < ME; ++a) ev[a] = ep[((int64_t)a * KS + ks) * 64];
-#pragma unroll
-    for (int b = 0; b < NQ; ++b) hv[b] = hl[(b * KS + ks) * 64 + lane];
-#pragma unroll
-    for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-      for (int b = 0; b < NQ; ++b)
-#pragma unroll
-        for (int a = 0; a < ME; ++a)
-          acc[b][a] = __builtin_amdgcn_mfma_f32_32x32x2f32(F4C(hv[b], tt), F4C(ev[a], tt), acc[b][a], 0, 0, 0);
+  const float4* hp = hfrag + (qb0 * KS) * 64 + lane;
+  float4 e0[ME], h0[NQ], e1[ME], h1[NQ];
+#define LOAD_EH(ev, hv, ks_)                                                              \
+  {                                                                                       \
+    _Pragma("unroll") for (int a = 0; a < ME; ++a) ev[a] = ep[((int64_t)a * KS + (ks_)) * 64]; \
+    _Pragma("unroll") for (int b = 0; b < NQ; ++b) hv[b] = hp[((int64_t)b * KS + (ks_)) * 64]; \
   }
+#define MFMA_EH(ev, hv)                                                                                     \
+  {                                                                                                         \
+    _Pragma("unroll") for (int tt = 0; tt < 4; ++tt) _Pragma("unroll") for (int b = 0; b < NQ; ++b)          \
+        _Pragma("unroll") for (int a = 0; a < ME; ++a) acc[b][a] =                                           \
+            __builtin_amdgcn_mfma_f32_32x32x2f32(F4C(hv[b], tt), F4C(ev[a], tt), acc[b][a], 0, 0, 0);        \
+  }
+  LOAD_EH(e0, h0, 0);
+  int ks = 0;
+  for (; ks + 2 <= KS; ks += 2) {
+    LOAD_EH(e1, h1, ks + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    MFMA_EH(e0, h0);
+    const int kn = ks + 2 < KS ? ks + 2 : KS - 1;
+    LOAD_EH(e0, h0, kn);
+    __builtin_amdgcn_sched_barrier(0);
+    MFMA_EH(e1, h1);
+  }
+  if (ks < KS) MFMA_EH(e0, h0);
+#undef LOAD_EH
+#undef MFMA_EH
 #pragma unroll
   for (int b = 0; b < NQ; ++b)
 #pragma unroll
@@ -294,10 +306,14 @@ int launch_score_all(coper_handle* h, const float* hvec, int64_t B, float* logit
   int64_t q_tiles = (B + 32 * NQ - 1) / (32 * NQ);
   int64_t e_groups = (dm.n_eblk + 4 * ME - 1) / (4 * ME);
   if (e_groups > 65535) return fail(h, COPER_EUNSUPPORTED, "score_all: shard too large to materialise logits");
-  size_t lds = (size_t)NQ * dm.KS * 64 * sizeof(float4);
+  int64_t q_tiles4 = (B + 32 * SC_NQ - 1) / (32 * SC_NQ);
+  int64_t total = q_tiles4 * SC_NQ * dm.KS * 64;
+  hipLaunchKernelGGL(k_pack_h, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, hvec, B, dm.d, dm.KS,
+                     (float4*)h->hfrag_ws, total, (int32_t*)nullptr, (int32_t*)nullptr);
   ScopedKernelTimer t(h, "score_all", s);
-  hipLaunchKernelGGL((k_score_all_f32<NQ, ME>), dim3((unsigned)q_tiles, (unsigned)e_groups), dim3(256), lds, s,
-                     (const float4*)h->Ef, h->bias_pad, hvec, B, dm.d, dm.KS, dm.n_eblk, dm.n_local, logits, ld);
+  hipLaunchKernelGGL((k_score_all_f32<NQ, ME>), dim3((unsigned)q_tiles, (unsigned)e_groups), dim3(256), 0, s,
+                     (const float4*)h->Ef, h->bias_pad, (const float4*)h->hfrag_ws, B, dm.KS, dm.n_eblk, dm.n_local,
+                     logits, ld);
   COPER_HIP_TRY(h, hipGetLastError());
   return COPER_OK;
 }

@@ -266,9 +266,10 @@ int score_bf16_kernels_init(coper_handle* h) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// logits out (predictions_all): same operand roles as score_count (entity rows on the accumulator
-// registers, one query per lane) so the bits are the same; each lane stores 4 consecutive entities of
-// its query per register quad (16-B stores).
+// logits out (predictions_all): operand roles swapped relative to score_count (queries = A rows, entities
+// = B columns) so that a register row is 32 consecutive entities of one query -> 128-B contiguous stores.
+// The three MFMAs of a k-step multiply the same (entity, query) terms in the same order, and a product
+// does not depend on which side of the matrix unit its factors enter: the bits equal score_count's.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void k_score_all_bf16x3(const uint4* __restrict__ Ehi,
                                                              const uint4* __restrict__ Elo,
@@ -282,52 +283,62 @@ __global__ __launch_bounds__(256, 2) void k_score_all_bf16x3(const uint4* __rest
   const int64_t qblk0 = (int64_t)blockIdx.x * NQ;  // 32-query blocks (hfrag is packed per 32-query block)
   const int64_t eb0 = ((int64_t)blockIdx.y * 4 + wave) * ME;
   if (eb0 >= n_eblk) return;
-  f32x16 acc[ME][NQ];
+  f32x16 acc[NQ][ME];
 #pragma unroll
   for (int a = 0; a < ME; ++a) {
-    const float4* bp = (const float4*)(bias_pad + (eb0 + a) * 32 + 4 * (lane >> 5));
+    float bv = bias_pad[(eb0 + a) * 32 + (lane & 31)];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float4 b4 = bp[2 * j];
+    for (int b = 0; b < NQ; ++b)
 #pragma unroll
-      for (int b = 0; b < NQ; ++b) {
-        acc[a][b][4 * j + 0] = b4.x; acc[a][b][4 * j + 1] = b4.y;
-        acc[a][b][4 * j + 2] = b4.z; acc[a][b][4 * j + 3] = b4.w;
-      }
-    }
+      for (int r = 0; r < 16; ++r) acc[b][a][r] = bv;
   }
-  for (int ks = 0; ks < KS; ++ks) {
-    uint4 ah[ME], al[ME], bh[NQ], bl[NQ];
+  uint4 eh0[ME], el0[ME], qh0[NQ], ql0[NQ], eh1[ME], el1[ME], qh1[NQ], ql1[NQ];
+#define LOAD_EQ(eh, el, qh, ql, ks_)                                          \
+  {                                                                           \
+    _Pragma("unroll") for (int a = 0; a < ME; ++a) {                          \
+      int64_t o = ((eb0 + a) * KS + (ks_)) * 64 + lane;                       \
+      eh[a] = Ehi[o];                                                         \
+      el[a] = Elo[o];                                                         \
+    }                                                                         \
+    _Pragma("unroll") for (int b = 0; b < NQ; ++b) {                          \
+      int64_t o = ((qblk0 + b) * KS + (ks_)) * 64 + lane;                     \
+      qh[b] = Hhi[o];                                                         \
+      ql[b] = Hlo[o];                                                         \
+    }                                                                         \
+  }
+  // same term order as MFMA_X3(e_hi, e_lo, q_hi, q_lo): e_lo*q_hi, e_hi*q_lo, e_hi*q_hi -- with the query as A
+#define STEP_EQ(eh, el, qh, ql)                                                                      \
+  {                                                                                                  \
+    _Pragma("unroll") for (int b = 0; b < NQ; ++b) _Pragma("unroll") for (int a = 0; a < ME; ++a) {  \
+      acc[b][a] = MFMA_BF16(qh[b], el[a], acc[b][a]);                                                \
+      acc[b][a] = MFMA_BF16(ql[b], eh[a], acc[b][a]);                                                \
+      acc[b][a] = MFMA_BF16(qh[b], eh[a], acc[b][a]);                                                \
+    }                                                                                                \
+  }
+  LOAD_EQ(eh0, el0, qh0, ql0, 0);
+  int ks = 0;
+  for (; ks + 2 <= KS; ks += 2) {
+    LOAD_EQ(eh1, el1, qh1, ql1, ks + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    STEP_EQ(eh0, el0, qh0, ql0);
+    const int kn = ks + 2 < KS ? ks + 2 : KS - 1;
+    LOAD_EQ(eh0, el0, qh0, ql0, kn);
+    __builtin_amdgcn_sched_barrier(0);
+    STEP_EQ(eh1, el1, qh1, ql1);
+  }
+  if (ks < KS) STEP_EQ(eh0, el0, qh0, ql0);
+#undef LOAD_EQ
+#undef STEP_EQ
+#pragma unroll
+  for (int b = 0; b < NQ; ++b)
 #pragma unroll
     for (int a = 0; a < ME; ++a) {
-      int64_t o = ((eb0 + a) * KS + ks) * 64 + lane;
-      ah[a] = Ehi[o];
-      al[a] = Elo[o];
-    }
+      int64_t e = (eb0 + a) * 32 + (lane & 31);
+      if (e >= n_local) continue;
 #pragma unroll
-    for (int b = 0; b < NQ; ++b) {
-      int64_t o = ((qblk0 + b) * KS + ks) * 64 + lane;
-      bh[b] = Hhi[o];
-      bl[b] = Hlo[o];
-    }
-#pragma unroll
-    for (int a = 0; a < ME; ++a)
-#pragma unroll
-      for (int b = 0; b < NQ; ++b) MFMA_X3(ah[a], al[a], bh[b], bl[b], acc[a][b]);
-  }
-#pragma unroll
-  for (int a = 0; a < ME; ++a)
-#pragma unroll
-    for (int b = 0; b < NQ; ++b) {
-      int64_t q = (qblk0 + b) * 32 + (lane & 31);
-      if (q >= B) continue;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        int64_t e = (eb0 + a) * 32 + 8 * j + 4 * (lane >> 5);
-        float* dst = logits + q * ld + e;
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-          if (e + c < n_local) dst[c] = acc[a][b][4 * j + c];
+      for (int r = 0; r < 16; ++r) {
+        int64_t q = (qblk0 + b) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (q < B) logits[q * ld + e] = acc[b][a][r];
       }
     }
 }
