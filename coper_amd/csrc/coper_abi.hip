@@ -115,7 +115,9 @@ static int ensure_workspace(coper_handle* h, int64_t B, int64_t nnz, hipStream_t
   } else {
     size_t plane = (size_t)((cap + 127) / 128) * 4 * dm.KS16 * 64 * 16;
     dev_free((char**)&h->hfrag16_hi); dev_free((char**)&h->hfrag16_lo);
-    if (hipMalloc(&h->hfrag16_hi, plane) != hipSuccess || hipMalloc(&h->hfrag16_lo, plane) != hipSuccess)
+    dev_free((char**)&h->hrm16_hi); dev_free((char**)&h->hrm16_lo);
+    if (hipMalloc(&h->hfrag16_hi, plane) != hipSuccess || hipMalloc(&h->hfrag16_lo, plane) != hipSuccess ||
+        hipMalloc(&h->hrm16_hi, plane) != hipSuccess || hipMalloc(&h->hrm16_lo, plane) != hipSuccess)
       return fail(h, COPER_ENOMEM, "hipMalloc of the bf16 query planes failed");
   }
   h->ws_queries = cap;
@@ -235,6 +237,7 @@ COPER_API void coper_destroy(coper_handle* h) {
   dev_free(&h->tgt_ws); dev_free(&h->cnt_ws); dev_free(&h->hfrag_ws); dev_free(&h->logits_ws); dev_free(&h->row_of_ws);
   dev_free((char**)&h->Wf16_hi); dev_free((char**)&h->Wf16_lo);
   dev_free((char**)&h->Ef16_hi); dev_free((char**)&h->Ef16_lo); dev_free((char**)&h->hfrag16_hi); dev_free((char**)&h->hfrag16_lo);
+  dev_free((char**)&h->Erm16_hi); dev_free((char**)&h->Erm16_lo); dev_free((char**)&h->hrm16_hi); dev_free((char**)&h->hrm16_lo);
   for (auto& kv : h->timers)
     for (auto& p : kv.second.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   delete h;
@@ -402,11 +405,14 @@ COPER_API int coper_prepare(coper_handle* h, void* stream) {
     // bias_pad comes from the (tiny-KS) fp32 image builder run on a 1-k-step view; the table goes to two bf16 planes
     size_t plane = (size_t)dm.n_eblk * dm.KS16 * 64 * 16;
     dev_free((char**)&h->Ef16_hi); dev_free((char**)&h->Ef16_lo);
-    if (hipMalloc(&h->Ef16_hi, plane) != hipSuccess || hipMalloc(&h->Ef16_lo, plane) != hipSuccess)
+    dev_free((char**)&h->Erm16_hi); dev_free((char**)&h->Erm16_lo);
+    if (hipMalloc(&h->Ef16_hi, plane) != hipSuccess || hipMalloc(&h->Ef16_lo, plane) != hipSuccess ||
+        hipMalloc(&h->Erm16_hi, plane) != hipSuccess || hipMalloc(&h->Erm16_lo, plane) != hipSuccess)
       return fail(h, COPER_ENOMEM, "hipMalloc of the bf16 entity planes failed");
     if ((rc = dev_alloc(h, &h->bias_pad, (size_t)dm.n_eblk * 32))) return rc;
     if ((rc = launch_bias_pad(h, P("pred_bias"), s))) return rc;
-    if ((rc = launch_rows_to_frag_bf16(h, P("ent_emb"), dm.n_local, dm.n_eblk, (uint4*)h->Ef16_hi, (uint4*)h->Ef16_lo, s)))
+    if ((rc = launch_rows_to_frag_bf16(h, P("ent_emb"), dm.n_local, dm.n_eblk, (uint4*)h->Ef16_hi, (uint4*)h->Ef16_lo,
+                                       (uint4*)h->Erm16_hi, (uint4*)h->Erm16_lo, s)))
       return rc;
     if ((rc = score_bf16_kernels_init(h))) return rc;
   }

@@ -75,6 +75,8 @@ struct coper_handle {
   bool enc_bf16 = false;        // encoder runs in bf16x3 (needs 3x3 filters, C % 8 == 0)
   void* Ef16_hi = nullptr;      // COPER_SCORE_BF16X3: entity table hi / lo bf16 planes, fragment-major
   void* Ef16_lo = nullptr;      //   [n_eblk][KS16][64] x 16 B
+  void* Erm16_hi = nullptr;     //   row-major twins [n_eblk*32][KS16*16] bf16 (pair kernel gathers)
+  void* Erm16_lo = nullptr;
   float* ctx_tmp[2] = {nullptr, nullptr};  // generator hidden activations
   size_t ctx_tmp_elems = 0;
 
@@ -97,6 +99,8 @@ struct coper_handle {
   int64_t logits_ws_rows = 0;
   void* hfrag16_hi = nullptr;     // bf16x3: h hi / lo planes in fragment order
   void* hfrag16_lo = nullptr;
+  void* hrm16_hi = nullptr;       //   row-major twins
+  void* hrm16_lo = nullptr;
   const float* packed_hvec = nullptr;  // what hfrag16 currently holds (only trusted inside coper_rank)
   int64_t packed_B = 0;
   bool trust_packed = false;
@@ -155,7 +159,7 @@ int launch_finish_ranks(coper_handle* h, const int32_t* ng, int64_t B, int32_t* 
 int score_kernels_init(coper_handle* h);
 // kernels_score_bf16.hip (COPER_SCORE_BF16X3)
 int launch_rows_to_frag_bf16(coper_handle* h, const float* src, int64_t n_rows, int64_t n_blk, uint4* hi, uint4* lo,
-                             hipStream_t s);
+                             uint4* rm_hi, uint4* rm_lo, hipStream_t s);
 int launch_pack_h_bf16(coper_handle* h, const float* hvec, int64_t B, hipStream_t s);
 int launch_score_count_bf16x3(coper_handle* h, const float* hvec, const float* tgt, int64_t B, int32_t* ng,
                               int32_t* ne, hipStream_t s);

@@ -54,6 +54,7 @@ __device__ __forceinline__ void split8(const float* v, uint4& hi, uint4& lo) {
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_rows_to_frag_bf16(const float* __restrict__ src, int64_t n_rows, int d,
                                                            int KS16, uint4* __restrict__ hi, uint4* __restrict__ lo,
+                                                           uint4* __restrict__ rm_hi, uint4* __restrict__ rm_lo,
                                                            int64_t total) {
   int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (blk*KS16 + ks)*64 + l
   if (j >= total) return;
@@ -70,14 +71,19 @@ __global__ __launch_bounds__(256) void k_rows_to_frag_bf16(const float* __restri
   split8(v, h4, l4);
   hi[j] = h4;
   lo[j] = l4;
+  if (rm_hi) {  // row-major twin of the planes: row r = 2*KS16 pieces of 16 B (the pair kernel gathers whole rows)
+    int64_t o = row * (2 * KS16) + 2 * ks + (l >> 5);
+    rm_hi[o] = h4;
+    rm_lo[o] = l4;
+  }
 }
 
 int launch_rows_to_frag_bf16(coper_handle* h, const float* src, int64_t n_rows, int64_t n_blk, uint4* hi, uint4* lo,
-                             hipStream_t s) {
+                             uint4* rm_hi, uint4* rm_lo, hipStream_t s) {
   const Dims& dm = h->dm;
   int64_t total = n_blk * dm.KS16 * 64;
   hipLaunchKernelGGL(k_rows_to_frag_bf16, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, n_rows, dm.d,
-                     dm.KS16, hi, lo, total);
+                     dm.KS16, hi, lo, rm_hi, rm_lo, total);
   COPER_HIP_TRY(h, hipGetLastError());
   return COPER_OK;
 }
@@ -231,7 +237,8 @@ __global__ __launch_bounds__(512, 2) void k_score_count_bf16x3(const uint4* __re
 
 int launch_pack_h_bf16(coper_handle* h, const float* hvec, int64_t B, hipStream_t s) {
   int64_t n_blk = (B + 32 * BX_NQ - 1) / (32 * BX_NQ) * BX_NQ;
-  return launch_rows_to_frag_bf16(h, hvec, B, n_blk, (uint4*)h->hfrag16_hi, (uint4*)h->hfrag16_lo, s);
+  return launch_rows_to_frag_bf16(h, hvec, B, n_blk, (uint4*)h->hfrag16_hi, (uint4*)h->hfrag16_lo, (uint4*)h->hrm16_hi,
+                                  (uint4*)h->hrm16_lo, s);
 }
 
 int launch_score_count_bf16x3(coper_handle* h, const float* hvec, const float* tgt, int64_t B, int32_t* ng,
@@ -407,24 +414,25 @@ __global__ __launch_bounds__(256) void k_pair_bf16x3(const uint4* __restrict__ E
     acc[r] = er >= 0 ? bias_pad[er] : 0.f;
   }
   const int64_t ea = erow >= 0 ? erow : 0;
-  const uint4* pa_h = Ehi + ((ea >> 5) * KS) * 64 + half * 32 + (ea & 31);
-  const uint4* pa_l = Elo + ((ea >> 5) * KS) * 64 + half * 32 + (ea & 31);
-  const uint4* pb_h = Hhi + ((q >> 5) * KS) * 64 + half * 32 + (q & 31);
-  const uint4* pb_l = Hlo + ((q >> 5) * KS) * 64 + half * 32 + (q & 31);
+  // row-major twins of the planes: a lane walks its own row (32 B per k-step), so every fetched line is used whole
+  const uint4* pa_h = Ehi + ea * (2 * KS) + half;
+  const uint4* pa_l = Elo + ea * (2 * KS) + half;
+  const uint4* pb_h = Hhi + q * (2 * KS) + half;
+  const uint4* pb_l = Hlo + q * (2 * KS) + half;
   // gathered 16-B loads, batched four k-steps deep (one wave per SIMD here: nothing else hides their latency)
   int ks = 0;
   for (; ks + 4 <= KS; ks += 4) {
     uint4 ah[4], al[4], bh[4], bl[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      ah[u] = pa_h[(ks + u) * 64]; al[u] = pa_l[(ks + u) * 64];
-      bh[u] = pb_h[(ks + u) * 64]; bl[u] = pb_l[(ks + u) * 64];
+      ah[u] = pa_h[(ks + u) * 2]; al[u] = pa_l[(ks + u) * 2];
+      bh[u] = pb_h[(ks + u) * 2]; bl[u] = pb_l[(ks + u) * 2];
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) MFMA_X3(ah[u], al[u], bh[u], bl[u], acc);
   }
   for (; ks < KS; ++ks) {
-    uint4 ah = pa_h[ks * 64], al = pa_l[ks * 64], bh = pb_h[ks * 64], bl = pb_l[ks * 64];
+    uint4 ah = pa_h[ks * 2], al = pa_l[ks * 2], bh = pb_h[ks * 2], bl = pb_l[ks * 2];
     MFMA_X3(ah, al, bh, bl, acc);
   }
   // D[i][i] sits in lane i + 32*((i>>2)&1), register (i&3) + 4*(i>>3)
@@ -464,8 +472,8 @@ static void pair_launch(coper_handle* h, int mode, int64_t n_pairs, int64_t B, i
                         const float* tgt, float* out, int32_t* ng, int32_t* ne, hipStream_t s) {
   const Dims& dm = h->dm;
   if (n_pairs <= 0) return;
-  hipLaunchKernelGGL(k_pair_bf16x3, dim3((unsigned)((n_pairs + 127) / 128)), dim3(256), 0, s, (const uint4*)h->Ef16_hi,
-                     (const uint4*)h->Ef16_lo, h->bias_pad, (const uint4*)h->hfrag16_hi, (const uint4*)h->hfrag16_lo,
+  hipLaunchKernelGGL(k_pair_bf16x3, dim3((unsigned)((n_pairs + 127) / 128)), dim3(256), 0, s, (const uint4*)h->Erm16_hi,
+                     (const uint4*)h->Erm16_lo, h->bias_pad, (const uint4*)h->hrm16_hi, (const uint4*)h->hrm16_lo,
                      dm.KS16, mode, n_pairs, B, L, e2, lookup, indptr, idx, row_of, tgt, (int64_t)h->cfg.shard_lo,
                      dm.n_local, out, ng, ne);
 }
