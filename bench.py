@@ -40,8 +40,11 @@ def pmc_traffic(workload, Q, kernel):
             d = json.load(open(path))
         except Exception:
             continue
-        if d.get("workload") == workload and d.get("queries") == Q and kernel in d.get("kernels", {}):
-            return d["kernels"][kernel]["hbm_bytes_per_launch"]
+        if d.get("workload") != workload or d.get("queries") != Q:
+            continue
+        for name, v in d.get("kernels", {}).items():     # template arguments (<13>, <false>) follow the base name
+            if name == kernel or name.startswith(kernel + "<"):
+                return v["hbm_bytes_per_launch"]
     return None
 
 
