@@ -17,6 +17,7 @@ namespace coper {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ unsigned short bf16_rne_e(float x) {
   unsigned u = __float_as_uint(x);
@@ -439,6 +440,189 @@ __global__ __launch_bounds__(256) void k_dense_big_bf16x3(const uint4* __restric
 #undef BODY
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// dense, tiles of 33..128 queries, weights streamed to registers.  Each of the 4 waves OWNS feature
+// blocks fb = wave, wave+4, ... and reads their W fragments straight from the fragment image into VGPRs
+// (1 KiB coalesced per fragment, non-temporal: every weight byte is used once per pass), PF k-steps
+// ahead; only the x planes, which all waves need, go through an LDS ring filled by LDS-DMA.  Against the
+// all-through-LDS ring this keeps (PF-1) whole k-steps of weights in flight per CU instead of 2, and LDS
+// reads drop from 4 fragments per MFMA triple to the x fragments once per wave.
+// Accumulation order per (query, feature, slice) is unchanged: k ascending, lo*hi, hi*lo, hi*hi.
+// ------------------------------------------------------------------------------------------------
+#ifndef COPER_DENSE_PF
+#define COPER_DENSE_PF 4
+#endif
+template <int N>
+__device__ __forceinline__ void vm_wait() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// VMEM ops issued after x-stage k when r = nk-1-k steps remain (r < P-1): r weight groups, min(P-2, r) x groups
+template <int P, int LX, int W2, int RR>
+__device__ __forceinline__ void vm_wait_tail(int r) {
+  if constexpr (RR >= 0) {
+    if (r == RR) vm_wait<RR * W2 + (RR < P - 2 ? RR : P - 2) * LX>();
+    else vm_wait_tail<P, LX, W2, RR - 1>(r);
+  }
+}
+
+template <int NB, int NOWN>
+__device__ __forceinline__ void dense_reg_body_bf16(uint4* __restrict__ ring, const uint4* __restrict__ Whi,
+                                                    const uint4* __restrict__ Wlo,
+                                                    const unsigned short* __restrict__ x_hi,
+                                                    const unsigned short* __restrict__ x_lo, int64_t relw, int start,
+                                                    int n, int fb0, int nfb, int64_t ks32n, int64_t F_pad, int64_t kb,
+                                                    int64_t ke, float* __restrict__ zdst, int d_pad16, int wave) {
+  constexpr int P = COPER_DENSE_PF;          // weight prefetch depth = x ring stages
+  constexpr int LX = (2 * NB + 3) / 4;       // x DMA instructions per wave per k-step
+  constexpr int XSTAGE = 4 * LX * 64;        // uint4 per ring stage: x hi [NB] | x lo [NB] (| padding)
+  constexpr int W2 = 2 * NOWN;
+  static_assert((P - 1) * W2 + (P - 2) * LX <= 63, "vmcnt is 6 bits");
+  const int lane = threadIdx.x & 63;
+  const uint4* wp[NOWN][2];
+#pragma unroll
+  for (int j = 0; j < NOWN; ++j) {
+    int fb = fb0 + wave + 4 * j;
+    if (fb > nfb - 1) fb = nfb - 1;
+    int64_t o = ((relw * nfb + fb) * ks32n + kb) * 64 + lane;
+    wp[j][0] = Whi + o;
+    wp[j][1] = Wlo + o;
+  }
+  const char* xsrc[LX];
+#pragma unroll
+  for (int i = 0; i < LX; ++i) {
+    int sl = wave + 4 * i;
+    if (sl >= 2 * NB) sl = wave;
+    int plane = sl >= NB;
+    int qb = sl - plane * NB;
+    int qi = qb * 16 + (lane & 15);
+    if (qi > n - 1) qi = n - 1;
+    xsrc[i] = (const char*)((plane ? x_lo : x_hi) + (int64_t)(start + qi) * F_pad + 32 * kb + 8 * (lane >> 4));
+  }
+#define X_ISSUE(buf, kk)                                                                                        \
+  {                                                                                                             \
+    _Pragma("unroll") for (int i = 0; i < LX; ++i) __builtin_amdgcn_global_load_lds(                            \
+        (const __attribute__((address_space(1))) void*)(xsrc[i] + (int64_t)(kk)*64),                            \
+        (__attribute__((address_space(3))) void*)(ring + (buf)*XSTAGE + (wave + 4 * i) * 64), 16, 0, 0);        \
+    asm volatile("" ::: "memory");                                                                              \
+  }
+#define W_ISSUE(s, kk)                                                                                          \
+  {                                                                                                             \
+    _Pragma("unroll") for (int j = 0; j < NOWN; ++j) {                                                          \
+      W[s][j][0] = __builtin_nontemporal_load((const u32x4*)(wp[j][0] + (int64_t)(kk)*64));                     \
+      W[s][j][1] = __builtin_nontemporal_load((const u32x4*)(wp[j][1] + (int64_t)(kk)*64));                     \
+    }                                                                                                           \
+    asm volatile("" ::: "memory");                                                                              \
+  }
+  u32x4 W[P][NOWN][2];
+  f32x4 acc[NOWN][NB];
+#pragma unroll
+  for (int j = 0; j < NOWN; ++j)
+#pragma unroll
+    for (int q = 0; q < NB; ++q) acc[j][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int nk = (int)(ke - kb);
+  // issue order is the steady-state one:  W(0) | x(0) W(1) | x(1) W(2) | ... so the counted waits below hold
+  // from the first step on; steps past the end are not issued (the tail waits count what is really there)
+  W_ISSUE(0, 0);
+#pragma unroll
+  for (int t = 0; t < P - 1; ++t) {
+#ifndef COPER_DBG_REG_NO_X
+    if (t < nk) X_ISSUE(t, t);
+#endif
+    if (t + 1 < nk) W_ISSUE(t + 1, t + 1);
+  }
+  for (int k0 = 0; k0 < nk; k0 += P) {
+#pragma unroll
+    for (int s = 0; s < P; ++s) {
+      const int k = k0 + s;
+      if (k < nk) {
+        const int r = nk - 1 - k;
+#ifndef COPER_DBG_REG_NO_X
+        if (r >= P - 1) vm_wait<(P - 1) * W2 + (P - 2) * LX>();   // x stage k landed, everything younger flies
+        else vm_wait_tail<P, LX, W2, P - 2>(r);
+#endif
+#ifndef COPER_DBG_REG_NO_BAR
+        __builtin_amdgcn_s_barrier();
+#endif
+#ifndef COPER_DBG_REG_NO_X
+        if (k + P - 1 < nk) X_ISSUE((s + P - 1) % P, k + P - 1);
+#endif
+        const uint4* xb = ring + s * XSTAGE + lane;
+#ifdef COPER_DBG_REG_NO_MFMA
+#pragma unroll
+        for (int j = 0; j < NOWN; ++j) {
+          acc[j][0][0] += __uint_as_float(W[s][j][0][0] ^ W[s][j][1][1]);
+          acc[j][0][1] += __uint_as_float(W[s][j][0][2] ^ W[s][j][1][3]);
+        }
+        acc[0][0][2] += __uint_as_float(xb[0].x);
+#else
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+          uint4 bh = xb[q * 64], bl = xb[(NB + q) * 64];
+#pragma unroll
+          for (int j = 0; j < NOWN; ++j) MFMA16_X3(W[s][j][0], W[s][j][1], bh, bl, acc[j][q]);
+        }
+#endif
+        if (k + P < nk) W_ISSUE(s, k + P);
+      }
+    }
+  }
+#undef X_ISSUE
+#undef W_ISSUE
+#pragma unroll
+  for (int j = 0; j < NOWN; ++j) {
+    int fb = fb0 + wave + 4 * j;
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+      int qi = q * 16 + (lane & 15);
+      if (fb < nfb && qi < n) {
+        float* dst = zdst + (int64_t)(start + qi) * d_pad16 + fb * 16 + 4 * (lane >> 4);
+        *(float4*)dst = make_float4(acc[j][q][0], acc[j][q][1], acc[j][q][2], acc[j][q][3]);
+      }
+    }
+  }
+}
+
+template <int NFB>
+__global__ __launch_bounds__(256) void k_dense_reg_bf16x3(const uint4* __restrict__ Whi, const uint4* __restrict__ Wlo,
+                                                          const unsigned short* __restrict__ x_hi,
+                                                          const unsigned short* __restrict__ x_lo,
+                                                          const int32_t* __restrict__ tiles,
+                                                          const int32_t* __restrict__ n_tiles, int64_t cap_small,
+                                                          int nfb, int64_t ks32n, int64_t F_pad, int nslices,
+                                                          int64_t Bcap, int d_pad16, float* __restrict__ z_part) {
+  extern __shared__ uint4 ring16[];
+  int tile = blockIdx.x;
+  if (tile >= n_tiles[1]) return;
+  const int32_t* tl = tiles + 4 * (cap_small + tile);
+  const int slice = blockIdx.y;
+  const int fb0 = blockIdx.z * NFB;
+  const int64_t relw = __builtin_amdgcn_readfirstlane(tl[0]);
+  const int start = __builtin_amdgcn_readfirstlane(tl[1]);
+  const int n = __builtin_amdgcn_readfirstlane(tl[2]);
+  const int64_t kb = ks32n * slice / nslices, ke = ks32n * (slice + 1) / nslices;
+  float* zdst = z_part + (int64_t)slice * Bcap * d_pad16;
+  const int nb = (n + 15) >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  constexpr int OWN_HI = (NFB + 3) / 4, N_HI = NFB - 4 * (OWN_HI - 1);   // waves < N_HI own OWN_HI blocks
+#define BODY(NB_)                                                                                                       \
+  if (wave < N_HI)                                                                                                      \
+    dense_reg_body_bf16<NB_, OWN_HI>(ring16, Whi, Wlo, x_hi, x_lo, relw, start, n, fb0, nfb, ks32n, F_pad, kb, ke, zdst, \
+                                     d_pad16, wave);                                                                    \
+  else                                                                                                                  \
+    dense_reg_body_bf16<NB_, (OWN_HI > 1 ? OWN_HI - 1 : 1)>(ring16, Whi, Wlo, x_hi, x_lo, relw, start, n, fb0, nfb,     \
+                                                            ks32n, F_pad, kb, ke, zdst, d_pad16, wave);
+  switch (nb) {
+    case 3: BODY(3); break;
+    case 4: BODY(4); break;
+    case 5: BODY(5); break;
+    case 6: BODY(6); break;
+    case 7: BODY(7); break;
+    default: BODY(8); break;
+  }
+#undef BODY
+}
+
 template <int NFB>
 static void dense_launch_bf16(coper_handle* h, int64_t B, int nslices, int zgroups, hipStream_t s) {
   const Dims& dm = h->dm;
@@ -451,6 +635,16 @@ static void dense_launch_bf16(coper_handle* h, int64_t B, int nslices, int zgrou
     hipLaunchKernelGGL((k_dense_small_bf16x3<NFB>), dim3((unsigned)n_small_max, (unsigned)((nslices + 3) / 4), (unsigned)zgroups),
                        dim3(256), 0, s, (const uint4*)h->Wf16_hi, (const uint4*)h->Wf16_lo, xh, xl, h->tiles, h->n_tiles,
                        dm.nfb, dm.F_pad / 32, dm.F_pad, nslices, h->ws_queries, dm.d_pad16, h->z_part);
+#ifndef COPER_DENSE_RING
+  if (B > 32 && NFB >= 8) {
+    // x ring only: P stages of (x hi | x lo) for up to 8 query blocks
+    size_t lds = (size_t)COPER_DENSE_PF * 16 * 64 * sizeof(uint4);
+    hipLaunchKernelGGL((k_dense_reg_bf16x3<NFB>), dim3((unsigned)n_big_max, (unsigned)nslices, (unsigned)zgroups), dim3(256),
+                       lds, s, (const uint4*)h->Wf16_hi, (const uint4*)h->Wf16_lo, xh, xl, h->tiles, h->n_tiles, cap_small,
+                       dm.nfb, dm.F_pad / 32, dm.F_pad, nslices, h->ws_queries, dm.d_pad16, h->z_part);
+    return;
+  }
+#endif
   if (B > 32) {
     size_t lds = (size_t)3 * (((2 * NFB + 16 + 3) / 4) * 4) * 64 * sizeof(uint4);
     if (!h->dense_attr_done) {
