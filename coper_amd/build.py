@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libcoper_hip.so")
 SOURCES = ["coper_abi.hip", "kernels_prepare.hip", "kernels_encode.hip", "kernels_score.hip", "kernels_score_bf16.hip",
-           "kernels_encode_bf16.hip"]
+           "kernels_encode_bf16.hip", "kernels_dense_fused_bf16.hip"]
 
 
 def _hipcc():
@@ -29,21 +29,53 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force=False, verbose=False, extra_flags=()):
-    if not force and not needs_build():
-        return LIB_PATH
-    cmd = [_hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC",
-           "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
-           # accumulate MFMAs in place in VGPRs: without it hipcc parks accumulators in AGPRs and shuffles
-           # them through a working range with v_accvgpr_mov around every chain (dense kernels: -40 % VGPRs)
-           "-mllvm", "-amdgpu-mfma-vgpr-form",
-           "-DCOPER_BUILD", *extra_flags, "-o", LIB_PATH + ".tmp"]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES]
+# per-source extra flags
+#  -amdgpu-mfma-vgpr-form: accumulate MFMAs in place in VGPRs: without it hipcc parks accumulators in AGPRs and
+#  shuffles them through a working range with v_accvgpr_mov around every chain (dense kernels: -40 % VGPRs)
+VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
+SOURCE_FLAGS = {name: VGPR_FORM for name in SOURCES}
+# the fused conv + dense kernel wants its 128 accumulators in AGPRs: the conv's taps and the weight prefetch fill the VGPRs
+SOURCE_FLAGS["kernels_dense_fused_bf16.hip"] = []
+
+
+def _compile_one(args):
+    cmd, verbose = args
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
-    return LIB_PATH
+
+
+def build_library(force=False, verbose=False, extra_flags=(), out=None, jobs=4):
+    """Compiles each source to an object under build/obj/<flags-key>/ (only the stale ones), then links."""
+    out = out or LIB_PATH
+    if not force and out == LIB_PATH and not extra_flags and not needs_build():
+        return LIB_PATH
+    import hashlib
+    from concurrent.futures import ThreadPoolExecutor
+    key = hashlib.sha1(" ".join(extra_flags).encode()).hexdigest()[:10] if extra_flags else "default"
+    objdir = os.path.join(HERE, "..", "build", "obj", key)
+    os.makedirs(objdir, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers.append(os.path.join(HERE, "..", "include", "coper_hip.h"))
+    hdr_t = max(os.path.getmtime(p) for p in headers + [os.path.abspath(__file__)])
+    base = [_hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-fvisibility=hidden", "-Wall",
+            "-Wno-unused-function", "-DCOPER_BUILD", *extra_flags]
+    todo, objs = [], []
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        op = os.path.join(objdir, src + ".o")
+        objs.append(op)
+        if os.path.exists(op) and os.path.getmtime(op) > max(os.path.getmtime(sp), hdr_t):
+            continue
+        todo.append((base + SOURCE_FLAGS.get(src, []) + ["-c", sp, "-o", op], verbose))
+    with ThreadPoolExecutor(max_workers=jobs) as ex:
+        list(ex.map(_compile_one, todo))
+    link = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out + ".tmp", *objs]
+    if verbose:
+        print(" ".join(link), file=sys.stderr)
+    subprocess.check_call(link)
+    os.replace(out + ".tmp", out)
+    return out
 
 
 if __name__ == "__main__":

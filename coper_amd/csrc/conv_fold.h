@@ -1,0 +1,51 @@
+// Conv + BN + ReLU arithmetic of the COPER_SCORE_BF16X3 encoder, shared by the stand-alone conv kernel
+// (kernels_encode_bf16.hip) and the fused conv + dense kernel (kernels_dense_fused_bf16.hip) so that both
+// produce the same x bits for the same (e1, rel):
+//   inference BN folded into the filter:  tap'[k][c] = tap[k][c] * scale[c],  b'[c] = bias[c]*scale[c] + shift[c]
+//   x[c] = max(fma chain over the 9 taps started from b'[c], 0)           (models.py:390-404 at inference)
+//   x = hi + lo,  hi = bf16(x), lo = bf16(x - hi)
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace coper {
+
+__device__ __forceinline__ void conv_fold_taps(const float* __restrict__ w, const float* __restrict__ b,
+                                               const float* __restrict__ scale, const float* __restrict__ shift, int C,
+                                               int c0, float (&tap)[9][8], float (&bs)[8]) {
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const float sc = scale[c0 + c];
+    bs[c] = fmaf(b[c0 + c], sc, shift[c0 + c]);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) tap[k][c] = w[k * C + c0 + c] * sc;
+  }
+}
+
+__device__ __forceinline__ void conv_x8(const float (&w)[9], const float (&tap)[9][8], const float (&bs)[8],
+                                        float (&y)[8]) {
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    float a = bs[c];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) a = fmaf(w[k], tap[k][c], a);
+    y[c] = fmaxf(a, 0.f);
+  }
+}
+
+__device__ __forceinline__ void split8_bf16(const float* v, uint4& hi, uint4& lo) {
+  // plain casts: hipcc emits v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN stays NaN)
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  unsigned hw[4], lw[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    bf16x2_t hp = {(__bf16)v[2 * j], (__bf16)v[2 * j + 1]};
+    float r0 = v[2 * j] - (float)hp[0], r1 = v[2 * j + 1] - (float)hp[1];
+    bf16x2_t lp = {(__bf16)r0, (__bf16)r1};
+    hw[j] = __builtin_bit_cast(unsigned, hp);
+    lw[j] = __builtin_bit_cast(unsigned, lp);
+  }
+  hi = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+  lo = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+}
+
+}  // namespace coper

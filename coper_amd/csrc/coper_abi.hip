@@ -463,8 +463,18 @@ COPER_API int coper_encode(coper_handle* h, const int64_t* e1, const int64_t* re
   if (ksplit > h->ws_ksplit) ksplit = h->ws_ksplit;
   if ((rc = launch_group_by_relation(h, rel, B, tq, s))) return rc;
   if (h->enc_bf16) {
-    if ((rc = launch_conv_bf16(h, e1, rel, e1_rows, B, s))) return rc;
-    if ((rc = launch_dense_bf16(h, B, ksplit, s))) return rc;
+#ifdef COPER_NO_FUSED_DENSE
+    const bool fused = false;
+#else
+    const bool fused = dense_fused_supported(h, ksplit);
+#endif
+    // tiles of <= 32 queries: conv -> x planes -> small dense; larger tiles: conv fused into the dense kernel
+    if ((rc = launch_conv_bf16(h, e1, rel, e1_rows, B, fused, s))) return rc;
+    {
+      ScopedKernelTimer t(h, "dense", s);
+      if ((rc = launch_dense_bf16(h, B, ksplit, fused, s))) return rc;
+      if (fused && (rc = launch_dense_fused_bf16(h, e1, rel, e1_rows, B, ksplit, s))) return rc;
+    }
     return launch_dense_finalize(h, rel, B, ksplit, h_out, s);
   }
   if ((rc = launch_conv(h, e1, rel, e1_rows, B, s))) return rc;

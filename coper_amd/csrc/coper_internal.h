@@ -109,6 +109,8 @@ struct coper_handle {
   float* hfrag_ws = nullptr;      // h re-packed in MFMA-fragment order [ceil(B/128)*4][KS][64] float4
   int num_cus = 256;
   bool dense_attr_done = false;
+  bool fused_attr_done = false;
+  bool dense_small_only = false;  // set per launch: tiles above 32 queries go to the fused conv + dense kernel
 
   bool profile = false;
   std::map<std::string, coper::Timer> timers;
@@ -176,8 +178,11 @@ int score_bf16_kernels_init(coper_handle* h);
 bool conv_bf16_supported(const Dims& dm);
 int launch_wfrag_to_bf16(coper_handle* h, const float* Wf, int64_t Rw, void* hi, void* lo, hipStream_t s);
 int launch_conv_bf16(coper_handle* h, const int64_t* e1, const int64_t* rel, const float* e1_rows, int64_t B,
-                     hipStream_t s);
-int launch_dense_bf16(coper_handle* h, int64_t B, int nslices, hipStream_t s);
+                     bool skip_big, hipStream_t s);
+int launch_dense_bf16(coper_handle* h, int64_t B, int nslices, bool small_only, hipStream_t s);
+bool dense_fused_supported(const coper_handle* h, int nslices);
+int launch_dense_fused_bf16(coper_handle* h, const int64_t* e1, const int64_t* rel, const float* e1_rows, int64_t B,
+                            int nslices, hipStream_t s);
 int launch_dense_finalize(coper_handle* h, const int64_t* rel, int64_t B, int ksplit, float* h_out, hipStream_t s);
 int score_all_dispatch(coper_handle* h, const float* hvec, int64_t B, float* logits, int64_t ld, hipStream_t s);
 int launch_bias_pad(coper_handle* h, const float* bias, hipStream_t s);

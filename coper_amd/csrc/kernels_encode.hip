@@ -663,7 +663,7 @@ static void dense_launch(coper_handle* h, int64_t B, int nslices, int zgroups, h
   if (B > 32) {
     size_t lds = (size_t)COPER_DENSE_NSTAGE * (((NFB + 8 + 3) / 4) * 4) * 64 * sizeof(float4);  // ring, max NB = 8
     if (!h->dense_attr_done) {
-      (void)hipFuncSetAttribute((const void*)k_dense_big_f32<NFB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute((const void*)k_dense_big_f32<NFB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       h->dense_attr_done = true;
     }
     hipLaunchKernelGGL((k_dense_big_f32<NFB>), dim3((unsigned)n_big_max, (unsigned)nslices, (unsigned)zgroups), dim3(256),

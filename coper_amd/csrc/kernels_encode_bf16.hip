@@ -12,6 +12,7 @@
 //   B operand (queries on columns): lane l holds 8 bf16 x[q = l&15][f = 32ks + 8(l>>4) + j]
 //   D: col = lane&15 (query), row = 4(lane>>4) + reg (feature).
 #include "coper_internal.h"
+#include "conv_fold.h"
 
 namespace coper {
 
@@ -92,21 +93,26 @@ __global__ __launch_bounds__(256) void k_conv3x3_bn_relu_bf16(
     const float* __restrict__ rel_emb, const float* __restrict__ conv_w, const float* __restrict__ conv_b,
     int per_rel_conv, const float* __restrict__ scale, const float* __restrict__ shift, int d, int r, int in_h,
     int in_w, int stacked, int C, int Ho, int Wo, int concat_rel, int64_t F, int64_t F_pad, int64_t R, int64_t B,
+    const int32_t* __restrict__ group_count, int group_by_rel, int skip_big,
     unsigned short* __restrict__ x_hi, unsigned short* __restrict__ x_lo) {
   extern __shared__ float lds[];  // img[QPB][in_h*in_w]
   const int img_sz = in_h * in_w;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t pos0 = (int64_t)blockIdx.x * QPB;
   int64_t rids[QPB];
+  bool live[QPB];   // positions whose tile (> 32 queries) the fused conv + dense kernel serves are skipped
 #pragma unroll
   for (int qq = 0; qq < QPB; ++qq) {
     int64_t pos = pos0 + qq;
     rids[qq] = 0;
+    live[qq] = false;
     if (pos >= B) continue;
     int64_t q = perm[pos];
     int64_t rid = rel[q];
     if (rid < 0 || rid >= R) rid = 0;
     rids[qq] = rid;
+    live[qq] = !(skip_big && group_count[group_by_rel ? rid : 0] > 32);
+    if (!live[qq]) continue;
     float* img = lds + qq * img_sz;
     for (int k = threadIdx.x; k < d; k += 256) {
       float v;
@@ -121,29 +127,24 @@ __global__ __launch_bounds__(256) void k_conv3x3_bn_relu_bf16(
     if (stacked)
       for (int k = threadIdx.x; k < r; k += 256) img[d + k] = rel_emb[rid * r + k];
   }
+  if (!(live[0] || live[1] || live[2] || live[3])) return;   // workgroup-uniform
   __syncthreads();
   const int noct = C >> 3;                 // channel octets per pixel
   const int ppg = 64 / noct;               // pixels per wave-group (16 for C = 32)
   const int pl = lane / noct, oc = lane % noct;
   const int npix = Ho * Wo;
-  float tap[9][8], kb[8], sc[8], sh[8];
-#pragma unroll
-  for (int c = 0; c < 8; ++c) { sc[c] = scale[8 * oc + c]; sh[c] = shift[8 * oc + c]; }
+  float tap[9][8], bs[8];
   int64_t tap_rid = -1;
 #pragma unroll
   for (int qq = 0; qq < QPB; ++qq) {
     int64_t pos = pos0 + qq;
     if (pos >= B) break;
+    if (!live[qq]) continue;
     const int64_t rid = per_rel_conv ? rids[qq] : 0;
     if (rid != tap_rid) {  // workgroup-uniform
       const float* wsrc = per_rel_conv ? conv_w + rid * (int64_t)(9 * C) : conv_w;
       const float* bsrc = per_rel_conv ? conv_b + rid * (int64_t)C : conv_b;
-#pragma unroll
-      for (int k = 0; k < 9; ++k)
-#pragma unroll
-        for (int c = 0; c < 8; ++c) tap[k][c] = wsrc[k * C + 8 * oc + c];
-#pragma unroll
-      for (int c = 0; c < 8; ++c) kb[c] = bsrc[8 * oc + c];
+      conv_fold_taps(wsrc, bsrc, scale, shift, C, 8 * oc, tap, bs);
       tap_rid = rid;
     }
     const float* img = lds + qq * img_sz;
@@ -159,17 +160,9 @@ __global__ __launch_bounds__(256) void k_conv3x3_bn_relu_bf16(
         float w[9] = {r0[0], r0[1], r0[2], r0[in_w], r0[in_w + 1], r0[in_w + 2],
                       r0[2 * in_w], r0[2 * in_w + 1], r0[2 * in_w + 2]};
         float y[8];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          float a = 0.f;
-#pragma unroll
-          for (int k = 0; k < 9; ++k) a = fmaf(w[k], tap[k][c], a);
-          a += kb[c];
-          a = fmaf(a, sc[c], sh[c]);
-          y[c] = fmaxf(a, 0.f);
-        }
+        conv_x8(w, tap, bs, y);
         uint4 h4, l4;
-        split8_e(y, h4, l4);
+        split8_bf16(y, h4, l4);
         *(uint4*)(xh + (int64_t)p * C + 8 * oc) = h4;
         *(uint4*)(xl + (int64_t)p * C + 8 * oc) = l4;
       }
@@ -180,6 +173,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_bn_relu_bf16(
   for (int qq = 0; qq < QPB; ++qq) {
     int64_t pos = pos0 + qq;
     if (pos >= B) break;
+    if (!live[qq]) continue;
     int64_t Fc = (int64_t)npix * C;
     unsigned short* xh = x_hi + pos * F_pad;
     unsigned short* xl = x_lo + pos * F_pad;
@@ -197,7 +191,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_bn_relu_bf16(
 bool conv_bf16_supported(const Dims& dm) { return dm.fh == 3 && dm.fw == 3 && dm.C % 8 == 0 && 64 % (dm.C / 8) == 0; }
 
 int launch_conv_bf16(coper_handle* h, const int64_t* e1, const int64_t* rel, const float* e1_rows, int64_t B,
-                     hipStream_t s) {
+                     bool skip_big, hipStream_t s) {
   const Dims& dm = h->dm;
   const float* rel_emb = dm.lookup ? nullptr : h->params["rel_emb"].ptr;
   const float* cw = dm.gen_conv ? h->conv_w_rel : h->params["conv1_weights"].ptr;
@@ -210,7 +204,8 @@ int launch_conv_bf16(coper_handle* h, const int64_t* e1, const int64_t* rel, con
   hipLaunchKernelGGL((k_conv3x3_bn_relu_bf16<QPB>), dim3((unsigned)((B + QPB - 1) / QPB)), dim3(256), lds, s, e1, rel,
                      e1_rows, h->perm, h->params["ent_emb"].ptr, (int64_t)h->cfg.shard_lo, dm.n_local, rel_emb, cw, cb,
                      dm.gen_conv ? 1 : 0, h->conv_scale, h->conv_shift, dm.d, dm.r, dm.in_h, dm.in_w,
-                     dm.stacked ? 1 : 0, dm.C, dm.Ho, dm.Wo, dm.concat_rel ? 1 : 0, dm.F, dm.F_pad, dm.R, B, xh, xl);
+                     dm.stacked ? 1 : 0, dm.C, dm.Ho, dm.Wo, dm.concat_rel ? 1 : 0, dm.F, dm.F_pad, dm.R, B, h->rel_count,
+                     dm.gen_fc ? 1 : 0, skip_big ? 1 : 0, xh, xl);
   COPER_HIP_TRY(h, hipGetLastError());
   return COPER_OK;
 }
@@ -635,6 +630,7 @@ static void dense_launch_bf16(coper_handle* h, int64_t B, int nslices, int zgrou
     hipLaunchKernelGGL((k_dense_small_bf16x3<NFB>), dim3((unsigned)n_small_max, (unsigned)((nslices + 3) / 4), (unsigned)zgroups),
                        dim3(256), 0, s, (const uint4*)h->Wf16_hi, (const uint4*)h->Wf16_lo, xh, xl, h->tiles, h->n_tiles,
                        dm.nfb, dm.F_pad / 32, dm.F_pad, nslices, h->ws_queries, dm.d_pad16, h->z_part);
+  if (h->dense_small_only) return;
 #ifndef COPER_DENSE_RING
   if (B > 32 && NFB >= 8) {
     // x ring only: P stages of (x hi | x lo) for up to 8 query blocks
@@ -648,7 +644,7 @@ static void dense_launch_bf16(coper_handle* h, int64_t B, int nslices, int zgrou
   if (B > 32) {
     size_t lds = (size_t)3 * (((2 * NFB + 16 + 3) / 4) * 4) * 64 * sizeof(uint4);
     if (!h->dense_attr_done) {
-      (void)hipFuncSetAttribute((const void*)k_dense_big_bf16x3<NFB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute((const void*)k_dense_big_bf16x3<NFB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       h->dense_attr_done = true;
     }
     hipLaunchKernelGGL((k_dense_big_bf16x3<NFB>), dim3((unsigned)n_big_max, (unsigned)nslices, (unsigned)zgroups), dim3(256),
@@ -657,9 +653,9 @@ static void dense_launch_bf16(coper_handle* h, int64_t B, int nslices, int zgrou
   }
 }
 
-int launch_dense_bf16(coper_handle* h, int64_t B, int nslices, hipStream_t s) {
+int launch_dense_bf16(coper_handle* h, int64_t B, int nslices, bool small_only, hipStream_t s) {
   const Dims& dm = h->dm;
-  ScopedKernelTimer t(h, "dense", s);
+  h->dense_small_only = small_only;
   int nfb = dm.nfb;
   if (nfb == 13) dense_launch_bf16<13>(h, B, nslices, 1, s);
   else if (nfb <= 2) dense_launch_bf16<2>(h, B, nslices, 1, s);
