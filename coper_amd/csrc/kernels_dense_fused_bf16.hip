@@ -25,12 +25,6 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define MFMA16_X3(ahi, alo, bhi, blo, c) \
   { (c) = MFMA16_BF16(alo, bhi, c); (c) = MFMA16_BF16(ahi, blo, c); (c) = MFMA16_BF16(ahi, bhi, c); }
 
-#ifndef COPER_FUSED_SCHED
-#define COPER_FUSED_SCHED 0
-#endif
-#ifndef COPER_FUSED_PF
-#define COPER_FUSED_PF 3
-#endif
 
 struct FusedConvArgs {
   const int64_t* e1;
@@ -47,23 +41,86 @@ struct FusedConvArgs {
   int per_rel_conv, d, r, in_w, in_hw, Wo, img_stride;
 };
 
-// One wave's share of a tile x slice.  WAVE is a template argument so that everything a k-step does -- which
-// feature blocks (fb = WAVE, WAVE+4, ...) and which x fragments (f = 3-WAVE, 7-WAVE) the wave owns -- is static
-// and the whole step is ONE basic block: the scheduler can then put the conv's VALU work into the issue
-// slots the MFMAs leave free (an MFMA 16x16x32 holds the vector issue port for 8 of its 16 cycles).
+// Roles.  A workgroup is 8 waves, two per SIMD: waves 0..3 are MATRIX waves (wave w owns feature blocks
+// fb = w, w+4, ...: weight fragments prefetched into its registers, accumulators, all the MFMAs), waves 4..7
+// are CONV waves (produce the x fragments of k-step k+1 while the matrix waves consume k-step k).  One wave
+// cannot overlap its own MFMAs with its own VALU work on gfx950 (measured: a 54-MFMA / 216-FMA loop costs
+// the sum of the two alone, whatever the interleaving), two waves on one SIMD can: the conv rides in the
+// matrix pipe's shadow and each role hides the other's LDS latency.
+//   barrier protocol (every wave, nk + 2 barriers): B0 index table -> B1 image rows -> [conv(0)] ->
+//   for k: barrier (x(k) visible, stage (k+1)&1 free) ; matrix: MFMA(k) | conv: conv(k+1)
+
+// ---- prologue shared by both roles: the slice's rows of the tile's images -> LDS
+__device__ __forceinline__ void fused_load_images(float* __restrict__ img, int* __restrict__ tab, const FusedConvArgs& A,
+                                                  int start, int n, int t0, int t1) {
+  // index table first (one dependent chain perm -> e1 for the whole tile), rows after it, 4 rows in flight per wave
+  const int tid = threadIdx.x;
+  if (tid < n) {
+    const int64_t q = A.perm[start + tid];
+    int64_t rid = A.rel[q];
+    if (rid < 0 || rid >= A.R) rid = 0;
+    int64_t row = A.e1_rows ? q : A.e1[q] - A.shard_lo;
+    if (!A.e1_rows && (row < 0 || row >= A.n_local)) row = -1;
+    tab[2 * tid] = (int)row;          // rows fit 31 bits: B <= 2^31 and shards are far smaller
+    tab[2 * tid + 1] = (int)rid;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  const int wave = tid >> 6, lane = tid & 63;
+  const float* base = A.e1_rows ? A.e1_rows : A.ent;
+  const int len = t1 - t0;
+  for (int q0 = wave * 4; q0 < n; q0 += 32) {
+    float v[4][2];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int qi = q0 + u < n ? q0 + u : n - 1;
+      const int row = tab[2 * qi], rid = tab[2 * qi + 1];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int t = t0 + lane + 64 * h;
+        float x = 0.f;
+        if (t < t1) {
+          if (t < A.d) x = row >= 0 ? base[(int64_t)row * A.d + t] : 0.f;
+          else x = A.rel_emb[(int64_t)rid * A.r + (t - A.d)];
+        }
+        v[u][h] = x;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (q0 + u < n) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          if (lane + 64 * h < len) img[(q0 + u) * A.img_stride + lane + 64 * h] = v[u][h];
+      }
+  }
+  // rows longer than 128 floats (not the shipped shapes): the rest, plainly
+  for (int qi = wave; qi < n; qi += 8) {
+    const int row = tab[2 * qi], rid = tab[2 * qi + 1];
+    for (int t = t0 + 128 + lane; t < t1; t += 64) {
+      float x;
+      if (t < A.d) x = row >= 0 ? base[(int64_t)row * A.d + t] : 0.f;
+      else x = A.rel_emb[(int64_t)rid * A.r + (t - A.d)];
+      img[qi * A.img_stride + (t - t0)] = x;
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+
+// ---- matrix role
 template <int NFB, int NB, int WAVE>
-__device__ __forceinline__ void dense_fused_body(uint4* __restrict__ xring, float* __restrict__ img,
-                                                 const uint4* __restrict__ Whi, const uint4* __restrict__ Wlo,
-                                                 const FusedConvArgs& A, int64_t relw, int start, int n, int fb0,
-                                                 int nfb, int64_t ks32n, int64_t kb, int64_t ke,
-                                                 float* __restrict__ zdst, int d_pad16) {
-  constexpr int P = COPER_FUSED_PF;
-  constexpr int NOWN = (NFB - WAVE + 3) / 4;                       // feature blocks of this wave
-  constexpr int NFR = 3 - WAVE < NB ? (NB - (3 - WAVE) + 3) / 4 : 0;  // x fragments this wave produces
-  constexpr int XSTAGE = 2 * NB * 64;                              // uint4 per stage: x hi [NB] | x lo [NB]
+__device__ __forceinline__ void fused_matrix_role(const uint4* __restrict__ xring, float* __restrict__ img,
+                                                  int* __restrict__ tab, const uint4* __restrict__ Whi,
+                                                  const uint4* __restrict__ Wlo, const FusedConvArgs& A, int64_t relw,
+                                                  int start, int n, int fb0, int nfb, int64_t ks32n, int64_t kb,
+                                                  int64_t ke, int t0, int t1, float* __restrict__ zdst, int d_pad16) {
+  constexpr int NOWN = (NFB - WAVE + 3) / 4;                        // feature blocks of this wave
+  // two waves per SIMD: 256 registers each, accumulators included
+  constexpr int P = (NOWN * NB * 4 + 3 * NOWN * 8 + 44 <= 256) ? 3 : 2;
+  constexpr int XSTAGE = 2 * NB * 64;                               // uint4 per stage: x hi [NB] | x lo [NB]
   const int lane = threadIdx.x & 63;
   const int nk = (int)(ke - kb);
-  // ---- weight stream: start it before anything else
   const uint4* wp[NOWN][2];
 #pragma unroll
   for (int j = 0; j < NOWN; ++j) {
@@ -83,169 +140,38 @@ __device__ __forceinline__ void dense_fused_body(uint4* __restrict__ xring, floa
   }
 #pragma unroll
   for (int t = 0; t < P; ++t)
-    if (t < nk) W_ISSUE(t, t);
-  // ---- the slice's rows of the tile's images -> LDS  (pixel p = k-step index; rows i_lo .. i_hi + 2)
-  const int Wo = A.Wo, in_w = A.in_w;
-  const int i_lo = (int)(kb / Wo);
-  const int t0 = i_lo * in_w;
-  int t1 = ((int)((ke - 1) / Wo) + 3) * in_w;
-  if (t1 > A.in_hw) t1 = A.in_hw;
-  for (int qi = WAVE; qi < n; qi += 4) {
-    const int64_t q = __builtin_amdgcn_readfirstlane(A.perm[start + qi]);
-    int64_t rid = A.rel[q];
-    if (rid < 0 || rid >= A.R) rid = 0;
-    const int64_t row = A.e1_rows ? q : A.e1[q] - A.shard_lo;
-    const bool ok = A.e1_rows || (row >= 0 && row < A.n_local);
-    const float* src = (A.e1_rows ? A.e1_rows : A.ent) + row * A.d;
-    float* dst = img + qi * A.img_stride - t0;
-    for (int t = t0 + lane; t < t1; t += 64) {
-      float v;
-      if (t < A.d) v = ok ? src[t] : 0.f;
-      else v = A.rel_emb[rid * A.r + (t - A.d)];
-      dst[t] = v;
-    }
-  }
-  // ---- folded taps of this lane's channel octet
-  const int g = lane >> 4;
-  float tap[9][8], bs[8];
-  {
-    const float* wsrc = A.per_rel_conv ? A.conv_w + relw * (int64_t)(9 * 32) : A.conv_w;
-    const float* bsrc = A.per_rel_conv ? A.conv_b + relw * (int64_t)32 : A.conv_b;
-    conv_fold_taps(wsrc, bsrc, A.scale, A.shift, 32, 8 * g, tap, bs);
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-
-  // image rows of this lane's query in each of the wave's fragments (padding lanes repeat the last query)
-  const float* qimg[NFR > 0 ? NFR : 1];
-#pragma unroll
-  for (int t = 0; t < NFR; ++t) {
-    int qi = (3 - WAVE + 4 * t) * 16 + (lane & 15);
-    if (qi > n - 1) qi = n - 1;
-    qimg[t] = img + qi * A.img_stride;
-  }
-  const unsigned xaddr = (unsigned)(uintptr_t)(xring + lane);   // LDS byte address of this lane's fragment piece
-  int poff = (int)(kb - (int64_t)i_lo * Wo);   // pixel offset ci*in_w + cj of the NEXT conv step
-  int cj = poff;
-  // conv of the next pixel for the wave's fragments -> ring stage `stage`; advance = 0 freezes the pixel
-  // (the step past the slice's end recomputes the last pixel instead of branching around the conv)
-#define CONV_LOAD()                                                                               \
-  float cw[NFR > 0 ? NFR : 1][9];                                                                 \
-  _Pragma("unroll") for (int t = 0; t < NFR; ++t) {                                               \
-    const float* r0 = qimg[t] + poff;                                                             \
-    cw[t][0] = r0[0]; cw[t][1] = r0[1]; cw[t][2] = r0[2];                                         \
-    cw[t][3] = r0[in_w]; cw[t][4] = r0[in_w + 1]; cw[t][5] = r0[in_w + 2];                        \
-    cw[t][6] = r0[2 * in_w]; cw[t][7] = r0[2 * in_w + 1]; cw[t][8] = r0[2 * in_w + 2];            \
-  }
-#define CONV_COMPUTE(stage, advance)                                                              \
-  {                                                                                               \
-    _Pragma("unroll") for (int t = 0; t < NFR; ++t) {                                             \
-      float y[8];                                                                                 \
-      conv_x8(cw[t], tap, bs, y);                                                                 \
-      uint4 h4, l4;                                                                               \
-      split8_bf16(y, h4, l4);                                                                     \
-      uint4* dst = xring + (stage)*XSTAGE + (3 - WAVE + 4 * t) * 64 + lane;                       \
-      dst[0] = h4;                                                                                \
-      dst[NB * 64] = l4;                                                                          \
-    }                                                                                             \
-    const int wrap = (cj + 1 == Wo);                                                              \
-    poff += (advance) ? (wrap ? in_w - Wo + 1 : 1) : 0;                                           \
-    cj = (advance) ? (wrap ? 0 : cj + 1) : cj;                                                    \
-  }
-#define CONV_STEP(stage, advance) { CONV_LOAD(); CONV_COMPUTE(stage, advance); }
-
+    if (t < nk) W_ISSUE(t, t);      // the weight stream starts before anything else
+  fused_load_images(img, tab, A, start, n, t0, t1);
   f32x4 acc[NOWN][NB];
 #pragma unroll
   for (int j = 0; j < NOWN; ++j)
 #pragma unroll
     for (int q = 0; q < NB; ++q) acc[j][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  CONV_STEP(0, 1 < nk);
   for (int k0 = 0; k0 < nk; k0 += 2 * P) {
 #pragma unroll
     for (int s2 = 0; s2 < 2 * P; ++s2) {   // unrolled over lcm(ring stages, prefetch depth): static indices
       const int k = k0 + s2;
       const int s = s2 % P;
       if (k < nk) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my x writes of step k have landed in LDS
-        __builtin_amdgcn_s_barrier();                         // everyone's have; stage (k+1)&1 is free again
+        __builtin_amdgcn_s_barrier();
         const uint4* xb = xring + (s2 & 1) * XSTAGE + lane;
-        // every LDS read of the step is issued here and waited for once (one wave per SIMD: nobody else
-        // hides LDS latency, and left alone hipcc sinks each read to just before its first use): the empty
-        // asm "uses" all of them, so they cannot move below it and nothing that needs them moves above
-        CONV_LOAD();
-        u32x4 bh[NB], bl[NB];
-#pragma unroll
-        for (int q = 0; q < NB; ++q) { bh[q] = *(const u32x4*)(xb + q * 64); bl[q] = *(const u32x4*)(xb + (NB + q) * 64); }
-#pragma unroll
-        for (int q = 0; q < NB; ++q) asm volatile("" : "+v"(bh[q]), "+v"(bl[q]));
-#pragma unroll
-        for (int t = 0; t < NFR; ++t)
-#pragma unroll
-          for (int i = 0; i < 9; ++i) asm volatile("" : "+v"(cw[t][i]));
-#ifndef COPER_DBG_FUSED_NO_CONV
-        CONV_COMPUTE((s2 + 1) & 1, k + 2 < nk);
-#endif
-#ifdef COPER_DBG_FUSED_NO_MFMA
-#pragma unroll
-        for (int j = 0; j < NOWN; ++j) {
-          acc[j][0][0] += __uint_as_float(W[s][j][0][0] ^ W[s][j][1][1]);
-          acc[j][0][1] += __uint_as_float(W[s][j][0][2] ^ W[s][j][1][3]);
-        }
-        acc[0][0][2] += __uint_as_float(bh[0][0]);
-#else
         // term-major MFMA order: consecutive MFMAs write different accumulators; each accumulator still
         // sees lo*hi, hi*lo, hi*hi in that order
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
+          const uint4 bh = xb[q * 64], bl = xb[(NB + q) * 64];
 #pragma unroll
-          for (int j = 0; j < NOWN; ++j) acc[j][q] = MFMA16_BF16(W[s][j][1], bh[q], acc[j][q]);
+          for (int j = 0; j < NOWN; ++j) acc[j][q] = MFMA16_BF16(W[s][j][1], bh, acc[j][q]);
 #pragma unroll
-          for (int j = 0; j < NOWN; ++j) acc[j][q] = MFMA16_BF16(W[s][j][0], bl[q], acc[j][q]);
+          for (int j = 0; j < NOWN; ++j) acc[j][q] = MFMA16_BF16(W[s][j][0], bl, acc[j][q]);
 #pragma unroll
-          for (int j = 0; j < NOWN; ++j) acc[j][q] = MFMA16_BF16(W[s][j][0], bh[q], acc[j][q]);
+          for (int j = 0; j < NOWN; ++j) acc[j][q] = MFMA16_BF16(W[s][j][0], bh, acc[j][q]);
         }
-#endif
-#if !defined(COPER_FUSED_NO_SCHED) && !defined(COPER_DBG_FUSED_NO_MFMA) && !defined(COPER_DBG_FUSED_NO_CONV)
-        {
-          // issue order: the conv's patch reads and the first x fragments, then per query block the next
-          // block's two fragment reads followed by its MFMAs, each with VPM conv VALU instructions behind it
-          constexpr int NM = 3 * NOWN, NV = NFR * 128 + 16, VPM = (NV + NM * NB - 1) / (NM * NB);
-#if COPER_FUSED_SCHED == 1
-          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-#pragma unroll
-          for (int q = 0; q < NB; ++q) {
-            if (q + 1 < NB) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-#pragma unroll
-            for (int i = 0; i < NM; ++i) {
-              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-              if (VPM > 0) __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
-            }
-          }
-#elif COPER_FUSED_SCHED == 2
-          // all DS reads up front
-          __builtin_amdgcn_sched_group_barrier(0x100, 2 * NB + 9 * NFR, 0);
-#pragma unroll
-          for (int i = 0; i < NM * NB; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (VPM > 0) __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
-          }
-#else
-#pragma unroll
-          for (int i = 0; i < NM * NB; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (VPM > 0) __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
-          }
-#endif
-        }
-#endif
-#ifndef COPER_DBG_FUSED_NO_W
         if (k + P < nk) W_ISSUE(s, k + P);
-#endif
       }
     }
   }
 #undef W_ISSUE
-#undef CONV_STEP
 #pragma unroll
   for (int j = 0; j < NOWN; ++j) {
     int fb = fb0 + WAVE + 4 * j;
@@ -260,8 +186,63 @@ __device__ __forceinline__ void dense_fused_body(uint4* __restrict__ xring, floa
   }
 }
 
+// ---- conv role: conv wave CW produces x fragments f = 3-CW, 7-CW (so that the SIMD whose matrix wave owns
+// the most feature blocks gets the fewest fragments)
+template <int NB, int CW>
+__device__ __forceinline__ void fused_conv_role(uint4* __restrict__ xring, float* __restrict__ img,
+                                                int* __restrict__ tab, const FusedConvArgs& A, int64_t relw, int start,
+                                                int n, int64_t kb, int64_t ke, int i_lo, int t0, int t1) {
+  constexpr int NFR = 3 - CW < NB ? (NB - (3 - CW) + 3) / 4 : 0;
+  constexpr int XSTAGE = 2 * NB * 64;
+  const int lane = threadIdx.x & 63;
+  const int nk = (int)(ke - kb);
+  const int Wo = A.Wo, in_w = A.in_w;
+  // folded taps of this lane's channel octet (loads in flight during the image prologue)
+  const int g = lane >> 4;
+  float tap[9][8], bs[8];
+  {
+    const float* wsrc = A.per_rel_conv ? A.conv_w + relw * (int64_t)(9 * 32) : A.conv_w;
+    const float* bsrc = A.per_rel_conv ? A.conv_b + relw * (int64_t)32 : A.conv_b;
+    conv_fold_taps(wsrc, bsrc, A.scale, A.shift, 32, 8 * g, tap, bs);
+  }
+  fused_load_images(img, tab, A, start, n, t0, t1);
+  // image rows of this lane's query in each of the wave's fragments (padding lanes repeat the last query)
+  const float* qimg[NFR > 0 ? NFR : 1];
+#pragma unroll
+  for (int t = 0; t < NFR; ++t) {
+    int qi = (3 - CW + 4 * t) * 16 + (lane & 15);
+    if (qi > n - 1) qi = n - 1;
+    qimg[t] = img + qi * A.img_stride;
+  }
+  int poff = (int)(kb - (int64_t)i_lo * Wo);   // pixel offset ci*in_w + cj of the NEXT conv step
+  int cj = poff;
+  for (int kk = 0; kk <= nk; ++kk) {
+    // kk = 0: x(0) before the first barrier; kk >= 1: barrier k = kk-1, then x(kk) while the matrix waves run k
+    if (kk > 0) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my x writes of step kk-1 have landed in LDS
+      __builtin_amdgcn_s_barrier();
+    }
+    if (kk < nk) {
+#pragma unroll
+      for (int t = 0; t < NFR; ++t) {
+        const float* r0 = qimg[t] + poff;
+        float w[9] = {r0[0], r0[1], r0[2], r0[in_w], r0[in_w + 1], r0[in_w + 2],
+                      r0[2 * in_w], r0[2 * in_w + 1], r0[2 * in_w + 2]};
+        float y[8];
+        conv_x8(w, tap, bs, y);
+        uint4 h4, l4;
+        split8_bf16(y, h4, l4);
+        uint4* dst = xring + (kk & 1) * XSTAGE + (3 - CW + 4 * t) * 64 + lane;
+        dst[0] = h4;
+        dst[NB * 64] = l4;
+      }
+      if (++cj == Wo) { cj = 0; poff += in_w - Wo + 1; } else { ++poff; }
+    }
+  }
+}
+
 template <int NFB>
-__global__ __launch_bounds__(256) void k_dense_fused_bf16x3(const uint4* __restrict__ Whi, const uint4* __restrict__ Wlo,
+__global__ __launch_bounds__(512) void k_dense_fused_bf16x3(const uint4* __restrict__ Whi, const uint4* __restrict__ Wlo,
                                                             FusedConvArgs A, const int32_t* __restrict__ tiles,
                                                             const int32_t* __restrict__ n_tiles, int64_t cap_small,
                                                             int nfb, int64_t ks32n, int nslices, int64_t Bcap,
@@ -280,14 +261,25 @@ __global__ __launch_bounds__(256) void k_dense_fused_bf16x3(const uint4* __restr
   const int nb = (n + 15) >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   uint4* xring = fused_lds;                       // 2 stages x 16 slots x 1 KiB
-  float* img = (float*)(fused_lds + 2 * 16 * 64);
-#define BODYW(NB_, W_) dense_fused_body<NFB, NB_, W_>(xring, img, Whi, Wlo, A, relw, start, n, fb0, nfb, ks32n, kb, ke, zdst, d_pad16)
-#define BODY(NB_)                                   \
-  switch (wave) {                                   \
-    case 0: BODYW(NB_, 0); break;                   \
-    case 1: BODYW(NB_, 1); break;                   \
-    case 2: BODYW(NB_, 2); break;                   \
-    default: BODYW(NB_, 3); break;                  \
+  int* tab = (int*)(fused_lds + 2 * 16 * 64);     // [128][2] row, relation of the tile's queries
+  float* img = (float*)(tab + 256);
+  // pixel p = k-step index: the slice needs image rows i_lo .. i_hi + 2
+  const int i_lo = (int)(kb / A.Wo);
+  const int t0 = i_lo * A.in_w;
+  int t1 = ((int)((ke - 1) / A.Wo) + 3) * A.in_w;
+  if (t1 > A.in_hw) t1 = A.in_hw;
+#define MROLE(NB_, W_) fused_matrix_role<NFB, NB_, W_>(xring, img, tab, Whi, Wlo, A, relw, start, n, fb0, nfb, ks32n, kb, ke, t0, t1, zdst, d_pad16)
+#define CROLE(NB_, W_) fused_conv_role<NB_, W_>(xring, img, tab, A, relw, start, n, kb, ke, i_lo, t0, t1)
+#define BODY(NB_)                                 \
+  switch (wave) {                                 \
+    case 0: MROLE(NB_, 0); break;                 \
+    case 1: MROLE(NB_, 1); break;                 \
+    case 2: MROLE(NB_, 2); break;                 \
+    case 3: MROLE(NB_, 3); break;                 \
+    case 4: CROLE(NB_, 0); break;                 \
+    case 5: CROLE(NB_, 1); break;                 \
+    case 6: CROLE(NB_, 2); break;                 \
+    default: CROLE(NB_, 3); break;                \
   }
   switch (nb) {
     case 3: BODY(3); break;
@@ -298,7 +290,8 @@ __global__ __launch_bounds__(256) void k_dense_fused_bf16x3(const uint4* __restr
     default: BODY(8); break;
   }
 #undef BODY
-#undef BODYW
+#undef MROLE
+#undef CROLE
 }
 
 // slice geometry: rows of the image a K slice needs (same formula as the kernel), maximum over the slices
@@ -322,7 +315,7 @@ bool dense_fused_supported(const coper_handle* h, int nslices) {
   if (!(dm.nfb == 13 || dm.nfb == 8 || dm.nfb == 16)) return false;
   int stride = fused_rows_max(dm, nslices) * dm.in_w;
   stride |= 1;
-  size_t lds = (size_t)2 * 16 * 64 * sizeof(uint4) + (size_t)128 * stride * sizeof(float);
+  size_t lds = (size_t)2 * 16 * 64 * sizeof(uint4) + 256 * sizeof(int) + (size_t)128 * stride * sizeof(float);
   return lds <= 160 * 1024;
 }
 
@@ -343,12 +336,12 @@ static void dense_fused_launch(coper_handle* h, const int64_t* e1, const int64_t
   A.per_rel_conv = dm.gen_conv ? 1 : 0;
   A.d = dm.d; A.r = dm.r; A.in_w = dm.in_w; A.in_hw = dm.in_h * dm.in_w; A.Wo = dm.Wo;
   A.img_stride = (fused_rows_max(dm, nslices) * dm.in_w) | 1;
-  size_t lds = (size_t)2 * 16 * 64 * sizeof(uint4) + (size_t)128 * A.img_stride * sizeof(float);
+  size_t lds = (size_t)2 * 16 * 64 * sizeof(uint4) + 256 * sizeof(int) + (size_t)128 * A.img_stride * sizeof(float);
   if (!h->fused_attr_done) {   // process-wide attribute: always the hardware maximum, whatever this handle needs
     (void)hipFuncSetAttribute((const void*)k_dense_fused_bf16x3<NFB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     h->fused_attr_done = true;
   }
-  hipLaunchKernelGGL((k_dense_fused_bf16x3<NFB>), dim3((unsigned)n_big_max, (unsigned)nslices, (unsigned)zgroups), dim3(256),
+  hipLaunchKernelGGL((k_dense_fused_bf16x3<NFB>), dim3((unsigned)n_big_max, (unsigned)nslices, (unsigned)zgroups), dim3(512),
                      lds, s, (const uint4*)h->Wf16_hi, (const uint4*)h->Wf16_lo, A, h->tiles, h->n_tiles, cap_small, dm.nfb,
                      dm.F_pad / 32, nslices, h->ws_queries, dm.d_pad16, h->z_part);
 }
