@@ -26,6 +26,16 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   { (c) = MFMA16_BF16(alo, bhi, c); (c) = MFMA16_BF16(ahi, blo, c); (c) = MFMA16_BF16(ahi, bhi, c); }
 
 
+#ifndef COPER_FUSED_TAIL
+#define COPER_FUSED_TAIL 0
+#endif
+#ifndef COPER_FUSED_DUMMY
+#define COPER_FUSED_DUMMY 0
+#endif
+#ifndef COPER_FUSED_PMAX
+#define COPER_FUSED_PMAX 2
+#endif
+
 struct FusedConvArgs {
   const int64_t* e1;
   const int64_t* rel;
@@ -117,7 +127,7 @@ __device__ __forceinline__ void fused_matrix_role(const uint4* __restrict__ xrin
                                                   int64_t ke, int t0, int t1, float* __restrict__ zdst, int d_pad16) {
   constexpr int NOWN = (NFB - WAVE + 3) / 4;                        // feature blocks of this wave
   // two waves per SIMD: 256 registers each, accumulators included
-  constexpr int P = (NOWN * NB * 4 + 3 * NOWN * 8 + 44 <= 256) ? 3 : 2;
+  constexpr int P = (COPER_FUSED_PMAX >= 3 && NOWN * NB * 4 + 3 * NOWN * 8 + 44 <= 256) ? 3 : 2;
   constexpr int XSTAGE = 2 * NB * 64;                               // uint4 per stage: x hi [NB] | x lo [NB]
   const int lane = threadIdx.x & 63;
   const int nk = (int)(ke - kb);
@@ -126,17 +136,17 @@ __device__ __forceinline__ void fused_matrix_role(const uint4* __restrict__ xrin
   for (int j = 0; j < NOWN; ++j) {
     int fb = fb0 + WAVE + 4 * j;
     if (fb > nfb - 1) fb = nfb - 1;
-    int64_t o = ((relw * nfb + fb) * ks32n + kb) * 64 + lane;
+    int64_t o = ((relw * nfb + fb) * ks32n + kb) * 64;   // wave-uniform: scalar base + one shared lane offset
     wp[j][0] = Whi + o;
     wp[j][1] = Wlo + o;
   }
   u32x4 W[P][NOWN][2];
-#define W_ISSUE(s, kk)                                                                          \
-  {                                                                                             \
-    _Pragma("unroll") for (int j = 0; j < NOWN; ++j) {                                          \
-      W[s][j][0] = __builtin_nontemporal_load((const u32x4*)(wp[j][0] + (int64_t)(kk)*64));     \
-      W[s][j][1] = __builtin_nontemporal_load((const u32x4*)(wp[j][1] + (int64_t)(kk)*64));     \
-    }                                                                                           \
+#define W_ISSUE(s, kk)                                                                                 \
+  {                                                                                                    \
+    _Pragma("unroll") for (int j = 0; j < NOWN; ++j) {                                                 \
+      W[s][j][0] = __builtin_nontemporal_load((const u32x4*)(wp[j][0] + (int64_t)(kk)*64) + lane);     \
+      W[s][j][1] = __builtin_nontemporal_load((const u32x4*)(wp[j][1] + (int64_t)(kk)*64) + lane);     \
+    }                                                                                                  \
   }
 #pragma unroll
   for (int t = 0; t < P; ++t)
@@ -147,30 +157,75 @@ __device__ __forceinline__ void fused_matrix_role(const uint4* __restrict__ xrin
   for (int j = 0; j < NOWN; ++j)
 #pragma unroll
     for (int q = 0; q < NB; ++q) acc[j][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  for (int k0 = 0; k0 < nk; k0 += 2 * P) {
+  // one k-step: barrier (x(k) visible), MFMAs on ring stage s2&1 with the weights of register stage s2 % P.
+  // Term-major MFMA order: consecutive MFMAs write different accumulators; each accumulator still sees
+  // lo*hi, hi*lo, hi*hi in that order.
+#ifdef COPER_DBG_FUSED_NO_MFMA
+#define M_STEP(s2)                                                                                  \
+  {                                                                                                 \
+    __builtin_amdgcn_s_barrier();                                                                   \
+    const uint4* xb = xring + ((s2)&1) * XSTAGE + lane;                                             \
+    _Pragma("unroll") for (int j = 0; j < NOWN; ++j) {                                              \
+      acc[j][0][0] += __uint_as_float(W[(s2) % P][j][0][0] ^ W[(s2) % P][j][1][1]);                 \
+      acc[j][0][1] += __uint_as_float(W[(s2) % P][j][0][2] ^ W[(s2) % P][j][1][3]);                 \
+    }                                                                                               \
+    acc[0][0][2] += __uint_as_float(xb[0].x);                                                       \
+  }
+#else
+#define M_STEP(s2)                                                                                  \
+  {                                                                                                 \
+    __builtin_amdgcn_s_barrier();                                                                   \
+    const uint4* xb = xring + ((s2)&1) * XSTAGE + lane;                                             \
+    _Pragma("unroll") for (int q = 0; q < NB; ++q) {                                                \
+      const uint4 bh = xb[q * 64], bl = xb[(NB + q) * 64];                                          \
+      _Pragma("unroll") for (int j = 0; j < NOWN; ++j)                                              \
+          acc[j][q] = MFMA16_BF16(W[(s2) % P][j][1], bh, acc[j][q]);                                \
+      _Pragma("unroll") for (int j = 0; j < NOWN; ++j)                                              \
+          acc[j][q] = MFMA16_BF16(W[(s2) % P][j][0], bl, acc[j][q]);                                \
+      _Pragma("unroll") for (int j = 0; j < NOWN; ++j)                                              \
+          acc[j][q] = MFMA16_BF16(W[(s2) % P][j][0], bh, acc[j][q]);                                \
+    }                                                                                               \
+  }
+#endif
+  // main loop, 2P steps per trip (lcm of ring stages and prefetch depth: static register indices), with NO
+  // conditional code: hipcc's s_waitcnt insertion counts the loads in flight per path, and a branch around a
+  // step or around its prefetch makes the only safe count 0 -- the prefetch would be waited for the moment
+  // it is issued.  A prefetch past the slice's end re-reads the slice's first fragments instead (cache hits,
+  // never used).
+  int k0 = 0;
+#if COPER_FUSED_TAIL == 1
+  for (; k0 + 3 * P <= nk; k0 += 2 * P) {      // every prefetch of the trip is inside the slice
 #pragma unroll
-    for (int s2 = 0; s2 < 2 * P; ++s2) {   // unrolled over lcm(ring stages, prefetch depth): static indices
-      const int k = k0 + s2;
-      const int s = s2 % P;
-      if (k < nk) {
-        __builtin_amdgcn_s_barrier();
-        const uint4* xb = xring + (s2 & 1) * XSTAGE + lane;
-        // term-major MFMA order: consecutive MFMAs write different accumulators; each accumulator still
-        // sees lo*hi, hi*lo, hi*hi in that order
-#pragma unroll
-        for (int q = 0; q < NB; ++q) {
-          const uint4 bh = xb[q * 64], bl = xb[(NB + q) * 64];
-#pragma unroll
-          for (int j = 0; j < NOWN; ++j) acc[j][q] = MFMA16_BF16(W[s][j][1], bh, acc[j][q]);
-#pragma unroll
-          for (int j = 0; j < NOWN; ++j) acc[j][q] = MFMA16_BF16(W[s][j][0], bl, acc[j][q]);
-#pragma unroll
-          for (int j = 0; j < NOWN; ++j) acc[j][q] = MFMA16_BF16(W[s][j][0], bh, acc[j][q]);
-        }
-        if (k + P < nk) W_ISSUE(s, k + P);
-      }
+    for (int s2 = 0; s2 < 2 * P; ++s2) {
+      M_STEP(s2);
+#ifndef COPER_DBG_FUSED_NO_W
+      W_ISSUE(s2 % P, k0 + s2 + P);
+#endif
     }
   }
+#else
+  for (; k0 + 2 * P <= nk; k0 += 2 * P) {
+#pragma unroll
+    for (int s2 = 0; s2 < 2 * P; ++s2) {
+      M_STEP(s2);
+#ifndef COPER_DBG_FUSED_NO_W
+      const int kn = k0 + s2 + P;
+      W_ISSUE(s2 % P, kn < nk ? kn : COPER_FUSED_DUMMY);
+#endif
+    }
+  }
+#endif
+  // remaining steps (fewer than 2P, or 3P with COPER_FUSED_TAIL)
+#pragma unroll
+  for (int s2 = 0; s2 < (COPER_FUSED_TAIL == 1 ? 3 * P - 1 : 2 * P - 1); ++s2) {
+    if (k0 + s2 < nk) {
+      M_STEP(s2);
+#ifndef COPER_DBG_FUSED_NO_W
+      if (k0 + s2 + P < nk) W_ISSUE(s2 % P, k0 + s2 + P);
+#endif
+    }
+  }
+#undef M_STEP
 #undef W_ISSUE
 #pragma unroll
   for (int j = 0; j < NOWN; ++j) {
@@ -222,7 +277,11 @@ __device__ __forceinline__ void fused_conv_role(uint4* __restrict__ xring, float
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my x writes of step kk-1 have landed in LDS
       __builtin_amdgcn_s_barrier();
     }
+#ifdef COPER_DBG_FUSED_NO_CONV
+    if (kk < 1) {
+#else
     if (kk < nk) {
+#endif
 #pragma unroll
       for (int t = 0; t < NFR; ++t) {
         const float* r0 = qimg[t] + poff;

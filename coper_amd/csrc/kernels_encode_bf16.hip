@@ -93,26 +93,34 @@ __global__ __launch_bounds__(256) void k_conv3x3_bn_relu_bf16(
     const float* __restrict__ rel_emb, const float* __restrict__ conv_w, const float* __restrict__ conv_b,
     int per_rel_conv, const float* __restrict__ scale, const float* __restrict__ shift, int d, int r, int in_h,
     int in_w, int stacked, int C, int Ho, int Wo, int concat_rel, int64_t F, int64_t F_pad, int64_t R, int64_t B,
-    const int32_t* __restrict__ group_count, int group_by_rel, int skip_big,
+    const int32_t* __restrict__ small_tiles, const int32_t* __restrict__ n_tiles, int by_small_tile,
     unsigned short* __restrict__ x_hi, unsigned short* __restrict__ x_lo) {
   extern __shared__ float lds[];  // img[QPB][in_h*in_w]
   const int img_sz = in_h * in_w;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int64_t pos0 = (int64_t)blockIdx.x * QPB;
+  // by_small_tile: the fused conv + dense kernel serves every tile above 32 queries; this launch covers only
+  // the <= 32-query tiles, 32 / QPB workgroups per small-tile slot (unused slots exit on one scalar load)
+  int64_t pos0 = (int64_t)blockIdx.x * QPB, pos_end = B;
+  if (by_small_tile) {
+    const int t = blockIdx.x / (32 / QPB);
+    if (t >= n_tiles[0]) return;
+    const int start = small_tiles[4 * t + 1], n = small_tiles[4 * t + 2];
+    pos0 = start + (int64_t)(blockIdx.x % (32 / QPB)) * QPB;
+    pos_end = start + n;
+    if (pos0 >= pos_end) return;
+  }
   int64_t rids[QPB];
-  bool live[QPB];   // positions whose tile (> 32 queries) the fused conv + dense kernel serves are skipped
+  bool live[QPB];
 #pragma unroll
   for (int qq = 0; qq < QPB; ++qq) {
     int64_t pos = pos0 + qq;
     rids[qq] = 0;
-    live[qq] = false;
-    if (pos >= B) continue;
+    live[qq] = pos < pos_end;
+    if (!live[qq]) continue;
     int64_t q = perm[pos];
     int64_t rid = rel[q];
     if (rid < 0 || rid >= R) rid = 0;
     rids[qq] = rid;
-    live[qq] = !(skip_big && group_count[group_by_rel ? rid : 0] > 32);
-    if (!live[qq]) continue;
     float* img = lds + qq * img_sz;
     for (int k = threadIdx.x; k < d; k += 256) {
       float v;
@@ -127,7 +135,6 @@ __global__ __launch_bounds__(256) void k_conv3x3_bn_relu_bf16(
     if (stacked)
       for (int k = threadIdx.x; k < r; k += 256) img[d + k] = rel_emb[rid * r + k];
   }
-  if (!(live[0] || live[1] || live[2] || live[3])) return;   // workgroup-uniform
   __syncthreads();
   const int noct = C >> 3;                 // channel octets per pixel
   const int ppg = 64 / noct;               // pixels per wave-group (16 for C = 32)
@@ -201,11 +208,14 @@ int launch_conv_bf16(coper_handle* h, const int64_t* e1, const int64_t* rel, con
   unsigned short* xh = (unsigned short*)h->x_sorted;
   unsigned short* xl = xh + (size_t)h->ws_queries * dm.F_pad;
   ScopedKernelTimer t(h, "conv", s);
-  hipLaunchKernelGGL((k_conv3x3_bn_relu_bf16<QPB>), dim3((unsigned)((B + QPB - 1) / QPB)), dim3(256), lds, s, e1, rel,
+  int64_t cap_small = (dm.gen_fc ? dm.R : 1) + 1;
+  int64_t n_small_max = cap_small - 1 < B ? cap_small - 1 : B;
+  int64_t grid = skip_big ? n_small_max * (32 / QPB) : (B + QPB - 1) / QPB;
+  hipLaunchKernelGGL((k_conv3x3_bn_relu_bf16<QPB>), dim3((unsigned)grid), dim3(256), lds, s, e1, rel,
                      e1_rows, h->perm, h->params["ent_emb"].ptr, (int64_t)h->cfg.shard_lo, dm.n_local, rel_emb, cw, cb,
                      dm.gen_conv ? 1 : 0, h->conv_scale, h->conv_shift, dm.d, dm.r, dm.in_h, dm.in_w,
-                     dm.stacked ? 1 : 0, dm.C, dm.Ho, dm.Wo, dm.concat_rel ? 1 : 0, dm.F, dm.F_pad, dm.R, B, h->rel_count,
-                     dm.gen_fc ? 1 : 0, skip_big ? 1 : 0, xh, xl);
+                     dm.stacked ? 1 : 0, dm.C, dm.Ho, dm.Wo, dm.concat_rel ? 1 : 0, dm.F, dm.F_pad, dm.R, B, h->tiles,
+                     h->n_tiles, skip_big ? 1 : 0, xh, xl);
   COPER_HIP_TRY(h, hipGetLastError());
   return COPER_OK;
 }
