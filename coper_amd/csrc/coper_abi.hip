@@ -103,6 +103,8 @@ static int ensure_workspace(coper_handle* h, int64_t B, int64_t nnz, hipStream_t
   h->rel_cursor = h->rel_count + (dm.R + 2);
   if ((rc = dev_alloc(h, &h->rel_offset, dm.R + 2))) return rc;
   if ((rc = dev_alloc(h, &h->perm, cap))) return rc;
+  if ((rc = dev_alloc(h, &h->sorted_row, cap))) return rc;
+  if ((rc = dev_alloc(h, &h->sorted_rid, cap))) return rc;
   if ((rc = dev_alloc(h, &h->tiles, 4 * (cap / 32 + dm.R + 4)))) return rc;
   if ((rc = dev_alloc(h, &h->n_tiles, 4))) return rc;
   if ((rc = dev_alloc(h, &h->blk_off, dm.R + 2))) return rc;
@@ -232,7 +234,7 @@ COPER_API void coper_destroy(coper_handle* h) {
   dev_free(&h->conv_scale); dev_free(&h->conv_shift); dev_free(&h->fc_scale); dev_free(&h->fc_shift);
   dev_free(&h->conv_w_rel); dev_free(&h->conv_b_rel); dev_free(&h->fc_b_rel); dev_free(&h->Wf);
   dev_free(&h->Ef); dev_free(&h->bias_pad); dev_free(&h->ctx_tmp[0]); dev_free(&h->ctx_tmp[1]);
-  dev_free(&h->rel_count); dev_free(&h->rel_offset); h->rel_cursor = nullptr; dev_free(&h->perm);
+  dev_free(&h->rel_count); dev_free(&h->rel_offset); h->rel_cursor = nullptr; dev_free(&h->perm); dev_free(&h->sorted_row); dev_free(&h->sorted_rid);
   dev_free(&h->tiles); dev_free(&h->n_tiles); dev_free(&h->blk_off); dev_free(&h->x_sorted); dev_free(&h->z_part);
   dev_free(&h->tgt_ws); dev_free(&h->cnt_ws); dev_free(&h->hfrag_ws); dev_free(&h->logits_ws); dev_free(&h->row_of_ws);
   dev_free((char**)&h->Wf16_hi); dev_free((char**)&h->Wf16_lo);
@@ -461,7 +463,7 @@ COPER_API int coper_encode(coper_handle* h, const int64_t* e1, const int64_t* re
   int64_t ksteps = dm.F_pad / 16;
   int ksplit = ksteps >= 64 ? 4 : 1;  // DENSE_KSLICES
   if (ksplit > h->ws_ksplit) ksplit = h->ws_ksplit;
-  if ((rc = launch_group_by_relation(h, rel, B, tq, s))) return rc;
+  if ((rc = launch_group_by_relation(h, e1, rel, e1_rows != nullptr, B, tq, s))) return rc;
   if (h->enc_bf16) {
 #ifdef COPER_NO_FUSED_DENSE
     const bool fused = false;

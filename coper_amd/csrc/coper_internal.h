@@ -88,6 +88,8 @@ struct coper_handle {
   int32_t* rel_offset = nullptr;  // [R+1]
   int32_t* rel_cursor = nullptr;  // [R]
   int32_t* perm = nullptr;        // [B] sorted position -> query
+  int32_t* sorted_row = nullptr;  // [B] sorted position -> local entity row of e1 (or the e1_rows row), -1 = not on this shard
+  int32_t* sorted_rid = nullptr;  // [B] sorted position -> validated relation id
   int32_t* tiles = nullptr;       // [T_max*4] (rel, start, n, pad)
   int32_t* n_tiles = nullptr;     // [2] #small tiles, #big 16-query blocks
   int32_t* blk_off = nullptr;     // [R+1] exclusive scan of the big groups' block counts
@@ -141,7 +143,8 @@ int launch_gen_dense_frag(coper_handle* h, const float* ctx, int64_t R, int K, c
 int launch_entity_frag(coper_handle* h, const float* ent, const float* bias, hipStream_t s);
 
 // kernels_encode.hip
-int launch_group_by_relation(coper_handle* h, const int64_t* rel, int64_t B, int tq, hipStream_t s);
+int launch_group_by_relation(coper_handle* h, const int64_t* e1, const int64_t* rel, bool have_e1_rows, int64_t B, int tq,
+                             hipStream_t s);
 int launch_conv(coper_handle* h, const int64_t* e1, const int64_t* rel, const float* e1_rows, int64_t B,
                 hipStream_t s);
 int launch_dense(coper_handle* h, const int64_t* rel, int64_t B, int tq, int ksplit, float* h_out, hipStream_t s);

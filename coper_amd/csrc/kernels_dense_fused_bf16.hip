@@ -33,16 +33,17 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define COPER_FUSED_DUMMY 0
 #endif
 #ifndef COPER_FUSED_PMAX
-#define COPER_FUSED_PMAX 2
+#define COPER_FUSED_PMAX 3
+#endif
+#ifndef COPER_FUSED_PBUDGET
+#define COPER_FUSED_PBUDGET 216
 #endif
 
 struct FusedConvArgs {
-  const int64_t* e1;
-  const int64_t* rel;
   const float* e1_rows;
-  const int32_t* perm;
+  const int32_t* sorted_row;
+  const int32_t* sorted_rid;
   const float* ent;
-  int64_t shard_lo, n_local, R;
   const float* rel_emb;
   const float* conv_w;
   const float* conv_b;
@@ -57,34 +58,29 @@ struct FusedConvArgs {
 // cannot overlap its own MFMAs with its own VALU work on gfx950 (measured: a 54-MFMA / 216-FMA loop costs
 // the sum of the two alone, whatever the interleaving), two waves on one SIMD can: the conv rides in the
 // matrix pipe's shadow and each role hides the other's LDS latency.
-//   barrier protocol (every wave, nk + 2 barriers): B0 index table -> B1 image rows -> [conv(0)] ->
+//   barrier protocol (every wave, nk + 1 barriers): image rows in LDS -> [conv(0)] ->
 //   for k: barrier (x(k) visible, stage (k+1)&1 free) ; matrix: MFMA(k) | conv: conv(k+1)
 
-// ---- prologue shared by both roles: the slice's rows of the tile's images -> LDS
-__device__ __forceinline__ void fused_load_images(float* __restrict__ img, int* __restrict__ tab, const FusedConvArgs& A,
-                                                  int start, int n, int t0, int t1) {
-  // index table first (one dependent chain perm -> e1 for the whole tile), rows after it, 4 rows in flight per wave
-  const int tid = threadIdx.x;
-  if (tid < n) {
-    const int64_t q = A.perm[start + tid];
-    int64_t rid = A.rel[q];
-    if (rid < 0 || rid >= A.R) rid = 0;
-    int64_t row = A.e1_rows ? q : A.e1[q] - A.shard_lo;
-    if (!A.e1_rows && (row < 0 || row >= A.n_local)) row = -1;
-    tab[2 * tid] = (int)row;          // rows fit 31 bits: B <= 2^31 and shards are far smaller
-    tab[2 * tid + 1] = (int)rid;
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  const int wave = tid >> 6, lane = tid & 63;
-  const float* base = A.e1_rows ? A.e1_rows : A.ent;
-  const int len = t1 - t0;
-  for (int q0 = wave * 4; q0 < n; q0 += 32) {
-    float v[4][2];
+// ---- prologue shared by both roles: the slice's rows of the tile's images -> LDS.
+// Two dependent latencies in all: the sorted row / relation ids of the wave's 16 queries (written by
+// k_rel_scatter), then every row piece of those queries in flight at once.
+__device__ __forceinline__ void fused_load_images(float* __restrict__ img, const FusedConvArgs& A, int start, int n,
+                                                  int t0, int t1) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int q0 = wave * 16;
+  if (q0 < n) {
+    int qi = q0 + (lane & 15);
+    if (qi > n - 1) qi = n - 1;
+    int my_row = A.sorted_row[start + qi], my_rid = A.sorted_rid[start + qi];
+#ifdef COPER_DBG_FUSED_NO_IMG
+    my_row = -1;
+#endif
+    const float* base = A.e1_rows ? A.e1_rows : A.ent;
+    const int len = t1 - t0;
+    float v[16][2];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int qi = q0 + u < n ? q0 + u : n - 1;
-      const int row = tab[2 * qi], rid = tab[2 * qi + 1];
+    for (int u = 0; u < 16; ++u) {
+      const int row = __builtin_amdgcn_readlane(my_row, u), rid = __builtin_amdgcn_readlane(my_rid, u);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int t = t0 + lane + 64 * h;
@@ -97,53 +93,63 @@ __device__ __forceinline__ void fused_load_images(float* __restrict__ img, int* 
       }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < 16; ++u)
       if (q0 + u < n) {
 #pragma unroll
         for (int h = 0; h < 2; ++h)
           if (lane + 64 * h < len) img[(q0 + u) * A.img_stride + lane + 64 * h] = v[u][h];
       }
-  }
-  // rows longer than 128 floats (not the shipped shapes): the rest, plainly
-  for (int qi = wave; qi < n; qi += 8) {
-    const int row = tab[2 * qi], rid = tab[2 * qi + 1];
-    for (int t = t0 + 128 + lane; t < t1; t += 64) {
-      float x;
-      if (t < A.d) x = row >= 0 ? base[(int64_t)row * A.d + t] : 0.f;
-      else x = A.rel_emb[(int64_t)rid * A.r + (t - A.d)];
-      img[qi * A.img_stride + (t - t0)] = x;
+    // rows longer than 128 floats (not the shipped shapes): the rest, plainly
+    if (len > 128) {
+      for (int u = 0; u < 16 && q0 + u < n; ++u) {
+        const int row = __builtin_amdgcn_readlane(my_row, u), rid = __builtin_amdgcn_readlane(my_rid, u);
+        for (int t = t0 + 128 + lane; t < t1; t += 64) {
+          float x;
+          if (t < A.d) x = row >= 0 ? base[(int64_t)row * A.d + t] : 0.f;
+          else x = A.rel_emb[(int64_t)rid * A.r + (t - A.d)];
+          img[(q0 + u) * A.img_stride + (t - t0)] = x;
+        }
+      }
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 }
 
-// ---- matrix role
-template <int NFB, int NB, int WAVE>
+// ---- matrix role.  Wave w (0..3) owns feature blocks w, w+4, ... of the NFB/4*4 "full" ones for every query
+// block, and -- when NFB is not a multiple of 4 (d = 200: 13 blocks) -- query blocks w, w+4 of the one left
+// over, so that every SIMD carries the same MFMA load to within one query block (dealing whole feature blocks
+// would leave one wave with 4 of 13).  All four waves then stream that last block's weight fragments; the
+// repeats hit L1/L2.
+template <int NFB, int NB>
 __device__ __forceinline__ void fused_matrix_role(const uint4* __restrict__ xring, float* __restrict__ img,
-                                                  int* __restrict__ tab, const uint4* __restrict__ Whi,
-                                                  const uint4* __restrict__ Wlo, const FusedConvArgs& A, int64_t relw,
-                                                  int start, int n, int fb0, int nfb, int64_t ks32n, int64_t kb,
-                                                  int64_t ke, int t0, int t1, float* __restrict__ zdst, int d_pad16) {
-  constexpr int NOWN = (NFB - WAVE + 3) / 4;                        // feature blocks of this wave
+                                                  const uint4* __restrict__ Whi, const uint4* __restrict__ Wlo,
+                                                  const FusedConvArgs& A, int64_t relw, int start, int n, int fb0,
+                                                  int nfb, int64_t ks32n, int64_t kb, int64_t ke, int t0, int t1,
+                                                  float* __restrict__ zdst, int d_pad16, int wave) {
+  constexpr int NFULL = NFB / 4;              // whole feature blocks per wave
+  constexpr int REM = NFB % 4 ? 1 : 0;        // 1: one more block, shared by query block
+  static_assert(NFB % 4 <= 1, "at most one left-over feature block");
+  constexpr int NRQ = REM ? (NB + 3) / 4 : 0; // its query blocks per wave (w, w+4)
+  constexpr int NW = NFULL + REM;             // weight fragment streams per wave
   // two waves per SIMD: 256 registers each, accumulators included
-  constexpr int P = (COPER_FUSED_PMAX >= 3 && NOWN * NB * 4 + 3 * NOWN * 8 + 44 <= 256) ? 3 : 2;
-  constexpr int XSTAGE = 2 * NB * 64;                               // uint4 per stage: x hi [NB] | x lo [NB]
+  constexpr int P = (COPER_FUSED_PMAX >= 3 && (NFULL * NB + NRQ) * 4 + 3 * NW * 8 + 44 <= COPER_FUSED_PBUDGET) ? 3 : 2;
+  constexpr int XSTAGE = 2 * NB * 64;         // uint4 per stage: x hi [NB] | x lo [NB]
   const int lane = threadIdx.x & 63;
   const int nk = (int)(ke - kb);
-  const uint4* wp[NOWN][2];
+  const uint4* wp[NW][2];
 #pragma unroll
-  for (int j = 0; j < NOWN; ++j) {
-    int fb = fb0 + WAVE + 4 * j;
+  for (int j = 0; j < NW; ++j) {
+    int fb = fb0 + (j < NFULL ? wave + 4 * j : 4 * NFULL);
     if (fb > nfb - 1) fb = nfb - 1;
     int64_t o = ((relw * nfb + fb) * ks32n + kb) * 64;   // wave-uniform: scalar base + one shared lane offset
     wp[j][0] = Whi + o;
     wp[j][1] = Wlo + o;
   }
-  u32x4 W[P][NOWN][2];
+  u32x4 W[P][NW][2];
 #define W_ISSUE(s, kk)                                                                                 \
   {                                                                                                    \
-    _Pragma("unroll") for (int j = 0; j < NOWN; ++j) {                                                 \
+    _Pragma("unroll") for (int j = 0; j < NW; ++j) {                                                   \
       W[s][j][0] = __builtin_nontemporal_load((const u32x4*)(wp[j][0] + (int64_t)(kk)*64) + lane);     \
       W[s][j][1] = __builtin_nontemporal_load((const u32x4*)(wp[j][1] + (int64_t)(kk)*64) + lane);     \
     }                                                                                                  \
@@ -151,12 +157,14 @@ __device__ __forceinline__ void fused_matrix_role(const uint4* __restrict__ xrin
 #pragma unroll
   for (int t = 0; t < P; ++t)
     if (t < nk) W_ISSUE(t, t);      // the weight stream starts before anything else
-  fused_load_images(img, tab, A, start, n, t0, t1);
-  f32x4 acc[NOWN][NB];
+  fused_load_images(img, A, start, n, t0, t1);
+  f32x4 acc[NFULL][NB], accr[NRQ > 0 ? NRQ : 1];
 #pragma unroll
-  for (int j = 0; j < NOWN; ++j)
+  for (int j = 0; j < NFULL; ++j)
 #pragma unroll
     for (int q = 0; q < NB; ++q) acc[j][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < NRQ; ++t) accr[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
   // one k-step: barrier (x(k) visible), MFMAs on ring stage s2&1 with the weights of register stage s2 % P.
   // Term-major MFMA order: consecutive MFMAs write different accumulators; each accumulator still sees
   // lo*hi, hi*lo, hi*hi in that order.
@@ -165,9 +173,9 @@ __device__ __forceinline__ void fused_matrix_role(const uint4* __restrict__ xrin
   {                                                                                                 \
     __builtin_amdgcn_s_barrier();                                                                   \
     const uint4* xb = xring + ((s2)&1) * XSTAGE + lane;                                             \
-    _Pragma("unroll") for (int j = 0; j < NOWN; ++j) {                                              \
-      acc[j][0][0] += __uint_as_float(W[(s2) % P][j][0][0] ^ W[(s2) % P][j][1][1]);                 \
-      acc[j][0][1] += __uint_as_float(W[(s2) % P][j][0][2] ^ W[(s2) % P][j][1][3]);                 \
+    _Pragma("unroll") for (int j = 0; j < NW; ++j) {                                                \
+      acc[0][0][0] += __uint_as_float(W[(s2) % P][j][0][0] ^ W[(s2) % P][j][1][1]);                 \
+      acc[0][0][1] += __uint_as_float(W[(s2) % P][j][0][2] ^ W[(s2) % P][j][1][3]);                 \
     }                                                                                               \
     acc[0][0][2] += __uint_as_float(xb[0].x);                                                       \
   }
@@ -178,12 +186,19 @@ __device__ __forceinline__ void fused_matrix_role(const uint4* __restrict__ xrin
     const uint4* xb = xring + ((s2)&1) * XSTAGE + lane;                                             \
     _Pragma("unroll") for (int q = 0; q < NB; ++q) {                                                \
       const uint4 bh = xb[q * 64], bl = xb[(NB + q) * 64];                                          \
-      _Pragma("unroll") for (int j = 0; j < NOWN; ++j)                                              \
+      _Pragma("unroll") for (int j = 0; j < NFULL; ++j)                                             \
           acc[j][q] = MFMA16_BF16(W[(s2) % P][j][1], bh, acc[j][q]);                                \
-      _Pragma("unroll") for (int j = 0; j < NOWN; ++j)                                              \
+      _Pragma("unroll") for (int j = 0; j < NFULL; ++j)                                             \
           acc[j][q] = MFMA16_BF16(W[(s2) % P][j][0], bl, acc[j][q]);                                \
-      _Pragma("unroll") for (int j = 0; j < NOWN; ++j)                                              \
+      _Pragma("unroll") for (int j = 0; j < NFULL; ++j)                                             \
           acc[j][q] = MFMA16_BF16(W[(s2) % P][j][0], bh, acc[j][q]);                                \
+    }                                                                                               \
+    _Pragma("unroll") for (int t = 0; t < NRQ; ++t) {                                               \
+      const int q = wave + 4 * t < NB ? wave + 4 * t : NB - 1; /* past the tile: recompute, not stored */ \
+      const uint4 bh = xb[q * 64], bl = xb[(NB + q) * 64];                                          \
+      accr[t] = MFMA16_BF16(W[(s2) % P][NFULL][1], bh, accr[t]);                                    \
+      accr[t] = MFMA16_BF16(W[(s2) % P][NFULL][0], bl, accr[t]);                                    \
+      accr[t] = MFMA16_BF16(W[(s2) % P][NFULL][0], bh, accr[t]);                                    \
     }                                                                                               \
   }
 #endif
@@ -193,31 +208,19 @@ __device__ __forceinline__ void fused_matrix_role(const uint4* __restrict__ xrin
   // it is issued.  A prefetch past the slice's end re-reads the slice's first fragments instead (cache hits,
   // never used).
   int k0 = 0;
-#if COPER_FUSED_TAIL == 1
-  for (; k0 + 3 * P <= nk; k0 += 2 * P) {      // every prefetch of the trip is inside the slice
-#pragma unroll
-    for (int s2 = 0; s2 < 2 * P; ++s2) {
-      M_STEP(s2);
-#ifndef COPER_DBG_FUSED_NO_W
-      W_ISSUE(s2 % P, k0 + s2 + P);
-#endif
-    }
-  }
-#else
   for (; k0 + 2 * P <= nk; k0 += 2 * P) {
 #pragma unroll
     for (int s2 = 0; s2 < 2 * P; ++s2) {
       M_STEP(s2);
 #ifndef COPER_DBG_FUSED_NO_W
       const int kn = k0 + s2 + P;
-      W_ISSUE(s2 % P, kn < nk ? kn : COPER_FUSED_DUMMY);
+      W_ISSUE(s2 % P, kn < nk ? kn : 0);
 #endif
     }
   }
-#endif
-  // remaining steps (fewer than 2P, or 3P with COPER_FUSED_TAIL)
+  // remaining nk % 2P steps
 #pragma unroll
-  for (int s2 = 0; s2 < (COPER_FUSED_TAIL == 1 ? 3 * P - 1 : 2 * P - 1); ++s2) {
+  for (int s2 = 0; s2 < 2 * P - 1; ++s2) {
     if (k0 + s2 < nk) {
       M_STEP(s2);
 #ifndef COPER_DBG_FUSED_NO_W
@@ -227,27 +230,38 @@ __device__ __forceinline__ void fused_matrix_role(const uint4* __restrict__ xrin
   }
 #undef M_STEP
 #undef W_ISSUE
+#ifdef COPER_DBG_FUSED_NO_STORE
+  if (acc[0][0][0] != 1.2345f) return;
+#endif
 #pragma unroll
-  for (int j = 0; j < NOWN; ++j) {
-    int fb = fb0 + WAVE + 4 * j;
+  for (int j = 0; j < NFULL; ++j) {
+    const int fb = fb0 + wave + 4 * j;
 #pragma unroll
     for (int q = 0; q < NB; ++q) {
-      int qi = q * 16 + (lane & 15);
+      const int qi = q * 16 + (lane & 15);
       if (fb < nfb && qi < n) {
         float* dst = zdst + (int64_t)(start + qi) * d_pad16 + fb * 16 + 4 * (lane >> 4);
         *(float4*)dst = make_float4(acc[j][q][0], acc[j][q][1], acc[j][q][2], acc[j][q][3]);
       }
     }
   }
+#pragma unroll
+  for (int t = 0; t < NRQ; ++t) {
+    const int fb = fb0 + 4 * NFULL, q = wave + 4 * t;
+    const int qi = q * 16 + (lane & 15);
+    if (fb < nfb && q < NB && qi < n) {
+      float* dst = zdst + (int64_t)(start + qi) * d_pad16 + fb * 16 + 4 * (lane >> 4);
+      *(float4*)dst = make_float4(accr[t][0], accr[t][1], accr[t][2], accr[t][3]);
+    }
+  }
 }
 
-// ---- conv role: conv wave CW produces x fragments f = 3-CW, 7-CW (so that the SIMD whose matrix wave owns
-// the most feature blocks gets the fewest fragments)
-template <int NB, int CW>
+// ---- conv role: conv wave cw (0..3) produces x fragments f = cw, cw+4
+template <int NB>
 __device__ __forceinline__ void fused_conv_role(uint4* __restrict__ xring, float* __restrict__ img,
-                                                int* __restrict__ tab, const FusedConvArgs& A, int64_t relw, int start,
-                                                int n, int64_t kb, int64_t ke, int i_lo, int t0, int t1) {
-  constexpr int NFR = 3 - CW < NB ? (NB - (3 - CW) + 3) / 4 : 0;
+                                                const FusedConvArgs& A, int64_t relw, int start, int n, int64_t kb,
+                                                int64_t ke, int i_lo, int t0, int t1, int cw) {
+  constexpr int NFR = (NB + 3) / 4;
   constexpr int XSTAGE = 2 * NB * 64;
   const int lane = threadIdx.x & 63;
   const int nk = (int)(ke - kb);
@@ -260,12 +274,12 @@ __device__ __forceinline__ void fused_conv_role(uint4* __restrict__ xring, float
     const float* bsrc = A.per_rel_conv ? A.conv_b + relw * (int64_t)32 : A.conv_b;
     conv_fold_taps(wsrc, bsrc, A.scale, A.shift, 32, 8 * g, tap, bs);
   }
-  fused_load_images(img, tab, A, start, n, t0, t1);
+  fused_load_images(img, A, start, n, t0, t1);
   // image rows of this lane's query in each of the wave's fragments (padding lanes repeat the last query)
-  const float* qimg[NFR > 0 ? NFR : 1];
+  const float* qimg[NFR];
 #pragma unroll
   for (int t = 0; t < NFR; ++t) {
-    int qi = (3 - CW + 4 * t) * 16 + (lane & 15);
+    int qi = (cw + 4 * t) * 16 + (lane & 15);
     if (qi > n - 1) qi = n - 1;
     qimg[t] = img + qi * A.img_stride;
   }
@@ -284,16 +298,18 @@ __device__ __forceinline__ void fused_conv_role(uint4* __restrict__ xring, float
 #endif
 #pragma unroll
       for (int t = 0; t < NFR; ++t) {
-        const float* r0 = qimg[t] + poff;
-        float w[9] = {r0[0], r0[1], r0[2], r0[in_w], r0[in_w + 1], r0[in_w + 2],
-                      r0[2 * in_w], r0[2 * in_w + 1], r0[2 * in_w + 2]};
-        float y[8];
-        conv_x8(w, tap, bs, y);
-        uint4 h4, l4;
-        split8_bf16(y, h4, l4);
-        uint4* dst = xring + (kk & 1) * XSTAGE + (3 - CW + 4 * t) * 64 + lane;
-        dst[0] = h4;
-        dst[NB * 64] = l4;
+        if (cw + 4 * t < NB) {   // wave-uniform
+          const float* r0 = qimg[t] + poff;
+          float w[9] = {r0[0], r0[1], r0[2], r0[in_w], r0[in_w + 1], r0[in_w + 2],
+                        r0[2 * in_w], r0[2 * in_w + 1], r0[2 * in_w + 2]};
+          float y[8];
+          conv_x8(w, tap, bs, y);
+          uint4 h4, l4;
+          split8_bf16(y, h4, l4);
+          uint4* dst = xring + (kk & 1) * XSTAGE + (cw + 4 * t) * 64 + lane;
+          dst[0] = h4;
+          dst[NB * 64] = l4;
+        }
       }
       if (++cj == Wo) { cj = 0; poff += in_w - Wo + 1; } else { ++poff; }
     }
@@ -309,6 +325,9 @@ __global__ __launch_bounds__(512) void k_dense_fused_bf16x3(const uint4* __restr
   extern __shared__ uint4 fused_lds[];
   int tile = blockIdx.x;
   if (tile >= n_tiles[1]) return;
+#ifdef COPER_DBG_FUSED_EXIT
+  return;
+#endif
   const int32_t* tl = tiles + 4 * (cap_small + tile);
   const int slice = blockIdx.y;
   const int fb0 = blockIdx.z * NFB;
@@ -320,26 +339,18 @@ __global__ __launch_bounds__(512) void k_dense_fused_bf16x3(const uint4* __restr
   const int nb = (n + 15) >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   uint4* xring = fused_lds;                       // 2 stages x 16 slots x 1 KiB
-  int* tab = (int*)(fused_lds + 2 * 16 * 64);     // [128][2] row, relation of the tile's queries
-  float* img = (float*)(tab + 256);
+  float* img = (float*)(fused_lds + 2 * 16 * 64);
   // pixel p = k-step index: the slice needs image rows i_lo .. i_hi + 2
   const int i_lo = (int)(kb / A.Wo);
   const int t0 = i_lo * A.in_w;
   int t1 = ((int)((ke - 1) / A.Wo) + 3) * A.in_w;
   if (t1 > A.in_hw) t1 = A.in_hw;
-#define MROLE(NB_, W_) fused_matrix_role<NFB, NB_, W_>(xring, img, tab, Whi, Wlo, A, relw, start, n, fb0, nfb, ks32n, kb, ke, t0, t1, zdst, d_pad16)
-#define CROLE(NB_, W_) fused_conv_role<NB_, W_>(xring, img, tab, A, relw, start, n, kb, ke, i_lo, t0, t1)
-#define BODY(NB_)                                 \
-  switch (wave) {                                 \
-    case 0: MROLE(NB_, 0); break;                 \
-    case 1: MROLE(NB_, 1); break;                 \
-    case 2: MROLE(NB_, 2); break;                 \
-    case 3: MROLE(NB_, 3); break;                 \
-    case 4: CROLE(NB_, 0); break;                 \
-    case 5: CROLE(NB_, 1); break;                 \
-    case 6: CROLE(NB_, 2); break;                 \
-    default: CROLE(NB_, 3); break;                \
-  }
+#define BODY(NB_)                                                                                                      \
+  if (wave < 4)                                                                                                        \
+    fused_matrix_role<NFB, NB_>(xring, img, Whi, Wlo, A, relw, start, n, fb0, nfb, ks32n, kb, ke, t0, t1, zdst,        \
+                                d_pad16, wave);                                                                        \
+  else                                                                                                                 \
+    fused_conv_role<NB_>(xring, img, A, relw, start, n, kb, ke, i_lo, t0, t1, wave - 4);
   switch (nb) {
     case 3: BODY(3); break;
     case 4: BODY(4); break;
@@ -349,8 +360,6 @@ __global__ __launch_bounds__(512) void k_dense_fused_bf16x3(const uint4* __restr
     default: BODY(8); break;
   }
 #undef BODY
-#undef MROLE
-#undef CROLE
 }
 
 // slice geometry: rows of the image a K slice needs (same formula as the kernel), maximum over the slices
@@ -374,7 +383,7 @@ bool dense_fused_supported(const coper_handle* h, int nslices) {
   if (!(dm.nfb == 13 || dm.nfb == 8 || dm.nfb == 16)) return false;
   int stride = fused_rows_max(dm, nslices) * dm.in_w;
   stride |= 1;
-  size_t lds = (size_t)2 * 16 * 64 * sizeof(uint4) + 256 * sizeof(int) + (size_t)128 * stride * sizeof(float);
+  size_t lds = (size_t)2 * 16 * 64 * sizeof(uint4) + (size_t)128 * stride * sizeof(float);
   return lds <= 160 * 1024;
 }
 
@@ -385,9 +394,8 @@ static void dense_fused_launch(coper_handle* h, const int64_t* e1, const int64_t
   int64_t cap_small = (dm.gen_fc ? dm.R : 1) + 1;
   int64_t n_big_max = B / 33 + 1;
   FusedConvArgs A;
-  A.e1 = e1; A.rel = rel; A.e1_rows = e1_rows; A.perm = h->perm;
+  A.e1_rows = e1_rows; A.sorted_row = h->sorted_row; A.sorted_rid = h->sorted_rid;
   A.ent = h->params["ent_emb"].ptr;
-  A.shard_lo = h->cfg.shard_lo; A.n_local = dm.n_local; A.R = dm.R;
   A.rel_emb = dm.lookup ? nullptr : h->params["rel_emb"].ptr;
   A.conv_w = dm.gen_conv ? h->conv_w_rel : h->params["conv1_weights"].ptr;
   A.conv_b = dm.gen_conv ? h->conv_b_rel : h->params["conv1_bias"].ptr;
@@ -395,7 +403,7 @@ static void dense_fused_launch(coper_handle* h, const int64_t* e1, const int64_t
   A.per_rel_conv = dm.gen_conv ? 1 : 0;
   A.d = dm.d; A.r = dm.r; A.in_w = dm.in_w; A.in_hw = dm.in_h * dm.in_w; A.Wo = dm.Wo;
   A.img_stride = (fused_rows_max(dm, nslices) * dm.in_w) | 1;
-  size_t lds = (size_t)2 * 16 * 64 * sizeof(uint4) + 256 * sizeof(int) + (size_t)128 * A.img_stride * sizeof(float);
+  size_t lds = (size_t)2 * 16 * 64 * sizeof(uint4) + (size_t)128 * A.img_stride * sizeof(float);
   if (!h->fused_attr_done) {   // process-wide attribute: always the hardware maximum, whatever this handle needs
     (void)hipFuncSetAttribute((const void*)k_dense_fused_bf16x3<NFB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     h->fused_attr_done = true;

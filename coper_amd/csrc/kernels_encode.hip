@@ -127,20 +127,39 @@ __global__ __launch_bounds__(1024) void k_rel_scan_tiles(const int32_t* __restri
   }
 }
 
+// Besides perm, the scatter leaves what the fused conv + dense kernel's image prologue needs in sorted order
+// (one coalesced load instead of the dependent chain perm -> e1 / rel): the local entity row of e1 (-1 when it
+// is not on this shard; the query index itself when the caller passes e1_rows) and the validated relation id.
 __global__ __launch_bounds__(HIST_BLOCK) void k_rel_scatter(const int64_t* __restrict__ rel, int64_t B, int use_rel,
                                                              int64_t R, const int32_t* __restrict__ offset,
                                                              int32_t* __restrict__ cursor,
-                                                             int32_t* __restrict__ perm) {
+                                                             int32_t* __restrict__ perm,
+                                                             const int64_t* __restrict__ e1, int have_e1_rows,
+                                                             int64_t shard_lo, int64_t n_local, int64_t R_all,
+                                                             int32_t* __restrict__ sorted_row,
+                                                             int32_t* __restrict__ sorted_rid) {
   extern __shared__ int32_t sh[];  // [R] block counts, then block bases
   const bool priv = R <= HIST_LDS_MAX;
   int64_t b = (int64_t)blockIdx.x * HIST_BLOCK + threadIdx.x;
-  int64_t key = 0;
+  int64_t key = 0, rid = 0, row = -1;
   if (b < B) {
-    key = use_rel ? rel[b] : 0;
-    if (key < 0 || key >= R) key = 0;
+    rid = rel[b];
+    if (rid < 0 || rid >= R_all) rid = 0;
+    key = use_rel ? rid : 0;
+    if (have_e1_rows) {
+      row = b;
+    } else {
+      row = e1[b] - shard_lo;
+      if (row < 0 || row >= n_local) row = -1;
+    }
   }
   if (!priv) {
-    if (b < B) perm[offset[key] + atomicAdd(&cursor[key], 1)] = (int32_t)b;
+    if (b < B) {
+      int pos = offset[key] + atomicAdd(&cursor[key], 1);
+      perm[pos] = (int32_t)b;
+      sorted_row[pos] = (int32_t)row;
+      sorted_rid[pos] = (int32_t)rid;
+    }
     return;
   }
   for (int k = threadIdx.x; k < R; k += HIST_BLOCK) sh[k] = 0;
@@ -153,13 +172,19 @@ __global__ __launch_bounds__(HIST_BLOCK) void k_rel_scatter(const int64_t* __res
     sh[k] = c ? atomicAdd(&cursor[k], c) : 0;
   }
   __syncthreads();
-  if (b < B) perm[offset[key] + sh[key] + local] = (int32_t)b;
+  if (b < B) {
+    int pos = offset[key] + sh[key] + local;
+    perm[pos] = (int32_t)b;
+    sorted_row[pos] = (int32_t)row;
+    sorted_rid[pos] = (int32_t)rid;
+  }
 }
 
 // capacity of the small-tile list (one tile per relation key at most); the big list follows it
 static int64_t small_tile_cap(const coper_handle* h) { return (h->dm.gen_fc ? h->dm.R : 1) + 1; }
 
-int launch_group_by_relation(coper_handle* h, const int64_t* rel, int64_t B, int tq, hipStream_t s) {
+int launch_group_by_relation(coper_handle* h, const int64_t* e1, const int64_t* rel, bool have_e1_rows, int64_t B, int tq,
+                             hipStream_t s) {
   const Dims& dm = h->dm;
   int64_t R = dm.gen_fc ? dm.R : 1;
   COPER_HIP_TRY(h, hipMemsetAsync(h->rel_count, 0, sizeof(int32_t) * 2 * (dm.R + 2), s));  // counts | cursors
@@ -172,7 +197,8 @@ int launch_group_by_relation(coper_handle* h, const int64_t* rel, int64_t B, int
   hipLaunchKernelGGL(k_rel_scan_tiles, dim3(1), dim3(1024), 0, s, h->rel_count, R, small_tile_cap(h), h->rel_offset,
                      h->tiles, h->n_tiles);
   hipLaunchKernelGGL(k_rel_scatter, dim3(nb), dim3(HIST_BLOCK), hl, s, rel, B, dm.gen_fc ? 1 : 0, R, h->rel_offset,
-                     h->rel_cursor, h->perm);
+                     h->rel_cursor, h->perm, e1, have_e1_rows ? 1 : 0, (int64_t)h->cfg.shard_lo, dm.n_local, dm.R,
+                     h->sorted_row, h->sorted_rid);
   COPER_HIP_TRY(h, hipGetLastError());
   return COPER_OK;
 }
