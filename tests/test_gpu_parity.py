@@ -472,3 +472,72 @@ def test_tsv_loader_to_ranking_end_to_end(golden_dir, tmp_path, oracle_chain):
     st = O.forward(p, md, q["e1"], q["rel"], np.float64, materialise=False)
     assert np.abs(logits - O.score_all(st["h"], p["ent_emb"].astype(np.float64), p["pred_bias"].astype(np.float64))).max() < LOGIT_TOL
     m.close()
+
+
+_FUSED_CASES = {
+    # shapes the fused conv + dense kernel of the bf16x3 encoder serves (3x3 filters, C = 32, nfb in {8, 13, 16})
+    "cpg_fc_d128": dict(num_ent=301, num_rel=6, ent_emb_size=128, rel_emb_size=8, emb_h=8, emb_w=16,
+                        context_rel_conv=None, context_rel_out=[]),
+    "cpg_conv_fc_d128": dict(num_ent=301, num_rel=6, ent_emb_size=128, rel_emb_size=8, emb_h=8, emb_w=16,
+                             context_rel_conv=[], context_rel_out=[]),
+    "cpg_mlp_d128": dict(num_ent=301, num_rel=6, ent_emb_size=128, rel_emb_size=8, emb_h=8, emb_w=16,
+                         context_rel_conv=[7], context_rel_out=[9]),
+    "lookup_d128": dict(num_ent=301, num_rel=6, ent_emb_size=128, rel_emb_size=8, emb_h=8, emb_w=16,
+                        context_rel_conv=[], context_rel_out=[], do_parameter_lookup=True),
+    "plain_d128": dict(num_ent=301, num_rel=6, ent_emb_size=128, rel_emb_size=128, emb_h=8, emb_w=16,
+                       context_rel_conv=None, context_rel_out=None),
+    "cpg_fc_d200": dict(num_ent=301, num_rel=4, ent_emb_size=200, rel_emb_size=8, emb_h=10, emb_w=20,
+                        context_rel_conv=None, context_rel_out=[]),
+    "cpg_fc_d256": dict(num_ent=301, num_rel=4, ent_emb_size=256, rel_emb_size=8, emb_h=16, emb_w=16,
+                        context_rel_conv=None, context_rel_out=[]),
+}
+
+
+@pytest.mark.parametrize("name", sorted(_FUSED_CASES))
+def test_bf16x3_fused_encoder_vs_oracle(oracle_chain, name):
+    """The bf16x3 encoder's fused conv + dense kernel (relation groups above 32 queries) against the fp64 oracle
+    forward, against the <= 32-query path (same bits: h is a pure function of (e1, rel)), against the e1_rows
+    entry, and against the fp32-exact mode."""
+    O = oracle_chain
+    md = dict(cdata._COMMON)
+    md.update(_FUSED_CASES[name])
+    p = cdata.synthetic_params(md, seed=11)
+    Q = 420
+    q = cdata.synthetic_queries(md, Q, seed=12)
+    # relation groups: a few below 33 queries, the rest 33..128 and one above 128 (two balanced tiles)
+    rng = np.random.default_rng(13)
+    R2 = int(q["rel"].max()) + 1
+    sizes = np.bincount(q["rel"], minlength=R2)
+    big = int(np.argmax(sizes))
+    q["rel"][rng.permutation(Q)[:150]] = big
+    sizes = np.bincount(q["rel"], minlength=R2)
+    assert sizes.max() > 128 and (sizes > 32).sum() >= 2
+    m = _model(md, p, score_mode="bf16x3")
+    h = m.encode(q["e1"], q["rel"]).cpu().numpy()
+    ref = O.forward(p, md, q["e1"], q["rel"], np.float64)["h"]
+    err = np.abs(h - ref).max()
+    assert err < H_TOL, err
+    # the same queries through the small-tile path (conv kernel -> x planes -> small dense): same bits
+    small = np.concatenate([np.nonzero(q["rel"] == r)[0][:20] for r in range(R2)])
+    hs = m.encode(q["e1"][small], q["rel"][small]).cpu().numpy()
+    assert np.array_equal(hs, h[small])
+    # any order, any composition
+    perm = rng.permutation(Q)
+    assert np.array_equal(m.encode(q["e1"][perm], q["rel"][perm]).cpu().numpy(), h[perm])
+    # e1_rows entry (what the entity-sharded evaluator feeds after its all-reduce)
+    rows = torch.as_tensor(p["ent_emb"][q["e1"]])
+    assert np.array_equal(m.encode(None, q["rel"], e1_rows=rows).cpu().numpy(), h)
+    # an entity shard that does not hold a query's e1 contributes a zero image for it
+    lo, hi = 100, 250
+    ms = _model(md, p, score_mode="bf16x3", shard=(lo, hi))
+    inside = (q["e1"] >= lo) & (q["e1"] < hi)
+    hsd = ms.encode(q["e1"], q["rel"]).cpu().numpy()
+    assert np.array_equal(hsd[inside], h[inside])
+    zero_rows = torch.zeros_like(rows)
+    hz = m.encode(None, q["rel"], e1_rows=zero_rows).cpu().numpy()
+    assert np.array_equal(hsd[~inside], hz[~inside])
+    m32 = _model(md, p)
+    h32 = m32.encode(q["e1"], q["rel"]).cpu().numpy()
+    assert np.abs(h32 - h).max() < H_TOL
+    for x in (m, ms, m32):
+        x.close()
