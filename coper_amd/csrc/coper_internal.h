@@ -40,7 +40,7 @@ struct Dims {
   int64_t n_eblk = 0;  // 32-row entity blocks (padded to a multiple of EBLK_ALIGN)
 };
 
-constexpr int EBLK_ALIGN = 8;  // entity blocks consumed per workgroup iteration in score_count
+constexpr int EBLK_ALIGN = 16;  // entity blocks consumed per workgroup iteration in score_count (8 waves x 2)
 
 struct Timer {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;

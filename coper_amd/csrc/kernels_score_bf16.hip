@@ -100,6 +100,11 @@ int launch_rows_to_frag_bf16(coper_handle* h, const float* src, int64_t n_rows, 
 #endif
 constexpr int BX_NQ = COPER_BX_NQ;
 constexpr int BX_WAVES = 8;
+#ifndef COPER_BX_ME
+#define COPER_BX_ME 2
+#endif
+constexpr int BX_ME = COPER_BX_ME;
+static_assert(BX_WAVES * BX_ME <= EBLK_ALIGN, "entity blocks are padded to EBLK_ALIGN");
 
 __global__ void k_zero_counts(int64_t B, int32_t* __restrict__ ng, int32_t* __restrict__ ne) {
   int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -122,16 +127,19 @@ __global__ __launch_bounds__(512, 2) void k_score_count_bf16x3(const uint4* __re
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int64_t u_begin = units * blockIdx.x / gridDim.x;
   const int64_t u_end = units * (blockIdx.x + 1) / gridDim.x;
+  constexpr int ME = BX_ME;   // entity blocks per wave per unit: one LDS read of a query fragment feeds 3*ME MFMAs
   float t[NQ];
   int cg[NQ], ce[NQ];
   int64_t cur_tile = -1;
-  float4 bq[4];
+  float4 bq[ME][4];
 
-#define LOAD_A(ah, al, ebx, ks_)                         \
-  {                                                      \
-    int64_t o_ = ((ebx)*KS + (ks_)) * 64 + lane;         \
-    ah = Ehi[o_];                                        \
-    al = Elo[o_];                                        \
+#define LOAD_A(ah, al, ebx, ks_)                                  \
+  {                                                               \
+    _Pragma("unroll") for (int m = 0; m < ME; ++m) {              \
+      int64_t o_ = (((ebx) + m) * KS + (ks_)) * 64 + lane;        \
+      ah[m] = Ehi[o_];                                            \
+      al[m] = Elo[o_];                                            \
+    }                                                             \
   }
 #define LOAD_B(bh, bl, ks_)                                                   \
   {                                                                           \
@@ -140,13 +148,18 @@ __global__ __launch_bounds__(512, 2) void k_score_count_bf16x3(const uint4* __re
       bl[b] = hl_lo[(b * KS + (ks_)) * 64 + lane];                            \
     }                                                                         \
   }
-#define LOAD_BIAS(ebx)                                                         \
-  {                                                                            \
-    const float4* bp = (const float4*)(bias_pad + (ebx)*32 + 4 * (lane >> 5)); \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) bq[j] = bp[2 * j];           \
+#define LOAD_BIAS(ebx)                                                                \
+  {                                                                                   \
+    _Pragma("unroll") for (int m = 0; m < ME; ++m) {                                  \
+      const float4* bp = (const float4*)(bias_pad + ((ebx) + m) * 32 + 4 * (lane >> 5)); \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) bq[m][j] = bp[2 * j];             \
+    }                                                                                 \
   }
-#define STEP(ah, al, bh, bl) \
-  { _Pragma("unroll") for (int b = 0; b < NQ; ++b) MFMA_X3(ah, al, bh[b], bl[b], acc[b]); }
+#define STEP(ah, al, bh, bl)                                                  \
+  {                                                                           \
+    _Pragma("unroll") for (int b = 0; b < NQ; ++b)                            \
+      _Pragma("unroll") for (int m = 0; m < ME; ++m) MFMA_X3(ah[m], al[m], bh[b], bl[b], acc[m][b]); \
+  }
 #define FLUSH_COUNTS()                                                        \
   {                                                                           \
     _Pragma("unroll") for (int b = 0; b < NQ; ++b) {                          \
@@ -160,12 +173,12 @@ __global__ __launch_bounds__(512, 2) void k_score_count_bf16x3(const uint4* __re
     }                                                                         \
   }
 
-  // entity fragments are fetched THREE k-steps ahead (a k-step is only 12 MFMAs = 384 cycles here, shorter
-  // than an L2 round trip under load): four rotating register buffers
-  uint4 ah[4], al[4];
+  // entity fragments are fetched THREE k-steps ahead (a k-step is only 12*ME MFMAs here, shorter than an L2
+  // round trip under load): four rotating register buffers
+  uint4 ah[4][ME], al[4][ME];
 #define KCL(k_) ((k_) < KS ? (k_) : KS - 1)
   if (u_begin < u_end) {
-    int64_t eb = (u_begin % iters) * BX_WAVES + wave;
+    int64_t eb = ((u_begin % iters) * BX_WAVES + wave) * ME;
     LOAD_A(ah[0], al[0], eb, 0);
     LOAD_A(ah[1], al[1], eb, KCL(1));
     LOAD_A(ah[2], al[2], eb, KCL(2));
@@ -173,7 +186,7 @@ __global__ __launch_bounds__(512, 2) void k_score_count_bf16x3(const uint4* __re
   }
   for (int64_t u = u_begin; u < u_end; ++u) {
     const int64_t tile = u / iters;
-    const int64_t eb = (u % iters) * BX_WAVES + wave;
+    const int64_t eb = ((u % iters) * BX_WAVES + wave) * ME;
     if (tile != cur_tile) {  // workgroup-uniform
       if (cur_tile >= 0) FLUSH_COUNTS();
       __syncthreads();
@@ -190,41 +203,58 @@ __global__ __launch_bounds__(512, 2) void k_score_count_bf16x3(const uint4* __re
       }
       __syncthreads();
     }
-    f32x16 acc[NQ];
+    f32x16 acc[ME][NQ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int m = 0; m < ME; ++m)
 #pragma unroll
-      for (int b = 0; b < NQ; ++b) {
-        acc[b][4 * j + 0] = bq[j].x; acc[b][4 * j + 1] = bq[j].y;
-        acc[b][4 * j + 2] = bq[j].z; acc[b][4 * j + 3] = bq[j].w;
-      }
-    for (int ks = 0; ks < KS; ks += 4) {
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int b = 0; b < NQ; ++b) {
+          acc[m][b][4 * j + 0] = bq[m][j].x; acc[m][b][4 * j + 1] = bq[m][j].y;
+          acc[m][b][4 * j + 2] = bq[m][j].z; acc[m][b][4 * j + 3] = bq[m][j].w;
+        }
+    // No conditional code around a k-step or its prefetch in the main loop: hipcc's s_waitcnt insertion takes
+    // the minimum over paths, and a branch there turns the 3-step-ahead prefetch into "everything but the
+    // loads just issued must have landed" -- one step ahead.  Fetches past the last k-step re-read it (KCL),
+    // the prefetch for the unit after the last one re-reads this unit's blocks.
+    int ks = 0;
+    for (; ks + 4 <= KS; ks += 4) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        if (ks + j < KS) {  // wave-uniform
-          LOAD_A(ah[(j + 3) & 3], al[(j + 3) & 3], eb, KCL(ks + j + 3));
-          __builtin_amdgcn_sched_barrier(0);
-          uint4 bh[NQ], bl[NQ];
-          LOAD_B(bh, bl, ks + j);
-          STEP(ah[j], al[j], bh, bl);
-        }
+        LOAD_A(ah[(j + 3) & 3], al[(j + 3) & 3], eb, KCL(ks + j + 3));
+        __builtin_amdgcn_sched_barrier(0);
+        uint4 bh[NQ], bl[NQ];
+        LOAD_B(bh, bl, ks + j);
+        STEP(ah[j], al[j], bh, bl);
       }
     }
-    if (u + 1 < u_end) {
-      const int64_t ebn = ((u + 1) % iters) * BX_WAVES + wave;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      if (ks + j < KS) {  // wave-uniform; KS % 4 trailing steps
+        LOAD_A(ah[(j + 3) & 3], al[(j + 3) & 3], eb, KCL(ks + j + 3));
+        __builtin_amdgcn_sched_barrier(0);
+        uint4 bh[NQ], bl[NQ];
+        LOAD_B(bh, bl, ks + j);
+        STEP(ah[j], al[j], bh, bl);
+      }
+    }
+    {
+      const int64_t ebn = u + 1 < u_end ? (((u + 1) % iters) * BX_WAVES + wave) * ME : eb;
       LOAD_A(ah[0], al[0], ebn, 0);
       LOAD_A(ah[1], al[1], ebn, KCL(1));
       LOAD_A(ah[2], al[2], ebn, KCL(2));
       LOAD_BIAS(ebn);
     }
 #pragma unroll
-    for (int b = 0; b < NQ; ++b)
+    for (int m = 0; m < ME; ++m)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float sc = acc[b][r];
-        cg[b] += (sc > t[b]) ? 1 : 0;
-        if (EQ) ce[b] += (sc == t[b]) ? 1 : 0;
-      }
+      for (int b = 0; b < NQ; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float sc = acc[m][b][r];
+          cg[b] += (sc > t[b]) ? 1 : 0;
+          if (EQ) ce[b] += (sc == t[b]) ? 1 : 0;
+        }
   }
 #undef KCL
   if (cur_tile >= 0) FLUSH_COUNTS();
@@ -247,7 +277,7 @@ int launch_score_count_bf16x3(coper_handle* h, const float* hvec, const float* t
   (void)hvec;  // already packed by launch_pack_h_bf16 (coper_rank_counts packs once per call)
   hipLaunchKernelGGL(k_zero_counts, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, B, ng, ne);
   int64_t q_tiles = (B + 32 * BX_NQ - 1) / (32 * BX_NQ);
-  int64_t iters = dm.n_eblk / BX_WAVES;
+  int64_t iters = dm.n_eblk / (BX_WAVES * BX_ME);
   int64_t units = q_tiles * iters;
   int64_t grid = (int64_t)h->num_cus * COPER_BX_WGS_PER_CU;
   if (grid > units) grid = units;
