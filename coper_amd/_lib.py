@@ -49,6 +49,14 @@ class coper_config(C.Structure):
 _P = C.c_void_p
 _I64 = C.c_int64
 
+class coper_train_config(C.Structure):
+    """include/coper_hip.h: coper_train_config."""
+    _fields_ = [("abi_version", C.c_int32), ("learning_rate", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
+                ("epsilon", C.c_float), ("clip_norm", C.c_float), ("label_smoothing_epsilon", C.c_float),
+                ("hidden_dropout", C.c_float), ("output_dropout", C.c_float), ("batch_norm_momentum", C.c_float),
+                ("batch_norm_train_stats", C.c_int32), ("seed", C.c_uint32), ("reserved", C.c_int32 * 8)]
+
+
 # name -> (restype, argtypes): every symbol include/coper_hip.h declares
 PROTOTYPES = {
     "coper_abi_version": (C.c_int, []),
@@ -71,6 +79,9 @@ PROTOTYPES = {
     "coper_check_ids": (C.c_int, [_P, C.POINTER(_I64), _P]),
     "coper_profile_enable": (C.c_int, [_P, C.c_int]),
     "coper_profile_read": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_I64)]),
+    "coper_train_init": (C.c_int, [_P, C.POINTER(coper_train_config)]),
+    "coper_train_step": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _P, _P]),
+    "coper_train_grad": (C.c_int, [_P, C.c_char_p, _P, _I64, C.POINTER(_I64), C.POINTER(C.c_double), _P]),
 }
 
 _lib = None

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libcoper_hip.so")
 SOURCES = ["coper_abi.hip", "kernels_prepare.hip", "kernels_encode.hip", "kernels_score.hip", "kernels_score_bf16.hip",
-           "kernels_encode_bf16.hip", "kernels_dense_fused_bf16.hip"]
+           "kernels_encode_bf16.hip", "kernels_dense_fused_bf16.hip", "coper_train.hip"]
 
 
 def _hipcc():
@@ -70,7 +70,7 @@ def build_library(force=False, verbose=False, extra_flags=(), out=None, jobs=4):
         todo.append((base + SOURCE_FLAGS.get(src, []) + ["-c", sp, "-o", op], verbose))
     with ThreadPoolExecutor(max_workers=jobs) as ex:
         list(ex.map(_compile_one, todo))
-    link = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out + ".tmp", *objs]
+    link = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out + ".tmp", *objs, "-ldl"]
     if verbose:
         print(" ".join(link), file=sys.stderr)
     subprocess.check_call(link)

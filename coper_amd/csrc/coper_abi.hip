@@ -231,6 +231,7 @@ COPER_API void coper_destroy(coper_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->cfg.device);
   (void)hipDeviceSynchronize();
+  train_destroy(h);
   dev_free(&h->conv_scale); dev_free(&h->conv_shift); dev_free(&h->fc_scale); dev_free(&h->fc_shift);
   dev_free(&h->conv_w_rel); dev_free(&h->conv_b_rel); dev_free(&h->fc_b_rel); dev_free(&h->Wf);
   dev_free(&h->Ef); dev_free(&h->bias_pad); dev_free(&h->ctx_tmp[0]); dev_free(&h->ctx_tmp[1]);

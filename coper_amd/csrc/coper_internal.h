@@ -110,6 +110,7 @@ struct coper_handle {
   int64_t row_of_cap = 0;
   float* hfrag_ws = nullptr;      // h re-packed in MFMA-fragment order [ceil(B/128)*4][KS][64] float4
   int num_cus = 256;
+  void* train = nullptr;          // coper::TrainState (coper_train.hip)
   bool dense_attr_done = false;
   bool fused_attr_done = false;
   bool dense_small_only = false;  // set per launch: tiles above 32 queries go to the fused conv + dense kernel
@@ -121,6 +122,7 @@ struct coper_handle {
 namespace coper {
 
 int fail(coper_handle* h, int code, const std::string& msg);
+void train_destroy(coper_handle* h);   // coper_train.hip
 int hip_fail(coper_handle* h, hipError_t e, const char* what);
 
 #define COPER_HIP_TRY(h, expr)                                    \

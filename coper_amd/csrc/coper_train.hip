@@ -1,0 +1,784 @@
+// Training step (include/coper_hip.h "Training step").  fp32 throughout.
+//
+//   forward (train mode, models.py:354-426,438-443):
+//     img = ent_emb[e1] (+ rel_emb[rel] stacked below it for plain ConvE)            k_tr_conv_fwd
+//     y   = conv3x3(img) + conv1_bias                      [B, P = Ho*Wo, C]          k_tr_conv_fwd
+//     Conv1BN (batch statistics when batch_norm_train_stats), ReLU, dropout -> x [B, F]   k_tr_bn1_fwd
+//     dense: static z0 = x W, generated z0 = (x (x) c) P2 with P2 = Projection0 viewed [r*F, d]
+//            -- the FACTORED form: the [B,F,d] weight tensor of models.py:70,412 is never formed;
+//            one sgemm over K = r*F (rocBLAS, loaded lazily: a plain library GEMM)
+//     + dense bias, dropout, FCBN, ReLU -> h [B, d]                                   k_tr_fc_post, k_tr_fcbn_fwd
+//     s[b,l] = h[b] . ent_emb[lookup[b,l]] + pred_bias[lookup[b,l]];  loss; ds        k_tr_score_loss
+//   backward: the transposes of the above (dense: dA = dz P2^T, dP2 = A^T dz, two more sgemms), embedding rows
+//   by float atomics (as tf.scatter_add on a GPU, the summation order is not fixed).
+//   optimiser: tf.clip_by_global_norm + AMSGrad (amsgrad.py:130-159), one fused kernel per parameter.
+#include <dlfcn.h>
+
+#include <cmath>
+#include <cstring>
+
+#include "coper_internal.h"
+#include "train_common.h"
+
+namespace coper {
+
+namespace {
+
+constexpr float BN_EPS = 1e-3f;
+
+// ---- rocBLAS, resolved at coper_train_init (the inference library has no link-time dependency on it)
+typedef void* rb_handle;
+typedef int (*rb_create_t)(rb_handle*);
+typedef int (*rb_destroy_t)(rb_handle);
+typedef int (*rb_set_stream_t)(rb_handle, hipStream_t);
+typedef int (*rb_sgemm_t)(rb_handle, int, int, int, int, int, const float*, const float*, int, const float*, int,
+                          const float*, float*, int);
+constexpr int RB_N = 111, RB_T = 112;  // rocblas_operation_none / _transpose
+
+struct RocBlas {
+  void* lib = nullptr;
+  rb_handle handle = nullptr;
+  rb_create_t create = nullptr;
+  rb_destroy_t destroy = nullptr;
+  rb_set_stream_t set_stream = nullptr;
+  rb_sgemm_t sgemm = nullptr;
+};
+
+struct TrainParam {
+  std::string name;
+  float* p = nullptr;   // the caller's variable, updated in place
+  int64_t n = 0;
+  float* g = nullptr;   // gradient of the last step
+  float* m = nullptr;   // AMSGrad slots
+  float* v = nullptr;
+  float* vh = nullptr;
+};
+
+}  // namespace
+
+struct TrainState {
+  coper_train_config cfg;
+  RocBlas rb;
+  std::vector<TrainParam> tp;
+  double b1p = 0, b2p = 0;
+  uint32_t step = 0;
+  int64_t capB = 0, capL = 0;
+  // workspaces
+  float *img = nullptr, *y = nullptr, *x = nullptr, *c = nullptr, *A = nullptr, *dA = nullptr;
+  float *z0 = nullptr, *z1 = nullptr, *hv = nullptr, *dh = nullptr, *dz = nullptr, *ds = nullptr, *dx = nullptr, *dc = nullptr;
+  double* red = nullptr;     // reduction scratch: [0] loss, [1] grad sumsq, [2..] BN sums
+  float* bnst = nullptr;     // [4][max(C,d)]: mean1, inv1, mean2, inv2 ... see offsets below
+  float* zero_row = nullptr;
+  TrainParam* find(const char* name) {
+    for (auto& t : tp)
+      if (t.name == name) return &t;
+    return nullptr;
+  }
+};
+
+namespace {
+
+template <typename T>
+int talloc(coper_handle* h, T** p, size_t n) {
+  if (*p) { (void)hipFree(*p); *p = nullptr; }
+  if (hipMalloc((void**)p, n * sizeof(T)) != hipSuccess) return fail(h, COPER_ENOMEM, "hipMalloc failed (training workspace)");
+  return COPER_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward kernels
+// ------------------------------------------------------------------------------------------------
+// one workgroup per query: gather the image, 3x3 VALID cross-correlation + bias -> y[b, p, c]
+__global__ __launch_bounds__(256) void k_tr_conv_fwd(const int64_t* __restrict__ e1, const int64_t* __restrict__ rel,
+                                                     const float* __restrict__ ent, const float* __restrict__ rel_emb,
+                                                     const float* __restrict__ K, const float* __restrict__ kb, int64_t E,
+                                                     int64_t R, int d, int r, int in_h, int in_w, int stacked, int C, int Ho,
+                                                     int Wo, float* __restrict__ img_out, float* __restrict__ c_out,
+                                                     float* __restrict__ y) {
+  extern __shared__ float lds[];  // img[in_h*in_w] | taps[9*C] | kb[C]
+  float* img = lds;
+  float* taps = img + in_h * in_w;
+  float* bias = taps + 9 * C;
+  const int64_t b = blockIdx.x;
+  int64_t row = e1[b];
+  if (row < 0 || row >= E) row = 0;
+  int64_t rid = rel[b];
+  if (rid < 0 || rid >= R) rid = 0;
+  for (int t = threadIdx.x; t < d; t += 256) img[t] = ent[row * d + t];
+  if (stacked)
+    for (int t = threadIdx.x; t < r; t += 256) img[d + t] = rel_emb[rid * r + t];
+  if (c_out)
+    for (int t = threadIdx.x; t < r; t += 256) c_out[b * r + t] = rel_emb[rid * r + t];
+  for (int t = threadIdx.x; t < 9 * C; t += 256) taps[t] = K[t];
+  for (int t = threadIdx.x; t < C; t += 256) bias[t] = kb[t];
+  __syncthreads();
+  const int isz = in_h * in_w;
+  for (int t = threadIdx.x; t < isz; t += 256) img_out[b * isz + t] = img[t];
+  const int P = Ho * Wo;
+  float* yb = y + b * (int64_t)P * C;
+  for (int idx = threadIdx.x; idx < P * C; idx += 256) {
+    const int cc = idx % C, p = idx / C;
+    const int i = p / Wo, j = p - i * Wo;
+    float a = 0.f;
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+#pragma unroll
+      for (int v = 0; v < 3; ++v) a = fmaf(img[(i + u) * in_w + j + v], taps[(u * 3 + v) * C + cc], a);
+    yb[idx] = a + bias[cc];
+  }
+}
+
+// per-column sums of a [rows, cols] matrix in double: out[0..cols) = sum, out[cols..2cols) = sum of squares
+// (partial sums by row chunk, then atomics on doubles: order-dependent only in the last bits of a double)
+__global__ __launch_bounds__(256) void k_tr_col_sums(const float* __restrict__ m, int64_t rows, int cols, double* __restrict__ out) {
+  const int cpt = 256 / cols > 0 ? 256 / cols : 1;  // row lanes per column when cols <= 256
+  const int col = threadIdx.x % cols, rl = threadIdx.x / cols;
+  if (cols > 256 || rl >= cpt) {
+    if (cols <= 256) return;
+  }
+  double s = 0, q = 0;
+  if (cols <= 256) {
+    for (int64_t rr = (int64_t)blockIdx.x * cpt + rl; rr < rows; rr += (int64_t)gridDim.x * cpt) {
+      const double v = m[rr * cols + col];
+      s += v;
+      q += v * v;
+    }
+    atomicAdd(&out[col], s);
+    atomicAdd(&out[cols + col], q);
+  } else {
+    for (int cc = threadIdx.x; cc < cols; cc += 256) {
+      s = 0; q = 0;
+      for (int64_t rr = blockIdx.x; rr < rows; rr += gridDim.x) {
+        const double v = m[rr * cols + cc];
+        s += v;
+        q += v * v;
+      }
+      atomicAdd(&out[cc], s);
+      atomicAdd(&out[cols + cc], q);
+    }
+  }
+}
+
+// BN statistics -> (mean, inv_std) used by forward and backward; moving statistics updated in place.
+// unbiased_moving: [TF-semantics] the fused 4-D kernel feeds the unbiased variance into the moving average.
+__global__ void k_tr_bn_finish(const double* __restrict__ sums, int cols, double n, int use_batch, float momentum,
+                               int unbiased_moving, float* __restrict__ mov_mean, float* __restrict__ mov_var,
+                               float* __restrict__ mean_out, float* __restrict__ inv_out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  if (use_batch) {
+    const double mean = sums[c] / n;
+    double var = sums[cols + c] / n - mean * mean;
+    if (var < 0) var = 0;
+    mean_out[c] = (float)mean;
+    inv_out[c] = (float)(1.0 / sqrt(var + (double)BN_EPS));
+    const double var_m = unbiased_moving ? var * (n / (n - 1.0)) : var;
+    mov_mean[c] = (float)((double)mov_mean[c] * momentum + mean * (1.0 - (double)momentum));
+    mov_var[c] = (float)((double)mov_var[c] * momentum + var_m * (1.0 - (double)momentum));
+  } else {
+    mean_out[c] = mov_mean[c];
+    inv_out[c] = 1.0f / sqrtf(mov_var[c] + BN_EPS);
+  }
+}
+
+// x = keep * relu(bn(y)) / (1 - rate)     (elementwise over [B, P, C]; flat index = the dropout counter)
+__global__ __launch_bounds__(256) void k_tr_bn1_fwd(const float* __restrict__ y, const float* __restrict__ mean,
+                                                    const float* __restrict__ inv, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, int C, int64_t total, uint32_t seed,
+                                                    uint32_t step, uint32_t thr, float keep_scale, float* __restrict__ x) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  float v = (y[i] - mean[c]) * inv[c] * gamma[c] + beta[c];
+  v = v > 0.f ? v : 0.f;
+  x[i] = dropout_keep_u32(seed, step, 1u, (uint32_t)i, thr) ? v * keep_scale : 0.f;
+}
+
+// A[b, rho*F + f] = c[b, rho] * x[b, f]
+__global__ __launch_bounds__(256) void k_tr_outer(const float* __restrict__ x, const float* __restrict__ c, int64_t F, int r,
+                                                  float* __restrict__ A) {
+  const int64_t b = blockIdx.y;
+  const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (f >= F) return;
+  const float xv = x[b * F + f];
+  float* Ab = A + b * (int64_t)r * F + f;
+  for (int rho = 0; rho < r; ++rho) Ab[(int64_t)rho * F] = c[b * r + rho] * xv;
+}
+
+// z1 = keep * (z0 + bias_b) / (1 - rate);  bias_b = fc_bias[k] (static) or sum_rho c[b,rho] Pb[rho,k]
+__global__ __launch_bounds__(256) void k_tr_fc_post(const float* __restrict__ z0, const float* __restrict__ fc_bias,
+                                                    const float* __restrict__ c, const float* __restrict__ Pb, int r, int d,
+                                                    int64_t total, uint32_t seed, uint32_t step, uint32_t thr,
+                                                    float keep_scale, float* __restrict__ z1) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int k = (int)(i % d);
+  const int64_t b = i / d;
+  float bias;
+  if (Pb) {
+    bias = 0.f;
+    for (int rho = 0; rho < r; ++rho) bias = fmaf(c[b * r + rho], Pb[rho * d + k], bias);
+  } else {
+    bias = fc_bias[k];
+  }
+  const float v = z0[i] + bias;
+  z1[i] = dropout_keep_u32(seed, step, 2u, (uint32_t)i, thr) ? v * keep_scale : 0.f;
+}
+
+__global__ __launch_bounds__(256) void k_tr_fcbn_fwd(const float* __restrict__ z1, const float* __restrict__ mean,
+                                                     const float* __restrict__ inv, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, int d, int64_t total,
+                                                     float* __restrict__ hv) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int k = (int)(i % d);
+  const float v = (z1[i] - mean[k]) * inv[k] * gamma[k] + beta[k];
+  hv[i] = v > 0.f ? v : 0.f;
+}
+
+// sampled scorer + loss + d(loss)/ds.  One workgroup per query; h[b] in LDS; one lookup entry per thread.
+__global__ __launch_bounds__(256) void k_tr_score_loss(const float* __restrict__ hv, const float* __restrict__ ent,
+                                                       const float* __restrict__ pred_bias,
+                                                       const int32_t* __restrict__ lookup, const float* __restrict__ labels,
+                                                       int64_t E, int d, int64_t L, float ls_eps, float inv_E, float inv_BL,
+                                                       float* __restrict__ ds, double* __restrict__ loss_acc) {
+  extern __shared__ float hl[];
+  __shared__ double part[256];
+  const int64_t b = blockIdx.x;
+  for (int k = threadIdx.x; k < d; k += 256) hl[k] = hv[b * d + k];
+  __syncthreads();
+  double acc = 0.0;
+  for (int64_t l = threadIdx.x; l < L; l += 256) {
+    int64_t row = lookup[b * L + l];
+    if (row < 0 || row >= E) row = 0;
+    const float* er = ent + row * d;
+    float s = 0.f;
+    for (int k = 0; k < d; ++k) s = fmaf(hl[k], er[k], s);
+    s += pred_bias[row];
+    const float t = (1.f - ls_eps) * labels[b * L + l] + inv_E;                  // models.py:450
+    const float as = fabsf(s);
+    acc += (double)(fmaxf(s, 0.f) - s * t + log1pf(expf(-as)));                 // sigmoid cross-entropy with logits
+    const float sg = 1.f / (1.f + expf(-s));
+    ds[b * L + l] = (sg - t) * inv_BL;
+  }
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) atomicAdd(loss_acc, part[0]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward kernels
+// ------------------------------------------------------------------------------------------------
+// dh[b,k] = sum_l ds[b,l] E[lookup[b,l], k];  dE[lookup, k] += ds h[b,k];  dbias[lookup] += ds
+__global__ __launch_bounds__(256) void k_tr_score_bwd(const float* __restrict__ hv, const float* __restrict__ ent,
+                                                      const int32_t* __restrict__ lookup, const float* __restrict__ ds,
+                                                      int64_t E, int d, int64_t L, float* __restrict__ dh,
+                                                      float* __restrict__ dE, float* __restrict__ dbias) {
+  const int64_t b = blockIdx.x;
+  const int k = threadIdx.x;
+  const float hk = k < d ? hv[b * d + k] : 0.f;
+  float acc = 0.f;
+  for (int64_t l = 0; l < L; ++l) {
+    int64_t row = lookup[b * L + l];
+    if (row < 0 || row >= E) row = 0;
+    const float g = ds[b * L + l];
+    if (k < d) {
+      acc = fmaf(g, ent[row * d + k], acc);
+      atomicAdd(&dE[row * d + k], g * hk);
+    }
+    if (k == 0) atomicAdd(&dbias[row], g);
+  }
+  if (k < d) dh[b * d + k] = acc;
+}
+
+// FCBN backward, one workgroup per feature k (a column of [B, d]): gamma/beta gradients and dz1
+__global__ __launch_bounds__(256) void k_tr_fcbn_bwd(const float* __restrict__ z1, const float* __restrict__ hv,
+                                                     const float* __restrict__ dh, const float* __restrict__ mean,
+                                                     const float* __restrict__ inv, const float* __restrict__ gamma, int64_t B,
+                                                     int d, int use_batch, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta, float* __restrict__ dz1) {
+  __shared__ double s1[256], s2[256];
+  const int k = blockIdx.x;
+  const float mu = mean[k], iv = inv[k], ga = gamma[k];
+  double a1 = 0, a2 = 0;
+  for (int64_t b = threadIdx.x; b < B; b += 256) {
+    const float g = hv[b * d + k] > 0.f ? dh[b * d + k] : 0.f;   // through the ReLU
+    const float zh = (z1[b * d + k] - mu) * iv;
+    a1 += g;
+    a2 += (double)g * zh;
+  }
+  s1[threadIdx.x] = a1; s2[threadIdx.x] = a2;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) { s1[threadIdx.x] += s1[threadIdx.x + o]; s2[threadIdx.x] += s2[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  const double S1 = s1[0], S2 = s2[0];
+  if (threadIdx.x == 0) { dbeta[k] = (float)S1; dgamma[k] = (float)S2; }
+  for (int64_t b = threadIdx.x; b < B; b += 256) {
+    const float g = hv[b * d + k] > 0.f ? dh[b * d + k] : 0.f;
+    const float zh = (z1[b * d + k] - mu) * iv;
+    float dz;
+    if (use_batch) dz = (float)((double)ga * iv * ((double)g - S1 / (double)B - (double)zh * S2 / (double)B));
+    else dz = ga * iv * g;
+    dz1[b * d + k] = dz;
+  }
+}
+
+// dz0 = keep * dz1 / (1 - rate) (in place); dense-bias gradients: static dfc_bias[k] += dz0; generated
+// dPb[rho,k] += c[b,rho] dz0[b,k], dc[b,rho] = sum_k dz0[b,k] Pb[rho,k]
+__global__ __launch_bounds__(256) void k_tr_fc_post_bwd(float* __restrict__ dz, const float* __restrict__ c,
+                                                        const float* __restrict__ Pb, int r, int d, uint32_t seed,
+                                                        uint32_t step, uint32_t thr, float keep_scale,
+                                                        float* __restrict__ dfc_bias, float* __restrict__ dPb,
+                                                        float* __restrict__ dc) {
+  extern __shared__ float row[];  // dz0[b, :]
+  const int64_t b = blockIdx.x;
+  for (int k = threadIdx.x; k < d; k += 256) {
+    const int64_t i = b * d + k;
+    const float v = dropout_keep_u32(seed, step, 2u, (uint32_t)i, thr) ? dz[i] * keep_scale : 0.f;
+    dz[i] = v;
+    row[k] = v;
+    if (!Pb) atomicAdd(&dfc_bias[k], v);
+  }
+  __syncthreads();
+  if (Pb) {
+    for (int idx = threadIdx.x; idx < r * d; idx += 256) atomicAdd(&dPb[idx], c[b * r + idx / d] * row[idx % d]);
+    for (int rho = threadIdx.x; rho < r; rho += 256) {
+      float a = 0.f;
+      for (int k = 0; k < d; ++k) a = fmaf(row[k], Pb[rho * d + k], a);
+      dc[b * r + rho] = a;
+    }
+  }
+}
+
+// dx[b,f] = sum_rho c[b,rho] dA[b,rho*F+f];  dc[b,rho] += sum_f x[b,f] dA[b,rho*F+f]
+__global__ __launch_bounds__(256) void k_tr_outer_bwd(const float* __restrict__ dA, const float* __restrict__ x,
+                                                      const float* __restrict__ c, int64_t F, int r, float* __restrict__ dx,
+                                                      float* __restrict__ dc) {
+  __shared__ float part[256];
+  const int64_t b = blockIdx.y;
+  const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool ok = f < F;
+  const float xv = ok ? x[b * F + f] : 0.f;
+  const float* Ab = dA + b * (int64_t)r * F + f;
+  float a = 0.f;
+  for (int rho = 0; rho < r; ++rho) {
+    const float g = ok ? Ab[(int64_t)rho * F] : 0.f;
+    a = fmaf(c[b * r + rho], g, a);
+    part[threadIdx.x] = xv * g;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd(&dc[b * r + rho], part[0]);
+    __syncthreads();
+  }
+  if (ok) dx[b * F + f] = a;
+}
+
+// Conv1BN backward, pass 1: g = dx * keep/(1-rate) through the ReLU; per-channel sums of g and g*yhat
+// (dbeta, dgamma).  g overwrites dx.
+__global__ __launch_bounds__(256) void k_tr_bn1_bwd_sums(float* __restrict__ dx, const float* __restrict__ y,
+                                                         const float* __restrict__ mean, const float* __restrict__ inv,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta, int C,
+                                                         int64_t total, uint32_t seed, uint32_t step, uint32_t thr,
+                                                         float keep_scale, double* __restrict__ sums) {
+  __shared__ double s1[256], s2[256];
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  double a1 = 0, a2 = 0;
+  if (i < total) {
+    const int c = (int)(i % C);
+    const float yh = (y[i] - mean[c]) * inv[c];
+    const float act = yh * gamma[c] + beta[c];
+    float g = dropout_keep_u32(seed, step, 1u, (uint32_t)i, thr) ? dx[i] * keep_scale : 0.f;
+    if (!(act > 0.f)) g = 0.f;
+    dx[i] = g;
+    a1 = g;
+    a2 = (double)g * yh;
+  }
+  // 256 % C == 0 for the supported channel counts: threads with the same (threadIdx.x % C) share a channel
+  s1[threadIdx.x] = a1; s2[threadIdx.x] = a2;
+  __syncthreads();
+  for (int o = 128; o >= C; o >>= 1) {
+    if ((int)threadIdx.x < o) { s1[threadIdx.x] += s1[threadIdx.x + o]; s2[threadIdx.x] += s2[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if ((int)threadIdx.x < C) {
+    const int c = (int)(((int64_t)blockIdx.x * 256 + threadIdx.x) % C);
+    atomicAdd(&sums[c], s1[threadIdx.x]);
+    atomicAdd(&sums[C + c], s2[threadIdx.x]);
+  }
+}
+
+// pass 2: dy = gamma*inv*(g - S1/n - yhat*S2/n) (batch statistics) or gamma*inv*g; in place on dx
+__global__ __launch_bounds__(256) void k_tr_bn1_bwd_apply(float* __restrict__ dx, const float* __restrict__ y,
+                                                          const float* __restrict__ mean, const float* __restrict__ inv,
+                                                          const float* __restrict__ gamma, const double* __restrict__ sums, int C,
+                                                          int64_t total, double n, int use_batch, float* __restrict__ dgamma,
+                                                          float* __restrict__ dbeta) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < C) { dbeta[i] = (float)sums[i]; dgamma[i] = (float)sums[C + i]; }
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  const float g = dx[i];
+  if (use_batch) {
+    const float yh = (y[i] - mean[c]) * inv[c];
+    dx[i] = (float)((double)gamma[c] * inv[c] * ((double)g - sums[c] / n - (double)yh * sums[C + c] / n));
+  } else {
+    dx[i] = gamma[c] * inv[c] * g;
+  }
+}
+
+// conv backward, one workgroup per query: dK, dkb (block-reduced, then atomics), d(img) -> rows of dE / drel_emb
+__global__ __launch_bounds__(256) void k_tr_conv_bwd(const float* __restrict__ dy, const float* __restrict__ img_all,
+                                                     const float* __restrict__ K, const int64_t* __restrict__ e1,
+                                                     const int64_t* __restrict__ rel, int64_t E, int64_t R, int d, int r,
+                                                     int in_h, int in_w, int stacked, int C, int Ho, int Wo,
+                                                     float* __restrict__ dK, float* __restrict__ dkb,
+                                                     float* __restrict__ dE, float* __restrict__ drel) {
+  extern __shared__ float lds[];  // img[isz] | g[P*C] | taps[9*C]
+  const int isz = in_h * in_w, P = Ho * Wo;
+  float* img = lds;
+  float* g = img + isz;
+  float* taps = g + P * C;
+  const int64_t b = blockIdx.x;
+  for (int t = threadIdx.x; t < isz; t += 256) img[t] = img_all[b * isz + t];
+  for (int t = threadIdx.x; t < P * C; t += 256) g[t] = dy[b * (int64_t)P * C + t];
+  for (int t = threadIdx.x; t < 9 * C; t += 256) taps[t] = K[t];
+  __syncthreads();
+  // filter and bias gradients: entry (tap, c) = sum_p img[p + tap offset] * g[p, c]
+  for (int idx = threadIdx.x; idx < 10 * C; idx += 256) {
+    const int cc = idx % C, tap = idx / C;
+    float a = 0.f;
+    if (tap < 9) {
+      const int u = tap / 3, v = tap % 3;
+      for (int i = 0; i < Ho; ++i)
+        for (int j = 0; j < Wo; ++j) a = fmaf(img[(i + u) * in_w + j + v], g[(i * Wo + j) * C + cc], a);
+      atomicAdd(&dK[tap * C + cc], a);
+    } else {
+      for (int p = 0; p < P; ++p) a += g[p * C + cc];
+      atomicAdd(&dkb[cc], a);
+    }
+  }
+  // image gradient (full correlation), scattered to the embedding rows
+  int64_t row = e1[b];
+  if (row < 0 || row >= E) row = 0;
+  int64_t rid = rel[b];
+  if (rid < 0 || rid >= R) rid = 0;
+  for (int t = threadIdx.x; t < isz; t += 256) {
+    const int ii = t / in_w, jj = t - ii * in_w;
+    float a = 0.f;
+    for (int u = 0; u < 3; ++u) {
+      const int i = ii - u;
+      if (i < 0 || i >= Ho) continue;
+      for (int v = 0; v < 3; ++v) {
+        const int j = jj - v;
+        if (j < 0 || j >= Wo) continue;
+        const float* gp = g + (i * Wo + j) * C;
+        const float* tp = taps + (u * 3 + v) * C;
+        for (int cc = 0; cc < C; ++cc) a = fmaf(gp[cc], tp[cc], a);
+      }
+    }
+    if (t < d) atomicAdd(&dE[row * d + t], a);
+    else if (stacked) atomicAdd(&drel[rid * r + (t - d)], a);
+  }
+}
+
+// drel_emb[rel[b], :] += dc[b, :]
+__global__ __launch_bounds__(256) void k_tr_scatter_rows(const float* __restrict__ dc, const int64_t* __restrict__ rel, int64_t R,
+                                                         int r, int64_t total, float* __restrict__ drel) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  int64_t rid = rel[i / r];
+  if (rid < 0 || rid >= R) rid = 0;
+  atomicAdd(&drel[rid * r + i % r], dc[i]);
+}
+
+__global__ __launch_bounds__(256) void k_tr_sumsq(const float* __restrict__ g, int64_t n, double* __restrict__ acc) {
+  __shared__ double part[256];
+  double a = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) a += (double)g[i] * g[i];
+  part[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) atomicAdd(acc, part[0]);
+}
+
+// tf.clip_by_global_norm + AMSGrad (amsgrad.py:130-159), all in one pass over the parameter
+__global__ __launch_bounds__(256) void k_tr_amsgrad(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, float* __restrict__ vh, int64_t n,
+                                                    const double* __restrict__ sumsq, float clip, float lr_t, float b1, float b2,
+                                                    float eps) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const double gn = sqrt(*sumsq);
+  const float scale = (float)((double)clip / (gn > (double)clip ? gn : (double)clip));
+  const float gi = g[i] * scale;
+  const float mi = b1 * m[i] + (1.f - b1) * gi;
+  const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+  const float vhi = fmaxf(vh[i], vi);
+  m[i] = mi; v[i] = vi; vh[i] = vhi;
+  p[i] -= lr_t * mi / (sqrtf(vhi) + eps);
+}
+
+__global__ void k_tr_store_loss(const double* __restrict__ acc, double inv_BL, float* __restrict__ out) { out[0] = (float)(acc[0] * inv_BL); }
+
+int rb_check(coper_handle* h, int st, const char* what) {
+  if (st != 0) return fail(h, COPER_EHIP, std::string("rocBLAS call failed: ") + what);
+  return COPER_OK;
+}
+
+}  // namespace
+
+void train_destroy(coper_handle* h) {
+  TrainState* T = (TrainState*)h->train;
+  if (!T) return;
+  for (auto& t : T->tp) { (void)hipFree(t.g); (void)hipFree(t.m); (void)hipFree(t.v); (void)hipFree(t.vh); }
+  float* bufs[] = {T->img, T->y, T->x, T->c, T->A, T->dA, T->z0, T->z1, T->hv, T->dh, T->dz, T->ds, T->dx, T->dc, T->bnst};
+  for (float* b : bufs) (void)hipFree(b);
+  (void)hipFree(T->red);
+  if (T->rb.handle && T->rb.destroy) (void)T->rb.destroy(T->rb.handle);
+  if (T->rb.lib) dlclose(T->rb.lib);
+  delete T;
+  h->train = nullptr;
+}
+
+}  // namespace coper
+
+using namespace coper;
+
+extern "C" {
+
+COPER_API int coper_train_init(coper_handle* h, const coper_train_config* cfg) {
+  if (!h || !cfg) return COPER_EINVAL;
+  if (cfg->abi_version != COPER_ABI_VERSION) return fail(h, COPER_EINVAL, "coper_train_init: ABI version mismatch");
+  const Dims& dm = h->dm;
+  if (dm.gen_conv || dm.lookup || dm.concat_rel || (dm.gen_fc && h->cfg.n_ctx_out != 0))
+    return fail(h, COPER_EUNSUPPORTED,
+                "coper_train_init: this version trains static conv filters with a static or g_linear dense layer "
+                "(no generated conv, g_MLP, g_lookup or concat_rel)");
+  if (h->cfg.shard_lo != 0 || h->cfg.shard_hi != dm.E)
+    return fail(h, COPER_EUNSUPPORTED, "coper_train_init: training needs the whole entity table on the handle");
+  if (dm.fh != 3 || dm.fw != 3 || 256 % dm.C != 0 || dm.d > 256)
+    return fail(h, COPER_EUNSUPPORTED, "coper_train_init: 3x3 filters, C dividing 256, d <= 256");
+  if (!(cfg->learning_rate > 0) || cfg->hidden_dropout < 0 || cfg->hidden_dropout >= 1 || cfg->output_dropout < 0 ||
+      cfg->output_dropout >= 1)
+    return fail(h, COPER_EINVAL, "coper_train_init: bad hyper-parameter");
+  for (auto& sp : h->specs)
+    if (!h->params[sp.name].set) return fail(h, COPER_EINVAL, "coper_train_init: parameter not set: " + sp.name);
+  COPER_HIP_TRY(h, hipSetDevice(h->cfg.device));
+  train_destroy(h);
+  TrainState* T = new TrainState();
+  h->train = T;
+  T->cfg = *cfg;
+  T->b1p = cfg->beta1;   // the beta powers start at beta (amsgrad.py:108-113)
+  T->b2p = cfg->beta2;
+  std::vector<std::string> names = {"ent_emb", "rel_emb", "conv1_weights", "conv1_bias", "pred_bias", "Conv1BN/gamma",
+                                    "Conv1BN/beta", "FCBN/gamma", "FCBN/beta"};
+  if (dm.gen_fc) { names.push_back("fc_weights/CPG/Projection0"); names.push_back("fc_bias/CPG/Projection0"); }
+  else { names.push_back("fc_weights"); names.push_back("fc_bias"); }
+  for (auto& nm : names) {
+    auto it = h->params.find(nm);
+    if (it == h->params.end() || !it->second.set) return fail(h, COPER_EINVAL, "coper_train_init: missing parameter " + nm);
+    TrainParam tp;
+    tp.name = nm;
+    tp.p = const_cast<float*>(it->second.ptr);
+    tp.n = 1;
+    for (int64_t s : it->second.shape) tp.n *= s;
+    int rc;
+    if ((rc = talloc(h, &tp.g, (size_t)tp.n)) || (rc = talloc(h, &tp.m, (size_t)tp.n)) || (rc = talloc(h, &tp.v, (size_t)tp.n)) ||
+        (rc = talloc(h, &tp.vh, (size_t)tp.n)))
+      return rc;
+    COPER_HIP_TRY(h, hipMemset(tp.m, 0, sizeof(float) * tp.n));
+    COPER_HIP_TRY(h, hipMemset(tp.v, 0, sizeof(float) * tp.n));
+    COPER_HIP_TRY(h, hipMemset(tp.vh, 0, sizeof(float) * tp.n));
+    COPER_HIP_TRY(h, hipMemset(tp.g, 0, sizeof(float) * tp.n));
+    T->tp.push_back(tp);
+  }
+  // rocBLAS for the three plain GEMMs of the dense layer
+  RocBlas& rb = T->rb;
+  rb.lib = dlopen("librocblas.so", RTLD_NOW | RTLD_LOCAL);
+  if (!rb.lib) rb.lib = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_LOCAL);
+  if (!rb.lib) return fail(h, COPER_EUNSUPPORTED, std::string("coper_train_init: cannot load librocblas.so: ") + dlerror());
+  rb.create = (rb_create_t)dlsym(rb.lib, "rocblas_create_handle");
+  rb.destroy = (rb_destroy_t)dlsym(rb.lib, "rocblas_destroy_handle");
+  rb.set_stream = (rb_set_stream_t)dlsym(rb.lib, "rocblas_set_stream");
+  rb.sgemm = (rb_sgemm_t)dlsym(rb.lib, "rocblas_sgemm");
+  if (!rb.create || !rb.destroy || !rb.set_stream || !rb.sgemm) return fail(h, COPER_EUNSUPPORTED, "coper_train_init: rocBLAS symbols missing");
+  int rc;
+  if ((rc = rb_check(h, rb.create(&rb.handle), "rocblas_create_handle"))) return rc;
+  int mx = dm.C > dm.d ? dm.C : dm.d;
+  if ((rc = talloc(h, &T->bnst, (size_t)4 * mx))) return rc;
+  if ((rc = talloc(h, &T->red, (size_t)(2 + 2 * mx)))) return rc;
+  return COPER_OK;
+}
+
+COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t* rel, const int32_t* lookup, const float* labels,
+                               int64_t B, int64_t L, float* loss_out, void* stream) {
+  if (!h) return COPER_EINVAL;
+  TrainState* T = (TrainState*)h->train;
+  if (!T) return fail(h, COPER_ESTATE, "coper_train_step: call coper_train_init first");
+  if (!e1 || !rel || !lookup || !labels || B <= 0 || L <= 0 || B * L > 0x7fffffff)
+    return fail(h, COPER_EINVAL, "coper_train_step: bad argument");
+  const Dims& dm = h->dm;
+  hipStream_t s = (hipStream_t)stream;
+  COPER_HIP_TRY(h, hipSetDevice(h->cfg.device));
+  h->prepared = false;   // the variables change: per-relation caches, fragment images and folded BN go stale
+  const coper_train_config& tc = T->cfg;
+  const int d = dm.d, r = dm.r, C = dm.C, P = dm.Ho * dm.Wo, isz = dm.in_h * dm.in_w;
+  const int64_t F = dm.F;
+  if ((int64_t)B * F > 0xffffffffLL) return fail(h, COPER_EINVAL, "coper_train_step: batch too large for the dropout counter");
+  int rc;
+  if (B > T->capB || L > T->capL) {
+    COPER_HIP_TRY(h, hipStreamSynchronize(s));
+    int64_t cb = B > T->capB ? B : T->capB, cl = L > T->capL ? L : T->capL;
+    if ((rc = talloc(h, &T->img, (size_t)cb * isz)) || (rc = talloc(h, &T->y, (size_t)cb * F)) ||
+        (rc = talloc(h, &T->x, (size_t)cb * F)) || (rc = talloc(h, &T->dx, (size_t)cb * F)) ||
+        (rc = talloc(h, &T->c, (size_t)cb * r)) || (rc = talloc(h, &T->dc, (size_t)cb * r)) ||
+        (rc = talloc(h, &T->z0, (size_t)cb * d)) || (rc = talloc(h, &T->z1, (size_t)cb * d)) ||
+        (rc = talloc(h, &T->hv, (size_t)cb * d)) || (rc = talloc(h, &T->dh, (size_t)cb * d)) ||
+        (rc = talloc(h, &T->dz, (size_t)cb * d)) || (rc = talloc(h, &T->ds, (size_t)cb * cl)))
+      return rc;
+    if (dm.gen_fc && ((rc = talloc(h, &T->A, (size_t)cb * r * F)) || (rc = talloc(h, &T->dA, (size_t)cb * r * F)))) return rc;
+    T->capB = cb; T->capL = cl;
+  }
+  auto P_ = [&](const char* n) -> float* { return T->find(n)->p; };
+  auto G_ = [&](const char* n) -> float* { return T->find(n)->g; };
+  float* ent = P_("ent_emb");
+  float* relp = P_("rel_emb");
+  const int use_batch = tc.batch_norm_train_stats ? 1 : 0;
+  const int mx = C > d ? C : d;
+  float *mean1 = T->bnst, *inv1 = T->bnst + mx, *mean2 = T->bnst + 2 * mx, *inv2 = T->bnst + 3 * mx;
+  double* red = T->red;         // [0] loss, [1] sumsq, [2 .. 2+2mx) column sums
+  double* colsum = red + 2;
+  const uint32_t thr_h = dropout_threshold24(tc.hidden_dropout), thr_o = dropout_threshold24(tc.output_dropout);
+  const float ks_h = 1.f / (1.f - tc.hidden_dropout), ks_o = 1.f / (1.f - tc.output_dropout);
+  const uint32_t step = T->step;
+  const float one = 1.f, zero = 0.f;
+  if ((rc = rb_check(h, T->rb.set_stream(T->rb.handle, s), "rocblas_set_stream"))) return rc;
+
+  // ---- zero what is accumulated by atomics
+  COPER_HIP_TRY(h, hipMemsetAsync(red, 0, sizeof(double) * (2 + 2 * mx), s));
+  const char* zeroed[] = {"ent_emb", "rel_emb", "conv1_weights", "conv1_bias", "pred_bias"};
+  for (const char* nm : zeroed) COPER_HIP_TRY(h, hipMemsetAsync(G_(nm), 0, sizeof(float) * T->find(nm)->n, s));
+  if (dm.gen_fc) COPER_HIP_TRY(h, hipMemsetAsync(G_("fc_bias/CPG/Projection0"), 0, sizeof(float) * r * d, s));
+  else COPER_HIP_TRY(h, hipMemsetAsync(G_("fc_bias"), 0, sizeof(float) * d, s));
+
+  // ---- forward
+  size_t lds_conv = sizeof(float) * (size_t)(isz + 10 * C);
+  hipLaunchKernelGGL(k_tr_conv_fwd, dim3((unsigned)B), dim3(256), lds_conv, s, e1, rel, ent, relp, P_("conv1_weights"),
+                     P_("conv1_bias"), dm.E, dm.R, d, r, dm.in_h, dm.in_w, dm.stacked ? 1 : 0, C, dm.Ho, dm.Wo, T->img,
+                     dm.gen_fc ? T->c : nullptr, T->y);
+  const int64_t nBF = B * F;
+  if (use_batch) hipLaunchKernelGGL(k_tr_col_sums, dim3(128), dim3(256), 0, s, T->y, B * (int64_t)P, C, colsum);
+  hipLaunchKernelGGL(k_tr_bn_finish, dim3((C + 63) / 64), dim3(64), 0, s, colsum, C, (double)B * P, use_batch,
+                     tc.batch_norm_momentum, 1, const_cast<float*>(h->params["Conv1BN/moving_mean"].ptr),
+                     const_cast<float*>(h->params["Conv1BN/moving_variance"].ptr), mean1, inv1);
+  hipLaunchKernelGGL(k_tr_bn1_fwd, dim3((unsigned)((nBF + 255) / 256)), dim3(256), 0, s, T->y, mean1, inv1, P_("Conv1BN/gamma"),
+                     P_("Conv1BN/beta"), C, nBF, tc.seed, step, thr_h, ks_h, T->x);
+  const int64_t Kd = dm.gen_fc ? (int64_t)r * F : F;           // inner size of the dense GEMMs
+  const float* Amat = T->x;
+  const float* Wmat = dm.gen_fc ? P_("fc_weights/CPG/Projection0") : P_("fc_weights");   // row-major [Kd, d]
+  if (dm.gen_fc) {
+    hipLaunchKernelGGL(k_tr_outer, dim3((unsigned)((F + 255) / 256), (unsigned)B), dim3(256), 0, s, T->x, T->c, F, r, T->A);
+    Amat = T->A;
+  }
+  // z0[B,d] = A[B,Kd] W[Kd,d]   (row-major operands seen as column-major transposes)
+  if ((rc = rb_check(h, T->rb.sgemm(T->rb.handle, RB_N, RB_N, d, (int)B, (int)Kd, &one, Wmat, d, Amat, (int)Kd, &zero, T->z0, d),
+                     "sgemm forward")))
+    return rc;
+  const int64_t nBd = B * d;
+  hipLaunchKernelGGL(k_tr_fc_post, dim3((unsigned)((nBd + 255) / 256)), dim3(256), 0, s, T->z0, dm.gen_fc ? nullptr : P_("fc_bias"),
+                     T->c, dm.gen_fc ? P_("fc_bias/CPG/Projection0") : nullptr, r, d, nBd, tc.seed, step, thr_o, ks_o, T->z1);
+  COPER_HIP_TRY(h, hipMemsetAsync(colsum, 0, sizeof(double) * 2 * mx, s));
+  if (use_batch) hipLaunchKernelGGL(k_tr_col_sums, dim3(16), dim3(256), 0, s, T->z1, B, d, colsum);
+  hipLaunchKernelGGL(k_tr_bn_finish, dim3((d + 63) / 64), dim3(64), 0, s, colsum, d, (double)B, use_batch, tc.batch_norm_momentum, 0,
+                     const_cast<float*>(h->params["FCBN/moving_mean"].ptr), const_cast<float*>(h->params["FCBN/moving_variance"].ptr),
+                     mean2, inv2);
+  hipLaunchKernelGGL(k_tr_fcbn_fwd, dim3((unsigned)((nBd + 255) / 256)), dim3(256), 0, s, T->z1, mean2, inv2, P_("FCBN/gamma"),
+                     P_("FCBN/beta"), d, nBd, T->hv);
+  const float inv_BL = (float)(1.0 / ((double)B * (double)L));
+  hipLaunchKernelGGL(k_tr_score_loss, dim3((unsigned)B), dim3(256), sizeof(float) * d, s, T->hv, ent, P_("pred_bias"), lookup, labels,
+                     dm.E, d, L, tc.label_smoothing_epsilon, (float)(1.0 / (double)dm.E), inv_BL, T->ds, red);
+  if (loss_out) hipLaunchKernelGGL(k_tr_store_loss, dim3(1), dim3(1), 0, s, red, 1.0 / ((double)B * (double)L), loss_out);
+
+  // ---- backward
+  hipLaunchKernelGGL(k_tr_score_bwd, dim3((unsigned)B), dim3(256), 0, s, T->hv, ent, lookup, T->ds, dm.E, d, L, T->dh, G_("ent_emb"),
+                     G_("pred_bias"));
+  hipLaunchKernelGGL(k_tr_fcbn_bwd, dim3((unsigned)d), dim3(256), 0, s, T->z1, T->hv, T->dh, mean2, inv2, P_("FCBN/gamma"), B, d, use_batch,
+                     G_("FCBN/gamma"), G_("FCBN/beta"), T->dz);
+  if (dm.gen_fc) COPER_HIP_TRY(h, hipMemsetAsync(T->dc, 0, sizeof(float) * B * r, s));
+  hipLaunchKernelGGL(k_tr_fc_post_bwd, dim3((unsigned)B), dim3(256), sizeof(float) * d, s, T->dz, T->c,
+                     dm.gen_fc ? P_("fc_bias/CPG/Projection0") : nullptr, r, d, tc.seed, step, thr_o, ks_o,
+                     dm.gen_fc ? nullptr : G_("fc_bias"), dm.gen_fc ? G_("fc_bias/CPG/Projection0") : nullptr, T->dc);
+  float* dW = dm.gen_fc ? G_("fc_weights/CPG/Projection0") : G_("fc_weights");
+  // dW[Kd,d] = A^T dz
+  if ((rc = rb_check(h, T->rb.sgemm(T->rb.handle, RB_N, RB_T, d, (int)Kd, (int)B, &one, T->dz, d, Amat, (int)Kd, &zero, dW, d), "sgemm dW")))
+    return rc;
+  // dA[B,Kd] = dz W^T
+  float* dAmat = dm.gen_fc ? T->dA : T->dx;
+  if ((rc = rb_check(h, T->rb.sgemm(T->rb.handle, RB_T, RB_N, (int)Kd, (int)B, d, &one, Wmat, d, T->dz, d, &zero, dAmat, (int)Kd), "sgemm dA")))
+    return rc;
+  if (dm.gen_fc)
+    hipLaunchKernelGGL(k_tr_outer_bwd, dim3((unsigned)((F + 255) / 256), (unsigned)B), dim3(256), 0, s, T->dA, T->x, T->c, F, r, T->dx, T->dc);
+  COPER_HIP_TRY(h, hipMemsetAsync(colsum, 0, sizeof(double) * 2 * mx, s));
+  hipLaunchKernelGGL(k_tr_bn1_bwd_sums, dim3((unsigned)((nBF + 255) / 256)), dim3(256), 0, s, T->dx, T->y, mean1, inv1, P_("Conv1BN/gamma"),
+                     P_("Conv1BN/beta"), C, nBF, tc.seed, step, thr_h, ks_h, colsum);
+  hipLaunchKernelGGL(k_tr_bn1_bwd_apply, dim3((unsigned)((nBF + 255) / 256)), dim3(256), 0, s, T->dx, T->y, mean1, inv1, P_("Conv1BN/gamma"),
+                     colsum, C, nBF, (double)B * P, use_batch, G_("Conv1BN/gamma"), G_("Conv1BN/beta"));
+  size_t lds_cb = sizeof(float) * (size_t)(isz + (size_t)P * C + 9 * C);
+  if (lds_cb > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_tr_conv_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipLaunchKernelGGL(k_tr_conv_bwd, dim3((unsigned)B), dim3(256), lds_cb, s, T->dx, T->img, P_("conv1_weights"), e1, rel, dm.E, dm.R, d, r,
+                     dm.in_h, dm.in_w, dm.stacked ? 1 : 0, C, dm.Ho, dm.Wo, G_("conv1_weights"), G_("conv1_bias"), G_("ent_emb"),
+                     G_("rel_emb"));
+  if (dm.gen_fc)
+    hipLaunchKernelGGL(k_tr_scatter_rows, dim3((unsigned)((B * r + 255) / 256)), dim3(256), 0, s, T->dc, rel, dm.R, r, B * r, G_("rel_emb"));
+
+  // ---- clip + AMSGrad
+  for (auto& t : T->tp) {
+    int64_t nb = (t.n + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(k_tr_sumsq, dim3((unsigned)nb), dim3(256), 0, s, t.g, t.n, red + 1);
+  }
+  const float lr_t = (float)((double)tc.learning_rate * std::sqrt(1.0 - T->b2p) / (1.0 - T->b1p));
+  for (auto& t : T->tp)
+    hipLaunchKernelGGL(k_tr_amsgrad, dim3((unsigned)((t.n + 255) / 256)), dim3(256), 0, s, t.p, t.g, t.m, t.v, t.vh, t.n, red + 1,
+                       tc.clip_norm, lr_t, tc.beta1, tc.beta2, tc.epsilon);
+  COPER_HIP_TRY(h, hipGetLastError());
+  T->b1p *= tc.beta1;
+  T->b2p *= tc.beta2;
+  T->step += 1;
+  return COPER_OK;
+}
+
+COPER_API int coper_train_grad(coper_handle* h, const char* leaf_name, float* out, int64_t cap, int64_t* n, double* global_norm,
+                               void* stream) {
+  if (!h || !leaf_name) return COPER_EINVAL;
+  TrainState* T = (TrainState*)h->train;
+  if (!T) return fail(h, COPER_ESTATE, "coper_train_grad: call coper_train_init first");
+  TrainParam* t = T->find(leaf_name);
+  if (!t) return fail(h, COPER_EINVAL, std::string("coper_train_grad: not a trainable leaf: ") + leaf_name);
+  if (n) *n = t->n;
+  if (out) {
+    if (cap < t->n) return fail(h, COPER_EINVAL, "coper_train_grad: output buffer too small");
+    COPER_HIP_TRY(h, hipMemcpyAsync(out, t->g, sizeof(float) * t->n, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  }
+  if (global_norm) {
+    COPER_HIP_TRY(h, hipStreamSynchronize((hipStream_t)stream));
+    double ss = 0;
+    COPER_HIP_TRY(h, hipMemcpy(&ss, T->red + 1, sizeof(double), hipMemcpyDeviceToHost));
+    *global_norm = std::sqrt(ss);
+  }
+  return COPER_OK;
+}
+
+}  // extern "C"

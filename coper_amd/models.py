@@ -6,7 +6,7 @@ names (`.variables[...]`, models.py:316-325), same fetch attributes the callers 
 (`.e1 .e2 .rel .e2_multi .obj_lookup_values .predicted_e2_emb .predictions_all
 .predictions_lookup .is_train .input_iterator_handle`, models.py:135-190), evaluated through a
 `session.run(fetches, feed_dict)` shim (`ConvE.session()`), so `run_cpg.py:_evaluate` /
-`metrics.ranking_and_hits` read the same.  Inference only: `.loss` / `.train_op` raise.
+`metrics.ranking_and_hits` read the same.  Training: `train_init()` / `train_step(batch)`.
 
 torch is plumbing (device memory, streams); all compute is in the HIP library.  There is no CPU
 path: constructing a model without a GPU or without the built library raises."""
@@ -321,12 +321,69 @@ class ConvE(object):
         _lib.check(self._h, self._lib.coper_profile_read(self._h, kernel.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    # ---------------------------------------------------------------- training
+    def train_init(self, seed=0, beta1=0.9, beta2=0.999, epsilon=1e-8, clip_norm=5.0, **overrides):
+        """Allocates gradients and AMSGrad slots (amsgrad.py:112-118).  Hyper-parameters come from
+        model_descriptors (models.py:99-130) unless overridden.  The tensors passed to load_parameters ARE the
+        variables: train_step updates them in place (BN moving statistics included)."""
+        md = dict(self.model_descriptors)
+        md.update(overrides)
+        cfg = _lib.coper_train_config()
+        cfg.abi_version = _lib.COPER_ABI_VERSION
+        cfg.learning_rate = float(md["learning_rate"])
+        cfg.beta1, cfg.beta2, cfg.epsilon, cfg.clip_norm = float(beta1), float(beta2), float(epsilon), float(clip_norm)
+        cfg.label_smoothing_epsilon = float(md.get("label_smoothing_epsilon", 0.0))
+        cfg.hidden_dropout = float(md.get("hidden_dropout", 0.0))
+        cfg.output_dropout = float(md.get("output_dropout", 0.0))
+        cfg.batch_norm_momentum = float(md.get("batch_norm_momentum", 0.1))
+        cfg.batch_norm_train_stats = 1 if md.get("batch_norm_train_stats", False) else 0
+        cfg.seed = int(seed) & 0xFFFFFFFF
+        with torch.cuda.device(self.device):
+            _lib.check(self._h, self._lib.coper_train_init(self._h, C.byref(cfg)))
+        self._train_loss = torch.zeros(1, device=self.device, dtype=torch.float32)
+        return self
+
+    def train_step(self, batch):
+        """`session.run((model.train_op, model.loss))` on one training batch in the reference batch contract
+        (models.py:139-152): e1, rel [B]; lookup_values int32 [B,L]; e2_multi float [B,L].  Returns the loss as
+        a 1-element device tensor (no synchronisation)."""
+        if getattr(self, "_train_loss", None) is None:
+            raise _lib.CoperError(5, "call train_init() first")
+        e1, rel = self._ids(batch["e1"]), self._ids(batch["rel"])
+        lookup = self._ids(batch["lookup_values"], torch.int32)
+        labels = batch["e2_multi"]
+        labels = (labels if isinstance(labels, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(labels)))
+        labels = labels.to(device=self.device, dtype=torch.float32).contiguous()
+        B, L = lookup.shape
+        if tuple(labels.shape) != (B, L) or e1.numel() != B or rel.numel() != B:
+            raise ValueError("training batch: e1, rel [B]; lookup_values and e2_multi [B, L]")
+        with torch.cuda.device(self.device):
+            _lib.check(self._h, self._lib.coper_train_step(self._h, _ptr(e1), _ptr(rel), _ptr(lookup), _ptr(labels), B, L,
+                                                           _ptr(self._train_loss), self._stream()))
+        self._prepared = False       # caches are stale; the next inference call prepares again
+        return self._train_loss
+
+    def train_grad(self, leaf_name):
+        """(gradient of the last step as a tensor copy, global gradient norm) -- test / diagnostics hook."""
+        n, gn = C.c_int64(), C.c_double()
+        _lib.check(self._h, self._lib.coper_train_grad(self._h, leaf_name.encode(), None, 0, C.byref(n), None, self._stream()))
+        out = torch.empty(n.value, device=self.device, dtype=torch.float32)
+        _lib.check(self._h, self._lib.coper_train_grad(self._h, leaf_name.encode(), _ptr(out), n.value, C.byref(n), C.byref(gn),
+                                                       self._stream()))
+        return out, gn.value
+
     # ---------------------------------------------------------------- reference-style access
     @property
     def loss(self):
-        raise NotImplementedError("training (loss / train_op, models.py:192-200) is outside this build: SURVEY 8f-1")
+        """models.py:192: the last training step's loss (a device tensor)."""
+        if getattr(self, "_train_loss", None) is None:
+            raise NotImplementedError("no training step has run: call train_init() and train_step(batch)")
+        return self._train_loss
 
-    train_op = loss
+    @property
+    def train_op(self):
+        """models.py:196-200: a callable standing in for the TF op -- `model.train_op(batch)`."""
+        return self.train_step
 
     def session(self):
         return Session(self)

@@ -184,6 +184,45 @@ COPER_API int coper_check_ids(coper_handle* h, int64_t* n_bad, void* stream);
 COPER_API int coper_profile_enable(coper_handle* h, int enable);
 COPER_API int coper_profile_read(coper_handle* h, const char* kernel, double* total_ms, int64_t* launches);
 
+/* ---------------------------------------------------------------------------------------------
+ * Training step: replaces `session.run(model.train_op)` of run_cpg.py:211-219, i.e.
+ * models.py:176-200 (train-mode forward, sampled scorer, label-smoothed sigmoid cross-entropy),
+ * tf.clip_by_global_norm(5.0) (models.py:199) and utils/amsgrad.py:130-189.
+ * Supported in this version: static conv filters; static (plain ConvE) or g_linear generated dense
+ * layer; no concat_rel, no g_lookup, no g_MLP (COPER_EUNSUPPORTED otherwise).
+ * The parameters registered with coper_set_param are UPDATED IN PLACE (they are the variables), including
+ * the BN moving statistics; the caches built by coper_prepare go stale, so the handle must be prepared
+ * again before the next inference call (enforced).
+ * Dropout uses a counter-based hash of (seed, step, stage, element) instead of TF's RNG stream.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct coper_train_config {
+  int32_t abi_version;            /* COPER_ABI_VERSION */
+  float learning_rate;            /* model_descriptors['learning_rate'] (models.py:130) */
+  float beta1, beta2, epsilon;    /* AMSGrad defaults 0.9, 0.999, 1e-8 (amsgrad.py:60-62) */
+  float clip_norm;                /* 5.0 (models.py:199) */
+  float label_smoothing_epsilon;  /* models.py:101,450 */
+  float hidden_dropout;           /* after conv BN ReLU (models.py:390) */
+  float output_dropout;           /* before FCBN (models.py:414) */
+  float batch_norm_momentum;      /* moving-average DECAY (models.py:64,387,417) */
+  int32_t batch_norm_train_stats; /* BN uses batch statistics while training (models.py:62,358) */
+  uint32_t seed;                  /* dropout stream */
+  int32_t reserved[8];
+} coper_train_config;
+
+/* Allocates gradients and the AMSGrad slots m, v, v_hat (zeros) for every trainable parameter; every
+ * parameter must have been registered with coper_set_param. */
+COPER_API int coper_train_init(coper_handle* h, const coper_train_config* cfg);
+/* One optimisation step on a training batch in the reference batch contract (models.py:139-152):
+ * e1, rel int64 [B]; lookup int32 [B,L] (obj_lookup_values); labels float [B,L] (e2_multi for the looked-up
+ * entities).  loss_out: device float[1], the batch loss (models.py:448-453). */
+COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t* rel, const int32_t* lookup,
+                               const float* labels, int64_t B, int64_t L, float* loss_out, void* stream);
+/* Diagnostics: copies the (unclipped) gradient of the last step for a trainable leaf into `out` (device float
+ * buffer of `cap` elements; may be NULL), returns its length in *n, and in *global_norm (optional, host) the
+ * global gradient norm of the last step (synchronises). */
+COPER_API int coper_train_grad(coper_handle* h, const char* leaf_name, float* out, int64_t cap, int64_t* n,
+                               double* global_norm, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,103 @@
+"""GPU tests of the training step through the C ABI, against oracle/coper_train_oracle.py
+(float64 torch-autograd restatement of models.py:176-200,354-457 + utils/amsgrad.py).  Tolerances are fp32
+rounding of a ~5k-term reduction chain; the oracle gets the same dropout masks (same counter hash)."""
+import numpy as np
+import pytest
+import torch
+
+from coper_amd import data as cdata
+
+pytestmark = pytest.mark.gpu
+
+_CASES = {
+    "cpg_linear": dict(num_ent=211, num_rel=6, ent_emb_size=40, rel_emb_size=8, emb_h=10, emb_w=4, conv_num_channels=8,
+                       context_rel_conv=None, context_rel_out=[]),
+    "plain": dict(num_ent=211, num_rel=6, ent_emb_size=40, rel_emb_size=40, emb_h=10, emb_w=4, conv_num_channels=8,
+                  context_rel_conv=None, context_rel_out=None),
+    "cpg_linear_c32": dict(num_ent=157, num_rel=4, ent_emb_size=80, rel_emb_size=4, emb_h=10, emb_w=8, conv_num_channels=32,
+                           context_rel_conv=None, context_rel_out=[]),
+}
+
+
+def _batch(md, B, L, seed):
+    rng = np.random.default_rng(seed)
+    E, R = md["num_ent"], md["num_rel"]
+    lookup = rng.integers(0, E, (B, L)).astype(np.int32)
+    lookup[:, 0] = rng.integers(0, E, B)                      # the positive first, as the sampler does
+    labels = np.zeros((B, L), np.float32)
+    labels[:, 0] = 1.0
+    labels[rng.random((B, L)) < 0.05] = 1.0
+    return dict(e1=rng.integers(0, E, B), rel=rng.integers(0, R, B), lookup_values=lookup, e2_multi=labels)
+
+
+def _rel_err(a, b, floor):
+    # `floor`: gradients that are exactly zero in exact arithmetic (conv1_bias under batch-statistics BN is
+    # shift-invariant) come out as rounding noise on both sides
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), floor)
+
+
+@pytest.mark.parametrize("train_stats", [True, False])
+@pytest.mark.parametrize("name", sorted(_CASES))
+def test_train_step_matches_oracle(name, train_stats):
+    from coper_amd.models import ConvE
+    from oracle import coper_train_oracle as T
+    md = dict(cdata._COMMON)
+    md.update(_CASES[name])
+    md.update(batch_norm_train_stats=train_stats, batch_norm_momentum=0.9, hidden_dropout=0.3, output_dropout=0.2,
+              label_smoothing_epsilon=0.1, learning_rate=0.003)
+    p0 = cdata.synthetic_params(md, seed=21)
+    B, L, seed = 48, 37, 5
+    m = ConvE(md, device="cuda:0")
+    m.load_parameters({k: torch.as_tensor(np.array(v, np.float32)) for k, v in p0.items()})
+    m.train_init(seed=seed)
+    ref = {k: np.array(v, np.float64) for k, v in p0.items()}
+    opt = T.AMSGrad(T.trainable_names(md), ref, lr=md["learning_rate"])
+    for step in range(3):
+        batch = _batch(md, B, L, seed=100 + step)
+        ob = dict(e1=batch["e1"], rel=batch["rel"], lookup=batch["lookup_values"], labels=batch["e2_multi"])
+        loss_o, grads_o, gn_o = T.train_step(ref, md, ob, opt, seed=seed, step=step, momentum=md["batch_norm_momentum"])
+        loss = float(m.train_step(batch).cpu()[0])
+        assert abs(loss - loss_o) < 2e-5 * max(1.0, abs(loss_o)), (step, loss, loss_o)
+        dg = {}
+        for leaf in T.trainable_names(md):
+            g, gn = m.train_grad(leaf)
+            g = g.cpu().numpy().reshape(grads_o[leaf].shape)
+            err = _rel_err(g, grads_o[leaf], 1e-4 * gn_o)
+            assert err < 2e-4, (step, leaf, err)
+            dg[leaf] = np.abs(g - grads_o[leaf]).max()
+        assert abs(gn - gn_o) < 1e-4 * gn_o
+        # the variables themselves (updated in place), including the BN moving statistics
+        for leaf, want in ref.items():
+            if train_stats and leaf == "conv1_bias":
+                # exact gradient 0 (batch-statistics BN is shift-invariant): Adam-type updates m/(sqrt(v_hat)+eps)
+                # turn the fp32 rounding noise of either side into an O(lr) step -- nothing to compare
+                continue
+            got = m._tensors[leaf].cpu().numpy().reshape(np.shape(want))
+            # g -> lr_t * m / (sqrt(v_hat) + eps) has slope <= lr_t * (1 - beta1) / eps where |g| ~ eps = 1e-8: an
+            # absolute gradient error dg (fp32 rounding) may move such an entry by that much
+            lr_t = md["learning_rate"] * 0.32
+            tol = 2e-5 + 1e-5 * np.abs(want).max() + 2.0 * lr_t * 0.1 * dg.get(leaf, 0.0) / 1e-8
+            assert np.abs(got - want).max() < tol, (step, leaf, np.abs(got - want).max(), tol)
+    # inference after training: caches are rebuilt from the updated variables
+    q = cdata.synthetic_queries(md, 40, seed=3)
+    h = m.encode(q["e1"], q["rel"]).cpu().numpy()
+    from oracle import coper_oracle as O
+    hr = O.forward({k: np.asarray(v, np.float32) for k, v in ref.items()}, md, q["e1"], q["rel"], np.float64)["h"]
+    assert np.abs(h - hr).max() < 2e-4
+    m.close()
+
+
+def test_train_rejects_unsupported_variants_and_order():
+    from coper_amd.models import ConvE
+    from coper_amd._lib import CoperError
+    md = dict(cdata._COMMON)
+    md.update(num_ent=50, num_rel=4, ent_emb_size=40, rel_emb_size=8, emb_h=10, emb_w=4, conv_num_channels=8,
+              context_rel_conv=[], context_rel_out=[])
+    m = ConvE(md, device="cuda:0")
+    m.load_parameters(cdata.synthetic_params(md, seed=1))
+    with pytest.raises(CoperError):
+        m.train_init()                      # generated conv filters: not in this version
+    with pytest.raises(CoperError):
+        m.train_step(_batch(md, 4, 5, 0))   # no train_init
+    m.close()
