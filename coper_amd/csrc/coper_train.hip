@@ -33,6 +33,8 @@ typedef int (*rb_destroy_t)(rb_handle);
 typedef int (*rb_set_stream_t)(rb_handle, hipStream_t);
 typedef int (*rb_sgemm_t)(rb_handle, int, int, int, int, int, const float*, const float*, int, const float*, int,
                           const float*, float*, int);
+typedef int (*rb_sgemm_sb_t)(rb_handle, int, int, int, int, int, const float*, const float*, int, int64_t, const float*, int,
+                             int64_t, const float*, float*, int, int64_t, int);
 constexpr int RB_N = 111, RB_T = 112;  // rocblas_operation_none / _transpose
 
 struct RocBlas {
@@ -42,6 +44,7 @@ struct RocBlas {
   rb_destroy_t destroy = nullptr;
   rb_set_stream_t set_stream = nullptr;
   rb_sgemm_t sgemm = nullptr;
+  rb_sgemm_sb_t sgemm_sb = nullptr;
 };
 
 struct TrainParam {
@@ -64,7 +67,8 @@ struct TrainState {
   uint32_t step = 0;
   int64_t capB = 0, capL = 0;
   // workspaces
-  float *img = nullptr, *y = nullptr, *x = nullptr, *c = nullptr, *A = nullptr, *dA = nullptr;
+  float *img = nullptr, *y = nullptr, *x = nullptr, *c = nullptr, *dA = nullptr;
+  float* A = nullptr;        // generated dense: T[r][B][d] (forward partials) | dT[r][B][d]
   float *z0 = nullptr, *z1 = nullptr, *hv = nullptr, *dh = nullptr, *dz = nullptr, *ds = nullptr, *dx = nullptr, *dc = nullptr;
   double* red = nullptr;     // reduction scratch: [0] loss, [1] grad sumsq, [2..] BN sums
   float* bnst = nullptr;     // [4][max(C,d)]: mean1, inv1, mean2, inv2 ... see offsets below
@@ -194,18 +198,8 @@ __global__ __launch_bounds__(256) void k_tr_bn1_fwd(const float* __restrict__ y,
   x[i] = dropout_keep_u32(seed, step, 1u, (uint32_t)i, thr) ? v * keep_scale : 0.f;
 }
 
-// A[b, rho*F + f] = c[b, rho] * x[b, f]
-__global__ __launch_bounds__(256) void k_tr_outer(const float* __restrict__ x, const float* __restrict__ c, int64_t F, int r,
-                                                  float* __restrict__ A) {
-  const int64_t b = blockIdx.y;
-  const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (f >= F) return;
-  const float xv = x[b * F + f];
-  float* Ab = A + b * (int64_t)r * F + f;
-  for (int rho = 0; rho < r; ++rho) Ab[(int64_t)rho * F] = c[b * r + rho] * xv;
-}
-
-// z1 = keep * (z0 + bias_b) / (1 - rate);  bias_b = fc_bias[k] (static) or sum_rho c[b,rho] Pb[rho,k]
+// z1 = keep * (z0 + bias_b) / (1 - rate).  Static: z0 from the GEMM, bias_b = fc_bias[k].  Generated:
+// z0[b,k] = sum_rho c[b,rho] T[rho][b,k] (T[rho] = x P[rho], the batched GEMM), bias_b = sum_rho c[b,rho] Pb[rho,k]
 __global__ __launch_bounds__(256) void k_tr_fc_post(const float* __restrict__ z0, const float* __restrict__ fc_bias,
                                                     const float* __restrict__ c, const float* __restrict__ Pb, int r, int d,
                                                     int64_t total, uint32_t seed, uint32_t step, uint32_t thr,
@@ -214,14 +208,13 @@ __global__ __launch_bounds__(256) void k_tr_fc_post(const float* __restrict__ z0
   if (i >= total) return;
   const int k = (int)(i % d);
   const int64_t b = i / d;
-  float bias;
+  float v;
   if (Pb) {
-    bias = 0.f;
-    for (int rho = 0; rho < r; ++rho) bias = fmaf(c[b * r + rho], Pb[rho * d + k], bias);
+    v = 0.f;
+    for (int rho = 0; rho < r; ++rho) v = fmaf(c[b * r + rho], z0[(int64_t)rho * total + i] + Pb[rho * d + k], v);
   } else {
-    bias = fc_bias[k];
+    v = z0[i] + fc_bias[k];
   }
-  const float v = z0[i] + bias;
   z1[i] = dropout_keep_u32(seed, step, 2u, (uint32_t)i, thr) ? v * keep_scale : 0.f;
 }
 
@@ -356,6 +349,16 @@ __global__ __launch_bounds__(256) void k_tr_fc_post_bwd(float* __restrict__ dz, 
   }
 }
 
+// dT[rho][b,k] = c[b,rho] dz[b,k]   (operand of the batched weight-gradient GEMM dP[rho] = x^T dT[rho])
+__global__ __launch_bounds__(256) void k_tr_scale_rows(const float* __restrict__ dz, const float* __restrict__ c, int r, int d,
+                                                       int64_t total, float* __restrict__ dT) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int64_t b = i / d;
+  const float g = dz[i];
+  for (int rho = 0; rho < r; ++rho) dT[(int64_t)rho * total + i] = c[b * r + rho] * g;
+}
+
 // dx[b,f] = sum_rho c[b,rho] dA[b,rho*F+f];  dc[b,rho] += sum_f x[b,f] dA[b,rho*F+f]
 __global__ __launch_bounds__(256) void k_tr_outer_bwd(const float* __restrict__ dA, const float* __restrict__ x,
                                                       const float* __restrict__ c, int64_t F, int r, float* __restrict__ dx,
@@ -390,17 +393,17 @@ __global__ __launch_bounds__(256) void k_tr_bn1_bwd_sums(float* __restrict__ dx,
                                                          int64_t total, uint32_t seed, uint32_t step, uint32_t thr,
                                                          float keep_scale, double* __restrict__ sums) {
   __shared__ double s1[256], s2[256];
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   double a1 = 0, a2 = 0;
-  if (i < total) {
+  // grid-stride: 256 % C == 0, so a thread stays on one channel and the channel sums are built in registers
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int c = (int)(i % C);
     const float yh = (y[i] - mean[c]) * inv[c];
     const float act = yh * gamma[c] + beta[c];
     float g = dropout_keep_u32(seed, step, 1u, (uint32_t)i, thr) ? dx[i] * keep_scale : 0.f;
     if (!(act > 0.f)) g = 0.f;
     dx[i] = g;
-    a1 = g;
-    a2 = (double)g * yh;
+    a1 += g;
+    a2 += (double)g * yh;
   }
   // 256 % C == 0 for the supported channel counts: threads with the same (threadIdx.x % C) share a channel
   s1[threadIdx.x] = a1; s2[threadIdx.x] = a2;
@@ -500,8 +503,21 @@ __global__ __launch_bounds__(256) void k_tr_scatter_rows(const float* __restrict
   atomicAdd(&drel[rid * r + i % r], dc[i]);
 }
 
-__global__ __launch_bounds__(256) void k_tr_sumsq(const float* __restrict__ g, int64_t n, double* __restrict__ acc) {
+// every trainable tensor in one launch (blockIdx.y = tensor): the small ones would otherwise cost a launch each
+constexpr int TR_MAX_PARAMS = 12;
+struct TrainTensors {
+  float* p[TR_MAX_PARAMS];
+  float* g[TR_MAX_PARAMS];
+  float* m[TR_MAX_PARAMS];
+  float* v[TR_MAX_PARAMS];
+  float* vh[TR_MAX_PARAMS];
+  int64_t n[TR_MAX_PARAMS];
+};
+
+__global__ __launch_bounds__(256) void k_tr_sumsq(TrainTensors tt, double* __restrict__ acc) {
   __shared__ double part[256];
+  const float* g = tt.g[blockIdx.y];
+  const int64_t n = tt.n[blockIdx.y];
   double a = 0;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) a += (double)g[i] * g[i];
   part[threadIdx.x] = a;
@@ -510,24 +526,28 @@ __global__ __launch_bounds__(256) void k_tr_sumsq(const float* __restrict__ g, i
     if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) atomicAdd(acc, part[0]);
+  if (threadIdx.x == 0 && part[0] != 0.0) atomicAdd(acc, part[0]);
 }
 
-// tf.clip_by_global_norm + AMSGrad (amsgrad.py:130-159), all in one pass over the parameter
-__global__ __launch_bounds__(256) void k_tr_amsgrad(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                    float* __restrict__ v, float* __restrict__ vh, int64_t n,
-                                                    const double* __restrict__ sumsq, float clip, float lr_t, float b1, float b2,
-                                                    float eps) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
+// tf.clip_by_global_norm + AMSGrad (amsgrad.py:130-159), all in one pass over the parameters
+__global__ __launch_bounds__(256) void k_tr_amsgrad(TrainTensors tt, const double* __restrict__ sumsq, float clip, float lr_t,
+                                                    float b1, float b2, float eps) {
+  float* p = tt.p[blockIdx.y];
+  const float* g = tt.g[blockIdx.y];
+  float* m = tt.m[blockIdx.y];
+  float* v = tt.v[blockIdx.y];
+  float* vh = tt.vh[blockIdx.y];
+  const int64_t n = tt.n[blockIdx.y];
   const double gn = sqrt(*sumsq);
   const float scale = (float)((double)clip / (gn > (double)clip ? gn : (double)clip));
-  const float gi = g[i] * scale;
-  const float mi = b1 * m[i] + (1.f - b1) * gi;
-  const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-  const float vhi = fmaxf(vh[i], vi);
-  m[i] = mi; v[i] = vi; vh[i] = vhi;
-  p[i] -= lr_t * mi / (sqrtf(vhi) + eps);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float gi = g[i] * scale;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    const float vhi = fmaxf(vh[i], vi);
+    m[i] = mi; v[i] = vi; vh[i] = vhi;
+    p[i] -= lr_t * mi / (sqrtf(vhi) + eps);
+  }
 }
 
 __global__ void k_tr_store_loss(const double* __restrict__ acc, double inv_BL, float* __restrict__ out) { out[0] = (float)(acc[0] * inv_BL); }
@@ -586,6 +606,7 @@ COPER_API int coper_train_init(coper_handle* h, const coper_train_config* cfg) {
                                     "Conv1BN/beta", "FCBN/gamma", "FCBN/beta"};
   if (dm.gen_fc) { names.push_back("fc_weights/CPG/Projection0"); names.push_back("fc_bias/CPG/Projection0"); }
   else { names.push_back("fc_weights"); names.push_back("fc_bias"); }
+  if ((int)names.size() > TR_MAX_PARAMS) return fail(h, COPER_EUNSUPPORTED, "coper_train_init: too many trainable tensors");
   for (auto& nm : names) {
     auto it = h->params.find(nm);
     if (it == h->params.end() || !it->second.set) return fail(h, COPER_EINVAL, "coper_train_init: missing parameter " + nm);
@@ -613,7 +634,8 @@ COPER_API int coper_train_init(coper_handle* h, const coper_train_config* cfg) {
   rb.destroy = (rb_destroy_t)dlsym(rb.lib, "rocblas_destroy_handle");
   rb.set_stream = (rb_set_stream_t)dlsym(rb.lib, "rocblas_set_stream");
   rb.sgemm = (rb_sgemm_t)dlsym(rb.lib, "rocblas_sgemm");
-  if (!rb.create || !rb.destroy || !rb.set_stream || !rb.sgemm) return fail(h, COPER_EUNSUPPORTED, "coper_train_init: rocBLAS symbols missing");
+  rb.sgemm_sb = (rb_sgemm_sb_t)dlsym(rb.lib, "rocblas_sgemm_strided_batched");
+  if (!rb.create || !rb.destroy || !rb.set_stream || !rb.sgemm || !rb.sgemm_sb) return fail(h, COPER_EUNSUPPORTED, "coper_train_init: rocBLAS symbols missing");
   int rc;
   if ((rc = rb_check(h, rb.create(&rb.handle), "rocblas_create_handle"))) return rc;
   int mx = dm.C > dm.d ? dm.C : dm.d;
@@ -648,7 +670,7 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
         (rc = talloc(h, &T->hv, (size_t)cb * d)) || (rc = talloc(h, &T->dh, (size_t)cb * d)) ||
         (rc = talloc(h, &T->dz, (size_t)cb * d)) || (rc = talloc(h, &T->ds, (size_t)cb * cl)))
       return rc;
-    if (dm.gen_fc && ((rc = talloc(h, &T->A, (size_t)cb * r * F)) || (rc = talloc(h, &T->dA, (size_t)cb * r * F)))) return rc;
+    if (dm.gen_fc && ((rc = talloc(h, &T->A, (size_t)2 * r * cb * d)) || (rc = talloc(h, &T->dA, (size_t)cb * r * F)))) return rc;
     T->capB = cb; T->capL = cl;
   }
   auto P_ = [&](const char* n) -> float* { return T->find(n)->p; };
@@ -685,19 +707,24 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
                      const_cast<float*>(h->params["Conv1BN/moving_variance"].ptr), mean1, inv1);
   hipLaunchKernelGGL(k_tr_bn1_fwd, dim3((unsigned)((nBF + 255) / 256)), dim3(256), 0, s, T->y, mean1, inv1, P_("Conv1BN/gamma"),
                      P_("Conv1BN/beta"), C, nBF, tc.seed, step, thr_h, ks_h, T->x);
-  const int64_t Kd = dm.gen_fc ? (int64_t)r * F : F;           // inner size of the dense GEMMs
-  const float* Amat = T->x;
+  const int64_t Kd = dm.gen_fc ? (int64_t)r * F : F;           // inner size of the dA GEMM
   const float* Wmat = dm.gen_fc ? P_("fc_weights/CPG/Projection0") : P_("fc_weights");   // row-major [Kd, d]
-  if (dm.gen_fc) {
-    hipLaunchKernelGGL(k_tr_outer, dim3((unsigned)((F + 255) / 256), (unsigned)B), dim3(256), 0, s, T->x, T->c, F, r, T->A);
-    Amat = T->A;
-  }
-  // z0[B,d] = A[B,Kd] W[Kd,d]   (row-major operands seen as column-major transposes)
-  if ((rc = rb_check(h, T->rb.sgemm(T->rb.handle, RB_N, RB_N, d, (int)B, (int)Kd, &one, Wmat, d, Amat, (int)Kd, &zero, T->z0, d),
-                     "sgemm forward")))
-    return rc;
   const int64_t nBd = B * d;
-  hipLaunchKernelGGL(k_tr_fc_post, dim3((unsigned)((nBd + 255) / 256)), dim3(256), 0, s, T->z0, dm.gen_fc ? nullptr : P_("fc_bias"),
+  float* Tf = T->A;                 // T[rho][b][k]
+  float* dTf = T->A + (size_t)r * nBd;
+  if (dm.gen_fc) {
+    // T[rho] = x P[rho]: r independent [B,F]x[F,d] products fill the chip (a single GEMM over K = r*F has 8 tiles)
+    if ((rc = rb_check(h, T->rb.sgemm_sb(T->rb.handle, RB_N, RB_N, d, (int)B, (int)F, &one, Wmat, d, F * (int64_t)d, T->x, (int)F, 0, &zero,
+                                          Tf, d, nBd, r),
+                       "sgemm_strided_batched forward")))
+      return rc;
+  } else {
+    // z0[B,d] = x[B,F] W[F,d]   (row-major operands seen as column-major transposes)
+    if ((rc = rb_check(h, T->rb.sgemm(T->rb.handle, RB_N, RB_N, d, (int)B, (int)F, &one, Wmat, d, T->x, (int)F, &zero, T->z0, d),
+                       "sgemm forward")))
+      return rc;
+  }
+  hipLaunchKernelGGL(k_tr_fc_post, dim3((unsigned)((nBd + 255) / 256)), dim3(256), 0, s, dm.gen_fc ? Tf : T->z0, dm.gen_fc ? nullptr : P_("fc_bias"),
                      T->c, dm.gen_fc ? P_("fc_bias/CPG/Projection0") : nullptr, r, d, nBd, tc.seed, step, thr_o, ks_o, T->z1);
   COPER_HIP_TRY(h, hipMemsetAsync(colsum, 0, sizeof(double) * 2 * mx, s));
   if (use_batch) hipLaunchKernelGGL(k_tr_col_sums, dim3(16), dim3(256), 0, s, T->z1, B, d, colsum);
@@ -721,9 +748,18 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
                      dm.gen_fc ? P_("fc_bias/CPG/Projection0") : nullptr, r, d, tc.seed, step, thr_o, ks_o,
                      dm.gen_fc ? nullptr : G_("fc_bias"), dm.gen_fc ? G_("fc_bias/CPG/Projection0") : nullptr, T->dc);
   float* dW = dm.gen_fc ? G_("fc_weights/CPG/Projection0") : G_("fc_weights");
-  // dW[Kd,d] = A^T dz
-  if ((rc = rb_check(h, T->rb.sgemm(T->rb.handle, RB_N, RB_T, d, (int)Kd, (int)B, &one, T->dz, d, Amat, (int)Kd, &zero, dW, d), "sgemm dW")))
-    return rc;
+  if (dm.gen_fc) {
+    // dP[rho] = x^T dT[rho],  dT[rho][b,:] = c[b,rho] dz[b,:]
+    hipLaunchKernelGGL(k_tr_scale_rows, dim3((unsigned)((nBd + 255) / 256)), dim3(256), 0, s, T->dz, T->c, r, d, nBd, dTf);
+    if ((rc = rb_check(h, T->rb.sgemm_sb(T->rb.handle, RB_N, RB_T, d, (int)F, (int)B, &one, dTf, d, nBd, T->x, (int)F, 0, &zero, dW, d,
+                                          F * (int64_t)d, r),
+                       "sgemm_strided_batched dP")))
+      return rc;
+  } else {
+    // dW[F,d] = x^T dz
+    if ((rc = rb_check(h, T->rb.sgemm(T->rb.handle, RB_N, RB_T, d, (int)F, (int)B, &one, T->dz, d, T->x, (int)F, &zero, dW, d), "sgemm dW")))
+      return rc;
+  }
   // dA[B,Kd] = dz W^T
   float* dAmat = dm.gen_fc ? T->dA : T->dx;
   if ((rc = rb_check(h, T->rb.sgemm(T->rb.handle, RB_T, RB_N, (int)Kd, (int)B, d, &one, Wmat, d, T->dz, d, &zero, dAmat, (int)Kd), "sgemm dA")))
@@ -731,7 +767,7 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
   if (dm.gen_fc)
     hipLaunchKernelGGL(k_tr_outer_bwd, dim3((unsigned)((F + 255) / 256), (unsigned)B), dim3(256), 0, s, T->dA, T->x, T->c, F, r, T->dx, T->dc);
   COPER_HIP_TRY(h, hipMemsetAsync(colsum, 0, sizeof(double) * 2 * mx, s));
-  hipLaunchKernelGGL(k_tr_bn1_bwd_sums, dim3((unsigned)((nBF + 255) / 256)), dim3(256), 0, s, T->dx, T->y, mean1, inv1, P_("Conv1BN/gamma"),
+  hipLaunchKernelGGL(k_tr_bn1_bwd_sums, dim3((unsigned)((nBF + 255) / 256 < 1024 ? (nBF + 255) / 256 : 1024)), dim3(256), 0, s, T->dx, T->y, mean1, inv1, P_("Conv1BN/gamma"),
                      P_("Conv1BN/beta"), C, nBF, tc.seed, step, thr_h, ks_h, colsum);
   hipLaunchKernelGGL(k_tr_bn1_bwd_apply, dim3((unsigned)((nBF + 255) / 256)), dim3(256), 0, s, T->dx, T->y, mean1, inv1, P_("Conv1BN/gamma"),
                      colsum, C, nBF, (double)B * P, use_batch, G_("Conv1BN/gamma"), G_("Conv1BN/beta"));
@@ -744,15 +780,16 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
     hipLaunchKernelGGL(k_tr_scatter_rows, dim3((unsigned)((B * r + 255) / 256)), dim3(256), 0, s, T->dc, rel, dm.R, r, B * r, G_("rel_emb"));
 
   // ---- clip + AMSGrad
-  for (auto& t : T->tp) {
-    int64_t nb = (t.n + 255) / 256;
-    if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(k_tr_sumsq, dim3((unsigned)nb), dim3(256), 0, s, t.g, t.n, red + 1);
+  TrainTensors tt;
+  int np = (int)T->tp.size();
+  for (int i = 0; i < np; ++i) {
+    tt.p[i] = T->tp[i].p; tt.g[i] = T->tp[i].g; tt.m[i] = T->tp[i].m; tt.v[i] = T->tp[i].v; tt.vh[i] = T->tp[i].vh;
+    tt.n[i] = T->tp[i].n;
   }
+  hipLaunchKernelGGL(k_tr_sumsq, dim3(512, (unsigned)np), dim3(256), 0, s, tt, red + 1);
   const float lr_t = (float)((double)tc.learning_rate * std::sqrt(1.0 - T->b2p) / (1.0 - T->b1p));
-  for (auto& t : T->tp)
-    hipLaunchKernelGGL(k_tr_amsgrad, dim3((unsigned)((t.n + 255) / 256)), dim3(256), 0, s, t.p, t.g, t.m, t.v, t.vh, t.n, red + 1,
-                       tc.clip_norm, lr_t, tc.beta1, tc.beta2, tc.epsilon);
+  hipLaunchKernelGGL(k_tr_amsgrad, dim3(2048, (unsigned)np), dim3(256), 0, s, tt, red + 1, tc.clip_norm, lr_t, tc.beta1, tc.beta2,
+                     tc.epsilon);
   COPER_HIP_TRY(h, hipGetLastError());
   T->b1p *= tc.beta1;
   T->b2p *= tc.beta2;

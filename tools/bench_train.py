@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Training-step timing: `python tools/bench_train.py [workload] [B] [L]`.
+One step = one batch of B (e1, rel) queries scored against L sampled entities: forward, backward, clip, AMSGrad."""
+import json, os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np, torch
+from coper_amd import data as cdata
+from coper_amd.models import ConvE
+name = sys.argv[1] if len(sys.argv) > 1 else "fb15k237_cpg"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+L = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
+md = cdata.model_descriptors(name)
+md.update(batch_norm_train_stats=True, batch_norm_momentum=0.1, hidden_dropout=0.3, output_dropout=0.2,
+          label_smoothing_epsilon=0.1, learning_rate=1e-3)
+p = cdata.synthetic_params(md, 0)
+m = ConvE(md, device="cuda:0").load_parameters(p)
+m.train_init(seed=1)
+rng = np.random.default_rng(0)
+def batch():
+    lk = rng.integers(0, md["num_ent"], (B, L)).astype(np.int32)
+    lab = (rng.random((B, L)) < 0.01).astype(np.float32)
+    return dict(e1=torch.as_tensor(rng.integers(0, md["num_ent"], B)).cuda(), rel=torch.as_tensor(rng.integers(0, md["num_rel"], B)).cuda(),
+                lookup_values=torch.as_tensor(lk).cuda(), e2_multi=torch.as_tensor(lab).cuda())
+bs = [batch() for _ in range(4)]
+for i in range(3):
+    loss = m.train_step(bs[i % 4])
+torch.cuda.synchronize()
+K = 20
+t0 = time.perf_counter()
+for i in range(K):
+    loss = m.train_step(bs[i % 4])
+torch.cuda.synchronize()
+ms = (time.perf_counter() - t0) * 1e3 / K
+print(json.dumps({"metric": "training step", "workload": name, "B": B, "L": L, "ms_per_step": ms, "queries_per_s": B / ms * 1e3,
+                  "scored_pairs_per_s": B * L / ms * 1e3, "loss": float(loss.cpu()[0])}))
