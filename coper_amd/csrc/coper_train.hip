@@ -68,6 +68,8 @@ struct TrainState {
   int64_t capB = 0, capL = 0;
   // workspaces
   float *img = nullptr, *y = nullptr, *x = nullptr, *c = nullptr, *dA = nullptr;
+  float* Sd = nullptr;       // [B, |E|] dense d(loss)/d(logits) when it fits (scorer backward by GEMM)
+  int64_t capS = 0;
   float* A = nullptr;        // generated dense: T[r][B][d] (forward partials) | dT[r][B][d]
   float *z0 = nullptr, *z1 = nullptr, *hv = nullptr, *dh = nullptr, *dz = nullptr, *ds = nullptr, *dx = nullptr, *dc = nullptr;
   double* red = nullptr;     // reduction scratch: [0] loss, [1] grad sumsq, [2..] BN sums
@@ -266,7 +268,9 @@ __global__ __launch_bounds__(256) void k_tr_score_loss(const float* __restrict__
 // ------------------------------------------------------------------------------------------------
 // backward kernels
 // ------------------------------------------------------------------------------------------------
-// dh[b,k] = sum_l ds[b,l] E[lookup[b,l], k];  dE[lookup, k] += ds h[b,k];  dbias[lookup] += ds
+// dh[b,k] = sum_l ds[b,l] E[lookup[b,l], k];  SCATTER: also dE[lookup, k] += ds h[b,k], dbias[lookup] += ds by
+// float atomics (the route for entity tables too large for the dense S matrix below)
+template <bool SCATTER>
 __global__ __launch_bounds__(256) void k_tr_score_bwd(const float* __restrict__ hv, const float* __restrict__ ent,
                                                       const int32_t* __restrict__ lookup, const float* __restrict__ ds,
                                                       int64_t E, int d, int64_t L, float* __restrict__ dh,
@@ -281,11 +285,24 @@ __global__ __launch_bounds__(256) void k_tr_score_bwd(const float* __restrict__ 
     const float g = ds[b * L + l];
     if (k < d) {
       acc = fmaf(g, ent[row * d + k], acc);
-      atomicAdd(&dE[row * d + k], g * hk);
+      if (SCATTER) atomicAdd(&dE[row * d + k], g * hk);
     }
-    if (k == 0) atomicAdd(&dbias[row], g);
+    if (SCATTER && k == 0) atomicAdd(&dbias[row], g);
   }
   if (k < d) dh[b * d + k] = acc;
+}
+
+// dense route of the scorer backward (small entity tables): S[b, lookup[b,l]] += ds[b,l], dbias[lookup] += ds;
+// then dE = S^T h and dh = S E are two library GEMMs instead of B*L*d float atomics
+__global__ __launch_bounds__(256) void k_tr_scatter_ds(const int32_t* __restrict__ lookup, const float* __restrict__ ds, int64_t E,
+                                                       int64_t L, int64_t total, float* __restrict__ S, float* __restrict__ dbias) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  int64_t row = lookup[i];
+  if (row < 0 || row >= E) row = 0;
+  const float g = ds[i];
+  atomicAdd(&S[(i / L) * E + row], g);
+  atomicAdd(&dbias[row], g);
 }
 
 // FCBN backward, one workgroup per feature k (a column of [B, d]): gamma/beta gradients and dz1
@@ -563,7 +580,7 @@ void train_destroy(coper_handle* h) {
   TrainState* T = (TrainState*)h->train;
   if (!T) return;
   for (auto& t : T->tp) { (void)hipFree(t.g); (void)hipFree(t.m); (void)hipFree(t.v); (void)hipFree(t.vh); }
-  float* bufs[] = {T->img, T->y, T->x, T->c, T->A, T->dA, T->z0, T->z1, T->hv, T->dh, T->dz, T->ds, T->dx, T->dc, T->bnst};
+  float* bufs[] = {T->Sd, T->img, T->y, T->x, T->c, T->A, T->dA, T->z0, T->z1, T->hv, T->dh, T->dz, T->ds, T->dx, T->dc, T->bnst};
   for (float* b : bufs) (void)hipFree(b);
   (void)hipFree(T->red);
   if (T->rb.handle && T->rb.destroy) (void)T->rb.destroy(T->rb.handle);
@@ -739,8 +756,27 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
   if (loss_out) hipLaunchKernelGGL(k_tr_store_loss, dim3(1), dim3(1), 0, s, red, 1.0 / ((double)B * (double)L), loss_out);
 
   // ---- backward
-  hipLaunchKernelGGL(k_tr_score_bwd, dim3((unsigned)B), dim3(256), 0, s, T->hv, ent, lookup, T->ds, dm.E, d, L, T->dh, G_("ent_emb"),
-                     G_("pred_bias"));
+  const bool dense_scorer_bwd = (double)B * (double)dm.E * 4.0 <= 512.0 * 1024 * 1024 && dm.E <= 0x7fffffff;
+  if (dense_scorer_bwd) {
+    if (B * dm.E > T->capS) {
+      COPER_HIP_TRY(h, hipStreamSynchronize(s));
+      if ((rc = talloc(h, &T->Sd, (size_t)(B * dm.E)))) return rc;
+      T->capS = B * dm.E;
+    }
+    COPER_HIP_TRY(h, hipMemsetAsync(T->Sd, 0, sizeof(float) * B * dm.E, s));
+    hipLaunchKernelGGL(k_tr_scatter_ds, dim3((unsigned)((B * L + 255) / 256)), dim3(256), 0, s, lookup, T->ds, dm.E, L, B * L, T->Sd,
+                       G_("pred_bias"));
+    // dE[E,d] = S^T h  (overwrites the zeroed gradient; the e1-row contributions are added after it)
+    if ((rc = rb_check(h, T->rb.sgemm(T->rb.handle, RB_N, RB_T, d, (int)dm.E, (int)B, &one, T->hv, d, T->Sd, (int)dm.E, &zero, G_("ent_emb"), d),
+                       "sgemm dE")))
+      return rc;
+    // dh by the gather (a [d,B] = [d,|E|] x [|E|,B] GEMM has 8 output tiles and a long K: slower than the gather)
+    hipLaunchKernelGGL(k_tr_score_bwd<false>, dim3((unsigned)B), dim3(256), 0, s, T->hv, ent, lookup, T->ds, dm.E, d, L, T->dh, nullptr,
+                       nullptr);
+  } else {
+    hipLaunchKernelGGL(k_tr_score_bwd<true>, dim3((unsigned)B), dim3(256), 0, s, T->hv, ent, lookup, T->ds, dm.E, d, L, T->dh, G_("ent_emb"),
+                       G_("pred_bias"));
+  }
   hipLaunchKernelGGL(k_tr_fcbn_bwd, dim3((unsigned)d), dim3(256), 0, s, T->z1, T->hv, T->dh, mean2, inv2, P_("FCBN/gamma"), B, d, use_batch,
                      G_("FCBN/gamma"), G_("FCBN/beta"), T->dz);
   if (dm.gen_fc) COPER_HIP_TRY(h, hipMemsetAsync(T->dc, 0, sizeof(float) * B * r, s));
