@@ -291,3 +291,80 @@ class EvalDataset(object):
             if self.dense_mask:
                 batch["e2_multi"] = csr_to_dense_filter(batch["filt_indptr"], batch["filt_idx"], self.num_ent)
             yield batch
+
+
+class TrainDataset(object):
+    """Endless training-batch source in the reference batch contract (models.py:139-152): the mirror of
+    `train_dataset` (data.py:89-166) with its two samplers restated in NumPy.
+
+    `samples`: dict with `e1, rel` int64 [N] and the CSR list of ALL known tails of each (e1, rel) in the train
+    graph (`tail_indptr [N+1]`, `tail_idx`) -- what one TFRecord of the reference holds (data.py:574-594).
+
+    * one_positive_label_per_sample=True (the default, data.py:138-144 + :278-311): every (e1, rel, e2_i) becomes
+      its own row; lookup = [e2_i, a window of num_labels-1 consecutive entries of a fresh permutation of the
+      entities starting at a uniform offset]; labels = membership of the looked-up ids in the tail list (a sampled
+      "negative" that is a known tail is supervised as positive, as the reference comments).
+    * otherwise (data.py:228-277): positives shuffled, negatives a prefix of a permutation;
+      num_positives_needed = int(num_labels / (1 + prop_negatives)).
+    Rows pass through a shuffle buffer of 1000 (data.py:160) and are batched.  TF's RNG streams cannot be
+    reproduced: parity with the reference is distributional (tests check the construction rules)."""
+
+    def __init__(self, samples, num_ent, batch_size, num_labels=100, one_positive_label_per_sample=True,
+                 prop_negatives=10.0, seed=0, shuffle_buffer=1000):
+        self.s, self.num_ent, self.batch_size = samples, int(num_ent), int(batch_size)
+        self.num_labels, self.one_pos, self.prop = int(num_labels), bool(one_positive_label_per_sample), float(prop_negatives)
+        self.shuffle_buffer = int(shuffle_buffer)
+        self.rng = np.random.default_rng(seed)
+        if self.num_labels > self.num_ent:
+            raise ValueError("num_labels needs to be at most the total number of entities (data.py:146-147)")
+
+    # one TFRecord -> rows (lookup [k, L], labels [k, L], e1, rel, e2)
+    def _rows_one_positive(self, i):
+        s, L, E = self.s, self.num_labels, self.num_ent
+        tails = s["tail_idx"][s["tail_indptr"][i]:s["tail_indptr"][i + 1]]
+        k = len(tails)
+        perm = self.rng.permutation(E)
+        start = self.rng.integers(0, E - (L - 1), size=k) if E - (L - 1) > 0 else np.zeros(k, np.int64)
+        neg = perm[start[:, None] + np.arange(L - 1)[None, :]]
+        lookup = np.concatenate([tails[:, None], neg], axis=1)
+        member = np.zeros(E, np.float32)
+        member[tails] = 1.0
+        return lookup, member[lookup], np.full(k, s["e1"][i]), np.full(k, s["rel"][i]), tails
+
+    def _row_prop_negatives(self, i):
+        s, L, E = self.s, self.num_labels, self.num_ent
+        tails = self.rng.permutation(s["tail_idx"][s["tail_indptr"][i]:s["tail_indptr"][i + 1]])
+        wrong = self.rng.permutation(E)
+        need = int(1.0 / (1.0 + self.prop) * L)
+        if len(tails) <= need:
+            idx = np.concatenate([tails, wrong[:L - len(tails)]])
+        else:
+            n_neg = min(E, L - need)
+            idx = np.concatenate([tails[:L - n_neg], wrong[:n_neg]])
+        member = np.zeros(E, np.float32)
+        member[tails] = 1.0
+        e2 = tails[0] if len(tails) else -1
+        return idx[None, :], member[idx][None, :], np.array([s["e1"][i]]), np.array([s["rel"][i]]), np.array([e2])
+
+    def __iter__(self) -> Iterator[dict]:
+        N = len(self.s["e1"])
+        buf = []          # shuffle buffer of rows
+        order = np.arange(N)
+        pos = 0
+        while True:
+            while len(buf) < self.shuffle_buffer + self.batch_size:
+                i = order[pos % N]
+                pos += 1                                   # .repeat(): the record stream wraps around
+                lk, lab, e1, rel, e2 = self._rows_one_positive(i) if self.one_pos else self._row_prop_negatives(i)
+                for j in range(len(e1)):
+                    buf.append((lk[j], lab[j], e1[j], rel[j], e2[j]))
+            take = []
+            for _ in range(self.batch_size):
+                j = int(self.rng.integers(0, min(len(buf), self.shuffle_buffer)))
+                take.append(buf[j])
+                buf[j] = buf[-1]
+                buf.pop()
+            yield dict(e1=np.array([t[2] for t in take], np.int64), rel=np.array([t[3] for t in take], np.int64),
+                       e2=np.array([t[4] for t in take], np.int64),
+                       lookup_values=np.stack([t[0] for t in take]).astype(np.int32),
+                       e2_multi=np.stack([t[1] for t in take]).astype(np.float32))

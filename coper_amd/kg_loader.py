@@ -26,7 +26,7 @@ from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 
-from .data import EvalDataset
+from .data import EvalDataset, TrainDataset
 
 __all__ = ["TSVKGLoader"]
 
@@ -172,3 +172,30 @@ class TSVKGLoader(object):
         if self.num_ent is None:
             self.assign_ids()
         return EvalDataset(self.encoded_split(dataset_type, include_inv_relations), batch_size, self.num_ent, dense_mask)
+
+    # ---------------------------------------------------------------- data.py:89-166
+    def train_samples(self, include_inv_relations: bool = True):
+        """One record per (e1, rel) of the train graph with the list of all its train tails -- the content of the
+        reference's train TFRecords (`_graph_samples(..., labels=None)`, data.py:481-484)."""
+        if not self.entity_ids:
+            self.assign_ids()
+        E, Rm = self.entity_ids, self.relation_ids
+        e1, rel, indptr, idx = [], [], [0], []
+        for s in self._samples["train"]:
+            if not s["e2_multi"]:
+                continue
+            if s["rel"].endswith("_reverse") and not include_inv_relations:
+                continue
+            e1.append(E[s["e1"]]); rel.append(Rm[s["rel"]])
+            idx.extend(sorted(set(E[t] for t in s["e2_multi"] if t != "None")))
+            indptr.append(len(idx))
+        return dict(e1=np.asarray(e1, np.int64), rel=np.asarray(rel, np.int64), tail_indptr=np.asarray(indptr, np.int64),
+                    tail_idx=np.asarray(idx, np.int64))
+
+    def train_dataset(self, directory=None, batch_size=512, include_inv_relations=True, num_parallel_readers=None,
+                      num_parallel_batches=None, buffer_size=None, prefetch_buffer_size=None, prop_negatives=10.0,
+                      num_labels=100, cache=False, one_positive_label_per_sample=True, seed=0):
+        if num_labels is None:
+            raise NotImplementedError("1-vs-all training labels (num_labels=None, data.py:155-156) are not built")
+        return TrainDataset(self.train_samples(include_inv_relations), self.num_ent, batch_size, num_labels,
+                            one_positive_label_per_sample, prop_negatives, seed)

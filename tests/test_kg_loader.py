@@ -80,3 +80,51 @@ def test_ids_are_deterministic_without_id_files(golden_dir, tmp_path):
     a = TSVKGLoader(str(tmp_path)).assign_ids(write_files=True)
     b = TSVKGLoader(str(tmp_path)).assign_ids()            # now read back from the files
     assert a == b and list(a[0]) == sorted(a[0])
+
+
+def test_train_dataset_sampler_rules(tmp_path):
+    """TrainDataset restates data.py:228-311: row construction rules of both samplers."""
+    from coper_amd.data import TrainDataset
+    rng = np.random.default_rng(0)
+    E, N = 97, 40
+    indptr = [0]
+    idx = []
+    for i in range(N):
+        k = int(rng.integers(1, 9))
+        idx.extend(sorted(rng.choice(E, size=k, replace=False)))
+        indptr.append(len(idx))
+    s = dict(e1=rng.integers(0, E, N), rel=rng.integers(0, 6, N), tail_indptr=np.array(indptr), tail_idx=np.array(idx))
+    tails_of = {(int(s["e1"][i]), int(s["rel"][i])): set() for i in range(N)}
+    for i in range(N):
+        tails_of[(int(s["e1"][i]), int(s["rel"][i]))] |= set(idx[indptr[i]:indptr[i + 1]])
+    # one positive per row (the default)
+    ds = TrainDataset(s, E, batch_size=32, num_labels=20, seed=1)
+    it = iter(ds)
+    for _ in range(5):
+        b = next(it)
+        assert b["lookup_values"].shape == (32, 20) and b["lookup_values"].dtype == np.int32
+        assert b["e2_multi"].shape == (32, 20) and b["e2_multi"].dtype == np.float32
+        assert np.array_equal(b["lookup_values"][:, 0], b["e2"])            # the positive comes first (data.py:296)
+        assert (b["e2_multi"][:, 0] == 1.0).all()
+        for r in range(32):
+            # labels = membership in the record's tail list; negatives are a run of distinct entities
+            rec = [set(idx[indptr[i]:indptr[i + 1]]) for i in range(N)
+                   if s["e1"][i] == b["e1"][r] and s["rel"][i] == b["rel"][r] and int(b["e2"][r]) in idx[indptr[i]:indptr[i + 1]]]
+            assert any(np.array_equal(b["e2_multi"][r], np.array([float(v in t) for v in b["lookup_values"][r]], np.float32)) for t in rec)
+            assert len(set(b["lookup_values"][r, 1:].tolist())) == 19
+    # proportional sampler (data.py:228-277)
+    ds2 = TrainDataset(s, E, batch_size=16, num_labels=22, one_positive_label_per_sample=False, prop_negatives=10.0, seed=2)
+    b = next(iter(ds2))
+    need = int(1.0 / 11.0 * 22)
+    for r in range(16):
+        lab, lk = b["e2_multi"][r], b["lookup_values"][r]
+        recs = [idx[indptr[i]:indptr[i + 1]] for i in range(N) if s["e1"][i] == b["e1"][r] and s["rel"][i] == b["rel"][r]]
+        ok = False
+        for t in recs:
+            npos = len(t)
+            lead = npos if npos <= need else max(22 - min(E, 22 - need), 0)
+            if set(lk[:lead].tolist()) <= set(t) and np.array_equal(lab, np.array([float(v in t) for v in lk], np.float32)):
+                ok = True
+        assert ok
+    with pytest.raises(ValueError):
+        TrainDataset(s, E, 4, num_labels=E + 1)
