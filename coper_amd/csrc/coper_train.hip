@@ -305,6 +305,37 @@ __global__ __launch_bounds__(256) void k_tr_scatter_ds(const int32_t* __restrict
   atomicAdd(&dbias[row], g);
 }
 
+// 1-vs-all training (lookup == NULL, models.py:159-162,434-437): S holds the logits h E^T from a GEMM; add the bias,
+// accumulate the loss, overwrite with d(loss)/d(logit)
+__global__ __launch_bounds__(256) void k_tr_dense_loss(float* __restrict__ S, const float* __restrict__ pred_bias,
+                                                       const float* __restrict__ labels, int64_t E, int64_t total, float ls_eps,
+                                                       float inv_E, float inv_BL, double* __restrict__ loss_acc) {
+  __shared__ double part[256];
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const float s = S[i] + pred_bias[i % E];
+    const float t = (1.f - ls_eps) * labels[i] + inv_E;
+    acc += (double)(fmaxf(s, 0.f) - s * t + log1pf(expf(-fabsf(s))));
+    S[i] = (1.f / (1.f + expf(-s)) - t) * inv_BL;
+  }
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) atomicAdd(loss_acc, part[0]);
+}
+
+// out[c] = sum_b S[b, c]   (pred_bias gradient of the 1-vs-all route)
+__global__ __launch_bounds__(256) void k_tr_col_sum_f32(const float* __restrict__ S, int64_t rows, int64_t cols, float* __restrict__ out) {
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  float a = 0.f;
+  for (int64_t b = 0; b < rows; ++b) a += S[b * cols + c];
+  out[c] = a;
+}
+
 // FCBN backward, one workgroup per feature k (a column of [B, d]): gamma/beta gradients and dz1
 __global__ __launch_bounds__(256) void k_tr_fcbn_bwd(const float* __restrict__ z1, const float* __restrict__ hv,
                                                      const float* __restrict__ dh, const float* __restrict__ mean,
@@ -666,8 +697,12 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
   if (!h) return COPER_EINVAL;
   TrainState* T = (TrainState*)h->train;
   if (!T) return fail(h, COPER_ESTATE, "coper_train_step: call coper_train_init first");
-  if (!e1 || !rel || !lookup || !labels || B <= 0 || L <= 0 || B * L > 0x7fffffff)
+  if (!e1 || !rel || !labels || B <= 0 || L <= 0 || B * L > 0x7fffffff)
     return fail(h, COPER_EINVAL, "coper_train_step: bad argument");
+  const bool one_vs_all = lookup == nullptr;   // use_negative_sampling = False: labels are the dense e2_multi [B, |E|]
+  if (one_vs_all && L != h->dm.E) return fail(h, COPER_EINVAL, "coper_train_step: lookup == NULL needs labels of shape [B, num_ent]");
+  if (one_vs_all && (double)B * (double)h->dm.E * 4.0 > 512.0 * 1024 * 1024)
+    return fail(h, COPER_EUNSUPPORTED, "coper_train_step: 1-vs-all training needs B*num_ent*4 <= 512 MiB in this version");
   const Dims& dm = h->dm;
   hipStream_t s = (hipStream_t)stream;
   COPER_HIP_TRY(h, hipSetDevice(h->cfg.device));
@@ -677,15 +712,15 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
   const int64_t F = dm.F;
   if ((int64_t)B * F > 0xffffffffLL) return fail(h, COPER_EINVAL, "coper_train_step: batch too large for the dropout counter");
   int rc;
-  if (B > T->capB || L > T->capL) {
+  if (B > T->capB || (!one_vs_all && L > T->capL)) {
     COPER_HIP_TRY(h, hipStreamSynchronize(s));
-    int64_t cb = B > T->capB ? B : T->capB, cl = L > T->capL ? L : T->capL;
+    int64_t cb = B > T->capB ? B : T->capB, cl = (!one_vs_all && L > T->capL) ? L : (T->capL > 0 ? T->capL : 1);
     if ((rc = talloc(h, &T->img, (size_t)cb * isz)) || (rc = talloc(h, &T->y, (size_t)cb * F)) ||
         (rc = talloc(h, &T->x, (size_t)cb * F)) || (rc = talloc(h, &T->dx, (size_t)cb * F)) ||
         (rc = talloc(h, &T->c, (size_t)cb * r)) || (rc = talloc(h, &T->dc, (size_t)cb * r)) ||
         (rc = talloc(h, &T->z0, (size_t)cb * d)) || (rc = talloc(h, &T->z1, (size_t)cb * d)) ||
         (rc = talloc(h, &T->hv, (size_t)cb * d)) || (rc = talloc(h, &T->dh, (size_t)cb * d)) ||
-        (rc = talloc(h, &T->dz, (size_t)cb * d)) || (rc = talloc(h, &T->ds, (size_t)cb * cl)))
+        (rc = talloc(h, &T->dz, (size_t)cb * d)) || (rc = talloc(h, &T->ds, (size_t)cb * (one_vs_all ? 1 : cl))))
       return rc;
     if (dm.gen_fc && ((rc = talloc(h, &T->A, (size_t)2 * r * cb * d)) || (rc = talloc(h, &T->dA, (size_t)cb * r * F)))) return rc;
     T->capB = cb; T->capL = cl;
@@ -751,13 +786,35 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
   hipLaunchKernelGGL(k_tr_fcbn_fwd, dim3((unsigned)((nBd + 255) / 256)), dim3(256), 0, s, T->z1, mean2, inv2, P_("FCBN/gamma"),
                      P_("FCBN/beta"), d, nBd, T->hv);
   const float inv_BL = (float)(1.0 / ((double)B * (double)L));
-  hipLaunchKernelGGL(k_tr_score_loss, dim3((unsigned)B), dim3(256), sizeof(float) * d, s, T->hv, ent, P_("pred_bias"), lookup, labels,
-                     dm.E, d, L, tc.label_smoothing_epsilon, (float)(1.0 / (double)dm.E), inv_BL, T->ds, red);
+  if (one_vs_all) {
+    if (B * dm.E > T->capS) {
+      COPER_HIP_TRY(h, hipStreamSynchronize(s));
+      if ((rc = talloc(h, &T->Sd, (size_t)(B * dm.E)))) return rc;
+      T->capS = B * dm.E;
+    }
+    // S[B,E] = h E^T
+    if ((rc = rb_check(h, T->rb.sgemm(T->rb.handle, RB_T, RB_N, (int)dm.E, (int)B, d, &one, ent, d, T->hv, d, &zero, T->Sd, (int)dm.E),
+                       "sgemm logits")))
+      return rc;
+    hipLaunchKernelGGL(k_tr_dense_loss, dim3(2048), dim3(256), 0, s, T->Sd, P_("pred_bias"), labels, dm.E, B * dm.E,
+                       tc.label_smoothing_epsilon, (float)(1.0 / (double)dm.E), inv_BL, red);
+  } else {
+    hipLaunchKernelGGL(k_tr_score_loss, dim3((unsigned)B), dim3(256), sizeof(float) * d, s, T->hv, ent, P_("pred_bias"), lookup, labels,
+                       dm.E, d, L, tc.label_smoothing_epsilon, (float)(1.0 / (double)dm.E), inv_BL, T->ds, red);
+  }
   if (loss_out) hipLaunchKernelGGL(k_tr_store_loss, dim3(1), dim3(1), 0, s, red, 1.0 / ((double)B * (double)L), loss_out);
 
   // ---- backward
   const bool dense_scorer_bwd = (double)B * (double)dm.E * 4.0 <= 512.0 * 1024 * 1024 && dm.E <= 0x7fffffff;
-  if (dense_scorer_bwd) {
+  if (one_vs_all) {
+    hipLaunchKernelGGL(k_tr_col_sum_f32, dim3((unsigned)((dm.E + 255) / 256)), dim3(256), 0, s, T->Sd, B, dm.E, G_("pred_bias"));
+    if ((rc = rb_check(h, T->rb.sgemm(T->rb.handle, RB_N, RB_T, d, (int)dm.E, (int)B, &one, T->hv, d, T->Sd, (int)dm.E, &zero, G_("ent_emb"), d),
+                       "sgemm dE")))
+      return rc;
+    // dh[B,d] = S E
+    if ((rc = rb_check(h, T->rb.sgemm(T->rb.handle, RB_N, RB_N, d, (int)B, (int)dm.E, &one, ent, d, T->Sd, (int)dm.E, &zero, T->dh, d), "sgemm dh")))
+      return rc;
+  } else if (dense_scorer_bwd) {
     if (B * dm.E > T->capS) {
       COPER_HIP_TRY(h, hipStreamSynchronize(s));
       if ((rc = talloc(h, &T->Sd, (size_t)(B * dm.E)))) return rc;

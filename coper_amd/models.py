@@ -350,13 +350,15 @@ class ConvE(object):
         if getattr(self, "_train_loss", None) is None:
             raise _lib.CoperError(5, "call train_init() first")
         e1, rel = self._ids(batch["e1"]), self._ids(batch["rel"])
-        lookup = self._ids(batch["lookup_values"], torch.int32)
+        lv = batch.get("lookup_values", None)
+        one_vs_all = lv is None or (hasattr(lv, "shape") and len(lv.shape) == 2 and lv.shape[1] == 0)   # data.py:322
+        lookup = None if one_vs_all else self._ids(lv, torch.int32)
         labels = batch["e2_multi"]
         labels = (labels if isinstance(labels, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(labels)))
         labels = labels.to(device=self.device, dtype=torch.float32).contiguous()
-        B, L = lookup.shape
-        if tuple(labels.shape) != (B, L) or e1.numel() != B or rel.numel() != B:
-            raise ValueError("training batch: e1, rel [B]; lookup_values and e2_multi [B, L]")
+        B, L = labels.shape
+        if (lookup is not None and tuple(lookup.shape) != (B, L)) or e1.numel() != B or rel.numel() != B:
+            raise ValueError("training batch: e1, rel [B]; lookup_values and e2_multi [B, L] (or e2_multi [B, num_ent] alone)")
         with torch.cuda.device(self.device):
             _lib.check(self._h, self._lib.coper_train_step(self._h, _ptr(e1), _ptr(rel), _ptr(lookup), _ptr(labels), B, L,
                                                            _ptr(self._train_loss), self._stream()))

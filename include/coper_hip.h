@@ -214,7 +214,9 @@ typedef struct coper_train_config {
 COPER_API int coper_train_init(coper_handle* h, const coper_train_config* cfg);
 /* One optimisation step on a training batch in the reference batch contract (models.py:139-152):
  * e1, rel int64 [B]; lookup int32 [B,L] (obj_lookup_values); labels float [B,L] (e2_multi for the looked-up
- * entities).  loss_out: device float[1], the batch loss (models.py:448-453). */
+ * entities).  lookup == NULL with L == num_ent is 1-vs-all training (use_negative_sampling = False, run_cpg.py:116:
+ * labels are the dense e2_multi [B, num_ent], models.py:159-162).  loss_out: device float[1], the batch loss
+ * (models.py:448-453). */
 COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t* rel, const int32_t* lookup,
                                const float* labels, int64_t B, int64_t L, float* loss_out, void* stream);
 /* Diagnostics: copies the (unclipped) gradient of the last step for a trainable leaf into `out` (device float

@@ -62,7 +62,7 @@ def forward_train(p, md, batch, keep_hidden, keep_out, dtype=torch.float64):
     train_stats = bool(md.get("batch_norm_train_stats", False))
     e1 = torch.as_tensor(batch["e1"]).long()
     rel = torch.as_tensor(batch["rel"]).long()
-    lookup = torch.as_tensor(batch["lookup"]).long()
+    lookup = None if batch.get("lookup", None) is None else torch.as_tensor(batch["lookup"]).long()
     labels = torch.as_tensor(batch["labels"]).to(dtype)
     B = e1.shape[0]
     x0 = p["ent_emb"][e1]
@@ -109,7 +109,10 @@ def forward_train(p, md, batch, keep_hidden, keep_out, dtype=torch.float64):
         m2, v2 = p["FCBN/moving_mean"], p["FCBN/moving_variance"]
     z = (z - m2) / torch.sqrt(v2 + BN_EPS) * p["FCBN/gamma"] + p["FCBN/beta"]
     h = torch.relu(z)
-    s = torch.einsum("bk,blk->bl", h, p["ent_emb"][lookup]) + p["pred_bias"][lookup]   # models.py:439-443
+    if lookup is None:
+        s = h @ p["ent_emb"].T + p["pred_bias"]                                        # models.py:434-437
+    else:
+        s = torch.einsum("bk,blk->bl", h, p["ent_emb"][lookup]) + p["pred_bias"][lookup]   # models.py:439-443
     eps_ls = float(md.get("label_smoothing_epsilon", 0.0))
     t = (1.0 - eps_ls) * labels + 1.0 / float(md["num_ent"])               # models.py:450 (1/|E|, not eps/|E|)
     per = torch.clamp(s, min=0) - s * t + torch.log1p(torch.exp(-torch.abs(s)))
