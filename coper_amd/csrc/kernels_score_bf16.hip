@@ -104,6 +104,17 @@ constexpr int BX_WAVES = 8;
 #define COPER_BX_ME 2
 #endif
 constexpr int BX_ME = COPER_BX_ME;
+// ablation switches (tools/ab_build.py): fixed addresses instead of the streams, no compare epilogue
+#ifdef COPER_DBG_BX_NO_GLOADS
+#define BX_DBG_GL(x) (((x)*0) + m)
+#else
+#define BX_DBG_GL(x) (x)
+#endif
+#ifdef COPER_DBG_BX_NO_LDS
+#define BX_DBG_LDS(x) (((x)*0) + b)
+#else
+#define BX_DBG_LDS(x) (x)
+#endif
 static_assert(BX_WAVES * BX_ME <= EBLK_ALIGN, "entity blocks are padded to EBLK_ALIGN");
 
 __global__ void k_zero_counts(int64_t B, int32_t* __restrict__ ng, int32_t* __restrict__ ne) {
@@ -136,7 +147,7 @@ __global__ __launch_bounds__(512, 2) void k_score_count_bf16x3(const uint4* __re
 #define LOAD_A(ah, al, ebx, ks_)                                  \
   {                                                               \
     _Pragma("unroll") for (int m = 0; m < ME; ++m) {              \
-      int64_t o_ = (((ebx) + m) * KS + (ks_)) * 64 + lane;        \
+      int64_t o_ = BX_DBG_GL(((ebx) + m) * KS + (ks_)) * 64 + lane; \
       ah[m] = Ehi[o_];                                            \
       al[m] = Elo[o_];                                            \
     }                                                             \
@@ -144,8 +155,8 @@ __global__ __launch_bounds__(512, 2) void k_score_count_bf16x3(const uint4* __re
 #define LOAD_B(bh, bl, ks_)                                                   \
   {                                                                           \
     _Pragma("unroll") for (int b = 0; b < NQ; ++b) {                          \
-      bh[b] = hl_hi[(b * KS + (ks_)) * 64 + lane];                            \
-      bl[b] = hl_lo[(b * KS + (ks_)) * 64 + lane];                            \
+      bh[b] = hl_hi[BX_DBG_LDS(b * KS + (ks_)) * 64 + lane];                  \
+      bl[b] = hl_lo[BX_DBG_LDS(b * KS + (ks_)) * 64 + lane];                  \
     }                                                                         \
   }
 #define LOAD_BIAS(ebx)                                                                \
@@ -245,6 +256,12 @@ __global__ __launch_bounds__(512, 2) void k_score_count_bf16x3(const uint4* __re
       LOAD_A(ah[2], al[2], ebn, KCL(2));
       LOAD_BIAS(ebn);
     }
+#ifdef COPER_DBG_BX_NO_EPILOGUE
+#pragma unroll
+    for (int m = 0; m < ME; ++m)
+#pragma unroll
+      for (int b = 0; b < NQ; ++b) cg[b] += (acc[m][b][0] + acc[m][b][5] + acc[m][b][10] + acc[m][b][15] > t[b]) ? 1 : 0;
+#else
 #pragma unroll
     for (int m = 0; m < ME; ++m)
 #pragma unroll
@@ -255,6 +272,7 @@ __global__ __launch_bounds__(512, 2) void k_score_count_bf16x3(const uint4* __re
           cg[b] += (sc > t[b]) ? 1 : 0;
           if (EQ) ce[b] += (sc == t[b]) ? 1 : 0;
         }
+#endif
   }
 #undef KCL
   if (cur_tile >= 0) FLUSH_COUNTS();
