@@ -104,6 +104,16 @@ constexpr int BX_WAVES = 8;
 #define COPER_BX_ME 2
 #endif
 constexpr int BX_ME = COPER_BX_ME;
+#ifdef COPER_BX_NT
+typedef unsigned bx_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 bx_nt_load(const uint4* p) {
+  bx_u32x4 v = __builtin_nontemporal_load((const bx_u32x4*)p);
+  return make_uint4(v[0], v[1], v[2], v[3]);
+}
+#define BX_LOADQ(p) bx_nt_load(p)
+#else
+#define BX_LOADQ(p) (*(p))
+#endif
 // ablation switches (tools/ab_build.py): fixed addresses instead of the streams, no compare epilogue
 #ifdef COPER_DBG_BX_NO_GLOADS
 #define BX_DBG_GL(x) (((x)*0) + m)
@@ -148,8 +158,8 @@ __global__ __launch_bounds__(512, 2) void k_score_count_bf16x3(const uint4* __re
   {                                                               \
     _Pragma("unroll") for (int m = 0; m < ME; ++m) {              \
       int64_t o_ = BX_DBG_GL(((ebx) + m) * KS + (ks_)) * 64 + lane; \
-      ah[m] = Ehi[o_];                                            \
-      al[m] = Elo[o_];                                            \
+      ah[m] = BX_LOADQ(Ehi + o_);                                 \
+      al[m] = BX_LOADQ(Elo + o_);                                 \
     }                                                             \
   }
 #define LOAD_B(bh, bl, ks_)                                                   \
