@@ -54,7 +54,8 @@ class coper_train_config(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("learning_rate", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
                 ("epsilon", C.c_float), ("clip_norm", C.c_float), ("label_smoothing_epsilon", C.c_float),
                 ("hidden_dropout", C.c_float), ("output_dropout", C.c_float), ("batch_norm_momentum", C.c_float),
-                ("batch_norm_train_stats", C.c_int32), ("seed", C.c_uint32), ("reserved", C.c_int32 * 8)]
+                ("batch_norm_train_stats", C.c_int32), ("seed", C.c_uint32), ("context_rel_dropout", C.c_float),
+                ("reserved", C.c_int32 * 7)]
 
 
 # name -> (restype, argtypes): every symbol include/coper_hip.h declares

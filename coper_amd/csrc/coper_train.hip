@@ -68,6 +68,18 @@ struct TrainState {
   int64_t capB = 0, capL = 0;
   // workspaces
   float *img = nullptr, *y = nullptr, *x = nullptr, *c = nullptr, *dA = nullptr;
+  // g_MLP generator chains (models.py:56-70), one for fc_weights (0) and one for fc_bias (1):
+  //   v[0] = c;  u[i] = v[i] P_i;  a[i] = relu(BN_i(u[i]));  v[i+1] = dropout(a[i]);  context = v[nh]
+  struct Chain {
+    int dims[COPER_MAX_CTX + 1];
+    float* v[COPER_MAX_CTX + 1] = {};    // v[0] aliases TrainState::c
+    float* u[COPER_MAX_CTX] = {};
+    float* a[COPER_MAX_CTX] = {};
+    float* dv[COPER_MAX_CTX + 1] = {};   // gradient w.r.t. v[i]
+    float* du[COPER_MAX_CTX] = {};
+    float* st[COPER_MAX_CTX] = {};       // [2][n]: mean | inv_std
+  } chain[2];
+  int nh = 0;
   float* Sd = nullptr;       // [B, |E|] dense d(loss)/d(logits) when it fits (scorer backward by GEMM)
   int64_t capS = 0;
   float* A = nullptr;        // generated dense: T[r][B][d] (forward partials) | dT[r][B][d]
@@ -203,9 +215,9 @@ __global__ __launch_bounds__(256) void k_tr_bn1_fwd(const float* __restrict__ y,
 // z1 = keep * (z0 + bias_b) / (1 - rate).  Static: z0 from the GEMM, bias_b = fc_bias[k].  Generated:
 // z0[b,k] = sum_rho c[b,rho] T[rho][b,k] (T[rho] = x P[rho], the batched GEMM), bias_b = sum_rho c[b,rho] Pb[rho,k]
 __global__ __launch_bounds__(256) void k_tr_fc_post(const float* __restrict__ z0, const float* __restrict__ fc_bias,
-                                                    const float* __restrict__ c, const float* __restrict__ Pb, int r, int d,
-                                                    int64_t total, uint32_t seed, uint32_t step, uint32_t thr,
-                                                    float keep_scale, float* __restrict__ z1) {
+                                                    const float* __restrict__ cw, int rw, const float* __restrict__ cb,
+                                                    const float* __restrict__ Pb, int rb, int d, int64_t total, uint32_t seed,
+                                                    uint32_t step, uint32_t thr, float keep_scale, float* __restrict__ z1) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
   const int k = (int)(i % d);
@@ -213,7 +225,8 @@ __global__ __launch_bounds__(256) void k_tr_fc_post(const float* __restrict__ z0
   float v;
   if (Pb) {
     v = 0.f;
-    for (int rho = 0; rho < r; ++rho) v = fmaf(c[b * r + rho], z0[(int64_t)rho * total + i] + Pb[rho * d + k], v);
+    for (int rho = 0; rho < rw; ++rho) v = fmaf(cw[b * rw + rho], z0[(int64_t)rho * total + i], v);
+    for (int rho = 0; rho < rb; ++rho) v = fmaf(cb[b * rb + rho], Pb[rho * d + k], v);
   } else {
     v = z0[i] + fc_bias[k];
   }
@@ -336,14 +349,77 @@ __global__ __launch_bounds__(256) void k_tr_col_sum_f32(const float* __restrict_
   out[c] = a;
 }
 
+// ---- g_MLP generator chain pieces (small matrices: B <= a few thousand, widths <= a few hundred)
+// out[b,j] = sum_i in[b,i] P[i,j]
+__global__ __launch_bounds__(256) void k_tr_small_mm(const float* __restrict__ in, const float* __restrict__ P, int64_t B, int ni, int nj,
+                                                     float* __restrict__ out) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= B * nj) return;
+  const int64_t b = idx / nj;
+  const int j = (int)(idx % nj);
+  float a = 0.f;
+  for (int i = 0; i < ni; ++i) a = fmaf(in[b * ni + i], P[(int64_t)i * nj + j], a);
+  out[idx] = a;
+}
+// dv[b,i] (+)= sum_j du[b,j] P[i,j]
+__global__ __launch_bounds__(256) void k_tr_small_mm_nt(const float* __restrict__ du, const float* __restrict__ P, int64_t B, int ni, int nj,
+                                                        int accumulate, float* __restrict__ dv) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= B * ni) return;
+  const int64_t b = idx / ni;
+  const int i = (int)(idx % ni);
+  float a = accumulate ? dv[idx] : 0.f;
+  for (int j = 0; j < nj; ++j) a = fmaf(du[b * nj + j], P[(int64_t)i * nj + j], a);
+  dv[idx] = a;
+}
+// dP[i,j] = sum_b v[b,i] du[b,j]   (one thread per entry; B is small)
+__global__ __launch_bounds__(256) void k_tr_small_mm_tn(const float* __restrict__ v, const float* __restrict__ du, int64_t B, int ni, int nj,
+                                                        float* __restrict__ dP) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)ni * nj) return;
+  const int i = (int)(idx / nj), j = (int)(idx % nj);
+  float a = 0.f;
+  for (int64_t b = 0; b < B; ++b) a = fmaf(v[b * ni + i], du[b * nj + j], a);
+  dP[idx] = a;
+}
+// a = relu(BN(u)) (or relu(u) when the generator has no BN); v_next = dropout(a)
+__global__ __launch_bounds__(256) void k_tr_chain_act(const float* __restrict__ u, const float* __restrict__ st, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, int n, int64_t total, uint32_t seed, uint32_t step,
+                                                      uint32_t stage, uint32_t thr, float keep_scale, float* __restrict__ a,
+                                                      float* __restrict__ vnext) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int k = (int)(i % n);
+  float v = u[i];
+  if (gamma) v = (v - st[k]) * st[n + k] * gamma[k] + beta[k];
+  v = v > 0.f ? v : 0.f;
+  a[i] = v;
+  vnext[i] = dropout_keep_u32(seed, step, stage, (uint32_t)i, thr) ? v * keep_scale : 0.f;
+}
+// g = keep * dv_next / (1 - rate)   (dropout backward; the ReLU / BN part is k_tr_fcbn_bwd)
+__global__ __launch_bounds__(256) void k_tr_chain_drop_bwd(const float* __restrict__ dvn, int64_t total, uint32_t seed, uint32_t step,
+                                                           uint32_t stage, uint32_t thr, float keep_scale, float* __restrict__ g) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  g[i] = dropout_keep_u32(seed, step, stage, (uint32_t)i, thr) ? dvn[i] * keep_scale : 0.f;
+}
+__global__ __launch_bounds__(256) void k_tr_add(const float* __restrict__ a, int64_t n, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] += a[i];
+}
+
 // FCBN backward, one workgroup per feature k (a column of [B, d]): gamma/beta gradients and dz1
-__global__ __launch_bounds__(256) void k_tr_fcbn_bwd(const float* __restrict__ z1, const float* __restrict__ hv,
-                                                     const float* __restrict__ dh, const float* __restrict__ mean,
-                                                     const float* __restrict__ inv, const float* __restrict__ gamma, int64_t B,
-                                                     int d, int use_batch, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta, float* __restrict__ dz1) {
+// (dh and dz1 may be the same buffer: every element is read, then written, by one thread)
+__global__ __launch_bounds__(256) void k_tr_fcbn_bwd(const float* __restrict__ z1, const float* __restrict__ hv, const float* dh,
+                                                     const float* __restrict__ mean, const float* __restrict__ inv,
+                                                     const float* __restrict__ gamma, int64_t B, int d, int use_batch,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, float* dz1) {
   __shared__ double s1[256], s2[256];
   const int k = blockIdx.x;
+  if (!mean) {   // generator layer without BN: ReLU only
+    for (int64_t b = threadIdx.x; b < B; b += 256) dz1[b * d + k] = hv[b * d + k] > 0.f ? dh[b * d + k] : 0.f;
+    return;
+  }
   const float mu = mean[k], iv = inv[k], ga = gamma[k];
   double a1 = 0, a2 = 0;
   for (int64_t b = threadIdx.x; b < B; b += 256) {
@@ -552,7 +628,7 @@ __global__ __launch_bounds__(256) void k_tr_scatter_rows(const float* __restrict
 }
 
 // every trainable tensor in one launch (blockIdx.y = tensor): the small ones would otherwise cost a launch each
-constexpr int TR_MAX_PARAMS = 12;
+constexpr int TR_MAX_PARAMS = 40;
 struct TrainTensors {
   float* p[TR_MAX_PARAMS];
   float* g[TR_MAX_PARAMS];
@@ -613,6 +689,12 @@ void train_destroy(coper_handle* h) {
   for (auto& t : T->tp) { (void)hipFree(t.g); (void)hipFree(t.m); (void)hipFree(t.v); (void)hipFree(t.vh); }
   float* bufs[] = {T->Sd, T->img, T->y, T->x, T->c, T->A, T->dA, T->z0, T->z1, T->hv, T->dh, T->dz, T->ds, T->dx, T->dc, T->bnst};
   for (float* b : bufs) (void)hipFree(b);
+  for (auto& ch : T->chain)
+    for (int i = 0; i <= COPER_MAX_CTX; ++i) {
+      if (i > 0) (void)hipFree(ch.v[i]);
+      (void)hipFree(ch.dv[i]);
+      if (i < COPER_MAX_CTX) { (void)hipFree(ch.u[i]); (void)hipFree(ch.a[i]); (void)hipFree(ch.du[i]); (void)hipFree(ch.st[i]); }
+    }
   (void)hipFree(T->red);
   if (T->rb.handle && T->rb.destroy) (void)T->rb.destroy(T->rb.handle);
   if (T->rb.lib) dlclose(T->rb.lib);
@@ -630,10 +712,10 @@ COPER_API int coper_train_init(coper_handle* h, const coper_train_config* cfg) {
   if (!h || !cfg) return COPER_EINVAL;
   if (cfg->abi_version != COPER_ABI_VERSION) return fail(h, COPER_EINVAL, "coper_train_init: ABI version mismatch");
   const Dims& dm = h->dm;
-  if (dm.gen_conv || dm.lookup || dm.concat_rel || (dm.gen_fc && h->cfg.n_ctx_out != 0))
+  if (dm.gen_conv || dm.lookup || dm.concat_rel)
     return fail(h, COPER_EUNSUPPORTED,
-                "coper_train_init: this version trains static conv filters with a static or g_linear dense layer "
-                "(no generated conv, g_MLP, g_lookup or concat_rel)");
+                "coper_train_init: this version trains static conv filters with a static, g_linear or g_MLP dense layer "
+                "(no generated conv, g_lookup or concat_rel)");
   if (h->cfg.shard_lo != 0 || h->cfg.shard_hi != dm.E)
     return fail(h, COPER_EUNSUPPORTED, "coper_train_init: training needs the whole entity table on the handle");
   if (dm.fh != 3 || dm.fw != 3 || 256 % dm.C != 0 || dm.d > 256)
@@ -652,8 +734,21 @@ COPER_API int coper_train_init(coper_handle* h, const coper_train_config* cfg) {
   T->b2p = cfg->beta2;
   std::vector<std::string> names = {"ent_emb", "rel_emb", "conv1_weights", "conv1_bias", "pred_bias", "Conv1BN/gamma",
                                     "Conv1BN/beta", "FCBN/gamma", "FCBN/beta"};
-  if (dm.gen_fc) { names.push_back("fc_weights/CPG/Projection0"); names.push_back("fc_bias/CPG/Projection0"); }
-  else { names.push_back("fc_weights"); names.push_back("fc_bias"); }
+  T->nh = dm.gen_fc ? h->cfg.n_ctx_out : 0;
+  if (dm.gen_fc) {
+    for (const char* gname : {"fc_weights", "fc_bias"})
+      for (int i = 0; i <= T->nh; ++i) {
+        std::string pn = std::string(gname) + "/CPG/Projection" + std::to_string(i);
+        names.push_back(pn);
+        if (i < T->nh && dm.ctx_bn) { names.push_back(pn + "/BatchNorm/gamma"); names.push_back(pn + "/BatchNorm/beta"); }
+      }
+    for (int g = 0; g < 2; ++g) {
+      T->chain[g].dims[0] = dm.r;
+      for (int i = 0; i < T->nh; ++i) T->chain[g].dims[i + 1] = h->cfg.ctx_out[i];
+    }
+  } else {
+    names.push_back("fc_weights"); names.push_back("fc_bias");
+  }
   if ((int)names.size() > TR_MAX_PARAMS) return fail(h, COPER_EUNSUPPORTED, "coper_train_init: too many trainable tensors");
   for (auto& nm : names) {
     auto it = h->params.find(nm);
@@ -687,6 +782,7 @@ COPER_API int coper_train_init(coper_handle* h, const coper_train_config* cfg) {
   int rc;
   if ((rc = rb_check(h, rb.create(&rb.handle), "rocblas_create_handle"))) return rc;
   int mx = dm.C > dm.d ? dm.C : dm.d;
+  for (int i = 0; i < T->nh; ++i) mx = h->cfg.ctx_out[i] > mx ? h->cfg.ctx_out[i] : mx;
   if ((rc = talloc(h, &T->bnst, (size_t)4 * mx))) return rc;
   if ((rc = talloc(h, &T->red, (size_t)(2 + 2 * mx)))) return rc;
   return COPER_OK;
@@ -710,6 +806,9 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
   const coper_train_config& tc = T->cfg;
   const int d = dm.d, r = dm.r, C = dm.C, P = dm.Ho * dm.Wo, isz = dm.in_h * dm.in_w;
   const int64_t F = dm.F;
+  const int nh = T->nh;
+  const int rc_w = nh ? T->chain[0].dims[nh] : r;   // width of the context that multiplies the last projection
+  const int rc_b = nh ? T->chain[1].dims[nh] : r;
   if ((int64_t)B * F > 0xffffffffLL) return fail(h, COPER_EINVAL, "coper_train_step: batch too large for the dropout counter");
   int rc;
   if (B > T->capB || (!one_vs_all && L > T->capL)) {
@@ -722,7 +821,17 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
         (rc = talloc(h, &T->hv, (size_t)cb * d)) || (rc = talloc(h, &T->dh, (size_t)cb * d)) ||
         (rc = talloc(h, &T->dz, (size_t)cb * d)) || (rc = talloc(h, &T->ds, (size_t)cb * (one_vs_all ? 1 : cl))))
       return rc;
-    if (dm.gen_fc && ((rc = talloc(h, &T->A, (size_t)2 * r * cb * d)) || (rc = talloc(h, &T->dA, (size_t)cb * r * F)))) return rc;
+    if (dm.gen_fc && ((rc = talloc(h, &T->A, (size_t)2 * rc_w * cb * d)) || (rc = talloc(h, &T->dA, (size_t)cb * rc_w * F)))) return rc;
+    for (int g = 0; g < 2 && dm.gen_fc; ++g) {
+      TrainState::Chain& ch = T->chain[g];
+      for (int i = 0; i <= nh; ++i) {
+        if (i > 0 && (rc = talloc(h, &ch.v[i], (size_t)cb * ch.dims[i]))) return rc;
+        if ((rc = talloc(h, &ch.dv[i], (size_t)cb * ch.dims[i]))) return rc;
+        if (i < nh && ((rc = talloc(h, &ch.u[i], (size_t)cb * ch.dims[i + 1])) || (rc = talloc(h, &ch.a[i], (size_t)cb * ch.dims[i + 1])) ||
+                       (rc = talloc(h, &ch.du[i], (size_t)cb * ch.dims[i + 1])) || (rc = talloc(h, &ch.st[i], (size_t)2 * ch.dims[i + 1]))))
+          return rc;
+      }
+    }
     T->capB = cb; T->capL = cl;
   }
   auto P_ = [&](const char* n) -> float* { return T->find(n)->p; };
@@ -730,7 +839,8 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
   float* ent = P_("ent_emb");
   float* relp = P_("rel_emb");
   const int use_batch = tc.batch_norm_train_stats ? 1 : 0;
-  const int mx = C > d ? C : d;
+  int mx = C > d ? C : d;
+  for (int i = 0; i < nh; ++i) mx = h->cfg.ctx_out[i] > mx ? h->cfg.ctx_out[i] : mx;
   float *mean1 = T->bnst, *inv1 = T->bnst + mx, *mean2 = T->bnst + 2 * mx, *inv2 = T->bnst + 3 * mx;
   double* red = T->red;         // [0] loss, [1] sumsq, [2 .. 2+2mx) column sums
   double* colsum = red + 2;
@@ -744,7 +854,8 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
   COPER_HIP_TRY(h, hipMemsetAsync(red, 0, sizeof(double) * (2 + 2 * mx), s));
   const char* zeroed[] = {"ent_emb", "rel_emb", "conv1_weights", "conv1_bias", "pred_bias"};
   for (const char* nm : zeroed) COPER_HIP_TRY(h, hipMemsetAsync(G_(nm), 0, sizeof(float) * T->find(nm)->n, s));
-  if (dm.gen_fc) COPER_HIP_TRY(h, hipMemsetAsync(G_("fc_bias/CPG/Projection0"), 0, sizeof(float) * r * d, s));
+  const std::string wlast = "fc_weights/CPG/Projection" + std::to_string(nh), blast = "fc_bias/CPG/Projection" + std::to_string(nh);
+  if (dm.gen_fc) COPER_HIP_TRY(h, hipMemsetAsync(G_(blast.c_str()), 0, sizeof(float) * rc_b * d, s));
   else COPER_HIP_TRY(h, hipMemsetAsync(G_("fc_bias"), 0, sizeof(float) * d, s));
 
   // ---- forward
@@ -759,15 +870,43 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
                      const_cast<float*>(h->params["Conv1BN/moving_variance"].ptr), mean1, inv1);
   hipLaunchKernelGGL(k_tr_bn1_fwd, dim3((unsigned)((nBF + 255) / 256)), dim3(256), 0, s, T->y, mean1, inv1, P_("Conv1BN/gamma"),
                      P_("Conv1BN/beta"), C, nBF, tc.seed, step, thr_h, ks_h, T->x);
-  const int64_t Kd = dm.gen_fc ? (int64_t)r * F : F;           // inner size of the dA GEMM
-  const float* Wmat = dm.gen_fc ? P_("fc_weights/CPG/Projection0") : P_("fc_weights");   // row-major [Kd, d]
+  // ---- g_MLP generator chains: context rows c -> v[nh] (models.py:56-68); g_linear: the context is c itself
+  const uint32_t thr_c = dropout_threshold24(tc.context_rel_dropout);
+  const float ks_c = 1.f / (1.f - tc.context_rel_dropout);
+  for (int g = 0; g < 2 && nh > 0; ++g) {
+    TrainState::Chain& ch = T->chain[g];
+    ch.v[0] = T->c;
+    const char* gname = g == 0 ? "fc_weights" : "fc_bias";
+    for (int i = 0; i < nh; ++i) {
+      const int ni = ch.dims[i], nj = ch.dims[i + 1];
+      const std::string pn = std::string(gname) + "/CPG/Projection" + std::to_string(i);
+      const int64_t tot = B * nj;
+      hipLaunchKernelGGL(k_tr_small_mm, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, ch.v[i], P_(pn.c_str()), B, ni, nj, ch.u[i]);
+      const float *ga = nullptr, *be = nullptr;
+      if (dm.ctx_bn) {
+        COPER_HIP_TRY(h, hipMemsetAsync(colsum, 0, sizeof(double) * 2 * mx, s));
+        if (use_batch) hipLaunchKernelGGL(k_tr_col_sums, dim3(16), dim3(256), 0, s, ch.u[i], B, nj, colsum);
+        hipLaunchKernelGGL(k_tr_bn_finish, dim3((nj + 63) / 64), dim3(64), 0, s, colsum, nj, (double)B, use_batch, tc.batch_norm_momentum, 0,
+                           const_cast<float*>(h->params[pn + "/BatchNorm/moving_mean"].ptr),
+                           const_cast<float*>(h->params[pn + "/BatchNorm/moving_variance"].ptr), ch.st[i], ch.st[i] + nj);
+        ga = P_((pn + "/BatchNorm/gamma").c_str());
+        be = P_((pn + "/BatchNorm/beta").c_str());
+      }
+      hipLaunchKernelGGL(k_tr_chain_act, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, ch.u[i], ch.st[i], ga, be, nj, tot, tc.seed, step,
+                         (uint32_t)(16 + 8 * g + i), thr_c, ks_c, ch.a[i], ch.v[i + 1]);
+    }
+  }
+  const float* cw = nh ? T->chain[0].v[nh] : T->c;   // [B, rc_w]
+  const float* cbv = nh ? T->chain[1].v[nh] : T->c;  // [B, rc_b]
+  const int64_t Kd = dm.gen_fc ? (int64_t)rc_w * F : F;           // inner size of the dA GEMM
+  const float* Wmat = dm.gen_fc ? P_(wlast.c_str()) : P_("fc_weights");   // row-major [Kd, d]
   const int64_t nBd = B * d;
   float* Tf = T->A;                 // T[rho][b][k]
-  float* dTf = T->A + (size_t)r * nBd;
+  float* dTf = T->A + (size_t)rc_w * nBd;
   if (dm.gen_fc) {
     // T[rho] = x P[rho]: r independent [B,F]x[F,d] products fill the chip (a single GEMM over K = r*F has 8 tiles)
     if ((rc = rb_check(h, T->rb.sgemm_sb(T->rb.handle, RB_N, RB_N, d, (int)B, (int)F, &one, Wmat, d, F * (int64_t)d, T->x, (int)F, 0, &zero,
-                                          Tf, d, nBd, r),
+                                          Tf, d, nBd, rc_w),
                        "sgemm_strided_batched forward")))
       return rc;
   } else {
@@ -777,7 +916,7 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
       return rc;
   }
   hipLaunchKernelGGL(k_tr_fc_post, dim3((unsigned)((nBd + 255) / 256)), dim3(256), 0, s, dm.gen_fc ? Tf : T->z0, dm.gen_fc ? nullptr : P_("fc_bias"),
-                     T->c, dm.gen_fc ? P_("fc_bias/CPG/Projection0") : nullptr, r, d, nBd, tc.seed, step, thr_o, ks_o, T->z1);
+                     cw, rc_w, cbv, dm.gen_fc ? P_(blast.c_str()) : nullptr, rc_b, d, nBd, tc.seed, step, thr_o, ks_o, T->z1);
   COPER_HIP_TRY(h, hipMemsetAsync(colsum, 0, sizeof(double) * 2 * mx, s));
   if (use_batch) hipLaunchKernelGGL(k_tr_col_sums, dim3(16), dim3(256), 0, s, T->z1, B, d, colsum);
   hipLaunchKernelGGL(k_tr_bn_finish, dim3((d + 63) / 64), dim3(64), 0, s, colsum, d, (double)B, use_batch, tc.batch_norm_momentum, 0,
@@ -836,16 +975,19 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
   }
   hipLaunchKernelGGL(k_tr_fcbn_bwd, dim3((unsigned)d), dim3(256), 0, s, T->z1, T->hv, T->dh, mean2, inv2, P_("FCBN/gamma"), B, d, use_batch,
                      G_("FCBN/gamma"), G_("FCBN/beta"), T->dz);
-  if (dm.gen_fc) COPER_HIP_TRY(h, hipMemsetAsync(T->dc, 0, sizeof(float) * B * r, s));
-  hipLaunchKernelGGL(k_tr_fc_post_bwd, dim3((unsigned)B), dim3(256), sizeof(float) * d, s, T->dz, T->c,
-                     dm.gen_fc ? P_("fc_bias/CPG/Projection0") : nullptr, r, d, tc.seed, step, thr_o, ks_o,
-                     dm.gen_fc ? nullptr : G_("fc_bias"), dm.gen_fc ? G_("fc_bias/CPG/Projection0") : nullptr, T->dc);
-  float* dW = dm.gen_fc ? G_("fc_weights/CPG/Projection0") : G_("fc_weights");
+  // gradients of the two contexts: dcw [B, rc_w] (accumulated by k_tr_outer_bwd) and dcb [B, rc_b] (assigned)
+  float* dcw = dm.gen_fc ? T->chain[0].dv[nh] : nullptr;
+  float* dcb = dm.gen_fc ? T->chain[1].dv[nh] : nullptr;
+  if (dm.gen_fc) COPER_HIP_TRY(h, hipMemsetAsync(dcw, 0, sizeof(float) * B * rc_w, s));
+  hipLaunchKernelGGL(k_tr_fc_post_bwd, dim3((unsigned)B), dim3(256), sizeof(float) * d, s, T->dz, cbv,
+                     dm.gen_fc ? P_(blast.c_str()) : nullptr, rc_b, d, tc.seed, step, thr_o, ks_o,
+                     dm.gen_fc ? nullptr : G_("fc_bias"), dm.gen_fc ? G_(blast.c_str()) : nullptr, dcb);
+  float* dW = dm.gen_fc ? G_(wlast.c_str()) : G_("fc_weights");
   if (dm.gen_fc) {
-    // dP[rho] = x^T dT[rho],  dT[rho][b,:] = c[b,rho] dz[b,:]
-    hipLaunchKernelGGL(k_tr_scale_rows, dim3((unsigned)((nBd + 255) / 256)), dim3(256), 0, s, T->dz, T->c, r, d, nBd, dTf);
+    // dP[rho] = x^T dT[rho],  dT[rho][b,:] = cw[b,rho] dz[b,:]
+    hipLaunchKernelGGL(k_tr_scale_rows, dim3((unsigned)((nBd + 255) / 256)), dim3(256), 0, s, T->dz, cw, rc_w, d, nBd, dTf);
     if ((rc = rb_check(h, T->rb.sgemm_sb(T->rb.handle, RB_N, RB_T, d, (int)F, (int)B, &one, dTf, d, nBd, T->x, (int)F, 0, &zero, dW, d,
-                                          F * (int64_t)d, r),
+                                          F * (int64_t)d, rc_w),
                        "sgemm_strided_batched dP")))
       return rc;
   } else {
@@ -858,7 +1000,31 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
   if ((rc = rb_check(h, T->rb.sgemm(T->rb.handle, RB_T, RB_N, (int)Kd, (int)B, d, &one, Wmat, d, T->dz, d, &zero, dAmat, (int)Kd), "sgemm dA")))
     return rc;
   if (dm.gen_fc)
-    hipLaunchKernelGGL(k_tr_outer_bwd, dim3((unsigned)((F + 255) / 256), (unsigned)B), dim3(256), 0, s, T->dA, T->x, T->c, F, r, T->dx, T->dc);
+    hipLaunchKernelGGL(k_tr_outer_bwd, dim3((unsigned)((F + 255) / 256), (unsigned)B), dim3(256), 0, s, T->dA, T->x, cw, F, rc_w, T->dx, dcw);
+  // ---- back through the generator chains to the relation rows
+  for (int g = 0; g < 2 && dm.gen_fc; ++g) {
+    TrainState::Chain& ch = T->chain[g];
+    const char* gname = g == 0 ? "fc_weights" : "fc_bias";
+    for (int i = nh - 1; i >= 0; --i) {
+      const int ni = ch.dims[i], nj = ch.dims[i + 1];
+      const std::string pn = std::string(gname) + "/CPG/Projection" + std::to_string(i);
+      const int64_t tot = B * nj;
+      hipLaunchKernelGGL(k_tr_chain_drop_bwd, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, ch.dv[i + 1], tot, tc.seed, step,
+                         (uint32_t)(16 + 8 * g + i), thr_c, ks_c, ch.du[i]);
+      // ReLU (+ BN) backward, in place on du; BN gamma / beta gradients
+      if (dm.ctx_bn)
+        hipLaunchKernelGGL(k_tr_fcbn_bwd, dim3((unsigned)nj), dim3(256), 0, s, ch.u[i], ch.a[i], ch.du[i], ch.st[i], ch.st[i] + nj,
+                           P_((pn + "/BatchNorm/gamma").c_str()), B, nj, use_batch, G_((pn + "/BatchNorm/gamma").c_str()),
+                           G_((pn + "/BatchNorm/beta").c_str()), ch.du[i]);
+      else
+        hipLaunchKernelGGL(k_tr_fcbn_bwd, dim3((unsigned)nj), dim3(256), 0, s, ch.u[i], ch.a[i], ch.du[i], (const float*)nullptr,
+                           (const float*)nullptr, (const float*)nullptr, B, nj, 0, (float*)nullptr, (float*)nullptr, ch.du[i]);
+      hipLaunchKernelGGL(k_tr_small_mm_tn, dim3((unsigned)(((int64_t)ni * nj + 255) / 256)), dim3(256), 0, s, ch.v[i], ch.du[i], B, ni, nj,
+                         G_(pn.c_str()));
+      hipLaunchKernelGGL(k_tr_small_mm_nt, dim3((unsigned)((B * ni + 255) / 256)), dim3(256), 0, s, ch.du[i], P_(pn.c_str()), B, ni, nj, 0,
+                         ch.dv[i]);
+    }
+  }
   COPER_HIP_TRY(h, hipMemsetAsync(colsum, 0, sizeof(double) * 2 * mx, s));
   hipLaunchKernelGGL(k_tr_bn1_bwd_sums, dim3((unsigned)((nBF + 255) / 256 < 1024 ? (nBF + 255) / 256 : 1024)), dim3(256), 0, s, T->dx, T->y, mean1, inv1, P_("Conv1BN/gamma"),
                      P_("Conv1BN/beta"), C, nBF, tc.seed, step, thr_h, ks_h, colsum);
@@ -870,7 +1036,9 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
                      dm.in_h, dm.in_w, dm.stacked ? 1 : 0, C, dm.Ho, dm.Wo, G_("conv1_weights"), G_("conv1_bias"), G_("ent_emb"),
                      G_("rel_emb"));
   if (dm.gen_fc)
-    hipLaunchKernelGGL(k_tr_scatter_rows, dim3((unsigned)((B * r + 255) / 256)), dim3(256), 0, s, T->dc, rel, dm.R, r, B * r, G_("rel_emb"));
+    for (int g = 0; g < 2; ++g)
+      hipLaunchKernelGGL(k_tr_scatter_rows, dim3((unsigned)((B * r + 255) / 256)), dim3(256), 0, s, T->chain[g].dv[0], rel, dm.R, r, B * r,
+                         G_("rel_emb"));
 
   // ---- clip + AMSGrad
   TrainTensors tt;

@@ -335,6 +335,7 @@ class ConvE(object):
         cfg.label_smoothing_epsilon = float(md.get("label_smoothing_epsilon", 0.0))
         cfg.hidden_dropout = float(md.get("hidden_dropout", 0.0))
         cfg.output_dropout = float(md.get("output_dropout", 0.0))
+        cfg.context_rel_dropout = float(md.get("context_rel_dropout", 0.0))
         cfg.batch_norm_momentum = float(md.get("batch_norm_momentum", 0.1))
         cfg.batch_norm_train_stats = 1 if md.get("batch_norm_train_stats", False) else 0
         cfg.seed = int(seed) & 0xFFFFFFFF

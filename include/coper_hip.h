@@ -188,8 +188,8 @@ COPER_API int coper_profile_read(coper_handle* h, const char* kernel, double* to
  * Training step: replaces `session.run(model.train_op)` of run_cpg.py:211-219, i.e.
  * models.py:176-200 (train-mode forward, sampled scorer, label-smoothed sigmoid cross-entropy),
  * tf.clip_by_global_norm(5.0) (models.py:199) and utils/amsgrad.py:130-189.
- * Supported in this version: static conv filters; static (plain ConvE) or g_linear generated dense
- * layer; no concat_rel, no g_lookup, no g_MLP (COPER_EUNSUPPORTED otherwise).
+ * Supported in this version: static conv filters; static (plain ConvE), g_linear or g_MLP generated dense
+ * layer; no concat_rel, no g_lookup, no generated conv filters (COPER_EUNSUPPORTED otherwise).
  * The parameters registered with coper_set_param are UPDATED IN PLACE (they are the variables), including
  * the BN moving statistics; the caches built by coper_prepare go stale, so the handle must be prepared
  * again before the next inference call (enforced).
@@ -206,7 +206,8 @@ typedef struct coper_train_config {
   float batch_norm_momentum;      /* moving-average DECAY (models.py:64,387,417) */
   int32_t batch_norm_train_stats; /* BN uses batch statistics while training (models.py:62,358) */
   uint32_t seed;                  /* dropout stream */
-  int32_t reserved[8];
+  float context_rel_dropout;      /* dropout inside the g_MLP generators (models.py:67-68,118) */
+  int32_t reserved[7];
 } coper_train_config;
 
 /* Allocates gradients and the AMSGrad slots m, v, v_hat (zeros) for every trainable parameter; every

@@ -48,7 +48,29 @@ def dropout_keep(seed: int, step: int, stage: int, n: int, rate: float) -> np.nd
     return ((x >> np.uint64(8)) >= thr).astype(np.float32)
 
 
-def forward_train(p, md, batch, keep_hidden, keep_out, dtype=torch.float64):
+def _generate(p, md, name, c, train_stats, keep_ctx, stats, dtype):
+    """ContextualParameterGenerator.generate (models.py:56-70) in train mode; keep_ctx[(name, i)] = 0/1 dropout mask."""
+    ctx = list(md["context_rel_out"])
+    use_bn = bool(md.get("context_rel_use_batch_norm", False))
+    rate = float(md.get("context_rel_dropout", 0.0))
+    v = c
+    for i in range(len(ctx)):
+        v = v @ p["%s/CPG/Projection%d" % (name, i)]
+        if use_bn:
+            bn = "%s/CPG/Projection%d/BatchNorm" % (name, i)
+            if train_stats:
+                m = v.mean(dim=0)
+                var = ((v - m) ** 2).mean(dim=0)
+                stats[bn] = (m.detach(), var.detach(), v.shape[0])
+            else:
+                m, var = p[bn + "/moving_mean"], p[bn + "/moving_variance"]
+            v = (v - m) / torch.sqrt(var + BN_EPS) * p[bn + "/gamma"] + p[bn + "/beta"]
+        v = torch.relu(v)
+        v = v * torch.as_tensor(keep_ctx[(name, i)].reshape(v.shape)).to(dtype) / (1.0 - rate)
+    return v @ p["%s/CPG/Projection%d" % (name, len(ctx))]
+
+
+def forward_train(p, md, batch, keep_hidden, keep_out, dtype=torch.float64, keep_ctx=None):
     """p: dict leaf name -> torch tensor (requires_grad where trainable).  batch: e1, rel int64 [B],
     lookup int64 [B,L], labels float [B,L].  keep_*: 0/1 masks (numpy) for the two dropouts.
     Returns loss (scalar tensor) and the BN batch statistics dict."""
@@ -94,10 +116,8 @@ def forward_train(p, md, batch, keep_hidden, keep_out, dtype=torch.float64):
     if ctx_out is None:
         z = x @ p["fc_weights"] + p["fc_bias"]
     else:
-        if len(ctx_out) != 0:
-            raise NotImplementedError("training oracle: g_linear dense generator only")
-        Wg = (c @ p["fc_weights/CPG/Projection0"]).reshape(B, F, d)      # models.py:70,73
-        bg = c @ p["fc_bias/CPG/Projection0"]
+        Wg = _generate(p, md, "fc_weights", c, train_stats, keep_ctx, stats, dtype).reshape(B, F, d)   # models.py:70,73
+        bg = _generate(p, md, "fc_bias", c, train_stats, keep_ctx, stats, dtype)
         z = torch.einsum("bf,bfk->bk", x, Wg) + bg                       # models.py:412
     od = float(md.get("output_dropout", 0.0))
     z = z * torch.as_tensor(keep_out.reshape(B, -1)).to(dtype) / (1.0 - od)
@@ -129,7 +149,12 @@ def trainable_names(md):
     if md.get("context_rel_out", None) is None:
         names += ["fc_weights", "fc_bias"]
     else:
-        names += ["fc_weights/CPG/Projection0", "fc_bias/CPG/Projection0"]
+        nh = len(md["context_rel_out"])
+        for g in ("fc_weights", "fc_bias"):
+            for i in range(nh + 1):
+                names.append("%s/CPG/Projection%d" % (g, i))
+                if i < nh and md.get("context_rel_use_batch_norm", False):
+                    names += ["%s/CPG/Projection%d/BatchNorm/gamma" % (g, i), "%s/CPG/Projection%d/BatchNorm/beta" % (g, i)]
     return names
 
 
@@ -171,11 +196,16 @@ def train_step(params_np, md, batch, opt: AMSGrad, seed, step, momentum):
     F = (in_h - 2) * (d // H - 2) * C
     kh = dropout_keep(seed, step, 1, B * F, float(md.get("hidden_dropout", 0.0)))
     ko = dropout_keep(seed, step, 2, B * d, float(md.get("output_dropout", 0.0)))
-    loss, stats, _, _ = forward_train(p, md, batch, kh, ko)
+    kc = {}
+    ctx = md.get("context_rel_out", None) or []
+    for gi, g in enumerate(("fc_weights", "fc_bias")):
+        for i, n in enumerate(ctx):
+            kc[(g, i)] = dropout_keep(seed, step, 16 + 8 * gi + i, B * int(n), float(md.get("context_rel_dropout", 0.0)))
+    loss, stats, _, _ = forward_train(p, md, batch, kh, ko, keep_ctx=kc)
     loss.backward()
     grads = {k: p[k].grad.numpy().copy() for k in names}
     for bn, (mean, var, n) in stats.items():
-        unbiased = bn == "Conv1BN"                                # [TF-semantics] fused 4-D kernel vs 2-D fallback
+        unbiased = bn == "Conv1BN"                                # [TF-semantics] fused 4-D kernel vs 2-D fallback (FCBN, generators)
         var_m = var.numpy() * (n / (n - 1.0)) if unbiased else var.numpy()
         params_np[bn + "/moving_mean"] = params_np[bn + "/moving_mean"] * momentum + mean.numpy() * (1.0 - momentum)
         params_np[bn + "/moving_variance"] = params_np[bn + "/moving_variance"] * momentum + var_m * (1.0 - momentum)

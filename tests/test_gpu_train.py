@@ -14,6 +14,10 @@ _CASES = {
                        context_rel_conv=None, context_rel_out=[]),
     "plain": dict(num_ent=211, num_rel=6, ent_emb_size=40, rel_emb_size=40, emb_h=10, emb_w=4, conv_num_channels=8,
                   context_rel_conv=None, context_rel_out=None),
+    "cpg_mlp_bn": dict(num_ent=211, num_rel=6, ent_emb_size=40, rel_emb_size=8, emb_h=10, emb_w=4, conv_num_channels=8,
+                       context_rel_conv=None, context_rel_out=[12], context_rel_use_batch_norm=True, context_rel_dropout=0.2),
+    "cpg_mlp2": dict(num_ent=211, num_rel=6, ent_emb_size=40, rel_emb_size=8, emb_h=10, emb_w=4, conv_num_channels=8,
+                     context_rel_conv=None, context_rel_out=[9, 7], context_rel_use_batch_norm=False, context_rel_dropout=0.1),
     "cpg_linear_c32": dict(num_ent=157, num_rel=4, ent_emb_size=80, rel_emb_size=4, emb_h=10, emb_w=8, conv_num_channels=32,
                            context_rel_conv=None, context_rel_out=[]),
 }
