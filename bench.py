@@ -60,6 +60,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--score-mode", choices=["f32", "bf16x3"], default="bf16x3")
+    ap.add_argument("--dist-backend", default="nccl",
+                    help="torch.distributed backend (nccl = RCCL).  gloo + several ranks on one GPU is a debugging aid "
+                         "for the multi-process path on a single-GPU box; its numbers mean nothing")
     return ap.parse_args()
 
 
@@ -119,11 +122,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    if args.dist_backend != "nccl":
+        local_rank = local_rank % max(1, torch.cuda.device_count())   # debugging: ranks may share a GPU
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.dist_backend)
 
     md = cdata.model_descriptors(args.workload)
     Q = args.queries or cdata.CONFIGS[args.workload]["queries"]
@@ -171,7 +179,7 @@ def main():
     dt = time.perf_counter() - t0
     model.profile(False)
     if world > 1:
-        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        tmax = torch.tensor([dt], device=device if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
