@@ -408,6 +408,93 @@ __global__ __launch_bounds__(256) void k_tr_add(const float* __restrict__ a, int
   if (i < n) out[i] += a[i];
 }
 
+// ---- g_lookup dense layer (ParameterLookup, models.py:79-94): W = table[rel[b]] of shape [F, d], per sample
+// forward partials: part[sl][b][k] = sum_{f in slice sl} x[b,f] W[rel[b]][f,k]     (grid: B x NSL, thread = k)
+__global__ __launch_bounds__(256) void k_tr_lookup_fwd(const float* __restrict__ x, const float* __restrict__ Wt,
+                                                       const int64_t* __restrict__ rel, int64_t R, int64_t F, int d, int nsl,
+                                                       int64_t B, float* __restrict__ part) {
+  extern __shared__ float xs[];
+  const int64_t b = blockIdx.x;
+  const int sl = blockIdx.y;
+  const int64_t f0 = F * sl / nsl, f1 = F * (sl + 1) / nsl;
+  int64_t rid = rel[b];
+  if (rid < 0 || rid >= R) rid = 0;
+  for (int64_t f = f0 + threadIdx.x; f < f1; f += 256) xs[f - f0] = x[b * F + f];
+  __syncthreads();
+  const int k = threadIdx.x;
+  if (k >= d) return;
+  const float* W = Wt + (rid * F + f0) * d + k;
+  float a = 0.f;
+  for (int64_t f = 0; f < f1 - f0; ++f) a = fmaf(xs[f], W[f * d], a);
+  part[((int64_t)sl * B + b) * d + k] = a;
+}
+// dW[r][f,k] = sum_{b: rel[b] = r} x[b,f] dz[b,k]   (grid: F-chunks x R; relations absent from the batch are skipped:
+// their rows keep stale values and the optimiser kernels treat them as zero through the row mask)
+__global__ __launch_bounds__(256) void k_tr_lookup_dW(const float* __restrict__ x, const float* __restrict__ dz,
+                                                      const int32_t* __restrict__ perm, const int32_t* __restrict__ offset,
+                                                      const int32_t* __restrict__ count, int64_t F, int d, int rows_per_wg,
+                                                      float* __restrict__ dWt) {
+  const int64_t r = blockIdx.y;
+  const int n = count[r];
+  if (n == 0) return;
+  const int off = offset[r];
+  const int k = threadIdx.x;
+  if (k >= d) return;
+  const int64_t f0 = (int64_t)blockIdx.x * rows_per_wg;
+  for (int64_t f = f0; f < f0 + rows_per_wg && f < F; ++f) {
+    float a = 0.f;
+    for (int j = 0; j < n; ++j) {
+      const int64_t b = perm[off + j];
+      a = fmaf(x[b * F + f], dz[b * d + k], a);
+    }
+    dWt[(r * F + f) * d + k] = a;
+  }
+}
+// dx[b,f] = sum_k dz[b,k] W[rel[b]][f,k]   (one wave per row f, lanes over k)
+__global__ __launch_bounds__(256) void k_tr_lookup_dx(const float* __restrict__ dz, const float* __restrict__ Wt,
+                                                      const int64_t* __restrict__ rel, int64_t R, int64_t F, int d,
+                                                      float* __restrict__ dx) {
+  extern __shared__ float dzs[];
+  const int64_t b = blockIdx.y;
+  int64_t rid = rel[b];
+  if (rid < 0 || rid >= R) rid = 0;
+  for (int k = threadIdx.x; k < d; k += 256) dzs[k] = dz[b * d + k];
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int64_t f = (int64_t)blockIdx.x * 64 + wave; f < F && f < (int64_t)(blockIdx.x + 1) * 64; f += 4) {
+    const float* W = Wt + (rid * F + f) * d;
+    float a = 0.f;
+    for (int k = lane; k < d; k += 64) a = fmaf(dzs[k], W[k], a);
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+    if (lane == 0) dx[b * F + f] = a;
+  }
+}
+// z1 = keep * (sum of the forward partials + bias_table[rel[b]]) / (1 - rate)
+__global__ __launch_bounds__(256) void k_tr_lookup_post(const float* __restrict__ part, int nsl, const float* __restrict__ bias_t,
+                                                        const int64_t* __restrict__ rel, int64_t R, int d, int64_t total,
+                                                        uint32_t seed, uint32_t step, uint32_t thr, float keep_scale,
+                                                        float* __restrict__ z1) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  int64_t rid = rel[i / d];
+  if (rid < 0 || rid >= R) rid = 0;
+  float v = bias_t[rid * d + i % d];
+  for (int sl = 0; sl < nsl; ++sl) v += part[(int64_t)sl * total + i];
+  z1[i] = dropout_keep_u32(seed, step, 2u, (uint32_t)i, thr) ? v * keep_scale : 0.f;
+}
+// dz0 = keep * dz1 / (1 - rate) (in place);  dbias_table[rel[b], k] += dz0[b,k]
+__global__ __launch_bounds__(256) void k_tr_lookup_post_bwd(float* __restrict__ dz, const int64_t* __restrict__ rel, int64_t R, int d,
+                                                            int64_t total, uint32_t seed, uint32_t step, uint32_t thr,
+                                                            float keep_scale, float* __restrict__ dbias_t) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  int64_t rid = rel[i / d];
+  if (rid < 0 || rid >= R) rid = 0;
+  const float v = dropout_keep_u32(seed, step, 2u, (uint32_t)i, thr) ? dz[i] * keep_scale : 0.f;
+  dz[i] = v;
+  atomicAdd(&dbias_t[rid * d + i % d], v);
+}
+
 // FCBN backward, one workgroup per feature k (a column of [B, d]): gamma/beta gradients and dz1
 // (dh and dz1 may be the same buffer: every element is read, then written, by one thread)
 __global__ __launch_bounds__(256) void k_tr_fcbn_bwd(const float* __restrict__ z1, const float* __restrict__ hv, const float* dh,
@@ -636,6 +723,10 @@ struct TrainTensors {
   float* v[TR_MAX_PARAMS];
   float* vh[TR_MAX_PARAMS];
   int64_t n[TR_MAX_PARAMS];
+  // tensors whose gradient rows exist only for keys present in the batch (g_lookup tables): row length and the
+  // per-key count; a row with count 0 has gradient 0 whatever the buffer holds
+  int64_t rowlen[TR_MAX_PARAMS];
+  const int32_t* rowcnt[TR_MAX_PARAMS];
 };
 
 __global__ __launch_bounds__(256) void k_tr_sumsq(TrainTensors tt, double* __restrict__ acc) {
@@ -643,7 +734,12 @@ __global__ __launch_bounds__(256) void k_tr_sumsq(TrainTensors tt, double* __res
   const float* g = tt.g[blockIdx.y];
   const int64_t n = tt.n[blockIdx.y];
   double a = 0;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) a += (double)g[i] * g[i];
+  const int32_t* rc = tt.rowcnt[blockIdx.y];
+  const int64_t rl = tt.rowlen[blockIdx.y];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    if (rc && rc[i / rl] == 0) continue;
+    a += (double)g[i] * g[i];
+  }
   part[threadIdx.x] = a;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
@@ -664,8 +760,10 @@ __global__ __launch_bounds__(256) void k_tr_amsgrad(TrainTensors tt, const doubl
   const int64_t n = tt.n[blockIdx.y];
   const double gn = sqrt(*sumsq);
   const float scale = (float)((double)clip / (gn > (double)clip ? gn : (double)clip));
+  const int32_t* rc = tt.rowcnt[blockIdx.y];
+  const int64_t rl = tt.rowlen[blockIdx.y];
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const float gi = g[i] * scale;
+    const float gi = (rc && rc[i / rl] == 0) ? 0.f : g[i] * scale;
     const float mi = b1 * m[i] + (1.f - b1) * gi;
     const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
     const float vhi = fmaxf(vh[i], vi);
@@ -712,10 +810,10 @@ COPER_API int coper_train_init(coper_handle* h, const coper_train_config* cfg) {
   if (!h || !cfg) return COPER_EINVAL;
   if (cfg->abi_version != COPER_ABI_VERSION) return fail(h, COPER_EINVAL, "coper_train_init: ABI version mismatch");
   const Dims& dm = h->dm;
-  if (dm.gen_conv || dm.lookup || dm.concat_rel)
+  if (dm.gen_conv || dm.concat_rel || (dm.lookup && !dm.gen_fc))
     return fail(h, COPER_EUNSUPPORTED,
-                "coper_train_init: this version trains static conv filters with a static, g_linear or g_MLP dense layer "
-                "(no generated conv, g_lookup or concat_rel)");
+                "coper_train_init: this version trains static conv filters with a static, g_linear, g_MLP or g_lookup dense "
+                "layer (no generated / looked-up conv filters, no concat_rel)");
   if (h->cfg.shard_lo != 0 || h->cfg.shard_hi != dm.E)
     return fail(h, COPER_EUNSUPPORTED, "coper_train_init: training needs the whole entity table on the handle");
   if (dm.fh != 3 || dm.fw != 3 || 256 % dm.C != 0 || dm.d > 256)
@@ -732,10 +830,14 @@ COPER_API int coper_train_init(coper_handle* h, const coper_train_config* cfg) {
   T->cfg = *cfg;
   T->b1p = cfg->beta1;   // the beta powers start at beta (amsgrad.py:108-113)
   T->b2p = cfg->beta2;
-  std::vector<std::string> names = {"ent_emb", "rel_emb", "conv1_weights", "conv1_bias", "pred_bias", "Conv1BN/gamma",
+  std::vector<std::string> names = {"ent_emb", "conv1_weights", "conv1_bias", "pred_bias", "Conv1BN/gamma",
                                     "Conv1BN/beta", "FCBN/gamma", "FCBN/beta"};
-  T->nh = dm.gen_fc ? h->cfg.n_ctx_out : 0;
-  if (dm.gen_fc) {
+  if (!dm.lookup) names.push_back("rel_emb");      // g_lookup has no relation embedding (models.py:210)
+  T->nh = (dm.gen_fc && !dm.lookup) ? h->cfg.n_ctx_out : 0;
+  if (dm.lookup) {
+    names.push_back("fc_weights");   // [R, F*d] table
+    names.push_back("fc_bias");      // [R, d] table
+  } else if (dm.gen_fc) {
     for (const char* gname : {"fc_weights", "fc_bias"})
       for (int i = 0; i <= T->nh; ++i) {
         std::string pn = std::string(gname) + "/CPG/Projection" + std::to_string(i);
@@ -806,6 +908,8 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
   const coper_train_config& tc = T->cfg;
   const int d = dm.d, r = dm.r, C = dm.C, P = dm.Ho * dm.Wo, isz = dm.in_h * dm.in_w;
   const int64_t F = dm.F;
+  const bool lk = dm.lookup;
+  const bool gen = dm.gen_fc && !lk;
   const int nh = T->nh;
   const int rc_w = nh ? T->chain[0].dims[nh] : r;   // width of the context that multiplies the last projection
   const int rc_b = nh ? T->chain[1].dims[nh] : r;
@@ -821,8 +925,8 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
         (rc = talloc(h, &T->hv, (size_t)cb * d)) || (rc = talloc(h, &T->dh, (size_t)cb * d)) ||
         (rc = talloc(h, &T->dz, (size_t)cb * d)) || (rc = talloc(h, &T->ds, (size_t)cb * (one_vs_all ? 1 : cl))))
       return rc;
-    if (dm.gen_fc && ((rc = talloc(h, &T->A, (size_t)2 * rc_w * cb * d)) || (rc = talloc(h, &T->dA, (size_t)cb * rc_w * F)))) return rc;
-    for (int g = 0; g < 2 && dm.gen_fc; ++g) {
+    if (gen && ((rc = talloc(h, &T->A, (size_t)2 * rc_w * cb * d)) || (rc = talloc(h, &T->dA, (size_t)cb * rc_w * F)))) return rc;
+    for (int g = 0; g < 2 && gen; ++g) {
       TrainState::Chain& ch = T->chain[g];
       for (int i = 0; i <= nh; ++i) {
         if (i > 0 && (rc = talloc(h, &ch.v[i], (size_t)cb * ch.dims[i]))) return rc;
@@ -837,7 +941,7 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
   auto P_ = [&](const char* n) -> float* { return T->find(n)->p; };
   auto G_ = [&](const char* n) -> float* { return T->find(n)->g; };
   float* ent = P_("ent_emb");
-  float* relp = P_("rel_emb");
+  float* relp = lk ? nullptr : P_("rel_emb");
   const int use_batch = tc.batch_norm_train_stats ? 1 : 0;
   int mx = C > d ? C : d;
   for (int i = 0; i < nh; ++i) mx = h->cfg.ctx_out[i] > mx ? h->cfg.ctx_out[i] : mx;
@@ -853,16 +957,24 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
   // ---- zero what is accumulated by atomics
   COPER_HIP_TRY(h, hipMemsetAsync(red, 0, sizeof(double) * (2 + 2 * mx), s));
   const char* zeroed[] = {"ent_emb", "rel_emb", "conv1_weights", "conv1_bias", "pred_bias"};
-  for (const char* nm : zeroed) COPER_HIP_TRY(h, hipMemsetAsync(G_(nm), 0, sizeof(float) * T->find(nm)->n, s));
+  for (const char* nm : zeroed)
+    if (T->find(nm)) COPER_HIP_TRY(h, hipMemsetAsync(G_(nm), 0, sizeof(float) * T->find(nm)->n, s));
+  if (lk) {
+    // group the batch by relation (perm / rel_offset / rel_count of the inference path): the table gradient is
+    // written per present relation, never zero-filled (1.75 GB at FB15k-237 shapes)
+    if ((rc = coper_reserve(h, B, 0, stream))) return rc;
+    if ((rc = launch_group_by_relation(h, e1, rel, false, B, 32, s))) return rc;
+    COPER_HIP_TRY(h, hipMemsetAsync(G_("fc_bias"), 0, sizeof(float) * T->find("fc_bias")->n, s));
+  }
   const std::string wlast = "fc_weights/CPG/Projection" + std::to_string(nh), blast = "fc_bias/CPG/Projection" + std::to_string(nh);
-  if (dm.gen_fc) COPER_HIP_TRY(h, hipMemsetAsync(G_(blast.c_str()), 0, sizeof(float) * rc_b * d, s));
-  else COPER_HIP_TRY(h, hipMemsetAsync(G_("fc_bias"), 0, sizeof(float) * d, s));
+  if (gen) COPER_HIP_TRY(h, hipMemsetAsync(G_(blast.c_str()), 0, sizeof(float) * rc_b * d, s));
+  else if (!lk) COPER_HIP_TRY(h, hipMemsetAsync(G_("fc_bias"), 0, sizeof(float) * d, s));
 
   // ---- forward
   size_t lds_conv = sizeof(float) * (size_t)(isz + 10 * C);
   hipLaunchKernelGGL(k_tr_conv_fwd, dim3((unsigned)B), dim3(256), lds_conv, s, e1, rel, ent, relp, P_("conv1_weights"),
                      P_("conv1_bias"), dm.E, dm.R, d, r, dm.in_h, dm.in_w, dm.stacked ? 1 : 0, C, dm.Ho, dm.Wo, T->img,
-                     dm.gen_fc ? T->c : nullptr, T->y);
+                     gen ? T->c : nullptr, T->y);
   const int64_t nBF = B * F;
   if (use_batch) hipLaunchKernelGGL(k_tr_col_sums, dim3(128), dim3(256), 0, s, T->y, B * (int64_t)P, C, colsum);
   hipLaunchKernelGGL(k_tr_bn_finish, dim3((C + 63) / 64), dim3(64), 0, s, colsum, C, (double)B * P, use_batch,
@@ -898,25 +1010,34 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
   }
   const float* cw = nh ? T->chain[0].v[nh] : T->c;   // [B, rc_w]
   const float* cbv = nh ? T->chain[1].v[nh] : T->c;  // [B, rc_b]
-  const int64_t Kd = dm.gen_fc ? (int64_t)rc_w * F : F;           // inner size of the dA GEMM
-  const float* Wmat = dm.gen_fc ? P_(wlast.c_str()) : P_("fc_weights");   // row-major [Kd, d]
+  const int64_t Kd = gen ? (int64_t)rc_w * F : F;           // inner size of the dA GEMM
+  const float* Wmat = gen ? P_(wlast.c_str()) : P_("fc_weights");   // row-major [Kd, d]
   const int64_t nBd = B * d;
   float* Tf = T->A;                 // T[rho][b][k]
   float* dTf = T->A + (size_t)rc_w * nBd;
-  if (dm.gen_fc) {
-    // T[rho] = x P[rho]: r independent [B,F]x[F,d] products fill the chip (a single GEMM over K = r*F has 8 tiles)
-    if ((rc = rb_check(h, T->rb.sgemm_sb(T->rb.handle, RB_N, RB_N, d, (int)B, (int)F, &one, Wmat, d, F * (int64_t)d, T->x, (int)F, 0, &zero,
-                                          Tf, d, nBd, rc_w),
-                       "sgemm_strided_batched forward")))
-      return rc;
+  constexpr int LK_NSL = 4;      // F slices of the looked-up dense layer (deterministic partial sums)
+  if (lk) {
+    // z0[b] = x[b] W[rel[b]]: one pass over the looked-up rows (B * F * d * 4 bytes)
+    hipLaunchKernelGGL(k_tr_lookup_fwd, dim3((unsigned)B, LK_NSL), dim3(256), sizeof(float) * (size_t)((F + LK_NSL - 1) / LK_NSL + 1), s, T->x,
+                       P_("fc_weights"), rel, dm.R, F, d, LK_NSL, B, T->dx /* scratch: [NSL][B][d] fits in [B][F] */);
+    hipLaunchKernelGGL(k_tr_lookup_post, dim3((unsigned)((nBd + 255) / 256)), dim3(256), 0, s, T->dx, LK_NSL, P_("fc_bias"), rel, dm.R, d, nBd,
+                       tc.seed, step, thr_o, ks_o, T->z1);
   } else {
-    // z0[B,d] = x[B,F] W[F,d]   (row-major operands seen as column-major transposes)
-    if ((rc = rb_check(h, T->rb.sgemm(T->rb.handle, RB_N, RB_N, d, (int)B, (int)F, &one, Wmat, d, T->x, (int)F, &zero, T->z0, d),
-                       "sgemm forward")))
-      return rc;
+    if (gen) {
+      // T[rho] = x P[rho]: r independent [B,F]x[F,d] products fill the chip (a single GEMM over K = r*F has 8 tiles)
+      if ((rc = rb_check(h, T->rb.sgemm_sb(T->rb.handle, RB_N, RB_N, d, (int)B, (int)F, &one, Wmat, d, F * (int64_t)d, T->x, (int)F, 0, &zero,
+                                            Tf, d, nBd, rc_w),
+                         "sgemm_strided_batched forward")))
+        return rc;
+    } else {
+      // z0[B,d] = x[B,F] W[F,d]   (row-major operands seen as column-major transposes)
+      if ((rc = rb_check(h, T->rb.sgemm(T->rb.handle, RB_N, RB_N, d, (int)B, (int)F, &one, Wmat, d, T->x, (int)F, &zero, T->z0, d),
+                         "sgemm forward")))
+        return rc;
+    }
+    hipLaunchKernelGGL(k_tr_fc_post, dim3((unsigned)((nBd + 255) / 256)), dim3(256), 0, s, gen ? Tf : T->z0, gen ? nullptr : P_("fc_bias"),
+                       cw, rc_w, cbv, gen ? P_(blast.c_str()) : nullptr, rc_b, d, nBd, tc.seed, step, thr_o, ks_o, T->z1);
   }
-  hipLaunchKernelGGL(k_tr_fc_post, dim3((unsigned)((nBd + 255) / 256)), dim3(256), 0, s, dm.gen_fc ? Tf : T->z0, dm.gen_fc ? nullptr : P_("fc_bias"),
-                     cw, rc_w, cbv, dm.gen_fc ? P_(blast.c_str()) : nullptr, rc_b, d, nBd, tc.seed, step, thr_o, ks_o, T->z1);
   COPER_HIP_TRY(h, hipMemsetAsync(colsum, 0, sizeof(double) * 2 * mx, s));
   if (use_batch) hipLaunchKernelGGL(k_tr_col_sums, dim3(16), dim3(256), 0, s, T->z1, B, d, colsum);
   hipLaunchKernelGGL(k_tr_bn_finish, dim3((d + 63) / 64), dim3(64), 0, s, colsum, d, (double)B, use_batch, tc.batch_norm_momentum, 0,
@@ -975,15 +1096,24 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
   }
   hipLaunchKernelGGL(k_tr_fcbn_bwd, dim3((unsigned)d), dim3(256), 0, s, T->z1, T->hv, T->dh, mean2, inv2, P_("FCBN/gamma"), B, d, use_batch,
                      G_("FCBN/gamma"), G_("FCBN/beta"), T->dz);
+  if (lk) {
+    hipLaunchKernelGGL(k_tr_lookup_post_bwd, dim3((unsigned)((nBd + 255) / 256)), dim3(256), 0, s, T->dz, rel, dm.R, d, nBd, tc.seed, step, thr_o,
+                       ks_o, G_("fc_bias"));
+    const int rows_per_wg = 32;
+    hipLaunchKernelGGL(k_tr_lookup_dW, dim3((unsigned)((F + rows_per_wg - 1) / rows_per_wg), (unsigned)dm.R), dim3(256), 0, s, T->x, T->dz, h->perm,
+                       h->rel_offset, h->rel_count, F, d, rows_per_wg, G_("fc_weights"));
+    hipLaunchKernelGGL(k_tr_lookup_dx, dim3((unsigned)((F + 63) / 64), (unsigned)B), dim3(256), sizeof(float) * d, s, T->dz, P_("fc_weights"), rel,
+                       dm.R, F, d, T->dx);
+  } else {
   // gradients of the two contexts: dcw [B, rc_w] (accumulated by k_tr_outer_bwd) and dcb [B, rc_b] (assigned)
-  float* dcw = dm.gen_fc ? T->chain[0].dv[nh] : nullptr;
-  float* dcb = dm.gen_fc ? T->chain[1].dv[nh] : nullptr;
-  if (dm.gen_fc) COPER_HIP_TRY(h, hipMemsetAsync(dcw, 0, sizeof(float) * B * rc_w, s));
+  float* dcw = gen ? T->chain[0].dv[nh] : nullptr;
+  float* dcb = gen ? T->chain[1].dv[nh] : nullptr;
+  if (gen) COPER_HIP_TRY(h, hipMemsetAsync(dcw, 0, sizeof(float) * B * rc_w, s));
   hipLaunchKernelGGL(k_tr_fc_post_bwd, dim3((unsigned)B), dim3(256), sizeof(float) * d, s, T->dz, cbv,
-                     dm.gen_fc ? P_(blast.c_str()) : nullptr, rc_b, d, tc.seed, step, thr_o, ks_o,
-                     dm.gen_fc ? nullptr : G_("fc_bias"), dm.gen_fc ? G_(blast.c_str()) : nullptr, dcb);
-  float* dW = dm.gen_fc ? G_(wlast.c_str()) : G_("fc_weights");
-  if (dm.gen_fc) {
+                     gen ? P_(blast.c_str()) : nullptr, rc_b, d, tc.seed, step, thr_o, ks_o,
+                     gen ? nullptr : G_("fc_bias"), gen ? G_(blast.c_str()) : nullptr, dcb);
+  float* dW = gen ? G_(wlast.c_str()) : G_("fc_weights");
+  if (gen) {
     // dP[rho] = x^T dT[rho],  dT[rho][b,:] = cw[b,rho] dz[b,:]
     hipLaunchKernelGGL(k_tr_scale_rows, dim3((unsigned)((nBd + 255) / 256)), dim3(256), 0, s, T->dz, cw, rc_w, d, nBd, dTf);
     if ((rc = rb_check(h, T->rb.sgemm_sb(T->rb.handle, RB_N, RB_T, d, (int)F, (int)B, &one, dTf, d, nBd, T->x, (int)F, 0, &zero, dW, d,
@@ -996,13 +1126,14 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
       return rc;
   }
   // dA[B,Kd] = dz W^T
-  float* dAmat = dm.gen_fc ? T->dA : T->dx;
+  float* dAmat = gen ? T->dA : T->dx;
   if ((rc = rb_check(h, T->rb.sgemm(T->rb.handle, RB_T, RB_N, (int)Kd, (int)B, d, &one, Wmat, d, T->dz, d, &zero, dAmat, (int)Kd), "sgemm dA")))
     return rc;
-  if (dm.gen_fc)
+  if (gen)
     hipLaunchKernelGGL(k_tr_outer_bwd, dim3((unsigned)((F + 255) / 256), (unsigned)B), dim3(256), 0, s, T->dA, T->x, cw, F, rc_w, T->dx, dcw);
+  }
   // ---- back through the generator chains to the relation rows
-  for (int g = 0; g < 2 && dm.gen_fc; ++g) {
+  for (int g = 0; g < 2 && gen; ++g) {
     TrainState::Chain& ch = T->chain[g];
     const char* gname = g == 0 ? "fc_weights" : "fc_bias";
     for (int i = nh - 1; i >= 0; --i) {
@@ -1034,8 +1165,8 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
   if (lds_cb > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_tr_conv_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipLaunchKernelGGL(k_tr_conv_bwd, dim3((unsigned)B), dim3(256), lds_cb, s, T->dx, T->img, P_("conv1_weights"), e1, rel, dm.E, dm.R, d, r,
                      dm.in_h, dm.in_w, dm.stacked ? 1 : 0, C, dm.Ho, dm.Wo, G_("conv1_weights"), G_("conv1_bias"), G_("ent_emb"),
-                     G_("rel_emb"));
-  if (dm.gen_fc)
+                     lk ? nullptr : G_("rel_emb"));
+  if (gen)
     for (int g = 0; g < 2; ++g)
       hipLaunchKernelGGL(k_tr_scatter_rows, dim3((unsigned)((B * r + 255) / 256)), dim3(256), 0, s, T->chain[g].dv[0], rel, dm.R, r, B * r,
                          G_("rel_emb"));
@@ -1046,6 +1177,9 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
   for (int i = 0; i < np; ++i) {
     tt.p[i] = T->tp[i].p; tt.g[i] = T->tp[i].g; tt.m[i] = T->tp[i].m; tt.v[i] = T->tp[i].v; tt.vh[i] = T->tp[i].vh;
     tt.n[i] = T->tp[i].n;
+    const bool table = dm.lookup && T->tp[i].name == "fc_weights";
+    tt.rowlen[i] = table ? F * d : 1;
+    tt.rowcnt[i] = table ? h->rel_count : nullptr;
   }
   hipLaunchKernelGGL(k_tr_sumsq, dim3(512, (unsigned)np), dim3(256), 0, s, tt, red + 1);
   const float lr_t = (float)((double)tc.learning_rate * std::sqrt(1.0 - T->b2p) / (1.0 - T->b1p));

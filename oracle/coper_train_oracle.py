@@ -79,8 +79,9 @@ def forward_train(p, md, batch, keep_hidden, keep_out, dtype=torch.float64, keep
     Wd = d // H
     C = int(md.get("conv_num_channels", 32))
     ctx_conv, ctx_out = md.get("context_rel_conv", None), md.get("context_rel_out", None)
-    if ctx_conv is not None or md.get("do_parameter_lookup", False) or md.get("concat_rel", False):
-        raise NotImplementedError("training oracle: static conv filters, no lookup, no concat_rel")
+    lookup_params = bool(md.get("do_parameter_lookup", False))
+    if ctx_conv is not None or md.get("concat_rel", False) or (lookup_params and ctx_out is None):
+        raise NotImplementedError("training oracle: static conv filters, no concat_rel")
     train_stats = bool(md.get("batch_norm_train_stats", False))
     e1 = torch.as_tensor(batch["e1"]).long()
     rel = torch.as_tensor(batch["rel"]).long()
@@ -88,7 +89,7 @@ def forward_train(p, md, batch, keep_hidden, keep_out, dtype=torch.float64, keep
     labels = torch.as_tensor(batch["labels"]).to(dtype)
     B = e1.shape[0]
     x0 = p["ent_emb"][e1]
-    c = p["rel_emb"][rel]
+    c = None if lookup_params else p["rel_emb"][rel]          # g_lookup passes the ids through (models.py:180)
     img = x0.reshape(B, H, Wd)
     if ctx_out is None:                                     # plain ConvE: stack the relation image (models.py:360-362)
         img = torch.cat([img, c.reshape(B, H, r // H)], dim=1)
@@ -115,6 +116,9 @@ def forward_train(p, md, batch, keep_hidden, keep_out, dtype=torch.float64, keep
     F = x.shape[1]
     if ctx_out is None:
         z = x @ p["fc_weights"] + p["fc_bias"]
+    elif lookup_params:
+        Wg = p["fc_weights"][rel].reshape(B, F, d)                       # ParameterLookup.generate (models.py:90-94)
+        z = torch.einsum("bf,bfk->bk", x, Wg) + p["fc_bias"][rel]
     else:
         Wg = _generate(p, md, "fc_weights", c, train_stats, keep_ctx, stats, dtype).reshape(B, F, d)   # models.py:70,73
         bg = _generate(p, md, "fc_bias", c, train_stats, keep_ctx, stats, dtype)
@@ -146,6 +150,10 @@ TRAINABLE_STATIC = ["ent_emb", "rel_emb", "conv1_weights", "conv1_bias", "pred_b
 
 def trainable_names(md):
     names = list(TRAINABLE_STATIC)
+    if md.get("do_parameter_lookup", False):
+        names.remove("rel_emb")
+        names += ["fc_weights", "fc_bias"]
+        return names
     if md.get("context_rel_out", None) is None:
         names += ["fc_weights", "fc_bias"]
     else:
@@ -197,7 +205,7 @@ def train_step(params_np, md, batch, opt: AMSGrad, seed, step, momentum):
     kh = dropout_keep(seed, step, 1, B * F, float(md.get("hidden_dropout", 0.0)))
     ko = dropout_keep(seed, step, 2, B * d, float(md.get("output_dropout", 0.0)))
     kc = {}
-    ctx = md.get("context_rel_out", None) or []
+    ctx = [] if md.get("do_parameter_lookup", False) else (md.get("context_rel_out", None) or [])
     for gi, g in enumerate(("fc_weights", "fc_bias")):
         for i, n in enumerate(ctx):
             kc[(g, i)] = dropout_keep(seed, step, 16 + 8 * gi + i, B * int(n), float(md.get("context_rel_dropout", 0.0)))

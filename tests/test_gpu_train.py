@@ -18,6 +18,8 @@ _CASES = {
                        context_rel_conv=None, context_rel_out=[12], context_rel_use_batch_norm=True, context_rel_dropout=0.2),
     "cpg_mlp2": dict(num_ent=211, num_rel=6, ent_emb_size=40, rel_emb_size=8, emb_h=10, emb_w=4, conv_num_channels=8,
                      context_rel_conv=None, context_rel_out=[9, 7], context_rel_use_batch_norm=False, context_rel_dropout=0.1),
+    "lookup": dict(num_ent=211, num_rel=6, ent_emb_size=40, rel_emb_size=1, emb_h=10, emb_w=4, conv_num_channels=8,
+                   context_rel_conv=None, context_rel_out=[], do_parameter_lookup=True),
     "cpg_linear_c32": dict(num_ent=157, num_rel=4, ent_emb_size=80, rel_emb_size=4, emb_h=10, emb_w=8, conv_num_channels=32,
                            context_rel_conv=None, context_rel_out=[]),
 }
@@ -112,7 +114,7 @@ def test_train_rejects_unsupported_variants_and_order():
     m.close()
 
 
-@pytest.mark.parametrize("variant", ["cpg_linear", "plain"])
+@pytest.mark.parametrize("variant", ["cpg_linear", "plain", "lookup", "cpg_mlp_bn"])
 def test_training_loop_learns_a_small_graph(variant):
     """End to end: TrainDataset (the reference's one-positive-per-row sampler) -> train_step -> prepare ->
     ranking_and_hits.  The loss falls and the filtered MRR on the training triples ends far above chance."""
