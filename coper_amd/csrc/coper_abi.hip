@@ -562,13 +562,27 @@ COPER_API int coper_rank(coper_handle* h, const float* hvec, const int64_t* e2, 
   hipStream_t s = (hipStream_t)stream;
   int rc;
   if ((rc = ensure_workspace(h, B, filt_nnz, s))) return rc;
-  if ((rc = coper_target_scores(h, hvec, e2, B, h->tgt_ws, stream))) return rc;
-  int32_t* ng = h->cnt_ws;
+  const bool direct = h->cfg.score_mode != COPER_SCORE_F32;
+  if (direct) {
+    // bf16x3: n_greater accumulates straight into `ranks` started from 1 (no finish launch), preset by the packing
+    // launch of the target pass (no zeroing launch)
+    h->count_base = 1;
+    h->preset_cnt = ranks;
+    h->preset_eq = n_equal;
+  }
+  rc = coper_target_scores(h, hvec, e2, B, h->tgt_ws, stream);
+  h->preset_cnt = nullptr;
+  h->preset_eq = nullptr;
+  if (rc) { h->count_base = 0; h->counts_preset = nullptr; return rc; }
+  int32_t* ng = direct ? ranks : h->cnt_ws;
   int32_t* ne = n_equal;  // NULL: ties are not counted (one compare per score instead of two)
   h->trust_packed = true;  // same hvec, same stream, no caller code in between: the packing of target_scores is valid
   rc = coper_rank_counts(h, hvec, h->tgt_ws, e2, filt_indptr, filt_idx, filt_nnz, B, 0, ng, ne, nullptr, nullptr, stream);
   h->trust_packed = false;
+  h->count_base = 0;
+  h->counts_preset = nullptr;
   if (rc) return rc;
+  if (direct) return COPER_OK;
   return launch_finish_ranks(h, ng, B, ranks, s);
 }
 

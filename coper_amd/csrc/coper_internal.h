@@ -111,6 +111,11 @@ struct coper_handle {
   float* hfrag_ws = nullptr;      // h re-packed in MFMA-fragment order [ceil(B/128)*4][KS][64] float4
   int num_cus = 256;
   void* train = nullptr;          // coper::TrainState (coper_train.hip)
+  // coper_rank only: the counters accumulate straight into `ranks` (base 1) and are preset by the packing launch
+  int32_t count_base = 0;
+  int32_t* preset_cnt = nullptr;  // request: the next pack launch presets these [B] counters (and preset_eq to 0)
+  int32_t* preset_eq = nullptr;
+  const int32_t* counts_preset = nullptr;  // done: the next score_count on this buffer skips its own zeroing
   bool dense_attr_done = false;
   bool fused_attr_done = false;
   bool dense_small_only = false;  // set per launch: tiles above 32 queries go to the fused conv + dense kernel

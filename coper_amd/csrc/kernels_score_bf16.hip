@@ -55,8 +55,11 @@ __device__ __forceinline__ void split8(const float* v, uint4& hi, uint4& lo) {
 __global__ __launch_bounds__(256) void k_rows_to_frag_bf16(const float* __restrict__ src, int64_t n_rows, int d,
                                                            int KS16, uint4* __restrict__ hi, uint4* __restrict__ lo,
                                                            uint4* __restrict__ rm_hi, uint4* __restrict__ rm_lo,
-                                                           int64_t total) {
+                                                           int64_t total, int32_t* __restrict__ cnt, int32_t cnt_base,
+                                                           int32_t* __restrict__ cnt_eq) {
   int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (blk*KS16 + ks)*64 + l
+  // optional: preset the rank counters of the pass this packing opens (saves a launch on the ranking path)
+  if (cnt && j < n_rows) { cnt[j] = cnt_base; if (cnt_eq) cnt_eq[j] = 0; }
   if (j >= total) return;
   int l = (int)(j & 63);
   int64_t rest = j >> 6;
@@ -83,7 +86,10 @@ int launch_rows_to_frag_bf16(coper_handle* h, const float* src, int64_t n_rows, 
   const Dims& dm = h->dm;
   int64_t total = n_blk * dm.KS16 * 64;
   hipLaunchKernelGGL(k_rows_to_frag_bf16, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, n_rows, dm.d,
-                     dm.KS16, hi, lo, rm_hi, rm_lo, total);
+                     dm.KS16, hi, lo, rm_hi, rm_lo, total, h->preset_cnt, h->count_base, h->preset_eq);
+  if (h->preset_cnt) h->counts_preset = h->preset_cnt;
+  h->preset_cnt = nullptr;
+  h->preset_eq = nullptr;
   COPER_HIP_TRY(h, hipGetLastError());
   return COPER_OK;
 }
@@ -127,9 +133,9 @@ __device__ __forceinline__ uint4 bx_nt_load(const uint4* p) {
 #endif
 static_assert(BX_WAVES * BX_ME <= EBLK_ALIGN, "entity blocks are padded to EBLK_ALIGN");
 
-__global__ void k_zero_counts(int64_t B, int32_t* __restrict__ ng, int32_t* __restrict__ ne) {
+__global__ void k_zero_counts(int64_t B, int32_t* __restrict__ ng, int32_t* __restrict__ ne, int32_t base) {
   int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < B) { ng[j] = 0; if (ne) ne[j] = 0; }
+  if (j < B) { ng[j] = base; if (ne) ne[j] = 0; }
 }
 
 template <bool EQ>
@@ -303,7 +309,11 @@ int launch_score_count_bf16x3(coper_handle* h, const float* hvec, const float* t
                               int32_t* ne, hipStream_t s) {
   const Dims& dm = h->dm;
   (void)hvec;  // already packed by launch_pack_h_bf16 (coper_rank_counts packs once per call)
-  hipLaunchKernelGGL(k_zero_counts, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, B, ng, ne);
+  // coper_rank presets the counters in the pack launch of its target pass (n_greater accumulates straight into `ranks`,
+  // started from 1): nothing to do then
+  if (h->counts_preset != ng)
+    hipLaunchKernelGGL(k_zero_counts, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, B, ng, ne, h->count_base);
+  h->counts_preset = nullptr;
   int64_t q_tiles = (B + 32 * BX_NQ - 1) / (32 * BX_NQ);
   int64_t iters = dm.n_eblk / (BX_WAVES * BX_ME);
   int64_t units = q_tiles * iters;
@@ -454,7 +464,16 @@ __global__ __launch_bounds__(256) void k_pair_bf16x3(const uint4* __restrict__ E
     } else if (p >= indptr[B]) {
       erow = -1;  // the launch may be sized by a capacity larger than the CSR (hipGraph replay): no query owns p
     } else {
-      q = row_of[p];
+      if (row_of) {
+        q = row_of[p];
+      } else {   // CSR row of entry p: the last b with indptr[b] <= p
+        int64_t lo_b = 0, hi_b = B;
+        while (hi_b - lo_b > 1) {
+          const int64_t mid = (lo_b + hi_b) >> 1;
+          if (indptr[mid] <= p) lo_b = mid; else hi_b = mid;
+        }
+        q = lo_b;
+      }
       int64_t f = idx[p];
       erow = f - lo;
       if (p > indptr[q] && idx[p - 1] == f) erow = -1;  // adjacent duplicate: the dense mask is idempotent
@@ -560,10 +579,16 @@ int launch_filter_correct_bf16x3(coper_handle* h, const float* tgt, const int64_
                                  const int64_t* idx, int64_t nnz, int64_t B, int32_t* ng, int32_t* ne,
                                  hipStream_t s) {
   const Dims& dm = h->dm;
-  int64_t threads = B * 16;
-  hipLaunchKernelGGL(k_expand_rows_retire_target, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, indptr, B, e2,
-                     tgt, (int64_t)h->cfg.shard_lo, dm.n_local, h->row_of_ws, ne);
-  pair_launch(h, 2, nnz, B, 1, e2, nullptr, indptr, idx, h->row_of_ws, tgt, nullptr, ng, ne, s);
+  if (ne) {
+    // tie counts requested: the target itself was counted as "equal" and is retired here; the row expansion rides along
+    int64_t threads = B * 16;
+    hipLaunchKernelGGL(k_expand_rows_retire_target, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, indptr, B, e2,
+                       tgt, (int64_t)h->cfg.shard_lo, dm.n_local, h->row_of_ws, ne);
+    pair_launch(h, 2, nnz, B, 1, e2, nullptr, indptr, idx, h->row_of_ws, tgt, nullptr, ng, ne, s);
+  } else {
+    // ranks only (what the reference computes): the pair kernel finds each CSR entry's row by bisection of indptr
+    pair_launch(h, 2, nnz, B, 1, e2, nullptr, indptr, idx, nullptr, tgt, nullptr, ng, ne, s);
+  }
   COPER_HIP_TRY(h, hipGetLastError());
   return COPER_OK;
 }
