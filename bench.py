@@ -158,9 +158,10 @@ def main():
             # ids are tiny; the host copies drive the relation split, the device copies feed the kernels
             return ranker.rank(dict(e1=host_q["e1"], rel=host_q["rel"], e2=dev_q["e2"], filt_indptr=dev_q["filt_indptr"],
                                     filt_idx=dev_q["filt_idx"]))
-        h = model.encode(dev_q["e1"], dev_q["rel"])
-        # like ranking_and_hits (and the reference), the pass needs ranks only: tie counts are not requested
-        return model.rank(h, dev_q["e2"], dev_q["filt_indptr"], dev_q["filt_idx"], filt_nnz=nnz, want_equal=False)
+        # one call per pass, like one session.run of the reference's ranker loop; like ranking_and_hits (and the
+        # reference) the pass needs ranks only: tie counts and the embedding itself are not requested
+        return model.rank_pass(dev_q["e1"], dev_q["rel"], dev_q["e2"], dev_q["filt_indptr"], dev_q["filt_idx"], filt_nnz=nnz,
+                               want_equal=False)
 
     for _ in range(args.warmup):
         step()

@@ -77,6 +77,7 @@ PROTOTYPES = {
     "coper_target_scores": (C.c_int, [_P, _P, _P, _I64, _P, _P]),
     "coper_rank_counts": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, C.c_int32, _P, _P, _P, _P, _P]),
     "coper_rank": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P]),
+    "coper_encode_rank": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P]),
     "coper_check_ids": (C.c_int, [_P, C.POINTER(_I64), _P]),
     "coper_profile_enable": (C.c_int, [_P, C.c_int]),
     "coper_profile_read": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_I64)]),

@@ -237,7 +237,7 @@ COPER_API void coper_destroy(coper_handle* h) {
   dev_free(&h->Ef); dev_free(&h->bias_pad); dev_free(&h->ctx_tmp[0]); dev_free(&h->ctx_tmp[1]);
   dev_free(&h->rel_count); dev_free(&h->rel_offset); h->rel_cursor = nullptr; dev_free(&h->perm); dev_free(&h->sorted_row); dev_free(&h->sorted_rid);
   dev_free(&h->tiles); dev_free(&h->n_tiles); dev_free(&h->blk_off); dev_free(&h->x_sorted); dev_free(&h->z_part);
-  dev_free(&h->tgt_ws); dev_free(&h->cnt_ws); dev_free(&h->hfrag_ws); dev_free(&h->logits_ws); dev_free(&h->row_of_ws);
+  dev_free(&h->tgt_ws); dev_free(&h->h_ws); dev_free(&h->cnt_ws); dev_free(&h->hfrag_ws); dev_free(&h->logits_ws); dev_free(&h->row_of_ws);
   dev_free((char**)&h->Wf16_hi); dev_free((char**)&h->Wf16_lo);
   dev_free((char**)&h->Ef16_hi); dev_free((char**)&h->Ef16_lo); dev_free((char**)&h->hfrag16_hi); dev_free((char**)&h->hfrag16_lo);
   dev_free((char**)&h->Erm16_hi); dev_free((char**)&h->Erm16_lo); dev_free((char**)&h->hrm16_hi); dev_free((char**)&h->hrm16_lo);
@@ -448,13 +448,9 @@ COPER_API int coper_gather_entities(coper_handle* h, const int64_t* ids, int64_t
   return launch_gather_entities(h, ids, B, out, (hipStream_t)stream);
 }
 
-COPER_API int coper_encode(coper_handle* h, const int64_t* e1, const int64_t* rel, int64_t B, const float* e1_rows,
-                 float* h_out, void* stream) {
-  COPER_REQUIRE_PREPARED(h);
-  if (B == 0) return COPER_OK;  // empty batch: nothing to do (the reference's session.run on an empty batch returns [0,d])
-  if (!rel || !h_out || B < 0 || (!e1 && !e1_rows)) return fail(h, COPER_EINVAL, "coper_encode: bad argument");
-  if (B > 0x7fffffff) return fail(h, COPER_EINVAL, "coper_encode: batch too large");
-  hipStream_t s = (hipStream_t)stream;
+// grouping, conv and the dense layer up to the K-slice partials in z_part (everything of coper_encode but the finalize)
+static int encode_partials(coper_handle* h, const int64_t* e1, const int64_t* rel, int64_t B, const float* e1_rows, hipStream_t s,
+                           int* ksplit_out, float* h_out_f32_path) {
   const Dims& dm = h->dm;
   int rc;
   if ((rc = ensure_workspace(h, B, 0, s))) return rc;
@@ -464,6 +460,7 @@ COPER_API int coper_encode(coper_handle* h, const int64_t* e1, const int64_t* re
   int64_t ksteps = dm.F_pad / 16;
   int ksplit = ksteps >= 64 ? 4 : 1;  // DENSE_KSLICES
   if (ksplit > h->ws_ksplit) ksplit = h->ws_ksplit;
+  *ksplit_out = ksplit;
   if ((rc = launch_group_by_relation(h, e1, rel, e1_rows != nullptr, B, tq, s))) return rc;
   if (h->enc_bf16) {
 #ifdef COPER_NO_FUSED_DENSE
@@ -478,10 +475,23 @@ COPER_API int coper_encode(coper_handle* h, const int64_t* e1, const int64_t* re
       if ((rc = launch_dense_bf16(h, B, ksplit, fused, s))) return rc;
       if (fused && (rc = launch_dense_fused_bf16(h, e1, rel, e1_rows, B, ksplit, s))) return rc;
     }
-    return launch_dense_finalize(h, rel, B, ksplit, h_out, s);
+    return COPER_OK;
   }
   if ((rc = launch_conv(h, e1, rel, e1_rows, B, s))) return rc;
-  return launch_dense(h, rel, B, tq, ksplit, h_out, s);
+  return launch_dense(h, rel, B, tq, ksplit, h_out_f32_path, s);   // fp32 mode: finalize included
+}
+
+COPER_API int coper_encode(coper_handle* h, const int64_t* e1, const int64_t* rel, int64_t B, const float* e1_rows,
+                 float* h_out, void* stream) {
+  COPER_REQUIRE_PREPARED(h);
+  if (B == 0) return COPER_OK;  // empty batch: nothing to do (the reference's session.run on an empty batch returns [0,d])
+  if (!rel || !h_out || B < 0 || (!e1 && !e1_rows)) return fail(h, COPER_EINVAL, "coper_encode: bad argument");
+  if (B > 0x7fffffff) return fail(h, COPER_EINVAL, "coper_encode: batch too large");
+  hipStream_t s = (hipStream_t)stream;
+  int rc, ksplit = 1;
+  if ((rc = encode_partials(h, e1, rel, B, e1_rows, s, &ksplit, h_out))) return rc;
+  if (h->enc_bf16) return launch_dense_finalize(h, rel, B, ksplit, h_out, s);
+  return COPER_OK;
 }
 
 COPER_API int coper_score_all(coper_handle* h, const float* hvec, int64_t B, float* logits, int64_t ld, void* stream) {
@@ -584,6 +594,50 @@ COPER_API int coper_rank(coper_handle* h, const float* hvec, const int64_t* e2, 
   if (rc) return rc;
   if (direct) return COPER_OK;
   return launch_finish_ranks(h, ng, B, ranks, s);
+}
+
+COPER_API int coper_encode_rank(coper_handle* h, const int64_t* e1, const int64_t* rel, const float* e1_rows, const int64_t* e2,
+                                const int64_t* filt_indptr, const int64_t* filt_idx, int64_t filt_nnz, int64_t B, float* h_out,
+                                int32_t* ranks, int32_t* n_equal, void* stream) {
+  COPER_REQUIRE_PREPARED(h);
+  if (B == 0) return COPER_OK;
+  if (!rel || !e2 || !filt_indptr || !ranks || B < 0 || filt_nnz < 0 || (!e1 && !e1_rows) || (filt_nnz > 0 && !filt_idx))
+    return fail(h, COPER_EINVAL, "coper_encode_rank: bad argument");
+  if (B > 0x7fffffff) return fail(h, COPER_EINVAL, "coper_encode_rank: batch too large");
+  if (h->dm.n_local != h->dm.E) return fail(h, COPER_ESTATE, "coper_encode_rank needs the whole table (see coper_rank)");
+  hipStream_t s = (hipStream_t)stream;
+  int rc, ksplit = 1;
+  if ((rc = ensure_workspace(h, B, filt_nnz, s))) return rc;
+  if (!h->enc_bf16) {
+    // fp32-exact mode: the two-call path with an internal h when the caller does not want it
+    float* hv = h_out;
+    if (!hv) {
+      if (!h->h_ws || h->h_ws_rows < B) {
+        COPER_HIP_TRY(h, hipStreamSynchronize(s));
+        if ((rc = dev_alloc(h, &h->h_ws, (size_t)B * h->dm.d))) return rc;
+        h->h_ws_rows = B;
+      }
+      hv = h->h_ws;
+    }
+    if ((rc = coper_encode(h, e1, rel, B, e1_rows, hv, stream))) return rc;
+    return coper_rank(h, hv, e2, filt_indptr, filt_idx, filt_nnz, B, ranks, n_equal, stream);
+  }
+  // bf16x3: the finalize writes h straight into the planes the rank kernels read and presets the counters, which
+  // accumulate into `ranks` from 1: no fp32 h round trip, no pack, zero or finish launch
+  if ((rc = encode_partials(h, e1, rel, B, e1_rows, s, &ksplit, nullptr))) return rc;
+  if ((rc = launch_dense_finalize_pack(h, B, ksplit, h_out, ranks, 1, n_equal, s))) return rc;
+  if ((rc = launch_pair_targets_packed_bf16x3(h, e2, B, h->tgt_ws, s))) return rc;
+  const float* tag = h->tgt_ws;          // any pointer: identifies "the planes in place" for the count pass below
+  h->packed_hvec = tag;
+  h->packed_B = B;
+  h->trust_packed = true;
+  h->count_base = 1;
+  h->counts_preset = ranks;
+  rc = coper_rank_counts(h, tag, h->tgt_ws, e2, filt_indptr, filt_idx, filt_nnz, B, 0, ranks, n_equal, nullptr, nullptr, stream);
+  h->trust_packed = false;
+  h->count_base = 0;
+  h->counts_preset = nullptr;
+  return rc;
 }
 
 COPER_API int coper_check_ids(coper_handle* h, int64_t* n_bad, void* stream) {

@@ -97,6 +97,8 @@ struct coper_handle {
   float* z_part = nullptr;        // [ksplit, B, d_pad16]
   float* tgt_ws = nullptr;        // [B]
   int32_t* cnt_ws = nullptr;      // [2B]
+  float* h_ws = nullptr;          // internal h of coper_encode_rank when the caller does not want it (fp32 mode)
+  int64_t h_ws_rows = 0;
   float* logits_ws = nullptr;     // top-k path only: [chunk_rows, n_local]
   int64_t logits_ws_rows = 0;
   void* hfrag16_hi = nullptr;     // bf16x3: h hi / lo planes in fragment order
@@ -194,6 +196,9 @@ bool dense_fused_supported(const coper_handle* h, int nslices);
 int launch_dense_fused_bf16(coper_handle* h, const int64_t* e1, const int64_t* rel, const float* e1_rows, int64_t B,
                             int nslices, hipStream_t s);
 int launch_dense_finalize(coper_handle* h, const int64_t* rel, int64_t B, int ksplit, float* h_out, hipStream_t s);
+int launch_dense_finalize_pack(coper_handle* h, int64_t B, int ksplit, float* h_out, int32_t* cnt, int32_t cnt_base,
+                               int32_t* cnt_eq, hipStream_t s);
+int launch_pair_targets_packed_bf16x3(coper_handle* h, const int64_t* e2, int64_t B, float* tgt, hipStream_t s);
 int score_all_dispatch(coper_handle* h, const float* hvec, int64_t B, float* logits, int64_t ld, hipStream_t s);
 int launch_bias_pad(coper_handle* h, const float* bias, hipStream_t s);
 int launch_topk(coper_handle* h, const float* hvec, const int64_t* e2, const int64_t* indptr, const int64_t* idx,

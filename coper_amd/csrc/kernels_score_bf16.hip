@@ -566,6 +566,13 @@ int launch_pair_targets_bf16x3(coper_handle* h, const float* hvec, const int64_t
   return COPER_OK;
 }
 
+// targets of queries whose planes are already in place (coper_encode_rank: written by k_dense_finalize_pack)
+int launch_pair_targets_packed_bf16x3(coper_handle* h, const int64_t* e2, int64_t B, float* tgt, hipStream_t s) {
+  pair_launch(h, 0, B, B, 1, e2, nullptr, nullptr, nullptr, nullptr, nullptr, tgt, nullptr, nullptr, s);
+  COPER_HIP_TRY(h, hipGetLastError());
+  return COPER_OK;
+}
+
 int launch_score_lookup_bf16x3(coper_handle* h, const float* hvec, const int32_t* lookup, int64_t B, int64_t L,
                                float* out, hipStream_t s) {
   int rc = launch_pack_h_bf16(h, hvec, B, s);

@@ -41,12 +41,11 @@ def shard_bounds(num_ent: int, world: int, rank: int):
 def local_rank_pass(model, chunk, want_equal=False):
     """Unsharded: encode + fused filtered rank for one chunk of queries.  Returns (ranks, n_equal) int32 tensors;
     n_equal is None unless asked for (ranking_and_hits, like the reference, has no use for tie counts)."""
-    h = model.encode(chunk["e1"], chunk["rel"])
-    try:
-        return model.rank(h, chunk["e2"], chunk["filt_indptr"], chunk["filt_idx"], filt_nnz=len(chunk["filt_idx"]),
-                          want_equal=want_equal)
-    except TypeError:   # scorers without the option
-        return model.rank(h, chunk["e2"], chunk["filt_indptr"], chunk["filt_idx"], filt_nnz=len(chunk["filt_idx"]))
+    if hasattr(model, "rank_pass"):    # one call per chunk (coper_encode_rank)
+        return model.rank_pass(chunk["e1"], chunk["rel"], chunk["e2"], chunk["filt_indptr"], chunk["filt_idx"],
+                               filt_nnz=len(chunk["filt_idx"]), want_equal=want_equal)
+    h = model.encode(chunk["e1"], chunk["rel"])   # scorers that expose only the two-call protocol
+    return model.rank(h, chunk["e2"], chunk["filt_indptr"], chunk["filt_idx"], filt_nnz=len(chunk["filt_idx"]))
 
 
 def _slice_chunk(chunk, lo, hi):

@@ -174,6 +174,14 @@ COPER_API int coper_rank(coper_handle* h, const float* hvec, const int64_t* e2, 
                const int64_t* filt_idx, int64_t filt_nnz, int64_t B, int32_t* ranks, int32_t* n_equal,
                void* stream);
 
+/* One evaluation batch end to end: coper_encode + coper_rank in one call -- what one `session.run` of the
+ * reference's ranker loop computes (metrics.py:40-57).  h_out: optional float [B, d] (NULL: the embedding is
+ * not needed; in the bf16x3 mode it then never exists in fp32 -- the dense finalize writes the operand planes
+ * of the rank kernels directly).  Same results as the two calls, bit for bit. */
+COPER_API int coper_encode_rank(coper_handle* h, const int64_t* e1, const int64_t* rel, const float* e1_rows,
+                                const int64_t* e2, const int64_t* filt_indptr, const int64_t* filt_idx, int64_t filt_nnz,
+                                int64_t B, float* h_out, int32_t* ranks, int32_t* n_equal, void* stream);
+
 /* Timing hook used by bench.py: average device time (ms) of the dominant kernel
  * (score_count) over the launches since the last reset, measured with hipEvents recorded on
  * the launch stream.  enable != 0 turns per-launch event recording on. */

@@ -541,3 +541,21 @@ def test_bf16x3_fused_encoder_vs_oracle(oracle_chain, name):
     assert np.abs(h32 - h).max() < H_TOL
     for x in (m, ms, m32):
         x.close()
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+def test_encode_rank_single_call_equals_two_calls(mode):
+    """coper_encode_rank (one call per batch; in bf16x3 the finalize writes the rank kernels' operand planes directly)
+    returns the same ranks / tie counts / embedding as coper_encode + coper_rank, bit for bit."""
+    md = cdata.model_descriptors("fb15k237_cpg", num_ent=3001, num_rel=30)
+    p = cdata.synthetic_params(md, 2)
+    m = _model(md, p, score_mode=mode)
+    for Q, seed in ((700, 4), (129, 5), (31, 6)):
+        q = cdata.synthetic_queries(md, Q, seed=seed)
+        h = m.encode(q["e1"], q["rel"])
+        r2, ne2 = m.rank(h, q["e2"], q["filt_indptr"], q["filt_idx"])
+        r1, ne1, h1 = m.rank_pass(q["e1"], q["rel"], q["e2"], q["filt_indptr"], q["filt_idx"], want_h=True)
+        assert torch.equal(r1, r2) and torch.equal(ne1, ne2) and torch.equal(h1, h)
+        r0, none = m.rank_pass(q["e1"], q["rel"], q["e2"], q["filt_indptr"], q["filt_idx"], want_equal=False)
+        assert none is None and torch.equal(r0, r2)
+    m.close()
