@@ -468,12 +468,14 @@ static int encode_partials(coper_handle* h, const int64_t* e1, const int64_t* re
 #else
     const bool fused = dense_fused_supported(h, ksplit);
 #endif
-    // tiles of <= 32 queries: conv -> x planes -> small dense; larger tiles: conv fused into the dense kernel
-    if ((rc = launch_conv_bf16(h, e1, rel, e1_rows, B, fused, s))) return rc;
+    if (fused) {   // one launch serves every tile: conv, BN, ReLU and the dense layer (kernels_dense_fused_bf16.hip)
+      ScopedKernelTimer t(h, "dense", s);
+      return launch_dense_fused_bf16(h, e1, rel, e1_rows, B, ksplit, s);
+    }
+    if ((rc = launch_conv_bf16(h, e1, rel, e1_rows, B, false, s))) return rc;
     {
       ScopedKernelTimer t(h, "dense", s);
-      if ((rc = launch_dense_bf16(h, B, ksplit, fused, s))) return rc;
-      if (fused && (rc = launch_dense_fused_bf16(h, e1, rel, e1_rows, B, ksplit, s))) return rc;
+      if ((rc = launch_dense_bf16(h, B, ksplit, false, s))) return rc;
     }
     return COPER_OK;
   }

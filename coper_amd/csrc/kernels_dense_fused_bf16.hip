@@ -1,4 +1,4 @@
-// COPER_SCORE_BF16X3 encoder, fused conv + generated dense for tiles of 33..128 queries.
+// COPER_SCORE_BF16X3 encoder, fused conv + generated dense for every tile (1..128 queries of one relation).
 //
 // The unfused pair (k_conv3x3_bn_relu_bf16 -> x planes in HBM -> k_dense_reg_bf16x3) is bound by the x
 // traffic: 64-B pieces of 16 different rows per instruction make x 42 % of the dense kernel's memory
@@ -321,14 +321,23 @@ __global__ __launch_bounds__(512) void k_dense_fused_bf16x3(const uint4* __restr
                                                             FusedConvArgs A, const int32_t* __restrict__ tiles,
                                                             const int32_t* __restrict__ n_tiles, int64_t cap_small,
                                                             int nfb, int64_t ks32n, int nslices, int64_t Bcap,
-                                                            int d_pad16, float* __restrict__ z_part) {
+                                                            int d_pad16, float* __restrict__ z_part, int n_big_cap) {
   extern __shared__ uint4 fused_lds[];
+  // blockIdx.x < n_big_cap: the list of 33..128-query tiles; above it: the list of <= 32-query tiles (one per
+  // relation key at most) -- every tile of the batch is served by this one launch
   int tile = blockIdx.x;
-  if (tile >= n_tiles[1]) return;
+  const int32_t* tl;
+  if (tile < n_big_cap) {
+    if (tile >= n_tiles[1]) return;
+    tl = tiles + 4 * (cap_small + tile);
+  } else {
+    tile -= n_big_cap;
+    if (tile >= n_tiles[0]) return;
+    tl = tiles + 4 * (int64_t)tile;
+  }
 #ifdef COPER_DBG_FUSED_EXIT
   return;
 #endif
-  const int32_t* tl = tiles + 4 * (cap_small + tile);
   const int slice = blockIdx.y;
   const int fb0 = blockIdx.z * NFB;
   const int64_t relw = __builtin_amdgcn_readfirstlane(tl[0]);
@@ -352,6 +361,8 @@ __global__ __launch_bounds__(512) void k_dense_fused_bf16x3(const uint4* __restr
   else                                                                                                                 \
     fused_conv_role<NB_>(xring, img, A, relw, start, n, kb, ke, i_lo, t0, t1, wave - 4);
   switch (nb) {
+    case 1: BODY(1); break;
+    case 2: BODY(2); break;
     case 3: BODY(3); break;
     case 4: BODY(4); break;
     case 5: BODY(5); break;
@@ -393,6 +404,7 @@ static void dense_fused_launch(coper_handle* h, const int64_t* e1, const int64_t
   const Dims& dm = h->dm;
   int64_t cap_small = (dm.gen_fc ? dm.R : 1) + 1;
   int64_t n_big_max = B / 33 + 1;
+  int64_t n_small_max = cap_small - 1 < B ? cap_small - 1 : B;
   FusedConvArgs A;
   A.e1_rows = e1_rows; A.sorted_row = h->sorted_row; A.sorted_rid = h->sorted_rid;
   A.ent = h->params["ent_emb"].ptr;
@@ -408,14 +420,13 @@ static void dense_fused_launch(coper_handle* h, const int64_t* e1, const int64_t
     (void)hipFuncSetAttribute((const void*)k_dense_fused_bf16x3<NFB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     h->fused_attr_done = true;
   }
-  hipLaunchKernelGGL((k_dense_fused_bf16x3<NFB>), dim3((unsigned)n_big_max, (unsigned)nslices, (unsigned)zgroups), dim3(512),
+  hipLaunchKernelGGL((k_dense_fused_bf16x3<NFB>), dim3((unsigned)(n_big_max + n_small_max), (unsigned)nslices, (unsigned)zgroups), dim3(512),
                      lds, s, (const uint4*)h->Wf16_hi, (const uint4*)h->Wf16_lo, A, h->tiles, h->n_tiles, cap_small, dm.nfb,
-                     dm.F_pad / 32, nslices, h->ws_queries, dm.d_pad16, h->z_part);
+                     dm.F_pad / 32, nslices, h->ws_queries, dm.d_pad16, h->z_part, (int)n_big_max);
 }
 
 int launch_dense_fused_bf16(coper_handle* h, const int64_t* e1, const int64_t* rel, const float* e1_rows, int64_t B,
                             int nslices, hipStream_t s) {
-  if (B <= 32) return COPER_OK;   // no tile above 32 queries can exist
   if (h->dm.nfb == 13) dense_fused_launch<13>(h, e1, rel, e1_rows, B, nslices, 1, s);
   else dense_fused_launch<8>(h, e1, rel, e1_rows, B, nslices, (h->dm.nfb + 7) / 8, s);
   COPER_HIP_TRY(h, hipGetLastError());
