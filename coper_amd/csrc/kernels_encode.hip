@@ -54,10 +54,9 @@ __global__ __launch_bounds__(HIST_BLOCK) void k_rel_hist(const int64_t* __restri
 //                emitted largest-first (by 16-query block count) so the hardware dispatcher, which hands
 //                out workgroups in index order, ends the launch on the cheapest tiles.
 // tiles[] = small list at [0, 4*cap_small), big list after it; n_tiles[0] = #small, n_tiles[1] = #big.
-__global__ __launch_bounds__(1024) void k_rel_scan_tiles(const int32_t* __restrict__ count, int64_t R,
-                                                         int64_t cap_small, int32_t* __restrict__ offset,
-                                                         int32_t* __restrict__ tiles,
-                                                         int32_t* __restrict__ n_tiles) {
+__device__ __forceinline__ void rel_scan_tiles_body(const int32_t* count, int64_t R, int64_t cap_small,
+                                                    int32_t* offset, int32_t* __restrict__ tiles,
+                                                    int32_t* __restrict__ n_tiles) {
   __shared__ int s_cnt[1024];
   __shared__ int s_sml[1024];
   __shared__ int carry_cnt, carry_sml;
@@ -127,6 +126,58 @@ __global__ __launch_bounds__(1024) void k_rel_scan_tiles(const int32_t* __restri
   }
 }
 
+__global__ __launch_bounds__(1024) void k_rel_scan_tiles(const int32_t* __restrict__ count, int64_t R,
+                                                         int64_t cap_small, int32_t* __restrict__ offset,
+                                                         int32_t* __restrict__ tiles,
+                                                         int32_t* __restrict__ n_tiles) {
+  rel_scan_tiles_body(count, R, cap_small, offset, tiles, n_tiles);
+}
+
+// Small batches (<= 4096 queries, <= 8192 relation keys): histogram, scan / tile lists and scatter in ONE
+// single-workgroup launch (the four-launch path costs ~20 us of launch latency; measured: 110 -> 102 us per hipGraph
+// batch of 512; at B = 20,480 one workgroup is latency-bound and loses, so large batches keep the four launches).
+__global__ __launch_bounds__(1024) void k_rel_group_single(const int64_t* __restrict__ rel, const int64_t* __restrict__ e1,
+                                                           int64_t B, int use_rel, int64_t R, int64_t R_all, int have_e1_rows,
+                                                           int64_t shard_lo, int64_t n_local, int64_t cap_small,
+                                                           int32_t* __restrict__ count, int32_t* __restrict__ bad,
+                                                           int32_t* offset, int32_t* __restrict__ tiles,
+                                                           int32_t* __restrict__ n_tiles, int32_t* __restrict__ perm,
+                                                           int32_t* __restrict__ sorted_row, int32_t* __restrict__ sorted_rid) {
+  extern __shared__ int32_t sh[];   // cnt[R] | cursor[R]
+  int32_t* cnt = sh;
+  int32_t* cur = sh + R;
+  for (int k = threadIdx.x; k < 2 * R; k += 1024) sh[k] = 0;
+  if (threadIdx.x == 0) *bad = 0;
+  __syncthreads();
+  int nbad = 0;
+  for (int64_t b = threadIdx.x; b < B; b += 1024) {
+    int64_t key = use_rel ? rel[b] : 0;
+    if (key < 0 || key >= R) { ++nbad; key = 0; }
+    atomicAdd(&cnt[key], 1);
+  }
+  if (nbad) atomicAdd(bad, nbad);
+  __syncthreads();
+  for (int k = threadIdx.x; k < R; k += 1024) count[k] = cnt[k];   // the global copy other kernels read
+  rel_scan_tiles_body(cnt, R, cap_small, offset, tiles, n_tiles);
+  __syncthreads();
+  for (int64_t b = threadIdx.x; b < B; b += 1024) {
+    int64_t rid = rel[b];
+    if (rid < 0 || rid >= R_all) rid = 0;
+    const int64_t key = use_rel ? rid : 0;
+    int64_t row;
+    if (have_e1_rows) {
+      row = b;
+    } else {
+      row = e1[b] - shard_lo;
+      if (row < 0 || row >= n_local) row = -1;
+    }
+    const int pos = offset[key] + atomicAdd(&cur[key], 1);
+    perm[pos] = (int32_t)b;
+    sorted_row[pos] = (int32_t)row;
+    sorted_rid[pos] = (int32_t)rid;
+  }
+}
+
 // Besides perm, the scatter leaves what the fused conv + dense kernel's image prologue needs in sorted order
 // (one coalesced load instead of the dependent chain perm -> e1 / rel): the local entity row of e1 (-1 when it
 // is not on this shard; the query index itself when the caller passes e1_rows) and the validated relation id.
@@ -187,6 +238,15 @@ int launch_group_by_relation(coper_handle* h, const int64_t* e1, const int64_t* 
                              hipStream_t s) {
   const Dims& dm = h->dm;
   int64_t R = dm.gen_fc ? dm.R : 1;
+  if (R <= HIST_LDS_MAX && B <= 4096) {   // a single workgroup is latency-bound beyond a few ids per thread
+    // rel_count[R+1] doubles as the out-of-range counter (reset by the kernel)
+    hipLaunchKernelGGL(k_rel_group_single, dim3(1), dim3(1024), sizeof(int32_t) * 2 * (size_t)R, s, rel, e1, B, dm.gen_fc ? 1 : 0, R,
+                       dm.R, have_e1_rows ? 1 : 0, (int64_t)h->cfg.shard_lo, dm.n_local, small_tile_cap(h), h->rel_count,
+                       h->rel_count + dm.R + 1, h->rel_offset, h->tiles, h->n_tiles, h->perm, h->sorted_row, h->sorted_rid);
+    (void)tq;
+    COPER_HIP_TRY(h, hipGetLastError());
+    return COPER_OK;
+  }
   COPER_HIP_TRY(h, hipMemsetAsync(h->rel_count, 0, sizeof(int32_t) * 2 * (dm.R + 2), s));  // counts | cursors
   unsigned nb = (unsigned)((B + HIST_BLOCK - 1) / HIST_BLOCK);
   size_t hl = R <= HIST_LDS_MAX ? sizeof(int32_t) * (size_t)R : 0;
