@@ -458,7 +458,16 @@ static int encode_partials(coper_handle* h, const int64_t* e1, const int64_t* re
   // K-split of the dense layer depends on F only, never on the batch: h[b] is then a pure function of
   // (e1[b], rel[b]) -- bit-identical whatever batch, chunking or rank computes it.
   int64_t ksteps = dm.F_pad / 16;
-  int ksplit = ksteps >= 64 ? 4 : 1;  // DENSE_KSLICES
+  // Number of K slices: a function of the CONFIGURATION only (never of the batch).  More slices = more workgroups
+  // per weight stream (fills the chip when there are few streams) but more partial-sum traffic and prologues;
+  // measured on MI355X (same box, bf16x3): 474 relations 2 > 3 > 4 > 8; 22 relations 8 > 4 > 3 > 2; one shared
+  // weight (plain ConvE) 3 > 4 > 8 > 2.
+#ifdef COPER_KSPLIT
+  int ksplit = ksteps >= 64 ? COPER_KSPLIT : 1;
+#else
+  int ksplit = 1;
+  if (ksteps >= 64) ksplit = !dm.gen_fc ? 3 : dm.R >= 256 ? 2 : dm.R >= 32 ? 4 : 8;
+#endif
   if (ksplit > h->ws_ksplit) ksplit = h->ws_ksplit;
   *ksplit_out = ksplit;
   if ((rc = launch_group_by_relation(h, e1, rel, e1_rows != nullptr, B, tq, s))) return rc;
