@@ -416,9 +416,10 @@ static void dense_fused_launch(coper_handle* h, const int64_t* e1, const int64_t
   A.d = dm.d; A.r = dm.r; A.in_w = dm.in_w; A.in_hw = dm.in_h * dm.in_w; A.Wo = dm.Wo;
   A.img_stride = (fused_rows_max(dm, nslices) * dm.in_w) | 1;
   size_t lds = (size_t)2 * 16 * 64 * sizeof(uint4) + (size_t)128 * A.img_stride * sizeof(float);
-  if (!h->fused_attr_done) {   // process-wide attribute: always the hardware maximum, whatever this handle needs
+  static bool attr_done = false;   // per instantiation; process-wide attribute: always the hardware maximum
+  if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)k_dense_fused_bf16x3<NFB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    h->fused_attr_done = true;
+    attr_done = true;
   }
   hipLaunchKernelGGL((k_dense_fused_bf16x3<NFB>), dim3((unsigned)(n_big_max + n_small_max), (unsigned)nslices, (unsigned)zgroups), dim3(512),
                      lds, s, (const uint4*)h->Wf16_hi, (const uint4*)h->Wf16_lo, A, h->tiles, h->n_tiles, cap_small, dm.nfb,
@@ -427,7 +428,15 @@ static void dense_fused_launch(coper_handle* h, const int64_t* e1, const int64_t
 
 int launch_dense_fused_bf16(coper_handle* h, const int64_t* e1, const int64_t* rel, const float* e1_rows, int64_t B,
                             int nslices, hipStream_t s) {
-  if (h->dm.nfb == 13) dense_fused_launch<13>(h, e1, rel, e1_rows, B, nslices, 1, s);
+#ifndef COPER_FUSED_SPLIT_B
+#define COPER_FUSED_SPLIT_B 2048
+#endif
+  // Small batches leave most CUs idle (one workgroup per tile and slice): split the feature blocks over two
+  // (B <= 2048) or four (B <= 1024)
+  // workgroups (grid.z; every accumulation chain is unchanged, so h keeps its bits) -- the image / conv work is
+  // repeated per group, which small tiles do not notice.
+  if (B <= COPER_FUSED_SPLIT_B / 2) dense_fused_launch<4>(h, e1, rel, e1_rows, B, nslices, (h->dm.nfb + 3) / 4, s);
+  else if (h->dm.nfb == 13 && B > COPER_FUSED_SPLIT_B) dense_fused_launch<13>(h, e1, rel, e1_rows, B, nslices, 1, s);
   else dense_fused_launch<8>(h, e1, rel, e1_rows, B, nslices, (h->dm.nfb + 7) / 8, s);
   COPER_HIP_TRY(h, hipGetLastError());
   return COPER_OK;
