@@ -591,7 +591,9 @@ COPER_API int coper_rank(coper_handle* h, const float* hvec, const int64_t* e2, 
     h->preset_cnt = ranks;
     h->preset_eq = n_equal;
   }
+  if (direct && !n_equal) h->expand_indptr = filt_indptr;   // the target pass expands the CSR rows for the filter pass
   rc = coper_target_scores(h, hvec, e2, B, h->tgt_ws, stream);
+  h->expand_indptr = nullptr;
   h->preset_cnt = nullptr;
   h->preset_eq = nullptr;
   if (rc) { h->count_base = 0; h->counts_preset = nullptr; return rc; }
@@ -637,7 +639,10 @@ COPER_API int coper_encode_rank(coper_handle* h, const int64_t* e1, const int64_
   // accumulate into `ranks` from 1: no fp32 h round trip, no pack, zero or finish launch
   if ((rc = encode_partials(h, e1, rel, B, e1_rows, s, &ksplit, nullptr))) return rc;
   if ((rc = launch_dense_finalize_pack(h, B, ksplit, h_out, ranks, 1, n_equal, s))) return rc;
-  if ((rc = launch_pair_targets_packed_bf16x3(h, e2, B, h->tgt_ws, s))) return rc;
+  if (!n_equal) h->expand_indptr = filt_indptr;
+  rc = launch_pair_targets_packed_bf16x3(h, e2, B, h->tgt_ws, s);
+  h->expand_indptr = nullptr;
+  if (rc) return rc;
   const float* tag = h->tgt_ws;          // any pointer: identifies "the planes in place" for the count pass below
   h->packed_hvec = tag;
   h->packed_B = B;

@@ -117,6 +117,8 @@ struct coper_handle {
   int32_t count_base = 0;
   int32_t* preset_cnt = nullptr;  // request: the next pack launch presets these [B] counters (and preset_eq to 0)
   int32_t* preset_eq = nullptr;
+  const int64_t* expand_indptr = nullptr;      // request: the next target pass also writes row_of_ws for this CSR
+  const int64_t* rows_expanded_for = nullptr;  // done: row_of_ws holds the row ids of this CSR
   const int32_t* counts_preset = nullptr;  // done: the next score_count on this buffer skips its own zeroing
   bool dense_attr_done = false;
   bool fused_attr_done = false;

@@ -452,12 +452,16 @@ __global__ __launch_bounds__(256) void k_pair_bf16x3(const uint4* __restrict__ E
   __shared__ int64_t s_e[4][32];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int i = lane & 31, half = lane >> 5;
-  const int64_t p = ((int64_t)blockIdx.x * 4 + wave) * 32 + i;
+  const int64_t p = ((int64_t)blockIdx.x * (blockDim.x >> 6) + wave) * 32 + i;
   int64_t q = 0, erow = -1;  // erow < 0: nothing to score for this pair
   if (p < n_pairs) {
     if (mode == 0) {
       q = p;
       erow = e2[p] - lo;
+      // the ranking flows hand the CSR filter to the target pass too: it writes the row id of every filter entry
+      // (consumed by the filter pass that follows on the same stream) -- no separate expansion launch, no bisection
+      if (indptr && half == 0)
+        for (int64_t j = indptr[p]; j < indptr[p + 1]; ++j) const_cast<int32_t*>(row_of)[j] = (int32_t)p;
     } else if (mode == 1) {
       q = p / L;
       erow = (int64_t)lookup[p] - lo;
@@ -549,7 +553,9 @@ static void pair_launch(coper_handle* h, int mode, int64_t n_pairs, int64_t B, i
                         const float* tgt, float* out, int32_t* ng, int32_t* ne, hipStream_t s) {
   const Dims& dm = h->dm;
   if (n_pairs <= 0) return;
-  hipLaunchKernelGGL(k_pair_bf16x3, dim3((unsigned)((n_pairs + 127) / 128)), dim3(256), 0, s, (const uint4*)h->Erm16_hi,
+  // few pairs (the target pass: one per query): one wave per workgroup spreads them over all CUs
+  const int wpb = n_pairs <= (1 << 22) ? 1 : 4;
+  hipLaunchKernelGGL(k_pair_bf16x3, dim3((unsigned)((n_pairs + 32 * wpb - 1) / (32 * wpb))), dim3(64 * wpb), 0, s, (const uint4*)h->Erm16_hi,
                      (const uint4*)h->Erm16_lo, h->bias_pad, (const uint4*)h->hrm16_hi, (const uint4*)h->hrm16_lo,
                      dm.KS16, mode, n_pairs, B, L, e2, lookup, indptr, idx, row_of, tgt, (int64_t)h->cfg.shard_lo,
                      dm.n_local, out, ng, ne);
@@ -561,14 +567,20 @@ int launch_pair_targets_bf16x3(coper_handle* h, const float* hvec, const int64_t
   if (rc) return rc;
   h->packed_hvec = hvec;  // coper_rank reuses this packing for the count pass on the same stream
   h->packed_B = B;
-  pair_launch(h, 0, B, B, 1, e2, nullptr, nullptr, nullptr, nullptr, nullptr, tgt, nullptr, nullptr, s);
+  pair_launch(h, 0, B, B, 1, e2, nullptr, h->expand_indptr, nullptr, h->expand_indptr ? h->row_of_ws : nullptr, nullptr, tgt, nullptr,
+              nullptr, s);
+  if (h->expand_indptr) h->rows_expanded_for = h->expand_indptr;
+  h->expand_indptr = nullptr;
   COPER_HIP_TRY(h, hipGetLastError());
   return COPER_OK;
 }
 
 // targets of queries whose planes are already in place (coper_encode_rank: written by k_dense_finalize_pack)
 int launch_pair_targets_packed_bf16x3(coper_handle* h, const int64_t* e2, int64_t B, float* tgt, hipStream_t s) {
-  pair_launch(h, 0, B, B, 1, e2, nullptr, nullptr, nullptr, nullptr, nullptr, tgt, nullptr, nullptr, s);
+  pair_launch(h, 0, B, B, 1, e2, nullptr, h->expand_indptr, nullptr, h->expand_indptr ? h->row_of_ws : nullptr, nullptr, tgt, nullptr,
+              nullptr, s);
+  if (h->expand_indptr) h->rows_expanded_for = h->expand_indptr;
+  h->expand_indptr = nullptr;
   COPER_HIP_TRY(h, hipGetLastError());
   return COPER_OK;
 }
@@ -593,8 +605,11 @@ int launch_filter_correct_bf16x3(coper_handle* h, const float* tgt, const int64_
                        tgt, (int64_t)h->cfg.shard_lo, dm.n_local, h->row_of_ws, ne);
     pair_launch(h, 2, nnz, B, 1, e2, nullptr, indptr, idx, h->row_of_ws, tgt, nullptr, ng, ne, s);
   } else {
-    // ranks only (what the reference computes): the pair kernel finds each CSR entry's row by bisection of indptr
-    pair_launch(h, 2, nnz, B, 1, e2, nullptr, indptr, idx, nullptr, tgt, nullptr, ng, ne, s);
+    // ranks only (what the reference computes): row ids were written by the target pass of coper_rank /
+    // coper_encode_rank; other callers of coper_rank_counts get them by bisection of indptr inside the pair kernel
+    const int32_t* rows = h->rows_expanded_for == indptr ? h->row_of_ws : nullptr;
+    h->rows_expanded_for = nullptr;
+    pair_launch(h, 2, nnz, B, 1, e2, nullptr, indptr, idx, rows, tgt, nullptr, ng, ne, s);
   }
   COPER_HIP_TRY(h, hipGetLastError());
   return COPER_OK;
