@@ -59,6 +59,8 @@ struct TrainParam {
 
 }  // namespace
 
+static const char* const kGenNames[4] = {"fc_weights", "fc_bias", "conv1_weights", "conv1_bias"};
+
 struct TrainState {
   coper_train_config cfg;
   RocBlas rb;
@@ -78,8 +80,10 @@ struct TrainState {
     float* dv[COPER_MAX_CTX + 1] = {};   // gradient w.r.t. v[i]
     float* du[COPER_MAX_CTX] = {};
     float* st[COPER_MAX_CTX] = {};       // [2][n]: mean | inv_std
-  } chain[2];
-  int nh = 0;
+  } chain[4];                 // 0 fc_weights, 1 fc_bias, 2 conv1_weights, 3 conv1_bias
+  int nh = 0;                 // hidden layers of the dense-layer generators
+  int nhc = 0;                // hidden layers of the conv generators
+  float *Kt = nullptr, *Kbv = nullptr, *dKs = nullptr, *dkbs = nullptr;   // per-sample conv filters / biases and their gradients
   float* Sd = nullptr;       // [B, |E|] dense d(loss)/d(logits) when it fits (scorer backward by GEMM)
   int64_t capS = 0;
   float* A = nullptr;        // generated dense: T[r][B][d] (forward partials) | dT[r][B][d]
@@ -112,7 +116,8 @@ __global__ __launch_bounds__(256) void k_tr_conv_fwd(const int64_t* __restrict__
                                                      const float* __restrict__ K, const float* __restrict__ kb, int64_t E,
                                                      int64_t R, int d, int r, int in_h, int in_w, int stacked, int C, int Ho,
                                                      int Wo, float* __restrict__ img_out, float* __restrict__ c_out,
-                                                     float* __restrict__ y) {
+                                                     float* __restrict__ y, const float* __restrict__ K_ps,
+                                                     const float* __restrict__ kb_ps) {
   extern __shared__ float lds[];  // img[in_h*in_w] | taps[9*C] | kb[C]
   float* img = lds;
   float* taps = img + in_h * in_w;
@@ -127,8 +132,11 @@ __global__ __launch_bounds__(256) void k_tr_conv_fwd(const int64_t* __restrict__
     for (int t = threadIdx.x; t < r; t += 256) img[d + t] = rel_emb[rid * r + t];
   if (c_out)
     for (int t = threadIdx.x; t < r; t += 256) c_out[b * r + t] = rel_emb[rid * r + t];
-  for (int t = threadIdx.x; t < 9 * C; t += 256) taps[t] = K[t];
-  for (int t = threadIdx.x; t < C; t += 256) bias[t] = kb[t];
+  // per-sample filters (generated / looked up, models.py:374-380) or the shared static ones
+  const float* Ksrc = K_ps ? K_ps + b * 9 * C : K;
+  const float* bsrc = kb_ps ? kb_ps + b * C : kb;
+  for (int t = threadIdx.x; t < 9 * C; t += 256) taps[t] = Ksrc[t];
+  for (int t = threadIdx.x; t < C; t += 256) bias[t] = bsrc[t];
   __syncthreads();
   const int isz = in_h * in_w;
   for (int t = threadIdx.x; t < isz; t += 256) img_out[b * isz + t] = img[t];
@@ -655,7 +663,9 @@ __global__ __launch_bounds__(256) void k_tr_conv_bwd(const float* __restrict__ d
                                                      const int64_t* __restrict__ rel, int64_t E, int64_t R, int d, int r,
                                                      int in_h, int in_w, int stacked, int C, int Ho, int Wo,
                                                      float* __restrict__ dK, float* __restrict__ dkb,
-                                                     float* __restrict__ dE, float* __restrict__ drel) {
+                                                     float* __restrict__ dE, float* __restrict__ drel,
+                                                     const float* __restrict__ K_ps, float* __restrict__ dK_ps,
+                                                     float* __restrict__ dkb_ps) {
   extern __shared__ float lds[];  // img[isz] | g[P*C] | taps[9*C]
   const int isz = in_h * in_w, P = Ho * Wo;
   float* img = lds;
@@ -664,9 +674,11 @@ __global__ __launch_bounds__(256) void k_tr_conv_bwd(const float* __restrict__ d
   const int64_t b = blockIdx.x;
   for (int t = threadIdx.x; t < isz; t += 256) img[t] = img_all[b * isz + t];
   for (int t = threadIdx.x; t < P * C; t += 256) g[t] = dy[b * (int64_t)P * C + t];
-  for (int t = threadIdx.x; t < 9 * C; t += 256) taps[t] = K[t];
+  const float* Ksrc = K_ps ? K_ps + b * 9 * C : K;
+  for (int t = threadIdx.x; t < 9 * C; t += 256) taps[t] = Ksrc[t];
   __syncthreads();
   // filter and bias gradients: entry (tap, c) = sum_p img[p + tap offset] * g[p, c]
+  // (per-sample filters: written per sample, reduced through the generator / table afterwards)
   for (int idx = threadIdx.x; idx < 10 * C; idx += 256) {
     const int cc = idx % C, tap = idx / C;
     float a = 0.f;
@@ -674,10 +686,10 @@ __global__ __launch_bounds__(256) void k_tr_conv_bwd(const float* __restrict__ d
       const int u = tap / 3, v = tap % 3;
       for (int i = 0; i < Ho; ++i)
         for (int j = 0; j < Wo; ++j) a = fmaf(img[(i + u) * in_w + j + v], g[(i * Wo + j) * C + cc], a);
-      atomicAdd(&dK[tap * C + cc], a);
+      if (dK_ps) dK_ps[b * 9 * C + tap * C + cc] = a; else atomicAdd(&dK[tap * C + cc], a);
     } else {
       for (int p = 0; p < P; ++p) a += g[p * C + cc];
-      atomicAdd(&dkb[cc], a);
+      if (dkb_ps) dkb_ps[b * C + cc] = a; else atomicAdd(&dkb[cc], a);
     }
   }
   // image gradient (full correlation), scattered to the embedding rows
@@ -702,6 +714,16 @@ __global__ __launch_bounds__(256) void k_tr_conv_bwd(const float* __restrict__ d
     if (t < d) atomicAdd(&dE[row * d + t], a);
     else if (stacked) atomicAdd(&drel[rid * r + (t - d)], a);
   }
+}
+
+// out[b, :] = table[rel[b], :]   (relation rows; also the per-sample conv filters of g_lookup)
+__global__ __launch_bounds__(256) void k_tr_gather_rows(const float* __restrict__ table, const int64_t* __restrict__ rel, int64_t R, int n,
+                                                        int64_t total, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  int64_t rid = rel[i / n];
+  if (rid < 0 || rid >= R) rid = 0;
+  out[i] = table[rid * n + i % n];
 }
 
 // drel_emb[rel[b], :] += dc[b, :]
@@ -785,7 +807,7 @@ void train_destroy(coper_handle* h) {
   TrainState* T = (TrainState*)h->train;
   if (!T) return;
   for (auto& t : T->tp) { (void)hipFree(t.g); (void)hipFree(t.m); (void)hipFree(t.v); (void)hipFree(t.vh); }
-  float* bufs[] = {T->Sd, T->img, T->y, T->x, T->c, T->A, T->dA, T->z0, T->z1, T->hv, T->dh, T->dz, T->ds, T->dx, T->dc, T->bnst};
+  float* bufs[] = {T->Kt, T->Kbv, T->dKs, T->dkbs, T->Sd, T->img, T->y, T->x, T->c, T->A, T->dA, T->z0, T->z1, T->hv, T->dh, T->dz, T->ds, T->dx, T->dc, T->bnst};
   for (float* b : bufs) (void)hipFree(b);
   for (auto& ch : T->chain)
     for (int i = 0; i <= COPER_MAX_CTX; ++i) {
@@ -810,10 +832,11 @@ COPER_API int coper_train_init(coper_handle* h, const coper_train_config* cfg) {
   if (!h || !cfg) return COPER_EINVAL;
   if (cfg->abi_version != COPER_ABI_VERSION) return fail(h, COPER_EINVAL, "coper_train_init: ABI version mismatch");
   const Dims& dm = h->dm;
-  if (dm.gen_conv || dm.concat_rel || (dm.lookup && !dm.gen_fc))
+  if (dm.concat_rel || (dm.lookup && !dm.gen_fc) || (dm.gen_conv && !dm.gen_fc))
     return fail(h, COPER_EUNSUPPORTED,
-                "coper_train_init: this version trains static conv filters with a static, g_linear, g_MLP or g_lookup dense "
-                "layer (no generated / looked-up conv filters, no concat_rel)");
+                "coper_train_init: this version trains static, g_linear, g_MLP or g_lookup dense layers, with static conv "
+                "filters or conv filters generated / looked up the same way (no concat_rel; no generated conv without a "
+                "generated dense layer)");
   if (h->cfg.shard_lo != 0 || h->cfg.shard_hi != dm.E)
     return fail(h, COPER_EUNSUPPORTED, "coper_train_init: training needs the whole entity table on the handle");
   if (dm.fh != 3 || dm.fw != 3 || 256 % dm.C != 0 || dm.d > 256)
@@ -830,10 +853,25 @@ COPER_API int coper_train_init(coper_handle* h, const coper_train_config* cfg) {
   T->cfg = *cfg;
   T->b1p = cfg->beta1;   // the beta powers start at beta (amsgrad.py:108-113)
   T->b2p = cfg->beta2;
-  std::vector<std::string> names = {"ent_emb", "conv1_weights", "conv1_bias", "pred_bias", "Conv1BN/gamma",
-                                    "Conv1BN/beta", "FCBN/gamma", "FCBN/beta"};
+  std::vector<std::string> names = {"ent_emb", "pred_bias", "Conv1BN/gamma", "Conv1BN/beta", "FCBN/gamma", "FCBN/beta"};
   if (!dm.lookup) names.push_back("rel_emb");      // g_lookup has no relation embedding (models.py:210)
   T->nh = (dm.gen_fc && !dm.lookup) ? h->cfg.n_ctx_out : 0;
+  T->nhc = (dm.gen_conv && !dm.lookup) ? h->cfg.n_ctx_conv : 0;
+  if (dm.gen_conv && !dm.lookup) {
+    for (const char* gname : {"conv1_weights", "conv1_bias"})
+      for (int i = 0; i <= T->nhc; ++i) {
+        std::string pn = std::string(gname) + "/CPG/Projection" + std::to_string(i);
+        names.push_back(pn);
+        if (i < T->nhc && dm.ctx_bn) { names.push_back(pn + "/BatchNorm/gamma"); names.push_back(pn + "/BatchNorm/beta"); }
+      }
+    for (int g = 2; g < 4; ++g) {
+      T->chain[g].dims[0] = dm.r;
+      for (int i = 0; i < T->nhc; ++i) T->chain[g].dims[i + 1] = h->cfg.ctx_conv[i];
+    }
+  } else {
+    names.push_back("conv1_weights");   // static [3,3,1,C], or the [R, 9C] table of g_lookup
+    names.push_back("conv1_bias");
+  }
   if (dm.lookup) {
     names.push_back("fc_weights");   // [R, F*d] table
     names.push_back("fc_bias");      // [R, d] table
@@ -885,6 +923,7 @@ COPER_API int coper_train_init(coper_handle* h, const coper_train_config* cfg) {
   if ((rc = rb_check(h, rb.create(&rb.handle), "rocblas_create_handle"))) return rc;
   int mx = dm.C > dm.d ? dm.C : dm.d;
   for (int i = 0; i < T->nh; ++i) mx = h->cfg.ctx_out[i] > mx ? h->cfg.ctx_out[i] : mx;
+  for (int i = 0; i < T->nhc; ++i) mx = h->cfg.ctx_conv[i] > mx ? h->cfg.ctx_conv[i] : mx;
   if ((rc = talloc(h, &T->bnst, (size_t)4 * mx))) return rc;
   if ((rc = talloc(h, &T->red, (size_t)(2 + 2 * mx)))) return rc;
   return COPER_OK;
@@ -910,7 +949,11 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
   const int64_t F = dm.F;
   const bool lk = dm.lookup;
   const bool gen = dm.gen_fc && !lk;
-  const int nh = T->nh;
+  const bool genc = dm.gen_conv && !lk;     // conv filters from projection generators
+  const bool lkc = dm.gen_conv && lk;       // conv filters from g_lookup tables
+  const int nh = T->nh, nhc = T->nhc;
+  const int rc_cw = nhc ? T->chain[2].dims[nhc] : r;
+  const int rc_cb = nhc ? T->chain[3].dims[nhc] : r;
   const int rc_w = nh ? T->chain[0].dims[nh] : r;   // width of the context that multiplies the last projection
   const int rc_b = nh ? T->chain[1].dims[nh] : r;
   if ((int64_t)B * F > 0xffffffffLL) return fail(h, COPER_EINVAL, "coper_train_step: batch too large for the dropout counter");
@@ -926,16 +969,21 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
         (rc = talloc(h, &T->dz, (size_t)cb * d)) || (rc = talloc(h, &T->ds, (size_t)cb * (one_vs_all ? 1 : cl))))
       return rc;
     if (gen && ((rc = talloc(h, &T->A, (size_t)2 * rc_w * cb * d)) || (rc = talloc(h, &T->dA, (size_t)cb * rc_w * F)))) return rc;
-    for (int g = 0; g < 2 && gen; ++g) {
+    for (int g = 0; g < 4; ++g) {
+      if (g < 2 ? !gen : !genc) continue;
+      const int nhx = g < 2 ? nh : nhc;
       TrainState::Chain& ch = T->chain[g];
-      for (int i = 0; i <= nh; ++i) {
+      for (int i = 0; i <= nhx; ++i) {
         if (i > 0 && (rc = talloc(h, &ch.v[i], (size_t)cb * ch.dims[i]))) return rc;
         if ((rc = talloc(h, &ch.dv[i], (size_t)cb * ch.dims[i]))) return rc;
-        if (i < nh && ((rc = talloc(h, &ch.u[i], (size_t)cb * ch.dims[i + 1])) || (rc = talloc(h, &ch.a[i], (size_t)cb * ch.dims[i + 1])) ||
-                       (rc = talloc(h, &ch.du[i], (size_t)cb * ch.dims[i + 1])) || (rc = talloc(h, &ch.st[i], (size_t)2 * ch.dims[i + 1]))))
+        if (i < nhx && ((rc = talloc(h, &ch.u[i], (size_t)cb * ch.dims[i + 1])) || (rc = talloc(h, &ch.a[i], (size_t)cb * ch.dims[i + 1])) ||
+                        (rc = talloc(h, &ch.du[i], (size_t)cb * ch.dims[i + 1])) || (rc = talloc(h, &ch.st[i], (size_t)2 * ch.dims[i + 1]))))
           return rc;
       }
     }
+    if (dm.gen_conv && ((rc = talloc(h, &T->Kt, (size_t)cb * 9 * C)) || (rc = talloc(h, &T->Kbv, (size_t)cb * C)) ||
+                        (rc = talloc(h, &T->dKs, (size_t)cb * 9 * C)) || (rc = talloc(h, &T->dkbs, (size_t)cb * C))))
+      return rc;
     T->capB = cb; T->capL = cl;
   }
   auto P_ = [&](const char* n) -> float* { return T->find(n)->p; };
@@ -945,6 +993,7 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
   const int use_batch = tc.batch_norm_train_stats ? 1 : 0;
   int mx = C > d ? C : d;
   for (int i = 0; i < nh; ++i) mx = h->cfg.ctx_out[i] > mx ? h->cfg.ctx_out[i] : mx;
+  for (int i = 0; i < nhc; ++i) mx = h->cfg.ctx_conv[i] > mx ? h->cfg.ctx_conv[i] : mx;
   float *mean1 = T->bnst, *inv1 = T->bnst + mx, *mean2 = T->bnst + 2 * mx, *inv2 = T->bnst + 3 * mx;
   double* red = T->red;         // [0] loss, [1] sumsq, [2 .. 2+2mx) column sums
   double* colsum = red + 2;
@@ -971,27 +1020,15 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
   else if (!lk) COPER_HIP_TRY(h, hipMemsetAsync(G_("fc_bias"), 0, sizeof(float) * d, s));
 
   // ---- forward
-  size_t lds_conv = sizeof(float) * (size_t)(isz + 10 * C);
-  hipLaunchKernelGGL(k_tr_conv_fwd, dim3((unsigned)B), dim3(256), lds_conv, s, e1, rel, ent, relp, P_("conv1_weights"),
-                     P_("conv1_bias"), dm.E, dm.R, d, r, dm.in_h, dm.in_w, dm.stacked ? 1 : 0, C, dm.Ho, dm.Wo, T->img,
-                     gen ? T->c : nullptr, T->y);
-  const int64_t nBF = B * F;
-  if (use_batch) hipLaunchKernelGGL(k_tr_col_sums, dim3(128), dim3(256), 0, s, T->y, B * (int64_t)P, C, colsum);
-  hipLaunchKernelGGL(k_tr_bn_finish, dim3((C + 63) / 64), dim3(64), 0, s, colsum, C, (double)B * P, use_batch,
-                     tc.batch_norm_momentum, 1, const_cast<float*>(h->params["Conv1BN/moving_mean"].ptr),
-                     const_cast<float*>(h->params["Conv1BN/moving_variance"].ptr), mean1, inv1);
-  hipLaunchKernelGGL(k_tr_bn1_fwd, dim3((unsigned)((nBF + 255) / 256)), dim3(256), 0, s, T->y, mean1, inv1, P_("Conv1BN/gamma"),
-                     P_("Conv1BN/beta"), C, nBF, tc.seed, step, thr_h, ks_h, T->x);
-  // ---- g_MLP generator chains: context rows c -> v[nh] (models.py:56-68); g_linear: the context is c itself
   const uint32_t thr_c = dropout_threshold24(tc.context_rel_dropout);
   const float ks_c = 1.f / (1.f - tc.context_rel_dropout);
-  for (int g = 0; g < 2 && nh > 0; ++g) {
+  // g_MLP generator chain g: context rows c -> v[nhx] (models.py:56-68); g_linear: the context is c itself
+  auto chain_forward = [&](int g, int nhx) -> int {
     TrainState::Chain& ch = T->chain[g];
     ch.v[0] = T->c;
-    const char* gname = g == 0 ? "fc_weights" : "fc_bias";
-    for (int i = 0; i < nh; ++i) {
+    for (int i = 0; i < nhx; ++i) {
       const int ni = ch.dims[i], nj = ch.dims[i + 1];
-      const std::string pn = std::string(gname) + "/CPG/Projection" + std::to_string(i);
+      const std::string pn = std::string(kGenNames[g]) + "/CPG/Projection" + std::to_string(i);
       const int64_t tot = B * nj;
       hipLaunchKernelGGL(k_tr_small_mm, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, ch.v[i], P_(pn.c_str()), B, ni, nj, ch.u[i]);
       const float *ga = nullptr, *be = nullptr;
@@ -1007,7 +1044,38 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
       hipLaunchKernelGGL(k_tr_chain_act, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, ch.u[i], ch.st[i], ga, be, nj, tot, tc.seed, step,
                          (uint32_t)(16 + 8 * g + i), thr_c, ks_c, ch.a[i], ch.v[i + 1]);
     }
+    return COPER_OK;
+  };
+  // per-sample conv filters (models.py:231-250,374-380): generated from the relation rows, or looked up
+  const std::string cwlast = "conv1_weights/CPG/Projection" + std::to_string(nhc), cblast = "conv1_bias/CPG/Projection" + std::to_string(nhc);
+  const float *ccw = nullptr, *ccb = nullptr;   // contexts of the conv generators [B, rc_cw], [B, rc_cb]
+  if (genc) {
+    hipLaunchKernelGGL(k_tr_gather_rows, dim3((unsigned)((B * r + 255) / 256)), dim3(256), 0, s, relp, rel, dm.R, r, B * r, T->c);
+    if ((rc = chain_forward(2, nhc)) || (rc = chain_forward(3, nhc))) return rc;
+    ccw = nhc ? T->chain[2].v[nhc] : T->c;
+    ccb = nhc ? T->chain[3].v[nhc] : T->c;
+    hipLaunchKernelGGL(k_tr_small_mm, dim3((unsigned)((B * 9 * C + 255) / 256)), dim3(256), 0, s, ccw, P_(cwlast.c_str()), B, rc_cw, 9 * C, T->Kt);
+    hipLaunchKernelGGL(k_tr_small_mm, dim3((unsigned)((B * C + 255) / 256)), dim3(256), 0, s, ccb, P_(cblast.c_str()), B, rc_cb, C, T->Kbv);
+  } else if (lkc) {
+    hipLaunchKernelGGL(k_tr_gather_rows, dim3((unsigned)((B * 9 * C + 255) / 256)), dim3(256), 0, s, P_("conv1_weights"), rel, dm.R, 9 * C,
+                       B * 9 * C, T->Kt);
+    hipLaunchKernelGGL(k_tr_gather_rows, dim3((unsigned)((B * C + 255) / 256)), dim3(256), 0, s, P_("conv1_bias"), rel, dm.R, C, B * C, T->Kbv);
   }
+  const float* K_ps = dm.gen_conv ? T->Kt : nullptr;
+  const float* kb_ps = dm.gen_conv ? T->Kbv : nullptr;
+  size_t lds_conv = sizeof(float) * (size_t)(isz + 10 * C);
+  hipLaunchKernelGGL(k_tr_conv_fwd, dim3((unsigned)B), dim3(256), lds_conv, s, e1, rel, ent, relp, dm.gen_conv ? nullptr : P_("conv1_weights"),
+                     dm.gen_conv ? nullptr : P_("conv1_bias"), dm.E, dm.R, d, r, dm.in_h, dm.in_w, dm.stacked ? 1 : 0, C, dm.Ho, dm.Wo, T->img,
+                     (gen && !genc) ? T->c : nullptr, T->y, K_ps, kb_ps);
+  const int64_t nBF = B * F;
+  if (genc) COPER_HIP_TRY(h, hipMemsetAsync(colsum, 0, sizeof(double) * 2 * mx, s));   // the conv generators' BN used the scratch
+  if (use_batch) hipLaunchKernelGGL(k_tr_col_sums, dim3(128), dim3(256), 0, s, T->y, B * (int64_t)P, C, colsum);
+  hipLaunchKernelGGL(k_tr_bn_finish, dim3((C + 63) / 64), dim3(64), 0, s, colsum, C, (double)B * P, use_batch,
+                     tc.batch_norm_momentum, 1, const_cast<float*>(h->params["Conv1BN/moving_mean"].ptr),
+                     const_cast<float*>(h->params["Conv1BN/moving_variance"].ptr), mean1, inv1);
+  hipLaunchKernelGGL(k_tr_bn1_fwd, dim3((unsigned)((nBF + 255) / 256)), dim3(256), 0, s, T->y, mean1, inv1, P_("Conv1BN/gamma"),
+                     P_("Conv1BN/beta"), C, nBF, tc.seed, step, thr_h, ks_h, T->x);
+  if (nh > 0 && ((rc = chain_forward(0, nh)) || (rc = chain_forward(1, nh)))) return rc;
   const float* cw = nh ? T->chain[0].v[nh] : T->c;   // [B, rc_w]
   const float* cbv = nh ? T->chain[1].v[nh] : T->c;  // [B, rc_b]
   const int64_t Kd = gen ? (int64_t)rc_w * F : F;           // inner size of the dA GEMM
@@ -1132,13 +1200,12 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
   if (gen)
     hipLaunchKernelGGL(k_tr_outer_bwd, dim3((unsigned)((F + 255) / 256), (unsigned)B), dim3(256), 0, s, T->dA, T->x, cw, F, rc_w, T->dx, dcw);
   }
-  // ---- back through the generator chains to the relation rows
-  for (int g = 0; g < 2 && gen; ++g) {
+  // ---- back through a generator chain to the relation rows: dv[nhx] -> dv[0]
+  auto chain_backward = [&](int g, int nhx) {
     TrainState::Chain& ch = T->chain[g];
-    const char* gname = g == 0 ? "fc_weights" : "fc_bias";
-    for (int i = nh - 1; i >= 0; --i) {
+    for (int i = nhx - 1; i >= 0; --i) {
       const int ni = ch.dims[i], nj = ch.dims[i + 1];
-      const std::string pn = std::string(gname) + "/CPG/Projection" + std::to_string(i);
+      const std::string pn = std::string(kGenNames[g]) + "/CPG/Projection" + std::to_string(i);
       const int64_t tot = B * nj;
       hipLaunchKernelGGL(k_tr_chain_drop_bwd, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, ch.dv[i + 1], tot, tc.seed, step,
                          (uint32_t)(16 + 8 * g + i), thr_c, ks_c, ch.du[i]);
@@ -1155,7 +1222,8 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
       hipLaunchKernelGGL(k_tr_small_mm_nt, dim3((unsigned)((B * ni + 255) / 256)), dim3(256), 0, s, ch.du[i], P_(pn.c_str()), B, ni, nj, 0,
                          ch.dv[i]);
     }
-  }
+  };
+  if (gen) { chain_backward(0, nh); chain_backward(1, nh); }
   COPER_HIP_TRY(h, hipMemsetAsync(colsum, 0, sizeof(double) * 2 * mx, s));
   hipLaunchKernelGGL(k_tr_bn1_bwd_sums, dim3((unsigned)((nBF + 255) / 256 < 1024 ? (nBF + 255) / 256 : 1024)), dim3(256), 0, s, T->dx, T->y, mean1, inv1, P_("Conv1BN/gamma"),
                      P_("Conv1BN/beta"), C, nBF, tc.seed, step, thr_h, ks_h, colsum);
@@ -1163,11 +1231,30 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
                      colsum, C, nBF, (double)B * P, use_batch, G_("Conv1BN/gamma"), G_("Conv1BN/beta"));
   size_t lds_cb = sizeof(float) * (size_t)(isz + (size_t)P * C + 9 * C);
   if (lds_cb > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_tr_conv_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipLaunchKernelGGL(k_tr_conv_bwd, dim3((unsigned)B), dim3(256), lds_cb, s, T->dx, T->img, P_("conv1_weights"), e1, rel, dm.E, dm.R, d, r,
-                     dm.in_h, dm.in_w, dm.stacked ? 1 : 0, C, dm.Ho, dm.Wo, G_("conv1_weights"), G_("conv1_bias"), G_("ent_emb"),
-                     lk ? nullptr : G_("rel_emb"));
-  if (gen)
-    for (int g = 0; g < 2; ++g)
+  hipLaunchKernelGGL(k_tr_conv_bwd, dim3((unsigned)B), dim3(256), lds_cb, s, T->dx, T->img, dm.gen_conv ? nullptr : P_("conv1_weights"), e1, rel,
+                     dm.E, dm.R, d, r, dm.in_h, dm.in_w, dm.stacked ? 1 : 0, C, dm.Ho, dm.Wo, dm.gen_conv ? nullptr : G_("conv1_weights"),
+                     dm.gen_conv ? nullptr : G_("conv1_bias"), G_("ent_emb"), lk ? nullptr : G_("rel_emb"), K_ps,
+                     dm.gen_conv ? T->dKs : nullptr, dm.gen_conv ? T->dkbs : nullptr);
+  if (genc) {
+    // per-sample filter gradients -> last projections and contexts, then back through the conv generators
+    hipLaunchKernelGGL(k_tr_small_mm_tn, dim3((unsigned)(((int64_t)rc_cw * 9 * C + 255) / 256)), dim3(256), 0, s, ccw, T->dKs, B, rc_cw, 9 * C,
+                       G_(cwlast.c_str()));
+    hipLaunchKernelGGL(k_tr_small_mm_nt, dim3((unsigned)((B * rc_cw + 255) / 256)), dim3(256), 0, s, T->dKs, P_(cwlast.c_str()), B, rc_cw, 9 * C,
+                       0, T->chain[2].dv[nhc]);
+    hipLaunchKernelGGL(k_tr_small_mm_tn, dim3((unsigned)(((int64_t)rc_cb * C + 255) / 256)), dim3(256), 0, s, ccb, T->dkbs, B, rc_cb, C,
+                       G_(cblast.c_str()));
+    hipLaunchKernelGGL(k_tr_small_mm_nt, dim3((unsigned)((B * rc_cb + 255) / 256)), dim3(256), 0, s, T->dkbs, P_(cblast.c_str()), B, rc_cb, C, 0,
+                       T->chain[3].dv[nhc]);
+    chain_backward(2, nhc);
+    chain_backward(3, nhc);
+  } else if (lkc) {
+    // table rows: d(conv1_weights)[rel[b]] += dK[b] (the table gradients were zeroed above)
+    hipLaunchKernelGGL(k_tr_scatter_rows, dim3((unsigned)((B * 9 * C + 255) / 256)), dim3(256), 0, s, T->dKs, rel, dm.R, 9 * C, B * 9 * C,
+                       G_("conv1_weights"));
+    hipLaunchKernelGGL(k_tr_scatter_rows, dim3((unsigned)((B * C + 255) / 256)), dim3(256), 0, s, T->dkbs, rel, dm.R, C, B * C, G_("conv1_bias"));
+  }
+  for (int g = 0; g < 4; ++g)
+    if (g < 2 ? gen : genc)
       hipLaunchKernelGGL(k_tr_scatter_rows, dim3((unsigned)((B * r + 255) / 256)), dim3(256), 0, s, T->chain[g].dv[0], rel, dm.R, r, B * r,
                          G_("rel_emb"));
 

@@ -50,7 +50,7 @@ def dropout_keep(seed: int, step: int, stage: int, n: int, rate: float) -> np.nd
 
 def _generate(p, md, name, c, train_stats, keep_ctx, stats, dtype):
     """ContextualParameterGenerator.generate (models.py:56-70) in train mode; keep_ctx[(name, i)] = 0/1 dropout mask."""
-    ctx = list(md["context_rel_out"])
+    ctx = list(md["context_rel_conv"] if name.startswith("conv1") else md["context_rel_out"])
     use_bn = bool(md.get("context_rel_use_batch_norm", False))
     rate = float(md.get("context_rel_dropout", 0.0))
     v = c
@@ -80,8 +80,8 @@ def forward_train(p, md, batch, keep_hidden, keep_out, dtype=torch.float64, keep
     C = int(md.get("conv_num_channels", 32))
     ctx_conv, ctx_out = md.get("context_rel_conv", None), md.get("context_rel_out", None)
     lookup_params = bool(md.get("do_parameter_lookup", False))
-    if ctx_conv is not None or md.get("concat_rel", False) or (lookup_params and ctx_out is None):
-        raise NotImplementedError("training oracle: static conv filters, no concat_rel")
+    if md.get("concat_rel", False) or (lookup_params and ctx_out is None) or (ctx_conv is not None and ctx_out is None):
+        raise NotImplementedError("training oracle: no concat_rel; generated / looked-up conv filters only together with the dense layer")
     train_stats = bool(md.get("batch_norm_train_stats", False))
     e1 = torch.as_tensor(batch["e1"]).long()
     rel = torch.as_tensor(batch["rel"]).long()
@@ -93,14 +93,26 @@ def forward_train(p, md, batch, keep_hidden, keep_out, dtype=torch.float64, keep
     img = x0.reshape(B, H, Wd)
     if ctx_out is None:                                     # plain ConvE: stack the relation image (models.py:360-362)
         img = torch.cat([img, c.reshape(B, H, r // H)], dim=1)
-    K = p["conv1_weights"].reshape(3, 3, C)
+    stats = {}
     Ho, Wo = img.shape[1] - 2, img.shape[2] - 2
     y = torch.zeros((B, Ho, Wo, C), dtype=dtype)
-    for u in range(3):
-        for v in range(3):
-            y = y + img[:, u:u + Ho, v:v + Wo, None] * K[u, v][None, None, None, :]
-    y = y + p["conv1_bias"]
-    stats = {}
+    if ctx_conv is None:
+        K = p["conv1_weights"].reshape(3, 3, C)
+        for u in range(3):
+            for v in range(3):
+                y = y + img[:, u:u + Ho, v:v + Wo, None] * K[u, v][None, None, None, :]
+        y = y + p["conv1_bias"]
+    else:                                                   # per-sample filters (models.py:374-380)
+        if lookup_params:
+            Kb_ = p["conv1_weights"][rel].reshape(B, 3, 3, C)
+            kb_ = p["conv1_bias"][rel]
+        else:
+            Kb_ = _generate(p, md, "conv1_weights", c, train_stats, keep_ctx, stats, dtype).reshape(B, 3, 3, C)
+            kb_ = _generate(p, md, "conv1_bias", c, train_stats, keep_ctx, stats, dtype)
+        for u in range(3):
+            for v in range(3):
+                y = y + img[:, u:u + Ho, v:v + Wo, None] * Kb_[:, u, v][:, None, None, :]
+        y = y + kb_[:, None, None, :]
     if train_stats:
         m1 = y.mean(dim=(0, 1, 2))
         v1 = ((y - m1) ** 2).mean(dim=(0, 1, 2))
@@ -150,19 +162,26 @@ TRAINABLE_STATIC = ["ent_emb", "rel_emb", "conv1_weights", "conv1_bias", "pred_b
 
 def trainable_names(md):
     names = list(TRAINABLE_STATIC)
+    gen_conv = md.get("context_rel_conv", None) is not None
     if md.get("do_parameter_lookup", False):
         names.remove("rel_emb")
-        names += ["fc_weights", "fc_bias"]
+        names += ["fc_weights", "fc_bias"]            # tables; conv1_weights / conv1_bias are tables too when looked up
         return names
+    gens = []
     if md.get("context_rel_out", None) is None:
         names += ["fc_weights", "fc_bias"]
     else:
-        nh = len(md["context_rel_out"])
-        for g in ("fc_weights", "fc_bias"):
-            for i in range(nh + 1):
-                names.append("%s/CPG/Projection%d" % (g, i))
-                if i < nh and md.get("context_rel_use_batch_norm", False):
-                    names += ["%s/CPG/Projection%d/BatchNorm/gamma" % (g, i), "%s/CPG/Projection%d/BatchNorm/beta" % (g, i)]
+        gens += [("fc_weights", md["context_rel_out"]), ("fc_bias", md["context_rel_out"])]
+    if gen_conv:
+        names.remove("conv1_weights")
+        names.remove("conv1_bias")
+        gens += [("conv1_weights", md["context_rel_conv"]), ("conv1_bias", md["context_rel_conv"])]
+    for g, ctx in gens:
+        nh = len(ctx)
+        for i in range(nh + 1):
+            names.append("%s/CPG/Projection%d" % (g, i))
+            if i < nh and md.get("context_rel_use_batch_norm", False):
+                names += ["%s/CPG/Projection%d/BatchNorm/gamma" % (g, i), "%s/CPG/Projection%d/BatchNorm/beta" % (g, i)]
     return names
 
 
@@ -205,8 +224,10 @@ def train_step(params_np, md, batch, opt: AMSGrad, seed, step, momentum):
     kh = dropout_keep(seed, step, 1, B * F, float(md.get("hidden_dropout", 0.0)))
     ko = dropout_keep(seed, step, 2, B * d, float(md.get("output_dropout", 0.0)))
     kc = {}
-    ctx = [] if md.get("do_parameter_lookup", False) else (md.get("context_rel_out", None) or [])
-    for gi, g in enumerate(("fc_weights", "fc_bias")):
+    lk = md.get("do_parameter_lookup", False)
+    ctx_o = [] if lk else (md.get("context_rel_out", None) or [])
+    ctx_c = [] if lk else (md.get("context_rel_conv", None) or [])
+    for gi, (g, ctx) in enumerate((("fc_weights", ctx_o), ("fc_bias", ctx_o), ("conv1_weights", ctx_c), ("conv1_bias", ctx_c))):
         for i, n in enumerate(ctx):
             kc[(g, i)] = dropout_keep(seed, step, 16 + 8 * gi + i, B * int(n), float(md.get("context_rel_dropout", 0.0)))
     loss, stats, _, _ = forward_train(p, md, batch, kh, ko, keep_ctx=kc)
