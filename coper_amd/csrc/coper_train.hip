@@ -1,17 +1,20 @@
 // Training step (include/coper_hip.h "Training step").  fp32 throughout.
 //
 //   forward (train mode, models.py:354-426,438-443):
+//     c = rel_emb[rel]; generator chains (g_MLP: projection, BN with batch statistics, ReLU, dropout per hidden layer)
+//     conv filters: static, generated per sample (c or chain output times the last projection) or looked up
 //     img = ent_emb[e1] (+ rel_emb[rel] stacked below it for plain ConvE)            k_tr_conv_fwd
-//     y   = conv3x3(img) + conv1_bias                      [B, P = Ho*Wo, C]          k_tr_conv_fwd
+//     y   = conv3x3(img) + bias                             [B, P = Ho*Wo, C]          k_tr_conv_fwd
 //     Conv1BN (batch statistics when batch_norm_train_stats), ReLU, dropout -> x [B, F]   k_tr_bn1_fwd
-//     dense: static z0 = x W, generated z0 = (x (x) c) P2 with P2 = Projection0 viewed [r*F, d]
-//            -- the FACTORED form: the [B,F,d] weight tensor of models.py:70,412 is never formed;
-//            one sgemm over K = r*F (rocBLAS, loaded lazily: a plain library GEMM)
+//     dense: static z0 = x W (one GEMM); generated z[b] = sum_rho ctx[b,rho] (x[b] P[rho]) -- the FACTORED form: r
+//            independent [B,F]x[F,d] products (one strided-batched GEMM), the [B,F,d] weight tensor of
+//            models.py:70,412 is never formed; g_lookup: one pass over the looked-up [F,d] rows  (k_tr_lookup_*)
 //     + dense bias, dropout, FCBN, ReLU -> h [B, d]                                   k_tr_fc_post, k_tr_fcbn_fwd
-//     s[b,l] = h[b] . ent_emb[lookup[b,l]] + pred_bias[lookup[b,l]];  loss; ds        k_tr_score_loss
-//   backward: the transposes of the above (dense: dA = dz P2^T, dP2 = A^T dz, two more sgemms), embedding rows
-//   by float atomics (as tf.scatter_add on a GPU, the summation order is not fixed).
-//   optimiser: tf.clip_by_global_norm + AMSGrad (amsgrad.py:130-159), one fused kernel per parameter.
+//     sampled scorer s[b,l] = h[b] . ent_emb[lookup[b,l]] + pred_bias[...] (k_tr_score_loss) or 1-vs-all (GEMM)
+//   backward: the transposes of the above (dense: dP[rho] = x^T (ctx[:,rho] . dz) batched, dA = dz P2^T one GEMM, then
+//   the contraction with ctx / x); embedding-row gradients by float atomics or, when B*|E| is small, through a dense
+//   d(loss)/d(logits) matrix and one GEMM.  GEMMs are rocBLAS (dlopen'ed: plain library GEMMs).
+//   optimiser: tf.clip_by_global_norm + AMSGrad (amsgrad.py:130-159), one launch each over all tensors.
 #include <dlfcn.h>
 
 #include <cmath>
@@ -90,7 +93,6 @@ struct TrainState {
   float *z0 = nullptr, *z1 = nullptr, *hv = nullptr, *dh = nullptr, *dz = nullptr, *ds = nullptr, *dx = nullptr, *dc = nullptr;
   double* red = nullptr;     // reduction scratch: [0] loss, [1] grad sumsq, [2..] BN sums
   float* bnst = nullptr;     // [4][max(C,d)]: mean1, inv1, mean2, inv2 ... see offsets below
-  float* zero_row = nullptr;
   TrainParam* find(const char* name) {
     for (auto& t : tp)
       if (t.name == name) return &t;
