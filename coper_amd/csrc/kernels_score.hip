@@ -508,6 +508,76 @@ __global__ __launch_bounds__(256) void k_topk_select(float* __restrict__ logits,
   }
 }
 
+
+// Single-pass variant for k <= 32: every thread keeps the top-k of its strided share of the row in LDS (sorted,
+// score descending then index ascending), then k rounds of a 256-way arg-max over the heads of those lists pick the
+// row's top-k in order -- the row is read once instead of k times.  Same results as k_topk_select (ties by index).
+constexpr int TOPK_SMALL_MAX = 32;
+__global__ __launch_bounds__(256) void k_topk_select_small(const float* __restrict__ logits, int64_t ld, int64_t n_local,
+                                                           int64_t lo, int k, float* __restrict__ out_val,
+                                                           int64_t* __restrict__ out_idx, int64_t b0) {
+  extern __shared__ float tk_lds[];          // val[k][256] | idx[k][256] | red_val[256] | red_idx[256]
+  float* lv = tk_lds;
+  int* li = (int*)(tk_lds + k * 256);
+  float* rv = tk_lds + 2 * k * 256;
+  int* ri = (int*)(rv + 256);
+  const int tid = threadIdx.x;
+  const float* row = logits + (int64_t)blockIdx.x * ld;
+  const int64_t b = b0 + blockIdx.x;
+  for (int s = 0; s < k; ++s) { lv[s * 256 + tid] = -INFINITY; li[s * 256 + tid] = 0x7fffffff; }
+  float worst = -INFINITY;                   // value of the thread's k-th entry
+  int worst_i = 0x7fffffff;
+  for (int64_t j0 = tid; j0 < n_local; j0 += 256 * 8) {
+    float vb[8];   // eight independent loads in flight, then the (data-dependent) insertions
+#pragma unroll
+    for (int u = 0; u < 8; ++u) vb[u] = j0 + 256 * u < n_local ? row[j0 + 256 * u] : -INFINITY;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+    const float v = vb[u];
+    const int64_t j = j0 + 256 * u;
+    if (!(v > -INFINITY)) continue;
+    if (v < worst || (v == worst && (int)j > worst_i)) continue;
+    // insert (v, j) into the sorted list
+    int pos = k - 1;
+    while (pos > 0) {
+      const float pv = lv[(pos - 1) * 256 + tid];
+      const int pi = li[(pos - 1) * 256 + tid];
+      if (pv > v || (pv == v && pi < (int)j)) break;
+      lv[pos * 256 + tid] = pv;
+      li[pos * 256 + tid] = pi;
+      --pos;
+    }
+    lv[pos * 256 + tid] = v;
+    li[pos * 256 + tid] = (int)j;
+    worst = lv[(k - 1) * 256 + tid];
+    worst_i = li[(k - 1) * 256 + tid];
+    }
+  }
+  int head = 0;
+  for (int round = 0; round < k; ++round) {
+    rv[tid] = head < k ? lv[head * 256 + tid] : -INFINITY;
+    ri[tid] = head < k ? li[head * 256 + tid] : 0x7fffffff;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+      if (tid < off) {
+        const float v2 = rv[tid + off];
+        const int i2 = ri[tid + off];
+        if (v2 > rv[tid] || (v2 == rv[tid] && i2 < ri[tid])) { rv[tid] = v2; ri[tid] = i2; }
+      }
+      __syncthreads();
+    }
+    const float bv = rv[0];
+    const int bi = ri[0];
+    const bool ok = bi != 0x7fffffff && bv > -INFINITY;
+    if (tid == 0) {
+      out_val[b * k + round] = ok ? bv : -INFINITY;
+      out_idx[b * k + round] = ok ? lo + bi : -1;
+    }
+    if (ok && head < k && li[head * 256 + tid] == bi) ++head;   // the owner of the winner advances
+    __syncthreads();
+  }
+}
+
 int launch_topk(coper_handle* h, const float* hvec, const int64_t* e2, const int64_t* indptr, const int64_t* idx,
                 int64_t B, int k, float* topk_val, int64_t* topk_idx, float* logits_ws, int64_t chunk_rows,
                 hipStream_t s) {
@@ -519,8 +589,12 @@ int launch_topk(coper_handle* h, const float* hvec, const int64_t* e2, const int
     int64_t threads = nb * 16;
     hipLaunchKernelGGL(k_mask_filtered, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, logits_ws, dm.n_local,
                        e2, indptr, idx, b0, nb, (int64_t)h->cfg.shard_lo, dm.n_local);
-    hipLaunchKernelGGL(k_topk_select, dim3((unsigned)nb), dim3(256), 0, s, logits_ws, dm.n_local, dm.n_local,
-                       (int64_t)h->cfg.shard_lo, k, topk_val, topk_idx, b0);
+    if (k <= TOPK_SMALL_MAX)
+      hipLaunchKernelGGL(k_topk_select_small, dim3((unsigned)nb), dim3(256), sizeof(float) * (size_t)(2 * k + 2) * 256, s, logits_ws,
+                         dm.n_local, dm.n_local, (int64_t)h->cfg.shard_lo, k, topk_val, topk_idx, b0);
+    else
+      hipLaunchKernelGGL(k_topk_select, dim3((unsigned)nb), dim3(256), 0, s, logits_ws, dm.n_local, dm.n_local,
+                         (int64_t)h->cfg.shard_lo, k, topk_val, topk_idx, b0);
     COPER_HIP_TRY(h, hipGetLastError());
   }
   return COPER_OK;
