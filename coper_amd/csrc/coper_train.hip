@@ -6,6 +6,7 @@
 //     img = ent_emb[e1] (+ rel_emb[rel] stacked below it for plain ConvE)            k_tr_conv_fwd
 //     y   = conv3x3(img) + bias                             [B, P = Ho*Wo, C]          k_tr_conv_fwd
 //     Conv1BN (batch statistics when batch_norm_train_stats), ReLU, dropout -> x [B, F]   k_tr_bn1_fwd
+//     concat_rel: x = [x | c]                                                          k_tr_concat / k_tr_split
 //     dense: static z0 = x W (one GEMM); generated z[b] = sum_rho ctx[b,rho] (x[b] P[rho]) -- the FACTORED form: r
 //            independent [B,F]x[F,d] products (one strided-batched GEMM), the [B,F,d] weight tensor of
 //            models.py:70,412 is never formed; g_lookup: one pass over the looked-up [F,d] rows  (k_tr_lookup_*)
@@ -73,6 +74,7 @@ struct TrainState {
   int64_t capB = 0, capL = 0;
   // workspaces
   float *img = nullptr, *y = nullptr, *x = nullptr, *c = nullptr, *dA = nullptr;
+  float *xc = nullptr, *dxc = nullptr;   // concat_rel: [B, F_conv + r] input of the dense layer and its gradient
   // g_MLP generator chains (models.py:56-70), one for fc_weights (0) and one for fc_bias (1):
   //   v[0] = c;  u[i] = v[i] P_i;  a[i] = relu(BN_i(u[i]));  v[i+1] = dropout(a[i]);  context = v[nh]
   struct Chain {
@@ -728,6 +730,27 @@ __global__ __launch_bounds__(256) void k_tr_gather_rows(const float* __restrict_
   out[i] = table[rid * n + i % n];
 }
 
+// concat_rel (models.py:406-407): xc[b] = [x[b] | c[b]], after the hidden dropout
+__global__ __launch_bounds__(256) void k_tr_concat(const float* __restrict__ x, const float* __restrict__ c, int64_t Fc, int r, int64_t total,
+                                                   float* __restrict__ xc) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int64_t b = i / (Fc + r), f = i - b * (Fc + r);
+  xc[i] = f < Fc ? x[b * Fc + f] : c[b * r + (f - Fc)];
+}
+
+// ... and back: dx[b] = dxc[b, :Fc];  drel_emb[rel[b], :] += dxc[b, Fc:]
+__global__ __launch_bounds__(256) void k_tr_split(const float* __restrict__ dxc, const int64_t* __restrict__ rel, int64_t R, int64_t Fc, int r,
+                                                  int64_t total, float* __restrict__ dx, float* __restrict__ drel) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int64_t b = i / (Fc + r), f = i - b * (Fc + r);
+  if (f < Fc) { dx[b * Fc + f] = dxc[i]; return; }
+  int64_t rid = rel[b];
+  if (rid < 0 || rid >= R) rid = 0;
+  atomicAdd(&drel[rid * r + (f - Fc)], dxc[i]);
+}
+
 // drel_emb[rel[b], :] += dc[b, :]
 __global__ __launch_bounds__(256) void k_tr_scatter_rows(const float* __restrict__ dc, const int64_t* __restrict__ rel, int64_t R,
                                                          int r, int64_t total, float* __restrict__ drel) {
@@ -809,7 +832,7 @@ void train_destroy(coper_handle* h) {
   TrainState* T = (TrainState*)h->train;
   if (!T) return;
   for (auto& t : T->tp) { (void)hipFree(t.g); (void)hipFree(t.m); (void)hipFree(t.v); (void)hipFree(t.vh); }
-  float* bufs[] = {T->Kt, T->Kbv, T->dKs, T->dkbs, T->Sd, T->img, T->y, T->x, T->c, T->A, T->dA, T->z0, T->z1, T->hv, T->dh, T->dz, T->ds, T->dx, T->dc, T->bnst};
+  float* bufs[] = {T->Kt, T->Kbv, T->dKs, T->dkbs, T->Sd, T->img, T->y, T->x, T->c, T->A, T->dA, T->z0, T->z1, T->hv, T->dh, T->dz, T->ds, T->dx, T->dc, T->bnst, T->xc, T->dxc};
   for (float* b : bufs) (void)hipFree(b);
   for (auto& ch : T->chain)
     for (int i = 0; i <= COPER_MAX_CTX; ++i) {
@@ -834,11 +857,8 @@ COPER_API int coper_train_init(coper_handle* h, const coper_train_config* cfg) {
   if (!h || !cfg) return COPER_EINVAL;
   if (cfg->abi_version != COPER_ABI_VERSION) return fail(h, COPER_EINVAL, "coper_train_init: ABI version mismatch");
   const Dims& dm = h->dm;
-  if (dm.concat_rel || (dm.lookup && !dm.gen_fc) || (dm.gen_conv && !dm.gen_fc))
-    return fail(h, COPER_EUNSUPPORTED,
-                "coper_train_init: this version trains static, g_linear, g_MLP or g_lookup dense layers, with static conv "
-                "filters or conv filters generated / looked up the same way (no concat_rel; no generated conv without a "
-                "generated dense layer)");
+  if (dm.lookup && !dm.gen_fc)
+    return fail(h, COPER_EUNSUPPORTED, "coper_train_init: g_lookup is trained with a looked-up dense layer (context_rel_out set)");
   if (h->cfg.shard_lo != 0 || h->cfg.shard_hi != dm.E)
     return fail(h, COPER_EUNSUPPORTED, "coper_train_init: training needs the whole entity table on the handle");
   if (dm.fh != 3 || dm.fw != 3 || 256 % dm.C != 0 || dm.d > 256)
@@ -948,7 +968,8 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
   h->prepared = false;   // the variables change: per-relation caches, fragment images and folded BN go stale
   const coper_train_config& tc = T->cfg;
   const int d = dm.d, r = dm.r, C = dm.C, P = dm.Ho * dm.Wo, isz = dm.in_h * dm.in_w;
-  const int64_t F = dm.F;
+  const int64_t F = dm.F, Fc = dm.F_conv;   // dense input width (F_conv + r under concat_rel), conv features
+  const bool cat = dm.concat_rel;
   const bool lk = dm.lookup;
   const bool gen = dm.gen_fc && !lk;
   const bool genc = dm.gen_conv && !lk;     // conv filters from projection generators
@@ -970,6 +991,7 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
         (rc = talloc(h, &T->hv, (size_t)cb * d)) || (rc = talloc(h, &T->dh, (size_t)cb * d)) ||
         (rc = talloc(h, &T->dz, (size_t)cb * d)) || (rc = talloc(h, &T->ds, (size_t)cb * (one_vs_all ? 1 : cl))))
       return rc;
+    if (cat && ((rc = talloc(h, &T->xc, (size_t)cb * F)) || (rc = talloc(h, &T->dxc, (size_t)cb * F)))) return rc;
     if (gen && ((rc = talloc(h, &T->A, (size_t)2 * rc_w * cb * d)) || (rc = talloc(h, &T->dA, (size_t)cb * rc_w * F)))) return rc;
     for (int g = 0; g < 4; ++g) {
       if (g < 2 ? !gen : !genc) continue;
@@ -1068,8 +1090,8 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
   size_t lds_conv = sizeof(float) * (size_t)(isz + 10 * C);
   hipLaunchKernelGGL(k_tr_conv_fwd, dim3((unsigned)B), dim3(256), lds_conv, s, e1, rel, ent, relp, dm.gen_conv ? nullptr : P_("conv1_weights"),
                      dm.gen_conv ? nullptr : P_("conv1_bias"), dm.E, dm.R, d, r, dm.in_h, dm.in_w, dm.stacked ? 1 : 0, C, dm.Ho, dm.Wo, T->img,
-                     (gen && !genc) ? T->c : nullptr, T->y, K_ps, kb_ps);
-  const int64_t nBF = B * F;
+                     ((gen || cat) && !genc) ? T->c : nullptr, T->y, K_ps, kb_ps);
+  const int64_t nBF = B * Fc;
   if (genc) COPER_HIP_TRY(h, hipMemsetAsync(colsum, 0, sizeof(double) * 2 * mx, s));   // the conv generators' BN used the scratch
   if (use_batch) hipLaunchKernelGGL(k_tr_col_sums, dim3(128), dim3(256), 0, s, T->y, B * (int64_t)P, C, colsum);
   hipLaunchKernelGGL(k_tr_bn_finish, dim3((C + 63) / 64), dim3(64), 0, s, colsum, C, (double)B * P, use_batch,
@@ -1077,6 +1099,9 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
                      const_cast<float*>(h->params["Conv1BN/moving_variance"].ptr), mean1, inv1);
   hipLaunchKernelGGL(k_tr_bn1_fwd, dim3((unsigned)((nBF + 255) / 256)), dim3(256), 0, s, T->y, mean1, inv1, P_("Conv1BN/gamma"),
                      P_("Conv1BN/beta"), C, nBF, tc.seed, step, thr_h, ks_h, T->x);
+  if (cat) hipLaunchKernelGGL(k_tr_concat, dim3((unsigned)((B * F + 255) / 256)), dim3(256), 0, s, T->x, T->c, Fc, r, B * F, T->xc);
+  const float* xin = cat ? T->xc : T->x;   // [B, F]
+  float* dxin = cat ? T->dxc : T->dx;
   if (nh > 0 && ((rc = chain_forward(0, nh)) || (rc = chain_forward(1, nh)))) return rc;
   const float* cw = nh ? T->chain[0].v[nh] : T->c;   // [B, rc_w]
   const float* cbv = nh ? T->chain[1].v[nh] : T->c;  // [B, rc_b]
@@ -1095,13 +1120,13 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
   } else {
     if (gen) {
       // T[rho] = x P[rho]: r independent [B,F]x[F,d] products fill the chip (a single GEMM over K = r*F has 8 tiles)
-      if ((rc = rb_check(h, T->rb.sgemm_sb(T->rb.handle, RB_N, RB_N, d, (int)B, (int)F, &one, Wmat, d, F * (int64_t)d, T->x, (int)F, 0, &zero,
+      if ((rc = rb_check(h, T->rb.sgemm_sb(T->rb.handle, RB_N, RB_N, d, (int)B, (int)F, &one, Wmat, d, F * (int64_t)d, xin, (int)F, 0, &zero,
                                             Tf, d, nBd, rc_w),
                          "sgemm_strided_batched forward")))
         return rc;
     } else {
       // z0[B,d] = x[B,F] W[F,d]   (row-major operands seen as column-major transposes)
-      if ((rc = rb_check(h, T->rb.sgemm(T->rb.handle, RB_N, RB_N, d, (int)B, (int)F, &one, Wmat, d, T->x, (int)F, &zero, T->z0, d),
+      if ((rc = rb_check(h, T->rb.sgemm(T->rb.handle, RB_N, RB_N, d, (int)B, (int)F, &one, Wmat, d, xin, (int)F, &zero, T->z0, d),
                          "sgemm forward")))
         return rc;
     }
@@ -1186,21 +1211,22 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
   if (gen) {
     // dP[rho] = x^T dT[rho],  dT[rho][b,:] = cw[b,rho] dz[b,:]
     hipLaunchKernelGGL(k_tr_scale_rows, dim3((unsigned)((nBd + 255) / 256)), dim3(256), 0, s, T->dz, cw, rc_w, d, nBd, dTf);
-    if ((rc = rb_check(h, T->rb.sgemm_sb(T->rb.handle, RB_N, RB_T, d, (int)F, (int)B, &one, dTf, d, nBd, T->x, (int)F, 0, &zero, dW, d,
+    if ((rc = rb_check(h, T->rb.sgemm_sb(T->rb.handle, RB_N, RB_T, d, (int)F, (int)B, &one, dTf, d, nBd, xin, (int)F, 0, &zero, dW, d,
                                           F * (int64_t)d, rc_w),
                        "sgemm_strided_batched dP")))
       return rc;
   } else {
     // dW[F,d] = x^T dz
-    if ((rc = rb_check(h, T->rb.sgemm(T->rb.handle, RB_N, RB_T, d, (int)F, (int)B, &one, T->dz, d, T->x, (int)F, &zero, dW, d), "sgemm dW")))
+    if ((rc = rb_check(h, T->rb.sgemm(T->rb.handle, RB_N, RB_T, d, (int)F, (int)B, &one, T->dz, d, xin, (int)F, &zero, dW, d), "sgemm dW")))
       return rc;
   }
   // dA[B,Kd] = dz W^T
-  float* dAmat = gen ? T->dA : T->dx;
+  float* dAmat = gen ? T->dA : dxin;
   if ((rc = rb_check(h, T->rb.sgemm(T->rb.handle, RB_T, RB_N, (int)Kd, (int)B, d, &one, Wmat, d, T->dz, d, &zero, dAmat, (int)Kd), "sgemm dA")))
     return rc;
   if (gen)
-    hipLaunchKernelGGL(k_tr_outer_bwd, dim3((unsigned)((F + 255) / 256), (unsigned)B), dim3(256), 0, s, T->dA, T->x, cw, F, rc_w, T->dx, dcw);
+    hipLaunchKernelGGL(k_tr_outer_bwd, dim3((unsigned)((F + 255) / 256), (unsigned)B), dim3(256), 0, s, T->dA, xin, cw, F, rc_w, dxin, dcw);
+  if (cat) hipLaunchKernelGGL(k_tr_split, dim3((unsigned)((B * F + 255) / 256)), dim3(256), 0, s, T->dxc, rel, dm.R, Fc, r, B * F, T->dx, G_("rel_emb"));
   }
   // ---- back through a generator chain to the relation rows: dv[nhx] -> dv[0]
   auto chain_backward = [&](int g, int nhx) {

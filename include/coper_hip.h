@@ -196,8 +196,8 @@ COPER_API int coper_profile_read(coper_handle* h, const char* kernel, double* to
  * Training step: replaces `session.run(model.train_op)` of run_cpg.py:211-219, i.e.
  * models.py:176-200 (train-mode forward, sampled scorer, label-smoothed sigmoid cross-entropy),
  * tf.clip_by_global_norm(5.0) (models.py:199) and utils/amsgrad.py:130-189.
- * Supported in this version: static (plain ConvE), g_linear / g_MLP generated or g_lookup dense layer, with static
- * conv filters or conv filters generated / looked up the same way; no concat_rel (COPER_EUNSUPPORTED).
+ * Supported: static (plain ConvE), g_linear / g_MLP generated or g_lookup dense layer; static, generated or
+ * looked-up conv filters; concat_rel.  Looked-up conv filters with a static dense layer: COPER_EUNSUPPORTED.
  * The parameters registered with coper_set_param are UPDATED IN PLACE (they are the variables), including
  * the BN moving statistics; the caches built by coper_prepare go stale, so the handle must be prepared
  * again before the next inference call (enforced).

@@ -80,8 +80,8 @@ def forward_train(p, md, batch, keep_hidden, keep_out, dtype=torch.float64, keep
     C = int(md.get("conv_num_channels", 32))
     ctx_conv, ctx_out = md.get("context_rel_conv", None), md.get("context_rel_out", None)
     lookup_params = bool(md.get("do_parameter_lookup", False))
-    if md.get("concat_rel", False) or (lookup_params and ctx_out is None) or (ctx_conv is not None and ctx_out is None):
-        raise NotImplementedError("training oracle: no concat_rel; generated / looked-up conv filters only together with the dense layer")
+    if lookup_params and (ctx_out is None or md.get("concat_rel", False)):
+        raise NotImplementedError("training oracle: g_lookup needs the looked-up dense layer and cannot concat_rel (models.py:180,406)")
     train_stats = bool(md.get("batch_norm_train_stats", False))
     e1 = torch.as_tensor(batch["e1"]).long()
     rel = torch.as_tensor(batch["rel"]).long()
@@ -91,7 +91,7 @@ def forward_train(p, md, batch, keep_hidden, keep_out, dtype=torch.float64, keep
     x0 = p["ent_emb"][e1]
     c = None if lookup_params else p["rel_emb"][rel]          # g_lookup passes the ids through (models.py:180)
     img = x0.reshape(B, H, Wd)
-    if ctx_out is None:                                     # plain ConvE: stack the relation image (models.py:360-362)
+    if ctx_out is None and ctx_conv is None:                # plain ConvE: stack the relation image (models.py:360-362)
         img = torch.cat([img, c.reshape(B, H, r // H)], dim=1)
     stats = {}
     Ho, Wo = img.shape[1] - 2, img.shape[2] - 2
@@ -125,6 +125,8 @@ def forward_train(p, md, batch, keep_hidden, keep_out, dtype=torch.float64, keep
     hd = float(md.get("hidden_dropout", 0.0))
     x = y.reshape(B, -1)
     x = x * torch.as_tensor(keep_hidden.reshape(B, -1)).to(dtype) / (1.0 - hd)
+    if md.get("concat_rel", False):                         # models.py:406-407 (after the dropout)
+        x = torch.cat([x, c], dim=1)
     F = x.shape[1]
     if ctx_out is None:
         z = x @ p["fc_weights"] + p["fc_bias"]
@@ -219,7 +221,7 @@ def train_step(params_np, md, batch, opt: AMSGrad, seed, step, momentum):
     H = int(md.get("emb_h", 10))
     d, r = int(md["ent_emb_size"]), int(md["rel_emb_size"])
     C = int(md.get("conv_num_channels", 32))
-    in_h = H * 2 if md.get("context_rel_out", None) is None else H
+    in_h = H * 2 if (md.get("context_rel_out", None) is None and md.get("context_rel_conv", None) is None) else H
     F = (in_h - 2) * (d // H - 2) * C
     kh = dropout_keep(seed, step, 1, B * F, float(md.get("hidden_dropout", 0.0)))
     ko = dropout_keep(seed, step, 2, B * d, float(md.get("output_dropout", 0.0)))

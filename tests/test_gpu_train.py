@@ -26,6 +26,13 @@ _CASES = {
                          context_rel_conv=[5], context_rel_out=[7], context_rel_use_batch_norm=True, context_rel_dropout=0.2),
     "lookup_conv": dict(num_ent=211, num_rel=6, ent_emb_size=40, rel_emb_size=1, emb_h=10, emb_w=4, conv_num_channels=8,
                         context_rel_conv=[], context_rel_out=[], do_parameter_lookup=True),
+    "cpg_linear_concat": dict(num_ent=211, num_rel=6, ent_emb_size=40, rel_emb_size=8, emb_h=10, emb_w=4, conv_num_channels=8,
+                              context_rel_conv=None, context_rel_out=[], concat_rel=True),
+    "plain_concat": dict(num_ent=211, num_rel=6, ent_emb_size=40, rel_emb_size=40, emb_h=10, emb_w=4, conv_num_channels=8,
+                         context_rel_conv=None, context_rel_out=None, concat_rel=True),
+    "cpg_conv_static_fc": dict(num_ent=211, num_rel=6, ent_emb_size=40, rel_emb_size=8, emb_h=10, emb_w=4, conv_num_channels=8,
+                               context_rel_conv=[6], context_rel_out=None, concat_rel=True, context_rel_use_batch_norm=True,
+                               context_rel_dropout=0.1),
     "cpg_linear_c32": dict(num_ent=157, num_rel=4, ent_emb_size=80, rel_emb_size=4, emb_h=10, emb_w=8, conv_num_channels=32,
                            context_rel_conv=None, context_rel_out=[]),
 }
@@ -111,12 +118,12 @@ def test_train_rejects_unsupported_variants_and_order():
     from coper_amd.models import ConvE
     from coper_amd._lib import CoperError
     md = dict(cdata._COMMON)
-    md.update(num_ent=50, num_rel=4, ent_emb_size=40, rel_emb_size=8, emb_h=10, emb_w=4, conv_num_channels=8,
-              context_rel_conv=[], context_rel_out=[], concat_rel=True)
+    md.update(num_ent=50, num_rel=4, ent_emb_size=40, rel_emb_size=1, emb_h=10, emb_w=4, conv_num_channels=8,
+              context_rel_conv=[], context_rel_out=None, do_parameter_lookup=True)
     m = ConvE(md, device="cuda:0")
     m.load_parameters(cdata.synthetic_params(md, seed=1))
     with pytest.raises(CoperError):
-        m.train_init()                      # concat_rel: not in this version
+        m.train_init()                      # looked-up conv filters with a static dense layer: not in this version
     with pytest.raises(CoperError):
         m.train_step(_batch(md, 4, 5, 0))   # no train_init
     m.close()
