@@ -4,7 +4,8 @@
     `[rel_emb, ent_emb]`, or `ent_emb` alone for g_lookup models,
   * the state_dict of the reference's PyTorch sister models (`CoPER_MINERVA/src/emb/fact_network.py`
     `ConvE` :116-197 and `CPG_ConvE` :261-439), whose tensors are re-laid out for the qa_cpg graph.
-The TF-1.14 `Saver` bundle itself (`model_weights.ckpt.index/.data`) is not parsed here."""
+  * the TF `Saver` checkpoint itself (`model_weights.ckpt.index` + `.data-00000-of-00001`, `run_cpg.py:92-94,189,
+    206,252`) through `coper_amd.tf_bundle` (no TensorFlow needed), both directions."""
 from __future__ import annotations
 
 import pickle
@@ -12,7 +13,8 @@ from typing import Dict
 
 import numpy as np
 
-__all__ = ["load_npz", "load_best_embeddings_pickle", "from_minerva_state_dict", "leaf_name"]
+__all__ = ["load_npz", "load_best_embeddings_pickle", "from_minerva_state_dict", "leaf_name", "tf_variable_name",
+           "load_tf_checkpoint", "save_tf_checkpoint"]
 
 
 def leaf_name(tf_variable_name: str) -> str:
@@ -22,6 +24,49 @@ def leaf_name(tf_variable_name: str) -> str:
     while n.startswith("variables/"):
         n = n[len("variables/"):]
     return n
+
+
+def tf_variable_name(leaf: str) -> str:
+    """Inverse of leaf_name: BN layers are created outside the inner `variables` scope (models.py:183; the
+    generators' BN at models.py:65), everything else inside it (models.py:169)."""
+    if leaf.startswith(("Conv1BN/", "FCBN/")) or "/BatchNorm/" in leaf:
+        return "variables/" + leaf
+    return "variables/variables/" + leaf
+
+
+_SLOT_SUFFIXES = ("/AMSGrad", "/AMSGrad_1", "/AMSGrad_2")     # m, v, v_hat (amsgrad.py:117-119)
+
+
+def load_tf_checkpoint(prefix, with_optimizer=False):
+    """`saver.save(session, prefix)` output -> parameters by leaf name (float32).  Optimizer slots
+    (`<var>/AMSGrad{,_1,_2}` = m, v, v_hat, amsgrad.py:117-119) and the beta powers are dropped unless
+    `with_optimizer`, which returns (params, {leaf: (m, v, v_hat)}, {"beta1_power": .., "beta2_power": ..})."""
+    from . import tf_bundle
+    raw = tf_bundle.read_bundle(str(prefix))
+    params, slots, powers = {}, {}, {}
+    for name, a in raw.items():
+        leaf = leaf_name(name)
+        if leaf in ("beta1_power", "beta2_power"):
+            powers[leaf] = float(a)
+            continue
+        for k, suf in enumerate(_SLOT_SUFFIXES):
+            if leaf.endswith(suf) and not leaf[:-len(suf)].endswith("/AMSGrad"):
+                slots.setdefault(leaf[:-len(suf)], [None, None, None])[k] = np.asarray(a, np.float32)
+                break
+        else:
+            if a.dtype.kind == "f":
+                params[leaf] = np.asarray(a, np.float32)
+    if with_optimizer:
+        return params, {k: tuple(v) for k, v in slots.items()}, powers
+    return params
+
+
+def save_tf_checkpoint(prefix, params) -> None:
+    """Parameters by leaf name -> a checkpoint `saver.restore(session, prefix)` of the reference graph can read
+    (variable names per SURVEY.md 8-A; optimizer slots are not written: restore them with a fresh optimizer or use
+    `tf.train.Saver(var_list=...)` over the model variables)."""
+    from . import tf_bundle
+    tf_bundle.write_bundle(str(prefix), {tf_variable_name(k): np.asarray(v, np.float32) for k, v in params.items()})
 
 
 def load_npz(path) -> Dict[str, np.ndarray]:
