@@ -238,6 +238,7 @@ COPER_API void coper_destroy(coper_handle* h) {
   dev_free(&h->rel_count); dev_free(&h->rel_offset); h->rel_cursor = nullptr; dev_free(&h->perm); dev_free(&h->sorted_row); dev_free(&h->sorted_rid);
   dev_free(&h->tiles); dev_free(&h->n_tiles); dev_free(&h->blk_off); dev_free(&h->x_sorted); dev_free(&h->z_part);
   dev_free(&h->tgt_ws); dev_free(&h->h_ws); dev_free(&h->cnt_ws); dev_free(&h->hfrag_ws); dev_free(&h->logits_ws); dev_free(&h->row_of_ws);
+  dev_free(&h->gmax_ws); dev_free(&h->cand_blk_ws); dev_free(&h->cand_val_ws); dev_free(&h->cand_q_ws); dev_free(&h->cand_tau_ws); dev_free(&h->cand_sorted_ws); dev_free(&h->blk_cnt_ws); dev_free(&h->blk_off_ws);
   dev_free((char**)&h->Wf16_hi); dev_free((char**)&h->Wf16_lo);
   dev_free((char**)&h->Ef16_hi); dev_free((char**)&h->Ef16_lo); dev_free((char**)&h->hfrag16_hi); dev_free((char**)&h->hfrag16_lo);
   dev_free((char**)&h->Erm16_hi); dev_free((char**)&h->Erm16_lo); dev_free((char**)&h->hrm16_hi); dev_free((char**)&h->hrm16_lo);
@@ -553,8 +554,42 @@ COPER_API int coper_rank_counts(coper_handle* h, const float* hvec, const float*
   if ((rc = ensure_workspace(h, B, filt_nnz, s))) return rc;
   if (h->cfg.score_mode != COPER_SCORE_F32) {
     if (!(h->trust_packed && h->packed_hvec == hvec && h->packed_B == B) && (rc = launch_pack_h_bf16(h, hvec, B, s))) return rc;
-    if ((rc = launch_score_count_bf16x3(h, hvec, tgt, B, n_greater, n_equal, s))) return rc;
+    // 0 < k <= 32: the count pass also writes block maxima and the top-k is selected from the few blocks that can
+    // hold it (kernels_topk_bf16.hip): no logits workspace
+    const bool pruned = k > 0 && k <= COPER_TOPK_PRUNED_MAX;
+    if (pruned) {
+      const size_t gneed = (size_t)(h->dm.n_eblk * topk_chunk_queries(h->dm.n_eblk, B)), tneed = (size_t)((int64_t)k * B + filt_nnz);
+      if (gneed > h->gmax_cap || tneed > h->cand_cap || (size_t)B > h->cand_tau_cap) {
+        COPER_HIP_TRY(h, hipStreamSynchronize(s));
+        if (gneed > h->gmax_cap) {
+          if ((rc = dev_alloc(h, &h->gmax_ws, gneed))) return rc;
+          h->gmax_cap = gneed;
+        }
+        if (tneed > h->cand_cap) {
+          h->cand_cap = 0;
+          if ((rc = dev_alloc(h, &h->cand_blk_ws, tneed)) || (rc = dev_alloc(h, &h->cand_q_ws, tneed)) ||
+              (rc = dev_alloc(h, &h->cand_val_ws, tneed * 32)) ||
+              (rc = dev_alloc(h, &h->cand_sorted_ws, topk_sorted_cap(h->dm.n_eblk * topk_nseg(h->dm.n_eblk), (int64_t)tneed))))
+            return rc;
+          h->cand_cap = tneed;
+        }
+        if ((size_t)B > h->cand_tau_cap) {
+          if ((rc = dev_alloc(h, &h->cand_tau_ws, (size_t)B))) return rc;
+          h->cand_tau_cap = (size_t)B;
+        }
+        if (!h->blk_cnt_ws) {
+          const size_t gv = (size_t)(h->dm.n_eblk * topk_nseg(h->dm.n_eblk));
+          if ((rc = dev_alloc(h, &h->blk_cnt_ws, 2 * gv)) || (rc = dev_alloc(h, &h->blk_off_ws, gv + 1))) return rc;
+        }
+      }
+    }
+    if (pruned)
+      rc = launch_topk_pruned_bf16x3(h, tgt, e2, filt_indptr, filt_idx, filt_nnz, B, k, n_greater, n_equal, topk_val, topk_idx, s);
+    else
+      rc = launch_score_count_bf16x3(h, hvec, tgt, B, n_greater, n_equal, s);
+    if (rc) return rc;
     if ((rc = launch_filter_correct_bf16x3(h, tgt, e2, filt_indptr, filt_idx, filt_nnz, B, n_greater, n_equal, s))) return rc;
+    if (pruned) return COPER_OK;
   } else {
     if ((rc = launch_score_count(h, hvec, tgt, B, n_greater, n_equal, s))) return rc;
     if ((rc = launch_filter_correct(h, hvec, tgt, e2, filt_indptr, filt_idx, filt_nnz, B, n_greater, n_equal, s))) return rc;

@@ -1,6 +1,7 @@
 // Internal declarations shared by the libcoper_hip.so translation units (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <stdint.h>
 #include <map>
 #include <string>
@@ -40,6 +41,7 @@ struct Dims {
   int64_t n_eblk = 0;  // 32-row entity blocks (padded to a multiple of EBLK_ALIGN)
 };
 
+constexpr int COPER_TOPK_PRUNED_MAX = 32;   // largest k served by the block-maxima top-k (bf16x3); above: logits chunks
 constexpr int EBLK_ALIGN = 16;  // entity blocks consumed per workgroup iteration in score_count (8 waves x 2)
 
 struct Timer {
@@ -101,6 +103,18 @@ struct coper_handle {
   int64_t h_ws_rows = 0;
   float* logits_ws = nullptr;     // top-k path only: [chunk_rows, n_local]
   int64_t logits_ws_rows = 0;
+  // pruned top-k (bf16x3, k <= 32; kernels_topk_bf16.hip)
+  float* gmax_ws = nullptr;       // [n_eblk][query chunk]: block maxima written by the count pass
+  size_t gmax_cap = 0;
+  int32_t* cand_blk_ws = nullptr; // [k*B + nnz] candidate blocks, query q's at k*q + indptr[q]
+  float* cand_val_ws = nullptr;   // [k*B + nnz][32] their logits
+  size_t cand_cap = 0;
+  int32_t* cand_q_ws = nullptr;   // [k*B + nnz] the query of every candidate slot
+  uint32_t* cand_tau_ws = nullptr; // [B] selection threshold per query (ordered float bits; 0: none)
+  size_t cand_tau_cap = 0;
+  int32_t* cand_sorted_ws = nullptr;  // candidate slots grouped by entity block, 32-padded per block
+  int32_t* blk_cnt_ws = nullptr;  // [2 n_eblk] slots per block | scatter cursors
+  int32_t* blk_off_ws = nullptr;  // [n_eblk + 1]
   void* hfrag16_hi = nullptr;     // bf16x3: h hi / lo planes in fragment order
   void* hfrag16_lo = nullptr;
   void* hrm16_hi = nullptr;       //   row-major twins
@@ -188,6 +202,24 @@ int launch_filter_correct_bf16x3(coper_handle* h, const float* tgt, const int64_
                                  const int64_t* idx, int64_t nnz, int64_t B, int32_t* ng, int32_t* ne,
                                  hipStream_t s);
 int score_bf16_kernels_init(coper_handle* h);
+// queries whose block maxima are held at a time: at most 1 GiB of floats (or one 128-query tile)
+inline int64_t topk_chunk_queries(int64_t n_eblk, int64_t B) {
+  int64_t qc = ((int64_t)1 << 28) / n_eblk / 128 * 128;
+  if (const char* e = getenv("COPER_TOPK_CHUNK_QUERIES")) qc = atoll(e) / 128 * 128;   // tests: force several chunks
+  if (qc < 128) qc = 128;
+  const int64_t Bpad = (B + 127) / 128 * 128;
+  return qc > Bpad ? Bpad : qc;
+}
+// size of the block-grouped slot list: every block with candidates is padded to a multiple of 32
+// counters per block for the grouping of candidate slots: few blocks = many slots per block = contended atomics
+inline int topk_nseg(int64_t n_eblk) { return n_eblk < 4096 ? 8 : 1; }
+inline size_t topk_sorted_cap(int64_t n_eblk, int64_t T) { return (size_t)((T + 31 * (n_eblk < T ? n_eblk : T) + 31) / 32 * 32); }
+void score_count_begin_bf16x3(coper_handle* h, int64_t B, int32_t* ng, int32_t* ne, hipStream_t s);
+int score_count_chunk_bf16x3(coper_handle* h, int64_t q0, int64_t Bc, const float* tgt, int32_t* ng, int32_t* ne, float* gmax,
+                             int64_t gm_stride, hipStream_t s);
+int launch_topk_pruned_bf16x3(coper_handle* h, const float* tgt, const int64_t* e2, const int64_t* indptr, const int64_t* idx,
+                              int64_t nnz, int64_t B, int k, int32_t* ng, int32_t* ne, float* topk_val, int64_t* topk_idx,
+                              hipStream_t s);
 // kernels_encode_bf16.hip
 bool conv_bf16_supported(const Dims& dm);
 int launch_wfrag_to_bf16(coper_handle* h, const float* Wf, int64_t Rw, void* hi, void* lo, hipStream_t s);

@@ -138,7 +138,9 @@ __global__ void k_zero_counts(int64_t B, int32_t* __restrict__ ng, int32_t* __re
   if (j < B) { ng[j] = base; if (ne) ne[j] = 0; }
 }
 
-template <bool EQ>
+// GM: also write, per (32-entity block, query), the largest logit of the block -- what the pruned top-k
+// (kernels_topk_bf16.hip) selects its candidate blocks from; gmax[block * gm_stride + query].
+template <bool EQ, bool GM>
 __global__ __launch_bounds__(512, 2) void k_score_count_bf16x3(const uint4* __restrict__ Ehi,
                                                                const uint4* __restrict__ Elo,
                                                                const float* __restrict__ bias_pad,
@@ -146,7 +148,8 @@ __global__ __launch_bounds__(512, 2) void k_score_count_bf16x3(const uint4* __re
                                                                const uint4* __restrict__ Hlo,
                                                                const float* __restrict__ tgt, int64_t B, int KS,
                                                                int64_t iters, int64_t units,
-                                                               int32_t* __restrict__ ng, int32_t* __restrict__ ne) {
+                                                               int32_t* __restrict__ ng, int32_t* __restrict__ ne,
+                                                               float* __restrict__ gmax, int64_t gm_stride) {
   constexpr int NQ = BX_NQ;
   extern __shared__ uint4 hl16[];  // [2 planes][NQ][KS][64]
   uint4* hl_hi = hl16;
@@ -289,6 +292,18 @@ __global__ __launch_bounds__(512, 2) void k_score_count_bf16x3(const uint4* __re
           if (EQ) ce[b] += (sc == t[b]) ? 1 : 0;
         }
 #endif
+    if (GM) {
+#pragma unroll
+      for (int m = 0; m < ME; ++m)
+#pragma unroll
+        for (int b = 0; b < NQ; ++b) {
+          float mx = acc[m][b][0];
+#pragma unroll
+          for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[m][b][r]);
+          mx = fmaxf(mx, __shfl_xor(mx, 32));   // the other 16 rows of the block
+          if (lane < 32) gmax[(eb + m) * gm_stride + cur_tile * (32 * NQ) + b * 32 + lane] = mx;
+        }
+    }
   }
 #undef KCL
   if (cur_tile >= 0) FLUSH_COUNTS();
@@ -305,38 +320,51 @@ int launch_pack_h_bf16(coper_handle* h, const float* hvec, int64_t B, hipStream_
                                   (uint4*)h->hrm16_lo, s);
 }
 
-int launch_score_count_bf16x3(coper_handle* h, const float* hvec, const float* tgt, int64_t B, int32_t* ng,
-                              int32_t* ne, hipStream_t s) {
+// queries [q0, q0 + Bc) of the packed batch (q0 a multiple of the 128-query tile); gmax != NULL: block maxima too
+int score_count_chunk_bf16x3(coper_handle* h, int64_t q0, int64_t Bc, const float* tgt, int32_t* ng, int32_t* ne, float* gmax,
+                             int64_t gm_stride, hipStream_t s) {
   const Dims& dm = h->dm;
-  (void)hvec;  // already packed by launch_pack_h_bf16 (coper_rank_counts packs once per call)
-  // coper_rank presets the counters in the pack launch of its target pass (n_greater accumulates straight into `ranks`,
-  // started from 1): nothing to do then
-  if (h->counts_preset != ng)
-    hipLaunchKernelGGL(k_zero_counts, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, B, ng, ne, h->count_base);
-  h->counts_preset = nullptr;
-  int64_t q_tiles = (B + 32 * BX_NQ - 1) / (32 * BX_NQ);
+  int64_t q_tiles = (Bc + 32 * BX_NQ - 1) / (32 * BX_NQ);
   int64_t iters = dm.n_eblk / (BX_WAVES * BX_ME);
   int64_t units = q_tiles * iters;
   int64_t grid = (int64_t)h->num_cus * COPER_BX_WGS_PER_CU;
   if (grid > units) grid = units;
   size_t lds = (size_t)2 * BX_NQ * dm.KS16 * 64 * sizeof(uint4);
+  const uint4* hhi = (const uint4*)h->hfrag16_hi + (q0 / 32) * dm.KS16 * 64;
+  const uint4* hlo = (const uint4*)h->hfrag16_lo + (q0 / 32) * dm.KS16 * 64;
   ScopedKernelTimer t(h, "score_count", s);
-  if (ne)
-    hipLaunchKernelGGL(k_score_count_bf16x3<true>, dim3((unsigned)grid), dim3(512), lds, s, (const uint4*)h->Ef16_hi,
-                       (const uint4*)h->Ef16_lo, h->bias_pad, (const uint4*)h->hfrag16_hi, (const uint4*)h->hfrag16_lo, tgt,
-                       B, dm.KS16, iters, units, ng, ne);
-  else
-    hipLaunchKernelGGL(k_score_count_bf16x3<false>, dim3((unsigned)grid), dim3(512), lds, s, (const uint4*)h->Ef16_hi,
-                       (const uint4*)h->Ef16_lo, h->bias_pad, (const uint4*)h->hfrag16_hi, (const uint4*)h->hfrag16_lo, tgt,
-                       B, dm.KS16, iters, units, ng, ne);
+#define BX_LAUNCH(EQ_, GM_)                                                                                                       \
+  hipLaunchKernelGGL((k_score_count_bf16x3<EQ_, GM_>), dim3((unsigned)grid), dim3(512), lds, s, (const uint4*)h->Ef16_hi,         \
+                     (const uint4*)h->Ef16_lo, h->bias_pad, hhi, hlo, tgt + q0, Bc, dm.KS16, iters, units, ng + q0,                \
+                     ne ? ne + q0 : nullptr, gmax, gm_stride)
+  if (gmax) { if (ne) BX_LAUNCH(true, true); else BX_LAUNCH(false, true); }
+  else      { if (ne) BX_LAUNCH(true, false); else BX_LAUNCH(false, false); }
+#undef BX_LAUNCH
   COPER_HIP_TRY(h, hipGetLastError());
   return COPER_OK;
 }
 
+// counters start from count_base unless the caller's pack launch preset them (coper_rank: n_greater accumulates
+// straight into `ranks`, started from 1)
+void score_count_begin_bf16x3(coper_handle* h, int64_t B, int32_t* ng, int32_t* ne, hipStream_t s) {
+  if (h->counts_preset != ng)
+    hipLaunchKernelGGL(k_zero_counts, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, B, ng, ne, h->count_base);
+  h->counts_preset = nullptr;
+}
+
+int launch_score_count_bf16x3(coper_handle* h, const float* hvec, const float* tgt, int64_t B, int32_t* ng,
+                              int32_t* ne, hipStream_t s) {
+  (void)hvec;  // already packed by launch_pack_h_bf16 (coper_rank_counts packs once per call)
+  score_count_begin_bf16x3(h, B, ng, ne, s);
+  return score_count_chunk_bf16x3(h, 0, B, tgt, ng, ne, nullptr, 0, s);
+}
+
 int score_bf16_kernels_init(coper_handle* h) {
   int lds = (int)((size_t)2 * BX_NQ * h->dm.KS16 * 64 * sizeof(uint4));
-  COPER_HIP_TRY(h, hipFuncSetAttribute((const void*)k_score_count_bf16x3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  COPER_HIP_TRY(h, hipFuncSetAttribute((const void*)k_score_count_bf16x3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  COPER_HIP_TRY(h, hipFuncSetAttribute((const void*)k_score_count_bf16x3<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  COPER_HIP_TRY(h, hipFuncSetAttribute((const void*)k_score_count_bf16x3<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  COPER_HIP_TRY(h, hipFuncSetAttribute((const void*)k_score_count_bf16x3<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  COPER_HIP_TRY(h, hipFuncSetAttribute((const void*)k_score_count_bf16x3<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   return COPER_OK;
 }
 

@@ -1,0 +1,446 @@
+// Pruned top-k of the filtered rows for the bf16x3 mode (coper_rank_counts with 0 < k <= 32): the logits are
+// never materialised, also not for the top-k.
+//
+// The per-shard top-k is what the entity-sharded ranker exchanges (the masked row of
+// metrics.py:44-46 is the thing it is the top of).  At 1.25 M entities per shard a [B, |E_shard|] logit
+// matrix is 20 GB per 4096 queries, so the selection works on block maxima instead:
+//
+//   1. the count pass itself (k_score_count_bf16x3<.., GM>) writes, next to the rank counters, the largest logit
+//      of every (32-entity block, query): gmax[block][query], 1/32 of the logits, coalesced 128-B rows;
+//   2. k_topk_threshold_emit: per query, the m-th largest block maximum tau, m = k + (filter entries of the
+//      query), by a 4-pass radix select on the float bits.  m distinct blocks have their maximum >= tau and at most
+//      `filter entries` of those maxima are masked, so at least k unmasked logits >= tau exist: every entity of
+//      the row's top-k sits in a block whose maximum is >= tau.  Exactly m blocks are emitted (all above tau, and
+//      the lowest-numbered ones equal to tau), so the candidate list has a fixed place k*q + indptr[q] and no
+//      size exchange with the host is needed;
+//   3. k_topk_score_blocks: one wave per candidate block re-computes its 32 logits with the instruction
+//      sequence of every other bf16x3 kernel (bit-identical values), masks the known answers except the target;
+//   4. k_topk_select_cand: k rounds of arg-max over the query's candidates, (score desc, id asc).
+//
+// Work beyond the count pass: (k*B + nnz) blocks of 32 logits instead of B*|E|.
+#include "coper_internal.h"
+
+namespace coper {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define TK_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&(a), *(const bf16x8*)&(b), (c), 0, 0, 0)
+// same order as MFMA_X3 of kernels_score_bf16.hip: smallest terms first
+#define TK_MFMA_X3(ahi, alo, bhi, blo, c) \
+  { (c) = TK_MFMA(alo, bhi, c); (c) = TK_MFMA(ahi, blo, c); (c) = TK_MFMA(ahi, bhi, c); }
+
+// order-preserving map float -> uint32
+__device__ __forceinline__ uint32_t tk_key(float v) {
+  const uint32_t u = __float_as_uint(v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+constexpr int TK_THREADS = 512;
+
+// One workgroup per strip of NQS = 4 * QV queries (QV = 8: 32 queries; QV = 4: 16 queries, twice the workgroups when
+// the block axis is long).  gmax[block][query] is read as float4 = 4 queries of one block, eight such loads in flight
+// per thread (the sweeps are latency-bound otherwise: six passes over |E|/32 rows).  thread = (sub-range of the
+// block axis, 4 queries); HCOPY histogram copies (sub-range % HCOPY) thin out same-bank LDS atomics.
+template <int QV, int HCOPY>
+__global__ __launch_bounds__(TK_THREADS) void k_topk_threshold_emit(const float* __restrict__ gmax, int64_t G, int64_t Qs, int64_t q0,
+                                                                    int64_t Bc, int k, const int64_t* __restrict__ indptr,
+                                                                    int32_t* __restrict__ cand_blk, int32_t* __restrict__ cand_q,
+                                                                    int32_t* __restrict__ blk_cnt, int nseg,
+                                                                    uint32_t* __restrict__ cand_tau) {
+  constexpr int NQS = 4 * QV, SUB = TK_THREADS / QV;
+  extern __shared__ uint32_t tk_lds[];
+  uint32_t* hist = tk_lds;                               // [HCOPY][256 digits][NQS]
+  uint32_t* s_prefix = hist + HCOPY * 256 * NQS;         // [NQS]
+  uint32_t* s_rem = s_prefix + NQS;                      // [NQS]
+  uint32_t* s_cgt = s_rem + NQS;                         // [SUB][NQS]
+  uint32_t* s_ceq = s_cgt + SUB * NQS;                   // [SUB][NQS]
+  const int qv = threadIdx.x % QV, sr = threadIdx.x / QV;
+  const int64_t qs0 = (int64_t)blockIdx.x * NQS;         // first query of the strip within the chunk
+  const int64_t gs = (G + SUB - 1) / SUB;
+  const int64_t g_lo = sr * gs < G ? sr * gs : G;
+  const int64_t g_hi = g_lo + gs < G ? g_lo + gs : G;
+  const float4* col = (const float4*)(gmax + qs0) + qv;  // + g * (Qs / 4)
+  const int64_t qs4 = Qs >> 2;
+  if (threadIdx.x < NQS) {
+    const int64_t ql = qs0 + threadIdx.x;
+    int64_t m64 = 0;
+    if (ql < Bc) {
+      m64 = (int64_t)k + (indptr[q0 + ql + 1] - indptr[q0 + ql]);
+      if (m64 > G) m64 = G;
+    }
+    s_prefix[threadIdx.x] = 0;
+    s_rem[threadIdx.x] = (uint32_t)m64;
+  }
+  uint32_t* myhist = hist + (sr % HCOPY) * 256 * NQS + 4 * qv;
+  uint32_t mask = 0;
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    for (int j = threadIdx.x; j < HCOPY * 256 * NQS; j += TK_THREADS) hist[j] = 0;
+    __syncthreads();
+    uint32_t prefix[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) prefix[c] = s_prefix[4 * qv + c];
+#define TK_HIST(v4)                                                                       \
+  {                                                                                       \
+    const float vv[4] = {(v4).x, (v4).y, (v4).z, (v4).w};                                 \
+    _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                       \
+      const uint32_t key = tk_key(vv[c]);                                                 \
+      if ((key & mask) == prefix[c]) atomicAdd(&myhist[((key >> shift) & 255) * NQS + c], 1u); \
+    }                                                                                     \
+  }
+    int64_t g = g_lo;
+    for (; g + 8 <= g_hi; g += 8) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = col[(g + u) * qs4];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) TK_HIST(v[u]);
+    }
+    for (; g < g_hi; ++g) {
+      const float4 v = col[g * qs4];
+      TK_HIST(v);
+    }
+#undef TK_HIST
+    __syncthreads();
+    if (threadIdx.x < NQS) {
+      const int qi = threadIdx.x;
+      const uint32_t rem = s_rem[qi];
+      if (rem > 0) {   // the digit of the rem-th largest among the keys that share the prefix
+        uint32_t cum = 0;
+        int dg = 255;
+        for (; dg > 0; --dg) {
+          uint32_t c = 0;
+#pragma unroll
+          for (int hc = 0; hc < HCOPY; ++hc) c += hist[(hc * 256 + dg) * NQS + qi];
+          if (cum + c >= rem) break;
+          cum += c;
+        }
+        s_prefix[qi] |= (uint32_t)dg << shift;
+        s_rem[qi] = rem - cum;
+      }
+    }
+    mask |= 0xFFu << shift;
+    __syncthreads();
+  }
+  // tau = the m-th largest block maximum; s_rem = how many of the blocks equal to tau belong to the m
+  uint32_t tau[4], cgt[4] = {0, 0, 0, 0}, ceq[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int c = 0; c < 4; ++c) tau[c] = s_prefix[4 * qv + c];
+#define TK_COUNT(v4)                                        \
+  {                                                         \
+    const float vv[4] = {(v4).x, (v4).y, (v4).z, (v4).w};   \
+    _Pragma("unroll") for (int c = 0; c < 4; ++c) {         \
+      const uint32_t key = tk_key(vv[c]);                   \
+      cgt[c] += key > tau[c] ? 1u : 0u;                     \
+      ceq[c] += key == tau[c] ? 1u : 0u;                    \
+    }                                                       \
+  }
+  {
+    int64_t g = g_lo;
+    for (; g + 8 <= g_hi; g += 8) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = col[(g + u) * qs4];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) TK_COUNT(v[u]);
+    }
+    for (; g < g_hi; ++g) {
+      const float4 v4 = col[g * qs4];
+      TK_COUNT(v4);
+    }
+  }
+#undef TK_COUNT
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { s_cgt[sr * NQS + 4 * qv + c] = cgt[c]; s_ceq[sr * NQS + 4 * qv + c] = ceq[c]; }
+  __syncthreads();
+  const uint32_t kinf = tk_key(-INFINITY);
+  uint32_t bgt[4], beq[4], c1[4], need[4];
+  int64_t off[4];
+  bool valid[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int qi = 4 * qv + c;
+    bgt[c] = beq[c] = c1[c] = 0;
+    for (int s2 = 0; s2 < SUB; ++s2) {
+      const uint32_t x = s_cgt[s2 * NQS + qi];
+      if (s2 < sr) { bgt[c] += x; beq[c] += s_ceq[s2 * NQS + qi]; }
+      c1[c] += x;
+    }
+    need[c] = tau[c] > kinf ? s_rem[qi] : 0u;   // blocks whose maximum is -inf hold nothing
+    const int64_t ql = qs0 + qi;
+    valid[c] = ql < Bc;
+    off[c] = 0;
+    if (valid[c]) {
+      const int64_t qg = q0 + ql;
+      const int64_t beg = indptr[qg] - indptr[0];
+      off[c] = (int64_t)k * qg + beg;
+      // every slot of the query gets its query id; the unused ones (fewer than m blocks hold anything) are marked
+      const int64_t slots = (int64_t)k + (indptr[qg + 1] - indptr[0] - beg);
+      // what the selection may discard unseen: logits below tau, when tau is a real m-th largest (at least k unmasked
+      // logits >= tau exist then); with every block a candidate (m clamped to G) or a -inf tau nothing is discarded
+      if (sr == 0) cand_tau[qg] = (slots <= G && tau[c] > kinf) ? tau[c] : 0u;
+      for (int64_t j = sr; j < slots; j += SUB) {
+        cand_q[off[c] + j] = (int32_t)qg;
+        if (j >= (int64_t)(c1[c] + need[c])) cand_blk[off[c] + j] = -1;
+      }
+    }
+  }
+  for (int64_t g = g_lo; g < g_hi; ++g) {
+    const float4 v4 = col[g * qs4];
+    const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (!valid[c]) continue;
+      const uint32_t key = tk_key(vv[c]);
+      bool take = false;
+      int64_t slot = 0;
+      if (key > tau[c]) {
+        take = true;
+        slot = off[c] + bgt[c]++;
+      } else if (key == tau[c]) {
+        if (beq[c] < need[c]) { take = true; slot = off[c] + c1[c] + beq[c]; }
+        ++beq[c];
+      }
+      if (take) {
+        cand_blk[slot] = (int32_t)g;
+        // candidates are scored block by block: how many slots want block g (nseg counters per block thin out the
+        // same-address atomics when there are few blocks)
+        atomicAdd(&blk_cnt[g * nseg + (slot & (nseg - 1))], 1);
+      }
+    }
+  }
+}
+
+template <int QV, int HCOPY>
+constexpr size_t tk_emit_lds() { return sizeof(uint32_t) * (HCOPY * 256 * 4 * QV + 8 * QV + 2 * (TK_THREADS / QV) * 4 * QV); }
+
+// ---- group the candidate slots by entity block: every block's slots padded to a multiple of 32 (one wave each)
+// blk_off[g] = first position of block g in `sorted`, blk_off[G] = total (a multiple of 32)
+__global__ __launch_bounds__(1024) void k_topk_blk_scan(const int32_t* __restrict__ blk_cnt, int64_t G, int32_t* __restrict__ blk_off) {
+  __shared__ int32_t part[1024];
+  const int64_t per = (G + 1023) / 1024;
+  const int64_t lo_g = threadIdx.x * per, hi_g = lo_g + per < G ? lo_g + per : G;
+  int32_t sum = 0;
+  for (int64_t g = lo_g; g < hi_g; ++g) sum += (blk_cnt[g] + 31) & ~31;
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {   // inclusive scan
+    const int32_t add = (int)threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+    __syncthreads();
+    part[threadIdx.x] += add;
+    __syncthreads();
+  }
+  int32_t run = part[threadIdx.x] - sum;
+  for (int64_t g = lo_g; g < hi_g; ++g) { blk_off[g] = run; run += (blk_cnt[g] + 31) & ~31; }
+  if (threadIdx.x == 1023) blk_off[G] = part[1023];
+}
+
+__global__ __launch_bounds__(256) void k_topk_blk_scatter(const int32_t* __restrict__ cand_blk, int64_t T, const int32_t* __restrict__ blk_off,
+                                                          int32_t* __restrict__ blk_cur, int nseg, int32_t* __restrict__ sorted) {
+  const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (w >= T) return;
+  const int32_t g = cand_blk[w];
+  if (g < 0) return;
+  const int64_t vb = (int64_t)g * nseg + (w & (nseg - 1));
+  sorted[blk_off[vb] + atomicAdd(&blk_cur[vb], 1)] = (int32_t)w;
+}
+
+// One wave per 32 candidate slots of one entity block: A = the block's fragments (read as the count pass reads them),
+// B column c = the query of slot c (gathered from the row-major planes, as the pair kernel does).  Lane (c, half)
+// ends with 16 rows of its slot's 32 logits; known answers of the slot's query, except its target, become -inf.
+__global__ __launch_bounds__(256) void k_topk_score_blocks(const uint4* __restrict__ Ehi, const uint4* __restrict__ Elo,
+                                                           const float* __restrict__ bias_pad, const uint4* __restrict__ Hrm_hi,
+                                                           const uint4* __restrict__ Hrm_lo, int KS, int64_t G,
+                                                           const int64_t* __restrict__ e2, const int64_t* __restrict__ indptr,
+                                                           const int64_t* __restrict__ idx, const int32_t* __restrict__ cand_blk,
+                                                           const int32_t* __restrict__ cand_q, const int32_t* __restrict__ blk_off,
+                                                           const int32_t* __restrict__ sorted, int64_t lo,
+                                                           float* __restrict__ cand_val) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5, c = lane & 31;
+  const int64_t i = (int64_t)blockIdx.x * 4 + wave;
+  if (i * 32 >= blk_off[G]) return;   // G here: number of (block, segment) counters
+  const int64_t g = cand_blk[sorted[i * 32]];   // the first slot of a wave's 32 is always in use
+  const int32_t w = sorted[i * 32 + c];          // -1: padding
+  const int64_t q = w >= 0 ? cand_q[w] : 0;
+  f32x16 acc;
+  {
+    const float4* bp = (const float4*)(bias_pad + g * 32 + 4 * half);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 b4 = bp[2 * j];
+      acc[4 * j + 0] = b4.x; acc[4 * j + 1] = b4.y; acc[4 * j + 2] = b4.z; acc[4 * j + 3] = b4.w;
+    }
+  }
+  const uint4* pa_h = Ehi + g * KS * 64 + lane;
+  const uint4* pa_l = Elo + g * KS * 64 + lane;
+  const uint4* pb_h = Hrm_hi + q * (2 * KS) + half;
+  const uint4* pb_l = Hrm_lo + q * (2 * KS) + half;
+  int ks = 0;
+  for (; ks + 4 <= KS; ks += 4) {
+    uint4 ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      ah[u] = pa_h[(ks + u) * 64]; al[u] = pa_l[(ks + u) * 64];
+      bh[u] = pb_h[(ks + u) * 2]; bl[u] = pb_l[(ks + u) * 2];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) TK_MFMA_X3(ah[u], al[u], bh[u], bl[u], acc);
+  }
+  for (; ks < KS; ++ks) {
+    uint4 ah = pa_h[ks * 64], al = pa_l[ks * 64], bh = pb_h[ks * 2], bl = pb_l[ks * 2];
+    TK_MFMA_X3(ah, al, bh, bl, acc);
+  }
+  if (w < 0) return;
+  // known answers of this lane's query inside the block, except the target (metrics.py:45-46)
+  const int64_t target = e2[q];
+  uint32_t masked = 0;
+  for (int64_t j = indptr[q]; j < indptr[q + 1]; ++j) {
+    const int64_t f = idx[j];
+    const int64_t r = f - lo - g * 32;
+    if (f != target && r >= 0 && r < 32) masked |= 1u << (int)r;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float4 v = make_float4(acc[4 * j + 0], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]);
+    const int row = 8 * j + 4 * half;
+    if ((masked >> (row + 0)) & 1u) v.x = -INFINITY;
+    if ((masked >> (row + 1)) & 1u) v.y = -INFINITY;
+    if ((masked >> (row + 2)) & 1u) v.z = -INFINITY;
+    if ((masked >> (row + 3)) & 1u) v.w = -INFINITY;
+    *(float4*)(cand_val + (int64_t)w * 32 + row) = v;
+  }
+}
+
+// One wave per query.  Only candidates >= tau (cand_tau, from the threshold kernel) can be in the top-k: they are
+// compacted into LDS (a few dozen out of (k + filter entries) * 32) and placed by counting, for each survivor, the
+// survivors ahead of it in (score desc, entity id asc) order.  More survivors than the LDS list holds (tiny entity
+// sets where tau is -inf, heavy ties): k rounds of arg-max through memory instead.
+constexpr int TK_SURV = 256;   // survivors per query held in LDS
+__global__ __launch_bounds__(256) void k_topk_select_cand(float* __restrict__ cand_val, const int32_t* __restrict__ cand_blk,
+                                                          const uint32_t* __restrict__ cand_tau, const int64_t* __restrict__ indptr,
+                                                          int64_t B, int k, int64_t lo, float* __restrict__ out_val,
+                                                          int64_t* __restrict__ out_idx) {
+  __shared__ float s_v[4][TK_SURV];
+  __shared__ int s_id[4][TK_SURV];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t q = (int64_t)blockIdx.x * 4 + wave;
+  if (q >= B) return;
+  const int64_t beg = indptr[q] - indptr[0];
+  const int64_t off = (int64_t)k * q + beg;
+  const int n = (int)((int64_t)k + (indptr[q + 1] - indptr[0] - beg)) * 32;
+  float* val = cand_val + off * 32;
+  const int32_t* blk = cand_blk + off;
+  float* ov = out_val + q * k;
+  int64_t* oi = out_idx + q * k;
+  const uint32_t tau = cand_tau[q];
+  int S = 0;   // survivors so far (wave-uniform)
+  for (int j0 = 0; j0 < n; j0 += 64 * 4) {
+    float v[4];
+    int32_t b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = j0 + 64 * u + lane;
+      b[u] = j < n ? blk[j >> 5] : -1;
+      v[u] = b[u] >= 0 ? val[j] : -INFINITY;   // unused slots (block -1) hold nothing
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool keep = v[u] > -INFINITY && tk_key(v[u]) >= tau;
+      const unsigned long long m = __ballot(keep);
+      if (keep) {
+        const int pos = S + __popcll(m & ((1ull << lane) - 1ull));
+        if (pos < TK_SURV) { s_v[wave][pos] = v[u]; s_id[wave][pos] = b[u] * 32 + ((j0 + 64 * u + lane) & 31); }
+      }
+      S += __popcll(m);
+    }
+  }
+  if (S <= TK_SURV) {
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the list is wave-local
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < S; i += 64) {
+      const float v = s_v[wave][i];
+      const int id = s_id[wave][i];
+      int ahead = 0;
+      for (int t = 0; t < S; ++t) {
+        const float v2 = s_v[wave][t];
+        const int i2 = s_id[wave][t];
+        ahead += (v2 > v || (v2 == v && i2 < id)) ? 1 : 0;
+      }
+      if (ahead < k) { ov[ahead] = v; oi[ahead] = lo + id; }
+    }
+    for (int r = S + lane; r < k; r += 64) { ov[r] = -INFINITY; oi[r] = -1; }
+    return;
+  }
+  for (int round = 0; round < k; ++round) {
+    float best = -INFINITY;
+    int bid = 0x7fffffff, bpos = -1;
+    for (int j = lane; j < n; j += 64) {
+      const int32_t b = blk[j >> 5];
+      if (b < 0) continue;
+      const float v = val[j];
+      if (!(v > -INFINITY)) continue;
+      const int id = b * 32 + (j & 31);
+      if (v > best || (v == best && id < bid)) { best = v; bid = id; bpos = j; }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      const float v2 = __shfl_xor(best, o);
+      const int i2 = __shfl_xor(bid, o);
+      const int p2 = __shfl_xor(bpos, o);
+      if (v2 > best || (v2 == best && i2 < bid)) { best = v2; bid = i2; bpos = p2; }
+    }
+    // every lane holds the winner now; the lane that read it retires it (its own later reads see its own store)
+    if (lane == 0) {
+      ov[round] = bpos >= 0 ? best : -INFINITY;
+      oi[round] = bpos >= 0 ? lo + bid : -1;
+    }
+    if (bpos >= 0 && (bpos & 63) == lane) val[bpos] = -INFINITY;
+  }
+}
+
+template <int QV, int HCOPY>
+static void tk_launch_emit(coper_handle* h, int64_t G, int64_t qs, int64_t q0, int64_t bc, int k, const int64_t* indptr, hipStream_t s) {
+  const size_t lds = tk_emit_lds<QV, HCOPY>();
+  (void)hipFuncSetAttribute((const void*)k_topk_threshold_emit<QV, HCOPY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((k_topk_threshold_emit<QV, HCOPY>), dim3((unsigned)(qs / (4 * QV))), dim3(TK_THREADS), lds, s, h->gmax_ws, G, qs, q0, bc,
+                     k, indptr, h->cand_blk_ws, h->cand_q_ws, h->blk_cnt_ws, topk_nseg(G), h->cand_tau_ws);
+}
+
+int launch_topk_pruned_bf16x3(coper_handle* h, const float* tgt, const int64_t* e2, const int64_t* indptr, const int64_t* idx,
+                              int64_t nnz, int64_t B, int k, int32_t* ng, int32_t* ne, float* topk_val, int64_t* topk_idx,
+                              hipStream_t s) {
+  const Dims& dm = h->dm;
+  const int64_t G = dm.n_eblk;
+  const int64_t qc = topk_chunk_queries(G, B);
+  const int64_t T = (int64_t)k * B + nnz;   // candidate blocks: k + (filter entries) per query
+  if ((size_t)(G * qc) > h->gmax_cap || (size_t)T > h->cand_cap)
+    return fail(h, COPER_ESTATE, "pruned top-k: workspace not reserved");
+  int rc;
+  score_count_begin_bf16x3(h, B, ng, ne, s);
+  const int nseg = topk_nseg(G);
+  const int64_t GV = G * nseg;   // (block, segment) counters
+  COPER_HIP_TRY(h, hipMemsetAsync(h->blk_cnt_ws, 0, sizeof(int32_t) * 2 * GV, s));          // counts | scatter cursors
+  COPER_HIP_TRY(h, hipMemsetAsync(h->cand_sorted_ws, 0xFF, sizeof(int32_t) * topk_sorted_cap(GV, T), s));
+  for (int64_t q0 = 0; q0 < B; q0 += qc) {
+    const int64_t bc = B - q0 < qc ? B - q0 : qc;
+    const int64_t qs = (bc + 127) / 128 * 128;
+    if ((rc = score_count_chunk_bf16x3(h, q0, bc, tgt, ng, ne, h->gmax_ws, qs, s))) return rc;
+    // long block axis: half-width strips (twice the workgroups) and four histogram copies
+    if (G >= 4096) tk_launch_emit<4, 4>(h, G, qs, q0, bc, k, indptr, s);
+    else tk_launch_emit<8, 1>(h, G, qs, q0, bc, k, indptr, s);
+  }
+  hipLaunchKernelGGL(k_topk_blk_scan, dim3(1), dim3(1024), 0, s, h->blk_cnt_ws, GV, h->blk_off_ws);
+  hipLaunchKernelGGL(k_topk_blk_scatter, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, h->cand_blk_ws, T, h->blk_off_ws,
+                     h->blk_cnt_ws + GV, nseg, h->cand_sorted_ws);
+  const int64_t waves = topk_sorted_cap(GV, T) / 32;
+  hipLaunchKernelGGL(k_topk_score_blocks, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, (const uint4*)h->Ef16_hi,
+                     (const uint4*)h->Ef16_lo, h->bias_pad, (const uint4*)h->hrm16_hi, (const uint4*)h->hrm16_lo, dm.KS16, GV, e2,
+                     indptr, idx, h->cand_blk_ws, h->cand_q_ws, h->blk_off_ws, h->cand_sorted_ws, (int64_t)h->cfg.shard_lo,
+                     h->cand_val_ws);
+  hipLaunchKernelGGL(k_topk_select_cand, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s, h->cand_val_ws, h->cand_blk_ws, h->cand_tau_ws, indptr, B,
+                     k, (int64_t)h->cfg.shard_lo, topk_val, topk_idx);
+  COPER_HIP_TRY(h, hipGetLastError());
+  return COPER_OK;
+}
+
+}  // namespace coper

@@ -559,3 +559,63 @@ def test_encode_rank_single_call_equals_two_calls(mode):
         r0, none = m.rank_pass(q["e1"], q["rel"], q["e2"], q["filt_indptr"], q["filt_idx"], want_equal=False)
         assert none is None and torch.equal(r0, r2)
     m.close()
+
+
+@pytest.mark.parametrize("chunk", [None, 128])
+def test_pruned_topk_bf16x3_matches_masked_row_topk(oracle_chain, chunk, monkeypatch):
+    """bf16x3, k <= 32: top-k selected from block maxima (kernels_topk_bf16.hip), logits never materialised.
+    Must equal the top-k of the masked row of the mode's own logits, (score desc, id asc): with exact ties
+    (duplicate and all-zero entity rows), filters that hold the row's best entities, k above the number of
+    unfiltered entities, several query chunks, two entity shards merged, and the counts unchanged."""
+    O = oracle_chain
+    from coper_amd.sharding import merge_topk
+    if chunk:
+        monkeypatch.setenv("COPER_TOPK_CHUNK_QUERIES", str(chunk))
+    md = cdata.model_descriptors("fb15k237_cpg", num_ent=5000, num_rel=12)
+    p = dict(cdata.synthetic_params(md, 11))
+    ent = np.array(p["ent_emb"], np.float32)
+    bias = np.array(p["pred_bias"], np.float32)
+    rng = np.random.default_rng(5)
+    dup = rng.choice(5000, 600, replace=False)
+    ent[dup[:300]] = ent[dup[300:]]                       # exact duplicates (ties between blocks)
+    bias[dup[:300]] = bias[dup[300:]]
+    ent[4000:4100] = 0.0                                  # a run of identical logits (= the bias)
+    bias[4000:4100] = 0.25
+    p["ent_emb"], p["pred_bias"] = ent, bias
+    Q = 300
+    q = cdata.synthetic_queries(md, Q, seed=9, mean_filter=6.0, max_filter=40)
+    m = _model(md, p, score_mode="bf16x3")
+    h = m.encode(q["e1"], q["rel"])
+    logits = m.score_all(h).cpu().numpy()
+    # filters that contain the best-scoring entities of their row (what real filters do), CSR rebuilt
+    rows = [list(q["filt_idx"][q["filt_indptr"][i]:q["filt_indptr"][i + 1]]) for i in range(Q)]
+    for i in range(0, Q, 3):
+        rows[i] += list(np.argsort(-logits[i])[:int(rng.integers(1, 30))])
+    indptr = np.zeros(Q + 1, np.int64)
+    indptr[1:] = np.cumsum([len(r) for r in rows])
+    idx = np.concatenate([np.asarray(r, np.int64) for r in rows])
+    tgt = m.target_scores(h, q["e2"])
+    ng0, ne0 = m.rank_counts(h, tgt, q["e2"], indptr, idx)
+    for k in (1, 10, 32):
+        ng, ne, tv, ti = m.rank_counts(h, tgt, q["e2"], indptr, idx, k=k)
+        ev, ei = O.topk_filtered(logits, q["e2"], indptr, idx, k)
+        assert np.array_equal(ti.cpu().numpy(), ei) and np.array_equal(tv.cpu().numpy(), ev), k
+        assert np.array_equal(ng.cpu().numpy(), ng0.cpu().numpy()) and np.array_equal(ne.cpu().numpy(), ne0.cpu().numpy())
+    # two shards, merged
+    shards = [_model(md, p, shard=(0, 2100), score_mode="bf16x3"), _model(md, p, shard=(2100, 5000), score_mode="bf16x3")]
+    parts = [s_.rank_counts(h, tgt, q["e2"], indptr, idx, k=10) for s_ in shards]
+    tv, ti = merge_topk(torch.cat([x[2] for x in parts], 1), torch.cat([x[3] for x in parts], 1), 10)
+    ev, ei = O.topk_filtered(logits, q["e2"], indptr, idx, 10)
+    assert np.array_equal(tv.cpu().numpy(), ev) and np.array_equal(ti.cpu().numpy(), ei)
+    # fewer unfiltered entities than k: (-inf, -1) padding
+    md2 = cdata.model_descriptors("nations_cpg")
+    p2 = cdata.synthetic_params(md2, 1)
+    q2 = cdata.synthetic_queries(md2, 20, seed=1, mean_filter=3.0, max_filter=8)
+    m2 = _model(md2, p2, score_mode="bf16x3")
+    h2 = m2.encode(q2["e1"], q2["rel"])
+    _, _, tv, ti = m2.rank_counts(h2, m2.target_scores(h2, q2["e2"]), q2["e2"], q2["filt_indptr"], q2["filt_idx"], k=16)
+    ev, ei = O.topk_filtered(m2.score_all(h2).cpu().numpy(), q2["e2"], q2["filt_indptr"], q2["filt_idx"], 16)
+    assert np.array_equal(tv.cpu().numpy(), ev) and np.array_equal(ti.cpu().numpy(), ei)
+    assert (ti.cpu().numpy() == -1).any()
+    for x in shards + [m, m2]:
+        x.close()
