@@ -37,10 +37,42 @@ __device__ __forceinline__ uint32_t tk_key(float v) {
 
 constexpr int TK_THREADS = 512;
 
-// One workgroup per strip of NQS = 4 * QV queries (QV = 8: 32 queries; QV = 4: 16 queries, twice the workgroups when
-// the block axis is long).  gmax[block][query] is read as float4 = 4 queries of one block, eight such loads in flight
-// per thread (the sweeps are latency-bound otherwise: six passes over |E|/32 rows).  thread = (sub-range of the
-// block axis, 4 queries); HCOPY histogram copies (sub-range % HCOPY) thin out same-bank LDS atomics.
+// One sweep of a thread's share of the block axis: gmax[block][query] read as float4 (4 queries of one block), eight
+// loads per batch and the next batch in flight while the current one is consumed (the sweeps are latency-bound).
+template <typename F>
+__device__ __forceinline__ void tk_sweep(const float4* __restrict__ col, int64_t qs4, int64_t g_lo, int64_t g_hi, F&& f) {
+  int64_t g = g_lo;
+  if (g + 8 <= g_hi) {
+    float4 cur[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) cur[u] = col[(g + u) * qs4];
+    for (; g + 16 <= g_hi; g += 8) {
+      float4 nxt[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) nxt[u] = col[(g + 8 + u) * qs4];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) f(g + u, cur[u]);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) cur[u] = nxt[u];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) f(g + u, cur[u]);
+    g += 8;
+  }
+  for (; g < g_hi; ++g) f(g, col[g * qs4]);
+}
+
+constexpr int TK_BIN = 64;   // block maxima per query that may share the threshold's upper 16 bits on the fast path
+
+// Threshold + candidate blocks of a strip of NQS = 4 * QV queries (QV = 8: 32 queries; QV = 4: 16).
+// thread = (sub-range of the block axis, 4 queries); HCOPY histogram copies (sub-range % HCOPY) thin out same-bank
+// LDS atomics.  Three sweeps over the strip's block maxima in the common case:
+//   1, 2  radix-select the upper 16 bits of the m-th largest (two 8-bit digits);
+//   3     blocks above that 16-bit bin are candidates (slot by an LDS counter), blocks inside it go to a short LDS
+//         list; the list is ranked in LDS ((key desc, block asc): exact ties go to the lowest-numbered blocks) and
+//         its first `rem` entries complete the m candidates.
+// A bin with more than TK_BIN blocks (heavy ties, clustered maxima) takes the general route instead: two more radix
+// digits, a counting sweep and an ordered emission sweep, rewriting the strip's slots.
 template <int QV, int HCOPY>
 __global__ __launch_bounds__(TK_THREADS) void k_topk_threshold_emit(const float* __restrict__ gmax, int64_t G, int64_t Qs, int64_t q0,
                                                                     int64_t Bc, int k, const int64_t* __restrict__ indptr,
@@ -52,8 +84,12 @@ __global__ __launch_bounds__(TK_THREADS) void k_topk_threshold_emit(const float*
   uint32_t* hist = tk_lds;                               // [HCOPY][256 digits][NQS]
   uint32_t* s_prefix = hist + HCOPY * 256 * NQS;         // [NQS]
   uint32_t* s_rem = s_prefix + NQS;                      // [NQS]
-  uint32_t* s_cgt = s_rem + NQS;                         // [SUB][NQS]
+  uint32_t* s_slot = s_rem + NQS;                        // [NQS] fast path: candidates emitted so far
+  uint32_t* s_bn = s_slot + NQS;                         // [NQS] fast path: entries of the bin list
+  uint32_t* s_cgt = s_bn + NQS;                          // [SUB][NQS]   (general route)
   uint32_t* s_ceq = s_cgt + SUB * NQS;                   // [SUB][NQS]
+  uint32_t* s_bkey = s_ceq + SUB * NQS;                  // [NQS][TK_BIN]
+  int32_t* s_bg = (int32_t*)(s_bkey + NQS * TK_BIN);     // [NQS][TK_BIN]
   const int qv = threadIdx.x % QV, sr = threadIdx.x / QV;
   const int64_t qs0 = (int64_t)blockIdx.x * NQS;         // first query of the strip within the chunk
   const int64_t gs = (G + SUB - 1) / SUB;
@@ -61,6 +97,7 @@ __global__ __launch_bounds__(TK_THREADS) void k_topk_threshold_emit(const float*
   const int64_t g_hi = g_lo + gs < G ? g_lo + gs : G;
   const float4* col = (const float4*)(gmax + qs0) + qv;  // + g * (Qs / 4)
   const int64_t qs4 = Qs >> 2;
+  const uint32_t kinf = tk_key(-INFINITY);
   if (threadIdx.x < NQS) {
     const int64_t ql = qs0 + threadIdx.x;
     int64_t m64 = 0;
@@ -70,37 +107,41 @@ __global__ __launch_bounds__(TK_THREADS) void k_topk_threshold_emit(const float*
     }
     s_prefix[threadIdx.x] = 0;
     s_rem[threadIdx.x] = (uint32_t)m64;
+    s_slot[threadIdx.x] = 0;
+    s_bn[threadIdx.x] = 0;
+  }
+  // this thread's four queries: slot range and validity
+  int64_t off[4], slots[4];
+  bool valid[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int64_t ql = qs0 + 4 * qv + c;
+    valid[c] = ql < Bc;
+    off[c] = slots[c] = 0;
+    if (valid[c]) {
+      const int64_t qg = q0 + ql;
+      const int64_t beg = indptr[qg] - indptr[0];
+      off[c] = (int64_t)k * qg + beg;
+      slots[c] = (int64_t)k + (indptr[qg + 1] - indptr[0] - beg);
+    }
   }
   uint32_t* myhist = hist + (sr % HCOPY) * 256 * NQS + 4 * qv;
   uint32_t mask = 0;
-  for (int pass = 0; pass < 4; ++pass) {
+  auto radix_pass = [&](int pass) {
     const int shift = 24 - 8 * pass;
     for (int j = threadIdx.x; j < HCOPY * 256 * NQS; j += TK_THREADS) hist[j] = 0;
     __syncthreads();
     uint32_t prefix[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) prefix[c] = s_prefix[4 * qv + c];
-#define TK_HIST(v4)                                                                       \
-  {                                                                                       \
-    const float vv[4] = {(v4).x, (v4).y, (v4).z, (v4).w};                                 \
-    _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                       \
-      const uint32_t key = tk_key(vv[c]);                                                 \
-      if ((key & mask) == prefix[c]) atomicAdd(&myhist[((key >> shift) & 255) * NQS + c], 1u); \
-    }                                                                                     \
-  }
-    int64_t g = g_lo;
-    for (; g + 8 <= g_hi; g += 8) {
-      float4 v[8];
+    tk_sweep(col, qs4, g_lo, g_hi, [&](int64_t, const float4& v4) {
+      const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = col[(g + u) * qs4];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) TK_HIST(v[u]);
-    }
-    for (; g < g_hi; ++g) {
-      const float4 v = col[g * qs4];
-      TK_HIST(v);
-    }
-#undef TK_HIST
+      for (int c = 0; c < 4; ++c) {
+        const uint32_t key = tk_key(vv[c]);
+        if ((key & mask) == prefix[c]) atomicAdd(&myhist[((key >> shift) & 255) * NQS + c], 1u);
+      }
+    });
     __syncthreads();
     if (threadIdx.x < NQS) {
       const int qi = threadIdx.x;
@@ -109,11 +150,11 @@ __global__ __launch_bounds__(TK_THREADS) void k_topk_threshold_emit(const float*
         uint32_t cum = 0;
         int dg = 255;
         for (; dg > 0; --dg) {
-          uint32_t c = 0;
+          uint32_t cnt = 0;
 #pragma unroll
-          for (int hc = 0; hc < HCOPY; ++hc) c += hist[(hc * 256 + dg) * NQS + qi];
-          if (cum + c >= rem) break;
-          cum += c;
+          for (int hc = 0; hc < HCOPY; ++hc) cnt += hist[(hc * 256 + dg) * NQS + qi];
+          if (cum + cnt >= rem) break;
+          cum += cnt;
         }
         s_prefix[qi] |= (uint32_t)dg << shift;
         s_rem[qi] = rem - cum;
@@ -121,98 +162,145 @@ __global__ __launch_bounds__(TK_THREADS) void k_topk_threshold_emit(const float*
     }
     mask |= 0xFFu << shift;
     __syncthreads();
-  }
-  // tau = the m-th largest block maximum; s_rem = how many of the blocks equal to tau belong to the m
-  uint32_t tau[4], cgt[4] = {0, 0, 0, 0}, ceq[4] = {0, 0, 0, 0};
-#pragma unroll
-  for (int c = 0; c < 4; ++c) tau[c] = s_prefix[4 * qv + c];
-#define TK_COUNT(v4)                                        \
-  {                                                         \
-    const float vv[4] = {(v4).x, (v4).y, (v4).z, (v4).w};   \
-    _Pragma("unroll") for (int c = 0; c < 4; ++c) {         \
-      const uint32_t key = tk_key(vv[c]);                   \
-      cgt[c] += key > tau[c] ? 1u : 0u;                     \
-      ceq[c] += key == tau[c] ? 1u : 0u;                    \
-    }                                                       \
-  }
+  };
+  radix_pass(0);
+  radix_pass(1);
+
+  // ---- sweep 3: above the 16-bit bin -> candidate; inside it -> LDS list
   {
-    int64_t g = g_lo;
-    for (; g + 8 <= g_hi; g += 8) {
-      float4 v[8];
+    uint32_t p16[4];
+    bool live[4];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = col[(g + u) * qs4];
+    for (int c = 0; c < 4; ++c) {
+      p16[c] = s_prefix[4 * qv + c] >> 16;
+      live[c] = valid[c] && s_rem[4 * qv + c] > 0;
+    }
+    tk_sweep(col, qs4, g_lo, g_hi, [&](int64_t g, const float4& v4) {
+      const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
-      for (int u = 0; u < 8; ++u) TK_COUNT(v[u]);
-    }
-    for (; g < g_hi; ++g) {
-      const float4 v4 = col[g * qs4];
-      TK_COUNT(v4);
-    }
+      for (int c = 0; c < 4; ++c) {
+        if (!live[c]) continue;
+        const uint32_t key = tk_key(vv[c]);
+        const uint32_t k16 = key >> 16;
+        if (k16 > p16[c]) {
+          cand_blk[off[c] + atomicAdd(&s_slot[4 * qv + c], 1u)] = (int32_t)g;
+        } else if (k16 == p16[c]) {
+          const uint32_t i = atomicAdd(&s_bn[4 * qv + c], 1u);
+          if (i < (uint32_t)TK_BIN) { s_bkey[(4 * qv + c) * TK_BIN + i] = key; s_bg[(4 * qv + c) * TK_BIN + i] = (int32_t)g; }
+        }
+      }
+    });
   }
-#undef TK_COUNT
-#pragma unroll
-  for (int c = 0; c < 4; ++c) { s_cgt[sr * NQS + 4 * qv + c] = cgt[c]; s_ceq[sr * NQS + 4 * qv + c] = ceq[c]; }
   __syncthreads();
-  const uint32_t kinf = tk_key(-INFINITY);
-  uint32_t bgt[4], beq[4], c1[4], need[4];
-  int64_t off[4];
-  bool valid[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const int qi = 4 * qv + c;
-    bgt[c] = beq[c] = c1[c] = 0;
-    for (int s2 = 0; s2 < SUB; ++s2) {
-      const uint32_t x = s_cgt[s2 * NQS + qi];
-      if (s2 < sr) { bgt[c] += x; beq[c] += s_ceq[s2 * NQS + qi]; }
-      c1[c] += x;
-    }
-    need[c] = tau[c] > kinf ? s_rem[qi] : 0u;   // blocks whose maximum is -inf hold nothing
-    const int64_t ql = qs0 + qi;
-    valid[c] = ql < Bc;
-    off[c] = 0;
-    if (valid[c]) {
+  bool over = false;
+  if (threadIdx.x < NQS) over = s_bn[threadIdx.x] > (uint32_t)TK_BIN;
+  if (!__syncthreads_or(over ? 1 : 0)) {
+    // rank the bin lists: entry e of query qi is candidate number (gt + ahead) if ahead < rem
+    for (int t = threadIdx.x; t < NQS * TK_BIN; t += TK_THREADS) {
+      const int qi = t / TK_BIN, e = t % TK_BIN;
+      const int64_t ql = qs0 + qi;
+      const uint32_t nb = s_bn[qi], rem = s_rem[qi];
+      if (ql >= Bc || (uint32_t)e >= nb || rem == 0) continue;
+      const uint32_t key = s_bkey[qi * TK_BIN + e];
+      const int32_t g = s_bg[qi * TK_BIN + e];
+      uint32_t ahead = 0;
+      for (uint32_t t2 = 0; t2 < nb; ++t2) {
+        const uint32_t k2 = s_bkey[qi * TK_BIN + t2];
+        ahead += (k2 > key || (k2 == key && s_bg[qi * TK_BIN + t2] < g)) ? 1u : 0u;
+      }
+      if (ahead >= rem) continue;
       const int64_t qg = q0 + ql;
       const int64_t beg = indptr[qg] - indptr[0];
-      off[c] = (int64_t)k * qg + beg;
-      // every slot of the query gets its query id; the unused ones (fewer than m blocks hold anything) are marked
-      const int64_t slots = (int64_t)k + (indptr[qg + 1] - indptr[0] - beg);
+      const int64_t o = (int64_t)k * qg + beg;
+      const int64_t nslots = (int64_t)k + (indptr[qg + 1] - indptr[0] - beg);
+      // blocks whose maximum is -inf hold nothing: their slots stay unused
+      cand_blk[o + s_slot[qi] + ahead] = key > kinf ? g : -1;
       // what the selection may discard unseen: logits below tau, when tau is a real m-th largest (at least k unmasked
       // logits >= tau exist then); with every block a candidate (m clamped to G) or a -inf tau nothing is discarded
-      if (sr == 0) cand_tau[qg] = (slots <= G && tau[c] > kinf) ? tau[c] : 0u;
-      for (int64_t j = sr; j < slots; j += SUB) {
-        cand_q[off[c] + j] = (int32_t)qg;
-        if (j >= (int64_t)(c1[c] + need[c])) cand_blk[off[c] + j] = -1;
-      }
+      if (ahead == rem - 1) cand_tau[qg] = (nslots <= G && key > kinf) ? key : 0u;
     }
-  }
-  for (int64_t g = g_lo; g < g_hi; ++g) {
-    const float4 v4 = col[g * qs4];
-    const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+    // query ids of all slots; slots past the m candidates (m clamped to the number of blocks) are unused
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       if (!valid[c]) continue;
-      const uint32_t key = tk_key(vv[c]);
-      bool take = false;
-      int64_t slot = 0;
-      if (key > tau[c]) {
-        take = true;
-        slot = off[c] + bgt[c]++;
-      } else if (key == tau[c]) {
-        if (beq[c] < need[c]) { take = true; slot = off[c] + c1[c] + beq[c]; }
-        ++beq[c];
+      const int qi = 4 * qv + c;
+      const int64_t used = (int64_t)s_slot[qi] + s_rem[qi];
+      for (int64_t j = sr; j < slots[c]; j += SUB) {
+        cand_q[off[c] + j] = (int32_t)(q0 + qs0 + qi);
+        if (j >= used) cand_blk[off[c] + j] = -1;
       }
-      if (take) {
-        cand_blk[slot] = (int32_t)g;
-        // candidates are scored block by block: how many slots want block g (nseg counters per block thin out the
-        // same-address atomics when there are few blocks)
-        atomicAdd(&blk_cnt[g * nseg + (slot & (nseg - 1))], 1);
+    }
+  } else {
+    // ---- general route: the remaining two digits, then count and emit in block order
+    radix_pass(2);
+    radix_pass(3);
+    uint32_t tau[4], cgt[4] = {0, 0, 0, 0}, ceq[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) tau[c] = s_prefix[4 * qv + c];
+    tk_sweep(col, qs4, g_lo, g_hi, [&](int64_t, const float4& v4) {
+      const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const uint32_t key = tk_key(vv[c]);
+        cgt[c] += key > tau[c] ? 1u : 0u;
+        ceq[c] += key == tau[c] ? 1u : 0u;
       }
+    });
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { s_cgt[sr * NQS + 4 * qv + c] = cgt[c]; s_ceq[sr * NQS + 4 * qv + c] = ceq[c]; }
+    __syncthreads();
+    uint32_t bgt[4], beq[4], c1[4], need[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int qi = 4 * qv + c;
+      bgt[c] = beq[c] = c1[c] = 0;
+      for (int s2 = 0; s2 < SUB; ++s2) {
+        const uint32_t x = s_cgt[s2 * NQS + qi];
+        if (s2 < sr) { bgt[c] += x; beq[c] += s_ceq[s2 * NQS + qi]; }
+        c1[c] += x;
+      }
+      need[c] = tau[c] > kinf ? s_rem[qi] : 0u;
+      if (valid[c]) {
+        if (sr == 0) cand_tau[q0 + qs0 + qi] = (slots[c] <= G && tau[c] > kinf) ? tau[c] : 0u;
+        for (int64_t j = sr; j < slots[c]; j += SUB) {
+          cand_q[off[c] + j] = (int32_t)(q0 + qs0 + qi);
+          if (j >= (int64_t)(c1[c] + need[c])) cand_blk[off[c] + j] = -1;
+        }
+      }
+    }
+    tk_sweep(col, qs4, g_lo, g_hi, [&](int64_t g, const float4& v4) {
+      const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (!valid[c]) continue;
+        const uint32_t key = tk_key(vv[c]);
+        if (key > tau[c]) {
+          cand_blk[off[c] + bgt[c]++] = (int32_t)g;
+        } else if (key == tau[c]) {
+          if (beq[c] < need[c]) cand_blk[off[c] + c1[c] + beq[c]] = (int32_t)g;
+          ++beq[c];
+        }
+      }
+    });
+  }
+  // ---- candidates are scored block by block: how many slots want block g (nseg counters per block thin out the
+  // same-address atomics when there are few blocks)
+  __threadfence_block();
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    if (!valid[c]) continue;
+    for (int64_t j = sr; j < slots[c]; j += SUB) {
+      const int32_t g = cand_blk[off[c] + j];
+      if (g >= 0) atomicAdd(&blk_cnt[(int64_t)g * nseg + ((off[c] + j) & (nseg - 1))], 1);
     }
   }
 }
 
 template <int QV, int HCOPY>
-constexpr size_t tk_emit_lds() { return sizeof(uint32_t) * (HCOPY * 256 * 4 * QV + 8 * QV + 2 * (TK_THREADS / QV) * 4 * QV); }
+constexpr size_t tk_emit_lds() {
+  return sizeof(uint32_t) * (HCOPY * 256 * 4 * QV + 4 * 4 * QV + 2 * (TK_THREADS / QV) * 4 * QV + 2 * 4 * QV * TK_BIN);
+}
 
 // ---- group the candidate slots by entity block: every block's slots padded to a multiple of 32 (one wave each)
 // blk_off[g] = first position of block g in `sorted`, blk_off[G] = total (a multiple of 32)
@@ -426,7 +514,7 @@ int launch_topk_pruned_bf16x3(coper_handle* h, const float* tgt, const int64_t* 
     const int64_t qs = (bc + 127) / 128 * 128;
     if ((rc = score_count_chunk_bf16x3(h, q0, bc, tgt, ng, ne, h->gmax_ws, qs, s))) return rc;
     // long block axis: half-width strips (twice the workgroups) and four histogram copies
-    if (G >= 4096) tk_launch_emit<4, 4>(h, G, qs, q0, bc, k, indptr, s);
+    if (G >= 4096) tk_launch_emit<8, 2>(h, G, qs, q0, bc, k, indptr, s);
     else tk_launch_emit<8, 1>(h, G, qs, q0, bc, k, indptr, s);
   }
   hipLaunchKernelGGL(k_topk_blk_scan, dim3(1), dim3(1024), 0, s, h->blk_cnt_ws, GV, h->blk_off_ws);

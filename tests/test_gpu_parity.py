@@ -601,6 +601,20 @@ def test_pruned_topk_bf16x3_matches_masked_row_topk(oracle_chain, chunk, monkeyp
         ev, ei = O.topk_filtered(logits, q["e2"], indptr, idx, k)
         assert np.array_equal(ti.cpu().numpy(), ei) and np.array_equal(tv.cpu().numpy(), ev), k
         assert np.array_equal(ng.cpu().numpy(), ng0.cpu().numpy()) and np.array_equal(ne.cpu().numpy(), ne0.cpu().numpy())
+    # ~90 blocks whose maxima tie exactly at the threshold (more than the threshold kernel's LDS bin list holds): the
+    # general route, exact ties resolved towards the lowest entity ids
+    p3 = dict(p)
+    ent3, bias3 = ent.copy(), bias.copy()
+    ent3[1000:3900] = 0.0
+    bias3[1000:3900] = 30.0
+    p3["ent_emb"], p3["pred_bias"] = ent3, bias3
+    m3 = _model(md, p3, score_mode="bf16x3")
+    h3 = m3.encode(q["e1"], q["rel"])
+    logits3 = m3.score_all(h3).cpu().numpy()
+    _, _, tv, ti = m3.rank_counts(h3, m3.target_scores(h3, q["e2"]), q["e2"], indptr, idx, k=10)
+    ev, ei = O.topk_filtered(logits3, q["e2"], indptr, idx, 10)
+    assert np.array_equal(ti.cpu().numpy(), ei) and np.array_equal(tv.cpu().numpy(), ev)
+    m3.close()
     # two shards, merged
     shards = [_model(md, p, shard=(0, 2100), score_mode="bf16x3"), _model(md, p, shard=(2100, 5000), score_mode="bf16x3")]
     parts = [s_.rank_counts(h, tgt, q["e2"], indptr, idx, k=10) for s_ in shards]
