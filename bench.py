@@ -60,6 +60,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--score-mode", choices=["f32", "bf16x3"], default="bf16x3")
+    ap.add_argument("--topk", type=int, default=0,
+                    help="entity mode: also select and exchange the per-shard top-k of the filtered rows (SURVEY 8(e) step 3)")
     ap.add_argument("--dist-backend", default="nccl",
                     help="torch.distributed backend (nccl = RCCL).  gloo + several ranks on one GPU is a debugging aid "
                          "for the multi-process path on a single-GPU box; its numbers mean nothing")
@@ -157,7 +159,7 @@ def main():
         if entity_mode:
             # ids are tiny; the host copies drive the relation split, the device copies feed the kernels
             return ranker.rank(dict(e1=host_q["e1"], rel=host_q["rel"], e2=dev_q["e2"], filt_indptr=dev_q["filt_indptr"],
-                                    filt_idx=dev_q["filt_idx"]))
+                                    filt_idx=dev_q["filt_idx"]), k=args.topk)[:2]
         # one call per pass, like one session.run of the reference's ranker loop; like ranking_and_hits (and the
         # reference) the pass needs ranks only: tie counts and the embedding itself are not requested
         return model.rank_pass(dev_q["e1"], dev_q["rel"], dev_q["e2"], dev_q["filt_indptr"], dev_q["filt_idx"], filt_nnz=nnz,
@@ -203,7 +205,8 @@ def main():
             "config": {"workload": "%s: |E|=%d R2=%d d=%d r=%d, Q=%d queries/pass%s, %s relation order" % (
                 args.workload, md["num_ent"], md["num_rel"], d, md["rel_emb_size"], Q,
                 "" if entity_mode else " per GPU", args.order),
-                "parallelism": ("entity-sharded x%d" % world) if entity_mode else ("query-sharded x%d" % world),
+                "parallelism": ("entity-sharded x%d%s" % (world, ", top-%d exchanged" % args.topk if args.topk else ""))
+                if entity_mode else ("query-sharded x%d" % world),
                 "score_mode": "f32 (v_mfma_f32_32x32x2_f32, exact)" if args.score_mode == "f32" else
                 "bf16x3 (3 x v_mfma_f32_32x32x16_bf16 per product, ~2^-16 rel.)", "prepare_ms": round(prepare_ms, 2),
                 "mean_rank": float(np.mean(ranks_np)), "mrr": float(np.mean(1.0 / ranks_np))},

@@ -424,6 +424,8 @@ COPER_API int coper_prepare(coper_handle* h, void* stream) {
     hipDeviceProp_t prop;
     COPER_HIP_TRY(h, hipGetDeviceProperties(&prop, cfg.device));
     h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    const int64_t share = (int64_t)(prop.totalGlobalMem / 32 / sizeof(float));
+    h->gmax_max_floats = share > ((int64_t)1 << 28) ? share : ((int64_t)1 << 28);
   }
   if (cfg.score_mode == COPER_SCORE_F32 && (rc = score_kernels_init(h))) return rc;
   h->prepared = true;
@@ -558,7 +560,7 @@ COPER_API int coper_rank_counts(coper_handle* h, const float* hvec, const float*
     // hold it (kernels_topk_bf16.hip): no logits workspace
     const bool pruned = k > 0 && k <= COPER_TOPK_PRUNED_MAX;
     if (pruned) {
-      const size_t gneed = (size_t)(h->dm.n_eblk * topk_chunk_queries(h->dm.n_eblk, B)), tneed = (size_t)((int64_t)k * B + filt_nnz);
+      const size_t gneed = (size_t)(h->dm.n_eblk * topk_chunk_queries(h->dm.n_eblk, B, h->gmax_max_floats)), tneed = (size_t)((int64_t)k * B + filt_nnz);
       if (gneed > h->gmax_cap || tneed > h->cand_cap || (size_t)B > h->cand_tau_cap) {
         COPER_HIP_TRY(h, hipStreamSynchronize(s));
         if (gneed > h->gmax_cap) {

@@ -104,6 +104,7 @@ struct coper_handle {
   float* logits_ws = nullptr;     // top-k path only: [chunk_rows, n_local]
   int64_t logits_ws_rows = 0;
   // pruned top-k (bf16x3, k <= 32; kernels_topk_bf16.hip)
+  int64_t gmax_max_floats = (int64_t)1 << 28;   // set from the device memory size at prepare
   float* gmax_ws = nullptr;       // [n_eblk][query chunk]: block maxima written by the count pass
   size_t gmax_cap = 0;
   int32_t* cand_blk_ws = nullptr; // [k*B + nnz] candidate blocks, query q's at k*q + indptr[q]
@@ -202,9 +203,10 @@ int launch_filter_correct_bf16x3(coper_handle* h, const float* tgt, const int64_
                                  const int64_t* idx, int64_t nnz, int64_t B, int32_t* ng, int32_t* ne,
                                  hipStream_t s);
 int score_bf16_kernels_init(coper_handle* h);
-// queries whose block maxima are held at a time: at most 1 GiB of floats (or one 128-query tile)
-inline int64_t topk_chunk_queries(int64_t n_eblk, int64_t B) {
-  int64_t qc = ((int64_t)1 << 28) / n_eblk / 128 * 128;
+// queries whose block maxima are held at a time: at most `cap_floats` (1/32 of the device memory, at least 1 GiB;
+// the threshold kernel runs one workgroup per 16 or 32 queries, so short chunks leave the chip idle) or one tile
+inline int64_t topk_chunk_queries(int64_t n_eblk, int64_t B, int64_t cap_floats) {
+  int64_t qc = cap_floats / n_eblk / 128 * 128;
   if (const char* e = getenv("COPER_TOPK_CHUNK_QUERIES")) qc = atoll(e) / 128 * 128;   // tests: force several chunks
   if (qc < 128) qc = 128;
   const int64_t Bpad = (B + 127) / 128 * 128;

@@ -499,7 +499,7 @@ int launch_topk_pruned_bf16x3(coper_handle* h, const float* tgt, const int64_t* 
                               hipStream_t s) {
   const Dims& dm = h->dm;
   const int64_t G = dm.n_eblk;
-  const int64_t qc = topk_chunk_queries(G, B);
+  const int64_t qc = topk_chunk_queries(G, B, h->gmax_max_floats);
   const int64_t T = (int64_t)k * B + nnz;   // candidate blocks: k + (filter entries) per query
   if ((size_t)(G * qc) > h->gmax_cap || (size_t)T > h->cand_cap)
     return fail(h, COPER_ESTATE, "pruned top-k: workspace not reserved");
@@ -513,9 +513,11 @@ int launch_topk_pruned_bf16x3(coper_handle* h, const float* tgt, const int64_t* 
     const int64_t bc = B - q0 < qc ? B - q0 : qc;
     const int64_t qs = (bc + 127) / 128 * 128;
     if ((rc = score_count_chunk_bf16x3(h, q0, bc, tgt, ng, ne, h->gmax_ws, qs, s))) return rc;
-    // long block axis: half-width strips (twice the workgroups) and four histogram copies
-    if (G >= 4096) tk_launch_emit<8, 2>(h, G, qs, q0, bc, k, indptr, s);
-    else tk_launch_emit<8, 1>(h, G, qs, q0, bc, k, indptr, s);
+    // long block axis: more histogram copies; half-width strips (twice the workgroups) when 32-query strips would
+    // not cover the chip
+    if (G < 4096) tk_launch_emit<8, 1>(h, G, qs, q0, bc, k, indptr, s);
+    else if (qs / 32 >= h->num_cus) tk_launch_emit<8, 2>(h, G, qs, q0, bc, k, indptr, s);
+    else tk_launch_emit<4, 4>(h, G, qs, q0, bc, k, indptr, s);
   }
   hipLaunchKernelGGL(k_topk_blk_scan, dim3(1), dim3(1024), 0, s, h->blk_cnt_ws, GV, h->blk_off_ws);
   hipLaunchKernelGGL(k_topk_blk_scatter, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, h->cand_blk_ws, T, h->blk_off_ws,
