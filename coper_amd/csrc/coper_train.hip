@@ -1328,4 +1328,34 @@ COPER_API int coper_train_grad(coper_handle* h, const char* leaf_name, float* ou
   return COPER_OK;
 }
 
+COPER_API int coper_train_slot(coper_handle* h, const char* leaf_name, int32_t which, float* buf, int64_t cap, int32_t set,
+                               int64_t* n, void* stream) {
+  if (!h || !leaf_name) return COPER_EINVAL;
+  TrainState* T = (TrainState*)h->train;
+  if (!T) return fail(h, COPER_ESTATE, "coper_train_slot: call coper_train_init first");
+  TrainParam* t = T->find(leaf_name);
+  if (!t) return fail(h, COPER_EINVAL, std::string("coper_train_slot: not a trainable leaf: ") + leaf_name);
+  if (which < 0 || which > 2) return fail(h, COPER_EINVAL, "coper_train_slot: which = 0 (m), 1 (v), 2 (v_hat)");
+  float* slot = which == 0 ? t->m : which == 1 ? t->v : t->vh;
+  if (n) *n = t->n;
+  if (!buf) return COPER_OK;
+  if (cap < t->n) return fail(h, COPER_EINVAL, "coper_train_slot: buffer too small");
+  COPER_HIP_TRY(h, hipMemcpyAsync(set ? slot : buf, set ? buf : slot, sizeof(float) * t->n, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return COPER_OK;
+}
+
+COPER_API int coper_train_powers(coper_handle* h, const double* set_beta1_power, const double* set_beta2_power,
+                                 const int64_t* set_step, double* beta1_power, double* beta2_power, int64_t* step) {
+  if (!h) return COPER_EINVAL;
+  TrainState* T = (TrainState*)h->train;
+  if (!T) return fail(h, COPER_ESTATE, "coper_train_powers: call coper_train_init first");
+  if (set_beta1_power) T->b1p = *set_beta1_power;
+  if (set_beta2_power) T->b2p = *set_beta2_power;
+  if (set_step) T->step = (uint32_t)*set_step;
+  if (beta1_power) *beta1_power = T->b1p;
+  if (beta2_power) *beta2_power = T->b2p;
+  if (step) *step = (int64_t)T->step;
+  return COPER_OK;
+}
+
 }  // extern "C"

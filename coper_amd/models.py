@@ -394,6 +394,47 @@ class ConvE(object):
                                                        self._stream()))
         return out, gn.value
 
+    def optimizer_state(self):
+        """AMSGrad state for a checkpoint: ({leaf: (m, v, v_hat) numpy}, {"beta1_power", "beta2_power", "step"}) --
+        what `tf.train.Saver` keeps as `<var>/AMSGrad{,_1,_2}` and beta1_power / beta2_power (amsgrad.py:108-119)."""
+        slots = {}
+        for leaf in self.trainable_leaves():
+            parts = []
+            for which in range(3):
+                n = C.c_int64()
+                _lib.check(self._h, self._lib.coper_train_slot(self._h, leaf.encode(), which, None, 0, 0, C.byref(n), self._stream()))
+                buf = torch.empty(n.value, device=self.device, dtype=torch.float32)
+                _lib.check(self._h, self._lib.coper_train_slot(self._h, leaf.encode(), which, _ptr(buf), n.value, 0, C.byref(n),
+                                                               self._stream()))
+                parts.append(buf.cpu().numpy().reshape(tuple(self._tensors[leaf].shape)))
+            slots[leaf] = tuple(parts)
+        b1, b2, st = C.c_double(), C.c_double(), C.c_int64()
+        _lib.check(self._h, self._lib.coper_train_powers(self._h, None, None, None, C.byref(b1), C.byref(b2), C.byref(st)))
+        return slots, dict(beta1_power=b1.value, beta2_power=b2.value, step=st.value)
+
+    def load_optimizer_state(self, slots, powers=None):
+        """Inverse of optimizer_state (after train_init): resume training from a checkpoint's slots."""
+        for leaf, parts in slots.items():
+            for which, a in enumerate(parts):
+                if a is None:
+                    continue
+                src = torch.as_tensor(np.ascontiguousarray(np.asarray(a, np.float32))).reshape(-1).to(self.device)
+                n = C.c_int64()
+                _lib.check(self._h, self._lib.coper_train_slot(self._h, leaf.encode(), which, _ptr(src), src.numel(), 1, C.byref(n),
+                                                               self._stream()))
+                torch.cuda.current_stream(self.device).synchronize()    # src may be freed after this
+        if powers:
+            b1 = C.c_double(powers["beta1_power"]) if "beta1_power" in powers else None
+            b2 = C.c_double(powers["beta2_power"]) if "beta2_power" in powers else None
+            st = C.c_int64(int(powers["step"])) if "step" in powers else None
+            _lib.check(self._h, self._lib.coper_train_powers(self._h, C.byref(b1) if b1 else None, C.byref(b2) if b2 else None,
+                                                            C.byref(st) if st else None, None, None, None))
+        return self
+
+    def trainable_leaves(self):
+        """Leaves with optimizer slots (everything but the BN moving statistics)."""
+        return [k for k in self._tensors if not k.endswith(("moving_mean", "moving_variance"))]
+
     # ---------------------------------------------------------------- reference-style access
     @property
     def loss(self):

@@ -61,12 +61,20 @@ def load_tf_checkpoint(prefix, with_optimizer=False):
     return params
 
 
-def save_tf_checkpoint(prefix, params) -> None:
+def save_tf_checkpoint(prefix, params, slots=None, powers=None) -> None:
     """Parameters by leaf name -> a checkpoint `saver.restore(session, prefix)` of the reference graph can read
-    (variable names per SURVEY.md 8-A; optimizer slots are not written: restore them with a fresh optimizer or use
-    `tf.train.Saver(var_list=...)` over the model variables)."""
+    (variable names per SURVEY.md 8-A).  `slots` {leaf: (m, v, v_hat)} and `powers` {"beta1_power", "beta2_power"}
+    (ConvE.optimizer_state()) add the AMSGrad state under the names `tf.train.Saver()` expects for the full graph
+    (run_cpg.py:189); without them restore with `tf.train.Saver(var_list=<model variables>)`."""
     from . import tf_bundle
-    tf_bundle.write_bundle(str(prefix), {tf_variable_name(k): np.asarray(v, np.float32) for k, v in params.items()})
+    out = {tf_variable_name(k): np.asarray(v, np.float32) for k, v in params.items()}
+    for leaf, parts in (slots or {}).items():
+        for suf, a in zip(_SLOT_SUFFIXES, parts):
+            out[tf_variable_name(leaf) + suf] = np.asarray(a, np.float32)
+    for k in ("beta1_power", "beta2_power"):
+        if powers and k in powers:
+            out["variables/" + k] = np.float32(powers[k])
+    tf_bundle.write_bundle(str(prefix), out)
 
 
 def load_npz(path) -> Dict[str, np.ndarray]:

@@ -235,6 +235,16 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
 COPER_API int coper_train_grad(coper_handle* h, const char* leaf_name, float* out, int64_t cap, int64_t* n,
                                double* global_norm, void* stream);
 
+/* Optimizer state, for checkpoints (the reference's tf.train.Saver stores the slots `<var>/AMSGrad`, `/AMSGrad_1`,
+ * `/AMSGrad_2` = m, v, v_hat of utils/amsgrad.py:117-119 and the non-slot variables beta1_power / beta2_power,
+ * amsgrad.py:108-113).  `which`: 0 m, 1 v, 2 v_hat; `buf`: device float buffer of `cap` elements (may be NULL to
+ * query *n); set == 0 copies slot -> buf, set != 0 copies buf -> slot, stream-ordered.  Powers: get with non-NULL
+ * outputs, set with non-NULL inputs; `step` is the dropout counter of the next step. */
+COPER_API int coper_train_slot(coper_handle* h, const char* leaf_name, int32_t which, float* buf, int64_t cap, int32_t set,
+                               int64_t* n, void* stream);
+COPER_API int coper_train_powers(coper_handle* h, const double* set_beta1_power, const double* set_beta2_power,
+                                 const int64_t* set_step, double* beta1_power, double* beta2_power, int64_t* step);
+
 #ifdef __cplusplus
 }
 #endif

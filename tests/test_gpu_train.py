@@ -166,3 +166,37 @@ def test_training_loop_learns_a_small_graph(variant):
     assert np.isfinite(losses).all() and losses[-1] < 0.5 * losses[0], losses
     assert before < 0.15 and after > 0.5 and after > 4 * before, (before, after, losses)
     m.close()
+
+
+def test_checkpoint_resume_continues_the_same_trajectory(tmp_path):
+    """Variables + AMSGrad slots + beta powers through the TF-checkpoint writer / reader (run_cpg.py:189,206,252):
+    a model restored from the checkpoint takes the same next steps as the one that kept running."""
+    from coper_amd import weights
+    from coper_amd.models import ConvE
+    md = dict(cdata._COMMON)
+    md.update(_CASES["cpg_mlp_bn"])
+    md.update(batch_norm_train_stats=True, batch_norm_momentum=0.9, hidden_dropout=0.2, output_dropout=0.1,
+              label_smoothing_epsilon=0.1, learning_rate=0.003)
+    p0 = cdata.synthetic_params(md, seed=3)
+    a = ConvE(md, device="cuda:0").load_parameters({k: torch.as_tensor(np.array(v, np.float32)) for k, v in p0.items()})
+    a.train_init(seed=7)
+    for step in range(3):
+        a.train_step(_batch(md, 32, 20, seed=step))
+    slots, powers = a.optimizer_state()
+    assert powers["step"] == 3 and abs(powers["beta1_power"] - 0.9 ** 4) < 1e-6
+    prefix = str(tmp_path / "model_weights.ckpt")
+    weights.save_tf_checkpoint(prefix, {k: v.cpu().numpy() for k, v in a._tensors.items()}, slots, powers)
+    params, slots2, powers2 = weights.load_tf_checkpoint(prefix, with_optimizer=True)
+    assert sorted(slots2) == sorted(slots) and all(np.array_equal(slots2[k][2], slots[k][2]) for k in slots)
+    b = ConvE(md, device="cuda:0").load_parameters({k: torch.as_tensor(v) for k, v in params.items()})
+    b.train_init(seed=7)
+    b.load_optimizer_state(slots2, dict(powers2, step=powers["step"]))
+    for step in range(3, 5):
+        la = float(a.train_step(_batch(md, 32, 20, seed=step)).cpu()[0])
+        lb = float(b.train_step(_batch(md, 32, 20, seed=step)).cpu()[0])
+        assert abs(la - lb) < 1e-5 * max(1.0, abs(la))
+    for k in a._tensors:
+        x, y = a._tensors[k].cpu().numpy(), b._tensors[k].cpu().numpy()
+        assert np.abs(x - y).max() < 1e-5 + 1e-4 * np.abs(x).max(), k
+    a.close()
+    b.close()
