@@ -442,6 +442,23 @@ def test_end_to_end_matches_minerva_torch_models_gpu(golden_dir, tag, mode):
     m.close()
 
 
+@pytest.mark.parametrize("tag", ["plain", "cpg"])
+def test_fact_network_scorer_mirrors_the_sister_models(golden_dir, tag):
+    """coper_amd.fact_network.FactNetworkScorer: forward / forward_fact with the reference's argument order and
+    shapes, from the torch state_dict, == the sister models' own outputs (fixture generated from their code)."""
+    from coper_amd.fact_network import FactNetworkScorer
+    g = np.load(os.path.join(golden_dir, "minerva_e2e.npz"))
+    E, R, B, d1, d2, C, r_dim = (int(v) for v in g[tag + ":dims"])
+    sd = {k.split(":sd:")[1]: torch.as_tensor(g[k]) for k in g.files if k.startswith(tag + ":sd:")}
+    fn = FactNetworkScorer(sd, torch.as_tensor(g[tag + ":ent"]), g[tag + ":rel"], d1, d2, cpg=(tag == "cpg"), device="cuda:0")
+    e1, r, e2 = (torch.as_tensor(g[tag + ":" + k].astype(np.int64)) for k in ("e1", "r", "e2"))
+    S = fn.forward(e1, r)
+    Sf = fn.forward_fact(e1, r, e2)
+    assert tuple(S.shape) == (B, E) and tuple(Sf.shape) == (B, 1)
+    assert np.abs(S.cpu().numpy() - g[tag + ":S"]).max() < 1e-4 and np.abs(Sf.cpu().numpy() - g[tag + ":S_fact"]).max() < 1e-4
+    fn.close()
+
+
 def test_tsv_loader_to_ranking_end_to_end(golden_dir, tmp_path, oracle_chain):
     """TSV triples (a split of the nell-995 dev set the reference ships) -> TSVKGLoader -> ranking_and_hits on
     the GPU == the oracle's reference-semantics evaluation pass on the same batches."""
