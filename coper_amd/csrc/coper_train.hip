@@ -304,7 +304,29 @@ __global__ __launch_bounds__(256) void k_tr_score_bwd(const float* __restrict__ 
   const int k = threadIdx.x;
   const float hk = k < d ? hv[b * d + k] : 0.f;
   float acc = 0.f;
-  for (int64_t l = 0; l < L; ++l) {
+  int64_t l = 0;
+  // eight gathered rows in flight per thread: the loop is a chain of dependent loads otherwise (ids -> row)
+  for (; l + 8 <= L; l += 8) {
+    int64_t row[8];
+    float g[8], ev[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      row[u] = lookup[b * L + l + u];
+      if (row[u] < 0 || row[u] >= E) row[u] = 0;
+      g[u] = ds[b * L + l + u];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) ev[u] = k < d ? ent[row[u] * d + k] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {   // same summation order as the plain loop
+      acc = fmaf(g[u], ev[u], acc);
+      if (SCATTER) {
+        if (k < d) atomicAdd(&dE[row[u] * d + k], g[u] * hk);
+        if (k == 0) atomicAdd(&dbias[row[u]], g[u]);
+      }
+    }
+  }
+  for (; l < L; ++l) {
     int64_t row = lookup[b * L + l];
     if (row < 0 || row >= E) row = 0;
     const float g = ds[b * L + l];
@@ -783,7 +805,15 @@ __global__ __launch_bounds__(256) void k_tr_sumsq(TrainTensors tt, double* __res
   double a = 0;
   const int32_t* rc = tt.rowcnt[blockIdx.y];
   const int64_t rl = tt.rowlen[blockIdx.y];
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (!rc) {
+    for (; i + 3 * stride < n; i += 4 * stride) {   // four independent loads in flight
+      const float g0 = g[i], g1 = g[i + stride], g2 = g[i + 2 * stride], g3 = g[i + 3 * stride];
+      a += (double)g0 * g0 + (double)g1 * g1 + (double)g2 * g2 + (double)g3 * g3;
+    }
+  }
+  for (; i < n; i += stride) {
     if (rc && rc[i / rl] == 0) continue;
     a += (double)g[i] * g[i];
   }

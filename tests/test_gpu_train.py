@@ -196,6 +196,8 @@ def test_checkpoint_resume_continues_the_same_trajectory(tmp_path):
         lb = float(b.train_step(_batch(md, 32, 20, seed=step)).cpu()[0])
         assert abs(la - lb) < 1e-5 * max(1.0, abs(la))
     for k in a._tensors:
+        if k == "conv1_bias":      # exact gradient 0 under batch-statistics BN: Adam turns rounding noise into steps
+            continue
         x, y = a._tensors[k].cpu().numpy(), b._tensors[k].cpu().numpy()
         assert np.abs(x - y).max() < 1e-5 + 1e-4 * np.abs(x).max(), k
     a.close()
