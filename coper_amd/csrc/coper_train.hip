@@ -605,29 +605,43 @@ __global__ __launch_bounds__(256) void k_tr_scale_rows(const float* __restrict__
 }
 
 // dx[b,f] = sum_rho c[b,rho] dA[b,rho*F+f];  dc[b,rho] += sum_f x[b,f] dA[b,rho*F+f]
-__global__ __launch_bounds__(256) void k_tr_outer_bwd(const float* __restrict__ dA, const float* __restrict__ x,
-                                                      const float* __restrict__ c, int64_t F, int r, float* __restrict__ dx,
-                                                      float* __restrict__ dc) {
-  __shared__ float part[256];
+// dx[b, f] = sum_rho c[b, rho] dA[b, rho, f]   (one pass over dA, eight loads in flight)
+__global__ __launch_bounds__(256) void k_tr_outer_bwd(const float* __restrict__ dA, const float* __restrict__ c, int64_t F, int r,
+                                                      float* __restrict__ dx) {
   const int64_t b = blockIdx.y;
   const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const bool ok = f < F;
-  const float xv = ok ? x[b * F + f] : 0.f;
+  if (f >= F) return;
   const float* Ab = dA + b * (int64_t)r * F + f;
+  const float* cb = c + b * r;
   float a = 0.f;
-  for (int rho = 0; rho < r; ++rho) {
-    const float g = ok ? Ab[(int64_t)rho * F] : 0.f;
-    a = fmaf(c[b * r + rho], g, a);
-    part[threadIdx.x] = xv * g;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-      if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) atomicAdd(&dc[b * r + rho], part[0]);
-    __syncthreads();
+  int rho = 0;
+  for (; rho + 8 <= r; rho += 8) {
+    float g[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) g[u] = Ab[(int64_t)(rho + u) * F];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a = fmaf(cb[rho + u], g[u], a);
   }
-  if (ok) dx[b * F + f] = a;
+  for (; rho < r; ++rho) a = fmaf(cb[rho], Ab[(int64_t)rho * F], a);
+  dx[b * F + f] = a;
+}
+
+// dc[b, rho] = sum_k dz[b, k] T[rho][b][k]: z[b] = sum_rho c[b, rho] T[rho][b] with the forward partials T = x P[rho]
+// still in place, so the context gradient needs no second pass over dA.  One wave per (b, rho).
+__global__ __launch_bounds__(256) void k_tr_dc_from_partials(const float* __restrict__ dz, const float* __restrict__ Tf, int64_t B, int r,
+                                                             int d, float* __restrict__ dc) {
+  const int lane = threadIdx.x & 63;
+  const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= B * r) return;
+  const int64_t b = w / r;
+  const int rho = (int)(w - b * r);
+  const float* t = Tf + ((int64_t)rho * B + b) * d;
+  const float* g = dz + b * d;
+  float a = 0.f;
+  for (int k = lane; k < d; k += 64) a = fmaf(g[k], t[k], a);
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) a += __shfl_xor(a, o);
+  if (lane == 0) dc[b * r + rho] = a;
 }
 
 // Conv1BN backward, pass 1: g = dx * keep/(1-rate) through the ReLU; per-channel sums of g and g*yhat
@@ -1230,10 +1244,9 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
     hipLaunchKernelGGL(k_tr_lookup_dx, dim3((unsigned)((F + 63) / 64), (unsigned)B), dim3(256), sizeof(float) * d, s, T->dz, P_("fc_weights"), rel,
                        dm.R, F, d, T->dx);
   } else {
-  // gradients of the two contexts: dcw [B, rc_w] (accumulated by k_tr_outer_bwd) and dcb [B, rc_b] (assigned)
+  // gradients of the two contexts: dcw [B, rc_w] (k_tr_dc_from_partials) and dcb [B, rc_b] (k_tr_fc_post_bwd)
   float* dcw = gen ? T->chain[0].dv[nh] : nullptr;
   float* dcb = gen ? T->chain[1].dv[nh] : nullptr;
-  if (gen) COPER_HIP_TRY(h, hipMemsetAsync(dcw, 0, sizeof(float) * B * rc_w, s));
   hipLaunchKernelGGL(k_tr_fc_post_bwd, dim3((unsigned)B), dim3(256), sizeof(float) * d, s, T->dz, cbv,
                      gen ? P_(blast.c_str()) : nullptr, rc_b, d, tc.seed, step, thr_o, ks_o,
                      gen ? nullptr : G_("fc_bias"), gen ? G_(blast.c_str()) : nullptr, dcb);
@@ -1255,7 +1268,10 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
   if ((rc = rb_check(h, T->rb.sgemm(T->rb.handle, RB_T, RB_N, (int)Kd, (int)B, d, &one, Wmat, d, T->dz, d, &zero, dAmat, (int)Kd), "sgemm dA")))
     return rc;
   if (gen)
-    hipLaunchKernelGGL(k_tr_outer_bwd, dim3((unsigned)((F + 255) / 256), (unsigned)B), dim3(256), 0, s, T->dA, xin, cw, F, rc_w, dxin, dcw);
+  {
+    hipLaunchKernelGGL(k_tr_outer_bwd, dim3((unsigned)((F + 255) / 256), (unsigned)B), dim3(256), 0, s, T->dA, cw, F, rc_w, dxin);
+    hipLaunchKernelGGL(k_tr_dc_from_partials, dim3((unsigned)((B * rc_w + 3) / 4)), dim3(256), 0, s, T->dz, Tf, B, rc_w, d, dcw);
+  }
   if (cat) hipLaunchKernelGGL(k_tr_split, dim3((unsigned)((B * F + 255) / 256)), dim3(256), 0, s, T->dxc, rel, dm.R, Fc, r, B * F, T->dx, G_("rel_emb"));
   }
   // ---- back through a generator chain to the relation rows: dv[nhx] -> dv[0]
