@@ -273,7 +273,16 @@ __global__ __launch_bounds__(256) void k_tr_score_loss(const float* __restrict__
     if (row < 0 || row >= E) row = 0;
     const float* er = ent + row * d;
     float s = 0.f;
-    for (int k = 0; k < d; ++k) s = fmaf(hl[k], er[k], s);
+    if ((d & 3) == 0) {   // 16-byte loads of the gathered row; the fma chain keeps its order
+      const float4* er4 = (const float4*)er;
+      for (int k4 = 0; k4 < d / 4; ++k4) {
+        const float4 e = er4[k4];
+        s = fmaf(hl[4 * k4 + 0], e.x, s); s = fmaf(hl[4 * k4 + 1], e.y, s);
+        s = fmaf(hl[4 * k4 + 2], e.z, s); s = fmaf(hl[4 * k4 + 3], e.w, s);
+      }
+    } else {
+      for (int k = 0; k < d; ++k) s = fmaf(hl[k], er[k], s);
+    }
     s += pred_bias[row];
     const float t = (1.f - ls_eps) * labels[b * L + l] + inv_E;                  // models.py:450
     const float as = fabsf(s);
