@@ -554,48 +554,52 @@ COPER_API int coper_rank_counts(coper_handle* h, const float* hvec, const float*
   hipStream_t s = (hipStream_t)stream;
   int rc;
   if ((rc = ensure_workspace(h, B, filt_nnz, s))) return rc;
-  if (h->cfg.score_mode != COPER_SCORE_F32) {
-    if (!(h->trust_packed && h->packed_hvec == hvec && h->packed_B == B) && (rc = launch_pack_h_bf16(h, hvec, B, s))) return rc;
-    // 0 < k <= 32: the count pass also writes block maxima and the top-k is selected from the few blocks that can
-    // hold it (kernels_topk_bf16.hip): no logits workspace
-    const bool pruned = k > 0 && k <= COPER_TOPK_PRUNED_MAX;
-    if (pruned) {
-      const size_t gneed = (size_t)(h->dm.n_eblk * topk_chunk_queries(h->dm.n_eblk, B, h->gmax_max_floats)), tneed = (size_t)((int64_t)k * B + filt_nnz);
-      if (gneed > h->gmax_cap || tneed > h->cand_cap || (size_t)B > h->cand_tau_cap) {
-        COPER_HIP_TRY(h, hipStreamSynchronize(s));
-        if (gneed > h->gmax_cap) {
-          if ((rc = dev_alloc(h, &h->gmax_ws, gneed))) return rc;
-          h->gmax_cap = gneed;
-        }
-        if (tneed > h->cand_cap) {
-          h->cand_cap = 0;
-          if ((rc = dev_alloc(h, &h->cand_blk_ws, tneed)) || (rc = dev_alloc(h, &h->cand_q_ws, tneed)) ||
-              (rc = dev_alloc(h, &h->cand_val_ws, tneed * 32)) ||
-              (rc = dev_alloc(h, &h->cand_sorted_ws, topk_sorted_cap(h->dm.n_eblk * topk_nseg(h->dm.n_eblk), (int64_t)tneed))))
-            return rc;
-          h->cand_cap = tneed;
-        }
-        if ((size_t)B > h->cand_tau_cap) {
-          if ((rc = dev_alloc(h, &h->cand_tau_ws, (size_t)B))) return rc;
-          h->cand_tau_cap = (size_t)B;
-        }
-        if (!h->blk_cnt_ws) {
-          const size_t gv = (size_t)(h->dm.n_eblk * topk_nseg(h->dm.n_eblk));
-          if ((rc = dev_alloc(h, &h->blk_cnt_ws, 2 * gv)) || (rc = dev_alloc(h, &h->blk_off_ws, gv + 1))) return rc;
-        }
+  // 0 < k <= 32: the count pass also writes block maxima and the top-k is selected from the few blocks that can
+  // hold it (kernels_topk_bf16.hip): no logits workspace
+  const bool pruned = k > 0 && k <= COPER_TOPK_PRUNED_MAX;
+  if (pruned) {
+    const size_t gneed = (size_t)(h->dm.n_eblk * topk_chunk_queries(h->dm.n_eblk, B, h->gmax_max_floats)), tneed = (size_t)((int64_t)k * B + filt_nnz);
+    if (gneed > h->gmax_cap || tneed > h->cand_cap || (size_t)B > h->cand_tau_cap) {
+      COPER_HIP_TRY(h, hipStreamSynchronize(s));
+      if (gneed > h->gmax_cap) {
+        if ((rc = dev_alloc(h, &h->gmax_ws, gneed))) return rc;
+        h->gmax_cap = gneed;
+      }
+      if (tneed > h->cand_cap) {
+        h->cand_cap = 0;
+        if ((rc = dev_alloc(h, &h->cand_blk_ws, tneed)) || (rc = dev_alloc(h, &h->cand_q_ws, tneed)) ||
+            (rc = dev_alloc(h, &h->cand_val_ws, tneed * 32)) ||
+            (rc = dev_alloc(h, &h->cand_sorted_ws, topk_sorted_cap(h->dm.n_eblk * topk_nseg(h->dm.n_eblk), (int64_t)tneed))))
+          return rc;
+        h->cand_cap = tneed;
+      }
+      if ((size_t)B > h->cand_tau_cap) {
+        if ((rc = dev_alloc(h, &h->cand_tau_ws, (size_t)B))) return rc;
+        h->cand_tau_cap = (size_t)B;
+      }
+      if (!h->blk_cnt_ws) {
+        const size_t gv = (size_t)(h->dm.n_eblk * topk_nseg(h->dm.n_eblk));
+        if ((rc = dev_alloc(h, &h->blk_cnt_ws, 2 * gv)) || (rc = dev_alloc(h, &h->blk_off_ws, gv + 1))) return rc;
       }
     }
+  }
+  if (h->cfg.score_mode != COPER_SCORE_F32) {
+    if (!(h->trust_packed && h->packed_hvec == hvec && h->packed_B == B) && (rc = launch_pack_h_bf16(h, hvec, B, s))) return rc;
     if (pruned)
       rc = launch_topk_pruned_bf16x3(h, tgt, e2, filt_indptr, filt_idx, filt_nnz, B, k, n_greater, n_equal, topk_val, topk_idx, s);
     else
       rc = launch_score_count_bf16x3(h, hvec, tgt, B, n_greater, n_equal, s);
     if (rc) return rc;
     if ((rc = launch_filter_correct_bf16x3(h, tgt, e2, filt_indptr, filt_idx, filt_nnz, B, n_greater, n_equal, s))) return rc;
-    if (pruned) return COPER_OK;
   } else {
-    if ((rc = launch_score_count(h, hvec, tgt, B, n_greater, n_equal, s))) return rc;
+    if (pruned)
+      rc = launch_topk_pruned_f32(h, hvec, tgt, e2, filt_indptr, filt_idx, filt_nnz, B, k, n_greater, n_equal, topk_val, topk_idx, s);
+    else
+      rc = launch_score_count(h, hvec, tgt, B, n_greater, n_equal, s);
+    if (rc) return rc;
     if ((rc = launch_filter_correct(h, hvec, tgt, e2, filt_indptr, filt_idx, filt_nnz, B, n_greater, n_equal, s))) return rc;
   }
+  if (pruned) return COPER_OK;
   if (k > 0) {
     // logits workspace: at most 256 MiB (or one row) at a time
     int64_t rows = (int64_t)(256ll << 20) / (h->dm.n_local * 4);

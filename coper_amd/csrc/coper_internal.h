@@ -219,6 +219,14 @@ inline size_t topk_sorted_cap(int64_t n_eblk, int64_t T) { return (size_t)((T + 
 void score_count_begin_bf16x3(coper_handle* h, int64_t B, int32_t* ng, int32_t* ne, hipStream_t s);
 int score_count_chunk_bf16x3(coper_handle* h, int64_t q0, int64_t Bc, const float* tgt, int32_t* ng, int32_t* ne, float* gmax,
                              int64_t gm_stride, hipStream_t s);
+void score_count_begin_f32(coper_handle* h, const float* hvec, int64_t B, int32_t* ng, int32_t* ne, hipStream_t s);
+int score_count_chunk_f32(coper_handle* h, int64_t q0, int64_t Bc, const float* tgt, int32_t* ng, int32_t* ne, float* gmax,
+                          int64_t gm_stride, hipStream_t s);
+int launch_topk_score_blocks_f32(coper_handle* h, const float* hvec, int64_t T, const int64_t* e2, const int64_t* indptr,
+                                 const int64_t* idx, hipStream_t s);
+int launch_topk_pruned_f32(coper_handle* h, const float* hvec, const float* tgt, const int64_t* e2, const int64_t* indptr,
+                           const int64_t* idx, int64_t nnz, int64_t B, int k, int32_t* ng, int32_t* ne, float* topk_val,
+                           int64_t* topk_idx, hipStream_t s);
 int launch_topk_pruned_bf16x3(coper_handle* h, const float* tgt, const int64_t* e2, const int64_t* indptr, const int64_t* idx,
                               int64_t nnz, int64_t B, int k, int32_t* ng, int32_t* ne, float* topk_val, int64_t* topk_idx,
                               hipStream_t s);

@@ -77,13 +77,15 @@ __global__ void k_pack_h(const float* __restrict__ hvec, int64_t B, int d, int K
 
 // EQ = false: the caller does not want n_equal (ties are a diagnostic the reference never computes): the
 // epilogue is one compare per score instead of two.
-template <bool EQ>
+// GM: also write the largest logit of every (32-entity block, query) for the pruned top-k (kernels_topk_bf16.hip).
+template <bool EQ, bool GM>
 __global__ __launch_bounds__(512, 2) void k_score_count_f32(const float4* __restrict__ Ef,
                                                             const float* __restrict__ bias_pad,
                                                             const float4* __restrict__ hfrag,
                                                             const float* __restrict__ tgt, int64_t B, int KS,
                                                             int64_t iters, int64_t units,
-                                                            int32_t* __restrict__ ng, int32_t* __restrict__ ne) {
+                                                            int32_t* __restrict__ ng, int32_t* __restrict__ ne,
+                                                            float* __restrict__ gmax, int64_t gm_stride) {
   constexpr int NQ = SC_NQ;
   extern __shared__ float4 hl[];  // [NQ][KS][64]
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -193,6 +195,16 @@ __global__ __launch_bounds__(512, 2) void k_score_count_f32(const float4* __rest
         if (EQ) ce[b] += (sc == t[b]) ? 1 : 0;
       }
 #endif
+    if (GM) {
+#pragma unroll
+      for (int b = 0; b < NQ; ++b) {
+        float mx = acc[b][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[b][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        if (lane < 32) gmax[eb * gm_stride + cur_tile * (32 * NQ) + b * 32 + lane] = mx;
+      }
+    }
   }
   if (cur_tile >= 0) FLUSH_COUNTS();
 #undef EF_AT
@@ -202,36 +214,53 @@ __global__ __launch_bounds__(512, 2) void k_score_count_f32(const float4* __rest
 #undef FLUSH_COUNTS
 }
 
-int launch_score_count(coper_handle* h, const float* hvec, const float* tgt, int64_t B, int32_t* ng, int32_t* ne,
-                       hipStream_t s) {
+// packs h for the whole batch and zeroes the counters
+void score_count_begin_f32(coper_handle* h, const float* hvec, int64_t B, int32_t* ng, int32_t* ne, hipStream_t s) {
   const Dims& dm = h->dm;
   int64_t q_tiles = (B + 32 * SC_NQ - 1) / (32 * SC_NQ);
-  int64_t iters = dm.n_eblk / SC_WAVES;  // n_eblk is padded to EBLK_ALIGN = SC_WAVES
-  int64_t units = q_tiles * iters;
   int64_t total = q_tiles * SC_NQ * dm.KS * 64;
   hipLaunchKernelGGL(k_pack_h, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, hvec, B, dm.d, dm.KS,
                      (float4*)h->hfrag_ws, total, ng, ne);
+}
+
+// queries [q0, q0 + Bc) of the packed batch (q0 a multiple of the 128-query tile); gmax != NULL: block maxima too
+int score_count_chunk_f32(coper_handle* h, int64_t q0, int64_t Bc, const float* tgt, int32_t* ng, int32_t* ne, float* gmax,
+                          int64_t gm_stride, hipStream_t s) {
+  const Dims& dm = h->dm;
+  int64_t q_tiles = (Bc + 32 * SC_NQ - 1) / (32 * SC_NQ);
+  int64_t iters = dm.n_eblk / SC_WAVES;  // n_eblk is padded to EBLK_ALIGN = SC_WAVES
+  int64_t units = q_tiles * iters;
   int64_t grid = h->num_cus;
   if (grid > units) grid = units;
   size_t lds = (size_t)SC_NQ * dm.KS * 64 * sizeof(float4);
+  const float4* hf = (const float4*)h->hfrag_ws + (q0 / 32) * dm.KS * 64;
   ScopedKernelTimer t(h, "score_count", s);
-  if (ne)
-    hipLaunchKernelGGL(k_score_count_f32<true>, dim3((unsigned)grid), dim3(512), lds, s, (const float4*)h->Ef, h->bias_pad,
-                       (const float4*)h->hfrag_ws, tgt, B, dm.KS, iters, units, ng, ne);
-  else
-    hipLaunchKernelGGL(k_score_count_f32<false>, dim3((unsigned)grid), dim3(512), lds, s, (const float4*)h->Ef, h->bias_pad,
-                       (const float4*)h->hfrag_ws, tgt, B, dm.KS, iters, units, ng, ne);
+#define SC_LAUNCH(EQ_, GM_)                                                                                                    \
+  hipLaunchKernelGGL((k_score_count_f32<EQ_, GM_>), dim3((unsigned)grid), dim3(512), lds, s, (const float4*)h->Ef, h->bias_pad, \
+                     hf, tgt + q0, Bc, dm.KS, iters, units, ng + q0, ne ? ne + q0 : nullptr, gmax, gm_stride)
+  if (gmax) { if (ne) SC_LAUNCH(true, true); else SC_LAUNCH(false, true); }
+  else      { if (ne) SC_LAUNCH(true, false); else SC_LAUNCH(false, false); }
+#undef SC_LAUNCH
   COPER_HIP_TRY(h, hipGetLastError());
   return COPER_OK;
+}
+
+int launch_score_count(coper_handle* h, const float* hvec, const float* tgt, int64_t B, int32_t* ng, int32_t* ne,
+                       hipStream_t s) {
+  score_count_begin_f32(h, hvec, B, ng, ne, s);
+  return score_count_chunk_f32(h, 0, B, tgt, ng, ne, nullptr, 0, s);
 }
 
 int score_kernels_init(coper_handle* h) {
   const Dims& dm = h->dm;
   int lds = (int)((size_t)SC_NQ * dm.KS * 64 * sizeof(float4));
-  COPER_HIP_TRY(h, hipFuncSetAttribute((const void*)k_score_count_f32<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  COPER_HIP_TRY(h, hipFuncSetAttribute((const void*)k_score_count_f32<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  COPER_HIP_TRY(h, hipFuncSetAttribute((const void*)k_score_count_f32<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  COPER_HIP_TRY(h, hipFuncSetAttribute((const void*)k_score_count_f32<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  COPER_HIP_TRY(h, hipFuncSetAttribute((const void*)k_score_count_f32<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  COPER_HIP_TRY(h, hipFuncSetAttribute((const void*)k_score_count_f32<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   return COPER_OK;
 }
+
 
 // ------------------------------------------------------------------------------------------------
 // logits out.  D[i][j]: i = query (A operand from LDS), j = entity (B operand, one entity per lane):
@@ -607,6 +636,42 @@ __global__ void k_finish_ranks(const int32_t* __restrict__ ng, int64_t B, int32_
 
 int launch_finish_ranks(coper_handle* h, const int32_t* ng, int64_t B, int32_t* ranks, hipStream_t s) {
   hipLaunchKernelGGL(k_finish_ranks, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, ng, B, ranks);
+  COPER_HIP_TRY(h, hipGetLastError());
+  return COPER_OK;
+}
+
+// pruned top-k, fp32-exact mode: the 32 logits of every candidate (query, block) slot by the VALU chain (the bits
+// of the MFMA tiles), known answers except the target masked -- no grouping by block needed, a thread per logit
+__global__ __launch_bounds__(256) void k_topk_score_blocks_f32(const float* __restrict__ ent, const float* __restrict__ bias,
+                                                               const float* __restrict__ hvec, int d, int64_t T,
+                                                               const int64_t* __restrict__ e2, const int64_t* __restrict__ indptr,
+                                                               const int64_t* __restrict__ idx, const int32_t* __restrict__ cand_blk,
+                                                               const int32_t* __restrict__ cand_q, int64_t lo, int64_t n_local,
+                                                               float* __restrict__ cand_val) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= T * 32) return;
+  const int64_t w = i >> 5;
+  const int32_t g = cand_blk[w];
+  if (g < 0) { cand_val[i] = -INFINITY; return; }
+  const int64_t q = cand_q[w];
+  const int64_t row = (int64_t)g * 32 + (i & 31);
+  float v = -INFINITY;
+  if (row < n_local) {
+    const int64_t ent_id = row + lo;
+    bool known = false;
+    if (ent_id != e2[q])
+      for (int64_t j = indptr[q]; j < indptr[q + 1]; ++j) known |= idx[j] == ent_id;
+    if (!known) v = chain_score(ent + row * d, hvec + q * d, bias[row], d);
+  }
+  cand_val[i] = v;
+}
+
+int launch_topk_score_blocks_f32(coper_handle* h, const float* hvec, int64_t T, const int64_t* e2, const int64_t* indptr,
+                                 const int64_t* idx, hipStream_t s) {
+  const Dims& dm = h->dm;
+  hipLaunchKernelGGL(k_topk_score_blocks_f32, dim3((unsigned)((T * 32 + 255) / 256)), dim3(256), 0, s, h->params["ent_emb"].ptr,
+                     h->params["pred_bias"].ptr, hvec, dm.d, T, e2, indptr, idx, h->cand_blk_ws, h->cand_q_ws, (int64_t)h->cfg.shard_lo,
+                     dm.n_local, h->cand_val_ws);
   COPER_HIP_TRY(h, hipGetLastError());
   return COPER_OK;
 }

@@ -533,4 +533,33 @@ int launch_topk_pruned_bf16x3(coper_handle* h, const float* tgt, const int64_t* 
   return COPER_OK;
 }
 
+// fp32-exact mode: same threshold / selection kernels on the block maxima of k_score_count_f32; candidates are
+// rescored by the VALU chain (kernels_score.hip), which needs no grouping by block
+int launch_topk_pruned_f32(coper_handle* h, const float* hvec, const float* tgt, const int64_t* e2, const int64_t* indptr,
+                           const int64_t* idx, int64_t nnz, int64_t B, int k, int32_t* ng, int32_t* ne, float* topk_val,
+                           int64_t* topk_idx, hipStream_t s) {
+  const Dims& dm = h->dm;
+  const int64_t G = dm.n_eblk;
+  const int64_t qc = topk_chunk_queries(G, B, h->gmax_max_floats);
+  const int64_t T = (int64_t)k * B + nnz;
+  if ((size_t)(G * qc) > h->gmax_cap || (size_t)T > h->cand_cap)
+    return fail(h, COPER_ESTATE, "pruned top-k: workspace not reserved");
+  int rc;
+  score_count_begin_f32(h, hvec, B, ng, ne, s);
+  COPER_HIP_TRY(h, hipMemsetAsync(h->blk_cnt_ws, 0, sizeof(int32_t) * 2 * G * topk_nseg(G), s));
+  for (int64_t q0 = 0; q0 < B; q0 += qc) {
+    const int64_t bc = B - q0 < qc ? B - q0 : qc;
+    const int64_t qs = (bc + 127) / 128 * 128;
+    if ((rc = score_count_chunk_f32(h, q0, bc, tgt, ng, ne, h->gmax_ws, qs, s))) return rc;
+    if (G < 4096) tk_launch_emit<8, 1>(h, G, qs, q0, bc, k, indptr, s);
+    else if (qs / 32 >= h->num_cus) tk_launch_emit<8, 2>(h, G, qs, q0, bc, k, indptr, s);
+    else tk_launch_emit<4, 4>(h, G, qs, q0, bc, k, indptr, s);
+  }
+  if ((rc = launch_topk_score_blocks_f32(h, hvec, T, e2, indptr, idx, s))) return rc;
+  hipLaunchKernelGGL(k_topk_select_cand, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s, h->cand_val_ws, h->cand_blk_ws, h->cand_tau_ws, indptr, B,
+                     k, (int64_t)h->cfg.shard_lo, topk_val, topk_idx);
+  COPER_HIP_TRY(h, hipGetLastError());
+  return COPER_OK;
+}
+
 }  // namespace coper

@@ -578,9 +578,10 @@ def test_encode_rank_single_call_equals_two_calls(mode):
     m.close()
 
 
+@pytest.mark.parametrize("mode", ["bf16x3", "f32"])
 @pytest.mark.parametrize("chunk", [None, 128])
-def test_pruned_topk_bf16x3_matches_masked_row_topk(oracle_chain, chunk, monkeypatch):
-    """bf16x3, k <= 32: top-k selected from block maxima (kernels_topk_bf16.hip), logits never materialised.
+def test_pruned_topk_matches_masked_row_topk(oracle_chain, chunk, mode, monkeypatch):
+    """k <= 32, both score modes: top-k selected from block maxima (kernels_topk_bf16.hip), logits never materialised.
     Must equal the top-k of the masked row of the mode's own logits, (score desc, id asc): with exact ties
     (duplicate and all-zero entity rows), filters that hold the row's best entities, k above the number of
     unfiltered entities, several query chunks, two entity shards merged, and the counts unchanged."""
@@ -601,7 +602,7 @@ def test_pruned_topk_bf16x3_matches_masked_row_topk(oracle_chain, chunk, monkeyp
     p["ent_emb"], p["pred_bias"] = ent, bias
     Q = 300
     q = cdata.synthetic_queries(md, Q, seed=9, mean_filter=6.0, max_filter=40)
-    m = _model(md, p, score_mode="bf16x3")
+    m = _model(md, p, score_mode=mode)
     h = m.encode(q["e1"], q["rel"])
     logits = m.score_all(h).cpu().numpy()
     # filters that contain the best-scoring entities of their row (what real filters do), CSR rebuilt
@@ -625,7 +626,7 @@ def test_pruned_topk_bf16x3_matches_masked_row_topk(oracle_chain, chunk, monkeyp
     ent3[1000:3900] = 0.0
     bias3[1000:3900] = 30.0
     p3["ent_emb"], p3["pred_bias"] = ent3, bias3
-    m3 = _model(md, p3, score_mode="bf16x3")
+    m3 = _model(md, p3, score_mode=mode)
     h3 = m3.encode(q["e1"], q["rel"])
     logits3 = m3.score_all(h3).cpu().numpy()
     _, _, tv, ti = m3.rank_counts(h3, m3.target_scores(h3, q["e2"]), q["e2"], indptr, idx, k=10)
@@ -633,7 +634,7 @@ def test_pruned_topk_bf16x3_matches_masked_row_topk(oracle_chain, chunk, monkeyp
     assert np.array_equal(ti.cpu().numpy(), ei) and np.array_equal(tv.cpu().numpy(), ev)
     m3.close()
     # two shards, merged
-    shards = [_model(md, p, shard=(0, 2100), score_mode="bf16x3"), _model(md, p, shard=(2100, 5000), score_mode="bf16x3")]
+    shards = [_model(md, p, shard=(0, 2100), score_mode=mode), _model(md, p, shard=(2100, 5000), score_mode=mode)]
     parts = [s_.rank_counts(h, tgt, q["e2"], indptr, idx, k=10) for s_ in shards]
     tv, ti = merge_topk(torch.cat([x[2] for x in parts], 1), torch.cat([x[3] for x in parts], 1), 10)
     ev, ei = O.topk_filtered(logits, q["e2"], indptr, idx, 10)
@@ -642,7 +643,7 @@ def test_pruned_topk_bf16x3_matches_masked_row_topk(oracle_chain, chunk, monkeyp
     md2 = cdata.model_descriptors("nations_cpg")
     p2 = cdata.synthetic_params(md2, 1)
     q2 = cdata.synthetic_queries(md2, 20, seed=1, mean_filter=3.0, max_filter=8)
-    m2 = _model(md2, p2, score_mode="bf16x3")
+    m2 = _model(md2, p2, score_mode=mode)
     h2 = m2.encode(q2["e1"], q2["rel"])
     _, _, tv, ti = m2.rank_counts(h2, m2.target_scores(h2, q2["e2"]), q2["e2"], q2["filt_indptr"], q2["filt_idx"], k=16)
     ev, ei = O.topk_filtered(m2.score_all(h2).cpu().numpy(), q2["e2"], q2["filt_indptr"], q2["filt_idx"], 16)
