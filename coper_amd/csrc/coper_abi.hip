@@ -556,7 +556,8 @@ COPER_API int coper_rank_counts(coper_handle* h, const float* hvec, const float*
   if ((rc = ensure_workspace(h, B, filt_nnz, s))) return rc;
   // 0 < k <= 32: the count pass also writes block maxima and the top-k is selected from the few blocks that can
   // hold it (kernels_topk_bf16.hip): no logits workspace
-  const bool pruned = k > 0 && k <= COPER_TOPK_PRUNED_MAX;
+  const bool pruned = k > 0 && k <= COPER_TOPK_PRUNED_MAX &&
+                      (int64_t)k * B + filt_nnz + 32 * h->dm.n_eblk * topk_nseg(h->dm.n_eblk) < 0x7fffffffLL;   // int32 slot ids
   if (pruned) {
     const size_t gneed = (size_t)(h->dm.n_eblk * topk_chunk_queries(h->dm.n_eblk, B, h->gmax_max_floats)), tneed = (size_t)((int64_t)k * B + filt_nnz);
     if (gneed > h->gmax_cap || tneed > h->cand_cap || (size_t)B > h->cand_tau_cap) {

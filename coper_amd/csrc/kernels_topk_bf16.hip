@@ -505,6 +505,8 @@ int launch_topk_pruned_bf16x3(coper_handle* h, const float* tgt, const int64_t* 
     return fail(h, COPER_ESTATE, "pruned top-k: workspace not reserved");
   int rc;
   score_count_begin_bf16x3(h, B, ng, ne, s);
+  // slots no query owns (filt_nnz may be a capacity larger than the CSR) must read as unused
+  COPER_HIP_TRY(h, hipMemsetAsync(h->cand_blk_ws, 0xFF, sizeof(int32_t) * T, s));
   const int nseg = topk_nseg(G);
   const int64_t GV = G * nseg;   // (block, segment) counters
   COPER_HIP_TRY(h, hipMemsetAsync(h->blk_cnt_ws, 0, sizeof(int32_t) * 2 * GV, s));          // counts | scatter cursors
@@ -546,6 +548,7 @@ int launch_topk_pruned_f32(coper_handle* h, const float* hvec, const float* tgt,
     return fail(h, COPER_ESTATE, "pruned top-k: workspace not reserved");
   int rc;
   score_count_begin_f32(h, hvec, B, ng, ne, s);
+  COPER_HIP_TRY(h, hipMemsetAsync(h->cand_blk_ws, 0xFF, sizeof(int32_t) * T, s));
   COPER_HIP_TRY(h, hipMemsetAsync(h->blk_cnt_ws, 0, sizeof(int32_t) * 2 * G * topk_nseg(G), s));
   for (int64_t q0 = 0; q0 < B; q0 += qc) {
     const int64_t bc = B - q0 < qc ? B - q0 : qc;
