@@ -60,6 +60,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--score-mode", choices=["f32", "bf16x3"], default="bf16x3")
+    ap.add_argument("--profile-every", type=int, default=4,
+                    help="HIP-event timing of the dominant kernels on every N-th timed step (an event pair around a launch "
+                         "costs the stream a few microseconds of pipeline drain; 1 = every step)")
     ap.add_argument("--topk", type=int, default=0,
                     help="entity mode: also select and exchange the per-shard top-k of the filtered rows (SURVEY 8(e) step 3)")
     ap.add_argument("--dist-backend", default="nccl",
@@ -170,11 +173,13 @@ def main():
     model.profile(True)
     for k in ("score_count", "dense", "conv"):
         model.profile_read(k)
+    model.profile(False)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        model.profile(i % max(1, args.profile_every) == 0)     # per-kernel HIP events on a sample of the timed steps
         ranks, _ = step()
     torch.cuda.synchronize(device)
     if world > 1:
