@@ -109,6 +109,9 @@ constexpr int BX_WAVES = 8;
 #ifndef COPER_BX_ME
 #define COPER_BX_ME 2
 #endif
+#ifndef COPER_BX_PD
+#define COPER_BX_PD 3
+#endif
 constexpr int BX_ME = COPER_BX_ME;
 #ifdef COPER_BX_NT
 typedef unsigned bx_u32x4 __attribute__((ext_vector_type(4)));
@@ -203,15 +206,15 @@ __global__ __launch_bounds__(512, 2) void k_score_count_bf16x3(const uint4* __re
     }                                                                         \
   }
 
-  // entity fragments are fetched THREE k-steps ahead (a k-step is only 12*ME MFMAs here, shorter than an L2
+  // entity fragments are fetched PD = 3 k-steps ahead (a k-step is only 12*ME MFMAs here, shorter than an L2
   // round trip under load): four rotating register buffers
-  uint4 ah[4][ME], al[4][ME];
+  constexpr int PD = COPER_BX_PD, NBF = PD + 1;   // prefetch distance in k-steps, rotating register buffers
+  uint4 ah[NBF][ME], al[NBF][ME];
 #define KCL(k_) ((k_) < KS ? (k_) : KS - 1)
   if (u_begin < u_end) {
     int64_t eb = ((u_begin % iters) * BX_WAVES + wave) * ME;
-    LOAD_A(ah[0], al[0], eb, 0);
-    LOAD_A(ah[1], al[1], eb, KCL(1));
-    LOAD_A(ah[2], al[2], eb, KCL(2));
+#pragma unroll
+    for (int i = 0; i < PD; ++i) LOAD_A(ah[i], al[i], eb, KCL(i));
     LOAD_BIAS(eb);
   }
   for (int64_t u = u_begin; u < u_end; ++u) {
@@ -248,10 +251,10 @@ __global__ __launch_bounds__(512, 2) void k_score_count_bf16x3(const uint4* __re
     // loads just issued must have landed" -- one step ahead.  Fetches past the last k-step re-read it (KCL),
     // the prefetch for the unit after the last one re-reads this unit's blocks.
     int ks = 0;
-    for (; ks + 4 <= KS; ks += 4) {
+    for (; ks + NBF <= KS; ks += NBF) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        LOAD_A(ah[(j + 3) & 3], al[(j + 3) & 3], eb, KCL(ks + j + 3));
+      for (int j = 0; j < NBF; ++j) {
+        LOAD_A(ah[(j + PD) % NBF], al[(j + PD) % NBF], eb, KCL(ks + j + PD));
         __builtin_amdgcn_sched_barrier(0);
         uint4 bh[NQ], bl[NQ];
         LOAD_B(bh, bl, ks + j);
@@ -259,9 +262,9 @@ __global__ __launch_bounds__(512, 2) void k_score_count_bf16x3(const uint4* __re
       }
     }
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      if (ks + j < KS) {  // wave-uniform; KS % 4 trailing steps
-        LOAD_A(ah[(j + 3) & 3], al[(j + 3) & 3], eb, KCL(ks + j + 3));
+    for (int j = 0; j < NBF - 1; ++j) {
+      if (ks + j < KS) {  // wave-uniform; KS % NBF trailing steps
+        LOAD_A(ah[(j + PD) % NBF], al[(j + PD) % NBF], eb, KCL(ks + j + PD));
         __builtin_amdgcn_sched_barrier(0);
         uint4 bh[NQ], bl[NQ];
         LOAD_B(bh, bl, ks + j);
@@ -270,9 +273,8 @@ __global__ __launch_bounds__(512, 2) void k_score_count_bf16x3(const uint4* __re
     }
     {
       const int64_t ebn = u + 1 < u_end ? (((u + 1) % iters) * BX_WAVES + wave) * ME : eb;
-      LOAD_A(ah[0], al[0], ebn, 0);
-      LOAD_A(ah[1], al[1], ebn, KCL(1));
-      LOAD_A(ah[2], al[2], ebn, KCL(2));
+#pragma unroll
+      for (int i = 0; i < PD; ++i) LOAD_A(ah[i], al[i], ebn, KCL(i));
       LOAD_BIAS(ebn);
     }
 #ifdef COPER_DBG_BX_NO_EPILOGUE
