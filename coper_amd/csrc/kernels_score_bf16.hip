@@ -211,6 +211,11 @@ __global__ __launch_bounds__(512, 2) void k_score_count_bf16x3(const uint4* __re
   constexpr int PD = COPER_BX_PD, NBF = PD + 1;   // prefetch distance in k-steps, rotating register buffers
   uint4 ah[NBF][ME], al[NBF][ME];
 #define KCL(k_) ((k_) < KS ? (k_) : KS - 1)
+#ifdef COPER_BX_STAGGER
+  // the two waves of a SIMD (w, w + 4) would otherwise run their compare epilogues at the same time, matrix pipe idle:
+  // start the second one late so that one wave's epilogue falls into the other's k-loop
+  if (wave >= 4) __builtin_amdgcn_s_sleep(COPER_BX_STAGGER);
+#endif
   if (u_begin < u_end) {
     int64_t eb = ((u_begin % iters) * BX_WAVES + wave) * ME;
 #pragma unroll
