@@ -105,7 +105,11 @@ int launch_rows_to_frag_bf16(coper_handle* h, const float* src, int64_t n_rows, 
 #define COPER_BX_WGS_PER_CU 1
 #endif
 constexpr int BX_NQ = COPER_BX_NQ;
-constexpr int BX_WAVES = 8;
+#ifndef COPER_BX_WAVES
+#define COPER_BX_WAVES 8
+#endif
+constexpr int BX_WAVES = COPER_BX_WAVES;          // waves per workgroup (8: two per SIMD; 16: four per SIMD, needs ME = 1)
+constexpr int BX_THREADS = 64 * BX_WAVES;
 #ifndef COPER_BX_ME
 #define COPER_BX_ME 2
 #endif
@@ -144,7 +148,7 @@ __global__ void k_zero_counts(int64_t B, int32_t* __restrict__ ng, int32_t* __re
 // GM: also write, per (32-entity block, query), the largest logit of the block -- what the pruned top-k
 // (kernels_topk_bf16.hip) selects its candidate blocks from; gmax[block * gm_stride + query].
 template <bool EQ, bool GM>
-__global__ __launch_bounds__(512, 2) void k_score_count_bf16x3(const uint4* __restrict__ Ehi,
+__global__ __launch_bounds__(BX_THREADS, BX_WAVES / 4) void k_score_count_bf16x3(const uint4* __restrict__ Ehi,
                                                                const uint4* __restrict__ Elo,
                                                                const float* __restrict__ bias_pad,
                                                                const uint4* __restrict__ Hhi,
@@ -230,7 +234,7 @@ __global__ __launch_bounds__(512, 2) void k_score_count_bf16x3(const uint4* __re
       __syncthreads();
       const uint4* sh = Hhi + tile * (NQ * KS * 64);
       const uint4* sl = Hlo + tile * (NQ * KS * 64);
-      for (int j = threadIdx.x; j < NQ * KS * 64; j += 512) { hl_hi[j] = sh[j]; hl_lo[j] = sl[j]; }
+      for (int j = threadIdx.x; j < NQ * KS * 64; j += BX_THREADS) { hl_hi[j] = sh[j]; hl_lo[j] = sl[j]; }
       cur_tile = tile;
 #pragma unroll
       for (int b = 0; b < NQ; ++b) {
@@ -341,7 +345,7 @@ int score_count_chunk_bf16x3(coper_handle* h, int64_t q0, int64_t Bc, const floa
   const uint4* hlo = (const uint4*)h->hfrag16_lo + (q0 / 32) * dm.KS16 * 64;
   ScopedKernelTimer t(h, "score_count", s);
 #define BX_LAUNCH(EQ_, GM_)                                                                                                       \
-  hipLaunchKernelGGL((k_score_count_bf16x3<EQ_, GM_>), dim3((unsigned)grid), dim3(512), lds, s, (const uint4*)h->Ef16_hi,         \
+  hipLaunchKernelGGL((k_score_count_bf16x3<EQ_, GM_>), dim3((unsigned)grid), dim3(BX_THREADS), lds, s, (const uint4*)h->Ef16_hi,  \
                      (const uint4*)h->Ef16_lo, h->bias_pad, hhi, hlo, tgt + q0, Bc, dm.KS16, iters, units, ng + q0,                \
                      ne ? ne + q0 : nullptr, gmax, gm_stride)
   if (gmax) { if (ne) BX_LAUNCH(true, true); else BX_LAUNCH(false, true); }
