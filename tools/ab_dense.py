@@ -19,4 +19,4 @@ for _ in range(20):
     m.encode(dq["e1"], dq["rel"])
 torch.cuda.synchronize()
 ms, n = m.profile_read("dense"); ms2, n2 = m.profile_read("conv")
-print("%s: dense avg %.4f ms, conv avg %.4f ms" % (os.environ.get("COPER_HIP_LIB", "default"), ms / n, ms2 / n2))
+print("%s: dense avg %.4f ms, conv avg %.4f ms" % (os.environ.get("COPER_HIP_LIB", "default"), ms / max(n, 1), ms2 / max(n2, 1)))
