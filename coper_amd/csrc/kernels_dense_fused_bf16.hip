@@ -5,7 +5,7 @@
 // requests for 26 % of its bytes, and the conv kernel spends its time writing those bytes.  Here a workgroup
 // (one relation tile x one K slice) keeps the slice's rows of the e1 images in LDS and produces each k-step's
 // x fragments itself -- 3x3 conv, BN, ReLU, hi/lo split -- straight into the B-operand layout in LDS, one
-// k-step ahead of the MFMAs that consume them.  HBM sees the weight stream (read once, non-temporal, PF
+// k-step ahead of the MFMAs that consume them.  HBM sees the weight stream (read once, non-temporal when one tile reads a set, PF
 // k-steps ahead in registers of the owning wave, as in k_dense_reg_bf16x3), the gathered e1 rows and z.
 //
 // Supported when the filter is 3x3 with C = 32 channels (one k-step of 32 features = one output pixel), no
@@ -121,7 +121,7 @@ __device__ __forceinline__ void fused_load_images(float* __restrict__ img, const
 // over, so that every SIMD carries the same MFMA load to within one query block (dealing whole feature blocks
 // would leave one wave with 4 of 13).  All four waves then stream that last block's weight fragments; the
 // repeats hit L1/L2.
-template <int NFB, int NB>
+template <int NFB, int NB, bool WNT>
 __device__ __forceinline__ void fused_matrix_role(const uint4* __restrict__ xring, float* __restrict__ img,
                                                   const uint4* __restrict__ Whi, const uint4* __restrict__ Wlo,
                                                   const FusedConvArgs& A, int64_t relw, int start, int n, int fb0,
@@ -147,11 +147,16 @@ __device__ __forceinline__ void fused_matrix_role(const uint4* __restrict__ xrin
     wp[j][1] = Wlo + o;
   }
   u32x4 W[P][NW][2];
+  // WNT: non-temporal loads when a weight set is read by one tile only (FB15k-237 CoPER shapes: -2.3 % on the whole
+  // pass against cached loads, which push the entity table out of L2 ahead of the count pass); plain loads when every
+  // tile of a relation re-reads it and L2 serves the repeats (3 tiles per relation at WN18RR shapes: -11 % on this
+  // kernel; all 160 tiles for the static layer of plain ConvE: -3.5 %)
+#define FUSED_W_LOAD(p_) (WNT ? __builtin_nontemporal_load(p_) : *(p_))
 #define W_ISSUE(s, kk)                                                                                 \
   {                                                                                                    \
     _Pragma("unroll") for (int j = 0; j < NW; ++j) {                                                   \
-      W[s][j][0] = __builtin_nontemporal_load((const u32x4*)(wp[j][0] + (int64_t)(kk)*64) + lane);     \
-      W[s][j][1] = __builtin_nontemporal_load((const u32x4*)(wp[j][1] + (int64_t)(kk)*64) + lane);     \
+      W[s][j][0] = FUSED_W_LOAD((const u32x4*)(wp[j][0] + (int64_t)(kk)*64) + lane);                  \
+      W[s][j][1] = FUSED_W_LOAD((const u32x4*)(wp[j][1] + (int64_t)(kk)*64) + lane);                  \
     }                                                                                                  \
   }
 #pragma unroll
@@ -316,7 +321,7 @@ __device__ __forceinline__ void fused_conv_role(uint4* __restrict__ xring, float
   }
 }
 
-template <int NFB>
+template <int NFB, bool WNT>
 __global__ __launch_bounds__(512) void k_dense_fused_bf16x3(const uint4* __restrict__ Whi, const uint4* __restrict__ Wlo,
                                                             FusedConvArgs A, const int32_t* __restrict__ tiles,
                                                             const int32_t* __restrict__ n_tiles, int64_t cap_small,
@@ -356,7 +361,7 @@ __global__ __launch_bounds__(512) void k_dense_fused_bf16x3(const uint4* __restr
   if (t1 > A.in_hw) t1 = A.in_hw;
 #define BODY(NB_)                                                                                                      \
   if (wave < 4)                                                                                                        \
-    fused_matrix_role<NFB, NB_>(xring, img, Whi, Wlo, A, relw, start, n, fb0, nfb, ks32n, kb, ke, t0, t1, zdst,        \
+    fused_matrix_role<NFB, NB_, WNT>(xring, img, Whi, Wlo, A, relw, start, n, fb0, nfb, ks32n, kb, ke, t0, t1, zdst,        \
                                 d_pad16, wave);                                                                        \
   else                                                                                                                 \
     fused_conv_role<NB_>(xring, img, A, relw, start, n, kb, ke, i_lo, t0, t1, wave - 4);
@@ -398,7 +403,7 @@ bool dense_fused_supported(const coper_handle* h, int nslices) {
   return lds <= 160 * 1024;
 }
 
-template <int NFB>
+template <int NFB, bool WNT>
 static void dense_fused_launch(coper_handle* h, const int64_t* e1, const int64_t* rel, const float* e1_rows, int64_t B,
                                int nslices, int zgroups, hipStream_t s) {
   const Dims& dm = h->dm;
@@ -418,10 +423,10 @@ static void dense_fused_launch(coper_handle* h, const int64_t* e1, const int64_t
   size_t lds = (size_t)2 * 16 * 64 * sizeof(uint4) + (size_t)128 * A.img_stride * sizeof(float);
   static bool attr_done = false;   // per instantiation; process-wide attribute: always the hardware maximum
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)k_dense_fused_bf16x3<NFB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_dense_fused_bf16x3<NFB, WNT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  hipLaunchKernelGGL((k_dense_fused_bf16x3<NFB>), dim3((unsigned)(n_big_max + n_small_max), (unsigned)nslices, (unsigned)zgroups), dim3(512),
+  hipLaunchKernelGGL((k_dense_fused_bf16x3<NFB, WNT>), dim3((unsigned)(n_big_max + n_small_max), (unsigned)nslices, (unsigned)zgroups), dim3(512),
                      lds, s, (const uint4*)h->Wf16_hi, (const uint4*)h->Wf16_lo, A, h->tiles, h->n_tiles, cap_small, dm.nfb,
                      dm.F_pad / 32, nslices, h->ws_queries, dm.d_pad16, h->z_part, (int)n_big_max);
 }
@@ -435,9 +440,18 @@ int launch_dense_fused_bf16(coper_handle* h, const int64_t* e1, const int64_t* r
   // (B <= 2048) or four (B <= 1024)
   // workgroups (grid.z; every accumulation chain is unchanged, so h keeps its bits) -- the image / conv work is
   // repeated per group, which small tiles do not notice.
-  if (B <= COPER_FUSED_SPLIT_B / 2) dense_fused_launch<4>(h, e1, rel, e1_rows, B, nslices, (h->dm.nfb + 3) / 4, s);
-  else if (h->dm.nfb == 13 && B > COPER_FUSED_SPLIT_B) dense_fused_launch<13>(h, e1, rel, e1_rows, B, nslices, 1, s);
-  else dense_fused_launch<8>(h, e1, rel, e1_rows, B, nslices, (h->dm.nfb + 7) / 8, s);
+  // one tile per weight set (per-relation weights, on average at most 128 queries per forward relation): stream them
+  // past the caches; otherwise let L2 serve the tiles that re-read a set
+  const bool wnt = h->dm.gen_fc && B * 2 <= 128 * h->dm.R;
+#define FUSED_GO(NFB_, Z_)                                                             \
+  {                                                                                    \
+    if (wnt) dense_fused_launch<NFB_, true>(h, e1, rel, e1_rows, B, nslices, Z_, s);   \
+    else dense_fused_launch<NFB_, false>(h, e1, rel, e1_rows, B, nslices, Z_, s);      \
+  }
+  if (B <= COPER_FUSED_SPLIT_B / 2) FUSED_GO(4, (h->dm.nfb + 3) / 4)
+  else if (h->dm.nfb == 13 && B > COPER_FUSED_SPLIT_B) FUSED_GO(13, 1)
+  else FUSED_GO(8, (h->dm.nfb + 7) / 8)
+#undef FUSED_GO
   COPER_HIP_TRY(h, hipGetLastError());
   return COPER_OK;
 }
