@@ -116,6 +116,11 @@ def cpu_baseline(md, params, q, seconds):
 
 def main():
     args = parse_args()
+    # stdout carries exactly one line, the JSON result of rank 0: whatever libraries print on the way (RCCL's version
+    # banner at communicator creation goes to stdout) is sent to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     from coper_amd import data as cdata
@@ -131,7 +136,8 @@ def main():
         local_rank = local_rank % max(1, torch.cuda.device_count())   # debugging: ranks may share a GPU
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or bool(os.environ.get("COPER_BENCH_FORCE_DIST"))   # the env var: exercise the RCCL path with one rank
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
@@ -174,7 +180,7 @@ def main():
     for k in ("score_count", "dense", "conv"):
         model.profile_read(k)
     model.profile(False)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
@@ -182,11 +188,11 @@ def main():
         model.profile(i % max(1, args.profile_every) == 0)     # per-kernel HIP events on a sample of the timed steps
         ranks, _ = step()
     torch.cuda.synchronize(device)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
     model.profile(False)
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], device=device if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -275,8 +281,11 @@ def main():
             if host_p is not None:
                 out["cpu_baseline"] = cpu_baseline(md, host_p, q, args.cpu_seconds)
                 out["config"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        sys.stdout.flush()
+        os.dup2(json_fd, 1)
         print(json.dumps(out))
-    if world > 1:
+        sys.stdout.flush()
+    if use_dist:
         dist.destroy_process_group()
 
 
