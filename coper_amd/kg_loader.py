@@ -143,10 +143,30 @@ class TSVKGLoader(object):
         self.num_ent, self.num_rel = len(entity_ids), len(relation_ids)    # data.py:337-338
         return entity_ids, relation_ids
 
-    def maybe_create_tf_record_files(self, directory=None, buffer_size=None):
-        """Name kept for the driver (run_cpg.py:108): loads, assigns ids; nothing TF is written."""
+    def maybe_create_tf_record_files(self, directory=None, buffer_size=None, write_tfrecords=False,
+                                     max_records_per_file=1000000):
+        """Name kept for the driver (run_cpg.py:108): loads and assigns ids.  This engine feeds from the in-memory
+        id arrays; `write_tfrecords=True` also writes the reference's `<split>-<n>.tfrecords` files
+        (data.py:353-388) -- only the missing splits, as the reference does -- so that its own loader finds them.
+        Returns {split: [file names]} of what exists / was written, or None."""
         self.assign_ids()
-        return None
+        if not write_tfrecords:
+            return None
+        import glob
+        from . import tf_records
+        directory = directory or self.directory
+        E, Rm = self.entity_ids, self.relation_ids
+        out = {}
+        for split in ("train", "dev", "test"):
+            existing = glob.glob(os.path.join(directory, "%s-*.tfrecords" % split))
+            if existing:                       # data.py:360-363: not recreated
+                out[split] = sorted(existing)
+                continue
+            samples = ({"e1": E.get(s["e1"], -1), "e2": E.get(s["e2"], -1), "rel": Rm.get(s["rel"], -1),
+                        "e2_multi": [E[t] for t in s["e2_multi"] if t != "None"],
+                        "is_inverse": s["rel"].endswith("_reverse")} for s in self._samples[split])
+            out[split] = tf_records.write_split(directory, split, samples, max_records_per_file)
+        return out
 
     # ---------------------------------------------------------------- data.py:168-226 + 574-594
     def encoded_split(self, dataset_type: str, include_inv_relations: bool = False):

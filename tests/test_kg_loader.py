@@ -128,3 +128,53 @@ def test_train_dataset_sampler_rules(tmp_path):
         assert ok
     with pytest.raises(ValueError):
         TrainDataset(s, E, 4, num_labels=E + 1)
+
+
+def test_tfrecord_files_round_trip(tmp_path, golden_dir):
+    """The reference's TFRecord files (data.py:353-397, 574-594) without TensorFlow: framing known answers, Example
+    round trip incl. negative ids and empty lists, and the loader's splits written and read back == the in-memory
+    id arrays the engine feeds from."""
+    import shutil
+    import struct
+    from coper_amd import tf_records as tr
+    from coper_amd.kg_loader import TSVKGLoader
+    # framing: length | masked crc(length) | data | masked crc(data)
+    p = tmp_path / "x.tfrecords"
+    assert tr.write_records(str(p), [b"", b"abc"]) == 2
+    raw = p.read_bytes()
+    assert raw[:8] == struct.pack("<Q", 0) and len(raw) == 12 + 4 + 12 + 3 + 4
+    assert list(tr.read_records(str(p))) == [b"", b"abc"]
+    bad = bytearray(raw); bad[-6] ^= 1
+    p.write_bytes(bytes(bad))
+    with pytest.raises(ValueError, match="corrupt"):
+        list(tr.read_records(str(p)))
+    ex = dict(e1=[7], e2=[-1], rel=[3], e2_multi=[], is_inverse=[1])
+    assert tr.parse_example(tr.encode_example(ex)) == dict(e1=[7], e2=[-1], rel=[3], e2_multi=[], is_inverse=[1])
+    big = dict(e2_multi=list(range(0, 300000, 997)), e1=[2 ** 40])
+    assert tr.parse_example(tr.encode_example(big)) == big
+    # a hand-assembled Example with an UNPACKED int64 list (legal wire form): features{feature{key:"e1" value{int64_list{value:5 value:6}}}}
+    il = bytes([0x08, 5, 0x08, 6])
+    feat = bytes([0x1A, len(il)]) + il
+    entry = bytes([0x0A, 2]) + b"e1" + bytes([0x12, len(feat)]) + feat
+    feats = bytes([0x0A, len(entry)]) + entry
+    assert tr.parse_example(bytes([0x0A, len(feats)]) + feats) == {"e1": [5, 6]}
+    # the loader's splits
+    for f in ("train.txt", "dev.txt", "test.txt"):
+        shutil.copy(os.path.join(golden_dir, "kg_tsv", f), tmp_path)
+    loader = TSVKGLoader(str(tmp_path), "nell-995-test")
+    files = loader.maybe_create_tf_record_files(str(tmp_path), write_tfrecords=True, max_records_per_file=500)
+    assert sorted(files) == ["dev", "test", "train"] and len(files["train"]) > 1
+    for split in ("dev", "test"):
+        for inv in (False, True):
+            got = tr.read_split(str(tmp_path), split, include_inv_relations=inv)
+            want = loader.encoded_split(split, include_inv_relations=inv)
+            for k in ("e1", "e2", "rel", "filt_indptr", "filt_idx"):
+                assert np.array_equal(got[k], want[k]), (split, inv, k)
+    tr_got = tr.read_split(str(tmp_path), "train", include_inv_relations=True)
+    tr_want = loader.train_samples(include_inv_relations=True)
+    nonempty = np.diff(tr_got["filt_indptr"]) > 0
+    assert np.array_equal(tr_got["e1"][nonempty], tr_want["e1"]) and np.array_equal(tr_got["rel"][nonempty], tr_want["rel"])
+    assert np.array_equal(tr_got["filt_idx"], tr_want["tail_idx"])
+    # existing files are not recreated (data.py:360-363)
+    again = loader.maybe_create_tf_record_files(str(tmp_path), write_tfrecords=True)
+    assert again == {k: sorted(v) for k, v in files.items()}
