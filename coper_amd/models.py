@@ -298,10 +298,11 @@ class ConvE(object):
                   ranks=torch.empty(B, dtype=torch.int32, device=dev), ne=torch.empty(B, dtype=torch.int32, device=dev))
 
         def body():
-            # the filter launch is sized by max_nnz; entries past indptr[B] belong to no query and are skipped
-            _lib.check(self._h, self._lib.coper_encode(self._h, _ptr(st["e1"]), _ptr(st["rel"]), B, None, _ptr(st["h"]), self._stream()))
-            _lib.check(self._h, self._lib.coper_rank(self._h, _ptr(st["h"]), _ptr(st["e2"]), _ptr(st["ip"]), _ptr(st["ix"]),
-                                                     max_nnz, B, _ptr(st["ranks"]), _ptr(st["ne"]), self._stream()))
+            # one call per batch (the dense finalize writes h straight into the rank kernels' planes); the filter launch
+            # is sized by max_nnz: entries past indptr[B] belong to no query and are skipped
+            _lib.check(self._h, self._lib.coper_encode_rank(self._h, _ptr(st["e1"]), _ptr(st["rel"]), None, _ptr(st["e2"]),
+                                                            _ptr(st["ip"]), _ptr(st["ix"]), max_nnz, B, _ptr(st["h"]),
+                                                            _ptr(st["ranks"]), _ptr(st["ne"]), self._stream()))
 
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
