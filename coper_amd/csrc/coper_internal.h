@@ -90,6 +90,7 @@ struct coper_handle {
   int32_t* rel_offset = nullptr;  // [R+1]
   int32_t* rel_cursor = nullptr;  // [R]
   int32_t* perm = nullptr;        // [B] sorted position -> query
+  int32_t* inv_perm = nullptr;    // [B] query -> sorted position
   int32_t* sorted_row = nullptr;  // [B] sorted position -> local entity row of e1 (or the e1_rows row), -1 = not on this shard
   int32_t* sorted_rid = nullptr;  // [B] sorted position -> validated relation id
   int32_t* tiles = nullptr;       // [T_max*4] (rel, start, n, pad)

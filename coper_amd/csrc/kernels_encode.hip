@@ -142,7 +142,8 @@ __global__ __launch_bounds__(1024) void k_rel_group_single(const int64_t* __rest
                                                            int32_t* __restrict__ count, int32_t* __restrict__ bad,
                                                            int32_t* offset, int32_t* __restrict__ tiles,
                                                            int32_t* __restrict__ n_tiles, int32_t* __restrict__ perm,
-                                                           int32_t* __restrict__ sorted_row, int32_t* __restrict__ sorted_rid) {
+                                                           int32_t* __restrict__ sorted_row, int32_t* __restrict__ sorted_rid,
+                                                           int32_t* __restrict__ inv_perm) {
   extern __shared__ int32_t sh[];   // cnt[R] | cursor[R]
   int32_t* cnt = sh;
   int32_t* cur = sh + R;
@@ -173,6 +174,7 @@ __global__ __launch_bounds__(1024) void k_rel_group_single(const int64_t* __rest
     }
     const int pos = offset[key] + atomicAdd(&cur[key], 1);
     perm[pos] = (int32_t)b;
+    inv_perm[b] = pos;
     sorted_row[pos] = (int32_t)row;
     sorted_rid[pos] = (int32_t)rid;
   }
@@ -188,7 +190,8 @@ __global__ __launch_bounds__(HIST_BLOCK) void k_rel_scatter(const int64_t* __res
                                                              const int64_t* __restrict__ e1, int have_e1_rows,
                                                              int64_t shard_lo, int64_t n_local, int64_t R_all,
                                                              int32_t* __restrict__ sorted_row,
-                                                             int32_t* __restrict__ sorted_rid) {
+                                                             int32_t* __restrict__ sorted_rid,
+                                                             int32_t* __restrict__ inv_perm) {
   extern __shared__ int32_t sh[];  // [R] block counts, then block bases
   const bool priv = R <= HIST_LDS_MAX;
   int64_t b = (int64_t)blockIdx.x * HIST_BLOCK + threadIdx.x;
@@ -208,6 +211,7 @@ __global__ __launch_bounds__(HIST_BLOCK) void k_rel_scatter(const int64_t* __res
     if (b < B) {
       int pos = offset[key] + atomicAdd(&cursor[key], 1);
       perm[pos] = (int32_t)b;
+      inv_perm[b] = pos;
       sorted_row[pos] = (int32_t)row;
       sorted_rid[pos] = (int32_t)rid;
     }
@@ -226,6 +230,7 @@ __global__ __launch_bounds__(HIST_BLOCK) void k_rel_scatter(const int64_t* __res
   if (b < B) {
     int pos = offset[key] + sh[key] + local;
     perm[pos] = (int32_t)b;
+    inv_perm[b] = pos;
     sorted_row[pos] = (int32_t)row;
     sorted_rid[pos] = (int32_t)rid;
   }
@@ -242,7 +247,7 @@ int launch_group_by_relation(coper_handle* h, const int64_t* e1, const int64_t* 
     // rel_count[R+1] doubles as the out-of-range counter (reset by the kernel)
     hipLaunchKernelGGL(k_rel_group_single, dim3(1), dim3(1024), sizeof(int32_t) * 2 * (size_t)R, s, rel, e1, B, dm.gen_fc ? 1 : 0, R,
                        dm.R, have_e1_rows ? 1 : 0, (int64_t)h->cfg.shard_lo, dm.n_local, small_tile_cap(h), h->rel_count,
-                       h->rel_count + dm.R + 1, h->rel_offset, h->tiles, h->n_tiles, h->perm, h->sorted_row, h->sorted_rid);
+                       h->rel_count + dm.R + 1, h->rel_offset, h->tiles, h->n_tiles, h->perm, h->sorted_row, h->sorted_rid, h->inv_perm);
     (void)tq;
     COPER_HIP_TRY(h, hipGetLastError());
     return COPER_OK;
@@ -258,7 +263,7 @@ int launch_group_by_relation(coper_handle* h, const int64_t* e1, const int64_t* 
                      h->tiles, h->n_tiles);
   hipLaunchKernelGGL(k_rel_scatter, dim3(nb), dim3(HIST_BLOCK), hl, s, rel, B, dm.gen_fc ? 1 : 0, R, h->rel_offset,
                      h->rel_cursor, h->perm, e1, have_e1_rows ? 1 : 0, (int64_t)h->cfg.shard_lo, dm.n_local, dm.R,
-                     h->sorted_row, h->sorted_rid);
+                     h->sorted_row, h->sorted_rid, h->inv_perm);
   COPER_HIP_TRY(h, hipGetLastError());
   return COPER_OK;
 }
