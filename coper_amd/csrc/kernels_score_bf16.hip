@@ -539,21 +539,23 @@ __global__ __launch_bounds__(256) void k_pair_bf16x3(const uint4* __restrict__ E
   const uint4* pa_l = Elo + ea * (2 * KS) + half;
   const uint4* pb_h = Hhi + q * (2 * KS) + half;
   const uint4* pb_l = Hlo + q * (2 * KS) + half;
-  // gathered 16-B loads, batched four k-steps deep (one wave per SIMD here: nothing else hides their latency)
-  int ks = 0;
-  for (; ks + 4 <= KS; ks += 4) {
-    uint4 ah[4], al[4], bh[4], bl[4];
+  // gathered 16-B loads, batched PAIR_BATCH k-steps deep (few waves per SIMD here: nothing else hides their latency;
+  // d = 200 is 13 k-steps); a short last batch re-reads the final k-step and skips its MFMAs
+#ifndef COPER_PAIR_BATCH
+#define COPER_PAIR_BATCH 4
+#endif
+  constexpr int PB = COPER_PAIR_BATCH;
+  for (int ks = 0; ks < KS; ks += PB) {
+    uint4 ah[PB], al[PB], bh[PB], bl[PB];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      ah[u] = pa_h[(ks + u) * 2]; al[u] = pa_l[(ks + u) * 2];
-      bh[u] = pb_h[(ks + u) * 2]; bl[u] = pb_l[(ks + u) * 2];
+    for (int u = 0; u < PB; ++u) {
+      const int k = ks + u < KS ? ks + u : KS - 1;
+      ah[u] = pa_h[k * 2]; al[u] = pa_l[k * 2];
+      bh[u] = pb_h[k * 2]; bl[u] = pb_l[k * 2];
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) MFMA_X3(ah[u], al[u], bh[u], bl[u], acc);
-  }
-  for (; ks < KS; ++ks) {
-    uint4 ah = pa_h[ks * 2], al = pa_l[ks * 2], bh = pb_h[ks * 2], bl = pb_l[ks * 2];
-    MFMA_X3(ah, al, bh, bl, acc);
+    for (int u = 0; u < PB; ++u)
+      if (ks + u < KS) MFMA_X3(ah[u], al[u], bh[u], bl[u], acc);   // wave-uniform
   }
   // D[i][i] sits in lane i + 32*((i>>2)&1), register (i&3) + 4*(i>>3)
   if (((i >> 2) & 1) != half || p >= n_pairs) return;
