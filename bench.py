@@ -48,6 +48,23 @@ def pmc_traffic(workload, Q, kernel):
     return None
 
 
+def pmc_mfma_busy(workload, Q, kernel):
+    """Matrix-pipe busy fraction and effective clock of `kernel` from the committed PMC summary
+    (profiles/*pmc_mfma_busy*.json: SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE on this same command), or None."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_mfma_busy*.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if d.get("workload") != workload or d.get("queries") != Q:
+            continue
+        for name, v in d.get("kernels", {}).items():
+            if name == kernel or name.startswith(kernel + "<"):
+                return {"mfma_busy_frac": v["mfma_busy_frac"], "effective_clock_ghz": v["effective_clock_ghz"]}
+    return None
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -245,6 +262,9 @@ def main():
                                 "traffic": pmc_traffic(args.workload, Q, "coper::" + kname) if world == 1 else None}
                 if args.score_mode != "f32":
                     kinfo[kname]["note"] = "3 hardware bf16 MFMAs per algorithmic product: hardware MFMA utilisation = 3 x frac"
+                pm = pmc_mfma_busy(args.workload, Q, "coper::" + kname) if world == 1 else None
+                if pm:
+                    kinfo[kname]["pmc"] = pm      # counters: fraction of the kernel's cycles with the matrix pipes busy
         if kern["dense"]:
             fl = 2.0 * Q * F * d                 # ALGORITHMIC flops of the dense launch pair (small + big tiles)
             if args.score_mode == "f32":
