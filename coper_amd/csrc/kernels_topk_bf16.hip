@@ -1,5 +1,6 @@
-// Pruned top-k of the filtered rows for the bf16x3 mode (coper_rank_counts with 0 < k <= 32): the logits are
-// never materialised, also not for the top-k.
+// Pruned top-k of the filtered rows (coper_rank_counts with 0 < k <= 32): the logits are never materialised, also
+// not for the top-k.  Kernels of the bf16x3 mode; the fp32-exact mode shares the threshold and selection kernels
+// (launch_topk_pruned_f32 at the end; its block maxima and VALU rescoring live in kernels_score.hip).
 //
 // The per-shard top-k is what the entity-sharded ranker exchanges (the masked row of
 // metrics.py:44-46 is the thing it is the top of).  At 1.25 M entities per shard a [B, |E_shard|] logit
@@ -8,14 +9,16 @@
 //   1. the count pass itself (k_score_count_bf16x3<.., GM>) writes, next to the rank counters, the largest logit
 //      of every (32-entity block, query): gmax[block][query], 1/32 of the logits, coalesced 128-B rows;
 //   2. k_topk_threshold_emit: per query, the m-th largest block maximum tau, m = k + (filter entries of the
-//      query), by a 4-pass radix select on the float bits.  m distinct blocks have their maximum >= tau and at most
+//      query), by radix select on the float bits.  m distinct blocks have their maximum >= tau and at most
 //      `filter entries` of those maxima are masked, so at least k unmasked logits >= tau exist: every entity of
 //      the row's top-k sits in a block whose maximum is >= tau.  Exactly m blocks are emitted (all above tau, and
 //      the lowest-numbered ones equal to tau), so the candidate list has a fixed place k*q + indptr[q] and no
 //      size exchange with the host is needed;
-//   3. k_topk_score_blocks: one wave per candidate block re-computes its 32 logits with the instruction
-//      sequence of every other bf16x3 kernel (bit-identical values), masks the known answers except the target;
-//   4. k_topk_select_cand: k rounds of arg-max over the query's candidates, (score desc, id asc).
+//   3. the candidate slots are grouped by entity block (k_topk_blk_scan / k_topk_blk_scatter, device-side counters)
+//      and k_topk_score_blocks re-computes 32 logits x 32 slots per wave with the instruction sequence of every
+//      other bf16x3 kernel (bit-identical values), masking the known answers except the target;
+//   4. k_topk_select_cand, one wave per query: candidates >= tau are compacted into LDS and placed by counting the
+//      survivors ahead of each, (score desc, id asc).
 //
 // Work beyond the count pass: (k*B + nnz) blocks of 32 logits instead of B*|E|.
 #include "coper_internal.h"
