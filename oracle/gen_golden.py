@@ -262,6 +262,83 @@ def gen_minerva_e2e():
     print("minerva_e2e: keys", len(out), "S range", float(out["plain:S"].min()), float(out["plain:S"].max()))
 
 
+def gen_minerva_grads():
+    """Training-side pin: loss and GRADIENTS of the reference's PyTorch sister models by torch autograd through the
+    reference's own forward code (fact_network.py ConvE / CPG_ConvE .forward) and the reference's loss
+    (`EmbeddingBasedMethod.loss`, src/emb/emb.py:50-58: label smoothing (1 - eps) * e2 + 1 / num_entities, BCELoss
+    on the sigmoid scores, mean reduction), models in eval mode (BN on running statistics, no dropout).
+    tests/ compare coper_train_step's loss and gradients against these through the tensor mapping of
+    coper_amd.weights.from_minerva_state_dict (chain rule for the folded input BN)."""
+    import contextlib
+    import io
+    import torch
+    spec = importlib.util.spec_from_file_location("ref_fact_network3", os.path.join(REF, "CoPER_MINERVA/src/emb/fact_network.py"))
+    fn = importlib.util.module_from_spec(spec)
+    with contextlib.redirect_stdout(io.StringIO()):
+        spec.loader.exec_module(fn)
+    torch.manual_seed(321)
+    E, R, B, d1, d2, C = 60, 6, 12, 10, 4, 8
+    d = d1 * d2
+    eps_ls = 0.1
+    out = {}
+
+    class KG(object):
+        def __init__(self, ent, rel):
+            self.ent, self.rel = ent, rel
+        def get_entity_embeddings(self, e):
+            return self.ent[e]
+        def get_relation_embeddings(self, r):
+            return self.rel[r]
+        def get_all_entity_embeddings(self):
+            return self.ent
+
+    def randomise_bn(bn):
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.1)
+            bn.running_mean.normal_(0, 0.1); bn.running_var.uniform_(0.6, 1.4)
+
+    for tag, r_dim, cpg in (("plain", d, False), ("cpg", 20, True)):
+        args = types.SimpleNamespace(entity_dim=d, relation_dim=r_dim, emb_2D_d1=d1, emb_2D_d2=d2, num_out_channels=C,
+                                     kernel_size=3, hidden_dropout_rate=0.3, feat_dropout_rate=0.2, cpg_conv_net=[-1],
+                                     cpg_fc_net=[], cpg_dropout=0.2, cpg_batch_norm=False, cpg_batch_norm_momentum=0.1,
+                                     cpg_use_bias=False)
+        with contextlib.redirect_stdout(io.StringIO()):
+            m = fn.CPG_ConvE(args, E) if cpg else fn.ConvE(args, E)
+        m.eval()
+        randomise_bn(m.bn0); randomise_bn(m.bn2)
+        with torch.no_grad():
+            m.b.normal_(0, 0.1)
+            m.conv1.weight.normal_(0, 1.0); m.conv1.bias.normal_(0, 0.1)
+            if cpg:
+                for g_, std in ((m.fc_weights, 0.35), (m.fc_bias, 0.3)):
+                    for lin in g_.network:
+                        if isinstance(lin, torch.nn.Linear):
+                            lin.weight.normal_(0, std)
+            else:
+                m.fc.weight.normal_(0, 0.12); m.fc.bias.normal_(0, 0.1)
+        ent = (torch.randn(E, d) * 0.3).requires_grad_(True)
+        rel = (torch.randn(R, r_dim) * 0.3).requires_grad_(True)
+        kg = KG(ent, rel)
+        e1 = torch.randint(0, E, (B,)); r = torch.randint(0, R, (B,))
+        labels = (torch.rand(B, E) < 0.08).float()
+        labels[torch.arange(B), torch.randint(0, E, (B,))] = 1.0
+        pred = m.forward(e1, r, kg)                                         # reference forward, sigmoid scores [B, E]
+        e2_label = ((1 - eps_ls) * labels) + (1.0 / labels.size(1))         # emb.py:55
+        loss = torch.nn.BCELoss()(pred, e2_label)                           # emb.py:35,57
+        loss.backward()
+        out.update({tag + ":ent": ent.detach().numpy(), tag + ":rel": rel.detach().numpy(), tag + ":e1": e1.numpy(),
+                    tag + ":r": r.numpy(), tag + ":labels": labels.numpy(), tag + ":loss": np.float64(loss.item()),
+                    tag + ":eps_ls": np.float64(eps_ls), tag + ":dims": np.array([E, R, B, d1, d2, C, r_dim]),
+                    tag + ":grad:ent": ent.grad.numpy(), tag + ":grad:rel": rel.grad.numpy()})
+        for k, v in m.state_dict().items():
+            out[tag + ":sd:" + k] = v.numpy()
+        for k, v in m.named_parameters():
+            if v.grad is not None:
+                out[tag + ":grad:" + k] = v.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "minerva_grads.npz"), **out)
+    print("minerva_grads: keys", len(out), "losses", float(out["plain:loss"]), float(out["cpg:loss"]))
+
+
 def gen_loader_fixture():
     """TSV -> JSON -> id maps through the REFERENCE'S OWN loader code (qa_cpg/data.py load_and_preprocess,
     _write_graph, _assign_ids), imported under the stub tensorflow module, on a small split of the
@@ -349,6 +426,7 @@ if __name__ == "__main__":
     gen_cpg_substeps()
     gen_conv_torch()
     gen_minerva_e2e()
+    gen_minerva_grads()
     gen_loader_fixture()
     gen_fwd_fixtures()
     print("sizes:", {f: os.path.getsize(os.path.join(OUT, f)) for f in sorted(os.listdir(OUT))})

@@ -1,6 +1,7 @@
 """CPU: the training oracle (oracle/coper_train_oracle.py) against the inference oracle, finite differences
 and a hand-computed AMSGrad trace (utils/amsgrad.py:130-159 arithmetic)."""
 import numpy as np
+import pytest
 import torch
 
 from coper_amd import data as cdata
@@ -90,3 +91,23 @@ def test_dropout_keep_rate_and_determinism():
     assert np.array_equal(k, T.dropout_keep(9, 4, 1, 1 << 18, 0.3))
     assert not np.array_equal(k, T.dropout_keep(9, 5, 1, 1 << 18, 0.3))
     assert T.dropout_keep(1, 1, 1, 100, 0.0).all()
+
+
+@pytest.mark.parametrize("tag", ["plain", "cpg"])
+def test_oracle_gradients_match_reference_sister_models_autograd(golden_dir, tag):
+    """The training oracle's loss and gradients against torch autograd through the REFERENCE's own PyTorch forward
+    (fact_network.py ConvE / CPG_ConvE) and loss (emb.py:50-58), eval-mode BN, no dropout (fixture:
+    oracle/gen_golden.py gen_minerva_grads): pins the backward of the shared structure to reference code."""
+    import os
+    from oracle import coper_train_oracle as T
+    from tests.minerva_map import load_grad_case, reference_grads_in_our_layout
+    g = np.load(os.path.join(golden_dir, "minerva_grads.npz"))
+    md, p, sd, batch = load_grad_case(g, tag)
+    ref = {k: np.array(v, np.float64) for k, v in p.items()}
+    opt = T.AMSGrad(T.trainable_names(md), ref, lr=md["learning_rate"])
+    loss, grads, gn = T.train_step(ref, md, dict(e1=batch["e1"], rel=batch["rel"], lookup=None, labels=batch["labels"]), opt,
+                                   seed=0, step=0, momentum=0.1)
+    assert abs(loss - float(g[tag + ":loss"])) < 2e-6 * abs(loss)
+    for leaf, (want, got) in reference_grads_in_our_layout(g, tag, sd, grads).items():
+        want, got = np.asarray(want, np.float64), np.asarray(got, np.float64).reshape(np.shape(want))
+        assert np.abs(got - want).max() < 2e-5 * max(np.abs(want).max(), 1e-6) + 1e-9, leaf
