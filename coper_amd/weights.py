@@ -126,13 +126,33 @@ def from_minerva_state_dict(sd: Dict[str, np.ndarray], entity_emb, relation_emb,
     pix, ch = np.divmod(np.arange(F), C)      # ours: f = (i*Wo + j)*C + ch ; reference: f_ref = ch*(Ho*Wo) + (i*Wo + j)
     f_ref = ch * (Ho * Wo) + pix
     if cpg:
-        names = sorted(k for k in sd if k.startswith("fc_weights.network.") and k.endswith(".weight"))
-        if len(names) != 1:
-            raise NotImplementedError("g_MLP generators of the sister model: map each Linear to Projection<i> the same way")
-        Wg = sd[names[0]]                                                        # [F*d, r]
-        P = Wg.T.reshape(r_dim, F, d)[:, f_ref, :].reshape(r_dim, F * d)
-        p["fc_weights/CPG/Projection0"] = np.ascontiguousarray(P, np.float32)
-        p["fc_bias/CPG/Projection0"] = np.ascontiguousarray(sd["fc_bias.network.0.weight"].T, np.float32)
+        # generator networks (fact_network.py:228-259): Sequential of [Linear(no bias), (BatchNorm1d), ReLU, Dropout]* + Linear
+        hidden = []
+        for gname, last_perm in (("fc_weights", True), ("fc_bias", False)):
+            idx = sorted({int(k.split(".")[2]) for k in sd if k.startswith(gname + ".network.")})
+            lin = [i for i in idx if ("%s.network.%d.weight" % (gname, i)) in sd and sd["%s.network.%d.weight" % (gname, i)].ndim == 2]
+            bns = [i for i in idx if ("%s.network.%d.running_mean" % (gname, i)) in sd]
+            if any(("%s.network.%d.bias" % (gname, i)) in sd for i in lin):
+                raise NotImplementedError("generator Linear layers with bias (cpg_use_bias) have no counterpart in qa_cpg (models.py:44-54)")
+            for j, i in enumerate(lin):
+                W = sd["%s.network.%d.weight" % (gname, i)]                       # [out, in]
+                if j == len(lin) - 1 and last_perm:
+                    n_in = W.shape[1]
+                    P = W.T.reshape(n_in, F, d)[:, f_ref, :].reshape(n_in, F * d)
+                else:
+                    P = W.T
+                p["%s/CPG/Projection%d" % (gname, j)] = np.ascontiguousarray(P, np.float32)
+                if j < len(lin) - 1 and gname == "fc_weights":
+                    hidden.append(int(W.shape[0]))
+            for j, i in enumerate(bns):
+                base, pre = "%s/CPG/Projection%d/BatchNorm/" % (gname, j), "%s.network.%d." % (gname, i)
+                p[base + "gamma"] = sd[pre + "weight"].astype(np.float32)
+                p[base + "beta"] = sd[pre + "bias"].astype(np.float32)
+                p[base + "moving_mean"] = sd[pre + "running_mean"].astype(np.float32)
+                p[base + "moving_variance"] = (sd[pre + "running_var"].astype(np.float64) + 1e-5 - 1e-3).astype(np.float32)
+            if gname == "fc_weights":
+                md["context_rel_use_batch_norm"] = bool(bns)
+        md["context_rel_out"] = hidden
     else:
         p["fc_weights"] = np.ascontiguousarray(sd["fc.weight"].T[f_ref, :], np.float32)   # [F, d]
         p["fc_bias"] = sd["fc.bias"].astype(np.float32)

@@ -6,7 +6,7 @@ training tests or golden vectors); the forward restates `CoPER_ConvE/qa_cpg/mode
 and the gradients come from torch autograd over that restatement in float64, so what the tests pin
 is "the HIP step == the derivative of the documented forward", plus the optimizer arithmetic of
 `qa_cpg/utils/amsgrad.py`.  PINNED to reference code for the structure the PyTorch sister models share
-(conv -> dense, static or g_linear generated -> FCBN -> 1-vs-all scorer -> label-smoothed BCE, BN on moving
+(conv -> dense, static or g_linear / g_MLP(+BN) generated -> FCBN -> 1-vs-all scorer -> label-smoothed BCE, BN on moving
 statistics, no dropout): tests/golden/minerva_grads.npz holds loss and gradients from torch autograd through
 the reference's own `fact_network.py` forward and `emb.py:50-58` loss; this oracle (test_train_oracle.py) and the
 HIP step (test_gpu_train.py) both reproduce them.

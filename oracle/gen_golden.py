@@ -297,10 +297,11 @@ def gen_minerva_grads():
             bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.1)
             bn.running_mean.normal_(0, 0.1); bn.running_var.uniform_(0.6, 1.4)
 
-    for tag, r_dim, cpg in (("plain", d, False), ("cpg", 20, True)):
+    for tag, r_dim, cpg, fc_net, gen_bn in (("plain", d, False, [], False), ("cpg", 20, True, [], False),
+                                            ("cpg_mlp", 20, True, [12], True)):
         args = types.SimpleNamespace(entity_dim=d, relation_dim=r_dim, emb_2D_d1=d1, emb_2D_d2=d2, num_out_channels=C,
                                      kernel_size=3, hidden_dropout_rate=0.3, feat_dropout_rate=0.2, cpg_conv_net=[-1],
-                                     cpg_fc_net=[], cpg_dropout=0.2, cpg_batch_norm=False, cpg_batch_norm_momentum=0.1,
+                                     cpg_fc_net=fc_net, cpg_dropout=0.2, cpg_batch_norm=gen_bn, cpg_batch_norm_momentum=0.1,
                                      cpg_use_bias=False)
         with contextlib.redirect_stdout(io.StringIO()):
             m = fn.CPG_ConvE(args, E) if cpg else fn.ConvE(args, E)
@@ -310,10 +311,14 @@ def gen_minerva_grads():
             m.b.normal_(0, 0.1)
             m.conv1.weight.normal_(0, 1.0); m.conv1.bias.normal_(0, 0.1)
             if cpg:
-                for g_, std in ((m.fc_weights, 0.35), (m.fc_bias, 0.3)):
+                # (moderate logits: the sister's fp32 sigmoid + BCELoss saturates and clamps log(0) to -100 beyond |s| ~ 17,
+                # which is an artefact of that formulation, not of the model)
+                for g_, std in ((m.fc_weights, 0.35 if not fc_net else 0.12), (m.fc_bias, 0.3 if not fc_net else 0.15)):
                     for lin in g_.network:
                         if isinstance(lin, torch.nn.Linear):
                             lin.weight.normal_(0, std)
+                        if isinstance(lin, torch.nn.BatchNorm1d):
+                            randomise_bn(lin)
             else:
                 m.fc.weight.normal_(0, 0.12); m.fc.bias.normal_(0, 0.1)
         ent = (torch.randn(E, d) * 0.3).requires_grad_(True)
@@ -336,7 +341,7 @@ def gen_minerva_grads():
             if v.grad is not None:
                 out[tag + ":grad:" + k] = v.grad.numpy()
     np.savez_compressed(os.path.join(OUT, "minerva_grads.npz"), **out)
-    print("minerva_grads: keys", len(out), "losses", float(out["plain:loss"]), float(out["cpg:loss"]))
+    print("minerva_grads: keys", len(out), "losses", float(out["plain:loss"]), float(out["cpg:loss"]), float(out["cpg_mlp:loss"]))
 
 
 def gen_loader_fixture():

@@ -25,7 +25,7 @@ def load_grad_case(g, tag):
     1-vs-all label batch, and loss + gradients from torch autograd through the reference's forward and loss."""
     E, R, B, d1, d2, C, r_dim = (int(v) for v in g[tag + ":dims"])
     sd = {k.split(":sd:")[1]: g[k] for k in g.files if k.startswith(tag + ":sd:")}
-    over, p = from_minerva_state_dict(sd, g[tag + ":ent"], g[tag + ":rel"], d1, d2, cpg=(tag == "cpg"))
+    over, p = from_minerva_state_dict(sd, g[tag + ":ent"], g[tag + ":rel"], d1, d2, cpg=tag.startswith("cpg"))
     md = dict(cdata._COMMON)
     md.update(over)
     md.update(hidden_dropout=0.0, output_dropout=0.0, input_dropout=0.0, context_rel_dropout=0.0, batch_norm_train_stats=False,
@@ -40,7 +40,7 @@ def reference_grads_in_our_layout(g, tag, sd, ours):
     comparison runs on the sister's side by the chain rule: dL/dK = a dL/dK' + c dL/dkb', dL/dkb = dL/dkb'."""
     E, R, B, d1, d2, C, r_dim = (int(v) for v in g[tag + ":dims"])
     d = d1 * d2
-    cpg = tag == "cpg"
+    cpg = tag.startswith("cpg")
     in_h = d1 if cpg else 2 * d1
     Ho, Wo = in_h - 2, d2 - 2
     F = Ho * Wo * C
@@ -50,10 +50,24 @@ def reference_grads_in_our_layout(g, tag, sd, ours):
     pairs = {"ent_emb": (G("ent"), ours["ent_emb"]), "rel_emb": (G("rel"), ours["rel_emb"]), "pred_bias": (G("b"), ours["pred_bias"]),
              "FCBN/gamma": (G("bn2.weight"), ours["FCBN/gamma"]), "FCBN/beta": (G("bn2.bias"), ours["FCBN/beta"])}
     if cpg:
-        gw = G("fc_weights.network.0.weight")                                  # [F_ref * d, r]
-        pairs["fc_weights/CPG/Projection0"] = (gw.T.reshape(r_dim, F, d)[:, f_ref, :].reshape(r_dim, F * d),
-                                               ours["fc_weights/CPG/Projection0"])
-        pairs["fc_bias/CPG/Projection0"] = (G("fc_bias.network.0.weight").T, ours["fc_bias/CPG/Projection0"])
+        # generator networks: Linear layers in order -> Projection<j> (the last one of fc_weights re-indexed NCHW -> NHWC),
+        # BatchNorm1d layers in order -> Projection<j>/BatchNorm
+        for gname in ("fc_weights", "fc_bias"):
+            idx = sorted({int(k.split(".")[2]) for k in sd if k.startswith(gname + ".network.")})
+            lin = [i for i in idx if sd.get("%s.network.%d.weight" % (gname, i), np.zeros(1)).ndim == 2]
+            bns = [i for i in idx if ("%s.network.%d.running_mean" % (gname, i)) in sd]
+            for j, i in enumerate(lin):
+                gw = G("%s.network.%d.weight" % (gname, i))                   # [out, in]
+                if j == len(lin) - 1 and gname == "fc_weights":
+                    n_in = gw.shape[1]
+                    want = gw.T.reshape(n_in, F, d)[:, f_ref, :].reshape(n_in, F * d)
+                else:
+                    want = gw.T
+                pairs["%s/CPG/Projection%d" % (gname, j)] = (want, ours["%s/CPG/Projection%d" % (gname, j)])
+            for j, i in enumerate(bns):
+                base = "%s/CPG/Projection%d/BatchNorm/" % (gname, j)
+                pairs[base + "gamma"] = (G("%s.network.%d.weight" % (gname, i)), ours[base + "gamma"])
+                pairs[base + "beta"] = (G("%s.network.%d.bias" % (gname, i)), ours[base + "beta"])
     else:
         pairs["fc_weights"] = (G("fc.weight").T[f_ref, :], ours["fc_weights"])
         pairs["fc_bias"] = (G("fc.bias"), ours["fc_bias"])

@@ -217,7 +217,7 @@ def test_example_train_eval_checkpoint_loop(tmp_path):
     assert mrr > 0.1          # chance on 765 entities is ~0.01
 
 
-@pytest.mark.parametrize("tag", ["plain", "cpg"])
+@pytest.mark.parametrize("tag", ["plain", "cpg", "cpg_mlp"])
 def test_train_step_gradients_match_reference_sister_models_autograd(tag):
     """coper_train_step's loss and gradients against torch autograd through the REFERENCE's own PyTorch forward
     (fact_network.py ConvE / CPG_ConvE) and loss (emb.py:50-58): tests/golden/minerva_grads.npz, eval-mode BN, no

@@ -93,7 +93,7 @@ def test_dropout_keep_rate_and_determinism():
     assert T.dropout_keep(1, 1, 1, 100, 0.0).all()
 
 
-@pytest.mark.parametrize("tag", ["plain", "cpg"])
+@pytest.mark.parametrize("tag", ["plain", "cpg", "cpg_mlp"])
 def test_oracle_gradients_match_reference_sister_models_autograd(golden_dir, tag):
     """The training oracle's loss and gradients against torch autograd through the REFERENCE's own PyTorch forward
     (fact_network.py ConvE / CPG_ConvE) and loss (emb.py:50-58), eval-mode BN, no dropout (fixture:
