@@ -334,7 +334,8 @@ def gen_minerva_grads():
         out.update({tag + ":ent": ent.detach().numpy(), tag + ":rel": rel.detach().numpy(), tag + ":e1": e1.numpy(),
                     tag + ":r": r.numpy(), tag + ":labels": labels.numpy(), tag + ":loss": np.float64(loss.item()),
                     tag + ":eps_ls": np.float64(eps_ls), tag + ":dims": np.array([E, R, B, d1, d2, C, r_dim]),
-                    tag + ":grad:ent": ent.grad.numpy(), tag + ":grad:rel": rel.grad.numpy()})
+                    tag + ":grad:ent": ent.grad.numpy(), tag + ":grad:rel": rel.grad.numpy(),
+                    tag + ":S": pred.detach().numpy()})
         for k, v in m.state_dict().items():
             out[tag + ":sd:" + k] = v.numpy()
         for k, v in m.named_parameters():

@@ -652,3 +652,17 @@ def test_pruned_topk_matches_masked_row_topk(oracle_chain, chunk, mode, monkeypa
     assert (ti.cpu().numpy() == -1).any()
     for x in shards + [m, m2]:
         x.close()
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+@pytest.mark.parametrize("tag", ["cpg", "cpg_mlp"])
+def test_prepare_generators_match_sister_model_scores(golden_dir, tag, mode):
+    """coper_prepare's generator evaluation (g_linear; g_MLP with generator BatchNorm) -> encode -> score against the
+    sister models' own scores (fact_network.py CPG_ConvE.forward) stored with tests/golden/minerva_grads.npz."""
+    from tests.minerva_map import load_grad_case, sigmoid
+    g = np.load(os.path.join(golden_dir, "minerva_grads.npz"))
+    md, p, sd, batch = load_grad_case(g, tag)
+    m = _model(md, p, score_mode=mode)
+    logits = m.score_all(m.encode(batch["e1"], batch["rel"])).cpu().numpy()
+    assert np.abs(sigmoid(logits) - g[tag + ":S"]).max() < (2e-6 if mode == "f32" else 1e-4)
+    m.close()

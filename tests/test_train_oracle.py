@@ -111,3 +111,16 @@ def test_oracle_gradients_match_reference_sister_models_autograd(golden_dir, tag
     for leaf, (want, got) in reference_grads_in_our_layout(g, tag, sd, grads).items():
         want, got = np.asarray(want, np.float64), np.asarray(got, np.float64).reshape(np.shape(want))
         assert np.abs(got - want).max() < 2e-5 * max(np.abs(want).max(), 1e-6) + 1e-9, leaf
+
+
+@pytest.mark.parametrize("tag", ["plain", "cpg", "cpg_mlp"])
+def test_inference_oracle_matches_sister_model_scores_incl_mlp_generator(golden_dir, tag):
+    """Inference forward of the oracle (generators evaluated per relation) against the sister models' own sigmoid
+    scores stored with the gradient fixture -- adds the g_MLP + generator-BN variant to minerva_e2e's two."""
+    import os
+    from tests.minerva_map import load_grad_case, sigmoid
+    g = np.load(os.path.join(golden_dir, "minerva_grads.npz"))
+    md, p, sd, batch = load_grad_case(g, tag)
+    out = O.forward({k: np.asarray(v, np.float32) for k, v in p.items()}, md, batch["e1"], batch["rel"], np.float64)
+    s = out["h"] @ np.asarray(p["ent_emb"], np.float64).T + np.asarray(p["pred_bias"], np.float64)
+    assert np.abs(sigmoid(s) - g[tag + ":S"]).max() < 2e-6
