@@ -421,10 +421,11 @@ static void dense_fused_launch(coper_handle* h, const int64_t* e1, const int64_t
   A.d = dm.d; A.r = dm.r; A.in_w = dm.in_w; A.in_hw = dm.in_h * dm.in_w; A.Wo = dm.Wo;
   A.img_stride = (fused_rows_max(dm, nslices) * dm.in_w) | 1;
   size_t lds = (size_t)2 * 16 * 64 * sizeof(uint4) + (size_t)128 * A.img_stride * sizeof(float);
-  static bool attr_done = false;   // per instantiation; process-wide attribute: always the hardware maximum
-  if (!attr_done) {
+  static uint64_t attr_done = 0;   // per instantiation, one bit per device: always the hardware maximum
+  const uint64_t bit = 1ull << (h->cfg.device & 63);
+  if (!(attr_done & bit)) {
     (void)hipFuncSetAttribute((const void*)k_dense_fused_bf16x3<NFB, WNT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
+    attr_done |= bit;
   }
   hipLaunchKernelGGL((k_dense_fused_bf16x3<NFB, WNT>), dim3((unsigned)(n_big_max + n_small_max), (unsigned)nslices, (unsigned)zgroups), dim3(512),
                      lds, s, (const uint4*)h->Wf16_hi, (const uint4*)h->Wf16_lo, A, h->tiles, h->n_tiles, cap_small, dm.nfb,

@@ -492,10 +492,11 @@ __global__ __launch_bounds__(256) void k_topk_select_cand(float* __restrict__ ca
 template <int QV, int HCOPY>
 static void tk_launch_emit(coper_handle* h, int64_t G, int64_t qs, int64_t q0, int64_t bc, int k, const int64_t* indptr, hipStream_t s) {
   const size_t lds = tk_emit_lds<QV, HCOPY>();
-  static bool attr_done = false;   // per instantiation; one process drives one GPU
-  if (!attr_done) {
+  static uint64_t attr_done = 0;   // per instantiation, one bit per device (function attributes are per device)
+  const uint64_t bit = 1ull << (h->cfg.device & 63);
+  if (!(attr_done & bit)) {
     (void)hipFuncSetAttribute((const void*)k_topk_threshold_emit<QV, HCOPY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
+    attr_done |= bit;
   }
   hipLaunchKernelGGL((k_topk_threshold_emit<QV, HCOPY>), dim3((unsigned)(qs / (4 * QV))), dim3(TK_THREADS), lds, s, h->gmax_ws, G, qs, q0, bc,
                      k, indptr, h->cand_blk_ws, h->cand_q_ws, h->blk_cnt_ws, topk_nseg(G), h->cand_tau_ws);
