@@ -219,3 +219,58 @@ class TSVKGLoader(object):
             raise NotImplementedError("1-vs-all training labels (num_labels=None, data.py:155-156) are not built")
         return TrainDataset(self.train_samples(include_inv_relations), self.num_ent, batch_size, num_labels,
                             one_positive_label_per_sample, prop_negatives, seed)
+
+
+class TFRecordKGLoader(object):
+    """The same loader surface fed from a directory the REFERENCE already preprocessed (`<split>-<n>.tfrecords`,
+    `entities.txt`, `relations.txt`; data.py:353-397,506-572): no TSV needed, no TensorFlow needed.  Ids are the
+    ones stored in the records, so weights trained by the reference on that directory line up."""
+
+    def __init__(self, directory, dataset_name="tfrecords", num_ent=None, num_rel=None, needs_test_set_cleaning=False):
+        self.directory, self.dataset_name = directory, dataset_name
+        self.needs_test_set_cleaning = needs_test_set_cleaning
+        self.num_ent, self.num_rel = num_ent, num_rel
+
+    def maybe_create_tf_record_files(self, directory=None, buffer_size=None):
+        """run_cpg.py:108: after this call `num_ent` / `num_rel` are valid (data.py:337-338: the sizes of the id maps)."""
+        directory = directory or self.directory
+        for attr, fname in (("num_ent", "entities.txt"), ("num_rel", "relations.txt")):
+            path = os.path.join(directory, fname)
+            if getattr(self, attr) is None:
+                if not os.path.exists(path):
+                    raise FileNotFoundError("%s not found and %s not given" % (path, attr))
+                with open(path) as handle:
+                    setattr(self, attr, sum(1 for line in handle if line.strip()))
+        return None
+
+    def eval_dataset(self, directory=None, dataset_type="test", batch_size=512, include_inv_relations=False,
+                     buffer_size=None, prefetch_buffer_size=None, dense_mask=False):
+        from . import tf_records
+        if self.num_ent is None:
+            self.maybe_create_tf_record_files(directory)
+        q = tf_records.read_split(directory or self.directory, dataset_type, include_inv_relations)
+        keep = q["e2"] >= 0                                   # samples without a target (e2 'None' -> -1) are not queries
+        if not keep.all():
+            sel = np.nonzero(keep)[0]
+            rows = [q["filt_idx"][q["filt_indptr"][i]:q["filt_indptr"][i + 1]] for i in sel]
+            q = dict(e1=q["e1"][sel], e2=q["e2"][sel], rel=q["rel"][sel],
+                     filt_indptr=np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64),
+                     filt_idx=np.concatenate(rows).astype(np.int64) if rows else np.zeros(0, np.int64))
+        return EvalDataset(q, batch_size, self.num_ent, dense_mask)
+
+    def train_dataset(self, directory=None, batch_size=512, include_inv_relations=True, num_parallel_readers=None,
+                      num_parallel_batches=None, buffer_size=None, prefetch_buffer_size=None, prop_negatives=10.0,
+                      num_labels=100, cache=False, one_positive_label_per_sample=True, seed=0):
+        from . import tf_records
+        if self.num_ent is None:
+            self.maybe_create_tf_record_files(directory)
+        if num_labels is None:
+            raise NotImplementedError("1-vs-all training labels (num_labels=None, data.py:155-156) are not built")
+        q = tf_records.read_split(directory or self.directory, "train", include_inv_relations)
+        n = np.diff(q["filt_indptr"])
+        sel = np.nonzero(n > 0)[0]
+        rows = [q["filt_idx"][q["filt_indptr"][i]:q["filt_indptr"][i + 1]] for i in sel]
+        samples = dict(e1=q["e1"][sel], rel=q["rel"][sel],
+                       tail_indptr=np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64),
+                       tail_idx=np.concatenate(rows).astype(np.int64) if rows else np.zeros(0, np.int64))
+        return TrainDataset(samples, self.num_ent, batch_size, num_labels, one_positive_label_per_sample, prop_negatives, seed)

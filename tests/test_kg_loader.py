@@ -178,3 +178,31 @@ def test_tfrecord_files_round_trip(tmp_path, golden_dir):
     # existing files are not recreated (data.py:360-363)
     again = loader.maybe_create_tf_record_files(str(tmp_path), write_tfrecords=True)
     assert again == {k: sorted(v) for k, v in files.items()}
+
+
+def test_tfrecord_loader_equals_tsv_loader(tmp_path, golden_dir):
+    """TFRecordKGLoader on a directory holding only <split>-*.tfrecords + id files == TSVKGLoader on the TSVs."""
+    import shutil
+    from coper_amd.kg_loader import TFRecordKGLoader, TSVKGLoader
+    src = tmp_path / "src"; src.mkdir()
+    for f in ("train.txt", "dev.txt", "test.txt"):
+        shutil.copy(os.path.join(golden_dir, "kg_tsv", f), src)
+    a = TSVKGLoader(str(src), "nell-995-test")
+    a.assign_ids(write_files=True)
+    a.maybe_create_tf_record_files(str(src), write_tfrecords=True)
+    rec = tmp_path / "rec"; rec.mkdir()
+    for f in os.listdir(src):
+        if f.endswith(".tfrecords") or f in ("entities.txt", "relations.txt"):
+            shutil.copy(src / f, rec)
+    b = TFRecordKGLoader(str(rec))
+    b.maybe_create_tf_record_files()
+    assert (b.num_ent, b.num_rel) == (a.num_ent, a.num_rel)
+    for split in ("dev", "test"):
+        qa, qb = a.eval_dataset(None, split).as_single_batch(), b.eval_dataset(None, split).as_single_batch()
+        for k in ("e1", "e2", "rel", "filt_indptr", "filt_idx"):
+            assert np.array_equal(qa[k], qb[k]), (split, k)
+    ta, tb = a.train_samples(), None
+    it = iter(b.train_dataset(None, batch_size=16, num_labels=20, seed=1))
+    batch = next(it)
+    assert batch["lookup_values"].shape == (16, 20) and batch["e2_multi"].shape == (16, 20) and batch["e2_multi"][:, 0].all()
+    assert len(ta["e1"]) == len(b.train_dataset(None, batch_size=16, num_labels=20).s["e1"])
