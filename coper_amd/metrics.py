@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from .data import dense_filter_to_csr
-from .sharding import EntityShardedRanker, local_rank_pass
+from .sharding import local_rank_pass
 
 __all__ = ["ranking_and_hits", "hits_and_means", "collect_batches"]
 

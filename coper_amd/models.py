@@ -19,7 +19,6 @@ import numpy as np
 import torch
 
 from . import _lib
-from .data import param_shapes
 
 __all__ = ["ConvE", "ContextualParameterGenerator", "ParameterLookup", "OutOfRangeError"]
 

@@ -2,7 +2,7 @@
 """A/B timing of the encode kernels for a given build of the library (COPER_HIP_LIB=...)."""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-import numpy as np, torch
+import torch
 from coper_amd import data as cdata
 from coper_amd.models import ConvE
 name = sys.argv[1] if len(sys.argv) > 1 else "fb15k237_cpg"

@@ -2,7 +2,7 @@
 """Drop-in entry timed end to end: ranking_and_hits with host batches in, float64 means out (PCIe-inclusive)."""
 import sys, time
 sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), ".."))
-import numpy as np, torch
+import torch
 from coper_amd import data as cdata
 from coper_amd.models import ConvE
 from coper_amd.metrics import ranking_and_hits

@@ -3,7 +3,7 @@
 1.25 M-entity shard of the 10M-entity config (random h; the kernels do not care)."""
 import sys, time
 sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), ".."))
-import numpy as np, torch
+import torch
 from coper_amd import data as cdata
 from coper_amd.models import ConvE
 def run(name, Q, shard=None, big=False):
