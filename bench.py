@@ -2,21 +2,35 @@
 """bench.py -- scored triples/sec (1-vs-all) of the CoPER-ConvE evaluation hot path on MI355X.
 
 A "step" = one pass of the hot path (encode -> 1-vs-all score -> filtered rank) over one batch of
-synthetic queries: the evaluation set of the workload (Q queries), resident in
-HBM before the timed region starts.  Default workload = BASELINE.json configs[1]
-(FB15k-237-shaped CoPER-ConvE: |E|=14541, R2=474, d=200, r=32; Q=20480), fp32-exact mode.
+synthetic queries: the evaluation set of the workload (Q queries).
 
   python bench.py --gpus N --steps K --warmup W
   N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`
-         query-sharded (every rank holds the model and ranks its own Q queries): weak scaling.
-  --workload synth10m_cpg --mode entity : the 10M-entity config, entity-sharded (strong scaling).
 
-Prints ONE JSON line (rank 0)."""
+The JSON line (rank 0, stdout) carries, for the default workload (BASELINE.json configs[1], FB15k-237-shaped
+CoPER-ConvE, bf16x3 arithmetic; query-sharded across ranks = weak scaling):
+
+  value / ms_per_step     K passes with ids + CSR filters resident in HBM, barrier + synchronize on both sides,
+                          MAX over ranks (the driver contract); `timing` adds median / min per pass (HIP events)
+  pcie_inclusive          the SURVEY 8(d) region: H2D of ids / CSR + pass + D2H of ranks, median / min per pass
+  config.f32_exact        the same pass in the fp32-exact mode, and how far the bf16x3 ranks are from its ranks
+  roofline                the dominant kernel against its roof (HIP events on the launch stream), other kernels
+                          under all_kernels -- among them the score kernel in its HBM-bound regime
+                          (`k_score_count_bf16x3@hbm`: 128 queries against this rank's shard of the 10M x 256 table)
+  scale                   BASELINE.json configs[4]: the 10M-entity KG, entity-sharded across the N ranks, per-shard
+                          top-10 exchanged in the one all-gather; strong scaling; run at N = 1 too.
+                          Its ranks must not depend on N (checked against the committed single-GPU checksum)
+  cpu_baseline            torch-CPU restatement of the reference pass (oracle/coper_oracle_torch.py), all host cores
+                          and one core, rank 0 at N = 1 only
+
+  --workload X --mode entity : any one workload as the main line, entity-sharded (strong scaling)."""
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -30,12 +44,16 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: Peak FP
 PEAK_HBM_GBS = 8000.0
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA; the bf16x3 mode spends 3 hardware MFMAs per algorithmic product
 
+SCALE_WORKLOAD, SCALE_TOPK, HBM_REGIME_QUERIES = "synth10m_cpg", 10, 128
+# Ranks of the `scale` pass on ONE GPU holding all 10M entities (seed 0, Q = 4096, bf16x3), measured on MI355X: every
+# entity sharding of the same table must reproduce them bit for bit (integer counts summed across shards).
+SCALE_EXPECTED = {"ranks_sha1": "046ac4218504f24ad31fe32c9fd8230332f1b1ee", "mean_rank": 4908458.672607422}
 
-def pmc_traffic(workload, Q, kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (profiles/), collected on
-    this same command in separate --pmc passes; None when no summary matches the workload."""
+
+def _profile_entry(pattern, workload, Q, kernel):
+    """(value dict, path) from the newest committed rocprofv3 PMC summary (profiles/) of this workload, or (None, None)."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
         try:
             d = json.load(open(path))
         except Exception:
@@ -44,25 +62,24 @@ def pmc_traffic(workload, Q, kernel):
             continue
         for name, v in d.get("kernels", {}).items():     # template arguments (<13>, <false>) follow the base name
             if name == kernel or name.startswith(kernel + "<"):
-                return v["hbm_bytes_per_launch"]
-    return None
+                return v, os.path.relpath(path, ROOT)
+    return None, None
 
 
-def pmc_mfma_busy(workload, Q, kernel):
-    """Matrix-pipe busy fraction and effective clock of `kernel` from the committed PMC summary
-    (profiles/*pmc_mfma_busy*.json: SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE on this same command), or None."""
-    import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_mfma_busy*.json")), reverse=True):
-        try:
-            d = json.load(open(path))
-        except Exception:
-            continue
-        if d.get("workload") != workload or d.get("queries") != Q:
-            continue
-        for name, v in d.get("kernels", {}).items():
-            if name == kernel or name.startswith(kernel + "<"):
-                return {"mfma_busy_frac": v["mfma_busy_frac"], "effective_clock_ghz": v["effective_clock_ghz"]}
-    return None
+def pmc_traffic(entry, workload, Q, kernel):
+    """HBM bytes per launch of `kernel`: NOT measured in this run -- replayed from the committed PMC summary of the
+    same command (separate --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied); provenance recorded."""
+    v, path = _profile_entry("*pmc_traffic*.json", workload, Q, kernel)
+    entry["traffic"] = v["hbm_bytes_per_launch"] if v else None
+    if v:
+        entry["traffic_source"] = "%s (rocprofv3 --pmc passes of this command, committed; not collected in this run)" % path
+
+
+def pmc_mfma_busy(entry, workload, Q, kernel):
+    v, path = _profile_entry("*pmc_mfma_busy*.json", workload, Q, kernel)
+    if v:
+        entry["pmc"] = {"mfma_busy_frac": v["mfma_busy_frac"], "effective_clock_ghz": v["effective_clock_ghz"],
+                        "source": "%s (SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE; committed, not collected in this run)" % path}
 
 
 def parse_args():
@@ -75,13 +92,16 @@ def parse_args():
     ap.add_argument("--queries", type=int, default=None)
     ap.add_argument("--order", choices=["shuffled", "sorted"], default="shuffled")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget per thread setting")
     ap.add_argument("--score-mode", choices=["f32", "bf16x3"], default="bf16x3")
     ap.add_argument("--profile-every", type=int, default=4,
                     help="HIP-event timing of the dominant kernels on every N-th timed step (an event pair around a launch "
                          "costs the stream a few microseconds of pipeline drain; 1 = every step)")
     ap.add_argument("--topk", type=int, default=0,
                     help="entity mode: also select and exchange the per-shard top-k of the filtered rows (SURVEY 8(e) step 3)")
+    ap.add_argument("--no-scale", action="store_true", help="skip the 10M-entity blocks (scale, HBM-regime roofline)")
+    ap.add_argument("--no-extras", action="store_true", help="main line only: no f32 comparison, PCIe-inclusive loop, 10M blocks")
+    ap.add_argument("--scale-steps", type=int, default=None, help="timed passes of the scale block (default min(steps, 10))")
     ap.add_argument("--dist-backend", default="nccl",
                     help="torch.distributed backend (nccl = RCCL).  gloo + several ranks on one GPU is a debugging aid "
                          "for the multi-process path on a single-GPU box; its numbers mean nothing")
@@ -89,46 +109,202 @@ def parse_args():
 
 
 def device_params(md, seed, device, shard=None):
-    """Random-init weights of the named architecture.  Small tensors come from the seeded numpy
-    generator; an entity table too large to build on the host is drawn on the device (same
-    N(0, 0.3^2) law), row-sharded."""
-    import torch
+    """Random-init weights of the named architecture.  Small tensors come from the seeded numpy generator; an
+    entity table too large to build on the host is drawn on the device in independently seeded row blocks
+    (coper_amd.data.synthetic_entity_rows_device): the same values whatever the sharding."""
     from coper_amd import data as cdata
     big = int(md["num_ent"]) * int(md["ent_emb_size"]) > (1 << 28)
     p = cdata.synthetic_params(md, seed, skip=("ent_emb", "pred_bias") if big else ())
     if big:
         lo, hi = shard if shard is not None else (0, int(md["num_ent"]))
-        g = torch.Generator(device=device)
-        g.manual_seed(seed * 1000 + lo)
-        p["ent_emb"] = torch.randn((hi - lo, int(md["ent_emb_size"])), generator=g, device=device, dtype=torch.float32) * 0.3
-        p["pred_bias"] = torch.randn((hi - lo,), generator=g, device=device, dtype=torch.float32) * 0.1
+        p["ent_emb"], p["pred_bias"] = cdata.synthetic_entity_rows_device(md, seed, device, lo, hi)
     return p, big
 
 
 def cpu_baseline(md, params, q, seconds):
-    """Reference-semantics CPU restatement (oracle, kind "port"): forward with the generated dense
-    weights materialised [B,F,d] (models.py:70,412), logits for all entities, dense mask, per-row
-    np.argsort (metrics.py:44-57), on a bounded sample of the same workload."""
-    from oracle import coper_oracle as O
-    try:
-        from threadpoolctl import threadpool_info
-        threads = max([i.get("num_threads", 1) for i in threadpool_info()] or [1])
-    except Exception:
-        threads = os.cpu_count() or 1
-    bs = 256
-    done, t0 = 0, time.perf_counter()
-    Q = len(q["e1"])
-    while done + bs <= Q:
-        ip = q["filt_indptr"][done:done + bs + 1]
-        O.eval_pass_reference_semantics(params, md, q["e1"][done:done + bs], q["rel"][done:done + bs],
-                                        q["e2"][done:done + bs], ip - ip[0], q["filt_idx"][ip[0]:ip[-1]], batch_size=bs)
-        done += bs
-        if time.perf_counter() - t0 >= seconds:
-            break
+    """SURVEY 8(d) CPU baseline (kind "port": the reference's own CPU path needs TensorFlow 1.14): the reference pass
+    restated on torch-CPU fp32 library kernels (conv2d / mm / bmm with the generated dense weights materialised
+    [B,F,d] as models.py:70,412) + the literal per-row argsort ranker (metrics.py:44-57), B = 512 as every shipped
+    config, on a bounded sample of the same workload: once on all host cores of this process, once on one."""
+    import torch
+    from oracle.coper_oracle_torch import TorchCPUModel
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    tm = TorchCPUModel(params, md)
+    Q, bs = len(q["e1"]), 512
+
+    def run(threads, budget):
+        torch.set_num_threads(threads)
+        done, t0 = 0, time.perf_counter()
+        while done < Q:
+            e = min(Q, done + bs)
+            ip = q["filt_indptr"][done:e + 1]
+            tm.eval_pass(q["e1"][done:e], q["rel"][done:e], q["e2"][done:e], ip - ip[0], q["filt_idx"][ip[0]:ip[-1]], batch_size=bs)
+            done = e
+            if time.perf_counter() - t0 >= budget:
+                break
+        dt = time.perf_counter() - t0
+        return done / dt, done, dt
+
+    prev = torch.get_num_threads()
+    # "all cores": the library threads are given every core this process may run on; oversubscribed thread pools can
+    # be slower than fewer threads (a 512-batch bmm on 256 hardware threads), so one batch is timed at a few thread
+    # counts first and the budget is spent on the fastest -- `cores` reports the threads actually used
+    cand = sorted({c for c in (cores, cores // 2, 64, 32, 16) if 1 < c <= cores}, reverse=True) or [cores]
+    calib = {c: run(c, 0.0)[0] for c in cand}
+    best = max(calib, key=calib.get)
+    v_all, n_all, t_all = run(best, seconds)
+    v_one, n_one, t_one = run(1, seconds)
+    torch.set_num_threads(prev)
+    what = ("torch-CPU fp32 forward (conv2d, mm, bmm over materialised [B,F,d] generated weights), logits for all entities, "
+            "dense mask, per-row np.argsort (single-threaded, as the reference's Python loop); batches of %d" % bs)
+    return {"value": v_all, "unit": "triples/s", "cores": best, "host_cores": cores, "kind": "port",
+            "sample": "%d queries of the same workload (%.1f s): %s" % (n_all, t_all, what),
+            "threads_tried": {str(c): round(v, 1) for c, v in calib.items()},
+            "one_core": {"value": v_one, "unit": "triples/s", "cores": 1, "sample": "%d queries (%.1f s)" % (n_one, t_one)}}
+
+
+class Ctx(object):
+    pass
+
+
+def timed_passes(ctx, step, steps):
+    """The driver contract: barrier + synchronize, EXACTLY `steps` passes, synchronize + barrier, MAX over ranks."""
+    import torch
+    import torch.distributed as dist
+    if ctx.use_dist:
+        dist.barrier()
+    torch.cuda.synchronize(ctx.device)
+    t0 = time.perf_counter()
+    out = None
+    for i in range(steps):
+        out = step(i)
+    torch.cuda.synchronize(ctx.device)
+    if ctx.use_dist:
+        dist.barrier()
     dt = time.perf_counter() - t0
-    return {"value": done / dt, "unit": "triples/s", "cores": int(threads), "kind": "port",
-            "sample": "%d queries of the same workload in batches of %d (%.1f s): NumPy forward with materialised "
-                      "[B,F,d] generated weights + dense mask + per-row argsort" % (done, bs, dt)}
+    if ctx.use_dist:
+        tmax = torch.tensor([dt], device=ctx.device if ctx.backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    return dt, out
+
+
+def event_times(ctx, step, steps):
+    """Per-pass durations (ms) from HIP events on the launch stream, no host synchronisation between passes."""
+    import torch
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    for i in range(steps):
+        ev[i][0].record()
+        step(i)
+        ev[i][1].record()
+    torch.cuda.synchronize(ctx.device)
+    return [a.elapsed_time(b) for a, b in ev]
+
+
+def score_roofline(ctx, kname, mode, Q, n_local, d, t_ms, workload, want_pmc=True):
+    """The score kernel against the lower of its two roofs at this shape.  ALGORITHMIC figures (fused
+    rank): flops = 2 Q n d; bytes = the entity table once (fp32 rows or two bf16 planes: 4 B per value) + pred_bias
+    + h in + counters out."""
+    fl = 2.0 * Q * n_local * d
+    by = n_local * d * 4.0 + n_local * 4.0 + Q * d * 4.0 + Q * 8.0
+    peak = PEAK_F32_MFMA_TFLOPS if mode == "f32" else PEAK_BF16_MFMA_TFLOPS
+    if by / (PEAK_HBM_GBS * 1e9) > fl / (peak * 1e12):
+        ach = by / (t_ms * 1e-3) / 1e9
+        e = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
+             "avg_launch_ms": t_ms, "algorithmic_bytes": by, "algorithmic_tflops": fl / (t_ms * 1e-3) / 1e12}
+    else:
+        ach = fl / (t_ms * 1e-3) / 1e12
+        e = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+             "avg_launch_ms": t_ms, "algorithmic_flops": fl, "algorithmic_gbs": by / (t_ms * 1e-3) / 1e9}
+        if mode != "f32":
+            e["note"] = "3 hardware bf16 MFMAs per algorithmic product: hardware MFMA utilisation = 3 x frac"
+    e["shape"] = "Q=%d x n=%d x d=%d" % (Q, n_local, d)
+    if ctx.world == 1 and want_pmc:
+        pmc_traffic(e, workload, Q, "coper::" + kname)
+        if e["bound"] == "mfma":
+            pmc_mfma_busy(e, workload, Q, "coper::" + kname)
+    else:
+        e["traffic"] = None
+    return e
+
+
+def run_scale_blocks(ctx, args):
+    """BASELINE.json configs[4] on this job's ranks: builds this rank's shard of the 10M-entity model once and runs
+    (1) the score kernel's HBM-bound regime (128 queries) and (2) the entity-sharded pass with the top-10 exchange."""
+    import torch
+    from coper_amd import data as cdata
+    from coper_amd.models import ConvE
+    from coper_amd.sharding import EntityShardedRanker, shard_bounds
+    md = cdata.model_descriptors(SCALE_WORKLOAD)
+    d = int(md["ent_emb_size"])
+    shard = shard_bounds(md["num_ent"], ctx.world, ctx.rank)
+    params, _ = device_params(md, 0, ctx.device, shard)
+    model = ConvE(md, device=ctx.device, shard=shard, score_mode="bf16x3")
+    model.load_parameters(params, global_rows=False)
+    t0 = time.perf_counter()
+    model.prepare()
+    torch.cuda.synchronize(ctx.device)
+    prepare_ms = (time.perf_counter() - t0) * 1e3
+    ranker = EntityShardedRanker(model)
+    out = {}
+
+    def make_step(Q, k):
+        q = cdata.synthetic_queries(md, Q, seed=0)
+        dq = {n: torch.as_tensor(v).to(ctx.device) for n, v in q.items()}
+        model.reserve(Q, len(q["filt_idx"]))
+        chunk = dict(e1=q["e1"], rel=q["rel"], e2=dq["e2"], filt_indptr=dq["filt_indptr"], filt_idx=dq["filt_idx"])
+        return (lambda i=0: ranker.rank(chunk, k=k)), q
+
+    # (1) HBM-bound regime of the score kernel: few queries against a table far larger than the caches
+    step, _ = make_step(HBM_REGIME_QUERIES, 0)
+    for _ in range(2):
+        step()
+    model.profile(True)
+    model.profile_read("score_count")
+    for _ in range(6):
+        step()
+    torch.cuda.synchronize(ctx.device)
+    ms, n = model.profile_read("score_count")
+    model.profile(False)
+    if n:
+        out["hbm_regime"] = score_roofline(ctx, "k_score_count_bf16x3", "bf16x3", HBM_REGIME_QUERIES, model.n_local, d, ms / n,
+                                           SCALE_WORKLOAD)
+    # (2) the entity-sharded pass, top-10 exchanged
+    Q = cdata.CONFIGS[SCALE_WORKLOAD]["queries"]
+    step, q = make_step(Q, SCALE_TOPK)
+    for _ in range(2):
+        step()
+    model.profile(True)
+    model.profile_read("score_count")
+    steps = args.scale_steps or min(args.steps, 10)
+    dt, res = timed_passes(ctx, step, steps)
+    ms, n = model.profile_read("score_count")
+    model.profile(False)
+    ranks = res[0].cpu().numpy()
+    sha = hashlib.sha1(np.ascontiguousarray(ranks.astype(np.int32)).tobytes()).hexdigest()
+    blk = {"metric": "scored triples/sec (1-vs-all)", "value": Q * steps / dt, "unit": "triples/s", "n_gpus": ctx.world,
+           "steps": steps, "ms_per_step": dt / steps * 1e3, "scaling": "strong",
+           "config": {"workload": "%s: |E|=%d R2=%d d=%d r=%d, Q=%d queries/pass (the same queries on every rank)" % (
+               SCALE_WORKLOAD, md["num_ent"], md["num_rel"], d, md["rel_emb_size"], Q),
+               "parallelism": "entity-sharded x%d (%d rows per rank), top-%d exchanged in one all-gather" % (
+                   ctx.world, model.n_local, SCALE_TOPK),
+               "score_mode": "bf16x3", "prepare_ms": round(prepare_ms, 2)},
+           "mean_rank": float(np.mean(ranks)), "mrr": float(np.mean(1.0 / ranks)), "ranks_sha1": sha,
+           "top1_id_sum": int(res[3][:, 0].sum().item())}
+    if n:
+        blk["roofline"] = dict(kernel="k_score_count_bf16x3", **score_roofline(ctx, "k_score_count_bf16x3", "bf16x3", Q, model.n_local, d,
+                                                                                  ms / n, SCALE_WORKLOAD, want_pmc=ctx.world == 1))
+    exp = SCALE_EXPECTED
+    if exp.get("ranks_sha1"):
+        blk["ranks_independent_of_world"] = bool(sha == exp["ranks_sha1"])
+        if not blk["ranks_independent_of_world"] and not os.environ.get("COPER_BENCH_NO_ASSERT"):
+            raise AssertionError("entity-sharded ranks at world=%d differ from the single-GPU ranks of the same KG: sha1 %s != %s, "
+                                 "mean rank %.6f != %.6f" % (ctx.world, sha, exp["ranks_sha1"], blk["mean_rank"], exp["mean_rank"]))
+    out["scale"] = blk
+    model.close()
+    del model, params
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -142,18 +318,20 @@ def main():
     import torch.distributed as dist
     from coper_amd import data as cdata
     from coper_amd.models import ConvE
-    from coper_amd.sharding import EntityShardedRanker, local_rank_pass, shard_bounds
+    from coper_amd.sharding import EntityShardedRanker, shard_bounds
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
+    ctx = Ctx()
+    ctx.world = world = int(os.environ.get("WORLD_SIZE", "1"))
+    ctx.rank = rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
     if args.dist_backend != "nccl":
         local_rank = local_rank % max(1, torch.cuda.device_count())   # debugging: ranks may share a GPU
     torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    use_dist = world > 1 or bool(os.environ.get("COPER_BENCH_FORCE_DIST"))   # the env var: exercise the RCCL path with one rank
+    ctx.device = device = torch.device("cuda", local_rank)
+    ctx.backend = args.dist_backend
+    ctx.use_dist = use_dist = world > 1 or bool(os.environ.get("COPER_BENCH_FORCE_DIST"))   # env: the RCCL path with one rank
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.dist_backend == "nccl":
@@ -181,7 +359,7 @@ def main():
     ranker = EntityShardedRanker(model) if entity_mode else None
     host_q = dict(q)
 
-    def step():
+    def step(i=0):
         if entity_mode:
             # ids are tiny; the host copies drive the relation split, the device copies feed the kernels
             return ranker.rank(dict(e1=host_q["e1"], rel=host_q["rel"], e2=dev_q["e2"], filt_indptr=dev_q["filt_indptr"],
@@ -191,39 +369,84 @@ def main():
         return model.rank_pass(dev_q["e1"], dev_q["rel"], dev_q["e2"], dev_q["filt_indptr"], dev_q["filt_idx"], filt_nnz=nnz,
                                want_equal=False)
 
+    def profiled_step(i):
+        model.profile(i % max(1, args.profile_every) == 0)     # per-kernel HIP events on a sample of the timed steps
+        return step()
+
     for _ in range(args.warmup):
         step()
     model.profile(True)
     for k in ("score_count", "dense", "conv"):
         model.profile_read(k)
     model.profile(False)
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        model.profile(i % max(1, args.profile_every) == 0)     # per-kernel HIP events on a sample of the timed steps
-        ranks, _ = step()
-    torch.cuda.synchronize(device)
-    if use_dist:
-        dist.barrier()
-    dt = time.perf_counter() - t0
+    dt, res = timed_passes(ctx, profiled_step, args.steps)
     model.profile(False)
-    if use_dist:
-        tmax = torch.tensor([dt], device=device if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-
+    ranks = res[0]
     kern = {}
     for k in ("score_count", "dense", "conv"):
         ms, n = model.profile_read(k)
         kern[k] = (ms / n) if n else None
     ranks_np = ranks.cpu().numpy()
+    extras = not args.no_extras
+
+    # per-pass medians (resident inputs), then the SURVEY 8(d) region: H2D ids / CSR + pass + D2H ranks
+    per_pass = event_times(ctx, step, args.steps) if extras else None
+    pcie = None
+    if extras and not entity_mode:
+        pin = {k: torch.as_tensor(v).pin_memory() for k, v in q.items()}
+        out_host = torch.empty(Q, dtype=torch.int32).pin_memory()
+
+        def pcie_step():
+            t0 = time.perf_counter()
+            dq = {k: v.to(device, non_blocking=True) for k, v in pin.items()}
+            r, _ = model.rank_pass(dq["e1"], dq["rel"], dq["e2"], dq["filt_indptr"], dq["filt_idx"], filt_nnz=nnz, want_equal=False)
+            out_host.copy_(r, non_blocking=True)
+            torch.cuda.synchronize(device)
+            return (time.perf_counter() - t0) * 1e3
+
+        for _ in range(max(1, args.warmup)):
+            pcie_step()
+        ts = [pcie_step() for _ in range(args.steps)]
+        assert np.array_equal(out_host.numpy(), ranks_np)
+        pcie = {"ms_per_step_median": statistics.median(ts), "ms_per_step_min": min(ts), "value_median": Q * world / (statistics.median(ts) * 1e-3),
+                "unit": "triples/s", "region": "H2D of e1/rel/e2 ids + CSR filter (pinned host buffers, %d bytes) + pass + D2H of int32 "
+                                               "ranks + synchronize, host clock, per rank" % sum(v.numel() * v.element_size() for v in pin.values())}
+
+    # the fp32-exact mode on the same queries: its throughput, and how far the headline mode's ranks are from its ranks
+    f32_info = None
+    if extras and not entity_mode and args.score_mode == "bf16x3" and not big:
+        m32 = ConvE(md, device=device, score_mode="f32").load_parameters(params).prepare()
+        m32.reserve(Q, nnz)
+
+        def step32(i=0):
+            return m32.rank_pass(dev_q["e1"], dev_q["rel"], dev_q["e2"], dev_q["filt_indptr"], dev_q["filt_idx"], filt_nnz=nnz, want_equal=False)
+
+        for _ in range(2):
+            step32()
+        dt32, res32 = timed_passes(ctx, step32, args.steps)
+        r32 = res32[0].cpu().numpy()
+        diff = np.abs(ranks_np.astype(np.int64) - r32.astype(np.int64))
+        f32_info = {"value": Q * world * args.steps / dt32, "unit": "triples/s", "ms_per_step": dt32 / args.steps * 1e3,
+                    "mean_rank": float(np.mean(r32)), "mrr": float(np.mean(1.0 / r32)),
+                    "rank_agreement_vs_f32": {"fraction_equal": float(np.mean(diff == 0)), "max_abs_diff": int(diff.max()),
+                                              "queries": int(len(diff)),
+                                              "note": "ranks are bit-exact inside a mode; across modes a logit gap below the "
+                                                      "bf16x3 error (~2e-4, gate 1e-3) can move a rank by the entities inside it"}}
+        m32.close()
+        del m32
+
+    scale = None
+    if extras and not args.no_scale and not entity_mode:
+        model.close()
+        del model, params
+        torch.cuda.empty_cache()
+        model = None
+        scale = run_scale_blocks(ctx, args)
 
     if rank == 0:
         units = Q * (1 if entity_mode else world) * args.steps
-        n_local = model.n_local
         d = int(md["ent_emb_size"])
+        n_local = int(shard[1] - shard[0]) if shard else int(md["num_ent"])
         out = {
             "metric": "scored triples/sec (1-vs-all)", "value": units / dt, "unit": "triples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -237,70 +460,66 @@ def main():
                 if entity_mode else ("query-sharded x%d" % world),
                 "score_mode": "f32 (v_mfma_f32_32x32x2_f32, exact)" if args.score_mode == "f32" else
                 "bf16x3 (3 x v_mfma_f32_32x32x16_bf16 per product, ~2^-16 rel.)", "prepare_ms": round(prepare_ms, 2),
+                "inputs": "ids + CSR filters resident in HBM before the timed region (pcie_inclusive: host buffers in, host ranks out)",
                 "mean_rank": float(np.mean(ranks_np)), "mrr": float(np.mean(1.0 / ranks_np))},
         }
-        F = model.fc_input_size
+        if per_pass:
+            out["timing"] = {"ms_per_step_median": statistics.median(per_pass), "ms_per_step_min": min(per_pass),
+                             "how": "HIP events on the launch stream around each of %d further passes, resident inputs" % len(per_pass)}
+        if pcie:
+            out["pcie_inclusive"] = pcie
+        if f32_info:
+            out["config"]["f32_exact"] = f32_info
+        cnt = np.bincount(q["rel"])
+        dm = cdata._dims(md)
+        F = dm["F"]
         kinfo = {}
         if kern["score_count"]:
-            fl = 2.0 * Q * n_local * d           # ALGORITHMIC flops of one score_count launch
-            # ALGORITHMIC bytes (fused rank): the entity table once (fp32 rows or two bf16 planes: 4 B per
-            # value either way) + pred_bias + h in + counters out
-            by = n_local * d * 4.0 + n_local * 4.0 + Q * d * 4.0 + Q * 8.0
-            peak = PEAK_F32_MFMA_TFLOPS if args.score_mode == "f32" else PEAK_BF16_MFMA_TFLOPS
-            t_ms = kern["score_count"]
             kname = "k_score_count_f32" if args.score_mode == "f32" else "k_score_count_bf16x3"
-            # which roof is lower at this shape: few queries against a table larger than the caches -> HBM
-            if by / (PEAK_HBM_GBS * 1e9) > fl / (peak * 1e12):
-                ach = by / (t_ms * 1e-3) / 1e9
-                kinfo[kname] = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
-                                "avg_launch_ms": t_ms, "algorithmic_bytes": by, "algorithmic_tflops": fl / (t_ms * 1e-3) / 1e12,
-                                "traffic": pmc_traffic(args.workload, Q, "coper::" + kname) if world == 1 else None}
-            else:
-                ach = fl / (t_ms * 1e-3) / 1e12
-                kinfo[kname] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                                "avg_launch_ms": t_ms, "algorithmic_gbs": by / (t_ms * 1e-3) / 1e9,
-                                "traffic": pmc_traffic(args.workload, Q, "coper::" + kname) if world == 1 else None}
-                if args.score_mode != "f32":
-                    kinfo[kname]["note"] = "3 hardware bf16 MFMAs per algorithmic product: hardware MFMA utilisation = 3 x frac"
-                pm = pmc_mfma_busy(args.workload, Q, "coper::" + kname) if world == 1 else None
-                if pm:
-                    kinfo[kname]["pmc"] = pm      # counters: fraction of the kernel's cycles with the matrix pipes busy
+            kinfo[kname] = score_roofline(ctx, kname, args.score_mode, Q, n_local, d, kern["score_count"], args.workload)
         if kern["dense"]:
             fl = 2.0 * Q * F * d                 # ALGORITHMIC flops of the dense launch pair (small + big tiles)
             if args.score_mode == "f32":
                 ach = fl / (kern["dense"] * 1e-3) / 1e12
                 kinfo["k_dense_big_f32"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                            "frac": ach / PEAK_F32_MFMA_TFLOPS, "avg_launch_ms": kern["dense"],
-                                            "traffic": pmc_traffic(args.workload, Q, "coper::k_dense_big_f32<13>") if world == 1 else None}
+                                            "frac": ach / PEAK_F32_MFMA_TFLOPS, "avg_launch_ms": kern["dense"]}
+                if world == 1:
+                    pmc_traffic(kinfo["k_dense_big_f32"], args.workload, Q, "coper::k_dense_big_f32<13>")
             else:
                 # ALGORITHMIC bytes (cached per-relation weights): G weight streams (one per
                 # relation tile of <= 128 queries) of F*d values in two bf16 planes + the e1 rows in + h out.
                 # The conv runs inside this kernel (x never touches HBM); "dense" times it together with the
                 # launch that serves the <= 32-query tiles.
-                cnt = np.bincount(q["rel"]) if md.get("context_rel_out", None) is not None else np.array([Q])
-                G = int(np.sum((cnt[cnt > 0] + 127) // 128))
+                cc = cnt if md.get("context_rel_out", None) is not None else np.array([Q])
+                G = int(np.sum((cc[cc > 0] + 127) // 128))
                 by = G * F * d * 4.0 + Q * d * 4.0 + Q * d * 4.0
                 ach = by / (kern["dense"] * 1e-3) / 1e9
                 kinfo["k_dense_fused_bf16x3"] = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                                  "frac": ach / PEAK_HBM_GBS, "avg_launch_ms": kern["dense"],
                                                  "algorithmic_bytes": by,
-                                                 "algorithmic_tflops": (fl + 2.0 * Q * F * 9) / (kern["dense"] * 1e-3) / 1e12,
-                                                 "traffic": pmc_traffic(args.workload, Q, "coper::k_dense_fused_bf16x3") if world == 1 else None}
+                                                 "algorithmic_tflops": (fl + 2.0 * Q * F * 9) / (kern["dense"] * 1e-3) / 1e12}
+                if world == 1:
+                    pmc_traffic(kinfo["k_dense_fused_bf16x3"], args.workload, Q, "coper::k_dense_fused_bf16x3")
         if kern["conv"] and args.score_mode == "f32":
-            by = Q * (F * 4.0 + d * 4.0)         # ALGORITHMIC bytes: x written (fp32 or two bf16 planes) + e1 row read
+            by = Q * (F * 4.0 + d * 4.0)         # ALGORITHMIC bytes: x written + e1 row read
             ach = by / (kern["conv"] * 1e-3) / 1e9
-            kinfo["k_conv3x3_bn_relu" if args.score_mode == "f32" else "k_conv3x3_bn_relu_bf16"] = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                          "frac": ach / PEAK_HBM_GBS, "avg_launch_ms": kern["conv"],
-                                          "traffic": pmc_traffic(args.workload, Q, "coper::k_conv3x3_bn_relu<4>" if args.score_mode == "f32" else "coper::k_conv3x3_bn_relu_bf16<4>") if world == 1 else None}
+            kinfo["k_conv3x3_bn_relu"] = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                          "frac": ach / PEAK_HBM_GBS, "avg_launch_ms": kern["conv"]}
+            if world == 1:
+                pmc_traffic(kinfo["k_conv3x3_bn_relu"], args.workload, Q, "coper::k_conv3x3_bn_relu<4>")
         if kinfo:
             dom = max(kinfo, key=lambda k: kinfo[k]["avg_launch_ms"])   # the dominant kernel of the step
             out["roofline"] = dict(kernel=dom, **kinfo[dom])
             out["roofline"]["all_kernels"] = {k: {kk: vv for kk, vv in v.items() if kk != "note"} for k, v in kinfo.items() if k != dom}
-        if not args.no_cpu_baseline and world == 1:
-            host_p = {k: (v.cpu().numpy() if hasattr(v, "cpu") else v) for k, v in params.items()} if not big else None
-            if host_p is not None:
-                out["cpu_baseline"] = cpu_baseline(md, host_p, q, args.cpu_seconds)
-                out["config"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+            out["roofline"]["tail_frac"] = 1.0 - sum(v["avg_launch_ms"] for v in kinfo.values()) / (dt / args.steps * 1e3)
+        if scale:
+            if "hbm_regime" in scale and "roofline" in out:
+                out["roofline"]["all_kernels"]["k_score_count_bf16x3@hbm"] = scale["hbm_regime"]
+            out["scale"] = scale["scale"]
+        if not args.no_cpu_baseline and world == 1 and not big:
+            host_p = {k: (v.cpu().numpy() if hasattr(v, "cpu") else v) for k, v in cdata.synthetic_params(md, 0).items()}
+            out["cpu_baseline"] = cpu_baseline(md, host_p, q, args.cpu_seconds)
+            out["config"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         sys.stdout.flush()
         os.dup2(json_fd, 1)
         print(json.dumps(out))

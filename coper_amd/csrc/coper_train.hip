@@ -910,8 +910,6 @@ COPER_API int coper_train_init(coper_handle* h, const coper_train_config* cfg) {
   if (!h || !cfg) return COPER_EINVAL;
   if (cfg->abi_version != COPER_ABI_VERSION) return fail(h, COPER_EINVAL, "coper_train_init: ABI version mismatch");
   const Dims& dm = h->dm;
-  if (dm.lookup && !dm.gen_fc)
-    return fail(h, COPER_EUNSUPPORTED, "coper_train_init: g_lookup is trained with a looked-up dense layer (context_rel_out set)");
   if (h->cfg.shard_lo != 0 || h->cfg.shard_hi != dm.E)
     return fail(h, COPER_EUNSUPPORTED, "coper_train_init: training needs the whole entity table on the handle");
   if (dm.fh != 3 || dm.fw != 3 || 256 % dm.C != 0 || dm.d > 256)
@@ -1023,10 +1021,10 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
   const int d = dm.d, r = dm.r, C = dm.C, P = dm.Ho * dm.Wo, isz = dm.in_h * dm.in_w;
   const int64_t F = dm.F, Fc = dm.F_conv;   // dense input width (F_conv + r under concat_rel), conv features
   const bool cat = dm.concat_rel;
-  const bool lk = dm.lookup;
-  const bool gen = dm.gen_fc && !lk;
-  const bool genc = dm.gen_conv && !lk;     // conv filters from projection generators
-  const bool lkc = dm.gen_conv && lk;       // conv filters from g_lookup tables
+  const bool lk = dm.lookup && dm.gen_fc;    // dense layer from g_lookup tables (otherwise static: models.py:217-228 with context_rel_out None)
+  const bool gen = dm.gen_fc && !dm.lookup;
+  const bool genc = dm.gen_conv && !dm.lookup;     // conv filters from projection generators
+  const bool lkc = dm.gen_conv && dm.lookup;       // conv filters from g_lookup tables
   const int nh = T->nh, nhc = T->nhc;
   const int rc_cw = nhc ? T->chain[2].dims[nhc] : r;
   const int rc_cb = nhc ? T->chain[3].dims[nhc] : r;
@@ -1066,7 +1064,7 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
   auto P_ = [&](const char* n) -> float* { return T->find(n)->p; };
   auto G_ = [&](const char* n) -> float* { return T->find(n)->g; };
   float* ent = P_("ent_emb");
-  float* relp = lk ? nullptr : P_("rel_emb");
+  float* relp = dm.lookup ? nullptr : P_("rel_emb");
   const int use_batch = tc.batch_norm_train_stats ? 1 : 0;
   int mx = C > d ? C : d;
   for (int i = 0; i < nh; ++i) mx = h->cfg.ctx_out[i] > mx ? h->cfg.ctx_out[i] : mx;
@@ -1316,7 +1314,7 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
   if (lds_cb > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_tr_conv_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipLaunchKernelGGL(k_tr_conv_bwd, dim3((unsigned)B), dim3(256), lds_cb, s, T->dx, T->img, dm.gen_conv ? nullptr : P_("conv1_weights"), e1, rel,
                      dm.E, dm.R, d, r, dm.in_h, dm.in_w, dm.stacked ? 1 : 0, C, dm.Ho, dm.Wo, dm.gen_conv ? nullptr : G_("conv1_weights"),
-                     dm.gen_conv ? nullptr : G_("conv1_bias"), G_("ent_emb"), lk ? nullptr : G_("rel_emb"), K_ps,
+                     dm.gen_conv ? nullptr : G_("conv1_bias"), G_("ent_emb"), dm.lookup ? nullptr : G_("rel_emb"), K_ps,
                      dm.gen_conv ? T->dKs : nullptr, dm.gen_conv ? T->dkbs : nullptr);
   if (genc) {
     // per-sample filter gradients -> last projections and contexts, then back through the conv generators
@@ -1347,7 +1345,7 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
   for (int i = 0; i < np; ++i) {
     tt.p[i] = T->tp[i].p; tt.g[i] = T->tp[i].g; tt.m[i] = T->tp[i].m; tt.v[i] = T->tp[i].v; tt.vh[i] = T->tp[i].vh;
     tt.n[i] = T->tp[i].n;
-    const bool table = dm.lookup && T->tp[i].name == "fc_weights";
+    const bool table = lk && T->tp[i].name == "fc_weights";
     tt.rowlen[i] = table ? F * d : 1;
     tt.rowcnt[i] = table ? h->rel_count : nullptr;
   }

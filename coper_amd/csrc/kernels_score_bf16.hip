@@ -170,7 +170,7 @@ __global__ __launch_bounds__(BX_THREADS, BX_WAVES / 4) void k_score_count_bf16x3
   int64_t cur_tile = -1;
   float4 bq[ME][4];
 
-#define LOAD_A(ah, al, ebx, ks_)                                  \
+#define LOAD_A_R(ah, al, ebx, ks_)                                \
   {                                                               \
     _Pragma("unroll") for (int m = 0; m < ME; ++m) {              \
       int64_t o_ = BX_DBG_GL(((ebx) + m) * KS + (ks_)) * 64 + lane; \
@@ -178,13 +178,26 @@ __global__ __launch_bounds__(BX_THREADS, BX_WAVES / 4) void k_score_count_bf16x3
       al[m] = BX_LOADQ(Elo + o_);                                 \
     }                                                             \
   }
-#define LOAD_B(bh, bl, ks_)                                                   \
+#define LOAD_B_R(bh, bl, ks_)                                                 \
   {                                                                           \
     _Pragma("unroll") for (int b = 0; b < NQ; ++b) {                          \
       bh[b] = hl_hi[BX_DBG_LDS(b * KS + (ks_)) * 64 + lane];                  \
       bl[b] = hl_lo[BX_DBG_LDS(b * KS + (ks_)) * 64 + lane];                  \
     }                                                                         \
   }
+  /* ablations: the loop without its global loads / without its LDS reads (operands loaded once, outside) */
+#ifdef COPER_DBG_BX_SKIP_GL
+#define LOAD_A(ah, al, ebx, ks_) {}
+#else
+#define LOAD_A(ah, al, ebx, ks_) LOAD_A_R(ah, al, ebx, ks_)
+#endif
+#ifdef COPER_DBG_BX_SKIP_LDS
+#define LOAD_B(bh, bl, ks_) {}
+#define BX_DECL_B
+#else
+#define LOAD_B(bh, bl, ks_) LOAD_B_R(bh, bl, ks_)
+#define BX_DECL_B uint4 bh[NQ], bl[NQ];
+#endif
 #define LOAD_BIAS(ebx)                                                                \
   {                                                                                   \
     _Pragma("unroll") for (int m = 0; m < ME; ++m) {                                  \
@@ -192,11 +205,20 @@ __global__ __launch_bounds__(BX_THREADS, BX_WAVES / 4) void k_score_count_bf16x3
       _Pragma("unroll") for (int j = 0; j < 4; ++j) bq[m][j] = bp[2 * j];             \
     }                                                                                 \
   }
+#ifdef COPER_DBG_BX_NO_MFMA   /* ablation: the fragment stream without the matrix work (loads stay live) */
+#define STEP(ah, al, bh, bl)                                                  \
+  {                                                                           \
+    _Pragma("unroll") for (int b = 0; b < NQ; ++b)                            \
+      _Pragma("unroll") for (int m = 0; m < ME; ++m)                          \
+        acc[m][b][0] += __uint_as_float((ah[m].x ^ al[m].y ^ ah[m].z ^ al[m].w ^ bh[b].x ^ bl[b].y) & 0x3fffffffu); \
+  }
+#else
 #define STEP(ah, al, bh, bl)                                                  \
   {                                                                           \
     _Pragma("unroll") for (int b = 0; b < NQ; ++b)                            \
       _Pragma("unroll") for (int m = 0; m < ME; ++m) MFMA_X3(ah[m], al[m], bh[b], bl[b], acc[m][b]); \
   }
+#endif
 #define FLUSH_COUNTS()                                                        \
   {                                                                           \
     _Pragma("unroll") for (int b = 0; b < NQ; ++b) {                          \
@@ -224,6 +246,10 @@ __global__ __launch_bounds__(BX_THREADS, BX_WAVES / 4) void k_score_count_bf16x3
     int64_t eb = ((u_begin % iters) * BX_WAVES + wave) * ME;
 #pragma unroll
     for (int i = 0; i < PD; ++i) LOAD_A(ah[i], al[i], eb, KCL(i));
+#ifdef COPER_DBG_BX_SKIP_GL
+#pragma unroll
+    for (int i = 0; i < NBF; ++i) LOAD_A_R(ah[i], al[i], eb, KCL(i));
+#endif
     LOAD_BIAS(eb);
   }
   for (int64_t u = u_begin; u < u_end; ++u) {
@@ -260,12 +286,16 @@ __global__ __launch_bounds__(BX_THREADS, BX_WAVES / 4) void k_score_count_bf16x3
     // loads just issued must have landed" -- one step ahead.  Fetches past the last k-step re-read it (KCL),
     // the prefetch for the unit after the last one re-reads this unit's blocks.
     int ks = 0;
+#ifdef COPER_DBG_BX_SKIP_LDS
+    uint4 bh[NQ], bl[NQ];
+    LOAD_B_R(bh, bl, 0);
+#endif
     for (; ks + NBF <= KS; ks += NBF) {
 #pragma unroll
       for (int j = 0; j < NBF; ++j) {
         LOAD_A(ah[(j + PD) % NBF], al[(j + PD) % NBF], eb, KCL(ks + j + PD));
         __builtin_amdgcn_sched_barrier(0);
-        uint4 bh[NQ], bl[NQ];
+        BX_DECL_B
         LOAD_B(bh, bl, ks + j);
         STEP(ah[j], al[j], bh, bl);
       }
@@ -275,7 +305,7 @@ __global__ __launch_bounds__(BX_THREADS, BX_WAVES / 4) void k_score_count_bf16x3
       if (ks + j < KS) {  // wave-uniform; KS % NBF trailing steps
         LOAD_A(ah[(j + PD) % NBF], al[(j + PD) % NBF], eb, KCL(ks + j + PD));
         __builtin_amdgcn_sched_barrier(0);
-        uint4 bh[NQ], bl[NQ];
+        BX_DECL_B
         LOAD_B(bh, bl, ks + j);
         STEP(ah[j], al[j], bh, bl);
       }
@@ -320,6 +350,9 @@ __global__ __launch_bounds__(BX_THREADS, BX_WAVES / 4) void k_score_count_bf16x3
   if (cur_tile >= 0) FLUSH_COUNTS();
 #undef LOAD_A
 #undef LOAD_B
+#undef LOAD_A_R
+#undef LOAD_B_R
+#undef BX_DECL_B
 #undef LOAD_BIAS
 #undef STEP
 #undef FLUSH_COUNTS

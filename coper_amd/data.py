@@ -12,7 +12,8 @@ This module yields that contract with the mask kept SPARSE (`filt_indptr`, `filt
 int64 list the reference stores in its TFRecords before `tf.sparse_to_dense`, data.py:182-186,591)
 and a dense-mask adapter for API parity.  No real dataset exists offline
 (`/root/reference/.MISSING_LARGE_BLOBS`), so the BASELINE configurations are synthetic KGs of the
-named |E|, |R|, d.  numpy only: nothing here touches the oracle or the GPU."""
+named |E|, |R|, d.  numpy only, except `synthetic_entity_rows_device` (torch, lazily imported: an entity
+table too large to draw on the host).  Nothing here touches the oracle."""
 from __future__ import annotations
 
 import math
@@ -21,6 +22,7 @@ from typing import Dict, Iterator, Optional
 import numpy as np
 
 __all__ = ["CONFIGS", "model_descriptors", "synthetic_params", "synthetic_queries", "SyntheticKGLoader",
+           "synthetic_entity_rows_device", "ENTITY_SEED_BLOCK",
            "dense_filter_to_csr", "csr_to_dense_filter", "param_shapes"]
 
 _COMMON = dict(use_negative_sampling=False, label_smoothing_epsilon=0.1, input_dropout=0.2, hidden_dropout=0.3,
@@ -181,6 +183,35 @@ def synthetic_params(md: dict, seed: int = 0, skip=()) -> Dict[str, np.ndarray]:
         else:  # pragma: no cover
             raise KeyError(name)
     return p
+
+
+ENTITY_SEED_BLOCK = 1 << 16   # rows per independently seeded block of a device-drawn entity table
+
+
+def synthetic_entity_rows_device(md: dict, seed: int, device, lo: int = 0, hi: Optional[int] = None):
+    """Rows [lo, hi) of the synthetic entity table of a config too large for the host generator
+    (`ent_emb ~ N(0, 0.3^2)`, `pred_bias ~ N(0, 0.1^2)`, the laws of `synthetic_params`), drawn on `device`.
+    The table is cut into blocks of ENTITY_SEED_BLOCK rows and block b is drawn from its own generator seeded
+    with (seed, b), so a row's values do not depend on which shard, or how many shards, hold it: every
+    sharding of the table scores the same KG (entity-sharded ranks can be compared across world sizes).
+    Returns (ent_emb [hi-lo, d] f32, pred_bias [hi-lo] f32)."""
+    import torch
+    E, d = int(md["num_ent"]), int(md["ent_emb_size"])
+    hi = E if hi is None else int(hi)
+    lo = int(lo)
+    ent = torch.empty((hi - lo, d), device=device, dtype=torch.float32)
+    bias = torch.empty((hi - lo,), device=device, dtype=torch.float32)
+    g = torch.Generator(device=device)
+    for b in range(lo // ENTITY_SEED_BLOCK, (hi + ENTITY_SEED_BLOCK - 1) // ENTITY_SEED_BLOCK):
+        b0 = b * ENTITY_SEED_BLOCK
+        n = min(ENTITY_SEED_BLOCK, E - b0)
+        g.manual_seed((int(seed) * 1000003 + b) * 2 + 1)
+        rows = torch.randn((n, d), generator=g, device=device, dtype=torch.float32) * 0.3
+        bs = torch.randn((n,), generator=g, device=device, dtype=torch.float32) * 0.1
+        s0, s1 = max(lo, b0), min(hi, b0 + n)
+        ent[s0 - lo:s1 - lo] = rows[s0 - b0:s1 - b0]
+        bias[s0 - lo:s1 - lo] = bs[s0 - b0:s1 - b0]
+    return ent, bias
 
 
 def synthetic_queries(md: dict, Q: int, seed: int = 0, mean_filter: float = 4.0, max_filter: int = 64,

@@ -50,6 +50,18 @@ class _Fetch(object):
         return "<coper fetch %s>" % self.name
 
 
+class _TrainOp(_Fetch):
+    """`model.train_op` (models.py:196-200): a fetch for `session.run((model.loss, model.train_op), {model.is_train: True,
+    ...})` as `run_cpg.py:211-219` issues it, and callable on a batch for loops that hold the batches themselves."""
+
+    def __init__(self, model):
+        _Fetch.__init__(self, "train_op")
+        self._model = model
+
+    def __call__(self, batch):
+        return self._model.train_step(batch)
+
+
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
@@ -107,6 +119,8 @@ class ConvE(object):
         self.predicted_e2_emb = _Fetch("predicted_e2_emb")
         self.predictions_all = _Fetch("predictions_all")
         self.predictions_lookup = _Fetch("predictions_lookup")
+        self.loss = _Fetch("loss")                 # models.py:192
+        self.train_op = _TrainOp(self)             # models.py:196-200
         self.summaries = None
 
     # ---------------------------------------------------------------- parameters
@@ -437,16 +451,11 @@ class ConvE(object):
 
     # ---------------------------------------------------------------- reference-style access
     @property
-    def loss(self):
-        """models.py:192: the last training step's loss (a device tensor)."""
+    def last_loss(self):
+        """The last training step's loss (a 1-element device tensor); `session.run(model.loss, ...)` returns it as a float."""
         if getattr(self, "_train_loss", None) is None:
             raise NotImplementedError("no training step has run: call train_init() and train_step(batch)")
         return self._train_loss
-
-    @property
-    def train_op(self):
-        """models.py:196-200: a callable standing in for the TF op -- `model.train_op(batch)`."""
-        return self.train_step
 
     def session(self):
         return Session(self)
@@ -474,9 +483,15 @@ class Session(object):
 
     def run(self, fetches, feed_dict=None):
         m = self.model
+        feed_dict = feed_dict or {}
         single = not isinstance(fetches, (tuple, list))
         fl = [fetches] if single else list(fetches)
-        handle = (feed_dict or {}).get(m.input_iterator_handle)
+        # variables fetched directly, `session.run([model.variables['rel_emb'], model.variables['ent_emb']])`
+        # (run_cpg.py:244-248): device tensors -> host arrays; no batch is consumed
+        if all(isinstance(f, torch.Tensor) for f in fl):
+            out = [f.detach().cpu().numpy() for f in fl]
+            return out[0] if single else (out if isinstance(fetches, list) else tuple(out))
+        handle = feed_dict.get(m.input_iterator_handle)
         if handle is None:
             raise ValueError("feed_dict must map model.input_iterator_handle to a batch iterator")
         key = id(handle)
@@ -487,8 +502,33 @@ class Session(object):
         except StopIteration:
             del self._iters[key]
             raise OutOfRangeError()
-        if feed_dict.get(m.is_train, False):
-            raise NotImplementedError("is_train=True: training is outside this build (SURVEY 8f-1)")
+        is_train = bool(feed_dict.get(m.is_train, False))
+        names = [getattr(f, "name", None) for f in fl]
+        if "train_op" in names:
+            # one optimisation step on this batch (run_cpg.py:211-219: `loss, _ = session.run((model.loss, model.train_op), feed)`);
+            # TF evaluates `loss` and the update in one graph execution: the loss returned is the loss of THIS batch before
+            # the update, which is what coper_train_step reports
+            if not is_train:
+                raise ValueError("train_op needs feed_dict[model.is_train] = True (run_cpg.py:212)")
+            if getattr(m, "_train_loss", None) is None:
+                m.train_init()
+            loss = m.train_step(batch)
+            out = []
+            for f, n in zip(fl, names):
+                if n == "train_op":
+                    out.append(None)
+                elif n == "loss":
+                    out.append(float(loss.cpu()[0]))
+                elif n in ("e1", "e2", "rel", "e2_multi", "lookup_values"):
+                    out.append(np.asarray(batch[n]))
+                elif n is None and f is None:       # model.summaries is None in this build (run_cpg.py:216 checks for it)
+                    out.append(None)
+                else:
+                    raise KeyError("fetch %r cannot be combined with train_op" % (n,))
+            return out[0] if single else tuple(out)
+        if is_train:
+            raise NotImplementedError("is_train=True without train_op: train-mode forward values (dropout, batch statistics) are "
+                                      "only produced inside the training step")
         cache = {}
 
         def h():
@@ -515,6 +555,8 @@ class Session(object):
                 out.append(m.score_all(h()).cpu().numpy())
             elif n == "predictions_lookup":
                 out.append(m.score_lookup(h(), batch["lookup_values"]).cpu().numpy())
+            elif n == "loss":
+                out.append(float(m.last_loss.cpu()[0]))
             else:
                 raise KeyError(n)
         return out[0] if single else tuple(out)

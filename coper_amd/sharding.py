@@ -59,8 +59,9 @@ class QueryShardedEvaluator(object):
 
     def __init__(self, scorer, group=None, rank_fn=local_rank_pass):
         self.scorer, self.group, self.rank_fn = scorer, group, rank_fn
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.rank_id = dist.get_rank(group) if dist.is_initialized() else 0
+        self.dist = dist.is_initialized()      # a process group of ONE rank still runs its collectives (RCCL on one GPU)
+        self.world = dist.get_world_size(group) if self.dist else 1
+        self.rank_id = dist.get_rank(group) if self.dist else 0
 
     def rank(self, chunk):
         Q = len(chunk["e1"])
@@ -71,7 +72,7 @@ class QueryShardedEvaluator(object):
             dev = getattr(self.scorer, "device", "cpu")
             r = torch.zeros(0, dtype=torch.int32, device=dev)
             ne = torch.zeros(0, dtype=torch.int32, device=dev)
-        if self.world == 1:
+        if not self.dist:
             return r, ne
         # ragged all-gather: pad to the largest share
         cap = shard_bounds(Q, self.world, 0)[1]
@@ -94,11 +95,12 @@ class EntityShardedRanker(object):
 
     def __init__(self, scorer, group=None, split_encoder=True):
         self.scorer, self.group, self.split_encoder = scorer, group, split_encoder
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.rank_id = dist.get_rank(group) if dist.is_initialized() else 0
+        self.dist = dist.is_initialized()      # a process group of ONE rank still runs its collectives (RCCL on one GPU)
+        self.world = dist.get_world_size(group) if self.dist else 1
+        self.rank_id = dist.get_rank(group) if self.dist else 0
 
     def _allreduce(self, t):
-        if self.world > 1:
+        if self.dist:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
@@ -107,7 +109,8 @@ class EntityShardedRanker(object):
         rows = self._allreduce(sc.gather_entities(e1))                          # step 1
         rel_np = np.asarray(rel)
         if self.world == 1 or not self.split_encoder:
-            return sc.encode(e1, rel, e1_rows=rows)
+            h = sc.encode(e1, rel, e1_rows=rows)
+            return self._allreduce(h) if self.world == 1 else h   # one rank: the sum over ranks of a single share
         mine = np.nonzero(rel_np % self.world == self.rank_id)[0]               # step 2
         h = torch.zeros((len(rel_np), rows.shape[1]), dtype=torch.float32, device=rows.device)
         if len(mine):
@@ -132,7 +135,7 @@ class EntityShardedRanker(object):
         if k > 0:
             rec[:, 1:1 + k] = out[2].contiguous().view(torch.int32).to(torch.int64)
             rec[:, 1 + k:] = out[3]
-        if self.world > 1:
+        if self.dist:
             allrec = torch.empty((self.world * B, 1 + 2 * k), dtype=torch.int64, device=rec.device)
             dist.all_gather_into_tensor(allrec, rec, group=self.group)           # concatenated along dim 0 (gloo + nccl)
             allrec = allrec.view(self.world, B, 1 + 2 * k)

@@ -165,3 +165,27 @@ def test_end_to_end_matches_minerva_torch_models(golden_dir, tag):
     assert np.abs(sigmoid(fact) - S_fact).max() < 2e-6
     st64 = O.forward(p, md, q["e1"], q["rel"], np.float64)
     assert np.abs(sigmoid(O.score_all(st64["h"], p["ent_emb"], p["pred_bias"])) - S).max() < 2e-6
+
+
+@pytest.mark.parametrize("name", ["plain", "cpg_fc", "cpg_fc_mlp", "cpg_conv_fc", "cpg_conv_only_concat", "lookup"])
+def test_torch_cpu_baseline_matches_the_oracle(golden_dir, name):
+    """bench.py's cpu_baseline (oracle/coper_oracle_torch.py: torch-CPU conv2d / bmm / mm + the literal argsort
+    ranker) computes what the NumPy oracle computes: stage output `h`, logits, and ranks of a filtered pass."""
+    from oracle.coper_oracle_torch import TorchCPUModel
+    from oracle.gen_golden import FWD_CASES
+    g = _load(golden_dir, "fwd_%s.npz" % name)
+    md = dict(cdata._COMMON)
+    md.update(FWD_CASES[name][0])
+    p = {k[6:]: g[k] for k in g.files if k.startswith("param:")}
+    q = {k[2:]: g[k] for k in g.files if k.startswith("q:")}
+    tm = TorchCPUModel(p, md)
+    h = tm.forward(q["e1"], q["rel"])
+    np.testing.assert_allclose(h.numpy(), g["f32:h"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(tm.predictions_all(h).numpy(), g["f64:logits"], rtol=0, atol=1e-4)
+    # a filtered pass in two ragged batches against the oracle's closed form on the fp64 logits (the fixture's scores
+    # are tie-free with margins far above the fp32 error)
+    qq = cdata.synthetic_queries(md, len(q["e1"]), seed=3)
+    ranks = tm.eval_pass(q["e1"], q["rel"], qq["e2"], qq["filt_indptr"], qq["filt_idx"], batch_size=max(1, len(q["e1"]) // 2 + 1))
+    ng, ne = O.rank_counts(g["f64:logits"], qq["e2"], qq["filt_indptr"], qq["filt_idx"])
+    assert np.all(ne == 0)       # tie-free (the target itself is not counted)
+    assert np.array_equal(ranks, 1 + ng)
