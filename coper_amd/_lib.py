@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(HERE, "libcoper_hip.so")
 COPER_ABI_VERSION = 1
 COPER_MAX_CTX = 4
 
-SCORE_F32, SCORE_BF16X3, SCORE_BF16 = 0, 1, 2
+SCORE_F32, SCORE_BF16X3 = 0, 1
 
 STATUS = {0: "COPER_OK", 1: "COPER_EINVAL", 2: "COPER_EMISSING", 3: "COPER_ESHAPE", 4: "COPER_EHIP",
           5: "COPER_ESTATE", 6: "COPER_ENOMEM", 7: "COPER_EUNSUPPORTED"}

@@ -168,7 +168,7 @@ COPER_API int coper_create(const coper_config* cfg, coper_handle** out) {
   if (cfg->n_ctx_conv > COPER_MAX_CTX || cfg->n_ctx_out > COPER_MAX_CTX) return bad("too many generator hidden layers");
   if (cfg->shard_lo < 0 || cfg->shard_hi > dm.E || cfg->shard_lo >= cfg->shard_hi) return bad("entity shard [lo,hi) out of range");
   if (cfg->score_mode != COPER_SCORE_F32 && cfg->score_mode != COPER_SCORE_BF16X3)
-    return bad("score_mode: COPER_SCORE_F32 and COPER_SCORE_BF16X3 are built; COPER_SCORE_BF16 is not");
+    return bad("score_mode: COPER_SCORE_F32 or COPER_SCORE_BF16X3");
   // models.py:360: e1 stacked on the reshaped relation only for plain ConvE
   dm.stacked = !dm.gen_conv && !dm.gen_fc && !dm.lookup;
   dm.in_h = dm.emb_h; dm.in_w = dm.emb_w;

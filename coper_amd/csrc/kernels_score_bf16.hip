@@ -368,6 +368,10 @@ int launch_pack_h_bf16(coper_handle* h, const float* hvec, int64_t B, hipStream_
 int score_count_chunk_bf16x3(coper_handle* h, int64_t q0, int64_t Bc, const float* tgt, int32_t* ng, int32_t* ne, float* gmax,
                              int64_t gm_stride, hipStream_t s) {
   const Dims& dm = h->dm;
+  if (score_count2_supported(h)) {   // the pipelined kernel (kernels_score2_bf16.hip): same counts, same block maxima
+    ScopedKernelTimer t(h, "score_count", s);
+    return score_count2_chunk_bf16x3(h, q0, Bc, tgt, ng, ne, gmax, gm_stride, s);
+  }
   int64_t q_tiles = (Bc + 32 * BX_NQ - 1) / (32 * BX_NQ);
   int64_t iters = dm.n_eblk / (BX_WAVES * BX_ME);
   int64_t units = q_tiles * iters;

@@ -89,7 +89,9 @@ class ConvE(object):
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         self.shard = (0, self.num_ent) if shard is None else (int(shard[0]), int(shard[1]))
         self._lib = _lib.load()
-        mode = {"f32": _lib.SCORE_F32, "bf16x3": _lib.SCORE_BF16X3, "bf16": _lib.SCORE_BF16}[score_mode]
+        if score_mode not in ("f32", "bf16x3"):
+            raise ValueError("score_mode: 'f32' (exact-f32 MFMA) or 'bf16x3' (split-bf16 operands, 3 bf16 MFMAs per product)")
+        mode = {"f32": _lib.SCORE_F32, "bf16x3": _lib.SCORE_BF16X3}[score_mode]
         self.score_mode = score_mode
         cfg = _lib.make_config(md, device=self.device.index or 0, shard=self.shard, score_mode=mode)
         h = C.c_void_p()

@@ -49,8 +49,8 @@ typedef enum coper_status {
 
 typedef enum coper_score_mode {
   COPER_SCORE_F32 = 0,   /* entity table fp32, exact-f32 MFMA (v_mfma_f32_32x32x2_f32): parity mode */
-  COPER_SCORE_BF16X3 = 1,/* table + query split hi/lo bf16, 3 bf16 MFMAs per product: ~2^-16 rel. error */
-  COPER_SCORE_BF16 = 2   /* table + query rounded to bf16, 1 MFMA: ~2^-9 rel. error (throughput mode) */
+  COPER_SCORE_BF16X3 = 1 /* table + query split hi/lo bf16, 3 bf16 MFMAs per product: ~2^-16 rel. error */
+  /* (a single-bf16 mode, ~2^-9 per product, cannot meet the 1e-3 logit gate of the path and is not part of the ABI) */
 } coper_score_mode;
 
 /* Mirrors the `model_descriptors` dict of ConvE.__init__ (models.py:98-130) -- only the keys

@@ -84,8 +84,8 @@ def forward_train(p, md, batch, keep_hidden, keep_out, dtype=torch.float64, keep
     C = int(md.get("conv_num_channels", 32))
     ctx_conv, ctx_out = md.get("context_rel_conv", None), md.get("context_rel_out", None)
     lookup_params = bool(md.get("do_parameter_lookup", False))
-    if lookup_params and (ctx_out is None or md.get("concat_rel", False)):
-        raise NotImplementedError("training oracle: g_lookup needs the looked-up dense layer and cannot concat_rel (models.py:180,406)")
+    if lookup_params and ((ctx_out is None and ctx_conv is None) or md.get("concat_rel", False)):
+        raise NotImplementedError("training oracle: g_lookup needs a looked-up layer and cannot concat_rel (models.py:180,263-264,406)")
     train_stats = bool(md.get("batch_norm_train_stats", False))
     e1 = torch.as_tensor(batch["e1"]).long()
     rel = torch.as_tensor(batch["rel"]).long()

@@ -1,5 +1,6 @@
 """TF `Saver` checkpoint reader / writer (run_cpg.py:189,206,252).  No TensorFlow here, so the
 format pieces with published known answers are pinned to those, and the rest by the round trip."""
+import os
 import struct
 
 import numpy as np
@@ -121,3 +122,36 @@ def test_corruption_is_detected(tmp_path):
     open(prefix + "2.data-00000-of-00001", "wb").write(b"\0" * 10)
     with pytest.raises(ValueError, match="bytes on disk"):
         tb.read_bundle(prefix + "2")
+
+
+def test_reader_on_a_hand_assembled_checkpoint(tmp_path):
+    """The reader against bytes the writer of this package did NOT produce: tests/golden/tf_bundle_handmade.json holds
+    a two-block table assembled byte by byte from the published table / proto layouts by
+    tests/golden/make_tf_bundle_handmade.py (own bitwise CRC-32C, restart points inside a block, a prefix-compressed key,
+    a scalar int64 tensor, omitted zero fields, a shortened index separator).  Not a TensorFlow-written file: none exists
+    in this environment, the format stays restated-from-publication."""
+    import json
+    from coper_amd import tf_bundle
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tf_bundle_handmade.json")))
+    prefix = str(tmp_path / "model.ckpt")
+    open(prefix + ".index", "wb").write(bytes.fromhex(g["index_hex"]))
+    open(prefix + ".data-00000-of-00001", "wb").write(bytes.fromhex(g["data_hex"]))
+    listed = tf_bundle.list_bundle(prefix)
+    assert sorted(listed) == sorted(g["tensors"])
+    got = tf_bundle.read_bundle(prefix)
+    for name, want in g["tensors"].items():
+        a = got[name]
+        assert a.dtype == np.dtype(want["dtype"]) and list(a.shape) == want["shape"], name
+        assert np.array_equal(a.reshape(-1), np.asarray(want["values"], a.dtype)), name
+    # a flipped tensor byte and a flipped table byte are both detected by the stored CRCs
+    data = bytearray(bytes.fromhex(g["data_hex"]))
+    data[9] ^= 0x40
+    open(prefix + ".data-00000-of-00001", "wb").write(bytes(data))
+    with pytest.raises(Exception):
+        tf_bundle.read_bundle(prefix)
+    open(prefix + ".data-00000-of-00001", "wb").write(bytes.fromhex(g["data_hex"]))
+    index = bytearray(bytes.fromhex(g["index_hex"]))
+    index[20] ^= 0x01
+    open(prefix + ".index", "wb").write(bytes(index))
+    with pytest.raises(Exception):
+        tf_bundle.read_bundle(prefix)

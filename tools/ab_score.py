@@ -32,3 +32,12 @@ by = md["num_ent"] * md["ent_emb_size"] * 4.0
 print("%s %s Q=%d: score_count avg %.4f ms  %.1f TFLOP/s  %.2f TB/s (table once)  sum(ng)=%d" % (
     os.path.basename(os.environ.get("COPER_HIP_LIB", "default")), name, Q, t, fl / (t * 1e-3) / 1e12, by / (t * 1e-3) / 1e12,
     int(ng.sum().item())))
+
+try:
+    import ctypes
+    lib = ctypes.CDLL(os.environ.get("COPER_HIP_LIB", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "coper_amd", "libcoper_hip.so")))
+    g, u = ctypes.c_double(), ctypes.c_double()
+    if lib.coper_dbg_clock(256, ctypes.byref(g), ctypes.byref(u)) == 0:
+        print("   in-kernel clock (median over workgroups): %.3f GHz, in-kernel time %.1f us" % (g.value, u.value))
+except AttributeError:
+    pass
