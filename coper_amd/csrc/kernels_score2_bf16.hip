@@ -59,9 +59,17 @@ template <int KS, int PD, bool EQ, bool GM, int M, int V>
 __device__ __forceinline__ void sc2_value(SC2<KS, PD, EQ, GM>& S, const int lane, const bool store_gm, float* __restrict__ gm_row,
                                           const int64_t gm_col) {
   constexpr int b = V / 16, r = V % 16;
-  const float sc = S.acc[M][b][r];
-  S.cg[b] += (sc > S.t[b]) ? 1 : 0;
-  if constexpr (EQ) S.ce[b] += (sc == S.t[b]) ? 1 : 0;
+#ifdef COPER_DBG_SC2_EPI_R0   /* ablation: one value per accumulator keeps the MFMA chains alive, the epilogue nearly free */
+  if constexpr (r != 0) return;
+#endif
+  // The accumulator is read out of its AGPR here, at the point of use: left to the compiler the whole accumulator is
+  // copied to VGPRs right behind its last MFMA (s_nop + 16 reads that wait for the matrix pipe to drain).
+  float sc;
+  asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(sc) : "a"(S.acc[M][b][r]));
+  // count += (sc > t): compare into VCC, add with carry
+  asm volatile("v_cmp_gt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(S.cg[b]) : "v"(sc), "v"(S.t[b]) : "vcc");
+  if constexpr (EQ)
+    asm volatile("v_cmp_eq_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(S.ce[b]) : "v"(sc), "v"(S.t[b]) : "vcc");
   if constexpr (GM) {
     if constexpr (r == 0) S.mx[b] = sc; else S.mx[b] = fmaxf(S.mx[b], sc);
     if constexpr (r == 15) {
