@@ -23,6 +23,7 @@
 
 #include "coper_internal.h"
 #include "train_common.h"
+#include "train_gemm.h"
 
 namespace coper {
 
@@ -92,6 +93,8 @@ struct TrainState {
   float* Sd = nullptr;       // [B, |E|] dense d(loss)/d(logits) when it fits (scorer backward by GEMM)
   int64_t capS = 0;
   float* A = nullptr;        // generated dense: T[r][B][d] (forward partials) | dT[r][B][d]
+  // generated dense, split-bf16 GEMMs (train_gemm_bf16.hip): operand planes
+  TgPlanes pX, pXt, pP1, pP3, pTn, pTb;   // x rows b | x rows f | P rows (rho,k) | P rows f | dT rows (rho,k) | dT rows b
   float *z0 = nullptr, *z1 = nullptr, *hv = nullptr, *dh = nullptr, *dz = nullptr, *ds = nullptr, *dx = nullptr, *dc = nullptr;
   double* red = nullptr;     // reduction scratch: [0] loss, [1] grad sumsq, [2..] BN sums
   float* bnst = nullptr;     // [4][max(C,d)]: mean1, inv1, mean2, inv2 ... see offsets below
@@ -615,25 +618,6 @@ __global__ __launch_bounds__(256) void k_tr_scale_rows(const float* __restrict__
 
 // dx[b,f] = sum_rho c[b,rho] dA[b,rho*F+f];  dc[b,rho] += sum_f x[b,f] dA[b,rho*F+f]
 // dx[b, f] = sum_rho c[b, rho] dA[b, rho, f]   (one pass over dA, eight loads in flight)
-__global__ __launch_bounds__(256) void k_tr_outer_bwd(const float* __restrict__ dA, const float* __restrict__ c, int64_t F, int r,
-                                                      float* __restrict__ dx) {
-  const int64_t b = blockIdx.y;
-  const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (f >= F) return;
-  const float* Ab = dA + b * (int64_t)r * F + f;
-  const float* cb = c + b * r;
-  float a = 0.f;
-  int rho = 0;
-  for (; rho + 8 <= r; rho += 8) {
-    float g[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) g[u] = Ab[(int64_t)(rho + u) * F];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) a = fmaf(cb[rho + u], g[u], a);
-  }
-  for (; rho < r; ++rho) a = fmaf(cb[rho], Ab[(int64_t)rho * F], a);
-  dx[b * F + f] = a;
-}
 
 // dc[b, rho] = sum_k dz[b, k] T[rho][b][k]: z[b] = sum_rho c[b, rho] T[rho][b] with the forward partials T = x P[rho]
 // still in place, so the context gradient needs no second pass over dA.  One wave per (b, rho).
@@ -885,6 +869,10 @@ void train_destroy(coper_handle* h) {
   TrainState* T = (TrainState*)h->train;
   if (!T) return;
   for (auto& t : T->tp) { (void)hipFree(t.g); (void)hipFree(t.m); (void)hipFree(t.v); (void)hipFree(t.vh); }
+  for (TgPlanes* pl : {&T->pX, &T->pXt, &T->pP1, &T->pP3, &T->pTn, &T->pTb}) {
+    if (pl->hi) (void)hipFree(pl->hi);
+    if (pl->lo) (void)hipFree(pl->lo);
+  }
   float* bufs[] = {T->Kt, T->Kbv, T->dKs, T->dkbs, T->Sd, T->img, T->y, T->x, T->c, T->A, T->dA, T->z0, T->z1, T->hv, T->dh, T->dz, T->ds, T->dx, T->dc, T->bnst, T->xc, T->dxc};
   for (float* b : bufs) (void)hipFree(b);
   for (auto& ch : T->chain)
@@ -1043,7 +1031,14 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
         (rc = talloc(h, &T->dz, (size_t)cb * d)) || (rc = talloc(h, &T->ds, (size_t)cb * (one_vs_all ? 1 : cl))))
       return rc;
     if (cat && ((rc = talloc(h, &T->xc, (size_t)cb * F)) || (rc = talloc(h, &T->dxc, (size_t)cb * F)))) return rc;
-    if (gen && ((rc = talloc(h, &T->A, (size_t)2 * rc_w * cb * d)) || (rc = talloc(h, &T->dA, (size_t)cb * rc_w * F)))) return rc;
+    if (gen) {
+      if ((rc = talloc(h, &T->A, (size_t)2 * rc_w * cb * d))) return rc;
+      const int64_t nrk = (int64_t)rc_w * d;
+      struct { TgPlanes* p; int64_t rows, K; } planes[] = {{&T->pX, cb, F}, {&T->pXt, F, cb}, {&T->pP1, nrk, F}, {&T->pP3, F, nrk},
+                                                          {&T->pTn, nrk, cb}, {&T->pTb, cb, nrk}};
+      for (auto& pl : planes)
+        if ((rc = talloc(h, &pl.p->hi, tg_plane_elems(pl.rows, pl.K))) || (rc = talloc(h, &pl.p->lo, tg_plane_elems(pl.rows, pl.K)))) return rc;
+    }
     for (int g = 0; g < 4; ++g) {
       if (g < 2 ? !gen : !genc) continue;
       const int nhx = g < 2 ? nh : nhc;
@@ -1170,11 +1165,12 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
                        tc.seed, step, thr_o, ks_o, T->z1);
   } else {
     if (gen) {
-      // T[rho] = x P[rho]: r independent [B,F]x[F,d] products fill the chip (a single GEMM over K = r*F has 8 tiles)
-      if ((rc = rb_check(h, T->rb.sgemm_sb(T->rb.handle, RB_N, RB_N, d, (int)B, (int)F, &one, Wmat, d, F * (int64_t)d, xin, (int)F, 0, &zero,
-                                            Tf, d, nBd, rc_w),
-                         "sgemm_strided_batched forward")))
-        return rc;
+      // T[rho][b][k] = sum_f x[b][f] P[rho][f][k] on the bf16 matrix cores with split operands (train_gemm_bf16.hip): x and P
+      // are packed into fragment planes (P as rows (rho, k) with f contracted), one GEMM of [B] x [r*d] outputs
+      const int64_t nrk = (int64_t)rc_w * d;
+      if ((rc = tg_pack(h, xin, tg_idx(F), tg_idx(1), B, F, tg_rows_pad(B), false, T->pX, s))) return rc;
+      if ((rc = tg_pack(h, Wmat, tg_idx2(d, F * (int64_t)d, 1), tg_idx(d), nrk, F, tg_rows_pad(nrk), true, T->pP1, s))) return rc;
+      if ((rc = tg_gemm_nt(h, T->pX, B, T->pP1, nrk, F, Tf, tg_idx(d), tg_idx2(d, nBd, 1), s))) return rc;
     } else {
       // z0[B,d] = x[B,F] W[F,d]   (row-major operands seen as column-major transposes)
       if ((rc = rb_check(h, T->rb.sgemm(T->rb.handle, RB_N, RB_N, d, (int)B, (int)F, &one, Wmat, d, xin, (int)F, &zero, T->z0, d),
@@ -1259,25 +1255,23 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
                      gen ? nullptr : G_("fc_bias"), gen ? G_(blast.c_str()) : nullptr, dcb);
   float* dW = gen ? G_(wlast.c_str()) : G_("fc_weights");
   if (gen) {
-    // dP[rho] = x^T dT[rho],  dT[rho][b,:] = cw[b,rho] dz[b,:]
+    // dT[rho][b,:] = cw[b,rho] dz[b,:];  dP[rho][f][k] = sum_b x[b][f] dT[rho][b][k]  and
+    // dx[b][f] = sum_(rho,k) dT[rho][b][k] P[rho][f][k]: two split-bf16 GEMMs, the [B, r*F] intermediate dz P2^T is never formed
+    const int64_t nrk = (int64_t)rc_w * d;
     hipLaunchKernelGGL(k_tr_scale_rows, dim3((unsigned)((nBd + 255) / 256)), dim3(256), 0, s, T->dz, cw, rc_w, d, nBd, dTf);
-    if ((rc = rb_check(h, T->rb.sgemm_sb(T->rb.handle, RB_N, RB_T, d, (int)F, (int)B, &one, dTf, d, nBd, xin, (int)F, 0, &zero, dW, d,
-                                          F * (int64_t)d, rc_w),
-                       "sgemm_strided_batched dP")))
-      return rc;
+    if ((rc = tg_pack(h, xin, tg_idx(1), tg_idx(F), F, B, tg_rows_pad(F), true, T->pXt, s))) return rc;
+    if ((rc = tg_pack(h, dTf, tg_idx2(d, nBd, 1), tg_idx(d), nrk, B, tg_rows_pad(nrk), true, T->pTn, s))) return rc;
+    if ((rc = tg_gemm_nt(h, T->pXt, F, T->pTn, nrk, B, dW, tg_idx(d), tg_idx2(d, F * (int64_t)d, 1), s))) return rc;
+    if ((rc = tg_pack(h, dTf, tg_idx(d), tg_idx2(d, nBd, 1), B, nrk, tg_rows_pad(B), false, T->pTb, s))) return rc;
+    if ((rc = tg_pack(h, Wmat, tg_idx(d), tg_idx2(d, F * (int64_t)d, 1), F, nrk, tg_rows_pad(F), false, T->pP3, s))) return rc;
+    if ((rc = tg_gemm_nt(h, T->pTb, B, T->pP3, F, nrk, dxin, tg_idx(F), tg_idx(1), s))) return rc;
+    hipLaunchKernelGGL(k_tr_dc_from_partials, dim3((unsigned)((B * rc_w + 3) / 4)), dim3(256), 0, s, T->dz, Tf, B, rc_w, d, dcw);
   } else {
-    // dW[F,d] = x^T dz
+    // static dense layer (plain ConvE): dW[F,d] = x^T dz and dx[B,F] = dz W^T, plain library GEMMs
     if ((rc = rb_check(h, T->rb.sgemm(T->rb.handle, RB_N, RB_T, d, (int)F, (int)B, &one, T->dz, d, xin, (int)F, &zero, dW, d), "sgemm dW")))
       return rc;
-  }
-  // dA[B,Kd] = dz W^T
-  float* dAmat = gen ? T->dA : dxin;
-  if ((rc = rb_check(h, T->rb.sgemm(T->rb.handle, RB_T, RB_N, (int)Kd, (int)B, d, &one, Wmat, d, T->dz, d, &zero, dAmat, (int)Kd), "sgemm dA")))
-    return rc;
-  if (gen)
-  {
-    hipLaunchKernelGGL(k_tr_outer_bwd, dim3((unsigned)((F + 255) / 256), (unsigned)B), dim3(256), 0, s, T->dA, cw, F, rc_w, dxin);
-    hipLaunchKernelGGL(k_tr_dc_from_partials, dim3((unsigned)((B * rc_w + 3) / 4)), dim3(256), 0, s, T->dz, Tf, B, rc_w, d, dcw);
+    if ((rc = rb_check(h, T->rb.sgemm(T->rb.handle, RB_T, RB_N, (int)Kd, (int)B, d, &one, Wmat, d, T->dz, d, &zero, dxin, (int)Kd), "sgemm dx")))
+      return rc;
   }
   if (cat) hipLaunchKernelGGL(k_tr_split, dim3((unsigned)((B * F + 255) / 256)), dim3(256), 0, s, T->dxc, rel, dm.R, Fc, r, B * F, T->dx, G_("rel_emb"));
   }

@@ -1,0 +1,34 @@
+// Split-bf16 GEMMs of the training step (train_gemm_bf16.hip): operand packing and C(i,j) = sum_k X(i,k) Y(j,k).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct coper_handle;
+
+namespace coper {
+
+// two-level strided index: offset(i) = (i / seg) * s_hi + (i % seg) * s_lo   (seg == 0: i * s_lo)
+struct TgIdx {
+  int64_t seg, s_hi, s_lo;
+};
+inline TgIdx tg_idx(int64_t stride) { return TgIdx{0, 0, stride}; }
+inline TgIdx tg_idx2(int64_t seg, int64_t s_hi, int64_t s_lo) { return TgIdx{seg, s_hi, s_lo}; }
+
+// hi / lo bf16 planes in the fragment order of v_mfma_f32_32x32x16_bf16: [rows_pad / 32][KS16][64 lanes] x 16 B each
+struct TgPlanes {
+  uint4* hi = nullptr;
+  uint4* lo = nullptr;
+};
+
+constexpr int64_t TG_ROW_PAD = 128;   // rows of a plane set are padded to the GEMM's workgroup tile
+inline int64_t tg_rows_pad(int64_t rows) { return (rows + TG_ROW_PAD - 1) / TG_ROW_PAD * TG_ROW_PAD; }
+inline size_t tg_plane_elems(int64_t rows, int64_t K) { return (size_t)(tg_rows_pad(rows) / 32) * (size_t)((K + 15) / 16) * 64; }   // uint4 per plane
+
+// X(row, k) = src[off(ri, row) + off(ki, k)] -> planes (rows zero-padded to R_pad, k to a multiple of 16).
+// rows_fast: consecutive rows are contiguous in memory (the pack reads along rows), else consecutive k are.
+int tg_pack(coper_handle* h, const float* src, TgIdx ri, TgIdx ki, int64_t R, int64_t K, int64_t R_pad, bool rows_fast, TgPlanes out,
+            hipStream_t s);
+// C[off(ci, i) + off(cj, j)] = sum_k X(i, k) Y(j, k), i < M, j < N
+int tg_gemm_nt(coper_handle* h, TgPlanes X, int64_t M, TgPlanes Y, int64_t N, int64_t K, float* C, TgIdx ci, TgIdx cj, hipStream_t s);
+
+}  // namespace coper

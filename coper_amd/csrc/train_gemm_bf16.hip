@@ -1,0 +1,205 @@
+// The three GEMMs of the generated dense layer in the training step (coper_train.hip), on the bf16 matrix cores with
+// split operands -- the arithmetic of the inference path's bf16x3 mode: every fp32 operand x = hi + lo (two bf16
+// terms), every product lo*hi + hi*lo + hi*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (~2^-16 relative per
+// product; the training parity tests hold gradients to 2e-4).  gfx950's exact-f32 MFMA runs at 1/16 of the bf16 rate,
+// so three bf16 MFMAs per product are 5.3x the matrix throughput of an fp32 GEMM.
+//
+//   forward   T[rho][b][k]  = sum_f       x[b][f]      * P[rho][f][k]        (models.py:70,412 in factored form)
+//   dP        dP[rho][f][k] = sum_b       x[b][f]      * dT[rho][b][k]       dT[rho][b][k] = ctx[b][rho] dz[b][k]
+//   dx        dx[b][f]      = sum_(rho,k) dT[rho][b][k] * P[rho][f][k]       (the [B, r*F] intermediate dA = dz P2^T of the
+//                                                                             library-GEMM version is never formed)
+// Each is C(i, j) = sum_k X(i, k) Y(j, k): both operands are first packed into the fragment-major hi / lo planes of the
+// inference path (k_pack_frag: any two-level strided view of an fp32 tensor -> [row block of 32][k-step][64 lanes] x 16 B,
+// transposing through LDS so that the reads follow the contiguous dimension), then k_gemm_nt_bf16x3 streams fragments
+// straight into the registers the MFMAs consume and stores C through a two-level strided view.
+#include "coper_internal.h"
+#include "train_gemm.h"
+
+namespace coper {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define TG_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&(a), *(const bf16x8*)&(b), (c), 0, 0, 0)
+
+__device__ __forceinline__ int64_t tg_off(const TgIdx& a, int64_t i) {
+  return a.seg > 0 ? (i / a.seg) * a.s_hi + (i % a.seg) * a.s_lo : i * a.s_lo;
+}
+
+__device__ __forceinline__ void tg_split8(const float* v, uint4& hi, uint4& lo) {
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  unsigned hw[4], lw[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    bf16x2_t hp = {(__bf16)v[2 * j], (__bf16)v[2 * j + 1]};
+    float r0 = v[2 * j] - (float)hp[0], r1 = v[2 * j + 1] - (float)hp[1];
+    bf16x2_t lp = {(__bf16)r0, (__bf16)r1};
+    hw[j] = __builtin_bit_cast(unsigned, hp);
+    lw[j] = __builtin_bit_cast(unsigned, lp);
+  }
+  hi = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+  lo = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// pack: X(row, k) = src[off(ri, row) + off(ki, k)], rows [0, R), k [0, K)  ->  planes[(blk * KS16 + ks) * 64 + l] =
+// 8 bf16 { X[32 blk + (l & 31)][16 ks + 8 (l >> 5) + j] } (zero beyond R / K); grid (ceil(KS16 / 8), row blocks).
+// MODE 0: consecutive threads read consecutive k (k contiguous in memory); 1: consecutive rows; +2: four elements per
+// thread along that direction as one 16-byte load (alignment checked by the host).
+// ------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void k_pack_frag(const float* __restrict__ src, TgIdx ri, TgIdx ki, int64_t R, int64_t K,
+                                                   int KS16, uint4* __restrict__ hi, uint4* __restrict__ lo) {
+  __shared__ float tile[32][129];
+  const int64_t row0 = (int64_t)blockIdx.y * 32, k0 = (int64_t)blockIdx.x * 128;
+  const int t = threadIdx.x;
+  if (MODE == 0) {
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+      const int e = t + 256 * i, row = e >> 7, kk = e & 127;
+      const bool ok = row0 + row < R && k0 + kk < K;
+      tile[row][kk] = ok ? src[tg_off(ri, row0 + row) + tg_off(ki, k0 + kk)] : 0.f;
+    }
+  } else if (MODE == 1) {
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+      const int e = t + 256 * i, kk = e >> 5, row = e & 31;
+      const bool ok = row0 + row < R && k0 + kk < K;
+      tile[row][kk] = ok ? src[tg_off(ri, row0 + row) + tg_off(ki, k0 + kk)] : 0.f;
+    }
+  } else if (MODE == 2) {   // four consecutive k per thread
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = t + 256 * i, row = e >> 5, kk = (e & 31) * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row0 + row < R && k0 + kk < K) v = *(const float4*)(src + tg_off(ri, row0 + row) + tg_off(ki, k0 + kk));   // K % 4 == 0
+      tile[row][kk] = v.x; tile[row][kk + 1] = v.y; tile[row][kk + 2] = v.z; tile[row][kk + 3] = v.w;
+    }
+  } else {                  // four consecutive rows per thread
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = t + 256 * i, kk = e >> 3, row = (e & 7) * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row0 + row < R && k0 + kk < K) v = *(const float4*)(src + tg_off(ri, row0 + row) + tg_off(ki, k0 + kk));   // R % 4 == 0
+      tile[row][kk] = v.x; tile[row + 1][kk] = v.y; tile[row + 2][kk] = v.z; tile[row + 3][kk] = v.w;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int f = t + 256 * p, ksl = f >> 6, l = f & 63;
+    const int64_t ks = (int64_t)blockIdx.x * 8 + ksl;
+    if (ks >= KS16) continue;
+    const int row = l & 31, kb = 16 * ksl + 8 * (l >> 5);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = tile[row][kb + j];
+    uint4 h4, l4;
+    tg_split8(v, h4, l4);
+    const int64_t o = ((int64_t)blockIdx.y * KS16 + ks) * 64 + l;
+    hi[o] = h4;
+    lo[o] = l4;
+  }
+}
+
+static bool tg_vec_ok(const float* src, const TgIdx& fast, const TgIdx& slow, int64_t n_fast) {
+  // 16-byte loads along the fast index: unit stride, segments and extents in multiples of 4, every other stride too
+  if (fast.s_lo != 1 || (n_fast & 3) || ((uintptr_t)src & 15)) return false;
+  if (fast.seg > 0 && ((fast.seg & 3) || (fast.s_hi & 3))) return false;
+  if (slow.s_lo & 3) return false;
+  if (slow.seg > 0 && (slow.s_hi & 3)) return false;
+  return true;
+}
+
+int tg_pack(coper_handle* h, const float* src, TgIdx ri, TgIdx ki, int64_t R, int64_t K, int64_t R_pad, bool rows_fast, TgPlanes out,
+            hipStream_t s) {
+  const int KS16 = (int)((K + 15) / 16);
+  dim3 grid((unsigned)((KS16 + 7) / 8), (unsigned)(R_pad / 32));
+  const bool vec = rows_fast ? tg_vec_ok(src, ri, ki, R) : tg_vec_ok(src, ki, ri, K);
+  if (!rows_fast && vec) hipLaunchKernelGGL(k_pack_frag<2>, grid, dim3(256), 0, s, src, ri, ki, R, K, KS16, out.hi, out.lo);
+  else if (!rows_fast) hipLaunchKernelGGL(k_pack_frag<0>, grid, dim3(256), 0, s, src, ri, ki, R, K, KS16, out.hi, out.lo);
+  else if (vec) hipLaunchKernelGGL(k_pack_frag<3>, grid, dim3(256), 0, s, src, ri, ki, R, K, KS16, out.hi, out.lo);
+  else hipLaunchKernelGGL(k_pack_frag<1>, grid, dim3(256), 0, s, src, ri, ki, R, K, KS16, out.hi, out.lo);
+  COPER_HIP_TRY(h, hipGetLastError());
+  return COPER_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C(i, j) = sum_k X(i, k) Y(j, k).  A workgroup is 4 waves (2 x 2), a wave owns TI x TJ blocks of 32 x 32: X and Y
+// fragments come straight from the planes into registers, one k-step ahead (two register buffers); the i tiles of one
+// j tile are neighbours in the grid, so the Y fragments they share are read from HBM once.
+// Accumulator (i, j) layout of v_mfma_f32_32x32x16_bf16 with X as A and Y as B: register r of lane l is
+// i = (r & 3) + 8 (r >> 2) + 4 (l >> 5), j = l & 31 -> one register of a wave is 32 consecutive j of two rows i.
+// ------------------------------------------------------------------------------------------------
+template <int TI, int TJ>
+__global__ __launch_bounds__(256) void k_gemm_nt_bf16x3(const uint4* __restrict__ Xhi, const uint4* __restrict__ Xlo,
+                                                        const uint4* __restrict__ Yhi, const uint4* __restrict__ Ylo, int KS16,
+                                                        float* __restrict__ C, TgIdx ci, TgIdx cj, int64_t M, int64_t N) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int64_t ib0 = ((int64_t)blockIdx.x * 2 + (wave & 1)) * TI;
+  const int64_t jb0 = ((int64_t)blockIdx.y * 2 + (wave >> 1)) * TJ;
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int a = 0; a < TI; ++a)
+#pragma unroll
+    for (int b = 0; b < TJ; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  uint4 xh[2][TI], xl[2][TI], yh[2][TJ], yl[2][TJ];
+#define TG_LOAD(s_, ks_)                                                                     \
+  {                                                                                          \
+    _Pragma("unroll") for (int a = 0; a < TI; ++a) {                                         \
+      const int64_t o = ((ib0 + a) * KS16 + (ks_)) * 64 + lane;                              \
+      xh[s_][a] = Xhi[o]; xl[s_][a] = Xlo[o];                                                \
+    }                                                                                        \
+    _Pragma("unroll") for (int b = 0; b < TJ; ++b) {                                         \
+      const int64_t o = ((jb0 + b) * KS16 + (ks_)) * 64 + lane;                              \
+      yh[s_][b] = Yhi[o]; yl[s_][b] = Ylo[o];                                                \
+    }                                                                                        \
+  }
+#define TG_STEP(s_)                                                                          \
+  {                                                                                          \
+    _Pragma("unroll") for (int a = 0; a < TI; ++a) _Pragma("unroll") for (int b = 0; b < TJ; ++b) { \
+      acc[a][b] = TG_MFMA(xl[s_][a], yh[s_][b], acc[a][b]);                                  \
+      acc[a][b] = TG_MFMA(xh[s_][a], yl[s_][b], acc[a][b]);                                  \
+      acc[a][b] = TG_MFMA(xh[s_][a], yh[s_][b], acc[a][b]);                                  \
+    }                                                                                        \
+  }
+  TG_LOAD(0, 0);
+  int ks = 0;
+  for (; ks + 2 <= KS16; ks += 2) {
+    TG_LOAD(1, ks + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    TG_STEP(0);
+    const int kn = ks + 2 < KS16 ? ks + 2 : KS16 - 1;
+    TG_LOAD(0, kn);
+    __builtin_amdgcn_sched_barrier(0);
+    TG_STEP(1);
+  }
+  if (ks < KS16) TG_STEP(0);
+#undef TG_LOAD
+#undef TG_STEP
+#pragma unroll
+  for (int a = 0; a < TI; ++a)
+#pragma unroll
+    for (int b = 0; b < TJ; ++b) {
+      const int64_t j = (jb0 + b) * 32 + (lane & 31);
+      if (j >= N) continue;
+      const int64_t oj = tg_off(cj, j);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t i = (ib0 + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (i < M) C[tg_off(ci, i) + oj] = acc[a][b][r];
+      }
+    }
+}
+
+int tg_gemm_nt(coper_handle* h, TgPlanes X, int64_t M, TgPlanes Y, int64_t N, int64_t K, float* C, TgIdx ci, TgIdx cj, hipStream_t s) {
+  const int KS16 = (int)((K + 15) / 16);
+  // rows of both plane sets are padded to TG_ROW_PAD = 128: workgroup tiles of 128 x 128
+  dim3 grid((unsigned)((M + 127) / 128), (unsigned)((N + 127) / 128));
+  hipLaunchKernelGGL((k_gemm_nt_bf16x3<2, 2>), grid, dim3(256), 0, s, X.hi, X.lo, Y.hi, Y.lo, KS16, C, ci, cj, M, N);
+  COPER_HIP_TRY(h, hipGetLastError());
+  return COPER_OK;
+}
+
+}  // namespace coper

@@ -37,5 +37,7 @@ def test_bench_entity_mode_through_rccl_with_one_rank():
                           "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extras"], env=env, capture_output=True,
                          text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-4000:]
-    line = json.loads(out.stdout.strip().splitlines()[-1])
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert lines, out.stdout[-2000:] + out.stderr[-2000:]
+    line = json.loads(lines[-1])
     assert line["config"]["parallelism"].startswith("entity-sharded x1") and line["value"] > 0

@@ -121,15 +121,24 @@ def test_train_rejects_unsupported_variants_and_order():
     from coper_amd.models import ConvE
     from coper_amd._lib import CoperError
     md = dict(cdata._COMMON)
-    md.update(num_ent=50, num_rel=4, ent_emb_size=40, rel_emb_size=1, emb_h=10, emb_w=4, conv_num_channels=8,
-              context_rel_conv=[], context_rel_out=None, do_parameter_lookup=True)
+    md.update(_CASES["cpg_linear"])
+    p = cdata.synthetic_params(md, seed=1)
     m = ConvE(md, device="cuda:0")
-    m.load_parameters(cdata.synthetic_params(md, seed=1))
-    with pytest.raises(CoperError):
-        m.train_init()                      # looked-up conv filters with a static dense layer: not in this version
+    m.load_parameters(p)
     with pytest.raises(CoperError):
         m.train_step(_batch(md, 4, 5, 0))   # no train_init
     m.close()
+    sh = ConvE(md, device="cuda:0", shard=(0, 100))
+    sh.load_parameters(p)
+    with pytest.raises(CoperError, match="whole entity table"):
+        sh.train_init()                     # training needs the whole table on the handle
+    sh.close()
+    md5 = dict(md, conv_filter_height=5, conv_filter_width=3)
+    m5 = ConvE(md5, device="cuda:0")
+    m5.load_parameters(cdata.synthetic_params(md5, seed=1))
+    with pytest.raises(CoperError, match="3x3"):
+        m5.train_init()                     # the training kernels are built for the reference's 3x3 filters
+    m5.close()
 
 
 @pytest.mark.parametrize("variant", ["cpg_linear", "plain", "lookup", "cpg_mlp_bn"])
