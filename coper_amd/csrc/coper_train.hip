@@ -163,24 +163,52 @@ __global__ __launch_bounds__(256) void k_tr_conv_fwd(const int64_t* __restrict__
 
 // per-column sums of a [rows, cols] matrix in double: out[0..cols) = sum, out[cols..2cols) = sum of squares
 // (partial sums by row chunk, then atomics on doubles: order-dependent only in the last bits of a double)
+// everything the step accumulates into with atomics, zeroed by ONE launch (was a dozen memsets of ~5 us each)
+constexpr int TR_ZERO_MAX = 12;
+constexpr int TR_COLSUM_SLICES = 20;   // column-sum scratch: one slice per use within a step (see colsum_slice)
+struct ZeroList {
+  void* p[TR_ZERO_MAX];
+  size_t bytes[TR_ZERO_MAX];   // multiples of 4
+  int n;
+};
+__global__ __launch_bounds__(256) void k_tr_zero_list(ZeroList zl) {
+  const int e = blockIdx.y;
+  if (e >= zl.n) return;
+  char* base = (char*)zl.p[e];
+  const size_t bytes = zl.bytes[e];
+  const size_t head = ((16 - ((uintptr_t)base & 15)) & 15) < bytes ? ((16 - ((uintptr_t)base & 15)) & 15) : bytes;
+  const size_t n16 = (bytes - head) / 16, tail0 = head + n16 * 16;
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+  for (size_t i = t; i < n16; i += stride) ((uint4*)(base + head))[i] = make_uint4(0, 0, 0, 0);
+  for (size_t i = t * 4; i < head; i += stride * 4) *(uint32_t*)(base + i) = 0;
+  for (size_t i = tail0 + t * 4; i < bytes; i += stride * 4) *(uint32_t*)(base + i) = 0;
+}
+
 __global__ __launch_bounds__(256) void k_tr_col_sums(const float* __restrict__ m, int64_t rows, int cols, double* __restrict__ out) {
-  const int cpt = 256 / cols > 0 ? 256 / cols : 1;  // row lanes per column when cols <= 256
-  const int col = threadIdx.x % cols, rl = threadIdx.x / cols;
-  if (cols > 256 || rl >= cpt) {
-    if (cols <= 256) return;
-  }
-  double s = 0, q = 0;
+  // per-column sum and sum of squares in double; a block reduces its row lanes in LDS and issues ONE atomic pair per
+  // column (many blocks adding to the same few addresses are contention-bound: 14x slower per add)
+  __shared__ double sh[2][256];
   if (cols <= 256) {
-    for (int64_t rr = (int64_t)blockIdx.x * cpt + rl; rr < rows; rr += (int64_t)gridDim.x * cpt) {
-      const double v = m[rr * cols + col];
-      s += v;
-      q += v * v;
+    const int cpt = 256 / cols;                         // row lanes per column
+    const int col = threadIdx.x % cols, rl = threadIdx.x / cols;
+    double s = 0, q = 0;
+    if (rl < cpt)
+      for (int64_t rr = (int64_t)blockIdx.x * cpt + rl; rr < rows; rr += (int64_t)gridDim.x * cpt) {
+        const double v = m[rr * cols + col];
+        s += v;
+        q += v * v;
+      }
+    sh[0][threadIdx.x] = s;
+    sh[1][threadIdx.x] = q;
+    __syncthreads();
+    if (threadIdx.x < cols) {
+      for (int l = 1; l < cpt; ++l) { s += sh[0][threadIdx.x + l * cols]; q += sh[1][threadIdx.x + l * cols]; }
+      atomicAdd(&out[col], s);
+      atomicAdd(&out[cols + col], q);
     }
-    atomicAdd(&out[col], s);
-    atomicAdd(&out[cols + col], q);
   } else {
     for (int cc = threadIdx.x; cc < cols; cc += 256) {
-      s = 0; q = 0;
+      double s = 0, q = 0;
       for (int64_t rr = blockIdx.x; rr < rows; rr += gridDim.x) {
         const double v = m[rr * cols + cc];
         s += v;
@@ -986,7 +1014,7 @@ COPER_API int coper_train_init(coper_handle* h, const coper_train_config* cfg) {
   for (int i = 0; i < T->nh; ++i) mx = h->cfg.ctx_out[i] > mx ? h->cfg.ctx_out[i] : mx;
   for (int i = 0; i < T->nhc; ++i) mx = h->cfg.ctx_conv[i] > mx ? h->cfg.ctx_conv[i] : mx;
   if ((rc = talloc(h, &T->bnst, (size_t)4 * mx))) return rc;
-  if ((rc = talloc(h, &T->red, (size_t)(2 + 2 * mx)))) return rc;
+  if ((rc = talloc(h, &T->red, (size_t)(2 + 2 * mx * TR_COLSUM_SLICES)))) return rc;
   return COPER_OK;
 }
 
@@ -1065,29 +1093,42 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
   for (int i = 0; i < nh; ++i) mx = h->cfg.ctx_out[i] > mx ? h->cfg.ctx_out[i] : mx;
   for (int i = 0; i < nhc; ++i) mx = h->cfg.ctx_conv[i] > mx ? h->cfg.ctx_conv[i] : mx;
   float *mean1 = T->bnst, *inv1 = T->bnst + mx, *mean2 = T->bnst + 2 * mx, *inv2 = T->bnst + 3 * mx;
-  double* red = T->red;         // [0] loss, [1] sumsq, [2 .. 2+2mx) column sums
-  double* colsum = red + 2;
+  double* red = T->red;         // [0] loss, [1] sumsq, then TR_COLSUM_SLICES slices of 2 mx column sums, one per use
+  auto colsum_slice = [&](int i) { return red + 2 + (size_t)i * 2 * mx; };   // 0 Conv1BN, 1 FCBN, 2 Conv1BN backward, 3 + 4 g + i chains
+  double* colsum = colsum_slice(0);
   const uint32_t thr_h = dropout_threshold24(tc.hidden_dropout), thr_o = dropout_threshold24(tc.output_dropout);
   const float ks_h = 1.f / (1.f - tc.hidden_dropout), ks_o = 1.f / (1.f - tc.output_dropout);
   const uint32_t step = T->step;
   const float one = 1.f, zero = 0.f;
   if ((rc = rb_check(h, T->rb.set_stream(T->rb.handle, s), "rocblas_set_stream"))) return rc;
 
-  // ---- zero what is accumulated by atomics
-  COPER_HIP_TRY(h, hipMemsetAsync(red, 0, sizeof(double) * (2 + 2 * mx), s));
-  const char* zeroed[] = {"ent_emb", "rel_emb", "conv1_weights", "conv1_bias", "pred_bias"};
-  for (const char* nm : zeroed)
-    if (T->find(nm)) COPER_HIP_TRY(h, hipMemsetAsync(G_(nm), 0, sizeof(float) * T->find(nm)->n, s));
+  // ---- zero what is accumulated by atomics: one launch
+  const bool dense_scorer_bwd = (double)B * (double)dm.E * 4.0 <= 512.0 * 1024 * 1024 && dm.E <= 0x7fffffff;
+  if (!one_vs_all && dense_scorer_bwd && B * dm.E > T->capS) {
+    COPER_HIP_TRY(h, hipStreamSynchronize(s));
+    if ((rc = talloc(h, &T->Sd, (size_t)(B * dm.E)))) return rc;
+    T->capS = B * dm.E;
+  }
+  const std::string wlast = "fc_weights/CPG/Projection" + std::to_string(nh), blast = "fc_bias/CPG/Projection" + std::to_string(nh);
+  {
+    ZeroList zl;
+    zl.n = 0;
+    auto add = [&](void* p, size_t bytes) { if (p && bytes && zl.n < TR_ZERO_MAX) { zl.p[zl.n] = p; zl.bytes[zl.n] = bytes; ++zl.n; } };
+    add(red, sizeof(double) * (2 + (size_t)2 * mx * TR_COLSUM_SLICES));
+    for (const char* nm : {"ent_emb", "rel_emb", "conv1_weights", "conv1_bias", "pred_bias"})
+      if (T->find(nm)) add(G_(nm), sizeof(float) * T->find(nm)->n);
+    if (lk) add(G_("fc_bias"), sizeof(float) * T->find("fc_bias")->n);
+    else if (gen) add(G_(blast.c_str()), sizeof(float) * rc_b * d);
+    else add(G_("fc_bias"), sizeof(float) * d);
+    if (!one_vs_all && dense_scorer_bwd) add(T->Sd, sizeof(float) * B * dm.E);
+    hipLaunchKernelGGL(k_tr_zero_list, dim3(256, (unsigned)zl.n), dim3(256), 0, s, zl);
+  }
   if (lk) {
     // group the batch by relation (perm / rel_offset / rel_count of the inference path): the table gradient is
     // written per present relation, never zero-filled (1.75 GB at FB15k-237 shapes)
     if ((rc = coper_reserve(h, B, 0, stream))) return rc;
     if ((rc = launch_group_by_relation(h, e1, rel, false, B, 32, s))) return rc;
-    COPER_HIP_TRY(h, hipMemsetAsync(G_("fc_bias"), 0, sizeof(float) * T->find("fc_bias")->n, s));
   }
-  const std::string wlast = "fc_weights/CPG/Projection" + std::to_string(nh), blast = "fc_bias/CPG/Projection" + std::to_string(nh);
-  if (gen) COPER_HIP_TRY(h, hipMemsetAsync(G_(blast.c_str()), 0, sizeof(float) * rc_b * d, s));
-  else if (!lk) COPER_HIP_TRY(h, hipMemsetAsync(G_("fc_bias"), 0, sizeof(float) * d, s));
 
   // ---- forward
   const uint32_t thr_c = dropout_threshold24(tc.context_rel_dropout);
@@ -1103,9 +1144,9 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
       hipLaunchKernelGGL(k_tr_small_mm, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, ch.v[i], P_(pn.c_str()), B, ni, nj, ch.u[i]);
       const float *ga = nullptr, *be = nullptr;
       if (dm.ctx_bn) {
-        COPER_HIP_TRY(h, hipMemsetAsync(colsum, 0, sizeof(double) * 2 * mx, s));
-        if (use_batch) hipLaunchKernelGGL(k_tr_col_sums, dim3(16), dim3(256), 0, s, ch.u[i], B, nj, colsum);
-        hipLaunchKernelGGL(k_tr_bn_finish, dim3((nj + 63) / 64), dim3(64), 0, s, colsum, nj, (double)B, use_batch, tc.batch_norm_momentum, 0,
+        double* cs = colsum_slice(3 + 4 * g + i);
+        if (use_batch) hipLaunchKernelGGL(k_tr_col_sums, dim3(64), dim3(256), 0, s, ch.u[i], B, nj, cs);
+        hipLaunchKernelGGL(k_tr_bn_finish, dim3((nj + 63) / 64), dim3(64), 0, s, cs, nj, (double)B, use_batch, tc.batch_norm_momentum, 0,
                            const_cast<float*>(h->params[pn + "/BatchNorm/moving_mean"].ptr),
                            const_cast<float*>(h->params[pn + "/BatchNorm/moving_variance"].ptr), ch.st[i], ch.st[i] + nj);
         ga = P_((pn + "/BatchNorm/gamma").c_str());
@@ -1138,8 +1179,7 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
                      dm.gen_conv ? nullptr : P_("conv1_bias"), dm.E, dm.R, d, r, dm.in_h, dm.in_w, dm.stacked ? 1 : 0, C, dm.Ho, dm.Wo, T->img,
                      ((gen || cat) && !genc) ? T->c : nullptr, T->y, K_ps, kb_ps);
   const int64_t nBF = B * Fc;
-  if (genc) COPER_HIP_TRY(h, hipMemsetAsync(colsum, 0, sizeof(double) * 2 * mx, s));   // the conv generators' BN used the scratch
-  if (use_batch) hipLaunchKernelGGL(k_tr_col_sums, dim3(128), dim3(256), 0, s, T->y, B * (int64_t)P, C, colsum);
+  if (use_batch) hipLaunchKernelGGL(k_tr_col_sums, dim3(256), dim3(256), 0, s, T->y, B * (int64_t)P, C, colsum);
   hipLaunchKernelGGL(k_tr_bn_finish, dim3((C + 63) / 64), dim3(64), 0, s, colsum, C, (double)B * P, use_batch,
                      tc.batch_norm_momentum, 1, const_cast<float*>(h->params["Conv1BN/moving_mean"].ptr),
                      const_cast<float*>(h->params["Conv1BN/moving_variance"].ptr), mean1, inv1);
@@ -1180,9 +1220,8 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
     hipLaunchKernelGGL(k_tr_fc_post, dim3((unsigned)((nBd + 255) / 256)), dim3(256), 0, s, gen ? Tf : T->z0, gen ? nullptr : P_("fc_bias"),
                        cw, rc_w, cbv, gen ? P_(blast.c_str()) : nullptr, rc_b, d, nBd, tc.seed, step, thr_o, ks_o, T->z1);
   }
-  COPER_HIP_TRY(h, hipMemsetAsync(colsum, 0, sizeof(double) * 2 * mx, s));
-  if (use_batch) hipLaunchKernelGGL(k_tr_col_sums, dim3(16), dim3(256), 0, s, T->z1, B, d, colsum);
-  hipLaunchKernelGGL(k_tr_bn_finish, dim3((d + 63) / 64), dim3(64), 0, s, colsum, d, (double)B, use_batch, tc.batch_norm_momentum, 0,
+  if (use_batch) hipLaunchKernelGGL(k_tr_col_sums, dim3(64), dim3(256), 0, s, T->z1, B, d, colsum_slice(1));
+  hipLaunchKernelGGL(k_tr_bn_finish, dim3((d + 63) / 64), dim3(64), 0, s, colsum_slice(1), d, (double)B, use_batch, tc.batch_norm_momentum, 0,
                      const_cast<float*>(h->params["FCBN/moving_mean"].ptr), const_cast<float*>(h->params["FCBN/moving_variance"].ptr),
                      mean2, inv2);
   hipLaunchKernelGGL(k_tr_fcbn_fwd, dim3((unsigned)((nBd + 255) / 256)), dim3(256), 0, s, T->z1, mean2, inv2, P_("FCBN/gamma"),
@@ -1207,7 +1246,6 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
   if (loss_out) hipLaunchKernelGGL(k_tr_store_loss, dim3(1), dim3(1), 0, s, red, 1.0 / ((double)B * (double)L), loss_out);
 
   // ---- backward
-  const bool dense_scorer_bwd = (double)B * (double)dm.E * 4.0 <= 512.0 * 1024 * 1024 && dm.E <= 0x7fffffff;
   if (one_vs_all) {
     hipLaunchKernelGGL(k_tr_col_sum_f32, dim3((unsigned)((dm.E + 255) / 256)), dim3(256), 0, s, T->Sd, B, dm.E, G_("pred_bias"));
     if ((rc = rb_check(h, T->rb.sgemm(T->rb.handle, RB_N, RB_T, d, (int)dm.E, (int)B, &one, T->hv, d, T->Sd, (int)dm.E, &zero, G_("ent_emb"), d),
@@ -1217,12 +1255,6 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
     if ((rc = rb_check(h, T->rb.sgemm(T->rb.handle, RB_N, RB_N, d, (int)B, (int)dm.E, &one, ent, d, T->Sd, (int)dm.E, &zero, T->dh, d), "sgemm dh")))
       return rc;
   } else if (dense_scorer_bwd) {
-    if (B * dm.E > T->capS) {
-      COPER_HIP_TRY(h, hipStreamSynchronize(s));
-      if ((rc = talloc(h, &T->Sd, (size_t)(B * dm.E)))) return rc;
-      T->capS = B * dm.E;
-    }
-    COPER_HIP_TRY(h, hipMemsetAsync(T->Sd, 0, sizeof(float) * B * dm.E, s));
     hipLaunchKernelGGL(k_tr_scatter_ds, dim3((unsigned)((B * L + 255) / 256)), dim3(256), 0, s, lookup, T->ds, dm.E, L, B * L, T->Sd,
                        G_("pred_bias"));
     // dE[E,d] = S^T h  (overwrites the zeroed gradient; the e1-row contributions are added after it)
@@ -1299,7 +1331,7 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
     }
   };
   if (gen) { chain_backward(0, nh); chain_backward(1, nh); }
-  COPER_HIP_TRY(h, hipMemsetAsync(colsum, 0, sizeof(double) * 2 * mx, s));
+  colsum = colsum_slice(2);
   hipLaunchKernelGGL(k_tr_bn1_bwd_sums, dim3((unsigned)((nBF + 255) / 256 < 1024 ? (nBF + 255) / 256 : 1024)), dim3(256), 0, s, T->dx, T->y, mean1, inv1, P_("Conv1BN/gamma"),
                      P_("Conv1BN/beta"), C, nBF, tc.seed, step, thr_h, ks_h, colsum);
   hipLaunchKernelGGL(k_tr_bn1_bwd_apply, dim3((unsigned)((nBF + 255) / 256)), dim3(256), 0, s, T->dx, T->y, mean1, inv1, P_("Conv1BN/gamma"),

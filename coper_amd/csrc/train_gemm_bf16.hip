@@ -125,8 +125,11 @@ int tg_pack(coper_handle* h, const float* src, TgIdx ri, TgIdx ki, int64_t R, in
 
 // ------------------------------------------------------------------------------------------------
 // C(i, j) = sum_k X(i, k) Y(j, k).  A workgroup is 4 waves (2 x 2), a wave owns TI x TJ blocks of 32 x 32: X and Y
-// fragments come straight from the planes into registers, one k-step ahead (two register buffers); the i tiles of one
+// fragments come straight from the planes into registers, two k-steps ahead (three register buffers); the i tiles of one
 // j tile are neighbours in the grid, so the Y fragments they share are read from HBM once.
+// Measured (MI355X, 30 GFLOP shapes of the FB15k-237 step): 140-145 us per GEMM -- bound by the CU's L2 -> L1 fill rate
+// (~33 B/clk per CU for 683 B of fragments per MFMA); staging a k-step's 16 fragments in LDS by LDS-DMA (half the fill
+// traffic, one barrier per 12-MFMA k-step) measured 245 us: the barrier per k-step costs more than the duplicates.
 // Accumulator (i, j) layout of v_mfma_f32_32x32x16_bf16 with X as A and Y as B: register r of lane l is
 // i = (r & 3) + 8 (r >> 2) + 4 (l >> 5), j = l & 31 -> one register of a wave is 32 consecutive j of two rows i.
 // ------------------------------------------------------------------------------------------------
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt_bf16x3(const uint4* __restrict_
     for (int b = 0; b < TJ; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-  uint4 xh[2][TI], xl[2][TI], yh[2][TJ], yl[2][TJ];
+  uint4 xh[3][TI], xl[3][TI], yh[3][TJ], yl[3][TJ];
 #define TG_LOAD(s_, ks_)                                                                     \
   {                                                                                          \
     _Pragma("unroll") for (int a = 0; a < TI; ++a) {                                         \
@@ -164,18 +167,26 @@ __global__ __launch_bounds__(256) void k_gemm_nt_bf16x3(const uint4* __restrict_
       acc[a][b] = TG_MFMA(xh[s_][a], yh[s_][b], acc[a][b]);                                  \
     }                                                                                        \
   }
+  // three register buffers, fragments fetched two k-steps ahead (a k-step is 12 MFMAs per wave: shorter than an L2 round
+  // trip); no conditional code around a step or its prefetch (a prefetch past the end re-reads the last k-step)
+#define TG_KCL(k_) ((k_) < KS16 ? (k_) : KS16 - 1)
   TG_LOAD(0, 0);
+  TG_LOAD(1, TG_KCL(1));
   int ks = 0;
-  for (; ks + 2 <= KS16; ks += 2) {
-    TG_LOAD(1, ks + 1);
+  for (; ks + 3 <= KS16; ks += 3) {
+    TG_LOAD(2, TG_KCL(ks + 2));
     __builtin_amdgcn_sched_barrier(0);
     TG_STEP(0);
-    const int kn = ks + 2 < KS16 ? ks + 2 : KS16 - 1;
-    TG_LOAD(0, kn);
+    TG_LOAD(0, TG_KCL(ks + 3));
     __builtin_amdgcn_sched_barrier(0);
     TG_STEP(1);
+    TG_LOAD(1, TG_KCL(ks + 4));
+    __builtin_amdgcn_sched_barrier(0);
+    TG_STEP(2);
   }
   if (ks < KS16) TG_STEP(0);
+  if (ks + 1 < KS16) TG_STEP(1);
+#undef TG_KCL
 #undef TG_LOAD
 #undef TG_STEP
 #pragma unroll
