@@ -50,13 +50,19 @@ SCALE_WORKLOAD, SCALE_TOPK, HBM_REGIME_QUERIES = "synth10m_cpg", 10, 128
 SCALE_EXPECTED = {"ranks_sha1": "046ac4218504f24ad31fe32c9fd8230332f1b1ee", "mean_rank": 4908458.672607422}
 
 
-def _profile_entry(pattern, workload, Q, kernel):
-    """(value dict, path) from the newest committed rocprofv3 PMC summary (profiles/) of this workload, or (None, None)."""
+def _profile_entry(pattern, workload, Q, kernel, exact=None):
+    """(value dict, path) from the newest committed rocprofv3 PMC summary (profiles/), or (None, None): a summary of this
+    workload holding the kernel, or -- `exact`: a template instantiation that only one shape launches (the 10M-entity
+    blocks of the default command) -- any summary holding exactly that instantiation."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
         try:
             d = json.load(open(path))
         except Exception:
+            continue
+        if exact:
+            if exact in d.get("kernels", {}):
+                return d["kernels"][exact], os.path.relpath(path, ROOT)
             continue
         if d.get("workload") != workload or d.get("queries") != Q:
             continue
@@ -66,17 +72,17 @@ def _profile_entry(pattern, workload, Q, kernel):
     return None, None
 
 
-def pmc_traffic(entry, workload, Q, kernel):
+def pmc_traffic(entry, workload, Q, kernel, exact=None):
     """HBM bytes per launch of `kernel`: NOT measured in this run -- replayed from the committed PMC summary of the
     same command (separate --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied); provenance recorded."""
-    v, path = _profile_entry("*pmc_traffic*.json", workload, Q, kernel)
+    v, path = _profile_entry("*pmc_traffic*.json", workload, Q, kernel, exact)
     entry["traffic"] = v["hbm_bytes_per_launch"] if v else None
     if v:
         entry["traffic_source"] = "%s (rocprofv3 --pmc passes of this command, committed; not collected in this run)" % path
 
 
-def pmc_mfma_busy(entry, workload, Q, kernel):
-    v, path = _profile_entry("*pmc_mfma_busy*.json", workload, Q, kernel)
+def pmc_mfma_busy(entry, workload, Q, kernel, exact=None):
+    v, path = _profile_entry("*pmc_mfma_busy*.json", workload, Q, kernel, exact)
     if v:
         entry["pmc"] = {"mfma_busy_frac": v["mfma_busy_frac"], "effective_clock_ghz": v["effective_clock_ghz"],
                         "source": "%s (SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE; committed, not collected in this run)" % path}
@@ -201,7 +207,14 @@ def event_times(ctx, step, steps):
     return [a.elapsed_time(b) for a, b in ev]
 
 
-def score_roofline(ctx, kname, mode, Q, n_local, d, t_ms, workload, want_pmc=True):
+def score_kernel_name(mode, d):
+    """The count kernel that serves this shape: the software-pipelined form is instantiated for 13 and 16 k-steps of 16."""
+    if mode == "f32":
+        return "k_score_count_f32"
+    return "k_score_count2_bf16x3" if (d + 15) // 16 in (13, 16) else "k_score_count_bf16x3"
+
+
+def score_roofline(ctx, kname, mode, Q, n_local, d, t_ms, workload, want_pmc=True, exact=None):
     """The score kernel against the lower of its two roofs at this shape.  ALGORITHMIC figures (fused
     rank): flops = 2 Q n d; bytes = the entity table once (fp32 rows or two bf16 planes: 4 B per value) + pred_bias
     + h in + counters out."""
@@ -220,9 +233,8 @@ def score_roofline(ctx, kname, mode, Q, n_local, d, t_ms, workload, want_pmc=Tru
             e["note"] = "3 hardware bf16 MFMAs per algorithmic product: hardware MFMA utilisation = 3 x frac"
     e["shape"] = "Q=%d x n=%d x d=%d" % (Q, n_local, d)
     if ctx.world == 1 and want_pmc:
-        pmc_traffic(e, workload, Q, "coper::" + kname)
-        if e["bound"] == "mfma":
-            pmc_mfma_busy(e, workload, Q, "coper::" + kname)
+        pmc_traffic(e, workload, Q, "coper::" + kname, exact)
+        pmc_mfma_busy(e, workload, Q, "coper::" + kname, exact)
     else:
         e["traffic"] = None
     return e
@@ -267,8 +279,9 @@ def run_scale_blocks(ctx, args):
     ms, n = model.profile_read("score_count")
     model.profile(False)
     if n:
-        out["hbm_regime"] = score_roofline(ctx, "k_score_count_bf16x3", "bf16x3", HBM_REGIME_QUERIES, model.n_local, d, ms / n,
-                                           SCALE_WORKLOAD)
+        out["hbm_regime"] = score_roofline(ctx, score_kernel_name("bf16x3", d), "bf16x3", HBM_REGIME_QUERIES, model.n_local, d, ms / n,
+                                           SCALE_WORKLOAD, exact="coper::k_score_count2_bf16x3<16, 6, true, false>")
+        out["hbm_regime"]["kernel"] = score_kernel_name("bf16x3", d)
     # (2) the entity-sharded pass, top-10 exchanged
     Q = cdata.CONFIGS[SCALE_WORKLOAD]["queries"]
     step, q = make_step(Q, SCALE_TOPK)
@@ -292,8 +305,9 @@ def run_scale_blocks(ctx, args):
            "mean_rank": float(np.mean(ranks)), "mrr": float(np.mean(1.0 / ranks)), "ranks_sha1": sha,
            "top1_id_sum": int(res[3][:, 0].sum().item())}
     if n:
-        blk["roofline"] = dict(kernel="k_score_count_bf16x3", **score_roofline(ctx, "k_score_count_bf16x3", "bf16x3", Q, model.n_local, d,
-                                                                                  ms / n, SCALE_WORKLOAD, want_pmc=ctx.world == 1))
+        kn = score_kernel_name("bf16x3", d)
+        blk["roofline"] = dict(kernel=kn, **score_roofline(ctx, kn, "bf16x3", Q, model.n_local, d, ms / n, SCALE_WORKLOAD,
+                                                           want_pmc=ctx.world == 1, exact="coper::k_score_count2_bf16x3<16, 6, true, true>"))
     exp = SCALE_EXPECTED
     if exp.get("ranks_sha1"):
         blk["ranks_independent_of_world"] = bool(sha == exp["ranks_sha1"])
@@ -475,7 +489,7 @@ def main():
         F = dm["F"]
         kinfo = {}
         if kern["score_count"]:
-            kname = "k_score_count_f32" if args.score_mode == "f32" else "k_score_count_bf16x3"
+            kname = score_kernel_name(args.score_mode, d)
             kinfo[kname] = score_roofline(ctx, kname, args.score_mode, Q, n_local, d, kern["score_count"], args.workload)
         if kern["dense"]:
             fl = 2.0 * Q * F * d                 # ALGORITHMIC flops of the dense launch pair (small + big tiles)
@@ -514,7 +528,7 @@ def main():
             out["roofline"]["tail_frac"] = 1.0 - sum(v["avg_launch_ms"] for v in kinfo.values()) / (dt / args.steps * 1e3)
         if scale:
             if "hbm_regime" in scale and "roofline" in out:
-                out["roofline"]["all_kernels"]["k_score_count_bf16x3@hbm"] = scale["hbm_regime"]
+                out["roofline"]["all_kernels"]["%s@hbm" % scale["hbm_regime"].get("kernel", "k_score_count_bf16x3")] = scale["hbm_regime"]
             out["scale"] = scale["scale"]
         if not args.no_cpu_baseline and world == 1 and not big:
             host_p = {k: (v.cpu().numpy() if hasattr(v, "cpu") else v) for k, v in cdata.synthetic_params(md, 0).items()}

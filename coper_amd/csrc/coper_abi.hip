@@ -99,8 +99,15 @@ static int ensure_workspace(coper_handle* h, int64_t B, int64_t nnz, hipStream_t
   int64_t cap = B < 64 ? 64 : B;
   int rc;
   const int KSPLIT_MAX = 8;
-  if ((rc = dev_alloc(h, &h->rel_count, 2 * (dm.R + 2)))) return rc;  // counts | cursors: one memset
-  h->rel_cursor = h->rel_count + (dm.R + 2);
+  // counts (two buffers, ping-pong: see launch_group_by_relation) | cursors | ticket; zeroed once here, kept zero by the kernels
+  dev_free(&h->rel_count_buf[0]);
+  if ((rc = dev_alloc(h, &h->rel_count_buf[0], 3 * (dm.R + 2) + 4))) return rc;
+  COPER_HIP_TRY(h, hipMemsetAsync(h->rel_count_buf[0], 0, sizeof(int32_t) * (3 * (dm.R + 2) + 4), s));
+  h->rel_count_buf[1] = h->rel_count_buf[0] + (dm.R + 2);
+  h->rel_cursor = h->rel_count_buf[0] + 2 * (dm.R + 2);
+  h->group_done = h->rel_count_buf[0] + 3 * (dm.R + 2);
+  h->rel_count_cur = 0;
+  h->rel_count = h->rel_count_buf[0];
   if ((rc = dev_alloc(h, &h->rel_offset, dm.R + 2))) return rc;
   if ((rc = dev_alloc(h, &h->perm, cap))) return rc;
   if ((rc = dev_alloc(h, &h->inv_perm, cap))) return rc;
@@ -236,7 +243,7 @@ COPER_API void coper_destroy(coper_handle* h) {
   dev_free(&h->conv_scale); dev_free(&h->conv_shift); dev_free(&h->fc_scale); dev_free(&h->fc_shift);
   dev_free(&h->conv_w_rel); dev_free(&h->conv_b_rel); dev_free(&h->fc_b_rel); dev_free(&h->Wf);
   dev_free(&h->Ef); dev_free(&h->bias_pad); dev_free(&h->ctx_tmp[0]); dev_free(&h->ctx_tmp[1]);
-  dev_free(&h->rel_count); dev_free(&h->rel_offset); h->rel_cursor = nullptr; dev_free(&h->perm); dev_free(&h->inv_perm); dev_free(&h->sorted_row); dev_free(&h->sorted_rid);
+  dev_free(&h->rel_count_buf[0]); h->rel_count = nullptr; h->rel_count_buf[1] = nullptr; h->group_done = nullptr; dev_free(&h->rel_offset); h->rel_cursor = nullptr; dev_free(&h->perm); dev_free(&h->inv_perm); dev_free(&h->sorted_row); dev_free(&h->sorted_rid);
   dev_free(&h->tiles); dev_free(&h->n_tiles); dev_free(&h->blk_off); dev_free(&h->x_sorted); dev_free(&h->z_part);
   dev_free(&h->tgt_ws); dev_free(&h->h_ws); dev_free(&h->cnt_ws); dev_free(&h->hfrag_ws); dev_free(&h->logits_ws); dev_free(&h->row_of_ws);
   dev_free(&h->gmax_ws); dev_free(&h->cand_blk_ws); dev_free(&h->cand_val_ws); dev_free(&h->cand_q_ws); dev_free(&h->cand_tau_ws); dev_free(&h->cand_sorted_ws); dev_free(&h->blk_cnt_ws); dev_free(&h->blk_off_ws);

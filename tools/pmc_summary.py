@@ -23,6 +23,34 @@ def counter_means(d, counter):
     return {k: acc[k] / n[k] for k in acc}
 
 
+def busy_summary(out):
+    """Matrix-pipe busy fraction and effective clock per kernel from the SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE pass
+    (MI355X_MICROARCH.md: the first is summed over the 1024 SIMDs, the second over the 8 XCDs)."""
+    d = os.path.join(out, "pmc_BUSY")
+    acc = defaultdict(lambda: defaultdict(list))
+    dur = defaultdict(list)
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            name = r["Kernel_Name"].split("(")[0].replace("void ", "").strip()
+            acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            name = r["Kernel_Name"].split("(")[0].replace("void ", "").strip()
+            dur[name].append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3)
+    kernels = {}
+    for name, c in acc.items():
+        if "SQ_VALU_MFMA_BUSY_CYCLES" not in c or "GRBM_GUI_ACTIVE" not in c or not dur.get(name):
+            continue
+        mf = sum(c["SQ_VALU_MFMA_BUSY_CYCLES"]) / len(c["SQ_VALU_MFMA_BUSY_CYCLES"])
+        gui = sum(c["GRBM_GUI_ACTIVE"]) / len(c["GRBM_GUI_ACTIVE"])
+        us = sum(dur[name]) / len(dur[name])
+        if mf <= 0 or gui <= 0:
+            continue
+        kernels[name] = {"mfma_busy_cycles": mf, "gui_active": gui, "avg_us_under_pmc": us, "launches": len(dur[name]),
+                         "mfma_busy_frac": (mf / 1024.0) / (gui / 8.0), "effective_clock_ghz": (gui / 8.0) / (us * 1e3)}
+    return kernels
+
+
 def main(out):
     fetch = counter_means(os.path.join(out, "pmc_FETCH_SIZE"), "FETCH_SIZE")
     write = counter_means(os.path.join(out, "pmc_WRITE_SIZE"), "WRITE_SIZE")
@@ -48,6 +76,16 @@ def main(out):
         doc["score_mode"] = line["config"]["score_mode"].split(" ")[0]
         doc["bench_line"] = line
     json.dump(doc, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
+    busy = busy_summary(out)
+    if busy:
+        bdoc = {"workload": doc.get("workload"), "queries": doc.get("queries"),
+                "command": "tools/collect_profiles.sh (rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- python3 bench.py "
+                           "--steps 10 --warmup 2 --no-cpu-baseline)",
+                "note": "SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs (MI355X_MICROARCH.md): busy "
+                        "fraction = (MFMA/1024)/(GUI/8); effective clock = (GUI/8)/duration (reads high on dispatches under ~0.3 ms; the "
+                        "in-kernel clock of the score kernel is measured with s_memtime stamps in a diagnostic build, DESIGN.md)",
+                "kernels": busy}
+        json.dump(bdoc, open(os.path.join(out, "pmc_mfma_busy.json"), "w"), indent=1)
     st = glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True)
     if st:
         shutil.copy(st[0], os.path.join(out, "kernel_stats.csv"))
