@@ -21,9 +21,27 @@ int hip_fail(coper_handle* h, hipError_t e, const char* what) {
   return fail(h, COPER_EHIP, msg);
 }
 
+// Event pairs come from a pool (creating events costs tens of microseconds of host time per launch: inside bench.py's
+// timed region that alone was 10 % of a pass) and carry no system-scope release (device-side timestamps only).
+static hipEvent_t timer_event(coper_handle* h) {
+  if (!h->event_pool.empty()) {
+    hipEvent_t e = h->event_pool.back();
+    h->event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  if (hipEventCreateWithFlags(&e, hipEventReleaseToDevice) != hipSuccess) {
+    (void)hipGetLastError();
+    if (hipEventCreate(&e) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  }
+  return e;
+}
+
 ScopedKernelTimer::ScopedKernelTimer(coper_handle* h_, const char* n, hipStream_t s_) : h(h_), name(n), s(s_) {
   if (!h->profile) return;
-  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { e0 = e1 = nullptr; return; }
+  e0 = timer_event(h);
+  e1 = timer_event(h);
+  if (!e0 || !e1) { e0 = e1 = nullptr; return; }
   (void)hipEventRecord(e0, s);
 }
 
@@ -252,6 +270,7 @@ COPER_API void coper_destroy(coper_handle* h) {
   dev_free((char**)&h->Erm16_hi); dev_free((char**)&h->Erm16_lo); dev_free((char**)&h->hrm16_hi); dev_free((char**)&h->hrm16_lo);
   for (auto& kv : h->timers)
     for (auto& p : kv.second.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+  for (auto e : h->event_pool) (void)hipEventDestroy(e);
   delete h;
 }
 
@@ -732,8 +751,8 @@ COPER_API int coper_profile_read(coper_handle* h, const char* kernel, double* to
     COPER_HIP_TRY(h, hipEventElapsedTime(&ms, p.first, p.second));
     t.total_ms += ms;
     t.launches += 1;
-    (void)hipEventDestroy(p.first);
-    (void)hipEventDestroy(p.second);
+    h->event_pool.push_back(p.first);
+    h->event_pool.push_back(p.second);
   }
   t.pending.clear();
   if (total_ms) *total_ms = t.total_ms;

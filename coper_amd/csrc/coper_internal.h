@@ -145,6 +145,7 @@ struct coper_handle {
 
   bool profile = false;
   std::map<std::string, coper::Timer> timers;
+  std::vector<hipEvent_t> event_pool;   // recycled by coper_profile_read
 };
 
 namespace coper {
