@@ -707,6 +707,19 @@ COPER_API int coper_encode_rank(coper_handle* h, const int64_t* e1, const int64_
   // bf16x3: the finalize writes h straight into the planes the rank kernels read and presets the counters, which
   // accumulate into `ranks` from 1: no fp32 h round trip, no pack, zero or finish launch
   if ((rc = encode_partials(h, e1, rel, B, e1_rows, s, &ksplit, nullptr))) return rc;
+  if (!n_equal && tail_fused_supported(h)) {
+    // ranks only (what the reference computes): finalize, targets and the filter correction in ONE launch
+    // (kernels_tail_bf16.hip) that leaves ranks = 1 - (known answers above the target); the count kernel adds to it
+    if ((rc = launch_finalize_targets_filter_bf16x3(h, B, ksplit, h_out, e2, filt_indptr, filt_idx, h->tgt_ws, ranks, s))) return rc;
+    h->packed_hvec = h->tgt_ws;
+    h->packed_B = B;
+    h->counts_preset = ranks;
+    h->count_base = 1;
+    rc = launch_score_count_bf16x3(h, h->tgt_ws, h->tgt_ws, B, ranks, nullptr, s);
+    h->count_base = 0;
+    h->counts_preset = nullptr;
+    return rc;
+  }
   if ((rc = launch_dense_finalize_pack(h, B, ksplit, h_out, ranks, 1, n_equal, s))) return rc;
   if (!n_equal) h->expand_indptr = filt_indptr;
   rc = launch_pair_targets_packed_bf16x3(h, e2, B, h->tgt_ws, s);

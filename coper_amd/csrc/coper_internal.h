@@ -224,6 +224,10 @@ inline size_t topk_sorted_cap(int64_t n_eblk, int64_t T) { return (size_t)((T + 
 void score_count_begin_bf16x3(coper_handle* h, int64_t B, int32_t* ng, int32_t* ne, hipStream_t s);
 int score_count_chunk_bf16x3(coper_handle* h, int64_t q0, int64_t Bc, const float* tgt, int32_t* ng, int32_t* ne, float* gmax,
                              int64_t gm_stride, hipStream_t s);
+// kernels_tail_bf16.hip: finalize + targets + filter correction of a ranking pass in one launch
+bool tail_fused_supported(const coper_handle* h);
+int launch_finalize_targets_filter_bf16x3(coper_handle* h, int64_t B, int ksplit, float* h_out, const int64_t* e2, const int64_t* indptr,
+                                          const int64_t* idx, float* tgt, int32_t* ranks, hipStream_t s);
 // kernels_score2_bf16.hip: the software-pipelined one-wave-per-SIMD form of the same pass
 bool score_count2_supported(const coper_handle* h);
 int score_count2_chunk_bf16x3(coper_handle* h, int64_t q0, int64_t Bc, const float* tgt, int32_t* ng, int32_t* ne, float* gmax,

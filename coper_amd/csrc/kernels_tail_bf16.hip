@@ -1,0 +1,224 @@
+// k_finalize_targets_filter_bf16x3 -- everything of a ranking pass between the dense layer and the count kernel, and the
+// sparse filter correction that used to follow it, in ONE launch (coper_encode_rank, bf16x3, ranks only).
+//
+// Before: k_dense_finalize_pack_q (h -> bf16 planes, 22 us) -> k_pair_bf16x3 mode 0 (targets, 15 us) -> count ->
+// k_pair_bf16x3 mode 2 (filter correction, 22 us): three small launches and their gaps were 12 % of an FB15k-237-shaped
+// pass.  Now one workgroup (4 waves) owns a block of 32 queries from the K-slice partial sums to their final rank offsets
+// (the waves split the finalize by k-step, exchange the fragments through LDS, and deal the filter tiles among themselves):
+//   1. finalize: sum the K slices in slice order + dense bias + folded FCBN + ReLU (the arithmetic of
+//      k_dense_finalize_pack_q, bit for bit), split into hi / lo bf16.  Lane l computes piece (k-step ks, half l >> 5) of
+//      query l & 31 -- which IS lane l's part of the block's B-operand fragment of k-step ks: the KS fragments stay in the
+//      wave's registers and are written once to the fragment planes the count kernel reads.
+//   2. targets: logit(q_i, e2[q_i]) = the diagonal of the 32 x 32 tile whose A rows are the gathered entity rows of e2 and
+//      whose B operand are those fragments -- the MFMA sequence of every other bf16x3 kernel, so the same bits.
+//   3. filter correction: the CSR entries of these 32 queries are contiguous; 32 entries at a time their entity rows are
+//      the A rows, the tile against the SAME resident B fragments holds logit(f_i, q_j) for every local query j, and
+//      entry i reads column j = its own query (one cross-lane read per accumulator register).  What the count kernel will
+//      count for a known answer (logit > target) is subtracted in advance: ranks[q] = 1 - #(such entries); the count kernel
+//      then adds to it.  No atomics: the wave owns every entry of its queries (the reference: pred[e2_multi == 1] = -inf;
+//      pred[e2] = target, metrics.py:45-46).
+#include "coper_internal.h"
+#include "conv_fold.h"
+
+namespace coper {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define TL_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&(a), *(const bf16x8*)&(b), (c), 0, 0, 0)
+
+// one 32 x 32 tile: A rows = entity rows erow[i] (gathered from the row-major twins; erow < 0: a zero row is not needed,
+// its result is discarded), B = the resident query fragments; accumulators start from pred_bias of the row
+template <int KS>
+__device__ __forceinline__ f32x16 tail_tile(const uint4* __restrict__ Ehi, const uint4* __restrict__ Elo, const float* __restrict__ bias_pad,
+                                            const int64_t* s_e, const int64_t my_erow, const uint4 (&bh)[KS], const uint4 (&bl)[KS],
+                                            const int half) {
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int64_t er = s_e[(r & 3) + 8 * (r >> 2) + 4 * half];
+    acc[r] = er >= 0 ? bias_pad[er] : 0.f;
+  }
+  const int64_t ea = my_erow >= 0 ? my_erow : 0;
+  const uint4* pa_h = Ehi + ea * (2 * KS) + half;
+  const uint4* pa_l = Elo + ea * (2 * KS) + half;
+  constexpr int PB = KS;  // every gathered 16-byte load of the tile in flight at once: a wave is alone on its SIMD (one
+                          // latency per tile instead of one per batch of k-steps)
+#pragma unroll
+  for (int k0 = 0; k0 < KS; k0 += PB) {
+    uint4 ah[PB], al[PB];
+#pragma unroll
+    for (int u = 0; u < PB; ++u) {
+      const int k = k0 + u < KS ? k0 + u : KS - 1;
+      ah[u] = pa_h[k * 2];
+      al[u] = pa_l[k * 2];
+    }
+#pragma unroll
+    for (int u = 0; u < PB; ++u)
+      if (k0 + u < KS) {
+        acc = TL_MFMA(al[u], bh[k0 + u], acc);
+        acc = TL_MFMA(ah[u], bl[k0 + u], acc);
+        acc = TL_MFMA(ah[u], bh[k0 + u], acc);
+      }
+  }
+  return acc;
+}
+
+#ifndef COPER_TL_WAVES
+#define COPER_TL_WAVES 4
+#endif
+constexpr int TL_WAVES = COPER_TL_WAVES;   // waves per 32-query block: they share the finalize and deal the filter tiles among themselves
+
+template <int KS>
+__global__ __launch_bounds__(64 * TL_WAVES) void k_finalize_targets_filter_bf16x3(
+    const float* __restrict__ z_part, int ksplit, int64_t Bcap, int64_t B, int d, int d_pad16, const int32_t* __restrict__ inv_perm,
+    const int32_t* __restrict__ sorted_rid, const float* __restrict__ fc_b, int per_rel_bias, const float* __restrict__ scale,
+    const float* __restrict__ shift, float* __restrict__ h_out, uint4* __restrict__ fhi, uint4* __restrict__ flo,
+    const uint4* __restrict__ Ehi, const uint4* __restrict__ Elo, const float* __restrict__ bias_pad, int64_t n_local,
+    const int64_t* __restrict__ e2, const int64_t* __restrict__ indptr, const int64_t* __restrict__ idx, float* __restrict__ tgt,
+    int32_t* __restrict__ ranks) {
+  __shared__ uint4 s_bh[KS][64], s_bl[KS][64];   // the block's B-operand fragments (hi / lo), shared by the waves
+  __shared__ int64_t s_e[TL_WAVES][32];
+  __shared__ int s_corr[32];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, i = lane & 31, half = lane >> 5;
+  const int64_t blk = blockIdx.x, q0 = blk * 32, q = q0 + i;
+  const bool live = q < B;
+  if (threadIdx.x < 32) s_corr[threadIdx.x] = 0;
+
+  // ---- 1. finalize: wave w takes k-steps w, w + 4, ...; a lane computes piece (ks, half) of its query
+  {
+    const int64_t pos = live ? inv_perm[q] : 0;
+    const float* bsrc = live ? (per_rel_bias ? fc_b + (int64_t)sorted_rid[pos] * d : fc_b) : fc_b;
+#pragma unroll
+    for (int ks = wave; ks < KS; ks += TL_WAVES) {
+      const int k0 = 16 * ks + 8 * half;
+      float y[8];
+      if (live && k0 < d_pad16) {
+        float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < ksplit; ++s) {
+          const float4* pp = (const float4*)(z_part + ((int64_t)s * Bcap + pos) * d_pad16 + k0);
+          const float4 a = pp[0], b = pp[1];
+          z[0] += a.x; z[1] += a.y; z[2] += a.z; z[3] += a.w;
+          z[4] += b.x; z[5] += b.y; z[6] += b.z; z[7] += b.w;
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const int k = k0 + c;
+          float v = 0.f;
+          if (k < d) {
+            v = z[c] + bsrc[k];
+            v = fmaf(v, scale[k], shift[k]);
+            v = fmaxf(v, 0.f);
+            if (h_out) h_out[q * d + k] = v;
+          }
+          y[c] = v;
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) y[c] = 0.f;
+      }
+      uint4 h4, l4;
+      split8_bf16(y, h4, l4);
+      const int64_t fo = (blk * KS + ks) * 64 + lane;
+      fhi[fo] = h4;
+      flo[fo] = l4;
+      s_bh[ks][lane] = h4;
+      s_bl[ks][lane] = l4;
+    }
+  }
+  __syncthreads();
+  uint4 bh[KS], bl[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) { bh[ks] = s_bh[ks][lane]; bl[ks] = s_bl[ks][lane]; }
+
+  // ---- 2. targets: pair i = (query i, e2[query i]), the diagonal of the tile; every wave computes it for itself (32
+  // gathered rows: cheaper than handing the targets from one wave to the others)
+  const int64_t my_e2 = live ? e2[q] : -1;
+  int64_t erow = my_e2;
+  if (erow < 0 || erow >= n_local) erow = -1;
+  if (half == 0) s_e[wave][i] = erow;
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): wave-local LDS exchange
+  __builtin_amdgcn_wave_barrier();
+  f32x16 acc = tail_tile<KS>(Ehi, Elo, bias_pad, s_e[wave], erow, bh, bl, half);
+  // D[i][i] sits in lane i + 32 * ((i >> 2) & 1), register (i & 3) + 4 * (i >> 3)
+  float diag = 0.f;
+  {
+    const int reg = (i & 3) + 4 * (i >> 3);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) diag = (r == reg) ? acc[r] : diag;
+  }
+  float t = __shfl(diag, i + 32 * ((i >> 2) & 1));   // lane i (both halves): the target of query i
+  t = erow >= 0 ? t : 0.f;
+  if (wave == 0 && half == 0 && live) tgt[q] = t;
+
+  // ---- 3. known answers of these queries: CSR entries [indptr[q0], indptr[min(q0 + 32, B)]), 32 per tile, tiles dealt
+  // to the waves round-robin
+  const int64_t qe = q0 + 32 < B ? q0 + 32 : B;
+  const int64_t p_begin = q0 < B ? indptr[q0] : 0, p_end = q0 < B ? indptr[qe] : 0;
+  const int64_t my_lo = live ? indptr[q] : p_end;   // first entry of query i (lane i), for the search below
+  for (int64_t pb = p_begin + 32 * wave; pb < p_end; pb += 32 * TL_WAVES) {
+    const int64_t p = pb + i;
+    // every lane runs the same cross-lane reads (a shuffle must not sit in divergent code: inactive lanes supply nothing);
+    // lanes past the last entry carry frow = -1
+    const bool valid = p < p_end;
+    // local query of entry p: the last j with indptr[q0 + j] <= p (binary lifting over the lanes' first entries)
+    int qi = 0;
+#pragma unroll
+    for (int step = 16; step >= 1; step >>= 1) {
+      const int cand = qi + step;
+      const int64_t first = __shfl(my_lo, cand < 32 ? cand : 31);
+      qi = (valid && cand < 32 && first <= p) ? cand : qi;
+    }
+    const int64_t qfirst = __shfl(my_lo, qi);
+    const int64_t qe2 = __shfl(my_e2, qi);
+    int64_t frow = -1;
+    if (valid) {
+      const int64_t f = idx[p];
+      frow = f;
+      if (p > qfirst && idx[p - 1] == f) frow = -1;          // adjacent duplicate: the dense mask is idempotent
+      if (f == qe2) frow = -1;                                // the target is restored after masking (metrics.py:46)
+      if (frow < 0 || frow >= n_local) frow = -1;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (half == 0) s_e[wave][i] = frow;
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    acc = tail_tile<KS>(Ehi, Elo, bias_pad, s_e[wave], frow, bh, bl, half);
+    // entry i wants D[i][qi]: register (i & 3) + 4 * (i >> 3) of lane qi + 32 * ((i >> 2) & 1)
+    const int src = qi + 32 * ((i >> 2) & 1);
+    const int reg = (i & 3) + 4 * (i >> 3);
+    float sc = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float v = __shfl(acc[r], src);
+      sc = (r == reg) ? v : sc;
+    }
+    const float tq = __shfl(t, qi);
+    if (half == 0 && frow >= 0 && sc > tq) atomicAdd(&s_corr[qi], 1);
+  }
+  __syncthreads();
+  if (wave == 0 && half == 0 && live) ranks[q] = 1 - s_corr[i];
+}
+
+bool tail_fused_supported(const coper_handle* h) {
+  if (getenv("COPER_TAIL_UNFUSED")) return false;
+  return (h->dm.KS16 == 13 || h->dm.KS16 == 16) && h->dm.n_local == h->dm.E;
+}
+
+int launch_finalize_targets_filter_bf16x3(coper_handle* h, int64_t B, int ksplit, float* h_out, const int64_t* e2, const int64_t* indptr,
+                                          const int64_t* idx, float* tgt, int32_t* ranks, hipStream_t s) {
+  const Dims& dm = h->dm;
+  const float* fcb = dm.gen_fc ? h->fc_b_rel : h->params["fc_bias"].ptr;
+  const int64_t rows_pad = (B + 127) / 128 * 128;
+  const unsigned grid = (unsigned)(rows_pad / 32);
+#define TL_GO(KS_)                                                                                                                 \
+  hipLaunchKernelGGL(k_finalize_targets_filter_bf16x3<KS_>, dim3(grid), dim3(64 * TL_WAVES), 0, s, h->z_part, ksplit, h->ws_queries, B, dm.d,   \
+                     dm.d_pad16, h->inv_perm, h->sorted_rid, fcb, dm.gen_fc ? 1 : 0, h->fc_scale, h->fc_shift, h_out,               \
+                     (uint4*)h->hfrag16_hi, (uint4*)h->hfrag16_lo, (const uint4*)h->Erm16_hi, (const uint4*)h->Erm16_lo,            \
+                     h->bias_pad, dm.n_local, e2, indptr, idx, tgt, ranks)
+  if (dm.KS16 == 13) TL_GO(13); else TL_GO(16);
+#undef TL_GO
+  COPER_HIP_TRY(h, hipGetLastError());
+  return COPER_OK;
+}
+
+}  // namespace coper
