@@ -690,3 +690,37 @@ def test_prepare_generators_match_sister_model_scores(golden_dir, tag, mode):
     logits = m.score_all(m.encode(batch["e1"], batch["rel"])).cpu().numpy()
     assert np.abs(sigmoid(logits) - g[tag + ":S"]).max() < (2e-6 if mode == "f32" else 1e-4)
     m.close()
+
+
+@pytest.mark.parametrize("d,emb", [(200, (10, 20)), (256, (16, 16))])
+def test_fused_tail_path_edge_cases(oracle_chain, d, emb):
+    """coper_encode_rank, ranks only, bf16x3 with 13 / 16 k-steps: finalize + targets + filter correction run as ONE launch
+    (kernels_tail_bf16.hip) and the pipelined count kernel adds to its output.  Same ranks as the reference ranker applied
+    to the mode's own materialised logits, same embedding bits as the two-call path, for: batch sizes around the 32-query
+    block and 128-query tile boundaries, empty filters, filters without the target, duplicated and unsorted-free CSR rows
+    with up to 64 entries, entries that equal the target, a query block whose entries span several 32-entry tiles."""
+    O = oracle_chain
+    md = cdata.model_descriptors("fb15k237_cpg", num_ent=1203, num_rel=14, ent_emb_size=d, emb_h=emb[0], emb_w=emb[1])
+    p = cdata.synthetic_params(md, 4)
+    m = _model(md, p, score_mode="bf16x3")
+    rng = np.random.default_rng(0)
+    for B in (1, 31, 32, 33, 127, 128, 129, 300):
+        q = cdata.synthetic_queries(md, B, seed=B, mean_filter=9.0, max_filter=64)
+        variants = [(q["filt_indptr"], q["filt_idx"])]
+        variants.append((np.zeros(B + 1, np.int64), np.zeros(0, np.int64)))                      # no filters at all
+        variants.append((q["filt_indptr"] * 2, np.repeat(q["filt_idx"], 2)))                     # every entry twice
+        rows = [q["filt_idx"][q["filt_indptr"][i]:q["filt_indptr"][i + 1]] for i in range(B)]
+        rows = [r[r != q["e2"][i]] if i % 2 else r for i, r in enumerate(rows)]                  # half the rows lose their target
+        rows[0] = np.unique(rng.integers(0, md["num_ent"], 64))                                  # one long row
+        ip = np.zeros(B + 1, np.int64)
+        ip[1:] = np.cumsum([len(r) for r in rows])
+        variants.append((ip, np.concatenate(rows).astype(np.int64)))
+        h2 = m.encode(q["e1"], q["rel"])
+        logits = m.score_all(h2).cpu().numpy()
+        for ipv, ixv in variants:
+            r_fused, none, h1 = m.rank_pass(q["e1"], q["rel"], q["e2"], ipv, ixv, want_equal=False, want_h=True)
+            assert none is None and torch.equal(h1, h2)
+            r_two, _ = m.rank(h2, q["e2"], ipv, ixv)
+            ng, _ = O.rank_counts_c(logits, q["e2"], ipv, ixv)
+            assert np.array_equal(r_fused.cpu().numpy(), 1 + ng) and torch.equal(r_fused, r_two), (B, len(ixv))
+    m.close()
