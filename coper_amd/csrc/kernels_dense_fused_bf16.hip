@@ -321,6 +321,10 @@ __device__ __forceinline__ void fused_conv_role(uint4* __restrict__ xring, float
   }
 }
 
+// (Round 2, measured and not kept: a persistent form -- one workgroup per CU walking the (tile, K slice) items round-robin
+// instead of a grid sized by the worst case, most of it empty workgroups -- took 0.24 ms where this launch takes 0.19
+// (FB15k-237 CoPER shapes; plain ConvE 0.30 vs 0.27): the hardware dispatcher hands a freed CU the next workgroup, a static
+// walk does not.)
 template <int NFB, bool WNT>
 __global__ __launch_bounds__(512) void k_dense_fused_bf16x3(const uint4* __restrict__ Whi, const uint4* __restrict__ Wlo,
                                                             FusedConvArgs A, const int32_t* __restrict__ tiles,
