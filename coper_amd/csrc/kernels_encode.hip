@@ -70,15 +70,23 @@ __device__ __forceinline__ void rel_scan_tiles_body(const int32_t* count, int64_
     int64_t rid = base + threadIdx.x;
     int c = rid < R ? count[rid] : 0;
     int ns = (c > 0 && c <= 32) ? 1 : 0;
-    s_cnt[threadIdx.x] = c;
-    s_sml[threadIdx.x] = ns;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-      int a = 0, b2 = 0;
-      if ((int)threadIdx.x >= off) { a = s_cnt[threadIdx.x - off]; b2 = s_sml[threadIdx.x - off]; }
+    // inclusive scan of (c, ns) over the 1024 threads: shuffles inside a wave, the 16 wave totals through LDS
+    // (two barriers; a Hillis-Steele scan over LDS took twenty)
+    {
+      int ic = c, is = ns;
+      const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int a = __shfl_up(ic, off), b2 = __shfl_up(is, off);
+        if (lane >= off) { ic += a; is += b2; }
+      }
+      if (lane == 63) { s_cnt[wv] = ic; s_sml[wv] = is; }
       __syncthreads();
-      s_cnt[threadIdx.x] += a;
-      s_sml[threadIdx.x] += b2;
+      int pc = 0, ps = 0;
+      for (int w2 = 0; w2 < wv; ++w2) { pc += s_cnt[w2]; ps += s_sml[w2]; }
+      __syncthreads();
+      s_cnt[threadIdx.x] = ic + pc;
+      s_sml[threadIdx.x] = is + ps;
       __syncthreads();
     }
     int excl_c = carry_cnt + s_cnt[threadIdx.x] - c;
