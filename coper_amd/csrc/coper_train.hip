@@ -379,6 +379,60 @@ __global__ __launch_bounds__(256) void k_tr_score_bwd(const float* __restrict__ 
   if (k < d) dh[b * d + k] = acc;
 }
 
+// dh[b,:] = sum_l ds[b,l] E[lookup[b,l], :] without the scatter (the dense-route backward adds dE by a GEMM): the gather is
+// bandwidth work -- B L rows of d floats (410 MB at 512 x 1000 x 200) -- and needs tens of KB in flight per CU: a thread owns
+// four features (16-byte loads) of one of 256 / (d / 4) row slots, eight rows ahead, so a workgroup keeps 8 * slots rows
+// (32 KB at d = 200) in flight; the slots' partial sums meet in LDS.  (The per-feature form with eight 4-byte loads in
+// flight per thread read at 3.1 TB/s.)
+__global__ __launch_bounds__(256) void k_tr_dh_gather4(const float* __restrict__ ent, const int32_t* __restrict__ lookup,
+                                                       const float* __restrict__ ds, int64_t E, int d, int64_t L,
+                                                       float* __restrict__ dh) {
+  extern __shared__ float4 sh4[];   // [slots][d / 4]
+  const int64_t b = blockIdx.x;
+  const int d4 = d >> 2, slots = 256 / d4;
+  const int slot = threadIdx.x / d4, q4 = threadIdx.x - slot * d4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (slot < slots) {
+    const int32_t* lk = lookup + b * L;
+    const float* gs = ds + b * L;
+    int64_t l = slot;
+    for (; l + 7 * slots < L; l += 8 * slots) {
+      int64_t row[8];
+      float g[8];
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        row[u] = lk[l + u * slots];
+        if (row[u] < 0 || row[u] >= E) row[u] = 0;
+        g[u] = gs[l + u * slots];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *(const float4*)(ent + row[u] * d + 4 * q4);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        acc.x = fmaf(g[u], v[u].x, acc.x); acc.y = fmaf(g[u], v[u].y, acc.y);
+        acc.z = fmaf(g[u], v[u].z, acc.z); acc.w = fmaf(g[u], v[u].w, acc.w);
+      }
+    }
+    for (; l < L; l += slots) {
+      int64_t row = lk[l];
+      if (row < 0 || row >= E) row = 0;
+      const float g = gs[l];
+      const float4 v = *(const float4*)(ent + row * d + 4 * q4);
+      acc.x = fmaf(g, v.x, acc.x); acc.y = fmaf(g, v.y, acc.y); acc.z = fmaf(g, v.z, acc.z); acc.w = fmaf(g, v.w, acc.w);
+    }
+    sh4[slot * d4 + q4] = acc;
+  }
+  __syncthreads();
+  if (slot == 0) {
+    for (int s2 = 1; s2 < slots; ++s2) {   // fixed order
+      const float4 o = sh4[s2 * d4 + q4];
+      acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+    }
+    *(float4*)(dh + b * d + 4 * q4) = acc;
+  }
+}
+
 // dense route of the scorer backward (small entity tables): S[b, lookup[b,l]] += ds[b,l], dbias[lookup] += ds;
 // then dE = S^T h and dh = S E are two library GEMMs instead of B*L*d float atomics
 __global__ __launch_bounds__(256) void k_tr_scatter_ds(const int32_t* __restrict__ lookup, const float* __restrict__ ds, int64_t E,
@@ -842,7 +896,24 @@ __global__ __launch_bounds__(256) void k_tr_sumsq(TrainTensors tt, double* __res
   const int64_t rl = tt.rowlen[blockIdx.y];
   const int64_t stride = (int64_t)gridDim.x * 256;
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (!rc) {
+  if (!rc && ((uintptr_t)g & 15) == 0) {
+    // 16-byte loads, four in flight per thread; the scalar loop below takes what is left
+    const int64_t n4 = n >> 2;
+    const float4* g4 = (const float4*)g;
+    int64_t j = i;
+    for (; j + 3 * stride < n4; j += 4 * stride) {
+      const float4 v0 = g4[j], v1 = g4[j + stride], v2 = g4[j + 2 * stride], v3 = g4[j + 3 * stride];
+      a += (double)v0.x * v0.x + (double)v0.y * v0.y + (double)v0.z * v0.z + (double)v0.w * v0.w;
+      a += (double)v1.x * v1.x + (double)v1.y * v1.y + (double)v1.z * v1.z + (double)v1.w * v1.w;
+      a += (double)v2.x * v2.x + (double)v2.y * v2.y + (double)v2.z * v2.z + (double)v2.w * v2.w;
+      a += (double)v3.x * v3.x + (double)v3.y * v3.y + (double)v3.z * v3.z + (double)v3.w * v3.w;
+    }
+    for (; j < n4; j += stride) {
+      const float4 v0 = g4[j];
+      a += (double)v0.x * v0.x + (double)v0.y * v0.y + (double)v0.z * v0.z + (double)v0.w * v0.w;
+    }
+    i += n4 * 4;   // the scalar loop: elements [4 n4, n)
+  } else if (!rc) {
     for (; i + 3 * stride < n; i += 4 * stride) {   // four independent loads in flight
       const float g0 = g[i], g1 = g[i + stride], g2 = g[i + 2 * stride], g3 = g[i + 3 * stride];
       a += (double)g0 * g0 + (double)g1 * g1 + (double)g2 * g2 + (double)g3 * g3;
@@ -1262,8 +1333,12 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
                        "sgemm dE")))
       return rc;
     // dh by the gather (a [d,B] = [d,|E|] x [|E|,B] GEMM has 8 output tiles and a long K: slower than the gather)
-    hipLaunchKernelGGL(k_tr_score_bwd<false>, dim3((unsigned)B), dim3(256), 0, s, T->hv, ent, lookup, T->ds, dm.E, d, L, T->dh, nullptr,
-                       nullptr);
+    if ((d & 3) == 0 && d >= 16 && d <= 1024 && (((uintptr_t)ent | (uintptr_t)T->dh) & 15) == 0)
+      hipLaunchKernelGGL(k_tr_dh_gather4, dim3((unsigned)B), dim3(256), sizeof(float4) * (size_t)(256 / (d >> 2)) * (d >> 2), s, ent, lookup,
+                         T->ds, dm.E, d, L, T->dh);
+    else
+      hipLaunchKernelGGL(k_tr_score_bwd<false>, dim3((unsigned)B), dim3(256), 0, s, T->hv, ent, lookup, T->ds, dm.E, d, L, T->dh, nullptr,
+                         nullptr);
   } else {
     hipLaunchKernelGGL(k_tr_score_bwd<true>, dim3((unsigned)B), dim3(256), 0, s, T->hv, ent, lookup, T->ds, dm.E, d, L, T->dh, G_("ent_emb"),
                        G_("pred_bias"));
