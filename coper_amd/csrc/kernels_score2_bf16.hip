@@ -219,7 +219,26 @@ __global__ __launch_bounds__(256, 1) void k_score_count2_bf16x3(const uint4* __r
       __syncthreads();
       const uint4* sh = Hhi + tile * (NQ * KS * 64);
       const uint4* sl = Hlo + tile * (NQ * KS * 64);
-      for (int j = threadIdx.x; j < NQ * KS * 64; j += 256) { hl_hi[j] = sh[j]; hl_lo[j] = sl[j]; }
+      // the query tile (2 x NQ x KS KiB) into LDS: NQ * KS / 4 pieces per thread and plane, all loads of a plane's half in
+      // flight before the first LDS store (a load-store-load-store loop pays one L2 round trip per piece)
+      {
+        constexpr int NPC = NQ * KS * 64 / 256;   // pieces per thread per plane (13 or 16)
+        constexpr int HB = (NPC + 1) / 2;
+        uint4 th[HB], tl[HB];
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+#pragma unroll
+          for (int u = 0; u < HB; ++u) {
+            const int j = (part * HB + u) * 256 + threadIdx.x;
+            if (part * HB + u < NPC) { th[u] = sh[j]; tl[u] = sl[j]; }
+          }
+#pragma unroll
+          for (int u = 0; u < HB; ++u) {
+            const int j = (part * HB + u) * 256 + threadIdx.x;
+            if (part * HB + u < NPC) { hl_hi[j] = th[u]; hl_lo[j] = tl[u]; }
+          }
+        }
+      }
       cur_tile = tile;
       {
         const int64_t q = tile * (32 * NQ) + (lane & 31);
