@@ -72,7 +72,7 @@ def build_library(force=False, verbose=False, extra_flags=(), out=None, jobs=4):
         todo.append((base + SOURCE_FLAGS.get(src, []) + ["-c", sp, "-o", op], verbose))
     with ThreadPoolExecutor(max_workers=jobs) as ex:
         list(ex.map(_compile_one, todo))
-    link = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out + ".tmp", *objs, "-ldl"]
+    link = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out + ".tmp", *objs]
     if verbose:
         print(" ".join(link), file=sys.stderr)
     subprocess.check_call(link)

@@ -14,10 +14,8 @@
 //     sampled scorer s[b,l] = h[b] . ent_emb[lookup[b,l]] + pred_bias[...] (k_tr_score_loss) or 1-vs-all (GEMM)
 //   backward: the transposes of the above (dense: dP[rho] = x^T (ctx[:,rho] . dz) batched, dA = dz P2^T one GEMM, then
 //   the contraction with ctx / x); embedding-row gradients by float atomics or, when B*|E| is small, through a dense
-//   d(loss)/d(logits) matrix and one GEMM.  GEMMs are rocBLAS (dlopen'ed: plain library GEMMs).
+//   d(loss)/d(logits) matrix and one GEMM.  Every GEMM is the split-bf16 MFMA kernel of train_gemm_bf16.hip (no library).
 //   optimiser: tf.clip_by_global_norm + AMSGrad (amsgrad.py:130-159), one launch each over all tensors.
-#include <dlfcn.h>
-
 #include <cmath>
 #include <cstring>
 
@@ -30,27 +28,6 @@ namespace coper {
 namespace {
 
 constexpr float BN_EPS = 1e-3f;
-
-// ---- rocBLAS, resolved at coper_train_init (the inference library has no link-time dependency on it)
-typedef void* rb_handle;
-typedef int (*rb_create_t)(rb_handle*);
-typedef int (*rb_destroy_t)(rb_handle);
-typedef int (*rb_set_stream_t)(rb_handle, hipStream_t);
-typedef int (*rb_sgemm_t)(rb_handle, int, int, int, int, int, const float*, const float*, int, const float*, int,
-                          const float*, float*, int);
-typedef int (*rb_sgemm_sb_t)(rb_handle, int, int, int, int, int, const float*, const float*, int, int64_t, const float*, int,
-                             int64_t, const float*, float*, int, int64_t, int);
-constexpr int RB_N = 111, RB_T = 112;  // rocblas_operation_none / _transpose
-
-struct RocBlas {
-  void* lib = nullptr;
-  rb_handle handle = nullptr;
-  rb_create_t create = nullptr;
-  rb_destroy_t destroy = nullptr;
-  rb_set_stream_t set_stream = nullptr;
-  rb_sgemm_t sgemm = nullptr;
-  rb_sgemm_sb_t sgemm_sb = nullptr;
-};
 
 struct TrainParam {
   std::string name;
@@ -68,7 +45,6 @@ static const char* const kGenNames[4] = {"fc_weights", "fc_bias", "conv1_weights
 
 struct TrainState {
   coper_train_config cfg;
-  RocBlas rb;
   std::vector<TrainParam> tp;
   double b1p = 0, b2p = 0;
   uint32_t step = 0;
@@ -95,6 +71,11 @@ struct TrainState {
   float* A = nullptr;        // generated dense: T[r][B][d] (forward partials) | dT[r][B][d]
   // generated dense, split-bf16 GEMMs (train_gemm_bf16.hip): operand planes
   TgPlanes pX, pXt, pP1, pP3, pTn, pTb;   // x rows b | x rows f | P rows (rho,k) | P rows f | dT rows (rho,k) | dT rows b
+  // the other products (static dense layer, 1-vs-all scorer, dE of the dense scorer backward): two operand plane sets and
+  // the split-K partial sums, grown on demand
+  TgPlanes mmX, mmY;
+  size_t mmX_cap = 0, mmY_cap = 0, mmP_cap = 0;
+  float* mmP = nullptr;
   float *z0 = nullptr, *z1 = nullptr, *hv = nullptr, *dh = nullptr, *dz = nullptr, *ds = nullptr, *dx = nullptr, *dc = nullptr;
   double* red = nullptr;     // reduction scratch: [0] loss, [1] grad sumsq, [2..] BN sums
   float* bnst = nullptr;     // [4][max(C,d)]: mean1, inv1, mean2, inv2 ... see offsets below
@@ -113,6 +94,16 @@ int talloc(coper_handle* h, T** p, size_t n) {
   if (hipMalloc((void**)p, n * sizeof(T)) != hipSuccess) return fail(h, COPER_ENOMEM, "hipMalloc failed (training workspace)");
   return COPER_OK;
 }
+
+// C(i, j) = sum_k X(i, k) Y(j, k) for two strided fp32 views, on the split-bf16 GEMM of train_gemm_bf16.hip: packs both
+// operands into the state's plane sets (grown on demand), cuts K into slices when the output has few tiles.
+struct MmView {
+  const float* p;
+  TgIdx ri, ki;
+  bool rows_fast;   // consecutive rows contiguous in memory (else consecutive k)
+};
+static int tg_matmul(coper_handle* h, TrainState* T, hipStream_t s, const MmView& X, int64_t M, const MmView& Y, int64_t N, int64_t K,
+                     float* C, TgIdx ci, TgIdx cj);
 
 // ------------------------------------------------------------------------------------------------
 // forward kernels
@@ -957,10 +948,32 @@ __global__ __launch_bounds__(256) void k_tr_amsgrad(TrainTensors tt, const doubl
 
 __global__ void k_tr_store_loss(const double* __restrict__ acc, double inv_BL, float* __restrict__ out) { out[0] = (float)(acc[0] * inv_BL); }
 
-int rb_check(coper_handle* h, int st, const char* what) {
-  if (st != 0) return fail(h, COPER_EHIP, std::string("rocBLAS call failed: ") + what);
-  return COPER_OK;
+static int tg_matmul(coper_handle* h, TrainState* T, hipStream_t s, const MmView& X, int64_t M, const MmView& Y, int64_t N, int64_t K,
+                     float* C, TgIdx ci, TgIdx cj) {
+  int rc;
+  const size_t nx = tg_plane_elems(M, K), ny = tg_plane_elems(N, K);
+  const int nsplit = tg_split_k(M, N, K);
+  const size_t np = nsplit > 1 ? (size_t)nsplit * M * N : 0;
+  if (nx > T->mmX_cap || ny > T->mmY_cap || np > T->mmP_cap) {
+    COPER_HIP_TRY(h, hipStreamSynchronize(s));
+    if (nx > T->mmX_cap) {
+      if ((rc = talloc(h, &T->mmX.hi, nx)) || (rc = talloc(h, &T->mmX.lo, nx))) return rc;
+      T->mmX_cap = nx;
+    }
+    if (ny > T->mmY_cap) {
+      if ((rc = talloc(h, &T->mmY.hi, ny)) || (rc = talloc(h, &T->mmY.lo, ny))) return rc;
+      T->mmY_cap = ny;
+    }
+    if (np > T->mmP_cap) {
+      if ((rc = talloc(h, &T->mmP, np))) return rc;
+      T->mmP_cap = np;
+    }
+  }
+  if ((rc = tg_pack(h, X.p, X.ri, X.ki, M, K, tg_rows_pad(M), X.rows_fast, T->mmX, s))) return rc;
+  if ((rc = tg_pack(h, Y.p, Y.ri, Y.ki, N, K, tg_rows_pad(N), Y.rows_fast, T->mmY, s))) return rc;
+  return tg_gemm_nt(h, T->mmX, M, T->mmY, N, K, C, ci, cj, s, nsplit, T->mmP);
 }
+
 
 }  // namespace
 
@@ -981,8 +994,11 @@ void train_destroy(coper_handle* h) {
       if (i < COPER_MAX_CTX) { (void)hipFree(ch.u[i]); (void)hipFree(ch.a[i]); (void)hipFree(ch.du[i]); (void)hipFree(ch.st[i]); }
     }
   (void)hipFree(T->red);
-  if (T->rb.handle && T->rb.destroy) (void)T->rb.destroy(T->rb.handle);
-  if (T->rb.lib) dlclose(T->rb.lib);
+  for (TgPlanes* pl : {&T->mmX, &T->mmY}) {
+    if (pl->hi) (void)hipFree(pl->hi);
+    if (pl->lo) (void)hipFree(pl->lo);
+  }
+  if (T->mmP) (void)hipFree(T->mmP);
   delete T;
   h->train = nullptr;
 }
@@ -1068,19 +1084,7 @@ COPER_API int coper_train_init(coper_handle* h, const coper_train_config* cfg) {
     COPER_HIP_TRY(h, hipMemset(tp.g, 0, sizeof(float) * tp.n));
     T->tp.push_back(tp);
   }
-  // rocBLAS for the three plain GEMMs of the dense layer
-  RocBlas& rb = T->rb;
-  rb.lib = dlopen("librocblas.so", RTLD_NOW | RTLD_LOCAL);
-  if (!rb.lib) rb.lib = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_LOCAL);
-  if (!rb.lib) return fail(h, COPER_EUNSUPPORTED, std::string("coper_train_init: cannot load librocblas.so: ") + dlerror());
-  rb.create = (rb_create_t)dlsym(rb.lib, "rocblas_create_handle");
-  rb.destroy = (rb_destroy_t)dlsym(rb.lib, "rocblas_destroy_handle");
-  rb.set_stream = (rb_set_stream_t)dlsym(rb.lib, "rocblas_set_stream");
-  rb.sgemm = (rb_sgemm_t)dlsym(rb.lib, "rocblas_sgemm");
-  rb.sgemm_sb = (rb_sgemm_sb_t)dlsym(rb.lib, "rocblas_sgemm_strided_batched");
-  if (!rb.create || !rb.destroy || !rb.set_stream || !rb.sgemm || !rb.sgemm_sb) return fail(h, COPER_EUNSUPPORTED, "coper_train_init: rocBLAS symbols missing");
   int rc;
-  if ((rc = rb_check(h, rb.create(&rb.handle), "rocblas_create_handle"))) return rc;
   int mx = dm.C > dm.d ? dm.C : dm.d;
   for (int i = 0; i < T->nh; ++i) mx = h->cfg.ctx_out[i] > mx ? h->cfg.ctx_out[i] : mx;
   for (int i = 0; i < T->nhc; ++i) mx = h->cfg.ctx_conv[i] > mx ? h->cfg.ctx_conv[i] : mx;
@@ -1170,8 +1174,6 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
   const uint32_t thr_h = dropout_threshold24(tc.hidden_dropout), thr_o = dropout_threshold24(tc.output_dropout);
   const float ks_h = 1.f / (1.f - tc.hidden_dropout), ks_o = 1.f / (1.f - tc.output_dropout);
   const uint32_t step = T->step;
-  const float one = 1.f, zero = 0.f;
-  if ((rc = rb_check(h, T->rb.set_stream(T->rb.handle, s), "rocblas_set_stream"))) return rc;
 
   // ---- zero what is accumulated by atomics: one launch
   const bool dense_scorer_bwd = (double)B * (double)dm.E * 4.0 <= 512.0 * 1024 * 1024 && dm.E <= 0x7fffffff;
@@ -1262,8 +1264,7 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
   if (nh > 0 && ((rc = chain_forward(0, nh)) || (rc = chain_forward(1, nh)))) return rc;
   const float* cw = nh ? T->chain[0].v[nh] : T->c;   // [B, rc_w]
   const float* cbv = nh ? T->chain[1].v[nh] : T->c;  // [B, rc_b]
-  const int64_t Kd = gen ? (int64_t)rc_w * F : F;           // inner size of the dA GEMM
-  const float* Wmat = gen ? P_(wlast.c_str()) : P_("fc_weights");   // row-major [Kd, d]
+  const float* Wmat = gen ? P_(wlast.c_str()) : P_("fc_weights");   // row-major [rc_w * F, d] (generated) or [F, d] (static)
   const int64_t nBd = B * d;
   float* Tf = T->A;                 // T[rho][b][k]
   float* dTf = T->A + (size_t)rc_w * nBd;
@@ -1283,9 +1284,9 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
       if ((rc = tg_pack(h, Wmat, tg_idx2(d, F * (int64_t)d, 1), tg_idx(d), nrk, F, tg_rows_pad(nrk), true, T->pP1, s))) return rc;
       if ((rc = tg_gemm_nt(h, T->pX, B, T->pP1, nrk, F, Tf, tg_idx(d), tg_idx2(d, nBd, 1), s))) return rc;
     } else {
-      // z0[B,d] = x[B,F] W[F,d]   (row-major operands seen as column-major transposes)
-      if ((rc = rb_check(h, T->rb.sgemm(T->rb.handle, RB_N, RB_N, d, (int)B, (int)F, &one, Wmat, d, xin, (int)F, &zero, T->z0, d),
-                         "sgemm forward")))
+      // z0[B,d] = x[B,F] W[F,d]: 8 output tiles, K = F cut into slices
+      if ((rc = tg_matmul(h, T, s, MmView{xin, tg_idx(F), tg_idx(1), false}, B, MmView{Wmat, tg_idx(1), tg_idx(d), true}, d, F, T->z0,
+                          tg_idx(d), tg_idx(1))))
         return rc;
     }
     hipLaunchKernelGGL(k_tr_fc_post, dim3((unsigned)((nBd + 255) / 256)), dim3(256), 0, s, gen ? Tf : T->z0, gen ? nullptr : P_("fc_bias"),
@@ -1305,8 +1306,8 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
       T->capS = B * dm.E;
     }
     // S[B,E] = h E^T
-    if ((rc = rb_check(h, T->rb.sgemm(T->rb.handle, RB_T, RB_N, (int)dm.E, (int)B, d, &one, ent, d, T->hv, d, &zero, T->Sd, (int)dm.E),
-                       "sgemm logits")))
+    if ((rc = tg_matmul(h, T, s, MmView{T->hv, tg_idx(d), tg_idx(1), false}, B, MmView{ent, tg_idx(d), tg_idx(1), false}, dm.E, d, T->Sd,
+                        tg_idx(dm.E), tg_idx(1))))
       return rc;
     hipLaunchKernelGGL(k_tr_dense_loss, dim3(2048), dim3(256), 0, s, T->Sd, P_("pred_bias"), labels, dm.E, B * dm.E,
                        tc.label_smoothing_epsilon, (float)(1.0 / (double)dm.E), inv_BL, red);
@@ -1319,18 +1320,20 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
   // ---- backward
   if (one_vs_all) {
     hipLaunchKernelGGL(k_tr_col_sum_f32, dim3((unsigned)((dm.E + 255) / 256)), dim3(256), 0, s, T->Sd, B, dm.E, G_("pred_bias"));
-    if ((rc = rb_check(h, T->rb.sgemm(T->rb.handle, RB_N, RB_T, d, (int)dm.E, (int)B, &one, T->hv, d, T->Sd, (int)dm.E, &zero, G_("ent_emb"), d),
-                       "sgemm dE")))
+    // dE[E,d] = S^T h
+    if ((rc = tg_matmul(h, T, s, MmView{T->Sd, tg_idx(1), tg_idx(dm.E), true}, dm.E, MmView{T->hv, tg_idx(1), tg_idx(d), true}, d, B,
+                        G_("ent_emb"), tg_idx(d), tg_idx(1))))
       return rc;
-    // dh[B,d] = S E
-    if ((rc = rb_check(h, T->rb.sgemm(T->rb.handle, RB_N, RB_N, d, (int)B, (int)dm.E, &one, ent, d, T->Sd, (int)dm.E, &zero, T->dh, d), "sgemm dh")))
+    // dh[B,d] = S E: 8 output tiles, K = |E| cut into slices
+    if ((rc = tg_matmul(h, T, s, MmView{T->Sd, tg_idx(dm.E), tg_idx(1), false}, B, MmView{ent, tg_idx(1), tg_idx(d), true}, d, dm.E,
+                        T->dh, tg_idx(d), tg_idx(1))))
       return rc;
   } else if (dense_scorer_bwd) {
     hipLaunchKernelGGL(k_tr_scatter_ds, dim3((unsigned)((B * L + 255) / 256)), dim3(256), 0, s, lookup, T->ds, dm.E, L, B * L, T->Sd,
                        G_("pred_bias"));
     // dE[E,d] = S^T h  (overwrites the zeroed gradient; the e1-row contributions are added after it)
-    if ((rc = rb_check(h, T->rb.sgemm(T->rb.handle, RB_N, RB_T, d, (int)dm.E, (int)B, &one, T->hv, d, T->Sd, (int)dm.E, &zero, G_("ent_emb"), d),
-                       "sgemm dE")))
+    if ((rc = tg_matmul(h, T, s, MmView{T->Sd, tg_idx(1), tg_idx(dm.E), true}, dm.E, MmView{T->hv, tg_idx(1), tg_idx(d), true}, d, B,
+                        G_("ent_emb"), tg_idx(d), tg_idx(1))))
       return rc;
     // dh by the gather (a [d,B] = [d,|E|] x [|E|,B] GEMM has 8 output tiles and a long K: slower than the gather)
     if ((d & 3) == 0 && d >= 16 && d <= 1024 && (((uintptr_t)ent | (uintptr_t)T->dh) & 15) == 0)
@@ -1374,10 +1377,12 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
     if ((rc = tg_gemm_nt(h, T->pTb, B, T->pP3, F, nrk, dxin, tg_idx(F), tg_idx(1), s))) return rc;
     hipLaunchKernelGGL(k_tr_dc_from_partials, dim3((unsigned)((B * rc_w + 3) / 4)), dim3(256), 0, s, T->dz, Tf, B, rc_w, d, dcw);
   } else {
-    // static dense layer (plain ConvE): dW[F,d] = x^T dz and dx[B,F] = dz W^T, plain library GEMMs
-    if ((rc = rb_check(h, T->rb.sgemm(T->rb.handle, RB_N, RB_T, d, (int)F, (int)B, &one, T->dz, d, xin, (int)F, &zero, dW, d), "sgemm dW")))
+    // static dense layer (plain ConvE): dW[F,d] = x^T dz and dx[B,F] = dz W^T
+    if ((rc = tg_matmul(h, T, s, MmView{xin, tg_idx(1), tg_idx(F), true}, F, MmView{T->dz, tg_idx(1), tg_idx(d), true}, d, B, dW, tg_idx(d),
+                        tg_idx(1))))
       return rc;
-    if ((rc = rb_check(h, T->rb.sgemm(T->rb.handle, RB_T, RB_N, (int)Kd, (int)B, d, &one, Wmat, d, T->dz, d, &zero, dxin, (int)Kd), "sgemm dx")))
+    if ((rc = tg_matmul(h, T, s, MmView{T->dz, tg_idx(d), tg_idx(1), false}, B, MmView{Wmat, tg_idx(d), tg_idx(1), false}, F, d, dxin,
+                        tg_idx(F), tg_idx(1))))
       return rc;
   }
   if (cat) hipLaunchKernelGGL(k_tr_split, dim3((unsigned)((B * F + 255) / 256)), dim3(256), 0, s, T->dxc, rel, dm.R, Fc, r, B * F, T->dx, G_("rel_emb"));

@@ -29,6 +29,10 @@ inline size_t tg_plane_elems(int64_t rows, int64_t K) { return (size_t)(tg_rows_
 int tg_pack(coper_handle* h, const float* src, TgIdx ri, TgIdx ki, int64_t R, int64_t K, int64_t R_pad, bool rows_fast, TgPlanes out,
             hipStream_t s);
 // C[off(ci, i) + off(cj, j)] = sum_k X(i, k) Y(j, k), i < M, j < N
-int tg_gemm_nt(coper_handle* h, TgPlanes X, int64_t M, TgPlanes Y, int64_t N, int64_t K, float* C, TgIdx ci, TgIdx cj, hipStream_t s);
+// nsplit > 1: K is cut into nsplit slices whose partial sums go to `part` ([nsplit][M][N] floats) and are summed in slice order
+int tg_gemm_nt(coper_handle* h, TgPlanes X, int64_t M, TgPlanes Y, int64_t N, int64_t K, float* C, TgIdx ci, TgIdx cj, hipStream_t s,
+               int nsplit = 1, float* part = nullptr);
+// slices that fill the chip when the output has few 128 x 128 tiles and K is long (1: no split)
+int tg_split_k(int64_t M, int64_t N, int64_t K);
 
 }  // namespace coper

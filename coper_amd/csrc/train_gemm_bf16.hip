@@ -135,11 +135,16 @@ int tg_pack(coper_handle* h, const float* src, TgIdx ri, TgIdx ki, int64_t R, in
 // ------------------------------------------------------------------------------------------------
 template <int TI, int TJ, int NBUF>
 __global__ __launch_bounds__(256) void k_gemm_nt_bf16x3(const uint4* __restrict__ Xhi, const uint4* __restrict__ Xlo,
-                                                        const uint4* __restrict__ Yhi, const uint4* __restrict__ Ylo, int KS16,
-                                                        float* __restrict__ C, TgIdx ci, TgIdx cj, int64_t M, int64_t N) {
+                                                        const uint4* __restrict__ Yhi, const uint4* __restrict__ Ylo, int KS16_all,
+                                                        float* __restrict__ C, TgIdx ci, TgIdx cj, int64_t M, int64_t N, int nsplit,
+                                                        float* __restrict__ part) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int64_t ib0 = ((int64_t)blockIdx.x * 2 + (wave & 1)) * TI;
   const int64_t jb0 = ((int64_t)blockIdx.y * 2 + (wave >> 1)) * TJ;
+  // split K (few output tiles, long K): slice blockIdx.z of the k-steps, partial sums to `part` [nsplit][M][N], summed in
+  // slice order by k_tg_reduce
+  const int kb = (int)((int64_t)KS16_all * blockIdx.z / nsplit), KS16 = (int)((int64_t)KS16_all * (blockIdx.z + 1) / nsplit) - kb;
+  Xhi += (int64_t)kb * 64; Xlo += (int64_t)kb * 64; Yhi += (int64_t)kb * 64; Ylo += (int64_t)kb * 64;
   f32x16 acc[TI][TJ];
 #pragma unroll
   for (int a = 0; a < TI; ++a)
@@ -151,11 +156,11 @@ __global__ __launch_bounds__(256) void k_gemm_nt_bf16x3(const uint4* __restrict_
 #define TG_LOAD(s_, ks_)                                                                     \
   {                                                                                          \
     _Pragma("unroll") for (int a = 0; a < TI; ++a) {                                         \
-      const int64_t o = ((ib0 + a) * KS16 + (ks_)) * 64 + lane;                              \
+      const int64_t o = ((ib0 + a) * KS16_all + (ks_)) * 64 + lane;                          \
       xh[s_][a] = Xhi[o]; xl[s_][a] = Xlo[o];                                                \
     }                                                                                        \
     _Pragma("unroll") for (int b = 0; b < TJ; ++b) {                                         \
-      const int64_t o = ((jb0 + b) * KS16 + (ks_)) * 64 + lane;                              \
+      const int64_t o = ((jb0 + b) * KS16_all + (ks_)) * 64 + lane;                          \
       yh[s_][b] = Yhi[o]; yl[s_][b] = Ylo[o];                                                \
     }                                                                                        \
   }
@@ -209,6 +214,15 @@ __global__ __launch_bounds__(256) void k_gemm_nt_bf16x3(const uint4* __restrict_
     for (int b = 0; b < TJ; ++b) {
       const int64_t j = (jb0 + b) * 32 + (lane & 31);
       if (j >= N) continue;
+      if (nsplit > 1) {
+        float* pz = part + (int64_t)blockIdx.z * M * N + j;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t i = (ib0 + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (i < M) pz[i * N] = acc[a][b][r];
+        }
+        continue;
+      }
       const int64_t oj = tg_off(cj, j);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -218,13 +232,35 @@ __global__ __launch_bounds__(256) void k_gemm_nt_bf16x3(const uint4* __restrict_
     }
 }
 
-int tg_gemm_nt(coper_handle* h, TgPlanes X, int64_t M, TgPlanes Y, int64_t N, int64_t K, float* C, TgIdx ci, TgIdx cj, hipStream_t s) {
+__global__ __launch_bounds__(256) void k_tg_reduce(const float* __restrict__ part, int nsplit, int64_t M, int64_t N, float* __restrict__ C,
+                                                   TgIdx ci, TgIdx cj) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= M * N) return;
+  float a = 0.f;
+  for (int z = 0; z < nsplit; ++z) a += part[(int64_t)z * M * N + e];   // slice order: deterministic
+  C[tg_off(ci, e / N) + tg_off(cj, e % N)] = a;
+}
+
+int tg_split_k(int64_t M, int64_t N, int64_t K) {
+  const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128), ks16 = (K + 15) / 16;
+  if (tiles >= 160 || ks16 < 32) return 1;
+  int64_t sp = (512 + tiles - 1) / tiles;
+  if (sp > ks16 / 8) sp = ks16 / 8;
+  if (sp > 64) sp = 64;
+  return sp < 2 ? 1 : (int)sp;
+}
+
+int tg_gemm_nt(coper_handle* h, TgPlanes X, int64_t M, TgPlanes Y, int64_t N, int64_t K, float* C, TgIdx ci, TgIdx cj, hipStream_t s,
+               int nsplit, float* part) {
   const int KS16 = (int)((K + 15) / 16);
+  if (nsplit < 1 || !part) nsplit = 1;
   // workgroup tiles of 128 x 128 (rows of both plane sets are padded to TG_ROW_PAD).  A 128 x 256 tile (64 x 128 per wave,
   // 512 B of fragments per MFMA instead of 683, two register buffers) measured 165 us against 148 on the dP shape
   // (4608 x 6400 x 512): one k-step of prefetch does not cover the fill latency.
-  dim3 grid((unsigned)((M + 127) / 128), (unsigned)((N + 127) / 128));
-  hipLaunchKernelGGL((k_gemm_nt_bf16x3<2, 2, 3>), grid, dim3(256), 0, s, X.hi, X.lo, Y.hi, Y.lo, KS16, C, ci, cj, M, N);
+  dim3 grid((unsigned)((M + 127) / 128), (unsigned)((N + 127) / 128), (unsigned)nsplit);
+  hipLaunchKernelGGL((k_gemm_nt_bf16x3<2, 2, 3>), grid, dim3(256), 0, s, X.hi, X.lo, Y.hi, Y.lo, KS16, C, ci, cj, M, N, nsplit, part);
+  if (nsplit > 1)
+    hipLaunchKernelGGL(k_tg_reduce, dim3((unsigned)((M * N + 255) / 256)), dim3(256), 0, s, part, nsplit, M, N, C, ci, cj);
   COPER_HIP_TRY(h, hipGetLastError());
   return COPER_OK;
 }
