@@ -36,6 +36,12 @@ _CASES = {
     "cpg_conv_static_fc": dict(num_ent=211, num_rel=6, ent_emb_size=40, rel_emb_size=8, emb_h=10, emb_w=4, conv_num_channels=8,
                                context_rel_conv=[6], context_rel_out=None, concat_rel=True, context_rel_use_batch_norm=True,
                                context_rel_dropout=0.1),
+    # full-width layers (F = 10368 / 4608, d = 200): the GEMMs span several 128 x 128 tiles and the few-tile products
+    # (z0 = x W, dh = S E) take the split-K route
+    "plain_wide": dict(num_ent=700, num_rel=6, ent_emb_size=200, rel_emb_size=200, emb_h=10, emb_w=20, conv_num_channels=32,
+                       context_rel_conv=None, context_rel_out=None),
+    "cpg_wide": dict(num_ent=700, num_rel=6, ent_emb_size=200, rel_emb_size=8, emb_h=10, emb_w=20, conv_num_channels=32,
+                     context_rel_conv=None, context_rel_out=[]),
     "cpg_linear_c32": dict(num_ent=157, num_rel=4, ent_emb_size=80, rel_emb_size=4, emb_h=10, emb_w=8, conv_num_channels=32,
                            context_rel_conv=None, context_rel_out=[]),
 }
@@ -75,8 +81,15 @@ def test_train_step_matches_oracle(name, train_stats, one_vs_all):
     m.train_init(seed=seed)
     ref = {k: np.array(v, np.float64) for k, v in p0.items()}
     opt = T.AMSGrad(T.trainable_names(md), ref, lr=md["learning_rate"])
+    # the wide cases restart the oracle from the device's variables before every step, so that each step is held to the
+    # step-0 bounds (the other cases let the two trajectories run free and bound the Adam-amplified drift instead)
+    sync = name.endswith("_wide")
     for step in range(3):
         batch = _batch(md, B, L, seed=100 + step)
+        if sync and step > 0:
+            for k in ref:
+                ref[k] = m._tensors[k].cpu().numpy().reshape(np.shape(ref[k])).astype(np.float64)
+        tight = step == 0 or sync
         if one_vs_all:       # use_negative_sampling = False: dense labels over all entities, no lookup (data.py:313-334)
             dense = np.zeros((B, md["num_ent"]), np.float32)
             np.put_along_axis(dense, batch["lookup_values"].astype(np.int64), batch["e2_multi"], axis=1)
@@ -84,7 +97,7 @@ def test_train_step_matches_oracle(name, train_stats, one_vs_all):
         ob = dict(e1=batch["e1"], rel=batch["rel"], lookup=None if one_vs_all else batch["lookup_values"], labels=batch["e2_multi"])
         loss_o, grads_o, gn_o = T.train_step(ref, md, ob, opt, seed=seed, step=step, momentum=md["batch_norm_momentum"])
         loss = float(m.train_step(batch).cpu()[0])
-        assert abs(loss - loss_o) < (2e-5 if step == 0 else 2e-4) * max(1.0, abs(loss_o)), (step, loss, loss_o)
+        assert abs(loss - loss_o) < (2e-5 if tight else 2e-4) * max(1.0, abs(loss_o)), (step, loss, loss_o)
         dg = {}
         for leaf in T.trainable_names(md):
             g, gn = m.train_grad(leaf)
@@ -92,7 +105,7 @@ def test_train_step_matches_oracle(name, train_stats, one_vs_all):
             err = _rel_err(g, grads_o[leaf], 1e-3 * gn_o)
             # step 0 starts from identical variables; later steps inherit the (bounded, Adam-amplified) differences of the
             # variables themselves, which the gradients see
-            assert err < (2e-4 if step == 0 else 3e-3), (step, leaf, err)
+            assert err < (2e-4 if tight else 3e-3), (step, leaf, err)
             dg[leaf] = np.abs(g - grads_o[leaf]).max()
         assert abs(gn - gn_o) < 1e-4 * gn_o
         # the variables themselves (updated in place), including the BN moving statistics
@@ -105,7 +118,14 @@ def test_train_step_matches_oracle(name, train_stats, one_vs_all):
             # g -> lr_t * m / (sqrt(v_hat) + eps) has slope <= lr_t * (1 - beta1) / eps where |g| ~ eps = 1e-8: an
             # absolute gradient error dg (fp32 rounding) may move such an entry by that much
             lr_t = md["learning_rate"] * 0.32
-            tol = 2e-5 + 1e-5 * np.abs(want).max() + 2.0 * lr_t * 0.1 * dg.get(leaf, 0.0) / 1e-8
+            # moving statistics after step 0 are batch statistics of activations computed from variables that already
+            # differ by the bound above (summed over up to F = 10368 inputs in the wide cases)
+            rel = 5e-5 if (not tight and leaf not in dg) else 1e-5
+            tol = 2e-5 + rel * np.abs(want).max() + 2.0 * lr_t * 0.1 * dg.get(leaf, 0.0) / 1e-8
+            if train_stats and leaf == "Conv1BN/moving_mean" and "conv1_bias" in ref:
+                # mean(conv) carries conv1_bias, whose noise-driven steps are excluded above
+                bias = m._tensors["conv1_bias"].cpu().numpy().reshape(-1)
+                tol += np.abs(bias - np.reshape(ref["conv1_bias"], -1)).max()
             assert np.abs(got - want).max() < tol, (step, leaf, np.abs(got - want).max(), tol)
     # inference after training: caches are rebuilt from the updated variables
     q = cdata.synthetic_queries(md, 40, seed=3)
