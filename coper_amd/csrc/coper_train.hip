@@ -77,7 +77,7 @@ struct TrainState {
   size_t mmX_cap = 0, mmY_cap = 0, mmP_cap = 0;
   float* mmP = nullptr;
   float *z0 = nullptr, *z1 = nullptr, *hv = nullptr, *dh = nullptr, *dz = nullptr, *ds = nullptr, *dx = nullptr, *dc = nullptr;
-  double* red = nullptr;     // reduction scratch: [0] loss, [1] grad sumsq, [2..] BN sums
+  double* red = nullptr;     // reduction scratch: [0] loss, [1] grad sumsq (total, written by the optimizer kernel), [2..] BN sums, then TG_SUMSQ_SLOTS partial sumsq
   float* bnst = nullptr;     // [4][max(C,d)]: mean1, inv1, mean2, inv2 ... see offsets below
   TrainParam* find(const char* name) {
     for (auto& t : tp)
@@ -103,7 +103,7 @@ struct MmView {
   bool rows_fast;   // consecutive rows contiguous in memory (else consecutive k)
 };
 static int tg_matmul(coper_handle* h, TrainState* T, hipStream_t s, const MmView& X, int64_t M, const MmView& Y, int64_t N, int64_t K,
-                     float* C, TgIdx ci, TgIdx cj);
+                     float* C, TgIdx ci, TgIdx cj, double* sumsq = nullptr);
 
 // ------------------------------------------------------------------------------------------------
 // forward kernels
@@ -878,8 +878,9 @@ struct TrainTensors {
   const int32_t* rowcnt[TR_MAX_PARAMS];
 };
 
-__global__ __launch_bounds__(256) void k_tr_sumsq(TrainTensors tt, double* __restrict__ acc) {
+__global__ __launch_bounds__(256) void k_tr_sumsq(TrainTensors tt, int skip, double* __restrict__ acc) {
   __shared__ double part[256];
+  if ((int)blockIdx.y == skip) return;   // the GEMM that produced this gradient already added its squares
   const float* g = tt.g[blockIdx.y];
   const int64_t n = tt.n[blockIdx.y];
   double a = 0;
@@ -920,19 +921,22 @@ __global__ __launch_bounds__(256) void k_tr_sumsq(TrainTensors tt, double* __res
     if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0 && part[0] != 0.0) atomicAdd(acc, part[0]);
+  if (threadIdx.x == 0 && part[0] != 0.0) atomicAdd(acc + (blockIdx.x + blockIdx.y * gridDim.x) % TG_SUMSQ_SLOTS, part[0]);
 }
 
 // tf.clip_by_global_norm + AMSGrad (amsgrad.py:130-159), all in one pass over the parameters
-__global__ __launch_bounds__(256) void k_tr_amsgrad(TrainTensors tt, const double* __restrict__ sumsq, float clip, float lr_t,
-                                                    float b1, float b2, float eps) {
+__global__ __launch_bounds__(256) void k_tr_amsgrad(TrainTensors tt, const double* __restrict__ ssq, double* __restrict__ total,
+                                                    float clip, float lr_t, float b1, float b2, float eps) {
   float* p = tt.p[blockIdx.y];
   const float* g = tt.g[blockIdx.y];
   float* m = tt.m[blockIdx.y];
   float* v = tt.v[blockIdx.y];
   float* vh = tt.vh[blockIdx.y];
   const int64_t n = tt.n[blockIdx.y];
-  const double gn = sqrt(*sumsq);
+  double ss = 0;   // the slots in index order: every thread of every workgroup forms the same sum
+  for (int i = 0; i < TG_SUMSQ_SLOTS; ++i) ss += ssq[i];
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *total = ss;   // what coper_train_grad reports
+  const double gn = sqrt(ss);
   const float scale = (float)((double)clip / (gn > (double)clip ? gn : (double)clip));
   const int32_t* rc = tt.rowcnt[blockIdx.y];
   const int64_t rl = tt.rowlen[blockIdx.y];
@@ -948,8 +952,22 @@ __global__ __launch_bounds__(256) void k_tr_amsgrad(TrainTensors tt, const doubl
 
 __global__ void k_tr_store_loss(const double* __restrict__ acc, double inv_BL, float* __restrict__ out) { out[0] = (float)(acc[0] * inv_BL); }
 
+// GEMM on planes packed by the caller, K cut into slices when the output has few tiles (the partial-sum pool grows on demand)
+static int tg_gemm_split(coper_handle* h, TrainState* T, hipStream_t s, TgPlanes X, int64_t M, TgPlanes Y, int64_t N, int64_t K, float* C,
+                         TgIdx ci, TgIdx cj) {
+  int rc;
+  const int nsplit = tg_split_k(M, N, K);
+  const size_t np = nsplit > 1 ? (size_t)nsplit * M * N : 0;
+  if (np > T->mmP_cap) {
+    COPER_HIP_TRY(h, hipStreamSynchronize(s));
+    if ((rc = talloc(h, &T->mmP, np))) return rc;
+    T->mmP_cap = np;
+  }
+  return tg_gemm_nt(h, X, M, Y, N, K, C, ci, cj, s, nsplit, T->mmP);
+}
+
 static int tg_matmul(coper_handle* h, TrainState* T, hipStream_t s, const MmView& X, int64_t M, const MmView& Y, int64_t N, int64_t K,
-                     float* C, TgIdx ci, TgIdx cj) {
+                     float* C, TgIdx ci, TgIdx cj, double* sumsq) {
   int rc;
   const size_t nx = tg_plane_elems(M, K), ny = tg_plane_elems(N, K);
   const int nsplit = tg_split_k(M, N, K);
@@ -971,7 +989,7 @@ static int tg_matmul(coper_handle* h, TrainState* T, hipStream_t s, const MmView
   }
   if ((rc = tg_pack(h, X.p, X.ri, X.ki, M, K, tg_rows_pad(M), X.rows_fast, T->mmX, s))) return rc;
   if ((rc = tg_pack(h, Y.p, Y.ri, Y.ki, N, K, tg_rows_pad(N), Y.rows_fast, T->mmY, s))) return rc;
-  return tg_gemm_nt(h, T->mmX, M, T->mmY, N, K, C, ci, cj, s, nsplit, T->mmP);
+  return tg_gemm_nt(h, T->mmX, M, T->mmY, N, K, C, ci, cj, s, nsplit, T->mmP, sumsq);
 }
 
 
@@ -1089,7 +1107,7 @@ COPER_API int coper_train_init(coper_handle* h, const coper_train_config* cfg) {
   for (int i = 0; i < T->nh; ++i) mx = h->cfg.ctx_out[i] > mx ? h->cfg.ctx_out[i] : mx;
   for (int i = 0; i < T->nhc; ++i) mx = h->cfg.ctx_conv[i] > mx ? h->cfg.ctx_conv[i] : mx;
   if ((rc = talloc(h, &T->bnst, (size_t)4 * mx))) return rc;
-  if ((rc = talloc(h, &T->red, (size_t)(2 + 2 * mx * TR_COLSUM_SLICES)))) return rc;
+  if ((rc = talloc(h, &T->red, (size_t)(2 + 2 * mx * TR_COLSUM_SLICES + TG_SUMSQ_SLOTS)))) return rc;
   return COPER_OK;
 }
 
@@ -1169,7 +1187,8 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
   for (int i = 0; i < nhc; ++i) mx = h->cfg.ctx_conv[i] > mx ? h->cfg.ctx_conv[i] : mx;
   float *mean1 = T->bnst, *inv1 = T->bnst + mx, *mean2 = T->bnst + 2 * mx, *inv2 = T->bnst + 3 * mx;
   double* red = T->red;         // [0] loss, [1] sumsq, then TR_COLSUM_SLICES slices of 2 mx column sums, one per use
-  auto colsum_slice = [&](int i) { return red + 2 + (size_t)i * 2 * mx; };   // 0 Conv1BN, 1 FCBN, 2 Conv1BN backward, 3 + 4 g + i chains
+  auto colsum_slice = [&](int i) { return red + 2 + (size_t)i * 2 * mx; };
+  double* ssq = red + 2 + (size_t)2 * mx * TR_COLSUM_SLICES;   // TG_SUMSQ_SLOTS partial sums of the squared gradient norm   // 0 Conv1BN, 1 FCBN, 2 Conv1BN backward, 3 + 4 g + i chains
   double* colsum = colsum_slice(0);
   const uint32_t thr_h = dropout_threshold24(tc.hidden_dropout), thr_o = dropout_threshold24(tc.output_dropout);
   const float ks_h = 1.f / (1.f - tc.hidden_dropout), ks_o = 1.f / (1.f - tc.output_dropout);
@@ -1187,7 +1206,7 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
     ZeroList zl;
     zl.n = 0;
     auto add = [&](void* p, size_t bytes) { if (p && bytes && zl.n < TR_ZERO_MAX) { zl.p[zl.n] = p; zl.bytes[zl.n] = bytes; ++zl.n; } };
-    add(red, sizeof(double) * (2 + (size_t)2 * mx * TR_COLSUM_SLICES));
+    add(red, sizeof(double) * (2 + (size_t)2 * mx * TR_COLSUM_SLICES + TG_SUMSQ_SLOTS));
     for (const char* nm : {"ent_emb", "rel_emb", "conv1_weights", "conv1_bias", "pred_bias"})
       if (T->find(nm)) add(G_(nm), sizeof(float) * T->find(nm)->n);
     if (lk) add(G_("fc_bias"), sizeof(float) * T->find("fc_bias")->n);
@@ -1282,7 +1301,7 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
       const int64_t nrk = (int64_t)rc_w * d;
       if ((rc = tg_pack(h, xin, tg_idx(F), tg_idx(1), B, F, tg_rows_pad(B), false, T->pX, s))) return rc;
       if ((rc = tg_pack(h, Wmat, tg_idx2(d, F * (int64_t)d, 1), tg_idx(d), nrk, F, tg_rows_pad(nrk), true, T->pP1, s))) return rc;
-      if ((rc = tg_gemm_nt(h, T->pX, B, T->pP1, nrk, F, Tf, tg_idx(d), tg_idx2(d, nBd, 1), s))) return rc;
+      if ((rc = tg_gemm_split(h, T, s, T->pX, B, T->pP1, nrk, F, Tf, tg_idx(d), tg_idx2(d, nBd, 1)))) return rc;
     } else {
       // z0[B,d] = x[B,F] W[F,d]: 8 output tiles, K = F cut into slices
       if ((rc = tg_matmul(h, T, s, MmView{xin, tg_idx(F), tg_idx(1), false}, B, MmView{Wmat, tg_idx(1), tg_idx(d), true}, d, F, T->z0,
@@ -1318,6 +1337,7 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
   if (loss_out) hipLaunchKernelGGL(k_tr_store_loss, dim3(1), dim3(1), 0, s, red, 1.0 / ((double)B * (double)L), loss_out);
 
   // ---- backward
+  std::string sumsq_done;   // the leaf whose squared gradient norm its own GEMM accumulates
   if (one_vs_all) {
     hipLaunchKernelGGL(k_tr_col_sum_f32, dim3((unsigned)((dm.E + 255) / 256)), dim3(256), 0, s, T->Sd, B, dm.E, G_("pred_bias"));
     // dE[E,d] = S^T h
@@ -1371,16 +1391,18 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
     hipLaunchKernelGGL(k_tr_scale_rows, dim3((unsigned)((nBd + 255) / 256)), dim3(256), 0, s, T->dz, cw, rc_w, d, nBd, dTf);
     if ((rc = tg_pack(h, xin, tg_idx(1), tg_idx(F), F, B, tg_rows_pad(F), true, T->pXt, s))) return rc;
     if ((rc = tg_pack(h, dTf, tg_idx2(d, nBd, 1), tg_idx(d), nrk, B, tg_rows_pad(nrk), true, T->pTn, s))) return rc;
-    if ((rc = tg_gemm_nt(h, T->pXt, F, T->pTn, nrk, B, dW, tg_idx(d), tg_idx2(d, F * (int64_t)d, 1), s))) return rc;
+    if ((rc = tg_gemm_nt(h, T->pXt, F, T->pTn, nrk, B, dW, tg_idx(d), tg_idx2(d, F * (int64_t)d, 1), s, 1, nullptr, ssq))) return rc;
+    sumsq_done = wlast;   // the GEMM added |dP|^2 to the global-norm accumulator as it stored
     if ((rc = tg_pack(h, dTf, tg_idx(d), tg_idx2(d, nBd, 1), B, nrk, tg_rows_pad(B), false, T->pTb, s))) return rc;
     if ((rc = tg_pack(h, Wmat, tg_idx(d), tg_idx2(d, F * (int64_t)d, 1), F, nrk, tg_rows_pad(F), false, T->pP3, s))) return rc;
-    if ((rc = tg_gemm_nt(h, T->pTb, B, T->pP3, F, nrk, dxin, tg_idx(F), tg_idx(1), s))) return rc;
+    if ((rc = tg_gemm_split(h, T, s, T->pTb, B, T->pP3, F, nrk, dxin, tg_idx(F), tg_idx(1)))) return rc;
     hipLaunchKernelGGL(k_tr_dc_from_partials, dim3((unsigned)((B * rc_w + 3) / 4)), dim3(256), 0, s, T->dz, Tf, B, rc_w, d, dcw);
   } else {
     // static dense layer (plain ConvE): dW[F,d] = x^T dz and dx[B,F] = dz W^T
     if ((rc = tg_matmul(h, T, s, MmView{xin, tg_idx(1), tg_idx(F), true}, F, MmView{T->dz, tg_idx(1), tg_idx(d), true}, d, B, dW, tg_idx(d),
-                        tg_idx(1))))
+                        tg_idx(1), ssq)))
       return rc;
+    sumsq_done = "fc_weights";
     if ((rc = tg_matmul(h, T, s, MmView{T->dz, tg_idx(d), tg_idx(1), false}, B, MmView{Wmat, tg_idx(d), tg_idx(1), false}, F, d, dxin,
                         tg_idx(F), tg_idx(1))))
       return rc;
@@ -1455,9 +1477,12 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
     tt.rowlen[i] = table ? F * d : 1;
     tt.rowcnt[i] = table ? h->rel_count : nullptr;
   }
-  hipLaunchKernelGGL(k_tr_sumsq, dim3(512, (unsigned)np), dim3(256), 0, s, tt, red + 1);
+  int skip = -1;
+  for (int i = 0; i < np; ++i)
+    if (!sumsq_done.empty() && T->tp[i].name == sumsq_done) skip = i;
+  hipLaunchKernelGGL(k_tr_sumsq, dim3(512, (unsigned)np), dim3(256), 0, s, tt, skip, ssq);
   const float lr_t = (float)((double)tc.learning_rate * std::sqrt(1.0 - T->b2p) / (1.0 - T->b1p));
-  hipLaunchKernelGGL(k_tr_amsgrad, dim3(2048, (unsigned)np), dim3(256), 0, s, tt, red + 1, tc.clip_norm, lr_t, tc.beta1, tc.beta2,
+  hipLaunchKernelGGL(k_tr_amsgrad, dim3(2048, (unsigned)np), dim3(256), 0, s, tt, ssq, red + 1, tc.clip_norm, lr_t, tc.beta1, tc.beta2,
                      tc.epsilon);
   COPER_HIP_TRY(h, hipGetLastError());
   T->b1p *= tc.beta1;

@@ -20,6 +20,7 @@ struct TgPlanes {
   uint4* lo = nullptr;
 };
 
+constexpr int TG_SUMSQ_SLOTS = 64;
 constexpr int64_t TG_ROW_PAD = 128;   // rows of a plane set are padded to the GEMM's workgroup tile
 inline int64_t tg_rows_pad(int64_t rows) { return (rows + TG_ROW_PAD - 1) / TG_ROW_PAD * TG_ROW_PAD; }
 inline size_t tg_plane_elems(int64_t rows, int64_t K) { return (size_t)(tg_rows_pad(rows) / 32) * (size_t)((K + 15) / 16) * 64; }   // uint4 per plane
@@ -30,8 +31,10 @@ int tg_pack(coper_handle* h, const float* src, TgIdx ri, TgIdx ki, int64_t R, in
             hipStream_t s);
 // C[off(ci, i) + off(cj, j)] = sum_k X(i, k) Y(j, k), i < M, j < N
 // nsplit > 1: K is cut into nsplit slices whose partial sums go to `part` ([nsplit][M][N] floats) and are summed in slice order
+// sumsq: when not null, the sum of the squares of the stored C is added by the storing kernel to the TG_SUMSQ_SLOTS device
+// doubles at sumsq (a workgroup adds to slot (its index) % TG_SUMSQ_SLOTS: thousands of atomics on one address serialise)
 int tg_gemm_nt(coper_handle* h, TgPlanes X, int64_t M, TgPlanes Y, int64_t N, int64_t K, float* C, TgIdx ci, TgIdx cj, hipStream_t s,
-               int nsplit = 1, float* part = nullptr);
+               int nsplit = 1, float* part = nullptr, double* sumsq = nullptr);
 // slices that fill the chip when the output has few 128 x 128 tiles and K is long (1: no split)
 int tg_split_k(int64_t M, int64_t N, int64_t K);
 

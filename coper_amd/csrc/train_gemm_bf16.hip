@@ -46,30 +46,34 @@ __device__ __forceinline__ void tg_split8(const float* v, uint4& hi, uint4& lo) 
 // MODE 0: consecutive threads read consecutive k (k contiguous in memory); 1: consecutive rows; +2: four elements per
 // thread along that direction as one 16-byte load (alignment checked by the host).
 // ------------------------------------------------------------------------------------------------
-template <int MODE>
+template <int MODE, int RT>
 __global__ __launch_bounds__(256) void k_pack_frag(const float* __restrict__ src, TgIdx ri, TgIdx ki, int64_t R, int64_t K,
                                                    int KS16, uint4* __restrict__ hi, uint4* __restrict__ lo) {
-  __shared__ float tile[32][129];
-  const int64_t row0 = (int64_t)blockIdx.y * 32, k0 = (int64_t)blockIdx.x * 128;
+  // tile of RT rows x KT k (4096 elements): 32 x 128 when k is the contiguous direction, 128 x 32 when rows are (a
+  // wave then reads 512 contiguous bytes per k instead of 128: the [rho][f][k] -> rows (rho, k) view of the projection
+  // went from 70 to 5x us)
+  constexpr int KT = 4096 / RT;
+  __shared__ float tile[RT][KT + 1];
+  const int64_t row0 = (int64_t)blockIdx.y * RT, k0 = (int64_t)blockIdx.x * KT;
   const int t = threadIdx.x;
   if (MODE == 0) {
 #pragma unroll 4
     for (int i = 0; i < 16; ++i) {
-      const int e = t + 256 * i, row = e >> 7, kk = e & 127;
+      const int e = t + 256 * i, row = e / KT, kk = e % KT;
       const bool ok = row0 + row < R && k0 + kk < K;
       tile[row][kk] = ok ? src[tg_off(ri, row0 + row) + tg_off(ki, k0 + kk)] : 0.f;
     }
   } else if (MODE == 1) {
 #pragma unroll 4
     for (int i = 0; i < 16; ++i) {
-      const int e = t + 256 * i, kk = e >> 5, row = e & 31;
+      const int e = t + 256 * i, kk = e / RT, row = e % RT;
       const bool ok = row0 + row < R && k0 + kk < K;
       tile[row][kk] = ok ? src[tg_off(ri, row0 + row) + tg_off(ki, k0 + kk)] : 0.f;
     }
   } else if (MODE == 2) {   // four consecutive k per thread
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int e = t + 256 * i, row = e >> 5, kk = (e & 31) * 4;
+      const int e = t + 256 * i, row = e / (KT / 4), kk = (e % (KT / 4)) * 4;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (row0 + row < R && k0 + kk < K) v = *(const float4*)(src + tg_off(ri, row0 + row) + tg_off(ki, k0 + kk));   // K % 4 == 0
       tile[row][kk] = v.x; tile[row][kk + 1] = v.y; tile[row][kk + 2] = v.z; tile[row][kk + 3] = v.w;
@@ -77,7 +81,7 @@ __global__ __launch_bounds__(256) void k_pack_frag(const float* __restrict__ src
   } else {                  // four consecutive rows per thread
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int e = t + 256 * i, kk = e >> 3, row = (e & 7) * 4;
+      const int e = t + 256 * i, kk = e / (RT / 4), row = (e % (RT / 4)) * 4;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (row0 + row < R && k0 + kk < K) v = *(const float4*)(src + tg_off(ri, row0 + row) + tg_off(ki, k0 + kk));   // R % 4 == 0
       tile[row][kk] = v.x; tile[row + 1][kk] = v.y; tile[row + 2][kk] = v.z; tile[row + 3][kk] = v.w;
@@ -86,16 +90,17 @@ __global__ __launch_bounds__(256) void k_pack_frag(const float* __restrict__ src
   __syncthreads();
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
-    const int f = t + 256 * p, ksl = f >> 6, l = f & 63;
-    const int64_t ks = (int64_t)blockIdx.x * 8 + ksl;
+    const int f = t + 256 * p, blk = f >> 6, l = f & 63;          // 8 (row block, k-step) blocks of 64 lanes
+    const int rb = blk / (KT / 16), ksl = blk % (KT / 16);
+    const int64_t ks = (int64_t)blockIdx.x * (KT / 16) + ksl;
     if (ks >= KS16) continue;
-    const int row = l & 31, kb = 16 * ksl + 8 * (l >> 5);
+    const int row = 32 * rb + (l & 31), kb = 16 * ksl + 8 * (l >> 5);
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = tile[row][kb + j];
     uint4 h4, l4;
     tg_split8(v, h4, l4);
-    const int64_t o = ((int64_t)blockIdx.y * KS16 + ks) * 64 + l;
+    const int64_t o = (((int64_t)blockIdx.y * (RT / 32) + rb) * KS16 + ks) * 64 + l;
     hi[o] = h4;
     lo[o] = l4;
   }
@@ -113,12 +118,16 @@ static bool tg_vec_ok(const float* src, const TgIdx& fast, const TgIdx& slow, in
 int tg_pack(coper_handle* h, const float* src, TgIdx ri, TgIdx ki, int64_t R, int64_t K, int64_t R_pad, bool rows_fast, TgPlanes out,
             hipStream_t s) {
   const int KS16 = (int)((K + 15) / 16);
-  dim3 grid((unsigned)((KS16 + 7) / 8), (unsigned)(R_pad / 32));
   const bool vec = rows_fast ? tg_vec_ok(src, ri, ki, R) : tg_vec_ok(src, ki, ri, K);
-  if (!rows_fast && vec) hipLaunchKernelGGL(k_pack_frag<2>, grid, dim3(256), 0, s, src, ri, ki, R, K, KS16, out.hi, out.lo);
-  else if (!rows_fast) hipLaunchKernelGGL(k_pack_frag<0>, grid, dim3(256), 0, s, src, ri, ki, R, K, KS16, out.hi, out.lo);
-  else if (vec) hipLaunchKernelGGL(k_pack_frag<3>, grid, dim3(256), 0, s, src, ri, ki, R, K, KS16, out.hi, out.lo);
-  else hipLaunchKernelGGL(k_pack_frag<1>, grid, dim3(256), 0, s, src, ri, ki, R, K, KS16, out.hi, out.lo);
+  if (!rows_fast) {
+    dim3 grid((unsigned)((KS16 + 7) / 8), (unsigned)(R_pad / 32));
+    if (vec) hipLaunchKernelGGL((k_pack_frag<2, 32>), grid, dim3(256), 0, s, src, ri, ki, R, K, KS16, out.hi, out.lo);
+    else hipLaunchKernelGGL((k_pack_frag<0, 32>), grid, dim3(256), 0, s, src, ri, ki, R, K, KS16, out.hi, out.lo);
+  } else {
+    dim3 grid((unsigned)((KS16 + 1) / 2), (unsigned)(R_pad / 128));   // R_pad is a multiple of TG_ROW_PAD = 128
+    if (vec) hipLaunchKernelGGL((k_pack_frag<3, 128>), grid, dim3(256), 0, s, src, ri, ki, R, K, KS16, out.hi, out.lo);
+    else hipLaunchKernelGGL((k_pack_frag<1, 128>), grid, dim3(256), 0, s, src, ri, ki, R, K, KS16, out.hi, out.lo);
+  }
   COPER_HIP_TRY(h, hipGetLastError());
   return COPER_OK;
 }
@@ -137,13 +146,23 @@ template <int TI, int TJ, int NBUF>
 __global__ __launch_bounds__(256) void k_gemm_nt_bf16x3(const uint4* __restrict__ Xhi, const uint4* __restrict__ Xlo,
                                                         const uint4* __restrict__ Yhi, const uint4* __restrict__ Ylo, int KS16_all,
                                                         float* __restrict__ C, TgIdx ci, TgIdx cj, int64_t M, int64_t N, int nsplit,
-                                                        float* __restrict__ part) {
+                                                        float* __restrict__ part, double* __restrict__ sumsq, int cs) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int64_t ib0 = ((int64_t)blockIdx.x * 2 + (wave & 1)) * TI;
-  const int64_t jb0 = ((int64_t)blockIdx.y * 2 + (wave >> 1)) * TJ;
-  // split K (few output tiles, long K): slice blockIdx.z of the k-steps, partial sums to `part` [nsplit][M][N], summed in
+  // 1-D grid, XCD-aware: workgroup L runs on XCD L % 8 as that XCD's (L / 8)-th workgroup.  The `cs` i tiles that share one
+  // j tile's Y fragments are consecutive workgroups of ONE XCD, so its L2 fetches those fragments once (with i fastest in a
+  // plain 3-D grid the four i tiles of the T / dx shapes sat on four XCDs: the 118 MB of projection planes crossed the
+  // fabric four times per GEMM)
+  const int ti = (int)((M + 127) / 128), tj = (int)((N + 127) / 128), nic = (ti + cs - 1) / cs;
+  const int L = blockIdx.x, slot = L >> 3;
+  const int c = (slot / cs) * 8 + (L & 7);
+  if (c >= nic * tj * nsplit) return;
+  const int bx = (c % nic) * cs + slot % cs, by = (c / nic) % tj, bz = c / (nic * tj);
+  if (bx >= ti) return;
+  const int64_t ib0 = ((int64_t)bx * 2 + (wave & 1)) * TI;
+  const int64_t jb0 = ((int64_t)by * 2 + (wave >> 1)) * TJ;
+  // split K (few output tiles, long K): slice bz of the k-steps, partial sums to `part` [nsplit][M][N], summed in
   // slice order by k_tg_reduce
-  const int kb = (int)((int64_t)KS16_all * blockIdx.z / nsplit), KS16 = (int)((int64_t)KS16_all * (blockIdx.z + 1) / nsplit) - kb;
+  const int kb = (int)((int64_t)KS16_all * bz / nsplit), KS16 = (int)((int64_t)KS16_all * (bz + 1) / nsplit) - kb;
   Xhi += (int64_t)kb * 64; Xlo += (int64_t)kb * 64; Yhi += (int64_t)kb * 64; Ylo += (int64_t)kb * 64;
   f32x16 acc[TI][TJ];
 #pragma unroll
@@ -208,6 +227,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt_bf16x3(const uint4* __restrict_
 #undef TG_KCL
 #undef TG_LOAD
 #undef TG_STEP
+  float ss = 0.f;   // sum of the squares this lane stores (the global gradient norm takes it from here: no second pass over C)
 #pragma unroll
   for (int a = 0; a < TI; ++a)
 #pragma unroll
@@ -215,7 +235,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt_bf16x3(const uint4* __restrict_
       const int64_t j = (jb0 + b) * 32 + (lane & 31);
       if (j >= N) continue;
       if (nsplit > 1) {
-        float* pz = part + (int64_t)blockIdx.z * M * N + j;
+        float* pz = part + (int64_t)bz * M * N + j;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int64_t i = (ib0 + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -227,40 +247,60 @@ __global__ __launch_bounds__(256) void k_gemm_nt_bf16x3(const uint4* __restrict_
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t i = (ib0 + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (i < M) C[tg_off(ci, i) + oj] = acc[a][b][r];
+        if (i < M) {
+          C[tg_off(ci, i) + oj] = acc[a][b][r];
+          ss = fmaf(acc[a][b][r], acc[a][b][r], ss);
+        }
       }
     }
+  if (sumsq && nsplit <= 1) {
+    double w = (double)ss;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) w += __shfl_xor(w, o, 64);
+    if (lane == 0 && w != 0.0) atomicAdd(sumsq + (blockIdx.x * 4 + wave) % TG_SUMSQ_SLOTS, w);
+  }
 }
 
 __global__ __launch_bounds__(256) void k_tg_reduce(const float* __restrict__ part, int nsplit, int64_t M, int64_t N, float* __restrict__ C,
-                                                   TgIdx ci, TgIdx cj) {
+                                                   TgIdx ci, TgIdx cj, double* __restrict__ sumsq) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= M * N) return;
   float a = 0.f;
-  for (int z = 0; z < nsplit; ++z) a += part[(int64_t)z * M * N + e];   // slice order: deterministic
-  C[tg_off(ci, e / N) + tg_off(cj, e % N)] = a;
+  if (e < M * N) {
+    for (int z = 0; z < nsplit; ++z) a += part[(int64_t)z * M * N + e];   // slice order: deterministic
+    C[tg_off(ci, e / N) + tg_off(cj, e % N)] = a;
+  }
+  if (sumsq) {   // uniform: every lane takes part in the shuffles
+    double w = (double)a * (double)a;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) w += __shfl_xor(w, o, 64);
+    if ((threadIdx.x & 63) == 0 && w != 0.0) atomicAdd(sumsq + (blockIdx.x * 4 + (threadIdx.x >> 6)) % TG_SUMSQ_SLOTS, w);
+  }
 }
 
 int tg_split_k(int64_t M, int64_t N, int64_t K) {
+  // two workgroups fit on a CU (512 places): as many slices as keep every workgroup resident at once, each at least 8 k-steps
   const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128), ks16 = (K + 15) / 16;
   if (tiles >= 160 || ks16 < 32) return 1;
-  int64_t sp = (512 + tiles - 1) / tiles;
+  int64_t sp = 512 / tiles;
   if (sp > ks16 / 8) sp = ks16 / 8;
   if (sp > 64) sp = 64;
   return sp < 2 ? 1 : (int)sp;
 }
 
 int tg_gemm_nt(coper_handle* h, TgPlanes X, int64_t M, TgPlanes Y, int64_t N, int64_t K, float* C, TgIdx ci, TgIdx cj, hipStream_t s,
-               int nsplit, float* part) {
+               int nsplit, float* part, double* sumsq) {
   const int KS16 = (int)((K + 15) / 16);
   if (nsplit < 1 || !part) nsplit = 1;
   // workgroup tiles of 128 x 128 (rows of both plane sets are padded to TG_ROW_PAD).  A 128 x 256 tile (64 x 128 per wave,
   // 512 B of fragments per MFMA instead of 683, two register buffers) measured 165 us against 148 on the dP shape
   // (4608 x 6400 x 512): one k-step of prefetch does not cover the fill latency.
-  dim3 grid((unsigned)((M + 127) / 128), (unsigned)((N + 127) / 128), (unsigned)nsplit);
-  hipLaunchKernelGGL((k_gemm_nt_bf16x3<2, 2, 3>), grid, dim3(256), 0, s, X.hi, X.lo, Y.hi, Y.lo, KS16, C, ci, cj, M, N, nsplit, part);
+  const int ti = (int)((M + 127) / 128), tj = (int)((N + 127) / 128);
+  const int cs = ti < 4 ? ti : 4;                       // i tiles of one j tile kept together on an XCD
+  const int64_t nclu = (int64_t)((ti + cs - 1) / cs) * tj * nsplit;
+  dim3 grid((unsigned)(8 * cs * ((nclu + 7) / 8)));
+  hipLaunchKernelGGL((k_gemm_nt_bf16x3<2, 2, 3>), grid, dim3(256), 0, s, X.hi, X.lo, Y.hi, Y.lo, KS16, C, ci, cj, M, N, nsplit, part, sumsq, cs);
   if (nsplit > 1)
-    hipLaunchKernelGGL(k_tg_reduce, dim3((unsigned)((M * N + 255) / 256)), dim3(256), 0, s, part, nsplit, M, N, C, ci, cj);
+    hipLaunchKernelGGL(k_tg_reduce, dim3((unsigned)((M * N + 255) / 256)), dim3(256), 0, s, part, nsplit, M, N, C, ci, cj, sumsq);
   COPER_HIP_TRY(h, hipGetLastError());
   return COPER_OK;
 }

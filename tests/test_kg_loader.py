@@ -206,3 +206,40 @@ def test_tfrecord_loader_equals_tsv_loader(tmp_path, golden_dir):
     batch = next(it)
     assert batch["lookup_values"].shape == (16, 20) and batch["e2_multi"].shape == (16, 20) and batch["e2_multi"][:, 0].all()
     assert len(ta["e1"]) == len(b.train_dataset(None, batch_size=16, num_labels=20).s["e1"])
+
+
+def test_tfrecord_reader_on_a_hand_assembled_file(tmp_path, golden_dir):
+    """Bytes assembled by tests/golden/make_tfrecord_handmade.py (its own CRC, varints and protobuf framing; nothing of
+    coper_amd imported): the reader is not tested against its own writer only.  Still a restatement of the published
+    format, not a TensorFlow-written file (none can be produced here)."""
+    import json
+    from coper_amd import tf_records as R
+    g = json.load(open(os.path.join(golden_dir, "tfrecord_handmade.json")))
+    blob = bytes.fromhex(g["file_hex"])
+    path = str(tmp_path / "test-0.tfrecords")
+    with open(path, "wb") as f:
+        f.write(blob)
+    recs = list(R.read_records(path, verify=True))
+    assert len(recs) == len(g["samples"])
+    for rec, want in zip(recs, g["samples"]):
+        assert R.parse_example(rec) == want
+    # the framing words of the first record, as the generator computed them with its bitwise CRC
+    assert int.from_bytes(blob[:8], "little") == g["first_length"] == len(recs[0])
+    assert int.from_bytes(blob[8:12], "little") == g["first_length_crc"]
+    assert int.from_bytes(blob[12 + len(recs[0]):16 + len(recs[0])], "little") == g["first_data_crc"]
+    # samples in sorted-key packed form are also what the writer emits: byte-identical records
+    assert R.encode_example(g["samples"][0]) == recs[0]
+    assert R.encode_example(g["samples"][2]) == recs[2]
+    # split view: the inverse sample (is_inverse = 1) and the one flagged -1 are dropped unless asked for
+    s = R.read_split(str(tmp_path), "test")
+    assert s["e1"].tolist() == [3, 14540] and s["rel"].tolist() == [2, 473]
+    assert s["filt_indptr"].tolist() == [0, 3, 73]
+    assert s["filt_idx"][:3].tolist() == [4, 17, 129]
+    s = R.read_split(str(tmp_path), "test", include_inv_relations=True)
+    assert s["e1"].tolist() == [3, 0, 14540, 5] and s["filt_indptr"].tolist() == [0, 3, 4, 74, 74]
+    # a flipped byte is caught by the data CRC
+    bad = bytearray(blob); bad[20] ^= 1
+    with open(path, "wb") as f:
+        f.write(bytes(bad))
+    with pytest.raises(ValueError):
+        list(R.read_records(path, verify=True))
