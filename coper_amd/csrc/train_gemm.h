@@ -14,7 +14,7 @@ struct TgIdx {
 inline TgIdx tg_idx(int64_t stride) { return TgIdx{0, 0, stride}; }
 inline TgIdx tg_idx2(int64_t seg, int64_t s_hi, int64_t s_lo) { return TgIdx{seg, s_hi, s_lo}; }
 
-// hi / lo bf16 planes in the fragment order of v_mfma_f32_32x32x16_bf16: [rows_pad / 32][KS16][64 lanes] x 16 B each
+// hi / lo bf16 planes in the fragment order of v_mfma_f32_32x32x16_bf16: [rows_pad / 32][tg_ks_stride(K)][64 lanes] x 16 B each
 struct TgPlanes {
   uint4* hi = nullptr;
   uint4* lo = nullptr;
@@ -23,7 +23,11 @@ struct TgPlanes {
 constexpr int TG_SUMSQ_SLOTS = 64;
 constexpr int64_t TG_ROW_PAD = 128;   // rows of a plane set are padded to the GEMM's workgroup tile
 inline int64_t tg_rows_pad(int64_t rows) { return (rows + TG_ROW_PAD - 1) / TG_ROW_PAD * TG_ROW_PAD; }
-inline size_t tg_plane_elems(int64_t rows, int64_t K) { return (size_t)(tg_rows_pad(rows) / 32) * (size_t)((K + 15) / 16) * 64; }   // uint4 per plane
+// k-steps between two row blocks of a plane: odd, so that the fragments a wave reads in one k-step (row blocks a, a+1, ...: same
+// k-step, one block stride apart) do not all sit on the same few memory channels -- with strides of 288 / 32 / 400 KiB (the
+// FB15k-237 shapes) every wave of the chip hit the same quarter of the channels in every k-step
+inline int64_t tg_ks_stride(int64_t K) { return ((K + 15) / 16) | 1; }
+inline size_t tg_plane_elems(int64_t rows, int64_t K) { return (size_t)(tg_rows_pad(rows) / 32) * (size_t)tg_ks_stride(K) * 64; }   // uint4 per plane
 
 // X(row, k) = src[off(ri, row) + off(ki, k)] -> planes (rows zero-padded to R_pad, k to a multiple of 16).
 // rows_fast: consecutive rows are contiguous in memory (the pack reads along rows), else consecutive k are.

@@ -48,7 +48,7 @@ __device__ __forceinline__ void tg_split8(const float* v, uint4& hi, uint4& lo) 
 // ------------------------------------------------------------------------------------------------
 template <int MODE, int RT>
 __global__ __launch_bounds__(256) void k_pack_frag(const float* __restrict__ src, TgIdx ri, TgIdx ki, int64_t R, int64_t K,
-                                                   int KS16, uint4* __restrict__ hi, uint4* __restrict__ lo) {
+                                                   int KS16, int KST, uint4* __restrict__ hi, uint4* __restrict__ lo) {
   // tile of RT rows x KT k (4096 elements): 32 x 128 when k is the contiguous direction, 128 x 32 when rows are (a
   // wave then reads 512 contiguous bytes per k instead of 128: the [rho][f][k] -> rows (rho, k) view of the projection
   // went from 70 to 5x us)
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void k_pack_frag(const float* __restrict__ src
     for (int j = 0; j < 8; ++j) v[j] = tile[row][kb + j];
     uint4 h4, l4;
     tg_split8(v, h4, l4);
-    const int64_t o = (((int64_t)blockIdx.y * (RT / 32) + rb) * KS16 + ks) * 64 + l;
+    const int64_t o = (((int64_t)blockIdx.y * (RT / 32) + rb) * KST + ks) * 64 + l;
     hi[o] = h4;
     lo[o] = l4;
   }
@@ -117,16 +117,16 @@ static bool tg_vec_ok(const float* src, const TgIdx& fast, const TgIdx& slow, in
 
 int tg_pack(coper_handle* h, const float* src, TgIdx ri, TgIdx ki, int64_t R, int64_t K, int64_t R_pad, bool rows_fast, TgPlanes out,
             hipStream_t s) {
-  const int KS16 = (int)((K + 15) / 16);
+  const int KS16 = (int)((K + 15) / 16), KST = (int)tg_ks_stride(K);
   const bool vec = rows_fast ? tg_vec_ok(src, ri, ki, R) : tg_vec_ok(src, ki, ri, K);
   if (!rows_fast) {
     dim3 grid((unsigned)((KS16 + 7) / 8), (unsigned)(R_pad / 32));
-    if (vec) hipLaunchKernelGGL((k_pack_frag<2, 32>), grid, dim3(256), 0, s, src, ri, ki, R, K, KS16, out.hi, out.lo);
-    else hipLaunchKernelGGL((k_pack_frag<0, 32>), grid, dim3(256), 0, s, src, ri, ki, R, K, KS16, out.hi, out.lo);
+    if (vec) hipLaunchKernelGGL((k_pack_frag<2, 32>), grid, dim3(256), 0, s, src, ri, ki, R, K, KS16, KST, out.hi, out.lo);
+    else hipLaunchKernelGGL((k_pack_frag<0, 32>), grid, dim3(256), 0, s, src, ri, ki, R, K, KS16, KST, out.hi, out.lo);
   } else {
     dim3 grid((unsigned)((KS16 + 1) / 2), (unsigned)(R_pad / 128));   // R_pad is a multiple of TG_ROW_PAD = 128
-    if (vec) hipLaunchKernelGGL((k_pack_frag<3, 128>), grid, dim3(256), 0, s, src, ri, ki, R, K, KS16, out.hi, out.lo);
-    else hipLaunchKernelGGL((k_pack_frag<1, 128>), grid, dim3(256), 0, s, src, ri, ki, R, K, KS16, out.hi, out.lo);
+    if (vec) hipLaunchKernelGGL((k_pack_frag<3, 128>), grid, dim3(256), 0, s, src, ri, ki, R, K, KS16, KST, out.hi, out.lo);
+    else hipLaunchKernelGGL((k_pack_frag<1, 128>), grid, dim3(256), 0, s, src, ri, ki, R, K, KS16, KST, out.hi, out.lo);
   }
   COPER_HIP_TRY(h, hipGetLastError());
   return COPER_OK;
@@ -144,7 +144,7 @@ int tg_pack(coper_handle* h, const float* src, TgIdx ri, TgIdx ki, int64_t R, in
 // ------------------------------------------------------------------------------------------------
 template <int TI, int TJ, int NBUF>
 __global__ __launch_bounds__(256) void k_gemm_nt_bf16x3(const uint4* __restrict__ Xhi, const uint4* __restrict__ Xlo,
-                                                        const uint4* __restrict__ Yhi, const uint4* __restrict__ Ylo, int KS16_all,
+                                                        const uint4* __restrict__ Yhi, const uint4* __restrict__ Ylo, int KS16_all, int KST,
                                                         float* __restrict__ C, TgIdx ci, TgIdx cj, int64_t M, int64_t N, int nsplit,
                                                         float* __restrict__ part, double* __restrict__ sumsq, int cs) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -175,11 +175,11 @@ __global__ __launch_bounds__(256) void k_gemm_nt_bf16x3(const uint4* __restrict_
 #define TG_LOAD(s_, ks_)                                                                     \
   {                                                                                          \
     _Pragma("unroll") for (int a = 0; a < TI; ++a) {                                         \
-      const int64_t o = ((ib0 + a) * KS16_all + (ks_)) * 64 + lane;                          \
+      const int64_t o = ((ib0 + a) * KST + (ks_)) * 64 + lane;                                \
       xh[s_][a] = Xhi[o]; xl[s_][a] = Xlo[o];                                                \
     }                                                                                        \
     _Pragma("unroll") for (int b = 0; b < TJ; ++b) {                                         \
-      const int64_t o = ((jb0 + b) * KS16_all + (ks_)) * 64 + lane;                          \
+      const int64_t o = ((jb0 + b) * KST + (ks_)) * 64 + lane;                                \
       yh[s_][b] = Yhi[o]; yl[s_][b] = Ylo[o];                                                \
     }                                                                                        \
   }
@@ -277,9 +277,25 @@ __global__ __launch_bounds__(256) void k_tg_reduce(const float* __restrict__ par
   }
 }
 
-int tg_split_k(int64_t M, int64_t N, int64_t K) {
-  // two workgroups fit on a CU (512 places): as many slices as keep every workgroup resident at once, each at least 8 k-steps
+// one wave per 128 x 128 tile (train_gemm_w128_bf16.hip) when tiles x K slices can fill the 1024 SIMDs
+static bool tg_use_w128(int64_t M, int64_t N, int64_t K) {
   const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128), ks16 = (K + 15) / 16;
+  if (getenv("COPER_TG_NO_W128")) return false;
+  if (tiles >= 768) return true;
+  return tiles * (ks16 / 16) >= 768;      // slices of at least 16 k-steps
+}
+
+int tg_split_k(int64_t M, int64_t N, int64_t K) {
+  const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128), ks16 = (K + 15) / 16;
+  if (tg_use_w128(M, N, K)) {
+    // tiles x slices just under a whole number of rounds of 1024 single-wave workgroups
+    if (tiles >= 768) return 1;
+    int64_t sp = 1024 / tiles;
+    if (sp > ks16 / 16) sp = ks16 / 16;
+    return sp < 2 ? 1 : (int)sp;
+  }
+  // four-wave kernel: two workgroups fit on a CU (512 places): as many slices as keep every workgroup resident at once, each
+  // at least 8 k-steps
   if (tiles >= 160 || ks16 < 32) return 1;
   int64_t sp = 512 / tiles;
   if (sp > ks16 / 8) sp = ks16 / 8;
@@ -287,18 +303,28 @@ int tg_split_k(int64_t M, int64_t N, int64_t K) {
   return sp < 2 ? 1 : (int)sp;
 }
 
+void tg_launch_w128(const TgPlanes& X, int64_t M, const TgPlanes& Y, int64_t N, int KS16, int KST, float* C, TgIdx ci, TgIdx cj, hipStream_t s,
+                    int nsplit, float* part, double* sumsq);
+
 int tg_gemm_nt(coper_handle* h, TgPlanes X, int64_t M, TgPlanes Y, int64_t N, int64_t K, float* C, TgIdx ci, TgIdx cj, hipStream_t s,
                int nsplit, float* part, double* sumsq) {
-  const int KS16 = (int)((K + 15) / 16);
+  const int KS16 = (int)((K + 15) / 16), KST = (int)tg_ks_stride(K);
   if (nsplit < 1 || !part) nsplit = 1;
   // workgroup tiles of 128 x 128 (rows of both plane sets are padded to TG_ROW_PAD).  A 128 x 256 tile (64 x 128 per wave,
   // 512 B of fragments per MFMA instead of 683, two register buffers) measured 165 us against 148 on the dP shape
   // (4608 x 6400 x 512): one k-step of prefetch does not cover the fill latency.
+  if (tg_use_w128(M, N, K) && ci.seg == 0) {   // (two-level row views of C: the four-wave kernel)
+    tg_launch_w128(X, M, Y, N, KS16, KST, C, ci, cj, s, nsplit, part, sumsq);
+    if (nsplit > 1)
+      hipLaunchKernelGGL(k_tg_reduce, dim3((unsigned)((M * N + 255) / 256)), dim3(256), 0, s, part, nsplit, M, N, C, ci, cj, sumsq);
+    COPER_HIP_TRY(h, hipGetLastError());
+    return COPER_OK;
+  }
   const int ti = (int)((M + 127) / 128), tj = (int)((N + 127) / 128);
   const int cs = ti < 4 ? ti : 4;                       // i tiles of one j tile kept together on an XCD
   const int64_t nclu = (int64_t)((ti + cs - 1) / cs) * tj * nsplit;
   dim3 grid((unsigned)(8 * cs * ((nclu + 7) / 8)));
-  hipLaunchKernelGGL((k_gemm_nt_bf16x3<2, 2, 3>), grid, dim3(256), 0, s, X.hi, X.lo, Y.hi, Y.lo, KS16, C, ci, cj, M, N, nsplit, part, sumsq, cs);
+  hipLaunchKernelGGL((k_gemm_nt_bf16x3<2, 2, 3>), grid, dim3(256), 0, s, X.hi, X.lo, Y.hi, Y.lo, KS16, KST, C, ci, cj, M, N, nsplit, part, sumsq, cs);
   if (nsplit > 1)
     hipLaunchKernelGGL(k_tg_reduce, dim3((unsigned)((M * N + 255) / 256)), dim3(256), 0, s, part, nsplit, M, N, C, ci, cj, sumsq);
   COPER_HIP_TRY(h, hipGetLastError());
