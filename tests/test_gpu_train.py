@@ -307,3 +307,42 @@ def test_session_run_serves_the_training_fetches():
     assert pred.shape == (16, md["num_ent"])
     a.close()
     b.close()
+
+
+def test_handles_release_their_device_memory():
+    """coper_destroy gives back everything a handle allocated -- caches, workspaces, the training state (plane sets,
+    split-K partial sums, optimizer slots): 12 create / prepare / rank / train / destroy cycles leave the device's free memory
+    where it was."""
+    from coper_amd.models import ConvE
+    md = dict(cdata._COMMON)
+    md.update(_CASES["cpg_wide"])
+    md.update(batch_norm_train_stats=True, batch_norm_momentum=0.9, hidden_dropout=0.3, output_dropout=0.2,
+              label_smoothing_epsilon=0.1, learning_rate=0.003)
+    p0 = {k: torch.as_tensor(np.array(v, np.float32)) for k, v in cdata.synthetic_params(md, seed=3).items()}
+    q = cdata.synthetic_queries(md, 300, seed=1)
+    batch = _batch(md, 48, 37, seed=7)
+
+    def cycle(mode):
+        m = ConvE(md, device="cuda:0", score_mode=mode)
+        m.load_parameters({k: v.clone() for k, v in p0.items()})
+        m.prepare()
+        m.rank_pass(q["e1"], q["rel"], q["e2"], q["filt_indptr"], q["filt_idx"])
+        h = m.encode(q["e1"], q["rel"])
+        m.rank_counts(h, m.target_scores(h, q["e2"]), q["e2"], q["filt_indptr"], q["filt_idx"], k=10)   # top-k workspaces
+        m.train_init(seed=1)
+        m.train_step(batch)
+        m.train_step(dict(e1=batch["e1"], rel=batch["rel"], e2_multi=np.zeros((48, md["num_ent"]), np.float32),
+                          lookup_values=np.zeros((48, 0), np.int32)))
+        m.close()
+
+    def free_after(n):
+        for i in range(n):
+            cycle("bf16x3" if i % 2 == 0 else "f32")
+        torch.cuda.synchronize(); torch.cuda.empty_cache()
+        return torch.cuda.mem_get_info()[0]
+
+    free0 = free_after(4)                 # first uses: library / allocator pools reach their steady size
+    free1 = free_after(8)
+    free2 = free_after(8)
+    print("free memory after 4 / 12 / 20 cycles:", free0, free1, free2)
+    assert free1 - free2 < (4 << 20), (free0, free1, free2)   # one handle of this size holds > 60 MB
