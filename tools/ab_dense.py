@@ -14,8 +14,22 @@ q = cdata.synthetic_queries(md, Q, seed=0)
 dq = {k: torch.as_tensor(v).cuda() for k, v in q.items()}
 for _ in range(3):
     m.encode(dq["e1"], dq["rel"])
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+def _mark(kind):   # tools/power_probe.sh: time window of the measured loop
+    if os.environ.get("COPER_PP_MARK"):
+        import time
+        with open(os.environ["COPER_PP_MARK"], "a") as f:
+            f.write("MARK %.2f %s encoder (fused conv + dense) %s Q=%d\n" % (time.time(), kind, name, Q))
+if reps > 400:
+    torch.cuda.synchronize(); _mark("start")
+    for i in range(reps):
+        m.encode(dq["e1"], dq["rel"])
+        if i % 1000 == 999:
+            torch.cuda.synchronize()
+    torch.cuda.synchronize(); _mark("end")
+    reps = 20
 m.profile(True); m.profile_read("dense"); m.profile_read("conv")
-for _ in range(20):
+for i in range(reps):
     m.encode(dq["e1"], dq["rel"])
 torch.cuda.synchronize()
 ms, n = m.profile_read("dense"); ms2, n2 = m.profile_read("conv")

@@ -51,11 +51,34 @@ void run(const u32x4* in, float* out, const char* tag) {
   double flop = (double)nwg * (THREADS / 64) * iters * 64.0 * 16384.0;   // both shapes: 64 x 16384 flop per iteration per wave
   printf("%-28s shape=%d waves/SIMD=%d: %.3f ms  %.0f TFLOP/s\n", tag, SHAPE, THREADS / 256, ms, flop / ms / 1e9);
 }
+// long mode (tools/power_probe.sh): `mfma_rate <seconds> [zeros]` keeps 32x32x16, one wave per SIMD, running for that long
+static void run_long(const u32x4* in, float* out, double seconds, const char* tag) {
+  const int iters = 4000, nwg = 256;
+  hipFuncSetAttribute((const void*)k_rate<32, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  double total_ms = 0; long launches = 0;
+  while (total_ms < seconds * 1e3) {
+    hipEventRecord(a);
+    for (int i = 0; i < 100; ++i) hipLaunchKernelGGL((k_rate<32, 256>), dim3(nwg), dim3(256), 100 * 1024, 0, in, out, iters);
+    hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    total_ms += ms; launches += 100;
+  }
+  double flop = (double)nwg * 4 * iters * 64.0 * 16384.0 * launches;
+  printf("%-8s shape=32 waves/SIMD=1, %.1f s: %.0f TFLOP/s\n", tag, total_ms / 1e3, flop / total_ms / 1e9);
+}
 int main(int argc, char** argv) {
   u32x4* in; float* out;
   size_t n = 8192 * 64;
   hipMalloc(&in, n * 16); hipMalloc(&out, 256 * 512 * 4);
   unsigned* h = (unsigned*)malloc(n * 16);
+  if (argc > 1) {
+    const bool zeros = argc > 2;
+    for (size_t i = 0; i < n * 4; ++i) { unsigned r = rand(); h[i] = zeros ? 0u : (0x3f803f80u ^ (r & 0x007f007fu) ^ ((r >> 8) & 0x80008000u)); }
+    hipMemcpy(in, h, n * 16, hipMemcpyHostToDevice);
+    run_long(in, out, atof(argv[1]), zeros ? "zeros" : "random");
+    return 0;
+  }
   for (int pass = 0; pass < 2; ++pass) {
     for (size_t i = 0; i < n * 4; ++i) { unsigned r = rand(); h[i] = pass ? (0x3f803f80u ^ (r & 0x007f007fu) ^ ((r >> 8) & 0x80008000u)) : 0u; }
     hipMemcpy(in, h, n * 16, hipMemcpyHostToDevice);
