@@ -500,7 +500,10 @@ static int encode_partials(coper_handle* h, const int64_t* e1, const int64_t* re
 #endif
   if (ksplit > h->ws_ksplit) ksplit = h->ws_ksplit;
   *ksplit_out = ksplit;
-  if ((rc = launch_group_by_relation(h, e1, rel, e1_rows != nullptr, B, tq, s))) return rc;
+  {
+    ScopedKernelTimer t(h, "group", s);
+    if ((rc = launch_group_by_relation(h, e1, rel, e1_rows != nullptr, B, tq, s))) return rc;
+  }
   if (h->enc_bf16) {
 #ifdef COPER_NO_FUSED_DENSE
     const bool fused = false;
@@ -710,7 +713,10 @@ COPER_API int coper_encode_rank(coper_handle* h, const int64_t* e1, const int64_
   if (!n_equal && tail_fused_supported(h)) {
     // ranks only (what the reference computes): finalize, targets and the filter correction in ONE launch
     // (kernels_tail_bf16.hip) that leaves ranks = 1 - (known answers above the target); the count kernel adds to it
-    if ((rc = launch_finalize_targets_filter_bf16x3(h, B, ksplit, h_out, e2, filt_indptr, filt_idx, h->tgt_ws, ranks, s))) return rc;
+    {
+      ScopedKernelTimer t(h, "tail", s);
+      if ((rc = launch_finalize_targets_filter_bf16x3(h, B, ksplit, h_out, e2, filt_indptr, filt_idx, h->tgt_ws, ranks, s))) return rc;
+    }
     h->packed_hvec = h->tgt_ws;
     h->packed_B = B;
     h->counts_preset = ranks;

@@ -19,6 +19,8 @@
 //      pred[e2] = target, metrics.py:45-46).
 #include "coper_internal.h"
 #include "conv_fold.h"
+#include <algorithm>
+#include <vector>
 
 namespace coper {
 
@@ -69,6 +71,19 @@ __device__ __forceinline__ f32x16 tail_tile(const uint4* __restrict__ Ehi, const
 #endif
 constexpr int TL_WAVES = COPER_TL_WAVES;   // waves per 32-query block: they share the finalize and deal the filter tiles among themselves
 
+#ifdef COPER_DBG_TL_CLOCK
+// diagnostic build (tools/ab_build.py): s_memrealtime (100 MHz) at the phase boundaries of wave 0 of every workgroup;
+// g_tl_clk[blk] = {kernel-relative start, after finalize, after the fragment exchange, after the targets, after the filter
+// tiles, end}.  No output depends on them.
+constexpr int TL_NSTAMP = 6;
+__device__ unsigned long long g_tl_clk[TL_NSTAMP * 1024];
+__device__ unsigned long long g_tl_t0;
+#define TL_STAMP(i_)                                                                                         \
+  if (threadIdx.x == 0 && blockIdx.x < 1024) g_tl_clk[TL_NSTAMP * blockIdx.x + (i_)] = __builtin_amdgcn_s_memrealtime();
+#else
+#define TL_STAMP(i_)
+#endif
+
 template <int KS>
 __global__ __launch_bounds__(64 * TL_WAVES) void k_finalize_targets_filter_bf16x3(
     const float* __restrict__ z_part, int ksplit, int64_t Bcap, int64_t B, int d, int d_pad16, const int32_t* __restrict__ inv_perm,
@@ -80,10 +95,17 @@ __global__ __launch_bounds__(64 * TL_WAVES) void k_finalize_targets_filter_bf16x
   __shared__ uint4 s_bh[KS][64], s_bl[KS][64];   // the block's B-operand fragments (hi / lo), shared by the waves
   __shared__ int64_t s_e[TL_WAVES][32];
   __shared__ int s_corr[32];
+  __shared__ float s_t[32];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, i = lane & 31, half = lane >> 5;
   const int64_t blk = blockIdx.x, q0 = blk * 32, q = q0 + i;
   const bool live = q < B;
   if (threadIdx.x < 32) s_corr[threadIdx.x] = 0;
+  TL_STAMP(0);
+  // ids of the later phases, requested before the finalize so that their latency lies under it
+  const int64_t my_e2 = live ? e2[q] : -1;
+  const int64_t qe = q0 + 32 < B ? q0 + 32 : B;
+  const int64_t p_begin = q0 < B ? indptr[q0] : 0, p_end = q0 < B ? indptr[qe] : 0;
+  const int64_t my_lo = live ? indptr[q] : p_end;   // first entry of query i (lane i), for the search in filter_tile
 
   // ---- 1. finalize: wave w takes k-steps w, w + 4, ...; a lane computes piece (ks, half) of its query
   {
@@ -143,37 +165,26 @@ __global__ __launch_bounds__(64 * TL_WAVES) void k_finalize_targets_filter_bf16x
       s_bl[ks][lane] = l4;
     }
   }
+  TL_STAMP(1);
   __syncthreads();
   uint4 bh[KS], bl[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) { bh[ks] = s_bh[ks][lane]; bl[ks] = s_bl[ks][lane]; }
+  TL_STAMP(2);
 
-  // ---- 2. targets: pair i = (query i, e2[query i]), the diagonal of the tile; every wave computes it for itself (32
-  // gathered rows: cheaper than handing the targets from one wave to the others)
-  const int64_t my_e2 = live ? e2[q] : -1;
+  // ---- 2. + 3. items of the block, dealt to the waves round-robin: item 0 = the targets (pair i = (query i, e2[query i]),
+  // the diagonal of the tile), item 1 + n = the n-th tile of 32 CSR entries of these queries ([indptr[q0], indptr[min(q0 + 32,
+  // B)]) is contiguous).  Round 0 runs in parallel -- wave 0 the targets, waves 1.. the first tiles, their comparisons held
+  // back until the targets are published through LDS.  Phases of a workgroup (COPER_DBG_TL_CLOCK build, tools/ab_tail.py;
+  // all 640 workgroups of an FB15k-237-shaped pass are resident at once and move in step): finalize 10.7 us (the 34 MB of
+  // K-slice partial sums), round 0 10.7 us, the remaining tiles 7 us for the median workgroup, 13 us for the one with the
+  // most entries -- 42 us per launch.  With every wave computing the targets first: 7.6 us for them alone, then two tile
+  // rounds of 7.7 us, 43 us per launch: the gathers of a round queue behind one another (the kernel is a sequence of
+  // chip-wide bursts of 16-byte gathers), so shortening the chain of one workgroup moves the median, not the end.
   int64_t erow = my_e2;
   if (erow < 0 || erow >= n_local) erow = -1;
-  if (half == 0) s_e[wave][i] = erow;
-  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): wave-local LDS exchange
-  __builtin_amdgcn_wave_barrier();
-  f32x16 acc = tail_tile<KS>(Ehi, Elo, bias_pad, s_e[wave], erow, bh, bl, half);
-  // D[i][i] sits in lane i + 32 * ((i >> 2) & 1), register (i & 3) + 4 * (i >> 3)
-  float diag = 0.f;
-  {
-    const int reg = (i & 3) + 4 * (i >> 3);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) diag = (r == reg) ? acc[r] : diag;
-  }
-  float t = __shfl(diag, i + 32 * ((i >> 2) & 1));   // lane i (both halves): the target of query i
-  t = erow >= 0 ? t : 0.f;
-  if (wave == 0 && half == 0 && live) tgt[q] = t;
-
-  // ---- 3. known answers of these queries: CSR entries [indptr[q0], indptr[min(q0 + 32, B)]), 32 per tile, tiles dealt
-  // to the waves round-robin
-  const int64_t qe = q0 + 32 < B ? q0 + 32 : B;
-  const int64_t p_begin = q0 < B ? indptr[q0] : 0, p_end = q0 < B ? indptr[qe] : 0;
-  const int64_t my_lo = live ? indptr[q] : p_end;   // first entry of query i (lane i), for the search below
-  for (int64_t pb = p_begin + 32 * wave; pb < p_end; pb += 32 * TL_WAVES) {
+  // one tile of entries [pb, pb + 32): (score of entry i against its own query, that query, the entry's row or -1)
+  auto filter_tile = [&](const int64_t pb, float& sc, int& qi_out) -> int64_t {
     const int64_t p = pb + i;
     // every lane runs the same cross-lane reads (a shuffle must not sit in divergent code: inactive lanes supply nothing);
     // lanes past the last entry carry frow = -1
@@ -198,24 +209,82 @@ __global__ __launch_bounds__(64 * TL_WAVES) void k_finalize_targets_filter_bf16x
     }
     __builtin_amdgcn_wave_barrier();
     if (half == 0) s_e[wave][i] = frow;
-    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): wave-local LDS exchange
     __builtin_amdgcn_wave_barrier();
-    acc = tail_tile<KS>(Ehi, Elo, bias_pad, s_e[wave], frow, bh, bl, half);
+    const f32x16 acc = tail_tile<KS>(Ehi, Elo, bias_pad, s_e[wave], frow, bh, bl, half);
     // entry i wants D[i][qi]: register (i & 3) + 4 * (i >> 3) of lane qi + 32 * ((i >> 2) & 1)
     const int src = qi + 32 * ((i >> 2) & 1);
     const int reg = (i & 3) + 4 * (i >> 3);
-    float sc = 0.f;
+    sc = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float v = __shfl(acc[r], src);
       sc = (r == reg) ? v : sc;
     }
+    qi_out = qi;
+    return frow;
+  };
+  float sc0 = 0.f;
+  int qi0 = 0;
+  int64_t frow0 = -1;
+  if (wave == 0) {   // (wave-uniform branches: the shuffles inside run with every lane)
+    if (half == 0) s_e[0][i] = erow;
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    const f32x16 acc = tail_tile<KS>(Ehi, Elo, bias_pad, s_e[0], erow, bh, bl, half);
+    // D[i][i] sits in lane i + 32 * ((i >> 2) & 1), register (i & 3) + 4 * (i >> 3)
+    float diag = 0.f;
+    const int reg = (i & 3) + 4 * (i >> 3);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) diag = (r == reg) ? acc[r] : diag;
+    float t0 = __shfl(diag, i + 32 * ((i >> 2) & 1));   // lane i (both halves): the target of query i
+    t0 = erow >= 0 ? t0 : 0.f;
+    if (half == 0) {
+      s_t[i] = t0;
+      if (live) tgt[q] = t0;
+    }
+  } else {
+    const int64_t pb = p_begin + 32 * (int64_t)(wave - 1);
+    if (pb < p_end) frow0 = filter_tile(pb, sc0, qi0);
+  }
+  TL_STAMP(3);
+  __syncthreads();
+  const float t = s_t[i];
+  {
+    const float tq = __shfl(t, qi0);
+    if (half == 0 && frow0 >= 0 && sc0 > tq) atomicAdd(&s_corr[qi0], 1);
+  }
+  for (int64_t pb = p_begin + 32 * (int64_t)(TL_WAVES - 1 + wave); pb < p_end; pb += 32 * TL_WAVES) {
+    float sc;
+    int qi;
+    const int64_t frow = filter_tile(pb, sc, qi);
     const float tq = __shfl(t, qi);
     if (half == 0 && frow >= 0 && sc > tq) atomicAdd(&s_corr[qi], 1);
   }
+  TL_STAMP(4);
   __syncthreads();
   if (wave == 0 && half == 0 && live) ranks[q] = 1 - s_corr[i];
+  TL_STAMP(5);
 }
+
+#ifdef COPER_DBG_TL_CLOCK
+extern "C" __attribute__((visibility("default"))) int coper_dbg_tl_clock(int n_wg, double* out /* [TL_NSTAMP] medians, us from the earliest start */) {
+  static unsigned long long hbuf[TL_NSTAMP * 1024];
+  if (hipMemcpyFromSymbol(hbuf, HIP_SYMBOL(g_tl_clk), sizeof hbuf) != hipSuccess) return 1;
+  if (n_wg > 1024) n_wg = 1024;
+  unsigned long long t0 = ~0ull;
+  for (int i = 0; i < n_wg; ++i) if (hbuf[TL_NSTAMP * i] && hbuf[TL_NSTAMP * i] < t0) t0 = hbuf[TL_NSTAMP * i];
+  for (int j = 0; j < TL_NSTAMP; ++j) {
+    std::vector<double> v;
+    for (int i = 0; i < n_wg; ++i) if (hbuf[TL_NSTAMP * i]) v.push_back((double)(hbuf[TL_NSTAMP * i + j] - t0) * 0.01);
+    if (v.empty()) return 2;
+    std::sort(v.begin(), v.end());
+    out[j] = v[v.size() / 2];
+    out[TL_NSTAMP + j] = v.back();
+  }
+  return 0;
+}
+#endif
 
 bool tail_fused_supported(const coper_handle* h) {
   if (getenv("COPER_TAIL_UNFUSED")) return false;
