@@ -610,7 +610,7 @@ COPER_API int coper_rank_counts(coper_handle* h, const float* hvec, const float*
       }
       if (!h->blk_cnt_ws) {
         const size_t gv = (size_t)(h->dm.n_eblk * topk_nseg(h->dm.n_eblk));
-        if ((rc = dev_alloc(h, &h->blk_cnt_ws, 2 * gv)) || (rc = dev_alloc(h, &h->blk_off_ws, gv + 1))) return rc;
+        if ((rc = dev_alloc(h, &h->blk_cnt_ws, 2 * gv)) || (rc = dev_alloc(h, &h->blk_off_ws, gv + 1 + gv / 4096 + 2))) return rc;   // + chunk sums of the scan
       }
     }
   }

@@ -119,7 +119,7 @@ struct coper_handle {
   size_t cand_tau_cap = 0;
   int32_t* cand_sorted_ws = nullptr;  // candidate slots grouped by entity block, 32-padded per block
   int32_t* blk_cnt_ws = nullptr;  // [2 n_eblk] slots per block | scatter cursors
-  int32_t* blk_off_ws = nullptr;  // [n_eblk + 1]
+  int32_t* blk_off_ws = nullptr;  // [n_eblk + 1] (+ the scan's chunk sums)
   void* hfrag16_hi = nullptr;     // bf16x3: h hi / lo planes in fragment order
   void* hfrag16_lo = nullptr;
   void* hrm16_hi = nullptr;       //   row-major twins

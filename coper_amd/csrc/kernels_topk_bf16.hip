@@ -39,30 +39,63 @@ __device__ __forceinline__ uint32_t tk_key(float v) {
 }
 
 constexpr int TK_THREADS = 512;
+#ifndef COPER_TK_DEPTH
+#define COPER_TK_DEPTH 4
+#endif
+constexpr int TK_DEPTH = COPER_TK_DEPTH;   // 16-byte loads a thread keeps in flight per batch (two batches overlap).  Measured on
+// the 10M-entity table (threshold kernel, 4,096 queries): 4 -> 3.49 ms, 2 -> 3.60, 8 -> 4.03, 16 -> 4.60
 
-// One sweep of a thread's share of the block axis: gmax[block][query] read as float4 (4 queries of one block), eight
+// One sweep of a thread's share of the block axis: gmax[block][query] read as float4 (4 queries of one block), TK_DEPTH
 // loads per batch and the next batch in flight while the current one is consumed (the sweeps are latency-bound).
 template <typename F>
 __device__ __forceinline__ void tk_sweep(const float4* __restrict__ col, int64_t qs4, int64_t g_lo, int64_t g_hi, F&& f) {
+  constexpr int D = TK_DEPTH;
   int64_t g = g_lo;
-  if (g + 8 <= g_hi) {
-    float4 cur[8];
+  if (g + D <= g_hi) {
+    float4 cur[D];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) cur[u] = col[(g + u) * qs4];
-    for (; g + 16 <= g_hi; g += 8) {
-      float4 nxt[8];
+    for (int u = 0; u < D; ++u) cur[u] = col[(g + u) * qs4];
+    for (; g + 2 * D <= g_hi; g += D) {
+      float4 nxt[D];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) nxt[u] = col[(g + 8 + u) * qs4];
+      for (int u = 0; u < D; ++u) nxt[u] = col[(g + D + u) * qs4];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) f(g + u, cur[u]);
+      for (int u = 0; u < D; ++u) f(g + u, cur[u]);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) cur[u] = nxt[u];
+      for (int u = 0; u < D; ++u) cur[u] = nxt[u];
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) f(g + u, cur[u]);
-    g += 8;
+    for (int u = 0; u < D; ++u) f(g + u, cur[u]);
+    g += D;
   }
   for (; g < g_hi; ++g) f(g, col[g * qs4]);
+}
+
+// The same, for the blocks g = first, first + step, ...: at any moment the threads of a workgroup -- and the workgroups of
+// the other strips, which move through the block axis at the same pace -- read neighbouring rows of gmax.  For the sweeps
+// whose result does not depend on the visiting order: histograms, and the fast path's emission (slots by counter, ties by id).
+template <typename F>
+__device__ __forceinline__ void tk_sweep_strided(const float4* __restrict__ col, int64_t qs4, int64_t first, int64_t step, int64_t G, F&& f) {
+  constexpr int D = TK_DEPTH;
+  int64_t g = first;
+  if (g + (D - 1) * step < G) {
+    float4 cur[D];
+#pragma unroll
+    for (int u = 0; u < D; ++u) cur[u] = col[(g + u * step) * qs4];
+    for (; g + (2 * D - 1) * step < G; g += D * step) {
+      float4 nxt[D];
+#pragma unroll
+      for (int u = 0; u < D; ++u) nxt[u] = col[(g + (D + u) * step) * qs4];
+#pragma unroll
+      for (int u = 0; u < D; ++u) f(g + u * step, cur[u]);
+#pragma unroll
+      for (int u = 0; u < D; ++u) cur[u] = nxt[u];
+    }
+#pragma unroll
+    for (int u = 0; u < D; ++u) f(g + u * step, cur[u]);
+    g += D * step;
+  }
+  for (; g < G; g += step) f(g, col[g * qs4]);
 }
 
 constexpr int TK_BIN = 64;   // block maxima per query that may share the threshold's upper 16 bits on the fast path
@@ -76,12 +109,23 @@ constexpr int TK_BIN = 64;   // block maxima per query that may share the thresh
 //         its first `rem` entries complete the m candidates.
 // A bin with more than TK_BIN blocks (heavy ties, clustered maxima) takes the general route instead: two more radix
 // digits, a counting sweep and an ordered emission sweep, rewriting the strip's slots.
+#ifdef COPER_DBG_TK_OVER
+// diagnostic build: strips that left the fast path (a query of the strip has more than TK_BIN maxima in its threshold bin)
+__device__ int g_tk_over;
+extern "C" __attribute__((visibility("default"))) int coper_dbg_tk_over() {
+  int v = -1, z = 0;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_tk_over), sizeof v) != hipSuccess) return -1;
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tk_over), &z, sizeof z);
+  return v;
+}
+#endif
+
 template <int QV, int HCOPY>
 __global__ __launch_bounds__(TK_THREADS) void k_topk_threshold_emit(const float* __restrict__ gmax, int64_t G, int64_t Qs, int64_t q0,
                                                                     int64_t Bc, int k, const int64_t* __restrict__ indptr,
                                                                     int32_t* __restrict__ cand_blk, int32_t* __restrict__ cand_q,
                                                                     int32_t* __restrict__ blk_cnt, int nseg,
-                                                                    uint32_t* __restrict__ cand_tau) {
+                                                                    uint32_t* __restrict__ cand_tau, int pair_xcd) {
   constexpr int NQS = 4 * QV, SUB = TK_THREADS / QV;
   extern __shared__ uint32_t tk_lds[];
   uint32_t* hist = tk_lds;                               // [HCOPY][256 digits][NQS]
@@ -94,7 +138,12 @@ __global__ __launch_bounds__(TK_THREADS) void k_topk_threshold_emit(const float*
   uint32_t* s_bkey = s_ceq + SUB * NQS;                  // [NQS][TK_BIN]
   int32_t* s_bg = (int32_t*)(s_bkey + NQS * TK_BIN);     // [NQS][TK_BIN]
   const int qv = threadIdx.x % QV, sr = threadIdx.x / QV;
-  const int64_t qs0 = (int64_t)blockIdx.x * NQS;         // first query of the strip within the chunk
+  // 16-query strips are 64 B of a 128-B line of gmax: the two strips of a line go to workgroups 8 apart, i.e. to the same
+  // XCD (workgroup w runs on XCD w % 8) -- one L2 then fetches the line once, where neighbouring workgroups (two XCDs)
+  // fetched it twice
+  int64_t strip = blockIdx.x;
+  if (QV == 4 && pair_xcd && (gridDim.x & 15) == 0) strip = (((int64_t)blockIdx.x >> 4) * 8 + (blockIdx.x & 7)) * 2 + ((blockIdx.x >> 3) & 1);
+  const int64_t qs0 = strip * NQS;                       // first query of the strip within the chunk
   const int64_t gs = (G + SUB - 1) / SUB;
   const int64_t g_lo = sr * gs < G ? sr * gs : G;
   const int64_t g_hi = g_lo + gs < G ? g_lo + gs : G;
@@ -128,6 +177,14 @@ __global__ __launch_bounds__(TK_THREADS) void k_topk_threshold_emit(const float*
       slots[c] = (int64_t)k + (indptr[qg + 1] - indptr[0] - beg);
     }
   }
+  // a sweep whose result does not depend on the visiting order (COPER_TK_BLOCKED_SWEEPS: A/B build with contiguous ranges)
+  auto sweep_any_order = [&](auto&& f) {
+#ifdef COPER_TK_BLOCKED_SWEEPS
+    tk_sweep(col, qs4, g_lo, g_hi, f);
+#else
+    tk_sweep_strided(col, qs4, (int64_t)sr, (int64_t)SUB, G, f);
+#endif
+  };
   uint32_t* myhist = hist + (sr % HCOPY) * 256 * NQS + 4 * qv;
   uint32_t mask = 0;
   auto radix_pass = [&](int pass) {
@@ -137,14 +194,29 @@ __global__ __launch_bounds__(TK_THREADS) void k_topk_threshold_emit(const float*
     uint32_t prefix[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) prefix[c] = s_prefix[4 * qv + c];
-    tk_sweep(col, qs4, g_lo, g_hi, [&](int64_t, const float4& v4) {
+    // block maxima cluster: consecutive values of a query mostly share the digit (in the first pass -- sign and the upper
+    // exponent bits -- nearly all of them), so a thread counts runs in registers and adds a run at once; one LDS atomic per
+    // value on a handful of addresses was what the sweep spent its time on
+    uint32_t run_d[4] = {0, 0, 0, 0}, run_n[4] = {0, 0, 0, 0};
+    sweep_any_order([&](int64_t, const float4& v4) {
       const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const uint32_t key = tk_key(vv[c]);
-        if ((key & mask) == prefix[c]) atomicAdd(&myhist[((key >> shift) & 255) * NQS + c], 1u);
+        if ((key & mask) == prefix[c]) {
+          const uint32_t dgt = (key >> shift) & 255;
+          if (dgt != run_d[c]) {
+            if (run_n[c]) atomicAdd(&myhist[run_d[c] * NQS + c], run_n[c]);
+            run_d[c] = dgt;
+            run_n[c] = 0;
+          }
+          ++run_n[c];
+        }
       }
     });
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (run_n[c]) atomicAdd(&myhist[run_d[c] * NQS + c], run_n[c]);
     __syncthreads();
     if (threadIdx.x < NQS) {
       const int qi = threadIdx.x;
@@ -178,7 +250,7 @@ __global__ __launch_bounds__(TK_THREADS) void k_topk_threshold_emit(const float*
       p16[c] = s_prefix[4 * qv + c] >> 16;
       live[c] = valid[c] && s_rem[4 * qv + c] > 0;
     }
-    tk_sweep(col, qs4, g_lo, g_hi, [&](int64_t g, const float4& v4) {
+    sweep_any_order([&](int64_t g, const float4& v4) {
       const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
@@ -234,6 +306,9 @@ __global__ __launch_bounds__(TK_THREADS) void k_topk_threshold_emit(const float*
       }
     }
   } else {
+#ifdef COPER_DBG_TK_OVER
+    if (threadIdx.x == 0) atomicAdd(&g_tk_over, 1);
+#endif
     // ---- general route: the remaining two digits, then count and emit in block order
     radix_pass(2);
     radix_pass(3);
@@ -324,6 +399,99 @@ __global__ __launch_bounds__(1024) void k_topk_blk_scan(const int32_t* __restric
   int32_t run = part[threadIdx.x] - sum;
   for (int64_t g = lo_g; g < hi_g; ++g) { blk_off[g] = run; run += (blk_cnt[g] + 31) & ~31; }
   if (threadIdx.x == 1023) blk_off[G] = part[1023];
+}
+
+// Long block axes (the 10M-entity table: 312,500 counters): the same exclusive scan in three coalesced launches -- chunk sums,
+// a scan of the chunk sums, chunk-local scans.  The single workgroup above walks 305 counters per thread with a stride of
+// 1.2 KB between lanes: 0.58 ms; these take ~0.02 ms together.
+constexpr int TK_SCAN_CHUNK = 4096;   // counters per workgroup: 256 threads x 16
+__global__ __launch_bounds__(256) void k_topk_blk_chunk_sums(const int32_t* __restrict__ blk_cnt, int64_t G, int32_t* __restrict__ chunk_sum) {
+  __shared__ int32_t red[256];
+  const int64_t base = (int64_t)blockIdx.x * TK_SCAN_CHUNK;
+  int32_t sum = 0;
+#pragma unroll
+  for (int j = 0; j < TK_SCAN_CHUNK / 256; ++j) {
+    const int64_t g = base + threadIdx.x + 256 * j;
+    if (g < G) sum += (blk_cnt[g] + 31) & ~31;
+  }
+  red[threadIdx.x] = sum;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) chunk_sum[blockIdx.x] = red[0];
+}
+
+// exclusive scan of the chunk sums in place (one workgroup; any number of chunks), total -> blk_off[G]
+__global__ __launch_bounds__(1024) void k_topk_blk_chunk_scan(int32_t* __restrict__ chunk_sum, int nchunk, int32_t* __restrict__ total_out) {
+  __shared__ int32_t part[1024];
+  __shared__ int32_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int c0 = 0; c0 < nchunk; c0 += 1024) {
+    const int i = c0 + threadIdx.x;
+    const int32_t v = i < nchunk ? chunk_sum[i] : 0;
+    part[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      const int32_t add = (int)threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+      __syncthreads();
+      part[threadIdx.x] += add;
+      __syncthreads();
+    }
+    if (i < nchunk) chunk_sum[i] = carry + part[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += part[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total_out = carry;
+}
+
+__global__ __launch_bounds__(256) void k_topk_blk_chunk_apply(const int32_t* __restrict__ blk_cnt, int64_t G, const int32_t* __restrict__ chunk_off,
+                                                              int32_t* __restrict__ blk_off) {
+  __shared__ int32_t v[TK_SCAN_CHUNK];
+  __shared__ int32_t tsum[256];
+  const int64_t base = (int64_t)blockIdx.x * TK_SCAN_CHUNK;
+#pragma unroll
+  for (int j = 0; j < TK_SCAN_CHUNK / 256; ++j) {
+    const int64_t g = base + threadIdx.x + 256 * j;
+    v[threadIdx.x + 256 * j] = g < G ? ((blk_cnt[g] + 31) & ~31) : 0;
+  }
+  __syncthreads();
+  // thread t owns counters [16 t, 16 t + 16) of the chunk
+  int32_t loc[16], s = 0;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) { loc[j] = s; s += v[16 * threadIdx.x + j]; }
+  tsum[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {
+    const int32_t add = (int)threadIdx.x >= o ? tsum[threadIdx.x - o] : 0;
+    __syncthreads();
+    tsum[threadIdx.x] += add;
+    __syncthreads();
+  }
+  const int32_t off = chunk_off[blockIdx.x] + tsum[threadIdx.x] - s;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) v[16 * threadIdx.x + j] = off + loc[j];
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < TK_SCAN_CHUNK / 256; ++j) {
+    const int64_t g = base + threadIdx.x + 256 * j;
+    if (g < G) blk_off[g] = v[threadIdx.x + 256 * j];
+  }
+}
+
+// blk_off[0..GV] from blk_cnt[0..GV): one workgroup for short axes, three coalesced launches for long ones (chunk sums in `tmp`)
+static void tk_launch_blk_scan(const int32_t* blk_cnt, int64_t GV, int32_t* blk_off, int32_t* tmp, int64_t tmp_cap, hipStream_t s) {
+  const int64_t nchunk = (GV + TK_SCAN_CHUNK - 1) / TK_SCAN_CHUNK;
+  if (GV <= 4 * TK_SCAN_CHUNK || !tmp || nchunk > tmp_cap) {
+    hipLaunchKernelGGL(k_topk_blk_scan, dim3(1), dim3(1024), 0, s, blk_cnt, GV, blk_off);
+    return;
+  }
+  hipLaunchKernelGGL(k_topk_blk_chunk_sums, dim3((unsigned)nchunk), dim3(256), 0, s, blk_cnt, GV, tmp);
+  hipLaunchKernelGGL(k_topk_blk_chunk_scan, dim3(1), dim3(1024), 0, s, tmp, (int)nchunk, blk_off + GV);
+  hipLaunchKernelGGL(k_topk_blk_chunk_apply, dim3((unsigned)nchunk), dim3(256), 0, s, blk_cnt, GV, tmp, blk_off);
 }
 
 __global__ __launch_bounds__(256) void k_topk_blk_scatter(const int32_t* __restrict__ cand_blk, int64_t T, const int32_t* __restrict__ blk_off,
@@ -489,6 +657,11 @@ __global__ __launch_bounds__(256) void k_topk_select_cand(float* __restrict__ ca
   }
 }
 
+static bool tk_pair_xcd() {
+  static const bool on = getenv("COPER_TK_NO_XCD_PAIRS") == nullptr;   // A/B switch
+  return on;
+}
+
 template <int QV, int HCOPY>
 static void tk_launch_emit(coper_handle* h, int64_t G, int64_t qs, int64_t q0, int64_t bc, int k, const int64_t* indptr, hipStream_t s) {
   const size_t lds = tk_emit_lds<QV, HCOPY>();
@@ -499,7 +672,20 @@ static void tk_launch_emit(coper_handle* h, int64_t G, int64_t qs, int64_t q0, i
     attr_done |= bit;
   }
   hipLaunchKernelGGL((k_topk_threshold_emit<QV, HCOPY>), dim3((unsigned)(qs / (4 * QV))), dim3(TK_THREADS), lds, s, h->gmax_ws, G, qs, q0, bc,
-                     k, indptr, h->cand_blk_ws, h->cand_q_ws, h->blk_cnt_ws, topk_nseg(G), h->cand_tau_ws);
+                     k, indptr, h->cand_blk_ws, h->cand_q_ws, h->blk_cnt_ws, topk_nseg(G), h->cand_tau_ws, tk_pair_xcd() ? 1 : 0);
+}
+
+// strip width / histogram copies of the threshold kernel by shape
+static void tk_dispatch_emit(coper_handle* h, int64_t G, int64_t qs, int64_t q0, int64_t bc, int k, const int64_t* indptr, hipStream_t s) {
+  static const char* force = getenv("COPER_TK_EMIT");   // experiments: "8_1", "8_2", "4_4"
+  if (force && force[0] == '8' && force[2] == '1') return tk_launch_emit<8, 1>(h, G, qs, q0, bc, k, indptr, s);
+  if (force && force[0] == '8' && force[2] == '2') return tk_launch_emit<8, 2>(h, G, qs, q0, bc, k, indptr, s);
+  if (force && force[0] == '4') return tk_launch_emit<4, 4>(h, G, qs, q0, bc, k, indptr, s);
+  // long block axis: more histogram copies; half-width strips (twice the workgroups) when 32-query strips would
+  // not cover the chip
+  if (G < 4096) tk_launch_emit<8, 1>(h, G, qs, q0, bc, k, indptr, s);
+  else if (qs / 32 >= h->num_cus) tk_launch_emit<8, 2>(h, G, qs, q0, bc, k, indptr, s);
+  else tk_launch_emit<4, 4>(h, G, qs, q0, bc, k, indptr, s);
 }
 
 int launch_topk_pruned_bf16x3(coper_handle* h, const float* tgt, const int64_t* e2, const int64_t* indptr, const int64_t* idx,
@@ -525,11 +711,9 @@ int launch_topk_pruned_bf16x3(coper_handle* h, const float* tgt, const int64_t* 
     if ((rc = score_count_chunk_bf16x3(h, q0, bc, tgt, ng, ne, h->gmax_ws, qs, s))) return rc;
     // long block axis: more histogram copies; half-width strips (twice the workgroups) when 32-query strips would
     // not cover the chip
-    if (G < 4096) tk_launch_emit<8, 1>(h, G, qs, q0, bc, k, indptr, s);
-    else if (qs / 32 >= h->num_cus) tk_launch_emit<8, 2>(h, G, qs, q0, bc, k, indptr, s);
-    else tk_launch_emit<4, 4>(h, G, qs, q0, bc, k, indptr, s);
+    tk_dispatch_emit(h, G, qs, q0, bc, k, indptr, s);
   }
-  hipLaunchKernelGGL(k_topk_blk_scan, dim3(1), dim3(1024), 0, s, h->blk_cnt_ws, GV, h->blk_off_ws);
+  tk_launch_blk_scan(h->blk_cnt_ws, GV, h->blk_off_ws, h->blk_off_ws + GV + 1, GV / TK_SCAN_CHUNK + 2, s);   // (chunk sums behind blk_off: reserved with it)
   hipLaunchKernelGGL(k_topk_blk_scatter, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, h->cand_blk_ws, T, h->blk_off_ws,
                      h->blk_cnt_ws + GV, nseg, h->cand_sorted_ws);
   const int64_t waves = topk_sorted_cap(GV, T) / 32;
@@ -562,9 +746,7 @@ int launch_topk_pruned_f32(coper_handle* h, const float* hvec, const float* tgt,
     const int64_t bc = B - q0 < qc ? B - q0 : qc;
     const int64_t qs = (bc + 127) / 128 * 128;
     if ((rc = score_count_chunk_f32(h, q0, bc, tgt, ng, ne, h->gmax_ws, qs, s))) return rc;
-    if (G < 4096) tk_launch_emit<8, 1>(h, G, qs, q0, bc, k, indptr, s);
-    else if (qs / 32 >= h->num_cus) tk_launch_emit<8, 2>(h, G, qs, q0, bc, k, indptr, s);
-    else tk_launch_emit<4, 4>(h, G, qs, q0, bc, k, indptr, s);
+    tk_dispatch_emit(h, G, qs, q0, bc, k, indptr, s);
   }
   if ((rc = launch_topk_score_blocks_f32(h, hvec, T, e2, indptr, idx, s))) return rc;
   hipLaunchKernelGGL(k_topk_select_cand, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s, h->cand_val_ws, h->cand_blk_ws, h->cand_tau_ws, indptr, B,

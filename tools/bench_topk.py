@@ -31,6 +31,12 @@ def run(name, Q, shard=None, big=False):
         for _ in range(5): m.rank_counts(h, tgt, dq["e2"], dq["filt_indptr"], dq["filt_idx"], k=k)
         torch.cuda.synchronize()
         print(name, shard, "k=%d" % k, "%.3f ms" % ((time.perf_counter() - t0) / 5 * 1e3), flush=True)
+        try:      # -DCOPER_DBG_TK_OVER build: strips of the threshold kernel that left the fast path (7 launches above)
+            import ctypes, os
+            lib = ctypes.CDLL(os.environ.get("COPER_HIP_LIB", ""))
+            print("    strips on the general route: %d of %d" % (lib.coper_dbg_tk_over(), 7 * ((Q + 15) // 16)))
+        except (OSError, AttributeError):
+            pass
     m.close()
 run("fb15k237_cpg", 20480)
 run("wn18rr_cpg", 3072)
