@@ -79,6 +79,7 @@ PROTOTYPES = {
     "coper_rank": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P]),
     "coper_encode_rank": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P]),
     "coper_check_ids": (C.c_int, [_P, C.POINTER(_I64), _P]),
+    "coper_live_device_bytes": (_I64, []),
     "coper_profile_enable": (C.c_int, [_P, C.c_int]),
     "coper_profile_read": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_I64)]),
     "coper_train_init": (C.c_int, [_P, C.POINTER(coper_train_config)]),

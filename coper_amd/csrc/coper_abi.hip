@@ -5,6 +5,8 @@
 #include <string.h>
 
 #include "coper_internal.h"
+#include <mutex>
+#include <unordered_map>
 
 static thread_local std::string g_create_error;
 
@@ -35,6 +37,33 @@ static hipEvent_t timer_event(coper_handle* h) {
     if (hipEventCreate(&e) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
   }
   return e;
+}
+
+static std::mutex g_ledger_mu;
+static std::unordered_map<void*, size_t> g_ledger;
+static int64_t g_ledger_bytes = 0;
+
+hipError_t tracked_malloc_impl(void** p, size_t bytes) {
+  const hipError_t e = hipMalloc(p, bytes);
+  if (e == hipSuccess && *p) {
+    std::lock_guard<std::mutex> lk(g_ledger_mu);
+    g_ledger[*p] = bytes;
+    g_ledger_bytes += (int64_t)bytes;
+  }
+  return e;
+}
+
+hipError_t tracked_free(void* p) {
+  if (!p) return hipSuccess;
+  {
+    std::lock_guard<std::mutex> lk(g_ledger_mu);
+    auto it = g_ledger.find(p);
+    if (it != g_ledger.end()) {
+      g_ledger_bytes -= (int64_t)it->second;
+      g_ledger.erase(it);
+    }
+  }
+  return hipFree(p);
 }
 
 ScopedKernelTimer::ScopedKernelTimer(coper_handle* h_, const char* n, hipStream_t s_) : h(h_), name(n), s(s_) {
@@ -85,9 +114,9 @@ static int64_t prod(const std::vector<int64_t>& v) {
 
 template <typename T>
 static int dev_alloc(coper_handle* h, T** p, size_t n) {
-  if (*p) { (void)hipFree(*p); *p = nullptr; }
+  if (*p) { (void)tracked_free(*p); *p = nullptr; }
   if (n == 0) n = 1;
-  hipError_t e = hipMalloc((void**)p, n * sizeof(T));
+  hipError_t e = tracked_malloc((void**)p, n * sizeof(T));
   if (e != hipSuccess) {
     *p = nullptr;
     (void)hipGetLastError();
@@ -100,7 +129,7 @@ static int dev_alloc(coper_handle* h, T** p, size_t n) {
 
 template <typename T>
 static void dev_free(T** p) {
-  if (*p) { (void)hipFree(*p); *p = nullptr; }
+  if (*p) { (void)tracked_free(*p); *p = nullptr; }
 }
 
 static int ensure_workspace(coper_handle* h, int64_t B, int64_t nnz, hipStream_t s) {
@@ -144,8 +173,8 @@ static int ensure_workspace(coper_handle* h, int64_t B, int64_t nnz, hipStream_t
     size_t plane = (size_t)((cap + 127) / 128) * 4 * dm.KS16 * 64 * 16;
     dev_free((char**)&h->hfrag16_hi); dev_free((char**)&h->hfrag16_lo);
     dev_free((char**)&h->hrm16_hi); dev_free((char**)&h->hrm16_lo);
-    if (hipMalloc(&h->hfrag16_hi, plane) != hipSuccess || hipMalloc(&h->hfrag16_lo, plane) != hipSuccess ||
-        hipMalloc(&h->hrm16_hi, plane) != hipSuccess || hipMalloc(&h->hrm16_lo, plane) != hipSuccess)
+    if (tracked_malloc(&h->hfrag16_hi, plane) != hipSuccess || tracked_malloc(&h->hfrag16_lo, plane) != hipSuccess ||
+        tracked_malloc(&h->hrm16_hi, plane) != hipSuccess || tracked_malloc(&h->hrm16_lo, plane) != hipSuccess)
       return fail(h, COPER_ENOMEM, "hipMalloc of the bf16 query planes failed");
   }
   h->ws_queries = cap;
@@ -421,7 +450,7 @@ COPER_API int coper_prepare(coper_handle* h, void* stream) {
   if (h->enc_bf16) {
     size_t plane = (size_t)h->Rw * dm.nfb * (dm.F_pad / 32) * 64 * 16;
     dev_free((char**)&h->Wf16_hi); dev_free((char**)&h->Wf16_lo);
-    if (hipMalloc(&h->Wf16_hi, plane) != hipSuccess || hipMalloc(&h->Wf16_lo, plane) != hipSuccess)
+    if (tracked_malloc(&h->Wf16_hi, plane) != hipSuccess || tracked_malloc(&h->Wf16_lo, plane) != hipSuccess)
       return fail(h, COPER_ENOMEM, "hipMalloc of the bf16 weight planes failed");
     if ((rc = launch_wfrag_to_bf16(h, h->Wf, h->Rw, h->Wf16_hi, h->Wf16_lo, s))) return rc;
     COPER_HIP_TRY(h, hipStreamSynchronize(s));
@@ -437,8 +466,8 @@ COPER_API int coper_prepare(coper_handle* h, void* stream) {
     size_t plane = (size_t)dm.n_eblk * dm.KS16 * 64 * 16;
     dev_free((char**)&h->Ef16_hi); dev_free((char**)&h->Ef16_lo);
     dev_free((char**)&h->Erm16_hi); dev_free((char**)&h->Erm16_lo);
-    if (hipMalloc(&h->Ef16_hi, plane) != hipSuccess || hipMalloc(&h->Ef16_lo, plane) != hipSuccess ||
-        hipMalloc(&h->Erm16_hi, plane) != hipSuccess || hipMalloc(&h->Erm16_lo, plane) != hipSuccess)
+    if (tracked_malloc(&h->Ef16_hi, plane) != hipSuccess || tracked_malloc(&h->Ef16_lo, plane) != hipSuccess ||
+        tracked_malloc(&h->Erm16_hi, plane) != hipSuccess || tracked_malloc(&h->Erm16_lo, plane) != hipSuccess)
       return fail(h, COPER_ENOMEM, "hipMalloc of the bf16 entity planes failed");
     if ((rc = dev_alloc(h, &h->bias_pad, (size_t)dm.n_eblk * 32))) return rc;
     if ((rc = launch_bias_pad(h, P("pred_bias"), s))) return rc;
@@ -753,6 +782,11 @@ COPER_API int coper_check_ids(coper_handle* h, int64_t* n_bad, void* stream) {
   COPER_HIP_TRY(h, hipStreamSynchronize((hipStream_t)stream));
   *n_bad = v;
   return COPER_OK;
+}
+
+COPER_API int64_t coper_live_device_bytes(void) {
+  std::lock_guard<std::mutex> lk(g_ledger_mu);
+  return g_ledger_bytes;
 }
 
 COPER_API int coper_profile_enable(coper_handle* h, int enable) {

@@ -11,6 +11,15 @@
 
 namespace coper {
 
+// every device allocation of the library goes through these two: a process-wide ledger (pointer -> bytes) behind
+// coper_live_device_bytes(), so that a leak shows up as a number and not as a guess from hipMemGetInfo (which also moves with
+// the runtime's own scratch and pool decisions)
+hipError_t tracked_malloc_impl(void** p, size_t bytes);
+hipError_t tracked_free(void* p);
+template <typename T>
+inline hipError_t tracked_malloc(T** p, size_t bytes) { return tracked_malloc_impl((void**)p, bytes); }
+
+
 struct Param {
   const float* ptr = nullptr;
   std::vector<int64_t> shape;

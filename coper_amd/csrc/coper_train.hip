@@ -90,8 +90,8 @@ namespace {
 
 template <typename T>
 int talloc(coper_handle* h, T** p, size_t n) {
-  if (*p) { (void)hipFree(*p); *p = nullptr; }
-  if (hipMalloc((void**)p, n * sizeof(T)) != hipSuccess) return fail(h, COPER_ENOMEM, "hipMalloc failed (training workspace)");
+  if (*p) { (void)tracked_free(*p); *p = nullptr; }
+  if (tracked_malloc((void**)p, n * sizeof(T)) != hipSuccess) return fail(h, COPER_ENOMEM, "hipMalloc failed (training workspace)");
   return COPER_OK;
 }
 
@@ -998,25 +998,25 @@ static int tg_matmul(coper_handle* h, TrainState* T, hipStream_t s, const MmView
 void train_destroy(coper_handle* h) {
   TrainState* T = (TrainState*)h->train;
   if (!T) return;
-  for (auto& t : T->tp) { (void)hipFree(t.g); (void)hipFree(t.m); (void)hipFree(t.v); (void)hipFree(t.vh); }
+  for (auto& t : T->tp) { (void)tracked_free(t.g); (void)tracked_free(t.m); (void)tracked_free(t.v); (void)tracked_free(t.vh); }
   for (TgPlanes* pl : {&T->pX, &T->pXt, &T->pP1, &T->pP3, &T->pTn, &T->pTb}) {
-    if (pl->hi) (void)hipFree(pl->hi);
-    if (pl->lo) (void)hipFree(pl->lo);
+    if (pl->hi) (void)tracked_free(pl->hi);
+    if (pl->lo) (void)tracked_free(pl->lo);
   }
   float* bufs[] = {T->Kt, T->Kbv, T->dKs, T->dkbs, T->Sd, T->img, T->y, T->x, T->c, T->A, T->dA, T->z0, T->z1, T->hv, T->dh, T->dz, T->ds, T->dx, T->dc, T->bnst, T->xc, T->dxc};
-  for (float* b : bufs) (void)hipFree(b);
+  for (float* b : bufs) (void)tracked_free(b);
   for (auto& ch : T->chain)
     for (int i = 0; i <= COPER_MAX_CTX; ++i) {
-      if (i > 0) (void)hipFree(ch.v[i]);
-      (void)hipFree(ch.dv[i]);
-      if (i < COPER_MAX_CTX) { (void)hipFree(ch.u[i]); (void)hipFree(ch.a[i]); (void)hipFree(ch.du[i]); (void)hipFree(ch.st[i]); }
+      if (i > 0) (void)tracked_free(ch.v[i]);
+      (void)tracked_free(ch.dv[i]);
+      if (i < COPER_MAX_CTX) { (void)tracked_free(ch.u[i]); (void)tracked_free(ch.a[i]); (void)tracked_free(ch.du[i]); (void)tracked_free(ch.st[i]); }
     }
-  (void)hipFree(T->red);
+  (void)tracked_free(T->red);
   for (TgPlanes* pl : {&T->mmX, &T->mmY}) {
-    if (pl->hi) (void)hipFree(pl->hi);
-    if (pl->lo) (void)hipFree(pl->lo);
+    if (pl->hi) (void)tracked_free(pl->hi);
+    if (pl->lo) (void)tracked_free(pl->lo);
   }
-  if (T->mmP) (void)hipFree(T->mmP);
+  if (T->mmP) (void)tracked_free(T->mmP);
   delete T;
   h->train = nullptr;
 }

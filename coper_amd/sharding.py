@@ -148,6 +148,8 @@ class EntityShardedRanker(object):
             return ranks, ne_tot.to(torch.int32)
         vals = allrec[:, :, 1:1 + k].to(torch.int32).view(torch.float32).permute(1, 0, 2).reshape(B, -1)
         ids = allrec[:, :, 1 + k:].permute(1, 0, 2).reshape(B, -1)
+        if self.world == 1:      # one shard: its list is already in (score desc, id asc) order
+            return ranks, ne_tot.to(torch.int32), vals.contiguous(), ids.contiguous()
         tv, ti = merge_topk(vals, ids, k)
         return ranks, ne_tot.to(torch.int32), tv, ti
 

@@ -190,6 +190,11 @@ COPER_API int coper_encode_rank(coper_handle* h, const int64_t* e1, const int64_
  * out-of-range relation ids seen by coper_encode since the last call (synchronises the stream). */
 COPER_API int coper_check_ids(coper_handle* h, int64_t* n_bad, void* stream);
 
+/* Device memory (bytes) currently held by all handles of this process: every allocation of the library is entered in a
+ * ledger.  Returns to its previous value when a handle is destroyed (tests/test_gpu_train.py checks exactly that).  The
+ * reference has no counterpart: TensorFlow owns its allocations (`tf.Session` of run_cpg.py:111). */
+COPER_API int64_t coper_live_device_bytes(void);
+
 COPER_API int coper_profile_enable(coper_handle* h, int enable);
 COPER_API int coper_profile_read(coper_handle* h, const char* kernel, double* total_ms, int64_t* launches);
 

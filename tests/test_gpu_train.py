@@ -311,8 +311,8 @@ def test_session_run_serves_the_training_fetches():
 
 def test_handles_release_their_device_memory():
     """coper_destroy gives back everything a handle allocated -- caches, workspaces, the training state (plane sets,
-    split-K partial sums, optimizer slots): 12 create / prepare / rank / train / destroy cycles leave the device's free memory
-    where it was."""
+    split-K partial sums, optimizer slots): after create / prepare / rank / top-k / train / destroy cycles the library's
+    allocation ledger (coper_live_device_bytes) is back where it was, to the byte."""
     from coper_amd.models import ConvE
     md = dict(cdata._COMMON)
     md.update(_CASES["cpg_wide"])
@@ -335,14 +335,24 @@ def test_handles_release_their_device_memory():
                           lookup_values=np.zeros((48, 0), np.int32)))
         m.close()
 
-    def free_after(n):
-        for i in range(n):
-            cycle("bf16x3" if i % 2 == 0 else "f32")
-        torch.cuda.synchronize(); torch.cuda.empty_cache()
-        return torch.cuda.mem_get_info()[0]
-
-    free0 = free_after(4)                 # first uses: library / allocator pools reach their steady size
-    free1 = free_after(8)
-    free2 = free_after(8)
-    print("free memory after 4 / 12 / 20 cycles:", free0, free1, free2)
-    assert free1 - free2 < (4 << 20), (free0, free1, free2)   # one handle of this size holds > 60 MB
+    from coper_amd import _lib
+    import gc
+    lib = _lib.load()
+    gc.collect()                              # handles earlier tests dropped without close()
+    base = lib.coper_live_device_bytes()      # other live handles of this process, if any
+    held = []
+    for i in range(6):
+        m = ConvE(md, device="cuda:0", score_mode="bf16x3" if i % 2 == 0 else "f32")
+        assert lib.coper_live_device_bytes() >= base
+        m.close()
+        cycle("bf16x3" if i % 2 == 0 else "f32")
+        held.append(lib.coper_live_device_bytes())
+    # the library's own ledger (every allocation it makes is entered there): exact, unlike hipMemGetInfo, which also moves
+    # with the runtime's scratch and pool decisions
+    assert held == [base] * len(held), (base, held)
+    m = ConvE(md, device="cuda:0")
+    m.load_parameters({k: v.clone() for k, v in p0.items()})
+    m.prepare()
+    assert lib.coper_live_device_bytes() - base > (8 << 20)     # a prepared handle of this size holds 24 MB
+    m.close()
+    assert lib.coper_live_device_bytes() == base
