@@ -1,0 +1,90 @@
+"""Seeded random model shapes through the whole path: sizes the BASELINE configs do not have --
+embedding sizes that are not multiples of 8 or 16, few or many channels, other filter sizes, tiny entity tables, single-query
+batches -- in both arithmetic modes.  Every case is checked against the fp64 oracle (h, logits) and for the consistency the
+kernels promise among themselves: the fused ranks equal the closed form on the library's own logits bit for bit, the
+pruned top-k equals the masked row top-k."""
+import numpy as np
+import pytest
+import torch
+
+from coper_amd import data as cdata
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_TOL = 1e-3      # north_star: "logits within 1e-3 fp32"
+H_TOL = 2e-4
+
+
+def _random_case(seed):
+    rng = np.random.default_rng(1000 + seed)
+    while True:
+        emb_h = int(rng.integers(3, 17))
+        emb_w = int(rng.integers(3, 25))
+        d = emb_h * emb_w
+        if d <= 320:      # coper_create: the 128-query tile of the count kernels has to fit in LDS
+            break
+    variant = ["cpg_fc", "cpg_conv_fc", "cpg_mlp", "lookup", "plain", "cpg_fc_concat"][seed % 6]
+    fh, fw = [(3, 3), (3, 3), (2, 2), (1, 3), (3, 2)][int(rng.integers(0, 5))]
+    C = int(rng.choice([4, 8, 16, 32, 32, 40]))
+    md = dict(cdata._COMMON)
+    md.update(num_ent=int(rng.choice([5, 31, 33, 64, 257, 700])), num_rel=int(rng.choice([2, 6, 22, 40])),
+              ent_emb_size=d, rel_emb_size=int(rng.choice([3, 8, 10])), emb_h=emb_h, emb_w=emb_w,
+              conv_filter_height=fh, conv_filter_width=fw, conv_num_channels=C)
+    if variant == "cpg_fc":
+        md.update(context_rel_conv=None, context_rel_out=[])
+    elif variant == "cpg_conv_fc":
+        md.update(context_rel_conv=[], context_rel_out=[])
+    elif variant == "cpg_mlp":
+        md.update(context_rel_conv=[5], context_rel_out=[7, 6])
+    elif variant == "lookup":
+        md.update(context_rel_conv=[], context_rel_out=[], do_parameter_lookup=True)
+    elif variant == "plain":    # the relation row is stacked under the entity image: same width, r = d
+        md.update(context_rel_conv=None, context_rel_out=None, rel_emb_size=d)
+    else:
+        md.update(context_rel_conv=None, context_rel_out=[], concat_rel=True)
+    Q = int(rng.choice([1, 31, 33, 129, 300, 520]))
+    return variant, md, Q
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_random_shapes_against_oracle(oracle_chain, seed):
+    from coper_amd.models import ConvE
+    O = oracle_chain
+    variant, md, Q = _random_case(seed)
+    p = cdata.synthetic_params(md, seed=seed)
+    q = cdata.synthetic_queries(md, Q, seed=seed)
+    E = md["num_ent"]
+    st = O.forward(p, md, q["e1"], q["rel"], np.float64, materialise=False)
+    ref_logits = O.score_all(st["h"], p["ent_emb"].astype(np.float64), p["pred_bias"].astype(np.float64))
+    mask = cdata.csr_to_dense_filter(q["filt_indptr"], q["filt_idx"], E).astype(bool)
+    for mode in ("f32", "bf16x3"):
+        m = ConvE(md, device="cuda:0", score_mode=mode)
+        m.load_parameters(p)
+        m.prepare()
+        h = m.encode(q["e1"], q["rel"])
+        assert np.abs(h.cpu().numpy() - st["h"]).max() < H_TOL, (variant, md, mode)
+        logits = m.score_all(h).cpu().numpy()
+        assert np.abs(logits - ref_logits).max() < LOGIT_TOL, (variant, md, mode)
+        # the fused pass (no logits) against the closed form on the library's own logits: the count kernels, the pair
+        # kernels and score_all compute the same bits
+        ranks, ne = m.rank_pass(q["e1"], q["rel"], q["e2"], q["filt_indptr"], q["filt_idx"])
+        tgt = logits[np.arange(Q), q["e2"]]
+        keep = ~mask
+        keep[np.arange(Q), q["e2"]] = False
+        want = 1 + ((logits > tgt[:, None]) & keep).sum(axis=1)
+        want_eq = ((logits == tgt[:, None]) & keep).sum(axis=1)
+        assert np.array_equal(ranks.cpu().numpy(), want), (variant, md, mode)
+        assert np.array_equal(ne.cpu().numpy(), want_eq), (variant, md, mode)
+        r0, _ = m.rank_pass(q["e1"], q["rel"], q["e2"], q["filt_indptr"], q["filt_idx"], want_equal=False)
+        assert torch.equal(r0, ranks)
+        # top-k of the filtered rows (known answers except the target masked), (score desc, id asc)
+        k = min(5, E)
+        out = m.rank_counts(h, m.target_scores(h, q["e2"]), q["e2"], q["filt_indptr"], q["filt_idx"], k=k)
+        masked = np.where(keep | (np.arange(E)[None, :] == q["e2"][:, None]), logits, -np.inf)
+        order = np.lexsort((np.broadcast_to(np.arange(E), masked.shape), -masked), axis=1)[:, :k]
+        want_val = np.take_along_axis(masked, order, axis=1)
+        got_val, got_idx = out[2].cpu().numpy(), out[3].cpu().numpy()
+        assert np.array_equal(got_val, want_val), (variant, md, mode)
+        finite = np.isfinite(want_val)
+        assert np.array_equal(got_idx[finite], order[finite]), (variant, md, mode)
+        m.close()

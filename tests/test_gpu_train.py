@@ -47,6 +47,38 @@ _CASES = {
 }
 
 
+def _fuzz_cases(n):
+    """Seeded random shapes for the training step: embedding sizes that are not multiples of 4 or 8, image shapes and channel
+    counts the fixed cases do not have, every model variant in turn."""
+    out = {}
+    for seed in range(n):
+        rng = np.random.default_rng(500 + seed)
+        emb_h, emb_w = int(rng.integers(3, 11)), int(rng.integers(3, 13))
+        d = emb_h * emb_w
+        # (coper_train_init serves 3 x 3 filters, channel counts that divide 256, d <= 256: the shapes the reference ships)
+        md = dict(num_ent=int(rng.choice([37, 130, 301])), num_rel=int(rng.choice([2, 6, 10])), ent_emb_size=d,
+                  rel_emb_size=int(rng.choice([3, 8])), emb_h=emb_h, emb_w=emb_w,
+                  conv_num_channels=int(rng.choice([4, 8, 16, 32])))
+        v = seed % 6
+        if v == 0:
+            md.update(context_rel_conv=None, context_rel_out=[])
+        elif v == 1:
+            md.update(context_rel_conv=[], context_rel_out=[])
+        elif v == 2:
+            md.update(context_rel_conv=[5], context_rel_out=[7], context_rel_use_batch_norm=bool(seed & 8), context_rel_dropout=0.1)
+        elif v == 3:
+            md.update(context_rel_conv=[], context_rel_out=[], do_parameter_lookup=True, rel_emb_size=1)
+        elif v == 4:
+            md.update(context_rel_conv=None, context_rel_out=None, rel_emb_size=d)
+        else:
+            md.update(context_rel_conv=None, context_rel_out=[], concat_rel=True)
+        out["fuzz_%02d" % seed] = md
+    return out
+
+
+_CASES.update(_fuzz_cases(12))
+
+
 def _batch(md, B, L, seed):
     rng = np.random.default_rng(seed)
     E, R = md["num_ent"], md["num_rel"]
