@@ -115,11 +115,12 @@ __global__ __launch_bounds__(256) void k_tr_conv_fwd(const int64_t* __restrict__
                                                      int64_t R, int d, int r, int in_h, int in_w, int stacked, int C, int Ho,
                                                      int Wo, float* __restrict__ img_out, float* __restrict__ c_out,
                                                      float* __restrict__ y, const float* __restrict__ K_ps,
-                                                     const float* __restrict__ kb_ps) {
-  extern __shared__ float lds[];  // img[in_h*in_w] | taps[9*C] | kb[C]
+                                                     const float* __restrict__ kb_ps, int fh, int fw) {
+  extern __shared__ float lds[];  // img[in_h*in_w] | taps[fh*fw*C] | kb[C]
+  const int nt = fh * fw;
   float* img = lds;
   float* taps = img + in_h * in_w;
-  float* bias = taps + 9 * C;
+  float* bias = taps + nt * C;
   const int64_t b = blockIdx.x;
   int64_t row = e1[b];
   if (row < 0 || row >= E) row = 0;
@@ -131,9 +132,9 @@ __global__ __launch_bounds__(256) void k_tr_conv_fwd(const int64_t* __restrict__
   if (c_out)
     for (int t = threadIdx.x; t < r; t += 256) c_out[b * r + t] = rel_emb[rid * r + t];
   // per-sample filters (generated / looked up, models.py:374-380) or the shared static ones
-  const float* Ksrc = K_ps ? K_ps + b * 9 * C : K;
+  const float* Ksrc = K_ps ? K_ps + b * (int64_t)nt * C : K;
   const float* bsrc = kb_ps ? kb_ps + b * C : kb;
-  for (int t = threadIdx.x; t < 9 * C; t += 256) taps[t] = Ksrc[t];
+  for (int t = threadIdx.x; t < nt * C; t += 256) taps[t] = Ksrc[t];
   for (int t = threadIdx.x; t < C; t += 256) bias[t] = bsrc[t];
   __syncthreads();
   const int isz = in_h * in_w;
@@ -144,10 +145,15 @@ __global__ __launch_bounds__(256) void k_tr_conv_fwd(const int64_t* __restrict__
     const int cc = idx % C, p = idx / C;
     const int i = p / Wo, j = p - i * Wo;
     float a = 0.f;
+    if (fh == 3 && fw == 3) {   // the shipped shape, unrolled; same summation order as the general loop
 #pragma unroll
-    for (int u = 0; u < 3; ++u)
+      for (int u = 0; u < 3; ++u)
 #pragma unroll
-      for (int v = 0; v < 3; ++v) a = fmaf(img[(i + u) * in_w + j + v], taps[(u * 3 + v) * C + cc], a);
+        for (int v = 0; v < 3; ++v) a = fmaf(img[(i + u) * in_w + j + v], taps[(u * 3 + v) * C + cc], a);
+    } else {
+      for (int u = 0; u < fh; ++u)
+        for (int v = 0; v < fw; ++v) a = fmaf(img[(i + u) * in_w + j + v], taps[(u * fw + v) * C + cc], a);
+    }
     yb[idx] = a + bias[cc];
   }
 }
@@ -332,7 +338,8 @@ __global__ __launch_bounds__(256) void k_tr_score_bwd(const float* __restrict__ 
                                                       int64_t E, int d, int64_t L, float* __restrict__ dh,
                                                       float* __restrict__ dE, float* __restrict__ dbias) {
   const int64_t b = blockIdx.x;
-  const int k = threadIdx.x;
+  for (int k0 = 0; k0 < d; k0 += 256) {   // a thread per feature, 256 features at a time (d <= 256: one trip)
+  const int k = k0 + threadIdx.x;
   const float hk = k < d ? hv[b * d + k] : 0.f;
   float acc = 0.f;
   int64_t l = 0;
@@ -353,7 +360,7 @@ __global__ __launch_bounds__(256) void k_tr_score_bwd(const float* __restrict__ 
       acc = fmaf(g[u], ev[u], acc);
       if (SCATTER) {
         if (k < d) atomicAdd(&dE[row[u] * d + k], g[u] * hk);
-        if (k == 0) atomicAdd(&dbias[row[u]], g[u]);
+        if (k == 0) atomicAdd(&dbias[row[u]], g[u]);   // (k == 0 only in the first trip)
       }
     }
   }
@@ -368,6 +375,7 @@ __global__ __launch_bounds__(256) void k_tr_score_bwd(const float* __restrict__ 
     if (SCATTER && k == 0) atomicAdd(&dbias[row], g);
   }
   if (k < d) dh[b * d + k] = acc;
+  }
 }
 
 // dh[b,:] = sum_l ds[b,l] E[lookup[b,l], :] without the scatter (the dense-route backward adds dE by a GEMM): the gather is
@@ -718,6 +726,28 @@ __global__ __launch_bounds__(256) void k_tr_bn1_bwd_sums(float* __restrict__ dx,
                                                          int64_t total, uint32_t seed, uint32_t step, uint32_t thr,
                                                          float keep_scale, double* __restrict__ sums) {
   __shared__ double s1[256], s2[256];
+  if (256 % C != 0) {
+    // channel counts that do not divide the workgroup: a thread meets every channel, so the channel sums are built in LDS
+    // (C <= 256 doubles per array) with one LDS atomic pair per element, then added to the global sums
+    for (int c = threadIdx.x; c < C; c += 256) { s1[c] = 0; s2[c] = 0; }
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+      const int c = (int)(i % C);
+      const float yh = (y[i] - mean[c]) * inv[c];
+      const float act = yh * gamma[c] + beta[c];
+      float g = dropout_keep_u32(seed, step, 1u, (uint32_t)i, thr) ? dx[i] * keep_scale : 0.f;
+      if (!(act > 0.f)) g = 0.f;
+      dx[i] = g;
+      atomicAdd(&s1[c], (double)g);
+      atomicAdd(&s2[c], (double)g * yh);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+      atomicAdd(&sums[c], s1[c]);
+      atomicAdd(&sums[C + c], s2[c]);
+    }
+    return;
+  }
   double a1 = 0, a2 = 0;
   // grid-stride: 256 % C == 0, so a thread stays on one channel and the channel sums are built in registers
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -730,7 +760,7 @@ __global__ __launch_bounds__(256) void k_tr_bn1_bwd_sums(float* __restrict__ dx,
     a1 += g;
     a2 += (double)g * yh;
   }
-  // 256 % C == 0 for the supported channel counts: threads with the same (threadIdx.x % C) share a channel
+  // 256 % C == 0 here: threads with the same (threadIdx.x % C) share a channel
   s1[threadIdx.x] = a1; s2[threadIdx.x] = a2;
   __syncthreads();
   for (int o = 128; o >= C; o >>= 1) {
@@ -771,28 +801,28 @@ __global__ __launch_bounds__(256) void k_tr_conv_bwd(const float* __restrict__ d
                                                      float* __restrict__ dK, float* __restrict__ dkb,
                                                      float* __restrict__ dE, float* __restrict__ drel,
                                                      const float* __restrict__ K_ps, float* __restrict__ dK_ps,
-                                                     float* __restrict__ dkb_ps) {
-  extern __shared__ float lds[];  // img[isz] | g[P*C] | taps[9*C]
-  const int isz = in_h * in_w, P = Ho * Wo;
+                                                     float* __restrict__ dkb_ps, int fh, int fw) {
+  extern __shared__ float lds[];  // img[isz] | g[P*C] | taps[fh*fw*C]
+  const int isz = in_h * in_w, P = Ho * Wo, nt = fh * fw;
   float* img = lds;
   float* g = img + isz;
   float* taps = g + P * C;
   const int64_t b = blockIdx.x;
   for (int t = threadIdx.x; t < isz; t += 256) img[t] = img_all[b * isz + t];
   for (int t = threadIdx.x; t < P * C; t += 256) g[t] = dy[b * (int64_t)P * C + t];
-  const float* Ksrc = K_ps ? K_ps + b * 9 * C : K;
-  for (int t = threadIdx.x; t < 9 * C; t += 256) taps[t] = Ksrc[t];
+  const float* Ksrc = K_ps ? K_ps + b * (int64_t)nt * C : K;
+  for (int t = threadIdx.x; t < nt * C; t += 256) taps[t] = Ksrc[t];
   __syncthreads();
   // filter and bias gradients: entry (tap, c) = sum_p img[p + tap offset] * g[p, c]
   // (per-sample filters: written per sample, reduced through the generator / table afterwards)
-  for (int idx = threadIdx.x; idx < 10 * C; idx += 256) {
+  for (int idx = threadIdx.x; idx < (nt + 1) * C; idx += 256) {
     const int cc = idx % C, tap = idx / C;
     float a = 0.f;
-    if (tap < 9) {
-      const int u = tap / 3, v = tap % 3;
+    if (tap < nt) {
+      const int u = tap / fw, v = tap % fw;
       for (int i = 0; i < Ho; ++i)
         for (int j = 0; j < Wo; ++j) a = fmaf(img[(i + u) * in_w + j + v], g[(i * Wo + j) * C + cc], a);
-      if (dK_ps) dK_ps[b * 9 * C + tap * C + cc] = a; else atomicAdd(&dK[tap * C + cc], a);
+      if (dK_ps) dK_ps[b * (int64_t)nt * C + tap * C + cc] = a; else atomicAdd(&dK[tap * C + cc], a);
     } else {
       for (int p = 0; p < P; ++p) a += g[p * C + cc];
       if (dkb_ps) dkb_ps[b * C + cc] = a; else atomicAdd(&dkb[cc], a);
@@ -806,14 +836,14 @@ __global__ __launch_bounds__(256) void k_tr_conv_bwd(const float* __restrict__ d
   for (int t = threadIdx.x; t < isz; t += 256) {
     const int ii = t / in_w, jj = t - ii * in_w;
     float a = 0.f;
-    for (int u = 0; u < 3; ++u) {
+    for (int u = 0; u < fh; ++u) {
       const int i = ii - u;
       if (i < 0 || i >= Ho) continue;
-      for (int v = 0; v < 3; ++v) {
+      for (int v = 0; v < fw; ++v) {
         const int j = jj - v;
         if (j < 0 || j >= Wo) continue;
         const float* gp = g + (i * Wo + j) * C;
-        const float* tp = taps + (u * 3 + v) * C;
+        const float* tp = taps + (u * fw + v) * C;
         for (int cc = 0; cc < C; ++cc) a = fmaf(gp[cc], tp[cc], a);
       }
     }
@@ -1033,8 +1063,8 @@ COPER_API int coper_train_init(coper_handle* h, const coper_train_config* cfg) {
   const Dims& dm = h->dm;
   if (h->cfg.shard_lo != 0 || h->cfg.shard_hi != dm.E)
     return fail(h, COPER_EUNSUPPORTED, "coper_train_init: training needs the whole entity table on the handle");
-  if (dm.fh != 3 || dm.fw != 3 || 256 % dm.C != 0 || dm.d > 256)
-    return fail(h, COPER_EUNSUPPORTED, "coper_train_init: 3x3 filters, C dividing 256, d <= 256");
+  if (dm.C > 256)
+    return fail(h, COPER_EUNSUPPORTED, "coper_train_init: at most 256 conv channels");
   if (!(cfg->learning_rate > 0) || cfg->hidden_dropout < 0 || cfg->hidden_dropout >= 1 || cfg->output_dropout < 0 ||
       cfg->output_dropout >= 1)
     return fail(h, COPER_EINVAL, "coper_train_init: bad hyper-parameter");
@@ -1127,7 +1157,7 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
   COPER_HIP_TRY(h, hipSetDevice(h->cfg.device));
   h->prepared = false;   // the variables change: per-relation caches, fragment images and folded BN go stale
   const coper_train_config& tc = T->cfg;
-  const int d = dm.d, r = dm.r, C = dm.C, P = dm.Ho * dm.Wo, isz = dm.in_h * dm.in_w;
+  const int d = dm.d, r = dm.r, C = dm.C, P = dm.Ho * dm.Wo, isz = dm.in_h * dm.in_w, NT = dm.fh * dm.fw;   // NT: filter taps
   const int64_t F = dm.F, Fc = dm.F_conv;   // dense input width (F_conv + r under concat_rel), conv features
   const bool cat = dm.concat_rel;
   const bool lk = dm.lookup && dm.gen_fc;    // dense layer from g_lookup tables (otherwise static: models.py:217-228 with context_rel_out None)
@@ -1172,8 +1202,8 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
           return rc;
       }
     }
-    if (dm.gen_conv && ((rc = talloc(h, &T->Kt, (size_t)cb * 9 * C)) || (rc = talloc(h, &T->Kbv, (size_t)cb * C)) ||
-                        (rc = talloc(h, &T->dKs, (size_t)cb * 9 * C)) || (rc = talloc(h, &T->dkbs, (size_t)cb * C))))
+    if (dm.gen_conv && ((rc = talloc(h, &T->Kt, (size_t)cb * NT * C)) || (rc = talloc(h, &T->Kbv, (size_t)cb * C)) ||
+                        (rc = talloc(h, &T->dKs, (size_t)cb * NT * C)) || (rc = talloc(h, &T->dkbs, (size_t)cb * C))))
       return rc;
     T->capB = cb; T->capL = cl;
   }
@@ -1257,19 +1287,19 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
     if ((rc = chain_forward(2, nhc)) || (rc = chain_forward(3, nhc))) return rc;
     ccw = nhc ? T->chain[2].v[nhc] : T->c;
     ccb = nhc ? T->chain[3].v[nhc] : T->c;
-    hipLaunchKernelGGL(k_tr_small_mm, dim3((unsigned)((B * 9 * C + 255) / 256)), dim3(256), 0, s, ccw, P_(cwlast.c_str()), B, rc_cw, 9 * C, T->Kt);
+    hipLaunchKernelGGL(k_tr_small_mm, dim3((unsigned)((B * NT * C + 255) / 256)), dim3(256), 0, s, ccw, P_(cwlast.c_str()), B, rc_cw, NT * C, T->Kt);
     hipLaunchKernelGGL(k_tr_small_mm, dim3((unsigned)((B * C + 255) / 256)), dim3(256), 0, s, ccb, P_(cblast.c_str()), B, rc_cb, C, T->Kbv);
   } else if (lkc) {
-    hipLaunchKernelGGL(k_tr_gather_rows, dim3((unsigned)((B * 9 * C + 255) / 256)), dim3(256), 0, s, P_("conv1_weights"), rel, dm.R, 9 * C,
-                       B * 9 * C, T->Kt);
+    hipLaunchKernelGGL(k_tr_gather_rows, dim3((unsigned)((B * NT * C + 255) / 256)), dim3(256), 0, s, P_("conv1_weights"), rel, dm.R, NT * C,
+                       B * NT * C, T->Kt);
     hipLaunchKernelGGL(k_tr_gather_rows, dim3((unsigned)((B * C + 255) / 256)), dim3(256), 0, s, P_("conv1_bias"), rel, dm.R, C, B * C, T->Kbv);
   }
   const float* K_ps = dm.gen_conv ? T->Kt : nullptr;
   const float* kb_ps = dm.gen_conv ? T->Kbv : nullptr;
-  size_t lds_conv = sizeof(float) * (size_t)(isz + 10 * C);
+  size_t lds_conv = sizeof(float) * (size_t)(isz + (NT + 1) * C);
   hipLaunchKernelGGL(k_tr_conv_fwd, dim3((unsigned)B), dim3(256), lds_conv, s, e1, rel, ent, relp, dm.gen_conv ? nullptr : P_("conv1_weights"),
                      dm.gen_conv ? nullptr : P_("conv1_bias"), dm.E, dm.R, d, r, dm.in_h, dm.in_w, dm.stacked ? 1 : 0, C, dm.Ho, dm.Wo, T->img,
-                     ((gen || cat) && !genc) ? T->c : nullptr, T->y, K_ps, kb_ps);
+                     ((gen || cat) && !genc) ? T->c : nullptr, T->y, K_ps, kb_ps, dm.fh, dm.fw);
   const int64_t nBF = B * Fc;
   if (use_batch) hipLaunchKernelGGL(k_tr_col_sums, dim3(256), dim3(256), 0, s, T->y, B * (int64_t)P, C, colsum);
   hipLaunchKernelGGL(k_tr_bn_finish, dim3((C + 63) / 64), dim3(64), 0, s, colsum, C, (double)B * P, use_batch,
@@ -1438,17 +1468,17 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
                      P_("Conv1BN/beta"), C, nBF, tc.seed, step, thr_h, ks_h, colsum);
   hipLaunchKernelGGL(k_tr_bn1_bwd_apply, dim3((unsigned)((nBF + 255) / 256)), dim3(256), 0, s, T->dx, T->y, mean1, inv1, P_("Conv1BN/gamma"),
                      colsum, C, nBF, (double)B * P, use_batch, G_("Conv1BN/gamma"), G_("Conv1BN/beta"));
-  size_t lds_cb = sizeof(float) * (size_t)(isz + (size_t)P * C + 9 * C);
+  size_t lds_cb = sizeof(float) * (size_t)(isz + (size_t)P * C + NT * C);
   if (lds_cb > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_tr_conv_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipLaunchKernelGGL(k_tr_conv_bwd, dim3((unsigned)B), dim3(256), lds_cb, s, T->dx, T->img, dm.gen_conv ? nullptr : P_("conv1_weights"), e1, rel,
                      dm.E, dm.R, d, r, dm.in_h, dm.in_w, dm.stacked ? 1 : 0, C, dm.Ho, dm.Wo, dm.gen_conv ? nullptr : G_("conv1_weights"),
                      dm.gen_conv ? nullptr : G_("conv1_bias"), G_("ent_emb"), dm.lookup ? nullptr : G_("rel_emb"), K_ps,
-                     dm.gen_conv ? T->dKs : nullptr, dm.gen_conv ? T->dkbs : nullptr);
+                     dm.gen_conv ? T->dKs : nullptr, dm.gen_conv ? T->dkbs : nullptr, dm.fh, dm.fw);
   if (genc) {
     // per-sample filter gradients -> last projections and contexts, then back through the conv generators
-    hipLaunchKernelGGL(k_tr_small_mm_tn, dim3((unsigned)(((int64_t)rc_cw * 9 * C + 255) / 256)), dim3(256), 0, s, ccw, T->dKs, B, rc_cw, 9 * C,
+    hipLaunchKernelGGL(k_tr_small_mm_tn, dim3((unsigned)(((int64_t)rc_cw * NT * C + 255) / 256)), dim3(256), 0, s, ccw, T->dKs, B, rc_cw, NT * C,
                        G_(cwlast.c_str()));
-    hipLaunchKernelGGL(k_tr_small_mm_nt, dim3((unsigned)((B * rc_cw + 255) / 256)), dim3(256), 0, s, T->dKs, P_(cwlast.c_str()), B, rc_cw, 9 * C,
+    hipLaunchKernelGGL(k_tr_small_mm_nt, dim3((unsigned)((B * rc_cw + 255) / 256)), dim3(256), 0, s, T->dKs, P_(cwlast.c_str()), B, rc_cw, NT * C,
                        0, T->chain[2].dv[nhc]);
     hipLaunchKernelGGL(k_tr_small_mm_tn, dim3((unsigned)(((int64_t)rc_cb * C + 255) / 256)), dim3(256), 0, s, ccb, T->dkbs, B, rc_cb, C,
                        G_(cblast.c_str()));
@@ -1458,7 +1488,7 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
     chain_backward(3, nhc);
   } else if (lkc) {
     // table rows: d(conv1_weights)[rel[b]] += dK[b] (the table gradients were zeroed above)
-    hipLaunchKernelGGL(k_tr_scatter_rows, dim3((unsigned)((B * 9 * C + 255) / 256)), dim3(256), 0, s, T->dKs, rel, dm.R, 9 * C, B * 9 * C,
+    hipLaunchKernelGGL(k_tr_scatter_rows, dim3((unsigned)((B * NT * C + 255) / 256)), dim3(256), 0, s, T->dKs, rel, dm.R, NT * C, B * NT * C,
                        G_("conv1_weights"));
     hipLaunchKernelGGL(k_tr_scatter_rows, dim3((unsigned)((B * C + 255) / 256)), dim3(256), 0, s, T->dkbs, rel, dm.R, C, B * C, G_("conv1_bias"));
   }

@@ -98,23 +98,24 @@ def forward_train(p, md, batch, keep_hidden, keep_out, dtype=torch.float64, keep
     if ctx_out is None and ctx_conv is None:                # plain ConvE: stack the relation image (models.py:360-362)
         img = torch.cat([img, c.reshape(B, H, r // H)], dim=1)
     stats = {}
-    Ho, Wo = img.shape[1] - 2, img.shape[2] - 2
+    fh, fw = int(md.get("conv_filter_height", 3)), int(md.get("conv_filter_width", 3))   # models.py:109-110
+    Ho, Wo = img.shape[1] - fh + 1, img.shape[2] - fw + 1                                # VALID, stride 1 (models.py:382-385)
     y = torch.zeros((B, Ho, Wo, C), dtype=dtype)
     if ctx_conv is None:
-        K = p["conv1_weights"].reshape(3, 3, C)
-        for u in range(3):
-            for v in range(3):
+        K = p["conv1_weights"].reshape(fh, fw, C)
+        for u in range(fh):
+            for v in range(fw):
                 y = y + img[:, u:u + Ho, v:v + Wo, None] * K[u, v][None, None, None, :]
         y = y + p["conv1_bias"]
     else:                                                   # per-sample filters (models.py:374-380)
         if lookup_params:
-            Kb_ = p["conv1_weights"][rel].reshape(B, 3, 3, C)
+            Kb_ = p["conv1_weights"][rel].reshape(B, fh, fw, C)
             kb_ = p["conv1_bias"][rel]
         else:
-            Kb_ = _generate(p, md, "conv1_weights", c, train_stats, keep_ctx, stats, dtype).reshape(B, 3, 3, C)
+            Kb_ = _generate(p, md, "conv1_weights", c, train_stats, keep_ctx, stats, dtype).reshape(B, fh, fw, C)
             kb_ = _generate(p, md, "conv1_bias", c, train_stats, keep_ctx, stats, dtype)
-        for u in range(3):
-            for v in range(3):
+        for u in range(fh):
+            for v in range(fw):
                 y = y + img[:, u:u + Ho, v:v + Wo, None] * Kb_[:, u, v][:, None, None, :]
         y = y + kb_[:, None, None, :]
     if train_stats:
@@ -226,7 +227,8 @@ def train_step(params_np, md, batch, opt: AMSGrad, seed, step, momentum):
     d, r = int(md["ent_emb_size"]), int(md["rel_emb_size"])
     C = int(md.get("conv_num_channels", 32))
     in_h = H * 2 if (md.get("context_rel_out", None) is None and md.get("context_rel_conv", None) is None) else H
-    F = (in_h - 2) * (d // H - 2) * C
+    fh, fw = int(md.get("conv_filter_height", 3)), int(md.get("conv_filter_width", 3))
+    F = (in_h - fh + 1) * (d // H - fw + 1) * C
     kh = dropout_keep(seed, step, 1, B * F, float(md.get("hidden_dropout", 0.0)))
     ko = dropout_keep(seed, step, 2, B * d, float(md.get("output_dropout", 0.0)))
     kc = {}

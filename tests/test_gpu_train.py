@@ -48,17 +48,17 @@ _CASES = {
 
 
 def _fuzz_cases(n):
-    """Seeded random shapes for the training step: embedding sizes that are not multiples of 4 or 8, image shapes and channel
-    counts the fixed cases do not have, every model variant in turn."""
+    """Seeded random shapes for the training step: embedding sizes that are not multiples of 4 or 8, other filter sizes,
+    channel counts that do not divide the workgroup, every model variant in turn; one case above d = 256."""
     out = {}
     for seed in range(n):
         rng = np.random.default_rng(500 + seed)
         emb_h, emb_w = int(rng.integers(3, 11)), int(rng.integers(3, 13))
         d = emb_h * emb_w
-        # (coper_train_init serves 3 x 3 filters, channel counts that divide 256, d <= 256: the shapes the reference ships)
+        fh, fw = [(3, 3), (2, 2), (1, 3), (3, 2), (3, 3)][int(rng.integers(0, 5))]
         md = dict(num_ent=int(rng.choice([37, 130, 301])), num_rel=int(rng.choice([2, 6, 10])), ent_emb_size=d,
-                  rel_emb_size=int(rng.choice([3, 8])), emb_h=emb_h, emb_w=emb_w,
-                  conv_num_channels=int(rng.choice([4, 8, 16, 32])))
+                  rel_emb_size=int(rng.choice([3, 8])), emb_h=emb_h, emb_w=emb_w, conv_filter_height=fh, conv_filter_width=fw,
+                  conv_num_channels=int(rng.choice([3, 8, 12, 32])))
         v = seed % 6
         if v == 0:
             md.update(context_rel_conv=None, context_rel_out=[])
@@ -73,6 +73,8 @@ def _fuzz_cases(n):
         else:
             md.update(context_rel_conv=None, context_rel_out=[], concat_rel=True)
         out["fuzz_%02d" % seed] = md
+    out["fuzz_d288"] = dict(num_ent=130, num_rel=6, ent_emb_size=288, rel_emb_size=8, emb_h=12, emb_w=24, conv_filter_height=2,
+                            conv_filter_width=3, conv_num_channels=5, context_rel_conv=None, context_rel_out=[])
     return out
 
 
@@ -113,9 +115,9 @@ def test_train_step_matches_oracle(name, train_stats, one_vs_all):
     m.train_init(seed=seed)
     ref = {k: np.array(v, np.float64) for k, v in p0.items()}
     opt = T.AMSGrad(T.trainable_names(md), ref, lr=md["learning_rate"])
-    # the wide cases restart the oracle from the device's variables before every step, so that each step is held to the
+    # the wide and the random-shape cases restart the oracle from the device's variables before every step, so that each step is held to the
     # step-0 bounds (the other cases let the two trajectories run free and bound the Adam-amplified drift instead)
-    sync = name.endswith("_wide")
+    sync = name.endswith("_wide") or name.startswith("fuzz_")
     for step in range(3):
         batch = _batch(md, B, L, seed=100 + step)
         if sync and step > 0:
@@ -185,11 +187,11 @@ def test_train_rejects_unsupported_variants_and_order():
     with pytest.raises(CoperError, match="whole entity table"):
         sh.train_init()                     # training needs the whole table on the handle
     sh.close()
-    md5 = dict(md, conv_filter_height=5, conv_filter_width=3)
+    md5 = dict(md, conv_num_channels=300)
     m5 = ConvE(md5, device="cuda:0")
     m5.load_parameters(cdata.synthetic_params(md5, seed=1))
-    with pytest.raises(CoperError, match="3x3"):
-        m5.train_init()                     # the training kernels are built for the reference's 3x3 filters
+    with pytest.raises(CoperError, match="256 conv channels"):
+        m5.train_init()                     # (any filter size, channel count up to 256, d up to coper_create's 320)
     m5.close()
 
 
