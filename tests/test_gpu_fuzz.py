@@ -88,3 +88,50 @@ def test_random_shapes_against_oracle(oracle_chain, seed):
         finite = np.isfinite(want_val)
         assert np.array_equal(got_idx[finite], order[finite]), (variant, md, mode)
         m.close()
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_shards_sum_to_the_unsharded_result(seed):
+    """SURVEY.md 8(e) on random shapes: the entity table cut at random rows into 2 or 3 shard handles on one GPU, the exchange
+    done by hand -- gathered e1 rows, targets and rank counts add up to the unsharded handle's, the concatenated logits and
+    the merged top-k are the unsharded ones, bit for bit, in both modes."""
+    from coper_amd.models import ConvE
+    from coper_amd.sharding import merge_topk
+    variant, md, Q = _random_case(100 + seed)
+    rng = np.random.default_rng(7000 + seed)
+    E = md["num_ent"]
+    if E < 8:
+        md["num_ent"] = E = 40
+    p = cdata.synthetic_params(md, seed=seed)
+    q = cdata.synthetic_queries(md, Q, seed=seed)
+    cuts = sorted(set(int(c) for c in rng.integers(1, E, size=int(rng.integers(1, 3)))))
+    bounds = list(zip([0] + cuts, cuts + [E]))
+    mode = "bf16x3" if seed % 2 else "f32"
+
+    def make(shard=None):
+        m = ConvE(md, device="cuda:0", score_mode=mode, shard=shard)
+        m.load_parameters(p)
+        m.prepare()
+        return m
+
+    full = make()
+    h = full.encode(q["e1"], q["rel"])
+    tgt_full = full.target_scores(h, q["e2"])
+    k = min(4, min(hi - lo for lo, hi in bounds))
+    ng_f, ne_f, tv_f, ti_f = full.rank_counts(h, tgt_full, q["e2"], q["filt_indptr"], q["filt_idx"], k=k)
+    shards = [make(b) for b in bounds]
+    rows = sum(s.gather_entities(q["e1"]) for s in shards)
+    assert np.array_equal(rows.cpu().numpy(), np.asarray(p["ent_emb"], np.float32)[q["e1"]])
+    hs = shards[-1].encode(q["e1"], q["rel"], e1_rows=rows)
+    assert torch.equal(hs, h), (variant, md, bounds, mode)
+    tgt = sum(s.target_scores(hs, q["e2"]) for s in shards)
+    assert torch.equal(tgt, tgt_full)
+    outs = [s.rank_counts(hs, tgt, q["e2"], q["filt_indptr"], q["filt_idx"], k=k) for s in shards]
+    assert torch.equal(sum(o[0] for o in outs), ng_f) and torch.equal(sum(o[1] for o in outs), ne_f), (variant, md, bounds, mode)
+    tv, ti = merge_topk(torch.cat([o[2] for o in outs], dim=1), torch.cat([o[3] for o in outs], dim=1), k)
+    assert torch.equal(tv, tv_f), (variant, md, bounds, mode)
+    fin = torch.isfinite(tv_f)
+    assert torch.equal(ti[fin], ti_f[fin]), (variant, md, bounds, mode)
+    assert torch.equal(torch.cat([s.score_all(hs) for s in shards], dim=1), full.score_all(h))
+    for s in shards + [full]:
+        s.close()
