@@ -28,7 +28,7 @@ def _random_case(seed):
     C = int(rng.choice([4, 8, 16, 32, 32, 40]))
     md = dict(cdata._COMMON)
     md.update(num_ent=int(rng.choice([5, 31, 33, 64, 257, 700])), num_rel=int(rng.choice([2, 6, 22, 40])),
-              ent_emb_size=d, rel_emb_size=int(rng.choice([3, 8, 10])), emb_h=emb_h, emb_w=emb_w,
+              ent_emb_size=d, rel_emb_size=int(rng.choice([1, 3, 8, 10, 37, 50])), emb_h=emb_h, emb_w=emb_w,   # (config_*: 1, 8, 32, 37, 50, 200)
               conv_filter_height=fh, conv_filter_width=fw, conv_num_channels=C)
     if variant == "cpg_fc":
         md.update(context_rel_conv=None, context_rel_out=[])
