@@ -251,6 +251,26 @@ def dense_filter_to_csr(e2_multi: np.ndarray):
     return np.cumsum(indptr), cols.astype(np.int64)
 
 
+def canonical_csr(indptr, idx):
+    """The rank kernels take every row of the CSR filter sorted ascending (include/coper_hip.h; repeated ids are harmless
+    when adjacent -- the dense mask of metrics.py:45 is idempotent).  Rows that come unsorted (hand-built lists) are sorted
+    here; rows already in order -- everything this package's loaders produce -- cost one vectorised check."""
+    indptr = np.asarray(indptr, np.int64)
+    idx = np.asarray(idx, np.int64)
+    if len(idx) < 2:
+        return indptr, idx
+    down = np.diff(idx) < 0
+    inner = indptr[1:-1]
+    inner = inner[(inner > 0) & (inner < len(idx))]
+    down[inner - 1] = False                     # steps across row boundaries do not count
+    if not down.any():
+        return indptr, idx
+    out = idx.copy()
+    for i in np.unique(np.searchsorted(indptr, np.nonzero(down)[0], side="right") - 1):
+        out[indptr[i]:indptr[i + 1]] = np.sort(idx[indptr[i]:indptr[i + 1]], kind="stable")
+    return indptr, out
+
+
 def csr_to_dense_filter(indptr, idx, num_ent: int) -> np.ndarray:
     B = len(indptr) - 1
     m = np.zeros((B, num_ent), dtype=np.float32)

@@ -13,7 +13,7 @@ import os
 import numpy as np
 import torch
 
-from .data import dense_filter_to_csr
+from .data import canonical_csr, dense_filter_to_csr
 from .sharding import local_rank_pass
 
 __all__ = ["ranking_and_hits", "hits_and_means", "collect_batches"]
@@ -54,7 +54,7 @@ def collect_batches(data_iterator_handle):
         e2.append(np.asarray(batch["e2"], np.int64))
         rel.append(np.asarray(batch["rel"], np.int64))
         if "filt_indptr" in batch:
-            ip, ix = np.asarray(batch["filt_indptr"], np.int64), np.asarray(batch["filt_idx"], np.int64)
+            ip, ix = canonical_csr(batch["filt_indptr"], batch["filt_idx"])
         else:
             ip, ix = dense_filter_to_csr(np.asarray(batch["e2_multi"]))
         indptr.append(ip[1:] + base)

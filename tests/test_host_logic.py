@@ -114,3 +114,19 @@ def test_bench_finds_the_committed_pmc_summaries():
     none = {}
     bench.pmc_traffic(none, "no_such_workload", 1, "coper::k_nothing")
     assert none["traffic"] is None and "traffic_source" not in none
+
+
+def test_unsorted_filter_rows_are_sorted_before_the_kernels_see_them():
+    """include/coper_hip.h: filter rows sorted ascending.  Batches with hand-built, unsorted rows go through canonical_csr."""
+    from coper_amd.data import canonical_csr
+    from coper_amd.metrics import collect_batches
+    indptr = np.array([0, 3, 3, 7, 8])
+    idx = np.array([5, 2, 9, 4, 4, 1, 8, 0])
+    ip, ix = canonical_csr(indptr, idx)
+    assert ip.tolist() == indptr.tolist() and ix.tolist() == [2, 5, 9, 1, 4, 4, 8, 0]
+    ok = np.array([2, 5, 9, 1, 4, 4, 8, 0])
+    ip2, ix2 = canonical_csr(indptr, ok)
+    assert ix2 is not None and ix2.tolist() == ok.tolist()
+    assert canonical_csr(np.array([0, 0]), np.zeros(0, np.int64))[1].tolist() == []
+    q = collect_batches([dict(e1=[0, 1], e2=[5, 4], rel=[0, 0], filt_indptr=[0, 3, 5], filt_idx=[9, 5, 2, 4, 1])])
+    assert q["filt_idx"].tolist() == [2, 5, 9, 1, 4] and q["filt_indptr"].tolist() == [0, 3, 5]
