@@ -50,7 +50,7 @@ struct Dims {
   int64_t n_eblk = 0;  // 32-row entity blocks (padded to a multiple of EBLK_ALIGN)
 };
 
-constexpr int COPER_TOPK_PRUNED_MAX = 32;   // largest k served by the block-maxima top-k (bf16x3); above: logits chunks
+constexpr int COPER_TOPK_PRUNED_MAX = 128;   // largest k served by the block-maxima top-k (bf16x3); above: logits chunks
 constexpr int EBLK_ALIGN = 16;  // entity blocks consumed per workgroup iteration in score_count (8 waves x 2)
 
 struct Timer {

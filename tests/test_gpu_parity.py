@@ -639,7 +639,7 @@ def test_pruned_topk_matches_masked_row_topk(oracle_chain, chunk, mode, monkeypa
     idx = np.concatenate(rows)
     tgt = m.target_scores(h, q["e2"])
     ng0, ne0 = m.rank_counts(h, tgt, q["e2"], indptr, idx)
-    for k in (1, 10, 32):
+    for k in (1, 10, 32, 33, 64, 128):
         ng, ne, tv, ti = m.rank_counts(h, tgt, q["e2"], indptr, idx, k=k)
         ev, ei = O.topk_filtered(logits, q["e2"], indptr, idx, k)
         assert np.array_equal(ti.cpu().numpy(), ei) and np.array_equal(tv.cpu().numpy(), ev), k
