@@ -613,7 +613,7 @@ COPER_API int coper_rank_counts(coper_handle* h, const float* hvec, const float*
   hipStream_t s = (hipStream_t)stream;
   int rc;
   if ((rc = ensure_workspace(h, B, filt_nnz, s))) return rc;
-  // 0 < k <= 32: the count pass also writes block maxima and the top-k is selected from the few blocks that can
+  // 0 < k <= COPER_TOPK_PRUNED_MAX (128): the count pass also writes block maxima and the top-k is selected from the few blocks that can
   // hold it (kernels_topk_bf16.hip): no logits workspace
   const bool pruned = k > 0 && k <= COPER_TOPK_PRUNED_MAX &&
                       (int64_t)k * B + filt_nnz + 32 * h->dm.n_eblk * topk_nseg(h->dm.n_eblk) < 0x7fffffffLL;   // int32 slot ids

@@ -116,7 +116,7 @@ struct coper_handle {
   int64_t h_ws_rows = 0;
   float* logits_ws = nullptr;     // top-k path only: [chunk_rows, n_local]
   int64_t logits_ws_rows = 0;
-  // pruned top-k (bf16x3, k <= 32; kernels_topk_bf16.hip)
+  // pruned top-k (k <= COPER_TOPK_PRUNED_MAX; kernels_topk_bf16.hip)
   int64_t gmax_max_floats = (int64_t)1 << 28;   // set from the device memory size at prepare
   float* gmax_ws = nullptr;       // [n_eblk][query chunk]: block maxima written by the count pass
   size_t gmax_cap = 0;

@@ -1,4 +1,4 @@
-// Pruned top-k of the filtered rows (coper_rank_counts with 0 < k <= 32): the logits are never materialised, also
+// Pruned top-k of the filtered rows (coper_rank_counts with 0 < k <= 128): the logits are never materialised, also
 // not for the top-k.  Kernels of the bf16x3 mode; the fp32-exact mode shares the threshold and selection kernels
 // (launch_topk_pruned_f32 at the end; its block maxima and VALU rescoring live in kernels_score.hip).
 //

@@ -161,7 +161,7 @@ COPER_API int coper_target_scores(coper_handle* h, const float* hvec, const int6
  * filt_nnz = filt_indptr[B], passed from the host that built the CSR (sizes the launch).
  * k > 0 additionally returns the shard's top-k of the FILTERED row (target kept, like
  * metrics.py:46), order (score desc, id asc): topk_val [B,k] (-inf padded), topk_idx [B,k]
- * global ids (-1 padded).  k == 0: both may be NULL.  Not needed for ranks.  k <= 32 selects from
+ * global ids (-1 padded).  k == 0: both may be NULL.  Not needed for ranks.  k <= 128 selects from
  * per-block maxima written by the count pass (no logits; workspace: one float per (32 entities, query) of a
  * query chunk + 32 floats per (k + filter entries)); otherwise logits are materialised chunk by chunk (<= 256 MiB). */
 COPER_API int coper_rank_counts(coper_handle* h, const float* hvec, const float* tgt, const int64_t* e2,

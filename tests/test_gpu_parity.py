@@ -334,7 +334,7 @@ def test_topk_of_filtered_rows(oracle_chain):
     h = m.encode(q["e1"], q["rel"])
     tgt = m.target_scores(h, q["e2"])
     logits = m.score_all(h).cpu().numpy()
-    for k in (1, 10, 33):
+    for k in (1, 10, 33, 130):   # 130: above the block-maxima route's bound -> logits chunks
         ng, ne, tv, ti = m.rank_counts(h, tgt, q["e2"], q["filt_indptr"], q["filt_idx"], k=k)
         ev, ei = O.topk_filtered(logits, q["e2"], q["filt_indptr"], q["filt_idx"], k)
         assert np.array_equal(tv.cpu().numpy(), ev) and np.array_equal(ti.cpu().numpy(), ei)
@@ -605,7 +605,7 @@ def test_encode_rank_single_call_equals_two_calls(mode):
 @pytest.mark.parametrize("mode", ["bf16x3", "f32"])
 @pytest.mark.parametrize("chunk", [None, 128])
 def test_pruned_topk_matches_masked_row_topk(oracle_chain, chunk, mode, monkeypatch):
-    """k <= 32, both score modes: top-k selected from block maxima (kernels_topk_bf16.hip), logits never materialised.
+    """k <= 128, both score modes: top-k selected from block maxima (kernels_topk_bf16.hip), logits never materialised.
     Must equal the top-k of the masked row of the mode's own logits, (score desc, id asc): with exact ties
     (duplicate and all-zero entity rows), filters that hold the row's best entities, k above the number of
     unfiltered entities, several query chunks, two entity shards merged, and the counts unchanged."""
