@@ -135,3 +135,42 @@ def test_random_shards_sum_to_the_unsharded_result(seed):
     assert torch.equal(torch.cat([s.score_all(hs) for s in shards], dim=1), full.score_all(h))
     for s in shards + [full]:
         s.close()
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "f32"])
+def test_one_handle_many_calls_of_changing_size(mode):
+    """State that outlives a call -- the two relation-count buffers that zero each other, cursors, tickets, workspaces that
+    grow, pooled timer events -- under 120 consecutive passes whose batch size jumps between 1 and 5,000 queries (single-launch
+    and multi-launch grouping, one or many tiles, workspace regrowth), with the top-k route in between: every pass must equal
+    the closed form on the handle's own logits."""
+    from coper_amd.models import ConvE
+    md = cdata.model_descriptors("fb15k237_cpg", num_ent=1500, num_rel=40)
+    p = cdata.synthetic_params(md, 3)
+    m = ConvE(md, device="cuda:0", score_mode=mode)
+    m.load_parameters(p)
+    m.prepare()
+    E = md["num_ent"]
+    rng = np.random.default_rng(99)
+    sizes = [1, 5000, 33, 4096, 4097, 2, 512, 31, 129, 3000] + [int(x) for x in rng.integers(1, 5001, 110)]
+    m.profile(True)
+    for it, Q in enumerate(sizes):
+        q = cdata.synthetic_queries(md, Q, seed=1000 + it)
+        ranks, ne = m.rank_pass(q["e1"], q["rel"], q["e2"], q["filt_indptr"], q["filt_idx"])
+        if it % 7 == 3:     # the top-k route reuses the count buffers and its own workspaces
+            h = m.encode(q["e1"], q["rel"])
+            m.rank_counts(h, m.target_scores(h, q["e2"]), q["e2"], q["filt_indptr"], q["filt_idx"], k=10)
+        if it % 5 == 0 or Q < 64:
+            h = m.encode(q["e1"], q["rel"])
+            logits = m.score_all(h).cpu().numpy()
+            mask = cdata.csr_to_dense_filter(q["filt_indptr"], q["filt_idx"], E).astype(bool)
+            tgt = logits[np.arange(Q), q["e2"]]
+            keep = ~mask
+            keep[np.arange(Q), q["e2"]] = False
+            want = 1 + ((logits > tgt[:, None]) & keep).sum(axis=1)
+            assert np.array_equal(ranks.cpu().numpy(), want), (it, Q)
+        else:               # against the two-call path (its own grouping pass, other workspaces)
+            h = m.encode(q["e1"], q["rel"])
+            r2, ne2 = m.rank(h, q["e2"], q["filt_indptr"], q["filt_idx"])
+            assert torch.equal(ranks, r2) and torch.equal(ne, ne2), (it, Q)
+    assert m.check_ids() == 0 if hasattr(m, "check_ids") else True
+    m.close()
