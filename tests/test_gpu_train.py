@@ -390,3 +390,41 @@ def test_handles_release_their_device_memory():
     assert lib.coper_live_device_bytes() - base > (8 << 20)     # a prepared handle of this size holds 24 MB
     m.close()
     assert lib.coper_live_device_bytes() == base
+
+
+def test_train_batch_shape_changes_between_steps():
+    """One handle, consecutive steps whose batch changes shape -- B 16 / 70 / 48 / 5, sampled lists of 9 / 60 / 37 entities and
+    1-vs-all rows in between (the training workspaces, plane sets and split-K pools regrow; label modes alternate): loss and
+    every gradient of every step against the oracle restarted from the device's variables."""
+    from coper_amd.models import ConvE
+    from oracle import coper_train_oracle as T
+    md = dict(cdata._COMMON)
+    md.update(_CASES["cpg_wide"])
+    md.update(num_ent=300, batch_norm_train_stats=True, batch_norm_momentum=0.9, hidden_dropout=0.3, output_dropout=0.2,
+              label_smoothing_epsilon=0.1, learning_rate=0.003)
+    p0 = cdata.synthetic_params(md, seed=4)
+    seed = 9
+    m = ConvE(md, device="cuda:0")
+    m.load_parameters({k: torch.as_tensor(np.array(v, np.float32)) for k, v in p0.items()})
+    m.train_init(seed=seed)
+    ref = {k: np.array(v, np.float64) for k, v in p0.items()}
+    opt = T.AMSGrad(T.trainable_names(md), ref, lr=md["learning_rate"])
+    shapes = [(16, 9, False), (70, 60, False), (48, 0, True), (5, 37, False), (70, 0, True), (16, 60, False)]
+    for step, (B, L, one_vs_all) in enumerate(shapes):
+        for k in ref:
+            ref[k] = m._tensors[k].cpu().numpy().reshape(np.shape(ref[k])).astype(np.float64)
+        batch = _batch(md, B, max(L, 3), seed=300 + step)
+        if one_vs_all:
+            dense = np.zeros((B, md["num_ent"]), np.float32)
+            np.put_along_axis(dense, batch["lookup_values"].astype(np.int64), batch["e2_multi"], axis=1)
+            batch = dict(e1=batch["e1"], rel=batch["rel"], e2_multi=dense, lookup_values=np.zeros((B, 0), np.int32))
+        ob = dict(e1=batch["e1"], rel=batch["rel"], lookup=None if one_vs_all else batch["lookup_values"], labels=batch["e2_multi"])
+        loss_o, grads_o, gn_o = T.train_step(ref, md, ob, opt, seed=seed, step=step, momentum=md["batch_norm_momentum"])
+        loss = float(m.train_step(batch).cpu()[0])
+        assert abs(loss - loss_o) < 2e-5 * max(1.0, abs(loss_o)), (step, B, L, loss, loss_o)
+        for leaf in T.trainable_names(md):
+            g, gn = m.train_grad(leaf)
+            err = _rel_err(g.cpu().numpy().reshape(grads_o[leaf].shape), grads_o[leaf], 1e-3 * gn_o)
+            assert err < 2e-4, (step, B, L, leaf, err)
+        assert abs(gn - gn_o) < 1e-4 * gn_o
+    m.close()
