@@ -519,13 +519,15 @@ static int encode_partials(coper_handle* h, const int64_t* e1, const int64_t* re
   int64_t ksteps = dm.F_pad / 16;
   // Number of K slices: a function of the CONFIGURATION only (never of the batch).  More slices = more workgroups
   // per weight stream (fills the chip when there are few streams) but more partial-sum traffic and prologues;
-  // measured on MI355X (same box, bf16x3): 474 relations 2 > 3 > 4 > 8; 22 relations 8 > 4 > 3 > 2; one shared
-  // weight (plain ConvE) 3 > 4 > 8 > 2.
+  // measured on MI355X (same box, bf16x3): 474 relations 1 > 2 > 3 > 4 > 8 (one slice = one workgroup per relation tile,
+  // 237 of them on 256 CUs: fused encoder 0.184 vs 0.189 ms, and half the partial sums for the tail kernel to read: pass
+  // 0.526 vs 0.534 ms); 2,000 relations (the 10M-entity config, ~1,000 tiles of ~4 queries) 2 > 1 (1.00 vs 1.30 ms);
+  // 22 relations 8 > 4 > 3 > 2; one shared weight (plain ConvE) 3 > 4 > 8 > 2.
 #ifdef COPER_KSPLIT
   int ksplit = ksteps >= 64 ? COPER_KSPLIT : 1;
 #else
   int ksplit = 1;
-  if (ksteps >= 64) ksplit = !dm.gen_fc ? 3 : dm.R >= 256 ? 2 : dm.R >= 32 ? 4 : 8;
+  if (ksteps >= 64) ksplit = !dm.gen_fc ? 3 : dm.R >= 1024 ? 2 : dm.R >= 256 ? 1 : dm.R >= 32 ? 4 : 8;
 #endif
   if (ksplit > h->ws_ksplit) ksplit = h->ws_ksplit;
   *ksplit_out = ksplit;
