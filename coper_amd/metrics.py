@@ -54,15 +54,17 @@ def collect_batches(data_iterator_handle):
         e2.append(np.asarray(batch["e2"], np.int64))
         rel.append(np.asarray(batch["rel"], np.int64))
         if "filt_indptr" in batch:
-            ip, ix = canonical_csr(batch["filt_indptr"], batch["filt_idx"])
+            ip, ix = np.asarray(batch["filt_indptr"], np.int64), np.asarray(batch["filt_idx"], np.int64)
         else:
             ip, ix = dense_filter_to_csr(np.asarray(batch["e2_multi"]))
         indptr.append(ip[1:] + base)
         idx.append(ix)
         base += int(ip[-1])
     cat = lambda xs, dt: np.concatenate(xs).astype(dt) if xs else np.zeros(0, dt)
-    return dict(e1=cat(e1, np.int64), e2=cat(e2, np.int64), rel=cat(rel, np.int64),
-                filt_indptr=np.concatenate(indptr).astype(np.int64), filt_idx=cat(idx, np.int64))
+    # the rank kernels take every filter row sorted ascending: one vectorised check over the whole pass (rows that come
+    # unsorted are sorted)
+    ip_all, ix_all = canonical_csr(np.concatenate(indptr), cat(idx, np.int64))
+    return dict(e1=cat(e1, np.int64), e2=cat(e2, np.int64), rel=cat(rel, np.int64), filt_indptr=ip_all, filt_idx=ix_all)
 
 
 def ranking_and_hits(model, results_dir, data_iterator_handle, name, session=None, hits_to_compute=(1, 3, 5, 10, 20),
