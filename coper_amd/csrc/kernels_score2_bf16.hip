@@ -374,7 +374,8 @@ static int sc2_launch(coper_handle* h, int64_t q0, int64_t Bc, const float* tgt,
 
 // true when the pipelined kernel serves this configuration (k-step counts it is instantiated for)
 bool score_count2_supported(const coper_handle* h) {
-  if (getenv("COPER_SCORE_V1")) return false;
+  static const bool off = getenv("COPER_SCORE_V1") != nullptr;   // A/B switch, read once
+  if (off) return false;
   return h->dm.KS16 == 13 || h->dm.KS16 == 16;
 }
 

@@ -287,7 +287,8 @@ extern "C" __attribute__((visibility("default"))) int coper_dbg_tl_clock(int n_w
 #endif
 
 bool tail_fused_supported(const coper_handle* h) {
-  if (getenv("COPER_TAIL_UNFUSED")) return false;
+  static const bool off = getenv("COPER_TAIL_UNFUSED") != nullptr;   // A/B switch, read once
+  if (off) return false;
   return (h->dm.KS16 == 13 || h->dm.KS16 == 16) && h->dm.n_local == h->dm.E;
 }
 

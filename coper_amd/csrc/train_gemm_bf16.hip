@@ -280,7 +280,8 @@ __global__ __launch_bounds__(256) void k_tg_reduce(const float* __restrict__ par
 // one wave per 128 x 128 tile (train_gemm_w128_bf16.hip) when tiles x K slices can fill the 1024 SIMDs
 static bool tg_use_w128(int64_t M, int64_t N, int64_t K) {
   const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128), ks16 = (K + 15) / 16;
-  if (getenv("COPER_TG_NO_W128")) return false;
+  static const bool off = getenv("COPER_TG_NO_W128") != nullptr;   // A/B switch
+  if (off) return false;
   if (tiles >= 768) return true;
   return tiles * (ks16 / 16) >= 768;      // slices of at least 16 k-steps
 }
