@@ -34,3 +34,23 @@ for i in range(reps):
 torch.cuda.synchronize()
 ms, n = m.profile_read("dense"); ms2, n2 = m.profile_read("conv")
 print("%s: dense avg %.4f ms, conv avg %.4f ms" % (os.environ.get("COPER_HIP_LIB", "default"), ms / max(n, 1), ms2 / max(n2, 1)))
+
+try:      # -DCOPER_DBG_FUSED_CLOCK build: when each workgroup of the last launch started and ended, by tile size
+    import ctypes
+    import numpy as np
+    lib = ctypes.CDLL(os.environ.get("COPER_HIP_LIB", ""))
+    buf = (ctypes.c_ulonglong * (3 * 2048))()
+    if lib.coper_dbg_fused_clock(buf, 2048) == 0:
+        a = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 3).astype(np.int64)
+        a = a[a[:, 2] > 0]
+        t0 = a[:, 1].min()
+        st, en, n = (a[:, 1] - t0) * 0.01, (a[:, 2] - t0) * 0.01, a[:, 0]
+        print("   %d workgroups; start: median %.1f us, last %.1f us; end: median %.1f, p90 %.1f, last %.1f us" % (
+            len(a), np.median(st), st.max(), np.median(en), np.percentile(en, 90), en.max()))
+        for lo, hi in ((1, 32), (33, 64), (65, 80), (81, 96), (97, 112), (113, 128)):
+            m_ = (n >= lo) & (n <= hi)
+            if m_.any():
+                print("   tiles of %3d..%3d queries: %3d workgroups, duration median %.1f us, max %.1f us, end max %.1f us" % (
+                    lo, hi, m_.sum(), np.median((en - st)[m_]), (en - st)[m_].max(), en[m_].max()))
+except (OSError, AttributeError):
+    pass
