@@ -325,6 +325,14 @@ __device__ __forceinline__ void fused_conv_role(uint4* __restrict__ xring, float
 // instead of a grid sized by the worst case, most of it empty workgroups -- took 0.24 ms where this launch takes 0.19
 // (FB15k-237 CoPER shapes; plain ConvE 0.30 vs 0.27): the hardware dispatcher hands a freed CU the next workgroup, a static
 // walk does not.)
+#ifdef COPER_DBG_FUSED_CLOCK
+// diagnostic build: per workgroup (queries of its tile, start and end on the 100 MHz s_memrealtime clock), wave 0
+__device__ unsigned long long g_fused_clk[3 * 2048];
+extern "C" __attribute__((visibility("default"))) int coper_dbg_fused_clock(unsigned long long* out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fused_clk), sizeof(unsigned long long) * 3 * (n < 2048 ? n : 2048)) == hipSuccess ? 0 : 1;
+}
+#endif
+
 template <int NFB, bool WNT>
 __global__ __launch_bounds__(512) void k_dense_fused_bf16x3(const uint4* __restrict__ Whi, const uint4* __restrict__ Wlo,
                                                             FusedConvArgs A, const int32_t* __restrict__ tiles,
@@ -356,6 +364,9 @@ __global__ __launch_bounds__(512) void k_dense_fused_bf16x3(const uint4* __restr
   float* zdst = z_part + (int64_t)slice * Bcap * d_pad16;
   const int nb = (n + 15) >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#ifdef COPER_DBG_FUSED_CLOCK
+  const unsigned long long dbg_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
   uint4* xring = fused_lds;                       // 2 stages x 16 slots x 1 KiB
   float* img = (float*)(fused_lds + 2 * 16 * 64);
   // pixel p = k-step index: the slice needs image rows i_lo .. i_hi + 2
@@ -380,6 +391,12 @@ __global__ __launch_bounds__(512) void k_dense_fused_bf16x3(const uint4* __restr
     default: BODY(8); break;
   }
 #undef BODY
+#ifdef COPER_DBG_FUSED_CLOCK
+  if (threadIdx.x == 0) {
+    const int w = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (w < 2048) { g_fused_clk[3 * w] = (unsigned long long)n; g_fused_clk[3 * w + 1] = dbg_t0; g_fused_clk[3 * w + 2] = __builtin_amdgcn_s_memrealtime(); }
+  }
+#endif
 }
 
 // slice geometry: rows of the image a K slice needs (same formula as the kernel), maximum over the slices
