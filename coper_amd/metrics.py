@@ -38,7 +38,7 @@ def hits_and_means(ranks, hits_to_compute=(1, 3, 5, 10, 20)):
     return mr, mrr, hits
 
 
-def collect_batches(data_iterator_handle):
+def collect_batches(data_iterator_handle, device=None):
     """Drains a batch source (the role of the `while not stopped` loop, metrics.py:38-60) into one set
     of query arrays with a CSR filter.  Accepts batches carrying `filt_indptr`/`filt_idx` or the
     reference's dense `e2_multi`."""
@@ -56,7 +56,7 @@ def collect_batches(data_iterator_handle):
         if "filt_indptr" in batch:
             ip, ix = np.asarray(batch["filt_indptr"], np.int64), np.asarray(batch["filt_idx"], np.int64)
         else:
-            ip, ix = dense_filter_to_csr(np.asarray(batch["e2_multi"]))
+            ip, ix = dense_filter_to_csr(np.asarray(batch["e2_multi"]), device=device)   # on the model's device when it has one
         indptr.append(ip[1:] + base)
         idx.append(ix)
         base += int(ip[-1])
@@ -80,7 +80,7 @@ def ranking_and_hits(model, results_dir, data_iterator_handle, name, session=Non
     logger.info("-" * 50)
     logger.info("")
 
-    q = collect_batches(data_iterator_handle)
+    q = collect_batches(data_iterator_handle, device=getattr(model, "device", None))
     Q = len(q["e1"])
     ranks = []
     for s in range(0, Q, max_chunk):

@@ -174,3 +174,30 @@ def test_one_handle_many_calls_of_changing_size(mode):
             assert torch.equal(ranks, r2) and torch.equal(ne, ne2), (it, Q)
     assert m.check_ids() == 0 if hasattr(m, "check_ids") else True
     m.close()
+
+
+def test_reference_style_dense_mask_batches():
+    """The reference's batch contract carries a dense 0/1 mask e2_multi [B, |E|] (data.py:182-186, models.py:139-152).  Batches
+    in that form go through ranking_and_hits like CSR batches: the mask is scanned on the model's device and the result is
+    the CSR the loaders would have produced (same ranks)."""
+    from coper_amd.data import dense_filter_to_csr
+    from coper_amd.metrics import ranking_and_hits
+    from coper_amd.models import ConvE
+    md = cdata.model_descriptors("fb15k237_cpg", num_ent=3000, num_rel=30)
+    m = ConvE(md, device="cuda:0", score_mode="bf16x3").load_parameters(cdata.synthetic_params(md, 1)).prepare()
+    q = cdata.synthetic_queries(md, 700, seed=2)
+    E = md["num_ent"]
+    mask = cdata.csr_to_dense_filter(q["filt_indptr"], q["filt_idx"], E)
+    ip_d, ix_d = dense_filter_to_csr(mask, device=m.device)
+    ip_h, ix_h = dense_filter_to_csr(mask)
+    assert np.array_equal(ip_d, ip_h) and np.array_equal(ix_d, ix_h)
+    assert np.array_equal(ip_d, q["filt_indptr"]) and np.array_equal(ix_d, q["filt_idx"])
+    csr_batches = [dict(e1=q["e1"][s:s + 128], e2=q["e2"][s:s + 128], rel=q["rel"][s:s + 128],
+                        filt_indptr=q["filt_indptr"][s:s + 129] - q["filt_indptr"][s],
+                        filt_idx=q["filt_idx"][q["filt_indptr"][s]:q["filt_indptr"][min(s + 128, 700)]]) for s in range(0, 700, 128)]
+    dense_batches = [dict(e1=q["e1"][s:s + 128], e2=q["e2"][s:s + 128], rel=q["rel"][s:s + 128], e2_multi=mask[s:s + 128],
+                          lookup_values=np.zeros((len(q["e1"][s:s + 128]), 0), np.int32)) for s in range(0, 700, 128)]
+    a = ranking_and_hits(m, None, iter(csr_batches), "csr", return_ranks=True)
+    b = ranking_and_hits(m, None, iter(dense_batches), "dense", return_ranks=True)
+    assert a[:3] == b[:3] and np.array_equal(a[3], b[3])
+    m.close()
