@@ -428,3 +428,48 @@ def test_train_batch_shape_changes_between_steps():
             assert err < 2e-4, (step, B, L, leaf, err)
         assert abs(gn - gn_o) < 1e-4 * gn_o
     m.close()
+
+
+def test_device_sampler_feeds_the_training_loop():
+    """DeviceTrainDataset on the HIP device: batches of device tensors in the reference's batch contract, construction
+    rules as on the host, and a training loop fed by it learns the small graph like the host-fed one."""
+    from coper_amd.data import DeviceTrainDataset, EvalDataset
+    from coper_amd.metrics import ranking_and_hits
+    from coper_amd.models import ConvE
+    E, R = 120, 4
+    md = dict(cdata._COMMON)
+    md.update(_CASES["cpg_linear"])
+    md.update(num_ent=E, num_rel=R, batch_norm_train_stats=True, batch_norm_momentum=0.9, hidden_dropout=0.1, output_dropout=0.1,
+              label_smoothing_epsilon=0.1, learning_rate=0.003)
+    mult, off = [1, 7, 11, 13], [3, 17, 29, 41]
+    e1 = np.repeat(np.arange(E), R)
+    rel = np.tile(np.arange(R), E)
+    e2 = (e1 * np.array(mult)[rel] + np.array(off)[rel]) % E
+    samples = dict(e1=e1, rel=rel, tail_indptr=np.arange(len(e1) + 1), tail_idx=e2.astype(np.int64))
+    ds = DeviceTrainDataset(samples, E, batch_size=96, num_labels=40, seed=5, device="cuda:0")
+    it = iter(ds)
+    b = next(it)
+    assert all(v.is_cuda for v in b.values())
+    assert b["lookup_values"].shape == (96, 40) and b["lookup_values"].dtype == torch.int32 and b["e2_multi"].dtype == torch.float32
+    lk, lab = b["lookup_values"].cpu().numpy(), b["e2_multi"].cpu().numpy()
+    assert np.array_equal(lk[:, 0], b["e2"].cpu().numpy()) and (lab[:, 0] == 1).all()
+    want = (lk == ((b["e1"].cpu().numpy() * np.array(mult)[b["rel"].cpu().numpy()] + np.array(off)[b["rel"].cpu().numpy()]) % E)[:, None])
+    assert np.array_equal(lab, want.astype(np.float32))              # one known tail per (e1, rel) in this graph
+    assert all(len(set(row[1:].tolist())) == 39 for row in lk)
+    m = ConvE(md, device="cuda:0").load_parameters(cdata.synthetic_params(md, seed=4))
+
+    def mrr():
+        q = dict(e1=e1, rel=rel, e2=e2, filt_indptr=np.arange(len(e1) + 1), filt_idx=e2.astype(np.int64))
+        return ranking_and_hits(m, None, EvalDataset(q, 256, E), "train")[1]
+
+    before = mrr()
+    m.train_init(seed=3)
+    losses = []
+    for step in range(600):
+        loss = m.train_step(next(it))
+        if step % 50 == 0 or step == 599:
+            losses.append(float(loss.cpu()[0]))
+    after = mrr()
+    assert np.isfinite(losses).all() and losses[-1] < 0.5 * losses[0], losses
+    assert before < 0.15 and after > 0.5 and after > 4 * before, (before, after, losses)
+    m.close()

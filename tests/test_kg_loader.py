@@ -243,3 +243,44 @@ def test_tfrecord_reader_on_a_hand_assembled_file(tmp_path, golden_dir):
         f.write(bytes(bad))
     with pytest.raises(ValueError):
         list(R.read_records(path, verify=True))
+
+
+def test_device_train_dataset_sampler_rules():
+    """DeviceTrainDataset (here on torch's CPU device; the GPU suite runs it on the HIP device): the construction rules of
+    the one-positive-per-row sampler (data.py:278-311) -- positive first, L - 1 distinct negatives, labels = membership in
+    the record's tail list -- and the row stream: over an epoch every (record, tail) row appears, rows pass a shuffle buffer."""
+    from coper_amd.data import DeviceTrainDataset
+    rng = np.random.default_rng(3)
+    E, N = 97, 40
+    indptr, idx = [0], []
+    for i in range(N):
+        k = int(rng.integers(0, 9))          # records without tails produce no rows
+        idx.extend(sorted(rng.choice(E, size=k, replace=False)))
+        indptr.append(len(idx))
+    s = dict(e1=rng.integers(0, E, N), rel=rng.integers(0, 6, N), tail_indptr=np.array(indptr), tail_idx=np.array(idx))
+    ds = DeviceTrainDataset(s, E, batch_size=32, num_labels=20, seed=1, device="cpu", shuffle_buffer=40)
+    it = iter(ds)
+    seen = set()
+    n_rows = len(idx)
+    for _ in range(8 * (n_rows // 32 + 1)):
+        b = {k: v.numpy() for k, v in next(it).items()}
+        assert b["lookup_values"].shape == (32, 20) and b["lookup_values"].dtype == np.int32
+        assert b["e2_multi"].shape == (32, 20) and b["e2_multi"].dtype == np.float32
+        assert np.array_equal(b["lookup_values"][:, 0], b["e2"]) and (b["e2_multi"][:, 0] == 1.0).all()
+        assert b["lookup_values"].min() >= 0 and b["lookup_values"].max() < E
+        for r in range(32):
+            recs = [i for i in range(N) if s["e1"][i] == b["e1"][r] and s["rel"][i] == b["rel"][r]
+                    and int(b["e2"][r]) in idx[indptr[i]:indptr[i + 1]]]
+            assert recs
+            assert any(np.array_equal(b["e2_multi"][r], np.array([float(v in set(idx[indptr[i]:indptr[i + 1]])) for v in b["lookup_values"][r]],
+                                                                 np.float32)) for i in recs)
+            assert len(set(b["lookup_values"][r, 1:].tolist())) == 19
+            seen.add((int(b["e1"][r]), int(b["rel"][r]), int(b["e2"][r])))
+    assert seen == {(int(s["e1"][i]), int(s["rel"][i]), int(t)) for i in range(N) for t in idx[indptr[i]:indptr[i + 1]]}
+    # negatives are uniform over the entities: every entity turns up as a negative over a few hundred rows
+    counts = np.zeros(E, np.int64)
+    for _ in range(10):
+        np.add.at(counts, next(it)["lookup_values"].numpy()[:, 1:].reshape(-1), 1)
+    assert counts.min() > 0 and counts.max() < 4 * counts.mean()
+    with pytest.raises(ValueError):
+        DeviceTrainDataset(s, E, 4, num_labels=E + 1, device="cpu")
