@@ -391,14 +391,35 @@ class DeviceTrainDataset(object):
         self.d_ip = torch.as_tensor(ip).to(self.device)
         self.d_tails = torch.as_tensor(self.row_tail).to(self.device)
 
+    def _negatives(self, B):
+        """[B, L - 1] int64: per row the first L - 1 entries of a fresh uniform permutation of the entities = an ordered uniform
+        sample without replacement.  Few labels against many entities: uniform draws in order, repeats skipped (the same
+        distribution; sorts M = L - 1 + slack draws per row instead of |E| keys); otherwise, or if a row runs short of distinct draws, the sorted-keys form."""
+        dev, E, n = self.device, self.num_ent, self.num_labels - 1
+        if n <= 0:
+            return torch.zeros((B, 0), dtype=torch.int64, device=dev)
+        if 4 * n <= E:
+            M = n + max(32, int(2.0 * n * n / E) + 8 * int(math.sqrt(max(n * n / (2.0 * E), 1.0))))   # expected repeats n^2 / 2E
+            draws = torch.randint(0, E, (B, M), device=dev, generator=self.gen)
+            vals, order = torch.sort(draws, dim=1, stable=True)
+            dup_sorted = torch.zeros((B, M), dtype=torch.bool, device=dev)
+            dup_sorted[:, 1:] = vals[:, 1:] == vals[:, :-1]          # stable sort: the later draw of a repeat comes second
+            dup = torch.zeros((B, M), dtype=torch.bool, device=dev)
+            dup.scatter_(1, order, dup_sorted)
+            keep = ~dup
+            rank = torch.cumsum(keep, dim=1)
+            if bool((rank[:, -1] >= n).all()):
+                sel = keep & (rank <= n)
+                return draws[sel].view(B, n)
+        keys = torch.rand((B, E), device=dev, generator=self.gen)
+        return torch.argsort(keys, dim=1)[:, :n]
+
     def _device_batch(self, rows):
         dev, E, L, B = self.device, self.num_ent, self.num_labels, len(rows)
         rows_d = torch.as_tensor(rows).to(dev)
         rec = torch.as_tensor(self.row_rec[rows]).to(dev)
         e2 = self.d_tails[rows_d]
-        # negatives: the first L - 1 entries of a fresh permutation per row
-        keys = torch.rand((B, E), device=dev, generator=self.gen)
-        neg = torch.argsort(keys, dim=1)[:, :L - 1]
+        neg = self._negatives(B)
         lookup = torch.cat([e2[:, None], neg], dim=1)
         # labels: membership in the row's tail list
         lo, hi = self.d_ip[rec], self.d_ip[rec + 1]
@@ -410,7 +431,7 @@ class DeviceTrainDataset(object):
         labels = torch.gather(member, 1, lookup)
         return dict(e1=self.d_e1[rec], rel=self.d_rel[rec], e2=e2, lookup_values=lookup.to(torch.int32), e2_multi=labels)
 
-    def __iter__(self):
+    def _row_batches(self):
         buf, pos = [], 0        # shuffle buffer of row ids; the record stream repeats (.repeat())
         while True:
             need = self.shuffle_buffer + self.batch_size - len(buf)
@@ -428,7 +449,34 @@ class DeviceTrainDataset(object):
                 take.append(buf[j])
                 buf[j] = buf[-1]
                 buf.pop()
-            yield self._device_batch(np.asarray(take, np.int64))
+            yield np.asarray(take, np.int64)
+
+    def __iter__(self):
+        """One batch ahead: batch k + 1 is sampled -- on a stream of its own when the device is a GPU -- while the consumer
+        works on batch k; the consumer's stream waits for the batch's event, nothing waits for the consumer."""
+        rows = self._row_batches()
+        if self.device.type != "cuda":
+            for r in rows:
+                yield self._device_batch(r)
+            return
+        side = torch.cuda.Stream(device=self.device)
+
+        def produce():
+            with torch.cuda.stream(side):
+                b = self._device_batch(next(rows))
+                ev = torch.cuda.Event()
+                ev.record(side)
+            return b, ev
+
+        nxt = produce()
+        while True:
+            b, ev = nxt
+            nxt = produce()
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(ev)
+            for v in b.values():
+                v.record_stream(cur)          # allocated on the side stream, consumed on the caller's
+            yield b
 
 
 class TrainDataset(object):

@@ -33,3 +33,21 @@ torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) * 1e3 / K
 print(json.dumps({"metric": "training step", "workload": name, "B": B, "L": L, "ms_per_step": ms, "queries_per_s": B / ms * 1e3,
                   "scored_pairs_per_s": B * L / ms * 1e3, "loss": float(loss.cpu()[0])}))
+
+# the same step fed by the samplers: a synthetic train graph of this shape, one known tail list per (e1, rel)
+if "--with-sampler" in sys.argv:
+    from coper_amd.data import DeviceTrainDataset
+    N = 100000
+    ip = np.zeros(N + 1, np.int64); ip[1:] = np.cumsum(rng.integers(1, 4, N))
+    s = dict(e1=rng.integers(0, md["num_ent"], N), rel=rng.integers(0, md["num_rel"], N), tail_indptr=ip,
+             tail_idx=rng.integers(0, md["num_ent"], ip[-1]))
+    it = iter(DeviceTrainDataset(s, md["num_ent"], B, num_labels=L, device="cuda:0"))
+    for _ in range(3):
+        m.train_step(next(it))
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(K):
+        loss = m.train_step(next(it))
+    torch.cuda.synchronize()
+    ms2 = (time.perf_counter() - t0) * 1e3 / K
+    print(json.dumps({"metric": "training step fed by DeviceTrainDataset", "workload": name, "B": B, "L": L, "ms_per_step": ms2,
+                      "queries_per_s": B / ms2 * 1e3}))
