@@ -61,6 +61,7 @@ class coper_train_config(C.Structure):
 # name -> (restype, argtypes): every symbol include/coper_hip.h declares
 PROTOTYPES = {
     "coper_abi_version": (C.c_int, []),
+    "coper_crc32c": (C.c_uint32, [C.c_uint32, C.c_void_p, C.c_uint64]),
     "coper_create": (C.c_int, [C.POINTER(coper_config), C.POINTER(_P)]),
     "coper_destroy": (None, [_P]),
     "coper_last_error": (C.c_char_p, [_P]),

@@ -788,6 +788,51 @@ COPER_API int coper_check_ids(coper_handle* h, int64_t* n_bad, void* stream) {
   return COPER_OK;
 }
 
+// ---- CRC-32C on the host (tf_bundle.py): hardware instruction when present, slicing-by-8 tables otherwise
+static uint32_t g_crc_tab[8][256];
+static void crc_tables_init() {
+  for (uint32_t i = 0; i < 256; ++i) {
+    uint32_t c = i;
+    for (int k = 0; k < 8; ++k) c = (c >> 1) ^ ((c & 1) ? 0x82F63B78u : 0u);
+    g_crc_tab[0][i] = c;
+  }
+  for (uint32_t i = 0; i < 256; ++i)
+    for (int t = 1; t < 8; ++t) g_crc_tab[t][i] = (g_crc_tab[t - 1][i] >> 8) ^ g_crc_tab[0][g_crc_tab[t - 1][i] & 0xFF];
+}
+#if defined(__x86_64__)
+__attribute__((target("sse4.2"))) static uint32_t crc32c_hw(uint32_t c, const unsigned char* p, uint64_t n) {
+  while (n && ((uintptr_t)p & 7)) { c = __builtin_ia32_crc32qi(c, *p++); --n; }
+  uint64_t c64 = c;
+  for (; n >= 8; n -= 8, p += 8) { uint64_t v; memcpy(&v, p, 8); c64 = __builtin_ia32_crc32di(c64, v); }
+  c = (uint32_t)c64;
+  while (n--) c = __builtin_ia32_crc32qi(c, *p++);
+  return c;
+}
+#endif
+static uint32_t crc32c_sw(uint32_t c, const unsigned char* p, uint64_t n) {
+  static std::once_flag once;
+  std::call_once(once, crc_tables_init);
+  for (; n >= 8; n -= 8, p += 8) {
+    uint32_t lo, hi;
+    memcpy(&lo, p, 4); memcpy(&hi, p + 4, 4);
+    lo ^= c;
+    c = g_crc_tab[7][lo & 0xFF] ^ g_crc_tab[6][(lo >> 8) & 0xFF] ^ g_crc_tab[5][(lo >> 16) & 0xFF] ^ g_crc_tab[4][lo >> 24] ^
+        g_crc_tab[3][hi & 0xFF] ^ g_crc_tab[2][(hi >> 8) & 0xFF] ^ g_crc_tab[1][(hi >> 16) & 0xFF] ^ g_crc_tab[0][hi >> 24];
+  }
+  while (n--) c = g_crc_tab[0][(c ^ *p++) & 0xFF] ^ (c >> 8);
+  return c;
+}
+
+COPER_API uint32_t coper_crc32c(uint32_t crc, const void* data, uint64_t n) {
+  uint32_t c = crc ^ 0xFFFFFFFFu;
+  const unsigned char* p = (const unsigned char*)data;
+  static const int force_sw = getenv("COPER_CRC_SOFTWARE") != nullptr;   // tests: the table path on a CPU that has the instruction
+#if defined(__x86_64__)
+  if (!force_sw && __builtin_cpu_supports("sse4.2")) return crc32c_hw(c, p, n) ^ 0xFFFFFFFFu;
+#endif
+  return crc32c_sw(c, p, n) ^ 0xFFFFFFFFu;
+}
+
 COPER_API int64_t coper_live_device_bytes(void) {
   std::lock_guard<std::mutex> lk(g_ledger_mu);
   return g_ledger_bytes;

@@ -81,11 +81,28 @@ def _zero_shift_matrix(nbytes: int):
     return result
 
 
-def crc32c(data) -> int:
-    """CRC-32C of a bytes-like object.  Large inputs run as parallel lanes in NumPy and are combined with the
-    zero-shift operator, so an 11 MB embedding table checks in well under a second."""
+_native = None   # coper_crc32c of libcoper_hip.so when the library is built (False: looked for and absent)
+
+
+def _native_crc():
+    global _native
+    if _native is None:
+        try:
+            from . import _lib
+            _native = _lib.load().coper_crc32c
+        except Exception:          # no built library (a bare checkout): the NumPy form below is complete on its own
+            _native = False
+    return _native
+
+
+def crc32c(data, native=True) -> int:
+    """CRC-32C of a bytes-like object: the library's host routine (hardware crc32 instruction, GB/s) when libcoper_hip.so is
+    built, else -- or with native=False -- NumPy: large inputs run as parallel lanes and are combined with the zero-shift
+    operator (65 MB/s: an 11 MB embedding table checks in well under a second, a 500 MB checkpoint in 8 s)."""
     buf = np.frombuffer(memoryview(data).cast("B"), np.uint8)
     n = buf.size
+    if native and n >= 4096 and _native_crc():
+        return int(_native_crc()(0, buf.ctypes.data, n))
     lanes = 4096
     if n < 64 * lanes:
         return _crc_update_scalar(0xFFFFFFFF, buf.tobytes()) ^ 0xFFFFFFFF

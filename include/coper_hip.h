@@ -94,6 +94,12 @@ COPER_API void coper_destroy(coper_handle* h);
 COPER_API const char* coper_last_error(const coper_handle* h);
 COPER_API int coper_abi_version(void);
 
+/* CRC-32C (Castagnoli) of a host buffer, continuing from `crc` (0 for a fresh one): the checksum of the TensorFlow
+ * checkpoint files `tf.train.Saver` writes and reads (run_cpg.py:189,206,252; tensor_bundle.proto crc32c fields, the table
+ * blocks of the .index file).  Host code (SSE4.2 crc32 instruction when the CPU has it): coper_amd/tf_bundle.py checks a
+ * 500 MB checkpoint with it in well under a second, its NumPy form needs 65 MB/s. */
+COPER_API uint32_t coper_crc32c(uint32_t crc, const void* data, uint64_t n);
+
 /* Derived sizes (models.py:261-271): F = fc_input_size, Ho/Wo = conv output; n_local = shard_hi - shard_lo. */
 COPER_API int coper_get_dims(const coper_handle* h, int64_t* F, int32_t* Ho, int32_t* Wo, int64_t* n_local);
 

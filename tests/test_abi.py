@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _declared_symbols():
     text = open(os.path.join(ROOT, "include", "coper_hip.h")).read()
-    return sorted(set(re.findall(r"^COPER_API [^;(]*?\b(coper_[a-z_]+)\(", text, flags=re.M)))
+    return sorted(set(re.findall(r"^COPER_API [^;(]*?\b(coper_[a-z0-9_]+)\(", text, flags=re.M)))
 
 
 def test_library_exports_every_declared_symbol():

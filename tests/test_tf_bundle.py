@@ -29,7 +29,29 @@ def test_crc32c_lane_path_equals_scalar_path():
     rng = np.random.default_rng(0)
     for n in (64 * 4096, 64 * 4096 + 1, 1_000_003):
         b = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
-        assert tb.crc32c(b) == tb._crc_update_scalar(0xFFFFFFFF, b) ^ 0xFFFFFFFF
+        assert tb.crc32c(b, native=False) == tb._crc_update_scalar(0xFFFFFFFF, b) ^ 0xFFFFFFFF
+
+
+def test_native_crc32c_equals_the_numpy_form(monkeypatch):
+    """coper_crc32c of libcoper_hip.so (host code: crc32 instruction, or slicing-by-8 tables) against the NumPy form and the
+    RFC 3720 known answers; chaining over pieces; unaligned starts."""
+    import ctypes
+    from coper_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(1)
+    assert lib.coper_crc32c(0, b"123456789", 9) == 0xE3069283
+    assert lib.coper_crc32c(0, bytes(32), 32) == 0x8A9136AA and lib.coper_crc32c(0, b"", 0) == 0
+    for n in (1, 7, 8, 9, 63, 4096, 64 * 4096 + 5, 1_000_003):
+        b = rng.integers(0, 256, n + 3, dtype=np.uint8)
+        for off in (0, 1, 3):
+            piece = b[off:off + n]
+            want = tb.crc32c(piece.tobytes(), native=False)
+            assert lib.coper_crc32c(0, piece.ctypes.data, n) == want, (n, off)
+            if n >= 4096:
+                assert tb.crc32c(piece.tobytes()) == want                       # the route tf_bundle takes by default
+        k = n // 3
+        c = lib.coper_crc32c(0, b.ctypes.data, k)
+        assert lib.coper_crc32c(c, b.ctypes.data + k, n - k) == tb.crc32c(b[:n].tobytes(), native=False)
 
 
 def test_varint_and_snappy():
