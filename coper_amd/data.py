@@ -355,7 +355,8 @@ class EvalDataset(object):
 
 
 class DeviceTrainDataset(object):
-    """The one-positive-per-row sampler of `TrainDataset` (data.py:138-144, 278-311) with the heavy parts on the device: the
+    """The samplers of `TrainDataset` -- one positive per row (data.py:138-144, 278-311) and the proportional one most shipped
+    configs use (`one_positive_label_per_sample: False`, data.py:228-277; `_device_batch_prop`) -- with the heavy parts on the device: the
     host sampler takes ~40 ms per 512 x 1000 batch on one core (the reference spreads it over 32 `tf.data` map threads,
     data.py:93-94), a training step 1.1 ms.
 
@@ -369,8 +370,10 @@ class DeviceTrainDataset(object):
     Batches are dicts of device tensors in the reference's batch contract (models.py:139-152); `ConvE.train_step` takes
     them as they are."""
 
-    def __init__(self, samples, num_ent, batch_size, num_labels=100, seed=0, shuffle_buffer=1000, device="cuda:0"):
+    def __init__(self, samples, num_ent, batch_size, num_labels=100, seed=0, shuffle_buffer=1000, device="cuda:0",
+                 one_positive_label_per_sample=True, prop_negatives=10.0):
         self.num_ent, self.batch_size, self.num_labels = int(num_ent), int(batch_size), int(num_labels)
+        self.one_pos, self.prop = bool(one_positive_label_per_sample), float(prop_negatives)
         if self.num_labels > self.num_ent:
             raise ValueError("num_labels needs to be at most the total number of entities (data.py:146-147)")
         self.shuffle_buffer = int(shuffle_buffer)
@@ -386,16 +389,19 @@ class DeviceTrainDataset(object):
         self.row_tail = np.asarray(samples["tail_idx"], np.int64)          # the positive of each row (same order)
         self.rec_first_row = ip[:-1]
         self.n_rows = len(self.row_rec)
+        if not self.one_pos:      # the proportional sampler (data.py:228-277): one row per record that has tails
+            self.rows_of_rec = np.nonzero(k > 0)[0].astype(np.int64)
         self.d_e1 = torch.as_tensor(np.asarray(samples["e1"], np.int64)).to(self.device)
         self.d_rel = torch.as_tensor(np.asarray(samples["rel"], np.int64)).to(self.device)
         self.d_ip = torch.as_tensor(ip).to(self.device)
         self.d_tails = torch.as_tensor(self.row_tail).to(self.device)
 
-    def _negatives(self, B):
-        """[B, L - 1] int64: per row the first L - 1 entries of a fresh uniform permutation of the entities = an ordered uniform
+    def _negatives(self, B, n=None):
+        """[B, n] int64 (n = L - 1 by default): per row the first n entries of a fresh uniform permutation of the entities = an ordered uniform
         sample without replacement.  Few labels against many entities: uniform draws in order, repeats skipped (the same
         distribution; sorts M = L - 1 + slack draws per row instead of |E| keys); otherwise, or if a row runs short of distinct draws, the sorted-keys form."""
-        dev, E, n = self.device, self.num_ent, self.num_labels - 1
+        dev, E = self.device, self.num_ent
+        n = self.num_labels - 1 if n is None else int(n)
         if n <= 0:
             return torch.zeros((B, 0), dtype=torch.int64, device=dev)
         if 4 * n <= E:
@@ -431,11 +437,46 @@ class DeviceTrainDataset(object):
         labels = torch.gather(member, 1, lookup)
         return dict(e1=self.d_e1[rec], rel=self.d_rel[rec], e2=e2, lookup_values=lookup.to(torch.int32), e2_multi=labels)
 
+    def _device_batch_prop(self, recs):
+        """data.py:228-277: per record the tails in a fresh random order, then the head of a fresh permutation of ALL entities;
+        num_positives_needed = int(L / (1 + prop_negatives)); a record with more tails than that keeps L - min(|E|, L - needed)
+        of them.  Labels = membership in the tail list; e2 = the first tail of the shuffled order."""
+        dev, E, L, B = self.device, self.num_ent, self.num_labels, len(recs)
+        rec = torch.as_tensor(recs).to(dev)
+        lo, hi = self.d_ip[rec], self.d_ip[rec + 1]
+        cnt = hi - lo
+        tot = int(cnt.sum().item())
+        owner = torch.repeat_interleave(torch.arange(B, device=dev), cnt)
+        first = torch.cumsum(cnt, 0) - cnt
+        pos = torch.arange(tot, device=dev) - first[owner]
+        tails = self.d_tails[lo[owner] + pos]
+        # random order inside every record: sort by (owner, uniform key)
+        order = torch.argsort(owner.to(torch.float64) + torch.rand(tot, device=dev, generator=self.gen, dtype=torch.float64))
+        tails_sh = tails[order]                      # segments stay contiguous (owner is the integer part), shuffled inside
+        need = int(1.0 / (1.0 + self.prop) * L)
+        n_neg_big = min(E, L - need)
+        lead = torch.where(cnt <= need, cnt, torch.full_like(cnt, L - n_neg_big)).clamp(max=L)      # tails kept per row
+        neg = self._negatives(B, min(L, E))
+        grid = torch.arange(L, device=dev)[None, :]
+        idx = torch.gather(neg, 1, (grid - lead[:, None]).clamp(min=0, max=neg.shape[1] - 1))
+        keep = pos < lead[owner]                     # (pos = rank inside the shuffled segment as well)
+        idx[owner[keep], pos[keep]] = tails_sh[keep]
+        member = torch.zeros((B, E), dtype=torch.float32, device=dev)
+        member[owner, tails] = 1.0
+        labels = torch.gather(member, 1, idx)
+        e2 = tails_sh[first]                         # every record here has at least one tail
+        return dict(e1=self.d_e1[rec], rel=self.d_rel[rec], e2=e2, lookup_values=idx.to(torch.int32), e2_multi=labels)
+
     def _row_batches(self):
         buf, pos = [], 0        # shuffle buffer of row ids; the record stream repeats (.repeat())
         while True:
             need = self.shuffle_buffer + self.batch_size - len(buf)
             while need > 0:
+                if not self.one_pos:                 # rows are records
+                    buf.append(int(self.rows_of_rec[pos % len(self.rows_of_rec)]))
+                    pos += 1
+                    need -= 1
+                    continue
                 i = pos % self.n_rec
                 pos += 1
                 first = int(self.rec_first_row[i])
@@ -457,13 +498,14 @@ class DeviceTrainDataset(object):
         rows = self._row_batches()
         if self.device.type != "cuda":
             for r in rows:
-                yield self._device_batch(r)
+                yield self._device_batch(r) if self.one_pos else self._device_batch_prop(r)
             return
         side = torch.cuda.Stream(device=self.device)
 
         def produce():
             with torch.cuda.stream(side):
-                b = self._device_batch(next(rows))
+                r = next(rows)
+                b = self._device_batch(r) if self.one_pos else self._device_batch_prop(r)
                 ev = torch.cuda.Event()
                 ev.record(side)
             return b, ev

@@ -216,11 +216,12 @@ class TSVKGLoader(object):
                       num_parallel_batches=None, buffer_size=None, prefetch_buffer_size=None, prop_negatives=10.0,
                       num_labels=100, cache=False, one_positive_label_per_sample=True, seed=0, device=None):
         """`device` (extra keyword): sample on that device (`DeviceTrainDataset`: batches of device tensors; the
-        one-positive-per-row sampler only) instead of on the host."""
+        both samplers) instead of on the host."""
         if num_labels is None:
             raise NotImplementedError("1-vs-all training labels (num_labels=None, data.py:155-156) are not built")
-        if device is not None and one_positive_label_per_sample:
-            return DeviceTrainDataset(self.train_samples(include_inv_relations), self.num_ent, batch_size, num_labels, seed, device=device)
+        if device is not None:
+            return DeviceTrainDataset(self.train_samples(include_inv_relations), self.num_ent, batch_size, num_labels, seed, device=device,
+                                      one_positive_label_per_sample=one_positive_label_per_sample, prop_negatives=prop_negatives)
         return TrainDataset(self.train_samples(include_inv_relations), self.num_ent, batch_size, num_labels,
                             one_positive_label_per_sample, prop_negatives, seed)
 
@@ -277,6 +278,7 @@ class TFRecordKGLoader(object):
         samples = dict(e1=q["e1"][sel], rel=q["rel"][sel],
                        tail_indptr=np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64),
                        tail_idx=np.concatenate(rows).astype(np.int64) if rows else np.zeros(0, np.int64))
-        if device is not None and one_positive_label_per_sample:
-            return DeviceTrainDataset(samples, self.num_ent, batch_size, num_labels, seed, device=device)
+        if device is not None:
+            return DeviceTrainDataset(samples, self.num_ent, batch_size, num_labels, seed, device=device,
+                                      one_positive_label_per_sample=one_positive_label_per_sample, prop_negatives=prop_negatives)
         return TrainDataset(samples, self.num_ent, batch_size, num_labels, one_positive_label_per_sample, prop_negatives, seed)

@@ -473,3 +473,39 @@ def test_device_sampler_feeds_the_training_loop():
     assert np.isfinite(losses).all() and losses[-1] < 0.5 * losses[0], losses
     assert before < 0.15 and after > 0.5 and after > 4 * before, (before, after, losses)
     m.close()
+
+
+def test_device_sampler_proportional_mode_on_the_gpu():
+    """The proportional sampler (the shipped configs' default) on the HIP device: construction rules, and steps fed by it run."""
+    from coper_amd.data import DeviceTrainDataset
+    from coper_amd.models import ConvE
+    rng = np.random.default_rng(6)
+    E, N, L = 211, 60, 37
+    indptr, idx = [0], []
+    for i in range(N):
+        k = int(rng.integers(1, 12))
+        idx.extend(sorted(rng.choice(E, size=k, replace=False)))
+        indptr.append(len(idx))
+    s = dict(e1=np.arange(N), rel=rng.integers(0, 6, N), tail_indptr=np.array(indptr), tail_idx=np.array(idx))
+    prop = 5.0
+    need = int(1.0 / (1.0 + prop) * L)
+    it = iter(DeviceTrainDataset(s, E, batch_size=48, num_labels=L, seed=2, device="cuda:0", one_positive_label_per_sample=False,
+                                 prop_negatives=prop))
+    md = dict(cdata._COMMON)
+    md.update(_CASES["cpg_linear"])
+    md.update(batch_norm_train_stats=True, batch_norm_momentum=0.9, hidden_dropout=0.1, output_dropout=0.1, label_smoothing_epsilon=0.1,
+              learning_rate=0.003)
+    m = ConvE(md, device="cuda:0").load_parameters(cdata.synthetic_params(md, seed=4))
+    m.train_init(seed=1)
+    for _ in range(5):
+        b = next(it)
+        assert all(v.is_cuda for v in b.values())
+        h = {k: v.cpu().numpy() for k, v in b.items()}
+        for r in range(48):
+            t = idx[indptr[int(h["e1"][r])]:indptr[int(h["e1"][r]) + 1]]
+            lk, lab = h["lookup_values"][r], h["e2_multi"][r]
+            lead = len(t) if len(t) <= need else max(L - min(E, L - need), 0)
+            assert set(lk[:lead].tolist()) <= set(t) and len(set(lk[:lead].tolist())) == lead and len(set(lk[lead:].tolist())) == L - lead
+            assert np.array_equal(lab, np.array([float(v in t) for v in lk], np.float32)) and int(h["e2"][r]) == int(lk[0])
+        assert np.isfinite(float(m.train_step(b).cpu()[0]))
+    m.close()

@@ -284,3 +284,42 @@ def test_device_train_dataset_sampler_rules():
     assert counts.min() > 0 and counts.max() < 4 * counts.mean()
     with pytest.raises(ValueError):
         DeviceTrainDataset(s, E, 4, num_labels=E + 1, device="cpu")
+
+
+def test_device_train_dataset_proportional_sampler_rules():
+    """The proportional sampler most shipped configs use (one_positive_label_per_sample: False, data.py:228-277) on the device
+    path: the leading entries are the record's tails (all of them when there are at most int(L / (1 + prop)) of them, else
+    L - min(|E|, L - needed)), in a random order; the rest is the head of a permutation of all entities; labels = membership;
+    e2 = the first listed tail."""
+    from coper_amd.data import DeviceTrainDataset
+    rng = np.random.default_rng(4)
+    E, N, L = 97, 40, 22
+    indptr, idx = [0], []
+    for i in range(N):
+        k = int(rng.integers(1, 9))
+        idx.extend(sorted(rng.choice(E, size=k, replace=False)))
+        indptr.append(len(idx))
+    s = dict(e1=np.arange(N), rel=rng.integers(0, 6, N), tail_indptr=np.array(indptr), tail_idx=np.array(idx))
+    for prop in (10.0, 2.0):
+        need = int(1.0 / (1.0 + prop) * L)
+        ds = DeviceTrainDataset(s, E, batch_size=16, num_labels=L, seed=2, device="cpu", one_positive_label_per_sample=False,
+                                prop_negatives=prop, shuffle_buffer=30)
+        it = iter(ds)
+        orders = set()
+        for _ in range(12):
+            b = {k: v.numpy() for k, v in next(it).items()}
+            assert b["lookup_values"].shape == (16, L) and b["e2_multi"].shape == (16, L)
+            for r in range(16):
+                i = int(b["e1"][r])                                      # e1 = record id in this fixture
+                t = idx[indptr[i]:indptr[i + 1]]
+                lk, lab = b["lookup_values"][r], b["e2_multi"][r]
+                lead = len(t) if len(t) <= need else max(L - min(E, L - need), 0)
+                assert set(lk[:lead].tolist()) <= set(t) and len(set(lk[:lead].tolist())) == lead
+                assert len(set(lk[lead:].tolist())) == L - lead          # the head of a permutation: distinct
+                assert np.array_equal(lab, np.array([float(v in t) for v in lk], np.float32))
+                assert int(b["e2"][r]) == int(lk[0]) if lead else int(b["e2"][r]) in t
+                assert b["rel"][r] == s["rel"][i]
+                if len(t) >= 3 and lead >= 3:
+                    orders.add((i, tuple(lk[:3].tolist())))
+        if prop == 2.0:
+            assert len({i for i, _ in orders}) < len(orders)              # tails come in different orders on different visits
