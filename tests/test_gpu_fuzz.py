@@ -201,3 +201,36 @@ def test_reference_style_dense_mask_batches():
     b = ranking_and_hits(m, None, iter(dense_batches), "dense", return_ranks=True)
     assert a[:3] == b[:3] and np.array_equal(a[3], b[3])
     m.close()
+
+
+def test_filter_rows_with_thousands_of_known_answers():
+    """A query whose filter list holds most of the entity table (real KGs have such (e1, rel) pairs): the pass takes the
+    balanced two-call path (sharding._heavy_filter_rows) and both it and the fused call give the closed-form ranks."""
+    from coper_amd import sharding
+    from coper_amd.metrics import ranking_and_hits
+    from coper_amd.models import ConvE
+    md = cdata.model_descriptors("fb15k237_cpg", num_ent=6000, num_rel=20)
+    m = ConvE(md, device="cuda:0", score_mode="bf16x3").load_parameters(cdata.synthetic_params(md, 2)).prepare()
+    Q, E = 200, md["num_ent"]
+    q = cdata.synthetic_queries(md, Q, seed=5)
+    rng = np.random.default_rng(8)
+    rows = [q["filt_idx"][q["filt_indptr"][i]:q["filt_indptr"][i + 1]] for i in range(Q)]
+    for i, n in ((7, 5000), (8, 1500), (150, 3000)):
+        rows[i] = np.unique(np.concatenate([rows[i], rng.choice(E, n, replace=False)]))
+    indptr = np.zeros(Q + 1, np.int64)
+    indptr[1:] = np.cumsum([len(r) for r in rows])
+    idx = np.concatenate(rows)
+    assert sharding._heavy_filter_rows(indptr)
+    h = m.encode(q["e1"], q["rel"])
+    logits = m.score_all(h).cpu().numpy()
+    mask = cdata.csr_to_dense_filter(indptr, idx, E).astype(bool)
+    tgt = logits[np.arange(Q), q["e2"]]
+    keep = ~mask
+    keep[np.arange(Q), q["e2"]] = False
+    want = 1 + ((logits > tgt[:, None]) & keep).sum(axis=1)
+    fused, _ = m.rank_pass(q["e1"], q["rel"], q["e2"], indptr, idx)
+    assert np.array_equal(fused.cpu().numpy(), want)
+    batches = [dict(e1=q["e1"], e2=q["e2"], rel=q["rel"], filt_indptr=indptr, filt_idx=idx)]
+    out = ranking_and_hits(m, None, iter(batches), "heavy", return_ranks=True)
+    assert np.array_equal(out[3], want)
+    m.close()

@@ -130,3 +130,25 @@ def test_unsorted_filter_rows_are_sorted_before_the_kernels_see_them():
     assert canonical_csr(np.array([0, 0]), np.zeros(0, np.int64))[1].tolist() == []
     q = collect_batches([dict(e1=[0, 1], e2=[5, 4], rel=[0, 0], filt_indptr=[0, 3, 5], filt_idx=[9, 5, 2, 4, 1])])
     assert q["filt_idx"].tolist() == [2, 5, 9, 1, 4] and q["filt_indptr"].tolist() == [0, 3, 5]
+
+
+def test_heavy_filter_rows_take_the_two_call_path():
+    from coper_amd import sharding
+    calls = []
+
+    class M:
+        def rank_pass(self, *a, **k):
+            calls.append("fused"); return "r", None
+        def encode(self, e1, rel):
+            calls.append("encode"); return "h"
+        def rank(self, h, e2, ip, ix, filt_nnz=None):
+            calls.append("rank"); return "r", "ne"
+
+    light = np.arange(0, 5 * 101, 5)                       # 100 queries, 5 entries each
+    heavy = light.copy(); heavy[40:] += 3000               # one query with 3,000 known answers
+    z = np.zeros(100, np.int64)
+    sharding.local_rank_pass(M(), dict(e1=z, rel=z, e2=z, filt_indptr=light, filt_idx=np.zeros(light[-1], np.int64)))
+    sharding.local_rank_pass(M(), dict(e1=z, rel=z, e2=z, filt_indptr=heavy, filt_idx=np.zeros(heavy[-1], np.int64)))
+    assert calls == ["fused", "encode", "rank"]
+    assert not sharding._heavy_filter_rows(np.array([0])) and not sharding._heavy_filter_rows(np.array([0, 1024]))
+    assert sharding._heavy_filter_rows(np.array([0, 1025]))
