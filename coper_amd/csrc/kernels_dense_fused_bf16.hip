@@ -151,6 +151,11 @@ __device__ __forceinline__ void fused_matrix_role(const uint4* __restrict__ xrin
   // pass against cached loads, which push the entity table out of L2 ahead of the count pass); plain loads when every
   // tile of a relation re-reads it and L2 serves the repeats (3 tiles per relation at WN18RR shapes: -11 % on this
   // kernel; all 160 tiles for the static layer of plain ConvE: -3.5 %)
+  // ... and per tile: a relation cut into several tiles (skewed batches: a few relations carry most queries) keeps cached
+  // loads even under WNT, so that L2 / the Infinity Cache serve the repeats -- with every tile streaming past the caches a
+  // Zipf-distributed batch (328 tiles for 237 relations) cost 261 us against 184 for the uniform one
+  // (the workgroup-level dispatch in k_dense_fused_bf16x3 instantiates this role with WNT = false for such tiles: a
+  // run-time choice between the two load forms inside the loop cost the uniform batch 3.7 % on this kernel)
 #define FUSED_W_LOAD(p_) (WNT ? __builtin_nontemporal_load(p_) : *(p_))
 #define W_ISSUE(s, kk)                                                                                 \
   {                                                                                                    \
@@ -360,6 +365,7 @@ __global__ __launch_bounds__(512) void k_dense_fused_bf16x3(const uint4* __restr
   const int64_t relw = __builtin_amdgcn_readfirstlane(tl[0]);
   const int start = __builtin_amdgcn_readfirstlane(tl[1]);
   const int n = __builtin_amdgcn_readfirstlane(tl[2]);
+  const bool shared_w = __builtin_amdgcn_readfirstlane(tl[3]) != 0;
   const int64_t kb = ks32n * slice / nslices, ke = ks32n * (slice + 1) / nslices;
   float* zdst = z_part + (int64_t)slice * Bcap * d_pad16;
   const int nb = (n + 15) >> 4;
@@ -374,11 +380,20 @@ __global__ __launch_bounds__(512) void k_dense_fused_bf16x3(const uint4* __restr
   const int t0 = i_lo * A.in_w;
   int t1 = ((int)((ke - 1) / A.Wo) + 3) * A.in_w;
   if (t1 > A.in_hw) t1 = A.in_hw;
+#ifdef COPER_FUSED_NO_TILE_POLICY   // A/B: the launch-level choice only
+#define TILE_WNT(x_) WNT
+#else
+#define TILE_WNT(x_) (x_)
+#endif
 #define BODY(NB_)                                                                                                      \
-  if (wave < 4)                                                                                                        \
-    fused_matrix_role<NFB, NB_, WNT>(xring, img, Whi, Wlo, A, relw, start, n, fb0, nfb, ks32n, kb, ke, t0, t1, zdst,        \
-                                d_pad16, wave);                                                                        \
-  else                                                                                                                 \
+  if (wave < 4) {                                                                                                      \
+    if (WNT && !shared_w)                                                                                              \
+      fused_matrix_role<NFB, NB_, TILE_WNT(true)>(xring, img, Whi, Wlo, A, relw, start, n, fb0, nfb, ks32n, kb, ke, t0, t1, zdst, \
+                                                  d_pad16, wave);                                                      \
+    else                                                                                                               \
+      fused_matrix_role<NFB, NB_, TILE_WNT(false)>(xring, img, Whi, Wlo, A, relw, start, n, fb0, nfb, ks32n, kb, ke, t0, t1, zdst, \
+                                                   d_pad16, wave);                                                     \
+  } else                                                                                                               \
     fused_conv_role<NB_>(xring, img, A, relw, start, n, kb, ke, i_lo, t0, t1, wave - 4);
   switch (nb) {
     case 1: BODY(1); break;

@@ -129,7 +129,7 @@ __device__ __forceinline__ void rel_scan_tiles_body(const int32_t* count, int64_
       t[0] = (int32_t)rid;
       t[1] = off + j * bsz + (j < rem ? j : rem);
       t[2] = sz;
-      t[3] = 0;
+      t[3] = nb > 1 ? 1 : 0;   // the relation has several tiles: its weights are worth caching (k_dense_fused_bf16x3)
     }
   }
 }
