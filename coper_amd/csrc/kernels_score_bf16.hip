@@ -536,8 +536,11 @@ __global__ __launch_bounds__(256) void k_pair_bf16x3(const uint4* __restrict__ E
       erow = e2[p] - lo;
       // the ranking flows hand the CSR filter to the target pass too: it writes the row id of every filter entry
       // (consumed by the filter pass that follows on the same stream) -- no separate expansion launch, no bisection
-      if (indptr && half == 0)
-        for (int64_t j = indptr[p]; j < indptr[p + 1]; ++j) const_cast<int32_t*>(row_of)[j] = (int32_t)p;
+      // (a lane writes the first 32 entries of its row; longer rows are finished by the whole wave below)
+      if (indptr && half == 0) {
+        const int64_t j0 = indptr[p], j1 = indptr[p + 1];
+        for (int64_t j = j0; j < j1 && j < j0 + 32; ++j) const_cast<int32_t*>(row_of)[j] = (int32_t)p;
+      }
     } else if (mode == 1) {
       q = p / L;
       erow = (int64_t)lookup[p] - lo;
@@ -560,6 +563,19 @@ __global__ __launch_bounds__(256) void k_pair_bf16x3(const uint4* __restrict__ E
       if (f == e2[q]) erow = -1;                        // the target is restored after masking (metrics.py:46)
     }
     if (erow >= n_local) erow = -1;
+  }
+  if (mode == 0 && indptr) {
+    // rows with more than 32 known answers (real KGs have rows with thousands): the wave fills the rest of row_of together,
+    // one such row at a time -- a single lane walking 5,000 entries held the whole launch back by ~50 us
+    const bool is_long = half == 0 && p < n_pairs && indptr[p + 1] - indptr[p] > 32;
+    unsigned long long todo = __ballot(is_long);
+    while (todo) {
+      const int src = __builtin_ctzll(todo);
+      todo &= todo - 1;
+      const int64_t pp = __shfl(p, src);
+      const int64_t j0 = indptr[pp] + 32, j1 = indptr[pp + 1];
+      for (int64_t j = j0 + lane; j < j1; j += 64) const_cast<int32_t*>(row_of)[j] = (int32_t)pp;
+    }
   }
   if (half == 0) s_e[wave][i] = erow;
   __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): wave-local LDS exchange
@@ -595,19 +611,37 @@ __global__ __launch_bounds__(256) void k_pair_bf16x3(const uint4* __restrict__ E
       if (ks + u < KS) MFMA_X3(ah[u], al[u], bh[u], bl[u], acc);   // wave-uniform
   }
   // D[i][i] sits in lane i + 32*((i>>2)&1), register (i&3) + 4*(i>>3)
-  if (((i >> 2) & 1) != half || p >= n_pairs) return;
+  const bool diag_lane = ((i >> 2) & 1) == half && p < n_pairs;
   const int reg = (i & 3) + 4 * (i >> 3);
   float sc = 0.f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) sc = (r == reg) ? acc[r] : sc;
   if (mode != 2) {
-    out[p] = erow >= 0 ? sc : 0.f;
+    if (diag_lane) out[p] = erow >= 0 ? sc : 0.f;
     return;
   }
-  if (erow < 0) return;
-  float t = tgt[q];
-  if (sc > t) atomicSub(&ng[q], 1);
-  else if (ne && sc == t) atomicSub(&ne[q], 1);
+  // filter correction: consecutive entries belong to the same query (CSR order), so the wave adds up each run of equal
+  // query ids and issues ONE atomic per run and counter -- a row with 5,000 known answers was 5,000 atomics on one address
+  // (~100 us), now 157.  Every lane runs the cross-lane steps; lanes 0..31 stand for entries 0..31.
+  const bool valid = diag_lane && erow >= 0;
+  const float t = valid ? tgt[q] : 0.f;
+  const int src = i + 32 * ((i >> 2) & 1);                       // the lane that holds entry i's diagonal value
+  const int hit_g = __shfl((valid && sc > t) ? 1 : 0, src);
+  const int hit_e = __shfl((valid && sc == t) ? 1 : 0, src);
+  const int64_t q_prev = __shfl_up(q, 1);
+  const bool in_tile = p < n_pairs && p < indptr[B];
+  const bool head = half == 0 && in_tile && (i == 0 || q_prev != q);
+  const unsigned heads = (unsigned)(__ballot(head) & 0xFFFFFFFFull);
+  const unsigned m_g = (unsigned)(__ballot(half == 0 && hit_g) & 0xFFFFFFFFull);
+  const unsigned m_e = (unsigned)(__ballot(half == 0 && hit_e) & 0xFFFFFFFFull);
+  if (head) {
+    const unsigned later = i < 31 ? (heads >> (i + 1)) : 0u;
+    const int end = later ? i + 1 + __builtin_ctz(later) : 32;   // entries [i, end) share this lane's query
+    const unsigned run = (end >= 32 ? 0xFFFFFFFFu : ((1u << end) - 1u)) & ~((1u << i) - 1u);
+    const int cg = __builtin_popcount(m_g & run), ce = __builtin_popcount(m_e & run);
+    if (cg) atomicSub(&ng[q], cg);
+    if (ne && ce) atomicSub(&ne[q], ce);
+  }
 }
 
 // CSR -> row id per entry, and the retirement of the target itself (scored == tgt, counted as "equal")
