@@ -401,42 +401,76 @@ int launch_pair_targets(coper_handle* h, const float* hvec, const int64_t* e2, i
 
 // 16 lanes per query walk its CSR filter list (coalesced id reads, no row search); lane 0 of the group
 // also retires the target itself, which scored == tgt by construction and was counted as "equal".
-__global__ void k_filter_correct(const float* __restrict__ ent, const float* __restrict__ bias,
+constexpr int FC_GROUP_ENTRIES = 256;   // entries of a row its 16-lane group walks; the rest of a longer row: the whole workgroup
+
+__global__ __launch_bounds__(256) void k_filter_correct(const float* __restrict__ ent, const float* __restrict__ bias,
                                  const float* __restrict__ hvec, const float* __restrict__ tgt,
                                  const int64_t* __restrict__ e2, const int64_t* __restrict__ indptr,
                                  const int64_t* __restrict__ idx, int64_t B, int d, int64_t lo, int64_t n_local,
                                  int32_t* __restrict__ ng, int32_t* __restrict__ ne) {
+  __shared__ int s_long[16];       // queries of this workgroup (16 per workgroup) with more than FC_GROUP_ENTRIES entries
+  __shared__ int s_nlong;
+  __shared__ int s_dg, s_de;
+  if (threadIdx.x == 0) s_nlong = 0;
+  __syncthreads();
   int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int64_t b = gid >> 4;
   int sub = (int)(gid & 15);
-  if (b >= B) return;
-  const float t = tgt[b];
-  const int64_t target = e2[b];
-  if (sub == 0) {
-    int64_t row = target - lo;
-    if (ne && row >= 0 && row < n_local && t == t) atomicSub(&ne[b], 1);
-  }
-  const int64_t beg = indptr[b], end = indptr[b + 1];
-  int dg = 0, de = 0;
-  for (int64_t i = beg + sub; i < end; i += 16) {
+  // one entry of the filter list against the query's target: (greater, equal) contributions
+  auto entry = [&](int64_t bq, int64_t i, int64_t beg, float t, int64_t target, int& dg, int& de) {
     int64_t f = idx[i];
-    if (i > beg && idx[i - 1] == f) continue;  // adjacent duplicate: the dense mask is idempotent
-    if (f == target) continue;                 // the target is restored after masking (metrics.py:46)
+    if (i > beg && idx[i - 1] == f) return;    // adjacent duplicate: the dense mask is idempotent
+    if (f == target) return;                   // the target is restored after masking (metrics.py:46)
     int64_t row = f - lo;
-    if (row < 0 || row >= n_local) continue;
-    float s = chain_score(ent + row * d, hvec + b * d, bias[row], d);
-    dg += s > t ? 1 : 0;
-    de += s == t ? 1 : 0;
-  }
-  // reduce over the 16-lane group
+    if (row < 0 || row >= n_local) return;
+    float sc = chain_score(ent + row * d, hvec + bq * d, bias[row], d);
+    dg += sc > t ? 1 : 0;
+    de += sc == t ? 1 : 0;
+  };
+  if (b < B) {
+    const float t = tgt[b];
+    const int64_t target = e2[b];
+    if (sub == 0) {
+      int64_t row = target - lo;
+      if (ne && row >= 0 && row < n_local && t == t) atomicSub(&ne[b], 1);
+    }
+    const int64_t beg = indptr[b], end = indptr[b + 1];
+    const int64_t stop = end - beg > FC_GROUP_ENTRIES ? beg + FC_GROUP_ENTRIES : end;
+    if (sub == 0 && end > stop) s_long[atomicAdd(&s_nlong, 1)] = (int)(b - (int64_t)blockIdx.x * 16);
+    int dg = 0, de = 0;
+    for (int64_t i = beg + sub; i < stop; i += 16) entry(b, i, beg, t, target, dg, de);
+    // reduce over the 16-lane group
 #pragma unroll
-  for (int m = 8; m >= 1; m >>= 1) {
-    dg += __shfl_xor(dg, m);
-    de += __shfl_xor(de, m);
+    for (int m = 8; m >= 1; m >>= 1) {
+      dg += __shfl_xor(dg, m);
+      de += __shfl_xor(de, m);
+    }
+    if (sub == 0) {
+      if (dg) atomicSub(&ng[b], dg);
+      if (ne && de) atomicSub(&ne[b], de);
+    }
   }
-  if (sub == 0) {
-    if (dg) atomicSub(&ng[b], dg);
-    if (ne && de) atomicSub(&ne[b], de);
+  __syncthreads();
+  // rows with thousands of known answers (real KGs have them): all 256 threads take the rest of such a row together -- 16
+  // lanes walking 5,000 entries one fma chain at a time held the launch back by hundreds of microseconds
+  const int nlong = s_nlong;
+  for (int r = 0; r < nlong; ++r) {
+    if (threadIdx.x == 0) { s_dg = 0; s_de = 0; }
+    __syncthreads();
+    const int64_t bq = (int64_t)blockIdx.x * 16 + s_long[r];
+    const float t = tgt[bq];
+    const int64_t target = e2[bq];
+    const int64_t beg = indptr[bq], end = indptr[bq + 1];
+    int dg = 0, de = 0;
+    for (int64_t i = beg + FC_GROUP_ENTRIES + threadIdx.x; i < end; i += 256) entry(bq, i, beg, t, target, dg, de);
+    if (dg) atomicAdd(&s_dg, dg);
+    if (de) atomicAdd(&s_de, de);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      if (s_dg) atomicSub(&ng[bq], s_dg);
+      if (ne && s_de) atomicSub(&ne[bq], s_de);
+    }
+    __syncthreads();
   }
 }
 

@@ -203,14 +203,15 @@ def test_reference_style_dense_mask_batches():
     m.close()
 
 
-def test_filter_rows_with_thousands_of_known_answers():
+@pytest.mark.parametrize("mode", ["bf16x3", "f32"])
+def test_filter_rows_with_thousands_of_known_answers(mode):
     """A query whose filter list holds most of the entity table (real KGs have such (e1, rel) pairs): the pass takes the
     balanced two-call path (sharding._heavy_filter_rows) and both it and the fused call give the closed-form ranks."""
     from coper_amd import sharding
     from coper_amd.metrics import ranking_and_hits
     from coper_amd.models import ConvE
     md = cdata.model_descriptors("fb15k237_cpg", num_ent=6000, num_rel=20)
-    m = ConvE(md, device="cuda:0", score_mode="bf16x3").load_parameters(cdata.synthetic_params(md, 2)).prepare()
+    m = ConvE(md, device="cuda:0", score_mode=mode).load_parameters(cdata.synthetic_params(md, 2)).prepare()
     Q, E = 200, md["num_ent"]
     q = cdata.synthetic_queries(md, Q, seed=5)
     rng = np.random.default_rng(8)
