@@ -389,6 +389,8 @@ class DeviceTrainDataset(object):
         self.row_tail = np.asarray(samples["tail_idx"], np.int64)          # the positive of each row (same order)
         self.rec_first_row = ip[:-1]
         self.n_rows = len(self.row_rec)
+        if self.n_rows == 0:
+            raise ValueError("DeviceTrainDataset: no (e1, rel) record has a known tail -- nothing to sample from")
         if not self.one_pos:      # the proportional sampler (data.py:228-277): one row per record that has tails
             self.rows_of_rec = np.nonzero(k > 0)[0].astype(np.int64)
         self.d_e1 = torch.as_tensor(np.asarray(samples["e1"], np.int64)).to(self.device)
