@@ -146,14 +146,13 @@ static int ensure_workspace(coper_handle* h, int64_t B, int64_t nnz, hipStream_t
   int64_t cap = B < 64 ? 64 : B;
   int rc;
   const int KSPLIT_MAX = 8;
-  // counts (two buffers, ping-pong: see launch_group_by_relation) | cursors | ticket; zeroed once here, kept zero by the kernels
+  // published counts | accumulation buffer (see launch_group_by_relation) | cursors | ticket; zeroed once here, kept zero by the kernels
   dev_free(&h->rel_count_buf[0]);
   if ((rc = dev_alloc(h, &h->rel_count_buf[0], 3 * (dm.R + 2) + 4))) return rc;
   COPER_HIP_TRY(h, hipMemsetAsync(h->rel_count_buf[0], 0, sizeof(int32_t) * (3 * (dm.R + 2) + 4), s));
   h->rel_count_buf[1] = h->rel_count_buf[0] + (dm.R + 2);
   h->rel_cursor = h->rel_count_buf[0] + 2 * (dm.R + 2);
   h->group_done = h->rel_count_buf[0] + 3 * (dm.R + 2);
-  h->rel_count_cur = 0;
   h->rel_count = h->rel_count_buf[0];
   if ((rc = dev_alloc(h, &h->rel_offset, dm.R + 2))) return rc;
   if ((rc = dev_alloc(h, &h->perm, cap))) return rc;

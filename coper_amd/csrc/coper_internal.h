@@ -95,9 +95,8 @@ struct coper_handle {
   int64_t ws_queries = 0;
   int64_t ws_nnz = 0;
   int ws_ksplit = 0;
-  int32_t* rel_count = nullptr;   // [R+2] counts of the LAST grouping call (+ the out-of-range counter at R+1): one of the two below
-  int32_t* rel_count_buf[2] = {nullptr, nullptr};   // ping-pong: a grouping call zeroes the other buffer for the next call
-  int rel_count_cur = 0;
+  int32_t* rel_count = nullptr;   // [R+2] counts of the LAST grouping call (+ the out-of-range counter at R+1) = rel_count_buf[0]
+  int32_t* rel_count_buf[2] = {nullptr, nullptr};   // [0] the published counts; [1] the accumulation buffer of k_rel_hist_scan (zero between calls)
   int32_t* group_done = nullptr;  // ticket counter of the histogram launch (its last block runs the scan)
   int32_t* rel_offset = nullptr;  // [R+1]
   int32_t* rel_cursor = nullptr;  // [R]

@@ -141,17 +141,21 @@ __global__ __launch_bounds__(1024) void k_rel_scan_tiles(const int32_t* __restri
   rel_scan_tiles_body(count, R, cap_small, offset, tiles, n_tiles);
 }
 
-// Histogram with the scan folded in: the last block to finish (ticket counter) reads the totals back with atomics
-// (executed at the memory side: coherent whatever XCD added them), runs the scan / tile lists, and zeroes the scatter
-// cursors -- two launches per grouping (this one and k_rel_scatter) instead of memset + hist + scan + scatter.
-// `count` arrives zeroed: every grouping call zeroes the OTHER of two count buffers for the call after it (k_rel_scatter).
+// Histogram with the scan folded in: the last block to finish (ticket counter) takes the totals out of the accumulation
+// buffer with memory-side atomic exchanges (coherent whatever XCD added them; the exchange leaves the buffer ZERO for the
+// next call), publishes them in `count` (what later kernels and coper_check_ids read), runs the scan / tile lists, and
+// zeroes the scatter cursors -- two launches per grouping (this one and k_rel_scatter).  Every pointer is fixed for the
+// life of the workspace and the launch resets its own state: a hipGraph that captured it replays correctly any number
+// of times, also interleaved with eager calls (round 2 alternated two count buffers from HOST state, which a captured
+// graph froze: ADVICE r2).  `acc` must be zero on entry: ensure_workspace zeroes it once, every call leaves it zero.
 __global__ __launch_bounds__(HIST_BLOCK) void k_rel_hist_scan(const int64_t* __restrict__ rel, int64_t B, int use_rel, int64_t R,
-                                                               int32_t* __restrict__ count, int32_t* __restrict__ bad,
+                                                               int64_t R_all, int32_t* __restrict__ acc, int32_t* __restrict__ count,
                                                                int32_t* __restrict__ done, int64_t cap_small,
                                                                int32_t* __restrict__ offset, int32_t* __restrict__ tiles,
                                                                int32_t* __restrict__ n_tiles, int32_t* __restrict__ cursor) {
   extern __shared__ int32_t sh[];   // [R]
   __shared__ int s_last;
+  int32_t* bad = acc + R_all + 1;
   for (int k = threadIdx.x; k < R; k += HIST_BLOCK) sh[k] = 0;
   __syncthreads();
   int64_t b = (int64_t)blockIdx.x * HIST_BLOCK + threadIdx.x;
@@ -162,17 +166,22 @@ __global__ __launch_bounds__(HIST_BLOCK) void k_rel_hist_scan(const int64_t* __r
   }
   __syncthreads();
   for (int k = threadIdx.x; k < R; k += HIST_BLOCK)
-    if (sh[k]) atomicAdd(&count[k], sh[k]);
+    if (sh[k]) atomicAdd(&acc[k], sh[k]);
   __threadfence();
   __syncthreads();
   if (threadIdx.x == 0) s_last = atomicAdd(done, 1) == (int)gridDim.x - 1 ? 1 : 0;
   __syncthreads();
   if (!s_last) return;
   for (int k = threadIdx.x; k < R; k += HIST_BLOCK) {
-    sh[k] = atomicAdd(&count[k], 0);
+    const int32_t c = atomicExch(&acc[k], 0);
+    sh[k] = c;
+    count[k] = c;
     cursor[k] = 0;
   }
-  if (threadIdx.x == 0) *done = 0;
+  if (threadIdx.x == 0) {
+    count[R_all + 1] = atomicExch(bad, 0);
+    *done = 0;
+  }
   __syncthreads();
   rel_scan_tiles_body(sh, R, cap_small, offset, tiles, n_tiles);
 }
@@ -235,12 +244,10 @@ __global__ __launch_bounds__(HIST_BLOCK) void k_rel_scatter(const int64_t* __res
                                                              int64_t shard_lo, int64_t n_local, int64_t R_all,
                                                              int32_t* __restrict__ sorted_row,
                                                              int32_t* __restrict__ sorted_rid,
-                                                             int32_t* __restrict__ inv_perm, int32_t* __restrict__ zero_next,
-                                                             int64_t n_zero) {
+                                                             int32_t* __restrict__ inv_perm) {
   extern __shared__ int32_t sh[];  // [R] block counts, then block bases
   const bool priv = R <= HIST_LDS_MAX;
   int64_t b = (int64_t)blockIdx.x * HIST_BLOCK + threadIdx.x;
-  if (zero_next && b < n_zero) zero_next[b] = 0;   // the count buffer of the NEXT grouping call
   int64_t key = 0, rid = 0, row = -1;
   if (b < B) {
     rid = rel[b];
@@ -289,11 +296,11 @@ int launch_group_by_relation(coper_handle* h, const int64_t* e1, const int64_t* 
                              hipStream_t s) {
   const Dims& dm = h->dm;
   int64_t R = dm.gen_fc ? dm.R : 1;
-  // Two count buffers: buffer[cur] is all zero (kept so by the two-launch path: each call zeroes the buffer of the call
-  // after it), buffer[cur ^ 1] is scratch -- the paths that reset their counts themselves use that one.
+  // rel_count (= rel_count_buf[0]) holds the counts of the last call; rel_count_buf[1] is the accumulation buffer of the
+  // two-launch path, zero between calls (its last block takes the totals out with atomic exchanges).  No host-side state
+  // changes per call: every path below is hipGraph-capturable and replayable, alone or mixed with eager calls.
   if (R <= HIST_LDS_MAX && B <= 4096) {   // a single workgroup is latency-bound beyond a few ids per thread
     // rel_count[R+1] doubles as the out-of-range counter (reset by the kernel)
-    h->rel_count = h->rel_count_buf[h->rel_count_cur ^ 1];
     hipLaunchKernelGGL(k_rel_group_single, dim3(1), dim3(1024), sizeof(int32_t) * 2 * (size_t)R, s, rel, e1, B, dm.gen_fc ? 1 : 0, R,
                        dm.R, have_e1_rows ? 1 : 0, (int64_t)h->cfg.shard_lo, dm.n_local, small_tile_cap(h), h->rel_count,
                        h->rel_count + dm.R + 1, h->rel_offset, h->tiles, h->n_tiles, h->perm, h->sorted_row, h->sorted_rid, h->inv_perm);
@@ -303,25 +310,21 @@ int launch_group_by_relation(coper_handle* h, const int64_t* e1, const int64_t* 
   }
   unsigned nb = (unsigned)((B + HIST_BLOCK - 1) / HIST_BLOCK);
   (void)tq;
-  if (R <= HIST_LDS_MAX && (int64_t)nb * HIST_BLOCK >= dm.R + 2) {
-    // two launches: histogram + scan (last block), scatter (which zeroes the other count buffer for the next call)
-    int32_t* cnt = h->rel_count_buf[h->rel_count_cur];
-    int32_t* other = h->rel_count_buf[h->rel_count_cur ^ 1];
-    h->rel_count = cnt;
-    h->rel_count_cur ^= 1;
-    hipLaunchKernelGGL(k_rel_hist_scan, dim3(nb), dim3(HIST_BLOCK), sizeof(int32_t) * (size_t)R, s, rel, B, dm.gen_fc ? 1 : 0, R, cnt,
-                       cnt + dm.R + 1, h->group_done, small_tile_cap(h), h->rel_offset, h->tiles, h->n_tiles, h->rel_cursor);
+  if (R <= HIST_LDS_MAX) {
+    // two launches: histogram + scan (last block), scatter
+    hipLaunchKernelGGL(k_rel_hist_scan, dim3(nb), dim3(HIST_BLOCK), sizeof(int32_t) * (size_t)R, s, rel, B, dm.gen_fc ? 1 : 0, R,
+                       (int64_t)dm.R, h->rel_count_buf[1], h->rel_count, h->group_done, small_tile_cap(h), h->rel_offset, h->tiles,
+                       h->n_tiles, h->rel_cursor);
     hipLaunchKernelGGL(k_rel_scatter, dim3(nb), dim3(HIST_BLOCK), sizeof(int32_t) * (size_t)R, s, rel, B, dm.gen_fc ? 1 : 0, R,
                        h->rel_offset, h->rel_cursor, h->perm, e1, have_e1_rows ? 1 : 0, (int64_t)h->cfg.shard_lo, dm.n_local, dm.R,
-                       h->sorted_row, h->sorted_rid, h->inv_perm, other, dm.R + 2);
+                       h->sorted_row, h->sorted_rid, h->inv_perm);
     COPER_HIP_TRY(h, hipGetLastError());
     return COPER_OK;
   }
-  // relation tables beyond the LDS histogram (or batches too small to zero the next buffer on the way): memset + three launches
-  h->rel_count = h->rel_count_buf[h->rel_count_cur ^ 1];
+  // relation tables beyond the LDS histogram: memset + three launches
   COPER_HIP_TRY(h, hipMemsetAsync(h->rel_count, 0, sizeof(int32_t) * (dm.R + 2), s));
   COPER_HIP_TRY(h, hipMemsetAsync(h->rel_cursor, 0, sizeof(int32_t) * (dm.R + 2), s));
-  size_t hl = R <= HIST_LDS_MAX ? sizeof(int32_t) * (size_t)R : 0;
+  size_t hl = 0;
   // rel_count[R+1] doubles as the out-of-range counter (ids are validated on device, never trusted)
   hipLaunchKernelGGL(k_rel_hist, dim3(nb), dim3(HIST_BLOCK), hl, s, rel, B, dm.gen_fc ? 1 : 0, R, h->rel_count,
                      h->rel_count + dm.R + 1);
@@ -329,7 +332,7 @@ int launch_group_by_relation(coper_handle* h, const int64_t* e1, const int64_t* 
                      h->tiles, h->n_tiles);
   hipLaunchKernelGGL(k_rel_scatter, dim3(nb), dim3(HIST_BLOCK), hl, s, rel, B, dm.gen_fc ? 1 : 0, R, h->rel_offset,
                      h->rel_cursor, h->perm, e1, have_e1_rows ? 1 : 0, (int64_t)h->cfg.shard_lo, dm.n_local, dm.R,
-                     h->sorted_row, h->sorted_rid, h->inv_perm, (int32_t*)nullptr, (int64_t)0);
+                     h->sorted_row, h->sorted_rid, h->inv_perm);
   COPER_HIP_TRY(h, hipGetLastError());
   return COPER_OK;
 }

@@ -450,6 +450,49 @@ def test_hipgraph_replay_equals_eager(mode):
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+def test_hipgraph_large_batch_and_mixed_with_eager(mode):
+    """The grouping of batches above 4,096 queries (histogram + scan, scatter) keeps no host-side state: a captured
+    pass of 5,000 queries replays correctly many times, and eager passes of every grouping path (single-workgroup
+    <= 4,096, two-launch above) interleave with replays of a 512-query graph and of the large graph in any order."""
+    md = cdata.model_descriptors("fb15k237_cpg", num_ent=3001, num_rel=30)
+    p = cdata.synthetic_params(md, 2)
+    m = _model(md, p, score_mode=mode)
+    BL, BS = 5000, 512
+    ql = [cdata.synthetic_queries(md, BL, seed=s_) for s_ in (11, 12, 13)]
+    qs = [cdata.synthetic_queries(md, BS, seed=s_) for s_ in (21, 22)]
+    qe = cdata.synthetic_queries(md, 6000, seed=31)      # eager, two-launch grouping
+    qf = cdata.synthetic_queries(md, 700, seed=32)       # eager, single-workgroup grouping
+    m.reserve(6000, len(qe["filt_idx"]) + 64)            # a workspace that grows after a capture would strand the graph's pointers
+    run_l = m.capture_rank_pass(BL, max(len(q["filt_idx"]) for q in ql) + 64)
+    run_s = m.capture_rank_pass(BS, max(len(q["filt_idx"]) for q in qs) + 64)
+
+    def eager(q):
+        r, ne = m.rank_pass(q["e1"], q["rel"], q["e2"], q["filt_indptr"], q["filt_idx"])
+        return r.cpu().numpy().copy(), ne.cpu().numpy().copy()
+
+    want = {id(q): eager(q) for q in ql + qs + [qe, qf]}
+
+    def check(q, run=None):
+        if run is None:
+            r, ne = eager(q)
+        else:
+            r, ne = run(q["e1"], q["rel"], q["e2"], q["filt_indptr"], q["filt_idx"])
+            r, ne = r.cpu().numpy().copy(), ne.cpu().numpy().copy()
+        assert np.array_equal(r, want[id(q)][0]) and np.array_equal(ne, want[id(q)][1])
+
+    # the large graph several times in a row (round 2: every replay added to the same, never re-zeroed histogram)
+    for q in ql + ql[::-1]:
+        check(q, run_l)
+    # replays and eager passes of every grouping path, odd and even numbers of eager large passes between replays
+    for step in (lambda: check(qe), lambda: check(qs[0], run_s), lambda: check(ql[1], run_l), lambda: check(qe),
+                 lambda: check(qe), lambda: check(qf), lambda: check(qs[1], run_s), lambda: check(qe),
+                 lambda: check(ql[2], run_l), lambda: check(qf), lambda: check(ql[0], run_l), lambda: check(qs[0], run_s)):
+        step()
+    assert m.check_ids() == 0
+    m.close()
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
 @pytest.mark.parametrize("tag", ["plain", "cpg"])
 def test_end_to_end_matches_minerva_torch_models_gpu(golden_dir, tag, mode):
     """HIP path vs the OUTPUT of the reference's PyTorch sister models (fact_network.py forward / forward_fact)."""
