@@ -5,7 +5,10 @@ A "step" = one pass of the hot path (encode -> 1-vs-all score -> filtered rank) 
 synthetic queries: the evaluation set of the workload (Q queries).
 
   python bench.py --gpus N --steps K --warmup W
-  N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`
+  N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (RANK /
+  LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment), or from a plain shell: the process then starts the N ranks
+  itself as fresh child processes (before anything here touches the GPU), relays rank 0's JSON line and exits
+  non-zero when any rank fails.
 
 The JSON line (rank 0, stdout) carries, for the default workload (BASELINE.json configs[1], FB15k-237-shaped
 CoPER-ConvE, bf16x3 arithmetic; query-sharded across ranks = weak scaling):
@@ -323,8 +326,69 @@ def run_scale_blocks(ctx, args):
     return out
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` from a plain shell (no WORLD_SIZE): start the N ranks as fresh child processes of this
+    one -- which has not imported torch, let alone touched the GPU, and never exec()s --, one rank per GPU over RCCL
+    (`--dist-backend gloo`: ranks may share a GPU; debugging on a one-GPU box).  Rank 0's stdout carries the one JSON
+    line and is relayed; a rank that fails takes the others down with it instead of leaving them in the rendezvous."""
+    import signal
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, start_new_session=True))
+    rc, failed = 0, None
+    try:
+        live = set(range(args.gpus))
+        while live and failed is None:
+            time.sleep(0.2)
+            for r in sorted(live):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                live.discard(r)
+                if code != 0:
+                    failed, rc = r, code
+                    break
+    finally:
+        if failed is not None:
+            print("bench.py: rank %d exited with code %s; stopping the other ranks" % (failed, rc), file=sys.stderr)
+        for r, pr in enumerate(procs):
+            if pr.poll() is None:                  # our own children, by process group (each is a session leader)
+                try:
+                    os.killpg(pr.pid, signal.SIGTERM)
+                except ProcessLookupError:
+                    pass
+        for pr in procs:
+            try:
+                pr.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(pr.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+    out = procs[0].stdout.read().decode() if procs[0].stdout else ""
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    if lines:
+        print(lines[-1])
+        sys.stdout.flush()
+    if failed is None and not lines:
+        print("bench.py: rank 0 printed no JSON line", file=sys.stderr)
+        rc = 1
+    sys.exit(rc if rc else 0)
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)          # never returns
     # stdout carries exactly one line, the JSON result of rank 0: whatever libraries print on the way (RCCL's version
     # banner at communicator creation goes to stdout) is sent to stderr
     sys.stdout.flush()
@@ -341,7 +405,8 @@ def main():
     ctx.rank = rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        sys.exit("bench.py --gpus %d: WORLD_SIZE is %d (launch with torch.distributed.run --nproc-per-node %d, or from a plain "
+                 "shell without WORLD_SIZE: the ranks are then started here)" % (args.gpus, world, args.gpus))
     if args.dist_backend != "nccl":
         local_rank = local_rank % max(1, torch.cuda.device_count())   # debugging: ranks may share a GPU
     torch.cuda.set_device(local_rank)

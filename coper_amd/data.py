@@ -12,8 +12,8 @@ This module yields that contract with the mask kept SPARSE (`filt_indptr`, `filt
 int64 list the reference stores in its TFRecords before `tf.sparse_to_dense`, data.py:182-186,591)
 and a dense-mask adapter for API parity.  No real dataset exists offline
 (`/root/reference/.MISSING_LARGE_BLOBS`), so the BASELINE configurations are synthetic KGs of the
-named |E|, |R|, d.  numpy only, except `synthetic_entity_rows_device` (torch, lazily imported: an entity
-table too large to draw on the host).  Nothing here touches the oracle."""
+named |E|, |R|, d.  NumPy for everything on the host; torch for what lives on the device (`synthetic_entity_rows_device`:
+an entity table too large to draw on the host; `DeviceTrainDataset`: the samplers on the GPU).  Nothing here touches the oracle."""
 from __future__ import annotations
 
 import math
@@ -503,6 +503,7 @@ class DeviceTrainDataset(object):
                 yield self._device_batch(r) if self.one_pos else self._device_batch_prop(r)
             return
         side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))   # the uploads of __init__ (rows, CSR) come first
 
         def produce():
             with torch.cuda.stream(side):

@@ -66,6 +66,11 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
+def _host(v):
+    """A batch field as a host NumPy array (`session.run` returns host arrays); device tensors are copied back."""
+    return v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+
+
 class ConvE(object):
     def __init__(self, model_descriptors: dict, device=None, shard=None, score_mode="f32"):
         md = dict(model_descriptors)
@@ -522,7 +527,7 @@ class Session(object):
                 elif n == "loss":
                     out.append(float(loss.cpu()[0]))
                 elif n in ("e1", "e2", "rel", "e2_multi", "lookup_values"):
-                    out.append(np.asarray(batch[n]))
+                    out.append(_host(batch[n]))      # DeviceTrainDataset yields device tensors
                 elif n is None and f is None:       # model.summaries is None in this build (run_cpg.py:216 checks for it)
                     out.append(None)
                 else:
@@ -542,15 +547,15 @@ class Session(object):
         for f in fl:
             n = f.name
             if n in ("e1", "e2", "rel"):
-                out.append(np.asarray(batch[n]))
+                out.append(_host(batch[n]))
             elif n == "e2_multi":
                 if "e2_multi" in batch:
-                    out.append(np.asarray(batch["e2_multi"]))
+                    out.append(_host(batch["e2_multi"]))
                 else:
                     from .data import csr_to_dense_filter
                     out.append(csr_to_dense_filter(batch["filt_indptr"], batch["filt_idx"], m.num_ent))
             elif n == "lookup_values":
-                out.append(np.asarray(batch["lookup_values"]))
+                out.append(_host(batch["lookup_values"]))
             elif n == "predicted_e2_emb":
                 out.append(h().cpu().numpy())
             elif n == "predictions_all":

@@ -1,0 +1,58 @@
+"""GPU: N > 1 ranks of the HIP scorer, started the way the driver starts `bench.py` -- from a plain shell.
+
+`python bench.py --gpus 2` (no WORLD_SIZE) starts its two ranks itself as fresh child processes (bench.py: self_launch).
+On a box with one GPU the ranks share it and talk over gloo (`--dist-backend gloo`); with two or more GPUs they get one
+each and talk over RCCL.  Either way every rank runs the real kernels on its own shard:
+  * main line: query-sharded, every rank its own 20,480 queries on a replicated model (weak scaling);
+  * `scale` block: BASELINE.json configs[4] (10 M entities x 256), entity-sharded -- each rank holds a 5 M-row shard, the
+    encoder is split by relation, the per-shard (counts, top-10) records are exchanged in the one all-gather -- and the
+    ranks must equal the single-GPU ranks of the same KG bit for bit (`ranks_independent_of_world`, SHA-1 of the ranks
+    against the committed single-GPU value)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run_bench(extra, timeout=1500):
+    import torch
+    backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", backend, "--steps", "3",
+                          "--warmup", "1", "--no-cpu-baseline"] + extra, env=env, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-6000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0]), backend
+
+
+def test_bench_two_ranks_from_a_plain_shell():
+    from bench import SCALE_EXPECTED
+    line, backend = _run_bench([])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["value"] > 0
+    assert line["config"]["parallelism"] == "query-sharded x2"
+    sc = line["scale"]
+    assert sc["n_gpus"] == 2 and sc["config"]["parallelism"].startswith("entity-sharded x2 (5000000 rows per rank)")
+    assert sc["ranks_independent_of_world"] is True
+    assert sc["ranks_sha1"] == SCALE_EXPECTED["ranks_sha1"]
+    assert abs(sc["mean_rank"] - SCALE_EXPECTED["mean_rank"]) < 1e-6
+
+
+def test_bench_two_ranks_entity_sharded_main_line():
+    """The entity-sharded path as the main line on a small KG (WN18RR-shaped), top-10 exchanged: its ranks are those of the
+    one-rank run of the same command (mean rank / MRR carried by the line)."""
+    two, _ = _run_bench(["--workload", "wn18rr_cpg", "--mode", "entity", "--topk", "10", "--no-extras"], timeout=900)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "wn18rr_cpg", "--mode", "entity", "--topk", "10",
+                          "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extras"], env=env, capture_output=True, text=True,
+                         timeout=900)
+    assert out.returncode == 0, out.stderr[-4000:]
+    one = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert two["n_gpus"] == 2 and one["n_gpus"] == 1
+    assert two["config"]["mean_rank"] == one["config"]["mean_rank"] and two["config"]["mrr"] == one["config"]["mrr"]

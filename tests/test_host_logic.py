@@ -1,4 +1,6 @@
 """CPU: host-side logic of the drop-in (batch contract, CSR filters, metric means, shard bounds)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -152,3 +154,19 @@ def test_heavy_filter_rows_take_the_two_call_path():
     assert calls == ["fused", "encode", "rank"]
     assert not sharding._heavy_filter_rows(np.array([0])) and not sharding._heavy_filter_rows(np.array([0, 1024]))
     assert sharding._heavy_filter_rows(np.array([0, 1025]))
+
+
+def test_bench_self_launch_propagates_a_failing_rank():
+    """`python bench.py --gpus 2` from a plain shell starts its ranks itself; on this box (no GPU) both ranks fail at
+    device set-up, the launcher stops what is left, prints no JSON line and exits non-zero."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--steps", "1",
+                          "--no-extras", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0
+    assert "stopping the other ranks" in out.stderr and not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]

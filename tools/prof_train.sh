@@ -1,6 +1,7 @@
+R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_train -- python3 $GRAFT_REPO_ROOT/tools/bench_train.py fb15k237_cpg > $GRAFT_REPO_ROOT/gpurun_out/prof_train.log 2>&1
-cd $GRAFT_REPO_ROOT
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_train -- python3 $R/tools/bench_train.py fb15k237_cpg > $R/gpurun_out/prof_train.log 2>&1
+cd $R
 f=$(find gpurun_out/prof_train -name "*kernel_stats.csv" | head -1); python3 - "$f" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))

@@ -1,7 +1,8 @@
+R=${GRAFT_REPO_ROOT:-/root/repo}
 # per-dispatch durations of one training step (the last one of the run): `bash tools/trace_train.sh [workload]`
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/trace_train -- python3 $GRAFT_REPO_ROOT/tools/bench_train.py ${1:-fb15k237_cpg} > $GRAFT_REPO_ROOT/gpurun_out/trace_train.log 2>&1
-cd $GRAFT_REPO_ROOT
+rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/trace_train -- python3 $R/tools/bench_train.py ${1:-fb15k237_cpg} > $R/gpurun_out/trace_train.log 2>&1
+cd $R
 f=$(find gpurun_out/trace_train -name "*kernel_trace.csv" | head -1); python3 - "$f" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
