@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libcoper_hip.so")
 
-COPER_ABI_VERSION = 1
+COPER_ABI_VERSION = 2
 COPER_MAX_CTX = 4
 
 SCORE_F32, SCORE_BF16X3 = 0, 1
@@ -42,7 +42,7 @@ class coper_config(C.Structure):
         ("n_ctx_out", C.c_int32), ("ctx_out", C.c_int32 * COPER_MAX_CTX),
         ("context_rel_use_batch_norm", C.c_int32), ("bn_epsilon", C.c_float),
         ("shard_lo", C.c_int64), ("shard_hi", C.c_int64),
-        ("score_mode", C.c_int32), ("reserved", C.c_int32 * 7),
+        ("score_mode", C.c_int32), ("rank_band_kappa", C.c_float), ("reserved", C.c_int32 * 6),
     ]
 
 
@@ -129,7 +129,7 @@ def check(handle, rc):
         raise CoperError(rc, text.decode() if text else "")
 
 
-def make_config(md, device=0, shard=None, score_mode=SCORE_F32, bn_epsilon=1e-3):
+def make_config(md, device=0, shard=None, score_mode=SCORE_F32, bn_epsilon=1e-3, rank_band_kappa=0.0):
     """model_descriptors dict (models.py:98-130 keys) -> coper_config."""
     cfg = coper_config()
     cfg.abi_version = COPER_ABI_VERSION
@@ -164,4 +164,5 @@ def make_config(md, device=0, shard=None, score_mode=SCORE_F32, bn_epsilon=1e-3)
     lo, hi = shard if shard is not None else (0, cfg.num_ent)
     cfg.shard_lo, cfg.shard_hi = int(lo), int(hi)
     cfg.score_mode = int(score_mode)
+    cfg.rank_band_kappa = float(rank_band_kappa)     # 0: the library default (include/coper_hip.h)
     return cfg

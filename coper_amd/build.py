@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libcoper_hip.so")
-SOURCES = ["coper_abi.hip", "kernels_prepare.hip", "kernels_encode.hip", "kernels_score.hip", "kernels_score_bf16.hip", "kernels_score2_bf16.hip", "kernels_tail_bf16.hip",
+SOURCES = ["coper_abi.hip", "kernels_prepare.hip", "kernels_encode.hip", "kernels_score.hip", "kernels_score_bf16.hip", "kernels_score3_bf16.hip", "kernels_tail_bf16.hip",
            "kernels_encode_bf16.hip", "kernels_dense_fused_bf16.hip", "kernels_topk_bf16.hip", "coper_train.hip", "train_gemm_bf16.hip", "train_gemm_w128_bf16.hip"]
 
 
@@ -37,7 +37,7 @@ SOURCE_FLAGS = {name: VGPR_FORM for name in SOURCES}
 # the fused conv + dense kernel wants its 128 accumulators in AGPRs: the conv's taps and the weight prefetch fill the VGPRs
 SOURCE_FLAGS["kernels_dense_fused_bf16.hip"] = []
 # the pipelined score kernel keeps its accumulators in AGPRs and everything else in the 256 VGPRs (one wave per SIMD)
-SOURCE_FLAGS["kernels_score2_bf16.hip"] = []
+SOURCE_FLAGS["kernels_score3_bf16.hip"] = []
 SOURCE_FLAGS["train_gemm_w128_bf16.hip"] = []   # 256 accumulator registers per lane: they have to be AGPRs
 
 

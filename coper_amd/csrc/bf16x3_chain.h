@@ -1,0 +1,114 @@
+// The ONE summation order of every COPER_SCORE_BF16X3 logit, and the operand images of the count kernel that follow from it.
+//
+// A logit is  s = pred_bias[e] + sum_k E[e][k] h[q][k]  with every factor split into two bf16 terms (x = hi + lo) and the
+// product formed as  E_lo h_hi + E_hi h_lo + E_hi h_hi  on the bf16 matrix cores with fp32 accumulation.  Per k-step of
+// 16 that is three "virtual ops" of one K = 16 matrix instruction each:
+//     T1(ks) = E_lo(ks) . h_hi(ks)      T2(ks) = E_hi(ks) . h_lo(ks)      T3(ks) = E_hi(ks) . h_hi(ks)
+// Round 3 measured (tools/microbench/mfma_shape.hip, 1 M outputs, bit for bit): ONE v_mfma_f32_16x16x32_bf16 over 32 k is
+// the same function of (A, B, C) as TWO chained v_mfma_f32_32x32x16_bf16 over k 0..15 then 16..31 -- the K = 32 instruction
+// is two K = 16 accumulation steps (lanes 0..31 carry the first, lanes 32..63 the second).  The count kernel
+// (kernels_score3_bf16.hip) runs on the 16x16x32 shape (1.12x the FLOP/s of 32x32x16 at the chip's power limit, same
+// microbenchmark) and packs two virtual ops into each instruction; the order that makes this possible with two registers
+// per pair of k-steps -- and that every other kernel of the mode (tiles of score_all, the gathered-pair kernels, the fused
+// tail, the top-k rescoring; all on 32x32x16) follows so that all logits of the mode agree bit for bit -- is
+//
+//     acc = pred_bias
+//     for j in 0 .. NP-1   (NP = KS16 / 2 pairs of k-steps):
+//         acc += T1(2j); acc += T1(2j+1); acc += T2(2j); acc += T2(2j+1); acc += T3(2j); acc += T3(2j+1)
+//     if KS16 is odd (last k-step t = KS16 - 1):
+//         acc += T1(t); acc += T2(t); acc += T3(t)            [the K = 32 form adds an all-zero second half to T3: acc + 0]
+//
+// Count-kernel images ("f3"): per block of 16 rows (entities) or 16 columns (queries), per step s (NP pair steps, then
+// the tail step when KS16 is odd), two 64-lane registers of 16 bytes; lane l holds row (l & 15), 8 consecutive k of one
+// plane: k = 16 ks + 8 ((l >> 4) & 1), with (plane, ks) chosen per half-wave (l >> 5):
+//     pair step s:   reg 0 = [lo(2s) | lo(2s+1)]      reg 1 = [hi(2s) | hi(2s+1)]                  (both sides)
+//     tail step:     entities: reg 0 = [lo(t) | hi(t)], reg 1 = [hi(t) | 0]
+//                    queries:  reg 0 = [hi(t) | 0],     reg 1 = [hi(t) | lo(t)]
+// and the instructions of a step are  (e.reg0, q.reg1), (e.reg1, q.reg0), and for pair steps (e.reg1, q.reg1).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace coper {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define BX3_MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&(a), *(const bf16x8*)&(b), (c), 0, 0, 0)
+#define BX3_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&(a), *(const bf16x8*)&(b), (c), 0, 0, 0)
+
+// 32x32x16 kernels, entity rows = A, queries = B: two consecutive k-steps (fragments *0 of the first, *1 of the second)
+#define BX3_PAIR(eh0, el0, qh0, ql0, eh1, el1, qh1, ql1, c)                     \
+  {                                                                             \
+    (c) = BX3_MFMA32(el0, qh0, c); (c) = BX3_MFMA32(el1, qh1, c);               \
+    (c) = BX3_MFMA32(eh0, ql0, c); (c) = BX3_MFMA32(eh1, ql1, c);               \
+    (c) = BX3_MFMA32(eh0, qh0, c); (c) = BX3_MFMA32(eh1, qh1, c);               \
+  }
+// ... the last k-step of an odd count
+#define BX3_LAST(eh, el, qh, ql, c) \
+  { (c) = BX3_MFMA32(el, qh, c); (c) = BX3_MFMA32(eh, ql, c); (c) = BX3_MFMA32(eh, qh, c); }
+// the same virtual ops with the roles swapped (queries = A rows, entities = B columns: k_score_all_bf16x3): a product does
+// not depend on which side of the matrix unit its factors enter
+#define BX3_PAIR_QA(eh0, el0, qh0, ql0, eh1, el1, qh1, ql1, c)                  \
+  {                                                                             \
+    (c) = BX3_MFMA32(qh0, el0, c); (c) = BX3_MFMA32(qh1, el1, c);               \
+    (c) = BX3_MFMA32(ql0, eh0, c); (c) = BX3_MFMA32(ql1, eh1, c);               \
+    (c) = BX3_MFMA32(qh0, eh0, c); (c) = BX3_MFMA32(qh1, eh1, c);               \
+  }
+#define BX3_LAST_QA(eh, el, qh, ql, c) \
+  { (c) = BX3_MFMA32(qh, el, c); (c) = BX3_MFMA32(ql, eh, c); (c) = BX3_MFMA32(qh, eh, c); }
+
+// ---- f3 images ------------------------------------------------------------------------------------------------------
+__host__ __device__ inline int f3_steps(int KS16) { return (KS16 + 1) / 2; }          // NS = NP + TAIL
+// uint4 index of register (blk16, step s, which) lane l
+__host__ __device__ inline int64_t f3_at(int64_t blk16, int NS, int s, int which, int l) { return ((blk16 * NS + s) * 2 + which) * 64 + l; }
+
+// Writes the 16-byte pieces (hi, lo) of (row, k-step ks, half) into an f3 image.  `query_side`: the queries' tail layout.
+// Zero halves of the tail registers are never written: the image is zero-filled when it is allocated.
+__device__ __forceinline__ void f3_store_piece(uint4* __restrict__ img, int KS16, int64_t row, int ks, int half, const uint4& hi,
+                                               const uint4& lo, bool query_side) {
+  const int NS = f3_steps(KS16), NP = KS16 / 2;
+  const int64_t blk = row >> 4;
+  const int r = (int)(row & 15) + 16 * half;
+  if (ks < 2 * NP) {
+    const int s = ks >> 1, l = r + 32 * (ks & 1);
+    img[f3_at(blk, NS, s, 0, l)] = lo;
+    img[f3_at(blk, NS, s, 1, l)] = hi;
+  } else if (!query_side) {   // entities: reg 0 = [lo | hi], reg 1 = [hi | 0]
+    img[f3_at(blk, NS, NP, 0, r)] = lo;
+    img[f3_at(blk, NS, NP, 0, r + 32)] = hi;
+    img[f3_at(blk, NS, NP, 1, r)] = hi;
+  } else {                    // queries: reg 0 = [hi | 0], reg 1 = [hi | lo]
+    img[f3_at(blk, NS, NP, 0, r)] = hi;
+    img[f3_at(blk, NS, NP, 1, r)] = hi;
+    img[f3_at(blk, NS, NP, 1, r + 32)] = lo;
+  }
+}
+
+// ---- the exact chain (the logit of COPER_SCORE_F32: chain_score of kernels_score.hip) on fp32 rows ---------------------
+// s = bias; for ks: for t in 0..3: s = fma(E[8ks+t], h[8ks+t], s); s = fma(E[8ks+4+t], h[8ks+4+t], s)
+__device__ __forceinline__ float exact_chain(const float* __restrict__ er, const float* __restrict__ hr, float bias, int d) {
+  float s = bias;
+  const int KS = (d + 7) >> 3;
+  if ((d & 7) == 0 && ((((uintptr_t)er) | ((uintptr_t)hr)) & 15) == 0) {
+    for (int ks = 0; ks < KS; ++ks) {
+      const float4 e0 = *(const float4*)(er + 8 * ks), e1 = *(const float4*)(er + 8 * ks + 4);
+      const float4 h0 = *(const float4*)(hr + 8 * ks), h1 = *(const float4*)(hr + 8 * ks + 4);
+      s = __builtin_fmaf(e0.x, h0.x, s); s = __builtin_fmaf(e1.x, h1.x, s);
+      s = __builtin_fmaf(e0.y, h0.y, s); s = __builtin_fmaf(e1.y, h1.y, s);
+      s = __builtin_fmaf(e0.z, h0.z, s); s = __builtin_fmaf(e1.z, h1.z, s);
+      s = __builtin_fmaf(e0.w, h0.w, s); s = __builtin_fmaf(e1.w, h1.w, s);
+    }
+    return s;
+  }
+  for (int ks = 0; ks < KS; ++ks)
+    for (int t = 0; t < 4; ++t) {
+      const int k0 = 8 * ks + t, k1 = k0 + 4;
+      if (k0 < d) s = __builtin_fmaf(er[k0], hr[k0], s);
+      if (k1 < d) s = __builtin_fmaf(er[k1], hr[k1], s);
+    }
+  return s;
+}
+
+}  // namespace coper

@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include "bf16x3_chain.h"
 #include "coper_internal.h"
 #include <mutex>
 #include <unordered_map>
@@ -21,6 +22,17 @@ int hip_fail(coper_handle* h, hipError_t e, const char* what) {
   std::string msg = std::string("HIP error '") + hipGetErrorString(e) + "' in " + what;
   (void)hipGetLastError();
   return fail(h, COPER_EHIP, msg);
+}
+
+int dbg_sync(coper_handle* h, hipStream_t s, const char* what) {
+  static const bool on = getenv("COPER_DBG_SYNC") != nullptr;
+  if (!on) return COPER_OK;
+  fprintf(stderr, "[coper] sync after %s ... ", what);
+  fflush(stderr);
+  const hipError_t e = hipStreamSynchronize(s);
+  fprintf(stderr, "%s\n", e == hipSuccess ? "ok" : hipGetErrorString(e));
+  if (e != hipSuccess) return hip_fail(h, e, what);
+  return COPER_OK;
 }
 
 // Event pairs come from a pool (creating events costs tens of microseconds of host time per launch: inside bench.py's
@@ -164,20 +176,51 @@ static int ensure_workspace(coper_handle* h, int64_t B, int64_t nnz, hipStream_t
   if ((rc = dev_alloc(h, &h->blk_off, dm.R + 2))) return rc;
   if ((rc = dev_alloc(h, &h->x_sorted, (size_t)cap * dm.F_pad))) return rc;
   if ((rc = dev_alloc(h, &h->z_part, (size_t)KSPLIT_MAX * cap * dm.d_pad16))) return rc;
-  if ((rc = dev_alloc(h, &h->tgt_ws, cap))) return rc;
+  if ((rc = dev_alloc(h, &h->tgt_ws, 2 * cap))) return rc;    // [mode logit | exact-chain logit] (coper_target_scores)
   if ((rc = dev_alloc(h, &h->cnt_ws, 2 * cap))) return rc;
   if (h->cfg.score_mode == COPER_SCORE_F32) {
     if ((rc = dev_alloc(h, &h->hfrag_ws, (size_t)((cap + 127) / 128) * 128 * dm.d_pad8))) return rc;
   } else {
     size_t plane = (size_t)((cap + 127) / 128) * 4 * dm.KS16 * 64 * 16;
+    const size_t f3 = (size_t)((cap + 127) / 128) * 8 * f3_steps(dm.KS16) * 2 * 64 * 16;   // the count kernel's query image
     dev_free((char**)&h->hfrag16_hi); dev_free((char**)&h->hfrag16_lo);
-    dev_free((char**)&h->hrm16_hi); dev_free((char**)&h->hrm16_lo);
+    dev_free((char**)&h->hrm16_hi); dev_free((char**)&h->hrm16_lo); dev_free((char**)&h->hf3_ws);
     if (tracked_malloc(&h->hfrag16_hi, plane) != hipSuccess || tracked_malloc(&h->hfrag16_lo, plane) != hipSuccess ||
-        tracked_malloc(&h->hrm16_hi, plane) != hipSuccess || tracked_malloc(&h->hrm16_lo, plane) != hipSuccess)
+        tracked_malloc(&h->hrm16_hi, plane) != hipSuccess || tracked_malloc(&h->hrm16_lo, plane) != hipSuccess ||
+        tracked_malloc(&h->hf3_ws, f3) != hipSuccess)
       return fail(h, COPER_ENOMEM, "hipMalloc of the bf16 query planes failed");
+    COPER_HIP_TRY(h, hipMemsetAsync(h->hf3_ws, 0, f3, s));     // the zero halves of its tail registers are never written again
+    if ((rc = dev_alloc(h, &h->tband_ws, 2 * (size_t)((cap + 127) / 128 * 128))) || (rc = dev_alloc(h, &h->tgtx_ws, cap))) return rc;
   }
   h->ws_queries = cap;
   h->ws_ksplit = KSPLIT_MAX;
+  return COPER_OK;
+}
+
+// what only the ranking entry points need, on top of ensure_workspace: the count kernel's band mask (1 bit per logit of
+// a count launch), the exact targets and the internal fp32 h of coper_encode_rank -- not allocated for encode / score_all
+// callers (the mask of a 4,096-query launch against 10 M entities is 5 GB)
+static int ensure_rank_workspace(coper_handle* h, int64_t B, int64_t nnz, bool need_h, hipStream_t s) {
+  int rc;
+  if ((rc = ensure_workspace(h, B, nnz, s))) return rc;
+  if (need_h && (!h->h_ws || h->h_ws_rows < B)) {
+    COPER_HIP_TRY(h, hipStreamSynchronize(s));
+    const int64_t rows = B > h->ws_queries ? B : h->ws_queries;
+    if ((rc = dev_alloc(h, &h->h_ws, (size_t)rows * h->dm.d))) return rc;
+    h->h_ws_rows = rows;
+  }
+  if (h->cfg.score_mode == COPER_SCORE_F32) return COPER_OK;
+  // the longest count launch any path issues: the mask has the size of the block maxima of the pruned top-k (one bit per logit
+  // against one float per 32), so both are cut into the same chunks of queries
+  const int64_t qc = topk_chunk_queries(h->dm.n_eblk, B, h->gmax_max_floats);
+  const size_t need = score_count3_mask_bytes(h, qc);
+  if (need > h->mask_cap) {
+    COPER_HIP_TRY(h, hipStreamSynchronize(s));
+    dev_free((char**)&h->mask_ws);
+    h->mask_cap = 0;
+    if (tracked_malloc(&h->mask_ws, need) != hipSuccess) { (void)hipGetLastError(); return fail(h, COPER_ENOMEM, "hipMalloc of the band mask failed"); }
+    h->mask_cap = need;
+  }
   return COPER_OK;
 }
 
@@ -296,6 +339,8 @@ COPER_API void coper_destroy(coper_handle* h) {
   dev_free((char**)&h->Wf16_hi); dev_free((char**)&h->Wf16_lo);
   dev_free((char**)&h->Ef16_hi); dev_free((char**)&h->Ef16_lo); dev_free((char**)&h->hfrag16_hi); dev_free((char**)&h->hfrag16_lo);
   dev_free((char**)&h->Erm16_hi); dev_free((char**)&h->Erm16_lo); dev_free((char**)&h->hrm16_hi); dev_free((char**)&h->hrm16_lo);
+  dev_free((char**)&h->Ef3); dev_free((char**)&h->hf3_ws); dev_free((char**)&h->mask_ws); dev_free(&h->band_consts); dev_free(&h->tband_ws);
+  dev_free(&h->tgtx_ws);
   for (auto& kv : h->timers)
     for (auto& p : kv.second.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   for (auto e : h->event_pool) (void)hipEventDestroy(e);
@@ -470,9 +515,15 @@ COPER_API int coper_prepare(coper_handle* h, void* stream) {
       return fail(h, COPER_ENOMEM, "hipMalloc of the bf16 entity planes failed");
     if ((rc = dev_alloc(h, &h->bias_pad, (size_t)dm.n_eblk * 32))) return rc;
     if ((rc = launch_bias_pad(h, P("pred_bias"), s))) return rc;
+    const size_t f3 = (size_t)dm.n_eblk * 2 * f3_steps(dm.KS16) * 2 * 64 * 16;    // the count kernel's image (bf16x3_chain.h)
+    dev_free((char**)&h->Ef3);
+    if (tracked_malloc(&h->Ef3, f3) != hipSuccess) { (void)hipGetLastError(); return fail(h, COPER_ENOMEM, "hipMalloc of the entity image failed"); }
+    COPER_HIP_TRY(h, hipMemsetAsync(h->Ef3, 0, f3, s));
     if ((rc = launch_rows_to_frag_bf16(h, P("ent_emb"), dm.n_local, dm.n_eblk, (uint4*)h->Ef16_hi, (uint4*)h->Ef16_lo,
-                                       (uint4*)h->Erm16_hi, (uint4*)h->Erm16_lo, s)))
+                                       (uint4*)h->Erm16_hi, (uint4*)h->Erm16_lo, (uint4*)h->Ef3, false, s)))
       return rc;
+    if ((rc = dev_alloc(h, &h->band_consts, 2))) return rc;
+    if ((rc = launch_band_consts(h, P("ent_emb"), P("pred_bias"), s))) return rc;
     if ((rc = score_bf16_kernels_init(h))) return rc;
   }
   {
@@ -490,7 +541,7 @@ COPER_API int coper_prepare(coper_handle* h, void* stream) {
 COPER_API int coper_reserve(coper_handle* h, int64_t max_queries, int64_t max_filter_nnz, void* stream) {
   if (!h || max_queries < 0 || max_filter_nnz < 0) return fail(h, COPER_EINVAL, "coper_reserve: bad argument");
   COPER_HIP_TRY(h, hipSetDevice(h->cfg.device));
-  return ensure_workspace(h, max_queries, max_filter_nnz, (hipStream_t)stream);
+  return ensure_rank_workspace(h, max_queries, max_filter_nnz, true, (hipStream_t)stream);
 }
 
 #define COPER_REQUIRE_PREPARED(h)                                                           \
@@ -599,8 +650,13 @@ COPER_API int coper_target_scores(coper_handle* h, const float* hvec, const int6
   hipStream_t s = (hipStream_t)stream;
   int rc;
   if ((rc = ensure_workspace(h, B, 0, s))) return rc;
-  if (h->cfg.score_mode != COPER_SCORE_F32) return launch_pair_targets_bf16x3(h, hvec, e2, B, tgt, s);
-  return launch_pair_targets(h, hvec, e2, B, tgt, s);
+  if (h->cfg.score_mode != COPER_SCORE_F32) {
+    if ((rc = launch_pair_targets_bf16x3(h, hvec, e2, B, tgt, s))) return rc;
+    return launch_exact_targets(h, hvec, e2, B, tgt + B, s);     // the fp32-chain logit: what the exact band compares against
+  }
+  if ((rc = launch_pair_targets(h, hvec, e2, B, tgt, s))) return rc;
+  COPER_HIP_TRY(h, hipMemcpyAsync(tgt + B, tgt, sizeof(float) * B, hipMemcpyDeviceToDevice, s));   // the mode's logit IS the chain's
+  return COPER_OK;
 }
 
 COPER_API int coper_rank_counts(coper_handle* h, const float* hvec, const float* tgt, const int64_t* e2,
@@ -615,7 +671,7 @@ COPER_API int coper_rank_counts(coper_handle* h, const float* hvec, const float*
     return fail(h, COPER_EINVAL, "coper_rank_counts: bad top-k arguments (0 <= k <= 1024)");
   hipStream_t s = (hipStream_t)stream;
   int rc;
-  if ((rc = ensure_workspace(h, B, filt_nnz, s))) return rc;
+  if ((rc = ensure_rank_workspace(h, B, filt_nnz, false, s))) return rc;
   // 0 < k <= COPER_TOPK_PRUNED_MAX (128): the count pass also writes block maxima and the top-k is selected from the few blocks that can
   // hold it (kernels_topk_bf16.hip): no logits workspace
   const bool pruned = k > 0 && k <= COPER_TOPK_PRUNED_MAX &&
@@ -648,12 +704,17 @@ COPER_API int coper_rank_counts(coper_handle* h, const float* hvec, const float*
   }
   if (h->cfg.score_mode != COPER_SCORE_F32) {
     if (!(h->trust_packed && h->packed_hvec == hvec && h->packed_B == B) && (rc = launch_pack_h_bf16(h, hvec, B, s))) return rc;
+    COPER_DBG_SYNC(h, s, "pack_h");
+    // the exact band of every query around the mode's target logit; comparisons inside it are decided against tgt[B ..]
+    if ((rc = launch_band_setup(h, hvec, tgt, B, s))) return rc;
+    COPER_DBG_SYNC(h, s, "band_setup");
     if (pruned)
-      rc = launch_topk_pruned_bf16x3(h, tgt, e2, filt_indptr, filt_idx, filt_nnz, B, k, n_greater, n_equal, topk_val, topk_idx, s);
+      rc = launch_topk_pruned_bf16x3(h, hvec, tgt + B, e2, filt_indptr, filt_idx, filt_nnz, B, k, n_greater, n_equal, topk_val, topk_idx, s);
     else
-      rc = launch_score_count_bf16x3(h, hvec, tgt, B, n_greater, n_equal, s);
+      rc = launch_score_count_bf16x3(h, hvec, tgt + B, e2, filt_indptr, filt_idx, B, n_greater, n_equal, s);
     if (rc) return rc;
-    if ((rc = launch_filter_correct_bf16x3(h, tgt, e2, filt_indptr, filt_idx, filt_nnz, B, n_greater, n_equal, s))) return rc;
+    if ((rc = launch_filter_correct_bf16x3(h, e2, filt_indptr, filt_idx, filt_nnz, B, n_greater, s))) return rc;
+    COPER_DBG_SYNC(h, s, "filter_correct");
   } else {
     if (pruned)
       rc = launch_topk_pruned_f32(h, hvec, tgt, e2, filt_indptr, filt_idx, filt_nnz, B, k, n_greater, n_equal, topk_val, topk_idx, s);
@@ -686,7 +747,7 @@ COPER_API int coper_rank(coper_handle* h, const float* hvec, const int64_t* e2, 
   if (h->dm.n_local != h->dm.E) return fail(h, COPER_ESTATE, "coper_rank needs the whole table; sharded handles use coper_target_scores + coper_rank_counts");
   hipStream_t s = (hipStream_t)stream;
   int rc;
-  if ((rc = ensure_workspace(h, B, filt_nnz, s))) return rc;
+  if ((rc = ensure_rank_workspace(h, B, filt_nnz, false, s))) return rc;
   const bool direct = h->cfg.score_mode != COPER_SCORE_F32;
   if (direct) {
     // bf16x3: n_greater accumulates straight into `ranks` started from 1 (no finish launch), preset by the packing
@@ -695,14 +756,14 @@ COPER_API int coper_rank(coper_handle* h, const float* hvec, const int64_t* e2, 
     h->preset_cnt = ranks;
     h->preset_eq = n_equal;
   }
-  if (direct && !n_equal) h->expand_indptr = filt_indptr;   // the target pass expands the CSR rows for the filter pass
+  if (direct) h->expand_indptr = filt_indptr;   // the target pass expands the CSR rows for the filter pass
   rc = coper_target_scores(h, hvec, e2, B, h->tgt_ws, stream);
   h->expand_indptr = nullptr;
   h->preset_cnt = nullptr;
   h->preset_eq = nullptr;
   if (rc) { h->count_base = 0; h->counts_preset = nullptr; return rc; }
   int32_t* ng = direct ? ranks : h->cnt_ws;
-  int32_t* ne = n_equal;  // NULL: ties are not counted (one compare per score instead of two)
+  int32_t* ne = n_equal;  // NULL: ties are not counted
   h->trust_packed = true;  // same hvec, same stream, no caller code in between: the packing of target_scores is valid
   rc = coper_rank_counts(h, hvec, h->tgt_ws, e2, filt_indptr, filt_idx, filt_nnz, B, 0, ng, ne, nullptr, nullptr, stream);
   h->trust_packed = false;
@@ -724,52 +785,44 @@ COPER_API int coper_encode_rank(coper_handle* h, const int64_t* e1, const int64_
   if (h->dm.n_local != h->dm.E) return fail(h, COPER_ESTATE, "coper_encode_rank needs the whole table (see coper_rank)");
   hipStream_t s = (hipStream_t)stream;
   int rc, ksplit = 1;
-  if ((rc = ensure_workspace(h, B, filt_nnz, s))) return rc;
+  // the embedding is needed in fp32 either way: the fp32-exact mode scores from it, the bf16x3 mode's exact band re-scores from it
+  if ((rc = ensure_rank_workspace(h, B, filt_nnz, h_out == nullptr, s))) return rc;
+  float* hv = h_out ? h_out : h->h_ws;
   if (!h->enc_bf16) {
-    // fp32-exact mode: the two-call path with an internal h when the caller does not want it
-    float* hv = h_out;
-    if (!hv) {
-      if (!h->h_ws || h->h_ws_rows < B) {
-        COPER_HIP_TRY(h, hipStreamSynchronize(s));
-        if ((rc = dev_alloc(h, &h->h_ws, (size_t)B * h->dm.d))) return rc;
-        h->h_ws_rows = B;
-      }
-      hv = h->h_ws;
-    }
+    // fp32-exact mode (or a configuration the bf16x3 encoder does not serve): the two-call path
     if ((rc = coper_encode(h, e1, rel, B, e1_rows, hv, stream))) return rc;
     return coper_rank(h, hv, e2, filt_indptr, filt_idx, filt_nnz, B, ranks, n_equal, stream);
   }
-  // bf16x3: the finalize writes h straight into the planes the rank kernels read and presets the counters, which
-  // accumulate into `ranks` from 1: no fp32 h round trip, no pack, zero or finish launch
+  // bf16x3: the finalize writes h straight into the planes the rank kernels read (and the fp32 rows the exact band needs) and
+  // presets the counters, which accumulate into `ranks` from 1: no pack, zero or finish launch
   if ((rc = encode_partials(h, e1, rel, B, e1_rows, s, &ksplit, nullptr))) return rc;
   if (!n_equal && tail_fused_supported(h)) {
-    // ranks only (what the reference computes): finalize, targets and the filter correction in ONE launch
-    // (kernels_tail_bf16.hip) that leaves ranks = 1 - (known answers above the target); the count kernel adds to it
+    // ranks only (what the reference computes): finalize, targets, the band and the filter correction in ONE launch
+    // (kernels_tail_bf16.hip) that leaves ranks = 1 - (known answers above the band); the count kernel and the exact
+    // decision of the band add to it
     {
       ScopedKernelTimer t(h, "tail", s);
-      if ((rc = launch_finalize_targets_filter_bf16x3(h, B, ksplit, h_out, e2, filt_indptr, filt_idx, h->tgt_ws, ranks, s))) return rc;
+      if ((rc = launch_finalize_targets_filter_bf16x3(h, B, ksplit, hv, e2, filt_indptr, filt_idx, h->tgt_ws, ranks, s))) return rc;
     }
-    h->packed_hvec = h->tgt_ws;
-    h->packed_B = B;
     h->counts_preset = ranks;
     h->count_base = 1;
-    rc = launch_score_count_bf16x3(h, h->tgt_ws, h->tgt_ws, B, ranks, nullptr, s);
+    rc = launch_score_count_bf16x3(h, hv, nullptr, e2, filt_indptr, filt_idx, B, ranks, nullptr, s);
     h->count_base = 0;
     h->counts_preset = nullptr;
     return rc;
   }
-  if ((rc = launch_dense_finalize_pack(h, B, ksplit, h_out, ranks, 1, n_equal, s))) return rc;
-  if (!n_equal) h->expand_indptr = filt_indptr;
+  if ((rc = launch_dense_finalize_pack(h, B, ksplit, hv, ranks, 1, n_equal, s))) return rc;
+  h->expand_indptr = filt_indptr;
   rc = launch_pair_targets_packed_bf16x3(h, e2, B, h->tgt_ws, s);
   h->expand_indptr = nullptr;
   if (rc) return rc;
-  const float* tag = h->tgt_ws;          // any pointer: identifies "the planes in place" for the count pass below
-  h->packed_hvec = tag;
+  if ((rc = launch_exact_targets(h, hv, e2, B, h->tgt_ws + B, s))) return rc;
+  h->packed_hvec = hv;
   h->packed_B = B;
   h->trust_packed = true;
   h->count_base = 1;
   h->counts_preset = ranks;
-  rc = coper_rank_counts(h, tag, h->tgt_ws, e2, filt_indptr, filt_idx, filt_nnz, B, 0, ranks, n_equal, nullptr, nullptr, stream);
+  rc = coper_rank_counts(h, hv, h->tgt_ws, e2, filt_indptr, filt_idx, filt_nnz, B, 0, ranks, n_equal, nullptr, nullptr, stream);
   h->trust_packed = false;
   h->count_base = 0;
   h->counts_preset = nullptr;

@@ -50,6 +50,12 @@ struct Dims {
   int64_t n_eblk = 0;  // 32-row entity blocks (padded to a multiple of EBLK_ALIGN)
 };
 
+// half-width of the exact band of the bf16x3 ranker, relative to |h_q| max|E_e| + max|bias| (per logit; a comparison of two
+// logits gets twice that): the largest error of the mode's logits against the fp32 chain measured over 3e8 logits of the
+// FB15k-237-shaped pass is 3.3e-6 |h_q||E_e| (rms 3.1e-7; tools/rank_decomp.py); the default keeps a factor 3 above the
+// worst case seen and ~30 sigma.  coper_config.rank_band_kappa overrides it (the proven worst case of the split and of
+// fp32 accumulation is 3 * 2^-16 + 2 (3 * 16 KS16 + 1) 2^-24 ~ 1.2e-4 at d = 200: about 35 band pairs per query instead of 4).
+constexpr float COPER_BAND_KAPPA_DEFAULT = 1e-5f;
 constexpr int COPER_TOPK_PRUNED_MAX = 128;   // largest k served by the block-maxima top-k (bf16x3); above: logits chunks
 constexpr int EBLK_ALIGN = 16;  // entity blocks consumed per workgroup iteration in score_count (8 waves x 2)
 
@@ -88,6 +94,8 @@ struct coper_handle {
   void* Ef16_lo = nullptr;      //   [n_eblk][KS16][64] x 16 B
   void* Erm16_hi = nullptr;     //   row-major twins [n_eblk*32][KS16*16] bf16 (pair kernel gathers)
   void* Erm16_lo = nullptr;
+  void* Ef3 = nullptr;          //   the count kernel's image (bf16x3_chain.h): [2 n_eblk][NS][2][64] x 16 B, zero-filled first
+  unsigned* band_consts = nullptr;   // [2] float bits: max |E_e|_2, max |pred_bias| of the shard (exact band)
   float* ctx_tmp[2] = {nullptr, nullptr};  // generator hidden activations
   size_t ctx_tmp_elems = 0;
 
@@ -132,6 +140,11 @@ struct coper_handle {
   void* hfrag16_lo = nullptr;
   void* hrm16_hi = nullptr;       //   row-major twins
   void* hrm16_lo = nullptr;
+  void* hf3_ws = nullptr;         //   the count kernel's query image [ceil(B/128) * 8][NS][2][64] x 16 B (zero-filled at allocation)
+  float* tband_ws = nullptr;      // [B] float2 {t_lo, t_hi}: the exact band around the mode's target logit
+  float* tgtx_ws = nullptr;       // [B] exact-chain targets of the two-call flows
+  void* mask_ws = nullptr;        // band bits of one count launch (kernels_score3_bf16.hip)
+  size_t mask_cap = 0;            //   bytes
   const float* packed_hvec = nullptr;  // what hfrag16 currently holds (only trusted inside coper_rank)
   int64_t packed_B = 0;
   bool trust_packed = false;
@@ -203,18 +216,17 @@ int launch_finish_ranks(coper_handle* h, const int32_t* ng, int64_t B, int32_t* 
 int score_kernels_init(coper_handle* h);
 // kernels_score_bf16.hip (COPER_SCORE_BF16X3)
 int launch_rows_to_frag_bf16(coper_handle* h, const float* src, int64_t n_rows, int64_t n_blk, uint4* hi, uint4* lo,
-                             uint4* rm_hi, uint4* rm_lo, hipStream_t s);
+                             uint4* rm_hi, uint4* rm_lo, uint4* f3, bool query_side, hipStream_t s);
 int launch_pack_h_bf16(coper_handle* h, const float* hvec, int64_t B, hipStream_t s);
-int launch_score_count_bf16x3(coper_handle* h, const float* hvec, const float* tgt, int64_t B, int32_t* ng,
-                              int32_t* ne, hipStream_t s);
+int launch_score_count_bf16x3(coper_handle* h, const float* hvec, const float* tgt_x, const int64_t* e2, const int64_t* indptr,
+                              const int64_t* idx, int64_t B, int32_t* ng, int32_t* ne, hipStream_t s);
 int launch_score_all_bf16x3(coper_handle* h, const float* hvec, int64_t B, float* logits, int64_t ld, hipStream_t s);
 int launch_pair_targets_bf16x3(coper_handle* h, const float* hvec, const int64_t* e2, int64_t B, float* tgt,
                                hipStream_t s);
 int launch_score_lookup_bf16x3(coper_handle* h, const float* hvec, const int32_t* lookup, int64_t B, int64_t L,
                                float* out, hipStream_t s);
-int launch_filter_correct_bf16x3(coper_handle* h, const float* tgt, const int64_t* e2, const int64_t* indptr,
-                                 const int64_t* idx, int64_t nnz, int64_t B, int32_t* ng, int32_t* ne,
-                                 hipStream_t s);
+int launch_filter_correct_bf16x3(coper_handle* h, const int64_t* e2, const int64_t* indptr, const int64_t* idx, int64_t nnz,
+                                 int64_t B, int32_t* ng, hipStream_t s);
 int score_bf16_kernels_init(coper_handle* h);
 // queries whose block maxima are held at a time: at most `cap_floats` (1/32 of the device memory, at least 1 GiB;
 // the threshold kernel runs one workgroup per 16 or 32 queries, so short chunks leave the chip idle) or one tile
@@ -230,16 +242,19 @@ inline int64_t topk_chunk_queries(int64_t n_eblk, int64_t B, int64_t cap_floats)
 inline int topk_nseg(int64_t n_eblk) { return n_eblk < 4096 ? 8 : 1; }
 inline size_t topk_sorted_cap(int64_t n_eblk, int64_t T) { return (size_t)((T + 31 * (n_eblk < T ? n_eblk : T) + 31) / 32 * 32); }
 void score_count_begin_bf16x3(coper_handle* h, int64_t B, int32_t* ng, int32_t* ne, hipStream_t s);
-int score_count_chunk_bf16x3(coper_handle* h, int64_t q0, int64_t Bc, const float* tgt, int32_t* ng, int32_t* ne, float* gmax,
-                             int64_t gm_stride, hipStream_t s);
+// kernels_score3_bf16.hip: the count kernel (16x16x32, software-pipelined, one wave per SIMD) and the exact band
+int score_count3_chunk_bf16x3(coper_handle* h, int64_t q0, int64_t Bc, const float* hvec, const float* tgt_x, const int64_t* e2,
+                              const int64_t* indptr, const int64_t* idx, int32_t* ng, int32_t* ne, float* gmax, int64_t gm_stride,
+                              hipStream_t s);
+size_t score_count3_mask_bytes(const coper_handle* h, int64_t Bc);
+int launch_band_consts(coper_handle* h, const float* ent, const float* bias, hipStream_t s);
+int launch_band_setup(coper_handle* h, const float* hvec, const float* tgt, int64_t B, hipStream_t s);
+int launch_exact_targets(coper_handle* h, const float* hvec, const int64_t* e2, int64_t B, float* out, hipStream_t s);
+float band_kappa(const coper_handle* h);
 // kernels_tail_bf16.hip: finalize + targets + filter correction of a ranking pass in one launch
 bool tail_fused_supported(const coper_handle* h);
 int launch_finalize_targets_filter_bf16x3(coper_handle* h, int64_t B, int ksplit, float* h_out, const int64_t* e2, const int64_t* indptr,
                                           const int64_t* idx, float* tgt, int32_t* ranks, hipStream_t s);
-// kernels_score2_bf16.hip: the software-pipelined one-wave-per-SIMD form of the same pass
-bool score_count2_supported(const coper_handle* h);
-int score_count2_chunk_bf16x3(coper_handle* h, int64_t q0, int64_t Bc, const float* tgt, int32_t* ng, int32_t* ne, float* gmax,
-                              int64_t gm_stride, hipStream_t s);
 void score_count_begin_f32(coper_handle* h, const float* hvec, int64_t B, int32_t* ng, int32_t* ne, hipStream_t s);
 int score_count_chunk_f32(coper_handle* h, int64_t q0, int64_t Bc, const float* tgt, int32_t* ng, int32_t* ne, float* gmax,
                           int64_t gm_stride, hipStream_t s);
@@ -248,9 +263,9 @@ int launch_topk_score_blocks_f32(coper_handle* h, const float* hvec, int64_t T, 
 int launch_topk_pruned_f32(coper_handle* h, const float* hvec, const float* tgt, const int64_t* e2, const int64_t* indptr,
                            const int64_t* idx, int64_t nnz, int64_t B, int k, int32_t* ng, int32_t* ne, float* topk_val,
                            int64_t* topk_idx, hipStream_t s);
-int launch_topk_pruned_bf16x3(coper_handle* h, const float* tgt, const int64_t* e2, const int64_t* indptr, const int64_t* idx,
-                              int64_t nnz, int64_t B, int k, int32_t* ng, int32_t* ne, float* topk_val, int64_t* topk_idx,
-                              hipStream_t s);
+int launch_topk_pruned_bf16x3(coper_handle* h, const float* hvec, const float* tgt_x, const int64_t* e2, const int64_t* indptr,
+                              const int64_t* idx, int64_t nnz, int64_t B, int k, int32_t* ng, int32_t* ne, float* topk_val,
+                              int64_t* topk_idx, hipStream_t s);
 // kernels_encode_bf16.hip
 bool conv_bf16_supported(const Dims& dm);
 int launch_wfrag_to_bf16(coper_handle* h, const float* Wf, int64_t Rw, void* hi, void* lo, hipStream_t s);
@@ -269,6 +284,11 @@ int launch_bias_pad(coper_handle* h, const float* bias, hipStream_t s);
 int launch_topk(coper_handle* h, const float* hvec, const int64_t* e2, const int64_t* indptr, const int64_t* idx,
                 int64_t B, int k, float* topk_val, int64_t* topk_idx, float* logits_ws, int64_t chunk_rows,
                 hipStream_t s);
+
+// COPER_DBG_SYNC=1 in the environment: synchronise after the launches that carry this hook and report the first failing one
+// (localises a faulting kernel; read once per process)
+int dbg_sync(coper_handle* h, hipStream_t s, const char* what);
+#define COPER_DBG_SYNC(h, s, what) do { int _d = coper::dbg_sync((h), (s), (what)); if (_d) return _d; } while (0)
 
 // profiling helpers (hipEvents on the launch stream)
 struct ScopedKernelTimer {

@@ -11,6 +11,7 @@
 //   A operand (features on rows):  lane l holds 8 bf16 W[f = 32ks + 8(l>>4) + j][feat = 16fb + (l&15)]
 //   B operand (queries on columns): lane l holds 8 bf16 x[q = l&15][f = 32ks + 8(l>>4) + j]
 //   D: col = lane&15 (query), row = 4(lane>>4) + reg (feature).
+#include "bf16x3_chain.h"
 #include "coper_internal.h"
 #include "conv_fold.h"
 
@@ -688,7 +689,7 @@ __global__ __launch_bounds__(256) void k_dense_finalize_pack(const float* __rest
                                                              const float* __restrict__ fc_b, int per_rel_bias,
                                                              const float* __restrict__ scale, const float* __restrict__ shift,
                                                              float* __restrict__ h_out, uint4* __restrict__ fhi, uint4* __restrict__ flo,
-                                                             uint4* __restrict__ rhi, uint4* __restrict__ rlo,
+                                                             uint4* __restrict__ rhi, uint4* __restrict__ rlo, uint4* __restrict__ hf3,
                                                              int32_t* __restrict__ cnt, int32_t cnt_base, int32_t* __restrict__ cnt_eq) {
   const int np = d_pad16 >> 3;                       // 16-B pieces per row (= 2 * KS16)
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -734,6 +735,7 @@ __global__ __launch_bounds__(256) void k_dense_finalize_pack(const float* __rest
   const int64_t ro = q * np + j;
   rhi[ro] = h4;
   rlo[ro] = l4;
+  f3_store_piece(hf3, KS16, q, ks, half, h4, l4, true);   // the count kernel's image (bf16x3_chain.h)
 }
 
 // Destination-ordered variant: thread = (query q, 16-byte piece j), so the four plane writes of a wave are contiguous
@@ -747,7 +749,8 @@ __global__ __launch_bounds__(256) void k_dense_finalize_pack_q(const float* __re
                                                                const float* __restrict__ scale, const float* __restrict__ shift,
                                                                float* __restrict__ h_out, uint4* __restrict__ fhi,
                                                                uint4* __restrict__ flo, uint4* __restrict__ rhi,
-                                                               uint4* __restrict__ rlo, int32_t* __restrict__ cnt,
+                                                               uint4* __restrict__ rlo, uint4* __restrict__ hf3,
+                                                               int32_t* __restrict__ cnt,
                                                                int32_t cnt_base, int32_t* __restrict__ cnt_eq) {
   const int np = d_pad16 >> 3;
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -796,6 +799,7 @@ __global__ __launch_bounds__(256) void k_dense_finalize_pack_q(const float* __re
   const int64_t ro = q * np + j;
   rhi[ro] = h4;
   rlo[ro] = l4;
+  f3_store_piece(hf3, KS16, q, ks, half, h4, l4, true);   // the count kernel's image (bf16x3_chain.h)
 }
 
 int launch_dense_finalize_pack(coper_handle* h, int64_t B, int ksplit, float* h_out, int32_t* cnt, int32_t cnt_base,
@@ -807,12 +811,12 @@ int launch_dense_finalize_pack(coper_handle* h, int64_t B, int ksplit, float* h_
 #ifndef COPER_FINALIZE_POS   // default: destination-ordered (coalesced plane writes: -2.5 % on the FB15k-237 pass)
   hipLaunchKernelGGL(k_dense_finalize_pack_q, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, h->z_part, ksplit, h->ws_queries, B,
                      rows_pad, dm.d, dm.d_pad16, dm.KS16, h->inv_perm, h->sorted_rid, fcb, dm.gen_fc ? 1 : 0, h->fc_scale,
-                     h->fc_shift, h_out, (uint4*)h->hfrag16_hi, (uint4*)h->hfrag16_lo, (uint4*)h->hrm16_hi, (uint4*)h->hrm16_lo, cnt,
+                     h->fc_shift, h_out, (uint4*)h->hfrag16_hi, (uint4*)h->hfrag16_lo, (uint4*)h->hrm16_hi, (uint4*)h->hrm16_lo, (uint4*)h->hf3_ws, cnt,
                      cnt_base, cnt_eq);
 #else
   hipLaunchKernelGGL(k_dense_finalize_pack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, h->z_part, ksplit, h->ws_queries, B,
                      rows_pad, dm.d, dm.d_pad16, dm.KS16, h->perm, h->sorted_rid, fcb, dm.gen_fc ? 1 : 0, h->fc_scale, h->fc_shift,
-                     h_out, (uint4*)h->hfrag16_hi, (uint4*)h->hfrag16_lo, (uint4*)h->hrm16_hi, (uint4*)h->hrm16_lo, cnt, cnt_base,
+                     h_out, (uint4*)h->hfrag16_hi, (uint4*)h->hfrag16_lo, (uint4*)h->hrm16_hi, (uint4*)h->hrm16_lo, (uint4*)h->hf3_ws, cnt, cnt_base,
                      cnt_eq);
 #endif
   COPER_HIP_TRY(h, hipGetLastError());

@@ -1,0 +1,648 @@
+// k_score_count3_bf16x3 -- the fused score + count pass of the bf16x3 mode (round 3): v_mfma_f32_16x16x32_bf16, software-
+// pipelined for ONE wave per SIMD, with the EXACT-BAND output that makes the mode's ranks the ranks of the fp32 chain.
+//
+// Arithmetic: bf16x3_chain.h (every logit of the mode is that one sequence of K = 16 accumulation steps; a 16x16x32
+// instruction carries two of them).  Why this shape: at this kernel's MFMA density the chip holds its clock down, and the
+// 16x16x32 loop delivers 1.12x the FLOP/s of the 32x32x16 loop at equal cycles per FLOP (tools/microbench/mfma_shape.hip:
+// 1.96 against 1.75 PFLOP/s with the operands re-read from LDS; MI355X_MICROARCH.md, DVFS item 7).
+//
+// Schedule (the structure of round 2's kernel, kernels_score2_bf16.hip, re-cut for the new shape): a workgroup is 4 waves,
+// one per SIMD, 128 queries in LDS as f3 fragments (8 column blocks of 16); a wave owns two 32-entity blocks of a row of 8
+// and alternates between them: while the MFMAs of block M run (per step and column block b: 6 instructions on two
+// independent accumulator chains, or 4 in the tail step), the compare epilogue of block 1-M is issued between them, one or
+// two values per region; accumulators live in AGPRs and are read out at the point of use; the first instruction of a chain
+// takes pred_bias as its C operand; query fragments come from LDS two regions ahead (a ring of 4 register pairs), entity
+// fragments straight from the f3 image into registers PD steps ahead (two sets of PD slots), across block and row
+// boundaries.  All register state is indexed with template constants.
+//
+// The exact band.  The bf16x3 logit differs from the fp32-chain logit of the same (h, E) by a few
+// 1e-5 relative to |h||E| -- enough to move a rank whenever a competitor's logit is that close to the target's.  So the
+// kernel does not decide such comparisons: with  t_hi = t + tau_q,  t_lo = t - tau_q  (tau_q = 2 kappa (|h_q| max|E_e| +
+// max|bias|), kernels below) it counts only  s > t_hi  (greater under either arithmetic) and writes ONE BIT per logit,
+// "t_lo <= s <= t_hi", to a mask (the 128 bits a lane produces per row of a wave = one 16-byte store; 1/32 of the bytes of
+// the logits it stands for).  k_band_exact then walks the mask and decides every marked pair that is not a known answer
+// with the fp32 chain itself (exact_chain on the fp32 rows the caller registered) -- a few pairs per query.  Ranks and
+// tie counts of the mode are therefore those of COPER_SCORE_F32 on the same h, bit for bit, as long as the bf16x3 error
+// stays inside tau (tests measure the margin; coper_config.rank_band_kappa widens it up to the proven worst case).
+#include <algorithm>
+#include <utility>
+#include <vector>
+
+#include "bf16x3_chain.h"
+#include "coper_internal.h"
+
+namespace coper {
+
+#define SC3_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+template <int NP, int TAIL, int PD, bool GM>
+struct SC3 {
+  static constexpr int NS = NP + TAIL;                    // steps per half-row
+  static constexpr int NB = 8;                            // 16-query column blocks of the tile
+  static constexpr int NR = NS * NB;                      // regions per half-row
+  static constexpr int NV = 64;                           // accumulator values per lane per half-row: 2 row blocks x 8 x 4
+  static constexpr int CH = (NV + NS - 1) / NS;           // epilogue values handled per step
+  static constexpr int G = (NS + PD - 1) / PD;            // prefetch groups per half-row
+  f32x4 acc[2][2][NB];                                    // [entity block M][16-row block m2][column block b]
+  uint4 a0[2][PD][2], a1[2][PD][2];                       // entity fragments: two sets of PD steps, [m2]; reg 0 / reg 1 of the step
+  uint4 q0[4], q1[4];                                     // query fragments of four consecutive regions (ring)
+  f32x4 biasv[2][2];                                      // [M][m2]
+  float thi[NB], tlo[NB];
+  int cg[NB];
+  unsigned mk[4];                                         // band bits: word 2 M + (V >> 5), value V at bit 31 - (V & 31)
+  float mx;
+};
+
+struct SC3Ptrs {
+  const uint4* a[2];     // f3 register (16-row block 0 of entity block M, step 0, reg 0) of this row, lane included
+  const uint4* n;        // ... of the next row's block 0
+  const uint4* hl;       // the query tile in LDS, lane included
+#ifdef COPER_DBG_SC3_CHECK
+  const uint4* base;     // diagnostic build: the image and its size, every fragment load is bounds-checked
+  long long n_regs;
+#endif
+};
+
+#ifdef COPER_DBG_SC3_CHECK
+__device__ long long g_sc3_bad[8];   // [0] count, [1] first bad index, [2] kind, [3] blockIdx, [4] image size
+__device__ __forceinline__ uint4 sc3_ld(const SC3Ptrs& X, const uint4* p, int kind) {
+  const long long i = p - X.base;
+  if (i < 0 || i >= X.n_regs) {
+    if (atomicAdd((unsigned long long*)&g_sc3_bad[0], 1ull) == 0) { g_sc3_bad[1] = i; g_sc3_bad[2] = kind; g_sc3_bad[3] = blockIdx.x; g_sc3_bad[4] = X.n_regs; }
+    return make_uint4(0, 0, 0, 0);
+  }
+  return *p;
+}
+#define SC3_LD(X_, p_, kind_) sc3_ld(X_, &(p_), kind_)
+#else
+#define SC3_LD(X_, p_, kind_) (p_)
+#endif
+
+// value V = 8 b + 4 m2 + j of block M: entity row 16 m2 + 4 (lane >> 4) + j of the block, query 16 b + (lane & 15) of the tile
+template <int NP, int TAIL, int PD, bool GM, int M, int V>
+__device__ __forceinline__ void sc3_value(SC3<NP, TAIL, PD, GM>& S, const int lane, const bool store_ok, float* __restrict__ gm_row,
+                                          const int64_t gm_col, uint4* __restrict__ mask_row) {
+  constexpr int b = V >> 3, m2 = (V >> 2) & 1, j = V & 3, w = 2 * M + (V >> 5);
+#ifdef COPER_DBG_SC3_EPI_R0   /* ablation: one value per column block keeps the chains alive, the epilogue nearly free */
+  if constexpr ((V & 7) != 0) return;
+#endif
+  float sc;
+  unsigned long long gt;
+  // the accumulator is read out of its AGPR here, at the point of use;  count += (sc > t_hi);  band bit = (sc >= t_lo) & !(sc > t_hi)
+  // shifted into the mask word (m = 2 m + bit)
+#ifdef COPER_DBG_SC3_NO_BAND
+  asm volatile("v_accvgpr_read_b32 %2, %3\n\tv_cmp_gt_f32 %1, %2, %4\n\tv_addc_co_u32 %0, vcc, 0, %0, %1"
+               : "+v"(S.cg[b]), "=&s"(gt), "=&v"(sc)
+               : "a"(S.acc[M][m2][b][j]), "v"(S.thi[b])
+               : "vcc", "scc");
+#else
+  asm volatile(
+      "v_accvgpr_read_b32 %3, %4\n\t"
+      "v_cmp_gt_f32 %2, %3, %5\n\t"
+      "v_addc_co_u32 %0, vcc, 0, %0, %2\n\t"
+      "v_cmp_ge_f32 vcc, %3, %6\n\t"
+      "s_andn2_b64 vcc, vcc, %2\n\t"          /* (writes SCC: declared, or a scalar carry chain of the address arithmetic around it breaks) */
+      "v_addc_co_u32 %1, vcc, %1, %1, vcc"
+      : "+v"(S.cg[b]), "+v"(S.mk[w]), "=&s"(gt), "=&v"(sc)
+      : "a"(S.acc[M][m2][b][j]), "v"(S.thi[b]), "v"(S.tlo[b])
+      : "vcc", "scc");
+#endif
+  if constexpr (GM) {
+    if constexpr ((V & 7) == 0) S.mx = sc; else S.mx = fmaxf(S.mx, sc);
+    if constexpr ((V & 7) == 7) {
+      float mxx = fmaxf(S.mx, __shfl_xor(S.mx, 16));          // the other rows of the 32-entity block
+      mxx = fmaxf(mxx, __shfl_xor(mxx, 32));
+      if (store_ok && lane < 16) gm_row[gm_col + b * 16 + lane] = mxx;
+    }
+  }
+  if constexpr (M == 1 && V == 63) {     // the row's 128 band bits of this lane are complete
+#ifndef COPER_DBG_SC3_NO_BAND
+    if (store_ok) mask_row[lane] = make_uint4(S.mk[0], S.mk[1], S.mk[2], S.mk[3]);
+#endif
+  }
+}
+
+template <int NP, int TAIL, int PD, bool GM, int M, int... V>
+__device__ __forceinline__ void sc3_values(SC3<NP, TAIL, PD, GM>& S, const int lane, float* __restrict__ gm_row, const int64_t gm_col,
+                                           uint4* __restrict__ mask_row, std::integer_sequence<int, V...>) {
+  (sc3_value<NP, TAIL, PD, GM, M, V>(S, lane, true, gm_row, gm_col, mask_row), ...);
+}
+
+template <int NP, int TAIL, int PD, bool GM, int M>
+__device__ __forceinline__ void sc3_load_bias(SC3<NP, TAIL, PD, GM>& S, const float* __restrict__ bias_pad, const int64_t blk, const int lane) {
+  const float4* bp = (const float4*)(bias_pad + blk * 32 + 4 * (lane >> 4));
+  const float4 v0 = bp[0], v1 = bp[4];
+  S.biasv[M][0][0] = v0.x; S.biasv[M][0][1] = v0.y; S.biasv[M][0][2] = v0.z; S.biasv[M][0][3] = v0.w;
+  S.biasv[M][1][0] = v1.x; S.biasv[M][1][1] = v1.y; S.biasv[M][1][2] = v1.z; S.biasv[M][1][3] = v1.w;
+}
+
+// Region (step s, column block b) of block M: in front, one entity-fragment load PD steps ahead (regions b < 4: the four
+// registers of a step) and the two LDS reads of the region after next; then the instructions of the two accumulator chains
+// (m2 = 0, 1) interleaved; behind them this region's share of the other block's epilogue.
+template <int NP, int TAIL, int PD, bool GM, int M, int s, int b>
+__device__ __forceinline__ void sc3_region(SC3<NP, TAIL, PD, GM>& S, const SC3Ptrs& X, const int lane, const bool prev_valid,
+                                           float* __restrict__ gm_row, const int64_t gm_col, uint4* __restrict__ mask_row) {
+  typedef SC3<NP, TAIL, PD, GM> ST;
+  constexpr int NS = ST::NS, NR = ST::NR, G = ST::G, CH = ST::CH, NV = ST::NV;
+  constexpr bool tail = TAIL && s == NP;
+  constexpr int PA = (G & 1) ? M : 0;        // entity-fragment set of this block's step 0
+  constexpr int PA_NEXT = (PA + G) & 1;      // ... of the next block's step 0
+  constexpr int sa = (PA + s / PD) & 1, sl = s % PD, tk = s + PD;
+#ifndef COPER_DBG_SC3_SKIP_GL
+  if constexpr (b < 4) {
+    constexpr int m2 = b >> 1, wh = b & 1;
+    if constexpr (tk < NS) {
+      constexpr int ta = (PA + tk / PD) & 1, tl = tk % PD;
+      if constexpr (wh == 0) S.a0[ta][tl][m2] = SC3_LD(X, X.a[M][((m2 * NS + tk) * 2 + 0) * 64], 10 + M);
+      else S.a1[ta][tl][m2] = SC3_LD(X, X.a[M][((m2 * NS + tk) * 2 + 1) * 64], 10 + M);
+    } else if constexpr (M == 0) {           // step tk - NS of this row's block 1
+      constexpr int u = tk - NS;
+      if constexpr (wh == 0) S.a0[PA_NEXT][u][m2] = SC3_LD(X, X.a[1][((m2 * NS + u) * 2 + 0) * 64], 20);
+      else S.a1[PA_NEXT][u][m2] = SC3_LD(X, X.a[1][((m2 * NS + u) * 2 + 1) * 64], 20);
+    } else {                                 // ... of the next row's block 0
+      constexpr int u = tk - NS;
+      if constexpr (wh == 0) S.a0[PA_NEXT][u][m2] = SC3_LD(X, X.n[((m2 * NS + u) * 2 + 0) * 64], 30);
+      else S.a1[PA_NEXT][u][m2] = SC3_LD(X, X.n[((m2 * NS + u) * 2 + 1) * 64], 30);
+    }
+  }
+#endif
+  constexpr int R = s * 8 + b;
+#ifndef COPER_DBG_SC3_SKIP_LDS
+  {
+    constexpr int R2 = (R + 2) % NR, s2 = R2 / 8, b2 = R2 % 8;
+    S.q0[(R + 2) & 3] = X.hl[((b2 * NS + s2) * 2 + 0) * 64];
+    S.q1[(R + 2) & 3] = X.hl[((b2 * NS + s2) * 2 + 1) * 64];
+  }
+#endif
+  constexpr int rs = R & 3;
+  // (e.reg0, q.reg1): T1 of both k-steps (tail: T1 then T2); step 0 starts the chains from pred_bias
+  if constexpr (s == 0) {
+    S.acc[M][0][b] = BX3_MFMA16(S.a0[sa][sl][0], S.q1[rs], S.biasv[M][0]);
+    S.acc[M][1][b] = BX3_MFMA16(S.a0[sa][sl][1], S.q1[rs], S.biasv[M][1]);
+  } else {
+    S.acc[M][0][b] = BX3_MFMA16(S.a0[sa][sl][0], S.q1[rs], S.acc[M][0][b]);
+    S.acc[M][1][b] = BX3_MFMA16(S.a0[sa][sl][1], S.q1[rs], S.acc[M][1][b]);
+  }
+  // (e.reg1, q.reg0): T2 of both k-steps (tail: T3 and an all-zero half)
+  S.acc[M][0][b] = BX3_MFMA16(S.a1[sa][sl][0], S.q0[rs], S.acc[M][0][b]);
+  S.acc[M][1][b] = BX3_MFMA16(S.a1[sa][sl][1], S.q0[rs], S.acc[M][1][b]);
+  if constexpr (!tail) {   // (e.reg1, q.reg1): T3 of both k-steps
+    S.acc[M][0][b] = BX3_MFMA16(S.a1[sa][sl][0], S.q1[rs], S.acc[M][0][b]);
+    S.acc[M][1][b] = BX3_MFMA16(S.a1[sa][sl][1], S.q1[rs], S.acc[M][1][b]);
+  }
+  // epilogue of the other block: this step's chunk of CH values is dealt to the eight regions in order
+  constexpr int c0 = b * CH / 8, c1 = (b + 1) * CH / 8, v0 = s * CH + c0;
+#ifndef COPER_DBG_SC3_NO_EPI
+  if constexpr (c1 - c0 > 0 && v0 + 0 < NV) sc3_value<NP, TAIL, PD, GM, 1 - M, v0 + 0>(S, lane, prev_valid, gm_row, gm_col, mask_row);
+  if constexpr (c1 - c0 > 1 && v0 + 1 < NV) sc3_value<NP, TAIL, PD, GM, 1 - M, v0 + 1>(S, lane, prev_valid, gm_row, gm_col, mask_row);
+  if constexpr (c1 - c0 > 2 && v0 + 2 < NV) sc3_value<NP, TAIL, PD, GM, 1 - M, v0 + 2>(S, lane, prev_valid, gm_row, gm_col, mask_row);
+  if constexpr (c1 - c0 > 3 && v0 + 3 < NV) sc3_value<NP, TAIL, PD, GM, 1 - M, v0 + 3>(S, lane, prev_valid, gm_row, gm_col, mask_row);
+  if constexpr (c1 - c0 > 4 && v0 + 4 < NV) sc3_value<NP, TAIL, PD, GM, 1 - M, v0 + 4>(S, lane, prev_valid, gm_row, gm_col, mask_row);
+  if constexpr (c1 - c0 > 5 && v0 + 5 < NV) sc3_value<NP, TAIL, PD, GM, 1 - M, v0 + 5>(S, lane, prev_valid, gm_row, gm_col, mask_row);
+  if constexpr (c1 - c0 > 6 && v0 + 6 < NV) sc3_value<NP, TAIL, PD, GM, 1 - M, v0 + 6>(S, lane, prev_valid, gm_row, gm_col, mask_row);
+  if constexpr (c1 - c0 > 7 && v0 + 7 < NV) sc3_value<NP, TAIL, PD, GM, 1 - M, v0 + 7>(S, lane, prev_valid, gm_row, gm_col, mask_row);
+#endif
+  static_assert(CH <= 64, "eight epilogue values per region at most");
+  SC3_FENCE();
+}
+
+template <int NP, int TAIL, int PD, bool GM, int M, int s>
+__device__ __forceinline__ void sc3_step(SC3<NP, TAIL, PD, GM>& S, const SC3Ptrs& X, const float* __restrict__ bias_pad,
+                                         const int64_t bias_blk_next, const int lane, const bool prev_valid, float* __restrict__ gm_row,
+                                         const int64_t gm_col, uint4* __restrict__ mask_row) {
+  sc3_region<NP, TAIL, PD, GM, M, s, 0>(S, X, lane, prev_valid, gm_row, gm_col, mask_row);
+  sc3_region<NP, TAIL, PD, GM, M, s, 1>(S, X, lane, prev_valid, gm_row, gm_col, mask_row);
+  sc3_region<NP, TAIL, PD, GM, M, s, 2>(S, X, lane, prev_valid, gm_row, gm_col, mask_row);
+  sc3_region<NP, TAIL, PD, GM, M, s, 3>(S, X, lane, prev_valid, gm_row, gm_col, mask_row);
+  sc3_region<NP, TAIL, PD, GM, M, s, 4>(S, X, lane, prev_valid, gm_row, gm_col, mask_row);
+  sc3_region<NP, TAIL, PD, GM, M, s, 5>(S, X, lane, prev_valid, gm_row, gm_col, mask_row);
+  sc3_region<NP, TAIL, PD, GM, M, s, 6>(S, X, lane, prev_valid, gm_row, gm_col, mask_row);
+  sc3_region<NP, TAIL, PD, GM, M, s, 7>(S, X, lane, prev_valid, gm_row, gm_col, mask_row);
+  if constexpr (s == 0) {
+    // pred_bias of this block in the NEXT row: the sixteen chains have consumed biasv[M] (program order)
+    sc3_load_bias<NP, TAIL, PD, GM, M>(S, bias_pad, bias_blk_next, lane);
+    SC3_FENCE();
+  }
+}
+
+template <int NP, int TAIL, int PD, bool GM, int M, int... K>
+__device__ __forceinline__ void sc3_half(SC3<NP, TAIL, PD, GM>& S, const SC3Ptrs& X, const float* __restrict__ bias_pad,
+                                         const int64_t bias_blk_next, const int lane, const bool prev_valid, float* __restrict__ gm_row,
+                                         const int64_t gm_col, uint4* __restrict__ mask_row, std::integer_sequence<int, K...>) {
+  (sc3_step<NP, TAIL, PD, GM, M, K>(S, X, bias_pad, bias_blk_next, lane, prev_valid, gm_row, gm_col, mask_row), ...);
+}
+
+template <int NP, int TAIL, int PD, bool GM, int... J>
+__device__ __forceinline__ void sc3_prologue_a(SC3<NP, TAIL, PD, GM>& S, const uint4* __restrict__ pa, std::integer_sequence<int, J...>) {
+  constexpr int NS = NP + TAIL;
+  ((S.a0[0][J][0] = pa[((0 * NS + (J < NS ? J : NS - 1)) * 2 + 0) * 64], S.a1[0][J][0] = pa[((0 * NS + (J < NS ? J : NS - 1)) * 2 + 1) * 64],
+    S.a0[0][J][1] = pa[((1 * NS + (J < NS ? J : NS - 1)) * 2 + 0) * 64], S.a1[0][J][1] = pa[((1 * NS + (J < NS ? J : NS - 1)) * 2 + 1) * 64]),
+   ...);
+}
+template <int NP, int TAIL, int PD, bool GM, int... J>
+__device__ __forceinline__ void sc3_prologue_a1(SC3<NP, TAIL, PD, GM>& S, std::integer_sequence<int, J...>) {   // ablation builds only
+  ((S.a0[1][J][0] = S.a0[0][J][0], S.a1[1][J][0] = S.a1[0][J][0], S.a0[1][J][1] = S.a0[0][J][1], S.a1[1][J][1] = S.a1[0][J][1]), ...);
+}
+
+#ifdef COPER_DBG_CLOCK
+// diagnostic build (tools/ab_build.py): shader clock held inside the kernel = d(s_memtime) / d(s_memrealtime) x 100 MHz;
+// the stamps go to a buffer of their own, no output depends on them
+__device__ unsigned long long g_sc3_clk[2 * 1024];
+#endif
+
+// Ef3: the entities' f3 image; Hf3: the queries' (one 128-query tile = 8 column blocks = 16 NS KiB, copied to LDS as it lies);
+// tband[q] = {t_lo, t_hi}; mask: [tile][row][wave][lane] 16 bytes (band bits of the 64 entities x 128 queries of a wave's row)
+template <int NP, int TAIL, int PD, bool GM>
+__global__ __launch_bounds__(256, 1) void k_score_count3_bf16x3(const uint4* __restrict__ Ef3, const float* __restrict__ bias_pad,
+                                                                 const uint4* __restrict__ Hf3, const float2* __restrict__ tband,
+                                                                 int64_t B, int64_t rows_per_tile, int64_t total_rows,
+                                                                 int32_t* __restrict__ ng, uint4* __restrict__ mask,
+                                                                 float* __restrict__ gmax, int64_t gm_stride) {
+  typedef SC3<NP, TAIL, PD, GM> ST;
+  constexpr int NS = ST::NS, NB = ST::NB, NV = ST::NV;
+  static_assert(PD <= NS, "the prefetch reaches at most one half-row ahead");
+  extern __shared__ uint4 hl3[];  // [NB][NS][2][64]
+  constexpr int TILE_REGS = NB * NS * 2;          // KiB of a query tile
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int64_t r_begin = total_rows * blockIdx.x / gridDim.x, r_end = total_rows * (blockIdx.x + 1) / gridDim.x;
+  if (r_begin >= r_end) return;
+#ifdef COPER_DBG_CLOCK
+  const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  ST S;
+  int64_t cur_tile = -1;
+  int64_t eb_prev = 0;
+  bool prev_valid = false;
+  const std::make_integer_sequence<int, NS> SSEQ{};
+  const std::make_integer_sequence<int, NV> VSEQ{};
+  constexpr int64_t BLK_REGS = 2 * NS * 2;   // f3 registers of one 32-entity block (two 16-row blocks)
+
+  for (int64_t r = r_begin; r < r_end; ++r) {
+    const int64_t tile = r / rows_per_tile;
+    const int64_t row = r % rows_per_tile;
+    const int64_t eb = (row * 4 + wave) * 2;
+    if (tile != cur_tile) {   // workgroup-uniform: (re)start of the pipeline
+      __syncthreads();
+      const uint4* sh = Hf3 + tile * (TILE_REGS * 64);
+      {
+        // the query tile into LDS: TILE_REGS / 4 pieces per thread, half of them in flight before the first LDS store
+        constexpr int NPC = TILE_REGS * 64 / 256;
+        constexpr int HB = (NPC + 1) / 2;
+        uint4 th[HB];
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+#pragma unroll
+          for (int u = 0; u < HB; ++u) {
+            const int jx = (part * HB + u) * 256 + threadIdx.x;
+            if (part * HB + u < NPC) th[u] = sh[jx];
+          }
+#pragma unroll
+          for (int u = 0; u < HB; ++u) {
+            const int jx = (part * HB + u) * 256 + threadIdx.x;
+            if (part * HB + u < NPC) hl3[jx] = th[u];
+          }
+        }
+      }
+      cur_tile = tile;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const int64_t q = tile * 128 + b * 16 + (lane & 15);
+        float2 tb = make_float2(INFINITY, INFINITY);
+        if (q < B) tb = tband[q];
+        S.tlo[b] = tb.x; S.thi[b] = tb.y;
+        S.cg[b] = 0;
+      }
+      S.mk[0] = S.mk[1] = S.mk[2] = S.mk[3] = 0u;
+      // entity fragments of block 0's first PD steps, pred_bias of both blocks, "previous block" accumulators that count nothing
+      sc3_prologue_a<NP, TAIL, PD, GM>(S, Ef3 + eb * BLK_REGS * 64 + lane, std::make_integer_sequence<int, PD>{});
+      sc3_load_bias<NP, TAIL, PD, GM, 0>(S, bias_pad, eb, lane);
+      sc3_load_bias<NP, TAIL, PD, GM, 1>(S, bias_pad, eb + 1, lane);
+#pragma unroll
+      for (int b = 0; b < NB; ++b) { S.acc[1][0][b] = f32x4(-INFINITY); S.acc[1][1][b] = f32x4(-INFINITY); }
+      prev_valid = false;
+      __syncthreads();
+      // query fragments of regions 0 and 1 (step 0, column blocks 0 and 1)
+      S.q0[0] = hl3[((0 * NS + 0) * 2 + 0) * 64 + lane]; S.q1[0] = hl3[((0 * NS + 0) * 2 + 1) * 64 + lane];
+      S.q0[1] = hl3[((1 * NS + 0) * 2 + 0) * 64 + lane]; S.q1[1] = hl3[((1 * NS + 0) * 2 + 1) * 64 + lane];
+#if defined(COPER_DBG_SC3_SKIP_LDS) || defined(COPER_DBG_SC3_SKIP_GL)
+      S.q0[2] = S.q0[0]; S.q1[2] = S.q1[0]; S.q0[3] = S.q0[1]; S.q1[3] = S.q1[1];
+      sc3_prologue_a1<NP, TAIL, PD, GM>(S, std::make_integer_sequence<int, PD>{});
+#endif
+    }
+    const bool has_next = r + 1 < r_end;
+    const bool last_of_tile = !has_next || (r + 1) / rows_per_tile != tile;
+    const int64_t eb_next = has_next ? (((r + 1) % rows_per_tile) * 4 + wave) * 2 : eb;     // past the end: re-read this row's blocks
+    const int64_t gm_col = cur_tile * 128;
+    SC3Ptrs X;
+    X.a[0] = Ef3 + eb * BLK_REGS * 64 + lane;
+    X.a[1] = X.a[0] + BLK_REGS * 64;
+    X.n = Ef3 + eb_next * BLK_REGS * 64 + lane;
+    X.hl = hl3 + lane;
+#ifdef COPER_DBG_SC3_CHECK
+    X.base = Ef3;
+    X.n_regs = (long long)(total_rows / ((total_rows + rows_per_tile - 1) / rows_per_tile > 0 ? 1 : 1)) * 0 + rows_per_tile * 8 * BLK_REGS * 64;
+#endif
+    uint4* mask_cur = mask + ((cur_tile * rows_per_tile + row) * 4 + wave) * 64;
+    // block 0 (epilogue of the previous row's block 1 beside it: its last value completes that row's mask), then block 1
+    sc3_half<NP, TAIL, PD, GM, 0>(S, X, bias_pad, eb_next, lane, prev_valid, GM ? gmax + (eb_prev + 1) * gm_stride : nullptr, gm_col,
+                                  mask_cur - 4 * 64, SSEQ);
+    sc3_half<NP, TAIL, PD, GM, 1>(S, X, bias_pad, eb_next + 1, lane, true, GM ? gmax + eb * gm_stride : nullptr, gm_col, mask_cur, SSEQ);
+    eb_prev = eb;
+    prev_valid = true;
+    if (last_of_tile) {
+      // drain: block 1's accumulators have no next row of the same tile to hide behind
+      sc3_values<NP, TAIL, PD, GM, 1>(S, lane, GM ? gmax + (eb + 1) * gm_stride : nullptr, gm_col, mask_cur, VSEQ);
+#pragma unroll
+      for (int b = 0; b < NB; ++b) { S.acc[1][0][b] = f32x4(-INFINITY); S.acc[1][1][b] = f32x4(-INFINITY); }
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        int g = S.cg[b] + __shfl_xor(S.cg[b], 16);
+        g += __shfl_xor(g, 32);
+        const int64_t q = cur_tile * 128 + b * 16 + lane;
+        if (lane < 16 && q < B && g) atomicAdd(&ng[q], g);
+        S.cg[b] = 0;
+      }
+      prev_valid = false;
+    }
+  }
+#ifdef COPER_DBG_CLOCK
+  if (threadIdx.x == 0 && blockIdx.x < 1024) {
+    g_sc3_clk[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - clk_t0;
+    g_sc3_clk[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
+  }
+#endif
+}
+
+#ifdef COPER_DBG_SC3_CHECK
+extern "C" __attribute__((visibility("default"))) int coper_dbg_sc3_bad(long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sc3_bad), 8 * sizeof(long long)) == hipSuccess ? 0 : 1;
+}
+#endif
+
+#ifdef COPER_DBG_CLOCK
+extern "C" __attribute__((visibility("default"))) int coper_dbg_clock(int n_wg, double* ghz_median, double* us_median) {
+  static unsigned long long hbuf[2 * 1024];
+  if (hipMemcpyFromSymbol(hbuf, HIP_SYMBOL(g_sc3_clk), sizeof hbuf) != hipSuccess) return 1;
+  std::vector<double> g, u;
+  for (int i = 0; i < n_wg && i < 1024; ++i)
+    if (hbuf[2 * i + 1]) { g.push_back((double)hbuf[2 * i] / (double)hbuf[2 * i + 1] * 0.1); u.push_back((double)hbuf[2 * i + 1] * 0.01); }
+  if (g.empty()) return 2;
+  std::sort(g.begin(), g.end());
+  std::sort(u.begin(), u.end());
+  *ghz_median = g[g.size() / 2];
+  *us_median = u[u.size() / 2];
+  return 0;
+}
+#endif
+
+// ------------------------------------------------------------------------------------------------
+// the exact band
+// ------------------------------------------------------------------------------------------------
+// max over the shard of |E_e|_2 and |pred_bias[e]| (prepare): consts[0], consts[1] as float bit patterns (non-negative floats
+// order like unsigned integers)
+__global__ __launch_bounds__(256) void k_band_consts(const float* __restrict__ ent, const float* __restrict__ bias, int64_t n, int d,
+                                                     unsigned* __restrict__ consts) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wv = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * 256) >> 6;
+  float emax = 0.f, bmax = 0.f;
+  for (int64_t e = wv; e < n; e += nw) {
+    float s2 = 0.f;
+    for (int k = lane; k < d; k += 64) { const float v = ent[e * d + k]; s2 = fmaf(v, v, s2); }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s2 += __shfl_xor(s2, o);
+    emax = fmaxf(emax, s2);
+    if (lane == 0) bmax = fmaxf(bmax, fabsf(bias[e]));
+  }
+  if (lane == 0) {
+    const float en = sqrtf(emax) * 1.0000005f;     // rounding of the sum of squares and of the root
+    if (en == en) atomicMax(&consts[0], __float_as_uint(en));
+    if (bmax == bmax) atomicMax(&consts[1], __float_as_uint(bmax));
+  }
+}
+
+// tau_q = 2 kappa (|h_q| Emax + Bmax): both logits of a comparison carry an error of at most kappa (...) each
+__device__ __forceinline__ float band_tau(float h_norm2, float kappa, const unsigned* __restrict__ consts) {
+  const float emax = __uint_as_float(consts[0]), bmax = __uint_as_float(consts[1]);
+  return 2.f * kappa * (sqrtf(h_norm2) * 1.000001f * emax + bmax);
+}
+__device__ __forceinline__ float2 band_of(float t, float tau) {
+  // outward rounding of t -+ tau is immaterial (tau carries a safety factor); NaN / inf targets: every comparison false
+  return make_float2(t - tau, t + tau);
+}
+
+// two-call path (coper_rank_counts): tband from the fp32 h rows and the mode's target logits; 16 lanes per query
+__global__ __launch_bounds__(256) void k_band_setup(const float* __restrict__ hvec, const float* __restrict__ tgt, int64_t B, int d, float kappa,
+                                                    const unsigned* __restrict__ consts, float2* __restrict__ tband) {
+  const int64_t q = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+  const int sub = threadIdx.x & 15;
+  float s2 = 0.f;
+  if (q < B)
+    for (int k = sub; k < d; k += 16) { const float v = hvec[q * d + k]; s2 = fmaf(v, v, s2); }
+#pragma unroll
+  for (int o = 8; o >= 1; o >>= 1) s2 += __shfl_xor(s2, o);
+  if (q < B && sub == 0) tband[q] = band_of(tgt[q], band_tau(s2, kappa, consts));
+}
+
+int launch_band_consts(coper_handle* h, const float* ent, const float* bias, hipStream_t s) {
+  COPER_HIP_TRY(h, hipMemsetAsync(h->band_consts, 0, 2 * sizeof(unsigned), s));
+  int64_t blocks = (h->dm.n_local + 3) / 4;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_band_consts, dim3((unsigned)blocks), dim3(256), 0, s, ent, bias, h->dm.n_local, h->dm.d, h->band_consts);
+  COPER_HIP_TRY(h, hipGetLastError());
+  return COPER_OK;
+}
+
+float band_kappa(const coper_handle* h) {
+  const float k = h->cfg.rank_band_kappa;
+  return k > 0.f ? k : COPER_BAND_KAPPA_DEFAULT;
+}
+
+int launch_band_setup(coper_handle* h, const float* hvec, const float* tgt, int64_t B, hipStream_t s) {
+  hipLaunchKernelGGL(k_band_setup, dim3((unsigned)((B * 16 + 255) / 256)), dim3(256), 0, s, hvec, tgt, B, h->dm.d, band_kappa(h),
+                     h->band_consts, (float2*)h->tband_ws);
+  COPER_HIP_TRY(h, hipGetLastError());
+  return COPER_OK;
+}
+
+// exact-chain targets: out[b] = fp32-chain logit of (b, e2[b]) if e2[b] is on this shard else 0
+__global__ void k_exact_targets(const float* __restrict__ ent, const float* __restrict__ bias, const float* __restrict__ hvec,
+                                const int64_t* __restrict__ e2, int64_t B, int d, int64_t lo, int64_t n_local, float* __restrict__ out) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int64_t row = e2[b] - lo;
+  out[b] = (row >= 0 && row < n_local) ? exact_chain(ent + row * d, hvec + b * d, bias[row], d) : 0.f;
+}
+
+int launch_exact_targets(coper_handle* h, const float* hvec, const int64_t* e2, int64_t B, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_exact_targets, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, h->params["ent_emb"].ptr, h->params["pred_bias"].ptr,
+                     hvec, e2, B, h->dm.d, (int64_t)h->cfg.shard_lo, h->dm.n_local, out);
+  COPER_HIP_TRY(h, hipGetLastError());
+  return COPER_OK;
+}
+
+// Walks the band mask of one count launch and decides every marked (query, entity) pair with the fp32 chain:
+//   known answers of the query and its target: nothing to add (the count kernel counted none of the band, the filter
+//     correction subtracted only what lies above t_hi);  otherwise  n_greater += (s > t),  n_equal += (s == t)
+// with s, t from exact_chain on the registered fp32 rows.  A workgroup takes a contiguous range of mask words; marked pairs are
+// compacted into an LDS list (a few per thousand words) and dealt to the threads; a list that overflows (heavy ties: every
+// logit of a row inside the band) is worked off in rounds.  tgt_x == NULL: the exact target is computed here from the
+// query's e2 row (unsharded handles); sharded: the all-reduced exact targets of coper_target_scores.
+constexpr int BE_CAP = 2048, BE_WPT = 4;
+__global__ __launch_bounds__(256) void k_band_exact(const uint4* __restrict__ mask, int64_t n_words, int64_t rows_per_tile, int64_t Bc,
+                                                    const float* __restrict__ hvec, int d, const float* __restrict__ ent,
+                                                    const float* __restrict__ bias, int64_t n_local, int64_t shard_lo,
+                                                    const int64_t* __restrict__ e2, const int64_t* __restrict__ indptr,
+                                                    const int64_t* __restrict__ idx, const float* __restrict__ tgt_x,
+                                                    int32_t* __restrict__ ng, int32_t* __restrict__ ne) {
+  __shared__ int s_q[BE_CAP], s_e[BE_CAP];
+  __shared__ int s_n;
+  const int64_t w_begin = n_words * blockIdx.x / gridDim.x, w_end = n_words * (blockIdx.x + 1) / gridDim.x;
+  for (int64_t base = w_begin; base < w_end; base += 256 * BE_WPT) {
+    uint4 w[BE_WPT];
+    bool any = false;
+#pragma unroll
+    for (int u = 0; u < BE_WPT; ++u) {
+      const int64_t wi = base + u * 256 + threadIdx.x;
+      w[u] = wi < w_end ? mask[wi] : make_uint4(0u, 0u, 0u, 0u);
+      any |= (w[u].x | w[u].y | w[u].z | w[u].w) != 0u;
+    }
+    if (!__syncthreads_or(any)) continue;
+    bool more = true;
+    while (more) {
+      if (threadIdx.x == 0) s_n = 0;
+      __syncthreads();
+      bool left = false;
+#pragma unroll
+      for (int u = 0; u < BE_WPT; ++u) {
+        const int64_t wi = base + u * 256 + threadIdx.x;
+        const int64_t unit = wi >> 6;
+        const int l = (int)(wi & 63);
+        const int64_t tile = unit / (rows_per_tile * 4);
+        const int64_t rem = unit % (rows_per_tile * 4);
+        const int64_t eb = ((rem >> 2) * 4 + (rem & 3)) * 2;
+        unsigned* wc = (unsigned*)&w[u];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          while (wc[c]) {
+            const int p = 31 - __builtin_clz(wc[c]);     // highest set bit first = lowest value index first
+            const int slot = atomicAdd(&s_n, 1);
+            if (slot >= BE_CAP) { left = true; break; }
+            wc[c] &= ~(1u << p);
+            const int V = 32 * (c & 1) + (31 - p);
+            const int b = V >> 3, m2 = (V >> 2) & 1, j = V & 3;
+            s_e[slot] = (int)((eb + (c >> 1)) * 32 + 16 * m2 + 4 * (l >> 4) + j);
+            s_q[slot] = (int)(tile * 128 + 16 * b + (l & 15));
+          }
+        }
+      }
+      __syncthreads();
+      const int n = s_n < BE_CAP ? s_n : BE_CAP;
+      for (int p = threadIdx.x; p < n; p += 256) {
+        const int64_t q = s_q[p], e = s_e[p];
+        if (q >= Bc || e >= n_local) continue;
+        const int64_t eg = e + shard_lo, tq = e2[q];
+        if (eg == tq) continue;                          // the target itself (metrics.py:46)
+        int64_t lo_i = indptr[q], hi_i = indptr[q + 1];  // known answer?  (ids sorted ascending inside a row)
+        bool known = false;
+        while (lo_i < hi_i) {
+          const int64_t mid = (lo_i + hi_i) >> 1;
+          const int64_t f = idx[mid];
+          if (f == eg) { known = true; break; }
+          if (f < eg) lo_i = mid + 1; else hi_i = mid;
+        }
+        if (known) continue;
+        const float* hr = hvec + q * d;
+        const float sx = exact_chain(ent + e * d, hr, bias[e], d);
+        float tx;
+        if (tgt_x) {
+          tx = tgt_x[q];
+        } else {
+          const int64_t trow = tq - shard_lo;
+          tx = (trow >= 0 && trow < n_local) ? exact_chain(ent + trow * d, hr, bias[trow], d) : 0.f;
+        }
+        if (sx > tx) atomicAdd(&ng[q], 1);
+        else if (ne && sx == tx) atomicAdd(&ne[q], 1);
+      }
+      more = __syncthreads_or(left);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+template <int NP, int TAIL, bool GM>
+static int sc3_go(coper_handle* h, int64_t q0, int64_t Bc, int32_t* ng, float* gmax, int64_t gm_stride, hipStream_t s) {
+  constexpr int NS = NP + TAIL;
+#ifdef COPER_SC3_PD
+  constexpr int PD = COPER_SC3_PD < NS ? COPER_SC3_PD : NS;
+#else
+  constexpr int PD = 3 < NS ? 3 : NS;       // three steps = six k-steps of 16 ahead (round 2's distance)
+#endif
+  const Dims& dm = h->dm;
+  const int64_t q_tiles = (Bc + 127) / 128;
+  const int64_t rows_per_tile = dm.n_eblk / 8;
+  const int64_t total_rows = q_tiles * rows_per_tile;
+  int64_t grid = h->num_cus;
+  if (grid > total_rows) grid = total_rows;
+  const size_t lds = (size_t)8 * NS * 2 * 64 * sizeof(uint4);
+  const uint4* hf3 = (const uint4*)h->hf3_ws + (q0 / 16) * NS * 2 * 64;
+  static bool attr_done[16] = {};
+  const int dev = h->cfg.device & 15;
+  if (!attr_done[dev]) {
+    COPER_HIP_TRY(h, hipFuncSetAttribute((const void*)k_score_count3_bf16x3<NP, TAIL, PD, GM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done[dev] = true;
+  }
+  hipLaunchKernelGGL((k_score_count3_bf16x3<NP, TAIL, PD, GM>), dim3((unsigned)grid), dim3(256), lds, s, (const uint4*)h->Ef3, h->bias_pad, hf3,
+                     (const float2*)h->tband_ws + q0, Bc, rows_per_tile, total_rows, ng + q0, (uint4*)h->mask_ws, gmax, gm_stride);
+  COPER_HIP_TRY(h, hipGetLastError());
+  return COPER_OK;
+}
+
+template <int NP, int TAIL>
+static int sc3_gm(coper_handle* h, int64_t q0, int64_t Bc, int32_t* ng, float* gmax, int64_t gm_stride, hipStream_t s) {
+  return gmax ? sc3_go<NP, TAIL, true>(h, q0, Bc, ng, gmax, gm_stride, s) : sc3_go<NP, TAIL, false>(h, q0, Bc, ng, gmax, gm_stride, s);
+}
+
+// bytes of the band mask of a count launch over Bc queries
+size_t score_count3_mask_bytes(const coper_handle* h, int64_t Bc) {
+  return (size_t)((Bc + 127) / 128) * (size_t)(h->dm.n_eblk / 8) * 4 * 64 * sizeof(uint4);
+}
+
+// Count launch over queries [q0, q0 + Bc) (q0 a multiple of 128) of the packed batch + the exact decision of its band.
+// tband_ws / hf3_ws hold the whole batch; hvec (fp32 rows of the whole batch), tgt_x (exact targets of the whole batch or NULL).
+int score_count3_chunk_bf16x3(coper_handle* h, int64_t q0, int64_t Bc, const float* hvec, const float* tgt_x, const int64_t* e2,
+                              const int64_t* indptr, const int64_t* idx, int32_t* ng, int32_t* ne, float* gmax, int64_t gm_stride,
+                              hipStream_t s) {
+  if (score_count3_mask_bytes(h, Bc) > h->mask_cap) return fail(h, COPER_ESTATE, "score_count3: band mask workspace not reserved");
+  int rc;
+  {
+    ScopedKernelTimer t(h, "score_count", s);
+    switch (h->dm.KS16) {
+#define SC3_CASE(KS_) case KS_: rc = sc3_gm<(KS_) / 2, (KS_) & 1>(h, q0, Bc, ng, gmax, gm_stride, s); break;
+      SC3_CASE(1) SC3_CASE(2) SC3_CASE(3) SC3_CASE(4) SC3_CASE(5) SC3_CASE(6) SC3_CASE(7) SC3_CASE(8) SC3_CASE(9) SC3_CASE(10)
+      SC3_CASE(11) SC3_CASE(12) SC3_CASE(13) SC3_CASE(14) SC3_CASE(15) SC3_CASE(16) SC3_CASE(17) SC3_CASE(18) SC3_CASE(19) SC3_CASE(20)
+#undef SC3_CASE
+      default: rc = fail(h, COPER_EUNSUPPORTED, "score_count3: ent_emb_size beyond 320");
+    }
+  }
+  if (rc) return rc;
+  COPER_DBG_SYNC(h, s, "score_count3");
+#ifndef COPER_DBG_SC3_NO_BAND
+  {
+    ScopedKernelTimer t(h, "band_exact", s);
+    const int64_t rows_per_tile = h->dm.n_eblk / 8;
+    const int64_t n_words = ((Bc + 127) / 128) * rows_per_tile * 4 * 64;
+    int64_t grid = (n_words + 256 * BE_WPT - 1) / (256 * BE_WPT);
+    if (grid > 4 * (int64_t)h->num_cus) grid = 4 * (int64_t)h->num_cus;
+    hipLaunchKernelGGL(k_band_exact, dim3((unsigned)grid), dim3(256), 0, s, (const uint4*)h->mask_ws, n_words, rows_per_tile, Bc,
+                       hvec + q0 * h->dm.d, h->dm.d, h->params["ent_emb"].ptr, h->params["pred_bias"].ptr, h->dm.n_local,
+                       (int64_t)h->cfg.shard_lo, e2 + q0, indptr + q0, idx, tgt_x ? tgt_x + q0 : nullptr, ng + q0, ne ? ne + q0 : nullptr);
+    COPER_HIP_TRY(h, hipGetLastError());
+  }
+  COPER_DBG_SYNC(h, s, "band_exact");
+#endif
+  return COPER_OK;
+}
+
+}  // namespace coper

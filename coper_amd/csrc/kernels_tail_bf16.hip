@@ -17,6 +17,11 @@
 //      count for a known answer (logit > target) is subtracted in advance: ranks[q] = 1 - #(such entries); the count kernel
 //      then adds to it.  No atomics: the wave owns every entry of its queries (the reference: pred[e2_multi == 1] = -inf;
 //      pred[e2] = target, metrics.py:45-46).
+//
+// Round 3: the k-steps run in the pair order of bf16x3_chain.h; the query fragments go to the count kernel's f3 image; the
+// kernel also forms the exact band of every query (tau from |h_q|, k_score_count3_bf16x3's header): tband[q] = {t - tau,
+// t + tau}, and a known answer is taken back only when its logit lies ABOVE the band (what the count kernel counts).
+#include "bf16x3_chain.h"
 #include "coper_internal.h"
 #include "conv_fold.h"
 #include <algorithm>
@@ -24,9 +29,10 @@
 
 namespace coper {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-#define TL_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&(a), *(const bf16x8*)&(b), (c), 0, 0, 0)
+__device__ __forceinline__ float tail_band_tau(float h_norm2, float kappa, const unsigned* __restrict__ consts) {   // = band_tau (kernels_score3_bf16.hip)
+  const float emax = __uint_as_float(consts[0]), bmax = __uint_as_float(consts[1]);
+  return 2.f * kappa * (sqrtf(h_norm2) * 1.000001f * emax + bmax);
+}
 
 // one 32 x 32 tile: A rows = entity rows erow[i] (gathered from the row-major twins; erow < 0: a zero row is not needed,
 // its result is discarded), B = the resident query fragments; accumulators start from pred_bias of the row
@@ -48,7 +54,7 @@ __device__ __forceinline__ f32x16 tail_tile(const uint4* __restrict__ Ehi, const
                           // registers first -- 252 registers, two workgroups per CU -- measured 52 us against 45)
 #pragma unroll
   for (int k0 = 0; k0 < KS; k0 += PB) {
-    uint4 ah[PB], al[PB];
+    uint4 ah[PB + 1], al[PB + 1];   // (+1: the pair loop names element u + 1 in a branch that is never taken for the last odd step)
 #pragma unroll
     for (int u = 0; u < PB; ++u) {
       const int k = k0 + u < KS ? k0 + u : KS - 1;
@@ -56,12 +62,10 @@ __device__ __forceinline__ f32x16 tail_tile(const uint4* __restrict__ Ehi, const
       al[u] = pa_l[k * 2];
     }
 #pragma unroll
-    for (int u = 0; u < PB; ++u)
-      if (k0 + u < KS) {
-        acc = TL_MFMA(al[u], bh[k0 + u], acc);
-        acc = TL_MFMA(ah[u], bl[k0 + u], acc);
-        acc = TL_MFMA(ah[u], bh[k0 + u], acc);
-      }
+    for (int u = 0; u < PB; u += 2) {
+      if (k0 + u + 1 < KS) { BX3_PAIR(ah[u], al[u], bh[k0 + u], bl[k0 + u], ah[u + 1], al[u + 1], bh[k0 + u + 1], bl[k0 + u + 1], acc); }
+      else if (k0 + u < KS) { BX3_LAST(ah[u], al[u], bh[k0 + u], bl[k0 + u], acc); }
+    }
   }
   return acc;
 }
@@ -88,14 +92,15 @@ template <int KS>
 __global__ __launch_bounds__(64 * TL_WAVES) void k_finalize_targets_filter_bf16x3(
     const float* __restrict__ z_part, int ksplit, int64_t Bcap, int64_t B, int d, int d_pad16, const int32_t* __restrict__ inv_perm,
     const int32_t* __restrict__ sorted_rid, const float* __restrict__ fc_b, int per_rel_bias, const float* __restrict__ scale,
-    const float* __restrict__ shift, float* __restrict__ h_out, uint4* __restrict__ fhi, uint4* __restrict__ flo,
+    const float* __restrict__ shift, float* __restrict__ h_out, uint4* __restrict__ hf3,
     const uint4* __restrict__ Ehi, const uint4* __restrict__ Elo, const float* __restrict__ bias_pad, int64_t n_local,
     const int64_t* __restrict__ e2, const int64_t* __restrict__ indptr, const int64_t* __restrict__ idx, float* __restrict__ tgt,
-    int32_t* __restrict__ ranks) {
+    float kappa, const unsigned* __restrict__ band_consts, float2* __restrict__ tband, int32_t* __restrict__ ranks) {
   __shared__ uint4 s_bh[KS][64], s_bl[KS][64];   // the block's B-operand fragments (hi / lo), shared by the waves
   __shared__ int64_t s_e[TL_WAVES][32];
   __shared__ int s_corr[32];
-  __shared__ float s_t[32];
+  __shared__ float s_t[32];       // t_hi of the block's queries: the upper edge of the exact band
+  __shared__ float s_n2[TL_WAVES][32];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, i = lane & 31, half = lane >> 5;
   const int64_t blk = blockIdx.x, q0 = blk * 32, q = q0 + i;
   const bool live = q < B;
@@ -112,6 +117,7 @@ __global__ __launch_bounds__(64 * TL_WAVES) void k_finalize_targets_filter_bf16x
     const int64_t pos = live ? inv_perm[q] : 0;
     const float* bsrc = live ? (per_rel_bias ? fc_b + (int64_t)sorted_rid[pos] * d : fc_b) : fc_b;
     const bool vec_ok = (d & 3) == 0 && (((uintptr_t)fc_b | (uintptr_t)scale | (uintptr_t)shift) & 15) == 0;
+    float n2 = 0.f;
 #pragma unroll
     for (int ks = wave; ks < KS; ks += TL_WAVES) {
       const int k0 = 16 * ks + 8 * half;
@@ -148,9 +154,19 @@ __global__ __launch_bounds__(64 * TL_WAVES) void k_finalize_targets_filter_bf16x
             v = z[c] + bb[c];
             v = fmaf(v, sc8[c], sh8[c]);
             v = fmaxf(v, 0.f);
-            if (h_out) h_out[q * d + k] = v;
+            n2 = fmaf(v, v, n2);
           }
           y[c] = v;
+        }
+        // fp32 rows: what the exact band re-scores from (and the caller's h when it asked for it)
+        if (k0 + 8 <= d && (d & 3) == 0 && (((uintptr_t)h_out) & 15) == 0) {
+          float4* ho = (float4*)(h_out + q * d + k0);
+          ho[0] = make_float4(y[0], y[1], y[2], y[3]);
+          ho[1] = make_float4(y[4], y[5], y[6], y[7]);
+        } else {
+#pragma unroll
+          for (int c = 0; c < 8; ++c)
+            if (k0 + c < d) h_out[q * d + k0 + c] = y[c];
         }
       } else {
 #pragma unroll
@@ -158,12 +174,12 @@ __global__ __launch_bounds__(64 * TL_WAVES) void k_finalize_targets_filter_bf16x
       }
       uint4 h4, l4;
       split8_bf16(y, h4, l4);
-      const int64_t fo = (blk * KS + ks) * 64 + lane;
-      fhi[fo] = h4;
-      flo[fo] = l4;
+      f3_store_piece(hf3, KS, q, ks, half, h4, l4, true);   // rows past B: zero pieces (the count kernel's tile is whole)
       s_bh[ks][lane] = h4;
       s_bl[ks][lane] = l4;
     }
+    n2 += __shfl_xor(n2, 32);
+    if (half == 0) s_n2[wave][i] = n2;
   }
   TL_STAMP(1);
   __syncthreads();
@@ -240,8 +256,12 @@ __global__ __launch_bounds__(64 * TL_WAVES) void k_finalize_targets_filter_bf16x
     float t0 = __shfl(diag, i + 32 * ((i >> 2) & 1));   // lane i (both halves): the target of query i
     t0 = erow >= 0 ? t0 : 0.f;
     if (half == 0) {
-      s_t[i] = t0;
-      if (live) tgt[q] = t0;
+      float n2 = 0.f;
+#pragma unroll
+      for (int w2 = 0; w2 < TL_WAVES; ++w2) n2 += s_n2[w2][i];
+      const float tau = tail_band_tau(n2, kappa, band_consts);
+      s_t[i] = t0 + tau;
+      if (live) { tgt[q] = t0; tband[q] = make_float2(t0 - tau, t0 + tau); }
     }
   } else {
     const int64_t pb = p_begin + 32 * (int64_t)(wave - 1);
@@ -289,7 +309,7 @@ extern "C" __attribute__((visibility("default"))) int coper_dbg_tl_clock(int n_w
 bool tail_fused_supported(const coper_handle* h) {
   static const bool off = getenv("COPER_TAIL_UNFUSED") != nullptr;   // A/B switch, read once
   if (off) return false;
-  return (h->dm.KS16 == 13 || h->dm.KS16 == 16) && h->dm.n_local == h->dm.E;
+  return (h->dm.KS16 == 13 || h->dm.KS16 == 16) && h->dm.n_local == h->dm.E;   // (the resident fragments: KS16 registers x 2 per lane)
 }
 
 int launch_finalize_targets_filter_bf16x3(coper_handle* h, int64_t B, int ksplit, float* h_out, const int64_t* e2, const int64_t* indptr,
@@ -301,8 +321,8 @@ int launch_finalize_targets_filter_bf16x3(coper_handle* h, int64_t B, int ksplit
 #define TL_GO(KS_)                                                                                                                 \
   hipLaunchKernelGGL(k_finalize_targets_filter_bf16x3<KS_>, dim3(grid), dim3(64 * TL_WAVES), 0, s, h->z_part, ksplit, h->ws_queries, B, dm.d,   \
                      dm.d_pad16, h->inv_perm, h->sorted_rid, fcb, dm.gen_fc ? 1 : 0, h->fc_scale, h->fc_shift, h_out,               \
-                     (uint4*)h->hfrag16_hi, (uint4*)h->hfrag16_lo, (const uint4*)h->Erm16_hi, (const uint4*)h->Erm16_lo,            \
-                     h->bias_pad, dm.n_local, e2, indptr, idx, tgt, ranks)
+                     (uint4*)h->hf3_ws, (const uint4*)h->Erm16_hi, (const uint4*)h->Erm16_lo,                                       \
+                     h->bias_pad, dm.n_local, e2, indptr, idx, tgt, band_kappa(h), h->band_consts, (float2*)h->tband_ws, ranks)
   if (dm.KS16 == 13) TL_GO(13); else TL_GO(16);
 #undef TL_GO
   COPER_HIP_TRY(h, hipGetLastError());

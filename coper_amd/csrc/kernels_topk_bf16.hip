@@ -21,16 +21,10 @@
 //      survivors ahead of each, (score desc, id asc).
 //
 // Work beyond the count pass: (k*B + nnz) blocks of 32 logits instead of B*|E|.
+#include "bf16x3_chain.h"
 #include "coper_internal.h"
 
 namespace coper {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-#define TK_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&(a), *(const bf16x8*)&(b), (c), 0, 0, 0)
-// same order as MFMA_X3 of kernels_score_bf16.hip: smallest terms first
-#define TK_MFMA_X3(ahi, alo, bhi, blo, c) \
-  { (c) = TK_MFMA(alo, bhi, c); (c) = TK_MFMA(ahi, blo, c); (c) = TK_MFMA(ahi, bhi, c); }
 
 // order-preserving map float -> uint32
 __device__ __forceinline__ uint32_t tk_key(float v) {
@@ -534,20 +528,20 @@ __global__ __launch_bounds__(256) void k_topk_score_blocks(const uint4* __restri
   const uint4* pa_l = Elo + g * KS * 64 + lane;
   const uint4* pb_h = Hrm_hi + q * (2 * KS) + half;
   const uint4* pb_l = Hrm_lo + q * (2 * KS) + half;
-  int ks = 0;
-  for (; ks + 4 <= KS; ks += 4) {
+  // pairs of k-steps, then the last one of an odd count (bf16x3_chain.h); batches of two pairs
+  for (int ks = 0; ks < KS; ks += 4) {
     uint4 ah[4], al[4], bh[4], bl[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      ah[u] = pa_h[(ks + u) * 64]; al[u] = pa_l[(ks + u) * 64];
-      bh[u] = pb_h[(ks + u) * 2]; bl[u] = pb_l[(ks + u) * 2];
+      const int k = ks + u < KS ? ks + u : KS - 1;
+      ah[u] = pa_h[k * 64]; al[u] = pa_l[k * 64];
+      bh[u] = pb_h[k * 2]; bl[u] = pb_l[k * 2];
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) TK_MFMA_X3(ah[u], al[u], bh[u], bl[u], acc);
-  }
-  for (; ks < KS; ++ks) {
-    uint4 ah = pa_h[ks * 64], al = pa_l[ks * 64], bh = pb_h[ks * 2], bl = pb_l[ks * 2];
-    TK_MFMA_X3(ah, al, bh, bl, acc);
+    for (int u = 0; u < 4; u += 2) {   // wave-uniform
+      if (ks + u + 1 < KS) { BX3_PAIR(ah[u], al[u], bh[u], bl[u], ah[u + 1], al[u + 1], bh[u + 1], bl[u + 1], acc); }
+      else if (ks + u < KS) { BX3_LAST(ah[u], al[u], bh[u], bl[u], acc); }
+    }
   }
   if (w < 0) return;
   // known answers of this lane's query inside the block, except the target (metrics.py:45-46)
@@ -688,9 +682,9 @@ static void tk_dispatch_emit(coper_handle* h, int64_t G, int64_t qs, int64_t q0,
   else tk_launch_emit<4, 4>(h, G, qs, q0, bc, k, indptr, s);
 }
 
-int launch_topk_pruned_bf16x3(coper_handle* h, const float* tgt, const int64_t* e2, const int64_t* indptr, const int64_t* idx,
-                              int64_t nnz, int64_t B, int k, int32_t* ng, int32_t* ne, float* topk_val, int64_t* topk_idx,
-                              hipStream_t s) {
+int launch_topk_pruned_bf16x3(coper_handle* h, const float* hvec, const float* tgt_x, const int64_t* e2, const int64_t* indptr,
+                              const int64_t* idx, int64_t nnz, int64_t B, int k, int32_t* ng, int32_t* ne, float* topk_val,
+                              int64_t* topk_idx, hipStream_t s) {
   const Dims& dm = h->dm;
   const int64_t G = dm.n_eblk;
   const int64_t qc = topk_chunk_queries(G, B, h->gmax_max_floats);
@@ -708,7 +702,7 @@ int launch_topk_pruned_bf16x3(coper_handle* h, const float* tgt, const int64_t* 
   for (int64_t q0 = 0; q0 < B; q0 += qc) {
     const int64_t bc = B - q0 < qc ? B - q0 : qc;
     const int64_t qs = (bc + 127) / 128 * 128;
-    if ((rc = score_count_chunk_bf16x3(h, q0, bc, tgt, ng, ne, h->gmax_ws, qs, s))) return rc;
+    if ((rc = score_count3_chunk_bf16x3(h, q0, bc, hvec, tgt_x, e2, indptr, idx, ng, ne, h->gmax_ws, qs, s))) return rc;
     // long block axis: more histogram copies; half-width strips (twice the workgroups) when 32-query strips would
     // not cover the chip
     tk_dispatch_emit(h, G, qs, q0, bc, k, indptr, s);

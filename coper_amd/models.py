@@ -72,7 +72,7 @@ def _host(v):
 
 
 class ConvE(object):
-    def __init__(self, model_descriptors: dict, device=None, shard=None, score_mode="f32"):
+    def __init__(self, model_descriptors: dict, device=None, shard=None, score_mode="f32", rank_band_kappa=0.0):
         md = dict(model_descriptors)
         # required keys, as models.py:99-105,119-130 reads them
         for key in ("use_negative_sampling", "label_smoothing_epsilon", "num_ent", "num_rel", "ent_emb_size",
@@ -98,7 +98,7 @@ class ConvE(object):
             raise ValueError("score_mode: 'f32' (exact-f32 MFMA) or 'bf16x3' (split-bf16 operands, 3 bf16 MFMAs per product)")
         mode = {"f32": _lib.SCORE_F32, "bf16x3": _lib.SCORE_BF16X3}[score_mode]
         self.score_mode = score_mode
-        cfg = _lib.make_config(md, device=self.device.index or 0, shard=self.shard, score_mode=mode)
+        cfg = _lib.make_config(md, device=self.device.index or 0, shard=self.shard, score_mode=mode, rank_band_kappa=rank_band_kappa)
         h = C.c_void_p()
         rc = self._lib.coper_create(C.byref(cfg), C.byref(h))
         if rc != 0:
@@ -247,16 +247,23 @@ class ConvE(object):
         return out
 
     def target_scores(self, h, e2):
+        """[2, B]: row 0 the mode's logit of (b, e2[b]), bit-identical to what score_all writes for that element; row 1
+        the fp32-chain logit of the same pair (what the bf16x3 mode's exact band decides close comparisons against; equal
+        to row 0 in the f32 mode).  Entries whose e2 is not on this shard are 0: the sum over shards is the full result."""
         self._need_prepared()
         e2 = self._ids(e2)
-        out = torch.empty((e2.numel(),), device=self.device, dtype=torch.float32)
+        out = torch.empty((2, e2.numel()), device=self.device, dtype=torch.float32)
         _lib.check(self._h, self._lib.coper_target_scores(self._h, _ptr(h), _ptr(e2), e2.numel(), _ptr(out), self._stream()))
         return out
 
     def rank_counts(self, h, tgt, e2, filt_indptr, filt_idx, filt_nnz=None, k=0):
         """(n_greater, n_equal) int32 [B] over this shard (metrics.py:44-50 without logits); with k > 0 also
-        the shard's top-k of the filtered row: (..., topk_val f32 [B,k], topk_idx int64 [B,k] global ids)."""
+        the shard's top-k of the filtered row: (..., topk_val f32 [B,k], topk_idx int64 [B,k] global ids).
+        `tgt`: the [2, B] tensor of target_scores (summed over shards)."""
         self._need_prepared()
+        if tuple(tgt.shape) != (2, self._ids(e2).numel()):
+            raise ValueError("rank_counts: tgt must be the [2, B] tensor target_scores returns")
+        tgt = tgt.contiguous()
         e2, ip, ix = self._ids(e2), self._ids(filt_indptr), self._ids(filt_idx)
         B = e2.numel()
         nnz = int(ix.numel()) if filt_nnz is None else int(filt_nnz)

@@ -33,7 +33,7 @@ extern "C" {
 #define COPER_API
 #endif
 
-#define COPER_ABI_VERSION 1
+#define COPER_ABI_VERSION 2
 #define COPER_MAX_CTX 4 /* max hidden layers of a g_MLP generator */
 
 typedef enum coper_status {
@@ -79,7 +79,12 @@ typedef struct coper_config {
   float bn_epsilon;             /* 1e-3 = tf.layers.batch_normalization default */
   int64_t shard_lo, shard_hi;   /* entity rows [lo, hi) held by this handle; [0, num_ent) = unsharded */
   int32_t score_mode;           /* coper_score_mode */
-  int32_t reserved[7];
+  /* COPER_SCORE_BF16X3: relative half-width of the exact band.  Comparisons of a competitor's logit with the target's that are
+   * closer than 2 kappa (|h_q| max|E_e| + max|pred_bias|) are decided by the fp32 chain of COPER_SCORE_F32 instead of the mode's
+   * own arithmetic (integer ranks: metrics.py:44-50).  0 = the library default (1e-5, three times the largest error observed
+   * on 3e8 logits); 3 * 2^-16 + 2 (48 ceil(d/16) + 1) 2^-24 is the proven worst case.  Larger = more pairs re-scored. */
+  float rank_band_kappa;
+  int32_t reserved[6];
 } coper_config;
 
 typedef struct coper_handle coper_handle;

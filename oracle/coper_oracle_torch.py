@@ -42,9 +42,13 @@ class TorchCPUModel(object):
     """Weights as CPU fp32 tensors by the reference's leaf names; `eval_pass` = one evaluation pass the way
     `run_cpg.py:18-35 -> metrics.py:38-60` runs it."""
 
-    def __init__(self, params, md):
+    def __init__(self, params, md, device="cpu", dtype=torch.float32):
+        """`device` / `dtype` other than the CPU-baseline defaults are for diagnostics (tools/rank_decomp.py runs the
+        same graph in float64 on the GPU to have reference-semantics ranks of a full-size pass in seconds)."""
         self.md, self.dims = md, Dims(md)
-        self.p = {k: torch.as_tensor(np.ascontiguousarray(np.asarray(v, dtype=np.float32))) for k, v in params.items()}
+        self.device = torch.device(device)
+        self.p = {k: torch.as_tensor(np.ascontiguousarray(np.asarray(v, dtype=np.float32))).to(device=self.device, dtype=dtype)
+                  for k, v in params.items()}
 
     def _generate(self, ctx, name, hidden):
         p, v = self.p, ctx
@@ -64,8 +68,8 @@ class TorchCPUModel(object):
     @torch.no_grad()
     def forward(self, e1, rel):
         dm, p = self.dims, self.p
-        e1 = torch.as_tensor(np.asarray(e1, dtype=np.int64))
-        rel = torch.as_tensor(np.asarray(rel, dtype=np.int64))
+        e1 = torch.as_tensor(np.asarray(e1, dtype=np.int64)).to(self.device)
+        rel = torch.as_tensor(np.asarray(rel, dtype=np.int64)).to(self.device)
         B = e1.shape[0]
         x0 = p["ent_emb"].index_select(0, e1)
         c = None if dm.lookup else p["rel_emb"].index_select(0, rel)

@@ -8,6 +8,7 @@ import pytest
 import torch
 
 from coper_amd import data as cdata
+from tests.helpers import rank_defining_logits
 
 pytestmark = pytest.mark.gpu
 
@@ -68,11 +69,12 @@ def test_random_shapes_against_oracle(oracle_chain, seed):
         # the fused pass (no logits) against the closed form on the library's own logits: the count kernels, the pair
         # kernels and score_all compute the same bits
         ranks, ne = m.rank_pass(q["e1"], q["rel"], q["e2"], q["filt_indptr"], q["filt_idx"])
-        tgt = logits[np.arange(Q), q["e2"]]
+        xl = rank_defining_logits(O, m, h, p)      # bf16x3: the fp32 chain on this h (exact band), not the mode's own logits
+        tgt = xl[np.arange(Q), q["e2"]]
         keep = ~mask
         keep[np.arange(Q), q["e2"]] = False
-        want = 1 + ((logits > tgt[:, None]) & keep).sum(axis=1)
-        want_eq = ((logits == tgt[:, None]) & keep).sum(axis=1)
+        want = 1 + ((xl > tgt[:, None]) & keep).sum(axis=1)
+        want_eq = ((xl == tgt[:, None]) & keep).sum(axis=1)
         assert np.array_equal(ranks.cpu().numpy(), want), (variant, md, mode)
         assert np.array_equal(ne.cpu().numpy(), want_eq), (variant, md, mode)
         r0, _ = m.rank_pass(q["e1"], q["rel"], q["e2"], q["filt_indptr"], q["filt_idx"], want_equal=False)
@@ -138,12 +140,13 @@ def test_random_shards_sum_to_the_unsharded_result(seed):
 
 
 @pytest.mark.parametrize("mode", ["bf16x3", "f32"])
-def test_one_handle_many_calls_of_changing_size(mode):
+def test_one_handle_many_calls_of_changing_size(oracle_chain, mode):
     """State that outlives a call -- the two relation-count buffers that zero each other, cursors, tickets, workspaces that
     grow, pooled timer events -- under 120 consecutive passes whose batch size jumps between 1 and 5,000 queries (single-launch
     and multi-launch grouping, one or many tiles, workspace regrowth), with the top-k route in between: every pass must equal
     the closed form on the handle's own logits."""
     from coper_amd.models import ConvE
+    O = oracle_chain
     md = cdata.model_descriptors("fb15k237_cpg", num_ent=1500, num_rel=40)
     p = cdata.synthetic_params(md, 3)
     m = ConvE(md, device="cuda:0", score_mode=mode)
@@ -161,7 +164,7 @@ def test_one_handle_many_calls_of_changing_size(mode):
             m.rank_counts(h, m.target_scores(h, q["e2"]), q["e2"], q["filt_indptr"], q["filt_idx"], k=10)
         if it % 5 == 0 or Q < 64:
             h = m.encode(q["e1"], q["rel"])
-            logits = m.score_all(h).cpu().numpy()
+            logits = rank_defining_logits(O, m, h, p)
             mask = cdata.csr_to_dense_filter(q["filt_indptr"], q["filt_idx"], E).astype(bool)
             tgt = logits[np.arange(Q), q["e2"]]
             keep = ~mask
@@ -204,7 +207,7 @@ def test_reference_style_dense_mask_batches():
 
 
 @pytest.mark.parametrize("mode", ["bf16x3", "f32"])
-def test_filter_rows_with_thousands_of_known_answers(mode):
+def test_filter_rows_with_thousands_of_known_answers(oracle_chain, mode):
     """A query whose filter list holds most of the entity table (real KGs have such (e1, rel) pairs): the pass takes the
     balanced two-call path (sharding._heavy_filter_rows) and both it and the fused call give the closed-form ranks."""
     from coper_amd import sharding
@@ -223,7 +226,7 @@ def test_filter_rows_with_thousands_of_known_answers(mode):
     idx = np.concatenate(rows)
     assert sharding._heavy_filter_rows(indptr)
     h = m.encode(q["e1"], q["rel"])
-    logits = m.score_all(h).cpu().numpy()
+    logits = rank_defining_logits(oracle_chain, m, h, cdata.synthetic_params(md, 2))
     mask = cdata.csr_to_dense_filter(indptr, idx, E).astype(bool)
     tgt = logits[np.arange(Q), q["e2"]]
     keep = ~mask

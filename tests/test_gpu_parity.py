@@ -9,6 +9,7 @@ import pytest
 import torch
 
 from coper_amd import data as cdata
+from tests.helpers import rank_defining_logits
 
 pytestmark = pytest.mark.gpu
 
@@ -258,23 +259,29 @@ def test_entity_sharded_handles_sum_to_unsharded(oracle_chain):
 @pytest.mark.parametrize("mode", ["f32", "bf16x3"])
 @pytest.mark.parametrize("name", ["fb15k237_cpg", "fb15k237_plain", "wn18rr_cpg"])
 def test_full_size_configs_properties(oracle_chain, name, mode):
-    """BASELINE.json full sizes, in BOTH arithmetic modes (bf16x3 is what bench.py reports): ranks of the fused
-    path == ranks recomputed from the mode's own materialised logits by the C restatement of the reference ranker;
-    on a query sample of every chunk, against the fp64 oracle DIRECTLY: h within 2e-4, logits within the 1e-3 gate,
-    and ranks equal to the oracle's fp64 ranks up to the entities inside the measured logit error band; fp32 mode:
-    logits bit-equal to the documented chain; Hits@10 / MRR identical to the recomputation."""
+    """BASELINE.json full sizes, in BOTH arithmetic modes (bf16x3 is what bench.py reports).
+
+    Ranks are those of the documented fp32 chain on the mode's own h, for EVERY query:
+      * f32 mode: fused ranks == the C restatement of the reference ranker on the materialised logits, which are bit-equal to
+        the C chain (sampled);
+      * bf16x3 mode (exact band, kernels_score3_bf16.hip): ranks and tie counts == the f32 mode's ranker fed the same h --
+        all Q queries -- and, on a query sample, == the closed form on logits the C chain computes from that h.
+    On the sample, against the fp64 oracle DIRECTLY: h within 2e-4, logits within the 1e-3 gate, the rank inside the
+    band the logit error allows, and EQUAL to the fp64 oracle's rank for >= 99 % (f32) of the sampled queries (the bf16x3
+    encoder's h error moves more: bound asserted below); Hits@10 / MRR identical to the recomputation."""
     O = oracle_chain
     from coper_amd.metrics import hits_and_means, ranking_and_hits
     md = cdata.model_descriptors(name)
     Q = {"fb15k237_cpg": 20480, "fb15k237_plain": 20480, "wn18rr_cpg": 3072}[name]
     p = cdata.synthetic_params(md, 0)
     m = _model(md, p, score_mode=mode)
+    m32 = _model(md, p, score_mode="f32") if mode != "f32" else None
     q = cdata.synthetic_queries(md, Q, seed=0)
     mr, mrr, hits, ranks = ranking_and_hits(m, None, cdata.EvalDataset(q, 512, md["num_ent"]), name, return_ranks=True)
     assert ranks.min() >= 1 and ranks.max() <= md["num_ent"]
     E64, b64 = p["ent_emb"].astype(np.float64), p["pred_bias"].astype(np.float64)
     exp = np.empty(Q, np.int64)
-    n_equal = n_sampled = n_safe = 0
+    n_equal = n_sampled = n_safe = n_same64 = 0
     max_err = 0.0
     for s in range(0, Q, 2048):
         e = min(Q, s + 2048)
@@ -282,17 +289,26 @@ def test_full_size_configs_properties(oracle_chain, name, mode):
         logits = m.score_all(h).cpu().numpy()
         ip = q["filt_indptr"][s:e + 1]
         ipl, ixl = ip - ip[0], q["filt_idx"][ip[0]:ip[-1]]
-        ng, ne = O.rank_counts_c(logits, q["e2"][s:e], ipl, ixl)
-        exp[s:e] = 1 + ng
-        n_equal += int(ne.sum())
-        # exact fp32 ties do occur at this scale (a few per 3e8 comparisons): the fused counts report them
         r_gpu, ne_gpu = m.rank(h, q["e2"][s:e], ipl, ixl)
-        assert np.array_equal(ne_gpu.cpu().numpy(), ne) and np.array_equal(r_gpu.cpu().numpy(), 1 + ng)
-        # query sample of this chunk against the fp64 oracle
-        sub = np.arange(s % 97, e - s, 97)
+        r_gpu, ne_gpu = r_gpu.cpu().numpy(), ne_gpu.cpu().numpy()
+        exp[s:e] = r_gpu
+        n_equal += int(ne_gpu.sum())
         hn = h.cpu().numpy()
+        sub = np.arange(s % 97, e - s, 97)
         if mode == "f32":
+            # exact fp32 ties do occur at this scale (a few per 3e8 comparisons): the fused counts report them
+            ng, ne = O.rank_counts_c(logits, q["e2"][s:e], ipl, ixl)
+            assert np.array_equal(ne_gpu, ne) and np.array_equal(r_gpu, 1 + ng)
             assert np.array_equal(logits[sub], O.score_chain(hn[sub], p["ent_emb"], p["pred_bias"]))
+        else:
+            r32, ne32 = m32.rank(h, q["e2"][s:e], ipl, ixl)           # the fp32-chain ranker on the SAME h: every query
+            assert np.array_equal(r_gpu, r32.cpu().numpy()) and np.array_equal(ne_gpu, ne32.cpu().numpy())
+            chain = O.score_chain(hn[sub], p["ent_emb"], p["pred_bias"])   # ... and the C chain, without any GPU arithmetic
+            sip = np.concatenate([[0], np.cumsum(ipl[sub + 1] - ipl[sub])])
+            six = np.concatenate([ixl[ipl[b]:ipl[b + 1]] for b in sub]) if len(sub) else np.zeros(0, np.int64)
+            ng_c, ne_c = O.rank_counts_c(chain, q["e2"][s:e][sub], sip, six)
+            assert np.array_equal(r_gpu[sub], 1 + ng_c) and np.array_equal(ne_gpu[sub], ne_c)
+        # query sample of this chunk against the fp64 oracle
         st = O.forward(p, md, q["e1"][s:e][sub], q["rel"][s:e][sub], np.float64, materialise=False)
         assert np.abs(hn[sub] - st["h"]).max() < H_TOL
         lg64 = O.score_all(st["h"], E64, b64)
@@ -313,13 +329,22 @@ def test_full_size_configs_properties(oracle_chain, name, mode):
             assert lo_r <= ranks[s + b] <= hi_r, (s + b, ranks[s + b], lo_r, hi_r)
             n_sampled += 1
             n_safe += int(lo_r == hi_r)
-    assert np.array_equal(ranks, exp)
-    assert n_safe > 0 and n_sampled >= Q // 100, (n_safe, n_sampled, max_err)   # n_safe ranks were pinned exactly
+            n_same64 += int(ranks[s + b] == 1 + int(np.sum(others > t)))
+    assert np.array_equal(ranks, exp)            # coper_encode_rank (fused) == encode + rank
+    assert n_safe > 0 and n_sampled >= Q // 100, (n_safe, n_sampled, max_err)
+    # ranks EQUAL to the float64 oracle's (reference semantics end to end): what is left is the encoder's rounding of h
+    # (measured with tools/rank_decomp.py: f32 mode 99.6 %, bf16x3 97.9 % at FB15k-237 shapes; WN18RR's 40,943 entities sit
+    # three times denser around the target)
+    frac64 = n_same64 / n_sampled
+    assert frac64 >= {"f32": 0.985, "bf16x3": 0.93}[mode] - (0.05 if name == "wn18rr_cpg" else 0.0), (frac64, n_sampled)
+    print("%s %s: ranks equal to the float64 oracle's for %.4f of %d sampled queries; max logit error %.2e" % (name, mode, frac64, n_sampled, max_err))
     assert max_err < (2e-5 if mode == "f32" else 3e-4), max_err
     mr2, mrr2, hits2 = hits_and_means(exp)
     assert (mr, mrr, hits[10]) == (mr2, mrr2, hits2[10])
     assert n_equal < 1e-6 * Q * md["num_ent"]
     m.close()
+    if m32 is not None:
+        m32.close()
 
 
 def test_topk_of_filtered_rows(oracle_chain):
@@ -363,8 +388,9 @@ def test_topk_of_filtered_rows(oracle_chain):
 @pytest.mark.parametrize("name", ["plain", "cpg_fc", "cpg_conv_fc"])
 def test_bf16x3_mode_golden_fixture(golden_dir, oracle_chain, name):
     """COPER_SCORE_BF16X3 (split-bf16 operands on the bf16 matrix cores): logits within 1e-3 of the fp64
-    oracle (measured ~1e-5); every kernel of the mode produces the same bits; fused ranks == the reference
-    ranker semantics on the mode's own logits; == the fp64 oracle's ranks outside the error band."""
+    oracle (measured ~1e-5); every kernel of the mode produces the same bits; ranks and tie counts == the reference
+    ranker semantics on the FP32 CHAIN's logits of the same h (the exact band); == the fp64 oracle's ranks outside the
+    error band."""
     O = oracle_chain
     g, md, p, q = _fwd_case(golden_dir, name)
     m = _model(md, p, score_mode="bf16x3")
@@ -374,11 +400,14 @@ def test_bf16x3_mode_golden_fixture(golden_dir, oracle_chain, name):
     err = np.abs(logits - g["f64:logits"]).max()
     assert err < LOGIT_TOL and err < 2e-4
     tgt = m.target_scores(h, q["e2"]).cpu().numpy()
-    assert np.array_equal(tgt, logits[np.arange(len(tgt)), q["e2"]])     # pair kernel == tile kernel, bit for bit
+    assert np.array_equal(tgt[0], logits[np.arange(tgt.shape[1]), q["e2"]])     # pair kernel == tile kernel, bit for bit
+    chain = rank_defining_logits(O, m, h, p)                                 # the fp32 chain on this h (C restatement)
+    assert np.array_equal(tgt[1], chain[np.arange(tgt.shape[1]), q["e2"]])   # the exact targets the band compares against
+    assert np.abs(logits - chain).max() < 2e-4
     lookup = np.random.default_rng(1).integers(0, md["num_ent"], (len(q["e1"]), 9)).astype(np.int32)
     assert np.array_equal(m.score_lookup(h, lookup).cpu().numpy(), np.take_along_axis(logits, lookup.astype(np.int64), axis=1))
     ranks, ne = m.rank(h, q["e2"], q["filt_indptr"], q["filt_idx"])
-    ng_o, ne_o = O.rank_counts_c(logits, q["e2"], q["filt_indptr"], q["filt_idx"])
+    ng_o, ne_o = O.rank_counts_c(chain, q["e2"], q["filt_indptr"], q["filt_idx"])     # ranks and ties of the mode ARE the chain's
     assert np.array_equal(ranks.cpu().numpy(), 1 + ng_o) and np.array_equal(ne.cpu().numpy(), ne_o)
     safe = g["f64:min_gap"] > 2 * err + 1e-6
     assert safe.mean() > 0.9
@@ -390,9 +419,8 @@ def test_bf16x3_mode_golden_fixture(golden_dir, oracle_chain, name):
 
 
 def test_bf16x3_mode_full_size_and_sharded(oracle_chain):
-    """FB15k-237 full size in bf16x3: fused ranks == C restatement of the reference ranker on the mode's own
-    materialised logits; agreement with the fp32-exact mode's ranks except inside the ~1e-5 logit band;
-    two entity shards == unsharded."""
+    """FB15k-237 full size in bf16x3: fused ranks == the fp32-exact mode's ranker fed the same h (the exact band);
+    against the fp32-exact mode END TO END what remains is the two encoders' rounding of h; two entity shards == unsharded."""
     O = oracle_chain
     from coper_amd.metrics import ranking_and_hits
     md = cdata.model_descriptors("fb15k237_cpg")
@@ -403,9 +431,9 @@ def test_bf16x3_mode_full_size_and_sharded(oracle_chain):
     mr, mrr, hits, ranks = ranking_and_hits(m, None, cdata.EvalDataset(q, 512, md["num_ent"]), "bf16x3", return_ranks=True)
     h = m.encode(q["e1"], q["rel"])
     logits = m.score_all(h).cpu().numpy()
-    ng, ne = O.rank_counts_c(logits, q["e2"], q["filt_indptr"], q["filt_idx"])
-    assert np.array_equal(ranks, 1 + ng)
     m32 = _model(md, p)
+    r_same_h, _ = m32.rank(h, q["e2"], q["filt_indptr"], q["filt_idx"])      # the fp32-chain ranker on the bf16x3 mode's h
+    assert np.array_equal(ranks, r_same_h.cpu().numpy())
     _, _, _, ranks32 = ranking_and_hits(m32, None, cdata.EvalDataset(q, 512, md["num_ent"]), "f32", return_ranks=True)
     lg32 = m32.score_all(m32.encode(q["e1"], q["rel"])).cpu().numpy()
     err = np.abs(logits - lg32).max()
@@ -738,8 +766,8 @@ def test_prepare_generators_match_sister_model_scores(golden_dir, tag, mode):
 @pytest.mark.parametrize("d,emb", [(200, (10, 20)), (256, (16, 16))])
 def test_fused_tail_path_edge_cases(oracle_chain, d, emb):
     """coper_encode_rank, ranks only, bf16x3 with 13 / 16 k-steps: finalize + targets + filter correction run as ONE launch
-    (kernels_tail_bf16.hip) and the pipelined count kernel adds to its output.  Same ranks as the reference ranker applied
-    to the mode's own materialised logits, same embedding bits as the two-call path, for: batch sizes around the 32-query
+    (kernels_tail_bf16.hip) and the pipelined count kernel and the exact band add to its output.  Same ranks as the reference
+    ranker applied to the fp32 chain's logits of the same h, same embedding bits as the two-call path, for: batch sizes around the 32-query
     block and 128-query tile boundaries, empty filters, filters without the target, duplicated and unsorted-free CSR rows
     with up to 64 entries, entries that equal the target, a query block whose entries span several 32-entry tiles."""
     O = oracle_chain
@@ -759,7 +787,7 @@ def test_fused_tail_path_edge_cases(oracle_chain, d, emb):
         ip[1:] = np.cumsum([len(r) for r in rows])
         variants.append((ip, np.concatenate(rows).astype(np.int64)))
         h2 = m.encode(q["e1"], q["rel"])
-        logits = m.score_all(h2).cpu().numpy()
+        logits = rank_defining_logits(O, m, h2, p)      # the fp32 chain on this h: what the mode's ranks are defined by
         for ipv, ixv in variants:
             r_fused, none, h1 = m.rank_pass(q["e1"], q["rel"], q["e2"], ipv, ixv, want_equal=False, want_h=True)
             assert none is None and torch.equal(h1, h2)

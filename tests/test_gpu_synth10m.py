@@ -57,18 +57,30 @@ def test_synth10m_full_size(oracle_chain, mode):
     sample = np.arange(5, Q, 113)                                            # 37 queries x 10M logits = 1.5 GB
     hs = h[torch.as_tensor(sample).cuda()].contiguous()
     rows = full.score_all(hs)
+    # the logits that define the ranks: the fp32 chain on this h -- the mode's own in the f32 mode, an f32 handle's in the
+    # bf16x3 mode (its count kernel hands every comparison closer than its error to that chain: the exact band)
+    if mode == "f32":
+        xrows = rows.clone()
+    else:
+        ref = _handle(md, small, ent, bias, "f32")
+        xrows = ref.score_all(hs)
+        ref.close()
+        del ref
     ip, ix = q["filt_indptr"], q["filt_idx"]
     for i, b in enumerate(sample):
-        row = rows[i]
-        t = row[q["e2"][b]].clone()
-        assert t.item() == tgt[b].item()                                     # pair kernel == tile kernel
+        row, xrow = rows[i], xrows[i]
+        t, tx = row[q["e2"][b]].clone(), xrow[q["e2"][b]].clone()
+        assert t.item() == tgt[0, b].item() and tx.item() == tgt[1, b].item()   # pair kernels == tile kernels
         filt = torch.as_tensor(ix[ip[b]:ip[b + 1]]).cuda()
         row[filt] = float("-inf")
+        xrow[filt] = float("-inf")
         row[q["e2"][b]] = t
-        assert int((row > t).sum().item()) + 1 == ranks_np[b]
-        assert int((row == t).sum().item()) - 1 == int(ne[b].item())
+        xrow[q["e2"][b]] = tx
+        assert int((xrow > tx).sum().item()) + 1 == ranks_np[b]
+        assert int((xrow == tx).sum().item()) - 1 == int(ne[b].item())
         ev, ei = torch.topk(row, K)                                          # ties at the top are not expected here
         assert torch.equal(ev, tv[b]) and torch.equal(ei, ti[b])
+    del xrows
     # (2) logits on sampled columns against the fp64 oracle; fp32 mode: bit-equal to the documented chain
     cols = np.unique(np.concatenate([np.random.default_rng(1).integers(0, E, 3000), q["e2"][sample], q["e1"][sample]]))
     cols_t = torch.as_tensor(cols).cuda()
