@@ -29,14 +29,16 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "split16.h"
+
 namespace coper {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-#define BX3_MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&(a), *(const bf16x8*)&(b), (c), 0, 0, 0)
-#define BX3_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&(a), *(const bf16x8*)&(b), (c), 0, 0, 0)
+// (the 16-bit type of the split -- fp16, or bf16 in COPER_SPLIT_BF16 builds -- is split16.h's business)
+#define BX3_MFMA32(a, b, c) S16_MFMA32(a, b, c)
+#define BX3_MFMA16(a, b, c) S16_MFMA16(a, b, c)
 
 // 32x32x16 kernels, entity rows = A, queries = B: two consecutive k-steps (fragments *0 of the first, *1 of the second)
 #define BX3_PAIR(eh0, el0, qh0, ql0, eh1, el1, qh1, ql1, c)                     \
@@ -109,6 +111,53 @@ __device__ __forceinline__ float exact_chain(const float* __restrict__ er, const
       if (k1 < d) s = __builtin_fmaf(er[k1], hr[k1], s);
     }
   return s;
+}
+
+
+// The same chain for the two logits of a comparison -- entity row `er` and target row `tr` (may be NULL: t_out untouched)
+// against one query row -- with the loads of CB k-steps of 8 issued before their fmas: a lane that walks a chain alone is
+// latency-bound on its row loads (25 dependent round trips to L2 at d = 200 took 25 us per chain; in batches of five: 5).
+__device__ __forceinline__ void exact_chain_pair(const float* __restrict__ er, const float* __restrict__ tr, const float* __restrict__ hr,
+                                                 float bias_e, float bias_t, int d, float& s_out, float& t_out) {
+  const int KS = (d + 7) >> 3;
+  uintptr_t al = ((uintptr_t)er) | ((uintptr_t)hr);
+  if (tr) al |= (uintptr_t)tr;
+  if ((d & 7) != 0 || (al & 15) != 0) {
+    s_out = exact_chain(er, hr, bias_e, d);
+    if (tr) t_out = exact_chain(tr, hr, bias_t, d);
+    return;
+  }
+  constexpr int CB = 5;
+  float s = bias_e, t = bias_t;
+  const float4* e4 = (const float4*)er;
+  const float4* t4 = (const float4*)(tr ? tr : er);
+  const float4* h4 = (const float4*)hr;
+  for (int k0 = 0; k0 < KS; k0 += CB) {
+    float4 ev[CB][2], tv[CB][2], hv[CB][2];
+#pragma unroll
+    for (int u = 0; u < CB; ++u) {
+      const int k = k0 + u < KS ? k0 + u : KS - 1;
+      ev[u][0] = e4[2 * k]; ev[u][1] = e4[2 * k + 1];
+      hv[u][0] = h4[2 * k]; hv[u][1] = h4[2 * k + 1];
+      if (tr) { tv[u][0] = t4[2 * k]; tv[u][1] = t4[2 * k + 1]; }
+    }
+#pragma unroll
+    for (int u = 0; u < CB; ++u)
+      if (k0 + u < KS) {
+        s = __builtin_fmaf(ev[u][0].x, hv[u][0].x, s); s = __builtin_fmaf(ev[u][1].x, hv[u][1].x, s);
+        s = __builtin_fmaf(ev[u][0].y, hv[u][0].y, s); s = __builtin_fmaf(ev[u][1].y, hv[u][1].y, s);
+        s = __builtin_fmaf(ev[u][0].z, hv[u][0].z, s); s = __builtin_fmaf(ev[u][1].z, hv[u][1].z, s);
+        s = __builtin_fmaf(ev[u][0].w, hv[u][0].w, s); s = __builtin_fmaf(ev[u][1].w, hv[u][1].w, s);
+        if (tr) {
+          t = __builtin_fmaf(tv[u][0].x, hv[u][0].x, t); t = __builtin_fmaf(tv[u][1].x, hv[u][1].x, t);
+          t = __builtin_fmaf(tv[u][0].y, hv[u][0].y, t); t = __builtin_fmaf(tv[u][1].y, hv[u][1].y, t);
+          t = __builtin_fmaf(tv[u][0].z, hv[u][0].z, t); t = __builtin_fmaf(tv[u][1].z, hv[u][1].z, t);
+          t = __builtin_fmaf(tv[u][0].w, hv[u][0].w, t); t = __builtin_fmaf(tv[u][1].w, hv[u][1].w, t);
+        }
+      }
+  }
+  s_out = s;
+  if (tr) t_out = t;
 }
 
 }  // namespace coper

@@ -7,6 +7,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "split16.h"
+
 namespace coper {
 
 __device__ __forceinline__ void conv_fold_taps(const float* __restrict__ w, const float* __restrict__ b,
@@ -32,20 +34,6 @@ __device__ __forceinline__ void conv_x8(const float (&w)[9], const float (&tap)[
   }
 }
 
-__device__ __forceinline__ void split8_bf16(const float* v, uint4& hi, uint4& lo) {
-  // plain casts: hipcc emits v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN stays NaN)
-  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-  unsigned hw[4], lw[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    bf16x2_t hp = {(__bf16)v[2 * j], (__bf16)v[2 * j + 1]};
-    float r0 = v[2 * j] - (float)hp[0], r1 = v[2 * j + 1] - (float)hp[1];
-    bf16x2_t lp = {(__bf16)r0, (__bf16)r1};
-    hw[j] = __builtin_bit_cast(unsigned, hp);
-    lw[j] = __builtin_bit_cast(unsigned, lp);
-  }
-  hi = make_uint4(hw[0], hw[1], hw[2], hw[3]);
-  lo = make_uint4(lw[0], lw[1], lw[2], lw[3]);
-}
+__device__ __forceinline__ void split8_bf16(const float* v, uint4& hi, uint4& lo) { split8_s16(v, hi, lo); }   // (split16.h: fp16 since round 3)
 
 }  // namespace coper

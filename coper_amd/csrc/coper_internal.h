@@ -50,12 +50,17 @@ struct Dims {
   int64_t n_eblk = 0;  // 32-row entity blocks (padded to a multiple of EBLK_ALIGN)
 };
 
-// half-width of the exact band of the bf16x3 ranker, relative to |h_q| max|E_e| + max|bias| (per logit; a comparison of two
-// logits gets twice that): the largest error of the mode's logits against the fp32 chain measured over 3e8 logits of the
-// FB15k-237-shaped pass is 3.3e-6 |h_q||E_e| (rms 3.1e-7; tools/rank_decomp.py); the default keeps a factor 3 above the
-// worst case seen and ~30 sigma.  coper_config.rank_band_kappa overrides it (the proven worst case of the split and of
-// fp32 accumulation is 3 * 2^-16 + 2 (3 * 16 KS16 + 1) 2^-24 ~ 1.2e-4 at d = 200: about 35 band pairs per query instead of 4).
+// half-width of the exact band of the x3 ranker, relative to |h_q| max|E_e| + max|bias| (per logit; a comparison of two
+// logits gets twice that).  The largest error of the mode's logits against the fp32 chain measured over 3e8 logits of the
+// FB15k-237-shaped pass (tools/rank_decomp.py): fp16 split 1.8e-7 |h_q||E_e| (rms 1.2e-8) -- the fp32 chain itself is
+// 2.3e-7 from float64 --; bf16 split (COPER_SPLIT_BF16 builds) 3.3e-6 (rms 3.1e-7).  The defaults keep a factor 5 (3) above
+// the worst case seen, 80 (30) sigma.  coper_config.rank_band_kappa overrides them; the proven worst case of the split and
+// of fp32 accumulation in any order is 3 * 2^-22 (2^-16) + 2 (3 * 16 KS16 + 1) 2^-24 ~ 7.5e-5 (1.2e-4) at d = 200.
+#ifdef COPER_SPLIT_BF16
 constexpr float COPER_BAND_KAPPA_DEFAULT = 1e-5f;
+#else
+constexpr float COPER_BAND_KAPPA_DEFAULT = 1e-6f;
+#endif
 constexpr int COPER_TOPK_PRUNED_MAX = 128;   // largest k served by the block-maxima top-k (bf16x3); above: logits chunks
 constexpr int EBLK_ALIGN = 16;  // entity blocks consumed per workgroup iteration in score_count (8 waves x 2)
 

@@ -18,10 +18,9 @@
 namespace coper {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-#define MFMA16_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&(a), *(const bf16x8*)&(b), (c), 0, 0, 0)
+#define MFMA16_BF16(a, b, c) S16_MFMA16(a, b, c)
 #define MFMA16_X3(ahi, alo, bhi, blo, c) \
   { (c) = MFMA16_BF16(alo, bhi, c); (c) = MFMA16_BF16(ahi, blo, c); (c) = MFMA16_BF16(ahi, bhi, c); }
 

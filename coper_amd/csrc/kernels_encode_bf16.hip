@@ -18,33 +18,11 @@
 namespace coper {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ unsigned short bf16_rne_e(float x) {
-  unsigned u = __float_as_uint(x);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
-  return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
-}
-__device__ __forceinline__ float bf16_f32_e(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
+__device__ __forceinline__ void split8_e(const float* v, uint4& hi, uint4& lo) { split8_s16(v, hi, lo); }
 
-__device__ __forceinline__ void split8_e(const float* v, uint4& hi, uint4& lo) {
-  // plain casts: hipcc emits v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN stays NaN)
-  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-  unsigned hw[4], lw[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    bf16x2_t hp = {(__bf16)v[2 * j], (__bf16)v[2 * j + 1]};
-    float r0 = v[2 * j] - (float)hp[0], r1 = v[2 * j + 1] - (float)hp[1];
-    bf16x2_t lp = {(__bf16)r0, (__bf16)r1};
-    hw[j] = __builtin_bit_cast(unsigned, hp);
-    lw[j] = __builtin_bit_cast(unsigned, lp);
-  }
-  hi = make_uint4(hw[0], hw[1], hw[2], hw[3]);
-  lo = make_uint4(lw[0], lw[1], lw[2], lw[3]);
-}
-
-#define MFMA16_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&(a), *(const bf16x8*)&(b), (c), 0, 0, 0)
+#define MFMA16_BF16(a, b, c) S16_MFMA16(a, b, c)
 #define MFMA16_X3(ahi, alo, bhi, blo, c) \
   { (c) = MFMA16_BF16(alo, bhi, c); (c) = MFMA16_BF16(ahi, blo, c); (c) = MFMA16_BF16(ahi, bhi, c); }
 
@@ -188,9 +166,10 @@ __global__ __launch_bounds__(256) void k_conv3x3_bn_relu_bf16(
     if (concat_rel)
       for (int k = threadIdx.x; k < r; k += 256) {
         float v = rel_emb[rids[qq] * r + k];
-        unsigned short hb = bf16_rne_e(v);
+        unsigned short hb, lb;
+        split1_s16(v, hb, lb);
         xh[Fc + k] = hb;
-        xl[Fc + k] = bf16_rne_e(v - bf16_f32_e(hb));
+        xl[Fc + k] = lb;
       }
     for (int64_t k = F + threadIdx.x; k < F_pad; k += 256) { xh[k] = 0; xl[k] = 0; }
   }

@@ -33,7 +33,14 @@
 
 namespace coper {
 
+size_t score_count3_mask_words_bytes(const coper_handle* h, int64_t Bc);
+
 #define SC3_FENCE() __builtin_amdgcn_sched_barrier(0)
+#ifndef COPER_SC3_LD
+#define COPER_SC3_LD 2
+#endif
+constexpr int SC3_LD = COPER_SC3_LD;     // regions between an LDS read of query fragments and their use (ring of 4: 1..3)
+static_assert(SC3_LD >= 1 && SC3_LD <= 3, "ring of four register pairs");
 
 template <int NP, int TAIL, int PD, bool GM>
 struct SC3 {
@@ -51,6 +58,8 @@ struct SC3 {
   int cg[NB];
   unsigned mk[4];                                         // band bits: word 2 M + (V >> 5), value V at bit 31 - (V & 31)
   float mx;
+  const uint4* mask_base;                                 // (to find a row's summary word from its mask pointer)
+  unsigned long long* summ_base;
 };
 
 struct SC3Ptrs {
@@ -117,7 +126,14 @@ __device__ __forceinline__ void sc3_value(SC3<NP, TAIL, PD, GM>& S, const int la
   }
   if constexpr (M == 1 && V == 63) {     // the row's 128 band bits of this lane are complete
 #ifndef COPER_DBG_SC3_NO_BAND
-    if (store_ok) mask_row[lane] = make_uint4(S.mk[0], S.mk[1], S.mk[2], S.mk[3]);
+    // only words that carry a bit are written (about one in a hundred), and one 64-bit summary per row of the wave says
+    // which: k_band_exact reads 8 bytes per 8,192 logits instead of 1,024
+    const bool nz = (S.mk[0] | S.mk[1] | S.mk[2] | S.mk[3]) != 0u;
+    const unsigned long long which = __ballot(nz);
+    if (store_ok) {
+      if (nz) mask_row[lane] = make_uint4(S.mk[0], S.mk[1], S.mk[2], S.mk[3]);
+      if (lane == 0) S.summ_base[(mask_row - S.mask_base) >> 6] = which;
+    }
 #endif
   }
 }
@@ -169,9 +185,9 @@ __device__ __forceinline__ void sc3_region(SC3<NP, TAIL, PD, GM>& S, const SC3Pt
   constexpr int R = s * 8 + b;
 #ifndef COPER_DBG_SC3_SKIP_LDS
   {
-    constexpr int R2 = (R + 2) % NR, s2 = R2 / 8, b2 = R2 % 8;
-    S.q0[(R + 2) & 3] = X.hl[((b2 * NS + s2) * 2 + 0) * 64];
-    S.q1[(R + 2) & 3] = X.hl[((b2 * NS + s2) * 2 + 1) * 64];
+    constexpr int R2 = (R + SC3_LD) % NR, s2 = R2 / 8, b2 = R2 % 8;
+    S.q0[(R + SC3_LD) & 3] = X.hl[((b2 * NS + s2) * 2 + 0) * 64];
+    S.q1[(R + SC3_LD) & 3] = X.hl[((b2 * NS + s2) * 2 + 1) * 64];
   }
 #endif
   constexpr int rs = R & 3;
@@ -251,12 +267,14 @@ __device__ unsigned long long g_sc3_clk[2 * 1024];
 #endif
 
 // Ef3: the entities' f3 image; Hf3: the queries' (one 128-query tile = 8 column blocks = 16 NS KiB, copied to LDS as it lies);
-// tband[q] = {t_lo, t_hi}; mask: [tile][row][wave][lane] 16 bytes (band bits of the 64 entities x 128 queries of a wave's row)
+// tband[q] = {t_lo, t_hi}; mask: [tile][row][wave][lane] 16 bytes (band bits of the 64 entities x 128 queries of a wave's row),
+// written only where a bit is set; summ: [tile][row][wave] 8 bytes: the lanes whose mask word was written
 template <int NP, int TAIL, int PD, bool GM>
 __global__ __launch_bounds__(256, 1) void k_score_count3_bf16x3(const uint4* __restrict__ Ef3, const float* __restrict__ bias_pad,
                                                                  const uint4* __restrict__ Hf3, const float2* __restrict__ tband,
                                                                  int64_t B, int64_t rows_per_tile, int64_t total_rows,
                                                                  int32_t* __restrict__ ng, uint4* __restrict__ mask,
+                                                                 unsigned long long* __restrict__ summ,
                                                                  float* __restrict__ gmax, int64_t gm_stride) {
   typedef SC3<NP, TAIL, PD, GM> ST;
   constexpr int NS = ST::NS, NB = ST::NB, NV = ST::NV;
@@ -270,6 +288,8 @@ __global__ __launch_bounds__(256, 1) void k_score_count3_bf16x3(const uint4* __r
   const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
   ST S;
+  S.mask_base = mask;
+  S.summ_base = summ;
   int64_t cur_tile = -1;
   int64_t eb_prev = 0;
   bool prev_valid = false;
@@ -321,11 +341,12 @@ __global__ __launch_bounds__(256, 1) void k_score_count3_bf16x3(const uint4* __r
       for (int b = 0; b < NB; ++b) { S.acc[1][0][b] = f32x4(-INFINITY); S.acc[1][1][b] = f32x4(-INFINITY); }
       prev_valid = false;
       __syncthreads();
-      // query fragments of regions 0 and 1 (step 0, column blocks 0 and 1)
+      // query fragments of the first SC3_LD regions (step 0, column blocks 0 ..)
       S.q0[0] = hl3[((0 * NS + 0) * 2 + 0) * 64 + lane]; S.q1[0] = hl3[((0 * NS + 0) * 2 + 1) * 64 + lane];
-      S.q0[1] = hl3[((1 * NS + 0) * 2 + 0) * 64 + lane]; S.q1[1] = hl3[((1 * NS + 0) * 2 + 1) * 64 + lane];
+      if constexpr (SC3_LD >= 2) { S.q0[1] = hl3[((1 * NS + 0) * 2 + 0) * 64 + lane]; S.q1[1] = hl3[((1 * NS + 0) * 2 + 1) * 64 + lane]; }
+      if constexpr (SC3_LD >= 3) { S.q0[2] = hl3[((2 * NS + 0) * 2 + 0) * 64 + lane]; S.q1[2] = hl3[((2 * NS + 0) * 2 + 1) * 64 + lane]; }
 #if defined(COPER_DBG_SC3_SKIP_LDS) || defined(COPER_DBG_SC3_SKIP_GL)
-      S.q0[2] = S.q0[0]; S.q1[2] = S.q1[0]; S.q0[3] = S.q0[1]; S.q1[3] = S.q1[1];
+      S.q0[1] = S.q0[0]; S.q1[1] = S.q1[0]; S.q0[2] = S.q0[0]; S.q1[2] = S.q1[0]; S.q0[3] = S.q0[0]; S.q1[3] = S.q1[0];
       sc3_prologue_a1<NP, TAIL, PD, GM>(S, std::make_integer_sequence<int, PD>{});
 #endif
     }
@@ -470,7 +491,9 @@ __global__ void k_exact_targets(const float* __restrict__ ent, const float* __re
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   const int64_t row = e2[b] - lo;
-  out[b] = (row >= 0 && row < n_local) ? exact_chain(ent + row * d, hvec + b * d, bias[row], d) : 0.f;
+  float sx = 0.f, unused = 0.f;
+  if (row >= 0 && row < n_local) exact_chain_pair(ent + row * d, nullptr, hvec + b * d, bias[row], 0.f, d, sx, unused);
+  out[b] = sx;
 }
 
 int launch_exact_targets(coper_handle* h, const float* hvec, const int64_t* e2, int64_t B, float* out, hipStream_t s) {
@@ -480,91 +503,108 @@ int launch_exact_targets(coper_handle* h, const float* hvec, const int64_t* e2, 
   return COPER_OK;
 }
 
-// Walks the band mask of one count launch and decides every marked (query, entity) pair with the fp32 chain:
-//   known answers of the query and its target: nothing to add (the count kernel counted none of the band, the filter
-//     correction subtracted only what lies above t_hi);  otherwise  n_greater += (s > t),  n_equal += (s == t)
-// with s, t from exact_chain on the registered fp32 rows.  A workgroup takes a contiguous range of mask words; marked pairs are
-// compacted into an LDS list (a few per thousand words) and dealt to the threads; a list that overflows (heavy ties: every
-// logit of a row inside the band) is worked off in rounds.  tgt_x == NULL: the exact target is computed here from the
-// query's e2 row (unsharded handles); sharded: the all-reduced exact targets of coper_target_scores.
-constexpr int BE_CAP = 2048, BE_WPT = 4;
-__global__ __launch_bounds__(256) void k_band_exact(const uint4* __restrict__ mask, int64_t n_words, int64_t rows_per_tile, int64_t Bc,
-                                                    const float* __restrict__ hvec, int d, const float* __restrict__ ent,
-                                                    const float* __restrict__ bias, int64_t n_local, int64_t shard_lo,
-                                                    const int64_t* __restrict__ e2, const int64_t* __restrict__ indptr,
-                                                    const int64_t* __restrict__ idx, const float* __restrict__ tgt_x,
-                                                    int32_t* __restrict__ ng, int32_t* __restrict__ ne) {
-  __shared__ int s_q[BE_CAP], s_e[BE_CAP];
+// The exact decision of the band: k_band_exact walks the mask of one count launch (one bit per logit; with the fp16 split a
+// query has ~0.3 marked competitors besides its own target) and decides every marked (query, entity) pair with the fp32 chain:
+//       known answers of the query and its target: nothing to add (the count kernel counted none of the band, the filter
+//         correction subtracted only what lies above t_hi);  otherwise  n_greater += (s > t),  n_equal += (s == t)
+//       with s, t from exact_chain_pair on the registered fp32 rows.
+// A workgroup takes 4,096 consecutive mask words, all loads in flight at once; the marked pairs (a few dozen) are compacted
+// into an LDS list and dealt one per lane: a pair's walk is a handful of dependent round trips to L2 (ids and CSR bounds,
+// the row's known answers, the rows in batches of nine k-steps), so the launch takes the time of ONE walk as long as a
+// workgroup's pairs fit its lanes.  (Measured on the way here: 64-bit divisions to decode every word -- set or not -- cost
+// 20 of 34 us; the bf16 split needed a 16x wider band, 78,000 pairs per pass, 50 us of uncoalesced row reads.)  A list that
+// overflows -- heavy ties: every logit of a row inside the band -- is worked off in rounds.  tgt_x == NULL: the exact target
+// is computed with the pair from the query's e2 row (unsharded handles); sharded: the all-reduced exact targets of
+// coper_target_scores.
+struct BandArgs {
+  const float* hvec; const float* ent; const float* bias; const int64_t* e2; const int64_t* indptr; const int64_t* idx;
+  const float* tgt_x; int32_t* ng; int32_t* ne; int64_t Bc, n_local, shard_lo; int d; int dbg;
+};
+
+__device__ __forceinline__ void band_decide(const BandArgs& A, const int64_t q, const int64_t e) {
+  if (q >= A.Bc || e >= A.n_local || A.dbg == 1) return;
+  const int64_t eg = e + A.shard_lo, tq = A.e2[q];
+  const int64_t lo0 = A.indptr[q], hi0 = A.indptr[q + 1];
+  if (eg == tq) return;                              // the target itself (metrics.py:46)
+  // known answer?  (ids sorted ascending inside a row)  Short rows -- nearly all -- in one round trip
+  bool known = false;
+  if (hi0 - lo0 <= 8) {
+    int64_t f[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) f[u] = lo0 + u < hi0 ? A.idx[lo0 + u] : -1;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) known |= f[u] == eg;
+  } else {
+    int64_t lo_i = lo0, hi_i = hi0;
+    while (lo_i < hi_i) {
+      const int64_t mid = (lo_i + hi_i) >> 1;
+      const int64_t f = A.idx[mid];
+      if (f == eg) { known = true; break; }
+      if (f < eg) lo_i = mid + 1; else hi_i = mid;
+    }
+  }
+  if (known || A.dbg == 2) return;
+  const float* hr = A.hvec + q * A.d;
+  float sx, tx = 0.f;
+  if (A.tgt_x) {
+    tx = A.tgt_x[q];
+    exact_chain_pair(A.ent + e * A.d, nullptr, hr, A.bias[e], 0.f, A.d, sx, tx);
+  } else {
+    const int64_t trow = tq - A.shard_lo;
+    if (trow >= 0 && trow < A.n_local) exact_chain_pair(A.ent + e * A.d, A.ent + trow * A.d, hr, A.bias[e], A.bias[trow], A.d, sx, tx);
+    else exact_chain_pair(A.ent + e * A.d, nullptr, hr, A.bias[e], 0.f, A.d, sx, tx);
+  }
+  if (sx > tx) atomicAdd(&A.ng[q], 1);
+  else if (A.ne && sx == tx) atomicAdd(&A.ne[q], 1);
+}
+
+constexpr int BE_CAP = 4096;
+__global__ __launch_bounds__(256) void k_band_exact(const uint4* __restrict__ mask, const unsigned long long* __restrict__ summ, int64_t n_units,
+                                                    unsigned rows4 /* rows per tile x 4 waves */, BandArgs A) {
+  __shared__ unsigned long long s_p[BE_CAP];
   __shared__ int s_n;
-  const int64_t w_begin = n_words * blockIdx.x / gridDim.x, w_end = n_words * (blockIdx.x + 1) / gridDim.x;
-  for (int64_t base = w_begin; base < w_end; base += 256 * BE_WPT) {
-    uint4 w[BE_WPT];
-    bool any = false;
+  // a thread per unit (one wave's row of 64 entities x 128 queries): its summary, then the mask words the summary names
+  const int64_t unit = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  unsigned long long lanes = unit < n_units ? summ[unit] : 0ull;
+  unsigned tile = 0, eb = 0;
+  if (lanes) {
+    tile = (unsigned)unit / rows4;
+    eb = ((unsigned)unit - tile * rows4) * 2;       // (row * 4 + wave) * 2: the wave's first 32-entity block
+  }
+  uint4 w = make_uint4(0u, 0u, 0u, 0u);
+  int l = 0;
+  while (true) {      // rounds: a list that fills up (heavy ties) is worked off and the walk goes on where it stopped
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    bool left = false;
+    while (!left) {
+      if (!(w.x | w.y | w.z | w.w)) {
+        if (!lanes) break;
+        l = __builtin_ctzll(lanes);
+        lanes &= lanes - 1;
+        w = mask[unit * 64 + l];
+      }
+      unsigned* wc = (unsigned*)&w;
 #pragma unroll
-    for (int u = 0; u < BE_WPT; ++u) {
-      const int64_t wi = base + u * 256 + threadIdx.x;
-      w[u] = wi < w_end ? mask[wi] : make_uint4(0u, 0u, 0u, 0u);
-      any |= (w[u].x | w[u].y | w[u].z | w[u].w) != 0u;
-    }
-    if (!__syncthreads_or(any)) continue;
-    bool more = true;
-    while (more) {
-      if (threadIdx.x == 0) s_n = 0;
-      __syncthreads();
-      bool left = false;
-#pragma unroll
-      for (int u = 0; u < BE_WPT; ++u) {
-        const int64_t wi = base + u * 256 + threadIdx.x;
-        const int64_t unit = wi >> 6;
-        const int l = (int)(wi & 63);
-        const int64_t tile = unit / (rows_per_tile * 4);
-        const int64_t rem = unit % (rows_per_tile * 4);
-        const int64_t eb = ((rem >> 2) * 4 + (rem & 3)) * 2;
-        unsigned* wc = (unsigned*)&w[u];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          while (wc[c]) {
-            const int p = 31 - __builtin_clz(wc[c]);     // highest set bit first = lowest value index first
-            const int slot = atomicAdd(&s_n, 1);
-            if (slot >= BE_CAP) { left = true; break; }
-            wc[c] &= ~(1u << p);
-            const int V = 32 * (c & 1) + (31 - p);
-            const int b = V >> 3, m2 = (V >> 2) & 1, j = V & 3;
-            s_e[slot] = (int)((eb + (c >> 1)) * 32 + 16 * m2 + 4 * (l >> 4) + j);
-            s_q[slot] = (int)(tile * 128 + 16 * b + (l & 15));
-          }
+      for (int c = 0; c < 4; ++c) {
+        while (wc[c] && !left) {
+          const int p = 31 - __builtin_clz(wc[c]);     // highest set bit first = lowest value index first
+          const int slot = atomicAdd(&s_n, 1);
+          if (slot >= BE_CAP) { left = true; break; }
+          wc[c] &= ~(1u << p);
+          const int V = 32 * (c & 1) + (31 - p);
+          const int b = V >> 3, m2 = (V >> 2) & 1, j = V & 3;
+          const unsigned long long e = (unsigned long long)(eb + (c >> 1)) * 32 + 16 * m2 + 4 * (l >> 4) + j;
+          const unsigned long long q = (unsigned long long)tile * 128 + 16 * b + (l & 15);
+          s_p[slot] = (q << 32) | e;
         }
       }
-      __syncthreads();
-      const int n = s_n < BE_CAP ? s_n : BE_CAP;
-      for (int p = threadIdx.x; p < n; p += 256) {
-        const int64_t q = s_q[p], e = s_e[p];
-        if (q >= Bc || e >= n_local) continue;
-        const int64_t eg = e + shard_lo, tq = e2[q];
-        if (eg == tq) continue;                          // the target itself (metrics.py:46)
-        int64_t lo_i = indptr[q], hi_i = indptr[q + 1];  // known answer?  (ids sorted ascending inside a row)
-        bool known = false;
-        while (lo_i < hi_i) {
-          const int64_t mid = (lo_i + hi_i) >> 1;
-          const int64_t f = idx[mid];
-          if (f == eg) { known = true; break; }
-          if (f < eg) lo_i = mid + 1; else hi_i = mid;
-        }
-        if (known) continue;
-        const float* hr = hvec + q * d;
-        const float sx = exact_chain(ent + e * d, hr, bias[e], d);
-        float tx;
-        if (tgt_x) {
-          tx = tgt_x[q];
-        } else {
-          const int64_t trow = tq - shard_lo;
-          tx = (trow >= 0 && trow < n_local) ? exact_chain(ent + trow * d, hr, bias[trow], d) : 0.f;
-        }
-        if (sx > tx) atomicAdd(&ng[q], 1);
-        else if (ne && sx == tx) atomicAdd(&ne[q], 1);
-      }
-      more = __syncthreads_or(left);
     }
+    const int full = __syncthreads_or(left ? 1 : 0);
+    const int n = s_n < BE_CAP ? s_n : BE_CAP;
+    for (int p = threadIdx.x; p < n; p += 256) band_decide(A, (int64_t)(s_p[p] >> 32), (int64_t)(s_p[p] & 0xFFFFFFFFull));
+    if (!full) break;
+    __syncthreads();
   }
 }
 
@@ -594,7 +634,8 @@ static int sc3_go(coper_handle* h, int64_t q0, int64_t Bc, int32_t* ng, float* g
     attr_done[dev] = true;
   }
   hipLaunchKernelGGL((k_score_count3_bf16x3<NP, TAIL, PD, GM>), dim3((unsigned)grid), dim3(256), lds, s, (const uint4*)h->Ef3, h->bias_pad, hf3,
-                     (const float2*)h->tband_ws + q0, Bc, rows_per_tile, total_rows, ng + q0, (uint4*)h->mask_ws, gmax, gm_stride);
+                     (const float2*)h->tband_ws + q0, Bc, rows_per_tile, total_rows, ng + q0, (uint4*)h->mask_ws,
+                     (unsigned long long*)((char*)h->mask_ws + score_count3_mask_words_bytes(h, Bc)), gmax, gm_stride);
   COPER_HIP_TRY(h, hipGetLastError());
   return COPER_OK;
 }
@@ -604,9 +645,13 @@ static int sc3_gm(coper_handle* h, int64_t q0, int64_t Bc, int32_t* ng, float* g
   return gmax ? sc3_go<NP, TAIL, true>(h, q0, Bc, ng, gmax, gm_stride, s) : sc3_go<NP, TAIL, false>(h, q0, Bc, ng, gmax, gm_stride, s);
 }
 
-// bytes of the band mask of a count launch over Bc queries
-size_t score_count3_mask_bytes(const coper_handle* h, int64_t Bc) {
+// bytes of the band mask of a count launch over Bc queries: the words (16 bytes per lane and row of a wave), then the
+// summaries (8 bytes per row of a wave)
+size_t score_count3_mask_words_bytes(const coper_handle* h, int64_t Bc) {
   return (size_t)((Bc + 127) / 128) * (size_t)(h->dm.n_eblk / 8) * 4 * 64 * sizeof(uint4);
+}
+size_t score_count3_mask_bytes(const coper_handle* h, int64_t Bc) {
+  return score_count3_mask_words_bytes(h, Bc) + (size_t)((Bc + 127) / 128) * (size_t)(h->dm.n_eblk / 8) * 4 * sizeof(unsigned long long);
 }
 
 // Count launch over queries [q0, q0 + Bc) (q0 a multiple of 128) of the packed batch + the exact decision of its band.
@@ -633,11 +678,16 @@ int score_count3_chunk_bf16x3(coper_handle* h, int64_t q0, int64_t Bc, const flo
     ScopedKernelTimer t(h, "band_exact", s);
     const int64_t rows_per_tile = h->dm.n_eblk / 8;
     const int64_t n_words = ((Bc + 127) / 128) * rows_per_tile * 4 * 64;
-    int64_t grid = (n_words + 256 * BE_WPT - 1) / (256 * BE_WPT);
-    if (grid > 4 * (int64_t)h->num_cus) grid = 4 * (int64_t)h->num_cus;
-    hipLaunchKernelGGL(k_band_exact, dim3((unsigned)grid), dim3(256), 0, s, (const uint4*)h->mask_ws, n_words, rows_per_tile, Bc,
-                       hvec + q0 * h->dm.d, h->dm.d, h->params["ent_emb"].ptr, h->params["pred_bias"].ptr, h->dm.n_local,
-                       (int64_t)h->cfg.shard_lo, e2 + q0, indptr + q0, idx, tgt_x ? tgt_x + q0 : nullptr, ng + q0, ne ? ne + q0 : nullptr);
+    BandArgs A;
+    A.hvec = hvec + q0 * h->dm.d; A.ent = h->params["ent_emb"].ptr; A.bias = h->params["pred_bias"].ptr;
+    A.e2 = e2 + q0; A.indptr = indptr + q0; A.idx = idx; A.tgt_x = tgt_x ? tgt_x + q0 : nullptr;
+    A.ng = ng + q0; A.ne = ne ? ne + q0 : nullptr; A.Bc = Bc; A.n_local = h->dm.n_local; A.shard_lo = (int64_t)h->cfg.shard_lo; A.d = h->dm.d;
+    { static const int dbg = getenv("COPER_DBG_BAND") ? atoi(getenv("COPER_DBG_BAND")) : 0; A.dbg = dbg; }
+    const int64_t n_units = n_words / 64;
+    if (rows_per_tile * 4 > 0x7fffffffLL || n_units > 0x7fffffffLL) return fail(h, COPER_EUNSUPPORTED, "band mask beyond 2^31 units");
+    hipLaunchKernelGGL(k_band_exact, dim3((unsigned)((n_units + 255) / 256)), dim3(256), 0, s, (const uint4*)h->mask_ws,
+                       (const unsigned long long*)((const char*)h->mask_ws + score_count3_mask_words_bytes(h, Bc)), n_units,
+                       (unsigned)(rows_per_tile * 4), A);
     COPER_HIP_TRY(h, hipGetLastError());
   }
   COPER_DBG_SYNC(h, s, "band_exact");
