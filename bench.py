@@ -13,10 +13,14 @@ synthetic queries: the evaluation set of the workload (Q queries; BASELINE.md se
 The JSON line (rank 0, stdout) carries, for the default workload (BASELINE.json configs[1], FB15k-237-shaped
 CoPER-ConvE, bf16x3 arithmetic; query-sharded across ranks = weak scaling):
 
-  value / ms_per_step     K passes with ids + CSR filters resident in HBM, barrier + synchronize on both sides,
-                          MAX over ranks (the driver contract); `timing` adds median / min per pass (HIP events)
-  pcie_inclusive          the SURVEY 8(d) region: H2D of ids / CSR + pass + D2H of ranks, median / min per pass
-  config.f32_exact        the same pass in the fp32-exact mode, and how far the bf16x3 ranks are from its ranks
+  value / ms_per_step     the SURVEY 8(d) region: K passes, each H2D of ids + CSR filters from pinned host buffers + pass + D2H
+                          of the int32 ranks to pinned host memory, barrier + synchronize on both sides, MAX over ranks (the
+                          driver contract)
+  resident_inputs         the same K passes with ids + CSR filters resident in HBM (round 2's headline); `timing` adds
+                          median / min per pass (HIP events)
+  config.f32_exact        the same pass in the fp32-exact mode; `rank_agreement`: the headline mode's ranks against the fp32
+                          chain's on the SAME h (equal for every query: the exact band), against the fp32-exact mode end to
+                          end, and against float64 arithmetic throughout (what the two encoders' rounding of h leaves)
   roofline                the dominant kernel against its roof (HIP events on the launch stream), other kernels
                           under all_kernels -- among them the score kernel in its HBM-bound regime
                           (`k_score_count_bf16x3@hbm`: 128 queries against this rank's shard of the 10M x 256 table)
@@ -45,12 +49,13 @@ if ROOT not in sys.path:
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: Peak FP32 (matrix)
 PEAK_HBM_GBS = 8000.0
-PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA; the bf16x3 mode spends 3 hardware MFMAs per algorithmic product
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 / fp16 MFMA (same rate); the x3 mode spends 3 hardware MFMAs per algorithmic product
 
 SCALE_WORKLOAD, SCALE_TOPK, HBM_REGIME_QUERIES = "synth10m_cpg", 10, 128
-# Ranks of the `scale` pass on ONE GPU holding all 10M entities (seed 0, Q = 4096, bf16x3), measured on MI355X: every
+# Ranks of the `scale` pass on ONE GPU holding all 10M entities (seed 0, Q = 4096, x3 mode with the fp16 split and the exact
+# band: round 3), measured on MI355X: every
 # entity sharding of the same table must reproduce them bit for bit (integer counts summed across shards).
-SCALE_EXPECTED = {"ranks_sha1": "046ac4218504f24ad31fe32c9fd8230332f1b1ee", "mean_rank": 4908458.672607422}
+SCALE_EXPECTED = {"ranks_sha1": "3436dfac069c6cf69e537cdb56cf0c54c32b44df", "mean_rank": 4908459.040283203}
 
 
 def _profile_entry(pattern, workload, Q, kernel, exact=None):
@@ -211,10 +216,8 @@ def event_times(ctx, step, steps):
 
 
 def score_kernel_name(mode, d):
-    """The count kernel that serves this shape: the software-pipelined form is instantiated for 13 and 16 k-steps of 16."""
-    if mode == "f32":
-        return "k_score_count_f32"
-    return "k_score_count2_bf16x3" if (d + 15) // 16 in (13, 16) else "k_score_count_bf16x3"
+    """The count kernel that serves this shape (kernels_score3_bf16.hip serves every d <= 320)."""
+    return "k_score_count_f32" if mode == "f32" else "k_score_count3_bf16x3"
 
 
 def score_roofline(ctx, kname, mode, Q, n_local, d, t_ms, workload, want_pmc=True, exact=None):
@@ -233,7 +236,7 @@ def score_roofline(ctx, kname, mode, Q, n_local, d, t_ms, workload, want_pmc=Tru
         e = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
              "avg_launch_ms": t_ms, "algorithmic_flops": fl, "algorithmic_gbs": by / (t_ms * 1e-3) / 1e9}
         if mode != "f32":
-            e["note"] = "3 hardware bf16 MFMAs per algorithmic product: hardware MFMA utilisation = 3 x frac"
+            e["note"] = "3 hardware 16-bit MFMA products per algorithmic product: hardware MFMA utilisation = 3 x frac"
     e["shape"] = "Q=%d x n=%d x d=%d" % (Q, n_local, d)
     if ctx.world == 1 and want_pmc:
         pmc_traffic(e, workload, Q, "coper::" + kname, exact)
@@ -283,7 +286,7 @@ def run_scale_blocks(ctx, args):
     model.profile(False)
     if n:
         out["hbm_regime"] = score_roofline(ctx, score_kernel_name("bf16x3", d), "bf16x3", HBM_REGIME_QUERIES, model.n_local, d, ms / n,
-                                           SCALE_WORKLOAD, exact="coper::k_score_count2_bf16x3<16, 6, true, false>")
+                                           SCALE_WORKLOAD, exact="coper::k_score_count3_bf16x3<8, 0, 3, false>")
         out["hbm_regime"]["kernel"] = score_kernel_name("bf16x3", d)
     # (2) the entity-sharded pass, top-10 exchanged
     Q = cdata.CONFIGS[SCALE_WORKLOAD]["queries"]
@@ -310,7 +313,7 @@ def run_scale_blocks(ctx, args):
     if n:
         kn = score_kernel_name("bf16x3", d)
         blk["roofline"] = dict(kernel=kn, **score_roofline(ctx, kn, "bf16x3", Q, model.n_local, d, ms / n, SCALE_WORKLOAD,
-                                                           want_pmc=ctx.world == 1, exact="coper::k_score_count2_bf16x3<16, 6, true, true>"))
+                                                           want_pmc=ctx.world == 1, exact="coper::k_score_count3_bf16x3<8, 0, 3, true>"))
     exp = SCALE_EXPECTED
     if exp.get("ranks_sha1"):
         # checked by main() AFTER the JSON line is out (every rank must first get through the collectives that follow; the line
@@ -450,45 +453,54 @@ def main():
         return model.rank_pass(dev_q["e1"], dev_q["rel"], dev_q["e2"], dev_q["filt_indptr"], dev_q["filt_idx"], filt_nnz=nnz,
                                want_equal=False)
 
-    def profiled_step(i):
-        model.profile(i % max(1, args.profile_every) == 0)     # per-kernel HIP events on a sample of the timed steps
-        return step()
+    KERNELS = ("score_count", "dense", "conv", "tail", "band_exact", "group")
+    n_passes = [0]            # passes issued before the contract's timed region (reported: the device is warmer than W says)
 
+    def counted(f):
+        def g(i=0):
+            n_passes[0] += 1
+            return f(i)
+        return g
+
+    step = counted(step)
     for _ in range(args.warmup):
         step()
     model.profile(True)
     step()                                   # one instrumented untimed pass: fills the library's pool of HIP events
     torch.cuda.synchronize(device)
-    for k in ("score_count", "dense", "conv"):
+    for k in KERNELS:
         model.profile_read(k)
     model.profile(False)
     extras = not args.no_extras
     ranks_np = step()[0].cpu().numpy()
 
-    # per-pass medians (resident inputs), then the SURVEY 8(d) region: H2D ids / CSR + pass + D2H ranks
-    per_pass = event_times(ctx, step, args.steps) if extras else None
-    pcie = None
-    if extras and not entity_mode:
+    # The SURVEY 8(d) region (the headline in query mode): ids + CSR filters start in pinned host memory, the ranks end in
+    # pinned host memory; copies and kernels of a pass are stream-ordered, passes follow each other on the stream.
+    pcie_step = None
+    if not entity_mode:
         pin = {k: torch.as_tensor(v).pin_memory() for k, v in q.items()}
+        stage = {k: torch.empty_like(v, device=device) for k, v in pin.items()}
         out_host = torch.empty(Q, dtype=torch.int32).pin_memory()
+        pcie_bytes = sum(v.numel() * v.element_size() for v in pin.values()) + out_host.numel() * 4
 
-        def pcie_step():
-            t0 = time.perf_counter()
-            dq = {k: v.to(device, non_blocking=True) for k, v in pin.items()}
-            r, _ = model.rank_pass(dq["e1"], dq["rel"], dq["e2"], dq["filt_indptr"], dq["filt_idx"], filt_nnz=nnz, want_equal=False)
+        def pcie_step(i=0):
+            for k, v in pin.items():
+                stage[k].copy_(v, non_blocking=True)
+            r, _ = model.rank_pass(stage["e1"], stage["rel"], stage["e2"], stage["filt_indptr"], stage["filt_idx"], filt_nnz=nnz,
+                                   want_equal=False)
             out_host.copy_(r, non_blocking=True)
-            torch.cuda.synchronize(device)
-            return (time.perf_counter() - t0) * 1e3
+            return r, None
 
+        pcie_step = counted(pcie_step)
         for _ in range(max(1, args.warmup)):
             pcie_step()
-        ts = [pcie_step() for _ in range(args.steps)]
+        torch.cuda.synchronize(device)
         assert np.array_equal(out_host.numpy(), ranks_np)
-        pcie = {"ms_per_step_median": statistics.median(ts), "ms_per_step_min": min(ts), "value_median": Q * world / (statistics.median(ts) * 1e-3),
-                "unit": "triples/s", "region": "H2D of e1/rel/e2 ids + CSR filter (pinned host buffers, %d bytes) + pass + D2H of int32 "
-                                               "ranks + synchronize, host clock, per rank" % sum(v.numel() * v.element_size() for v in pin.values())}
 
-    # the fp32-exact mode on the same queries: its throughput, and how far the headline mode's ranks are from its ranks
+    # per-pass medians with resident inputs (HIP events, no host synchronisation between passes)
+    per_pass = event_times(ctx, step, args.steps) if extras else None
+
+    # the fp32-exact mode on the same queries: its throughput, and where the headline mode's ranks stand against it
     f32_info = None
     if extras and not entity_mode and args.score_mode == "bf16x3" and not big:
         m32 = ConvE(md, device=device, score_mode="f32").load_parameters(params).prepare()
@@ -501,25 +513,61 @@ def main():
             step32()
         dt32, res32 = timed_passes(ctx, step32, args.steps)
         r32 = res32[0].cpu().numpy()
-        diff = np.abs(ranks_np.astype(np.int64) - r32.astype(np.int64))
+        # (1) the fp32 chain's ranker fed the headline mode's own h: the exact band makes these equal for every query
+        _, _, hA = model.rank_pass(dev_q["e1"], dev_q["rel"], dev_q["e2"], dev_q["filt_indptr"], dev_q["filt_idx"], filt_nnz=nnz,
+                                   want_equal=False, want_h=True)
+        r_same = m32.rank(hA, dev_q["e2"], dev_q["filt_indptr"], dev_q["filt_idx"], filt_nnz=nnz, want_equal=False)[0].cpu().numpy()
+        # (3) float64 scoring of the same h (torch on the device): what the fp32 chain's own rounding moves
+        E64 = model._tensors["ent_emb"].double()
+        lg = torch.addmm(model._tensors["pred_bias"].double(), hA.double(), E64.t())
+        rows = torch.arange(Q, device=device)
+        t64 = lg[rows, dev_q["e2"]].clone()
+        row_of = torch.repeat_interleave(rows, dev_q["filt_indptr"][1:] - dev_q["filt_indptr"][:-1])
+        lg[row_of, dev_q["filt_idx"]] = -float("inf")
+        lg[rows, dev_q["e2"]] = -float("inf")
+        r64 = (1 + (lg > t64[:, None]).sum(1)).cpu().numpy()
+        del lg, E64
+
+        def agree(a, b):
+            d = np.abs(a.astype(np.int64) - b.astype(np.int64))
+            return {"fraction_equal": float(np.mean(d == 0)), "max_abs_diff": int(d.max()), "queries": int(len(d))}
+
         f32_info = {"value": Q * world * args.steps / dt32, "unit": "triples/s", "ms_per_step": dt32 / args.steps * 1e3,
                     "mean_rank": float(np.mean(r32)), "mrr": float(np.mean(1.0 / r32)),
-                    "rank_agreement_vs_f32": {"fraction_equal": float(np.mean(diff == 0)), "max_abs_diff": int(diff.max()),
-                                              "queries": int(len(diff)),
-                                              "note": "ranks are bit-exact inside a mode; across modes a logit gap below the "
-                                                      "bf16x3 error (~2e-4, gate 1e-3) can move a rank by the entities inside it"}}
+                    "rank_agreement_vs_f32": dict(agree(ranks_np, r_same), note="fp32-chain ranker (COPER_SCORE_F32) fed the headline "
+                                                  "mode's own h: comparisons closer than the mode's error are decided by that chain"),
+                    "rank_agreement_vs_f32_end_to_end": dict(agree(ranks_np, r32), note="against the fp32-exact mode with its own "
+                                                             "encoder: what remains is the two encoders' rounding of h"),
+                    "rank_agreement_vs_float64_scoring_of_same_h": agree(ranks_np, r64)}
         m32.close()
         del m32
 
-    # The driver contract's timed region comes after the secondary measurements above, not before them: the device takes
+    # The driver contract's timed regions come after the secondary measurements above, not before them: the device takes
     # tens of milliseconds of load to leave its idle power state (measured: 0.588 ms per pass over the first 20 passes
-    # after setup, 0.549 over 100, 0.532 over 400), and W = 3-5 warm-up passes are 2-3 ms.  Nothing is carried over but the
-    # clocks: barrier + synchronize on both sides, EXACTLY K passes, MAX over ranks.
+    # after setup, 0.549 over 100, 0.532 over 400), and W = 3-5 warm-up passes are 2-3 ms; `pre_timed_passes` says how many
+    # passes ran before.  Nothing is carried over but the clocks: barrier + synchronize on both sides, EXACTLY K passes,
+    # MAX over ranks.
+    pre_timed = n_passes[0]
+    resident = None
+    if pcie_step is not None:
+        dt_res, _ = timed_passes(ctx, step, args.steps)
+        resident = {"value": Q * world * args.steps / dt_res, "unit": "triples/s", "ms_per_step": dt_res / args.steps * 1e3,
+                    "inputs": "ids + CSR filters resident in HBM before the timed region, ranks left in HBM (round 2's headline)"}
+        if per_pass:
+            resident["timing"] = {"ms_per_step_median": statistics.median(per_pass), "ms_per_step_min": min(per_pass),
+                                  "how": "HIP events on the launch stream around each of %d further passes" % len(per_pass)}
+
+    def profiled_step(i):
+        model.profile(i % max(1, args.profile_every) == 0)     # per-kernel HIP events on a sample of the timed steps
+        return (pcie_step or step)()
+
     dt, res = timed_passes(ctx, profiled_step, args.steps)
     model.profile(False)
+    if pcie_step is not None:
+        assert np.array_equal(out_host.numpy(), ranks_np)
     assert np.array_equal(res[0].cpu().numpy(), ranks_np)
     kern = {}
-    for k in ("score_count", "dense", "conv"):
+    for k in KERNELS:
         ms, n = model.profile_read(k)
         kern[k] = (ms / n) if n else None
 
@@ -539,7 +587,8 @@ def main():
             "metric": "scored triples/sec (1-vs-all)", "value": units / dt, "unit": "triples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if entity_mode else "weak", "vs_baseline": None,
-            "dtype": "f32" if args.score_mode == "f32" else "bf16x3 (fp32 values split into two bf16 terms, 3 bf16 MFMAs per product, fp32 accumulate)",
+            "dtype": "f32" if args.score_mode == "f32" else "fp16x3 (fp32 values split into two fp16 terms, 3 fp16 MFMAs per product, fp32 accumulate; "
+                     "comparisons closer than the split's error decided by the fp32 chain)",
             "data": "synthetic",
             "config": {"workload": "%s: |E|=%d R2=%d d=%d r=%d, Q=%d queries/pass%s, %s relation order" % (
                 args.workload, md["num_ent"], md["num_rel"], d, md["rel_emb_size"], Q,
@@ -547,15 +596,16 @@ def main():
                 "parallelism": ("entity-sharded x%d%s" % (world, ", top-%d exchanged" % args.topk if args.topk else ""))
                 if entity_mode else ("query-sharded x%d" % world),
                 "score_mode": "f32 (v_mfma_f32_32x32x2_f32, exact)" if args.score_mode == "f32" else
-                "bf16x3 (3 x v_mfma_f32_32x32x16_bf16 per product, ~2^-16 rel.)", "prepare_ms": round(prepare_ms, 2),
-                "inputs": "ids + CSR filters resident in HBM before the timed region (pcie_inclusive: host buffers in, host ranks out)",
+                "bf16x3 = the x3 mode (API name kept): fp16 split since round 3, 3 x v_mfma_f32_16x16x32_f16 (two K = 16 steps each) per "
+                "pair of products, ~2^-22 rel.; exact band decided by the fp32 chain", "prepare_ms": round(prepare_ms, 2),
+                "inputs": ("SURVEY 8(d) region: every pass copies ids + CSR filters from pinned host memory (H2D) and its int32 ranks "
+                           "back to pinned host memory (D2H), %d bytes per pass, inside the timed region" % pcie_bytes) if pcie_step is not None
+                else "ids + CSR filters resident in HBM before the timed region",
+                "pre_timed_passes": pre_timed,
                 "mean_rank": float(np.mean(ranks_np)), "mrr": float(np.mean(1.0 / ranks_np))},
         }
-        if per_pass:
-            out["timing"] = {"ms_per_step_median": statistics.median(per_pass), "ms_per_step_min": min(per_pass),
-                             "how": "HIP events on the launch stream around each of %d further passes, resident inputs" % len(per_pass)}
-        if pcie:
-            out["pcie_inclusive"] = pcie
+        if resident:
+            out["resident_inputs"] = resident
         if f32_info:
             out["config"]["f32_exact"] = f32_info
         cnt = np.bincount(q["rel"])
@@ -600,6 +650,7 @@ def main():
             out["roofline"] = dict(kernel=dom, **kinfo[dom])
             out["roofline"]["all_kernels"] = {k: {kk: vv for kk, vv in v.items() if kk != "note"} for k, v in kinfo.items() if k != dom}
             out["roofline"]["tail_frac"] = 1.0 - sum(v["avg_launch_ms"] for v in kinfo.values()) / (dt / args.steps * 1e3)
+            out["roofline"]["other_launches_ms"] = {k: kern[k] for k in ("group", "tail", "band_exact") if kern.get(k)}
         if scale:
             if "hbm_regime" in scale and "roofline" in out:
                 out["roofline"]["all_kernels"]["%s@hbm" % scale["hbm_regime"].get("kernel", "k_score_count_bf16x3")] = scale["hbm_regime"]
