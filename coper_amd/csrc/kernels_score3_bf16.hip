@@ -42,183 +42,205 @@ size_t score_count3_mask_words_bytes(const coper_handle* h, int64_t Bc);
 constexpr int SC3_LD = COPER_SC3_LD;     // regions between an LDS read of query fragments and their use (ring of 4: 1..3)
 static_assert(SC3_LD >= 1 && SC3_LD <= 3, "ring of four register pairs");
 
+#ifndef COPER_SC3_MB
+#define COPER_SC3_MB 4
+#endif
+// 16-row blocks per entity block of a wave.  A pair of query fragments read from LDS feeds 3 MB instructions: with MB = 2
+// (32-entity blocks, the first form of this kernel: 0.30 ms) the wave was bound by the ISSUE of its ds_read_b128 -- an
+// ablation that re-used every fragment pair for two regions ran in 0.23 ms -- so MB = 4: 64-entity blocks, both accumulator
+// sets fill the 256 AGPRs.
+constexpr int SC3_MB = COPER_SC3_MB;
+static_assert(SC3_MB == 2 || SC3_MB == 4, "mask words are written as whole 16-byte pieces");
+
 template <int NP, int TAIL, int PD, bool GM>
 struct SC3 {
+  static constexpr int MB = SC3_MB;
   static constexpr int NS = NP + TAIL;                    // steps per half-row
   static constexpr int NB = 8;                            // 16-query column blocks of the tile
   static constexpr int NR = NS * NB;                      // regions per half-row
-  static constexpr int NV = 64;                           // accumulator values per lane per half-row: 2 row blocks x 8 x 4
+  static constexpr int NV = 32 * MB;                      // accumulator values per lane per half-row: MB row blocks x 8 x 4
   static constexpr int CH = (NV + NS - 1) / NS;           // epilogue values handled per step
   static constexpr int G = (NS + PD - 1) / PD;            // prefetch groups per half-row
-  f32x4 acc[2][2][NB];                                    // [entity block M][16-row block m2][column block b]
-  uint4 a0[2][PD][2], a1[2][PD][2];                       // entity fragments: two sets of PD steps, [m2]; reg 0 / reg 1 of the step
+  f32x4 acc[2][MB][NB];                                   // [entity block M][16-row block m2][column block b]
+  uint4 a0[2][PD][MB], a1[2][PD][MB];                     // entity fragments: two sets of PD steps, [m2]; reg 0 / reg 1 of the step
   uint4 q0[4], q1[4];                                     // query fragments of four consecutive regions (ring)
-  f32x4 biasv[2][2];                                      // [M][m2]
+  f32x4 biasv[2][MB];                                     // [M][m2]
   float thi[NB], tlo[NB];
   int cg[NB];
-  unsigned mk[4];                                         // band bits: word 2 M + (V >> 5), value V at bit 31 - (V & 31)
+  unsigned mk[2 * MB], mg[2 * MB];                        // (logit >= t_lo) / (logit > t_hi): word MB M + (V >> 5), value V at bit 31 - (V & 31)
   float mx;
   const uint4* mask_base;                                 // (to find a row's summary word from its mask pointer)
   unsigned long long* summ_base;
+  int64_t gm_stride;
 };
 
 struct SC3Ptrs {
-  const uint4* a[2];     // f3 register (16-row block 0 of entity block M, step 0, reg 0) of this row, lane included
-  const uint4* n;        // ... of the next row's block 0
+  const uint4* a[2];     // f3 register (16-row block 0 of entity block M, step 0, reg 0) of this row: wave-uniform (scalar base +
+  const uint4* n;        // ... of the next row's block 0                              lane offset: no 64-bit vector adds per load)
   const uint4* hl;       // the query tile in LDS, lane included
-#ifdef COPER_DBG_SC3_CHECK
-  const uint4* base;     // diagnostic build: the image and its size, every fragment load is bounds-checked
-  long long n_regs;
-#endif
 };
 
-#ifdef COPER_DBG_SC3_CHECK
-__device__ long long g_sc3_bad[8];   // [0] count, [1] first bad index, [2] kind, [3] blockIdx, [4] image size
-__device__ __forceinline__ uint4 sc3_ld(const SC3Ptrs& X, const uint4* p, int kind) {
-  const long long i = p - X.base;
-  if (i < 0 || i >= X.n_regs) {
-    if (atomicAdd((unsigned long long*)&g_sc3_bad[0], 1ull) == 0) { g_sc3_bad[1] = i; g_sc3_bad[2] = kind; g_sc3_bad[3] = blockIdx.x; g_sc3_bad[4] = X.n_regs; }
-    return make_uint4(0, 0, 0, 0);
-  }
-  return *p;
-}
-#define SC3_LD(X_, p_, kind_) sc3_ld(X_, &(p_), kind_)
-#else
-#define SC3_LD(X_, p_, kind_) (p_)
-#endif
-
-// value V = 8 b + 4 m2 + j of block M: entity row 16 m2 + 4 (lane >> 4) + j of the block, query 16 b + (lane & 15) of the tile
+// value V = 4 MB b + 4 m2 + j of block M: entity row 16 m2 + 4 (lane >> 4) + j of the block, query 16 b + (lane & 15) of the tile
 template <int NP, int TAIL, int PD, bool GM, int M, int V>
 __device__ __forceinline__ void sc3_value(SC3<NP, TAIL, PD, GM>& S, const int lane, const bool store_ok, float* __restrict__ gm_row,
                                           const int64_t gm_col, uint4* __restrict__ mask_row) {
-  constexpr int b = V >> 3, m2 = (V >> 2) & 1, j = V & 3, w = 2 * M + (V >> 5);
+  constexpr int MB = SC3_MB, NV = 32 * MB;
+  constexpr int b = V / (4 * MB), m2 = (V >> 2) % MB, j = V & 3, w = MB * M + (V >> 5);
 #ifdef COPER_DBG_SC3_EPI_R0   /* ablation: one value per column block keeps the chains alive, the epilogue nearly free */
   if constexpr ((V & 7) != 0) return;
 #endif
   float sc;
-  unsigned long long gt;
-  // the accumulator is read out of its AGPR here, at the point of use;  count += (sc > t_hi);  band bit = (sc >= t_lo) & !(sc > t_hi)
-  // shifted into the mask word (m = 2 m + bit)
+  // The accumulator is read out of its AGPR here, at the point of use, and compared with both edges of the band; each
+  // result is shifted into a mask word (m = 2 m + bit: one add-with-carry).  No counting per value and no scalar
+  // instruction: the first form (v_cmp into an SGPR pair, add-with-carry from it, s_andn2, add-with-carry) paid wait
+  // states at every VALU -> SGPR -> VALU hand-over, in a kernel that is bound by its instruction issue.  Every 32 values
+  // the word pair gives  band = ge & ~gt  and  count += popcount(gt) per query.
 #ifdef COPER_DBG_SC3_NO_BAND
-  asm volatile("v_accvgpr_read_b32 %2, %3\n\tv_cmp_gt_f32 %1, %2, %4\n\tv_addc_co_u32 %0, vcc, 0, %0, %1"
-               : "+v"(S.cg[b]), "=&s"(gt), "=&v"(sc)
+  asm volatile("v_accvgpr_read_b32 %1, %2\n\tv_cmp_gt_f32 vcc, %1, %3\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+               : "+v"(S.mg[w]), "=&v"(sc)
                : "a"(S.acc[M][m2][b][j]), "v"(S.thi[b])
-               : "vcc", "scc");
+               : "vcc");
 #else
   asm volatile(
-      "v_accvgpr_read_b32 %3, %4\n\t"
-      "v_cmp_gt_f32 %2, %3, %5\n\t"
-      "v_addc_co_u32 %0, vcc, 0, %0, %2\n\t"
-      "v_cmp_ge_f32 vcc, %3, %6\n\t"
-      "s_andn2_b64 vcc, vcc, %2\n\t"          /* (writes SCC: declared, or a scalar carry chain of the address arithmetic around it breaks) */
+      "v_accvgpr_read_b32 %2, %3\n\t"
+      "v_cmp_gt_f32 vcc, %2, %4\n\t"
+      "v_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+      "v_cmp_ge_f32 vcc, %2, %5\n\t"
       "v_addc_co_u32 %1, vcc, %1, %1, vcc"
-      : "+v"(S.cg[b]), "+v"(S.mk[w]), "=&s"(gt), "=&v"(sc)
+      : "+v"(S.mg[w]), "+v"(S.mk[w]), "=&v"(sc)
       : "a"(S.acc[M][m2][b][j]), "v"(S.thi[b]), "v"(S.tlo[b])
-      : "vcc", "scc");
+      : "vcc");
 #endif
-  if constexpr (GM) {
+  if constexpr ((V & 31) == 31) {      // a word is complete: 32 / (4 MB) queries' worth
+    constexpr int QW = 32 / (4 * MB), B0 = (V - 31) / (4 * MB);       // column blocks in the word, the first of them
+    constexpr unsigned FM = QW == 1 ? 0xFFFFFFFFu : (1u << (4 * MB)) - 1u;
+#pragma unroll
+    for (int i = 0; i < QW; ++i)       // value V sits at bit 31 - (V & 31): column block B0 + i in bits [32 - 4 MB (i + 1), 32 - 4 MB i)
+      S.cg[B0 + i] += __builtin_popcount(S.mg[w] & (FM << (32 - 4 * MB * (i + 1))));
+    S.mk[w] &= ~S.mg[w];
+  }
+  if constexpr (GM) {   // block maxima per (32 entities, query): the eight values of two consecutive 16-row blocks
     if constexpr ((V & 7) == 0) S.mx = sc; else S.mx = fmaxf(S.mx, sc);
     if constexpr ((V & 7) == 7) {
       float mxx = fmaxf(S.mx, __shfl_xor(S.mx, 16));          // the other rows of the 32-entity block
       mxx = fmaxf(mxx, __shfl_xor(mxx, 32));
-      if (store_ok && lane < 16) gm_row[gm_col + b * 16 + lane] = mxx;
+      if (store_ok && lane < 16) gm_row[(m2 >> 1) * S.gm_stride + gm_col + b * 16 + lane] = mxx;
     }
   }
-  if constexpr (M == 1 && V == 63) {     // the row's 128 band bits of this lane are complete
+  if constexpr (M == 1 && V == NV - 1) {     // the row's 64 MB band bits of this lane are complete
 #ifndef COPER_DBG_SC3_NO_BAND
     // only words that carry a bit are written (about one in a hundred), and one 64-bit summary per row of the wave says
-    // which: k_band_exact reads 8 bytes per 8,192 logits instead of 1,024
-    const bool nz = (S.mk[0] | S.mk[1] | S.mk[2] | S.mk[3]) != 0u;
+    // which lanes wrote: k_band_exact reads 8 bytes per row of a wave instead of its 1 - 2 KiB
+    unsigned any = 0u;
+#pragma unroll
+    for (int i = 0; i < 2 * MB; ++i) any |= S.mk[i];
+    const bool nz = any != 0u;
     const unsigned long long which = __ballot(nz);
     if (store_ok) {
-      if (nz) mask_row[lane] = make_uint4(S.mk[0], S.mk[1], S.mk[2], S.mk[3]);
-      if (lane == 0) S.summ_base[(mask_row - S.mask_base) >> 6] = which;
+      if (nz) {
+#pragma unroll
+        for (int i = 0; i < MB / 2; ++i) mask_row[lane * (MB / 2) + i] = make_uint4(S.mk[4 * i], S.mk[4 * i + 1], S.mk[4 * i + 2], S.mk[4 * i + 3]);
+      }
+      if (lane == 0) S.summ_base[(mask_row - S.mask_base) / (64 * (MB / 2))] = which;
     }
 #endif
   }
 }
 
-template <int NP, int TAIL, int PD, bool GM, int M, int... V>
-__device__ __forceinline__ void sc3_values(SC3<NP, TAIL, PD, GM>& S, const int lane, float* __restrict__ gm_row, const int64_t gm_col,
-                                           uint4* __restrict__ mask_row, std::integer_sequence<int, V...>) {
-  (sc3_value<NP, TAIL, PD, GM, M, V>(S, lane, true, gm_row, gm_col, mask_row), ...);
+template <int NP, int TAIL, int PD, bool GM, int M, int V0, int... I>
+__device__ __forceinline__ void sc3_values(SC3<NP, TAIL, PD, GM>& S, const int lane, const bool store_ok, float* __restrict__ gm_row,
+                                           const int64_t gm_col, uint4* __restrict__ mask_row, std::integer_sequence<int, I...>) {
+  (sc3_value<NP, TAIL, PD, GM, M, V0 + I>(S, lane, store_ok, gm_row, gm_col, mask_row), ...);
 }
 
+template <int NP, int TAIL, int PD, bool GM, int M, int... m2>
+__device__ __forceinline__ void sc3_load_bias_(SC3<NP, TAIL, PD, GM>& S, const float4* __restrict__ bp, std::integer_sequence<int, m2...>) {
+  ((S.biasv[M][m2] = f32x4{bp[4 * m2].x, bp[4 * m2].y, bp[4 * m2].z, bp[4 * m2].w}), ...);
+}
 template <int NP, int TAIL, int PD, bool GM, int M>
 __device__ __forceinline__ void sc3_load_bias(SC3<NP, TAIL, PD, GM>& S, const float* __restrict__ bias_pad, const int64_t blk, const int lane) {
-  const float4* bp = (const float4*)(bias_pad + blk * 32 + 4 * (lane >> 4));
-  const float4 v0 = bp[0], v1 = bp[4];
-  S.biasv[M][0][0] = v0.x; S.biasv[M][0][1] = v0.y; S.biasv[M][0][2] = v0.z; S.biasv[M][0][3] = v0.w;
-  S.biasv[M][1][0] = v1.x; S.biasv[M][1][1] = v1.y; S.biasv[M][1][2] = v1.z; S.biasv[M][1][3] = v1.w;
+  sc3_load_bias_<NP, TAIL, PD, GM, M>(S, (const float4*)(bias_pad + blk * (16 * SC3_MB) + 4 * (lane >> 4)), std::make_integer_sequence<int, SC3_MB>{});
 }
 
-// Region (step s, column block b) of block M: in front, one entity-fragment load PD steps ahead (regions b < 4: the four
-// registers of a step) and the two LDS reads of the region after next; then the instructions of the two accumulator chains
-// (m2 = 0, 1) interleaved; behind them this region's share of the other block's epilogue.
+// the instructions of region (step s, column block b) on the MB accumulator chains of block M, chains interleaved
+template <int NP, int TAIL, int PD, bool GM, int M, int s, int b, int sa, int sl, int rs, bool tail, int... m2>
+__device__ __forceinline__ void sc3_mfmas(SC3<NP, TAIL, PD, GM>& S, std::integer_sequence<int, m2...>) {
+  // (e.reg0, q.reg1): T1 of both k-steps (tail: T1 then T2); step 0 starts the chains from pred_bias
+  if constexpr (s == 0) ((S.acc[M][m2][b] = BX3_MFMA16(S.a0[sa][sl][m2], S.q1[rs], S.biasv[M][m2])), ...);
+  else ((S.acc[M][m2][b] = BX3_MFMA16(S.a0[sa][sl][m2], S.q1[rs], S.acc[M][m2][b])), ...);
+  // (e.reg1, q.reg0): T2 of both k-steps (tail: T3 and an all-zero half)
+  ((S.acc[M][m2][b] = BX3_MFMA16(S.a1[sa][sl][m2], S.q0[rs], S.acc[M][m2][b])), ...);
+  // (e.reg1, q.reg1): T3 of both k-steps
+  if constexpr (!tail) ((S.acc[M][m2][b] = BX3_MFMA16(S.a1[sa][sl][m2], S.q1[rs], S.acc[M][m2][b])), ...);
+}
+
+// Region (step s, column block b) of block M: in front, one entity-fragment load PD steps ahead (regions b < 2 MB: the
+// registers of a step) and the two LDS reads of the region SC3_LD ahead; then the instructions of the MB accumulator
+// chains interleaved; behind them this region's share of the other block's epilogue.
 template <int NP, int TAIL, int PD, bool GM, int M, int s, int b>
 __device__ __forceinline__ void sc3_region(SC3<NP, TAIL, PD, GM>& S, const SC3Ptrs& X, const int lane, const bool prev_valid,
                                            float* __restrict__ gm_row, const int64_t gm_col, uint4* __restrict__ mask_row) {
   typedef SC3<NP, TAIL, PD, GM> ST;
-  constexpr int NS = ST::NS, NR = ST::NR, G = ST::G, CH = ST::CH, NV = ST::NV;
+  constexpr int MB = SC3_MB, NS = ST::NS, NR = ST::NR, G = ST::G, CH = ST::CH, NV = ST::NV;
   constexpr bool tail = TAIL && s == NP;
   constexpr int PA = (G & 1) ? M : 0;        // entity-fragment set of this block's step 0
   constexpr int PA_NEXT = (PA + G) & 1;      // ... of the next block's step 0
   constexpr int sa = (PA + s / PD) & 1, sl = s % PD, tk = s + PD;
 #ifndef COPER_DBG_SC3_SKIP_GL
-  if constexpr (b < 4) {
+  if constexpr (b < 2 * MB) {
     constexpr int m2 = b >> 1, wh = b & 1;
     if constexpr (tk < NS) {
       constexpr int ta = (PA + tk / PD) & 1, tl = tk % PD;
-      if constexpr (wh == 0) S.a0[ta][tl][m2] = SC3_LD(X, X.a[M][((m2 * NS + tk) * 2 + 0) * 64], 10 + M);
-      else S.a1[ta][tl][m2] = SC3_LD(X, X.a[M][((m2 * NS + tk) * 2 + 1) * 64], 10 + M);
+      if constexpr (wh == 0) S.a0[ta][tl][m2] = X.a[M][((m2 * NS + tk) * 2 + 0) * 64 + lane];
+      else S.a1[ta][tl][m2] = X.a[M][((m2 * NS + tk) * 2 + 1) * 64 + lane];
     } else if constexpr (M == 0) {           // step tk - NS of this row's block 1
       constexpr int u = tk - NS;
-      if constexpr (wh == 0) S.a0[PA_NEXT][u][m2] = SC3_LD(X, X.a[1][((m2 * NS + u) * 2 + 0) * 64], 20);
-      else S.a1[PA_NEXT][u][m2] = SC3_LD(X, X.a[1][((m2 * NS + u) * 2 + 1) * 64], 20);
+      if constexpr (wh == 0) S.a0[PA_NEXT][u][m2] = X.a[1][((m2 * NS + u) * 2 + 0) * 64 + lane];
+      else S.a1[PA_NEXT][u][m2] = X.a[1][((m2 * NS + u) * 2 + 1) * 64 + lane];
     } else {                                 // ... of the next row's block 0
       constexpr int u = tk - NS;
-      if constexpr (wh == 0) S.a0[PA_NEXT][u][m2] = SC3_LD(X, X.n[((m2 * NS + u) * 2 + 0) * 64], 30);
-      else S.a1[PA_NEXT][u][m2] = SC3_LD(X, X.n[((m2 * NS + u) * 2 + 1) * 64], 30);
+      if constexpr (wh == 0) S.a0[PA_NEXT][u][m2] = X.n[((m2 * NS + u) * 2 + 0) * 64 + lane];
+      else S.a1[PA_NEXT][u][m2] = X.n[((m2 * NS + u) * 2 + 1) * 64 + lane];
     }
   }
 #endif
   constexpr int R = s * 8 + b;
 #ifndef COPER_DBG_SC3_SKIP_LDS
+#ifdef COPER_DBG_SC3_HALF_LDS   /* ablation (wrong results): every second region re-uses its predecessor's query fragments */
+  if constexpr ((R & 1) == 0)
+#endif
   {
     constexpr int R2 = (R + SC3_LD) % NR, s2 = R2 / 8, b2 = R2 % 8;
-    S.q0[(R + SC3_LD) & 3] = X.hl[((b2 * NS + s2) * 2 + 0) * 64];
-    S.q1[(R + SC3_LD) & 3] = X.hl[((b2 * NS + s2) * 2 + 1) * 64];
+#ifdef COPER_DBG_SC3_DUMMY_LDS
+    if constexpr (((R + SC3_LD) & 3) != 0)
+#endif
+    {
+      S.q0[(R + SC3_LD) & 3] = X.hl[((b2 * NS + s2) * 2 + 0) * 64];
+#ifdef COPER_DBG_SC3_ONE_LDS   /* ablation (wrong results): one of the two reads */
+      if constexpr (R < 4)
+#endif
+      S.q1[(R + SC3_LD) & 3] = X.hl[((b2 * NS + s2) * 2 + 1) * 64];
+    }
   }
 #endif
+#ifdef COPER_DBG_SC3_HALF_LDS
+  constexpr int rs = (R & ~1) & 3;
+#elif defined(COPER_DBG_SC3_DUMMY_LDS)   /* ablation: the reads are issued and waited for, the instructions use fixed fragments */
+  asm volatile("" :: "v"(S.q0[R & 3].x), "v"(S.q1[R & 3].x));
+  constexpr int rs = 0;
+#else
   constexpr int rs = R & 3;
-  // (e.reg0, q.reg1): T1 of both k-steps (tail: T1 then T2); step 0 starts the chains from pred_bias
-  if constexpr (s == 0) {
-    S.acc[M][0][b] = BX3_MFMA16(S.a0[sa][sl][0], S.q1[rs], S.biasv[M][0]);
-    S.acc[M][1][b] = BX3_MFMA16(S.a0[sa][sl][1], S.q1[rs], S.biasv[M][1]);
-  } else {
-    S.acc[M][0][b] = BX3_MFMA16(S.a0[sa][sl][0], S.q1[rs], S.acc[M][0][b]);
-    S.acc[M][1][b] = BX3_MFMA16(S.a0[sa][sl][1], S.q1[rs], S.acc[M][1][b]);
-  }
-  // (e.reg1, q.reg0): T2 of both k-steps (tail: T3 and an all-zero half)
-  S.acc[M][0][b] = BX3_MFMA16(S.a1[sa][sl][0], S.q0[rs], S.acc[M][0][b]);
-  S.acc[M][1][b] = BX3_MFMA16(S.a1[sa][sl][1], S.q0[rs], S.acc[M][1][b]);
-  if constexpr (!tail) {   // (e.reg1, q.reg1): T3 of both k-steps
-    S.acc[M][0][b] = BX3_MFMA16(S.a1[sa][sl][0], S.q1[rs], S.acc[M][0][b]);
-    S.acc[M][1][b] = BX3_MFMA16(S.a1[sa][sl][1], S.q1[rs], S.acc[M][1][b]);
-  }
+#endif
+#ifdef COPER_DBG_SC3_LOADS_FIRST
+  SC3_FENCE();     // experiment: the region's loads are issued before its first instruction of the matrix pipe
+#endif
+  sc3_mfmas<NP, TAIL, PD, GM, M, s, b, sa, sl, rs, tail>(S, std::make_integer_sequence<int, MB>{});
   // epilogue of the other block: this step's chunk of CH values is dealt to the eight regions in order
   constexpr int c0 = b * CH / 8, c1 = (b + 1) * CH / 8, v0 = s * CH + c0;
+  constexpr int cnt = v0 >= NV ? 0 : (v0 + (c1 - c0) > NV ? NV - v0 : c1 - c0);
 #ifndef COPER_DBG_SC3_NO_EPI
-  if constexpr (c1 - c0 > 0 && v0 + 0 < NV) sc3_value<NP, TAIL, PD, GM, 1 - M, v0 + 0>(S, lane, prev_valid, gm_row, gm_col, mask_row);
-  if constexpr (c1 - c0 > 1 && v0 + 1 < NV) sc3_value<NP, TAIL, PD, GM, 1 - M, v0 + 1>(S, lane, prev_valid, gm_row, gm_col, mask_row);
-  if constexpr (c1 - c0 > 2 && v0 + 2 < NV) sc3_value<NP, TAIL, PD, GM, 1 - M, v0 + 2>(S, lane, prev_valid, gm_row, gm_col, mask_row);
-  if constexpr (c1 - c0 > 3 && v0 + 3 < NV) sc3_value<NP, TAIL, PD, GM, 1 - M, v0 + 3>(S, lane, prev_valid, gm_row, gm_col, mask_row);
-  if constexpr (c1 - c0 > 4 && v0 + 4 < NV) sc3_value<NP, TAIL, PD, GM, 1 - M, v0 + 4>(S, lane, prev_valid, gm_row, gm_col, mask_row);
-  if constexpr (c1 - c0 > 5 && v0 + 5 < NV) sc3_value<NP, TAIL, PD, GM, 1 - M, v0 + 5>(S, lane, prev_valid, gm_row, gm_col, mask_row);
-  if constexpr (c1 - c0 > 6 && v0 + 6 < NV) sc3_value<NP, TAIL, PD, GM, 1 - M, v0 + 6>(S, lane, prev_valid, gm_row, gm_col, mask_row);
-  if constexpr (c1 - c0 > 7 && v0 + 7 < NV) sc3_value<NP, TAIL, PD, GM, 1 - M, v0 + 7>(S, lane, prev_valid, gm_row, gm_col, mask_row);
+  if constexpr (cnt > 0) sc3_values<NP, TAIL, PD, GM, 1 - M, v0>(S, lane, prev_valid, gm_row, gm_col, mask_row, std::make_integer_sequence<int, cnt>{});
 #endif
-  static_assert(CH <= 64, "eight epilogue values per region at most");
   SC3_FENCE();
 }
 
@@ -235,7 +257,7 @@ __device__ __forceinline__ void sc3_step(SC3<NP, TAIL, PD, GM>& S, const SC3Ptrs
   sc3_region<NP, TAIL, PD, GM, M, s, 6>(S, X, lane, prev_valid, gm_row, gm_col, mask_row);
   sc3_region<NP, TAIL, PD, GM, M, s, 7>(S, X, lane, prev_valid, gm_row, gm_col, mask_row);
   if constexpr (s == 0) {
-    // pred_bias of this block in the NEXT row: the sixteen chains have consumed biasv[M] (program order)
+    // pred_bias of this block in the NEXT row: the chains have consumed biasv[M] (program order)
     sc3_load_bias<NP, TAIL, PD, GM, M>(S, bias_pad, bias_blk_next, lane);
     SC3_FENCE();
   }
@@ -248,16 +270,18 @@ __device__ __forceinline__ void sc3_half(SC3<NP, TAIL, PD, GM>& S, const SC3Ptrs
   (sc3_step<NP, TAIL, PD, GM, M, K>(S, X, bias_pad, bias_blk_next, lane, prev_valid, gm_row, gm_col, mask_row), ...);
 }
 
+template <int NP, int TAIL, int PD, bool GM, int J, int... m2>
+__device__ __forceinline__ void sc3_prologue_a_(SC3<NP, TAIL, PD, GM>& S, const uint4* __restrict__ pa, std::integer_sequence<int, m2...>) {
+  constexpr int NS = NP + TAIL, JJ = J < NS ? J : NS - 1;
+  ((S.a0[0][J][m2] = pa[((m2 * NS + JJ) * 2 + 0) * 64], S.a1[0][J][m2] = pa[((m2 * NS + JJ) * 2 + 1) * 64]), ...);
+}
 template <int NP, int TAIL, int PD, bool GM, int... J>
 __device__ __forceinline__ void sc3_prologue_a(SC3<NP, TAIL, PD, GM>& S, const uint4* __restrict__ pa, std::integer_sequence<int, J...>) {
-  constexpr int NS = NP + TAIL;
-  ((S.a0[0][J][0] = pa[((0 * NS + (J < NS ? J : NS - 1)) * 2 + 0) * 64], S.a1[0][J][0] = pa[((0 * NS + (J < NS ? J : NS - 1)) * 2 + 1) * 64],
-    S.a0[0][J][1] = pa[((1 * NS + (J < NS ? J : NS - 1)) * 2 + 0) * 64], S.a1[0][J][1] = pa[((1 * NS + (J < NS ? J : NS - 1)) * 2 + 1) * 64]),
-   ...);
+  (sc3_prologue_a_<NP, TAIL, PD, GM, J>(S, pa, std::make_integer_sequence<int, SC3_MB>{}), ...);
 }
 template <int NP, int TAIL, int PD, bool GM, int... J>
 __device__ __forceinline__ void sc3_prologue_a1(SC3<NP, TAIL, PD, GM>& S, std::integer_sequence<int, J...>) {   // ablation builds only
-  ((S.a0[1][J][0] = S.a0[0][J][0], S.a1[1][J][0] = S.a1[0][J][0], S.a0[1][J][1] = S.a0[0][J][1], S.a1[1][J][1] = S.a1[0][J][1]), ...);
+  for (int m2 = 0; m2 < SC3_MB; ++m2) ((S.a0[1][J][m2] = S.a0[0][J][m2], S.a1[1][J][m2] = S.a1[0][J][m2]), ...);
 }
 
 #ifdef COPER_DBG_CLOCK
@@ -267,8 +291,8 @@ __device__ unsigned long long g_sc3_clk[2 * 1024];
 #endif
 
 // Ef3: the entities' f3 image; Hf3: the queries' (one 128-query tile = 8 column blocks = 16 NS KiB, copied to LDS as it lies);
-// tband[q] = {t_lo, t_hi}; mask: [tile][row][wave][lane] 16 bytes (band bits of the 64 entities x 128 queries of a wave's row),
-// written only where a bit is set; summ: [tile][row][wave] 8 bytes: the lanes whose mask word was written
+// tband[q] = {t_lo, t_hi}; mask: [tile][row][wave][lane] MB / 2 x 16 bytes (band bits of the 32 MB entities x 128 queries of a
+// wave's row), written only where a bit is set; summ: [tile][row][wave] 8 bytes: the lanes whose mask words were written
 template <int NP, int TAIL, int PD, bool GM>
 __global__ __launch_bounds__(256, 1) void k_score_count3_bf16x3(const uint4* __restrict__ Ef3, const float* __restrict__ bias_pad,
                                                                  const uint4* __restrict__ Hf3, const float2* __restrict__ tband,
@@ -290,12 +314,15 @@ __global__ __launch_bounds__(256, 1) void k_score_count3_bf16x3(const uint4* __r
   ST S;
   S.mask_base = mask;
   S.summ_base = summ;
+  S.gm_stride = gm_stride;
   int64_t cur_tile = -1;
   int64_t eb_prev = 0;
   bool prev_valid = false;
   const std::make_integer_sequence<int, NS> SSEQ{};
   const std::make_integer_sequence<int, NV> VSEQ{};
-  constexpr int64_t BLK_REGS = 2 * NS * 2;   // f3 registers of one 32-entity block (two 16-row blocks)
+  constexpr int MB = SC3_MB;
+  constexpr int64_t BLK_REGS = MB * NS * 2;   // f3 registers of one entity block (MB 16-row blocks)
+  constexpr int64_t MW = 64 * (MB / 2);       // 16-byte mask pieces of one row of a wave
 
   for (int64_t r = r_begin; r < r_end; ++r) {
     const int64_t tile = r / rows_per_tile;
@@ -332,13 +359,16 @@ __global__ __launch_bounds__(256, 1) void k_score_count3_bf16x3(const uint4* __r
         S.tlo[b] = tb.x; S.thi[b] = tb.y;
         S.cg[b] = 0;
       }
-      S.mk[0] = S.mk[1] = S.mk[2] = S.mk[3] = 0u;
+#pragma unroll
+      for (int i = 0; i < 2 * MB; ++i) { S.mk[i] = 0u; S.mg[i] = 0u; }
       // entity fragments of block 0's first PD steps, pred_bias of both blocks, "previous block" accumulators that count nothing
       sc3_prologue_a<NP, TAIL, PD, GM>(S, Ef3 + eb * BLK_REGS * 64 + lane, std::make_integer_sequence<int, PD>{});
       sc3_load_bias<NP, TAIL, PD, GM, 0>(S, bias_pad, eb, lane);
       sc3_load_bias<NP, TAIL, PD, GM, 1>(S, bias_pad, eb + 1, lane);
 #pragma unroll
-      for (int b = 0; b < NB; ++b) { S.acc[1][0][b] = f32x4(-INFINITY); S.acc[1][1][b] = f32x4(-INFINITY); }
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int m2 = 0; m2 < MB; ++m2) S.acc[1][m2][b] = f32x4(-INFINITY);
       prev_valid = false;
       __syncthreads();
       // query fragments of the first SC3_LD regions (step 0, column blocks 0 ..)
@@ -355,26 +385,24 @@ __global__ __launch_bounds__(256, 1) void k_score_count3_bf16x3(const uint4* __r
     const int64_t eb_next = has_next ? (((r + 1) % rows_per_tile) * 4 + wave) * 2 : eb;     // past the end: re-read this row's blocks
     const int64_t gm_col = cur_tile * 128;
     SC3Ptrs X;
-    X.a[0] = Ef3 + eb * BLK_REGS * 64 + lane;
+    X.a[0] = Ef3 + eb * BLK_REGS * 64;
     X.a[1] = X.a[0] + BLK_REGS * 64;
-    X.n = Ef3 + eb_next * BLK_REGS * 64 + lane;
+    X.n = Ef3 + eb_next * BLK_REGS * 64;
     X.hl = hl3 + lane;
-#ifdef COPER_DBG_SC3_CHECK
-    X.base = Ef3;
-    X.n_regs = (long long)(total_rows / ((total_rows + rows_per_tile - 1) / rows_per_tile > 0 ? 1 : 1)) * 0 + rows_per_tile * 8 * BLK_REGS * 64;
-#endif
-    uint4* mask_cur = mask + ((cur_tile * rows_per_tile + row) * 4 + wave) * 64;
+    uint4* mask_cur = mask + ((cur_tile * rows_per_tile + row) * 4 + wave) * MW;
     // block 0 (epilogue of the previous row's block 1 beside it: its last value completes that row's mask), then block 1
-    sc3_half<NP, TAIL, PD, GM, 0>(S, X, bias_pad, eb_next, lane, prev_valid, GM ? gmax + (eb_prev + 1) * gm_stride : nullptr, gm_col,
-                                  mask_cur - 4 * 64, SSEQ);
-    sc3_half<NP, TAIL, PD, GM, 1>(S, X, bias_pad, eb_next + 1, lane, true, GM ? gmax + eb * gm_stride : nullptr, gm_col, mask_cur, SSEQ);
+    sc3_half<NP, TAIL, PD, GM, 0>(S, X, bias_pad, eb_next, lane, prev_valid, GM ? gmax + (eb_prev + 1) * (MB / 2) * gm_stride : nullptr, gm_col,
+                                  mask_cur - 4 * MW, SSEQ);
+    sc3_half<NP, TAIL, PD, GM, 1>(S, X, bias_pad, eb_next + 1, lane, true, GM ? gmax + eb * (MB / 2) * gm_stride : nullptr, gm_col, mask_cur, SSEQ);
     eb_prev = eb;
     prev_valid = true;
     if (last_of_tile) {
       // drain: block 1's accumulators have no next row of the same tile to hide behind
-      sc3_values<NP, TAIL, PD, GM, 1>(S, lane, GM ? gmax + (eb + 1) * gm_stride : nullptr, gm_col, mask_cur, VSEQ);
+      sc3_values<NP, TAIL, PD, GM, 1, 0>(S, lane, true, GM ? gmax + (eb + 1) * (MB / 2) * gm_stride : nullptr, gm_col, mask_cur, VSEQ);
 #pragma unroll
-      for (int b = 0; b < NB; ++b) { S.acc[1][0][b] = f32x4(-INFINITY); S.acc[1][1][b] = f32x4(-INFINITY); }
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int m2 = 0; m2 < MB; ++m2) S.acc[1][m2][b] = f32x4(-INFINITY);
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
         int g = S.cg[b] + __shfl_xor(S.cg[b], 16);
@@ -394,11 +422,6 @@ __global__ __launch_bounds__(256, 1) void k_score_count3_bf16x3(const uint4* __r
 #endif
 }
 
-#ifdef COPER_DBG_SC3_CHECK
-extern "C" __attribute__((visibility("default"))) int coper_dbg_sc3_bad(long long* out) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sc3_bad), 8 * sizeof(long long)) == hipSuccess ? 0 : 1;
-}
-#endif
 
 #ifdef COPER_DBG_CLOCK
 extern "C" __attribute__((visibility("default"))) int coper_dbg_clock(int n_wg, double* ghz_median, double* us_median) {
@@ -558,53 +581,104 @@ __device__ __forceinline__ void band_decide(const BandArgs& A, const int64_t q, 
   else if (A.ne && sx == tx) atomicAdd(&A.ne[q], 1);
 }
 
-constexpr int BE_CAP = 4096;
+constexpr int BE_CAP = 4096, BE_ITEMS = 2048;
 __global__ __launch_bounds__(256) void k_band_exact(const uint4* __restrict__ mask, const unsigned long long* __restrict__ summ, int64_t n_units,
                                                     unsigned rows4 /* rows per tile x 4 waves */, BandArgs A) {
-  __shared__ unsigned long long s_p[BE_CAP];
-  __shared__ int s_n;
-  // a thread per unit (one wave's row of 64 entities x 128 queries): its summary, then the mask words the summary names
-  const int64_t unit = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  unsigned long long lanes = unit < n_units ? summ[unit] : 0ull;
-  unsigned tile = 0, eb = 0;
-  if (lanes) {
-    tile = (unsigned)unit / rows4;
-    eb = ((unsigned)unit - tile * rows4) * 2;       // (row * 4 + wave) * 2: the wave's first 32-entity block
+  constexpr int MB = SC3_MB, NW = 2 * MB;      // 32-bit mask words per lane and row of a wave
+  __shared__ unsigned long long s_p[BE_CAP];   // marked pairs: (query << 32) | entity
+  __shared__ unsigned s_it[BE_ITEMS];          // (unit in the workgroup << 6) | lane: the mask words to fetch
+  __shared__ int s_n, s_ni;
+  // three phases, each spread over all threads (a thread that walks its unit's lanes one after the other pays a round trip
+  // per lane): a thread per unit (one wave's row of 32 MB entities x 128 queries) reads the summary and lists the lanes
+  // that wrote mask words; a thread per listed lane fetches its words and lists the marked pairs; a thread per pair walks.
+  const int64_t unit0 = (int64_t)blockIdx.x * 256;
+  if (threadIdx.x == 0) { s_n = 0; s_ni = 0; }
+  __syncthreads();
+  {
+    const int64_t unit = unit0 + threadIdx.x;
+    unsigned long long lanes = unit < n_units ? summ[unit] : 0ull;
+    while (lanes) {
+      const int l = __builtin_ctzll(lanes);
+      lanes &= lanes - 1;
+      const int slot = atomicAdd(&s_ni, 1);
+      if (slot < BE_ITEMS) s_it[slot] = ((unsigned)threadIdx.x << 6) | (unsigned)l;
+    }
   }
-  uint4 w = make_uint4(0u, 0u, 0u, 0u);
-  int l = 0;
-  while (true) {      // rounds: a list that fills up (heavy ties) is worked off and the walk goes on where it stopped
-    if (threadIdx.x == 0) s_n = 0;
-    __syncthreads();
-    bool left = false;
-    while (!left) {
-      if (!(w.x | w.y | w.z | w.w)) {
-        if (!lanes) break;
-        l = __builtin_ctzll(lanes);
-        lanes &= lanes - 1;
-        w = mask[unit * 64 + l];
-      }
-      unsigned* wc = (unsigned*)&w;
+  __syncthreads();
+  const int ni = s_ni;       // beyond BE_ITEMS (a workgroup's 256 x 64 lanes nearly all marked: heavy ties): the slow loop below
+  for (int it0 = 0; it0 < (ni < BE_ITEMS ? ni : BE_ITEMS); it0 += 256) {
+    const int it = it0 + threadIdx.x;
+    unsigned wc[NW];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < NW; ++c) wc[c] = 0u;
+    unsigned tile = 0, eb = 0;
+    int l = 0;
+    if (it < ni && it < BE_ITEMS) {
+      const int64_t unit = unit0 + (s_it[it] >> 6);
+      l = (int)(s_it[it] & 63u);
+      tile = (unsigned)unit / rows4;
+      eb = ((unsigned)unit - tile * rows4) * 2;       // (row * 4 + wave) * 2: the wave's first entity block (16 MB rows each)
+#pragma unroll
+      for (int i = 0; i < MB / 2; ++i) {
+        const uint4 w = mask[(unit * 64 + l) * (MB / 2) + i];
+        wc[4 * i] = w.x; wc[4 * i + 1] = w.y; wc[4 * i + 2] = w.z; wc[4 * i + 3] = w.w;
+      }
+    }
+    while (true) {      // rounds: a pair list that fills up is worked off and the words are gone on with
+      bool left = false;
+#pragma unroll
+      for (int c = 0; c < NW; ++c) {
         while (wc[c] && !left) {
           const int p = 31 - __builtin_clz(wc[c]);     // highest set bit first = lowest value index first
           const int slot = atomicAdd(&s_n, 1);
           if (slot >= BE_CAP) { left = true; break; }
           wc[c] &= ~(1u << p);
-          const int V = 32 * (c & 1) + (31 - p);
-          const int b = V >> 3, m2 = (V >> 2) & 1, j = V & 3;
-          const unsigned long long e = (unsigned long long)(eb + (c >> 1)) * 32 + 16 * m2 + 4 * (l >> 4) + j;
+          const int V = 32 * (c % MB) + (31 - p);
+          const int b = V / (4 * MB), m2 = (V >> 2) % MB, j = V & 3;
+          const unsigned long long e = (unsigned long long)(eb + c / MB) * (16 * MB) + 16 * m2 + 4 * (l >> 4) + j;
           const unsigned long long q = (unsigned long long)tile * 128 + 16 * b + (l & 15);
           s_p[slot] = (q << 32) | e;
         }
       }
+      const int full = __syncthreads_or(left ? 1 : 0);
+      const bool last = it0 + 256 >= (ni < BE_ITEMS ? ni : BE_ITEMS);
+      if (full || last) {
+        const int n = s_n < BE_CAP ? s_n : BE_CAP;
+        for (int p = threadIdx.x; p < n; p += 256) band_decide(A, (int64_t)(s_p[p] >> 32), (int64_t)(s_p[p] & 0xFFFFFFFFull));
+        __syncthreads();
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
+      }
+      if (!full) break;
     }
-    const int full = __syncthreads_or(left ? 1 : 0);
-    const int n = s_n < BE_CAP ? s_n : BE_CAP;
-    for (int p = threadIdx.x; p < n; p += 256) band_decide(A, (int64_t)(s_p[p] >> 32), (int64_t)(s_p[p] & 0xFFFFFFFFull));
-    if (!full) break;
-    __syncthreads();
+  }
+  if (ni > BE_ITEMS) {
+    // the lanes that did not fit the item list: every thread walks its own unit again and skips the lanes that were listed
+    // (the list took them in no particular order, so the listed ones are looked up) -- correctness path, not a fast one
+    const int64_t unit = unit0 + threadIdx.x;
+    unsigned long long lanes = unit < n_units ? summ[unit] : 0ull;
+    for (int i = 0; i < BE_ITEMS; ++i)
+      if ((s_it[i] >> 6) == (unsigned)threadIdx.x) lanes &= ~(1ull << (s_it[i] & 63u));
+    const unsigned tile = (unsigned)unit / rows4, eb = ((unsigned)unit - tile * rows4) * 2;
+    while (lanes) {
+      const int l = __builtin_ctzll(lanes);
+      lanes &= lanes - 1;
+      for (int i = 0; i < MB / 2; ++i) {
+        const uint4 w = mask[(unit * 64 + l) * (MB / 2) + i];
+        const unsigned ww[4] = {w.x, w.y, w.z, w.w};
+        for (int cc = 0; cc < 4; ++cc) {
+          unsigned bits = ww[cc];
+          const int c = 4 * i + cc;
+          while (bits) {
+            const int p = 31 - __builtin_clz(bits);
+            bits &= ~(1u << p);
+            const int V = 32 * (c % MB) + (31 - p);
+            const int b = V / (4 * MB), m2 = (V >> 2) % MB, j = V & 3;
+            band_decide(A, (int64_t)tile * 128 + 16 * b + (l & 15), (int64_t)(eb + c / MB) * (16 * MB) + 16 * m2 + 4 * (l >> 4) + j);
+          }
+        }
+      }
+    }
   }
 }
 
@@ -617,11 +691,12 @@ static int sc3_go(coper_handle* h, int64_t q0, int64_t Bc, int32_t* ng, float* g
 #ifdef COPER_SC3_PD
   constexpr int PD = COPER_SC3_PD < NS ? COPER_SC3_PD : NS;
 #else
-  constexpr int PD = 3 < NS ? 3 : NS;       // three steps = six k-steps of 16 ahead (round 2's distance)
+  constexpr int PDW = SC3_MB == 4 ? 2 : 3;  // steps ahead: 2 x 12 x 8 (MB = 4) or 3 x 6 x 8 (MB = 2) instructions of 16 cycles
+  constexpr int PD = PDW < NS ? PDW : NS;
 #endif
   const Dims& dm = h->dm;
   const int64_t q_tiles = (Bc + 127) / 128;
-  const int64_t rows_per_tile = dm.n_eblk / 8;
+  const int64_t rows_per_tile = dm.n_eblk * 2 / SC3_MB / 8;    // a row: 4 waves x 2 entity blocks of 16 MB rows
   const int64_t total_rows = q_tiles * rows_per_tile;
   int64_t grid = h->num_cus;
   if (grid > total_rows) grid = total_rows;
@@ -647,11 +722,12 @@ static int sc3_gm(coper_handle* h, int64_t q0, int64_t Bc, int32_t* ng, float* g
 
 // bytes of the band mask of a count launch over Bc queries: the words (16 bytes per lane and row of a wave), then the
 // summaries (8 bytes per row of a wave)
+static int64_t sc3_units(const coper_handle* h, int64_t Bc) { return ((Bc + 127) / 128) * (h->dm.n_eblk * 2 / SC3_MB / 8) * 4; }   // rows of waves
 size_t score_count3_mask_words_bytes(const coper_handle* h, int64_t Bc) {
-  return (size_t)((Bc + 127) / 128) * (size_t)(h->dm.n_eblk / 8) * 4 * 64 * sizeof(uint4);
+  return (size_t)sc3_units(h, Bc) * 64 * (SC3_MB / 2) * sizeof(uint4);     // one bit per logit
 }
 size_t score_count3_mask_bytes(const coper_handle* h, int64_t Bc) {
-  return score_count3_mask_words_bytes(h, Bc) + (size_t)((Bc + 127) / 128) * (size_t)(h->dm.n_eblk / 8) * 4 * sizeof(unsigned long long);
+  return score_count3_mask_words_bytes(h, Bc) + (size_t)sc3_units(h, Bc) * sizeof(unsigned long long);
 }
 
 // Count launch over queries [q0, q0 + Bc) (q0 a multiple of 128) of the packed batch + the exact decision of its band.
@@ -676,14 +752,13 @@ int score_count3_chunk_bf16x3(coper_handle* h, int64_t q0, int64_t Bc, const flo
 #ifndef COPER_DBG_SC3_NO_BAND
   {
     ScopedKernelTimer t(h, "band_exact", s);
-    const int64_t rows_per_tile = h->dm.n_eblk / 8;
-    const int64_t n_words = ((Bc + 127) / 128) * rows_per_tile * 4 * 64;
+    const int64_t rows_per_tile = h->dm.n_eblk * 2 / SC3_MB / 8;
     BandArgs A;
     A.hvec = hvec + q0 * h->dm.d; A.ent = h->params["ent_emb"].ptr; A.bias = h->params["pred_bias"].ptr;
     A.e2 = e2 + q0; A.indptr = indptr + q0; A.idx = idx; A.tgt_x = tgt_x ? tgt_x + q0 : nullptr;
     A.ng = ng + q0; A.ne = ne ? ne + q0 : nullptr; A.Bc = Bc; A.n_local = h->dm.n_local; A.shard_lo = (int64_t)h->cfg.shard_lo; A.d = h->dm.d;
     { static const int dbg = getenv("COPER_DBG_BAND") ? atoi(getenv("COPER_DBG_BAND")) : 0; A.dbg = dbg; }
-    const int64_t n_units = n_words / 64;
+    const int64_t n_units = sc3_units(h, Bc);
     if (rows_per_tile * 4 > 0x7fffffffLL || n_units > 0x7fffffffLL) return fail(h, COPER_EUNSUPPORTED, "band mask beyond 2^31 units");
     hipLaunchKernelGGL(k_band_exact, dim3((unsigned)((n_units + 255) / 256)), dim3(256), 0, s, (const uint4*)h->mask_ws,
                        (const unsigned long long*)((const char*)h->mask_ws + score_count3_mask_words_bytes(h, Bc)), n_units,
