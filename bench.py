@@ -116,6 +116,9 @@ def parse_args():
     ap.add_argument("--no-scale", action="store_true", help="skip the 10M-entity blocks (scale, HBM-regime roofline)")
     ap.add_argument("--no-extras", action="store_true", help="main line only: no f32 comparison, PCIe-inclusive loop, 10M blocks")
     ap.add_argument("--scale-steps", type=int, default=None, help="timed passes of the scale block (default min(steps, 10))")
+    ap.add_argument("--per-rank-of", type=int, default=8,
+                    help="N = 1 only: also time ONE rank's share of the scale pass at this world size (its entity shard, its "
+                         "relations' share of the encoder, no collectives) and print it as scale.projected; 0 = skip")
     ap.add_argument("--dist-backend", default="nccl",
                     help="torch.distributed backend (nccl = RCCL).  gloo + several ranks on one GPU is a debugging aid "
                          "for the multi-process path on a single-GPU box; its numbers mean nothing")
@@ -286,7 +289,7 @@ def run_scale_blocks(ctx, args):
     model.profile(False)
     if n:
         out["hbm_regime"] = score_roofline(ctx, score_kernel_name("bf16x3", d), "bf16x3", HBM_REGIME_QUERIES, model.n_local, d, ms / n,
-                                           SCALE_WORKLOAD, exact="coper::k_score_count3_bf16x3<8, 0, 3, false>")
+                                           SCALE_WORKLOAD, exact="coper::k_score_count3_bf16x3<8, 0, 2, false>")
         out["hbm_regime"]["kernel"] = score_kernel_name("bf16x3", d)
     # (2) the entity-sharded pass, top-10 exchanged
     Q = cdata.CONFIGS[SCALE_WORKLOAD]["queries"]
@@ -313,7 +316,7 @@ def run_scale_blocks(ctx, args):
     if n:
         kn = score_kernel_name("bf16x3", d)
         blk["roofline"] = dict(kernel=kn, **score_roofline(ctx, kn, "bf16x3", Q, model.n_local, d, ms / n, SCALE_WORKLOAD,
-                                                           want_pmc=ctx.world == 1, exact="coper::k_score_count3_bf16x3<8, 0, 3, true>"))
+                                                           want_pmc=ctx.world == 1, exact="coper::k_score_count3_bf16x3<8, 0, 2, true>"))
     exp = SCALE_EXPECTED
     if exp.get("ranks_sha1"):
         # checked by main() AFTER the JSON line is out (every rank must first get through the collectives that follow; the line
@@ -326,6 +329,44 @@ def run_scale_blocks(ctx, args):
     model.close()
     del model, params
     torch.cuda.empty_cache()
+    # What ONE rank of a G-rank job computes per pass, timed on this GPU (a projection, not a measurement of G GPUs): shard
+    # [0, |E|/G) of the table, the encoder for the relations rank 0 owns, targets from rows, counts + top-k over the shard.
+    # The three collectives of the exchange (<= 8 MB each, latency-bound) and the other ranks' skew are NOT in it.
+    G = int(getattr(args, "per_rank_of", 0) or 0)
+    if ctx.world == 1 and G > 1:
+        shard_g = shard_bounds(md["num_ent"], G, 0)
+        params_g, _ = device_params(md, 0, ctx.device, shard_g)
+        mg = ConvE(md, device=ctx.device, shard=shard_g, score_mode="bf16x3")
+        mg.load_parameters(params_g, global_rows=False)
+        mg.prepare()
+        mg.reserve(Q, len(q["filt_idx"]))
+        dq = {n: torch.as_tensor(v).to(ctx.device) for n, v in q.items()}
+        mine = np.nonzero(q["rel"] % G == 0)[0]
+        sel = torch.as_tensor(mine, device=ctx.device)
+        rows1 = torch.randn((Q, d), device=ctx.device) * 0.1            # stand-ins for the all-reduced rows (values do not change the work)
+        rows2 = torch.randn((Q, d), device=ctx.device) * 0.1
+        bias2 = torch.zeros(Q, device=ctx.device)
+        hfull = torch.randn((Q, d), device=ctx.device).abs()
+
+        def rank_step(i=0):
+            r1, r2, b2 = mg.gather_entities(dq["e1"]), mg.gather_entities(dq["e2"]), mg.gather_bias(dq["e2"])   # step 1, local part
+            hloc = mg.encode(q["e1"][mine], q["rel"][mine], e1_rows=rows1.index_select(0, sel).contiguous())      # step 2, this rank's share
+            hfull.index_copy_(0, sel, hloc)
+            tx = mg.score_rows(hfull, rows2, bias2)
+            return mg.rank_counts(hfull, torch.stack([tx, tx]), dq["e2"], dq["filt_indptr"], dq["filt_idx"], filt_nnz=len(q["filt_idx"]), k=SCALE_TOPK)
+
+        for _ in range(2):
+            rank_step()
+        dtp, _ = timed_passes(ctx, rank_step, steps)
+        per_rank_ms = dtp / steps * 1e3
+        blk["projected"] = {"world": G, "per_rank_ms": per_rank_ms, "single_gpu_ms": blk["ms_per_step"],
+                            "speedup_before_collectives": blk["ms_per_step"] / per_rank_ms,
+                            "note": "ONE rank's compute of a %d-rank pass timed on this GPU (shard of %d rows, %d of %d queries encoded, "
+                                    "targets from rows, counts + top-%d): a projection -- the three collectives (<= 8 MB, latency-bound) "
+                                    "and rank skew are not in it" % (G, mg.n_local, len(mine), Q, SCALE_TOPK)}
+        mg.close()
+        del mg, params_g
+        torch.cuda.empty_cache()
     return out
 
 

@@ -76,6 +76,7 @@ PROTOTYPES = {
     "coper_score_all": (C.c_int, [_P, _P, _I64, _P, _I64, _P]),
     "coper_score_lookup": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _P]),
     "coper_target_scores": (C.c_int, [_P, _P, _P, _I64, _P, _P]),
+    "coper_score_rows": (C.c_int, [_P, _P, _P, _P, _I64, _P, _P]),
     "coper_rank_counts": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, C.c_int32, _P, _P, _P, _P, _P]),
     "coper_rank": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P]),
     "coper_encode_rank": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P]),

@@ -659,6 +659,14 @@ COPER_API int coper_target_scores(coper_handle* h, const float* hvec, const int6
   return COPER_OK;
 }
 
+COPER_API int coper_score_rows(coper_handle* h, const float* hvec, const float* rows, const float* bias, int64_t B, float* out,
+                               void* stream) {
+  COPER_REQUIRE_PREPARED(h);
+  if (B == 0) return COPER_OK;
+  if (!hvec || !rows || !bias || !out || B < 0) return fail(h, COPER_EINVAL, "coper_score_rows: bad argument");
+  return launch_exact_rows(h, hvec, rows, bias, B, out, (hipStream_t)stream);     // (the chain is the f32 mode's own logit)
+}
+
 COPER_API int coper_rank_counts(coper_handle* h, const float* hvec, const float* tgt, const int64_t* e2,
                       const int64_t* filt_indptr, const int64_t* filt_idx, int64_t filt_nnz, int64_t B, int32_t k,
                       int32_t* n_greater, int32_t* n_equal, float* topk_val, int64_t* topk_idx, void* stream) {

@@ -255,6 +255,7 @@ size_t score_count3_mask_bytes(const coper_handle* h, int64_t Bc);
 int launch_band_consts(coper_handle* h, const float* ent, const float* bias, hipStream_t s);
 int launch_band_setup(coper_handle* h, const float* hvec, const float* tgt, int64_t B, hipStream_t s);
 int launch_exact_targets(coper_handle* h, const float* hvec, const int64_t* e2, int64_t B, float* out, hipStream_t s);
+int launch_exact_rows(coper_handle* h, const float* hvec, const float* rows, const float* bias, int64_t B, float* out, hipStream_t s);
 float band_kappa(const coper_handle* h);
 // kernels_tail_bf16.hip: finalize + targets + filter correction of a ranking pass in one launch
 bool tail_fused_supported(const coper_handle* h);

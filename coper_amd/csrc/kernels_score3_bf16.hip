@@ -519,6 +519,22 @@ __global__ void k_exact_targets(const float* __restrict__ ent, const float* __re
   out[b] = sx;
 }
 
+// the same chain on rows the caller holds (coper_score_rows)
+__global__ void k_exact_rows(const float* __restrict__ rows, const float* __restrict__ bias, const float* __restrict__ hvec, int64_t B, int d,
+                             float* __restrict__ out) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float sx = 0.f, unused = 0.f;
+  exact_chain_pair(rows + b * d, nullptr, hvec + b * d, bias[b], 0.f, d, sx, unused);
+  out[b] = sx;
+}
+
+int launch_exact_rows(coper_handle* h, const float* hvec, const float* rows, const float* bias, int64_t B, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_exact_rows, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, rows, bias, hvec, B, h->dm.d, out);
+  COPER_HIP_TRY(h, hipGetLastError());
+  return COPER_OK;
+}
+
 int launch_exact_targets(coper_handle* h, const float* hvec, const int64_t* e2, int64_t B, float* out, hipStream_t s) {
   hipLaunchKernelGGL(k_exact_targets, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, h->params["ent_emb"].ptr, h->params["pred_bias"].ptr,
                      hvec, e2, B, h->dm.d, (int64_t)h->cfg.shard_lo, h->dm.n_local, out);

@@ -256,6 +256,26 @@ class ConvE(object):
         _lib.check(self._h, self._lib.coper_target_scores(self._h, _ptr(h), _ptr(e2), e2.numel(), _ptr(out), self._stream()))
         return out
 
+    def gather_bias(self, ids):
+        """pred_bias[ids] restricted to the shard (0 for ids it does not hold): with gather_entities, what an entity-sharded
+        evaluation all-reduces for the targets (sharding.py step 1).  Plain indexing of the registered tensor."""
+        ids = self._ids(ids)
+        lo, hi = self.shard
+        own = (ids >= lo) & (ids < hi)
+        b = self._tensors["pred_bias"]
+        return torch.where(own, b[(ids - lo).clamp(0, hi - lo - 1)], torch.zeros((), device=self.device, dtype=torch.float32))
+
+    def score_rows(self, h, rows, bias):
+        """[B]: pred_bias_b + rows[b] . h[b] by the fp32 chain (coper_score_rows): the target logits from entity rows the
+        caller holds."""
+        self._need_prepared()
+        rows = rows.to(device=self.device, dtype=torch.float32).contiguous()
+        bias = bias.to(device=self.device, dtype=torch.float32).contiguous()
+        B = rows.shape[0]
+        out = torch.empty((B,), device=self.device, dtype=torch.float32)
+        _lib.check(self._h, self._lib.coper_score_rows(self._h, _ptr(h), _ptr(rows), _ptr(bias), B, _ptr(out), self._stream()))
+        return out
+
     def rank_counts(self, h, tgt, e2, filt_indptr, filt_idx, filt_nnz=None, k=0):
         """(n_greater, n_equal) int32 [B] over this shard (metrics.py:44-50 without logits); with k > 0 also
         the shard's top-k of the filtered row: (..., topk_val f32 [B,k], topk_idx int64 [B,k] global ids).

@@ -6,17 +6,20 @@ The reference has no distributed code at all; the path sha
   replicated): the queries of a pass are split across ranks, no data-path collective; one
   all-gather of int32 ranks at the end so every rank can form the global metrics.
 * `EntityShardedRanker` -- large KGs (the 10M-entity config): rank g owns entity rows
-  [g|E|/G, (g+1)|E|/G) of `ent_emb` / `pred_bias`.  Per chunk of B queries:
-    1. all-reduce(sum) of the shard-local gather of `ent_emb[e1]` (each row has one owner, the rest
-       contribute zeros: exact)                                                   [B, d]  f32
+  [g|E|/G, (g+1)|E|/G) of `ent_emb` / `pred_bias`.  Per chunk of B queries, THREE collectives
+  (round 2 had four):
+    1. ONE all-reduce(sum) of the shard-local gathers of `ent_emb[e1]`, `ent_emb[e2]` and `pred_bias[e2]`
+       (each row has one owner, the rest contribute zeros: exact)                 [B, 2d + 1]  f32
     2. the encoder is split by relation (rank = rel mod G: a rank touches only its relations'
-       generated dense weights), all-reduce(sum) of the zero-padded `h`           [B, d]  f32
-    3. the owner of `e2[b]` computes the target logit; all-reduce(sum)            [B]     f32
-    4. every rank runs the fused score+count over its rows; ONE all-gather of the packed per-shard
+       generated dense weights); all-gather of the OWNED `h` rows, padded to the largest share
+       (round 2 all-reduced a zero-padded [B, d]: G times the bytes)              [G, ceil-ish(B/G), d]  f32
+       -- then every rank scores the targets itself from its copy of the e2 rows, by the fp32 chain
+       (`score_rows`): the target logits are never exchanged
+    3. every rank runs the fused score+count over its rows; ONE all-gather of the packed per-shard
        record (n_greater, n_equal[, top-k]) -- the collective BASELINE.json's north_star names --
        and every rank sums the counts: rank = 1 + sum_g n_greater_g (integers: identical to the
        single-GPU result).
-  Payloads are <= B*d*4 bytes (<= 4 MB), i.e. latency-bound on xGMI; logits never cross GPUs.
+  Payloads are <= B*(2d+1)*4 bytes (<= 8 MB), i.e. latency-bound on xGMI; logits never cross GPUs.
 
 Both take a *scorer*: any object with `gather_entities / encode / target_scores / rank_counts`
 returning torch tensors on its own device.  `coper_amd.models.ConvE` is the product scorer; the
@@ -106,7 +109,7 @@ class QueryShardedEvaluator(object):
 
 
 class EntityShardedRanker(object):
-    """Entity-sharded ranking; see the module docstring for the four exchange steps."""
+    """Entity-sharded ranking; see the module docstring for the three exchange steps."""
 
     def __init__(self, scorer, group=None, split_encoder=True):
         self.scorer, self.group, self.split_encoder = scorer, group, split_encoder
@@ -119,31 +122,60 @@ class EntityShardedRanker(object):
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
-    def encode(self, e1, rel):
+    def _gather_rows(self, e1, e2):
+        """step 1: (ent_emb[e1] [B,d], ent_emb[e2] [B,d], pred_bias[e2] [B]) from ONE all-reduce"""
         sc = self.scorer
-        rows = self._allreduce(sc.gather_entities(e1))                          # step 1
-        rel_np = np.asarray(rel)
+        r1, r2, b2 = sc.gather_entities(e1), sc.gather_entities(e2), sc.gather_bias(e2)
+        d = r1.shape[1]
+        pack = torch.cat([r1, r2, b2.reshape(-1, 1)], dim=1)
+        self._allreduce(pack)
+        return pack[:, :d].contiguous(), pack[:, d:2 * d].contiguous(), pack[:, 2 * d].contiguous()
+
+    def encode(self, e1, rel, rows=None):
+        """step 2: h [B, d] on every rank; `rows` = ent_emb[e1] (step 1) or None to fetch them here"""
+        sc = self.scorer
+        if rows is None:
+            rows = self._allreduce(sc.gather_entities(e1))
+        rel_np = np.asarray(rel.cpu() if isinstance(rel, torch.Tensor) else rel)
+        e1_np = np.asarray(e1.cpu() if isinstance(e1, torch.Tensor) else e1)
+        B = len(rel_np)
         if self.world == 1 or not self.split_encoder:
-            h = sc.encode(e1, rel, e1_rows=rows)
-            return self._allreduce(h) if self.world == 1 else h   # one rank: the sum over ranks of a single share
-        mine = np.nonzero(rel_np % self.world == self.rank_id)[0]               # step 2
-        h = torch.zeros((len(rel_np), rows.shape[1]), dtype=torch.float32, device=rows.device)
+            h = sc.encode(e1_np, rel_np, e1_rows=rows)
+            if self.world == 1 and self.dist:          # one rank: the gather of a single share (keeps the RCCL path exercised)
+                out = torch.empty_like(h)
+                dist.all_gather_into_tensor(out, h.contiguous(), group=self.group)
+                h = out
+            return h
+        # the relation split is known to every rank (ids are replicated): shares, their order, the largest one
+        owner = rel_np % self.world
+        order = np.argsort(owner, kind="stable")
+        counts = np.bincount(owner, minlength=self.world)
+        cap = int(counts.max())
+        mine = order[int(counts[:self.rank_id].sum()):int(counts[:self.rank_id + 1].sum())]
+        buf = torch.zeros((cap, rows.shape[1]), dtype=torch.float32, device=rows.device)
         if len(mine):
             sel = torch.as_tensor(mine, device=rows.device)
-            h_loc = sc.encode(np.asarray(e1)[mine], rel_np[mine], e1_rows=rows.index_select(0, sel).contiguous())
-            h.index_copy_(0, sel, h_loc)
-        return self._allreduce(h)
+            buf[:len(mine)] = sc.encode(e1_np[mine], rel_np[mine], e1_rows=rows.index_select(0, sel).contiguous())
+        out = torch.empty((self.world * cap, rows.shape[1]), dtype=torch.float32, device=rows.device)
+        dist.all_gather_into_tensor(out, buf, group=self.group)
+        # share g sits at rows [g cap, g cap + counts[g]); `order` lists the queries share by share
+        take = np.concatenate([g * cap + np.arange(counts[g]) for g in range(self.world)])
+        h = torch.empty((B, rows.shape[1]), dtype=torch.float32, device=rows.device)
+        h.index_copy_(0, torch.as_tensor(order, device=rows.device), out.index_select(0, torch.as_tensor(take, device=rows.device)))
+        return h
 
     def rank(self, chunk, k=0):
         """Returns (ranks, n_equal) int32 [B]; with k > 0 also the global top-k of the filtered rows
         (topk_val f32 [B,k], topk_idx int64 [B,k]), merged from the per-shard top-k in (score desc, id asc) order."""
         sc = self.scorer
-        h = self.encode(chunk["e1"], chunk["rel"])
-        tgt = self._allreduce(sc.target_scores(h, chunk["e2"]))                  # step 3
+        rows1, rows2, bias2 = self._gather_rows(chunk["e1"], chunk["e2"])        # step 1
+        h = self.encode(chunk["e1"], chunk["rel"], rows=rows1)                    # step 2
+        tx = sc.score_rows(h, rows2, bias2)          # the targets by the fp32 chain, on every rank from its own copy of the rows
+        tgt = torch.stack([tx, tx])
         out = sc.rank_counts(h, tgt, chunk["e2"], chunk["filt_indptr"], chunk["filt_idx"],
                              filt_nnz=len(chunk["filt_idx"]), k=k)
         ng, ne = out[0], out[1]
-        # step 4: ONE all-gather of the packed per-shard record: [ng<<32 | ne, k score bit patterns, k ids]
+        # step 3: ONE all-gather of the packed per-shard record: [ng<<32 | ne, k score bit patterns, k ids]
         B = ng.shape[0]
         rec = torch.empty((B, 1 + 2 * k), dtype=torch.int64, device=ng.device)
         rec[:, 0] = (ng.to(torch.int64) << 32) | ne.to(torch.int64)

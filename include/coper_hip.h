@@ -154,9 +154,18 @@ COPER_API int coper_score_all(coper_handle* h, const float* hvec, int64_t B, flo
 COPER_API int coper_score_lookup(coper_handle* h, const float* hvec, const int32_t* lookup, int64_t B, int64_t L,
                        float* out, void* stream);
 
-/* Target scores: tgt[b] = logit(b, e2[b]) if e2[b] is in the shard else 0, bit-identical to
- * the value coper_score_all writes for that element (metrics.py:44). */
+/* Target scores, tgt: float [2 B].  tgt[b] = logit(b, e2[b]) in the mode's own arithmetic, bit-identical to the value
+ * coper_score_all writes for that element (metrics.py:44); tgt[B + b] = the same logit by the fp32 chain of COPER_SCORE_F32
+ * (equal to tgt[b] in that mode): what the x3 mode's exact band decides close comparisons against.  Entries whose e2 is not
+ * in the shard are 0 in both halves: the sum over shards is the full result. */
 COPER_API int coper_target_scores(coper_handle* h, const float* hvec, const int64_t* e2, int64_t B, float* tgt, void* stream);
+
+/* out[b] = pred_bias_b + rows[b] . hvec[b] by the fp32 chain, for entity rows the caller holds (rows float [B, d], bias float
+ * [B]): entity-sharded evaluation gathers ent_emb[e2] and pred_bias[e2] together with ent_emb[e1] in ONE all-reduce and
+ * every rank then scores the targets from its copy -- no exchange of target logits (coper_amd/sharding.py; SURVEY 8(e)
+ * step 1).  {out, out} is a valid `tgt` for coper_rank_counts. */
+COPER_API int coper_score_rows(coper_handle* h, const float* hvec, const float* rows, const float* bias, int64_t B, float* out,
+                               void* stream);
 
 /* Replaces the host ranker loop of ranking_and_hits (metrics.py:44-50) without materialising
  * logits: for every query b over the shard's entities j, with the known-answer filter given
@@ -168,7 +177,9 @@ COPER_API int coper_target_scores(coper_handle* h, const float* hvec, const int6
  * [1+n_greater, 1+n_greater+n_equal] under ties -- the reference's np.argsort is unstable).
  * n_equal may be NULL: ties are then not counted (the reference never computes them; saves one compare per
  * score) and rank = 1 + n_greater is the optimistic end of the band.
- * tgt: [B] global target scores (from coper_target_scores, summed over shards).
+ * tgt: [2 B] global target scores (from coper_target_scores, summed over shards; or {t, t} from coper_score_rows): the count
+ *   kernel of the x3 mode leaves every comparison closer than its own error (the band around tgt[b]) to the fp32 chain, which
+ *   compares against tgt[B + b]: n_greater / n_equal of both modes are those of the fp32 chain on hvec.
  * filt_nnz = filt_indptr[B], passed from the host that built the CSR (sizes the launch).
  * k > 0 additionally returns the shard's top-k of the FILTERED row (target kept, like
  * metrics.py:46), order (score desc, id asc): topk_val [B,k] (-inf padded), topk_idx [B,k]

@@ -31,6 +31,18 @@ class OracleShardScorer(object):
         st = O.forward(p, self.md, e1, rel, np.float32, materialise=False)
         return torch.from_numpy(np.ascontiguousarray(st["h"]))
 
+    def gather_bias(self, ids):
+        ids = np.asarray(ids)
+        out = np.zeros(len(ids), np.float32)
+        own = (ids >= self.lo) & (ids < self.hi)
+        out[own] = self.b[ids[own] - self.lo]
+        return torch.from_numpy(out)
+
+    def score_rows(self, h, rows, bias):
+        h, rows, bias = h.numpy(), rows.numpy(), bias.numpy()
+        out = np.array([O.score_chain(h[b:b + 1], rows[b:b + 1], bias[b:b + 1])[0, 0] for b in range(len(h))], np.float32)
+        return torch.from_numpy(out)
+
     def target_scores(self, h, e2):
         e2 = np.asarray(e2)
         h = h.numpy()
@@ -44,6 +56,8 @@ class OracleShardScorer(object):
         logits = O.score_chain(h.numpy(), self.E, self.b)
         e2, ip, ix = np.asarray(e2), np.asarray(filt_indptr), np.asarray(filt_idx)
         t = tgt.numpy()
+        if t.ndim == 2:          # the [2, B] form of the product scorer: comparisons are against the exact-chain targets
+            t = t[1]
         B = len(e2)
         ng, ne = np.zeros(B, np.int32), np.zeros(B, np.int32)
         for b in range(B):

@@ -100,18 +100,18 @@ def test_bench_finds_the_committed_pmc_summaries():
     """bench.py replays HBM bytes per launch and the matrix-pipe busy fraction from the committed rocprofv3 summaries
     (profiles/): the kernels it names must be the ones the summaries hold, with their provenance."""
     import bench
-    assert bench.score_kernel_name("bf16x3", 200) == "k_score_count2_bf16x3" and bench.score_kernel_name("bf16x3", 256) == "k_score_count2_bf16x3"
-    assert bench.score_kernel_name("bf16x3", 32) == "k_score_count_bf16x3" and bench.score_kernel_name("f32", 200) == "k_score_count_f32"
+    assert bench.score_kernel_name("bf16x3", 200) == "k_score_count3_bf16x3" and bench.score_kernel_name("bf16x3", 32) == "k_score_count3_bf16x3"
+    assert bench.score_kernel_name("f32", 200) == "k_score_count_f32"
     e = {}
-    bench.pmc_traffic(e, "fb15k237_cpg", 20480, "coper::k_score_count2_bf16x3")
+    bench.pmc_traffic(e, "fb15k237_cpg", 20480, "coper::k_score_count3_bf16x3")
     assert e["traffic"] and e["traffic"] < 1e9 and e["traffic_source"].startswith("profiles/")
-    bench.pmc_mfma_busy(e, "fb15k237_cpg", 20480, "coper::k_score_count2_bf16x3")
+    bench.pmc_mfma_busy(e, "fb15k237_cpg", 20480, "coper::k_score_count3_bf16x3")
     assert 0.5 < e["pmc"]["mfma_busy_frac"] < 1.0 and "profiles/" in e["pmc"]["source"]
     d = {}
     bench.pmc_traffic(d, "fb15k237_cpg", 20480, "coper::k_dense_fused_bf16x3")
     assert 0.9e9 < d["traffic"] < 1.2e9
     h = {}
-    bench.pmc_traffic(h, "synth10m_cpg", 128, "coper::k_score_count2_bf16x3", exact="coper::k_score_count2_bf16x3<16, 6, true, false>")
+    bench.pmc_traffic(h, "synth10m_cpg", 128, "coper::k_score_count3_bf16x3", exact="coper::k_score_count3_bf16x3<8, 0, 2, false>")
     assert 1.0e10 < h["traffic"] < 1.15e10        # the 10M x 256 table read once: PMC bytes within 1.1x of the algorithmic 10.28 GB
     none = {}
     bench.pmc_traffic(none, "no_such_workload", 1, "coper::k_nothing")
