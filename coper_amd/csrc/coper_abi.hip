@@ -191,6 +191,9 @@ static int ensure_workspace(coper_handle* h, int64_t B, int64_t nnz, hipStream_t
       return fail(h, COPER_ENOMEM, "hipMalloc of the bf16 query planes failed");
     COPER_HIP_TRY(h, hipMemsetAsync(h->hf3_ws, 0, f3, s));     // the zero halves of its tail registers are never written again
     if ((rc = dev_alloc(h, &h->tband_ws, 2 * (size_t)((cap + 127) / 128 * 128))) || (rc = dev_alloc(h, &h->tgtx_ws, cap))) return rc;
+    const size_t n_heavy = (size_t)(cap / 32 + 8);
+    if ((rc = dev_alloc(h, &h->heavy_ws, n_heavy))) return rc;
+    COPER_HIP_TRY(h, hipMemsetAsync(h->heavy_ws, 0, sizeof(int32_t) * n_heavy, s));   // the excess kernel leaves it zero again
   }
   h->ws_queries = cap;
   h->ws_ksplit = KSPLIT_MAX;
@@ -340,7 +343,7 @@ COPER_API void coper_destroy(coper_handle* h) {
   dev_free((char**)&h->Ef16_hi); dev_free((char**)&h->Ef16_lo); dev_free((char**)&h->hfrag16_hi); dev_free((char**)&h->hfrag16_lo);
   dev_free((char**)&h->Erm16_hi); dev_free((char**)&h->Erm16_lo); dev_free((char**)&h->hrm16_hi); dev_free((char**)&h->hrm16_lo);
   dev_free((char**)&h->Ef3); dev_free((char**)&h->hf3_ws); dev_free((char**)&h->mask_ws); dev_free(&h->band_consts); dev_free(&h->tband_ws);
-  dev_free(&h->tgtx_ws);
+  dev_free(&h->tgtx_ws); dev_free(&h->heavy_ws);
   for (auto& kv : h->timers)
     for (auto& p : kv.second.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   for (auto e : h->event_pool) (void)hipEventDestroy(e);
@@ -810,7 +813,7 @@ COPER_API int coper_encode_rank(coper_handle* h, const int64_t* e1, const int64_
     // decision of the band add to it
     {
       ScopedKernelTimer t(h, "tail", s);
-      if ((rc = launch_finalize_targets_filter_bf16x3(h, B, ksplit, hv, e2, filt_indptr, filt_idx, h->tgt_ws, ranks, s))) return rc;
+      if ((rc = launch_finalize_targets_filter_bf16x3(h, B, ksplit, hv, e2, filt_indptr, filt_idx, filt_nnz, h->tgt_ws, ranks, s))) return rc;
     }
     h->counts_preset = ranks;
     h->count_base = 1;

@@ -154,6 +154,8 @@ struct coper_handle {
   int64_t packed_B = 0;
   bool trust_packed = false;
   int32_t* row_of_ws = nullptr;   // bf16x3: CSR entry -> query row [nnz]
+  int32_t* heavy_ws = nullptr;    // fused tail: [0] number of listed blocks, [1] finished workgroups, [2..] 32-query blocks whose CSR entries
+                                  //   exceed what their workgroup corrects itself (k_filter_excess_bf16x3); zero between passes
   int64_t row_of_cap = 0;
   float* hfrag_ws = nullptr;      // h re-packed in MFMA-fragment order [ceil(B/128)*4][KS][64] float4
   int num_cus = 256;
@@ -260,7 +262,7 @@ float band_kappa(const coper_handle* h);
 // kernels_tail_bf16.hip: finalize + targets + filter correction of a ranking pass in one launch
 bool tail_fused_supported(const coper_handle* h);
 int launch_finalize_targets_filter_bf16x3(coper_handle* h, int64_t B, int ksplit, float* h_out, const int64_t* e2, const int64_t* indptr,
-                                          const int64_t* idx, float* tgt, int32_t* ranks, hipStream_t s);
+                                          const int64_t* idx, int64_t nnz, float* tgt, int32_t* ranks, hipStream_t s);
 void score_count_begin_f32(coper_handle* h, const float* hvec, int64_t B, int32_t* ng, int32_t* ne, hipStream_t s);
 int score_count_chunk_f32(coper_handle* h, int64_t q0, int64_t Bc, const float* tgt, int32_t* ng, int32_t* ne, float* gmax,
                           int64_t gm_stride, hipStream_t s);

@@ -328,13 +328,14 @@ class ConvE(object):
                                                         nnz, B, _ptr(h), _ptr(ranks), _ptr(ne), self._stream()))
         return (ranks, ne, h) if want_h else (ranks, ne)
 
-    def capture_rank_pass(self, B, max_nnz):
+    def capture_rank_pass(self, B, max_nnz, want_equal=True):
         """hipGraph capture of one encode -> fused-rank pass for batches of exactly B queries (the reference's
         per-`session.run` batch, B = 512, is launch-bound: ~14 kernel launches per batch).  Returns
         `run(e1, rel, e2, filt_indptr, filt_idx) -> (ranks, n_equal)`; the id / CSR arguments are copied into
         static device buffers (CSR padded to `max_nnz` entries), the graph is replayed, and the outputs are
         static tensors valid until the next replay.  Every coper_* call inside is allocation-free after
-        `reserve`, which is what makes the sequence capturable."""
+        `reserve`, which is what makes the sequence capturable.  want_equal=False: ranks only (what the reference
+        computes) -- in the bf16x3 mode the shorter sequence with the fused tail kernel; n_equal is then None."""
         self._need_prepared()
         self.reserve(B, max_nnz)
         dev = self.device
@@ -349,7 +350,8 @@ class ConvE(object):
             # is sized by max_nnz: entries past indptr[B] belong to no query and are skipped
             _lib.check(self._h, self._lib.coper_encode_rank(self._h, _ptr(st["e1"]), _ptr(st["rel"]), None, _ptr(st["e2"]),
                                                             _ptr(st["ip"]), _ptr(st["ix"]), max_nnz, B, _ptr(st["h"]),
-                                                            _ptr(st["ranks"]), _ptr(st["ne"]), self._stream()))
+                                                            _ptr(st["ranks"]), _ptr(st["ne"]) if want_equal else None,
+                                                            self._stream()))
 
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -370,7 +372,7 @@ class ConvE(object):
             st["ip"].copy_(self._ids(filt_indptr))
             st["ix"][:n].copy_(ix)
             graph.replay()
-            return st["ranks"], st["ne"]
+            return st["ranks"], (st["ne"] if want_equal else None)
 
         run.graph = graph
         return run

@@ -44,26 +44,12 @@ def shard_bounds(num_ent: int, world: int, rank: int):
 def local_rank_pass(model, chunk, want_equal=False):
     """Unsharded: encode + fused filtered rank for one chunk of queries.  Returns (ranks, n_equal) int32 tensors;
     n_equal is None unless asked for (ranking_and_hits, like the reference, has no use for tie counts)."""
-    if hasattr(model, "rank_pass") and not _heavy_filter_rows(chunk["filt_indptr"]):    # one call per chunk (coper_encode_rank)
+    if hasattr(model, "rank_pass"):    # one call per chunk (coper_encode_rank); the library itself spreads blocks with
+        # thousands of known answers over the chip (k_filter_excess_bf16x3), so there is nothing to route here
         return model.rank_pass(chunk["e1"], chunk["rel"], chunk["e2"], chunk["filt_indptr"], chunk["filt_idx"],
                                filt_nnz=len(chunk["filt_idx"]), want_equal=want_equal)
     h = model.encode(chunk["e1"], chunk["rel"])   # scorers that expose only the two-call protocol
     return model.rank(h, chunk["e2"], chunk["filt_indptr"], chunk["filt_idx"], filt_nnz=len(chunk["filt_idx"]))
-
-
-HEAVY_BLOCK_ENTRIES = 1024     # known answers of one 32-query block above which the two-call path is taken
-
-
-def _heavy_filter_rows(indptr):
-    """coper_encode_rank's fused tail kernel gives every block of 32 queries to one workgroup, filter entries included: a
-    block with thousands of known answers (real KGs have (e1, rel) pairs with that many tails; the SURVEY's synthetic
-    filters stop at 64 per query) would serialise ~7 us per 128 entries inside that workgroup.  Such passes take the
-    two-call path, whose filter correction is dealt over the whole grid entry by entry.  Same ranks either way."""
-    if not isinstance(indptr, np.ndarray) or len(indptr) < 2:
-        return False
-    edges = indptr[::32]
-    per_block = np.diff(np.append(edges, indptr[-1]))
-    return bool(per_block.max() > HEAVY_BLOCK_ENTRIES)
 
 
 def _slice_chunk(chunk, lo, hi):

@@ -201,10 +201,9 @@ COPER_API int coper_rank(coper_handle* h, const float* hvec, const int64_t* e2, 
  * reference's ranker loop computes (metrics.py:40-57).  h_out: optional float [B, d] (NULL: the embedding is
  * not needed; in the bf16x3 mode it then never exists in fp32 -- the dense finalize writes the operand planes
  * of the rank kernels directly).  Same results as the two calls, bit for bit.
- * Cost model of the filter: the bf16x3 mode handles the known answers of 32 consecutive queries inside one workgroup; a
- * batch in which 32 consecutive queries hold thousands of them (one (e1, rel) with 5,000 known tails: +0.16 ms) is served
- * better by coper_encode + coper_rank, whose correction is dealt over the whole grid (coper_amd.metrics.ranking_and_hits
- * makes that choice from the CSR it holds on the host). */
+ * Cost model of the filter: in the bf16x3 mode the workgroup that finalizes 32 consecutive queries also takes back their
+ * known answers, the first 352 CSR entries of the block; entries beyond that (one (e1, rel) with 5,000 known tails) are
+ * dealt over the whole chip by a second launch that costs ~2 us when no block needs it.  Callers have nothing to route. */
 COPER_API int coper_encode_rank(coper_handle* h, const int64_t* e1, const int64_t* rel, const float* e1_rows,
                                 const int64_t* e2, const int64_t* filt_indptr, const int64_t* filt_idx, int64_t filt_nnz,
                                 int64_t B, float* h_out, int32_t* ranks, int32_t* n_equal, void* stream);

@@ -1,0 +1,137 @@
+"""coper_encode_rank called the way a foreign host binds it (include/coper_hip.h): raw device pointers and sizes through
+ctypes, no routing by coper_amd's Python.  Filters with thousands of known answers inside one block of 32 queries -- the
+case round 2 routed away from this entry point in Python: the library now spreads what exceeds a
+workgroup's own share of its block over the chip (k_filter_excess_bf16x3).  Ranks must equal the closed form of
+metrics.py:40-57 on the rank-defining logits AND the two-call path (coper_encode + coper_rank), bit for bit."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from coper_amd import data as cdata
+from tests.helpers import rank_defining_logits
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a, dtype):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to("cuda:0")
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _encode_rank(m, e1, rel, e2, indptr, idx, want_equal):
+    from coper_amd import _lib
+    B = len(rel)
+    d_e1, d_rel, d_e2 = _dev(e1, torch.int64), _dev(rel, torch.int64), _dev(e2, torch.int64)
+    d_ip, d_ix = _dev(indptr, torch.int64), _dev(idx if len(idx) else np.zeros(1, np.int64), torch.int64)
+    ranks = torch.full((B,), -7, dtype=torch.int32, device="cuda:0")
+    ne = torch.full((B,), -7, dtype=torch.int32, device="cuda:0") if want_equal else None
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = m._lib.coper_encode_rank(m._h, _p(d_e1), _p(d_rel), None, _p(d_e2), _p(d_ip), _p(d_ix), int(indptr[-1]), B, None, _p(ranks),
+                                  _p(ne), stream)
+    _lib.check(m._h, rc)
+    torch.cuda.synchronize()
+    return ranks.cpu().numpy()
+
+
+def _two_calls(m, e1, rel, e2, indptr, idx):
+    from coper_amd import _lib
+    B = len(rel)
+    d_e1, d_rel, d_e2 = _dev(e1, torch.int64), _dev(rel, torch.int64), _dev(e2, torch.int64)
+    d_ip, d_ix = _dev(indptr, torch.int64), _dev(idx if len(idx) else np.zeros(1, np.int64), torch.int64)
+    h = torch.empty((B, m.ent_emb_size), dtype=torch.float32, device="cuda:0")
+    ranks = torch.empty((B,), dtype=torch.int32, device="cuda:0")
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(m._h, m._lib.coper_encode(m._h, _p(d_e1), _p(d_rel), B, None, _p(h), stream))
+    _lib.check(m._h, m._lib.coper_rank(m._h, _p(h), _p(d_e2), _p(d_ip), _p(d_ix), int(indptr[-1]), B, _p(ranks), None, stream))
+    torch.cuda.synchronize()
+    return ranks.cpu().numpy(), h
+
+
+def _csr(rows):
+    indptr = np.zeros(len(rows) + 1, np.int64)
+    indptr[1:] = np.cumsum([len(r) for r in rows])
+    return indptr, (np.concatenate(rows) if indptr[-1] else np.zeros(0, np.int64)).astype(np.int64)
+
+
+HEAVY_CASES = {
+    # name: (queries, [(query, known answers to add)], every query of these blocks gets `per_query` more)
+    "one_row_of_5000":            (200, [(7, 5000)], None),
+    "rows_across_a_block_edge":   (200, [(31, 3000), (32, 4000), (150, 2000)], None),
+    "whole_block_of_medium_rows": (200, [], (1, 300)),          # block 1: 32 queries x 300 entries = 9,600, none long by itself
+    "last_partial_block":         (77, [(70, 5000), (76, 2500)], None),
+    "every_block_listed":         (130, [(b, 1500) for b in range(0, 130, 32)], None),
+    "exactly_the_own_share":      (64, [], None),                # block 0 trimmed to 352 and block 1 to 353 entries below: only block 1 is listed
+    "single_query":               (1, [(0, 4000)], None),
+}
+
+
+@pytest.mark.parametrize("workload", ["fb15k237_cpg", "synth10m_cpg"])     # 13 and 16 k-steps: both instantiations of the tail kernels
+@pytest.mark.parametrize("case", sorted(HEAVY_CASES))
+def test_encode_rank_with_heavy_filter_blocks_through_the_c_abi(oracle_chain, workload, case):
+    from coper_amd.models import ConvE
+    Q, adds, block_fill = HEAVY_CASES[case]
+    md = cdata.model_descriptors(workload, num_ent=6000, num_rel=20)
+    params = cdata.synthetic_params(md, 3)
+    m = ConvE(md, device="cuda:0", score_mode="bf16x3").load_parameters(params).prepare()
+    E = md["num_ent"]
+    q = cdata.synthetic_queries(md, Q, seed=11)
+    rng = np.random.default_rng(21)
+    rows = [q["filt_idx"][q["filt_indptr"][i]:q["filt_indptr"][i + 1]] for i in range(Q)]
+    for i, n in adds:
+        rows[i] = np.unique(np.concatenate([rows[i], rng.choice(E, n, replace=False)]))
+    if block_fill:
+        blk, per = block_fill
+        for i in range(32 * blk, min(Q, 32 * blk + 32)):
+            rows[i] = np.unique(np.concatenate([rows[i], rng.choice(E, per, replace=False)]))
+    if case == "exactly_the_own_share":
+        for i in range(64):
+            rows[i] = np.unique(rng.choice(E, 40, replace=False))[:11 + (i == 40)]
+        assert sum(len(r) for r in rows[:32]) == 352 and sum(len(r) for r in rows[32:]) == 353
+    # what the dense mask of metrics.py:40-46 tolerates: the target inside its own row, and repeated ids (sorted: adjacent)
+    for i in range(0, Q if case != "exactly_the_own_share" else 0, 3):
+        rows[i] = np.sort(np.concatenate([rows[i], [q["e2"][i]], rows[i][:5]]))
+    indptr, idx = _csr(rows)
+
+    two, h = _two_calls(m, q["e1"], q["rel"], q["e2"], indptr, idx)
+    logits = rank_defining_logits(oracle_chain, m, h, params)
+    keep = ~cdata.csr_to_dense_filter(indptr, idx, E).astype(bool)
+    keep[np.arange(Q), q["e2"]] = False
+    tgt = logits[np.arange(Q), q["e2"]]
+    want = 1 + ((logits > tgt[:, None]) & keep).sum(axis=1)
+    assert np.array_equal(two, want)
+    for rep in range(3):      # the list of blocks empties itself: the second and third pass start clean
+        assert np.array_equal(_encode_rank(m, q["e1"], q["rel"], q["e2"], indptr, idx, want_equal=False), want), rep
+    assert np.array_equal(_encode_rank(m, q["e1"], q["rel"], q["e2"], indptr, idx, want_equal=True), want)
+    # a light pass after heavy ones on the same handle (nothing may be left in the list)
+    light = cdata.synthetic_queries(md, Q, seed=12)
+    a = _encode_rank(m, light["e1"], light["rel"], light["e2"], light["filt_indptr"], light["filt_idx"], want_equal=False)
+    b, _ = _two_calls(m, light["e1"], light["rel"], light["e2"], light["filt_indptr"], light["filt_idx"])
+    assert np.array_equal(a, b)
+    m.close()
+
+
+def test_heavy_blocks_inside_a_captured_graph(oracle_chain):
+    """The excess launch is part of the captured sequence (sized by the capacity the capture was given) and its list is
+    emptied on the device: replays with heavy and light CSRs alternate correctly."""
+    from coper_amd.models import ConvE
+    md = cdata.model_descriptors("fb15k237_cpg", num_ent=6000, num_rel=20)
+    params = cdata.synthetic_params(md, 3)
+    m = ConvE(md, device="cuda:0", score_mode="bf16x3").load_parameters(params).prepare()
+    B, E = 96, md["num_ent"]
+    rng = np.random.default_rng(5)
+    run = m.capture_rank_pass(B, 12000, want_equal=False)      # ranks only: the sequence with the fused tail kernel
+    for rep in range(4):
+        q = cdata.synthetic_queries(md, B, seed=30 + rep)
+        rows = [q["filt_idx"][q["filt_indptr"][i]:q["filt_indptr"][i + 1]] for i in range(B)]
+        if rep % 2 == 0:
+            rows[40 + rep] = np.unique(np.concatenate([rows[40 + rep], rng.choice(E, 5000, replace=False)]))
+        indptr, idx = _csr(rows)
+        got = run(q["e1"], q["rel"], q["e2"], indptr, idx)[0].cpu().numpy()
+        want, _ = _two_calls(m, q["e1"], q["rel"], q["e2"], indptr, idx)
+        assert np.array_equal(got, want), rep
+    m.close()

@@ -208,9 +208,9 @@ def test_reference_style_dense_mask_batches():
 
 @pytest.mark.parametrize("mode", ["bf16x3", "f32"])
 def test_filter_rows_with_thousands_of_known_answers(oracle_chain, mode):
-    """A query whose filter list holds most of the entity table (real KGs have such (e1, rel) pairs): the pass takes the
-    balanced two-call path (sharding._heavy_filter_rows) and both it and the fused call give the closed-form ranks."""
-    from coper_amd import sharding
+    """A query whose filter list holds most of the entity table (real KGs have such (e1, rel) pairs): coper_encode_rank
+    with and without tie counts (ranks only = the fused tail kernel, whose workgroup keeps the first 352 entries of its
+    block and lists the block for k_filter_excess_bf16x3) and the evaluation loop give the closed-form ranks."""
     from coper_amd.metrics import ranking_and_hits
     from coper_amd.models import ConvE
     md = cdata.model_descriptors("fb15k237_cpg", num_ent=6000, num_rel=20)
@@ -224,7 +224,6 @@ def test_filter_rows_with_thousands_of_known_answers(oracle_chain, mode):
     indptr = np.zeros(Q + 1, np.int64)
     indptr[1:] = np.cumsum([len(r) for r in rows])
     idx = np.concatenate(rows)
-    assert sharding._heavy_filter_rows(indptr)
     h = m.encode(q["e1"], q["rel"])
     logits = rank_defining_logits(oracle_chain, m, h, cdata.synthetic_params(md, 2))
     mask = cdata.csr_to_dense_filter(indptr, idx, E).astype(bool)
@@ -234,6 +233,9 @@ def test_filter_rows_with_thousands_of_known_answers(oracle_chain, mode):
     want = 1 + ((logits > tgt[:, None]) & keep).sum(axis=1)
     fused, _ = m.rank_pass(q["e1"], q["rel"], q["e2"], indptr, idx)
     assert np.array_equal(fused.cpu().numpy(), want)
+    for _ in range(3):       # (the excess list empties itself: every pass starts from zero)
+        only, none = m.rank_pass(q["e1"], q["rel"], q["e2"], indptr, idx, want_equal=False)
+        assert none is None and np.array_equal(only.cpu().numpy(), want)
     batches = [dict(e1=q["e1"], e2=q["e2"], rel=q["rel"], filt_indptr=indptr, filt_idx=idx)]
     out = ranking_and_hits(m, None, iter(batches), "heavy", return_ranks=True)
     assert np.array_equal(out[3], want)

@@ -134,7 +134,9 @@ def test_unsorted_filter_rows_are_sorted_before_the_kernels_see_them():
     assert q["filt_idx"].tolist() == [2, 5, 9, 1, 4] and q["filt_indptr"].tolist() == [0, 3, 5]
 
 
-def test_heavy_filter_rows_take_the_two_call_path():
+def test_one_fused_call_per_chunk_whatever_the_filter_rows_hold():
+    """Round 2 routed passes with thousands of known answers per 32-query block to the two-call path in Python; since round 3
+    coper_encode_rank deals such blocks over the chip itself, so local_rank_pass always makes the one call."""
     from coper_amd import sharding
     calls = []
 
@@ -146,14 +148,17 @@ def test_heavy_filter_rows_take_the_two_call_path():
         def rank(self, h, e2, ip, ix, filt_nnz=None):
             calls.append("rank"); return "r", "ne"
 
+    class TwoCall:
+        encode, rank = M.encode, M.rank
+
     light = np.arange(0, 5 * 101, 5)                       # 100 queries, 5 entries each
     heavy = light.copy(); heavy[40:] += 3000               # one query with 3,000 known answers
     z = np.zeros(100, np.int64)
     sharding.local_rank_pass(M(), dict(e1=z, rel=z, e2=z, filt_indptr=light, filt_idx=np.zeros(light[-1], np.int64)))
     sharding.local_rank_pass(M(), dict(e1=z, rel=z, e2=z, filt_indptr=heavy, filt_idx=np.zeros(heavy[-1], np.int64)))
-    assert calls == ["fused", "encode", "rank"]
-    assert not sharding._heavy_filter_rows(np.array([0])) and not sharding._heavy_filter_rows(np.array([0, 1024]))
-    assert sharding._heavy_filter_rows(np.array([0, 1025]))
+    sharding.local_rank_pass(TwoCall(), dict(e1=z, rel=z, e2=z, filt_indptr=heavy, filt_idx=np.zeros(heavy[-1], np.int64)))
+    assert calls == ["fused", "fused", "encode", "rank"]
+    assert not hasattr(sharding, "_heavy_filter_rows")
 
 
 def test_bench_self_launch_propagates_a_failing_rank():
