@@ -122,8 +122,14 @@ __device__ __forceinline__ void sc3_value(SC3<NP, TAIL, PD, GM>& S, const int la
   if constexpr (GM) {   // block maxima per (32 entities, query): the eight values of two consecutive 16-row blocks
     if constexpr ((V & 7) == 0) S.mx = sc; else S.mx = fmaxf(S.mx, sc);
     if constexpr ((V & 7) == 7) {
-      float mxx = fmaxf(S.mx, __shfl_xor(S.mx, 16));          // the other rows of the 32-entity block
-      mxx = fmaxf(mxx, __shfl_xor(mxx, 32));
+      // the other rows of the 32-entity block sit in lanes + 16, + 32, + 48: two lane swaps inside the vector unit
+      // (v_permlane32_swap / v_permlane16_swap).  __shfl_xor goes through the LDS pipe (ds_bpermute) and its wait fell on
+      // the query-fragment reads in flight: the maxima cost the 10M-entity launch 9 ms of 49.
+      const unsigned u = __float_as_uint(S.mx);
+      const auto s32 = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+      const unsigned v = __float_as_uint(fmaxf(__uint_as_float(s32[0]), __uint_as_float(s32[1])));
+      const auto s16 = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+      const float mxx = fmaxf(__uint_as_float(s16[0]), __uint_as_float(s16[1]));
       if (store_ok && lane < 16) gm_row[(m2 >> 1) * S.gm_stride + gm_col + b * 16 + lane] = mxx;
     }
   }
@@ -299,14 +305,28 @@ __global__ __launch_bounds__(256, 1) void k_score_count3_bf16x3(const uint4* __r
                                                                  int64_t B, int64_t rows_per_tile, int64_t total_rows,
                                                                  int32_t* __restrict__ ng, uint4* __restrict__ mask,
                                                                  unsigned long long* __restrict__ summ,
-                                                                 float* __restrict__ gmax, int64_t gm_stride) {
+                                                                 float* __restrict__ gmax, int64_t gm_stride, int64_t rows_per_item) {
   typedef SC3<NP, TAIL, PD, GM> ST;
   constexpr int NS = ST::NS, NB = ST::NB, NV = ST::NV;
   static_assert(PD <= NS, "the prefetch reaches at most one half-row ahead");
   extern __shared__ uint4 hl3[];  // [NB][NS][2][64]
   constexpr int TILE_REGS = NB * NS * 2;          // KiB of a query tile
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int64_t r_begin = total_rows * blockIdx.x / gridDim.x, r_end = total_rows * (blockIdx.x + 1) / gridDim.x;
+  // Two ways to deal the rows (a row: this workgroup's 8 entity blocks against one query tile):
+  //  rows_per_item == 0: an equal contiguous share for each of num_cus workgroups -- entity tables that L2 / MALL hold whole;
+  //  rows_per_item  > 0: one workgroup per item of that many rows of one tile, numbered so that the items of an XCD
+  //    (workgroups reach the XCDs round-robin: blockIdx & 7) run through the tiles of one chunk of entity rows before the
+  //    next chunk.  Workgroups start in blockIdx order, so those of an XCD stream the same entity rows at the same time
+  //    however long the launch runs.  With the static split the 16 workgroups on one stretch of a 10M-row table drifted
+  //    apart over their 20 ms and L2 served half of what they shared (PMC: 80 GB fetched per launch for a 10 GB table).
+  int64_t r_begin = total_rows * blockIdx.x / gridDim.x, r_end = total_rows * (blockIdx.x + 1) / gridDim.x;
+  if (rows_per_item > 0) {
+    const int64_t n_tiles = total_rows / rows_per_tile;
+    const int64_t j = blockIdx.x >> 3;
+    const int64_t c = (blockIdx.x & 7) + 8 * (j / n_tiles), t = j % n_tiles;
+    r_begin = t * rows_per_tile + c * rows_per_item;
+    r_end = (c + 1) * rows_per_item < rows_per_tile ? r_begin + rows_per_item : (t + 1) * rows_per_tile;
+  }
   if (r_begin >= r_end) return;
 #ifdef COPER_DBG_CLOCK
   const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
@@ -716,6 +736,11 @@ static int sc3_go(coper_handle* h, int64_t q0, int64_t Bc, int32_t* ng, float* g
   const int64_t total_rows = q_tiles * rows_per_tile;
   int64_t grid = h->num_cus;
   if (grid > total_rows) grid = total_rows;
+  // items (the kernel's header): when several query tiles stream an entity table that L2 + MALL cannot hold
+  static const int64_t item_rows = getenv("COPER_SC3_ITEM_ROWS") ? atoll(getenv("COPER_SC3_ITEM_ROWS")) : 32;
+  const bool big = (size_t)dm.n_local * dm.d * 4 > ((size_t)128 << 20);
+  const int64_t rows_per_item = (big && q_tiles > 1 && item_rows > 0 && rows_per_tile >= 16 * item_rows) ? item_rows : 0;
+  if (rows_per_item) grid = ((rows_per_tile + rows_per_item - 1) / rows_per_item + 7) / 8 * 8 * q_tiles;
   const size_t lds = (size_t)8 * NS * 2 * 64 * sizeof(uint4);
   const uint4* hf3 = (const uint4*)h->hf3_ws + (q0 / 16) * NS * 2 * 64;
   static bool attr_done[16] = {};
@@ -726,7 +751,7 @@ static int sc3_go(coper_handle* h, int64_t q0, int64_t Bc, int32_t* ng, float* g
   }
   hipLaunchKernelGGL((k_score_count3_bf16x3<NP, TAIL, PD, GM>), dim3((unsigned)grid), dim3(256), lds, s, (const uint4*)h->Ef3, h->bias_pad, hf3,
                      (const float2*)h->tband_ws + q0, Bc, rows_per_tile, total_rows, ng + q0, (uint4*)h->mask_ws,
-                     (unsigned long long*)((char*)h->mask_ws + score_count3_mask_words_bytes(h, Bc)), gmax, gm_stride);
+                     (unsigned long long*)((char*)h->mask_ws + score_count3_mask_words_bytes(h, Bc)), gmax, gm_stride, rows_per_item);
   COPER_HIP_TRY(h, hipGetLastError());
   return COPER_OK;
 }
