@@ -68,7 +68,7 @@ struct SC3 {
   float thi[NB], tlo[NB];
   int cg[NB];
   unsigned mk[2 * MB], mg[2 * MB];                        // (logit >= t_lo) / (logit > t_hi): word MB M + (V >> 5), value V at bit 31 - (V & 31)
-  float mx;
+  float mx, px;
   const uint4* mask_base;                                 // (to find a row's summary word from its mask pointer)
   unsigned long long* summ_base;
   int64_t gm_stride;
@@ -120,16 +120,24 @@ __device__ __forceinline__ void sc3_value(SC3<NP, TAIL, PD, GM>& S, const int la
     S.mk[w] &= ~S.mg[w];
   }
   if constexpr (GM) {   // block maxima per (32 entities, query): the eight values of two consecutive 16-row blocks
-    if constexpr ((V & 7) == 0) S.mx = sc; else S.mx = fmaxf(S.mx, sc);
+    // two values per v_max3 (the kernel is bound by instruction issue: a v_max per value and the library fmaxf's quieting
+    // moves were a fifth of the top-k launch), written as instructions because the values come out of an asm block
+    if constexpr ((V & 1) == 0) {
+      S.px = sc;
+    } else if constexpr ((V & 7) == 1) {
+      asm volatile("v_max_f32 %0, %1, %2" : "=v"(S.mx) : "v"(S.px), "v"(sc));
+    } else {
+      asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(S.mx) : "v"(S.px), "v"(sc));
+    }
     if constexpr ((V & 7) == 7) {
       // the other rows of the 32-entity block sit in lanes + 16, + 32, + 48: two lane swaps inside the vector unit
-      // (v_permlane32_swap / v_permlane16_swap).  __shfl_xor goes through the LDS pipe (ds_bpermute) and its wait fell on
-      // the query-fragment reads in flight: the maxima cost the 10M-entity launch 9 ms of 49.
-      const unsigned u = __float_as_uint(S.mx);
-      const auto s32 = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-      const unsigned v = __float_as_uint(fmaxf(__uint_as_float(s32[0]), __uint_as_float(s32[1])));
-      const auto s16 = __builtin_amdgcn_permlane16_swap(v, v, false, false);
-      const float mxx = fmaxf(__uint_as_float(s16[0]), __uint_as_float(s16[1]));
+      // (v_permlane32_swap / v_permlane16_swap; __shfl_xor goes through the LDS pipe and its wait falls on the query-
+      // fragment reads in flight).  After "swap a, b" with a == b: a = {lower, lower}, b = {upper, upper} halves (rows).
+      float a = S.mx, b2 = S.mx, mxx;
+      // (a swap must not read a register a vector instruction wrote within the last two wait states: the s_nop 1)
+      asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_max_f32 %0, %0, %1\n\tv_mov_b32 %1, %0\n\ts_nop 1\n\t"
+                   "v_permlane16_swap_b32 %0, %1\n\tv_max_f32 %2, %0, %1"
+                   : "+v"(a), "+v"(b2), "=&v"(mxx));
       if (store_ok && lane < 16) gm_row[(m2 >> 1) * S.gm_stride + gm_col + b * 16 + lane] = mxx;
     }
   }
@@ -617,7 +625,13 @@ __device__ __forceinline__ void band_decide(const BandArgs& A, const int64_t q, 
   else if (A.ne && sx == tx) atomicAdd(&A.ne[q], 1);
 }
 
-constexpr int BE_CAP = 4096, BE_ITEMS = 2048;
+#ifndef COPER_BE_UPW
+#define COPER_BE_UPW 64
+#endif
+// units (rows of waves) per workgroup: a pair's walk is latency, so the launch is as long as the longest chain of walks one
+// thread makes; at FB15k-237 shapes 256 units gave a workgroup ~350 pairs for its 256 threads (two walks for many), 64
+// units give ~90 (one walk) and 290 workgroups instead of 73
+constexpr int BE_CAP = 4096, BE_ITEMS = 2048, BE_UPW = COPER_BE_UPW;
 __global__ __launch_bounds__(256) void k_band_exact(const uint4* __restrict__ mask, const unsigned long long* __restrict__ summ, int64_t n_units,
                                                     unsigned rows4 /* rows per tile x 4 waves */, BandArgs A) {
   constexpr int MB = SC3_MB, NW = 2 * MB;      // 32-bit mask words per lane and row of a wave
@@ -627,12 +641,12 @@ __global__ __launch_bounds__(256) void k_band_exact(const uint4* __restrict__ ma
   // three phases, each spread over all threads (a thread that walks its unit's lanes one after the other pays a round trip
   // per lane): a thread per unit (one wave's row of 32 MB entities x 128 queries) reads the summary and lists the lanes
   // that wrote mask words; a thread per listed lane fetches its words and lists the marked pairs; a thread per pair walks.
-  const int64_t unit0 = (int64_t)blockIdx.x * 256;
+  const int64_t unit0 = (int64_t)blockIdx.x * BE_UPW;
   if (threadIdx.x == 0) { s_n = 0; s_ni = 0; }
   __syncthreads();
   {
     const int64_t unit = unit0 + threadIdx.x;
-    unsigned long long lanes = unit < n_units ? summ[unit] : 0ull;
+    unsigned long long lanes = (threadIdx.x < BE_UPW && unit < n_units) ? summ[unit] : 0ull;
     while (lanes) {
       const int l = __builtin_ctzll(lanes);
       lanes &= lanes - 1;
@@ -692,7 +706,7 @@ __global__ __launch_bounds__(256) void k_band_exact(const uint4* __restrict__ ma
     // the lanes that did not fit the item list: every thread walks its own unit again and skips the lanes that were listed
     // (the list took them in no particular order, so the listed ones are looked up) -- correctness path, not a fast one
     const int64_t unit = unit0 + threadIdx.x;
-    unsigned long long lanes = unit < n_units ? summ[unit] : 0ull;
+    unsigned long long lanes = (threadIdx.x < BE_UPW && unit < n_units) ? summ[unit] : 0ull;
     for (int i = 0; i < BE_ITEMS; ++i)
       if ((s_it[i] >> 6) == (unsigned)threadIdx.x) lanes &= ~(1ull << (s_it[i] & 63u));
     const unsigned tile = (unsigned)unit / rows4, eb = ((unsigned)unit - tile * rows4) * 2;
@@ -801,7 +815,7 @@ int score_count3_chunk_bf16x3(coper_handle* h, int64_t q0, int64_t Bc, const flo
     { static const int dbg = getenv("COPER_DBG_BAND") ? atoi(getenv("COPER_DBG_BAND")) : 0; A.dbg = dbg; }
     const int64_t n_units = sc3_units(h, Bc);
     if (rows_per_tile * 4 > 0x7fffffffLL || n_units > 0x7fffffffLL) return fail(h, COPER_EUNSUPPORTED, "band mask beyond 2^31 units");
-    hipLaunchKernelGGL(k_band_exact, dim3((unsigned)((n_units + 255) / 256)), dim3(256), 0, s, (const uint4*)h->mask_ws,
+    hipLaunchKernelGGL(k_band_exact, dim3((unsigned)((n_units + BE_UPW - 1) / BE_UPW)), dim3(256), 0, s, (const uint4*)h->mask_ws,
                        (const unsigned long long*)((const char*)h->mask_ws + score_count3_mask_words_bytes(h, Bc)), n_units,
                        (unsigned)(rows_per_tile * 4), A);
     COPER_HIP_TRY(h, hipGetLastError());

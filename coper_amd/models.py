@@ -309,10 +309,11 @@ class ConvE(object):
                                                  self._stream()))
         return ranks, ne
 
-    def rank_pass(self, e1, rel, e2, filt_indptr, filt_idx, filt_nnz=None, want_equal=True, want_h=False, e1_rows=None):
+    def rank_pass(self, e1, rel, e2, filt_indptr, filt_idx, filt_nnz=None, want_equal=True, want_h=False, e1_rows=None, out=None):
         """One evaluation batch end to end (coper_encode_rank): what one `session.run` of the reference's ranker
         loop computes (metrics.py:40-57).  Returns (ranks int32 [B], n_equal or None[, h [B, d] when want_h]); same
-        bits as encode() + rank().  In the bf16x3 mode without want_h the embedding never exists in fp32."""
+        bits as encode() + rank().  In the bf16x3 mode without want_h the embedding never exists in fp32.  out: an int32 [B]
+        device tensor to receive the ranks (pipelines that copy them out on another stream own their buffers)."""
         self._need_prepared()
         rel = self._ids(rel)
         e1 = self._ids(e1) if e1 is not None else None
@@ -321,7 +322,9 @@ class ConvE(object):
         nnz = int(ix.numel()) if filt_nnz is None else int(filt_nnz)
         if e1_rows is not None:
             e1_rows = e1_rows.to(device=self.device, dtype=torch.float32).contiguous()
-        ranks = torch.empty((B,), device=self.device, dtype=torch.int32)
+        if out is not None and (out.dtype != torch.int32 or out.numel() != B or not out.is_contiguous() or out.device != self.device):
+            raise ValueError("out: a contiguous int32 tensor of %d ranks on %s" % (B, self.device))
+        ranks = out if out is not None else torch.empty((B,), device=self.device, dtype=torch.int32)
         ne = torch.empty((B,), device=self.device, dtype=torch.int32) if want_equal else None
         h = torch.empty((B, self.ent_emb_size), device=self.device, dtype=torch.float32) if want_h else None
         _lib.check(self._h, self._lib.coper_encode_rank(self._h, _ptr(e1), _ptr(rel), _ptr(e1_rows), _ptr(e2), _ptr(ip), _ptr(ix),
