@@ -820,6 +820,7 @@ COPER_API int coper_encode_rank(coper_handle* h, const int64_t* e1, const int64_
     rc = launch_score_count_bf16x3(h, hv, nullptr, e2, filt_indptr, filt_idx, B, ranks, nullptr, s);
     h->count_base = 0;
     h->counts_preset = nullptr;
+    h->excess_pending = false;     // (consumed by the first band launch; a failed launch must not leave it to a later pass)
     return rc;
   }
   if ((rc = launch_dense_finalize_pack(h, B, ksplit, hv, ranks, 1, n_equal, s))) return rc;

@@ -154,6 +154,8 @@ struct coper_handle {
   int64_t packed_B = 0;
   bool trust_packed = false;
   int32_t* row_of_ws = nullptr;   // bf16x3: CSR entry -> query row [nnz]
+  bool excess_pending = false;    // the next band launch also runs the excess role (kernels_score3_bf16.hip), with
+  alignas(8) unsigned char excess_args[128] = {};   //   these FilterArgs
   int32_t* heavy_ws = nullptr;    // fused tail: [0] number of listed blocks, [1] finished workgroups, [2..] 32-query blocks whose CSR entries
                                   //   exceed what their workgroup corrects itself (k_filter_excess_bf16x3); zero between passes
   int64_t row_of_cap = 0;
@@ -263,6 +265,8 @@ float band_kappa(const coper_handle* h);
 bool tail_fused_supported(const coper_handle* h);
 int launch_finalize_targets_filter_bf16x3(coper_handle* h, int64_t B, int ksplit, float* h_out, const int64_t* e2, const int64_t* indptr,
                                           const int64_t* idx, int64_t nnz, float* tgt, int32_t* ranks, hipStream_t s);
+int launch_filter_excess_bf16x3(coper_handle* h, const float* hvec, const int64_t* e2, const int64_t* indptr, const int64_t* idx,
+                                int64_t nnz, int64_t B, int32_t* ranks, bool defer, hipStream_t s);
 void score_count_begin_f32(coper_handle* h, const float* hvec, int64_t B, int32_t* ng, int32_t* ne, hipStream_t s);
 int score_count_chunk_f32(coper_handle* h, int64_t q0, int64_t Bc, const float* tgt, int32_t* ng, int32_t* ne, float* gmax,
                           int64_t gm_stride, hipStream_t s);

@@ -25,11 +25,13 @@
 // tie counts of the mode are therefore those of COPER_SCORE_F32 on the same h, bit for bit, as long as the bf16x3 error
 // stays inside tau (tests measure the margin; coper_config.rank_band_kappa widens it up to the proven worst case).
 #include <algorithm>
+#include <cstring>
 #include <utility>
 #include <vector>
 
 #include "bf16x3_chain.h"
 #include "coper_internal.h"
+#include "tail_tile.h"
 
 namespace coper {
 
@@ -632,8 +634,8 @@ __device__ __forceinline__ void band_decide(const BandArgs& A, const int64_t q, 
 // thread makes; at FB15k-237 shapes 256 units gave a workgroup ~350 pairs for its 256 threads (two walks for many), 64
 // units give ~90 (one walk) and 290 workgroups instead of 73
 constexpr int BE_CAP = 4096, BE_ITEMS = 2048, BE_UPW = COPER_BE_UPW;
-__global__ __launch_bounds__(256) void k_band_exact(const uint4* __restrict__ mask, const unsigned long long* __restrict__ summ, int64_t n_units,
-                                                    unsigned rows4 /* rows per tile x 4 waves */, BandArgs A) {
+__device__ __forceinline__ void band_exact_body(const uint4* __restrict__ mask, const unsigned long long* __restrict__ summ, const int64_t n_units,
+                                                const unsigned rows4 /* rows per tile x 4 waves */, const BandArgs& A, const int64_t wg) {
   constexpr int MB = SC3_MB, NW = 2 * MB;      // 32-bit mask words per lane and row of a wave
   __shared__ unsigned long long s_p[BE_CAP];   // marked pairs: (query << 32) | entity
   __shared__ unsigned s_it[BE_ITEMS];          // (unit in the workgroup << 6) | lane: the mask words to fetch
@@ -641,7 +643,7 @@ __global__ __launch_bounds__(256) void k_band_exact(const uint4* __restrict__ ma
   // three phases, each spread over all threads (a thread that walks its unit's lanes one after the other pays a round trip
   // per lane): a thread per unit (one wave's row of 32 MB entities x 128 queries) reads the summary and lists the lanes
   // that wrote mask words; a thread per listed lane fetches its words and lists the marked pairs; a thread per pair walks.
-  const int64_t unit0 = (int64_t)blockIdx.x * BE_UPW;
+  const int64_t unit0 = wg * BE_UPW;
   if (threadIdx.x == 0) { s_n = 0; s_ni = 0; }
   __syncthreads();
   {
@@ -732,6 +734,105 @@ __global__ __launch_bounds__(256) void k_band_exact(const uint4* __restrict__ ma
   }
 }
 
+__global__ __launch_bounds__(256) void k_band_exact(const uint4* __restrict__ mask, const unsigned long long* __restrict__ summ, int64_t n_units,
+                                                    unsigned rows4, BandArgs A) {
+  band_exact_body(mask, summ, n_units, rows4, A, blockIdx.x);
+}
+
+// k_filter_excess_bf16x3 -- the CSR entries beyond the first TL_OWN_ENTRIES of a 32-query block (real KGs hold (e1, rel) pairs
+// with thousands of known tails; inside the workgroups that own the block they would run ~7 us per 128 entries while the rest
+// of the chip waits).  The listed blocks' remaining tiles are dealt over the waves of FX_GRID workgroups: a wave rebuilds the
+// block's query fragments from the fp32 rows (same values, same split), scores a tile exactly as the owners do and takes the
+// known answers above the band back from `ranks`.  No listed block (every pass of the benchmark shapes): the waves read one
+// word and leave.  The last workgroup to finish empties the list for the next pass.
+template <int KS>
+__device__ __forceinline__ void filter_excess_body(const FilterArgs& F, const int wg, const int n_wg, int64_t (*s_e_all)[32]) {
+  const int n = F.heavy[0];
+  if (n == 0) return;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, i = lane & 31, half = lane >> 5;
+  int64_t* s_e = s_e_all[wave];
+  const int G = n_wg * FX_WAVES;
+  const int64_t me = (int64_t)wg * FX_WAVES + wave;
+  for (int hb = 0; hb < n; ++hb) {
+    const int64_t blk = F.heavy[2 + hb], q0 = blk * 32, q = q0 + i;
+    const bool live = q < F.B;
+    const int64_t qe = q0 + 32 < F.B ? q0 + 32 : F.B;
+    const int64_t p_end = F.indptr[qe], p0 = F.indptr[q0] + TL_OWN_ENTRIES;
+    // tile t of listed block hb belongs to wave (t + 61 hb) mod G: consecutive blocks start on different waves
+    const int64_t t0 = ((me - 61 * (int64_t)hb) % G + G) % G;
+    if (p0 + 32 * t0 >= p_end) continue;
+    const int64_t my_lo = live ? F.indptr[q] : p_end;
+    const int64_t my_e2 = live ? F.e2[q] : -1;
+    const float t_hi = live ? F.tband[q].y : 0.f;
+    uint4 bh[KS], bl[KS];
+    tail_fragments_from_rows<KS>(F.hvec, q, live, F.d, half, bh, bl);
+    for (int64_t pb = p0 + 32 * t0; pb < p_end; pb += 32 * (int64_t)G) {
+      float sc;
+      int qi;
+      const int64_t frow = tail_filter_tile<KS>(pb, p_end, my_lo, my_e2, F.idx, F.n_local, s_e, F.Ehi, F.Elo, F.bias_pad, bh, bl, i, half, sc, qi);
+      const float tq = __shfl(t_hi, qi);
+      tail_take_back(half == 0 && frow >= 0 && sc > tq, qi, i, half, q0, F.ranks);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(&F.heavy[1], 1) == n_wg - 1) {   // every workgroup of the role has read the list
+      F.heavy[0] = 0;
+      F.heavy[1] = 0;
+    }
+  }
+}
+
+
+template <int KS>
+__global__ __launch_bounds__(64 * FX_WAVES) void k_filter_excess_bf16x3(FilterArgs F) {
+  __shared__ int64_t s_e_all[FX_WAVES][32];
+  filter_excess_body<KS>(F, (int)blockIdx.x, (int)gridDim.x, s_e_all);
+}
+
+// the band walk of a count launch with the excess role in the same launch (coper_encode_rank: the tail kernel listed the blocks
+// before the count launch; as its own launch the role cost 4 - 5 us per pass to find an empty list)
+template <int KS>
+__global__ __launch_bounds__(256) void k_band_excess_bf16x3(const uint4* __restrict__ mask, const unsigned long long* __restrict__ summ,
+                                                            int64_t n_units, unsigned rows4, BandArgs A, int n_band, FilterArgs F) {
+  static_assert(FX_WAVES == 4, "the roles share a launch of 256 threads");
+  __shared__ int64_t s_e_all[FX_WAVES][32];
+  if ((int)blockIdx.x < n_band) band_exact_body(mask, summ, n_units, rows4, A, blockIdx.x);
+  else filter_excess_body<KS>(F, (int)blockIdx.x - n_band, (int)gridDim.x - n_band, s_e_all);
+}
+
+static FilterArgs filter_args(coper_handle* h, const float* hvec, const int64_t* e2, const int64_t* indptr, const int64_t* idx,
+                              const float2* tband, int64_t B, int32_t* ranks) {
+  FilterArgs F;
+  F.hvec = hvec; F.Ehi = (const uint4*)h->Erm16_hi; F.Elo = (const uint4*)h->Erm16_lo; F.bias_pad = h->bias_pad; F.e2 = e2;
+  F.indptr = indptr; F.idx = idx; F.tband = tband; F.ranks = ranks; F.heavy = h->heavy_ws; F.B = B; F.n_local = h->dm.n_local;
+  F.d = h->dm.d;
+  return F;
+}
+
+// after a launch whose workgroups listed blocks beyond their own share (the tail kernel's filter phase).  defer: the role
+// joins the band launch of the count pass that follows on the same stream (score_count3_chunk_bf16x3) instead of its own
+int launch_filter_excess_bf16x3(coper_handle* h, const float* hvec, const int64_t* e2, const int64_t* indptr, const int64_t* idx,
+                                int64_t nnz, int64_t B, int32_t* ranks, bool defer, hipStream_t s) {
+  h->excess_pending = false;
+  if (nnz <= TL_OWN_ENTRIES) return COPER_OK;     // no block can exceed its own share
+  if (h->dm.KS16 != 13 && h->dm.KS16 != 16) return fail(h, COPER_EUNSUPPORTED, "filter excess: ent_emb_size not served by the fused tail");
+  const FilterArgs F = filter_args(h, hvec, e2, indptr, idx, (const float2*)h->tband_ws, B, ranks);
+#ifndef COPER_DBG_SC3_NO_BAND
+  if (defer) {
+    static_assert(sizeof(FilterArgs) <= sizeof(h->excess_args), "coper_internal.h: excess_args too small");
+    memcpy(h->excess_args, &F, sizeof F);
+    h->excess_pending = true;
+    return COPER_OK;
+  }
+#endif
+  if (h->dm.KS16 == 13) hipLaunchKernelGGL(k_filter_excess_bf16x3<13>, dim3(FX_GRID), dim3(64 * FX_WAVES), 0, s, F);
+  else hipLaunchKernelGGL(k_filter_excess_bf16x3<16>, dim3(FX_GRID), dim3(64 * FX_WAVES), 0, s, F);
+  COPER_HIP_TRY(h, hipGetLastError());
+  return COPER_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -815,9 +916,21 @@ int score_count3_chunk_bf16x3(coper_handle* h, int64_t q0, int64_t Bc, const flo
     { static const int dbg = getenv("COPER_DBG_BAND") ? atoi(getenv("COPER_DBG_BAND")) : 0; A.dbg = dbg; }
     const int64_t n_units = sc3_units(h, Bc);
     if (rows_per_tile * 4 > 0x7fffffffLL || n_units > 0x7fffffffLL) return fail(h, COPER_EUNSUPPORTED, "band mask beyond 2^31 units");
-    hipLaunchKernelGGL(k_band_exact, dim3((unsigned)((n_units + BE_UPW - 1) / BE_UPW)), dim3(256), 0, s, (const uint4*)h->mask_ws,
-                       (const unsigned long long*)((const char*)h->mask_ws + score_count3_mask_words_bytes(h, Bc)), n_units,
-                       (unsigned)(rows_per_tile * 4), A);
+    const unsigned n_band = (unsigned)((n_units + BE_UPW - 1) / BE_UPW);
+    const unsigned long long* summ = (const unsigned long long*)((const char*)h->mask_ws + score_count3_mask_words_bytes(h, Bc));
+    if (h->excess_pending) {
+      FilterArgs F;
+      memcpy(&F, h->excess_args, sizeof F);
+      h->excess_pending = false;
+      if (h->dm.KS16 == 13)
+        hipLaunchKernelGGL(k_band_excess_bf16x3<13>, dim3(n_band + FX_GRID), dim3(256), 0, s, (const uint4*)h->mask_ws, summ, n_units,
+                           (unsigned)(rows_per_tile * 4), A, (int)n_band, F);
+      else
+        hipLaunchKernelGGL(k_band_excess_bf16x3<16>, dim3(n_band + FX_GRID), dim3(256), 0, s, (const uint4*)h->mask_ws, summ, n_units,
+                           (unsigned)(rows_per_tile * 4), A, (int)n_band, F);
+    } else {
+      hipLaunchKernelGGL(k_band_exact, dim3(n_band), dim3(256), 0, s, (const uint4*)h->mask_ws, summ, n_units, (unsigned)(rows_per_tile * 4), A);
+    }
     COPER_HIP_TRY(h, hipGetLastError());
   }
   COPER_DBG_SYNC(h, s, "band_exact");

@@ -24,6 +24,7 @@
 #include "bf16x3_chain.h"
 #include "coper_internal.h"
 #include "conv_fold.h"
+#include "tail_tile.h"
 #include <algorithm>
 #include <vector>
 
@@ -33,106 +34,6 @@ __device__ __forceinline__ float tail_band_tau(float h_norm2, float kappa, const
   const float emax = __uint_as_float(consts[0]), bmax = __uint_as_float(consts[1]);
   return 2.f * kappa * (sqrtf(h_norm2) * 1.000001f * emax + bmax);
 }
-
-// one 32 x 32 tile: A rows = entity rows erow[i] (gathered from the row-major twins; erow < 0: a zero row is not needed,
-// its result is discarded), B = the resident query fragments; accumulators start from pred_bias of the row
-template <int KS>
-__device__ __forceinline__ f32x16 tail_tile(const uint4* __restrict__ Ehi, const uint4* __restrict__ Elo, const float* __restrict__ bias_pad,
-                                            const int64_t* s_e, const int64_t my_erow, const uint4 (&bh)[KS], const uint4 (&bl)[KS],
-                                            const int half) {
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int64_t er = s_e[(r & 3) + 8 * (r >> 2) + 4 * half];
-    acc[r] = er >= 0 ? bias_pad[er] : 0.f;
-  }
-  const int64_t ea = my_erow >= 0 ? my_erow : 0;
-  const uint4* pa_h = Ehi + ea * (2 * KS) + half;
-  const uint4* pa_l = Elo + ea * (2 * KS) + half;
-  constexpr int PB = KS;  // one batch: the compiler keeps as many of the tile's gathered 16-byte loads in flight as fit beside
-                          // the resident fragments (162 registers: three workgroups per CU.  Forcing all 2 KS loads into
-                          // registers first -- 252 registers, two workgroups per CU -- measured 52 us against 45)
-#pragma unroll
-  for (int k0 = 0; k0 < KS; k0 += PB) {
-    uint4 ah[PB + 1], al[PB + 1];   // (+1: the pair loop names element u + 1 in a branch that is never taken for the last odd step)
-#pragma unroll
-    for (int u = 0; u < PB; ++u) {
-      const int k = k0 + u < KS ? k0 + u : KS - 1;
-      ah[u] = pa_h[k * 2];
-      al[u] = pa_l[k * 2];
-    }
-#pragma unroll
-    for (int u = 0; u < PB; u += 2) {
-      if (k0 + u + 1 < KS) { BX3_PAIR(ah[u], al[u], bh[k0 + u], bl[k0 + u], ah[u + 1], al[u + 1], bh[k0 + u + 1], bl[k0 + u + 1], acc); }
-      else if (k0 + u < KS) { BX3_LAST(ah[u], al[u], bh[k0 + u], bl[k0 + u], acc); }
-    }
-  }
-  return acc;
-}
-
-// one tile of CSR entries [pb, pb + 32) of a 32-query block whose fragments the wave holds: the score of entry i against its
-// own query (sc), that query's index in the block (qi_out), and the entry's row -- or -1 for what the dense mask of
-// metrics.py:40-46 does not change (the target, an adjacent duplicate, a row of another shard, a lane past p_end).
-// my_lo / my_e2: lane i (both halves) holds the first entry and the target of query i.  s_e: 32 slots of the wave.
-template <int KS>
-__device__ __forceinline__ int64_t tail_filter_tile(const int64_t pb, const int64_t p_end, const int64_t my_lo, const int64_t my_e2,
-                                                    const int64_t* __restrict__ idx, const int64_t n_local, int64_t* s_e,
-                                                    const uint4* __restrict__ Ehi, const uint4* __restrict__ Elo,
-                                                    const float* __restrict__ bias_pad, const uint4 (&bh)[KS], const uint4 (&bl)[KS],
-                                                    const int i, const int half, float& sc, int& qi_out) {
-  const int64_t p = pb + i;
-  // every lane runs the same cross-lane reads (a shuffle must not sit in divergent code: inactive lanes supply nothing);
-  // lanes past the last entry carry frow = -1
-  const bool valid = p < p_end;
-  // local query of entry p: the last j with indptr[q0 + j] <= p (binary lifting over the lanes' first entries)
-  int qi = 0;
-#pragma unroll
-  for (int step = 16; step >= 1; step >>= 1) {
-    const int cand = qi + step;
-    const int64_t first = __shfl(my_lo, cand < 32 ? cand : 31);
-    qi = (valid && cand < 32 && first <= p) ? cand : qi;
-  }
-  const int64_t qfirst = __shfl(my_lo, qi);
-  const int64_t qe2 = __shfl(my_e2, qi);
-  int64_t frow = -1;
-  if (valid) {
-    const int64_t f = idx[p];
-    frow = f;
-    if (p > qfirst && idx[p - 1] == f) frow = -1;          // adjacent duplicate: the dense mask is idempotent
-    if (f == qe2) frow = -1;                                // the target is restored after masking (metrics.py:46)
-    if (frow < 0 || frow >= n_local) frow = -1;
-  }
-  __builtin_amdgcn_wave_barrier();
-  if (half == 0) s_e[i] = frow;
-  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): wave-local LDS exchange
-  __builtin_amdgcn_wave_barrier();
-  const f32x16 acc = tail_tile<KS>(Ehi, Elo, bias_pad, s_e, frow, bh, bl, half);
-  // entry i wants D[i][qi]: register (i & 3) + 4 * (i >> 3) of lane qi + 32 * ((i >> 2) & 1)
-  const int src = qi + 32 * ((i >> 2) & 1);
-  const int reg = (i & 3) + 4 * (i >> 3);
-  sc = 0.f;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const float v = __shfl(acc[r], src);
-    sc = (r == reg) ? v : sc;
-  }
-  qi_out = qi;
-  return frow;
-}
-
-#ifndef COPER_TL_WAVES
-#define COPER_TL_WAVES 4
-#endif
-#ifndef COPER_TL_OWN_TILES
-#define COPER_TL_OWN_TILES (3 * COPER_TL_WAVES - 1)
-#endif
-// CSR entries of its 32 queries a workgroup of the tail kernel takes back itself: round 0 (the waves beside the target wave)
-// and two more rounds of all waves -- 352 entries; the synthetic filters of the BASELINE configs hold 160 +- 25 per block, at
-// most 237.  A block with 1,024 kept its workgroup for eight rounds: +48 us on the launch, the chip idle behind it.
-constexpr int64_t TL_OWN_ENTRIES = 32 * (int64_t)(COPER_TL_OWN_TILES);
-constexpr int FX_WAVES = 4;                                // waves per workgroup of the excess kernel
-constexpr int FX_GRID = 512;                               // its workgroups: 2,048 waves, two per SIMD
-constexpr int TL_WAVES = COPER_TL_WAVES;   // waves per 32-query block: they share the finalize and deal the filter tiles among themselves
 
 #ifdef COPER_DBG_TL_CLOCK
 // diagnostic build (tools/ab_build.py): s_memrealtime (100 MHz) at the phase boundaries of wave 0 of every workgroup;
@@ -314,85 +215,6 @@ __global__ __launch_bounds__(64 * TL_WAVES) void k_finalize_targets_filter_bf16x
   TL_STAMP(5);
 }
 
-// ------------------------------------------------------------------------------------------------
-// k_filter_excess_bf16x3 -- the CSR entries the tail kernel left to it: those beyond the first TL_OWN_ENTRIES of a
-// 32-query block (real KGs hold (e1, rel) pairs with thousands of known tails; inside the one workgroup that owns the block
-// they would run ~7 us per 128 entries while the rest of the chip waits).  The listed blocks' remaining tiles are dealt
-// over the waves of FX_GRID workgroups: a wave rebuilds the block's query fragments from the fp32 rows the tail kernel wrote
-// (same values, same split: the bits it held), scores a tile exactly as the tail kernel does and takes the known answers
-// above the band back from `ranks` -- one atomic per run of entries of one query.  No listed block (every pass of the
-// benchmark shapes): the waves read one word and leave.  The last workgroup to finish empties the list for the next pass.
-// ------------------------------------------------------------------------------------------------
-template <int KS>
-__global__ __launch_bounds__(64 * FX_WAVES) void k_filter_excess_bf16x3(const float* __restrict__ hvec, int64_t B, int d,
-                                                             const uint4* __restrict__ Ehi, const uint4* __restrict__ Elo,
-                                                             const float* __restrict__ bias_pad, int64_t n_local,
-                                                             const int64_t* __restrict__ e2, const int64_t* __restrict__ indptr,
-                                                             const int64_t* __restrict__ idx, const float2* __restrict__ tband,
-                                                             int32_t* __restrict__ ranks, int32_t* __restrict__ heavy) {
-  __shared__ int64_t s_e_all[FX_WAVES][32];
-  const int n = heavy[0];
-  if (n == 0) return;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, i = lane & 31, half = lane >> 5;
-  int64_t* s_e = s_e_all[wave];
-  const int G = (int)gridDim.x * FX_WAVES;
-  const int64_t me = (int64_t)blockIdx.x * FX_WAVES + wave;
-  for (int hb = 0; hb < n; ++hb) {
-    const int64_t blk = heavy[2 + hb], q0 = blk * 32, q = q0 + i;
-    const bool live = q < B;
-    const int64_t qe = q0 + 32 < B ? q0 + 32 : B;
-    const int64_t p_end = indptr[qe], p0 = indptr[q0] + TL_OWN_ENTRIES;
-    // tile t of listed block hb belongs to wave (t + 61 hb) mod G: consecutive blocks start on different waves
-    const int64_t t0 = ((me - 61 * (int64_t)hb) % G + G) % G;
-    if (p0 + 32 * t0 >= p_end) continue;
-    const int64_t my_lo = live ? indptr[q] : p_end;
-    const int64_t my_e2 = live ? e2[q] : -1;
-    const float t_hi = live ? tband[q].y : 0.f;
-    uint4 bh[KS], bl[KS];
-    const bool vec_ok = (d & 3) == 0 && (((uintptr_t)hvec) & 15) == 0;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const int k0 = 16 * ks + 8 * half;
-      float y[8];
-      if (live && k0 + 8 <= d && vec_ok) {
-        const float4 a = *(const float4*)(hvec + q * d + k0), b = *(const float4*)(hvec + q * d + k0 + 4);
-        y[0] = a.x; y[1] = a.y; y[2] = a.z; y[3] = a.w; y[4] = b.x; y[5] = b.y; y[6] = b.z; y[7] = b.w;
-      } else {
-#pragma unroll
-        for (int c = 0; c < 8; ++c) y[c] = (live && k0 + c < d) ? hvec[q * d + k0 + c] : 0.f;
-      }
-      split8_bf16(y, bh[ks], bl[ks]);
-    }
-    for (int64_t pb = p0 + 32 * t0; pb < p_end; pb += 32 * (int64_t)G) {
-      float sc;
-      int qi;
-      const int64_t frow = tail_filter_tile<KS>(pb, p_end, my_lo, my_e2, idx, n_local, s_e, Ehi, Elo, bias_pad, bh, bl, i, half, sc, qi);
-      const float tq = __shfl(t_hi, qi);
-      const bool hit = half == 0 && frow >= 0 && sc > tq;
-      // entries of a tile are in CSR order: runs of equal qi; the first lane of a run subtracts the run's hits at once
-      const int q_prev = __shfl_up(qi, 1);
-      const bool head = half == 0 && (i == 0 || q_prev != qi);
-      const unsigned heads = (unsigned)(__ballot(head) & 0xFFFFFFFFull);
-      const unsigned m_hit = (unsigned)(__ballot(hit) & 0xFFFFFFFFull);
-      if (head) {
-        const unsigned later = i < 31 ? (heads >> (i + 1)) : 0u;
-        const int end = later ? i + 1 + __builtin_ctz(later) : 32;
-        const unsigned run = (end >= 32 ? 0xFFFFFFFFu : ((1u << end) - 1u)) & ~((1u << i) - 1u);
-        const int c = __builtin_popcount(m_hit & run);
-        if (c) atomicSub(&ranks[q0 + qi], c);
-      }
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();
-    if (atomicAdd(&heavy[1], 1) == (int)gridDim.x - 1) {   // every workgroup has read the list
-      heavy[0] = 0;
-      heavy[1] = 0;
-    }
-  }
-}
-
 #ifdef COPER_DBG_TL_CLOCK
 extern "C" __attribute__((visibility("default"))) int coper_dbg_tl_clock(int n_wg, double* out /* [TL_NSTAMP] medians, us from the earliest start */) {
   static unsigned long long hbuf[TL_NSTAMP * 1024];
@@ -418,6 +240,9 @@ bool tail_fused_supported(const coper_handle* h) {
   return (h->dm.KS16 == 13 || h->dm.KS16 == 16) && h->dm.n_local == h->dm.E;   // (the resident fragments: KS16 registers x 2 per lane)
 }
 
+// (Tried in round 3: the filter tiles moved out of this launch into extra workgroups of the band launch that follows the count
+// kernel -- this launch 44 -> 25 us, but the band launch 16 -> 51: at ~190 registers a wave only two workgroups fit a CU and
+// the 1,280 filter workgroups ran in three rounds.  Pass 0.536 against 0.516 ms; not kept.)
 int launch_finalize_targets_filter_bf16x3(coper_handle* h, int64_t B, int ksplit, float* h_out, const int64_t* e2, const int64_t* indptr,
                                           const int64_t* idx, int64_t nnz, float* tgt, int32_t* ranks, hipStream_t s) {
   const Dims& dm = h->dm;
@@ -425,19 +250,16 @@ int launch_finalize_targets_filter_bf16x3(coper_handle* h, int64_t B, int ksplit
   const int64_t rows_pad = (B + 127) / 128 * 128;
   const unsigned grid = (unsigned)(rows_pad / 32);
 #define TL_GO(KS_)                                                                                                                 \
-  hipLaunchKernelGGL(k_finalize_targets_filter_bf16x3<KS_>, dim3(grid), dim3(64 * TL_WAVES), 0, s, h->z_part, ksplit, h->ws_queries, B, dm.d,   \
+  hipLaunchKernelGGL(k_finalize_targets_filter_bf16x3<KS_>, dim3(grid), dim3(64 * TL_WAVES), 0, s, h->z_part, ksplit, h->ws_queries, B, dm.d, \
                      dm.d_pad16, h->inv_perm, h->sorted_rid, fcb, dm.gen_fc ? 1 : 0, h->fc_scale, h->fc_shift, h_out,               \
                      (uint4*)h->hf3_ws, (const uint4*)h->Erm16_hi, (const uint4*)h->Erm16_lo,                                       \
                      h->bias_pad, dm.n_local, e2, indptr, idx, tgt, band_kappa(h), h->band_consts, (float2*)h->tband_ws, ranks,   \
-                     h->heavy_ws);                                                                                                  \
-  if (nnz > TL_OWN_ENTRIES)   /* no block can exceed its own share otherwise */                                                     \
-    hipLaunchKernelGGL(k_filter_excess_bf16x3<KS_>, dim3(FX_GRID), dim3(64 * FX_WAVES), 0, s, h_out, B, dm.d, (const uint4*)h->Erm16_hi,       \
-                       (const uint4*)h->Erm16_lo, h->bias_pad, dm.n_local, e2, indptr, idx, (const float2*)h->tband_ws, ranks,      \
-                       h->heavy_ws)
+                     h->heavy_ws)
   if (dm.KS16 == 13) { TL_GO(13); } else { TL_GO(16); }
 #undef TL_GO
   COPER_HIP_TRY(h, hipGetLastError());
-  return COPER_OK;
+  // blocks beyond a workgroup's own share: worked off beside the band walk of the count pass the caller launches next
+  return launch_filter_excess_bf16x3(h, h_out, e2, indptr, idx, nnz, B, ranks, true, s);
 }
 
 }  // namespace coper
