@@ -267,8 +267,8 @@ def test_full_size_configs_properties(oracle_chain, name, mode):
       * bf16x3 mode (exact band, kernels_score3_bf16.hip): ranks and tie counts == the f32 mode's ranker fed the same h --
         all Q queries -- and, on a query sample, == the closed form on logits the C chain computes from that h.
     On the sample, against the fp64 oracle DIRECTLY: h within 2e-4, logits within the 1e-3 gate, the rank inside the
-    band the logit error allows, and EQUAL to the fp64 oracle's rank for >= 99 % (f32) of the sampled queries (the bf16x3
-    encoder's h error moves more: bound asserted below); Hits@10 / MRR identical to the recomputation."""
+    band the logit error allows; and for ALL queries EQUAL to the float64 oracle's rank for >= 99 % in both modes; Hits@10 /
+    MRR identical to the recomputation."""
     O = oracle_chain
     from coper_amd.metrics import hits_and_means, ranking_and_hits
     md = cdata.model_descriptors(name)
@@ -336,9 +336,37 @@ def test_full_size_configs_properties(oracle_chain, name, mode):
     # (measured with tools/rank_decomp.py: f32 mode 99.6 %, bf16x3 97.9 % at FB15k-237 shapes; WN18RR's 40,943 entities sit
     # three times denser around the target)
     frac64 = n_same64 / n_sampled
-    assert frac64 >= {"f32": 0.985, "bf16x3": 0.93}[mode] - (0.05 if name == "wn18rr_cpg" else 0.0), (frac64, n_sampled)
-    print("%s %s: ranks equal to the float64 oracle's for %.4f of %d sampled queries; max logit error %.2e" % (name, mode, frac64, n_sampled, max_err))
-    assert max_err < (2e-5 if mode == "f32" else 3e-4), max_err
+    assert frac64 >= 0.97 - (0.05 if name == "wn18rr_cpg" else 0.0), (frac64, n_sampled)      # (a sample of 1 %: 33 - 212 queries)
+    # ... and for EVERY query against the reference pass in float64 -- the torch restatement of the oracle (forward and
+    # scoring, oracle/coper_oracle_torch.py) run in float64 on the device, checked against the NumPy oracle's h on the sample:
+    # >= 99 % of the ranks are the float64 oracle's (measured 0.9937 in the x3 mode, 0.9960 in the fp32
+    # mode at FB15k-237 shapes: what is left is the fp32 rounding of h in the encoder, 1e-5 in a logit)
+    from oracle.coper_oracle_torch import TorchCPUModel
+    dev = torch.device("cuda:0")
+    tm = TorchCPUModel(p, md, device=dev, dtype=torch.float64)
+    h64 = torch.cat([tm.forward(q["e1"][s:s + 256], q["rel"][s:s + 256]) for s in range(0, Q, 256)])
+    chk = np.arange(0, Q, 97)
+    st = O.forward(p, md, q["e1"][chk], q["rel"][chk], np.float64, materialise=False)
+    assert np.abs(h64[chk].cpu().numpy() - st["h"]).max() < 1e-9
+    r64 = torch.empty(Q, dtype=torch.int64, device=dev)
+    E64t, b64t = torch.as_tensor(E64, device=dev), torch.as_tensor(b64, device=dev)
+    d_e2, d_ip, d_ix = (torch.as_tensor(q[k]).to(dev) for k in ("e2", "filt_indptr", "filt_idx"))
+    for s in range(0, Q, 2048):
+        e = min(Q, s + 2048)
+        lg = torch.addmm(b64t, h64[s:e], E64t.t())
+        rows = torch.arange(e - s, device=dev)
+        t = lg[rows, d_e2[s:e]].clone()
+        cnt = d_ip[s + 1:e + 1] - d_ip[s:e]
+        lg[torch.repeat_interleave(rows, cnt), d_ix[int(d_ip[s]):int(d_ip[e])]] = -float("inf")
+        lg[rows, d_e2[s:e]] = -float("inf")
+        r64[s:e] = 1 + (lg > t[:, None]).sum(1)
+    same_all = float((r64.cpu().numpy() == ranks).mean())
+    print("%s %s: ranks equal to the float64 oracle's for %.4f of %d sampled and %.4f of all %d queries; max logit error %.2e"
+          % (name, mode, frac64, n_sampled, same_all, Q, max_err))
+    # (WN18RR's 40,943 entities sit three times denser around a target: the x3 encoder's rounding of h moves 1.6 % of its ranks,
+    # the fp32 encoder's 0.5 %)
+    assert same_all >= (0.98 if (name, mode) == ("wn18rr_cpg", "bf16x3") else 0.99), same_all
+    assert max_err < (2e-5 if mode == "f32" else 4e-5), max_err
     mr2, mrr2, hits2 = hits_and_means(exp)
     assert (mr, mrr, hits[10]) == (mr2, mrr2, hits2[10])
     assert n_equal < 1e-6 * Q * md["num_ent"]
