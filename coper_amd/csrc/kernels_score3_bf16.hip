@@ -82,37 +82,13 @@ struct SC3Ptrs {
   const uint4* hl;       // the query tile in LDS, lane included
 };
 
-// value V = 4 MB b + 4 m2 + j of block M: entity row 16 m2 + 4 (lane >> 4) + j of the block, query 16 b + (lane & 15) of the tile
+// what follows the comparisons of value V: every 32 values the word pair gives the counts, every 8 (top-k launches) the block
+// maximum is reduced across lanes and stored, the row's last value stores the band words that carry a bit
 template <int NP, int TAIL, int PD, bool GM, int M, int V>
-__device__ __forceinline__ void sc3_value(SC3<NP, TAIL, PD, GM>& S, const int lane, const bool store_ok, float* __restrict__ gm_row,
-                                          const int64_t gm_col, uint4* __restrict__ mask_row) {
+__device__ __forceinline__ void sc3_value_tail(SC3<NP, TAIL, PD, GM>& S, const int lane, const bool store_ok, float* __restrict__ gm_row,
+                                               const int64_t gm_col, uint4* __restrict__ mask_row) {
   constexpr int MB = SC3_MB, NV = 32 * MB;
-  constexpr int b = V / (4 * MB), m2 = (V >> 2) % MB, j = V & 3, w = MB * M + (V >> 5);
-#ifdef COPER_DBG_SC3_EPI_R0   /* ablation: one value per column block keeps the chains alive, the epilogue nearly free */
-  if constexpr ((V & 7) != 0) return;
-#endif
-  float sc;
-  // The accumulator is read out of its AGPR here, at the point of use, and compared with both edges of the band; each
-  // result is shifted into a mask word (m = 2 m + bit: one add-with-carry).  No counting per value and no scalar
-  // instruction: the first form (v_cmp into an SGPR pair, add-with-carry from it, s_andn2, add-with-carry) paid wait
-  // states at every VALU -> SGPR -> VALU hand-over, in a kernel that is bound by its instruction issue.  Every 32 values
-  // the word pair gives  band = ge & ~gt  and  count += popcount(gt) per query.
-#ifdef COPER_DBG_SC3_NO_BAND
-  asm volatile("v_accvgpr_read_b32 %1, %2\n\tv_cmp_gt_f32 vcc, %1, %3\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
-               : "+v"(S.mg[w]), "=&v"(sc)
-               : "a"(S.acc[M][m2][b][j]), "v"(S.thi[b])
-               : "vcc");
-#else
-  asm volatile(
-      "v_accvgpr_read_b32 %2, %3\n\t"
-      "v_cmp_gt_f32 vcc, %2, %4\n\t"
-      "v_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
-      "v_cmp_ge_f32 vcc, %2, %5\n\t"
-      "v_addc_co_u32 %1, vcc, %1, %1, vcc"
-      : "+v"(S.mg[w]), "+v"(S.mk[w]), "=&v"(sc)
-      : "a"(S.acc[M][m2][b][j]), "v"(S.thi[b]), "v"(S.tlo[b])
-      : "vcc");
-#endif
+  constexpr int b = V / (4 * MB), m2 = (V >> 2) % MB, w = MB * M + (V >> 5);
   if constexpr ((V & 31) == 31) {      // a word is complete: 32 / (4 MB) queries' worth
     constexpr int QW = 32 / (4 * MB), B0 = (V - 31) / (4 * MB);       // column blocks in the word, the first of them
     constexpr unsigned FM = QW == 1 ? 0xFFFFFFFFu : (1u << (4 * MB)) - 1u;
@@ -121,16 +97,7 @@ __device__ __forceinline__ void sc3_value(SC3<NP, TAIL, PD, GM>& S, const int la
       S.cg[B0 + i] += __builtin_popcount(S.mg[w] & (FM << (32 - 4 * MB * (i + 1))));
     S.mk[w] &= ~S.mg[w];
   }
-  if constexpr (GM) {   // block maxima per (32 entities, query): the eight values of two consecutive 16-row blocks
-    // two values per v_max3 (the kernel is bound by instruction issue: a v_max per value and the library fmaxf's quieting
-    // moves were a fifth of the top-k launch), written as instructions because the values come out of an asm block
-    if constexpr ((V & 1) == 0) {
-      S.px = sc;
-    } else if constexpr ((V & 7) == 1) {
-      asm volatile("v_max_f32 %0, %1, %2" : "=v"(S.mx) : "v"(S.px), "v"(sc));
-    } else {
-      asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(S.mx) : "v"(S.px), "v"(sc));
-    }
+  if constexpr (GM) {
     if constexpr ((V & 7) == 7) {
       // the other rows of the 32-entity block sit in lanes + 16, + 32, + 48: two lane swaps inside the vector unit
       // (v_permlane32_swap / v_permlane16_swap; __shfl_xor goes through the LDS pipe and its wait falls on the query-
@@ -163,10 +130,84 @@ __device__ __forceinline__ void sc3_value(SC3<NP, TAIL, PD, GM>& S, const int la
   }
 }
 
+// value V = 4 MB b + 4 m2 + j of block M: entity row 16 m2 + 4 (lane >> 4) + j of the block, query 16 b + (lane & 15) of the tile
+template <int NP, int TAIL, int PD, bool GM, int M, int V>
+__device__ __forceinline__ void sc3_value(SC3<NP, TAIL, PD, GM>& S, const int lane, const bool store_ok, float* __restrict__ gm_row,
+                                          const int64_t gm_col, uint4* __restrict__ mask_row) {
+  constexpr int MB = SC3_MB, NV = 32 * MB;
+  constexpr int b = V / (4 * MB), m2 = (V >> 2) % MB, j = V & 3, w = MB * M + (V >> 5);
+#ifdef COPER_DBG_SC3_EPI_R0   /* ablation: one value per column block keeps the chains alive, the epilogue nearly free */
+  if constexpr ((V & 7) != 0) return;
+#endif
+  float sc;
+  // The accumulator is read out of its AGPR here, at the point of use, and compared with both edges of the band; each
+  // result is shifted into a mask word (m = 2 m + bit: one add-with-carry).  No counting per value and no scalar
+  // instruction: the first form (v_cmp into an SGPR pair, add-with-carry from it, s_andn2, add-with-carry) paid wait
+  // states at every VALU -> SGPR -> VALU hand-over, in a kernel that is bound by its instruction issue.  Every 32 values
+  // the word pair gives  band = ge & ~gt  and  count += popcount(gt) per query.
+#ifdef COPER_DBG_SC3_NO_BAND
+  asm volatile("v_accvgpr_read_b32 %1, %2\n\tv_cmp_gt_f32 vcc, %1, %3\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+               : "+v"(S.mg[w]), "=&v"(sc)
+               : "a"(S.acc[M][m2][b][j]), "v"(S.thi[b])
+               : "vcc");
+#else
+  asm volatile(
+      "v_accvgpr_read_b32 %2, %3\n\t"
+      "v_cmp_gt_f32 vcc, %2, %4\n\t"
+      "v_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+      "v_cmp_ge_f32 vcc, %2, %5\n\t"
+      "v_addc_co_u32 %1, vcc, %1, %1, vcc"
+      : "+v"(S.mg[w]), "+v"(S.mk[w]), "=&v"(sc)
+      : "a"(S.acc[M][m2][b][j]), "v"(S.thi[b]), "v"(S.tlo[b])
+      : "vcc");
+#endif
+  if constexpr (GM) {   // block maxima per (32 entities, query): the eight values of two consecutive 16-row blocks
+    // two values per v_max3 (the kernel is bound by instruction issue: a v_max per value and the library fmaxf's quieting
+    // moves were a fifth of the top-k launch), written as instructions because the values come out of an asm block
+    if constexpr ((V & 1) == 0) {
+      S.px = sc;
+    } else if constexpr ((V & 7) == 1) {
+      asm volatile("v_max_f32 %0, %1, %2" : "=v"(S.mx) : "v"(S.px), "v"(sc));
+    } else {
+      asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(S.mx) : "v"(S.px), "v"(sc));
+    }
+  }
+  sc3_value_tail<NP, TAIL, PD, GM, M, V>(S, lane, store_ok, gm_row, gm_col, mask_row);
+}
+
 template <int NP, int TAIL, int PD, bool GM, int M, int V0, int... I>
 __device__ __forceinline__ void sc3_values(SC3<NP, TAIL, PD, GM>& S, const int lane, const bool store_ok, float* __restrict__ gm_row,
                                            const int64_t gm_col, uint4* __restrict__ mask_row, std::integer_sequence<int, I...>) {
   (sc3_value<NP, TAIL, PD, GM, M, V0 + I>(S, lane, store_ok, gm_row, gm_col, mask_row), ...);
+}
+
+// ---- the epilogue of a value in two pieces (3 and 2 vector instructions), to be placed behind two consecutive MFMAs.
+// A 16x16x32 MFMA occupies the matrix pipe for 16 cycles and keeps the vector-issue port for the first 8 of them: TWO vector
+// instructions fit in its shadow, a third delays the next MFMA by 4 cycles.  The one-block form above (5 instructions behind
+// one MFMA: sc3_value) cost 12 cycles of an idle matrix pipe per value -- 256 values a row, the whole gap between the
+// measured 29,300 cycles per row and the 20,480 of its MFMAs (build/isa statistics: 991 of 1,280 MFMAs with nothing behind
+// them, 154 with 5 vector instructions, 47 with 10).  The carry travels in an SGPR pair from piece to piece (VCC could be
+// clobbered by the compiler's own address arithmetic between two asm statements); the MFMA between producer and consumer
+// hides the VALU -> SGPR -> VALU hand-over that made round 3's first scalar form slow.
+template <int NP, int TAIL, int PD, bool GM, int M, int V>
+__device__ __forceinline__ void sc3_piece1(SC3<NP, TAIL, PD, GM>& S, float& sc) {
+  constexpr int MB = SC3_MB, b = V / (4 * MB), m2 = (V >> 2) % MB, j = V & 3, w = MB * M + (V >> 5);
+  asm volatile("v_accvgpr_read_b32 %1, %2\n\tv_cmp_gt_f32 vcc, %1, %3\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+               : "+v"(S.mg[w]), "=&v"(sc) : "a"(S.acc[M][m2][b][j]), "v"(S.thi[b]) : "vcc");
+}
+template <int NP, int TAIL, int PD, bool GM, int M, int V>
+__device__ __forceinline__ void sc3_piece2(SC3<NP, TAIL, PD, GM>& S, const float sc, const int lane, const bool store_ok,
+                                           float* __restrict__ gm_row, const int64_t gm_col, uint4* __restrict__ mask_row) {
+  constexpr int MB = SC3_MB, b = V / (4 * MB), w = MB * M + (V >> 5);
+#ifndef COPER_DBG_SC3_NO_BAND
+  asm volatile("v_cmp_ge_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(S.mk[w]) : "v"(sc), "v"(S.tlo[b]) : "vcc");
+#endif
+  if constexpr (GM) {
+    if constexpr ((V & 1) == 0) S.px = sc;
+    else if constexpr ((V & 7) == 1) asm volatile("v_max_f32 %0, %1, %2" : "=v"(S.mx) : "v"(S.px), "v"(sc));
+    else asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(S.mx) : "v"(S.px), "v"(sc));
+  }
+  sc3_value_tail<NP, TAIL, PD, GM, M, V>(S, lane, store_ok, gm_row, gm_col, mask_row);
 }
 
 template <int NP, int TAIL, int PD, bool GM, int M, int... m2>
@@ -188,6 +229,52 @@ __device__ __forceinline__ void sc3_mfmas(SC3<NP, TAIL, PD, GM>& S, std::integer
   ((S.acc[M][m2][b] = BX3_MFMA16(S.a1[sa][sl][m2], S.q0[rs], S.acc[M][m2][b])), ...);
   // (e.reg1, q.reg1): T3 of both k-steps
   if constexpr (!tail) ((S.acc[M][m2][b] = BX3_MFMA16(S.a1[sa][sl][m2], S.q1[rs], S.acc[M][m2][b])), ...);
+}
+
+template <int NP, int TAIL, int PD, bool GM, int M, int v0, int cnt, int K0, int... U>
+__device__ __forceinline__ void sc3_slot_pieces(SC3<NP, TAIL, PD, GM>& S, float* sc, const int lane,
+                                                const bool store_ok, float* __restrict__ gm_row, const int64_t gm_col,
+                                                uint4* __restrict__ mask_row, std::integer_sequence<int, U...>) {
+  // (M here is the block whose values are finished: the OTHER block of the region that issues the MFMAs)
+  ([&] {
+    constexpr int k = K0 + U, vi = k / 2, pk = k % 2;
+    if constexpr (vi < cnt) {
+      if constexpr (pk == 0) sc3_piece1<NP, TAIL, PD, GM, M, v0 + vi>(S, sc[vi]);
+      else sc3_piece2<NP, TAIL, PD, GM, M, v0 + vi>(S, sc[vi], lane, store_ok, gm_row, gm_col, mask_row);
+    }
+  }(), ...);
+}
+
+// One slot of a region: MFMA number I of the region (term I / MB on chain I % MB) and, behind it, PP pieces of the other
+// block's epilogue (piece k of the region = piece k % 3 of value v0 + k / 3); a scheduling barrier pins the order.
+template <int NP, int TAIL, int PD, bool GM, int M, int s, int b, int sa, int sl, int rs, bool tail, int v0, int cnt, int PP, int I>
+__device__ __forceinline__ void sc3_slot(SC3<NP, TAIL, PD, GM>& S, float* sc, const int lane, const bool store_ok,
+                                         float* __restrict__ gm_row, const int64_t gm_col, uint4* __restrict__ mask_row) {
+  constexpr int MB = SC3_MB, NM = tail ? 2 * MB : 3 * MB;
+  if constexpr (I < NM) {
+    constexpr int t = I / MB, m2 = I % MB;
+    if constexpr (t == 0) {
+      if constexpr (s == 0) S.acc[M][m2][b] = BX3_MFMA16(S.a0[sa][sl][m2], S.q1[rs], S.biasv[M][m2]);
+      else S.acc[M][m2][b] = BX3_MFMA16(S.a0[sa][sl][m2], S.q1[rs], S.acc[M][m2][b]);
+    } else if constexpr (t == 1) {
+      S.acc[M][m2][b] = BX3_MFMA16(S.a1[sa][sl][m2], S.q0[rs], S.acc[M][m2][b]);
+    } else {
+      S.acc[M][m2][b] = BX3_MFMA16(S.a1[sa][sl][m2], S.q1[rs], S.acc[M][m2][b]);
+    }
+  }
+#ifndef COPER_DBG_SC3_NO_EPI
+  sc3_slot_pieces<NP, TAIL, PD, GM, 1 - M, v0, cnt, I * PP>(S, sc, lane, store_ok, gm_row, gm_col, mask_row, std::make_integer_sequence<int, PP>{});
+#endif
+#ifndef COPER_SC3_NO_SLOT_FENCE
+  SC3_FENCE();
+#endif
+}
+
+template <int NP, int TAIL, int PD, bool GM, int M, int s, int b, int sa, int sl, int rs, bool tail, int v0, int cnt, int PP, int... I>
+__device__ __forceinline__ void sc3_slots(SC3<NP, TAIL, PD, GM>& S, float* sc, const int lane, const bool store_ok,
+                                          float* __restrict__ gm_row, const int64_t gm_col, uint4* __restrict__ mask_row,
+                                          std::integer_sequence<int, I...>) {
+  (sc3_slot<NP, TAIL, PD, GM, M, s, b, sa, sl, rs, tail, v0, cnt, PP, I>(S, sc, lane, store_ok, gm_row, gm_col, mask_row), ...);
 }
 
 // Region (step s, column block b) of block M: in front, one entity-fragment load PD steps ahead (regions b < 2 MB: the
@@ -250,14 +337,28 @@ __device__ __forceinline__ void sc3_region(SC3<NP, TAIL, PD, GM>& S, const SC3Pt
 #ifdef COPER_DBG_SC3_LOADS_FIRST
   SC3_FENCE();     // experiment: the region's loads are issued before its first instruction of the matrix pipe
 #endif
-  sc3_mfmas<NP, TAIL, PD, GM, M, s, b, sa, sl, rs, tail>(S, std::make_integer_sequence<int, MB>{});
   // epilogue of the other block: this step's chunk of CH values is dealt to the eight regions in order
   constexpr int c0 = b * CH / 8, c1 = (b + 1) * CH / 8, v0 = s * CH + c0;
   constexpr int cnt = v0 >= NV ? 0 : (v0 + (c1 - c0) > NV ? NV - v0 : c1 - c0);
+#ifndef COPER_SC3_INTERLEAVED     /* the shipped form: the region's MFMAs, then whole values */
+  sc3_mfmas<NP, TAIL, PD, GM, M, s, b, sa, sl, rs, tail>(S, std::make_integer_sequence<int, MB>{});
 #ifndef COPER_DBG_SC3_NO_EPI
   if constexpr (cnt > 0) sc3_values<NP, TAIL, PD, GM, 1 - M, v0>(S, lane, prev_valid, gm_row, gm_col, mask_row, std::make_integer_sequence<int, cnt>{});
 #endif
   SC3_FENCE();
+#else
+  // experiment (tools/ab_build.py IL=-DCOPER_SC3_INTERLEAVED): one MFMA, one piece of the other block's epilogue, barrier --
+  // slot by slot.  tools/microbench/mfma_valu_mix.hip says clumps of 5 vector instructions cost ~12 % against the same
+  // instructions spread one behind each MFMA; this form spreads them, but the compiler answers the barriers with 37 - 53
+  // spilled registers and more wait states: 0.295 against 0.276 ms.  Not the default.
+  constexpr int NM = tail ? 2 * MB : 3 * MB;
+  constexpr int PP = cnt == 0 ? 0 : (2 * cnt + NM - 1) / NM;          // pieces behind one MFMA (1 for every d > 32)
+  constexpr int NSLOT = NM;
+  float sc[cnt > 0 ? cnt : 1];
+  SC3_FENCE();       // (the region's loads stay in front of its first MFMA)
+  sc3_slots<NP, TAIL, PD, GM, M, s, b, sa, sl, rs, tail, v0, cnt, PP>(S, sc, lane, prev_valid, gm_row, gm_col, mask_row,
+                                                                       std::make_integer_sequence<int, NSLOT>{});
+#endif
 }
 
 template <int NP, int TAIL, int PD, bool GM, int M, int s>
@@ -897,8 +998,12 @@ int score_count3_chunk_bf16x3(coper_handle* h, int64_t q0, int64_t Bc, const flo
     ScopedKernelTimer t(h, "score_count", s);
     switch (h->dm.KS16) {
 #define SC3_CASE(KS_) case KS_: rc = sc3_gm<(KS_) / 2, (KS_) & 1>(h, q0, Bc, ng, gmax, gm_stride, s); break;
+#ifdef COPER_SC3_ONLY_KS    /* quick experiment builds: one instantiation */
+      SC3_CASE(COPER_SC3_ONLY_KS)
+#else
       SC3_CASE(1) SC3_CASE(2) SC3_CASE(3) SC3_CASE(4) SC3_CASE(5) SC3_CASE(6) SC3_CASE(7) SC3_CASE(8) SC3_CASE(9) SC3_CASE(10)
       SC3_CASE(11) SC3_CASE(12) SC3_CASE(13) SC3_CASE(14) SC3_CASE(15) SC3_CASE(16) SC3_CASE(17) SC3_CASE(18) SC3_CASE(19) SC3_CASE(20)
+#endif
 #undef SC3_CASE
       default: rc = fail(h, COPER_EUNSUPPORTED, "score_count3: ent_emb_size beyond 320");
     }
