@@ -113,6 +113,9 @@ def parse_args():
                          "costs the stream a few microseconds of pipeline drain; 1 = every step)")
     ap.add_argument("--topk", type=int, default=0,
                     help="entity mode: also select and exchange the per-shard top-k of the filtered rows (SURVEY 8(e) step 3)")
+    ap.add_argument("--h2d", choices=["kernel", "sdma"], default="kernel",
+                    help="how a pass's pinned int32 batch reaches the device: coper_widen_ids reading host memory (one launch) or a "
+                         "copy-engine transfer followed by a widening pass")
     ap.add_argument("--no-scale", action="store_true", help="skip the 10M-entity blocks (scale, HBM-regime roofline)")
     ap.add_argument("--no-extras", action="store_true", help="main line only: no f32 comparison, PCIe-inclusive loop, 10M blocks")
     ap.add_argument("--scale-steps", type=int, default=None, help="timed passes of the scale block (default min(steps, 10))")
@@ -557,8 +560,11 @@ def main():
             brings pass n + 1's batch in under pass n's kernels reaches the resident-input rate in tools/pipe_probe.py --
             0.545 against 0.59 ms per pass -- but inside this program its passes stalled for 7 - 30 ms a few times per run,
             with torch streams and with raw HIP calls alike; not understood, so not used for the number that is reported.)"""
-            stage32.copy_(pin, non_blocking=True)
-            stage.copy_(stage32)
+            if args.h2d == "kernel":
+                model.widen_ids(pin, out=stage)        # one launch reads the pinned int32 batch over PCIe and writes int64 (coper_widen_ids)
+            else:
+                stage32.copy_(pin, non_blocking=True)  # copy engine, then a widening pass on the device
+                stage.copy_(stage32)
             v = views
             r, _ = model.rank_pass(v["e1"], v["rel"], v["e2"], v["filt_indptr"], v["filt_idx"], filt_nnz=nnz, want_equal=False,
                                    out=ranks_dev)
@@ -680,7 +686,7 @@ def main():
                 "score_mode": "f32 (v_mfma_f32_32x32x2_f32, exact)" if args.score_mode == "f32" else
                 "bf16x3 = the x3 mode (API name kept): fp16 split since round 3, 3 x v_mfma_f32_16x16x32_f16 (two K = 16 steps each) per "
                 "pair of products, ~2^-22 rel.; exact band decided by the fp32 chain", "prepare_ms": round(prepare_ms, 2),
-                "inputs": ("SURVEY 8(d) region: every pass copies its ids + CSR filters (int32, widened on the device) from pinned host memory (one H2D) and its int32 "
+                "inputs": ("SURVEY 8(d) region: every pass brings its ids + CSR filters (int32 in pinned host memory, " + ("read over PCIe and widened by one launch of coper_widen_ids" if args.h2d == "kernel" else "one copy-engine H2D, widened on the device") + ") in and copies its int32 "
                            "ranks back to pinned host memory (D2H), %d bytes per pass, inside the timed region; one stream, nothing overlapped"
                            % pcie_bytes) if pcie_step is not None
                 else "ids + CSR filters resident in HBM before the timed region",

@@ -553,6 +553,13 @@ COPER_API int coper_reserve(coper_handle* h, int64_t max_queries, int64_t max_fi
     if (!(h)->prepared) return fail((h), COPER_ESTATE, "coper_prepare has not been called"); \
   } while (0)
 
+COPER_API int coper_widen_ids(coper_handle* h, const int32_t* src, int64_t n, int64_t* dst, void* stream) {
+  if (!h) return COPER_EINVAL;
+  if (n == 0) return COPER_OK;
+  if (!src || !dst || n < 0) return fail(h, COPER_EINVAL, "coper_widen_ids: bad argument");
+  return launch_widen_ids(h, src, n, dst, (hipStream_t)stream);
+}
+
 COPER_API int coper_gather_entities(coper_handle* h, const int64_t* ids, int64_t B, float* out, void* stream) {
   COPER_REQUIRE_PREPARED(h);
   if (B == 0) return COPER_OK;

@@ -869,6 +869,25 @@ __global__ void k_gather_entities(const float* __restrict__ ent, const int64_t* 
   out[idx] = (row >= 0 && row < n_local) ? ent[row * d + k] : 0.f;
 }
 
+// int32 -> int64 (coper_widen_ids): 16 bytes in, 32 out per thread; src may live in pinned host memory
+__global__ __launch_bounds__(256) void k_widen_ids(const int32_t* __restrict__ src, int64_t n, int64_t* __restrict__ dst) {
+  const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 + 4 <= n && ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0) {
+    const int4 v = *(const int4*)(src + i4);
+    longlong2* o = (longlong2*)(dst + i4);
+    o[0] = make_longlong2(v.x, v.y);
+    o[1] = make_longlong2(v.z, v.w);
+  } else {
+    for (int64_t i = i4; i < i4 + 4 && i < n; ++i) dst[i] = src[i];
+  }
+}
+
+int launch_widen_ids(coper_handle* h, const int32_t* src, int64_t n, int64_t* dst, hipStream_t s) {
+  hipLaunchKernelGGL(k_widen_ids, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s, src, n, dst);
+  COPER_HIP_TRY(h, hipGetLastError());
+  return COPER_OK;
+}
+
 int launch_gather_entities(coper_handle* h, const int64_t* ids, int64_t B, float* out, hipStream_t s) {
   const Dims& dm = h->dm;
   int64_t total = B * dm.d;

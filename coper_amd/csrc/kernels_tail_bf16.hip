@@ -49,7 +49,7 @@ __device__ unsigned long long g_tl_t0;
 #endif
 
 template <int KS>
-__global__ __launch_bounds__(64 * TL_WAVES) void k_finalize_targets_filter_bf16x3(
+__global__ __launch_bounds__(64 * TL_WAVES, KS <= 13 ? 3 : 2) void k_finalize_targets_filter_bf16x3(
     const float* __restrict__ z_part, int ksplit, int64_t Bcap, int64_t B, int d, int d_pad16, const int32_t* __restrict__ inv_perm,
     const int32_t* __restrict__ sorted_rid, const float* __restrict__ fc_b, int per_rel_bias, const float* __restrict__ scale,
     const float* __restrict__ shift, float* __restrict__ h_out, uint4* __restrict__ hf3,

@@ -210,6 +210,22 @@ class ConvE(object):
         if not self._prepared:
             self.prepare()
 
+    def widen_ids(self, src: torch.Tensor, out: Optional[torch.Tensor] = None):
+        """int32 ids -> the int64 the C-ABI takes, on the device (coper_widen_ids).  `src`: an int32 tensor on the model's
+        device, or a PINNED host tensor -- the kernel then reads it over PCIe itself (one launch instead of a copy-engine
+        transfer and a widening pass)."""
+        if src.dtype != torch.int32 or not src.is_contiguous():
+            raise ValueError("widen_ids: a contiguous int32 tensor")
+        if src.device.type == "cpu" and not src.is_pinned():
+            raise ValueError("widen_ids: host tensors must be pinned (device-mapped) memory")
+        n = src.numel()
+        if out is None:
+            out = torch.empty(n, dtype=torch.int64, device=self.device)
+        elif out.dtype != torch.int64 or out.numel() != n or not out.is_contiguous() or out.device != self.device:
+            raise ValueError("widen_ids: out must be a contiguous int64 tensor of %d elements on %s" % (n, self.device))
+        _lib.check(self._h, self._lib.coper_widen_ids(self._h, C.c_void_p(src.data_ptr()), n, _ptr(out), self._stream()))
+        return out
+
     def gather_entities(self, ids):
         self._need_prepared()
         ids = self._ids(ids)

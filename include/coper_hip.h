@@ -133,6 +133,12 @@ COPER_API int coper_prepare(coper_handle* h, void* stream);
  * not allocate (needed before hipGraph capture).  Optional: calls grow the workspace lazily. */
 COPER_API int coper_reserve(coper_handle* h, int64_t max_queries, int64_t max_filter_nnz, void* stream);
 
+/* Batch staging: the reference's placeholders hold int32 ids (e1, e2, rel: models.py:148-152; so do the indices a host
+ * builds a CSR filter from), this ABI takes int64.  dst[i] = src[i] for n values; `src` may be device memory or PINNED,
+ * device-mapped HOST memory (hipHostMalloc): the kernel then pulls the ids over PCIe itself -- one launch instead of a copy
+ * engine transfer plus a widening pass.  No handle state is touched. */
+COPER_API int coper_widen_ids(coper_handle* h, const int32_t* src, int64_t n, int64_t* dst, void* stream);
+
 /* Row gather tf.nn.embedding_lookup(ent_emb, ids) (models.py:176) restricted to the shard:
  * out[b,:] = ent_emb[ids[b]] if shard_lo <= ids[b] < shard_hi else 0.  (Multi-GPU: sum over
  * ranks = the full gather.)  out: [B, d]. */

@@ -135,3 +135,26 @@ def test_heavy_blocks_inside_a_captured_graph(oracle_chain):
         want, _ = _two_calls(m, q["e1"], q["rel"], q["e2"], indptr, idx)
         assert np.array_equal(got, want), rep
     m.close()
+
+
+def test_widen_ids_from_device_and_pinned_host_memory():
+    """coper_widen_ids: int32 -> int64 for every length and alignment, the source on the device or in pinned host memory."""
+    from coper_amd.models import ConvE
+    md = cdata.model_descriptors("nations_cpg")
+    m = ConvE(md, device="cuda:0").load_parameters(cdata.synthetic_params(md, 0)).prepare()
+    rng = np.random.default_rng(0)
+    for n in (1, 3, 4, 5, 1023, 1024, 1025, 100003):
+        a = rng.integers(-2 ** 31, 2 ** 31 - 1, n, dtype=np.int64).astype(np.int32)
+        want = a.astype(np.int64)
+        dev = torch.as_tensor(a).to("cuda:0")
+        assert np.array_equal(m.widen_ids(dev).cpu().numpy(), want)
+        pin = torch.as_tensor(a).pin_memory()
+        assert np.array_equal(m.widen_ids(pin).cpu().numpy(), want)
+        if n > 8:      # unaligned views take the element loop
+            assert np.array_equal(m.widen_ids(dev[1:]).cpu().numpy(), want[1:])
+            out = torch.empty(n, dtype=torch.int64, device="cuda:0")
+            m.widen_ids(pin[3:], out=out[3:])
+            assert np.array_equal(out[3:].cpu().numpy(), want[3:])
+    with pytest.raises(ValueError):
+        m.widen_ids(torch.zeros(4, dtype=torch.int32))          # pageable host memory is not device-mapped
+    m.close()
