@@ -72,6 +72,7 @@ PROTOTYPES = {
     "coper_prepare": (C.c_int, [_P, _P]),
     "coper_reserve": (C.c_int, [_P, _I64, _I64, _P]),
     "coper_widen_ids": (C.c_int, [_P, _P, _I64, _P, _P]),
+    "coper_copy_out_i32": (C.c_int, [_P, _P, _I64, _P, _P]),
     "coper_gather_entities": (C.c_int, [_P, _P, _I64, _P, _P]),
     "coper_encode": (C.c_int, [_P, _P, _P, _I64, _P, _P, _P]),
     "coper_score_all": (C.c_int, [_P, _P, _I64, _P, _I64, _P]),

@@ -553,6 +553,13 @@ COPER_API int coper_reserve(coper_handle* h, int64_t max_queries, int64_t max_fi
     if (!(h)->prepared) return fail((h), COPER_ESTATE, "coper_prepare has not been called"); \
   } while (0)
 
+COPER_API int coper_copy_out_i32(coper_handle* h, const int32_t* src, int64_t n, int32_t* dst, void* stream) {
+  if (!h) return COPER_EINVAL;
+  if (n == 0) return COPER_OK;
+  if (!src || !dst || n < 0) return fail(h, COPER_EINVAL, "coper_copy_out_i32: bad argument");
+  return launch_copy_i32(h, src, n, dst, (hipStream_t)stream);
+}
+
 COPER_API int coper_widen_ids(coper_handle* h, const int32_t* src, int64_t n, int64_t* dst, void* stream) {
   if (!h) return COPER_EINVAL;
   if (n == 0) return COPER_OK;

@@ -882,6 +882,21 @@ __global__ __launch_bounds__(256) void k_widen_ids(const int32_t* __restrict__ s
   }
 }
 
+__global__ __launch_bounds__(256) void k_copy_i32(const int32_t* __restrict__ src, int64_t n, int32_t* __restrict__ dst) {
+  const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 + 4 <= n && ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0) {
+    *(int4*)(dst + i4) = *(const int4*)(src + i4);
+  } else {
+    for (int64_t i = i4; i < i4 + 4 && i < n; ++i) dst[i] = src[i];
+  }
+}
+
+int launch_copy_i32(coper_handle* h, const int32_t* src, int64_t n, int32_t* dst, hipStream_t s) {
+  hipLaunchKernelGGL(k_copy_i32, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s, src, n, dst);
+  COPER_HIP_TRY(h, hipGetLastError());
+  return COPER_OK;
+}
+
 int launch_widen_ids(coper_handle* h, const int32_t* src, int64_t n, int64_t* dst, hipStream_t s) {
   hipLaunchKernelGGL(k_widen_ids, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s, src, n, dst);
   COPER_HIP_TRY(h, hipGetLastError());

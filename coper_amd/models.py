@@ -226,6 +226,16 @@ class ConvE(object):
         _lib.check(self._h, self._lib.coper_widen_ids(self._h, C.c_void_p(src.data_ptr()), n, _ptr(out), self._stream()))
         return out
 
+    def copy_out(self, src: torch.Tensor, dst: torch.Tensor):
+        """int32 results (the ranks of a pass) from the device to `dst` -- a pinned host tensor (or a device tensor): one small
+        launch right behind the pass's last kernel (coper_copy_out_i32).  Synchronise with the stream before reading dst."""
+        if src.dtype != torch.int32 or dst.dtype != torch.int32 or src.numel() != dst.numel() or not (src.is_contiguous() and dst.is_contiguous()):
+            raise ValueError("copy_out: two contiguous int32 tensors of one size")
+        if src.device != self.device or (dst.device.type == "cpu" and not dst.is_pinned()):
+            raise ValueError("copy_out: src on %s, dst there or in pinned host memory" % self.device)
+        _lib.check(self._h, self._lib.coper_copy_out_i32(self._h, _ptr(src), src.numel(), C.c_void_p(dst.data_ptr()), self._stream()))
+        return dst
+
     def gather_entities(self, ids):
         self._need_prepared()
         ids = self._ids(ids)

@@ -139,6 +139,11 @@ COPER_API int coper_reserve(coper_handle* h, int64_t max_queries, int64_t max_fi
  * engine transfer plus a widening pass.  No handle state is touched. */
 COPER_API int coper_widen_ids(coper_handle* h, const int32_t* src, int64_t n, int64_t* dst, void* stream);
 
+/* The way back: n int32 values (the ranks of a pass) from device memory to `dst`, which may be PINNED, device-mapped HOST
+ * memory -- the kernel posts the writes over PCIe right behind the pass's last kernel (a copy-engine D2H on the same stream
+ * starts ~12 us later on this runtime).  The host reads dst after synchronising with the stream. */
+COPER_API int coper_copy_out_i32(coper_handle* h, const int32_t* src, int64_t n, int32_t* dst, void* stream);
+
 /* Row gather tf.nn.embedding_lookup(ent_emb, ids) (models.py:176) restricted to the shard:
  * out[b,:] = ent_emb[ids[b]] if shard_lo <= ids[b] < shard_hi else 0.  (Multi-GPU: sum over
  * ranks = the full gather.)  out: [B, d]. */

@@ -157,4 +157,16 @@ def test_widen_ids_from_device_and_pinned_host_memory():
             assert np.array_equal(out[3:].cpu().numpy(), want[3:])
     with pytest.raises(ValueError):
         m.widen_ids(torch.zeros(4, dtype=torch.int32))          # pageable host memory is not device-mapped
+    # the way back (coper_copy_out_i32): device -> pinned host / device, every length
+    for n in (1, 5, 1024, 100003):
+        a = torch.as_tensor(rng.integers(-2 ** 31, 2 ** 31 - 1, n, dtype=np.int64).astype(np.int32)).to("cuda:0")
+        host = torch.zeros(n, dtype=torch.int32).pin_memory()
+        m.copy_out(a, host)
+        torch.cuda.synchronize()
+        assert torch.equal(host, a.cpu())
+        if n > 8:
+            host.zero_()
+            m.copy_out(a[1:], host[1:])
+            torch.cuda.synchronize()
+            assert torch.equal(host[1:], a[1:].cpu()) and host[0] == 0
     m.close()
