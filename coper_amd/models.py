@@ -226,6 +226,40 @@ class ConvE(object):
         _lib.check(self._h, self._lib.coper_widen_ids(self._h, C.c_void_p(src.data_ptr()), n, _ptr(out), self._stream()))
         return out
 
+    def stage_batch(self, *arrays):
+        """Host (NumPy) id arrays of one batch -> int64 tensors on the device through ONE pinned int32 buffer and one launch of
+        coper_widen_ids (instead of one pageable H2D copy per array).  Arrays whose ids do not fit int32, and tensors, take
+        the ordinary route.  Two pinned buffers alternate; a buffer is reused when the launch that read it has finished."""
+        if not arrays or any(isinstance(a, torch.Tensor) for a in arrays):
+            return tuple(self._ids(a) for a in arrays)
+        arrs = [np.ascontiguousarray(a).reshape(-1) for a in arrays]
+        if any(a.dtype.kind not in "iu" or (a.size and (int(a.max()) >= 2 ** 31 or int(a.min()) < -2 ** 31)) for a in arrs):
+            return tuple(self._ids(a) for a in arrays)
+        total = sum(a.size for a in arrs)
+        if total == 0:
+            return tuple(self._ids(a) for a in arrays)
+        st = getattr(self, "_stage", None)
+        if st is None:
+            st = self._stage = {"pin": [None, None], "ev": [torch.cuda.Event(), torch.cuda.Event()], "turn": 0}
+        k = st["turn"]
+        st["turn"] = 1 - k
+        if st["pin"][k] is None or st["pin"][k].numel() < total:
+            st["ev"][k].synchronize()
+            st["pin"][k] = torch.empty(max(total, 1 << 16), dtype=torch.int32).pin_memory()
+        else:
+            st["ev"][k].synchronize()          # the launch that read this buffer two calls ago
+        pin = st["pin"][k]
+        host = pin.numpy()
+        offs, o = [], 0
+        for a in arrs:
+            host[o:o + a.size] = a               # (NumPy converts int64 -> int32 while copying)
+            offs.append(o)
+            o += a.size
+        dev = torch.empty(total, dtype=torch.int64, device=self.device)
+        self.widen_ids(pin[:total], out=dev)
+        st["ev"][k].record(torch.cuda.current_stream(self.device))
+        return tuple(dev[o:o + a.size] for o, a in zip(offs, arrs))
+
     def copy_out(self, src: torch.Tensor, dst: torch.Tensor):
         """int32 results (the ranks of a pass) from the device to `dst` -- a pinned host tensor (or a device tensor): one small
         launch right behind the pass's last kernel (coper_copy_out_i32).  Synchronise with the stream before reading dst."""
@@ -341,9 +375,12 @@ class ConvE(object):
         bits as encode() + rank().  In the bf16x3 mode without want_h the embedding never exists in fp32.  out: an int32 [B]
         device tensor to receive the ranks (pipelines that copy them out on another stream own their buffers)."""
         self._need_prepared()
-        rel = self._ids(rel)
-        e1 = self._ids(e1) if e1 is not None else None
-        e2, ip, ix = self._ids(e2), self._ids(filt_indptr), self._ids(filt_idx)
+        if e1 is not None and not any(isinstance(a, torch.Tensor) for a in (e1, rel, e2, filt_indptr, filt_idx)):
+            e1, rel, e2, ip, ix = self.stage_batch(e1, rel, e2, filt_indptr, filt_idx)    # host batch: one pinned buffer, one launch
+        else:
+            rel = self._ids(rel)
+            e1 = self._ids(e1) if e1 is not None else None
+            e2, ip, ix = self._ids(e2), self._ids(filt_indptr), self._ids(filt_idx)
         B = rel.numel()
         nnz = int(ix.numel()) if filt_nnz is None else int(filt_nnz)
         if e1_rows is not None:

@@ -170,3 +170,27 @@ def test_widen_ids_from_device_and_pinned_host_memory():
             torch.cuda.synchronize()
             assert torch.equal(host[1:], a[1:].cpu()) and host[0] == 0
     m.close()
+
+
+def test_host_batches_are_staged_through_one_pinned_buffer():
+    """rank_pass fed NumPy arrays (what ranking_and_hits hands it) stages them through ConvE.stage_batch -- one pinned int32
+    buffer, one coper_widen_ids launch, two buffers alternating -- and gives the ranks of the same batch fed as device tensors;
+    batches of changing sizes reuse and grow the buffers."""
+    from coper_amd.models import ConvE
+    md = cdata.model_descriptors("fb15k237_cpg", num_ent=3000, num_rel=20)
+    m = ConvE(md, device="cuda:0", score_mode="bf16x3").load_parameters(cdata.synthetic_params(md, 1)).prepare()
+    for rep, Q in enumerate((700, 5, 9000, 700, 1, 2048, 9000)):
+        q = cdata.synthetic_queries(md, Q, seed=40 + rep)
+        if rep == 1:      # a batch without any known answer
+            q["filt_indptr"] = np.zeros(Q + 1, np.int64)
+            q["filt_idx"] = np.zeros(0, np.int64)
+        host, _ = m.rank_pass(q["e1"], q["rel"], q["e2"], q["filt_indptr"], q["filt_idx"], want_equal=False)
+        dq = {k: torch.as_tensor(v).to("cuda:0") for k, v in q.items()}
+        dev, _ = m.rank_pass(dq["e1"], dq["rel"], dq["e2"], dq["filt_indptr"], dq["filt_idx"], filt_nnz=len(q["filt_idx"]), want_equal=False)
+        assert torch.equal(host, dev), (rep, Q)
+    assert m._stage["pin"][0] is not None and m._stage["pin"][1] is not None
+    # ids that do not fit int32 take the ordinary route (and are rejected by the id check, not mangled)
+    big = np.array([2 ** 33], np.int64)
+    t = m.stage_batch(big, big)
+    assert int(t[0][0]) == 2 ** 33
+    m.close()
