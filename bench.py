@@ -116,6 +116,8 @@ def parse_args():
     ap.add_argument("--h2d", choices=["kernel", "sdma"], default="kernel",
                     help="how a pass's pinned int32 batch reaches the device: coper_widen_ids reading host memory (one launch) or a "
                          "copy-engine transfer followed by a widening pass")
+    ap.add_argument("--launch-timeout", type=int, default=1200,
+                    help="self-launched ranks (--gpus N from a plain shell) are stopped after this many seconds")
     ap.add_argument("--no-scale", action="store_true", help="skip the 10M-entity blocks (scale, HBM-regime roofline)")
     ap.add_argument("--no-extras", action="store_true", help="main line only: no f32 comparison, PCIe-inclusive loop, 10M blocks")
     ap.add_argument("--scale-steps", type=int, default=None, help="timed passes of the scale block (default min(steps, 10))")
@@ -407,10 +409,15 @@ def self_launch(args):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, start_new_session=True))
     rc, failed = 0, None
+    t_start = time.time()
     try:
         live = set(range(args.gpus))
         while live and failed is None:
             time.sleep(0.2)
+            if time.time() - t_start > args.launch_timeout:      # a rank stuck in a rendezvous or a collective: bounded, not a hang
+                failed, rc = min(live), 124
+                print("bench.py: ranks %s still running after %d s" % (sorted(live), args.launch_timeout), file=sys.stderr)
+                break
             for r in sorted(live):
                 code = procs[r].poll()
                 if code is None:

@@ -19,13 +19,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run_bench(extra, timeout=1500):
+def _run_bench(extra, timeout=600):
     import torch
     backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", backend, "--steps", "3",
-                          "--warmup", "1", "--no-cpu-baseline"] + extra, env=env, capture_output=True, text=True, timeout=timeout)
+                          "--warmup", "1", "--no-cpu-baseline", "--launch-timeout", str(timeout - 60)] + extra, env=env, capture_output=True, text=True, timeout=timeout)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-6000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
@@ -47,11 +47,11 @@ def test_bench_two_ranks_from_a_plain_shell():
 def test_bench_two_ranks_entity_sharded_main_line():
     """The entity-sharded path as the main line on a small KG (WN18RR-shaped), top-10 exchanged: its ranks are those of the
     one-rank run of the same command (mean rank / MRR carried by the line)."""
-    two, _ = _run_bench(["--workload", "wn18rr_cpg", "--mode", "entity", "--topk", "10", "--no-extras"], timeout=900)
+    two, _ = _run_bench(["--workload", "wn18rr_cpg", "--mode", "entity", "--topk", "10", "--no-extras"], timeout=420)
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "wn18rr_cpg", "--mode", "entity", "--topk", "10",
                           "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extras"], env=env, capture_output=True, text=True,
-                         timeout=900)
+                         timeout=420)
     assert out.returncode == 0, out.stderr[-4000:]
     one = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert two["n_gpus"] == 2 and one["n_gpus"] == 1
