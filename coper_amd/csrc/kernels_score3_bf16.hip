@@ -76,10 +76,18 @@ struct SC3 {
   int64_t gm_stride;
 };
 
+// a 16-byte LDS read through an explicit LDS pointer (HIP's uint4 struct has no assignment from another address space)
+typedef unsigned sc3_u4n __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 sc3_lds_hi(const uint4 __attribute__((address_space(3)))* p, const int i) {
+  const sc3_u4n v = ((const sc3_u4n __attribute__((address_space(3)))*)p)[i];
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 struct SC3Ptrs {
   const uint4* a[2];     // f3 register (16-row block 0 of entity block M, step 0, reg 0) of this row: wave-uniform (scalar base +
   const uint4* n;        // ... of the next row's block 0                              lane offset: no 64-bit vector adds per load)
   const uint4* hl;       // the query tile in LDS, lane included
+  const uint4 __attribute__((address_space(3)))* hl_hi;    // ... its part beyond 64 KiB (an LDS pointer the compiler cannot fold back)
 };
 
 // what follows the comparisons of value V: every 32 values the word pair gives the counts, every 8 (top-k launches) the block
@@ -245,6 +253,34 @@ __device__ __forceinline__ void sc3_slot_pieces(SC3<NP, TAIL, PD, GM>& S, float*
   }(), ...);
 }
 
+// A region as ONE asm block (sc3_region_asm.inc, generated): its MFMAs in the order of sc3_mfmas with the other block's
+// epilogue instructions two behind each MFMA -- the order the microbenchmark asks for (mfma_valu_mix.hip: instructions spread
+// behind the MFMAs cost the matrix pipe nothing, clumps of 5 and 10 cost 7 - 23 %) and the compiler would not keep.  Registers
+// stay the compiler's (named operands).  Shapes: steps s > 0 (step 0 starts the chains from pred_bias; with the bias quads as
+// four more operands the allocator spilled 174 registers), 1 - 3 values that share one mask word, no block maxima;
+// everything else takes the form above.
+template <int NP, int TAIL, int PD, bool GM, int M, int s, int b, int sa, int sl, int rs, bool tail, int v0, int cnt>
+__device__ __forceinline__ void sc3_region_asm(SC3<NP, TAIL, PD, GM>& S, const int lane, const bool store_ok, float* __restrict__ gm_row,
+                                               const int64_t gm_col, uint4* __restrict__ mask_row) {
+  constexpr int MB = SC3_MB;
+  static_assert(MB == 4 && !GM && cnt >= 1 && cnt <= 3, "sc3_region_asm: shape not covered");
+  constexpr int w = MB * (1 - M) + (v0 >> 5);
+  constexpr int V1 = cnt > 1 ? v0 + 1 : v0, V2 = cnt > 2 ? v0 + 2 : V1;
+  constexpr int xb0 = v0 / (4 * MB), xm0 = (v0 >> 2) % MB, xj0 = v0 & 3;
+  constexpr int xb1 = V1 / (4 * MB), xm1 = (V1 >> 2) % MB, xj1 = V1 & 3;
+  constexpr int xb2 = V2 / (4 * MB), xm2 = (V2 >> 2) % MB, xj2 = V2 & 3;
+  constexpr int bA = xb0, bB = xb2;
+  constexpr int second = xb1 != xb0 ? 1 : (cnt > 2 && xb2 != xb0 ? 2 : cnt);
+  float sc;
+  typedef unsigned sc3_u4 __attribute__((ext_vector_type(4)));     // (a HIP uint4 is a struct: not a register operand)
+#define SC3_Q(x) (*(const sc3_u4*)&(x))
+#include "sc3_region_asm.inc"
+#undef SC3_Q
+  sc3_value_tail<NP, TAIL, PD, GM, 1 - M, v0>(S, lane, store_ok, gm_row, gm_col, mask_row);
+  if constexpr (cnt > 1) sc3_value_tail<NP, TAIL, PD, GM, 1 - M, v0 + 1>(S, lane, store_ok, gm_row, gm_col, mask_row);
+  if constexpr (cnt > 2) sc3_value_tail<NP, TAIL, PD, GM, 1 - M, v0 + 2>(S, lane, store_ok, gm_row, gm_col, mask_row);
+}
+
 // One slot of a region: MFMA number I of the region (term I / MB on chain I % MB) and, behind it, PP pieces of the other
 // block's epilogue (piece k of the region = piece k % 3 of value v0 + k / 3); a scheduling barrier pins the order.
 template <int NP, int TAIL, int PD, bool GM, int M, int s, int b, int sa, int sl, int rs, bool tail, int v0, int cnt, int PP, int I>
@@ -318,11 +354,13 @@ __device__ __forceinline__ void sc3_region(SC3<NP, TAIL, PD, GM>& S, const SC3Pt
     if constexpr (((R + SC3_LD) & 3) != 0)
 #endif
     {
-      S.q0[(R + SC3_LD) & 3] = X.hl[((b2 * NS + s2) * 2 + 0) * 64];
+      // (a ds_read offset holds 16 bits: registers beyond 64 KiB go through the second base instead of an add per read)
+      constexpr int i0 = ((b2 * NS + s2) * 2 + 0) * 64, i1 = i0 + 64;
+      if constexpr (i0 <= 4095) S.q0[(R + SC3_LD) & 3] = X.hl[i0]; else S.q0[(R + SC3_LD) & 3] = sc3_lds_hi(X.hl_hi, i0 - 4096);
 #ifdef COPER_DBG_SC3_ONE_LDS   /* ablation (wrong results): one of the two reads */
       if constexpr (R < 4)
 #endif
-      S.q1[(R + SC3_LD) & 3] = X.hl[((b2 * NS + s2) * 2 + 1) * 64];
+      if constexpr (i1 <= 4095) S.q1[(R + SC3_LD) & 3] = X.hl[i1]; else S.q1[(R + SC3_LD) & 3] = sc3_lds_hi(X.hl_hi, i1 - 4096);
     }
   }
 #endif
@@ -341,6 +379,13 @@ __device__ __forceinline__ void sc3_region(SC3<NP, TAIL, PD, GM>& S, const SC3Pt
   constexpr int c0 = b * CH / 8, c1 = (b + 1) * CH / 8, v0 = s * CH + c0;
   constexpr int cnt = v0 >= NV ? 0 : (v0 + (c1 - c0) > NV ? NV - v0 : c1 - c0);
 #ifndef COPER_SC3_INTERLEAVED     /* the shipped form: the region's MFMAs, then whole values */
+#if !defined(COPER_SC3_NO_ASM_REGION) && !defined(COPER_DBG_SC3_NO_EPI) && !defined(COPER_DBG_SC3_NO_BAND) && !defined(COPER_DBG_SC3_EPI_R0) && !defined(COPER_SPLIT_BF16)
+  if constexpr (MB == 4 && !GM && s > 0 && cnt >= 1 && cnt <= 3 && (v0 >> 5) == ((v0 + cnt - 1) >> 5)) {
+    sc3_region_asm<NP, TAIL, PD, GM, M, s, b, sa, sl, rs, tail, v0, cnt>(S, lane, prev_valid, gm_row, gm_col, mask_row);
+    SC3_FENCE();
+    return;
+  }
+#endif
   sc3_mfmas<NP, TAIL, PD, GM, M, s, b, sa, sl, rs, tail>(S, std::make_integer_sequence<int, MB>{});
 #ifndef COPER_DBG_SC3_NO_EPI
   // (Also tried: pinning value i between terms i and i + 1 of the region by a never-read accumulator operand, so that no two
@@ -522,6 +567,11 @@ __global__ __launch_bounds__(256, 1) void k_score_count3_bf16x3(const uint4* __r
     X.a[1] = X.a[0] + BLK_REGS * 64;
     X.n = Ef3 + eb_next * BLK_REGS * 64;
     X.hl = hl3 + lane;
+    {
+      unsigned hi_off = (unsigned)(uintptr_t)((const uint4 __attribute__((address_space(3)))*)(hl3 + lane + 4096));
+      asm volatile("" : "+v"(hi_off));     // opaque: otherwise the second base is re-derived from the first with an add per read
+      X.hl_hi = (const uint4 __attribute__((address_space(3)))*)(uintptr_t)hi_off;
+    }
     uint4* mask_cur = mask + ((cur_tile * rows_per_tile + row) * 4 + wave) * MW;
     // block 0 (epilogue of the previous row's block 1 beside it: its last value completes that row's mask), then block 1
     sc3_half<NP, TAIL, PD, GM, 0>(S, X, bias_pad, eb_next, lane, prev_valid, GM ? gmax + (eb_prev + 1) * (MB / 2) * gm_stride : nullptr, gm_col,
