@@ -257,13 +257,13 @@ __device__ __forceinline__ void sc3_slot_pieces(SC3<NP, TAIL, PD, GM>& S, float*
 // epilogue instructions two behind each MFMA -- the order the microbenchmark asks for (mfma_valu_mix.hip: instructions spread
 // behind the MFMAs cost the matrix pipe nothing, clumps of 5 and 10 cost 7 - 23 %) and the compiler would not keep.  Registers
 // stay the compiler's (named operands).  Shapes: steps s > 0 (step 0 starts the chains from pred_bias; with the bias quads as
-// four more operands the allocator spilled 174 registers), 1 - 3 values that share one mask word, no block maxima;
-// everything else takes the form above.
+// four more operands the allocator spilled 174 registers), 1 - 3 values that share one mask word; top-k launches fold their
+// block maxima in (sc3_region_asm_gm.inc).  Everything else takes the form above.
 template <int NP, int TAIL, int PD, bool GM, int M, int s, int b, int sa, int sl, int rs, bool tail, int v0, int cnt>
 __device__ __forceinline__ void sc3_region_asm(SC3<NP, TAIL, PD, GM>& S, const int lane, const bool store_ok, float* __restrict__ gm_row,
                                                const int64_t gm_col, uint4* __restrict__ mask_row) {
   constexpr int MB = SC3_MB;
-  static_assert(MB == 4 && !GM && cnt >= 1 && cnt <= 3, "sc3_region_asm: shape not covered");
+  static_assert(MB == 4 && cnt >= 1 && cnt <= 3, "sc3_region_asm: shape not covered");
   constexpr int w = MB * (1 - M) + (v0 >> 5);
   constexpr int V1 = cnt > 1 ? v0 + 1 : v0, V2 = cnt > 2 ? v0 + 2 : V1;
   constexpr int xb0 = v0 / (4 * MB), xm0 = (v0 >> 2) % MB, xj0 = v0 & 3;
@@ -274,7 +274,13 @@ __device__ __forceinline__ void sc3_region_asm(SC3<NP, TAIL, PD, GM>& S, const i
   float sc;
   typedef unsigned sc3_u4 __attribute__((ext_vector_type(4)));     // (a HIP uint4 is a struct: not a register operand)
 #define SC3_Q(x) (*(const sc3_u4*)&(x))
+  if constexpr (GM) {       // top-k launches: block maxima folded in (even values wait in S.px, odd ones fold the pair into S.mx)
+    constexpr int vm = v0 & 7;
+    static_assert(!(cnt == 3 && vm == 7), "the maximum of a group is stored after the block: it must not hold the next group's first pair");
+#include "sc3_region_asm_gm.inc"
+  } else {
 #include "sc3_region_asm.inc"
+  }
 #undef SC3_Q
   sc3_value_tail<NP, TAIL, PD, GM, 1 - M, v0>(S, lane, store_ok, gm_row, gm_col, mask_row);
   if constexpr (cnt > 1) sc3_value_tail<NP, TAIL, PD, GM, 1 - M, v0 + 1>(S, lane, store_ok, gm_row, gm_col, mask_row);
@@ -380,7 +386,7 @@ __device__ __forceinline__ void sc3_region(SC3<NP, TAIL, PD, GM>& S, const SC3Pt
   constexpr int cnt = v0 >= NV ? 0 : (v0 + (c1 - c0) > NV ? NV - v0 : c1 - c0);
 #ifndef COPER_SC3_INTERLEAVED     /* the shipped form: the region's MFMAs, then whole values */
 #if !defined(COPER_SC3_NO_ASM_REGION) && !defined(COPER_DBG_SC3_NO_EPI) && !defined(COPER_DBG_SC3_NO_BAND) && !defined(COPER_DBG_SC3_EPI_R0) && !defined(COPER_SPLIT_BF16)
-  if constexpr (MB == 4 && !GM && s > 0 && cnt >= 1 && cnt <= 3 && (v0 >> 5) == ((v0 + cnt - 1) >> 5)) {
+  if constexpr (MB == 4 && s > 0 && cnt >= 1 && cnt <= 3 && (v0 >> 5) == ((v0 + cnt - 1) >> 5) && !(GM && cnt == 3 && (v0 & 7) == 7)) {
     sc3_region_asm<NP, TAIL, PD, GM, M, s, b, sa, sl, rs, tail, v0, cnt>(S, lane, prev_valid, gm_row, gm_col, mask_row);
     SC3_FENCE();
     return;
