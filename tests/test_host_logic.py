@@ -175,3 +175,14 @@ def test_bench_self_launch_propagates_a_failing_rank():
                           "--no-extras", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode != 0
     assert "stopping the other ranks" in out.stderr and not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_generated_asm_regions_are_up_to_date(tmp_path):
+    """coper_amd/csrc/sc3_region_asm{,_gm}.inc are generated (tools/gen_sc3_region_asm.py) and committed: the committed files
+    must be what the generator writes today."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run([sys.executable, os.path.join(root, "tools", "gen_sc3_region_asm.py"), str(tmp_path)], check=True, capture_output=True)
+    for name in ("sc3_region_asm.inc", "sc3_region_asm_gm.inc"):
+        assert open(os.path.join(str(tmp_path), name)).read() == open(os.path.join(root, "coper_amd", "csrc", name)).read(), name
