@@ -58,7 +58,7 @@ def build_library(force=False, verbose=False, extra_flags=(), out=None, jobs=4):
     key = hashlib.sha1(" ".join(extra_flags).encode()).hexdigest()[:10] if extra_flags else "default"
     objdir = os.path.join(HERE, "..", "build", "obj", key)
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
     headers.append(os.path.join(HERE, "..", "include", "coper_hip.h"))
     hdr_t = max(os.path.getmtime(p) for p in headers + [os.path.abspath(__file__)])
     base = [_hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-fvisibility=hidden", "-Wall",
