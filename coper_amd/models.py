@@ -564,6 +564,11 @@ class ConvE(object):
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
+            st = getattr(self, "_stage", None)
+            if st is not None:                       # the staging launches may still be reading the pinned buffers
+                for ev in st["ev"]:
+                    ev.synchronize()
+                self._stage = None
             self._lib.coper_destroy(self._h)
             self._h = None
 
