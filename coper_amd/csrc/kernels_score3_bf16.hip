@@ -483,7 +483,27 @@ __global__ __launch_bounds__(256, 1) void k_score_count3_bf16x3(const uint4* __r
   //    next chunk.  Workgroups start in blockIdx order, so those of an XCD stream the same entity rows at the same time
   //    however long the launch runs.  With the static split the 16 workgroups on one stretch of a 10M-row table drifted
   //    apart over their 20 ms and L2 served half of what they shared (PMC: 80 GB fetched per launch for a 10 GB table).
-  int64_t r_begin = total_rows * blockIdx.x / gridDim.x, r_end = total_rows * (blockIdx.x + 1) / gridDim.x;
+  // (static split: a tile start -- drain of the accumulators, 104 KB of LDS, prologue -- costs a workgroup about a third of a
+  // row (4.5 us against 13.2 us per row at FB15k-237 shapes), so the share is cut on an axis where every tile is
+  // rows_per_tile + 1/3 long: workgroups that cross into a new tile get fewer rows)
+  int64_t r_begin, r_end;
+  {
+#ifdef COPER_SC3_EVEN_SPLIT
+    r_begin = total_rows * blockIdx.x / gridDim.x;
+    r_end = total_rows * (blockIdx.x + 1) / gridDim.x;
+#else
+    constexpr int64_t K = 48, C = 16;                        // units per row, units per tile start
+    const int64_t per_tile = rows_per_tile * K + C, n_t = total_rows / rows_per_tile, total_u = n_t * per_tile;
+    auto row_at = [&](const int64_t u) -> int64_t {
+      const int64_t t = u / per_tile, w = u - t * per_tile;
+      int64_t r = w <= C ? 0 : (w - C + K - 1) / K;
+      if (r > rows_per_tile) r = rows_per_tile;
+      return t * rows_per_tile + r;
+    };
+    r_begin = row_at(total_u * blockIdx.x / gridDim.x);
+    r_end = blockIdx.x + 1 == gridDim.x ? total_rows : row_at(total_u * (blockIdx.x + 1) / gridDim.x);
+#endif
+  }
   if (rows_per_item > 0) {
     const int64_t n_tiles = total_rows / rows_per_tile;
     const int64_t j = blockIdx.x >> 3;
