@@ -492,7 +492,10 @@ __global__ __launch_bounds__(256, 1) void k_score_count3_bf16x3(const uint4* __r
     r_begin = total_rows * blockIdx.x / gridDim.x;
     r_end = total_rows * (blockIdx.x + 1) / gridDim.x;
 #else
-    constexpr int64_t K = 48, C = 16;                        // units per row, units per tile start
+#ifndef COPER_SC3_TILE_COST
+#define COPER_SC3_TILE_COST 16
+#endif
+    constexpr int64_t K = 48, C = COPER_SC3_TILE_COST;       // units per row, units per tile start
     const int64_t per_tile = rows_per_tile * K + C, n_t = total_rows / rows_per_tile, total_u = n_t * per_tile;
     auto row_at = [&](const int64_t u) -> int64_t {
       const int64_t t = u / per_tile, w = u - t * per_tile;
