@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libcoper_hip.so")
 
-COPER_ABI_VERSION = 2
+COPER_ABI_VERSION = 3
 COPER_MAX_CTX = 4
 
 SCORE_F32, SCORE_BF16X3 = 0, 1
@@ -42,7 +42,8 @@ class coper_config(C.Structure):
         ("n_ctx_out", C.c_int32), ("ctx_out", C.c_int32 * COPER_MAX_CTX),
         ("context_rel_use_batch_norm", C.c_int32), ("bn_epsilon", C.c_float),
         ("shard_lo", C.c_int64), ("shard_hi", C.c_int64),
-        ("score_mode", C.c_int32), ("rank_band_kappa", C.c_float), ("reserved", C.c_int32 * 6),
+        ("score_mode", C.c_int32), ("rank_band_kappa", C.c_float), ("x3_ent_absmax", C.c_float),
+        ("reserved", C.c_int32 * 5),
     ]
 
 
@@ -69,6 +70,8 @@ PROTOTYPES = {
     "coper_num_params": (C.c_int, [_P]),
     "coper_param_spec": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(_I64), C.POINTER(C.c_int)]),
     "coper_set_param": (C.c_int, [_P, C.c_char_p, _P, C.POINTER(_I64), C.c_int]),
+    "coper_set_x3_ent_absmax": (C.c_int, [_P, C.c_float]),
+    "coper_band_audit": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_float), C.POINTER(_I64), _P]),
     "coper_prepare": (C.c_int, [_P, _P]),
     "coper_reserve": (C.c_int, [_P, _I64, _I64, _P]),
     "coper_widen_ids": (C.c_int, [_P, _P, _I64, _P, _P]),
@@ -132,7 +135,7 @@ def check(handle, rc):
         raise CoperError(rc, text.decode() if text else "")
 
 
-def make_config(md, device=0, shard=None, score_mode=SCORE_F32, bn_epsilon=1e-3, rank_band_kappa=0.0):
+def make_config(md, device=0, shard=None, score_mode=SCORE_F32, bn_epsilon=1e-3, rank_band_kappa=0.0, x3_ent_absmax=0.0):
     """model_descriptors dict (models.py:98-130 keys) -> coper_config."""
     cfg = coper_config()
     cfg.abi_version = COPER_ABI_VERSION
@@ -168,4 +171,5 @@ def make_config(md, device=0, shard=None, score_mode=SCORE_F32, bn_epsilon=1e-3,
     cfg.shard_lo, cfg.shard_hi = int(lo), int(hi)
     cfg.score_mode = int(score_mode)
     cfg.rank_band_kappa = float(rank_band_kappa)     # 0: the library default (include/coper_hip.h)
+    cfg.x3_ent_absmax = float(x3_ent_absmax)         # 0: the handle's own rows; entity shards pass the table-wide maximum
     return cfg

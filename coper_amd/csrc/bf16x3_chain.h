@@ -12,7 +12,8 @@
 // per pair of k-steps -- and that every other kernel of the mode (tiles of score_all, the gathered-pair kernels, the fused
 // tail, the top-k rescoring; all on 32x32x16) follows so that all logits of the mode agree bit for bit -- is
 //
-//     acc = pred_bias
+//     acc = pred_bias 2^(e_E + e_h)      [round 4: operands enter as E 2^e_E and h 2^e_h -- exact powers of two per table and
+//                                          per packed batch (split16.h) -- and whatever leaves is multiplied by 2^-(e_E + e_h)]
 //     for j in 0 .. NP-1   (NP = KS16 / 2 pairs of k-steps):
 //         acc += T1(2j); acc += T1(2j+1); acc += T2(2j); acc += T2(2j+1); acc += T3(2j); acc += T3(2j+1)
 //     if KS16 is odd (last k-step t = KS16 - 1):
@@ -86,6 +87,56 @@ __device__ __forceinline__ void f3_store_piece(uint4* __restrict__ img, int KS16
     img[f3_at(blk, NS, NP, 1, r)] = hi;
     img[f3_at(blk, NS, NP, 1, r + 32)] = lo;
   }
+}
+
+// ---- the exponent of a packed batch (split16.h) ---------------------------------------------------------------------------
+// x3s (device, int32[4]): [0] e_h of the batch whose query planes are in place, [1] e_E + e_h = the power of two its x3
+// accumulators, thresholds and block maxima carry, [2] the accumulation word of the batch's largest |h| (float bits),
+// [3] the ticket.  Every thread block of a kernel that produces h rows calls x3_block_publish with its own maximum; the last
+// one publishes and leaves [2], [3] zero (no host-side state: hipGraph-replayable).
+__device__ __forceinline__ void x3_block_publish(float m, const int ent_exp, int32_t* __restrict__ x3s) {
+  __shared__ float s_m[16];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  if ((threadIdx.x & 63) == 0) s_m[wave] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < nw; ++w) m = fmaxf(m, s_m[w]);
+    if (m > 0.f) atomicMax((unsigned*)&x3s[2], __float_as_uint(m));      // (NaN: no contribution)
+    __threadfence();
+    if (atomicAdd((unsigned*)&x3s[3], 1u) == gridDim.x * gridDim.y - 1u) {
+      __threadfence();
+      const int e = x3_exp_for_bits(atomicExch((unsigned*)&x3s[2], 0u));
+      x3s[0] = e;
+      x3s[1] = e + ent_exp;
+      x3s[3] = 0;
+    }
+  }
+}
+
+// ---- the half-width of the exact band (kernels_score3_bf16.hip) ------------------------------------------------------------
+// tau_q = 2 (kappa (|h_q| Emax + 8 Bmax) + abs_q): both logits of a comparison carry an error of at most that half each.
+//   kappa |h_q| Emax   the split's RELATIVE error and the rounding of the fp32 accumulation, for logits that are sums of products;
+//   8 kappa Bmax       the accumulation's rounding when pred_bias DOMINATES the logit: every step of either arithmetic rounds
+//                      to an ulp of the running sum ~ |bias| (the chain 200 times, the matrix cores ~40 times at d = 200), and
+//                      the two random walks differ by up to 1.2e-6 |bias| over 6e6 logits (tests/test_gpu_scale.py, tables of
+//                      N(0, 0.01^2) beside biases of N(0, 0.1^2)) -- where the products' term measures <= 2.1e-7 |h_q| Emax;
+//                      both terms keep a factor 5 above the largest error seen.  (Empirical, like kappa: the band audit
+//                      checks every count launch against them; the proven bound is 75x wider, coper_internal.h.)
+//   abs_q              the split's ABSOLUTE floor, rigorous: an element below 2^-3 after scaling is off by at most 2^-25
+//                      (split16.h), so a logit by at most 2^-25 (|E'|_1 + |h'|_1) in scaled units = 2^-25 sqrt(d) (Emax 2^-e_h +
+//                      |h_q| 2^-e_E).  ~2^-35 of |h_q| Emax for a query as large as its batch's largest; it takes over for
+//                      queries 2^15 smaller (the batch exponent serves its largest query) and keeps their ranks exact at the
+//                      price of more band pairs.
+constexpr float X3_BAND_BIAS_WEIGHT = 8.f;
+__device__ __forceinline__ float x3_band_tau(float h_norm2, float kappa, const unsigned* __restrict__ consts, int d,
+                                             const int32_t* __restrict__ x3s) {
+  const float emax = __uint_as_float(consts[0]), bmax = __uint_as_float(consts[1]);
+  const float hn = sqrtf(h_norm2) * 1.000001f;
+  const int eh = x3s[0], ee = x3s[1] - eh;
+  const float abs_q = 2.98023224e-8f * sqrtf((float)d) * (x3_scale(emax, -eh) + x3_scale(hn, -ee));
+  return 2.f * (kappa * (hn * emax + X3_BAND_BIAS_WEIGHT * bmax) + abs_q);
 }
 
 // ---- the exact chain (the logit of COPER_SCORE_F32: chain_score of kernels_score.hip) on fp32 rows ---------------------

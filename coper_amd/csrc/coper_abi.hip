@@ -342,7 +342,7 @@ COPER_API void coper_destroy(coper_handle* h) {
   dev_free((char**)&h->Wf16_hi); dev_free((char**)&h->Wf16_lo);
   dev_free((char**)&h->Ef16_hi); dev_free((char**)&h->Ef16_lo); dev_free((char**)&h->hfrag16_hi); dev_free((char**)&h->hfrag16_lo);
   dev_free((char**)&h->Erm16_hi); dev_free((char**)&h->Erm16_lo); dev_free((char**)&h->hrm16_hi); dev_free((char**)&h->hrm16_lo);
-  dev_free((char**)&h->Ef3); dev_free((char**)&h->hf3_ws); dev_free((char**)&h->mask_ws); dev_free(&h->band_consts); dev_free(&h->tband_ws);
+  dev_free((char**)&h->Ef3); dev_free((char**)&h->hf3_ws); dev_free((char**)&h->mask_ws); dev_free(&h->band_consts); dev_free(&h->tband_ws); dev_free(&h->x3s); dev_free(&h->w_exp);
   dev_free(&h->tgtx_ws); dev_free(&h->heavy_ws);
   for (auto& kv : h->timers)
     for (auto& p : kv.second.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
@@ -425,6 +425,13 @@ static int run_generator_hidden(coper_handle* h, const std::string& name, int n_
   }
   *ctx_out = cur;
   *K_out = K;
+  return COPER_OK;
+}
+
+COPER_API int coper_set_x3_ent_absmax(coper_handle* h, float absmax) {
+  if (!h || !(absmax >= 0.f)) return fail(h, COPER_EINVAL, "coper_set_x3_ent_absmax: bad argument");
+  h->cfg.x3_ent_absmax = absmax;
+  h->prepared = false;     // the entity planes were built for another power of two
   return COPER_OK;
 }
 
@@ -522,11 +529,30 @@ COPER_API int coper_prepare(coper_handle* h, void* stream) {
     dev_free((char**)&h->Ef3);
     if (tracked_malloc(&h->Ef3, f3) != hipSuccess) { (void)hipGetLastError(); return fail(h, COPER_ENOMEM, "hipMalloc of the entity image failed"); }
     COPER_HIP_TRY(h, hipMemsetAsync(h->Ef3, 0, f3, s));
+    // the shard's maxima (row norm, |pred_bias|: the exact band; |element|: the power of two of the entity planes, split16.h)
+    if ((rc = dev_alloc(h, &h->band_consts, BAND_NCONST)) || (rc = dev_alloc(h, &h->x3s, 4))) return rc;
+    COPER_HIP_TRY(h, hipMemsetAsync(h->x3s, 0, 4 * sizeof(int32_t), s));
+    if ((rc = launch_band_consts(h, P("ent_emb"), P("pred_bias"), s))) return rc;
+    {
+      unsigned cb[BAND_NCONST];
+      COPER_HIP_TRY(h, hipMemcpyAsync(cb, h->band_consts, sizeof cb, hipMemcpyDeviceToHost, s));
+      COPER_HIP_TRY(h, hipStreamSynchronize(s));
+      float xmax;
+      memcpy(&xmax, &cb[2], sizeof xmax);
+      // shards of one table agree on the exponent through the hint (the mode's logits are then the same bits on every shard
+      // layout); a hint below the shard's own maximum could overflow fp16: refused
+      if (cfg.x3_ent_absmax > 0.f) {
+        if (!(cfg.x3_ent_absmax >= xmax)) return fail(h, COPER_EINVAL, "coper_prepare: x3_ent_absmax is below the largest |ent_emb| element of the shard");
+        xmax = cfg.x3_ent_absmax;
+      }
+      unsigned xb;
+      memcpy(&xb, &xmax, sizeof xb);
+      h->x3_ent_absmax = xmax;
+      h->x3_ent_exp = x3_exp_for_bits(xb);
+    }
     if ((rc = launch_rows_to_frag_bf16(h, P("ent_emb"), dm.n_local, dm.n_eblk, (uint4*)h->Ef16_hi, (uint4*)h->Ef16_lo,
                                        (uint4*)h->Erm16_hi, (uint4*)h->Erm16_lo, (uint4*)h->Ef3, false, s)))
       return rc;
-    if ((rc = dev_alloc(h, &h->band_consts, 2))) return rc;
-    if ((rc = launch_band_consts(h, P("ent_emb"), P("pred_bias"), s))) return rc;
     if ((rc = score_bf16_kernels_init(h))) return rc;
   }
   {
@@ -853,6 +879,21 @@ COPER_API int coper_encode_rank(coper_handle* h, const int64_t* e1, const int64_
   h->count_base = 0;
   h->counts_preset = nullptr;
   return rc;
+}
+
+COPER_API int coper_band_audit(coper_handle* h, int32_t reset, float* max_ratio, int64_t* n_pairs, void* stream) {
+  if (!h) return COPER_EINVAL;
+  if (max_ratio) *max_ratio = 0.f;
+  if (n_pairs) *n_pairs = 0;
+  if (!h->band_consts) return COPER_OK;      // fp32-exact mode: no band
+  hipStream_t s = (hipStream_t)stream;
+  unsigned v[2] = {0u, 0u};
+  COPER_HIP_TRY(h, hipMemcpyAsync(v, h->band_consts + 3, sizeof v, hipMemcpyDeviceToHost, s));
+  if (reset) COPER_HIP_TRY(h, hipMemsetAsync(h->band_consts + 3, 0, sizeof v, s));
+  COPER_HIP_TRY(h, hipStreamSynchronize(s));
+  if (max_ratio) memcpy(max_ratio, &v[0], sizeof(float));
+  if (n_pairs) *n_pairs = (int64_t)v[1];
+  return COPER_OK;
 }
 
 COPER_API int coper_check_ids(coper_handle* h, int64_t* n_bad, void* stream) {

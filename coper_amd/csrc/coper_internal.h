@@ -62,6 +62,7 @@ constexpr float COPER_BAND_KAPPA_DEFAULT = 1e-5f;
 constexpr float COPER_BAND_KAPPA_DEFAULT = 1e-6f;
 #endif
 constexpr int COPER_TOPK_PRUNED_MAX = 128;   // largest k served by the block-maxima top-k (bf16x3); above: logits chunks
+constexpr int BAND_NCONST = 8;
 constexpr int EBLK_ALIGN = 16;  // entity blocks consumed per workgroup iteration in score_count (8 waves x 2)
 
 struct Timer {
@@ -100,7 +101,13 @@ struct coper_handle {
   void* Erm16_hi = nullptr;     //   row-major twins [n_eblk*32][KS16*16] bf16 (pair kernel gathers)
   void* Erm16_lo = nullptr;
   void* Ef3 = nullptr;          //   the count kernel's image (bf16x3_chain.h): [2 n_eblk][NS][2][64] x 16 B, zero-filled first
-  unsigned* band_consts = nullptr;   // [2] float bits: max |E_e|_2, max |pred_bias| of the shard (exact band)
+  unsigned* band_consts = nullptr;   // [BAND_NCONST] float bits: [0] max |E_e|_2, [1] max |pred_bias| of the shard (exact band), [2] max |E element|,
+                                     //   [3] the band audit's largest |x3 - chain| / (tau / 2), [4] its pair count (coper_band_audit)
+  int x3_ent_exp = 0;                // e_E: the entity planes hold E 2^e_E (split16.h; prepare)
+  float x3_ent_absmax = 0.f;         //   the maximum it was chosen from (the shard's, or coper_config.x3_ent_absmax)
+  int32_t* w_exp = nullptr;          // [Rw] e_W per relation: the dense-weight planes hold W_r 2^e_W (split16.h; prepare)
+  int x_exp = 0;                     // e_x: the conv activations enter the dense layer as x 2^e_x (from a bound; prepare)
+  int32_t* x3s = nullptr;            // [4] the packed batch's exponents + their accumulation words (bf16x3_chain.h: x3_block_publish)
   float* ctx_tmp[2] = {nullptr, nullptr};  // generator hidden activations
   size_t ctx_tmp_elems = 0;
 
@@ -229,6 +236,7 @@ int score_kernels_init(coper_handle* h);
 int launch_rows_to_frag_bf16(coper_handle* h, const float* src, int64_t n_rows, int64_t n_blk, uint4* hi, uint4* lo,
                              uint4* rm_hi, uint4* rm_lo, uint4* f3, bool query_side, hipStream_t s);
 int launch_pack_h_bf16(coper_handle* h, const float* hvec, int64_t B, hipStream_t s);
+int launch_absmax_publish(coper_handle* h, const float* src, int64_t n, hipStream_t s);
 int launch_score_count_bf16x3(coper_handle* h, const float* hvec, const float* tgt_x, const int64_t* e2, const int64_t* indptr,
                               const int64_t* idx, int64_t B, int32_t* ng, int32_t* ne, hipStream_t s);
 int launch_score_all_bf16x3(coper_handle* h, const float* hvec, int64_t B, float* logits, int64_t ld, hipStream_t s);
@@ -267,6 +275,7 @@ float band_kappa(const coper_handle* h);
 bool tail_fused_supported(const coper_handle* h);
 int launch_finalize_targets_filter_bf16x3(coper_handle* h, int64_t B, int ksplit, float* h_out, const int64_t* e2, const int64_t* indptr,
                                           const int64_t* idx, int64_t nnz, float* tgt, int32_t* ranks, hipStream_t s);
+int launch_finalize_h_publish(coper_handle* h, int64_t B, int ksplit, float* h_out, hipStream_t s);
 int launch_filter_excess_bf16x3(coper_handle* h, const float* hvec, const int64_t* e2, const int64_t* indptr, const int64_t* idx,
                                 int64_t nnz, int64_t B, int32_t* ranks, bool defer, hipStream_t s);
 void score_count_begin_f32(coper_handle* h, const float* hvec, int64_t B, int32_t* ng, int32_t* ne, hipStream_t s);

@@ -656,150 +656,24 @@ int launch_dense_bf16(coper_handle* h, int64_t B, int nslices, bool small_only, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// finalize + pack (coper_encode_rank): sum of the K slices + dense bias + folded FCBN + ReLU -> h, written
-// straight into the bf16 hi/lo planes the rank kernels read (fragment-major for k_score_count_bf16x3, row-major
-// for k_pair_bf16x3) -- the fp32 h row and the separate packing launch are skipped (h_out optional).
-// One thread per 8 consecutive features of one query = one 16-B piece of each plane.  Rows B .. rows_pad of the
-// planes are zeroed; the rank counters of the pass are preset here too.
+// finalize + pack (coper_encode_rank without the fused tail): the h rows (k_finalize_h_publish, kernels_tail_bf16.hip: sum of the
+// K slices + dense bias + folded FCBN + ReLU, and the batch's exponent), then the query planes from those rows.  (Rounds 2 - 3
+// wrote the planes from the partial sums in one launch; the planes hold h 2^e_h now and e_h is known only when every row is.)
+// The rank counters of the pass are preset by the packing launch.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_dense_finalize_pack(const float* __restrict__ z_part, int ksplit, int64_t Bcap, int64_t B,
-                                                             int64_t rows_pad, int d, int d_pad16, int KS16,
-                                                             const int32_t* __restrict__ perm, const int32_t* __restrict__ sorted_rid,
-                                                             const float* __restrict__ fc_b, int per_rel_bias,
-                                                             const float* __restrict__ scale, const float* __restrict__ shift,
-                                                             float* __restrict__ h_out, uint4* __restrict__ fhi, uint4* __restrict__ flo,
-                                                             uint4* __restrict__ rhi, uint4* __restrict__ rlo, uint4* __restrict__ hf3,
-                                                             int32_t* __restrict__ cnt, int32_t cnt_base, int32_t* __restrict__ cnt_eq) {
-  const int np = d_pad16 >> 3;                       // 16-B pieces per row (= 2 * KS16)
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (cnt && idx < B) { cnt[idx] = cnt_base; if (cnt_eq) cnt_eq[idx] = 0; }
-  if (idx >= rows_pad * np) return;
-  const int64_t pos = idx / np;
-  const int j = (int)(idx % np);
-  const int k0 = 8 * j;
-  float y[8];
-  int64_t q = pos;                                   // padding rows: zero pieces
-  if (pos < B) {
-    q = perm[pos];
-    float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < ksplit; ++s) {
-      const float4* pp = (const float4*)(z_part + ((int64_t)s * Bcap + pos) * d_pad16 + k0);
-      const float4 a = pp[0], b = pp[1];
-      z[0] += a.x; z[1] += a.y; z[2] += a.z; z[3] += a.w;
-      z[4] += b.x; z[5] += b.y; z[6] += b.z; z[7] += b.w;
-    }
-    const float* bsrc = per_rel_bias ? fc_b + (int64_t)sorted_rid[pos] * d : fc_b;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const int k = k0 + c;
-      float v = 0.f;
-      if (k < d) {
-        v = z[c] + bsrc[k];
-        v = fmaf(v, scale[k], shift[k]);
-        v = fmaxf(v, 0.f);
-        if (h_out) h_out[q * d + k] = v;
-      }
-      y[c] = v;
-    }
-  } else {
-#pragma unroll
-    for (int c = 0; c < 8; ++c) y[c] = 0.f;
-  }
-  uint4 h4, l4;
-  split8_bf16(y, h4, l4);
-  const int ks = j >> 1, half = j & 1;
-  const int64_t fo = ((q >> 5) * KS16 + ks) * 64 + half * 32 + (q & 31);
-  fhi[fo] = h4;
-  flo[fo] = l4;
-  const int64_t ro = q * np + j;
-  rhi[ro] = h4;
-  rlo[ro] = l4;
-  f3_store_piece(hf3, KS16, q, ks, half, h4, l4, true);   // the count kernel's image (bf16x3_chain.h)
-}
-
-// Destination-ordered variant: thread = (query q, 16-byte piece j), so the four plane writes of a wave are contiguous
-// (fragment-major: 64 lanes x 16 B of one (block, k-step); row-major: consecutive pieces); the partial sums are
-// gathered through inv_perm instead (32-byte reads per K slice).
-__global__ __launch_bounds__(256) void k_dense_finalize_pack_q(const float* __restrict__ z_part, int ksplit, int64_t Bcap, int64_t B,
-                                                               int64_t rows_pad, int d, int d_pad16, int KS16,
-                                                               const int32_t* __restrict__ inv_perm,
-                                                               const int32_t* __restrict__ sorted_rid,
-                                                               const float* __restrict__ fc_b, int per_rel_bias,
-                                                               const float* __restrict__ scale, const float* __restrict__ shift,
-                                                               float* __restrict__ h_out, uint4* __restrict__ fhi,
-                                                               uint4* __restrict__ flo, uint4* __restrict__ rhi,
-                                                               uint4* __restrict__ rlo, uint4* __restrict__ hf3,
-                                                               int32_t* __restrict__ cnt,
-                                                               int32_t cnt_base, int32_t* __restrict__ cnt_eq) {
-  const int np = d_pad16 >> 3;
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (cnt && idx < B) { cnt[idx] = cnt_base; if (cnt_eq) cnt_eq[idx] = 0; }
-  // work item -> (32-query block, k-step, half, query-in-block): consecutive lanes = consecutive fragment slots
-  const int64_t total = rows_pad * np;
-  if (idx >= total) return;
-  const int64_t blk = idx / ((int64_t)np * 32);
-  const int rest = (int)(idx - blk * (int64_t)np * 32);
-  const int j = rest >> 5;                 // piece: k-step = j >> 1, half = j & 1
-  const int64_t q = blk * 32 + (rest & 31);
-  const int k0 = 8 * j;
-  float y[8];
-  if (q < B) {
-    const int64_t pos = inv_perm[q];
-    float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < ksplit; ++s) {
-      const float4* pp = (const float4*)(z_part + ((int64_t)s * Bcap + pos) * d_pad16 + k0);
-      const float4 a = pp[0], b = pp[1];
-      z[0] += a.x; z[1] += a.y; z[2] += a.z; z[3] += a.w;
-      z[4] += b.x; z[5] += b.y; z[6] += b.z; z[7] += b.w;
-    }
-    const float* bsrc = per_rel_bias ? fc_b + (int64_t)sorted_rid[pos] * d : fc_b;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const int k = k0 + c;
-      float v = 0.f;
-      if (k < d) {
-        v = z[c] + bsrc[k];
-        v = fmaf(v, scale[k], shift[k]);
-        v = fmaxf(v, 0.f);
-        if (h_out) h_out[q * d + k] = v;
-      }
-      y[c] = v;
-    }
-  } else {
-#pragma unroll
-    for (int c = 0; c < 8; ++c) y[c] = 0.f;
-  }
-  uint4 h4, l4;
-  split8_bf16(y, h4, l4);
-  const int ks = j >> 1, half = j & 1;
-  const int64_t fo = (blk * KS16 + ks) * 64 + half * 32 + (q & 31);
-  fhi[fo] = h4;
-  flo[fo] = l4;
-  const int64_t ro = q * np + j;
-  rhi[ro] = h4;
-  rlo[ro] = l4;
-  f3_store_piece(hf3, KS16, q, ks, half, h4, l4, true);   // the count kernel's image (bf16x3_chain.h)
-}
-
 int launch_dense_finalize_pack(coper_handle* h, int64_t B, int ksplit, float* h_out, int32_t* cnt, int32_t cnt_base,
                                int32_t* cnt_eq, hipStream_t s) {
-  const Dims& dm = h->dm;
-  const float* fcb = dm.gen_fc ? h->fc_b_rel : h->params["fc_bias"].ptr;
-  const int64_t rows_pad = (B + 127) / 128 * 128;
-  const int64_t total = rows_pad * (dm.d_pad16 / 8);
-#ifndef COPER_FINALIZE_POS   // default: destination-ordered (coalesced plane writes: -2.5 % on the FB15k-237 pass)
-  hipLaunchKernelGGL(k_dense_finalize_pack_q, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, h->z_part, ksplit, h->ws_queries, B,
-                     rows_pad, dm.d, dm.d_pad16, dm.KS16, h->inv_perm, h->sorted_rid, fcb, dm.gen_fc ? 1 : 0, h->fc_scale,
-                     h->fc_shift, h_out, (uint4*)h->hfrag16_hi, (uint4*)h->hfrag16_lo, (uint4*)h->hrm16_hi, (uint4*)h->hrm16_lo, (uint4*)h->hf3_ws, cnt,
-                     cnt_base, cnt_eq);
-#else
-  hipLaunchKernelGGL(k_dense_finalize_pack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, h->z_part, ksplit, h->ws_queries, B,
-                     rows_pad, dm.d, dm.d_pad16, dm.KS16, h->perm, h->sorted_rid, fcb, dm.gen_fc ? 1 : 0, h->fc_scale, h->fc_shift,
-                     h_out, (uint4*)h->hfrag16_hi, (uint4*)h->hfrag16_lo, (uint4*)h->hrm16_hi, (uint4*)h->hrm16_lo, (uint4*)h->hf3_ws, cnt, cnt_base,
-                     cnt_eq);
-#endif
-  COPER_HIP_TRY(h, hipGetLastError());
-  return COPER_OK;
+  int rc = launch_finalize_h_publish(h, B, ksplit, h_out, s);
+  if (rc) return rc;
+  const int32_t base_was = h->count_base;
+  h->preset_cnt = cnt;
+  h->preset_eq = cnt_eq;
+  h->count_base = cnt_base;
+  const int64_t n_blk = (B + 127) / 128 * 4;
+  rc = launch_rows_to_frag_bf16(h, h_out, B, n_blk, (uint4*)h->hfrag16_hi, (uint4*)h->hfrag16_lo, (uint4*)h->hrm16_hi, (uint4*)h->hrm16_lo,
+                                (uint4*)h->hf3_ws, true, s);
+  h->count_base = base_was;
+  return rc;
 }
 
 }  // namespace coper

@@ -71,6 +71,7 @@ struct SC3 {
   int cg[NB];
   unsigned mk[2 * MB], mg[2 * MB];                        // (logit >= t_lo) / (logit > t_hi): word MB M + (V >> 5), value V at bit 31 - (V & 31)
   float mx, px;
+  int sexp;                                               // e_E + e_h: the power of two the accumulators carry (split16.h)
   const uint4* mask_base;                                 // (to find a row's summary word from its mask pointer)
   unsigned long long* summ_base;
   int64_t gm_stride;
@@ -220,7 +221,8 @@ __device__ __forceinline__ void sc3_piece2(SC3<NP, TAIL, PD, GM>& S, const float
 
 template <int NP, int TAIL, int PD, bool GM, int M, int... m2>
 __device__ __forceinline__ void sc3_load_bias_(SC3<NP, TAIL, PD, GM>& S, const float4* __restrict__ bp, std::integer_sequence<int, m2...>) {
-  ((S.biasv[M][m2] = f32x4{bp[4 * m2].x, bp[4 * m2].y, bp[4 * m2].z, bp[4 * m2].w}), ...);
+  ((S.biasv[M][m2] = f32x4{x3_scale(bp[4 * m2].x, S.sexp), x3_scale(bp[4 * m2].y, S.sexp), x3_scale(bp[4 * m2].z, S.sexp),
+                           x3_scale(bp[4 * m2].w, S.sexp)}), ...);
 }
 template <int NP, int TAIL, int PD, bool GM, int M>
 __device__ __forceinline__ void sc3_load_bias(SC3<NP, TAIL, PD, GM>& S, const float* __restrict__ bias_pad, const int64_t blk, const int lane) {
@@ -469,7 +471,8 @@ __global__ __launch_bounds__(256, 1) void k_score_count3_bf16x3(const uint4* __r
                                                                  int64_t B, int64_t rows_per_tile, int64_t total_rows,
                                                                  int32_t* __restrict__ ng, uint4* __restrict__ mask,
                                                                  unsigned long long* __restrict__ summ,
-                                                                 float* __restrict__ gmax, int64_t gm_stride, int64_t rows_per_item) {
+                                                                 float* __restrict__ gmax, int64_t gm_stride, int64_t rows_per_item,
+                                                                 const int32_t* __restrict__ x3s) {
   typedef SC3<NP, TAIL, PD, GM> ST;
   constexpr int NS = ST::NS, NB = ST::NB, NV = ST::NV;
   static_assert(PD <= NS, "the prefetch reaches at most one half-row ahead");
@@ -522,6 +525,7 @@ __global__ __launch_bounds__(256, 1) void k_score_count3_bf16x3(const uint4* __r
   S.mask_base = mask;
   S.summ_base = summ;
   S.gm_stride = gm_stride;
+  S.sexp = __builtin_amdgcn_readfirstlane(x3s[1]);   // (tband and the block maxima are in the same units)
   int64_t cur_tile = -1;
   int64_t eb_prev = 0;
   bool prev_valid = false;
@@ -654,41 +658,42 @@ extern "C" __attribute__((visibility("default"))) int coper_dbg_clock(int n_wg, 
 // ------------------------------------------------------------------------------------------------
 // the exact band
 // ------------------------------------------------------------------------------------------------
-// max over the shard of |E_e|_2 and |pred_bias[e]| (prepare): consts[0], consts[1] as float bit patterns (non-negative floats
+// max over the shard of |E_e|_2, |pred_bias[e]| and |E_e[k]| (prepare): consts[0..2] as float bit patterns (non-negative floats
 // order like unsigned integers)
 __global__ __launch_bounds__(256) void k_band_consts(const float* __restrict__ ent, const float* __restrict__ bias, int64_t n, int d,
                                                      unsigned* __restrict__ consts) {
   const int lane = threadIdx.x & 63;
   const int64_t wv = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * 256) >> 6;
-  float emax = 0.f, bmax = 0.f;
+  float emax = 0.f, bmax = 0.f, xmax = 0.f;
   for (int64_t e = wv; e < n; e += nw) {
     float s2 = 0.f;
-    for (int k = lane; k < d; k += 64) { const float v = ent[e * d + k]; s2 = fmaf(v, v, s2); }
+    for (int k = lane; k < d; k += 64) { const float v = ent[e * d + k]; s2 = fmaf(v, v, s2); xmax = fmaxf(xmax, fabsf(v)); }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) s2 += __shfl_xor(s2, o);
     emax = fmaxf(emax, s2);
     if (lane == 0) bmax = fmaxf(bmax, fabsf(bias[e]));
   }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) xmax = fmaxf(xmax, __shfl_xor(xmax, o));
   if (lane == 0) {
     const float en = sqrtf(emax) * 1.0000005f;     // rounding of the sum of squares and of the root
     if (en == en) atomicMax(&consts[0], __float_as_uint(en));
     if (bmax == bmax) atomicMax(&consts[1], __float_as_uint(bmax));
+    if (xmax == xmax) atomicMax(&consts[2], __float_as_uint(xmax));
   }
 }
 
-// tau_q = 2 kappa (|h_q| Emax + Bmax): both logits of a comparison carry an error of at most kappa (...) each
-__device__ __forceinline__ float band_tau(float h_norm2, float kappa, const unsigned* __restrict__ consts) {
-  const float emax = __uint_as_float(consts[0]), bmax = __uint_as_float(consts[1]);
-  return 2.f * kappa * (sqrtf(h_norm2) * 1.000001f * emax + bmax);
-}
+// tau_q: x3_band_tau (bf16x3_chain.h)
 __device__ __forceinline__ float2 band_of(float t, float tau) {
   // outward rounding of t -+ tau is immaterial (tau carries a safety factor); NaN / inf targets: every comparison false
   return make_float2(t - tau, t + tau);
 }
 
-// two-call path (coper_rank_counts): tband from the fp32 h rows and the mode's target logits; 16 lanes per query
+// two-call path (coper_rank_counts): tband from the fp32 h rows and the mode's target logits, in the units of the packed batch's
+// accumulators (x 2^(e_E + e_h): what the count kernel and the filter correction compare against); 16 lanes per query
 __global__ __launch_bounds__(256) void k_band_setup(const float* __restrict__ hvec, const float* __restrict__ tgt, int64_t B, int d, float kappa,
-                                                    const unsigned* __restrict__ consts, float2* __restrict__ tband) {
+                                                    const unsigned* __restrict__ consts, const int32_t* __restrict__ x3s,
+                                                    float2* __restrict__ tband) {
   const int64_t q = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
   const int sub = threadIdx.x & 15;
   float s2 = 0.f;
@@ -696,11 +701,16 @@ __global__ __launch_bounds__(256) void k_band_setup(const float* __restrict__ hv
     for (int k = sub; k < d; k += 16) { const float v = hvec[q * d + k]; s2 = fmaf(v, v, s2); }
 #pragma unroll
   for (int o = 8; o >= 1; o >>= 1) s2 += __shfl_xor(s2, o);
-  if (q < B && sub == 0) tband[q] = band_of(tgt[q], band_tau(s2, kappa, consts));
+  if (q < B && sub == 0) {
+    const int sexp = x3s[1];
+    // centred on the EXACT target tgt[B + q] (what the band walk compares against): the target's own x3 error -- its row may
+    // live on another shard, with a larger norm or bias than this shard's maxima -- then does not enter at all
+    tband[q] = band_of(x3_scale(tgt[B + q], sexp), x3_scale(x3_band_tau(s2, kappa, consts, d, x3s), sexp));
+  }
 }
 
 int launch_band_consts(coper_handle* h, const float* ent, const float* bias, hipStream_t s) {
-  COPER_HIP_TRY(h, hipMemsetAsync(h->band_consts, 0, 2 * sizeof(unsigned), s));
+  COPER_HIP_TRY(h, hipMemsetAsync(h->band_consts, 0, BAND_NCONST * sizeof(unsigned), s));
   int64_t blocks = (h->dm.n_local + 3) / 4;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(k_band_consts, dim3((unsigned)blocks), dim3(256), 0, s, ent, bias, h->dm.n_local, h->dm.d, h->band_consts);
@@ -715,7 +725,7 @@ float band_kappa(const coper_handle* h) {
 
 int launch_band_setup(coper_handle* h, const float* hvec, const float* tgt, int64_t B, hipStream_t s) {
   hipLaunchKernelGGL(k_band_setup, dim3((unsigned)((B * 16 + 255) / 256)), dim3(256), 0, s, hvec, tgt, B, h->dm.d, band_kappa(h),
-                     h->band_consts, (float2*)h->tband_ws);
+                     h->band_consts, h->x3s, (float2*)h->tband_ws);
   COPER_HIP_TRY(h, hipGetLastError());
   return COPER_OK;
 }
@@ -770,13 +780,16 @@ int launch_exact_targets(coper_handle* h, const float* hvec, const int64_t* e2, 
 struct BandArgs {
   const float* hvec; const float* ent; const float* bias; const int64_t* e2; const int64_t* indptr; const int64_t* idx;
   const float* tgt_x; int32_t* ng; int32_t* ne; int64_t Bc, n_local, shard_lo; int d; int dbg;
+  // the audit (below): the mode's own operands of the pairs the walk decides
+  const uint4* Ehi; const uint4* Elo; const float* bias_pad; const float2* tband; const int32_t* x3s; unsigned* consts; int KS16; int audit;
 };
 
-__device__ __forceinline__ void band_decide(const BandArgs& A, const int64_t q, const int64_t e) {
-  if (q >= A.Bc || e >= A.n_local || A.dbg == 1) return;
+// returns true when the pair was decided by the chain; sx_out / tx_out: the chain's logits of the competitor and of the target
+__device__ __forceinline__ bool band_decide(const BandArgs& A, const int64_t q, const int64_t e, float& sx_out, float& tx_out) {
+  if (q >= A.Bc || e >= A.n_local || A.dbg == 1) return false;
   const int64_t eg = e + A.shard_lo, tq = A.e2[q];
   const int64_t lo0 = A.indptr[q], hi0 = A.indptr[q + 1];
-  if (eg == tq) return;                              // the target itself (metrics.py:46)
+  if (eg == tq) return false;                        // the target itself (metrics.py:46)
   // known answer?  (ids sorted ascending inside a row)  Short rows -- nearly all -- in one round trip
   bool known = false;
   if (hi0 - lo0 <= 8) {
@@ -794,7 +807,7 @@ __device__ __forceinline__ void band_decide(const BandArgs& A, const int64_t q, 
       if (f < eg) lo_i = mid + 1; else hi_i = mid;
     }
   }
-  if (known || A.dbg == 2) return;
+  if (known || A.dbg == 2) return false;
   const float* hr = A.hvec + q * A.d;
   float sx, tx = 0.f;
   if (A.tgt_x) {
@@ -807,6 +820,79 @@ __device__ __forceinline__ void band_decide(const BandArgs& A, const int64_t q, 
   }
   if (sx > tx) atomicAdd(&A.ng[q], 1);
   else if (A.ne && sx == tx) atomicAdd(&A.ne[q], 1);
+  sx_out = sx;
+  tx_out = tx;
+  return true;
+}
+
+// The audit of the band: kappa, the relative half-width, is empirical -- the proven bound of the split and
+// of fp32 accumulation in any order is 75x wider -- so every count launch CHECKS it on the pairs its band walk decides anyway
+// (the competitors closest to the target: a few per query, ~26,000 per FB15k-237-shaped pass): a wave takes 32 decided pairs,
+// scores them once more with the mode's own sequence (their entity rows from the row-major planes, their query fragments
+// rebuilt from the fp32 rows: the bits the count kernel compared) and folds
+//        |s_x3 - s_chain| / (tau_q / 2)        (tau_q / 2 = the error the band allows ONE logit)
+// and the same for the x3 target the band is centred on into band_consts[3] (a maximum of non-negative floats) and the number of
+// audited pairs into band_consts[4].  coper_band_audit reads them: a ratio that approaches 1 means the mode's ranks may no
+// longer be the chain's (tests assert <= 0.5 on every configuration and at every operand scale; the drop-in ranker warns).
+__device__ __forceinline__ void band_audit_group(const BandArgs& A, const unsigned long long* __restrict__ s_p, const float* __restrict__ s_sx,
+                                                 const float* __restrict__ s_tx, const int base, const int n, int64_t* __restrict__ s_e) {
+  const int lane = threadIdx.x & 63, i = lane & 31, half = lane >> 5;
+  const int pi = base + i;
+  const bool have = pi < n;
+  const float sx = have ? s_sx[pi] : NAN, tx = have ? s_tx[pi] : 0.f;
+  const int64_t q = have ? (int64_t)(s_p[pi] >> 32) : 0, e = have ? (int64_t)(s_p[pi] & 0xFFFFFFFFull) : 0;
+  const bool live = have && sx == sx;
+  const int eh = A.x3s[0], sexp = A.x3s[1];
+  const int KS = A.KS16, d = A.d;
+  __builtin_amdgcn_wave_barrier();
+  if (half == 0) s_e[i] = live ? e : -1;
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_wave_barrier();
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int64_t er = s_e[(r & 3) + 8 * (r >> 2) + 4 * half];
+    acc[r] = er >= 0 ? x3_scale(A.bias_pad[er], sexp) : 0.f;
+  }
+  const uint4* pa_h = A.Ehi + (live ? e : 0) * (2 * KS) + half;
+  const uint4* pa_l = A.Elo + (live ? e : 0) * (2 * KS) + half;
+  const float* hr = A.hvec + q * d;
+  for (int ks = 0; ks < KS; ks += 2) {
+    uint4 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int k = ks + u < KS ? ks + u : KS - 1;
+      ah[u] = pa_h[k * 2]; al[u] = pa_l[k * 2];
+      float y[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) { const int kk = 16 * k + 8 * half + c; y[c] = (live && kk < d) ? x3_scale(hr[kk], eh) : 0.f; }
+      split8_s16(y, bh[u], bl[u]);
+    }
+    if (ks + 1 < KS) { BX3_PAIR(ah[0], al[0], bh[0], bl[0], ah[1], al[1], bh[1], bl[1], acc); }
+    else { BX3_LAST(ah[0], al[0], bh[0], bl[0], acc); }
+  }
+  const bool diag_lane = ((i >> 2) & 1) == half;
+  const int reg = (i & 3) + 4 * (i >> 3);
+  float sc = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) sc = (r == reg) ? acc[r] : sc;
+  float ratio = 0.f;
+  if (diag_lane && live) {
+    const float2 tb = A.tband[q];
+    const float allow = 0.25f * (tb.y - tb.x);           // tau / 2, in the accumulators' units
+    if (allow > 0.f) {
+      ratio = fabsf(sc - x3_scale(sx, sexp)) / allow;
+      ratio = fmaxf(ratio, fabsf(0.5f * (tb.x + tb.y) - x3_scale(tx, sexp)) / allow);
+      if (!(ratio == ratio)) ratio = 0.f;                // (inf - inf of a padded row: nothing to learn)
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) ratio = fmaxf(ratio, __shfl_xor(ratio, o));
+  const int cnt = __builtin_popcountll(__ballot(diag_lane && live));
+  if (lane == 0 && cnt) {
+    atomicMax(&A.consts[3], __float_as_uint(ratio));
+    atomicAdd(&A.consts[4], (unsigned)cnt);
+  }
 }
 
 #ifndef COPER_BE_UPW
@@ -816,10 +902,13 @@ __device__ __forceinline__ void band_decide(const BandArgs& A, const int64_t q, 
 // thread makes; at FB15k-237 shapes 256 units gave a workgroup ~350 pairs for its 256 threads (two walks for many), 64
 // units give ~90 (one walk) and 290 workgroups instead of 73
 constexpr int BE_CAP = 4096, BE_ITEMS = 2048, BE_UPW = COPER_BE_UPW;
+constexpr int BE_AUDIT = 256;     // pairs of a round the audit re-scores (a workgroup walks ~90 at FB15k-237 shapes: all of them)
 __device__ __forceinline__ void band_exact_body(const uint4* __restrict__ mask, const unsigned long long* __restrict__ summ, const int64_t n_units,
                                                 const unsigned rows4 /* rows per tile x 4 waves */, const BandArgs& A, const int64_t wg) {
   constexpr int MB = SC3_MB, NW = 2 * MB;      // 32-bit mask words per lane and row of a wave
   __shared__ unsigned long long s_p[BE_CAP];   // marked pairs: (query << 32) | entity
+  __shared__ float s_sx[BE_AUDIT], s_tx[BE_AUDIT];   // the chain's logits of the first pairs of a round (NaN: not decided): audited
+  __shared__ int64_t s_ae[4][32];
   __shared__ unsigned s_it[BE_ITEMS];          // (unit in the workgroup << 6) | lane: the mask words to fetch
   __shared__ int s_n, s_ni;
   // three phases, each spread over all threads (a thread that walks its unit's lanes one after the other pays a round trip
@@ -878,8 +967,17 @@ __device__ __forceinline__ void band_exact_body(const uint4* __restrict__ mask, 
       const bool last = it0 + 256 >= (ni < BE_ITEMS ? ni : BE_ITEMS);
       if (full || last) {
         const int n = s_n < BE_CAP ? s_n : BE_CAP;
-        for (int p = threadIdx.x; p < n; p += 256) band_decide(A, (int64_t)(s_p[p] >> 32), (int64_t)(s_p[p] & 0xFFFFFFFFull));
+        for (int p = threadIdx.x; p < n; p += 256) {
+          float sx = NAN, tx = 0.f;
+          const bool dec = band_decide(A, (int64_t)(s_p[p] >> 32), (int64_t)(s_p[p] & 0xFFFFFFFFull), sx, tx);
+          if (p < BE_AUDIT) { s_sx[p] = dec ? sx : NAN; s_tx[p] = tx; }
+        }
         __syncthreads();
+        if (A.audit) {
+          const int na = n < BE_AUDIT ? n : BE_AUDIT;
+          for (int g = (int)(threadIdx.x >> 6); g * 32 < na; g += 4) band_audit_group(A, s_p, s_sx, s_tx, g * 32, na, s_ae[threadIdx.x >> 6]);
+          __syncthreads();
+        }
         if (threadIdx.x == 0) s_n = 0;
         __syncthreads();
       }
@@ -908,7 +1006,8 @@ __device__ __forceinline__ void band_exact_body(const uint4* __restrict__ mask, 
             bits &= ~(1u << p);
             const int V = 32 * (c % MB) + (31 - p);
             const int b = V / (4 * MB), m2 = (V >> 2) % MB, j = V & 3;
-            band_decide(A, (int64_t)tile * 128 + 16 * b + (l & 15), (int64_t)(eb + c / MB) * (16 * MB) + 16 * m2 + 4 * (l >> 4) + j);
+            float sx_u, tx_u;
+            band_decide(A, (int64_t)tile * 128 + 16 * b + (l & 15), (int64_t)(eb + c / MB) * (16 * MB) + 16 * m2 + 4 * (l >> 4) + j, sx_u, tx_u);
           }
         }
       }
@@ -947,11 +1046,12 @@ __device__ __forceinline__ void filter_excess_body(const FilterArgs& F, const in
     const int64_t my_e2 = live ? F.e2[q] : -1;
     const float t_hi = live ? F.tband[q].y : 0.f;
     uint4 bh[KS], bl[KS];
-    tail_fragments_from_rows<KS>(F.hvec, q, live, F.d, half, bh, bl);
+    const int eh = F.x3s[0], sexp = F.x3s[1];
+    tail_fragments_from_rows<KS>(F.hvec, q, live, F.d, half, eh, bh, bl);
     for (int64_t pb = p0 + 32 * t0; pb < p_end; pb += 32 * (int64_t)G) {
       float sc;
       int qi;
-      const int64_t frow = tail_filter_tile<KS>(pb, p_end, my_lo, my_e2, F.idx, F.n_local, s_e, F.Ehi, F.Elo, F.bias_pad, bh, bl, i, half, sc, qi);
+      const int64_t frow = tail_filter_tile<KS>(pb, p_end, my_lo, my_e2, F.idx, F.n_local, s_e, F.Ehi, F.Elo, F.bias_pad, bh, bl, i, half, sexp, sc, qi);
       const float tq = __shfl(t_hi, qi);
       tail_take_back(half == 0 && frow >= 0 && sc > tq, qi, i, half, q0, F.ranks);
     }
@@ -988,7 +1088,7 @@ static FilterArgs filter_args(coper_handle* h, const float* hvec, const int64_t*
                               const float2* tband, int64_t B, int32_t* ranks) {
   FilterArgs F;
   F.hvec = hvec; F.Ehi = (const uint4*)h->Erm16_hi; F.Elo = (const uint4*)h->Erm16_lo; F.bias_pad = h->bias_pad; F.e2 = e2;
-  F.indptr = indptr; F.idx = idx; F.tband = tband; F.ranks = ranks; F.heavy = h->heavy_ws; F.B = B; F.n_local = h->dm.n_local;
+  F.indptr = indptr; F.idx = idx; F.tband = tband; F.ranks = ranks; F.heavy = h->heavy_ws; F.x3s = h->x3s; F.B = B; F.n_local = h->dm.n_local;
   F.d = h->dm.d;
   return F;
 }
@@ -1048,7 +1148,8 @@ static int sc3_go(coper_handle* h, int64_t q0, int64_t Bc, int32_t* ng, float* g
   }
   hipLaunchKernelGGL((k_score_count3_bf16x3<NP, TAIL, PD, GM>), dim3((unsigned)grid), dim3(256), lds, s, (const uint4*)h->Ef3, h->bias_pad, hf3,
                      (const float2*)h->tband_ws + q0, Bc, rows_per_tile, total_rows, ng + q0, (uint4*)h->mask_ws,
-                     (unsigned long long*)((char*)h->mask_ws + score_count3_mask_words_bytes(h, Bc)), gmax, gm_stride, rows_per_item);
+                     (unsigned long long*)((char*)h->mask_ws + score_count3_mask_words_bytes(h, Bc)), gmax, gm_stride, rows_per_item,
+                     h->x3s);
   COPER_HIP_TRY(h, hipGetLastError());
   return COPER_OK;
 }
@@ -1100,6 +1201,9 @@ int score_count3_chunk_bf16x3(coper_handle* h, int64_t q0, int64_t Bc, const flo
     A.e2 = e2 + q0; A.indptr = indptr + q0; A.idx = idx; A.tgt_x = tgt_x ? tgt_x + q0 : nullptr;
     A.ng = ng + q0; A.ne = ne ? ne + q0 : nullptr; A.Bc = Bc; A.n_local = h->dm.n_local; A.shard_lo = (int64_t)h->cfg.shard_lo; A.d = h->dm.d;
     { static const int dbg = getenv("COPER_DBG_BAND") ? atoi(getenv("COPER_DBG_BAND")) : 0; A.dbg = dbg; }
+    A.Ehi = (const uint4*)h->Erm16_hi; A.Elo = (const uint4*)h->Erm16_lo; A.bias_pad = h->bias_pad; A.tband = (const float2*)h->tband_ws + q0;
+    A.x3s = h->x3s; A.consts = h->band_consts; A.KS16 = h->dm.KS16;
+    { static const int off = getenv("COPER_BAND_NO_AUDIT") != nullptr; A.audit = off ? 0 : 1; }      // (A/B timing switch)
     const int64_t n_units = sc3_units(h, Bc);
     if (rows_per_tile * 4 > 0x7fffffffLL || n_units > 0x7fffffffLL) return fail(h, COPER_EUNSUPPORTED, "band mask beyond 2^31 units");
     const unsigned n_band = (unsigned)((n_units + BE_UPW - 1) / BE_UPW);

@@ -33,8 +33,11 @@ __global__ __launch_bounds__(256) void k_rows_to_frag_bf16(const float* __restri
                                                            uint4* __restrict__ rm_hi, uint4* __restrict__ rm_lo,
                                                            uint4* __restrict__ f3, int query_side,
                                                            int64_t total, int32_t* __restrict__ cnt, int32_t cnt_base,
-                                                           int32_t* __restrict__ cnt_eq) {
+                                                           int32_t* __restrict__ cnt_eq, int fixed_exp,
+                                                           const int32_t* __restrict__ x3s) {
   int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (blk*KS16 + ks)*64 + l
+  // the power of two of this operand class (split16.h): the table's (prepare) or the packed batch's (k_absmax_publish)
+  const int e2x = x3s ? x3s[0] : fixed_exp;
   // optional: preset the rank counters of the pass this packing opens (saves a launch on the ranking path)
   if (cnt && j < n_rows) { cnt[j] = cnt_base; if (cnt_eq) cnt_eq[j] = 0; }
   if (j >= total) return;
@@ -46,7 +49,7 @@ __global__ __launch_bounds__(256) void k_rows_to_frag_bf16(const float* __restri
   int k = 16 * ks + 8 * (l >> 5);
   float v[8];
 #pragma unroll
-  for (int t = 0; t < 8; ++t) v[t] = (row < n_rows && k + t < d) ? src[row * d + k + t] : 0.f;
+  for (int t = 0; t < 8; ++t) v[t] = (row < n_rows && k + t < d) ? x3_scale(src[row * d + k + t], e2x) : 0.f;
   uint4 h4, l4;
   split8(v, h4, l4);
   hi[j] = h4;
@@ -64,7 +67,8 @@ int launch_rows_to_frag_bf16(coper_handle* h, const float* src, int64_t n_rows, 
   const Dims& dm = h->dm;
   int64_t total = n_blk * dm.KS16 * 64;
   hipLaunchKernelGGL(k_rows_to_frag_bf16, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, n_rows, dm.d,
-                     dm.KS16, hi, lo, rm_hi, rm_lo, f3, query_side ? 1 : 0, total, h->preset_cnt, h->count_base, h->preset_eq);
+                     dm.KS16, hi, lo, rm_hi, rm_lo, f3, query_side ? 1 : 0, total, h->preset_cnt, h->count_base, h->preset_eq,
+                     h->x3_ent_exp, query_side ? h->x3s : nullptr);
   if (h->preset_cnt) h->counts_preset = h->preset_cnt;
   h->preset_cnt = nullptr;
   h->preset_eq = nullptr;
@@ -79,7 +83,28 @@ __global__ void k_zero_counts(int64_t B, int32_t* __restrict__ ng, int32_t* __re
 
 constexpr int BX_NQ = 4;    // 32-query blocks of a 128-query tile (the packing granule of the query planes)
 
+// The exponent of a batch of query rows (split16.h): e_h from the largest |h| element of the batch.  Blocks fold their maxima
+// into x3s[2] (non-negative floats order like unsigned integers); the last block to finish publishes x3s[0] = e_h,
+// x3s[1] = e_E + e_h (the power of two every x3 accumulator of this batch carries) and leaves the accumulation word and
+// the ticket zero: no host-side state, hipGraph-replayable.
+__global__ __launch_bounds__(256) void k_absmax_publish(const float* __restrict__ src, int64_t n, int ent_exp, int32_t* __restrict__ x3s) {
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(src[i]));
+  x3_block_publish(m, ent_exp, x3s);
+}
+
+int launch_absmax_publish(coper_handle* h, const float* src, int64_t n, hipStream_t s) {
+  int64_t blocks = (n + 256 * 8 - 1) / (256 * 8);
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(k_absmax_publish, dim3((unsigned)blocks), dim3(256), 0, s, src, n, h->x3_ent_exp, h->x3s);
+  COPER_HIP_TRY(h, hipGetLastError());
+  return COPER_OK;
+}
+
 int launch_pack_h_bf16(coper_handle* h, const float* hvec, int64_t B, hipStream_t s) {
+  int rc0 = launch_absmax_publish(h, hvec, B * h->dm.d, s);
+  if (rc0) return rc0;
   int64_t n_blk = (B + 32 * BX_NQ - 1) / (32 * BX_NQ) * BX_NQ;
   return launch_rows_to_frag_bf16(h, hvec, B, n_blk, (uint4*)h->hfrag16_hi, (uint4*)h->hfrag16_lo, (uint4*)h->hrm16_hi,
                                   (uint4*)h->hrm16_lo, (uint4*)h->hf3_ws, true, s);
@@ -120,8 +145,10 @@ __global__ __launch_bounds__(256, 2) void k_score_all_bf16x3(const uint4* __rest
                                                              const uint4* __restrict__ Hhi,
                                                              const uint4* __restrict__ Hlo, int64_t B, int KS,
                                                              int64_t n_eblk, int64_t n_local,
-                                                             float* __restrict__ logits, int64_t ld) {
+                                                             float* __restrict__ logits, int64_t ld,
+                                                             const int32_t* __restrict__ x3s) {
   constexpr int NQ = 2, ME = 2;
+  const int sexp = x3s[1];   // accumulators carry 2^(e_E + e_h) (split16.h)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t qblk0 = (int64_t)blockIdx.x * NQ;  // 32-query blocks (hfrag is packed per 32-query block)
   const int64_t eb0 = ((int64_t)blockIdx.y * 4 + wave) * ME;
@@ -129,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void k_score_all_bf16x3(const uint4* __rest
   f32x16 acc[NQ][ME];
 #pragma unroll
   for (int a = 0; a < ME; ++a) {
-    float bv = bias_pad[(eb0 + a) * 32 + (lane & 31)];
+    float bv = x3_scale(bias_pad[(eb0 + a) * 32 + (lane & 31)], sexp);
 #pragma unroll
     for (int b = 0; b < NQ; ++b)
 #pragma unroll
@@ -196,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void k_score_all_bf16x3(const uint4* __rest
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         int64_t q = (qblk0 + b) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (q < B) logits[q * ld + e] = acc[b][a][r];
+        if (q < B) logits[q * ld + e] = x3_scale(acc[b][a][r], -sexp);
       }
     }
 }
@@ -211,7 +238,7 @@ int launch_score_all_bf16x3(coper_handle* h, const float* hvec, int64_t B, float
   ScopedKernelTimer t(h, "score_all", s);
   hipLaunchKernelGGL(k_score_all_bf16x3, dim3((unsigned)q_groups, (unsigned)e_groups), dim3(256), 0, s,
                      (const uint4*)h->Ef16_hi, (const uint4*)h->Ef16_lo, h->bias_pad, (const uint4*)h->hfrag16_hi,
-                     (const uint4*)h->hfrag16_lo, B, dm.KS16, dm.n_eblk, dm.n_local, logits, ld);
+                     (const uint4*)h->hfrag16_lo, B, dm.KS16, dm.n_eblk, dm.n_local, logits, ld, h->x3s);
   COPER_HIP_TRY(h, hipGetLastError());
   return COPER_OK;
 }
@@ -231,8 +258,9 @@ __global__ __launch_bounds__(256) void k_pair_bf16x3(const uint4* __restrict__ E
                                                      const int64_t* __restrict__ indptr, const int64_t* __restrict__ idx,
                                                      const int32_t* __restrict__ row_of, const float2* __restrict__ tband,
                                                      int64_t lo, int64_t n_local, float* __restrict__ out,
-                                                     int32_t* __restrict__ ng) {
+                                                     int32_t* __restrict__ ng, const int32_t* __restrict__ x3s) {
   __shared__ int64_t s_e[4][32];
+  const int sexp = x3s[1];   // accumulators (and tband) carry 2^(e_E + e_h); logits leave descaled
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int i = lane & 31, half = lane >> 5;
   const int64_t p = ((int64_t)blockIdx.x * (blockDim.x >> 6) + wave) * 32 + i;
@@ -291,7 +319,7 @@ __global__ __launch_bounds__(256) void k_pair_bf16x3(const uint4* __restrict__ E
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     int64_t er = s_e[wave][(r & 3) + 8 * (r >> 2) + 4 * half];
-    acc[r] = er >= 0 ? bias_pad[er] : 0.f;
+    acc[r] = er >= 0 ? x3_scale(bias_pad[er], sexp) : 0.f;
   }
   const int64_t ea = erow >= 0 ? erow : 0;
   // row-major twins of the planes: a lane walks its own row (32 B per k-step), so every fetched line is used whole
@@ -327,7 +355,7 @@ __global__ __launch_bounds__(256) void k_pair_bf16x3(const uint4* __restrict__ E
 #pragma unroll
   for (int r = 0; r < 16; ++r) sc = (r == reg) ? acc[r] : sc;
   if (mode != 2) {
-    if (diag_lane) out[p] = erow >= 0 ? sc : 0.f;
+    if (diag_lane) out[p] = erow >= 0 ? x3_scale(sc, -sexp) : 0.f;
     return;
   }
   // filter correction: what the count kernel counted for a known answer -- its logit ABOVE THE BAND of the query's target
@@ -372,7 +400,7 @@ static void pair_launch(coper_handle* h, int mode, int64_t n_pairs, int64_t B, i
   hipLaunchKernelGGL(k_pair_bf16x3, dim3((unsigned)((n_pairs + 32 * wpb - 1) / (32 * wpb))), dim3(64 * wpb), 0, s, (const uint4*)h->Erm16_hi,
                      (const uint4*)h->Erm16_lo, h->bias_pad, (const uint4*)h->hrm16_hi, (const uint4*)h->hrm16_lo,
                      dm.KS16, mode, n_pairs, B, L, e2, lookup, indptr, idx, row_of, tband, (int64_t)h->cfg.shard_lo,
-                     dm.n_local, out, ng);
+                     dm.n_local, out, ng, h->x3s);
 }
 
 int launch_pair_targets_bf16x3(coper_handle* h, const float* hvec, const int64_t* e2, int64_t B, float* tgt,

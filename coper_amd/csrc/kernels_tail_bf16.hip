@@ -21,6 +21,12 @@
 // Round 3: the k-steps run in the pair order of bf16x3_chain.h; the query fragments go to the count kernel's f3 image; the
 // kernel also forms the exact band of every query (tau from |h_q|, k_score_count3_bf16x3's header): tband[q] = {t - tau,
 // t + tau}, and a known answer is taken back only when its logit lies ABOVE the band (what the count kernel counts).
+//
+// Round 4: the split is scale-invariant (split16.h) -- the query planes hold h 2^e_h with e_h chosen from the largest |h|
+// element of the BATCH, which no workgroup of this kernel can know while it finalizes its own 32 queries.  So the finalize
+// moved into a launch of its own, k_finalize_h_publish (sum of the K slices + dense bias + folded FCBN + ReLU -> the fp32 rows
+// the exact band re-scores from, the batch maximum folded into the handle's x3s words, published by the last block), and
+// phase 1 here reads those rows -- 16 MB instead of the 17 - 34 MB of partial sums -- scales and splits them.
 #include "bf16x3_chain.h"
 #include "coper_internal.h"
 #include "conv_fold.h"
@@ -29,11 +35,6 @@
 #include <vector>
 
 namespace coper {
-
-__device__ __forceinline__ float tail_band_tau(float h_norm2, float kappa, const unsigned* __restrict__ consts) {   // = band_tau (kernels_score3_bf16.hip)
-  const float emax = __uint_as_float(consts[0]), bmax = __uint_as_float(consts[1]);
-  return 2.f * kappa * (sqrtf(h_norm2) * 1.000001f * emax + bmax);
-}
 
 #ifdef COPER_DBG_TL_CLOCK
 // diagnostic build (tools/ab_build.py): s_memrealtime (100 MHz) at the phase boundaries of wave 0 of every workgroup;
@@ -48,15 +49,53 @@ __device__ unsigned long long g_tl_t0;
 #define TL_STAMP(i_)
 #endif
 
+// h rows of a pass: piece (query q, 8 features from 8 p) per thread; the arithmetic of k_dense_finalize (kernels_encode_bf16.hip),
+// bit for bit.  Every block folds its largest value into x3s (x3_block_publish: the last block publishes e_h of the batch).
+__global__ __launch_bounds__(256) void k_finalize_h_publish(const float* __restrict__ z_part, int ksplit, int64_t Bcap, int64_t B, int d,
+                                                            int d_pad16, const int32_t* __restrict__ inv_perm,
+                                                            const int32_t* __restrict__ sorted_rid, const float* __restrict__ fc_b,
+                                                            int per_rel_bias, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, const int32_t* __restrict__ w_exp, int x_exp,
+                                                            float* __restrict__ h_out, int ent_exp, int32_t* __restrict__ x3s) {
+  const int np = d_pad16 / 8;
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t q = j / np;
+  const int k0 = (int)(j - q * np) * 8;
+  float m = 0.f;
+  if (q < B && k0 < d) {
+    const int64_t pos = inv_perm[q];
+    const int rid = sorted_rid[pos];
+    const float* bsrc = per_rel_bias ? fc_b + (int64_t)rid * d : fc_b;
+    const int zexp = -((w_exp ? w_exp[per_rel_bias ? rid : 0] : 0) + x_exp);   // the partial sums carry 2^(e_W + e_x) (split16.h)
+    float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < ksplit; ++s) {
+      const float4* pp = (const float4*)(z_part + ((int64_t)s * Bcap + pos) * d_pad16 + k0);
+      const float4 a = pp[0], b = pp[1];
+      z[0] += a.x; z[1] += a.y; z[2] += a.z; z[3] += a.w;
+      z[4] += b.x; z[5] += b.y; z[6] += b.z; z[7] += b.w;
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int k = k0 + c;
+      if (k < d) {
+        float v = x3_scale(z[c], zexp) + bsrc[k];
+        v = fmaf(v, scale[k], shift[k]);
+        v = fmaxf(v, 0.f);
+        h_out[q * d + k] = v;
+        m = fmaxf(m, v);
+      }
+    }
+  }
+  x3_block_publish(m, ent_exp, x3s);
+}
+
 template <int KS>
 __global__ __launch_bounds__(64 * TL_WAVES, KS <= 13 ? 3 : 2) void k_finalize_targets_filter_bf16x3(
-    const float* __restrict__ z_part, int ksplit, int64_t Bcap, int64_t B, int d, int d_pad16, const int32_t* __restrict__ inv_perm,
-    const int32_t* __restrict__ sorted_rid, const float* __restrict__ fc_b, int per_rel_bias, const float* __restrict__ scale,
-    const float* __restrict__ shift, float* __restrict__ h_out, uint4* __restrict__ hf3,
+    int64_t B, int d, const float* __restrict__ h_rows, uint4* __restrict__ hf3,
     const uint4* __restrict__ Ehi, const uint4* __restrict__ Elo, const float* __restrict__ bias_pad, int64_t n_local,
     const int64_t* __restrict__ e2, const int64_t* __restrict__ indptr, const int64_t* __restrict__ idx, float* __restrict__ tgt,
-    float kappa, const unsigned* __restrict__ band_consts, float2* __restrict__ tband, int32_t* __restrict__ ranks,
-    int32_t* __restrict__ heavy) {
+    float kappa, const unsigned* __restrict__ band_consts, const int32_t* __restrict__ x3s, float2* __restrict__ tband,
+    int32_t* __restrict__ ranks, int32_t* __restrict__ heavy) {
   __shared__ uint4 s_bh[KS][64], s_bl[KS][64];   // the block's B-operand fragments (hi / lo), shared by the waves
   __shared__ int64_t s_e[TL_WAVES][32];
   __shared__ int s_corr[32];
@@ -77,66 +116,25 @@ __global__ __launch_bounds__(64 * TL_WAVES, KS <= 13 ? 3 : 2) void k_finalize_ta
   if (threadIdx.x == 0 && p_all > p_end) heavy[2 + atomicAdd(&heavy[0], 1)] = (int32_t)blk;
   const int64_t my_lo = live ? indptr[q] : p_end;   // first entry of query i (lane i), for the search in filter_tile
 
-  // ---- 1. finalize: wave w takes k-steps w, w + 4, ...; a lane computes piece (ks, half) of its query
+  // ---- 1. the block's fragments: wave w takes k-steps w, w + 4, ...; a lane scales and splits piece (ks, half) of its query's
+  // fp32 row (k_finalize_h_publish wrote it; the batch's exponents are published)
+  const int eh = x3s[0], sexp = x3s[1];
   {
-    const int64_t pos = live ? inv_perm[q] : 0;
-    const float* bsrc = live ? (per_rel_bias ? fc_b + (int64_t)sorted_rid[pos] * d : fc_b) : fc_b;
-    const bool vec_ok = (d & 3) == 0 && (((uintptr_t)fc_b | (uintptr_t)scale | (uintptr_t)shift) & 15) == 0;
+    const bool vec_ok = (d & 3) == 0 && (((uintptr_t)h_rows) & 15) == 0;
     float n2 = 0.f;
 #pragma unroll
     for (int ks = wave; ks < KS; ks += TL_WAVES) {
       const int k0 = 16 * ks + 8 * half;
       float y[8];
-      if (live && k0 < d_pad16) {
-        float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int s = 0; s < ksplit; ++s) {
-          const float4* pp = (const float4*)(z_part + ((int64_t)s * Bcap + pos) * d_pad16 + k0);
-          const float4 a = pp[0], b = pp[1];
-          z[0] += a.x; z[1] += a.y; z[2] += a.z; z[3] += a.w;
-          z[4] += b.x; z[5] += b.y; z[6] += b.z; z[7] += b.w;
-        }
-        // dense bias, folded FCBN: 16-byte loads when the piece lies inside d (d % 8 == 0 for every shipped shape)
-        float bb[8], sc8[8], sh8[8];
-        if (k0 + 8 <= d && vec_ok) {
-          const float4 b0 = *(const float4*)(bsrc + k0), b1 = *(const float4*)(bsrc + k0 + 4);
-          const float4 s0 = *(const float4*)(scale + k0), s1 = *(const float4*)(scale + k0 + 4);
-          const float4 t0 = *(const float4*)(shift + k0), t1 = *(const float4*)(shift + k0 + 4);
-          bb[0] = b0.x; bb[1] = b0.y; bb[2] = b0.z; bb[3] = b0.w; bb[4] = b1.x; bb[5] = b1.y; bb[6] = b1.z; bb[7] = b1.w;
-          sc8[0] = s0.x; sc8[1] = s0.y; sc8[2] = s0.z; sc8[3] = s0.w; sc8[4] = s1.x; sc8[5] = s1.y; sc8[6] = s1.z; sc8[7] = s1.w;
-          sh8[0] = t0.x; sh8[1] = t0.y; sh8[2] = t0.z; sh8[3] = t0.w; sh8[4] = t1.x; sh8[5] = t1.y; sh8[6] = t1.z; sh8[7] = t1.w;
-        } else {
-#pragma unroll
-          for (int c = 0; c < 8; ++c) {
-            const int k = k0 + c < d ? k0 + c : d - 1;
-            bb[c] = bsrc[k]; sc8[c] = scale[k]; sh8[c] = shift[k];
-          }
-        }
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          const int k = k0 + c;
-          float v = 0.f;
-          if (k < d) {
-            v = z[c] + bb[c];
-            v = fmaf(v, sc8[c], sh8[c]);
-            v = fmaxf(v, 0.f);
-            n2 = fmaf(v, v, n2);
-          }
-          y[c] = v;
-        }
-        // fp32 rows: what the exact band re-scores from (and the caller's h when it asked for it)
-        if (k0 + 8 <= d && (d & 3) == 0 && (((uintptr_t)h_out) & 15) == 0) {
-          float4* ho = (float4*)(h_out + q * d + k0);
-          ho[0] = make_float4(y[0], y[1], y[2], y[3]);
-          ho[1] = make_float4(y[4], y[5], y[6], y[7]);
-        } else {
-#pragma unroll
-          for (int c = 0; c < 8; ++c)
-            if (k0 + c < d) h_out[q * d + k0 + c] = y[c];
-        }
+      if (live && k0 + 8 <= d && vec_ok) {
+        const float4 a = *(const float4*)(h_rows + q * d + k0), b = *(const float4*)(h_rows + q * d + k0 + 4);
+        y[0] = a.x; y[1] = a.y; y[2] = a.z; y[3] = a.w; y[4] = b.x; y[5] = b.y; y[6] = b.z; y[7] = b.w;
       } else {
 #pragma unroll
-        for (int c = 0; c < 8; ++c) y[c] = 0.f;
+        for (int c = 0; c < 8; ++c) y[c] = (live && k0 + c < d) ? h_rows[q * d + k0 + c] : 0.f;
       }
+#pragma unroll
+      for (int c = 0; c < 8; ++c) { n2 = fmaf(y[c], y[c], n2); y[c] = x3_scale(y[c], eh); }
       uint4 h4, l4;
       split8_bf16(y, h4, l4);
       f3_store_piece(hf3, KS, q, ks, half, h4, l4, true);   // rows past B: zero pieces (the count kernel's tile is whole)
@@ -166,7 +164,7 @@ __global__ __launch_bounds__(64 * TL_WAVES, KS <= 13 ? 3 : 2) void k_finalize_ta
   if (erow < 0 || erow >= n_local) erow = -1;
   // one tile of entries [pb, pb + 32): (score of entry i against its own query, that query, the entry's row or -1)
   auto filter_tile = [&](const int64_t pb, float& sc, int& qi_out) -> int64_t {
-    return tail_filter_tile<KS>(pb, p_end, my_lo, my_e2, idx, n_local, s_e[wave], Ehi, Elo, bias_pad, bh, bl, i, half, sc, qi_out);
+    return tail_filter_tile<KS>(pb, p_end, my_lo, my_e2, idx, n_local, s_e[wave], Ehi, Elo, bias_pad, bh, bl, i, half, sexp, sc, qi_out);
   };
   float sc0 = 0.f;
   int qi0 = 0;
@@ -175,7 +173,7 @@ __global__ __launch_bounds__(64 * TL_WAVES, KS <= 13 ? 3 : 2) void k_finalize_ta
     if (half == 0) s_e[0][i] = erow;
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_wave_barrier();
-    const f32x16 acc = tail_tile<KS>(Ehi, Elo, bias_pad, s_e[0], erow, bh, bl, half);
+    const f32x16 acc = tail_tile<KS>(Ehi, Elo, bias_pad, s_e[0], erow, bh, bl, half, sexp);
     // D[i][i] sits in lane i + 32 * ((i >> 2) & 1), register (i & 3) + 4 * (i >> 3)
     float diag = 0.f;
     const int reg = (i & 3) + 4 * (i >> 3);
@@ -187,9 +185,10 @@ __global__ __launch_bounds__(64 * TL_WAVES, KS <= 13 ? 3 : 2) void k_finalize_ta
       float n2 = 0.f;
 #pragma unroll
       for (int w2 = 0; w2 < TL_WAVES; ++w2) n2 += s_n2[w2][i];
-      const float tau = tail_band_tau(n2, kappa, band_consts);
+      // t0, the band and everything compared with them stay in the accumulators' units (x 2^(e_E + e_h)); tgt leaves descaled
+      const float tau = x3_scale(x3_band_tau(n2, kappa, band_consts, d, x3s), sexp);
       s_t[i] = t0 + tau;
-      if (live) { tgt[q] = t0; tband[q] = make_float2(t0 - tau, t0 + tau); }
+      if (live) { tgt[q] = x3_scale(t0, -sexp); tband[q] = make_float2(t0 - tau, t0 + tau); }
     }
   } else {
     const int64_t pb = p_begin + 32 * (int64_t)(wave - 1);
@@ -243,18 +242,29 @@ bool tail_fused_supported(const coper_handle* h) {
 // (Tried in round 3: the filter tiles moved out of this launch into extra workgroups of the band launch that follows the count
 // kernel -- this launch 44 -> 25 us, but the band launch 16 -> 51: at ~190 registers a wave only two workgroups fit a CU and
 // the 1,280 filter workgroups ran in three rounds.  Pass 0.536 against 0.516 ms; not kept.)
+int launch_finalize_h_publish(coper_handle* h, int64_t B, int ksplit, float* h_out, hipStream_t s) {
+  const Dims& dm = h->dm;
+  const float* fcb = dm.gen_fc ? h->fc_b_rel : h->params["fc_bias"].ptr;
+  const int64_t total = B * (dm.d_pad16 / 8);
+  hipLaunchKernelGGL(k_finalize_h_publish, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, h->z_part, ksplit, h->ws_queries, B, dm.d,
+                     dm.d_pad16, h->inv_perm, h->sorted_rid, fcb, dm.gen_fc ? 1 : 0, h->fc_scale, h->fc_shift, h->w_exp, h->x_exp, h_out,
+                     h->x3_ent_exp, h->x3s);
+  COPER_HIP_TRY(h, hipGetLastError());
+  return COPER_OK;
+}
+
 int launch_finalize_targets_filter_bf16x3(coper_handle* h, int64_t B, int ksplit, float* h_out, const int64_t* e2, const int64_t* indptr,
                                           const int64_t* idx, int64_t nnz, float* tgt, int32_t* ranks, hipStream_t s) {
   const Dims& dm = h->dm;
-  const float* fcb = dm.gen_fc ? h->fc_b_rel : h->params["fc_bias"].ptr;
+  int rc0 = launch_finalize_h_publish(h, B, ksplit, h_out, s);
+  if (rc0) return rc0;
   const int64_t rows_pad = (B + 127) / 128 * 128;
   const unsigned grid = (unsigned)(rows_pad / 32);
 #define TL_GO(KS_)                                                                                                                 \
-  hipLaunchKernelGGL(k_finalize_targets_filter_bf16x3<KS_>, dim3(grid), dim3(64 * TL_WAVES), 0, s, h->z_part, ksplit, h->ws_queries, B, dm.d, \
-                     dm.d_pad16, h->inv_perm, h->sorted_rid, fcb, dm.gen_fc ? 1 : 0, h->fc_scale, h->fc_shift, h_out,               \
+  hipLaunchKernelGGL(k_finalize_targets_filter_bf16x3<KS_>, dim3(grid), dim3(64 * TL_WAVES), 0, s, B, dm.d, (const float*)h_out,   \
                      (uint4*)h->hf3_ws, (const uint4*)h->Erm16_hi, (const uint4*)h->Erm16_lo,                                       \
-                     h->bias_pad, dm.n_local, e2, indptr, idx, tgt, band_kappa(h), h->band_consts, (float2*)h->tband_ws, ranks,   \
-                     h->heavy_ws)
+                     h->bias_pad, dm.n_local, e2, indptr, idx, tgt, band_kappa(h), h->band_consts, h->x3s, (float2*)h->tband_ws,   \
+                     ranks, h->heavy_ws)
   if (dm.KS16 == 13) { TL_GO(13); } else { TL_GO(16); }
 #undef TL_GO
   COPER_HIP_TRY(h, hipGetLastError());

@@ -508,8 +508,9 @@ __global__ __launch_bounds__(256) void k_topk_score_blocks(const uint4* __restri
                                                            const int64_t* __restrict__ idx, const int32_t* __restrict__ cand_blk,
                                                            const int32_t* __restrict__ cand_q, const int32_t* __restrict__ blk_off,
                                                            const int32_t* __restrict__ sorted, int64_t lo,
-                                                           float* __restrict__ cand_val) {
+                                                           float* __restrict__ cand_val, const int32_t* __restrict__ x3s) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5, c = lane & 31;
+  const int sexp = x3s[1];   // the accumulators' power of two (split16.h): candidate values stay in the units of the block maxima
   const int64_t i = (int64_t)blockIdx.x * 4 + wave;
   if (i * 32 >= blk_off[G]) return;   // G here: number of (block, segment) counters
   const int64_t g = cand_blk[sorted[i * 32]];   // the first slot of a wave's 32 is always in use
@@ -521,7 +522,8 @@ __global__ __launch_bounds__(256) void k_topk_score_blocks(const uint4* __restri
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float4 b4 = bp[2 * j];
-      acc[4 * j + 0] = b4.x; acc[4 * j + 1] = b4.y; acc[4 * j + 2] = b4.z; acc[4 * j + 3] = b4.w;
+      acc[4 * j + 0] = x3_scale(b4.x, sexp); acc[4 * j + 1] = x3_scale(b4.y, sexp);
+      acc[4 * j + 2] = x3_scale(b4.z, sexp); acc[4 * j + 3] = x3_scale(b4.w, sexp);
     }
   }
   const uint4* pa_h = Ehi + g * KS * 64 + lane;
@@ -572,8 +574,9 @@ constexpr int TK_SURV = 256;   // survivors per query held in LDS
 __global__ __launch_bounds__(256) void k_topk_select_cand(float* __restrict__ cand_val, const int32_t* __restrict__ cand_blk,
                                                           const uint32_t* __restrict__ cand_tau, const int64_t* __restrict__ indptr,
                                                           int64_t B, int k, int64_t lo, float* __restrict__ out_val,
-                                                          int64_t* __restrict__ out_idx) {
+                                                          int64_t* __restrict__ out_idx, const int32_t* __restrict__ x3s) {
   __shared__ float s_v[4][TK_SURV];
+  const int dexp = x3s ? -x3s[1] : 0;   // x3 mode: candidate values carry 2^(e_E + e_h); what is written out does not
   __shared__ int s_id[4][TK_SURV];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t q = (int64_t)blockIdx.x * 4 + wave;
@@ -619,7 +622,7 @@ __global__ __launch_bounds__(256) void k_topk_select_cand(float* __restrict__ ca
         const int i2 = s_id[wave][t];
         ahead += (v2 > v || (v2 == v && i2 < id)) ? 1 : 0;
       }
-      if (ahead < k) { ov[ahead] = v; oi[ahead] = lo + id; }
+      if (ahead < k) { ov[ahead] = x3_scale(v, dexp); oi[ahead] = lo + id; }
     }
     for (int r = S + lane; r < k; r += 64) { ov[r] = -INFINITY; oi[r] = -1; }
     return;
@@ -644,7 +647,7 @@ __global__ __launch_bounds__(256) void k_topk_select_cand(float* __restrict__ ca
     }
     // every lane holds the winner now; the lane that read it retires it (its own later reads see its own store)
     if (lane == 0) {
-      ov[round] = bpos >= 0 ? best : -INFINITY;
+      ov[round] = bpos >= 0 ? x3_scale(best, dexp) : -INFINITY;
       oi[round] = bpos >= 0 ? lo + bid : -1;
     }
     if (bpos >= 0 && (bpos & 63) == lane) val[bpos] = -INFINITY;
@@ -714,9 +717,9 @@ int launch_topk_pruned_bf16x3(coper_handle* h, const float* hvec, const float* t
   hipLaunchKernelGGL(k_topk_score_blocks, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, (const uint4*)h->Ef16_hi,
                      (const uint4*)h->Ef16_lo, h->bias_pad, (const uint4*)h->hrm16_hi, (const uint4*)h->hrm16_lo, dm.KS16, GV, e2,
                      indptr, idx, h->cand_blk_ws, h->cand_q_ws, h->blk_off_ws, h->cand_sorted_ws, (int64_t)h->cfg.shard_lo,
-                     h->cand_val_ws);
+                     h->cand_val_ws, h->x3s);
   hipLaunchKernelGGL(k_topk_select_cand, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s, h->cand_val_ws, h->cand_blk_ws, h->cand_tau_ws, indptr, B,
-                     k, (int64_t)h->cfg.shard_lo, topk_val, topk_idx);
+                     k, (int64_t)h->cfg.shard_lo, topk_val, topk_idx, h->x3s);
   COPER_HIP_TRY(h, hipGetLastError());
   return COPER_OK;
 }
@@ -744,7 +747,7 @@ int launch_topk_pruned_f32(coper_handle* h, const float* hvec, const float* tgt,
   }
   if ((rc = launch_topk_score_blocks_f32(h, hvec, T, e2, indptr, idx, s))) return rc;
   hipLaunchKernelGGL(k_topk_select_cand, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s, h->cand_val_ws, h->cand_blk_ws, h->cand_tau_ws, indptr, B,
-                     k, (int64_t)h->cfg.shard_lo, topk_val, topk_idx);
+                     k, (int64_t)h->cfg.shard_lo, topk_val, topk_idx, (const int32_t*)nullptr);
   COPER_HIP_TRY(h, hipGetLastError());
   return COPER_OK;
 }

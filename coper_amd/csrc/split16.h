@@ -4,15 +4,25 @@
 // MI355X_MICROARCH.md, Matrix cores); what differs is where the 16 bits go:
 //   bf16 (8-bit exponent, 8-bit significand):  hi + lo carries 16-17 significant bits of x (error <= 2^-16 |x|), any fp32
 //        magnitude;
-//   fp16 (5-bit exponent, 11-bit significand): hi + lo carries 22-23 significant bits (error <= 2^-22 |x| while
-//        |x| >= 2^-3: lo normal; 2^-25 absolute below that -- gfx950's fp16 MFMA keeps subnormal inputs: measured,
-//        tools/microbench/mfma_shape.hip), for |x| < 65,504.
-// Round 3 measured what the 8 missing bits cost (tools/rank_decomp.py, FB15k-237-shaped pass): the bf16 split's logit
-// error moves 2.1 % of the ranks, the bf16-split encoder's error in h another 2.1 %, against 0.4 % for fp32 arithmetic
-// throughout -- and the exact band around the target (kernels_score3_bf16.hip) has to be 16x wider, with 16x the pairs to
-// re-score.  So the split is fp16 (COPER_SPLIT_BF16 builds the round-2 arithmetic for A/B).  Range: operands are clamped to
-// +-65,504 before the split (an embedding, weight or activation beyond that saturates instead of becoming inf; prepare
-// refuses an entity table whose largest row norm says the clamp could matter).
+//   fp16 (5-bit exponent, 11-bit significand): hi + lo carries 22-23 significant bits (error <= 2^-22 |x|) while lo is a
+//        NORMAL fp16, i.e. 2^-3 <= |x| < 65,504; below that lo is subnormal and the error is 2^-25 ABSOLUTE (gfx950's fp16
+//        MFMA keeps subnormal inputs: measured, tools/microbench/mfma_shape.hip).
+// Round 3 measured what the 8 missing bits cost (tools/rank_decomp.py): the split is fp16 (COPER_SPLIT_BF16 builds the
+// round-2 arithmetic for A/B).
+//
+// Round 4: the split is SCALE-INVARIANT.  fp16's 22 bits only exist in a window of magnitudes, and nothing about the model
+// puts its operands there: the reference initialises ent_emb with xavier_initializer (models.py:205-208: +-0.02 for
+// FB15k-237, +-7.7e-4 for a 10M-entity table), where EVERY element sat in the absolute-error regime.  So every operand class
+// is multiplied by an exact power of two before the split, chosen from its largest magnitude so that  max |x| 2^e  lies in
+// [2^14, 2^15)  (x3_exp_for below: one binade of headroom under fp16's 65,504; the clamp can no longer trigger on finite
+// data), and the inverse power of two is folded into everything that leaves the arithmetic:
+//   entity table      one exponent per handle (prepare; coper_config.x3_ent_absmax lets the shards of one table agree)
+//   queries h         one exponent per packed batch, from the batch's largest |h| element (k_absmax_publish / the finalize)
+//   dense weights W_r one exponent per relation (prepare);  conv activations x: one exponent per handle from a bound (prepare)
+// A power-of-two factor commutes with every fp32 rounding (no overflow / underflow: exponents are clamped to +-X3_EXP_CLAMP),
+// so the fp32 chain, the f32 mode and the oracle do not change, and an x3 accumulator is 2^(e_E + e_h) times the logit the
+// unscaled arithmetic would have produced with all 22 bits.  Elements more than 2^17 below the largest of their class still
+// fall into the absolute regime -- 2^-25 2^-e, i.e. 2^-39 of the class maximum: the exact band carries that term (band_tau).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -32,6 +42,23 @@ typedef _Float16 s16_t;
 __device__ __forceinline__ float s16_clamp(float v) { return __builtin_fminf(__builtin_fmaxf(v, -65504.f), 65504.f); }   // (NaN stays NaN)
 #endif
 typedef s16_t s16x8 __attribute__((ext_vector_type(8)));
+
+// exponent e with  maxabs * 2^e  in [2^14, 2^15)  (0 for zero / non-finite maxima); |e| <= X3_EXP_CLAMP
+constexpr int X3_EXP_CLAMP = 60;
+__host__ __device__ __forceinline__ int x3_exp_for_bits(unsigned bits) {   // bits of a non-negative float
+#ifdef COPER_SPLIT_BF16
+  (void)bits;
+  return 0;                                   // (bf16 carries fp32's exponent range: nothing to move)
+#else
+  const int be = (int)((bits >> 23) & 255u);
+  if ((bits & 0x7fffffffu) == 0u || be == 255) return 0;
+  // normal: maxabs in [2^(be-127), 2^(be-126));  subnormal maxima are treated like the smallest normal
+  const int e = 14 - ((be ? be : 1) - 127);
+  return e > X3_EXP_CLAMP ? X3_EXP_CLAMP : (e < -X3_EXP_CLAMP ? -X3_EXP_CLAMP : e);
+#endif
+}
+// v * 2^e, exact (v_ldexp_f32)
+__device__ __forceinline__ float x3_scale(float v, int e) { return __builtin_ldexpf(v, e); }
 typedef s16_t s16x2 __attribute__((ext_vector_type(2)));
 
 #define S16_MFMA32(a, b, c) S16_MFMA32_BUILTIN(*(const coper::s16x8*)&(a), *(const coper::s16x8*)&(b), (c), 0, 0, 0)

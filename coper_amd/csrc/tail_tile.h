@@ -15,12 +15,12 @@ namespace coper {
 template <int KS>
 __device__ __forceinline__ f32x16 tail_tile(const uint4* __restrict__ Ehi, const uint4* __restrict__ Elo, const float* __restrict__ bias_pad,
                                             const int64_t* s_e, const int64_t my_erow, const uint4 (&bh)[KS], const uint4 (&bl)[KS],
-                                            const int half) {
+                                            const int half, const int sexp) {
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int64_t er = s_e[(r & 3) + 8 * (r >> 2) + 4 * half];
-    acc[r] = er >= 0 ? bias_pad[er] : 0.f;
+    acc[r] = er >= 0 ? x3_scale(bias_pad[er], sexp) : 0.f;     // accumulators carry 2^(e_E + e_h) (split16.h)
   }
   const int64_t ea = my_erow >= 0 ? my_erow : 0;
   const uint4* pa_h = Ehi + ea * (2 * KS) + half;
@@ -55,7 +55,7 @@ __device__ __forceinline__ int64_t tail_filter_tile(const int64_t pb, const int6
                                                     const int64_t* __restrict__ idx, const int64_t n_local, int64_t* s_e,
                                                     const uint4* __restrict__ Ehi, const uint4* __restrict__ Elo,
                                                     const float* __restrict__ bias_pad, const uint4 (&bh)[KS], const uint4 (&bl)[KS],
-                                                    const int i, const int half, float& sc, int& qi_out) {
+                                                    const int i, const int half, const int sexp, float& sc, int& qi_out) {
   const int64_t p = pb + i;
   // every lane runs the same cross-lane reads (a shuffle must not sit in divergent code: inactive lanes supply nothing);
   // lanes past the last entry carry frow = -1
@@ -82,7 +82,7 @@ __device__ __forceinline__ int64_t tail_filter_tile(const int64_t pb, const int6
   if (half == 0) s_e[i] = frow;
   __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): wave-local LDS exchange
   __builtin_amdgcn_wave_barrier();
-  const f32x16 acc = tail_tile<KS>(Ehi, Elo, bias_pad, s_e, frow, bh, bl, half);
+  const f32x16 acc = tail_tile<KS>(Ehi, Elo, bias_pad, s_e, frow, bh, bl, half, sexp);
   // entry i wants D[i][qi]: register (i & 3) + 4 * (i >> 3) of lane qi + 32 * ((i >> 2) & 1)
   const int src = qi + 32 * ((i >> 2) & 1);
   const int reg = (i & 3) + 4 * (i >> 3);
@@ -112,10 +112,11 @@ constexpr int TL_WAVES = COPER_TL_WAVES;   // waves per 32-query block: they sha
 
 
 // The query fragments of 32-query block q0 .. q0 + 31 rebuilt from the fp32 rows the finalize wrote: lane (i, half) holds
-// piece (ks, half) of query q0 + i -- same values, same split, so the bits the finalize held.
+// piece (ks, half) of query q0 + i -- same values, same power of two (eh = e_h of the batch), same split, so the bits the
+// finalize held.
 template <int KS>
 __device__ __forceinline__ void tail_fragments_from_rows(const float* __restrict__ hvec, const int64_t q, const bool live, const int d,
-                                                         const int half, uint4 (&bh)[KS], uint4 (&bl)[KS]) {
+                                                         const int half, const int eh, uint4 (&bh)[KS], uint4 (&bl)[KS]) {
   const bool vec_ok = (d & 3) == 0 && (((uintptr_t)hvec) & 15) == 0;
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
@@ -128,6 +129,8 @@ __device__ __forceinline__ void tail_fragments_from_rows(const float* __restrict
 #pragma unroll
       for (int c = 0; c < 8; ++c) y[c] = (live && k0 + c < d) ? hvec[q * d + k0 + c] : 0.f;
     }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) y[c] = x3_scale(y[c], eh);
     split8_bf16(y, bh[ks], bl[ks]);
   }
 }
@@ -151,7 +154,7 @@ __device__ __forceinline__ void tail_take_back(const bool hit, const int qi, con
 
 struct FilterArgs {          // the filter role's view of a pass (queries of one count launch: all pointers at its first query)
   const float* hvec; const uint4* Ehi; const uint4* Elo; const float* bias_pad; const int64_t* e2; const int64_t* indptr;
-  const int64_t* idx; const float2* tband; int32_t* ranks; int32_t* heavy; int64_t B, n_local; int d;
+  const int64_t* idx; const float2* tband; int32_t* ranks; int32_t* heavy; const int32_t* x3s; int64_t B, n_local; int d;
 };
 
 }  // namespace coper

@@ -94,6 +94,14 @@ def ranking_and_hits(model, results_dir, data_iterator_handle, name, session=Non
             r, _ = local_rank_pass(model, chunk)
         ranks.append(r)
     ranks = torch.cat(ranks).cpu().numpy().astype(np.int64) if ranks else np.zeros(0, np.int64)
+    # bf16x3 mode: the run-time audit of the exact band (include/coper_hip.h: coper_band_audit) -- the largest error of the
+    # mode's logits on the pairs closest to the targets, relative to what the band allows; ranks are the fp32 chain's below 1
+    if Q and getattr(model, "score_mode", None) == "bf16x3" and hasattr(model, "band_audit"):
+        ratio, n_pairs = model.band_audit()
+        ranking_and_hits.last_band_audit = (ratio, n_pairs)
+        if ratio > 0.5:
+            logger.warning("bf16x3 band audit: |logit_x3 - logit_fp32| reached %.2f of the band's allowance on %d audited pairs; "
+                           "raise rank_band_kappa (ranks may differ from the fp32 chain's above 1.0)", ratio, n_pairs)
     count = Q
     logger.info("Evaluated %d samples." % count)
 

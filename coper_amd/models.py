@@ -146,6 +146,9 @@ class ConvE(object):
             v = params[name]
             t = v if isinstance(v, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(v))
             if name in ("ent_emb", "pred_bias") and global_rows and t.shape[0] == self.num_ent and (lo, hi) != (0, self.num_ent):
+                if name == "ent_emb" and self.score_mode == "bf16x3":
+                    # every shard of one table scales its planes by the same power of two (include/coper_hip.h: x3_ent_absmax)
+                    self.set_x3_ent_absmax(float(t.abs().max()) if t.numel() else 0.0)
                 t = t[lo:hi]
             t = t.to(device=self.device, dtype=torch.float32).contiguous()
             if t.numel() != int(np.prod(want)):
@@ -442,6 +445,19 @@ class ConvE(object):
 
         run.graph = graph
         return run
+
+    def set_x3_ent_absmax(self, absmax: float):
+        """coper_set_x3_ent_absmax: the largest |ent_emb| element of the WHOLE table, for a handle that holds a shard of it
+        (sharding.py all-reduces it; load_parameters sets it when it is handed the whole table)."""
+        _lib.check(self._h, self._lib.coper_set_x3_ent_absmax(self._h, float(absmax)))
+        self._prepared = False
+
+    def band_audit(self, reset=True):
+        """(max |logit_x3 - logit_chain| / (tau / 2), pairs audited) since the last reset (coper_band_audit): the run-time
+        check of the bf16x3 mode's exact band.  (0.0, 0) in the f32 mode."""
+        r, n = C.c_float(), C.c_int64()
+        _lib.check(self._h, self._lib.coper_band_audit(self._h, 1 if reset else 0, C.byref(r), C.byref(n), self._stream()))
+        return float(r.value), int(n.value)
 
     def check_ids(self):
         n = C.c_int64()

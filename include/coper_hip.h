@@ -33,7 +33,7 @@ extern "C" {
 #define COPER_API
 #endif
 
-#define COPER_ABI_VERSION 2
+#define COPER_ABI_VERSION 3
 #define COPER_MAX_CTX 4 /* max hidden layers of a g_MLP generator */
 
 typedef enum coper_status {
@@ -84,7 +84,12 @@ typedef struct coper_config {
    * own arithmetic (integer ranks: metrics.py:44-50).  0 = the library default (1e-5, three times the largest error observed
    * on 3e8 logits); 3 * 2^-16 + 2 (48 ceil(d/16) + 1) 2^-24 is the proven worst case.  Larger = more pairs re-scored. */
   float rank_band_kappa;
-  int32_t reserved[6];
+  /* COPER_SCORE_BF16X3: the entity planes hold ent_emb 2^e with e chosen so that this magnitude lands in [2^14, 2^15) of
+   * fp16's range.  0 = the largest |ent_emb| element of the handle's own rows.  Entity shards of one table pass the table-wide
+   * maximum (coper_amd/sharding.py all-reduces it) so that the mode's logits do not depend on the shard layout; a value below
+   * the shard's own maximum is refused by coper_prepare. */
+  float x3_ent_absmax;
+  int32_t reserved[5];
 } coper_config;
 
 typedef struct coper_handle coper_handle;
@@ -120,6 +125,10 @@ COPER_API int coper_param_spec(const coper_handle* h, int index, const char** le
  * dev_ptr: fp32, contiguous, on cfg.device.  ent_emb / pred_bias are the LOCAL shard rows. */
 COPER_API int coper_set_param(coper_handle* h, const char* leaf_name, const void* dev_ptr,
                     const int64_t* shape, int ndim);
+
+/* coper_config.x3_ent_absmax after coper_create (a host that learns the table-wide maximum only when the parameters arrive:
+ * coper_amd.models.ConvE.load_parameters, coper_amd/sharding.py).  The handle must be prepared (again) afterwards. */
+COPER_API int coper_set_x3_ent_absmax(coper_handle* h, float absmax);
 
 /* Builds everything inference derives from the parameters (re-run after any weight change):
  *   - BN (Conv1BN, FCBN, generator BNs) folded to per-channel affine   models.py:61-65,386-388,416-418
@@ -218,6 +227,15 @@ COPER_API int coper_rank(coper_handle* h, const float* hvec, const int64_t* e2, 
 COPER_API int coper_encode_rank(coper_handle* h, const int64_t* e1, const int64_t* rel, const float* e1_rows,
                                 const int64_t* e2, const int64_t* filt_indptr, const int64_t* filt_idx, int64_t filt_nnz,
                                 int64_t B, float* h_out, int32_t* ranks, int32_t* n_equal, void* stream);
+
+/* COPER_SCORE_BF16X3: the run-time audit of the exact band.  Every count launch re-scores the pairs its band walk decides (the
+ * competitors closest to each target) with the mode's own arithmetic as well and keeps the largest
+ *        |logit_x3 - logit_chain| / (tau_q / 2)      (tau_q / 2: the error the band allows one logit; see rank_band_kappa)
+ * seen since the last reset, and the number of pairs audited (modulo 2^32).  A ratio below 1 on every audited pair is what
+ * makes the mode's ranks the fp32 chain's; the library's tests assert <= 0.5, coper_amd.metrics.ranking_and_hits logs a
+ * warning above it.  Synchronises the stream.  COPER_SCORE_F32 handles report 0 / 0.  The reference has no counterpart: its
+ * ranker works on materialised fp32 logits (metrics.py:40-50). */
+COPER_API int coper_band_audit(coper_handle* h, int32_t reset, float* max_ratio, int64_t* n_pairs, void* stream);
 
 /* Timing hook used by bench.py: average device time (ms) of the dominant kernel
  * (score_count) over the launches since the last reset, measured with hipEvents recorded on
