@@ -3,7 +3,10 @@
 // produce the same x bits for the same (e1, rel):
 //   inference BN folded into the filter:  tap'[k][c] = tap[k][c] * scale[c],  b'[c] = bias[c]*scale[c] + shift[c]
 //   x[c] = max(fma chain over the 9 taps started from b'[c], 0)           (models.py:390-404 at inference)
-//   x = hi + lo,  hi = bf16(x), lo = bf16(x - hi)
+//   x = hi + lo,  hi = fp16(x 2^e_x), lo = fp16(x 2^e_x - hi)      (split16.h)
+// Round 4: the power of two of the activations (e_x, one per handle, from a bound on x computed at prepare: coper_abi.hip) is
+// folded into the taps and the bias -- a positive power of two commutes with every fma of the chain and with the ReLU, so the
+// chain below yields x 2^e_x exactly (no overflow / underflow) at no cost per value.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -13,13 +16,13 @@ namespace coper {
 
 __device__ __forceinline__ void conv_fold_taps(const float* __restrict__ w, const float* __restrict__ b,
                                                const float* __restrict__ scale, const float* __restrict__ shift, int C,
-                                               int c0, float (&tap)[9][8], float (&bs)[8]) {
+                                               int c0, int x_exp, float (&tap)[9][8], float (&bs)[8]) {
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
     const float sc = scale[c0 + c];
-    bs[c] = fmaf(b[c0 + c], sc, shift[c0 + c]);
+    bs[c] = x3_scale(fmaf(b[c0 + c], sc, shift[c0 + c]), x_exp);
 #pragma unroll
-    for (int k = 0; k < 9; ++k) tap[k][c] = w[k * C + c0 + c] * sc;
+    for (int k = 0; k < 9; ++k) tap[k][c] = x3_scale(w[k * C + c0 + c] * sc, x_exp);
   }
 }
 

@@ -455,6 +455,30 @@ COPER_API int coper_prepare(coper_handle* h, void* stream) {
                            dm.d, cfg.bn_epsilon, h->fc_scale, h->fc_shift, s)))
     return rc;
 
+  if (cfg.score_mode != COPER_SCORE_F32) {
+    // the shard's maxima (row norm, |pred_bias|: the exact band; |element|: the power of two of the entity planes, split16.h)
+    if ((rc = dev_alloc(h, &h->band_consts, BAND_NCONST)) || (rc = dev_alloc(h, &h->x3s, 4))) return rc;
+    COPER_HIP_TRY(h, hipMemsetAsync(h->x3s, 0, 4 * sizeof(int32_t), s));
+    if ((rc = launch_band_consts(h, P("ent_emb"), P("pred_bias"), s))) return rc;
+    {
+      unsigned cb[BAND_NCONST];
+      COPER_HIP_TRY(h, hipMemcpyAsync(cb, h->band_consts, sizeof cb, hipMemcpyDeviceToHost, s));
+      COPER_HIP_TRY(h, hipStreamSynchronize(s));
+      float xmax;
+      memcpy(&xmax, &cb[2], sizeof xmax);
+      // shards of one table agree on the exponent through the hint (the mode's logits are then the same bits on every shard
+      // layout); a hint below the shard's own maximum could overflow fp16: refused
+      if (cfg.x3_ent_absmax > 0.f) {
+        if (!(cfg.x3_ent_absmax >= xmax)) return fail(h, COPER_EINVAL, "coper_prepare: x3_ent_absmax is below the largest |ent_emb| element of the shard");
+        xmax = cfg.x3_ent_absmax;
+      }
+      unsigned xb;
+      memcpy(&xb, &xmax, sizeof xb);
+      h->x3_ent_absmax = xmax;
+      h->x3_ent_exp = x3_exp_for_bits(xb);
+    }
+  }
+
   // scratch for generator hidden activations: R * max_hidden (+ 2 * max_hidden for the folded BN)
   int max_hidden = 1;
   for (int i = 0; i < cfg.n_ctx_conv; ++i) max_hidden = cfg.ctx_conv[i] > max_hidden ? cfg.ctx_conv[i] : max_hidden;
@@ -501,12 +525,16 @@ COPER_API int coper_prepare(coper_handle* h, void* stream) {
     if ((rc = launch_gen_dense_frag(h, nullptr, 1, 0, P("fc_weights"), 1, h->Wf, s))) return rc;
   }
   h->enc_bf16 = cfg.score_mode != COPER_SCORE_F32 && conv_bf16_supported(dm);
+  h->x_exp = 0;
   if (h->enc_bf16) {
     size_t plane = (size_t)h->Rw * dm.nfb * (dm.F_pad / 32) * 64 * 16;
     dev_free((char**)&h->Wf16_hi); dev_free((char**)&h->Wf16_lo);
     if (tracked_malloc(&h->Wf16_hi, plane) != hipSuccess || tracked_malloc(&h->Wf16_lo, plane) != hipSuccess)
       return fail(h, COPER_ENOMEM, "hipMalloc of the bf16 weight planes failed");
+    // powers of two of the encoder's operands (split16.h): e_W per relation from its own largest |W|, e_x from a bound on x
+    if ((rc = dev_alloc(h, &h->w_exp, (size_t)h->Rw))) return rc;
     if ((rc = launch_wfrag_to_bf16(h, h->Wf, h->Rw, h->Wf16_hi, h->Wf16_lo, s))) return rc;
+    if ((rc = compute_x_exp(h, h->band_consts + 5, s))) return rc;
     COPER_HIP_TRY(h, hipStreamSynchronize(s));
     dev_free(&h->Wf);  // the fp32 image was only the staging form
   }
@@ -529,27 +557,6 @@ COPER_API int coper_prepare(coper_handle* h, void* stream) {
     dev_free((char**)&h->Ef3);
     if (tracked_malloc(&h->Ef3, f3) != hipSuccess) { (void)hipGetLastError(); return fail(h, COPER_ENOMEM, "hipMalloc of the entity image failed"); }
     COPER_HIP_TRY(h, hipMemsetAsync(h->Ef3, 0, f3, s));
-    // the shard's maxima (row norm, |pred_bias|: the exact band; |element|: the power of two of the entity planes, split16.h)
-    if ((rc = dev_alloc(h, &h->band_consts, BAND_NCONST)) || (rc = dev_alloc(h, &h->x3s, 4))) return rc;
-    COPER_HIP_TRY(h, hipMemsetAsync(h->x3s, 0, 4 * sizeof(int32_t), s));
-    if ((rc = launch_band_consts(h, P("ent_emb"), P("pred_bias"), s))) return rc;
-    {
-      unsigned cb[BAND_NCONST];
-      COPER_HIP_TRY(h, hipMemcpyAsync(cb, h->band_consts, sizeof cb, hipMemcpyDeviceToHost, s));
-      COPER_HIP_TRY(h, hipStreamSynchronize(s));
-      float xmax;
-      memcpy(&xmax, &cb[2], sizeof xmax);
-      // shards of one table agree on the exponent through the hint (the mode's logits are then the same bits on every shard
-      // layout); a hint below the shard's own maximum could overflow fp16: refused
-      if (cfg.x3_ent_absmax > 0.f) {
-        if (!(cfg.x3_ent_absmax >= xmax)) return fail(h, COPER_EINVAL, "coper_prepare: x3_ent_absmax is below the largest |ent_emb| element of the shard");
-        xmax = cfg.x3_ent_absmax;
-      }
-      unsigned xb;
-      memcpy(&xb, &xmax, sizeof xb);
-      h->x3_ent_absmax = xmax;
-      h->x3_ent_exp = x3_exp_for_bits(xb);
-    }
     if ((rc = launch_rows_to_frag_bf16(h, P("ent_emb"), dm.n_local, dm.n_eblk, (uint4*)h->Ef16_hi, (uint4*)h->Ef16_lo,
                                        (uint4*)h->Erm16_hi, (uint4*)h->Erm16_lo, (uint4*)h->Ef3, false, s)))
       return rc;

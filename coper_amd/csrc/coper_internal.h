@@ -292,6 +292,7 @@ int launch_topk_pruned_bf16x3(coper_handle* h, const float* hvec, const float* t
 // kernels_encode_bf16.hip
 bool conv_bf16_supported(const Dims& dm);
 int launch_wfrag_to_bf16(coper_handle* h, const float* Wf, int64_t Rw, void* hi, void* lo, hipStream_t s);
+int compute_x_exp(coper_handle* h, unsigned* scratch, hipStream_t s);
 int launch_conv_bf16(coper_handle* h, const int64_t* e1, const int64_t* rel, const float* e1_rows, int64_t B,
                      bool skip_big, hipStream_t s);
 int launch_dense_bf16(coper_handle* h, int64_t B, int nslices, bool small_only, hipStream_t s);

@@ -48,7 +48,7 @@ struct FusedConvArgs {
   const float* conv_b;
   const float* scale;
   const float* shift;
-  int per_rel_conv, d, r, in_w, in_hw, Wo, img_stride;
+  int per_rel_conv, d, r, in_w, in_hw, Wo, img_stride, x_exp;
 };
 
 // Roles.  A workgroup is 8 waves, two per SIMD: waves 0..3 are MATRIX waves (wave w owns feature blocks
@@ -281,7 +281,7 @@ __device__ __forceinline__ void fused_conv_role(uint4* __restrict__ xring, float
   {
     const float* wsrc = A.per_rel_conv ? A.conv_w + relw * (int64_t)(9 * 32) : A.conv_w;
     const float* bsrc = A.per_rel_conv ? A.conv_b + relw * (int64_t)32 : A.conv_b;
-    conv_fold_taps(wsrc, bsrc, A.scale, A.shift, 32, 8 * g, tap, bs);
+    conv_fold_taps(wsrc, bsrc, A.scale, A.shift, 32, 8 * g, A.x_exp, tap, bs);
   }
   fused_load_images(img, A, start, n, t0, t1);
   // image rows of this lane's query in each of the wave's fragments (padding lanes repeat the last query)
@@ -451,7 +451,7 @@ static void dense_fused_launch(coper_handle* h, const int64_t* e1, const int64_t
   A.rel_emb = dm.lookup ? nullptr : h->params["rel_emb"].ptr;
   A.conv_w = dm.gen_conv ? h->conv_w_rel : h->params["conv1_weights"].ptr;
   A.conv_b = dm.gen_conv ? h->conv_b_rel : h->params["conv1_bias"].ptr;
-  A.scale = h->conv_scale; A.shift = h->conv_shift;
+  A.scale = h->conv_scale; A.shift = h->conv_shift; A.x_exp = h->x_exp;
   A.per_rel_conv = dm.gen_conv ? 1 : 0;
   A.d = dm.d; A.r = dm.r; A.in_w = dm.in_w; A.in_hw = dm.in_h * dm.in_w; A.Wo = dm.Wo;
   A.img_stride = (fused_rows_max(dm, nslices) * dm.in_w) | 1;

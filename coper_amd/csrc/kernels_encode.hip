@@ -781,7 +781,7 @@ __global__ void k_dense_finalize(const float* __restrict__ z_part, int ksplit, i
                                  int d_pad16, const int32_t* __restrict__ perm, const int64_t* __restrict__ rel,
                                  const float* __restrict__ fc_b, int per_rel_bias, int64_t R,
                                  const float* __restrict__ scale, const float* __restrict__ shift,
-                                 float* __restrict__ h_out) {
+                                 float* __restrict__ h_out, const int32_t* __restrict__ w_exp, int x_exp) {
   // one thread per 4 consecutive features of one query (d_pad16 is a multiple of 4: 16-B partial loads)
   const int nq4 = d_pad16 >> 2;
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -799,11 +799,13 @@ __global__ void k_dense_finalize(const float* __restrict__ z_part, int ksplit, i
   if (rid < 0 || rid >= R) rid = 0;
   const float* bsrc = per_rel_bias ? fc_b + rid * d : fc_b;
   float zz[4] = {z.x, z.y, z.z, z.w};
+  // x3 encoder: the partial sums carry 2^(e_W + e_x) (split16.h); exact to take out.  (fp32 encoder: w_exp == NULL, x_exp == 0)
+  const int zexp = -((w_exp ? w_exp[per_rel_bias ? rid : 0] : 0) + x_exp);
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     int k = k0 + c;
     if (k < d) {
-      float v = zz[c] + bsrc[k];
+      float v = __builtin_ldexpf(zz[c], zexp) + bsrc[k];
       v = fmaf(v, scale[k], shift[k]);
       h_out[q * d + k] = fmaxf(v, 0.f);
     }
@@ -853,7 +855,7 @@ int launch_dense_finalize(coper_handle* h, const int64_t* rel, int64_t B, int ks
   int64_t total = B * (dm.d_pad16 / 4);
   hipLaunchKernelGGL(k_dense_finalize, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, h->z_part, ksplit,
                      h->ws_queries, B, dm.d, dm.d_pad16, h->perm, rel, fcb, dm.gen_fc ? 1 : 0, dm.R, h->fc_scale,
-                     h->fc_shift, h_out);
+                     h->fc_shift, h_out, h->enc_bf16 ? h->w_exp : nullptr, h->enc_bf16 ? h->x_exp : 0);
   COPER_HIP_TRY(h, hipGetLastError());
   return COPER_OK;
 }

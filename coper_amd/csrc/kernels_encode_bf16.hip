@@ -11,6 +11,8 @@
 //   A operand (features on rows):  lane l holds 8 bf16 W[f = 32ks + 8(l>>4) + j][feat = 16fb + (l&15)]
 //   B operand (queries on columns): lane l holds 8 bf16 x[q = l&15][f = 32ks + 8(l>>4) + j]
 //   D: col = lane&15 (query), row = 4(lane>>4) + reg (feature).
+#include <cstring>
+
 #include "bf16x3_chain.h"
 #include "coper_internal.h"
 #include "conv_fold.h"
@@ -31,7 +33,8 @@ __device__ __forceinline__ void split8_e(const float* v, uint4& hi, uint4& lo) {
 // -> two bf16 planes in the 16x16x32 layout:  W16[(rel*nfb + fb)*ks32n + ks][lane] = 8 bf16.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_wfrag_to_bf16(const float4* __restrict__ Wf, int64_t n_relfb, int64_t ks32n,
-                                                       uint4* __restrict__ hi, uint4* __restrict__ lo) {
+                                                       uint4* __restrict__ hi, uint4* __restrict__ lo, int nfb,
+                                                       const int32_t* __restrict__ w_exp) {
   int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (relfb*ks32n + ks)*64 + lane
   if (j >= n_relfb * ks32n * 64) return;
   int l = (int)(j & 63);
@@ -44,19 +47,96 @@ __global__ __launch_bounds__(256) void k_wfrag_to_bf16(const float4* __restrict_
   const float4* src = Wf + (relfb * (2 * ks32n) + ks16) * 64 + (l & 15);
   float4 a = src[16 * g], b = src[16 * (g + 1)];
   float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  const int ew = w_exp[relfb / nfb];       // the relation's power of two (split16.h): the planes hold W_r 2^e_W
+#pragma unroll
+  for (int t = 0; t < 8; ++t) v[t] = x3_scale(v[t], ew);
   uint4 h4, l4;
   split8_e(v, h4, l4);
   hi[j] = h4;
   lo[j] = l4;
 }
 
+// largest |W| of every relation's fragment image -> its power of two (split16.h): w_exp[rel] first accumulates the maximum's
+// float bits (non-negative floats order like unsigned integers), k_bits_to_exp turns them into exponents in place
+__global__ __launch_bounds__(256) void k_w_absmax(const float4* __restrict__ Wf, int64_t per_rel4, int32_t* __restrict__ w_exp) {
+  const int64_t rel = blockIdx.y;
+  const float4* src = Wf + rel * per_rel4;
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_rel4; i += (int64_t)gridDim.x * 256) {
+    const float4 v = src[i];
+    m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax((unsigned*)&w_exp[rel], __float_as_uint(m));
+}
+__global__ void k_bits_to_exp(int32_t* __restrict__ w_exp, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) w_exp[i] = x3_exp_for_bits((unsigned)w_exp[i]);
+}
+
 int launch_wfrag_to_bf16(coper_handle* h, const float* Wf, int64_t Rw, void* hi, void* lo, hipStream_t s) {
   const Dims& dm = h->dm;
   int64_t ks32n = dm.F_pad / 32;
   int64_t total = Rw * dm.nfb * ks32n * 64;
+  const int64_t per_rel4 = (int64_t)dm.nfb * (dm.F_pad / 16) * 64;
+  COPER_HIP_TRY(h, hipMemsetAsync(h->w_exp, 0, sizeof(int32_t) * Rw, s));
+  hipLaunchKernelGGL(k_w_absmax, dim3(64, (unsigned)Rw), dim3(256), 0, s, (const float4*)Wf, per_rel4, h->w_exp);
+  hipLaunchKernelGGL(k_bits_to_exp, dim3((unsigned)((Rw + 255) / 256)), dim3(256), 0, s, h->w_exp, Rw);
   hipLaunchKernelGGL(k_wfrag_to_bf16, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float4*)Wf,
-                     Rw * dm.nfb, ks32n, (uint4*)hi, (uint4*)lo);
+                     Rw * dm.nfb, ks32n, (uint4*)hi, (uint4*)lo, dm.nfb, h->w_exp);
   COPER_HIP_TRY(h, hipGetLastError());
+  return COPER_OK;
+}
+
+// A bound on the conv activations, for their power of two (conv_fold.h):  x[c] = relu(b'[c] + sum_k w_k tap'[k][c])
+// <= |b'[c]| + in_max sum_k |tap'[k][c]|  with in_max the largest |element| of an input image (entity rows, and relation
+// rows when they are stacked under them).  One thread per (relation, channel); *out = the maximum's float bits.  Loose by the
+// gap between a 9-term L1 bound and a sum of mixed signs (a few binades at most: the window below the bound is 17 wide).
+__global__ void k_x_bound(const float* __restrict__ conv_w, const float* __restrict__ conv_b, const float* __restrict__ scale,
+                          const float* __restrict__ shift, int64_t Rc, int C, int taps, float in_max, unsigned* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Rc * C) return;
+  const int64_t rel = i / C;
+  const int c = (int)(i - rel * C);
+  const float sc = scale[c];
+  float l1 = 0.f;
+  for (int k = 0; k < taps; ++k) l1 += fabsf(conv_w[rel * taps * C + k * C + c] * sc);
+  const float b = fabsf(fmaf(conv_b[rel * C + c], sc, shift[c])) + in_max * l1;
+  if (b > 0.f) atomicMax(out, __float_as_uint(b * 1.0001f));
+}
+__global__ void k_absmax_bits(const float* __restrict__ src, int64_t n, unsigned* __restrict__ out) {
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(src[i]));
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+}
+
+// e_x of the handle (synchronises: prepare).  scratch: two device words.
+int compute_x_exp(coper_handle* h, unsigned* scratch, hipStream_t s) {
+  const Dims& dm = h->dm;
+  const float* cw = dm.gen_conv ? h->conv_w_rel : h->params["conv1_weights"].ptr;
+  const float* cb = dm.gen_conv ? h->conv_b_rel : h->params["conv1_bias"].ptr;
+  COPER_HIP_TRY(h, hipMemsetAsync(scratch, 0, 2 * sizeof(unsigned), s));
+  float rel_max = 0.f;
+  if ((dm.stacked || dm.concat_rel) && !dm.lookup) {
+    hipLaunchKernelGGL(k_absmax_bits, dim3(64), dim3(256), 0, s, h->params["rel_emb"].ptr, dm.R * (int64_t)dm.r, scratch + 1);
+    COPER_HIP_TRY(h, hipMemcpyAsync(&rel_max, scratch + 1, sizeof(float), hipMemcpyDeviceToHost, s));
+    COPER_HIP_TRY(h, hipStreamSynchronize(s));
+  }
+  const float in_max = dm.stacked ? fmaxf(h->x3_ent_absmax, rel_max) : h->x3_ent_absmax;
+  const int64_t Rc = dm.gen_conv ? dm.R : 1;
+  hipLaunchKernelGGL(k_x_bound, dim3((unsigned)((Rc * dm.C + 255) / 256)), dim3(256), 0, s, cw, cb, h->conv_scale, h->conv_shift, Rc, dm.C,
+                     dm.fh * dm.fw, in_max, scratch);
+  COPER_HIP_TRY(h, hipGetLastError());
+  float bound = 0.f;
+  COPER_HIP_TRY(h, hipMemcpyAsync(&bound, scratch, sizeof(float), hipMemcpyDeviceToHost, s));
+  COPER_HIP_TRY(h, hipStreamSynchronize(s));
+  if (dm.concat_rel) bound = fmaxf(bound, rel_max);
+  unsigned bits;
+  memcpy(&bits, &bound, sizeof bits);
+  h->x_exp = x3_exp_for_bits(bits);
   return COPER_OK;
 }
 
@@ -73,7 +153,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_bn_relu_bf16(
     int per_rel_conv, const float* __restrict__ scale, const float* __restrict__ shift, int d, int r, int in_h,
     int in_w, int stacked, int C, int Ho, int Wo, int concat_rel, int64_t F, int64_t F_pad, int64_t R, int64_t B,
     const int32_t* __restrict__ small_tiles, const int32_t* __restrict__ n_tiles, int by_small_tile,
-    unsigned short* __restrict__ x_hi, unsigned short* __restrict__ x_lo) {
+    unsigned short* __restrict__ x_hi, unsigned short* __restrict__ x_lo, int x_exp) {
   extern __shared__ float lds[];  // img[QPB][in_h*in_w]
   const int img_sz = in_h * in_w;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -130,7 +210,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_bn_relu_bf16(
     if (rid != tap_rid) {  // workgroup-uniform
       const float* wsrc = per_rel_conv ? conv_w + rid * (int64_t)(9 * C) : conv_w;
       const float* bsrc = per_rel_conv ? conv_b + rid * (int64_t)C : conv_b;
-      conv_fold_taps(wsrc, bsrc, scale, shift, C, 8 * oc, tap, bs);
+      conv_fold_taps(wsrc, bsrc, scale, shift, C, 8 * oc, x_exp, tap, bs);
       tap_rid = rid;
     }
     const float* img = lds + qq * img_sz;
@@ -165,7 +245,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_bn_relu_bf16(
     unsigned short* xl = x_lo + pos * F_pad;
     if (concat_rel)
       for (int k = threadIdx.x; k < r; k += 256) {
-        float v = rel_emb[rids[qq] * r + k];
+        float v = x3_scale(rel_emb[rids[qq] * r + k], x_exp);      // (these columns of x carry e_x like the conv's)
         unsigned short hb, lb;
         split1_s16(v, hb, lb);
         xh[Fc + k] = hb;
@@ -195,7 +275,7 @@ int launch_conv_bf16(coper_handle* h, const int64_t* e1, const int64_t* rel, con
                      e1_rows, h->perm, h->params["ent_emb"].ptr, (int64_t)h->cfg.shard_lo, dm.n_local, rel_emb, cw, cb,
                      dm.gen_conv ? 1 : 0, h->conv_scale, h->conv_shift, dm.d, dm.r, dm.in_h, dm.in_w,
                      dm.stacked ? 1 : 0, dm.C, dm.Ho, dm.Wo, dm.concat_rel ? 1 : 0, dm.F, dm.F_pad, dm.R, B, h->tiles,
-                     h->n_tiles, skip_big ? 1 : 0, xh, xl);
+                     h->n_tiles, skip_big ? 1 : 0, xh, xl, h->x_exp);
   COPER_HIP_TRY(h, hipGetLastError());
   return COPER_OK;
 }

@@ -336,7 +336,7 @@ def test_full_size_configs_properties(oracle_chain, name, mode):
     # (measured with tools/rank_decomp.py: f32 mode 99.6 %, bf16x3 97.9 % at FB15k-237 shapes; WN18RR's 40,943 entities sit
     # three times denser around the target)
     frac64 = n_same64 / n_sampled
-    assert frac64 >= 0.97 - (0.05 if name == "wn18rr_cpg" else 0.0), (frac64, n_sampled)      # (a sample of 1 %: 33 - 212 queries)
+    assert frac64 >= 0.98 - (0.04 if name == "wn18rr_cpg" else 0.0), (frac64, n_sampled)      # (a sample of 1 %: 33 - 212 queries)
     # ... and for EVERY query against the reference pass in float64 -- the torch restatement of the oracle (forward and
     # scoring, oracle/coper_oracle_torch.py) run in float64 on the device, checked against the NumPy oracle's h on the sample:
     # >= 99 % of the ranks are the float64 oracle's (measured 0.9937 in the x3 mode, 0.9960 in the fp32
@@ -363,9 +363,10 @@ def test_full_size_configs_properties(oracle_chain, name, mode):
     same_all = float((r64.cpu().numpy() == ranks).mean())
     print("%s %s: ranks equal to the float64 oracle's for %.4f of %d sampled and %.4f of all %d queries; max logit error %.2e"
           % (name, mode, frac64, n_sampled, same_all, Q, max_err))
-    # (WN18RR's 40,943 entities sit three times denser around a target: the x3 encoder's rounding of h moves 1.6 % of its ranks,
-    # the fp32 encoder's 0.5 %)
-    assert same_all >= (0.98 if (name, mode) == ("wn18rr_cpg", "bf16x3") else 0.99), same_all
+    # Round 4 (scale-invariant split, split16.h: the x3 encoder's operands sit in fp16's 22-bit window now -- h is 1.3e-6 of
+    # its magnitude from float64, was ~1e-5): measured FB15k-237 0.9964 (f32 mode 0.9972), plain 0.9973 (0.9962), WN18RR 0.9954
+    # (0.9964; 40,943 entities sit three times denser around a target).  Round 3: 0.9937 / 0.984.
+    assert same_all >= (0.993 if name == "wn18rr_cpg" else 0.995), same_all
     assert max_err < (2e-5 if mode == "f32" else 4e-5), max_err
     mr2, mrr2, hits2 = hits_and_means(exp)
     assert (mr, mrr, hits[10]) == (mr2, mrr2, hits2[10])

@@ -23,6 +23,7 @@ KAPPA = 1e-6             # COPER_BAND_KAPPA_DEFAULT
 BIAS_WEIGHT = 8.0        # X3_BAND_BIAS_WEIGHT
 REL_ERR_BAR = 0.25       # max |s_x3 - s_chain| / (kappa (|h_q| max|E_e| + 8 max|bias|)): a quarter of the band's allowance
 AUDIT_BAR = 0.5
+H_REL_BAR = 1e-5         # max |h - h_float64| / max |h_float64| of the x3 encoder (measured 1.3e-5 ABSOLUTE on O(1) embeddings in round 3)
 
 
 def _model(md, params, **kw):
@@ -72,6 +73,14 @@ def _check(md, p, Q, h_scale=1.0, seed=0, kappa=0.0):
     m32 = _model(md, p, score_mode="f32")
     q = cdata.synthetic_queries(md, Q, seed=seed)
     h = m3.encode(q["e1"], q["rel"])
+    # the x3 ENCODER at this scale: its operands (dense weights per relation, conv activations) are moved into fp16's window
+    # too, so h is as close to float64 as at any other scale -- relative to the embedding's own magnitude
+    from oracle.coper_oracle_torch import TorchCPUModel
+    tm = TorchCPUModel(p, md, device=h.device, dtype=torch.float64)
+    h64 = torch.cat([tm.forward(q["e1"][s:s + 256], q["rel"][s:s + 256]) for s in range(0, min(Q, 512), 256)])
+    h_rel = float((h[:h64.shape[0]].double() - h64).abs().max() / h64.abs().max().clamp_min(1e-300))
+    assert h_rel <= H_REL_BAR, h_rel
+    _check.last_h_rel = h_rel
     if h_scale != 1.0:
         h = (h * h_scale).contiguous()
     m3.band_audit()                                                   # reset
@@ -117,8 +126,8 @@ def test_x3_ranks_equal_chain_at_every_table_scale_fb15k237(kind):
     md = cdata.model_descriptors("fb15k237_cpg")
     p = _tables(kind, md, 0)
     rel, ratio, n = _check(md, p, 4096)
-    print("fb15k237 %-12s max |s_x3 - s_chain| = %.3f of the band's allowance over %d logits; band audit %.3f over %d pairs"
-          % (kind, rel, 384 * md["num_ent"], ratio, n))
+    print("fb15k237 %-12s max |s_x3 - s_chain| = %.3f of the band's allowance over %d logits; band audit %.3f over %d pairs; "
+          "encoder max |h - h64| / max |h64| = %.2e" % (kind, rel, 384 * md["num_ent"], ratio, n, _check.last_h_rel))
 
 
 @pytest.mark.parametrize("h_scale", [1e-6, 1e-3, 1e3, 1e6])
