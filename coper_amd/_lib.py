@@ -43,7 +43,7 @@ class coper_config(C.Structure):
         ("context_rel_use_batch_norm", C.c_int32), ("bn_epsilon", C.c_float),
         ("shard_lo", C.c_int64), ("shard_hi", C.c_int64),
         ("score_mode", C.c_int32), ("rank_band_kappa", C.c_float), ("x3_ent_absmax", C.c_float),
-        ("reserved", C.c_int32 * 5),
+        ("band_audit_period", C.c_int32), ("reserved", C.c_int32 * 4),
     ]
 
 
@@ -135,7 +135,8 @@ def check(handle, rc):
         raise CoperError(rc, text.decode() if text else "")
 
 
-def make_config(md, device=0, shard=None, score_mode=SCORE_F32, bn_epsilon=1e-3, rank_band_kappa=0.0, x3_ent_absmax=0.0):
+def make_config(md, device=0, shard=None, score_mode=SCORE_F32, bn_epsilon=1e-3, rank_band_kappa=0.0, x3_ent_absmax=0.0,
+                band_audit_period=0):
     """model_descriptors dict (models.py:98-130 keys) -> coper_config."""
     cfg = coper_config()
     cfg.abi_version = COPER_ABI_VERSION
@@ -172,4 +173,5 @@ def make_config(md, device=0, shard=None, score_mode=SCORE_F32, bn_epsilon=1e-3,
     cfg.score_mode = int(score_mode)
     cfg.rank_band_kappa = float(rank_band_kappa)     # 0: the library default (include/coper_hip.h)
     cfg.x3_ent_absmax = float(x3_ent_absmax)         # 0: the handle's own rows; entity shards pass the table-wide maximum
+    cfg.band_audit_period = int(band_audit_period)   # 0: the library default (first count launch, then every 8th)
     return cfg

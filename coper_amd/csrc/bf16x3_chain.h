@@ -90,11 +90,17 @@ __device__ __forceinline__ void f3_store_piece(uint4* __restrict__ img, int KS16
 }
 
 // ---- the exponent of a packed batch (split16.h) ---------------------------------------------------------------------------
-// x3s (device, int32[4]): [0] e_h of the batch whose query planes are in place, [1] e_E + e_h = the power of two its x3
-// accumulators, thresholds and block maxima carry, [2] the accumulation word of the batch's largest |h| (float bits),
-// [3] the ticket.  Every thread block of a kernel that produces h rows calls x3_block_publish with its own maximum; the last
-// one publishes and leaves [2], [3] zero (no host-side state: hipGraph-replayable).
-__device__ __forceinline__ void x3_block_publish(float m, const int ent_exp, int32_t* __restrict__ x3s) {
+// e_h comes from the largest |h| element of the batch.  Two steps, no atomics and no fences (the first form -- blocks folding
+// their maxima into one word with atomicMax and a ticket -- cost 40 - 60 us per pass: thousands of device-scope atomics on one
+// line are served one after the other at the memory side):
+//   1. the kernel that PRODUCES the h rows (k_finalize_h_publish, k_absmax_publish) stores one maximum per block into
+//      x3m[blockIdx] (X3M_SLOTS floats; block 0 zeroes the slots beyond the grid);
+//   2. the kernel that SPLITS them (the tail kernel, k_rows_to_frag_bf16) reduces the X3M_SLOTS floats in every block (4 KB out
+//      of L2) -> e_h; its block 0 publishes x3s[0] = e_h, x3s[1] = e_E + e_h for the kernels that follow it on the stream
+//      (count, band walk, pair kernels, score_all, top-k).
+// Plain stores ordered by kernel boundaries: deterministic, no host-side state, hipGraph-replayable.
+constexpr int X3M_SLOTS = 1024;
+__device__ __forceinline__ void x3_block_store_max(float m, float* __restrict__ x3m) {     // blocks of <= 1024 threads, grid <= X3M_SLOTS
   __shared__ float s_m[16];
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
@@ -103,16 +109,24 @@ __device__ __forceinline__ void x3_block_publish(float m, const int ent_exp, int
   __syncthreads();
   if (threadIdx.x == 0) {
     for (int w = 1; w < nw; ++w) m = fmaxf(m, s_m[w]);
-    if (m > 0.f) atomicMax((unsigned*)&x3s[2], __float_as_uint(m));      // (NaN: no contribution)
-    __threadfence();
-    if (atomicAdd((unsigned*)&x3s[3], 1u) == gridDim.x * gridDim.y - 1u) {
-      __threadfence();
-      const int e = x3_exp_for_bits(atomicExch((unsigned*)&x3s[2], 0u));
-      x3s[0] = e;
-      x3s[1] = e + ent_exp;
-      x3s[3] = 0;
-    }
+    x3m[blockIdx.x] = m == m ? m : 0.f;            // (NaN: no contribution)
   }
+  if (blockIdx.x == 0)
+    for (int i = gridDim.x + threadIdx.x; i < X3M_SLOTS; i += blockDim.x) x3m[i] = 0.f;
+}
+// every thread of a 256-thread block returns e_h; block 0 publishes (s_red: 4 floats of the caller's LDS)
+__device__ __forceinline__ int x3_batch_exp(const float* __restrict__ x3m, const int ent_exp, int32_t* __restrict__ x3s, float* s_red) {
+  static_assert(X3M_SLOTS == 1024, "one float4 per thread of a 256-thread block");
+  const float4 v = ((const float4*)x3m)[threadIdx.x & 255];
+  float m = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+  const int e = x3_exp_for_bits(__float_as_uint(m));
+  if (blockIdx.x == 0 && threadIdx.x == 0) { x3s[0] = e; x3s[1] = e + ent_exp; }
+  return e;
 }
 
 // ---- the half-width of the exact band (kernels_score3_bf16.hip) ------------------------------------------------------------

@@ -342,7 +342,7 @@ COPER_API void coper_destroy(coper_handle* h) {
   dev_free((char**)&h->Wf16_hi); dev_free((char**)&h->Wf16_lo);
   dev_free((char**)&h->Ef16_hi); dev_free((char**)&h->Ef16_lo); dev_free((char**)&h->hfrag16_hi); dev_free((char**)&h->hfrag16_lo);
   dev_free((char**)&h->Erm16_hi); dev_free((char**)&h->Erm16_lo); dev_free((char**)&h->hrm16_hi); dev_free((char**)&h->hrm16_lo);
-  dev_free((char**)&h->Ef3); dev_free((char**)&h->hf3_ws); dev_free((char**)&h->mask_ws); dev_free(&h->band_consts); dev_free(&h->tband_ws); dev_free(&h->x3s); dev_free(&h->w_exp);
+  dev_free((char**)&h->Ef3); dev_free((char**)&h->hf3_ws); dev_free((char**)&h->mask_ws); dev_free(&h->band_consts); dev_free(&h->tband_ws); dev_free(&h->x3s); dev_free(&h->x3m); dev_free(&h->w_exp);
   dev_free(&h->tgtx_ws); dev_free(&h->heavy_ws);
   for (auto& kv : h->timers)
     for (auto& p : kv.second.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
@@ -457,8 +457,11 @@ COPER_API int coper_prepare(coper_handle* h, void* stream) {
 
   if (cfg.score_mode != COPER_SCORE_F32) {
     // the shard's maxima (row norm, |pred_bias|: the exact band; |element|: the power of two of the entity planes, split16.h)
-    if ((rc = dev_alloc(h, &h->band_consts, BAND_NCONST)) || (rc = dev_alloc(h, &h->x3s, 4))) return rc;
+    if ((rc = dev_alloc(h, &h->band_consts, BAND_NCONST)) || (rc = dev_alloc(h, &h->x3s, 4)) ||
+        (rc = dev_alloc(h, &h->x3m, (size_t)X3M_SLOTS)))
+      return rc;
     COPER_HIP_TRY(h, hipMemsetAsync(h->x3s, 0, 4 * sizeof(int32_t), s));
+    COPER_HIP_TRY(h, hipMemsetAsync(h->x3m, 0, X3M_SLOTS * sizeof(float), s));
     if ((rc = launch_band_consts(h, P("ent_emb"), P("pred_bias"), s))) return rc;
     {
       unsigned cb[BAND_NCONST];
@@ -526,6 +529,7 @@ COPER_API int coper_prepare(coper_handle* h, void* stream) {
   }
   h->enc_bf16 = cfg.score_mode != COPER_SCORE_F32 && conv_bf16_supported(dm);
   h->x_exp = 0;
+  h->band_launches = 0;
   if (h->enc_bf16) {
     size_t plane = (size_t)h->Rw * dm.nfb * (dm.F_pad / 32) * 64 * 16;
     dev_free((char**)&h->Wf16_hi); dev_free((char**)&h->Wf16_lo);

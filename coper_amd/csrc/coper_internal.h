@@ -103,11 +103,13 @@ struct coper_handle {
   void* Ef3 = nullptr;          //   the count kernel's image (bf16x3_chain.h): [2 n_eblk][NS][2][64] x 16 B, zero-filled first
   unsigned* band_consts = nullptr;   // [BAND_NCONST] float bits: [0] max |E_e|_2, [1] max |pred_bias| of the shard (exact band), [2] max |E element|,
                                      //   [3] the band audit's largest |x3 - chain| / (tau / 2), [4] its pair count (coper_band_audit)
+  unsigned band_launches = 0;        // count launches since prepare (which of them the band audit rides on: kernels_score3_bf16.hip)
   int x3_ent_exp = 0;                // e_E: the entity planes hold E 2^e_E (split16.h; prepare)
   float x3_ent_absmax = 0.f;         //   the maximum it was chosen from (the shard's, or coper_config.x3_ent_absmax)
   int32_t* w_exp = nullptr;          // [Rw] e_W per relation: the dense-weight planes hold W_r 2^e_W (split16.h; prepare)
   int x_exp = 0;                     // e_x: the conv activations enter the dense layer as x 2^e_x (from a bound; prepare)
-  int32_t* x3s = nullptr;            // [4] the packed batch's exponents + their accumulation words (bf16x3_chain.h: x3_block_publish)
+  int32_t* x3s = nullptr;            // [4] the packed batch's exponents: [0] e_h, [1] e_E + e_h (bf16x3_chain.h)
+  float* x3m = nullptr;              // [X3M_SLOTS] per-block maxima of the h rows being packed (bf16x3_chain.h)
   float* ctx_tmp[2] = {nullptr, nullptr};  // generator hidden activations
   size_t ctx_tmp_elems = 0;
 

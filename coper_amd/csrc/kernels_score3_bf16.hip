@@ -857,19 +857,41 @@ __device__ __forceinline__ void band_audit_group(const BandArgs& A, const unsign
   const uint4* pa_h = A.Ehi + (live ? e : 0) * (2 * KS) + half;
   const uint4* pa_l = A.Elo + (live ? e : 0) * (2 * KS) + half;
   const float* hr = A.hvec + q * d;
-  for (int ks = 0; ks < KS; ks += 2) {
-    uint4 ah[2], al[2], bh[2], bl[2];
+  const bool vec_ok = (d & 7) == 0 && (((uintptr_t)A.hvec) & 15) == 0;
+  // a wave walks its 32 pairs alone: the loads of CB k-steps are issued before their instructions (a round trip per k-step
+  // otherwise: the audit took 40 us of a 15 us launch)
+  constexpr int CB = 4;
+  for (int ks = 0; ks < KS; ks += CB) {
+    uint4 ah[CB], al[CB];
+    float4 y0[CB], y1[CB];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < CB; ++u) {
       const int k = ks + u < KS ? ks + u : KS - 1;
       ah[u] = pa_h[k * 2]; al[u] = pa_l[k * 2];
-      float y[8];
+      const int kk = 16 * k + 8 * half;
+      if (vec_ok && kk + 8 <= d) {
+        y0[u] = live ? *(const float4*)(hr + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+        y1[u] = live ? *(const float4*)(hr + kk + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        float t[8];
 #pragma unroll
-      for (int c = 0; c < 8; ++c) { const int kk = 16 * k + 8 * half + c; y[c] = (live && kk < d) ? x3_scale(hr[kk], eh) : 0.f; }
+        for (int c = 0; c < 8; ++c) t[c] = (live && kk + c < d) ? hr[kk + c] : 0.f;
+        y0[u] = make_float4(t[0], t[1], t[2], t[3]);
+        y1[u] = make_float4(t[4], t[5], t[6], t[7]);
+      }
+    }
+    uint4 bh[CB], bl[CB];
+#pragma unroll
+    for (int u = 0; u < CB; ++u) {
+      const float y[8] = {x3_scale(y0[u].x, eh), x3_scale(y0[u].y, eh), x3_scale(y0[u].z, eh), x3_scale(y0[u].w, eh),
+                          x3_scale(y1[u].x, eh), x3_scale(y1[u].y, eh), x3_scale(y1[u].z, eh), x3_scale(y1[u].w, eh)};
       split8_s16(y, bh[u], bl[u]);
     }
-    if (ks + 1 < KS) { BX3_PAIR(ah[0], al[0], bh[0], bl[0], ah[1], al[1], bh[1], bl[1], acc); }
-    else { BX3_LAST(ah[0], al[0], bh[0], bl[0], acc); }
+#pragma unroll
+    for (int u = 0; u < CB; u += 2) {   // wave-uniform
+      if (ks + u + 1 < KS) { BX3_PAIR(ah[u], al[u], bh[u], bl[u], ah[u + 1], al[u + 1], bh[u + 1], bl[u + 1], acc); }
+      else if (ks + u < KS) { BX3_LAST(ah[u], al[u], bh[u], bl[u], acc); }
+    }
   }
   const bool diag_lane = ((i >> 2) & 1) == half;
   const int reg = (i & 3) + 4 * (i >> 3);
@@ -902,7 +924,7 @@ __device__ __forceinline__ void band_audit_group(const BandArgs& A, const unsign
 // thread makes; at FB15k-237 shapes 256 units gave a workgroup ~350 pairs for its 256 threads (two walks for many), 64
 // units give ~90 (one walk) and 290 workgroups instead of 73
 constexpr int BE_CAP = 4096, BE_ITEMS = 2048, BE_UPW = COPER_BE_UPW;
-constexpr int BE_AUDIT = 256;     // pairs of a round the audit re-scores (a workgroup walks ~90 at FB15k-237 shapes: all of them)
+constexpr int BE_AUDIT = 128;     // pairs of a round the audit re-scores, 32 per wave (a workgroup walks ~90 at FB15k-237 shapes: all of them)
 __device__ __forceinline__ void band_exact_body(const uint4* __restrict__ mask, const unsigned long long* __restrict__ summ, const int64_t n_units,
                                                 const unsigned rows4 /* rows per tile x 4 waves */, const BandArgs& A, const int64_t wg) {
   constexpr int MB = SC3_MB, NW = 2 * MB;      // 32-bit mask words per lane and row of a wave
@@ -1203,7 +1225,16 @@ int score_count3_chunk_bf16x3(coper_handle* h, int64_t q0, int64_t Bc, const flo
     { static const int dbg = getenv("COPER_DBG_BAND") ? atoi(getenv("COPER_DBG_BAND")) : 0; A.dbg = dbg; }
     A.Ehi = (const uint4*)h->Erm16_hi; A.Elo = (const uint4*)h->Erm16_lo; A.bias_pad = h->bias_pad; A.tband = (const float2*)h->tband_ws + q0;
     A.x3s = h->x3s; A.consts = h->band_consts; A.KS16 = h->dm.KS16;
-    { static const int off = getenv("COPER_BAND_NO_AUDIT") != nullptr; A.audit = off ? 0 : 1; }      // (A/B timing switch)
+    {
+      // which launches are audited: a wave re-scores 32 pairs in ~25 us of gathers -- beside a 15 us walk that is too much to pay
+      // on every 0.5 ms pass, nothing beside a launch of milliseconds.  Default: the first count launch after prepare and
+      // every 8th from there (+3 us per pass), every launch of more than 2^31 logits; coper_config.band_audit_period
+      // overrides (1: every launch, what the tests run; negative: never)
+      static const int off = getenv("COPER_BAND_NO_AUDIT") != nullptr;      // (A/B timing switch)
+      int period = h->cfg.band_audit_period;
+      if (period == 0) period = (double)Bc * (double)h->dm.n_local >= 2147483648.0 ? 1 : 8;
+      A.audit = (!off && period > 0 && (h->band_launches++ % (unsigned)period) == 0u) ? 1 : 0;
+    }
     const int64_t n_units = sc3_units(h, Bc);
     if (rows_per_tile * 4 > 0x7fffffffLL || n_units > 0x7fffffffLL) return fail(h, COPER_EUNSUPPORTED, "band mask beyond 2^31 units");
     const unsigned n_band = (unsigned)((n_units + BE_UPW - 1) / BE_UPW);

@@ -34,10 +34,12 @@ __global__ __launch_bounds__(256) void k_rows_to_frag_bf16(const float* __restri
                                                            uint4* __restrict__ f3, int query_side,
                                                            int64_t total, int32_t* __restrict__ cnt, int32_t cnt_base,
                                                            int32_t* __restrict__ cnt_eq, int fixed_exp,
-                                                           const int32_t* __restrict__ x3s) {
+                                                           const float* __restrict__ x3m, int32_t* __restrict__ x3s) {
   int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (blk*KS16 + ks)*64 + l
-  // the power of two of this operand class (split16.h): the table's (prepare) or the packed batch's (k_absmax_publish)
-  const int e2x = x3s ? x3s[0] : fixed_exp;
+  // the power of two of this operand class (split16.h): the table's (prepare), or the packed batch's -- reduced here from the
+  // block maxima k_absmax_publish / k_finalize_h_publish left, and published by block 0 for the kernels that follow
+  __shared__ float s_red[4];
+  const int e2x = x3m ? x3_batch_exp(x3m, fixed_exp, x3s, s_red) : fixed_exp;
   // optional: preset the rank counters of the pass this packing opens (saves a launch on the ranking path)
   if (cnt && j < n_rows) { cnt[j] = cnt_base; if (cnt_eq) cnt_eq[j] = 0; }
   if (j >= total) return;
@@ -68,7 +70,7 @@ int launch_rows_to_frag_bf16(coper_handle* h, const float* src, int64_t n_rows, 
   int64_t total = n_blk * dm.KS16 * 64;
   hipLaunchKernelGGL(k_rows_to_frag_bf16, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, n_rows, dm.d,
                      dm.KS16, hi, lo, rm_hi, rm_lo, f3, query_side ? 1 : 0, total, h->preset_cnt, h->count_base, h->preset_eq,
-                     h->x3_ent_exp, query_side ? h->x3s : nullptr);
+                     h->x3_ent_exp, query_side ? h->x3m : nullptr, h->x3s);
   if (h->preset_cnt) h->counts_preset = h->preset_cnt;
   h->preset_cnt = nullptr;
   h->preset_eq = nullptr;
@@ -83,21 +85,19 @@ __global__ void k_zero_counts(int64_t B, int32_t* __restrict__ ng, int32_t* __re
 
 constexpr int BX_NQ = 4;    // 32-query blocks of a 128-query tile (the packing granule of the query planes)
 
-// The exponent of a batch of query rows (split16.h): e_h from the largest |h| element of the batch.  Blocks fold their maxima
-// into x3s[2] (non-negative floats order like unsigned integers); the last block to finish publishes x3s[0] = e_h,
-// x3s[1] = e_E + e_h (the power of two every x3 accumulator of this batch carries) and leaves the accumulation word and
-// the ticket zero: no host-side state, hipGraph-replayable.
-__global__ __launch_bounds__(256) void k_absmax_publish(const float* __restrict__ src, int64_t n, int ent_exp, int32_t* __restrict__ x3s) {
+// The largest |h| element of a batch of query rows, one maximum per block (bf16x3_chain.h: x3_block_store_max; the packing
+// launch that follows reduces them to the batch's exponent e_h).
+__global__ __launch_bounds__(256) void k_absmax_publish(const float* __restrict__ src, int64_t n, float* __restrict__ x3m) {
   float m = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(src[i]));
-  x3_block_publish(m, ent_exp, x3s);
+  x3_block_store_max(m, x3m);
 }
 
 int launch_absmax_publish(coper_handle* h, const float* src, int64_t n, hipStream_t s) {
   int64_t blocks = (n + 256 * 8 - 1) / (256 * 8);
-  if (blocks > 1024) blocks = 1024;
+  if (blocks > X3M_SLOTS) blocks = X3M_SLOTS;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(k_absmax_publish, dim3((unsigned)blocks), dim3(256), 0, s, src, n, h->x3_ent_exp, h->x3s);
+  hipLaunchKernelGGL(k_absmax_publish, dim3((unsigned)blocks), dim3(256), 0, s, src, n, h->x3m);
   COPER_HIP_TRY(h, hipGetLastError());
   return COPER_OK;
 }

@@ -49,44 +49,75 @@ __device__ unsigned long long g_tl_t0;
 #define TL_STAMP(i_)
 #endif
 
-// h rows of a pass: piece (query q, 8 features from 8 p) per thread; the arithmetic of k_dense_finalize (kernels_encode_bf16.hip),
-// bit for bit.  Every block folds its largest value into x3s (x3_block_publish: the last block publishes e_h of the batch).
+// h rows of a pass; the arithmetic of k_dense_finalize (kernels_encode.hip), bit for bit.  A thread owns piece p = 8 features
+// (32 lanes per row, np = d_pad16 / 8 of them in use: folded FCBN scale / shift of the piece stay in registers) and walks the
+// rows 8 apart; per row two 16-byte loads of partial sums per K slice, two of the dense bias, two 16-byte stores.  (The first
+// form -- a thread per piece, every operand a scalar load, 30 loads per piece -- took 43 us for 33 MB.)  Every block folds its
+// largest value into its slot of x3m (bf16x3_chain.h: the tail kernel reduces the slots to e_h of the batch).
 __global__ __launch_bounds__(256) void k_finalize_h_publish(const float* __restrict__ z_part, int ksplit, int64_t Bcap, int64_t B, int d,
                                                             int d_pad16, const int32_t* __restrict__ inv_perm,
                                                             const int32_t* __restrict__ sorted_rid, const float* __restrict__ fc_b,
                                                             int per_rel_bias, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, const int32_t* __restrict__ w_exp, int x_exp,
-                                                            float* __restrict__ h_out, int ent_exp, int32_t* __restrict__ x3s) {
-  const int np = d_pad16 / 8;
-  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t q = j / np;
-  const int k0 = (int)(j - q * np) * 8;
+                                                            float* __restrict__ h_out, float* __restrict__ x3m) {
+  const int np = d_pad16 >> 3;
+  const int p = threadIdx.x & 31, r = threadIdx.x >> 5;
+  const int k0 = 8 * p;
   float m = 0.f;
-  if (q < B && k0 < d) {
-    const int64_t pos = inv_perm[q];
-    const int rid = sorted_rid[pos];
-    const float* bsrc = per_rel_bias ? fc_b + (int64_t)rid * d : fc_b;
-    const int zexp = -((w_exp ? w_exp[per_rel_bias ? rid : 0] : 0) + x_exp);   // the partial sums carry 2^(e_W + e_x) (split16.h)
-    float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < ksplit; ++s) {
-      const float4* pp = (const float4*)(z_part + ((int64_t)s * Bcap + pos) * d_pad16 + k0);
-      const float4 a = pp[0], b = pp[1];
-      z[0] += a.x; z[1] += a.y; z[2] += a.z; z[3] += a.w;
-      z[4] += b.x; z[5] += b.y; z[6] += b.z; z[7] += b.w;
-    }
+  for (int p0 = 0; p0 < np; p0 += 32) {       // (d <= 256: one round)
+    const int kp = k0 + 8 * p0;
+    const bool mine = p + p0 < np && kp < d;
+    const bool vec = mine && kp + 8 <= d && (d & 3) == 0 &&
+                     ((((uintptr_t)fc_b) | ((uintptr_t)scale) | ((uintptr_t)shift) | ((uintptr_t)h_out)) & 15) == 0;
+    float sc8[8], sh8[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-      const int k = k0 + c;
-      if (k < d) {
-        float v = x3_scale(z[c], zexp) + bsrc[k];
-        v = fmaf(v, scale[k], shift[k]);
+      const int k = kp + c < d ? kp + c : d - 1;
+      sc8[c] = mine ? scale[k] : 0.f;
+      sh8[c] = mine ? shift[k] : 0.f;
+    }
+    for (int64_t q = (int64_t)blockIdx.x * 8 + r; q < B; q += (int64_t)gridDim.x * 8) {
+      if (!mine) continue;
+      const int64_t pos = inv_perm[q];
+      const int rid = sorted_rid[pos];
+      const float* bsrc = per_rel_bias ? fc_b + (int64_t)rid * d : fc_b;
+      const int zexp = -((w_exp ? w_exp[per_rel_bias ? rid : 0] : 0) + x_exp);   // the partial sums carry 2^(e_W + e_x) (split16.h)
+      float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int s = 0; s < ksplit; ++s) {
+        const float4* pp = (const float4*)(z_part + ((int64_t)s * Bcap + pos) * d_pad16 + kp);
+        const float4 a = pp[0], b = pp[1];
+        z[0] += a.x; z[1] += a.y; z[2] += a.z; z[3] += a.w;
+        z[4] += b.x; z[5] += b.y; z[6] += b.z; z[7] += b.w;
+      }
+      float bb[8];
+      if (vec) {
+        const float4 b0 = *(const float4*)(bsrc + kp), b1 = *(const float4*)(bsrc + kp + 4);
+        bb[0] = b0.x; bb[1] = b0.y; bb[2] = b0.z; bb[3] = b0.w; bb[4] = b1.x; bb[5] = b1.y; bb[6] = b1.z; bb[7] = b1.w;
+      } else {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) bb[c] = bsrc[kp + c < d ? kp + c : d - 1];
+      }
+      float y[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        float v = x3_scale(z[c], zexp) + bb[c];
+        v = fmaf(v, sc8[c], sh8[c]);
         v = fmaxf(v, 0.f);
-        h_out[q * d + k] = v;
-        m = fmaxf(m, v);
+        y[c] = v;
+        if (kp + c < d) m = fmaxf(m, v);
+      }
+      if (vec) {
+        float4* ho = (float4*)(h_out + q * d + kp);
+        ho[0] = make_float4(y[0], y[1], y[2], y[3]);
+        ho[1] = make_float4(y[4], y[5], y[6], y[7]);
+      } else {
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+          if (kp + c < d) h_out[q * d + kp + c] = y[c];
       }
     }
   }
-  x3_block_publish(m, ent_exp, x3s);
+  x3_block_store_max(m, x3m);
 }
 
 template <int KS>
@@ -94,8 +125,8 @@ __global__ __launch_bounds__(64 * TL_WAVES, KS <= 13 ? 3 : 2) void k_finalize_ta
     int64_t B, int d, const float* __restrict__ h_rows, uint4* __restrict__ hf3,
     const uint4* __restrict__ Ehi, const uint4* __restrict__ Elo, const float* __restrict__ bias_pad, int64_t n_local,
     const int64_t* __restrict__ e2, const int64_t* __restrict__ indptr, const int64_t* __restrict__ idx, float* __restrict__ tgt,
-    float kappa, const unsigned* __restrict__ band_consts, const int32_t* __restrict__ x3s, float2* __restrict__ tband,
-    int32_t* __restrict__ ranks, int32_t* __restrict__ heavy) {
+    float kappa, const unsigned* __restrict__ band_consts, const float* __restrict__ x3m, int ent_exp, int32_t* __restrict__ x3s,
+    float2* __restrict__ tband, int32_t* __restrict__ ranks, int32_t* __restrict__ heavy) {
   __shared__ uint4 s_bh[KS][64], s_bl[KS][64];   // the block's B-operand fragments (hi / lo), shared by the waves
   __shared__ int64_t s_e[TL_WAVES][32];
   __shared__ int s_corr[32];
@@ -118,7 +149,10 @@ __global__ __launch_bounds__(64 * TL_WAVES, KS <= 13 ? 3 : 2) void k_finalize_ta
 
   // ---- 1. the block's fragments: wave w takes k-steps w, w + 4, ...; a lane scales and splits piece (ks, half) of its query's
   // fp32 row (k_finalize_h_publish wrote it; the batch's exponents are published)
-  const int eh = x3s[0], sexp = x3s[1];
+  static_assert(TL_WAVES == 4, "x3_batch_exp: 256 threads");
+  const int eh = x3_batch_exp(x3m, ent_exp, x3s, &s_n2[0][0]), sexp = eh + ent_exp;
+  const int32_t x3l[2] = {eh, sexp};      // (what x3s holds once block 0 has published: this kernel must not read it back)
+  __syncthreads();                        // (s_n2 served as the reduction's scratch)
   {
     const bool vec_ok = (d & 3) == 0 && (((uintptr_t)h_rows) & 15) == 0;
     float n2 = 0.f;
@@ -186,7 +220,7 @@ __global__ __launch_bounds__(64 * TL_WAVES, KS <= 13 ? 3 : 2) void k_finalize_ta
 #pragma unroll
       for (int w2 = 0; w2 < TL_WAVES; ++w2) n2 += s_n2[w2][i];
       // t0, the band and everything compared with them stay in the accumulators' units (x 2^(e_E + e_h)); tgt leaves descaled
-      const float tau = x3_scale(x3_band_tau(n2, kappa, band_consts, d, x3s), sexp);
+      const float tau = x3_scale(x3_band_tau(n2, kappa, band_consts, d, x3l), sexp);
       s_t[i] = t0 + tau;
       if (live) { tgt[q] = x3_scale(t0, -sexp); tband[q] = make_float2(t0 - tau, t0 + tau); }
     }
@@ -245,10 +279,11 @@ bool tail_fused_supported(const coper_handle* h) {
 int launch_finalize_h_publish(coper_handle* h, int64_t B, int ksplit, float* h_out, hipStream_t s) {
   const Dims& dm = h->dm;
   const float* fcb = dm.gen_fc ? h->fc_b_rel : h->params["fc_bias"].ptr;
-  const int64_t total = B * (dm.d_pad16 / 8);
-  hipLaunchKernelGGL(k_finalize_h_publish, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, h->z_part, ksplit, h->ws_queries, B, dm.d,
+  int64_t blocks = (B + 7) / 8;                    // eight rows per block and round
+  if (blocks > X3M_SLOTS) blocks = X3M_SLOTS;
+  hipLaunchKernelGGL(k_finalize_h_publish, dim3((unsigned)blocks), dim3(256), 0, s, h->z_part, ksplit, h->ws_queries, B, dm.d,
                      dm.d_pad16, h->inv_perm, h->sorted_rid, fcb, dm.gen_fc ? 1 : 0, h->fc_scale, h->fc_shift, h->w_exp, h->x_exp, h_out,
-                     h->x3_ent_exp, h->x3s);
+                     h->x3m);
   COPER_HIP_TRY(h, hipGetLastError());
   return COPER_OK;
 }
@@ -263,8 +298,8 @@ int launch_finalize_targets_filter_bf16x3(coper_handle* h, int64_t B, int ksplit
 #define TL_GO(KS_)                                                                                                                 \
   hipLaunchKernelGGL(k_finalize_targets_filter_bf16x3<KS_>, dim3(grid), dim3(64 * TL_WAVES), 0, s, B, dm.d, (const float*)h_out,   \
                      (uint4*)h->hf3_ws, (const uint4*)h->Erm16_hi, (const uint4*)h->Erm16_lo,                                       \
-                     h->bias_pad, dm.n_local, e2, indptr, idx, tgt, band_kappa(h), h->band_consts, h->x3s, (float2*)h->tband_ws,   \
-                     ranks, h->heavy_ws)
+                     h->bias_pad, dm.n_local, e2, indptr, idx, tgt, band_kappa(h), h->band_consts, h->x3m, h->x3_ent_exp, h->x3s,   \
+                     (float2*)h->tband_ws, ranks, h->heavy_ws)
   if (dm.KS16 == 13) { TL_GO(13); } else { TL_GO(16); }
 #undef TL_GO
   COPER_HIP_TRY(h, hipGetLastError());

@@ -72,7 +72,7 @@ def _host(v):
 
 
 class ConvE(object):
-    def __init__(self, model_descriptors: dict, device=None, shard=None, score_mode="f32", rank_band_kappa=0.0):
+    def __init__(self, model_descriptors: dict, device=None, shard=None, score_mode="f32", rank_band_kappa=0.0, band_audit_period=0):
         md = dict(model_descriptors)
         # required keys, as models.py:99-105,119-130 reads them
         for key in ("use_negative_sampling", "label_smoothing_epsilon", "num_ent", "num_rel", "ent_emb_size",
@@ -98,7 +98,8 @@ class ConvE(object):
             raise ValueError("score_mode: 'f32' (exact-f32 MFMA) or 'bf16x3' (split-bf16 operands, 3 bf16 MFMAs per product)")
         mode = {"f32": _lib.SCORE_F32, "bf16x3": _lib.SCORE_BF16X3}[score_mode]
         self.score_mode = score_mode
-        cfg = _lib.make_config(md, device=self.device.index or 0, shard=self.shard, score_mode=mode, rank_band_kappa=rank_band_kappa)
+        cfg = _lib.make_config(md, device=self.device.index or 0, shard=self.shard, score_mode=mode, rank_band_kappa=rank_band_kappa,
+                               band_audit_period=band_audit_period)
         h = C.c_void_p()
         rc = self._lib.coper_create(C.byref(cfg), C.byref(h))
         if rc != 0:

@@ -89,7 +89,11 @@ typedef struct coper_config {
    * maximum (coper_amd/sharding.py all-reduces it) so that the mode's logits do not depend on the shard layout; a value below
    * the shard's own maximum is refused by coper_prepare. */
   float x3_ent_absmax;
-  int32_t reserved[5];
+  /* COPER_SCORE_BF16X3: which count launches carry the band audit (coper_band_audit).  0 = the library default: the first
+   * launch after coper_prepare and every 8th from there (+3 us per 0.5 ms pass), every launch of more than 2^31 logits;
+   * n > 0: every n-th launch; negative: never. */
+  int32_t band_audit_period;
+  int32_t reserved[4];
 } coper_config;
 
 typedef struct coper_handle coper_handle;

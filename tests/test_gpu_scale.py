@@ -28,6 +28,8 @@ H_REL_BAR = 1e-5         # max |h - h_float64| / max |h_float64| of the x3 encod
 
 def _model(md, params, **kw):
     from coper_amd.models import ConvE
+    if kw.get("score_mode") == "bf16x3":
+        kw.setdefault("band_audit_period", 1)      # every count launch audited (the default spares 7 of 8 short launches)
     m = ConvE(md, device="cuda:0", **kw)
     m.load_parameters(params)
     m.prepare()

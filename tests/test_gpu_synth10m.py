@@ -32,7 +32,7 @@ def test_entity_table_does_not_depend_on_the_sharding():
     for a, b in ((lo, lo + 500), (4 * cdata.ENTITY_SEED_BLOCK - 3, 4 * cdata.ENTITY_SEED_BLOCK + 9), (hi - 100, hi)):
         e2, b2 = cdata.synthetic_entity_rows_device(md, 0, "cuda:0", a, b)
         assert torch.equal(e2, ent[a - lo:b - lo]) and torch.equal(b2, bias[a - lo:b - lo])
-    assert abs(float(ent.std()) - 0.3) < 1e-3 and abs(float(bias.std()) - 0.1) < 1e-3
+    assert abs(float(ent.std()) - 0.1) < 1e-3 and abs(float(bias.std()) - 0.1) < 1e-3
 
 
 @pytest.mark.parametrize("mode", ["bf16x3", "f32"])
