@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libcoper_hip.so")
 
 COPER_ABI_VERSION = 3
-COPER_MAX_CTX = 4
+COPER_MAX_CTX = 8
 
 SCORE_F32, SCORE_BF16X3 = 0, 1
 

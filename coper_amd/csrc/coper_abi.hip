@@ -57,6 +57,26 @@ static int64_t g_ledger_bytes = 0;
 
 hipError_t tracked_malloc_impl(void** p, size_t bytes) {
   const hipError_t e = hipMalloc(p, bytes);
+  // COPER_DBG_POISON=<byte>: every allocation of the library starts filled with that byte (0xFF: NaN patterns) -- a kernel that
+  // reads workspace nobody wrote shows up as a wrong result in the first test that runs, not in whichever test inherits a
+  // predecessor's memory (tools/README.md)
+  // COPER_DBG_POISON_ONLY=<k>,<byte>: allocation number k of the process gets <byte> instead (and says so): which buffer is it
+  static const char* poison = getenv("COPER_DBG_POISON");
+  static const char* only = getenv("COPER_DBG_POISON_ONLY");
+  static long n_alloc = 0;
+  if (e == hipSuccess && *p && poison) {
+    int byte = (int)strtol(poison, nullptr, 0);
+    if (only) {
+      char* end = nullptr;
+      const long k = strtol(only, &end, 0);
+      if (k == n_alloc && end && *end == ',') {
+        byte = (int)strtol(end + 1, nullptr, 0);
+        fprintf(stderr, "[coper] allocation %ld (%zu bytes) poisoned with 0x%02x\n", k, bytes, byte & 255);
+      }
+    }
+    ++n_alloc;
+    (void)hipMemset(*p, byte, bytes);
+  }
   if (e == hipSuccess && *p) {
     std::lock_guard<std::mutex> lk(g_ledger_mu);
     g_ledger[*p] = bytes;

@@ -124,7 +124,7 @@ def param_shapes(md: dict) -> Dict[str, tuple]:
     return sh
 
 
-def synthetic_params(md: dict, seed: int = 0, skip=()) -> Dict[str, np.ndarray]:
+def synthetic_params(md: dict, seed: int = 0, skip=(), ent_std: float = 0.1) -> Dict[str, np.ndarray]:
     """Random-init weights of the named architecture with O(1) activations by construction
     (SURVEY 8(d)): entity rows ~ N(0, 0.1^2) (rounds 1 - 3 drew 0.3: the survey's law since round 4); filters / dense weights scaled so that the
     pre-BN activations have ~unit variance; BN statistics close to the analytic moments, with
@@ -135,7 +135,7 @@ def synthetic_params(md: dict, seed: int = 0, skip=()) -> Dict[str, np.ndarray]:
     dm = _dims(md)
     shapes = param_shapes(md)
     d, r, C, F = dm["d"], dm["r"], dm["C"], dm["F"]
-    s_e, s_c = 0.1, 0.3
+    s_e, s_c = float(ent_std), 0.3      # (ent_std = 0.3: the table of rounds 1 - 3, kept by the training tests whose bounds were set on it)
     p = {}
 
     def normal(shape, std):

@@ -447,10 +447,19 @@ class ConvE(object):
         run.graph = graph
         return run
 
+    def ent_absmax(self) -> float:
+        """The largest |ent_emb| element of the rows this handle holds."""
+        t = self._tensors.get("ent_emb")
+        return float(t.abs().max()) if t is not None and t.numel() else 0.0
+
     def set_x3_ent_absmax(self, absmax: float):
         """coper_set_x3_ent_absmax: the largest |ent_emb| element of the WHOLE table, for a handle that holds a shard of it
-        (sharding.py all-reduces it; load_parameters sets it when it is handed the whole table)."""
+        (sharding.py all-reduces it; load_parameters sets it when it is handed the whole table).  No-op in the f32 mode and
+        when the value is the one already set; otherwise the handle is prepared again on its next use."""
+        if self.score_mode != "bf16x3" or getattr(self, "_x3_absmax", None) == float(absmax):
+            return
         _lib.check(self._h, self._lib.coper_set_x3_ent_absmax(self._h, float(absmax)))
+        self._x3_absmax = float(absmax)
         self._prepared = False
 
     def band_audit(self, reset=True):

@@ -21,10 +21,17 @@ The reference has no distributed code at all; the path sha
        single-GPU result).
   Payloads are <= B*(2d+1)*4 bytes (<= 8 MB), i.e. latency-bound on xGMI; logits never cross GPUs.
 
-Both take a *scorer*: any object with `gather_entities / encode / target_scores / rank_counts`
-returning torch tensors on its own device.  `coper_amd.models.ConvE` is the product scorer; the
-CPU `gloo` tests (tests/test_sharding_gloo.py) plug a test-only scorer in to exercise the exchange
-logic without a GPU -- the product never routes through anything else."""
+Both take a *scorer* returning torch tensors on its own device.  `QueryShardedEvaluator` needs `rank_pass` (or `encode` +
+`rank`); `EntityShardedRanker` needs
+    gather_entities(ids) -> [B, d]      gather_bias(ids) -> [B]        (0 for ids the shard does not hold)
+    encode(e1, rel, e1_rows=rows) -> [B, d]
+    score_rows(h, rows, bias) -> [B]    (the fp32-chain logit of rows the caller holds)
+    rank_counts(h, tgt [2, B], e2, filt_indptr, filt_idx, filt_nnz=, k=) -> (n_greater, n_equal[, topk_val, topk_idx])
+and, optionally, `ent_absmax()` / `set_x3_ent_absmax(v)`: the largest |ent_emb| element of the local rows and the setter of the
+table-wide one -- the bf16x3 mode scales every shard's planes by the same power of two so that its logits do not depend on the
+shard layout (include/coper_hip.h: x3_ent_absmax); the ranker all-reduces (MAX) it once at construction.
+`coper_amd.models.ConvE` is the product scorer; the CPU `gloo` tests (tests/test_sharding_gloo.py) plug a test-only scorer in to
+exercise the exchange logic without a GPU -- the product never routes through anything else."""
 from __future__ import annotations
 
 import numpy as np
@@ -102,6 +109,11 @@ class EntityShardedRanker(object):
         self.dist = dist.is_initialized()      # a process group of ONE rank still runs its collectives (RCCL on one GPU)
         self.world = dist.get_world_size(group) if self.dist else 1
         self.rank_id = dist.get_rank(group) if self.dist else 0
+        # one power of two for the entity planes of every shard (the x3 mode's logits are then the same bits whatever the layout)
+        if self.dist and hasattr(scorer, "ent_absmax") and hasattr(scorer, "set_x3_ent_absmax"):
+            m = torch.as_tensor([float(scorer.ent_absmax())], dtype=torch.float32, device=getattr(scorer, "device", "cpu"))
+            dist.all_reduce(m, op=dist.ReduceOp.MAX, group=self.group)
+            scorer.set_x3_ent_absmax(float(m[0]))
 
     def _allreduce(self, t):
         if self.dist:

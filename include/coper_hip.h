@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 #define COPER_ABI_VERSION 3
-#define COPER_MAX_CTX 4 /* max hidden layers of a g_MLP generator */
+#define COPER_MAX_CTX 8 /* max hidden layers of a g_MLP generator (models.py:44-54 loops over any number; no shipped YAML has more than 1) */
 
 typedef enum coper_status {
   COPER_OK = 0,
@@ -49,8 +49,12 @@ typedef enum coper_status {
 
 typedef enum coper_score_mode {
   COPER_SCORE_F32 = 0,   /* entity table fp32, exact-f32 MFMA (v_mfma_f32_32x32x2_f32): parity mode */
-  COPER_SCORE_BF16X3 = 1 /* table + query split hi/lo bf16, 3 bf16 MFMAs per product: ~2^-16 rel. error */
-  /* (a single-bf16 mode, ~2^-9 per product, cannot meet the 1e-3 logit gate of the path and is not part of the ABI) */
+  COPER_SCORE_BF16X3 = 1 /* "x3" (the name is round 2's): every fp32 operand split into two fp16 terms hi + lo, 3 fp16 MFMAs per
+                          * product with fp32 accumulation.  Operands are first moved into fp16's window by exact powers of two
+                          * (per table, per relation's weights, per packed batch of queries), so hi + lo carries 22 bits at any
+                          * magnitude: logits within 2.5e-7 |h||E| of the fp32 chain; integer ranks ARE the fp32 chain's (the
+                          * exact band, rank_band_kappa below), checked at run time by coper_band_audit */
+  /* (a single-16-bit mode, ~2^-9 per product, cannot meet the 1e-3 logit gate of the path and is not part of the ABI) */
 } coper_score_mode;
 
 /* Mirrors the `model_descriptors` dict of ConvE.__init__ (models.py:98-130) -- only the keys
@@ -79,10 +83,17 @@ typedef struct coper_config {
   float bn_epsilon;             /* 1e-3 = tf.layers.batch_normalization default */
   int64_t shard_lo, shard_hi;   /* entity rows [lo, hi) held by this handle; [0, num_ent) = unsharded */
   int32_t score_mode;           /* coper_score_mode */
-  /* COPER_SCORE_BF16X3: relative half-width of the exact band.  Comparisons of a competitor's logit with the target's that are
-   * closer than 2 kappa (|h_q| max|E_e| + max|pred_bias|) are decided by the fp32 chain of COPER_SCORE_F32 instead of the mode's
-   * own arithmetic (integer ranks: metrics.py:44-50).  0 = the library default (1e-5, three times the largest error observed
-   * on 3e8 logits); 3 * 2^-16 + 2 (48 ceil(d/16) + 1) 2^-24 is the proven worst case.  Larger = more pairs re-scored. */
+  /* COPER_SCORE_BF16X3: kappa, the relative half-width of the exact band.  A comparison of a competitor's logit with the
+   * target's that is closer than
+   *       tau_q = 2 (kappa (|h_q| max|E_e| + 8 max|pred_bias|) + 2^-25 sqrt(d) (max|E_e| 2^-e_h + |h_q| 2^-e_E))
+   * is decided by the fp32 chain of COPER_SCORE_F32 instead of the mode's own arithmetic (integer ranks: metrics.py:44-50).
+   * 0 = the library default 1e-6: four to five times the largest error measured over 6e6 - 3e8 logits at every operand scale
+   * (tests/test_gpu_scale.py: <= 0.24 kappa (...) ), for logits dominated by their products and by pred_bias alike (the
+   * weight 8: an accumulation that runs at the magnitude of the bias rounds to ulps of it at every step).  The last term is
+   * rigorous: elements more than 2^17 below their class maximum lose bits to fp16's subnormals (e_h, e_E: the powers of
+   * two of the packed batch and of the table).  kappa itself is EMPIRICAL -- the proven bound of the split and of fp32
+   * accumulation in any order is 3 * 2^-22 + 2 (48 ceil(d/16) + 1) 2^-24 = 7.5e-5 at d = 200 -- which is why every count
+   * launch can audit it (coper_band_audit).  Larger = more pairs re-scored by the chain, proportionally. */
   float rank_band_kappa;
   /* COPER_SCORE_BF16X3: the entity planes hold ent_emb 2^e with e chosen so that this magnitude lands in [2^14, 2^15) of
    * fp16's range.  0 = the largest |ent_emb| element of the handle's own rows.  Entity shards of one table pass the table-wide

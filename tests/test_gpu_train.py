@@ -108,7 +108,7 @@ def test_train_step_matches_oracle(name, train_stats, one_vs_all):
     md.update(_CASES[name])
     md.update(batch_norm_train_stats=train_stats, batch_norm_momentum=0.9, hidden_dropout=0.3, output_dropout=0.2,
               label_smoothing_epsilon=0.1, learning_rate=0.003)
-    p0 = cdata.synthetic_params(md, seed=21)
+    p0 = cdata.synthetic_params(md, seed=21, ent_std=0.3)
     B, L, seed = 48, 37, 5
     m = ConvE(md, device="cuda:0")
     m.load_parameters({k: torch.as_tensor(np.array(v, np.float32)) for k, v in p0.items()})
@@ -176,7 +176,7 @@ def test_train_rejects_unsupported_variants_and_order():
     from coper_amd._lib import CoperError
     md = dict(cdata._COMMON)
     md.update(_CASES["cpg_linear"])
-    p = cdata.synthetic_params(md, seed=1)
+    p = cdata.synthetic_params(md, seed=1, ent_std=0.3)
     m = ConvE(md, device="cuda:0")
     m.load_parameters(p)
     with pytest.raises(CoperError):
@@ -189,7 +189,7 @@ def test_train_rejects_unsupported_variants_and_order():
     sh.close()
     md5 = dict(md, conv_num_channels=300)
     m5 = ConvE(md5, device="cuda:0")
-    m5.load_parameters(cdata.synthetic_params(md5, seed=1))
+    m5.load_parameters(cdata.synthetic_params(md5, seed=1, ent_std=0.3))
     with pytest.raises(CoperError, match="256 conv channels"):
         m5.train_init()                     # (any filter size, channel count up to 256, d up to coper_create's 320)
     m5.close()
@@ -213,7 +213,7 @@ def test_training_loop_learns_a_small_graph(variant):
     rel = np.tile(np.arange(R), E)
     e2 = (e1 * np.array(mult)[rel] + np.array(off)[rel]) % E
     samples = dict(e1=e1, rel=rel, tail_indptr=np.arange(len(e1) + 1), tail_idx=e2.astype(np.int64))
-    p = cdata.synthetic_params(md, seed=4)
+    p = cdata.synthetic_params(md, seed=4, ent_std=0.3)
     m = ConvE(md, device="cuda:0").load_parameters(p)
 
     def mrr():
@@ -243,7 +243,7 @@ def test_checkpoint_resume_continues_the_same_trajectory(tmp_path):
     md.update(_CASES["cpg_mlp_bn"])
     md.update(batch_norm_train_stats=True, batch_norm_momentum=0.9, hidden_dropout=0.2, output_dropout=0.1,
               label_smoothing_epsilon=0.1, learning_rate=0.003)
-    p0 = cdata.synthetic_params(md, seed=3)
+    p0 = cdata.synthetic_params(md, seed=3, ent_std=0.3)
     a = ConvE(md, device="cuda:0").load_parameters({k: torch.as_tensor(np.array(v, np.float32)) for k, v in p0.items()})
     a.train_init(seed=7)
     for step in range(3):
@@ -313,7 +313,7 @@ def test_session_run_serves_the_training_fetches():
     md = dict(cdata._COMMON)
     md.update(_CASES["cpg_linear"])
     md.update(learning_rate=0.003, use_negative_sampling=True)
-    p0 = cdata.synthetic_params(md, seed=3)
+    p0 = cdata.synthetic_params(md, seed=3, ent_std=0.3)
     batches = [_batch(md, 32, 20, seed=50 + i) for i in range(3)]
     a = ConvE(md, device="cuda:0").load_parameters({k: torch.as_tensor(np.array(v)) for k, v in p0.items()})
     b = ConvE(md, device="cuda:0").load_parameters({k: torch.as_tensor(np.array(v)) for k, v in p0.items()})
@@ -352,7 +352,7 @@ def test_handles_release_their_device_memory():
     md.update(_CASES["cpg_wide"])
     md.update(batch_norm_train_stats=True, batch_norm_momentum=0.9, hidden_dropout=0.3, output_dropout=0.2,
               label_smoothing_epsilon=0.1, learning_rate=0.003)
-    p0 = {k: torch.as_tensor(np.array(v, np.float32)) for k, v in cdata.synthetic_params(md, seed=3).items()}
+    p0 = {k: torch.as_tensor(np.array(v, np.float32)) for k, v in cdata.synthetic_params(md, seed=3, ent_std=0.3).items()}
     q = cdata.synthetic_queries(md, 300, seed=1)
     batch = _batch(md, 48, 37, seed=7)
 
@@ -402,7 +402,7 @@ def test_train_batch_shape_changes_between_steps():
     md.update(_CASES["cpg_wide"])
     md.update(num_ent=300, batch_norm_train_stats=True, batch_norm_momentum=0.9, hidden_dropout=0.3, output_dropout=0.2,
               label_smoothing_epsilon=0.1, learning_rate=0.003)
-    p0 = cdata.synthetic_params(md, seed=4)
+    p0 = cdata.synthetic_params(md, seed=4, ent_std=0.3)
     seed = 9
     m = ConvE(md, device="cuda:0")
     m.load_parameters({k: torch.as_tensor(np.array(v, np.float32)) for k, v in p0.items()})
@@ -456,7 +456,7 @@ def test_device_sampler_feeds_the_training_loop():
     want = (lk == ((b["e1"].cpu().numpy() * np.array(mult)[b["rel"].cpu().numpy()] + np.array(off)[b["rel"].cpu().numpy()]) % E)[:, None])
     assert np.array_equal(lab, want.astype(np.float32))              # one known tail per (e1, rel) in this graph
     assert all(len(set(row[1:].tolist())) == 39 for row in lk)
-    m = ConvE(md, device="cuda:0").load_parameters(cdata.synthetic_params(md, seed=4))
+    m = ConvE(md, device="cuda:0").load_parameters(cdata.synthetic_params(md, seed=4, ent_std=0.3))
 
     def mrr():
         q = dict(e1=e1, rel=rel, e2=e2, filt_indptr=np.arange(len(e1) + 1), filt_idx=e2.astype(np.int64))
@@ -495,7 +495,7 @@ def test_device_sampler_proportional_mode_on_the_gpu():
     md.update(_CASES["cpg_linear"])
     md.update(batch_norm_train_stats=True, batch_norm_momentum=0.9, hidden_dropout=0.1, output_dropout=0.1, label_smoothing_epsilon=0.1,
               learning_rate=0.003)
-    m = ConvE(md, device="cuda:0").load_parameters(cdata.synthetic_params(md, seed=4))
+    m = ConvE(md, device="cuda:0").load_parameters(cdata.synthetic_params(md, seed=4, ent_std=0.3))
     m.train_init(seed=1)
     for _ in range(5):
         b = next(it)
