@@ -217,7 +217,7 @@ static int ensure_workspace(coper_handle* h, int64_t B, int64_t nnz, hipStream_t
   }
   h->ws_queries = cap;
   h->ws_ksplit = KSPLIT_MAX;
-  return COPER_OK;
+  return fused_fin_update(h, s);        // (perm moved)
 }
 
 // what only the ranking entry points need, on top of ensure_workspace: the count kernel's band mask (1 bit per logit of
@@ -362,7 +362,7 @@ COPER_API void coper_destroy(coper_handle* h) {
   dev_free((char**)&h->Wf16_hi); dev_free((char**)&h->Wf16_lo);
   dev_free((char**)&h->Ef16_hi); dev_free((char**)&h->Ef16_lo); dev_free((char**)&h->hfrag16_hi); dev_free((char**)&h->hfrag16_lo);
   dev_free((char**)&h->Erm16_hi); dev_free((char**)&h->Erm16_lo); dev_free((char**)&h->hrm16_hi); dev_free((char**)&h->hrm16_lo);
-  dev_free((char**)&h->Ef3); dev_free((char**)&h->hf3_ws); dev_free((char**)&h->mask_ws); dev_free(&h->band_consts); dev_free(&h->tband_ws); dev_free(&h->x3s); dev_free(&h->x3m); dev_free(&h->w_exp);
+  dev_free((char**)&h->Ef3); dev_free((char**)&h->hf3_ws); dev_free((char**)&h->mask_ws); dev_free(&h->band_consts); dev_free(&h->tband_ws); dev_free(&h->x3s); dev_free(&h->x3m); dev_free(&h->w_exp); dev_free((char**)&h->fused_fin_dev);
   dev_free(&h->tgtx_ws); dev_free(&h->heavy_ws);
   for (auto& kv : h->timers)
     for (auto& p : kv.second.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
@@ -594,6 +594,7 @@ COPER_API int coper_prepare(coper_handle* h, void* stream) {
     h->gmax_max_floats = share > ((int64_t)1 << 28) ? share : ((int64_t)1 << 28);
   }
   if (cfg.score_mode == COPER_SCORE_F32 && (rc = score_kernels_init(h))) return rc;
+  if ((rc = fused_fin_update(h, s))) return rc;       // (parameters / exponents moved)
   h->prepared = true;
   return COPER_OK;
 }
@@ -632,8 +633,11 @@ COPER_API int coper_gather_entities(coper_handle* h, const int64_t* ids, int64_t
 }
 
 // grouping, conv and the dense layer up to the K-slice partials in z_part (everything of coper_encode but the finalize)
+// h_x3: where the x3 encoder may write finished h rows when its launch can finalize them itself (dense_fused_finalizes);
+// *finalized says whether it did (the caller then skips its finalize launch)
 static int encode_partials(coper_handle* h, const int64_t* e1, const int64_t* rel, int64_t B, const float* e1_rows, hipStream_t s,
-                           int* ksplit_out, float* h_out_f32_path) {
+                           int* ksplit_out, float* h_out_f32_path, float* h_x3 = nullptr, bool* finalized = nullptr) {
+  if (finalized) *finalized = false;
   const Dims& dm = h->dm;
   int rc;
   if ((rc = ensure_workspace(h, B, 0, s))) return rc;
@@ -669,7 +673,8 @@ static int encode_partials(coper_handle* h, const int64_t* e1, const int64_t* re
 #endif
     if (fused) {   // one launch serves every tile: conv, BN, ReLU and the dense layer (kernels_dense_fused_bf16.hip)
       ScopedKernelTimer t(h, "dense", s);
-      return launch_dense_fused_bf16(h, e1, rel, e1_rows, B, ksplit, s);
+      if (finalized) *finalized = dense_fused_finalizes(h, ksplit, h_x3);
+      return launch_dense_fused_bf16(h, e1, rel, e1_rows, B, ksplit, h_x3, s);
     }
     if ((rc = launch_conv_bf16(h, e1, rel, e1_rows, B, false, s))) return rc;
     {
@@ -690,8 +695,9 @@ COPER_API int coper_encode(coper_handle* h, const int64_t* e1, const int64_t* re
   if (B > 0x7fffffff) return fail(h, COPER_EINVAL, "coper_encode: batch too large");
   hipStream_t s = (hipStream_t)stream;
   int rc, ksplit = 1;
-  if ((rc = encode_partials(h, e1, rel, B, e1_rows, s, &ksplit, h_out))) return rc;
-  if (h->enc_bf16) return launch_dense_finalize(h, rel, B, ksplit, h_out, s);
+  bool finalized = false;
+  if ((rc = encode_partials(h, e1, rel, B, e1_rows, s, &ksplit, h_out, h_out, &finalized))) return rc;
+  if (h->enc_bf16 && !finalized) return launch_dense_finalize(h, rel, B, ksplit, h_out, s);
   return COPER_OK;
 }
 
@@ -877,14 +883,15 @@ COPER_API int coper_encode_rank(coper_handle* h, const int64_t* e1, const int64_
   }
   // bf16x3: the finalize writes h straight into the planes the rank kernels read (and the fp32 rows the exact band needs) and
   // presets the counters, which accumulate into `ranks` from 1: no pack, zero or finish launch
-  if ((rc = encode_partials(h, e1, rel, B, e1_rows, s, &ksplit, nullptr))) return rc;
+  bool finalized = false;
+  if ((rc = encode_partials(h, e1, rel, B, e1_rows, s, &ksplit, nullptr, hv, &finalized))) return rc;
   if (!n_equal && tail_fused_supported(h)) {
     // ranks only (what the reference computes): finalize, targets, the band and the filter correction in ONE launch
     // (kernels_tail_bf16.hip) that leaves ranks = 1 - (known answers above the band); the count kernel and the exact
     // decision of the band add to it
     {
       ScopedKernelTimer t(h, "tail", s);
-      if ((rc = launch_finalize_targets_filter_bf16x3(h, B, ksplit, hv, e2, filt_indptr, filt_idx, filt_nnz, h->tgt_ws, ranks, s))) return rc;
+      if ((rc = launch_finalize_targets_filter_bf16x3(h, B, finalized ? 0 : ksplit, hv, e2, filt_indptr, filt_idx, filt_nnz, h->tgt_ws, ranks, s))) return rc;
     }
     h->counts_preset = ranks;
     h->count_base = 1;
@@ -894,7 +901,7 @@ COPER_API int coper_encode_rank(coper_handle* h, const int64_t* e1, const int64_
     h->excess_pending = false;     // (consumed by the first band launch; a failed launch must not leave it to a later pass)
     return rc;
   }
-  if ((rc = launch_dense_finalize_pack(h, B, ksplit, hv, ranks, 1, n_equal, s))) return rc;
+  if ((rc = launch_dense_finalize_pack(h, B, finalized ? 0 : ksplit, hv, ranks, 1, n_equal, s))) return rc;
   h->expand_indptr = filt_indptr;
   rc = launch_pair_targets_packed_bf16x3(h, e2, B, h->tgt_ws, s);
   h->expand_indptr = nullptr;
@@ -924,6 +931,18 @@ COPER_API int coper_band_audit(coper_handle* h, int32_t reset, float* max_ratio,
   COPER_HIP_TRY(h, hipStreamSynchronize(s));
   if (max_ratio) memcpy(max_ratio, &v[0], sizeof(float));
   if (n_pairs) *n_pairs = (int64_t)v[1];
+  return COPER_OK;
+}
+
+COPER_API int coper_band_audit_post(coper_handle* h, int32_t reset, uint32_t* dst2, void* stream) {
+  if (!h || !dst2) return COPER_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (!h->band_consts) {       // fp32-exact mode: no band; zeros through the same kind of launch (dst2 may be host memory)
+    return fail(h, COPER_ESTATE, "coper_band_audit_post: the handle has no band (COPER_SCORE_F32)");
+  }
+  int rc = launch_copy_i32(h, (const int32_t*)(h->band_consts + 3), 2, (int32_t*)dst2, s);
+  if (rc) return rc;
+  if (reset) COPER_HIP_TRY(h, hipMemsetAsync(h->band_consts + 3, 0, 2 * sizeof(unsigned), s));
   return COPER_OK;
 }
 

@@ -106,6 +106,8 @@ struct coper_handle {
   unsigned band_launches = 0;        // count launches since prepare (which of them the band audit rides on: kernels_score3_bf16.hip)
   int x3_ent_exp = 0;                // e_E: the entity planes hold E 2^e_E (split16.h; prepare)
   float x3_ent_absmax = 0.f;         //   the maximum it was chosen from (the shard's, or coper_config.x3_ent_absmax)
+  void* fused_fin_dev = nullptr;     // FusedFinConst (kernels_dense_fused_bf16.hip): the fused encoder's finalize constants, in device memory
+  const int32_t* fused_fin_perm = nullptr;   //   the workspace generation they were written for
   int32_t* w_exp = nullptr;          // [Rw] e_W per relation: the dense-weight planes hold W_r 2^e_W (split16.h; prepare)
   int x_exp = 0;                     // e_x: the conv activations enter the dense layer as x 2^e_x (from a bound; prepare)
   int32_t* x3s = nullptr;            // [4] the packed batch's exponents: [0] e_h, [1] e_E + e_h (bf16x3_chain.h)
@@ -300,7 +302,9 @@ int launch_conv_bf16(coper_handle* h, const int64_t* e1, const int64_t* rel, con
 int launch_dense_bf16(coper_handle* h, int64_t B, int nslices, bool small_only, hipStream_t s);
 bool dense_fused_supported(const coper_handle* h, int nslices);
 int launch_dense_fused_bf16(coper_handle* h, const int64_t* e1, const int64_t* rel, const float* e1_rows, int64_t B,
-                            int nslices, hipStream_t s);
+                            int nslices, float* h_fin, hipStream_t s);
+bool dense_fused_finalizes(const coper_handle* h, int nslices, const float* h_out);
+int fused_fin_update(coper_handle* h, hipStream_t s);
 int launch_dense_finalize(coper_handle* h, const int64_t* rel, int64_t B, int ksplit, float* h_out, hipStream_t s);
 int launch_dense_finalize_pack(coper_handle* h, int64_t B, int ksplit, float* h_out, int32_t* cnt, int32_t cnt_base,
                                int32_t* cnt_eq, hipStream_t s);

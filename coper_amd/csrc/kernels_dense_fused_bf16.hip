@@ -12,6 +12,7 @@
 // concat_rel tail, and the conv filters are either shared or generated together with the dense weights (a
 // tile is then one relation).  Arithmetic per x value is conv_x8() below, shared with the stand-alone conv
 // kernel that still serves the <= 32-query tiles: x, and with it h[b], stays a pure function of (e1, rel).
+#include "bf16x3_chain.h"
 #include "coper_internal.h"
 #include "conv_fold.h"
 
@@ -49,6 +50,21 @@ struct FusedConvArgs {
   const float* scale;
   const float* shift;
   int per_rel_conv, d, r, in_w, in_hw, Wo, img_stride, x_exp;
+};
+
+// The dense finalize in this kernel's epilogue (round 4; one K slice only -- the workgroup's accumulators are then the whole
+// sum): dense bias, folded FCBN, ReLU -> the fp32 h rows (the arithmetic of k_dense_finalize / k_finalize_h_publish, bit for
+// bit), and the workgroup's largest value folded into a slot of x3m (bf16x3_chain.h: the batch's exponent; k_rel_scatter
+// zeroed the slots at the start of the pass).  Saves the 17 MB round trip of the partial sums and a launch: 14 us of an
+// FB15k-237-shaped pass.  h_out == NULL: partial sums to z_part as before.
+// (The constant part lives in device memory, written at prepare: as kernel arguments its nine words pushed the main loop's
+// scalar registers into spills -- the kernel ran 19 us longer to save a 14 us launch.)
+struct FusedFinConst {
+  const int32_t* perm; const float* fc_b; const float* scale; const float* shift; const int32_t* w_exp; float* x3m;
+  int per_rel_bias, x_exp, d, pad;
+};
+struct FusedFin {
+  float* h_out; const FusedFinConst* c;
 };
 
 // Roles.  A workgroup is 8 waves, two per SIMD: waves 0..3 are MATRIX waves (wave w owns feature blocks
@@ -125,7 +141,7 @@ __device__ __forceinline__ void fused_matrix_role(const uint4* __restrict__ xrin
                                                   const uint4* __restrict__ Whi, const uint4* __restrict__ Wlo,
                                                   const FusedConvArgs& A, int64_t relw, int start, int n, int fb0,
                                                   int nfb, int64_t ks32n, int64_t kb, int64_t ke, int t0, int t1,
-                                                  float* __restrict__ zdst, int d_pad16, int wave) {
+                                                  float* __restrict__ zdst, int d_pad16, int wave, const FusedFin& Fn) {
   constexpr int NFULL = NFB / 4;              // whole feature blocks per wave
   constexpr int REM = NFB % 4 ? 1 : 0;        // 1: one more block, shared by query block
   static_assert(NFB % 4 <= 1, "at most one left-over feature block");
@@ -242,6 +258,73 @@ __device__ __forceinline__ void fused_matrix_role(const uint4* __restrict__ xrin
 #ifdef COPER_DBG_FUSED_NO_STORE
   if (acc[0][0][0] != 1.2345f) return;
 #endif
+  if (Fn.h_out) {   // (kernel-uniform) finalize here: see FusedFin
+    const FusedFinConst Fc = *Fn.c;
+    const int d = Fc.d;
+    const int zexp = -((Fc.w_exp ? Fc.w_exp[Fc.per_rel_bias ? relw : 0] : 0) + Fc.x_exp);   // the sums carry 2^(e_W + e_x) (split16.h)
+    const float* bsrc = Fc.per_rel_bias ? Fc.fc_b + relw * d : Fc.fc_b;
+    float m = 0.f;
+    int qrow[NB];
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+      const int qi = q * 16 + (lane & 15);
+      qrow[q] = qi < n ? Fc.perm[start + qi] : -1;
+    }
+    auto fin = [&](const f32x4& a, const int fb, const int q, const float4& b4, const float4& s4, const float4& t4) {
+      const int k0 = fb * 16 + 4 * (lane >> 4);
+      if (fb >= nfb || qrow[q] < 0 || k0 >= d) return;
+      float z0 = 0.f, z1 = 0.f, z2 = 0.f, z3 = 0.f;       // (the finalize kernels add the slice to a zero: same bits, also for -0)
+      z0 += a[0]; z1 += a[1]; z2 += a[2]; z3 += a[3];
+      float4 v;
+      v.x = fmaxf(fmaf(x3_scale(z0, zexp) + b4.x, s4.x, t4.x), 0.f);
+      v.y = fmaxf(fmaf(x3_scale(z1, zexp) + b4.y, s4.y, t4.y), 0.f);
+      v.z = fmaxf(fmaf(x3_scale(z2, zexp) + b4.z, s4.z, t4.z), 0.f);
+      v.w = fmaxf(fmaf(x3_scale(z3, zexp) + b4.w, s4.w, t4.w), 0.f);
+      m = fmaxf(m, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+      *(float4*)(Fn.h_out + (int64_t)qrow[q] * d + k0) = v;
+    };
+    auto quad = [&](const float* p, const int fb) -> float4 {
+      const int k0 = fb * 16 + 4 * (lane >> 4);
+      return (fb < nfb && k0 < d) ? *(const float4*)(p + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+#pragma unroll
+    for (int j = 0; j < NFULL; ++j) {
+      const int fb = fb0 + wave + 4 * j;
+      const float4 b4 = quad(bsrc, fb), s4 = quad(Fc.scale, fb), t4 = quad(Fc.shift, fb);
+#pragma unroll
+      for (int q = 0; q < NB; ++q) fin(acc[j][q], fb, q, b4, s4, t4);
+    }
+    if (NRQ > 0) {
+      const int fb = fb0 + 4 * NFULL;
+      const float4 b4 = quad(bsrc, fb), s4 = quad(Fc.scale, fb), t4 = quad(Fc.shift, fb);
+#pragma unroll
+      for (int t = 0; t < NRQ; ++t) {
+        const int q = wave + 4 * t;
+        if (q < NB) {
+          // (qrow is indexed with compile-time constants above; here the wave's own query block: read it again)
+          const int qi = q * 16 + (lane & 15);
+          const int row = qi < n ? Fc.perm[start + qi] : -1;
+          const int k0 = fb * 16 + 4 * (lane >> 4);
+          if (fb < nfb && row >= 0 && k0 < d) {
+            float z0 = 0.f, z1 = 0.f, z2 = 0.f, z3 = 0.f;
+            z0 += accr[t][0]; z1 += accr[t][1]; z2 += accr[t][2]; z3 += accr[t][3];
+            float4 v;
+            v.x = fmaxf(fmaf(x3_scale(z0, zexp) + b4.x, s4.x, t4.x), 0.f);
+            v.y = fmaxf(fmaf(x3_scale(z1, zexp) + b4.y, s4.y, t4.y), 0.f);
+            v.z = fmaxf(fmaf(x3_scale(z2, zexp) + b4.z, s4.z, t4.z), 0.f);
+            v.w = fmaxf(fmaf(x3_scale(z3, zexp) + b4.w, s4.w, t4.w), 0.f);
+            m = fmaxf(m, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+            *(float4*)(Fn.h_out + (int64_t)row * d + k0) = v;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0 && m > 0.f)
+      atomicMax((unsigned*)&Fc.x3m[(blockIdx.x + gridDim.x * blockIdx.z) & (X3M_SLOTS - 1)], __float_as_uint(m));   // (<= ~1 block per slot: no contention)
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < NFULL; ++j) {
     const int fb = fb0 + wave + 4 * j;
@@ -342,7 +425,7 @@ __global__ __launch_bounds__(512) void k_dense_fused_bf16x3(const uint4* __restr
                                                             FusedConvArgs A, const int32_t* __restrict__ tiles,
                                                             const int32_t* __restrict__ n_tiles, int64_t cap_small,
                                                             int nfb, int64_t ks32n, int nslices, int64_t Bcap,
-                                                            int d_pad16, float* __restrict__ z_part, int n_big_cap) {
+                                                            int d_pad16, float* __restrict__ z_part, int n_big_cap, FusedFin Fn) {
   extern __shared__ uint4 fused_lds[];
   // blockIdx.x < n_big_cap: the list of 33..128-query tiles; above it: the list of <= 32-query tiles (one per
   // relation key at most) -- every tile of the batch is served by this one launch
@@ -388,10 +471,10 @@ __global__ __launch_bounds__(512) void k_dense_fused_bf16x3(const uint4* __restr
   if (wave < 4) {                                                                                                      \
     if (WNT && !shared_w)                                                                                              \
       fused_matrix_role<NFB, NB_, TILE_WNT(true)>(xring, img, Whi, Wlo, A, relw, start, n, fb0, nfb, ks32n, kb, ke, t0, t1, zdst, \
-                                                  d_pad16, wave);                                                      \
+                                                  d_pad16, wave, Fn);                                                  \
     else                                                                                                               \
       fused_matrix_role<NFB, NB_, TILE_WNT(false)>(xring, img, Whi, Wlo, A, relw, start, n, fb0, nfb, ks32n, kb, ke, t0, t1, zdst, \
-                                                   d_pad16, wave);                                                     \
+                                                   d_pad16, wave, Fn);                                                 \
   } else                                                                                                               \
     fused_conv_role<NB_>(xring, img, A, relw, start, n, kb, ke, i_lo, t0, t1, wave - 4);
   switch (nb) {
@@ -440,8 +523,10 @@ bool dense_fused_supported(const coper_handle* h, int nslices) {
 
 template <int NFB, bool WNT>
 static void dense_fused_launch(coper_handle* h, const int64_t* e1, const int64_t* rel, const float* e1_rows, int64_t B,
-                               int nslices, int zgroups, hipStream_t s) {
+                               int nslices, int zgroups, float* h_fin, hipStream_t s) {
   const Dims& dm = h->dm;
+  FusedFin Fn;
+  Fn.h_out = h_fin; Fn.c = (const FusedFinConst*)h->fused_fin_dev;
   int64_t cap_small = (dm.gen_fc ? dm.R : 1) + 1;
   int64_t n_big_max = B / 33 + 1;
   int64_t n_small_max = cap_small - 1 < B ? cap_small - 1 : B;
@@ -464,11 +549,35 @@ static void dense_fused_launch(coper_handle* h, const int64_t* e1, const int64_t
   }
   hipLaunchKernelGGL((k_dense_fused_bf16x3<NFB, WNT>), dim3((unsigned)(n_big_max + n_small_max), (unsigned)nslices, (unsigned)zgroups), dim3(512),
                      lds, s, (const uint4*)h->Wf16_hi, (const uint4*)h->Wf16_lo, A, h->tiles, h->n_tiles, cap_small, dm.nfb,
-                     dm.F_pad / 32, nslices, h->ws_queries, dm.d_pad16, h->z_part, (int)n_big_max);
+                     dm.F_pad / 32, nslices, h->ws_queries, dm.d_pad16, h->z_part, (int)n_big_max, Fn);
+}
+
+// the constant part of FusedFin, (re)written when the workspace or the parameters move (ensure_workspace / prepare)
+int fused_fin_update(coper_handle* h, hipStream_t s) {
+  const Dims& dm = h->dm;
+  if (!h->enc_bf16 || !h->x3m || !h->perm) return COPER_OK;
+  FusedFinConst c;
+  c.perm = h->perm; c.fc_b = dm.gen_fc ? h->fc_b_rel : h->params["fc_bias"].ptr; c.scale = h->fc_scale; c.shift = h->fc_shift;
+  c.w_exp = h->w_exp; c.x3m = h->x3m; c.per_rel_bias = dm.gen_fc ? 1 : 0; c.x_exp = h->x_exp; c.d = dm.d; c.pad = 0;
+  if (!h->fused_fin_dev && tracked_malloc(&h->fused_fin_dev, sizeof c) != hipSuccess) return fail(h, COPER_ENOMEM, "hipMalloc failed (fused finalize constants)");
+  COPER_HIP_TRY(h, hipMemcpyAsync(h->fused_fin_dev, &c, sizeof c, hipMemcpyHostToDevice, s));
+  COPER_HIP_TRY(h, hipStreamSynchronize(s));      // (c is on the stack)
+  h->fused_fin_perm = h->perm;
+  return COPER_OK;
+}
+
+// the finalize can ride in this kernel's epilogue: one K slice, rows of whole 16-byte quads
+bool dense_fused_finalizes(const coper_handle* h, int nslices, const float* h_out) {
+  static const bool off = getenv("COPER_FUSED_NO_FINALIZE") != nullptr;     // A/B switch, read once
+  const Dims& dm = h->dm;
+  const float* fcb = dm.gen_fc ? h->fc_b_rel : h->params.at("fc_bias").ptr;
+  return !off && h_out && nslices == 1 && h->x3m && h->fused_fin_dev && h->fused_fin_perm == h->perm && (dm.d & 3) == 0 &&
+         ((((uintptr_t)h_out) | ((uintptr_t)fcb) | ((uintptr_t)h->fc_scale) | ((uintptr_t)h->fc_shift)) & 15) == 0;
 }
 
 int launch_dense_fused_bf16(coper_handle* h, const int64_t* e1, const int64_t* rel, const float* e1_rows, int64_t B,
-                            int nslices, hipStream_t s) {
+                            int nslices, float* h_fin, hipStream_t s) {
+  if (!dense_fused_finalizes(h, nslices, h_fin)) h_fin = nullptr;
 #ifndef COPER_FUSED_SPLIT_B
 #define COPER_FUSED_SPLIT_B 2048
 #endif
@@ -481,8 +590,8 @@ int launch_dense_fused_bf16(coper_handle* h, const int64_t* e1, const int64_t* r
   const bool wnt = h->dm.gen_fc && B * 2 <= 128 * h->dm.R;
 #define FUSED_GO(NFB_, Z_)                                                             \
   {                                                                                    \
-    if (wnt) dense_fused_launch<NFB_, true>(h, e1, rel, e1_rows, B, nslices, Z_, s);   \
-    else dense_fused_launch<NFB_, false>(h, e1, rel, e1_rows, B, nslices, Z_, s);      \
+    if (wnt) dense_fused_launch<NFB_, true>(h, e1, rel, e1_rows, B, nslices, Z_, h_fin, s);   \
+    else dense_fused_launch<NFB_, false>(h, e1, rel, e1_rows, B, nslices, Z_, h_fin, s);      \
   }
   if (B <= COPER_FUSED_SPLIT_B / 2) FUSED_GO(4, (h->dm.nfb + 3) / 4)
   else if (h->dm.nfb == 13 && B > COPER_FUSED_SPLIT_B) FUSED_GO(13, 1)

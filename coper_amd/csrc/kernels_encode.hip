@@ -244,9 +244,12 @@ __global__ __launch_bounds__(HIST_BLOCK) void k_rel_scatter(const int64_t* __res
                                                              int64_t shard_lo, int64_t n_local, int64_t R_all,
                                                              int32_t* __restrict__ sorted_row,
                                                              int32_t* __restrict__ sorted_rid,
-                                                             int32_t* __restrict__ inv_perm) {
+                                                             int32_t* __restrict__ inv_perm, float* __restrict__ x3m) {
   extern __shared__ int32_t sh[];  // [R] block counts, then block bases
   const bool priv = R <= HIST_LDS_MAX;
+  // x3 mode: the slots the fused encoder folds its largest h values into start every pass at zero (bf16x3_chain.h)
+  if (x3m && blockIdx.x == 0)
+    for (int i = threadIdx.x; i < 1024; i += HIST_BLOCK) x3m[i] = 0.f;
   int64_t b = (int64_t)blockIdx.x * HIST_BLOCK + threadIdx.x;
   int64_t key = 0, rid = 0, row = -1;
   if (b < B) {
@@ -317,7 +320,7 @@ int launch_group_by_relation(coper_handle* h, const int64_t* e1, const int64_t* 
                        h->n_tiles, h->rel_cursor);
     hipLaunchKernelGGL(k_rel_scatter, dim3(nb), dim3(HIST_BLOCK), sizeof(int32_t) * (size_t)R, s, rel, B, dm.gen_fc ? 1 : 0, R,
                        h->rel_offset, h->rel_cursor, h->perm, e1, have_e1_rows ? 1 : 0, (int64_t)h->cfg.shard_lo, dm.n_local, dm.R,
-                       h->sorted_row, h->sorted_rid, h->inv_perm);
+                       h->sorted_row, h->sorted_rid, h->inv_perm, h->x3m);
     COPER_HIP_TRY(h, hipGetLastError());
     return COPER_OK;
   }
@@ -332,7 +335,7 @@ int launch_group_by_relation(coper_handle* h, const int64_t* e1, const int64_t* 
                      h->tiles, h->n_tiles);
   hipLaunchKernelGGL(k_rel_scatter, dim3(nb), dim3(HIST_BLOCK), hl, s, rel, B, dm.gen_fc ? 1 : 0, R, h->rel_offset,
                      h->rel_cursor, h->perm, e1, have_e1_rows ? 1 : 0, (int64_t)h->cfg.shard_lo, dm.n_local, dm.R,
-                     h->sorted_row, h->sorted_rid, h->inv_perm);
+                     h->sorted_row, h->sorted_rid, h->inv_perm, h->x3m);
   COPER_HIP_TRY(h, hipGetLastError());
   return COPER_OK;
 }

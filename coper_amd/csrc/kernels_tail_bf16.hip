@@ -277,6 +277,7 @@ bool tail_fused_supported(const coper_handle* h) {
 // kernel -- this launch 44 -> 25 us, but the band launch 16 -> 51: at ~190 registers a wave only two workgroups fit a CU and
 // the 1,280 filter workgroups ran in three rounds.  Pass 0.536 against 0.516 ms; not kept.)
 int launch_finalize_h_publish(coper_handle* h, int64_t B, int ksplit, float* h_out, hipStream_t s) {
+  if (ksplit == 0) return COPER_OK;      // the fused encoder finalized in its own epilogue (kernels_dense_fused_bf16.hip: FusedFin)
   const Dims& dm = h->dm;
   const float* fcb = dm.gen_fc ? h->fc_b_rel : h->params["fc_bias"].ptr;
   int64_t blocks = (B + 7) / 8;                    // eight rows per block and round

@@ -377,6 +377,23 @@ class EvalDataset(object):
         return dict(e1=q["e1"], e2=q["e2"], rel=q["rel"], filt_indptr=q["filt_indptr"], filt_idx=q["filt_idx"],
                     lookup_values=np.zeros((len(q["e1"]), 0), np.int32))
 
+    def staged_for(self, model):
+        """The whole dataset marshalled once for `model` (ConvE.stage_persistent: canonical CSR, int32 in pinned memory, device
+        buffers): `ranking_and_hits` scores the same evaluation set after every epoch (run_cpg.py:18-35, 228-250) and pays
+        the host-side marshalling once.  One entry per model, dropped with it; None when the model has no such path."""
+        if not hasattr(model, "stage_persistent"):
+            return None
+        import weakref
+        cache = self.__dict__.setdefault("_staged", {})
+        ent = cache.get(id(model))
+        if ent is not None and ent[0]() is model:
+            return ent[1]
+        q = self.q
+        ip, ix = canonical_csr(q["filt_indptr"], q["filt_idx"])
+        sb = model.stage_persistent(q["e1"], q["rel"], q["e2"], ip, ix)
+        cache[id(model)] = (weakref.ref(model), sb)
+        return sb
+
     def __iter__(self) -> Iterator[dict]:
         q = self.q
         Q = len(q["e1"])

@@ -28,13 +28,18 @@ def _write_data_to_file(file_path, data):
 
 
 def hits_and_means(ranks, hits_to_compute=(1, 3, 5, 10, 20)):
-    """metrics.py:53-57,65-76: per-query 1.0/0.0 hits, float64 means."""
-    ranks = np.asarray(ranks, dtype=np.int64)
+    """metrics.py:53-57,65-76: per-query 1.0/0.0 hits, float64 means.  (The mean of 1.0 / 0.0 flags is their count over their
+    number, exactly: a sum of ones is exact in float64 whatever the order -- np.float64(count) / n is the value
+    np.mean(np.where(ranks <= k, 1.0, 0.0)) has, at a third of the passes over the array.)"""
+    ranks = np.asarray(ranks)
+    if ranks.dtype.kind not in "iu":
+        ranks = ranks.astype(np.int64)
+    n = len(ranks)
     hits = {}
     for hits_level in hits_to_compute:
-        hits[hits_level] = np.mean(np.where(ranks <= hits_level, 1.0, 0.0)) if len(ranks) else float("nan")
-    mr = np.mean(ranks) if len(ranks) else float("nan")
-    mrr = np.mean(1. / ranks) if len(ranks) else float("nan")
+        hits[hits_level] = np.float64(np.count_nonzero(ranks <= hits_level)) / n if n else float("nan")
+    mr = np.mean(ranks) if n else float("nan")
+    mrr = np.mean(1. / ranks) if n else float("nan")
     return mr, mrr, hits
 
 
@@ -80,6 +85,22 @@ def ranking_and_hits(model, results_dir, data_iterator_handle, name, session=Non
     logger.info("-" * 50)
     logger.info("")
 
+    # an evaluation set that is scored again and again (after every epoch, run_cpg.py:228-250) is marshalled once: int32 in
+    # pinned memory, canonical CSR, device buffers (EvalDataset.staged_for); a pass is then three asynchronous calls and one wait
+    sb = None
+    if ranker is None and hasattr(data_iterator_handle, "staged_for") and hasattr(model, "rank_pass_staged") \
+            and getattr(data_iterator_handle, "num_queries", max_chunk + 1) <= max_chunk:
+        sb = data_iterator_handle.staged_for(model)
+    if sb is not None:
+        Q = sb["B"]
+        out = model.rank_pass_staged(sb)
+        sb["event"].synchronize()
+        ranks = out.numpy()
+        if Q and getattr(model, "score_mode", None) == "bf16x3":
+            aud = sb["out_host"][Q:Q + 2].numpy()
+            _report_band_audit(float(aud[:1].view(np.float32)[0]), int(aud[1:2].view(np.uint32)[0]))
+        return _finish(ranks, Q, results_dir, hits_to_compute, enable_write_to_file, return_ranks)
+
     q = collect_batches(data_iterator_handle, device=getattr(model, "device", None))
     Q = len(q["e1"])
     ranks = []
@@ -97,12 +118,18 @@ def ranking_and_hits(model, results_dir, data_iterator_handle, name, session=Non
     # bf16x3 mode: the run-time audit of the exact band (include/coper_hip.h: coper_band_audit) -- the largest error of the
     # mode's logits on the pairs closest to the targets, relative to what the band allows; ranks are the fp32 chain's below 1
     if Q and getattr(model, "score_mode", None) == "bf16x3" and hasattr(model, "band_audit"):
-        ratio, n_pairs = model.band_audit()
-        ranking_and_hits.last_band_audit = (ratio, n_pairs)
-        if ratio > 0.5:
-            logger.warning("bf16x3 band audit: |logit_x3 - logit_fp32| reached %.2f of the band's allowance on %d audited pairs; "
-                           "raise rank_band_kappa (ranks may differ from the fp32 chain's above 1.0)", ratio, n_pairs)
-    count = Q
+        _report_band_audit(*model.band_audit())
+    return _finish(ranks, Q, results_dir, hits_to_compute, enable_write_to_file, return_ranks)
+
+
+def _report_band_audit(ratio, n_pairs):
+    ranking_and_hits.last_band_audit = (ratio, n_pairs)
+    if ratio > 0.5:
+        logger.warning("bf16x3 band audit: |logit_x3 - logit_fp32| reached %.2f of the band's allowance on %d audited pairs; "
+                       "raise rank_band_kappa (ranks may differ from the fp32 chain's above 1.0)", ratio, n_pairs)
+
+
+def _finish(ranks, count, results_dir, hits_to_compute, enable_write_to_file, return_ranks):
     logger.info("Evaluated %d samples." % count)
 
     mr, mrr, hits = hits_and_means(ranks, hits_to_compute)
@@ -117,5 +144,5 @@ def ranking_and_hits(model, results_dir, data_iterator_handle, name, session=Non
         _write_data_to_file(os.path.join(results_dir, "mrr.txt"), mrr)
     logger.info("-" * 50)
     if return_ranks:
-        return mr, mrr, hits, ranks
+        return mr, mrr, hits, np.asarray(ranks).astype(np.int64)
     return mr, mrr, hits

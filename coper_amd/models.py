@@ -264,6 +264,49 @@ class ConvE(object):
         st["ev"][k].record(torch.cuda.current_stream(self.device))
         return tuple(dev[o:o + a.size] for o, a in zip(offs, arrs))
 
+    def stage_persistent(self, e1, rel, e2, filt_indptr, filt_idx):
+        """A host batch marshalled ONCE for repeated evaluation (an `EvalDataset` scored after every epoch, run_cpg.py:18-35):
+        [e1 | rel | e2 | filt_indptr | filt_idx] as int32 in one pinned buffer of its own, the int64 device arrays the C-ABI
+        takes, and pinned memory for the ranks.  `rank_pass_staged` brings the batch in with one launch per pass and posts
+        the ranks back; the host does no per-pass marshalling.  None when an id does not fit int32."""
+        arrs = [np.ascontiguousarray(np.asarray(a)).reshape(-1) for a in (e1, rel, e2, filt_indptr, filt_idx)]
+        if any(a.dtype.kind not in "iu" or (a.size and (int(a.max()) >= 2 ** 31 or int(a.min()) < -2 ** 31)) for a in arrs):
+            return None
+        sizes = [int(a.size) for a in arrs]
+        offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        total = max(1, int(offs[-1]))
+        pin = torch.empty(total, dtype=torch.int32).pin_memory()
+        host = pin.numpy()
+        for a, o in zip(arrs, offs):
+            host[o:o + a.size] = a
+        B = sizes[0]
+        sb = dict(pin=pin, total=int(offs[-1]), B=B, nnz=sizes[4],
+                  stage=torch.empty(total, dtype=torch.int64, device=self.device),
+                  ranks=torch.empty(max(1, B), dtype=torch.int32, device=self.device),
+                  out_host=torch.empty(max(1, B) + 2, dtype=torch.int32).pin_memory(),      # (+ 2: the band audit's words)
+                  event=torch.cuda.Event())
+        sb["views"] = tuple(sb["stage"][o:o + n] for o, n in zip(offs, sizes))
+        return sb
+
+    def rank_pass_staged(self, sb):
+        """One evaluation pass over a batch from `stage_persistent`: ids + CSR in over PCIe (coper_widen_ids), the fused pass
+        (coper_encode_rank, ranks only), the int32 ranks out to pinned memory (coper_copy_out_i32) -- all asynchronous.
+        Returns the pinned int32 tensor of the ranks, valid after `sb["event"].synchronize()`."""
+        self._need_prepared()
+        B = sb["B"]
+        if B == 0:
+            return sb["out_host"][:0]
+        self.widen_ids(sb["pin"][:sb["total"]], out=sb["stage"][:sb["total"]])
+        e1, rel, e2, ip, ix = sb["views"]
+        ranks = sb["ranks"][:B]
+        _lib.check(self._h, self._lib.coper_encode_rank(self._h, _ptr(e1), _ptr(rel), None, _ptr(e2), _ptr(ip), _ptr(ix),
+                                                        sb["nnz"], B, None, _ptr(ranks), None, self._stream()))
+        self.copy_out(ranks, sb["out_host"][:B])
+        if self.score_mode == "bf16x3":      # the audit's two words ride along (read and reset: coper_band_audit_post)
+            _lib.check(self._h, self._lib.coper_band_audit_post(self._h, 1, C.c_void_p(sb["out_host"][B:].data_ptr()), self._stream()))
+        sb["event"].record(torch.cuda.current_stream(self.device))
+        return sb["out_host"][:B]
+
     def copy_out(self, src: torch.Tensor, dst: torch.Tensor):
         """int32 results (the ranks of a pass) from the device to `dst` -- a pinned host tensor (or a device tensor): one small
         launch right behind the pass's last kernel (coper_copy_out_i32).  Synchronise with the stream before reading dst."""

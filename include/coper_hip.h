@@ -251,6 +251,10 @@ COPER_API int coper_encode_rank(coper_handle* h, const int64_t* e1, const int64_
  * warning above it.  Synchronises the stream.  COPER_SCORE_F32 handles report 0 / 0.  The reference has no counterpart: its
  * ranker works on materialised fp32 logits (metrics.py:40-50). */
 COPER_API int coper_band_audit(coper_handle* h, int32_t reset, float* max_ratio, int64_t* n_pairs, void* stream);
+/* The same two words without a synchronisation: dst2[0] = the ratio's float bits, dst2[1] = the pair count, posted to `dst2`
+ * (device memory or PINNED, device-mapped host memory, like coper_copy_out_i32) behind the work already on the stream; a
+ * host that waits for its ranks anyway reads them with the same wait.  COPER_ESTATE on a COPER_SCORE_F32 handle. */
+COPER_API int coper_band_audit_post(coper_handle* h, int32_t reset, uint32_t* dst2, void* stream);
 
 /* Timing hook used by bench.py: average device time (ms) of the dominant kernel
  * (score_count) over the launches since the last reset, measured with hipEvents recorded on
