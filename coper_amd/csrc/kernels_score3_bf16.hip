@@ -950,6 +950,7 @@ __device__ __forceinline__ void band_exact_body(const uint4* __restrict__ mask, 
     }
   }
   __syncthreads();
+  bool audited = false;      // (workgroup-uniform)
   const int ni = s_ni;       // beyond BE_ITEMS (a workgroup's 256 x 64 lanes nearly all marked: heavy ties): the slow loop below
   for (int it0 = 0; it0 < (ni < BE_ITEMS ? ni : BE_ITEMS); it0 += 256) {
     const int it = it0 + threadIdx.x;
@@ -995,7 +996,8 @@ __device__ __forceinline__ void band_exact_body(const uint4* __restrict__ mask, 
           if (p < BE_AUDIT) { s_sx[p] = dec ? sx : NAN; s_tx[p] = tx; }
         }
         __syncthreads();
-        if (A.audit) {
+        if (A.audit && !audited && n > 0) {      // the first round's pairs only: a launch over 10M entities has thousands of rounds
+          audited = true;
           const int na = n < BE_AUDIT ? n : BE_AUDIT;
           for (int g = (int)(threadIdx.x >> 6); g * 32 < na; g += 4) band_audit_group(A, s_p, s_sx, s_tx, g * 32, na, s_ae[threadIdx.x >> 6]);
           __syncthreads();

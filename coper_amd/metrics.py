@@ -36,8 +36,17 @@ def hits_and_means(ranks, hits_to_compute=(1, 3, 5, 10, 20)):
         ranks = ranks.astype(np.int64)
     n = len(ranks)
     hits = {}
-    for hits_level in hits_to_compute:
-        hits[hits_level] = np.float64(np.count_nonzero(ranks <= hits_level)) / n if n else float("nan")
+    levels = [int(k) for k in hits_to_compute]
+    if n and levels and 0 < max(levels) <= 4096 and int(ranks.min()) >= 0:
+        # every level from ONE pass: counts of the ranks up to the largest level (larger ranks fall into one overflow bin)
+        top = max(levels)
+        cum = np.cumsum(np.bincount(np.minimum(ranks, top + 1), minlength=top + 2))
+        for hits_level in hits_to_compute:
+            k = int(hits_level)
+            hits[hits_level] = np.float64(cum[k] if k >= 0 else 0) / n
+    else:
+        for hits_level in hits_to_compute:
+            hits[hits_level] = np.float64(np.count_nonzero(ranks <= hits_level)) / n if n else float("nan")
     mr = np.mean(ranks) if n else float("nan")
     mrr = np.mean(1. / ranks) if n else float("nan")
     return mr, mrr, hits

@@ -56,3 +56,15 @@ def test_bench_two_ranks_entity_sharded_main_line():
     one = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert two["n_gpus"] == 2 and one["n_gpus"] == 1
     assert two["config"]["mean_rank"] == one["config"]["mean_rank"] and two["config"]["mrr"] == one["config"]["mrr"]
+
+
+def test_bench_two_ranks_three_times_back_to_back():
+    """round 3 saw ONE two-rank run hang in a full-suite pass (never reproduced; the one latent deadlock found
+    since -- rank 0 blocking on a stdout pipe nobody drained -- is gone: bench.py's self_launch reads a file).  Three launches
+    in a row, each bounded by --launch-timeout, each with the ranks of the others."""
+    ranks = []
+    for _ in range(3):
+        line, _ = _run_bench(["--no-extras"], timeout=300)
+        assert line["n_gpus"] == 2 and line["value"] > 0
+        ranks.append((line["config"]["mean_rank"], line["config"]["mrr"]))
+    assert ranks[0] == ranks[1] == ranks[2]
