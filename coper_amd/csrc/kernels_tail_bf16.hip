@@ -120,6 +120,85 @@ __global__ __launch_bounds__(256) void k_finalize_h_publish(const float* __restr
   x3_block_store_max(m, x3m);
 }
 
+// ---- the tile of this kernel in three pieces (tail_tile.h holds the one-piece form the excess role keeps): the rows of a tile are
+// requested as soon as their ids are known -- for a wave's first tile that is BEFORE the block's fragments exist -- and the
+// fragments are read from LDS step by step instead of sitting in 104 registers, which is what leaves room for a whole tile of
+// gathers in flight.  Same instructions in the same order as tail_tile: the same bits.
+//   tl_prep:   CSR entries [pb, pb + 32) -> the entry's row (or -1: see tail_filter_tile) and its query; rows published in s_e
+__device__ __forceinline__ int64_t tl_prep(const int64_t pb, const int64_t p_end, const int64_t my_lo, const int64_t my_e2,
+                                           const int64_t f_cur, const int64_t f_prev, const int64_t n_local, int64_t* s_e, const int i,
+                                           const int half, int& qi_out) {
+  const int64_t p = pb + i;
+  const bool valid = p < p_end;
+  int qi = 0;
+#pragma unroll
+  for (int step = 16; step >= 1; step >>= 1) {
+    const int cand = qi + step;
+    const int64_t first = __shfl(my_lo, cand < 32 ? cand : 31);
+    qi = (valid && cand < 32 && first <= p) ? cand : qi;
+  }
+  const int64_t qfirst = __shfl(my_lo, qi);
+  const int64_t qe2 = __shfl(my_e2, qi);
+  int64_t frow = -1;
+  if (valid) {
+    frow = f_cur;
+    if (p > qfirst && f_prev == f_cur) frow = -1;          // adjacent duplicate: the dense mask is idempotent
+    if (f_cur == qe2) frow = -1;                            // the target is restored after masking (metrics.py:46)
+    if (frow < 0 || frow >= n_local) frow = -1;
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (half == 0) s_e[i] = frow;
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): wave-local LDS exchange
+  __builtin_amdgcn_wave_barrier();
+  qi_out = qi;
+  return frow;
+}
+//   tl_gather: the 2 KS 16-byte pieces of the lane's row, all in flight
+template <int KS>
+__device__ __forceinline__ void tl_gather(const uint4* __restrict__ Ehi, const uint4* __restrict__ Elo, const int64_t my_erow, const int half,
+                                          uint4 (&ah)[KS + 1], uint4 (&al)[KS + 1]) {
+  const int64_t ea = my_erow >= 0 ? my_erow : 0;
+  const uint4* pa_h = Ehi + ea * (2 * KS) + half;
+  const uint4* pa_l = Elo + ea * (2 * KS) + half;
+#pragma unroll
+  for (int k = 0; k < KS; ++k) { ah[k] = pa_h[k * 2]; al[k] = pa_l[k * 2]; }
+  ah[KS] = ah[KS - 1]; al[KS] = al[KS - 1];     // (never used: the pair loop names element u + 1 in a branch it does not take)
+}
+//   tl_mma:    the tile, query fragments from LDS
+template <int KS>
+__device__ __forceinline__ f32x16 tl_mma(const float* __restrict__ bias_pad, const int64_t* s_e, const uint4 (&ah)[KS + 1], const uint4 (&al)[KS + 1],
+                                         const uint4 (*s_bh)[64], const uint4 (*s_bl)[64], const int lane, const int half, const int sexp) {
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int64_t er = s_e[(r & 3) + 8 * (r >> 2) + 4 * half];
+    acc[r] = er >= 0 ? x3_scale(bias_pad[er], sexp) : 0.f;
+  }
+#pragma unroll
+  for (int u = 0; u < KS; u += 2) {
+    if (u + 1 < KS) {
+      const uint4 bh0 = s_bh[u][lane], bl0 = s_bl[u][lane], bh1 = s_bh[u + 1][lane], bl1 = s_bl[u + 1][lane];
+      BX3_PAIR(ah[u], al[u], bh0, bl0, ah[u + 1], al[u + 1], bh1, bl1, acc);
+    } else {
+      const uint4 bh0 = s_bh[u][lane], bl0 = s_bl[u][lane];
+      BX3_LAST(ah[u], al[u], bh0, bl0, acc);
+    }
+  }
+  return acc;
+}
+//   entry i's score: D[i][qi] = register (i & 3) + 4 (i >> 3) of lane qi + 32 ((i >> 2) & 1)
+__device__ __forceinline__ float tl_entry_score(const f32x16& acc, const int qi, const int i) {
+  const int src = qi + 32 * ((i >> 2) & 1);
+  const int reg = (i & 3) + 4 * (i >> 3);
+  float sc = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float v = __shfl(acc[r], src);
+    sc = (r == reg) ? v : sc;
+  }
+  return sc;
+}
+
 template <int KS>
 __global__ __launch_bounds__(64 * TL_WAVES, KS <= 13 ? 3 : 2) void k_finalize_targets_filter_bf16x3(
     int64_t B, int d, const float* __restrict__ h_rows, uint4* __restrict__ hf3,
@@ -147,8 +226,34 @@ __global__ __launch_bounds__(64 * TL_WAVES, KS <= 13 ? 3 : 2) void k_finalize_ta
   if (threadIdx.x == 0 && p_all > p_end) heavy[2 + atomicAdd(&heavy[0], 1)] = (int32_t)blk;
   const int64_t my_lo = live ? indptr[q] : p_end;   // first entry of query i (lane i), for the search in filter_tile
 
+  // ---- 0. the wave's first item, requested before anything else: item 0 = the targets (pair i = (query i, e2[query i]), the
+  // diagonal of the tile), item 1 + n = the n-th tile of 32 CSR entries of these queries ([indptr[q0], indptr[min(q0 + 32, B)])
+  // is contiguous); wave 0 takes the targets, waves 1.. the first tiles.  Their rows travel while the fragments are built.
+  int64_t erow = my_e2;
+  if (erow < 0 || erow >= n_local) erow = -1;
+  int qi0 = 0;
+  int64_t row0 = -1;
+  bool have0 = true;   // (wave-uniform) the wave has a first item
+  if (wave == 0) {   // (wave-uniform branches: the shuffles inside run with every lane)
+    row0 = erow;
+    if (half == 0) s_e[0][i] = erow;
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+  } else {
+    const int64_t pb = p_begin + 32 * (int64_t)(wave - 1);
+    if (pb < p_end) {
+      const int64_t p = pb + i;
+      const int64_t f_cur = p < p_end ? idx[p] : -1, f_prev = (p < p_end && p > p_begin) ? idx[p - 1] : -1;
+      row0 = tl_prep(pb, p_end, my_lo, my_e2, f_cur, f_prev, n_local, s_e[wave], i, half, qi0);
+    } else {
+      have0 = false;       // (s_e[wave] holds nothing: no tile, no gather)
+    }
+  }
+  uint4 ah[KS + 1], al[KS + 1];
+  if (have0) tl_gather<KS>(Ehi, Elo, row0, half, ah, al);
+
   // ---- 1. the block's fragments: wave w takes k-steps w, w + 4, ...; a lane scales and splits piece (ks, half) of its query's
-  // fp32 row (k_finalize_h_publish wrote it; the batch's exponents are published)
+  // fp32 row (the encoder's epilogue or k_finalize_h_publish wrote it), with the batch's exponent reduced from x3m
   static_assert(TL_WAVES == 4, "x3_batch_exp: 256 threads");
   const int eh = x3_batch_exp(x3m, ent_exp, x3s, &s_n2[0][0]), sexp = eh + ent_exp;
   const int32_t x3l[2] = {eh, sexp};      // (what x3s holds once block 0 has published: this kernel must not read it back)
@@ -180,65 +285,60 @@ __global__ __launch_bounds__(64 * TL_WAVES, KS <= 13 ? 3 : 2) void k_finalize_ta
   }
   TL_STAMP(1);
   __syncthreads();
-  uint4 bh[KS], bl[KS];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) { bh[ks] = s_bh[ks][lane]; bl[ks] = s_bl[ks][lane]; }
   TL_STAMP(2);
 
-  // ---- 2. + 3. items of the block, dealt to the waves round-robin: item 0 = the targets (pair i = (query i, e2[query i]),
-  // the diagonal of the tile), item 1 + n = the n-th tile of 32 CSR entries of these queries ([indptr[q0], indptr[min(q0 + 32,
-  // B)]) is contiguous).  Round 0 runs in parallel -- wave 0 the targets, waves 1.. the first tiles, their comparisons held
-  // back until the targets are published through LDS.  Phases of a workgroup (COPER_DBG_TL_CLOCK build, tools/ab_tail.py;
-  // all 640 workgroups of an FB15k-237-shaped pass are resident at once and move in step): finalize 10.7 us (the 34 MB of
-  // K-slice partial sums), round 0 10.7 us, the remaining tiles 7 us for the median workgroup, 13 us for the one with the
-  // most entries -- 42 us per launch.  With every wave computing the targets first: 7.6 us for them alone, then two tile
-  // rounds of 7.7 us, 43 us per launch: the gathers of a round queue behind one another (the kernel is a sequence of
-  // chip-wide bursts of 16-byte gathers), so shortening the chain of one workgroup moves the median, not the end.
-  int64_t erow = my_e2;
-  if (erow < 0 || erow >= n_local) erow = -1;
-  // one tile of entries [pb, pb + 32): (score of entry i against its own query, that query, the entry's row or -1)
-  auto filter_tile = [&](const int64_t pb, float& sc, int& qi_out) -> int64_t {
-    return tail_filter_tile<KS>(pb, p_end, my_lo, my_e2, idx, n_local, s_e[wave], Ehi, Elo, bias_pad, bh, bl, i, half, sexp, sc, qi_out);
-  };
+  // ---- 2. round 0: every wave's first tile against the fragments in LDS; the filter waves hold their comparisons back until
+  // the targets are published.  (Phases of a workgroup, COPER_DBG_TL_CLOCK build, tools/ab_tail.py -- all 640 workgroups of an
+  // FB15k-237-shaped pass are resident at once and move in step, a sequence of chip-wide bursts of 16-byte gathers.  Round 3:
+  // finalize 10.7 us, round 0 10.7, remaining tiles 7 - 13.  Round 4 before this form: fragments 5.1, round 0 12.2, rest 10 - 20.)
   float sc0 = 0.f;
-  int qi0 = 0;
-  int64_t frow0 = -1;
-  if (wave == 0) {   // (wave-uniform branches: the shuffles inside run with every lane)
-    if (half == 0) s_e[0][i] = erow;
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    __builtin_amdgcn_wave_barrier();
-    const f32x16 acc = tail_tile<KS>(Ehi, Elo, bias_pad, s_e[0], erow, bh, bl, half, sexp);
-    // D[i][i] sits in lane i + 32 * ((i >> 2) & 1), register (i & 3) + 4 * (i >> 3)
-    float diag = 0.f;
-    const int reg = (i & 3) + 4 * (i >> 3);
+  if (have0) {
+    const f32x16 acc = tl_mma<KS>(bias_pad, s_e[wave], ah, al, s_bh, s_bl, lane, half, sexp);
+    if (wave == 0) {
+      // D[i][i] sits in lane i + 32 * ((i >> 2) & 1), register (i & 3) + 4 * (i >> 3)
+      float diag = 0.f;
+      const int reg = (i & 3) + 4 * (i >> 3);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) diag = (r == reg) ? acc[r] : diag;
-    float t0 = __shfl(diag, i + 32 * ((i >> 2) & 1));   // lane i (both halves): the target of query i
-    t0 = erow >= 0 ? t0 : 0.f;
-    if (half == 0) {
-      float n2 = 0.f;
+      for (int r = 0; r < 16; ++r) diag = (r == reg) ? acc[r] : diag;
+      float t0 = __shfl(diag, i + 32 * ((i >> 2) & 1));   // lane i (both halves): the target of query i
+      t0 = erow >= 0 ? t0 : 0.f;
+      if (half == 0) {
+        float n2 = 0.f;
 #pragma unroll
-      for (int w2 = 0; w2 < TL_WAVES; ++w2) n2 += s_n2[w2][i];
-      // t0, the band and everything compared with them stay in the accumulators' units (x 2^(e_E + e_h)); tgt leaves descaled
-      const float tau = x3_scale(x3_band_tau(n2, kappa, band_consts, d, x3l), sexp);
-      s_t[i] = t0 + tau;
-      if (live) { tgt[q] = x3_scale(t0, -sexp); tband[q] = make_float2(t0 - tau, t0 + tau); }
+        for (int w2 = 0; w2 < TL_WAVES; ++w2) n2 += s_n2[w2][i];
+        // t0, the band and everything compared with them stay in the accumulators' units (x 2^(e_E + e_h)); tgt leaves descaled
+        const float tau = x3_scale(x3_band_tau(n2, kappa, band_consts, d, x3l), sexp);
+        s_t[i] = t0 + tau;
+        if (live) { tgt[q] = x3_scale(t0, -sexp); tband[q] = make_float2(t0 - tau, t0 + tau); }
+      }
+    } else {
+      sc0 = tl_entry_score(acc, qi0, i);
     }
-  } else {
-    const int64_t pb = p_begin + 32 * (int64_t)(wave - 1);
-    if (pb < p_end) frow0 = filter_tile(pb, sc0, qi0);
+  }
+  // ---- 3. the remaining tiles; the ids of a wave's next tile are requested before the block waits for the targets
+  int64_t pb = p_begin + 32 * (int64_t)(TL_WAVES - 1 + wave);
+  int64_t f_cur = -1, f_prev = -1;
+  if (pb < p_end) {
+    const int64_t p = pb + i;
+    f_cur = p < p_end ? idx[p] : -1;
+    f_prev = (p < p_end && p > p_begin) ? idx[p - 1] : -1;
   }
   TL_STAMP(3);
   __syncthreads();
   const float t = s_t[i];
-  {
+  if (wave != 0) {
     const float tq = __shfl(t, qi0);
-    if (half == 0 && frow0 >= 0 && sc0 > tq) atomicAdd(&s_corr[qi0], 1);
+    if (half == 0 && row0 >= 0 && sc0 > tq) atomicAdd(&s_corr[qi0], 1);
   }
-  for (int64_t pb = p_begin + 32 * (int64_t)(TL_WAVES - 1 + wave); pb < p_end; pb += 32 * TL_WAVES) {
-    float sc;
+  for (; pb < p_end; pb += 32 * TL_WAVES) {
     int qi;
-    const int64_t frow = filter_tile(pb, sc, qi);
+    const int64_t frow = tl_prep(pb, p_end, my_lo, my_e2, f_cur, f_prev, n_local, s_e[wave], i, half, qi);
+    tl_gather<KS>(Ehi, Elo, frow, half, ah, al);
+    const int64_t pn = pb + 32 * TL_WAVES + i;      // the ids of the tile after this one
+    f_cur = pn < p_end ? idx[pn] : -1;
+    f_prev = (pn < p_end && pn > p_begin) ? idx[pn - 1] : -1;
+    const f32x16 acc = tl_mma<KS>(bias_pad, s_e[wave], ah, al, s_bh, s_bl, lane, half, sexp);
+    const float sc = tl_entry_score(acc, qi, i);
     const float tq = __shfl(t, qi);
     if (half == 0 && frow >= 0 && sc > tq) atomicAdd(&s_corr[qi], 1);
   }
