@@ -196,8 +196,9 @@ __global__ __launch_bounds__(1024) void k_rel_group_single(const int64_t* __rest
                                                            int32_t* offset, int32_t* __restrict__ tiles,
                                                            int32_t* __restrict__ n_tiles, int32_t* __restrict__ perm,
                                                            int32_t* __restrict__ sorted_row, int32_t* __restrict__ sorted_rid,
-                                                           int32_t* __restrict__ inv_perm) {
+                                                           int32_t* __restrict__ inv_perm, float* __restrict__ x3m) {
   extern __shared__ int32_t sh[];   // cnt[R] | cursor[R]
+  if (x3m) x3m[threadIdx.x] = 0.f;  // (1024 threads, 1024 slots: see k_rel_scatter)
   int32_t* cnt = sh;
   int32_t* cur = sh + R;
   for (int k = threadIdx.x; k < 2 * R; k += 1024) sh[k] = 0;
@@ -306,7 +307,8 @@ int launch_group_by_relation(coper_handle* h, const int64_t* e1, const int64_t* 
     // rel_count[R+1] doubles as the out-of-range counter (reset by the kernel)
     hipLaunchKernelGGL(k_rel_group_single, dim3(1), dim3(1024), sizeof(int32_t) * 2 * (size_t)R, s, rel, e1, B, dm.gen_fc ? 1 : 0, R,
                        dm.R, have_e1_rows ? 1 : 0, (int64_t)h->cfg.shard_lo, dm.n_local, small_tile_cap(h), h->rel_count,
-                       h->rel_count + dm.R + 1, h->rel_offset, h->tiles, h->n_tiles, h->perm, h->sorted_row, h->sorted_rid, h->inv_perm);
+                       h->rel_count + dm.R + 1, h->rel_offset, h->tiles, h->n_tiles, h->perm, h->sorted_row, h->sorted_rid, h->inv_perm,
+                       h->x3m);
     (void)tq;
     COPER_HIP_TRY(h, hipGetLastError());
     return COPER_OK;
