@@ -1235,6 +1235,10 @@ int score_count3_chunk_bf16x3(coper_handle* h, int64_t q0, int64_t Bc, const flo
       static const int off = getenv("COPER_BAND_NO_AUDIT") != nullptr;      // (A/B timing switch)
       int period = h->cfg.band_audit_period;
       if (period == 0) period = (double)Bc * (double)h->dm.n_local >= 2147483648.0 ? 1 : 8;
+      // a launch recorded into a hipGraph is replayed as recorded: it carries the audit only when every launch does
+      // (period 1), never by the accident of where the counter stood at capture
+      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+      if (period != 1 && hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) period = -1;
       A.audit = (!off && period > 0 && (h->band_launches++ % (unsigned)period) == 0u) ? 1 : 0;
     }
     const int64_t n_units = sc3_units(h, Bc);

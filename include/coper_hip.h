@@ -102,7 +102,7 @@ typedef struct coper_config {
   float x3_ent_absmax;
   /* COPER_SCORE_BF16X3: which count launches carry the band audit (coper_band_audit).  0 = the library default: the first
    * launch after coper_prepare and every 8th from there (+3 us per 0.5 ms pass), every launch of more than 2^31 logits;
-   * n > 0: every n-th launch; negative: never. */
+   * n > 0: every n-th launch; negative: never.  Launches recorded into a hipGraph carry the audit only with n = 1. */
   int32_t band_audit_period;
   int32_t reserved[4];
 } coper_config;
