@@ -84,9 +84,28 @@ __device__ __forceinline__ uint4 sc3_lds_hi(const uint4 __attribute__((address_s
   return make_uint4(v.x, v.y, v.z, v.w);
 }
 
+// Entity fragments: global loads from a 64-bit vector address per stream; constants beyond the 13-bit immediate cost a v_add_co /
+// v_addc pair and the wait states of their carry (58 loads per half-row).  Round 4 tried BUFFER loads instead (-DCOPER_SC3_BUFFER_LOADS:
+// a resource descriptor per row in four scalar registers, the lane's 16-byte slot as the one vector offset, the register's place
+// inside the row as a scalar offset: `s_movk` + `buffer_load`, no vector instruction, wait states 29 -> 7 per half-row): 0.2645
+// against 0.2551 ms on the same box, three alternating runs -- the address arithmetic is not what the loads cost.
+#ifndef COPER_SC3_BUFFER_LOADS     /* the shipped form */
+struct sc3_rsrc_t { const char* p; };
+__device__ __forceinline__ sc3_rsrc_t sc3_make_rsrc(const void* p) { return sc3_rsrc_t{(const char*)p}; }
+__device__ __forceinline__ uint4 sc3_bload(const sc3_rsrc_t r, const int voff, const int soff) { return *(const uint4*)(r.p + soff + voff); }
+#else
+typedef __amdgpu_buffer_rsrc_t sc3_rsrc_t;
+// (raw buffers: no stride, 2 GiB of records -- every offset used lies inside a row's 2 BLK_REGS KiB; 0x00020000: 32-bit data format)
+__device__ __forceinline__ sc3_rsrc_t sc3_make_rsrc(const void* p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7FFFFFFE, 0x00020000); }
+__device__ __forceinline__ uint4 sc3_bload(const sc3_rsrc_t r, const int voff, const int soff) {
+  const sc3_u4n v = __builtin_bit_cast(sc3_u4n, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+#endif
 struct SC3Ptrs {
-  const uint4* a[2];     // f3 register (16-row block 0 of entity block M, step 0, reg 0) of this row: wave-uniform (scalar base +
-  const uint4* n;        // ... of the next row's block 0                              lane offset: no 64-bit vector adds per load)
+  sc3_rsrc_t ra;               // this row's two entity blocks: block M, 16-row block m2, step t, register w at byte
+  sc3_rsrc_t rn;               //   ((M BLK_REGS + (m2 NS + t) 2 + w) 64 + lane) 16;   rn: the next row's block 0
+  int voff;                    // lane * 16
   const uint4* hl;       // the query tile in LDS, lane included
   const uint4 __attribute__((address_space(3)))* hl_hi;    // ... its part beyond 64 KiB (an LDS pointer the compiler cannot fold back)
 };
@@ -336,18 +355,19 @@ __device__ __forceinline__ void sc3_region(SC3<NP, TAIL, PD, GM>& S, const SC3Pt
 #ifndef COPER_DBG_SC3_SKIP_GL
   if constexpr (b < 2 * MB) {
     constexpr int m2 = b >> 1, wh = b & 1;
+    constexpr int BLKB = MB * NS * 2 * 1024;     // bytes of one entity block's registers
     if constexpr (tk < NS) {
       constexpr int ta = (PA + tk / PD) & 1, tl = tk % PD;
-      if constexpr (wh == 0) S.a0[ta][tl][m2] = X.a[M][((m2 * NS + tk) * 2 + 0) * 64 + lane];
-      else S.a1[ta][tl][m2] = X.a[M][((m2 * NS + tk) * 2 + 1) * 64 + lane];
+      if constexpr (wh == 0) S.a0[ta][tl][m2] = sc3_bload(X.ra, X.voff, M * BLKB + ((m2 * NS + tk) * 2 + 0) * 1024);
+      else S.a1[ta][tl][m2] = sc3_bload(X.ra, X.voff, M * BLKB + ((m2 * NS + tk) * 2 + 1) * 1024);
     } else if constexpr (M == 0) {           // step tk - NS of this row's block 1
       constexpr int u = tk - NS;
-      if constexpr (wh == 0) S.a0[PA_NEXT][u][m2] = X.a[1][((m2 * NS + u) * 2 + 0) * 64 + lane];
-      else S.a1[PA_NEXT][u][m2] = X.a[1][((m2 * NS + u) * 2 + 1) * 64 + lane];
+      if constexpr (wh == 0) S.a0[PA_NEXT][u][m2] = sc3_bload(X.ra, X.voff, BLKB + ((m2 * NS + u) * 2 + 0) * 1024);
+      else S.a1[PA_NEXT][u][m2] = sc3_bload(X.ra, X.voff, BLKB + ((m2 * NS + u) * 2 + 1) * 1024);
     } else {                                 // ... of the next row's block 0
       constexpr int u = tk - NS;
-      if constexpr (wh == 0) S.a0[PA_NEXT][u][m2] = X.n[((m2 * NS + u) * 2 + 0) * 64 + lane];
-      else S.a1[PA_NEXT][u][m2] = X.n[((m2 * NS + u) * 2 + 1) * 64 + lane];
+      if constexpr (wh == 0) S.a0[PA_NEXT][u][m2] = sc3_bload(X.rn, X.voff, ((m2 * NS + u) * 2 + 0) * 1024);
+      else S.a1[PA_NEXT][u][m2] = sc3_bload(X.rn, X.voff, ((m2 * NS + u) * 2 + 1) * 1024);
     }
   }
 #endif
@@ -596,9 +616,9 @@ __global__ __launch_bounds__(256, 1) void k_score_count3_bf16x3(const uint4* __r
     const int64_t eb_next = has_next ? (((r + 1) % rows_per_tile) * 4 + wave) * 2 : eb;     // past the end: re-read this row's blocks
     const int64_t gm_col = cur_tile * 128;
     SC3Ptrs X;
-    X.a[0] = Ef3 + eb * BLK_REGS * 64;
-    X.a[1] = X.a[0] + BLK_REGS * 64;
-    X.n = Ef3 + eb_next * BLK_REGS * 64;
+    X.ra = sc3_make_rsrc(Ef3 + eb * BLK_REGS * 64);
+    X.rn = sc3_make_rsrc(Ef3 + eb_next * BLK_REGS * 64);
+    X.voff = lane * 16;
     X.hl = hl3 + lane;
     {
       unsigned hi_off = (unsigned)(uintptr_t)((const uint4 __attribute__((address_space(3)))*)(hl3 + lane + 4096));
