@@ -802,6 +802,7 @@ struct BandArgs {
   const float* tgt_x; int32_t* ng; int32_t* ne; int64_t Bc, n_local, shard_lo; int d; int dbg;
   // the audit (below): the mode's own operands of the pairs the walk decides
   const uint4* Ehi; const uint4* Elo; const float* bias_pad; const float2* tband; const int32_t* x3s; unsigned* consts; int KS16; int audit;
+  int audit_wg_mask;     // workgroups with (index & mask) == 0 audit: at most ~512 per launch (a 10M-entity launch has 20,000)
 };
 
 // returns true when the pair was decided by the chain; sx_out / tx_out: the chain's logits of the competitor and of the target
@@ -1016,7 +1017,7 @@ __device__ __forceinline__ void band_exact_body(const uint4* __restrict__ mask, 
           if (p < BE_AUDIT) { s_sx[p] = dec ? sx : NAN; s_tx[p] = tx; }
         }
         __syncthreads();
-        if (A.audit && !audited && n > 0) {      // the first round's pairs only: a launch over 10M entities has thousands of rounds
+        if (A.audit && !audited && n > 0 && (wg & (int64_t)A.audit_wg_mask) == 0) {   // the first round of (a sample of) the workgroups
           audited = true;
           const int na = n < BE_AUDIT ? n : BE_AUDIT;
           for (int g = (int)(threadIdx.x >> 6); g * 32 < na; g += 4) band_audit_group(A, s_p, s_sx, s_tx, g * 32, na, s_ae[threadIdx.x >> 6]);
@@ -1260,6 +1261,9 @@ int score_count3_chunk_bf16x3(coper_handle* h, int64_t q0, int64_t Bc, const flo
       hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
       if (period != 1 && hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) period = -1;
       A.audit = (!off && period > 0 && (h->band_launches++ % (unsigned)period) == 0u) ? 1 : 0;
+      int mask = 0;
+      while ((sc3_units(h, Bc) + BE_UPW - 1) / BE_UPW / (mask + 1) > 512) mask = 2 * mask + 1;
+      A.audit_wg_mask = mask;
     }
     const int64_t n_units = sc3_units(h, Bc);
     if (rows_per_tile * 4 > 0x7fffffffLL || n_units > 0x7fffffffLL) return fail(h, COPER_EUNSUPPORTED, "band mask beyond 2^31 units");

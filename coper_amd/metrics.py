@@ -110,6 +110,30 @@ def ranking_and_hits(model, results_dir, data_iterator_handle, name, session=Non
             _report_band_audit(float(aud[:1].view(np.float32)[0]), int(aud[1:2].view(np.uint32)[0]))
         return _finish(ranks, Q, results_dir, hits_to_compute, enable_write_to_file, return_ranks)
 
+    # a plain list of batches with CSR filters: the encoder needs the ids only, so it is launched as soon as THEY are
+    # concatenated, and the filters -- the bulk of the marshalling: concatenation, the canonical-order check, staging -- are
+    # put together on the host while the device encodes (coper_encode + coper_rank give coper_encode_rank's bits)
+    if not hasattr(data_iterator_handle, "as_single_batch") and not isinstance(data_iterator_handle, (list, tuple)):
+        data_iterator_handle = list(data_iterator_handle)          # (an iterator of batches: drained once, like metrics.py:38-60)
+    if ranker is None and isinstance(data_iterator_handle, (list, tuple)) and hasattr(model, "encode") and hasattr(model, "rank") \
+            and 0 < sum(len(b["e1"]) for b in data_iterator_handle) <= max_chunk \
+            and all("filt_indptr" in b for b in data_iterator_handle):
+        bs = [b for b in data_iterator_handle if len(b["e1"])]
+        e1 = np.concatenate([np.asarray(b["e1"], np.int64) for b in bs])
+        rel = np.concatenate([np.asarray(b["rel"], np.int64) for b in bs])
+        h = model.encode(e1, rel)                                          # asynchronous
+        e2 = np.concatenate([np.asarray(b["e2"], np.int64) for b in bs])
+        base = np.cumsum([0] + [int(np.asarray(b["filt_indptr"])[-1]) for b in bs])
+        ip = np.concatenate([np.zeros(1, np.int64)] + [np.asarray(b["filt_indptr"], np.int64)[1:] + o for b, o in zip(bs, base)])
+        ix = np.concatenate([np.asarray(b["filt_idx"], np.int64) for b in bs]) if base[-1] else np.zeros(0, np.int64)
+        ip, ix = canonical_csr(ip, ix)
+        r, _ = model.rank(h, e2, ip, ix, filt_nnz=len(ix), want_equal=False)
+        ranks = r.cpu().numpy()
+        Q = len(e1)
+        if getattr(model, "score_mode", None) == "bf16x3" and hasattr(model, "band_audit"):
+            _report_band_audit(*model.band_audit())
+        return _finish(ranks, Q, results_dir, hits_to_compute, enable_write_to_file, return_ranks)
+
     q = collect_batches(data_iterator_handle, device=getattr(model, "device", None))
     Q = len(q["e1"])
     ranks = []
