@@ -157,7 +157,11 @@ __device__ __forceinline__ int64_t tl_prep(const int64_t pb, const int64_t p_end
 template <int KS>
 __device__ __forceinline__ void tl_gather(const uint4* __restrict__ Ehi, const uint4* __restrict__ Elo, const int64_t my_erow, const int half,
                                           uint4 (&ah)[KS + 1], uint4 (&al)[KS + 1]) {
+#ifdef COPER_DBG_TL_NOGATHER   /* ablation (wrong results): every lane reads row 0 */
+  const int64_t ea = 0;
+#else
   const int64_t ea = my_erow >= 0 ? my_erow : 0;
+#endif
   const uint4* pa_h = Ehi + ea * (2 * KS) + half;
   const uint4* pa_l = Elo + ea * (2 * KS) + half;
 #pragma unroll

@@ -194,3 +194,52 @@ def test_host_batches_are_staged_through_one_pinned_buffer():
     t = m.stage_batch(big, big)
     assert int(t[0][0]) == 2 ** 33
     m.close()
+
+
+def test_band_audit_and_table_exponent_through_the_c_abi():
+    """coper_band_audit / coper_band_audit_post / coper_set_x3_ent_absmax as a foreign host binds them (include/coper_hip.h):
+    every count launch audited (band_audit_period = 1), the ratio read with a synchronisation and posted to pinned memory
+    without one; kappa squeezed to the point where the audit must speak up; the setter's refusal at prepare."""
+    from coper_amd import _lib
+    from coper_amd.models import ConvE
+    md = cdata.model_descriptors("fb15k237_cpg", num_ent=5000, num_rel=24)
+    p = cdata.synthetic_params(md, 3)
+    q = cdata.synthetic_queries(md, 1500, seed=9)
+
+    def model(**kw):
+        m = ConvE(md, device="cuda:0", score_mode="bf16x3", band_audit_period=1, **kw)
+        return m.load_parameters(p).prepare()
+
+    m = model()
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ratio, pairs = ctypes.c_float(-1.0), ctypes.c_int64(-1)
+    _lib.check(m._h, m._lib.coper_band_audit(m._h, 1, ctypes.byref(ratio), ctypes.byref(pairs), stream))      # reset
+    r1 = _encode_rank(m, q["e1"], q["rel"], q["e2"], q["filt_indptr"], q["filt_idx"], False)
+    pin = torch.zeros(2, dtype=torch.int32).pin_memory()
+    _lib.check(m._h, m._lib.coper_band_audit_post(m._h, 0, ctypes.c_void_p(pin.data_ptr()), stream))          # no reset, no sync
+    _lib.check(m._h, m._lib.coper_band_audit(m._h, 1, ctypes.byref(ratio), ctypes.byref(pairs), stream))      # synchronises
+    assert pairs.value > 0 and 0.0 < ratio.value <= 0.5, (ratio.value, pairs.value)
+    assert float(pin[:1].view(torch.float32)[0]) == ratio.value and int(pin[1]) == pairs.value
+    _lib.check(m._h, m._lib.coper_band_audit(m._h, 0, ctypes.byref(ratio), ctypes.byref(pairs), stream))
+    assert ratio.value == 0.0 and pairs.value == 0                                                          # the reset took
+    # a band 50x narrower than the library's: the audited error now exceeds what it allows, and the audit says so
+    m2 = model(rank_band_kappa=2e-8)
+    r2 = _encode_rank(m2, q["e1"], q["rel"], q["e2"], q["filt_indptr"], q["filt_idx"], False)
+    ratio2, pairs2 = m2.band_audit()
+    assert ratio2 > ratio.value and ratio2 > 1.0, ratio2
+    assert np.mean(r1 == r2) > 0.99          # (ranks barely move: the x3 logits are that close to the chain's)
+    # the f32 mode has no band: zeros from the read, ESTATE from the post
+    m3 = ConvE(md, device="cuda:0", score_mode="f32").load_parameters(p).prepare()
+    _lib.check(m3._h, m3._lib.coper_band_audit(m3._h, 1, ctypes.byref(ratio), ctypes.byref(pairs), stream))
+    assert ratio.value == 0.0 and pairs.value == 0
+    assert m3._lib.coper_band_audit_post(m3._h, 0, ctypes.c_void_p(pin.data_ptr()), stream) == 5
+    # table-wide maximum: accepted when it covers the rows, refused at prepare when it does not
+    assert m._lib.coper_set_x3_ent_absmax(m._h, ctypes.c_float(100.0)) == 0
+    _lib.check(m._h, m._lib.coper_prepare(m._h, stream))
+    r3 = _encode_rank(m, q["e1"], q["rel"], q["e2"], q["filt_indptr"], q["filt_idx"], False)
+    assert np.array_equal(r3, r1)            # another power of two on the planes, the same ranks
+    assert m._lib.coper_set_x3_ent_absmax(m._h, ctypes.c_float(1e-6)) == 0
+    assert m._lib.coper_prepare(m._h, stream) == 1 and b"x3_ent_absmax" in m._lib.coper_last_error(m._h)
+    assert m._lib.coper_set_x3_ent_absmax(m._h, ctypes.c_float(-1.0)) == 1
+    for x in (m, m2, m3):
+        x.close()
