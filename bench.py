@@ -113,8 +113,9 @@ def parse_args():
                          "costs the stream a few microseconds of pipeline drain; 1 = every step)")
     ap.add_argument("--topk", type=int, default=0,
                     help="entity mode: also select and exchange the per-shard top-k of the filtered rows (SURVEY 8(e) step 3)")
-    ap.add_argument("--h2d", choices=["kernel", "sdma"], default="kernel",
-                    help="how a pass's pinned int32 batch reaches the device: coper_widen_ids reading host memory (one launch) or a "
+    ap.add_argument("--h2d", choices=["overlap", "kernel", "sdma"], default="overlap",
+                    help="how a pass's pinned int32 batch reaches the device: read over PCIe by extra workgroups of the PREVIOUS pass's "
+                         "encoder launch (coper_stage_ids_next), by coper_widen_ids in front of the pass (one launch), or by a "
                          "copy-engine transfer followed by a widening pass")
     ap.add_argument("--launch-timeout", type=int, default=1200,
                     help="self-launched ranks (--gpus N from a plain shell) are stopped after this many seconds")
@@ -562,29 +563,43 @@ def main():
             assert int(np.max(q[k], initial=0)) < 2 ** 31
             pin[o:o + n].copy_(torch.as_tensor(np.asarray(q[k]).astype(np.int32)))
         stage32 = torch.empty_like(pin, device=device)
-        stage = torch.empty(pin.numel(), dtype=torch.int64, device=device)
-        views = {k: stage[o:o + n] for k, o, n in zip(keys, offs, sizes)}
+        # two staging arrays, used alternately: the pass that runs reads one while the NEXT pass's batch arrives in the other
+        stages = [torch.empty(pin.numel(), dtype=torch.int64, device=device) for _ in range(2)]
+        views2 = [{k: st[o:o + n] for k, o, n in zip(keys, offs, sizes)} for st in stages]
+        cur = [0]
+        primed = [False]
         ranks_dev = torch.empty(Q, dtype=torch.int32, device=device)
         out_host = torch.empty(Q, dtype=torch.int32).pin_memory()
         pcie_bytes = pin.numel() * 4 + Q * 4
 
         def pcie_step(i=0):
-            """H2D of the batch, the pass, D2H of its ranks: one stream, in order, passes back to back.  (A copy stream that
-            brings pass n + 1's batch in under pass n's kernels reaches the resident-input rate in tools/pipe_probe.py --
-            0.545 against 0.59 ms per pass -- but inside this program its passes stalled for 7 - 30 ms a few times per run,
-            with torch streams and with raw HIP calls alike; not understood, so not used for the number that is reported.)"""
-            if args.h2d == "kernel":
-                model.widen_ids(pin, out=stage)        # one launch reads the pinned int32 batch over PCIe and writes int64 (coper_widen_ids)
+            """One pass of the SURVEY 8(d) region: its batch in from pinned host memory, the pass, its ranks out to pinned host
+            memory; one stream.  --h2d overlap (default): the batch of pass n + 1 is read over PCIe by extra workgroups of pass
+            n's encoder launch (coper_stage_ids_next: they run on CUs the 237 relation tiles leave idle), so every pass still
+            moves one batch in and one set of ranks out, but the transfer no longer stands in front of the pass.  --h2d kernel:
+            coper_widen_ids in front of the pass (round 3's region); --h2d sdma: a copy-engine transfer and a widening pass.
+            (A copy STREAM reached the resident-input rate in tools/pipe_probe.py but stalled for 7 - 30 ms a few times per run
+            inside this program: not understood, not used.)"""
+            c = cur[0]
+            if args.h2d == "overlap":
+                if not primed[0]:                          # the very first pass brings its own batch in
+                    model.widen_ids(pin, out=stages[c])
+                    primed[0] = True
+                model.stage_next(pin, stages[1 - c])       # pass n + 1's batch: beside this pass's encoder launch
+            elif args.h2d == "kernel":
+                model.widen_ids(pin, out=stages[c])        # one launch reads the pinned int32 batch over PCIe and writes int64 (coper_widen_ids)
             else:
-                stage32.copy_(pin, non_blocking=True)  # copy engine, then a widening pass on the device
-                stage.copy_(stage32)
-            v = views
+                stage32.copy_(pin, non_blocking=True)      # copy engine, then a widening pass on the device
+                stages[c].copy_(stage32)
+            v = views2[c]
             r, _ = model.rank_pass(v["e1"], v["rel"], v["e2"], v["filt_indptr"], v["filt_idx"], filt_nnz=nnz, want_equal=False,
                                    out=ranks_dev)
-            if args.h2d == "kernel":
-                model.copy_out(r, out_host)            # posted writes to the pinned buffer, right behind the last kernel
-            else:
+            if args.h2d == "sdma":
                 out_host.copy_(r, non_blocking=True)
+            else:
+                model.copy_out(r, out_host)                # posted writes to the pinned buffer, right behind the last kernel
+            if args.h2d == "overlap":
+                cur[0] = 1 - c
             return r, None
 
         pcie_step = counted(pcie_step)
@@ -732,8 +747,8 @@ def main():
                 "score_mode": "f32 (v_mfma_f32_32x32x2_f32, exact)" if args.score_mode == "f32" else
                 "bf16x3 = the x3 mode (API name kept): fp16 split since round 3, 3 x v_mfma_f32_16x16x32_f16 (two K = 16 steps each) per "
                 "pair of products, ~2^-22 rel.; exact band decided by the fp32 chain", "prepare_ms": round(prepare_ms, 2),
-                "inputs": ("SURVEY 8(d) region: every pass brings its ids + CSR filters (int32 in pinned host memory, " + ("read over PCIe and widened by one launch of coper_widen_ids" if args.h2d == "kernel" else "one copy-engine H2D, widened on the device") + ") in and copies its int32 "
-                           "ranks back to pinned host memory (D2H), %d bytes per pass, inside the timed region; one stream, nothing overlapped"
+                "inputs": ("SURVEY 8(d) region: every pass brings a batch of ids + CSR filters (int32 in pinned host memory, " + ({"overlap": "the NEXT pass's batch, read over PCIe and widened by extra workgroups of this pass's encoder launch: coper_stage_ids_next", "kernel": "read over PCIe and widened by one launch of coper_widen_ids in front of the pass", "sdma": "one copy-engine H2D, widened on the device"}[args.h2d]) + ") in and copies its int32 "
+                           "ranks back to pinned host memory (D2H), %d bytes per pass, inside the timed region; one stream"
                            % pcie_bytes) if pcie_step is not None
                 else "ids + CSR filters resident in HBM before the timed region",
                 "pre_timed_passes": pre_timed,

@@ -77,6 +77,7 @@ PROTOTYPES = {
     "coper_reserve": (C.c_int, [_P, _I64, _I64, _P]),
     "coper_widen_ids": (C.c_int, [_P, _P, _I64, _P, _P]),
     "coper_copy_out_i32": (C.c_int, [_P, _P, _I64, _P, _P]),
+    "coper_stage_ids_next": (C.c_int, [_P, _P, _I64, _P]),
     "coper_gather_entities": (C.c_int, [_P, _P, _I64, _P, _P]),
     "coper_encode": (C.c_int, [_P, _P, _P, _I64, _P, _P, _P]),
     "coper_score_all": (C.c_int, [_P, _P, _I64, _P, _I64, _P]),

@@ -625,6 +625,13 @@ COPER_API int coper_widen_ids(coper_handle* h, const int32_t* src, int64_t n, in
   return launch_widen_ids(h, src, n, dst, (hipStream_t)stream);
 }
 
+COPER_API int coper_stage_ids_next(coper_handle* h, const int32_t* src, int64_t n, int64_t* dst) {
+  if (!h) return COPER_EINVAL;
+  if (n < 0 || (n > 0 && (!src || !dst))) return fail(h, COPER_EINVAL, "coper_stage_ids_next: bad argument");
+  h->stage_src = src; h->stage_n = n; h->stage_dst = dst;
+  return COPER_OK;
+}
+
 COPER_API int coper_gather_entities(coper_handle* h, const int64_t* ids, int64_t B, float* out, void* stream) {
   COPER_REQUIRE_PREPARED(h);
   if (B == 0) return COPER_OK;
@@ -671,6 +678,11 @@ static int encode_partials(coper_handle* h, const int64_t* e1, const int64_t* re
 #else
     const bool fused = dense_fused_supported(h, ksplit);
 #endif
+    if (!fused && h->stage_n > 0) {     // (a pending coper_stage_ids_next rides in the fused launch only)
+      const int64_t n = h->stage_n;
+      h->stage_n = 0;
+      if ((rc = launch_widen_ids(h, h->stage_src, n, h->stage_dst, s))) return rc;
+    }
     if (fused) {   // one launch serves every tile: conv, BN, ReLU and the dense layer (kernels_dense_fused_bf16.hip)
       ScopedKernelTimer t(h, "dense", s);
       if (finalized) *finalized = dense_fused_finalizes(h, ksplit, h_x3);
@@ -682,6 +694,11 @@ static int encode_partials(coper_handle* h, const int64_t* e1, const int64_t* re
       if ((rc = launch_dense_bf16(h, B, ksplit, false, s))) return rc;
     }
     return COPER_OK;
+  }
+  if (h->stage_n > 0) {
+    const int64_t n = h->stage_n;
+    h->stage_n = 0;
+    if ((rc = launch_widen_ids(h, h->stage_src, n, h->stage_dst, s))) return rc;
   }
   if ((rc = launch_conv(h, e1, rel, e1_rows, B, s))) return rc;
   return launch_dense(h, rel, B, tq, ksplit, h_out_f32_path, s);   // fp32 mode: finalize included

@@ -106,6 +106,9 @@ struct coper_handle {
   unsigned band_launches = 0;        // count launches since prepare (which of them the band audit rides on: kernels_score3_bf16.hip)
   int x3_ent_exp = 0;                // e_E: the entity planes hold E 2^e_E (split16.h; prepare)
   float x3_ent_absmax = 0.f;         //   the maximum it was chosen from (the shard's, or coper_config.x3_ent_absmax)
+  const int32_t* stage_src = nullptr;   // coper_stage_ids_next: a batch to bring in beside the next encoder launch (stage_n > 0: pending)
+  int64_t stage_n = 0;
+  int64_t* stage_dst = nullptr;
   void* fused_fin_dev = nullptr;     // FusedFinConst (kernels_dense_fused_bf16.hip): the fused encoder's finalize constants, in device memory
   const int32_t* fused_fin_perm = nullptr;   //   the workspace generation they were written for
   int32_t* w_exp = nullptr;          // [Rw] e_W per relation: the dense-weight planes hold W_r 2^e_W (split16.h; prepare)

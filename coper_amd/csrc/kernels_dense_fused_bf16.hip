@@ -66,6 +66,7 @@ struct FusedFinConst {
 struct FusedFin {
   float* h_out; const FusedFinConst* c;
 };
+constexpr int FUSED_STAGE_WGS = 16;     // workgroups of the staging role (512 threads, one 16-byte PCIe read each per round)
 
 // Roles.  A workgroup is 8 waves, two per SIMD: waves 0..3 are MATRIX waves (wave w owns feature blocks
 // fb = w, w+4, ...: weight fragments prefetched into its registers, accumulators, all the MFMAs), waves 4..7
@@ -425,8 +426,27 @@ __global__ __launch_bounds__(512) void k_dense_fused_bf16x3(const uint4* __restr
                                                             FusedConvArgs A, const int32_t* __restrict__ tiles,
                                                             const int32_t* __restrict__ n_tiles, int64_t cap_small,
                                                             int nfb, int64_t ks32n, int nslices, int64_t Bcap,
-                                                            int d_pad16, float* __restrict__ z_part, int n_big_cap, FusedFin Fn) {
+                                                            int d_pad16, float* __restrict__ z_part, int n_big_cap, FusedFin Fn,
+                                                            int n_tile_blocks, const int32_t* __restrict__ stage_src, int64_t stage_n,
+                                                            int64_t* __restrict__ stage_dst) {
   extern __shared__ uint4 fused_lds[];
+  // Staging role (coper_stage_ids_next): the workgroups behind the tile lists bring the NEXT pass's int32 batch in from pinned
+  // host memory (PCIe reads) and widen it to the int64 arrays the ABI takes, while the tiles stream their weights.  A pass has
+  // fewer relation tiles than the chip has CUs at the BASELINE shapes (237 of 256), so these land on CUs that would idle.
+  if ((int)blockIdx.x >= n_tile_blocks) {
+    if (blockIdx.y | blockIdx.z) return;
+    const int64_t nb = (int64_t)gridDim.x - n_tile_blocks, b = (int64_t)blockIdx.x - n_tile_blocks;
+    const bool vec = ((((uintptr_t)stage_src) | ((uintptr_t)stage_dst)) & 15) == 0;
+    const int64_t n4 = vec ? stage_n / 4 : 0;
+    for (int64_t i = b * 512 + threadIdx.x; i < n4; i += nb * 512) {
+      const int4 v = ((const int4*)stage_src)[i];
+      longlong2* o = (longlong2*)(stage_dst + 4 * i);
+      o[0] = make_longlong2(v.x, v.y);
+      o[1] = make_longlong2(v.z, v.w);
+    }
+    for (int64_t i = 4 * n4 + b * 512 + threadIdx.x; i < stage_n; i += nb * 512) stage_dst[i] = stage_src[i];
+    return;
+  }
   // blockIdx.x < n_big_cap: the list of 33..128-query tiles; above it: the list of <= 32-query tiles (one per
   // relation key at most) -- every tile of the batch is served by this one launch
   int tile = blockIdx.x;
@@ -547,9 +567,14 @@ static void dense_fused_launch(coper_handle* h, const int64_t* e1, const int64_t
     (void)hipFuncSetAttribute((const void*)k_dense_fused_bf16x3<NFB, WNT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done |= bit;
   }
-  hipLaunchKernelGGL((k_dense_fused_bf16x3<NFB, WNT>), dim3((unsigned)(n_big_max + n_small_max), (unsigned)nslices, (unsigned)zgroups), dim3(512),
+  // a pending staging job (coper_stage_ids_next) rides in this launch: FUSED_STAGE_WGS more workgroups
+  const int n_tile_blocks = (int)(n_big_max + n_small_max);
+  const int n_stage = h->stage_n > 0 ? FUSED_STAGE_WGS : 0;
+  hipLaunchKernelGGL((k_dense_fused_bf16x3<NFB, WNT>), dim3((unsigned)(n_tile_blocks + n_stage), (unsigned)nslices, (unsigned)zgroups), dim3(512),
                      lds, s, (const uint4*)h->Wf16_hi, (const uint4*)h->Wf16_lo, A, h->tiles, h->n_tiles, cap_small, dm.nfb,
-                     dm.F_pad / 32, nslices, h->ws_queries, dm.d_pad16, h->z_part, (int)n_big_max, Fn);
+                     dm.F_pad / 32, nslices, h->ws_queries, dm.d_pad16, h->z_part, (int)n_big_max, Fn, n_tile_blocks, h->stage_src,
+                     h->stage_n, h->stage_dst);
+  h->stage_n = 0;
 }
 
 // the constant part of FusedFin, (re)written when the workspace or the parameters move (ensure_workspace / prepare)

@@ -230,6 +230,17 @@ class ConvE(object):
         _lib.check(self._h, self._lib.coper_widen_ids(self._h, C.c_void_p(src.data_ptr()), n, _ptr(out), self._stream()))
         return out
 
+    def stage_next(self, src: torch.Tensor, out: torch.Tensor):
+        """coper_stage_ids_next: the pinned int32 batch `src` is brought in and widened into `out` (int64, device) BESIDE the
+        encoder launch of the next encode / rank_pass call on this model -- the staging of pass n + 1 under pass n's kernels.
+        `out` must not be a buffer that call reads."""
+        if src.dtype != torch.int32 or not src.is_contiguous() or (src.device.type == "cpu" and not src.is_pinned()):
+            raise ValueError("stage_next: a contiguous int32 tensor, pinned when on the host")
+        if out.dtype != torch.int64 or out.numel() != src.numel() or not out.is_contiguous() or out.device != self.device:
+            raise ValueError("stage_next: out must be a contiguous int64 tensor of %d elements on %s" % (src.numel(), self.device))
+        self._stage_keep = (src, out)      # (the job is carried out later: keep both alive)
+        _lib.check(self._h, self._lib.coper_stage_ids_next(self._h, C.c_void_p(src.data_ptr()), src.numel(), _ptr(out)))
+
     def stage_batch(self, *arrays):
         """Host (NumPy) id arrays of one batch -> int64 tensors on the device through ONE pinned int32 buffer and one launch of
         coper_widen_ids (instead of one pageable H2D copy per array).  Arrays whose ids do not fit int32, and tensors, take

@@ -163,6 +163,14 @@ COPER_API int coper_reserve(coper_handle* h, int64_t max_queries, int64_t max_fi
  * engine transfer plus a widening pass.  No handle state is touched. */
 COPER_API int coper_widen_ids(coper_handle* h, const int32_t* src, int64_t n, int64_t* dst, void* stream);
 
+/* The same staging, overlapped: registers (src, n, dst) as a job the NEXT coper_encode / coper_encode_rank on this handle carries
+ * out beside its encoder launch -- extra workgroups of that launch read the pinned batch over PCIe while the relation tiles
+ * stream their weights (fewer tiles than CUs at the BASELINE shapes: they run on CUs that would idle), so the batch of pass
+ * n + 1 arrives under pass n's kernels without a second stream.  dst must not be an array pass n itself reads (two staging
+ * buffers, used alternately); configurations the fused encoder does not serve run the job as a launch of its own at the same
+ * point.  Nothing is queued on a stream by this call; a later call replaces a job that has not run. */
+COPER_API int coper_stage_ids_next(coper_handle* h, const int32_t* src, int64_t n, int64_t* dst);
+
 /* The way back: n int32 values (the ranks of a pass) from device memory to `dst`, which may be PINNED, device-mapped HOST
  * memory -- the kernel posts the writes over PCIe right behind the pass's last kernel (a copy-engine D2H on the same stream
  * starts ~12 us later on this runtime).  The host reads dst after synchronising with the stream. */
