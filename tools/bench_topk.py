@@ -20,7 +20,7 @@ def run(name, Q, shard=None, big=False):
     q = cdata.synthetic_queries(md, Q, seed=0)
     if shard:
         h = torch.randn(Q, md["ent_emb_size"], device="cuda").abs() * 0.3
-        tgt = torch.zeros(Q, device="cuda")
+        tgt = torch.zeros((2, Q), device="cuda")
     else:
         h = m.encode(q["e1"], q["rel"])
         tgt = m.target_scores(h, q["e2"])
