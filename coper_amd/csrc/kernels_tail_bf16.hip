@@ -1,32 +1,24 @@
-// k_finalize_targets_filter_bf16x3 -- everything of a ranking pass between the dense layer and the count kernel, and the
-// sparse filter correction that used to follow it, in ONE launch (coper_encode_rank, bf16x3, ranks only).
+// k_finalize_targets_filter_bf16x3 -- everything of a ranking pass between the encoder and the count kernel, and the sparse
+// filter correction that used to follow it, in ONE launch (coper_encode_rank, bf16x3, ranks only).
 //
-// Before: k_dense_finalize_pack_q (h -> bf16 planes, 22 us) -> k_pair_bf16x3 mode 0 (targets, 15 us) -> count ->
+// Before (round 2): k_dense_finalize_pack_q (h -> 16-bit planes, 22 us) -> k_pair_bf16x3 mode 0 (targets, 15 us) -> count ->
 // k_pair_bf16x3 mode 2 (filter correction, 22 us): three small launches and their gaps were 12 % of an FB15k-237-shaped
-// pass.  Now one workgroup (4 waves) owns a block of 32 queries from the K-slice partial sums to their final rank offsets
-// (the waves split the finalize by k-step, exchange the fragments through LDS, and deal the filter tiles among themselves):
-//   1. finalize: sum the K slices in slice order + dense bias + folded FCBN + ReLU (the arithmetic of
-//      k_dense_finalize_pack_q, bit for bit), split into hi / lo bf16.  Lane l computes piece (k-step ks, half l >> 5) of
-//      query l & 31 -- which IS lane l's part of the block's B-operand fragment of k-step ks: the KS fragments stay in the
-//      wave's registers and are written once to the fragment planes the count kernel reads.
+// pass.  Now one workgroup (4 waves) owns a block of 32 queries from their fp32 h rows to their final rank offsets:
+//   1. fragments: the fp32 rows (written by the fused encoder's epilogue, or by k_finalize_h_publish below when the dense
+//      layer ran in several K slices) are multiplied by 2^e_h -- the batch's exponent, reduced here from the per-block maxima
+//      the producer left in x3m (bf16x3_chain.h) -- and split into hi / lo fp16.  Lane l handles piece (k-step ks, half l >> 5)
+//      of query l & 31, which IS lane l's part of the block's B-operand fragment of k-step ks: the fragments go to LDS (the
+//      tiles read them from there) and, once, to the f3 image the count kernel reads.
 //   2. targets: logit(q_i, e2[q_i]) = the diagonal of the 32 x 32 tile whose A rows are the gathered entity rows of e2 and
-//      whose B operand are those fragments -- the MFMA sequence of every other bf16x3 kernel, so the same bits.
+//      whose B operand are those fragments -- the MFMA sequence of every other bf16x3 kernel, so the same bits.  tau_q and the
+//      band tband[q] = {t - tau, t + tau} (x3_band_tau), in the accumulators' units.
 //   3. filter correction: the CSR entries of these 32 queries are contiguous; 32 entries at a time their entity rows are
-//      the A rows, the tile against the SAME resident B fragments holds logit(f_i, q_j) for every local query j, and
-//      entry i reads column j = its own query (one cross-lane read per accumulator register).  What the count kernel will
-//      count for a known answer (logit > target) is subtracted in advance: ranks[q] = 1 - #(such entries); the count kernel
-//      then adds to it.  No atomics: the wave owns every entry of its queries (the reference: pred[e2_multi == 1] = -inf;
-//      pred[e2] = target, metrics.py:45-46).
-//
-// Round 3: the k-steps run in the pair order of bf16x3_chain.h; the query fragments go to the count kernel's f3 image; the
-// kernel also forms the exact band of every query (tau from |h_q|, k_score_count3_bf16x3's header): tband[q] = {t - tau,
-// t + tau}, and a known answer is taken back only when its logit lies ABOVE the band (what the count kernel counts).
-//
-// Round 4: the split is scale-invariant (split16.h) -- the query planes hold h 2^e_h with e_h chosen from the largest |h|
-// element of the BATCH, which no workgroup of this kernel can know while it finalizes its own 32 queries.  So the finalize
-// moved into a launch of its own, k_finalize_h_publish (sum of the K slices + dense bias + folded FCBN + ReLU -> the fp32 rows
-// the exact band re-scores from, the batch maximum folded into the handle's x3s words, published by the last block), and
-// phase 1 here reads those rows -- 16 MB instead of the 17 - 34 MB of partial sums -- scales and splits them.
+//      the A rows, the tile against the SAME B fragments holds logit(f_i, q_j) for every local query j, and entry i reads
+//      column j = its own query (one cross-lane read per accumulator register).  What the count kernel will count for a
+//      known answer (logit ABOVE the band) is subtracted in advance: ranks[q] = 1 - #(such entries); the count kernel then
+//      adds to it (the reference: pred[e2_multi == 1] = -inf; pred[e2] = target, metrics.py:45-46).
+// Round 4: every wave requests the rows of its first tile (targets or CSR entries) BEFORE step 1 -- they do not depend on the
+// fragments -- and the ids of its next tile a tile ahead (tl_prep / tl_gather / tl_mma below).
 #include "bf16x3_chain.h"
 #include "coper_internal.h"
 #include "conv_fold.h"
