@@ -67,6 +67,7 @@ struct SC3 {
   uint4 a0[2][PD][MB], a1[2][PD][MB];                     // entity fragments: two sets of PD steps, [m2]; reg 0 / reg 1 of the step
   uint4 q0[4], q1[4];                                     // query fragments of four consecutive regions (ring)
   f32x4 biasv[2][MB];                                     // [M][m2]
+  f32x4 braw[2][MB];                                      // (COPER_SC3_ASM_LOADS) pred_bias as loaded: scaled into biasv at the top of the half-row
   float thi[NB], tlo[NB];
   int cg[NB];
   unsigned mk[2 * MB], mg[2 * MB];                        // (logit >= t_lo) / (logit > t_hi): word MB M + (V >> 5), value V at bit 31 - (V & 31)
@@ -108,7 +109,57 @@ struct SC3Ptrs {
   int voff;                    // lane * 16
   const uint4* hl;       // the query tile in LDS, lane included
   const uint4 __attribute__((address_space(3)))* hl_hi;    // ... its part beyond 64 KiB (an LDS pointer the compiler cannot fold back)
+  unsigned lds[3];             // (COPER_SC3_ASM_LOADS) LDS byte address of the lane's slot in register 0, 4096, 8192 of the tile
 };
+
+#ifdef COPER_SC3_ASM_LOADS
+// The loads of a region written as instructions (sc3_region_asm_ld.inc; tools/microbench/mfma_load_mix.hip: behind the region's
+// last MFMAs they cost the matrix pipe 3 %, in front of the region -- where the compiler puts them -- 21 %).  The compiler does
+// not see them, so it does not wait for them either: every region starts with an s_waitcnt written here.  The counters count in
+// order and every load of the row loop is one of these (pred_bias included: sc3_load_bias), so "at most n younger loads
+// outstanding" is exact; anything else the compiler issues in between (mask and maxima stores) only makes a wait stricter.
+//   LDS:    region R reads the query fragments of region R + SC3_LD behind its last MFMAs -> at its top the reads of regions
+//           R - SC3_LD + 1 .. R - 1 may be outstanding: lgkmcnt(2 (SC3_LD - 1));
+//   global: the eight regions of step s load the entity fragments of step s + PD -> at the top of a step the loads of steps
+//           s - PD + 1 .. s - 1 may be outstanding: vmcnt(8 (PD - 1)), first region of the step only.
+// s_waitcnt's immediate (gfx9 encoding): vmcnt [3:0] and [15:14], expcnt [6:4] (7: no wait), lgkmcnt [11:8]
+#define SC3_WAITENC(vm, lg) (((vm) & 15) | (7 << 4) | (((lg) & 15) << 8) | ((((vm) >> 4) & 3) << 14))
+template <int NP, int TAIL, int PD, int M, int s, int b>
+struct SC3Ld {
+  static constexpr int MB = SC3_MB, NS = NP + TAIL, NR = NS * 8, G = (NS + PD - 1) / PD;
+  static_assert(MB == 4, "one entity-fragment load per region: 2 MB = 8 registers per step");
+  static constexpr int PA = (G & 1) ? M : 0, PA_NEXT = (PA + G) & 1;                   // (as in sc3_region)
+  static constexpr int m2 = b >> 1, wh = b & 1, tk = s + PD, u = tk - NS;
+  static constexpr bool this_block = tk < NS;                                          // else: step u of the next block ...
+  static constexpr bool next_row = !this_block && M == 1;                              // ... which is block 0 of the next row
+  static constexpr int set = this_block ? ((PA + tk / PD) & 1) : PA_NEXT, slot = this_block ? tk % PD : u;
+  static constexpr int BLKB = MB * NS * 2 * 1024;                                      // bytes of one entity block's registers
+  static constexpr int goff = this_block ? M * BLKB + ((m2 * NS + tk) * 2 + wh) * 1024 : (M == 0 ? BLKB : 0) + ((m2 * NS + u) * 2 + wh) * 1024;
+  static constexpr int glit = goff & ~4095, gimm = goff & 4095;                        // page (a v_add_u32 literal), 12-bit immediate
+  static constexpr int R = s * 8 + b, R2 = (R + SC3_LD) % NR, s2 = R2 / 8, b2 = R2 % 8, ring = (R + SC3_LD) & 3;
+  static constexpr int i0 = ((b2 * NS + s2) * 2) * 64;                                 // register 0 of region R2 (register 1: + 64)
+  static constexpr int lbase = i0 / 4096, lo0 = (i0 % 4096) * 16, lo1 = lo0 + 1024;    // (a ds_read offset holds 16 bits)
+  static_assert(lbase < 3 && lo1 < 65536, "three LDS bases");
+  static constexpr int wc = SC3_WAITENC(b == 0 ? 8 * (PD - 1) : 63, 2 * (SC3_LD - 1));
+};
+typedef unsigned sc3_u4w __attribute__((ext_vector_type(4)));
+#define SC3_QW(x) (*(sc3_u4w*)&(x))
+template <class L, class ST>
+__device__ __forceinline__ uint4& sc3_ld_gd(ST& S) {
+  if constexpr (L::wh == 0) return S.a0[L::set][L::slot][L::m2];
+  else return S.a1[L::set][L::slot][L::m2];
+}
+// the loads of a region in front of it (regions the compiler schedules: step 0)
+template <class L, class ST>
+__device__ __forceinline__ void sc3_ld_issue(ST& S, const SC3Ptrs& X) {
+  unsigned gt;
+  const char* GS = L::next_row ? X.rn.p : X.ra.p;
+  asm volatile("v_add_u32 %1, %3, %2\n\tglobal_load_dwordx4 %0, %1, %4 offset:%5"
+               : "=&v"(SC3_QW(sc3_ld_gd<L>(S))), "=&v"(gt) : "v"(X.voff), "n"(L::glit), "s"(GS), "n"(L::gimm));
+  asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"
+               : "=&v"(SC3_QW(S.q0[L::ring])), "=&v"(SC3_QW(S.q1[L::ring])) : "v"(X.lds[L::lbase]), "n"(L::lo0), "n"(L::lo1));
+}
+#endif
 
 // what follows the comparisons of value V: every 32 values the word pair gives the counts, every 8 (top-k launches) the block
 // maximum is reduced across lanes and stored, the row's last value stores the band words that carry a bit
@@ -247,6 +298,26 @@ template <int NP, int TAIL, int PD, bool GM, int M>
 __device__ __forceinline__ void sc3_load_bias(SC3<NP, TAIL, PD, GM>& S, const float* __restrict__ bias_pad, const int64_t blk, const int lane) {
   sc3_load_bias_<NP, TAIL, PD, GM, M>(S, (const float4*)(bias_pad + blk * (16 * SC3_MB) + 4 * (lane >> 4)), std::make_integer_sequence<int, SC3_MB>{});
 }
+#ifdef COPER_SC3_ASM_LOADS
+// the same rows as loaded (no scale yet: the values arrive later): START = the tile's first row, loads the compiler sees
+template <int NP, int TAIL, int PD, bool GM, int M, bool START>
+__device__ __forceinline__ void sc3_load_braw(SC3<NP, TAIL, PD, GM>& S, const float* __restrict__ bias_pad, const int64_t blk, const int lane) {
+  static_assert(SC3_MB == 4, "four quads");
+  const f32x4* bp = (const f32x4*)(bias_pad + blk * (16 * SC3_MB) + 4 * (lane >> 4));
+  if constexpr (START) {
+    S.braw[M][0] = bp[0]; S.braw[M][1] = bp[4]; S.braw[M][2] = bp[8]; S.braw[M][3] = bp[12];
+  } else {
+    asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:64\n\t"
+                 "global_load_dwordx4 %2, %4, off offset:128\n\tglobal_load_dwordx4 %3, %4, off offset:192"
+                 : "=&v"(S.braw[M][0]), "=&v"(S.braw[M][1]), "=&v"(S.braw[M][2]), "=&v"(S.braw[M][3]) : "v"(bp));
+  }
+}
+template <int NP, int TAIL, int PD, bool GM, int M, int... m2>
+__device__ __forceinline__ void sc3_scale_bias(SC3<NP, TAIL, PD, GM>& S, std::integer_sequence<int, m2...>) {
+  ((S.biasv[M][m2] = f32x4{x3_scale(S.braw[M][m2][0], S.sexp), x3_scale(S.braw[M][m2][1], S.sexp), x3_scale(S.braw[M][m2][2], S.sexp),
+                           x3_scale(S.braw[M][m2][3], S.sexp)}), ...);
+}
+#endif
 
 // the instructions of region (step s, column block b) on the MB accumulator chains of block M, chains interleaved
 template <int NP, int TAIL, int PD, bool GM, int M, int s, int b, int sa, int sl, int rs, bool tail, int... m2>
@@ -281,7 +352,7 @@ __device__ __forceinline__ void sc3_slot_pieces(SC3<NP, TAIL, PD, GM>& S, float*
 // four more operands the allocator spilled 174 registers), 1 - 3 values that share one mask word; top-k launches fold their
 // block maxima in (sc3_region_asm_gm.inc).  Everything else takes the form above.
 template <int NP, int TAIL, int PD, bool GM, int M, int s, int b, int sa, int sl, int rs, bool tail, int v0, int cnt>
-__device__ __forceinline__ void sc3_region_asm(SC3<NP, TAIL, PD, GM>& S, const int lane, const bool store_ok, float* __restrict__ gm_row,
+__device__ __forceinline__ void sc3_region_asm(SC3<NP, TAIL, PD, GM>& S, const SC3Ptrs& X, const int lane, const bool store_ok, float* __restrict__ gm_row,
                                                const int64_t gm_col, uint4* __restrict__ mask_row) {
   constexpr int MB = SC3_MB;
   static_assert(MB == 4 && cnt >= 1 && cnt <= 3, "sc3_region_asm: shape not covered");
@@ -295,6 +366,22 @@ __device__ __forceinline__ void sc3_region_asm(SC3<NP, TAIL, PD, GM>& S, const i
   float sc;
   typedef unsigned sc3_u4 __attribute__((ext_vector_type(4)));     // (a HIP uint4 is a struct: not a register operand)
 #define SC3_Q(x) (*(const sc3_u4*)&(x))
+#ifdef COPER_SC3_ASM_LOADS
+  typedef SC3Ld<NP, TAIL, PD, M, s, b> L;
+  uint4& GD = sc3_ld_gd<L>(S);
+  uint4& QD0 = S.q0[L::ring];
+  uint4& QD1 = S.q1[L::ring];
+  const char* GS = L::next_row ? X.rn.p : X.ra.p;
+  const unsigned LA = X.lds[L::lbase];
+  unsigned gt;
+  if constexpr (GM) {
+    constexpr int vm = v0 & 7;
+    static_assert(!(cnt == 3 && vm == 7), "the maximum of a group is stored after the block: it must not hold the next group's first pair");
+#include "sc3_region_asm_gm_ld.inc"
+  } else {
+#include "sc3_region_asm_ld.inc"
+  }
+#else
   if constexpr (GM) {       // top-k launches: block maxima folded in (even values wait in S.px, odd ones fold the pair into S.mx)
     constexpr int vm = v0 & 7;
     static_assert(!(cnt == 3 && vm == 7), "the maximum of a group is stored after the block: it must not hold the next group's first pair");
@@ -302,6 +389,7 @@ __device__ __forceinline__ void sc3_region_asm(SC3<NP, TAIL, PD, GM>& S, const i
   } else {
 #include "sc3_region_asm.inc"
   }
+#endif
 #undef SC3_Q
   sc3_value_tail<NP, TAIL, PD, GM, 1 - M, v0>(S, lane, store_ok, gm_row, gm_col, mask_row);
   if constexpr (cnt > 1) sc3_value_tail<NP, TAIL, PD, GM, 1 - M, v0 + 1>(S, lane, store_ok, gm_row, gm_col, mask_row);
@@ -352,6 +440,37 @@ __device__ __forceinline__ void sc3_region(SC3<NP, TAIL, PD, GM>& S, const SC3Pt
   constexpr int PA = (G & 1) ? M : 0;        // entity-fragment set of this block's step 0
   constexpr int PA_NEXT = (PA + G) & 1;      // ... of the next block's step 0
   constexpr int sa = (PA + s / PD) & 1, sl = s % PD, tk = s + PD;
+#ifdef COPER_SC3_ASM_LOADS
+  {
+    typedef SC3Ld<NP, TAIL, PD, M, s, b> L;
+    constexpr int R = s * 8 + b, rs = R & 3;
+    constexpr int c0 = b * CH / 8, c1 = (b + 1) * CH / 8, v0 = s * CH + c0;
+    constexpr int cnt = v0 >= NV ? 0 : (v0 + (c1 - c0) > NV ? NV - v0 : c1 - c0);
+    if constexpr (MB == 4 && s > 0 && cnt >= 1 && cnt <= 3 && (v0 >> 5) == ((v0 + cnt - 1) >> 5) && !(GM && cnt == 3 && (v0 & 7) == 7)) {
+      sc3_region_asm<NP, TAIL, PD, GM, M, s, b, sa, sl, rs, tail, v0, cnt>(S, X, lane, prev_valid, gm_row, gm_col, mask_row);
+      SC3_FENCE();
+      return;
+    }
+    // a region the compiler schedules (step 0, whose chains start from pred_bias): the wait -- tied to the registers it is for,
+    // so that nothing that reads them moves above it -- then the loads in front
+#define SC3_T(x) "+v"(SC3_QW(x))
+    asm volatile("s_waitcnt %10"
+                 : SC3_T(S.q0[rs]), SC3_T(S.q1[rs]), SC3_T(S.a0[sa][sl][0]), SC3_T(S.a0[sa][sl][1]), SC3_T(S.a0[sa][sl][2]), SC3_T(S.a0[sa][sl][3]),
+                   SC3_T(S.a1[sa][sl][0]), SC3_T(S.a1[sa][sl][1]), SC3_T(S.a1[sa][sl][2]), SC3_T(S.a1[sa][sl][3])
+                 : "n"(L::wc));
+#undef SC3_T
+    if constexpr (R == 0) {     // pred_bias of this half-row: loaded a row ago, behind the same wait (volatile asm keeps its place)
+      asm volatile("" : "+v"(S.braw[M][0]), "+v"(S.braw[M][1]), "+v"(S.braw[M][2]), "+v"(S.braw[M][3]));
+      sc3_scale_bias<NP, TAIL, PD, GM, M>(S, std::make_integer_sequence<int, MB>{});
+    }
+    sc3_ld_issue<L>(S, X);
+    SC3_FENCE();
+    sc3_mfmas<NP, TAIL, PD, GM, M, s, b, sa, sl, rs, tail>(S, std::make_integer_sequence<int, MB>{});
+    if constexpr (cnt > 0) sc3_values<NP, TAIL, PD, GM, 1 - M, v0>(S, lane, prev_valid, gm_row, gm_col, mask_row, std::make_integer_sequence<int, cnt>{});
+    SC3_FENCE();
+    return;
+  }
+#endif
 #ifndef COPER_DBG_SC3_SKIP_GL
   if constexpr (b < 2 * MB) {
     constexpr int m2 = b >> 1, wh = b & 1;
@@ -409,7 +528,7 @@ __device__ __forceinline__ void sc3_region(SC3<NP, TAIL, PD, GM>& S, const SC3Pt
 #ifndef COPER_SC3_INTERLEAVED     /* the shipped form: the region's MFMAs, then whole values */
 #if !defined(COPER_SC3_NO_ASM_REGION) && !defined(COPER_DBG_SC3_NO_EPI) && !defined(COPER_DBG_SC3_NO_BAND) && !defined(COPER_DBG_SC3_EPI_R0) && !defined(COPER_SPLIT_BF16)
   if constexpr (MB == 4 && s > 0 && cnt >= 1 && cnt <= 3 && (v0 >> 5) == ((v0 + cnt - 1) >> 5) && !(GM && cnt == 3 && (v0 & 7) == 7)) {
-    sc3_region_asm<NP, TAIL, PD, GM, M, s, b, sa, sl, rs, tail, v0, cnt>(S, lane, prev_valid, gm_row, gm_col, mask_row);
+    sc3_region_asm<NP, TAIL, PD, GM, M, s, b, sa, sl, rs, tail, v0, cnt>(S, X, lane, prev_valid, gm_row, gm_col, mask_row);
     SC3_FENCE();
     return;
   }
@@ -450,7 +569,11 @@ __device__ __forceinline__ void sc3_step(SC3<NP, TAIL, PD, GM>& S, const SC3Ptrs
   sc3_region<NP, TAIL, PD, GM, M, s, 7>(S, X, lane, prev_valid, gm_row, gm_col, mask_row);
   if constexpr (s == 0) {
     // pred_bias of this block in the NEXT row: the chains have consumed biasv[M] (program order)
+#ifdef COPER_SC3_ASM_LOADS
+    sc3_load_braw<NP, TAIL, PD, GM, M, false>(S, bias_pad, bias_blk_next, lane);
+#else
     sc3_load_bias<NP, TAIL, PD, GM, M>(S, bias_pad, bias_blk_next, lane);
+#endif
     SC3_FENCE();
   }
 }
@@ -555,11 +678,17 @@ __global__ __launch_bounds__(256, 1) void k_score_count3_bf16x3(const uint4* __r
   constexpr int64_t BLK_REGS = MB * NS * 2;   // f3 registers of one entity block (MB 16-row blocks)
   constexpr int64_t MW = 64 * (MB / 2);       // 16-byte mask pieces of one row of a wave
 
+  // (Round 4 tried carrying (tile, row) along instead of these four 64-bit divisions per row -- some 100 instructions of a wave
+  // that issues one every four cycles: the two loop-carried values pushed the allocator into scratch (100 bytes, vmcnt(0) waits
+  // inside the loop) and the launch from 0.2775 to 0.3097 ms.  The divisions stay.)
   for (int64_t r = r_begin; r < r_end; ++r) {
     const int64_t tile = r / rows_per_tile;
     const int64_t row = r % rows_per_tile;
     const int64_t eb = (row * 4 + wave) * 2;
     if (tile != cur_tile) {   // workgroup-uniform: (re)start of the pipeline
+#ifdef COPER_SC3_ASM_LOADS
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the last row's look-ahead loads (the compiler does not know them)
+#endif
       __syncthreads();
       const uint4* sh = Hf3 + tile * (TILE_REGS * 64);
       {
@@ -594,8 +723,13 @@ __global__ __launch_bounds__(256, 1) void k_score_count3_bf16x3(const uint4* __r
       for (int i = 0; i < 2 * MB; ++i) { S.mk[i] = 0u; S.mg[i] = 0u; }
       // entity fragments of block 0's first PD steps, pred_bias of both blocks, "previous block" accumulators that count nothing
       sc3_prologue_a<NP, TAIL, PD, GM>(S, Ef3 + eb * BLK_REGS * 64 + lane, std::make_integer_sequence<int, PD>{});
+#ifdef COPER_SC3_ASM_LOADS
+      sc3_load_braw<NP, TAIL, PD, GM, 0, true>(S, bias_pad, eb, lane);
+      sc3_load_braw<NP, TAIL, PD, GM, 1, true>(S, bias_pad, eb + 1, lane);
+#else
       sc3_load_bias<NP, TAIL, PD, GM, 0>(S, bias_pad, eb, lane);
       sc3_load_bias<NP, TAIL, PD, GM, 1>(S, bias_pad, eb + 1, lane);
+#endif
 #pragma unroll
       for (int b = 0; b < NB; ++b)
 #pragma unroll
@@ -616,14 +750,27 @@ __global__ __launch_bounds__(256, 1) void k_score_count3_bf16x3(const uint4* __r
     const int64_t eb_next = has_next ? (((r + 1) % rows_per_tile) * 4 + wave) * 2 : eb;     // past the end: re-read this row's blocks
     const int64_t gm_col = cur_tile * 128;
     SC3Ptrs X;
+#ifdef COPER_SC3_ASM_LOADS
+    {   // the rows' bases as scalar registers whatever the compiler thinks of their uniformity (the loads' "s" operands)
+      const uint64_t pa = (uint64_t)(Ef3 + eb * BLK_REGS * 64), pn = (uint64_t)(Ef3 + eb_next * BLK_REGS * 64);
+      X.ra = sc3_make_rsrc((const void*)(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(pa >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)pa)));
+      X.rn = sc3_make_rsrc((const void*)(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(pn >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)pn)));
+    }
+#else
     X.ra = sc3_make_rsrc(Ef3 + eb * BLK_REGS * 64);
     X.rn = sc3_make_rsrc(Ef3 + eb_next * BLK_REGS * 64);
+#endif
     X.voff = lane * 16;
     X.hl = hl3 + lane;
     {
       unsigned hi_off = (unsigned)(uintptr_t)((const uint4 __attribute__((address_space(3)))*)(hl3 + lane + 4096));
       asm volatile("" : "+v"(hi_off));     // opaque: otherwise the second base is re-derived from the first with an add per read
       X.hl_hi = (const uint4 __attribute__((address_space(3)))*)(uintptr_t)hi_off;
+#ifdef COPER_SC3_ASM_LOADS
+      X.lds[0] = hi_off - 65536u; X.lds[1] = hi_off; X.lds[2] = hi_off + 65536u;
+      asm volatile("" : "+v"(X.lds[0]));         // (opaque, as hi_off: a base is a register, not an add in front of every block)
+      if constexpr (TILE_REGS > 128) asm volatile("" : "+v"(X.lds[2]));
+#endif
     }
     uint4* mask_cur = mask + ((cur_tile * rows_per_tile + row) * 4 + wave) * MW;
     // block 0 (epilogue of the previous row's block 1 beside it: its last value completes that row's mask), then block 1
