@@ -359,7 +359,7 @@ COPER_API void coper_destroy(coper_handle* h) {
   dev_free(&h->tiles); dev_free(&h->n_tiles); dev_free(&h->blk_off); dev_free(&h->x_sorted); dev_free(&h->z_part);
   dev_free(&h->tgt_ws); dev_free(&h->h_ws); dev_free(&h->cnt_ws); dev_free(&h->hfrag_ws); dev_free(&h->logits_ws); dev_free(&h->row_of_ws);
   dev_free(&h->gmax_ws); dev_free(&h->cand_blk_ws); dev_free(&h->cand_val_ws); dev_free(&h->cand_q_ws); dev_free(&h->cand_tau_ws); dev_free(&h->cand_sorted_ws); dev_free(&h->blk_cnt_ws); dev_free(&h->blk_off_ws);
-  dev_free((char**)&h->Wf16_hi); dev_free((char**)&h->Wf16_lo);
+  dev_free((char**)&h->Wf16_hi); dev_free((char**)&h->Wf16_lo); dev_free((char**)&h->Wf8_lo);
   dev_free((char**)&h->Ef16_hi); dev_free((char**)&h->Ef16_lo); dev_free((char**)&h->hfrag16_hi); dev_free((char**)&h->hfrag16_lo);
   dev_free((char**)&h->Erm16_hi); dev_free((char**)&h->Erm16_lo); dev_free((char**)&h->hrm16_hi); dev_free((char**)&h->hrm16_lo);
   dev_free((char**)&h->Ef3); dev_free((char**)&h->hf3_ws); dev_free((char**)&h->mask_ws); dev_free(&h->band_consts); dev_free(&h->tband_ws); dev_free(&h->x3s); dev_free(&h->x3m); dev_free(&h->w_exp); dev_free((char**)&h->fused_fin_dev);
@@ -552,12 +552,16 @@ COPER_API int coper_prepare(coper_handle* h, void* stream) {
   h->band_launches = 0;
   if (h->enc_bf16) {
     size_t plane = (size_t)h->Rw * dm.nfb * (dm.F_pad / 32) * 64 * 16;
-    dev_free((char**)&h->Wf16_hi); dev_free((char**)&h->Wf16_lo);
+    dev_free((char**)&h->Wf16_hi); dev_free((char**)&h->Wf16_lo); dev_free((char**)&h->Wf8_lo);
     if (tracked_malloc(&h->Wf16_hi, plane) != hipSuccess || tracked_malloc(&h->Wf16_lo, plane) != hipSuccess)
       return fail(h, COPER_ENOMEM, "hipMalloc of the bf16 weight planes failed");
+#if defined(COPER_FUSED_LO8) && !defined(COPER_SPLIT_BF16)      /* experiment: kernels_dense_fused_bf16.hip */
+    if (tracked_malloc(&h->Wf8_lo, plane / 2) != hipSuccess)
+      return fail(h, COPER_ENOMEM, "hipMalloc of the 8-bit weight plane failed");
+#endif
     // powers of two of the encoder's operands (split16.h): e_W per relation from its own largest |W|, e_x from a bound on x
     if ((rc = dev_alloc(h, &h->w_exp, (size_t)h->Rw))) return rc;
-    if ((rc = launch_wfrag_to_bf16(h, h->Wf, h->Rw, h->Wf16_hi, h->Wf16_lo, s))) return rc;
+    if ((rc = launch_wfrag_to_bf16(h, h->Wf, h->Rw, h->Wf16_hi, h->Wf16_lo, h->Wf8_lo, s))) return rc;
     if ((rc = compute_x_exp(h, h->band_consts + 5, s))) return rc;
     COPER_HIP_TRY(h, hipStreamSynchronize(s));
     dev_free(&h->Wf);  // the fp32 image was only the staging form

@@ -95,6 +95,7 @@ struct coper_handle {
   float* bias_pad = nullptr;    // [n_eblk*32], -inf padded
   void* Wf16_hi = nullptr;      // COPER_SCORE_BF16X3: dense weights as hi / lo bf16 planes (16x16x32 fragment order)
   void* Wf16_lo = nullptr;
+  void* Wf8_lo = nullptr;       // (-DCOPER_FUSED_LO8 only) the second term as bytes (split16.h: split8_q8); Wf16_lo then holds the same values
   bool enc_bf16 = false;        // encoder runs in bf16x3 (needs 3x3 filters, C % 8 == 0)
   void* Ef16_hi = nullptr;      // COPER_SCORE_BF16X3: entity table hi / lo bf16 planes, fragment-major
   void* Ef16_lo = nullptr;      //   [n_eblk][KS16][64] x 16 B
@@ -298,7 +299,7 @@ int launch_topk_pruned_bf16x3(coper_handle* h, const float* hvec, const float* t
                               int64_t* topk_idx, hipStream_t s);
 // kernels_encode_bf16.hip
 bool conv_bf16_supported(const Dims& dm);
-int launch_wfrag_to_bf16(coper_handle* h, const float* Wf, int64_t Rw, void* hi, void* lo, hipStream_t s);
+int launch_wfrag_to_bf16(coper_handle* h, const float* Wf, int64_t Rw, void* hi, void* lo, void* lo8, hipStream_t s);
 int compute_x_exp(coper_handle* h, unsigned* scratch, hipStream_t s);
 int launch_conv_bf16(coper_handle* h, const int64_t* e1, const int64_t* rel, const float* e1_rows, int64_t B,
                      bool skip_big, hipStream_t s);

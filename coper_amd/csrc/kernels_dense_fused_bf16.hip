@@ -39,6 +39,34 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define COPER_FUSED_PBUDGET 216
 #endif
 
+// -DCOPER_FUSED_LO8 (round 4, measured, NOT the default): the weights' second term streamed as BYTES (split16.h: split8_q8 /
+// lo8_decode; 3 bytes per value instead of 4) and rebuilt as fp16 in front of the k-step's MFMAs, 20 vector instructions per
+// fragment.  25 % fewer bytes bought nothing -- 0.1764 ms against 0.173 - 0.182: the kernel's compute side (conv waves and
+// matrix waves sharing the SIMDs' issue) needs the same 0.17 ms as the 4-byte stream (DESIGN_LOG.md, ablations) -- and the
+// 19 - 20 bits it leaves of every weight cost 0.2 % of the queries their float64-equal rank (99.64 -> 99.44 % at FB15k-237).
+// The default build's text is untouched: the weight registers are reached through the FW_* macros below.
+#if defined(COPER_FUSED_LO8) && !defined(COPER_SPLIT_BF16)
+#define FUSED_LO8 1
+typedef uint2 fused_wlo_t;
+typedef unsigned fused_wlo_reg __attribute__((ext_vector_type(2)));
+#define FW_DECL u32x4 W[P][NW]; fused_wlo_reg WL[P][NW]
+#define FW_HI(s_, j_) W[s_][j_]
+#define FW_LO(s_, j_) wl[j_]                          /* the k-step's decoded fragments (FW_PRE) */
+#define FW_LO_RAW(s_, j_) WL[s_][j_]
+#define FW_PRE(s_) u32x4 wl[NW]; _Pragma("unroll") for (int j = 0; j < NW; ++j) wl[j] = lo8_decode(WL[s_][j], W[s_][j]);
+#define FW_WREG3 (3 * NW * 6 + NW * 4)
+#else
+#define FUSED_LO8 0
+typedef uint4 fused_wlo_t;
+typedef u32x4 fused_wlo_reg;
+#define FW_DECL u32x4 W[P][NW][2]
+#define FW_HI(s_, j_) W[s_][j_][0]
+#define FW_LO(s_, j_) W[s_][j_][1]
+#define FW_LO_RAW(s_, j_) W[s_][j_][1]
+#define FW_PRE(s_)
+#define FW_WREG3 (3 * NW * 8)
+#endif
+
 struct FusedConvArgs {
   const float* e1_rows;
   const int32_t* sorted_row;
@@ -139,7 +167,7 @@ __device__ __forceinline__ void fused_load_images(float* __restrict__ img, const
 // repeats hit L1/L2.
 template <int NFB, int NB, bool WNT>
 __device__ __forceinline__ void fused_matrix_role(const uint4* __restrict__ xring, float* __restrict__ img,
-                                                  const uint4* __restrict__ Whi, const uint4* __restrict__ Wlo,
+                                                  const uint4* __restrict__ Whi, const fused_wlo_t* __restrict__ Wlo,
                                                   const FusedConvArgs& A, int64_t relw, int start, int n, int fb0,
                                                   int nfb, int64_t ks32n, int64_t kb, int64_t ke, int t0, int t1,
                                                   float* __restrict__ zdst, int d_pad16, int wave, const FusedFin& Fn) {
@@ -149,7 +177,7 @@ __device__ __forceinline__ void fused_matrix_role(const uint4* __restrict__ xrin
   constexpr int NRQ = REM ? (NB + 3) / 4 : 0; // its query blocks per wave (w, w+4)
   constexpr int NW = NFULL + REM;             // weight fragment streams per wave
   // two waves per SIMD: 256 registers each, accumulators included
-  constexpr int P = (COPER_FUSED_PMAX >= 3 && (NFULL * NB + NRQ) * 4 + 3 * NW * 8 + 44 <= COPER_FUSED_PBUDGET) ? 3 : 2;
+  constexpr int P = (COPER_FUSED_PMAX >= 3 && (NFULL * NB + NRQ) * 4 + FW_WREG3 + 44 <= COPER_FUSED_PBUDGET) ? 3 : 2;
   constexpr int XSTAGE = 2 * NB * 64;         // uint4 per stage: x hi [NB] | x lo [NB]
   const int lane = threadIdx.x & 63;
   const int nk = (int)(ke - kb);
@@ -160,9 +188,9 @@ __device__ __forceinline__ void fused_matrix_role(const uint4* __restrict__ xrin
     if (fb > nfb - 1) fb = nfb - 1;
     int64_t o = ((relw * nfb + fb) * ks32n + kb) * 64;   // wave-uniform: scalar base + one shared lane offset
     wp[j][0] = Whi + o;
-    wp[j][1] = Wlo + o;
+    wp[j][1] = (const uint4*)(Wlo + o);
   }
-  u32x4 W[P][NW][2];
+  FW_DECL;
   // WNT: non-temporal loads when a weight set is read by one tile only (FB15k-237 CoPER shapes: -2.3 % on the whole
   // pass against cached loads, which push the entity table out of L2 ahead of the count pass); plain loads when every
   // tile of a relation re-reads it and L2 serves the repeats (3 tiles per relation at WN18RR shapes: -11 % on this
@@ -176,8 +204,8 @@ __device__ __forceinline__ void fused_matrix_role(const uint4* __restrict__ xrin
 #define W_ISSUE(s, kk)                                                                                 \
   {                                                                                                    \
     _Pragma("unroll") for (int j = 0; j < NW; ++j) {                                                   \
-      W[s][j][0] = FUSED_W_LOAD((const u32x4*)(wp[j][0] + (int64_t)(kk)*64) + lane);                  \
-      W[s][j][1] = FUSED_W_LOAD((const u32x4*)(wp[j][1] + (int64_t)(kk)*64) + lane);                  \
+      FW_HI(s, j) = FUSED_W_LOAD((const u32x4*)(wp[j][0] + (int64_t)(kk)*64) + lane);                 \
+      FW_LO_RAW(s, j) = FUSED_W_LOAD((const fused_wlo_reg*)((const fused_wlo_t*)wp[j][1] + (int64_t)(kk)*64) + lane); \
     }                                                                                                  \
   }
 #pragma unroll
@@ -200,31 +228,32 @@ __device__ __forceinline__ void fused_matrix_role(const uint4* __restrict__ xrin
     __builtin_amdgcn_s_barrier();                                                                   \
     const uint4* xb = xring + ((s2)&1) * XSTAGE + lane;                                             \
     _Pragma("unroll") for (int j = 0; j < NW; ++j) {                                                \
-      acc[0][0][0] += __uint_as_float(W[(s2) % P][j][0][0] ^ W[(s2) % P][j][1][1]);                 \
-      acc[0][0][1] += __uint_as_float(W[(s2) % P][j][0][2] ^ W[(s2) % P][j][1][3]);                 \
+      acc[0][0][0] += __uint_as_float(FW_HI((s2) % P, j)[0] ^ FW_LO_RAW((s2) % P, j)[1]);           \
+      acc[0][0][1] += __uint_as_float(FW_HI((s2) % P, j)[2] ^ FW_LO_RAW((s2) % P, j)[0]);           \
     }                                                                                               \
     acc[0][0][2] += __uint_as_float(xb[0].x);                                                       \
   }
 #else
 #define M_STEP(s2)                                                                                  \
   {                                                                                                 \
+    FW_PRE((s2) % P)                                                                                \
     __builtin_amdgcn_s_barrier();                                                                   \
     const uint4* xb = xring + ((s2)&1) * XSTAGE + lane;                                             \
     _Pragma("unroll") for (int q = 0; q < NB; ++q) {                                                \
       const uint4 bh = xb[q * 64], bl = xb[(NB + q) * 64];                                          \
       _Pragma("unroll") for (int j = 0; j < NFULL; ++j)                                             \
-          acc[j][q] = MFMA16_BF16(W[(s2) % P][j][1], bh, acc[j][q]);                                \
+          acc[j][q] = MFMA16_BF16(FW_LO((s2) % P, j), bh, acc[j][q]);                               \
       _Pragma("unroll") for (int j = 0; j < NFULL; ++j)                                             \
-          acc[j][q] = MFMA16_BF16(W[(s2) % P][j][0], bl, acc[j][q]);                                \
+          acc[j][q] = MFMA16_BF16(FW_HI((s2) % P, j), bl, acc[j][q]);                               \
       _Pragma("unroll") for (int j = 0; j < NFULL; ++j)                                             \
-          acc[j][q] = MFMA16_BF16(W[(s2) % P][j][0], bh, acc[j][q]);                                \
+          acc[j][q] = MFMA16_BF16(FW_HI((s2) % P, j), bh, acc[j][q]);                               \
     }                                                                                               \
     _Pragma("unroll") for (int t = 0; t < NRQ; ++t) {                                               \
       const int q = wave + 4 * t < NB ? wave + 4 * t : NB - 1; /* past the tile: recompute, not stored */ \
       const uint4 bh = xb[q * 64], bl = xb[(NB + q) * 64];                                          \
-      accr[t] = MFMA16_BF16(W[(s2) % P][NFULL][1], bh, accr[t]);                                    \
-      accr[t] = MFMA16_BF16(W[(s2) % P][NFULL][0], bl, accr[t]);                                    \
-      accr[t] = MFMA16_BF16(W[(s2) % P][NFULL][0], bh, accr[t]);                                    \
+      accr[t] = MFMA16_BF16(FW_LO((s2) % P, NFULL), bh, accr[t]);                                   \
+      accr[t] = MFMA16_BF16(FW_HI((s2) % P, NFULL), bl, accr[t]);                                   \
+      accr[t] = MFMA16_BF16(FW_HI((s2) % P, NFULL), bh, accr[t]);                                   \
     }                                                                                               \
   }
 #endif
@@ -422,7 +451,7 @@ extern "C" __attribute__((visibility("default"))) int coper_dbg_fused_clock(unsi
 #endif
 
 template <int NFB, bool WNT>
-__global__ __launch_bounds__(512) void k_dense_fused_bf16x3(const uint4* __restrict__ Whi, const uint4* __restrict__ Wlo,
+__global__ __launch_bounds__(512) void k_dense_fused_bf16x3(const uint4* __restrict__ Whi, const fused_wlo_t* __restrict__ Wlo,
                                                             FusedConvArgs A, const int32_t* __restrict__ tiles,
                                                             const int32_t* __restrict__ n_tiles, int64_t cap_small,
                                                             int nfb, int64_t ks32n, int nslices, int64_t Bcap,
@@ -571,7 +600,7 @@ static void dense_fused_launch(coper_handle* h, const int64_t* e1, const int64_t
   const int n_tile_blocks = (int)(n_big_max + n_small_max);
   const int n_stage = h->stage_n > 0 ? FUSED_STAGE_WGS : 0;
   hipLaunchKernelGGL((k_dense_fused_bf16x3<NFB, WNT>), dim3((unsigned)(n_tile_blocks + n_stage), (unsigned)nslices, (unsigned)zgroups), dim3(512),
-                     lds, s, (const uint4*)h->Wf16_hi, (const uint4*)h->Wf16_lo, A, h->tiles, h->n_tiles, cap_small, dm.nfb,
+                     lds, s, (const uint4*)h->Wf16_hi, (const fused_wlo_t*)(FUSED_LO8 ? h->Wf8_lo : h->Wf16_lo), A, h->tiles, h->n_tiles, cap_small, dm.nfb,
                      dm.F_pad / 32, nslices, h->ws_queries, dm.d_pad16, h->z_part, (int)n_big_max, Fn, n_tile_blocks, h->stage_src,
                      h->stage_n, h->stage_dst);
   h->stage_n = 0;
