@@ -6,7 +6,10 @@ scale from 1e-4 to 10), a batch (1 - 6,000 queries, relation skew, duplicate que
 answers in one row, duplicates of the target).  Checked per case:
   * ranks of the fused pass == ranks (and tie counts) of the fp32-exact ranker fed the pass's own h rows, for EVERY query;
   * the two-call path (encode + rank) gives the same ranks, and the same h bit for bit;
-  * the band audit stays below 0.5.
+  * the band audit stays below 0.5;
+  * the pruned top-k of the filtered rows (k drawn from 1 - 128; logits never materialised by the library) == a stable sort of
+    the masked rows of the mode's own score_all logits: ids and values, (score desc, id asc), for every query (cases whose
+    logit matrix stays under 2^26 elements).
 Prints one line per case and a summary; exits non-zero on the first mismatch."""
 import os
 import sys
@@ -71,16 +74,37 @@ def main():
         r32, ne32 = m32.rank(h, q["e2"], q["filt_indptr"], q["filt_idx"], want_equal=True)
         h2 = m.encode(q["e1"], q["rel"])
         r2, ne2 = m.rank(h2, q["e2"], q["filt_indptr"], q["filt_idx"], want_equal=True)
+        topk_ok = True
+        E = int(md["num_ent"])
+        if Q * E <= (1 << 26):
+            k = int(rng.choice([1, 3, 10, 32, 33, 128]))
+            tgt = m.target_scores(h2, q["e2"])
+            ng_k, ne_k, tv, ti = m.rank_counts(h2, tgt, q["e2"], q["filt_indptr"], q["filt_idx"], k=k)
+            lg = m.score_all(h2)
+            dq_e2 = torch.as_tensor(q["e2"], device=lg.device)
+            ip = torch.as_tensor(q["filt_indptr"], device=lg.device)
+            rows = torch.repeat_interleave(torch.arange(Q, device=lg.device), ip[1:] - ip[:-1])
+            t = lg[torch.arange(Q, device=lg.device), dq_e2].clone()
+            masked = lg.clone()
+            if len(q["filt_idx"]):
+                masked[rows, torch.as_tensor(q["filt_idx"], device=lg.device)] = float("-inf")
+            masked[torch.arange(Q, device=lg.device), dq_e2] = t
+            sv, si = torch.sort(masked, dim=1, descending=True, stable=True)
+            kk = min(k, E)
+            ev = torch.full((Q, k), float("-inf"), device=lg.device); ei = torch.full((Q, k), -1, dtype=torch.int64, device=lg.device)
+            ev[:, :kk] = sv[:, :kk]; ei[:, :kk] = si[:, :kk]
+            ei[ev == float("-inf")] = -1
+            topk_ok = torch.equal(ti.to(torch.int64), ei) and torch.equal(tv, ev) and torch.equal(ng_k + 1, r32)
         torch.cuda.synchronize()
         ratio, pairs = m.band_audit()
         ok = (torch.equal(ranks, r32) and torch.equal(ranks_e, r32) and torch.equal(ne_e, ne32) and torch.equal(r2, r32) and torch.equal(ne2, ne32)
-              and torch.equal(h, h2) and torch.equal(h, h_e) and bool(torch.isfinite(h).all()) and ratio < 0.5)
+              and torch.equal(h, h2) and torch.equal(h, h_e) and bool(torch.isfinite(h).all()) and ratio < 0.5 and topk_ok)
         worst = max(worst, ratio)
         print("case %3d  %-13s E=%-6d R=%-4d std=%-8.2g Q=%-5d nnz=%-7d  audit %.3f over %d pairs  %s" % (
             c, "d=%d" % md["ent_emb_size"], md["num_ent"], md["num_rel"], ent_std, Q, int(q["filt_indptr"][-1]), ratio, pairs, "ok" if ok else "MISMATCH"), flush=True)
         if not ok:
             bad = (ranks != r32).nonzero().flatten()[:8].tolist()
-            print("   first differing queries:", bad, "fused", ranks[bad].tolist(), "chain", r32[bad].tolist())
+            print("   first differing queries:", bad, "fused", ranks[bad].tolist(), "chain", r32[bad].tolist(), "top-k ok:", topk_ok)
             sys.exit(1)
         m.close(); m32.close()
     print("soak: %d cases, all ranks == the fp32 chain's on the same h; largest band audit %.3f; %.0f s" % (cases, worst, time.time() - t0))
