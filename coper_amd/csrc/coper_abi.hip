@@ -783,10 +783,12 @@ COPER_API int coper_rank_counts(coper_handle* h, const float* hvec, const float*
   if ((rc = ensure_rank_workspace(h, B, filt_nnz, false, s))) return rc;
   // 0 < k <= COPER_TOPK_PRUNED_MAX (128): the count pass also writes block maxima and the top-k is selected from the few blocks that can
   // hold it (kernels_topk_bf16.hip): no logits workspace
+  const int XF = topk_expand(h);      // (2 on large tables: 64-entity candidate blocks, expanded to two 32-entity ones)
   const bool pruned = k > 0 && k <= COPER_TOPK_PRUNED_MAX &&
-                      (int64_t)k * B + filt_nnz + 32 * h->dm.n_eblk * topk_nseg(h->dm.n_eblk) < 0x7fffffffLL;   // int32 slot ids
+                      XF * ((int64_t)k * B + filt_nnz) + 32 * h->dm.n_eblk * topk_nseg(h->dm.n_eblk) < 0x7fffffffLL;   // int32 slot ids
   if (pruned) {
-    const size_t gneed = (size_t)(h->dm.n_eblk * topk_chunk_queries(h->dm.n_eblk, B, h->gmax_max_floats)), tneed = (size_t)((int64_t)k * B + filt_nnz);
+    const size_t gneed = (size_t)(topk_gm_rows(h) * topk_chunk_queries(h->dm.n_eblk, B, h->gmax_max_floats));
+    const size_t t64 = (size_t)((int64_t)k * B + filt_nnz), tneed = (size_t)XF * t64;
     if (gneed > h->gmax_cap || tneed > h->cand_cap || (size_t)B > h->cand_tau_cap) {
       COPER_HIP_TRY(h, hipStreamSynchronize(s));
       if (gneed > h->gmax_cap) {
@@ -795,7 +797,8 @@ COPER_API int coper_rank_counts(coper_handle* h, const float* hvec, const float*
       }
       if (tneed > h->cand_cap) {
         h->cand_cap = 0;
-        if ((rc = dev_alloc(h, &h->cand_blk_ws, tneed)) || (rc = dev_alloc(h, &h->cand_q_ws, tneed)) ||
+        const size_t tlist = tneed + (XF > 1 ? t64 : 0);      // (+ the 64-entity level's own lists, behind the expanded ones)
+        if ((rc = dev_alloc(h, &h->cand_blk_ws, tlist)) || (rc = dev_alloc(h, &h->cand_q_ws, tlist)) ||
             (rc = dev_alloc(h, &h->cand_val_ws, tneed * 32)) ||
             (rc = dev_alloc(h, &h->cand_sorted_ws, topk_sorted_cap(h->dm.n_eblk * topk_nseg(h->dm.n_eblk), (int64_t)tneed))))
           return rc;

@@ -267,6 +267,20 @@ inline int64_t topk_chunk_queries(int64_t n_eblk, int64_t B, int64_t cap_floats)
 // size of the block-grouped slot list: every block with candidates is padded to a multiple of 32
 // counters per block for the grouping of candidate slots: few blocks = many slots per block = contended atomics
 inline int topk_nseg(int64_t n_eblk) { return n_eblk < 4096 ? 8 : 1; }
+// Large tables: the x3 count kernel writes one block maximum per 64 entities instead of 32 (kernels_score3_bf16.hip: GM = 2),
+// the threshold kernel selects 64-entity candidate blocks and k_topk_expand64 turns each into its two 32-entity halves for
+// everything downstream -- half the bytes of the three threshold sweeps against twice the re-scoring.  Measured crossover
+// between WN18RR's 41 K entities (equal) and a 1.25 M-row shard (-0.3 ms of 7.1): from 65,536 local rows on.
+inline int topk_expand(const coper_handle* h) {
+  const char* force = getenv("COPER_TOPK_EXPAND");             // A/B and tests: "1" / "2" (read per call; set it before the handle's first top-k call and keep it)
+  if (h->cfg.score_mode == COPER_SCORE_F32) return 1;
+#if defined(COPER_SC3_MB) && COPER_SC3_MB != 4
+  return 1;                                                    // (A/B builds with 32-entity blocks per wave)
+#endif
+  if (force && (force[0] == '1' || force[0] == '2')) return force[0] - '0';
+  return h->dm.n_local >= 65536 ? 2 : 1;
+}
+inline int64_t topk_gm_rows(const coper_handle* h) { return h->dm.n_eblk / topk_expand(h); }     // rows of gmax (n_eblk is a multiple of 16)
 inline size_t topk_sorted_cap(int64_t n_eblk, int64_t T) { return (size_t)((T + 31 * (n_eblk < T ? n_eblk : T) + 31) / 32 * 32); }
 void score_count_begin_bf16x3(coper_handle* h, int64_t B, int32_t* ng, int32_t* ne, hipStream_t s);
 // kernels_score3_bf16.hip: the count kernel (16x16x32, software-pipelined, one wave per SIMD) and the exact band

@@ -53,8 +53,14 @@ static_assert(SC3_LD >= 1 && SC3_LD <= 3, "ring of four register pairs");
 // sets fill the 256 AGPRs.
 constexpr int SC3_MB = COPER_SC3_MB;
 static_assert(SC3_MB == 2 || SC3_MB == 4, "mask words are written as whole 16-byte pieces");
-
-template <int NP, int TAIL, int PD, bool GM>
+// Block maxima of the top-k launches.  GM = 1: one per (32 entities, query) -- the eight values of two consecutive 16-row
+// blocks; GM = 2: one per (the wave's 64-entity block, query) -- sixteen values, half the cross-lane reductions and stores in
+// this kernel and half the bytes for the threshold kernel's three sweeps (kernels_topk_bf16.hip expands a candidate block into
+// its two 32-entity halves before the re-scoring, which therefore doubles).  Large tables take GM = 2 (10 M entities, 4,096
+// queries, top-10: 48.9 -> 45.6 ms), small ones GM = 1 (FB15k-237, k = 10: 0.69 against 0.84 ms): topk_expand (coper_internal.h).
+__host__ __device__ constexpr int sc3_gmask(int GM) { return GM == 2 ? 15 : 7; }        // a maximum is complete at value V with (V & mask) == mask
+__host__ __device__ constexpr int sc3_gm_rows(int GM) { return GM == 2 ? 1 : SC3_MB / 2; }   // rows of gmax per entity block of 16 SC3_MB rows
+template <int NP, int TAIL, int PD, int GM>
 struct SC3 {
   static constexpr int MB = SC3_MB;
   static constexpr int NS = NP + TAIL;                    // steps per half-row
@@ -163,7 +169,7 @@ __device__ __forceinline__ void sc3_ld_issue(ST& S, const SC3Ptrs& X) {
 
 // what follows the comparisons of value V: every 32 values the word pair gives the counts, every 8 (top-k launches) the block
 // maximum is reduced across lanes and stored, the row's last value stores the band words that carry a bit
-template <int NP, int TAIL, int PD, bool GM, int M, int V>
+template <int NP, int TAIL, int PD, int GM, int M, int V>
 __device__ __forceinline__ void sc3_value_tail(SC3<NP, TAIL, PD, GM>& S, const int lane, const bool store_ok, float* __restrict__ gm_row,
                                                const int64_t gm_col, uint4* __restrict__ mask_row) {
   constexpr int MB = SC3_MB, NV = 32 * MB;
@@ -177,7 +183,7 @@ __device__ __forceinline__ void sc3_value_tail(SC3<NP, TAIL, PD, GM>& S, const i
     S.mk[w] &= ~S.mg[w];
   }
   if constexpr (GM) {
-    if constexpr ((V & 7) == 7) {
+    if constexpr ((V & sc3_gmask(GM)) == sc3_gmask(GM)) {
       // the other rows of the 32-entity block sit in lanes + 16, + 32, + 48: two lane swaps inside the vector unit
       // (v_permlane32_swap / v_permlane16_swap; __shfl_xor goes through the LDS pipe and its wait falls on the query-
       // fragment reads in flight).  After "swap a, b" with a == b: a = {lower, lower}, b = {upper, upper} halves (rows).
@@ -186,7 +192,7 @@ __device__ __forceinline__ void sc3_value_tail(SC3<NP, TAIL, PD, GM>& S, const i
       asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_max_f32 %0, %0, %1\n\tv_mov_b32 %1, %0\n\ts_nop 1\n\t"
                    "v_permlane16_swap_b32 %0, %1\n\tv_max_f32 %2, %0, %1"
                    : "+v"(a), "+v"(b2), "=&v"(mxx));
-      if (store_ok && lane < 16) gm_row[(m2 >> 1) * S.gm_stride + gm_col + b * 16 + lane] = mxx;
+      if (store_ok && lane < 16) gm_row[(sc3_gm_rows(GM) > 1 ? (m2 >> 1) : 0) * S.gm_stride + gm_col + b * 16 + lane] = mxx;
     }
   }
   if constexpr (M == 1 && V == NV - 1) {     // the row's 64 MB band bits of this lane are complete
@@ -210,7 +216,7 @@ __device__ __forceinline__ void sc3_value_tail(SC3<NP, TAIL, PD, GM>& S, const i
 }
 
 // value V = 4 MB b + 4 m2 + j of block M: entity row 16 m2 + 4 (lane >> 4) + j of the block, query 16 b + (lane & 15) of the tile
-template <int NP, int TAIL, int PD, bool GM, int M, int V>
+template <int NP, int TAIL, int PD, int GM, int M, int V>
 __device__ __forceinline__ void sc3_value(SC3<NP, TAIL, PD, GM>& S, const int lane, const bool store_ok, float* __restrict__ gm_row,
                                           const int64_t gm_col, uint4* __restrict__ mask_row) {
   constexpr int MB = SC3_MB, NV = 32 * MB;
@@ -245,7 +251,7 @@ __device__ __forceinline__ void sc3_value(SC3<NP, TAIL, PD, GM>& S, const int la
     // moves were a fifth of the top-k launch), written as instructions because the values come out of an asm block
     if constexpr ((V & 1) == 0) {
       S.px = sc;
-    } else if constexpr ((V & 7) == 1) {
+    } else if constexpr ((V & sc3_gmask(GM)) == 1) {
       asm volatile("v_max_f32 %0, %1, %2" : "=v"(S.mx) : "v"(S.px), "v"(sc));
     } else {
       asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(S.mx) : "v"(S.px), "v"(sc));
@@ -254,7 +260,7 @@ __device__ __forceinline__ void sc3_value(SC3<NP, TAIL, PD, GM>& S, const int la
   sc3_value_tail<NP, TAIL, PD, GM, M, V>(S, lane, store_ok, gm_row, gm_col, mask_row);
 }
 
-template <int NP, int TAIL, int PD, bool GM, int M, int V0, int... I>
+template <int NP, int TAIL, int PD, int GM, int M, int V0, int... I>
 __device__ __forceinline__ void sc3_values(SC3<NP, TAIL, PD, GM>& S, const int lane, const bool store_ok, float* __restrict__ gm_row,
                                            const int64_t gm_col, uint4* __restrict__ mask_row, std::integer_sequence<int, I...>) {
   (sc3_value<NP, TAIL, PD, GM, M, V0 + I>(S, lane, store_ok, gm_row, gm_col, mask_row), ...);
@@ -268,13 +274,13 @@ __device__ __forceinline__ void sc3_values(SC3<NP, TAIL, PD, GM>& S, const int l
 // them, 154 with 5 vector instructions, 47 with 10).  The carry travels in an SGPR pair from piece to piece (VCC could be
 // clobbered by the compiler's own address arithmetic between two asm statements); the MFMA between producer and consumer
 // hides the VALU -> SGPR -> VALU hand-over that made round 3's first scalar form slow.
-template <int NP, int TAIL, int PD, bool GM, int M, int V>
+template <int NP, int TAIL, int PD, int GM, int M, int V>
 __device__ __forceinline__ void sc3_piece1(SC3<NP, TAIL, PD, GM>& S, float& sc) {
   constexpr int MB = SC3_MB, b = V / (4 * MB), m2 = (V >> 2) % MB, j = V & 3, w = MB * M + (V >> 5);
   asm volatile("v_accvgpr_read_b32 %1, %2\n\tv_cmp_gt_f32 vcc, %1, %3\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
                : "+v"(S.mg[w]), "=&v"(sc) : "a"(S.acc[M][m2][b][j]), "v"(S.thi[b]) : "vcc");
 }
-template <int NP, int TAIL, int PD, bool GM, int M, int V>
+template <int NP, int TAIL, int PD, int GM, int M, int V>
 __device__ __forceinline__ void sc3_piece2(SC3<NP, TAIL, PD, GM>& S, const float sc, const int lane, const bool store_ok,
                                            float* __restrict__ gm_row, const int64_t gm_col, uint4* __restrict__ mask_row) {
   constexpr int MB = SC3_MB, b = V / (4 * MB), w = MB * M + (V >> 5);
@@ -283,24 +289,24 @@ __device__ __forceinline__ void sc3_piece2(SC3<NP, TAIL, PD, GM>& S, const float
 #endif
   if constexpr (GM) {
     if constexpr ((V & 1) == 0) S.px = sc;
-    else if constexpr ((V & 7) == 1) asm volatile("v_max_f32 %0, %1, %2" : "=v"(S.mx) : "v"(S.px), "v"(sc));
+    else if constexpr ((V & sc3_gmask(GM)) == 1) asm volatile("v_max_f32 %0, %1, %2" : "=v"(S.mx) : "v"(S.px), "v"(sc));
     else asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(S.mx) : "v"(S.px), "v"(sc));
   }
   sc3_value_tail<NP, TAIL, PD, GM, M, V>(S, lane, store_ok, gm_row, gm_col, mask_row);
 }
 
-template <int NP, int TAIL, int PD, bool GM, int M, int... m2>
+template <int NP, int TAIL, int PD, int GM, int M, int... m2>
 __device__ __forceinline__ void sc3_load_bias_(SC3<NP, TAIL, PD, GM>& S, const float4* __restrict__ bp, std::integer_sequence<int, m2...>) {
   ((S.biasv[M][m2] = f32x4{x3_scale(bp[4 * m2].x, S.sexp), x3_scale(bp[4 * m2].y, S.sexp), x3_scale(bp[4 * m2].z, S.sexp),
                            x3_scale(bp[4 * m2].w, S.sexp)}), ...);
 }
-template <int NP, int TAIL, int PD, bool GM, int M>
+template <int NP, int TAIL, int PD, int GM, int M>
 __device__ __forceinline__ void sc3_load_bias(SC3<NP, TAIL, PD, GM>& S, const float* __restrict__ bias_pad, const int64_t blk, const int lane) {
   sc3_load_bias_<NP, TAIL, PD, GM, M>(S, (const float4*)(bias_pad + blk * (16 * SC3_MB) + 4 * (lane >> 4)), std::make_integer_sequence<int, SC3_MB>{});
 }
 #ifdef COPER_SC3_ASM_LOADS
 // the same rows as loaded (no scale yet: the values arrive later): START = the tile's first row, loads the compiler sees
-template <int NP, int TAIL, int PD, bool GM, int M, bool START>
+template <int NP, int TAIL, int PD, int GM, int M, bool START>
 __device__ __forceinline__ void sc3_load_braw(SC3<NP, TAIL, PD, GM>& S, const float* __restrict__ bias_pad, const int64_t blk, const int lane) {
   static_assert(SC3_MB == 4, "four quads");
   const f32x4* bp = (const f32x4*)(bias_pad + blk * (16 * SC3_MB) + 4 * (lane >> 4));
@@ -312,7 +318,7 @@ __device__ __forceinline__ void sc3_load_braw(SC3<NP, TAIL, PD, GM>& S, const fl
                  : "=&v"(S.braw[M][0]), "=&v"(S.braw[M][1]), "=&v"(S.braw[M][2]), "=&v"(S.braw[M][3]) : "v"(bp));
   }
 }
-template <int NP, int TAIL, int PD, bool GM, int M, int... m2>
+template <int NP, int TAIL, int PD, int GM, int M, int... m2>
 __device__ __forceinline__ void sc3_scale_bias(SC3<NP, TAIL, PD, GM>& S, std::integer_sequence<int, m2...>) {
   ((S.biasv[M][m2] = f32x4{x3_scale(S.braw[M][m2][0], S.sexp), x3_scale(S.braw[M][m2][1], S.sexp), x3_scale(S.braw[M][m2][2], S.sexp),
                            x3_scale(S.braw[M][m2][3], S.sexp)}), ...);
@@ -320,7 +326,7 @@ __device__ __forceinline__ void sc3_scale_bias(SC3<NP, TAIL, PD, GM>& S, std::in
 #endif
 
 // the instructions of region (step s, column block b) on the MB accumulator chains of block M, chains interleaved
-template <int NP, int TAIL, int PD, bool GM, int M, int s, int b, int sa, int sl, int rs, bool tail, int... m2>
+template <int NP, int TAIL, int PD, int GM, int M, int s, int b, int sa, int sl, int rs, bool tail, int... m2>
 __device__ __forceinline__ void sc3_mfmas(SC3<NP, TAIL, PD, GM>& S, std::integer_sequence<int, m2...>) {
   // (e.reg0, q.reg1): T1 of both k-steps (tail: T1 then T2); step 0 starts the chains from pred_bias
   if constexpr (s == 0) ((S.acc[M][m2][b] = BX3_MFMA16(S.a0[sa][sl][m2], S.q1[rs], S.biasv[M][m2])), ...);
@@ -331,7 +337,7 @@ __device__ __forceinline__ void sc3_mfmas(SC3<NP, TAIL, PD, GM>& S, std::integer
   if constexpr (!tail) ((S.acc[M][m2][b] = BX3_MFMA16(S.a1[sa][sl][m2], S.q1[rs], S.acc[M][m2][b])), ...);
 }
 
-template <int NP, int TAIL, int PD, bool GM, int M, int v0, int cnt, int K0, int... U>
+template <int NP, int TAIL, int PD, int GM, int M, int v0, int cnt, int K0, int... U>
 __device__ __forceinline__ void sc3_slot_pieces(SC3<NP, TAIL, PD, GM>& S, float* sc, const int lane,
                                                 const bool store_ok, float* __restrict__ gm_row, const int64_t gm_col,
                                                 uint4* __restrict__ mask_row, std::integer_sequence<int, U...>) {
@@ -351,7 +357,7 @@ __device__ __forceinline__ void sc3_slot_pieces(SC3<NP, TAIL, PD, GM>& S, float*
 // stay the compiler's (named operands).  Shapes: steps s > 0 (step 0 starts the chains from pred_bias; with the bias quads as
 // four more operands the allocator spilled 174 registers), 1 - 3 values that share one mask word; top-k launches fold their
 // block maxima in (sc3_region_asm_gm.inc).  Everything else takes the form above.
-template <int NP, int TAIL, int PD, bool GM, int M, int s, int b, int sa, int sl, int rs, bool tail, int v0, int cnt>
+template <int NP, int TAIL, int PD, int GM, int M, int s, int b, int sa, int sl, int rs, bool tail, int v0, int cnt>
 __device__ __forceinline__ void sc3_region_asm(SC3<NP, TAIL, PD, GM>& S, const SC3Ptrs& X, const int lane, const bool store_ok, float* __restrict__ gm_row,
                                                const int64_t gm_col, uint4* __restrict__ mask_row) {
   constexpr int MB = SC3_MB;
@@ -367,6 +373,7 @@ __device__ __forceinline__ void sc3_region_asm(SC3<NP, TAIL, PD, GM>& S, const S
   typedef unsigned sc3_u4 __attribute__((ext_vector_type(4)));     // (a HIP uint4 is a struct: not a register operand)
 #define SC3_Q(x) (*(const sc3_u4*)&(x))
 #ifdef COPER_SC3_ASM_LOADS
+  static_assert(GM != 2, "COPER_SC3_ASM_LOADS: the generator writes no blocks with 64-entity maxima");
   typedef SC3Ld<NP, TAIL, PD, M, s, b> L;
   uint4& GD = sc3_ld_gd<L>(S);
   uint4& QD0 = S.q0[L::ring];
@@ -383,9 +390,13 @@ __device__ __forceinline__ void sc3_region_asm(SC3<NP, TAIL, PD, GM>& S, const S
   }
 #else
   if constexpr (GM) {       // top-k launches: block maxima folded in (even values wait in S.px, odd ones fold the pair into S.mx)
-    constexpr int vm = v0 & 7;
-    static_assert(!(cnt == 3 && vm == 7), "the maximum of a group is stored after the block: it must not hold the next group's first pair");
+    constexpr int vm = v0 & sc3_gmask(GM);
+    static_assert(!(cnt == 3 && vm == sc3_gmask(GM)), "the maximum of a group is stored after the block: it must not hold the next group's first pair");
+    if constexpr (GM == 2) {
+#include "sc3_region_asm_gm64.inc"
+    } else {
 #include "sc3_region_asm_gm.inc"
+    }
   } else {
 #include "sc3_region_asm.inc"
   }
@@ -398,7 +409,7 @@ __device__ __forceinline__ void sc3_region_asm(SC3<NP, TAIL, PD, GM>& S, const S
 
 // One slot of a region: MFMA number I of the region (term I / MB on chain I % MB) and, behind it, PP pieces of the other
 // block's epilogue (piece k of the region = piece k % 3 of value v0 + k / 3); a scheduling barrier pins the order.
-template <int NP, int TAIL, int PD, bool GM, int M, int s, int b, int sa, int sl, int rs, bool tail, int v0, int cnt, int PP, int I>
+template <int NP, int TAIL, int PD, int GM, int M, int s, int b, int sa, int sl, int rs, bool tail, int v0, int cnt, int PP, int I>
 __device__ __forceinline__ void sc3_slot(SC3<NP, TAIL, PD, GM>& S, float* sc, const int lane, const bool store_ok,
                                          float* __restrict__ gm_row, const int64_t gm_col, uint4* __restrict__ mask_row) {
   constexpr int MB = SC3_MB, NM = tail ? 2 * MB : 3 * MB;
@@ -421,7 +432,7 @@ __device__ __forceinline__ void sc3_slot(SC3<NP, TAIL, PD, GM>& S, float* sc, co
 #endif
 }
 
-template <int NP, int TAIL, int PD, bool GM, int M, int s, int b, int sa, int sl, int rs, bool tail, int v0, int cnt, int PP, int... I>
+template <int NP, int TAIL, int PD, int GM, int M, int s, int b, int sa, int sl, int rs, bool tail, int v0, int cnt, int PP, int... I>
 __device__ __forceinline__ void sc3_slots(SC3<NP, TAIL, PD, GM>& S, float* sc, const int lane, const bool store_ok,
                                           float* __restrict__ gm_row, const int64_t gm_col, uint4* __restrict__ mask_row,
                                           std::integer_sequence<int, I...>) {
@@ -431,7 +442,7 @@ __device__ __forceinline__ void sc3_slots(SC3<NP, TAIL, PD, GM>& S, float* sc, c
 // Region (step s, column block b) of block M: in front, one entity-fragment load PD steps ahead (regions b < 2 MB: the
 // registers of a step) and the two LDS reads of the region SC3_LD ahead; then the instructions of the MB accumulator
 // chains interleaved; behind them this region's share of the other block's epilogue.
-template <int NP, int TAIL, int PD, bool GM, int M, int s, int b>
+template <int NP, int TAIL, int PD, int GM, int M, int s, int b>
 __device__ __forceinline__ void sc3_region(SC3<NP, TAIL, PD, GM>& S, const SC3Ptrs& X, const int lane, const bool prev_valid,
                                            float* __restrict__ gm_row, const int64_t gm_col, uint4* __restrict__ mask_row) {
   typedef SC3<NP, TAIL, PD, GM> ST;
@@ -446,7 +457,7 @@ __device__ __forceinline__ void sc3_region(SC3<NP, TAIL, PD, GM>& S, const SC3Pt
     constexpr int R = s * 8 + b, rs = R & 3;
     constexpr int c0 = b * CH / 8, c1 = (b + 1) * CH / 8, v0 = s * CH + c0;
     constexpr int cnt = v0 >= NV ? 0 : (v0 + (c1 - c0) > NV ? NV - v0 : c1 - c0);
-    if constexpr (MB == 4 && s > 0 && cnt >= 1 && cnt <= 3 && (v0 >> 5) == ((v0 + cnt - 1) >> 5) && !(GM && cnt == 3 && (v0 & 7) == 7)) {
+    if constexpr (MB == 4 && s > 0 && cnt >= 1 && cnt <= 3 && (v0 >> 5) == ((v0 + cnt - 1) >> 5) && !(GM && cnt == 3 && (v0 & sc3_gmask(GM)) == sc3_gmask(GM))) {
       sc3_region_asm<NP, TAIL, PD, GM, M, s, b, sa, sl, rs, tail, v0, cnt>(S, X, lane, prev_valid, gm_row, gm_col, mask_row);
       SC3_FENCE();
       return;
@@ -527,7 +538,7 @@ __device__ __forceinline__ void sc3_region(SC3<NP, TAIL, PD, GM>& S, const SC3Pt
   constexpr int cnt = v0 >= NV ? 0 : (v0 + (c1 - c0) > NV ? NV - v0 : c1 - c0);
 #ifndef COPER_SC3_INTERLEAVED     /* the shipped form: the region's MFMAs, then whole values */
 #if !defined(COPER_SC3_NO_ASM_REGION) && !defined(COPER_DBG_SC3_NO_EPI) && !defined(COPER_DBG_SC3_NO_BAND) && !defined(COPER_DBG_SC3_EPI_R0) && !defined(COPER_SPLIT_BF16)
-  if constexpr (MB == 4 && s > 0 && cnt >= 1 && cnt <= 3 && (v0 >> 5) == ((v0 + cnt - 1) >> 5) && !(GM && cnt == 3 && (v0 & 7) == 7)) {
+  if constexpr (MB == 4 && s > 0 && cnt >= 1 && cnt <= 3 && (v0 >> 5) == ((v0 + cnt - 1) >> 5) && !(GM && cnt == 3 && (v0 & sc3_gmask(GM)) == sc3_gmask(GM))) {
     sc3_region_asm<NP, TAIL, PD, GM, M, s, b, sa, sl, rs, tail, v0, cnt>(S, X, lane, prev_valid, gm_row, gm_col, mask_row);
     SC3_FENCE();
     return;
@@ -555,7 +566,7 @@ __device__ __forceinline__ void sc3_region(SC3<NP, TAIL, PD, GM>& S, const SC3Pt
 #endif
 }
 
-template <int NP, int TAIL, int PD, bool GM, int M, int s>
+template <int NP, int TAIL, int PD, int GM, int M, int s>
 __device__ __forceinline__ void sc3_step(SC3<NP, TAIL, PD, GM>& S, const SC3Ptrs& X, const float* __restrict__ bias_pad,
                                          const int64_t bias_blk_next, const int lane, const bool prev_valid, float* __restrict__ gm_row,
                                          const int64_t gm_col, uint4* __restrict__ mask_row) {
@@ -578,23 +589,23 @@ __device__ __forceinline__ void sc3_step(SC3<NP, TAIL, PD, GM>& S, const SC3Ptrs
   }
 }
 
-template <int NP, int TAIL, int PD, bool GM, int M, int... K>
+template <int NP, int TAIL, int PD, int GM, int M, int... K>
 __device__ __forceinline__ void sc3_half(SC3<NP, TAIL, PD, GM>& S, const SC3Ptrs& X, const float* __restrict__ bias_pad,
                                          const int64_t bias_blk_next, const int lane, const bool prev_valid, float* __restrict__ gm_row,
                                          const int64_t gm_col, uint4* __restrict__ mask_row, std::integer_sequence<int, K...>) {
   (sc3_step<NP, TAIL, PD, GM, M, K>(S, X, bias_pad, bias_blk_next, lane, prev_valid, gm_row, gm_col, mask_row), ...);
 }
 
-template <int NP, int TAIL, int PD, bool GM, int J, int... m2>
+template <int NP, int TAIL, int PD, int GM, int J, int... m2>
 __device__ __forceinline__ void sc3_prologue_a_(SC3<NP, TAIL, PD, GM>& S, const uint4* __restrict__ pa, std::integer_sequence<int, m2...>) {
   constexpr int NS = NP + TAIL, JJ = J < NS ? J : NS - 1;
   ((S.a0[0][J][m2] = pa[((m2 * NS + JJ) * 2 + 0) * 64], S.a1[0][J][m2] = pa[((m2 * NS + JJ) * 2 + 1) * 64]), ...);
 }
-template <int NP, int TAIL, int PD, bool GM, int... J>
+template <int NP, int TAIL, int PD, int GM, int... J>
 __device__ __forceinline__ void sc3_prologue_a(SC3<NP, TAIL, PD, GM>& S, const uint4* __restrict__ pa, std::integer_sequence<int, J...>) {
   (sc3_prologue_a_<NP, TAIL, PD, GM, J>(S, pa, std::make_integer_sequence<int, SC3_MB>{}), ...);
 }
-template <int NP, int TAIL, int PD, bool GM, int... J>
+template <int NP, int TAIL, int PD, int GM, int... J>
 __device__ __forceinline__ void sc3_prologue_a1(SC3<NP, TAIL, PD, GM>& S, std::integer_sequence<int, J...>) {   // ablation builds only
   for (int m2 = 0; m2 < SC3_MB; ++m2) ((S.a0[1][J][m2] = S.a0[0][J][m2], S.a1[1][J][m2] = S.a1[0][J][m2]), ...);
 }
@@ -608,7 +619,7 @@ __device__ unsigned long long g_sc3_clk[2 * 1024];
 // Ef3: the entities' f3 image; Hf3: the queries' (one 128-query tile = 8 column blocks = 16 NS KiB, copied to LDS as it lies);
 // tband[q] = {t_lo, t_hi}; mask: [tile][row][wave][lane] MB / 2 x 16 bytes (band bits of the 32 MB entities x 128 queries of a
 // wave's row), written only where a bit is set; summ: [tile][row][wave] 8 bytes: the lanes whose mask words were written
-template <int NP, int TAIL, int PD, bool GM>
+template <int NP, int TAIL, int PD, int GM>
 __global__ __launch_bounds__(256, 1) void k_score_count3_bf16x3(const uint4* __restrict__ Ef3, const float* __restrict__ bias_pad,
                                                                  const uint4* __restrict__ Hf3, const float2* __restrict__ tband,
                                                                  int64_t B, int64_t rows_per_tile, int64_t total_rows,
@@ -774,14 +785,14 @@ __global__ __launch_bounds__(256, 1) void k_score_count3_bf16x3(const uint4* __r
     }
     uint4* mask_cur = mask + ((cur_tile * rows_per_tile + row) * 4 + wave) * MW;
     // block 0 (epilogue of the previous row's block 1 beside it: its last value completes that row's mask), then block 1
-    sc3_half<NP, TAIL, PD, GM, 0>(S, X, bias_pad, eb_next, lane, prev_valid, GM ? gmax + (eb_prev + 1) * (MB / 2) * gm_stride : nullptr, gm_col,
+    sc3_half<NP, TAIL, PD, GM, 0>(S, X, bias_pad, eb_next, lane, prev_valid, GM ? gmax + (eb_prev + 1) * sc3_gm_rows(GM) * gm_stride : nullptr, gm_col,
                                   mask_cur - 4 * MW, SSEQ);
-    sc3_half<NP, TAIL, PD, GM, 1>(S, X, bias_pad, eb_next + 1, lane, true, GM ? gmax + eb * (MB / 2) * gm_stride : nullptr, gm_col, mask_cur, SSEQ);
+    sc3_half<NP, TAIL, PD, GM, 1>(S, X, bias_pad, eb_next + 1, lane, true, GM ? gmax + eb * sc3_gm_rows(GM) * gm_stride : nullptr, gm_col, mask_cur, SSEQ);
     eb_prev = eb;
     prev_valid = true;
     if (last_of_tile) {
       // drain: block 1's accumulators have no next row of the same tile to hide behind
-      sc3_values<NP, TAIL, PD, GM, 1, 0>(S, lane, true, GM ? gmax + (eb + 1) * (MB / 2) * gm_stride : nullptr, gm_col, mask_cur, VSEQ);
+      sc3_values<NP, TAIL, PD, GM, 1, 0>(S, lane, true, GM ? gmax + (eb + 1) * sc3_gm_rows(GM) * gm_stride : nullptr, gm_col, mask_cur, VSEQ);
 #pragma unroll
       for (int b = 0; b < NB; ++b)
 #pragma unroll
@@ -1310,7 +1321,7 @@ int launch_filter_excess_bf16x3(coper_handle* h, const float* hvec, const int64_
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-template <int NP, int TAIL, bool GM>
+template <int NP, int TAIL, int GM>
 static int sc3_go(coper_handle* h, int64_t q0, int64_t Bc, int32_t* ng, float* gmax, int64_t gm_stride, hipStream_t s) {
   constexpr int NS = NP + TAIL;
 #ifdef COPER_SC3_PD
@@ -1348,7 +1359,11 @@ static int sc3_go(coper_handle* h, int64_t q0, int64_t Bc, int32_t* ng, float* g
 
 template <int NP, int TAIL>
 static int sc3_gm(coper_handle* h, int64_t q0, int64_t Bc, int32_t* ng, float* gmax, int64_t gm_stride, hipStream_t s) {
-  return gmax ? sc3_go<NP, TAIL, true>(h, q0, Bc, ng, gmax, gm_stride, s) : sc3_go<NP, TAIL, false>(h, q0, Bc, ng, gmax, gm_stride, s);
+  if (!gmax) return sc3_go<NP, TAIL, 0>(h, q0, Bc, ng, gmax, gm_stride, s);
+  if constexpr (SC3_MB == 4) {     // (64-entity maxima: the four 16-row blocks of an entity block)
+    if (topk_expand(h) == 2) return sc3_go<NP, TAIL, 2>(h, q0, Bc, ng, gmax, gm_stride, s);
+  }
+  return sc3_go<NP, TAIL, 1>(h, q0, Bc, ng, gmax, gm_stride, s);
 }
 
 // bytes of the band mask of a count launch over Bc queries: the words (16 bytes per lane and row of a wave), then the

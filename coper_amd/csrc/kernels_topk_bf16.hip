@@ -361,11 +361,29 @@ __global__ __launch_bounds__(TK_THREADS) void k_topk_threshold_emit(const float*
   __syncthreads();
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
-    if (!valid[c]) continue;
+    if (!valid[c] || !blk_cnt) continue;      // (blk_cnt == NULL: 64-entity candidates, counted after their expansion: k_topk_expand64)
     for (int64_t j = sr; j < slots[c]; j += SUB) {
       const int32_t g = cand_blk[off[c] + j];
       if (g >= 0) atomicAdd(&blk_cnt[(int64_t)g * nseg + ((off[c] + j) & (nseg - 1))], 1);
     }
+  }
+}
+
+// Large tables (topk_expand == 2): the threshold kernel worked on 64-entity block maxima; every candidate slot becomes two slots, the block's two
+// 32-entity halves (2g, 2g + 1) -- what the grouping, the re-scoring and the selection below are written for.  A query's slots
+// stay contiguous: [2 off, 2 (off + n)).
+__global__ __launch_bounds__(256) void k_topk_expand64(const int32_t* __restrict__ blk64, const int32_t* __restrict__ q64, int64_t T64,
+                                                       int32_t* __restrict__ cand_blk, int32_t* __restrict__ cand_q,
+                                                       int32_t* __restrict__ blk_cnt, int nseg) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= T64) return;
+  const int32_t g = blk64[j], q = q64[j];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int64_t j2 = 2 * j + u;
+    cand_blk[j2] = g >= 0 ? 2 * g + u : -1;
+    cand_q[j2] = q;
+    if (g >= 0) atomicAdd(&blk_cnt[(int64_t)(2 * g + u) * nseg + (j2 & (nseg - 1))], 1);
   }
 }
 
@@ -574,7 +592,7 @@ constexpr int TK_SURV = 256;   // survivors per query held in LDS
 __global__ __launch_bounds__(256) void k_topk_select_cand(float* __restrict__ cand_val, const int32_t* __restrict__ cand_blk,
                                                           const uint32_t* __restrict__ cand_tau, const int64_t* __restrict__ indptr,
                                                           int64_t B, int k, int64_t lo, float* __restrict__ out_val,
-                                                          int64_t* __restrict__ out_idx, const int32_t* __restrict__ x3s) {
+                                                          int64_t* __restrict__ out_idx, const int32_t* __restrict__ x3s, int xf) {
   __shared__ float s_v[4][TK_SURV];
   const int dexp = x3s ? -x3s[1] : 0;   // x3 mode: candidate values carry 2^(e_E + e_h); what is written out does not
   __shared__ int s_id[4][TK_SURV];
@@ -582,8 +600,8 @@ __global__ __launch_bounds__(256) void k_topk_select_cand(float* __restrict__ ca
   const int64_t q = (int64_t)blockIdx.x * 4 + wave;
   if (q >= B) return;
   const int64_t beg = indptr[q] - indptr[0];
-  const int64_t off = (int64_t)k * q + beg;
-  const int n = (int)((int64_t)k + (indptr[q + 1] - indptr[0] - beg)) * 32;
+  const int64_t off = xf * ((int64_t)k * q + beg);           // (xf = 2: slots expanded from 64-entity candidates)
+  const int n = xf * (int)((int64_t)k + (indptr[q + 1] - indptr[0] - beg)) * 32;
   float* val = cand_val + off * 32;
   const int32_t* blk = cand_blk + off;
   float* ov = out_val + q * k;
@@ -660,7 +678,8 @@ static bool tk_pair_xcd() {
 }
 
 template <int QV, int HCOPY>
-static void tk_launch_emit(coper_handle* h, int64_t G, int64_t qs, int64_t q0, int64_t bc, int k, const int64_t* indptr, hipStream_t s) {
+static void tk_launch_emit(coper_handle* h, int64_t G, int64_t qs, int64_t q0, int64_t bc, int k, const int64_t* indptr, hipStream_t s,
+                           int32_t* out_blk, int32_t* out_q, int32_t* out_cnt) {
   const size_t lds = tk_emit_lds<QV, HCOPY>();
   static uint64_t attr_done = 0;   // per instantiation, one bit per device (function attributes are per device)
   const uint64_t bit = 1ull << (h->cfg.device & 63);
@@ -669,47 +688,55 @@ static void tk_launch_emit(coper_handle* h, int64_t G, int64_t qs, int64_t q0, i
     attr_done |= bit;
   }
   hipLaunchKernelGGL((k_topk_threshold_emit<QV, HCOPY>), dim3((unsigned)(qs / (4 * QV))), dim3(TK_THREADS), lds, s, h->gmax_ws, G, qs, q0, bc,
-                     k, indptr, h->cand_blk_ws, h->cand_q_ws, h->blk_cnt_ws, topk_nseg(G), h->cand_tau_ws, tk_pair_xcd() ? 1 : 0);
+                     k, indptr, out_blk, out_q, out_cnt, topk_nseg(G), h->cand_tau_ws, tk_pair_xcd() ? 1 : 0);
 }
 
 // strip width / histogram copies of the threshold kernel by shape
-static void tk_dispatch_emit(coper_handle* h, int64_t G, int64_t qs, int64_t q0, int64_t bc, int k, const int64_t* indptr, hipStream_t s) {
+static void tk_dispatch_emit(coper_handle* h, int64_t G, int64_t qs, int64_t q0, int64_t bc, int k, const int64_t* indptr, hipStream_t s,
+                             int32_t* out_blk = nullptr, int32_t* out_q = nullptr, int32_t* out_cnt = nullptr) {
+  if (!out_blk) { out_blk = h->cand_blk_ws; out_q = h->cand_q_ws; out_cnt = h->blk_cnt_ws; }
   static const char* force = getenv("COPER_TK_EMIT");   // experiments: "8_1", "8_2", "4_4"
-  if (force && force[0] == '8' && force[2] == '1') return tk_launch_emit<8, 1>(h, G, qs, q0, bc, k, indptr, s);
-  if (force && force[0] == '8' && force[2] == '2') return tk_launch_emit<8, 2>(h, G, qs, q0, bc, k, indptr, s);
-  if (force && force[0] == '4') return tk_launch_emit<4, 4>(h, G, qs, q0, bc, k, indptr, s);
+  if (force && force[0] == '8' && force[2] == '1') return tk_launch_emit<8, 1>(h, G, qs, q0, bc, k, indptr, s, out_blk, out_q, out_cnt);
+  if (force && force[0] == '8' && force[2] == '2') return tk_launch_emit<8, 2>(h, G, qs, q0, bc, k, indptr, s, out_blk, out_q, out_cnt);
+  if (force && force[0] == '4') return tk_launch_emit<4, 4>(h, G, qs, q0, bc, k, indptr, s, out_blk, out_q, out_cnt);
   // long block axis: more histogram copies; half-width strips (twice the workgroups) when 32-query strips would
   // not cover the chip
-  if (G < 4096) tk_launch_emit<8, 1>(h, G, qs, q0, bc, k, indptr, s);
-  else if (qs / 32 >= h->num_cus) tk_launch_emit<8, 2>(h, G, qs, q0, bc, k, indptr, s);
-  else tk_launch_emit<4, 4>(h, G, qs, q0, bc, k, indptr, s);
+  if (G < 4096) tk_launch_emit<8, 1>(h, G, qs, q0, bc, k, indptr, s, out_blk, out_q, out_cnt);
+  else if (qs / 32 >= h->num_cus) tk_launch_emit<8, 2>(h, G, qs, q0, bc, k, indptr, s, out_blk, out_q, out_cnt);
+  else tk_launch_emit<4, 4>(h, G, qs, q0, bc, k, indptr, s, out_blk, out_q, out_cnt);
 }
 
 int launch_topk_pruned_bf16x3(coper_handle* h, const float* hvec, const float* tgt_x, const int64_t* e2, const int64_t* indptr,
                               const int64_t* idx, int64_t nnz, int64_t B, int k, int32_t* ng, int32_t* ne, float* topk_val,
                               int64_t* topk_idx, hipStream_t s) {
   const Dims& dm = h->dm;
-  const int64_t G = dm.n_eblk;
+  const int XF = topk_expand(h);            // 2: the count kernel writes 64-entity maxima (large tables), candidates are expanded below
+  const int64_t G = dm.n_eblk, Gm = G / XF;
   const int64_t qc = topk_chunk_queries(G, B, h->gmax_max_floats);
-  const int64_t T = (int64_t)k * B + nnz;   // candidate blocks: k + (filter entries) per query
-  if ((size_t)(G * qc) > h->gmax_cap || (size_t)T > h->cand_cap)
+  const int64_t T64 = (int64_t)k * B + nnz;   // candidate blocks: k + (filter entries) per query
+  const int64_t T = XF * T64;                 // ... as 32-entity slots
+  if ((size_t)(Gm * qc) > h->gmax_cap || (size_t)T > h->cand_cap)
     return fail(h, COPER_ESTATE, "pruned top-k: workspace not reserved");
   int rc;
   score_count_begin_bf16x3(h, B, ng, ne, s);
   // slots no query owns (filt_nnz may be a capacity larger than the CSR) must read as unused
-  COPER_HIP_TRY(h, hipMemsetAsync(h->cand_blk_ws, 0xFF, sizeof(int32_t) * T, s));
+  COPER_HIP_TRY(h, hipMemsetAsync(h->cand_blk_ws, 0xFF, sizeof(int32_t) * (T + (XF > 1 ? T64 : 0)), s));
   const int nseg = topk_nseg(G);
   const int64_t GV = G * nseg;   // (block, segment) counters
   COPER_HIP_TRY(h, hipMemsetAsync(h->blk_cnt_ws, 0, sizeof(int32_t) * 2 * GV, s));          // counts | scatter cursors
   COPER_HIP_TRY(h, hipMemsetAsync(h->cand_sorted_ws, 0xFF, sizeof(int32_t) * topk_sorted_cap(GV, T), s));
+  int32_t* blk64 = XF > 1 ? h->cand_blk_ws + T : nullptr;      // the 64-entity level's own lists, behind the expanded ones
+  int32_t* q64 = XF > 1 ? h->cand_q_ws + T : nullptr;
   for (int64_t q0 = 0; q0 < B; q0 += qc) {
     const int64_t bc = B - q0 < qc ? B - q0 : qc;
     const int64_t qs = (bc + 127) / 128 * 128;
     if ((rc = score_count3_chunk_bf16x3(h, q0, bc, hvec, tgt_x, e2, indptr, idx, ng, ne, h->gmax_ws, qs, s))) return rc;
-    // long block axis: more histogram copies; half-width strips (twice the workgroups) when 32-query strips would
-    // not cover the chip
-    tk_dispatch_emit(h, G, qs, q0, bc, k, indptr, s);
+    if (XF > 1) tk_dispatch_emit(h, Gm, qs, q0, bc, k, indptr, s, blk64, q64, nullptr);
+    else tk_dispatch_emit(h, G, qs, q0, bc, k, indptr, s);
   }
+  if (XF > 1)
+    hipLaunchKernelGGL(k_topk_expand64, dim3((unsigned)((T64 + 255) / 256)), dim3(256), 0, s, blk64, q64, T64, h->cand_blk_ws, h->cand_q_ws,
+                       h->blk_cnt_ws, nseg);
   tk_launch_blk_scan(h->blk_cnt_ws, GV, h->blk_off_ws, h->blk_off_ws + GV + 1, GV / TK_SCAN_CHUNK + 2, s);   // (chunk sums behind blk_off: reserved with it)
   hipLaunchKernelGGL(k_topk_blk_scatter, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, h->cand_blk_ws, T, h->blk_off_ws,
                      h->blk_cnt_ws + GV, nseg, h->cand_sorted_ws);
@@ -719,7 +746,7 @@ int launch_topk_pruned_bf16x3(coper_handle* h, const float* hvec, const float* t
                      indptr, idx, h->cand_blk_ws, h->cand_q_ws, h->blk_off_ws, h->cand_sorted_ws, (int64_t)h->cfg.shard_lo,
                      h->cand_val_ws, h->x3s);
   hipLaunchKernelGGL(k_topk_select_cand, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s, h->cand_val_ws, h->cand_blk_ws, h->cand_tau_ws, indptr, B,
-                     k, (int64_t)h->cfg.shard_lo, topk_val, topk_idx, h->x3s);
+                     k, (int64_t)h->cfg.shard_lo, topk_val, topk_idx, h->x3s, XF);
   COPER_HIP_TRY(h, hipGetLastError());
   return COPER_OK;
 }
@@ -747,7 +774,7 @@ int launch_topk_pruned_f32(coper_handle* h, const float* hvec, const float* tgt,
   }
   if ((rc = launch_topk_score_blocks_f32(h, hvec, T, e2, indptr, idx, s))) return rc;
   hipLaunchKernelGGL(k_topk_select_cand, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s, h->cand_val_ws, h->cand_blk_ws, h->cand_tau_ws, indptr, B,
-                     k, (int64_t)h->cfg.shard_lo, topk_val, topk_idx, (const int32_t*)nullptr);
+                     k, (int64_t)h->cfg.shard_lo, topk_val, topk_idx, (const int32_t*)nullptr, 1);
   COPER_HIP_TRY(h, hipGetLastError());
   return COPER_OK;
 }

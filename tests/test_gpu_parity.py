@@ -824,3 +824,34 @@ def test_fused_tail_path_edge_cases(oracle_chain, d, emb):
             ng, _ = O.rank_counts_c(logits, q["e2"], ipv, ixv)
             assert np.array_equal(r_fused.cpu().numpy(), 1 + ng) and torch.equal(r_fused, r_two), (B, len(ixv))
     m.close()
+
+
+@pytest.mark.parametrize("d", [200, 256])
+def test_topk_block_maxima_granularity(oracle_chain, d, monkeypatch):
+    """The x3 count kernel writes one block maximum per 32 entities on small tables and per 64 on large ones (from 65,536 rows on;
+    kernels_score3_bf16.hip GM = 1 / 2, candidates expanded by k_topk_expand64).  Both routes forced on one mid-sized table, several
+    query chunks, heavy filters and k up to 128: identical top-k ids and values, identical counts, and both equal to the masked
+    row's top-k of the mode's own logits."""
+    O = oracle_chain
+    md = cdata.model_descriptors("fb15k237_cpg" if d == 200 else "synth10m_cpg", num_ent=5000, num_rel=12)
+    p = cdata.synthetic_params(md, 3)
+    q = cdata.synthetic_queries(md, 700, seed=4, mean_filter=20.0, max_filter=400)
+    monkeypatch.setenv("COPER_TOPK_CHUNK_QUERIES", "256")
+    outs = {}
+    for xf in ("1", "2"):
+        monkeypatch.setenv("COPER_TOPK_EXPAND", xf)
+        m = _model(md, p, score_mode="bf16x3")
+        h = m.encode(q["e1"], q["rel"])
+        tgt = m.target_scores(h, q["e2"])
+        logits = m.score_all(h).cpu().numpy()
+        res = {}
+        for k in (1, 10, 33, 128):
+            ng, ne, tv, ti = m.rank_counts(h, tgt, q["e2"], q["filt_indptr"], q["filt_idx"], k=k)
+            ev, ei = O.topk_filtered(logits, q["e2"], q["filt_indptr"], q["filt_idx"], k)
+            assert np.array_equal(ti.cpu().numpy(), ei) and np.array_equal(tv.cpu().numpy(), ev), (xf, k)
+            res[k] = (ng.cpu().numpy(), ne.cpu().numpy(), tv.cpu().numpy(), ti.cpu().numpy())
+        outs[xf] = res
+        m.close()
+    for k in outs["1"]:
+        for a, b in zip(outs["1"][k], outs["2"][k]):
+            assert np.array_equal(a, b), k
