@@ -227,7 +227,7 @@ COPER_API int coper_score_rows(coper_handle* h, const float* hvec, const float* 
  * k > 0 additionally returns the shard's top-k of the FILTERED row (target kept, like
  * metrics.py:46), order (score desc, id asc): topk_val [B,k] (-inf padded), topk_idx [B,k]
  * global ids (-1 padded).  k == 0: both may be NULL.  Not needed for ranks.  k <= 128 selects from
- * per-block maxima written by the count pass (no logits; workspace: one float per (32 entities, query) of a
+ * per-block maxima written by the count pass (no logits; workspace: one float per (32 entities, query) -- per (64 entities, query) on shards of 65,536 rows and more -- of a
  * query chunk + 32 floats per (k + filter entries)); otherwise logits are materialised chunk by chunk (<= 256 MiB). */
 COPER_API int coper_rank_counts(coper_handle* h, const float* hvec, const float* tgt, const int64_t* e2,
                       const int64_t* filt_indptr, const int64_t* filt_idx, int64_t filt_nnz, int64_t B, int32_t k,
