@@ -277,6 +277,7 @@ inline int topk_expand(const coper_handle* h) {
 #if defined(COPER_SC3_MB) && COPER_SC3_MB != 4
   return 1;                                                    // (A/B builds with 32-entity blocks per wave)
 #endif
+  if (h->dm.KS16 != 13 && h->dm.KS16 != 16) return 1;          // (the 64-entity form is instantiated for d = 200 and 256 only: build time)
   if (force && (force[0] == '1' || force[0] == '2')) return force[0] - '0';
   return h->dm.n_local >= 65536 ? 2 : 1;
 }
