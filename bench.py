@@ -69,8 +69,9 @@ def _profile_entry(pattern, workload, Q, kernel, exact=None):
         except Exception:
             continue
         if exact:
-            if exact in d.get("kernels", {}):
-                return d["kernels"][exact], os.path.relpath(path, ROOT)
+            hit = [e for e in ((exact,) if isinstance(exact, str) else exact) if e in d.get("kernels", {})]
+            if hit:
+                return d["kernels"][hit[0]], os.path.relpath(path, ROOT)
             continue
         if d.get("workload") != workload or d.get("queries") != Q:
             continue
@@ -310,7 +311,7 @@ def run_scale_blocks(ctx, args):
     model.profile(False)
     if n:
         out["hbm_regime"] = score_roofline(ctx, score_kernel_name("bf16x3", d), "bf16x3", HBM_REGIME_QUERIES, model.n_local, d, ms / n,
-                                           SCALE_WORKLOAD, exact="coper::k_score_count3_bf16x3<8, 0, 2, false>")
+                                           SCALE_WORKLOAD, exact="coper::k_score_count3_bf16x3<8, 0, 2, 0>")      # (no block maxima)
         out["hbm_regime"]["kernel"] = score_kernel_name("bf16x3", d)
     # (2) the entity-sharded pass, top-10 exchanged
     Q = cdata.CONFIGS[SCALE_WORKLOAD]["queries"]
@@ -337,7 +338,7 @@ def run_scale_blocks(ctx, args):
     if n:
         kn = score_kernel_name("bf16x3", d)
         blk["roofline"] = dict(kernel=kn, **score_roofline(ctx, kn, "bf16x3", Q, model.n_local, d, ms / n, SCALE_WORKLOAD,
-                                                           want_pmc=ctx.world == 1, exact="coper::k_score_count3_bf16x3<8, 0, 2, true>"))
+                                                           want_pmc=ctx.world == 1, exact="coper::k_score_count3_bf16x3<8, 0, 2, 2>"))     # (64-entity block maxima: the top-k launch of a large table)
     exp = SCALE_EXPECTED
     if exp.get("ranks_sha1"):
         # checked by main() AFTER the JSON line is out (every rank must first get through the collectives that follow; the line
