@@ -111,8 +111,12 @@ def test_bench_finds_the_committed_pmc_summaries():
     bench.pmc_traffic(d, "fb15k237_cpg", 20480, "coper::k_dense_fused_bf16x3")
     assert 0.9e9 < d["traffic"] < 1.2e9
     h = {}
-    bench.pmc_traffic(h, "synth10m_cpg", 128, "coper::k_score_count3_bf16x3", exact="coper::k_score_count3_bf16x3<8, 0, 2, false>")
+    bench.pmc_traffic(h, "synth10m_cpg", 128, "coper::k_score_count3_bf16x3", exact="coper::k_score_count3_bf16x3<8, 0, 2, 0>")
     assert 1.0e10 < h["traffic"] < 1.15e10        # the 10M x 256 table read once: PMC bytes within 1.1x of the algorithmic 10.28 GB
+    assert "r04d" in h["traffic_source"]          # (the instantiation's name since the block-maxima mode became an integer)
+    t = {}
+    bench.pmc_traffic(t, "synth10m_cpg", 4096, "coper::k_score_count3_bf16x3", exact="coper::k_score_count3_bf16x3<8, 0, 2, 2>")
+    assert 8.0e9 < t["traffic"] < 1.0e10          # the top-k launch: the table through L2 / MALL for 32 query tiles + 1.5 GB of 64-entity maxima
     none = {}
     bench.pmc_traffic(none, "no_such_workload", 1, "coper::k_nothing")
     assert none["traffic"] is None and "traffic_source" not in none
