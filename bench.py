@@ -114,6 +114,7 @@ def parse_args():
                          "costs the stream a few microseconds of pipeline drain; 1 = every step)")
     ap.add_argument("--topk", type=int, default=0,
                     help="entity mode: also select and exchange the per-shard top-k of the filtered rows (SURVEY 8(e) step 3)")
+    ap.add_argument("--no-post-next", action="store_true", help="--h2d overlap with the ranks copied out by a launch of their own behind every pass (A/B against coper_post_i32_next)")
     ap.add_argument("--h2d", choices=["overlap", "kernel", "sdma"], default="overlap",
                     help="how a pass's pinned int32 batch reaches the device: read over PCIe by extra workgroups of the PREVIOUS pass's "
                          "encoder launch (coper_stage_ids_next), by coper_widen_ids in front of the pass (one launch), or by a "
@@ -597,6 +598,8 @@ def main():
                                    out=ranks_dev)
             if args.h2d == "sdma":
                 out_host.copy_(r, non_blocking=True)
+            elif args.h2d == "overlap" and not args.no_post_next:
+                model.post_next(r, out_host)               # ... and this pass's ranks go out beside the NEXT pass's first launch (coper_post_i32_next)
             else:
                 model.copy_out(r, out_host)                # posted writes to the pinned buffer, right behind the last kernel
             if args.h2d == "overlap":
@@ -606,6 +609,7 @@ def main():
         pcie_step = counted(pcie_step)
         for _ in range(max(1, args.warmup)):
             pcie_step()
+        model.post_flush()                                 # (the last pass's ranks: nothing follows that would carry them out)
         torch.cuda.synchronize(device)
         assert np.array_equal(out_host.numpy(), ranks_np)
         if extras:
@@ -714,6 +718,8 @@ def main():
                       "note": "largest |logit_x3 - logit_fp32chain| / (tau_q / 2) over the pairs the band walks decided; the mode's ranks are "
                               "the fp32 chain's while this stays below 1 (tests assert <= 0.5 at every operand scale)"}
     if pcie_step is not None:
+        model.post_flush()
+        torch.cuda.synchronize(device)
         assert np.array_equal(out_host.numpy(), ranks_np)
     assert np.array_equal(res[0].cpu().numpy(), ranks_np)
     kern = {}
@@ -748,7 +754,7 @@ def main():
                 "score_mode": "f32 (v_mfma_f32_32x32x2_f32, exact)" if args.score_mode == "f32" else
                 "bf16x3 = the x3 mode (API name kept): fp16 split since round 3, 3 x v_mfma_f32_16x16x32_f16 (two K = 16 steps each) per "
                 "pair of products, ~2^-22 rel.; exact band decided by the fp32 chain", "prepare_ms": round(prepare_ms, 2),
-                "inputs": ("SURVEY 8(d) region: every pass brings a batch of ids + CSR filters (int32 in pinned host memory, " + ({"overlap": "the NEXT pass's batch, read over PCIe and widened by extra workgroups of this pass's encoder launch: coper_stage_ids_next", "kernel": "read over PCIe and widened by one launch of coper_widen_ids in front of the pass", "sdma": "one copy-engine H2D, widened on the device"}[args.h2d]) + ") in and copies its int32 "
+                "inputs": ("SURVEY 8(d) region: every pass brings a batch of ids + CSR filters (int32 in pinned host memory, " + ({"overlap": "the NEXT pass's batch, read over PCIe and widened by extra workgroups of this pass's encoder launch: coper_stage_ids_next" + ("" if args.no_post_next else "; the ranks of a pass are posted to pinned host memory by extra blocks of the next pass's first launch: coper_post_i32_next"), "kernel": "read over PCIe and widened by one launch of coper_widen_ids in front of the pass", "sdma": "one copy-engine H2D, widened on the device"}[args.h2d]) + ") in and copies its int32 "
                            "ranks back to pinned host memory (D2H), %d bytes per pass, inside the timed region; one stream"
                            % pcie_bytes) if pcie_step is not None
                 else "ids + CSR filters resident in HBM before the timed region",

@@ -636,6 +636,13 @@ COPER_API int coper_stage_ids_next(coper_handle* h, const int32_t* src, int64_t 
   return COPER_OK;
 }
 
+COPER_API int coper_post_i32_next(coper_handle* h, const int32_t* src, int64_t n, int32_t* dst) {
+  if (!h) return COPER_EINVAL;
+  if (n < 0 || (n > 0 && (!src || !dst))) return fail(h, COPER_EINVAL, "coper_post_i32_next: bad argument");
+  h->post_src = src; h->post_n = n; h->post_dst = dst;
+  return COPER_OK;
+}
+
 COPER_API int coper_gather_entities(coper_handle* h, const int64_t* ids, int64_t B, float* out, void* stream) {
   COPER_REQUIRE_PREPARED(h);
   if (B == 0) return COPER_OK;

@@ -110,6 +110,9 @@ struct coper_handle {
   const int32_t* stage_src = nullptr;   // coper_stage_ids_next: a batch to bring in beside the next encoder launch (stage_n > 0: pending)
   int64_t stage_n = 0;
   int64_t* stage_dst = nullptr;
+  const int32_t* post_src = nullptr;    // coper_post_i32_next: int32 results to copy out beside the next grouping launch (post_n > 0: pending)
+  int64_t post_n = 0;
+  int32_t* post_dst = nullptr;
   void* fused_fin_dev = nullptr;     // FusedFinConst (kernels_dense_fused_bf16.hip): the fused encoder's finalize constants, in device memory
   const int32_t* fused_fin_perm = nullptr;   //   the workspace generation they were written for
   int32_t* w_exp = nullptr;          // [Rw] e_W per relation: the dense-weight planes hold W_r 2^e_W (split16.h; prepare)

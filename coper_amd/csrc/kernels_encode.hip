@@ -152,9 +152,21 @@ __global__ __launch_bounds__(HIST_BLOCK) void k_rel_hist_scan(const int64_t* __r
                                                                int64_t R_all, int32_t* __restrict__ acc, int32_t* __restrict__ count,
                                                                int32_t* __restrict__ done, int64_t cap_small,
                                                                int32_t* __restrict__ offset, int32_t* __restrict__ tiles,
-                                                               int32_t* __restrict__ n_tiles, int32_t* __restrict__ cursor) {
+                                                               int32_t* __restrict__ n_tiles, int32_t* __restrict__ cursor,
+                                                               int n_hist_blocks, const int32_t* __restrict__ post_src, int64_t post_n,
+                                                               int32_t* __restrict__ post_dst) {
   extern __shared__ int32_t sh[];   // [R]
   __shared__ int s_last;
+  // Posting role (coper_post_i32_next): the blocks behind the histogram's copy the LAST pass's int32 results (its ranks) to
+  // pinned host memory while this pass's histogram runs -- the copy that used to be a launch of its own behind every pass.
+  if ((int)blockIdx.x >= n_hist_blocks) {
+    const int64_t nb = (int64_t)gridDim.x - n_hist_blocks, b = (int64_t)blockIdx.x - n_hist_blocks;
+    const bool vec = ((((uintptr_t)post_src) | ((uintptr_t)post_dst)) & 15) == 0;
+    const int64_t n4 = vec ? post_n / 4 : 0;
+    for (int64_t i = b * HIST_BLOCK + threadIdx.x; i < n4; i += nb * HIST_BLOCK) ((int4*)post_dst)[i] = ((const int4*)post_src)[i];
+    for (int64_t i = 4 * n4 + b * HIST_BLOCK + threadIdx.x; i < post_n; i += nb * HIST_BLOCK) post_dst[i] = post_src[i];
+    return;
+  }
   int32_t* bad = acc + R_all + 1;
   for (int k = threadIdx.x; k < R; k += HIST_BLOCK) sh[k] = 0;
   __syncthreads();
@@ -169,7 +181,7 @@ __global__ __launch_bounds__(HIST_BLOCK) void k_rel_hist_scan(const int64_t* __r
     if (sh[k]) atomicAdd(&acc[k], sh[k]);
   __threadfence();
   __syncthreads();
-  if (threadIdx.x == 0) s_last = atomicAdd(done, 1) == (int)gridDim.x - 1 ? 1 : 0;
+  if (threadIdx.x == 0) s_last = atomicAdd(done, 1) == n_hist_blocks - 1 ? 1 : 0;
   __syncthreads();
   if (!s_last) return;
   for (int k = threadIdx.x; k < R; k += HIST_BLOCK) {
@@ -300,6 +312,12 @@ int launch_group_by_relation(coper_handle* h, const int64_t* e1, const int64_t* 
                              hipStream_t s) {
   const Dims& dm = h->dm;
   int64_t R = dm.gen_fc ? dm.R : 1;
+  if (h->post_n > 0 && !(R <= HIST_LDS_MAX && B > 4096)) {     // (a pending coper_post_i32_next rides in the two-launch path only)
+    const int64_t pn = h->post_n;
+    h->post_n = 0;
+    int rc0 = launch_copy_i32(h, h->post_src, pn, h->post_dst, s);
+    if (rc0) return rc0;
+  }
   // rel_count (= rel_count_buf[0]) holds the counts of the last call; rel_count_buf[1] is the accumulation buffer of the
   // two-launch path, zero between calls (its last block takes the totals out with atomic exchanges).  No host-side state
   // changes per call: every path below is hipGraph-capturable and replayable, alone or mixed with eager calls.
@@ -316,10 +334,17 @@ int launch_group_by_relation(coper_handle* h, const int64_t* e1, const int64_t* 
   unsigned nb = (unsigned)((B + HIST_BLOCK - 1) / HIST_BLOCK);
   (void)tq;
   if (R <= HIST_LDS_MAX) {
-    // two launches: histogram + scan (last block), scatter
-    hipLaunchKernelGGL(k_rel_hist_scan, dim3(nb), dim3(HIST_BLOCK), sizeof(int32_t) * (size_t)R, s, rel, B, dm.gen_fc ? 1 : 0, R,
+    // two launches: histogram + scan (last block), scatter.  A pending coper_post_i32_next rides in the first one.
+    unsigned npost = 0;
+    const int32_t* psrc = h->post_src; const int64_t pn = h->post_n; int32_t* pdst = h->post_dst;
+    if (pn > 0) {
+      npost = (unsigned)((pn + 4 * HIST_BLOCK - 1) / (4 * HIST_BLOCK));
+      if (npost > 32) npost = 32;
+      h->post_n = 0;
+    }
+    hipLaunchKernelGGL(k_rel_hist_scan, dim3(nb + npost), dim3(HIST_BLOCK), sizeof(int32_t) * (size_t)R, s, rel, B, dm.gen_fc ? 1 : 0, R,
                        (int64_t)dm.R, h->rel_count_buf[1], h->rel_count, h->group_done, small_tile_cap(h), h->rel_offset, h->tiles,
-                       h->n_tiles, h->rel_cursor);
+                       h->n_tiles, h->rel_cursor, (int)nb, psrc, pn, pdst);
     hipLaunchKernelGGL(k_rel_scatter, dim3(nb), dim3(HIST_BLOCK), sizeof(int32_t) * (size_t)R, s, rel, B, dm.gen_fc ? 1 : 0, R,
                        h->rel_offset, h->rel_cursor, h->perm, e1, have_e1_rows ? 1 : 0, (int64_t)h->cfg.shard_lo, dm.n_local, dm.R,
                        h->sorted_row, h->sorted_rid, h->inv_perm, h->x3m);

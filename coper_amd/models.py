@@ -328,6 +328,27 @@ class ConvE(object):
         _lib.check(self._h, self._lib.coper_copy_out_i32(self._h, _ptr(src), src.numel(), C.c_void_p(dst.data_ptr()), self._stream()))
         return dst
 
+    def post_next(self, src: torch.Tensor, dst: torch.Tensor):
+        """coper_post_i32_next: `src` (int32, device: the ranks of the pass just queued) is copied to `dst` (pinned host memory, or
+        the device) beside the first launch of the NEXT encode / rank_pass on this model instead of by a launch of its own.  Follow
+        the last pass of a loop with `copy_out(src, dst)`; synchronise before reading dst."""
+        if src.dtype != torch.int32 or dst.dtype != torch.int32 or src.numel() != dst.numel() or not (src.is_contiguous() and dst.is_contiguous()):
+            raise ValueError("post_next: two contiguous int32 tensors of one size")
+        if src.device != self.device or (dst.device.type == "cpu" and not dst.is_pinned()):
+            raise ValueError("post_next: src on %s, dst there or in pinned host memory" % self.device)
+        self._post_keep = (src, dst)
+        _lib.check(self._h, self._lib.coper_post_i32_next(self._h, _ptr(src), src.numel(), C.c_void_p(dst.data_ptr())))
+
+    def post_flush(self):
+        """The end of a loop of `post_next` passes: the registration of the last one is withdrawn and its copy issued now
+        (coper_copy_out_i32).  Synchronise before reading the destination."""
+        keep = getattr(self, "_post_keep", None)
+        if keep is None:
+            return
+        self._post_keep = None
+        _lib.check(self._h, self._lib.coper_post_i32_next(self._h, None, 0, None))
+        self.copy_out(*keep)
+
     def gather_entities(self, ids):
         self._need_prepared()
         ids = self._ids(ids)

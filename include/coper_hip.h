@@ -176,6 +176,13 @@ COPER_API int coper_stage_ids_next(coper_handle* h, const int32_t* src, int64_t 
  * starts ~12 us later on this runtime).  The host reads dst after synchronising with the stream. */
 COPER_API int coper_copy_out_i32(coper_handle* h, const int32_t* src, int64_t n, int32_t* dst, void* stream);
 
+/* The same copy, overlapped: registers (src, n, dst) as a job the NEXT call on this handle that groups a batch by relation
+ * (coper_encode, coper_encode_rank, a training step) carries out beside its first launch, on that call's stream: the ranks of pass
+ * n reach the host under pass n + 1's histogram instead of through a launch of their own behind pass n.  src must stay
+ * unchanged until then (it is: the next pass writes its ranks in its third launch); the last pass of a loop is followed by
+ * coper_copy_out_i32.  A later registration replaces a job that has not run; n == 0 cancels.  Nothing is queued by this call. */
+COPER_API int coper_post_i32_next(coper_handle* h, const int32_t* src, int64_t n, int32_t* dst);
+
 /* Row gather tf.nn.embedding_lookup(ent_emb, ids) (models.py:176) restricted to the shard:
  * out[b,:] = ent_emb[ids[b]] if shard_lo <= ids[b] < shard_hi else 0.  (Multi-GPU: sum over
  * ranks = the full gather.)  out: [B, d]. */

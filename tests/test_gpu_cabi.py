@@ -275,3 +275,42 @@ def test_stage_ids_next_brings_the_next_batch_in_beside_the_encoder(workload):
         assert np.array_equal(dst.cpu().numpy(), np.full(n, -3))
     assert m._lib.coper_stage_ids_next(m._h, None, 5, None) == 1
     m.close()
+
+
+@pytest.mark.parametrize("Q", [6000, 700])      # the two-launch grouping (the job rides in its first launch) / the single-workgroup one (a launch of its own)
+def test_post_i32_next_copies_the_last_ranks_beside_the_next_grouping(Q):
+    """coper_post_i32_next: the ranks of pass n, registered after it was queued, reach pinned host memory during pass n + 1 -- not
+    before -- and pass n + 1's own ranks are not disturbed; a withdrawn registration copies nothing."""
+    from coper_amd import _lib
+    from coper_amd.models import ConvE
+    md = cdata.model_descriptors("fb15k237_cpg", num_ent=4000)
+    p = cdata.synthetic_params(md, 5)
+    qa, qb = cdata.synthetic_queries(md, Q, seed=31), cdata.synthetic_queries(md, Q, seed=32)
+    m = ConvE(md, device="cuda:0", score_mode="bf16x3").load_parameters(p).prepare()
+    ra = _encode_rank(m, qa["e1"], qa["rel"], qa["e2"], qa["filt_indptr"], qa["filt_idx"], False)
+    rb = _encode_rank(m, qb["e1"], qb["rel"], qb["e2"], qb["filt_indptr"], qb["filt_idx"], False)
+    assert not np.array_equal(ra, rb)
+    ranks = torch.empty((Q,), dtype=torch.int32, device="cuda:0")
+    host = torch.full((Q,), -5, dtype=torch.int32).pin_memory()
+    r1, _ = m.rank_pass(qa["e1"], qa["rel"], qa["e2"], qa["filt_indptr"], qa["filt_idx"], want_equal=False, out=ranks)
+    m.post_next(ranks, host)
+    torch.cuda.synchronize()
+    assert np.array_equal(host.numpy(), np.full(Q, -5))                 # nothing is queued by the registration
+    keep = ranks.clone()
+    r2, _ = m.rank_pass(qb["e1"], qb["rel"], qb["e2"], qb["filt_indptr"], qb["filt_idx"], want_equal=False, out=ranks)
+    torch.cuda.synchronize()
+    assert np.array_equal(host.numpy(), ra) and np.array_equal(keep.cpu().numpy(), ra)    # pass n's ranks, copied before pass n + 1 wrote its own
+    assert np.array_equal(ranks.cpu().numpy(), rb)
+    # the job ran once; a withdrawn registration copies nothing; post_flush copies at once
+    host.fill_(-9)
+    m.post_next(ranks, host)
+    assert m._lib.coper_post_i32_next(m._h, None, 0, None) == 0
+    m.rank_pass(qa["e1"], qa["rel"], qa["e2"], qa["filt_indptr"], qa["filt_idx"], want_equal=False)
+    torch.cuda.synchronize()
+    assert np.array_equal(host.numpy(), np.full(Q, -9))
+    m.post_next(ranks, host)
+    m.post_flush()
+    torch.cuda.synchronize()
+    assert np.array_equal(host.numpy(), ranks.cpu().numpy())
+    assert m._lib.coper_post_i32_next(m._h, None, 5, None) == 1
+    m.close()
