@@ -17,3 +17,12 @@ def test_soak_short(seed):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak.py"), "14", str(seed)], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert "all ranks == the fp32 chain's" in out.stdout
+
+
+def test_eval_stream_example():
+    """examples/eval_stream.py: passes whose batches arrive beside the previous pass's encoder (coper_stage_ids_next) and whose ranks
+    leave beside the next pass's first launch (coper_post_i32_next) -- the script itself checks every pass against a plain one."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "eval_stream.py"), "--batches", "5", "--queries", "6000"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert "5 passes of 6000 queries" in out.stdout
