@@ -251,30 +251,50 @@ __global__ __launch_bounds__(64 * TL_WAVES, KS <= 13 ? 3 : 2) void k_finalize_ta
   // ---- 1. the block's fragments: wave w takes k-steps w, w + 4, ...; a lane scales and splits piece (ks, half) of its query's
   // fp32 row (the encoder's epilogue or k_finalize_h_publish wrote it), with the batch's exponent reduced from x3m
   static_assert(TL_WAVES == 4, "x3_batch_exp: 256 threads");
-  const int eh = x3_batch_exp(x3m, ent_exp, x3s, &s_n2[0][0]), sexp = eh + ent_exp;
-  const int32_t x3l[2] = {eh, sexp};      // (what x3s holds once block 0 has published: this kernel must not read it back)
+  int eh, sexp;
+  int32_t x3l[2];                         // (what x3s holds once block 0 has published: this kernel must not read it back)
+#ifdef COPER_TL_H_AFTER_EXP      /* the round-4 form before this one: the h rows requested after the exponent's reduction */
+  eh = x3_batch_exp(x3m, ent_exp, x3s, &s_n2[0][0]); sexp = eh + ent_exp; x3l[0] = eh; x3l[1] = sexp;
   __syncthreads();                        // (s_n2 served as the reduction's scratch)
+#endif
   {
     const bool vec_ok = (d & 3) == 0 && (((uintptr_t)h_rows) & 15) == 0;
+    constexpr int NKW = (KS + TL_WAVES - 1) / TL_WAVES;      // k-steps of a wave
+    float yv[NKW][8];
+    // the wave's pieces of the fp32 rows are requested BEFORE the exponent is reduced (they do not depend on it): one memory
+    // latency of the block's start lies under the other
+#pragma unroll
+    for (int u = 0; u < NKW; ++u) {
+      const int ks = wave + TL_WAVES * u;
+      const int k0 = 16 * ks + 8 * half;
+      if (ks < KS) {
+        if (live && k0 + 8 <= d && vec_ok) {
+          const float4 a = *(const float4*)(h_rows + q * d + k0), b = *(const float4*)(h_rows + q * d + k0 + 4);
+          yv[u][0] = a.x; yv[u][1] = a.y; yv[u][2] = a.z; yv[u][3] = a.w; yv[u][4] = b.x; yv[u][5] = b.y; yv[u][6] = b.z; yv[u][7] = b.w;
+        } else {
+#pragma unroll
+          for (int c = 0; c < 8; ++c) yv[u][c] = (live && k0 + c < d) ? h_rows[q * d + k0 + c] : 0.f;
+        }
+      }
+    }
+#ifndef COPER_TL_H_AFTER_EXP
+    eh = x3_batch_exp(x3m, ent_exp, x3s, &s_n2[0][0]); sexp = eh + ent_exp; x3l[0] = eh; x3l[1] = sexp;
+    __syncthreads();                        // (s_n2 served as the reduction's scratch)
+#endif
     float n2 = 0.f;
 #pragma unroll
-    for (int ks = wave; ks < KS; ks += TL_WAVES) {
-      const int k0 = 16 * ks + 8 * half;
-      float y[8];
-      if (live && k0 + 8 <= d && vec_ok) {
-        const float4 a = *(const float4*)(h_rows + q * d + k0), b = *(const float4*)(h_rows + q * d + k0 + 4);
-        y[0] = a.x; y[1] = a.y; y[2] = a.z; y[3] = a.w; y[4] = b.x; y[5] = b.y; y[6] = b.z; y[7] = b.w;
-      } else {
+    for (int u = 0; u < NKW; ++u) {
+      const int ks = wave + TL_WAVES * u;
+      if (ks < KS) {
+        float y[8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) y[c] = (live && k0 + c < d) ? h_rows[q * d + k0 + c] : 0.f;
+        for (int c = 0; c < 8; ++c) { n2 = fmaf(yv[u][c], yv[u][c], n2); y[c] = x3_scale(yv[u][c], eh); }
+        uint4 h4, l4;
+        split8_bf16(y, h4, l4);
+        f3_store_piece(hf3, KS, q, ks, half, h4, l4, true);   // rows past B: zero pieces (the count kernel's tile is whole)
+        s_bh[ks][lane] = h4;
+        s_bl[ks][lane] = l4;
       }
-#pragma unroll
-      for (int c = 0; c < 8; ++c) { n2 = fmaf(y[c], y[c], n2); y[c] = x3_scale(y[c], eh); }
-      uint4 h4, l4;
-      split8_bf16(y, h4, l4);
-      f3_store_piece(hf3, KS, q, ks, half, h4, l4, true);   // rows past B: zero pieces (the count kernel's tile is whole)
-      s_bh[ks][lane] = h4;
-      s_bl[ks][lane] = l4;
     }
     n2 += __shfl_xor(n2, 32);
     if (half == 0) s_n2[wave][i] = n2;
