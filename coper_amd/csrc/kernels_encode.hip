@@ -312,7 +312,13 @@ int launch_group_by_relation(coper_handle* h, const int64_t* e1, const int64_t* 
                              hipStream_t s) {
   const Dims& dm = h->dm;
   int64_t R = dm.gen_fc ? dm.R : 1;
-  if (h->post_n > 0 && !(R <= HIST_LDS_MAX && B > 4096)) {     // (a pending coper_post_i32_next rides in the two-launch path only)
+  bool post_now = h->post_n > 0;
+  if (post_now) {      // (a pass being captured into a hipGraph leaves the job to the next eager call: a replay must not repeat it)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); post_now = false; }
+    else if (cap != hipStreamCaptureStatusNone) post_now = false;
+  }
+  if (post_now && !(R <= HIST_LDS_MAX && B > 4096)) {     // (a pending coper_post_i32_next rides in the two-launch path only)
     const int64_t pn = h->post_n;
     h->post_n = 0;
     int rc0 = launch_copy_i32(h, h->post_src, pn, h->post_dst, s);
@@ -337,7 +343,7 @@ int launch_group_by_relation(coper_handle* h, const int64_t* e1, const int64_t* 
     // two launches: histogram + scan (last block), scatter.  A pending coper_post_i32_next rides in the first one.
     unsigned npost = 0;
     const int32_t* psrc = h->post_src; const int64_t pn = h->post_n; int32_t* pdst = h->post_dst;
-    if (pn > 0) {
+    if (pn > 0 && post_now) {
       npost = (unsigned)((pn + 4 * HIST_BLOCK - 1) / (4 * HIST_BLOCK));
       if (npost > 32) npost = 32;
       h->post_n = 0;

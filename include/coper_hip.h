@@ -180,7 +180,8 @@ COPER_API int coper_copy_out_i32(coper_handle* h, const int32_t* src, int64_t n,
  * (coper_encode, coper_encode_rank, a training step) carries out beside its first launch, on that call's stream: the ranks of pass
  * n reach the host under pass n + 1's histogram instead of through a launch of their own behind pass n.  src must stay
  * unchanged until then (it is: the next pass writes its ranks in its third launch); the last pass of a loop is followed by
- * coper_copy_out_i32.  A later registration replaces a job that has not run; n == 0 cancels.  Nothing is queued by this call. */
+ * coper_copy_out_i32.  A later registration replaces a job that has not run; n == 0 cancels; a call that is being captured into
+ * a hipGraph leaves the job to the next eager one.  Nothing is queued by this call. */
 COPER_API int coper_post_i32_next(coper_handle* h, const int32_t* src, int64_t n, int32_t* dst);
 
 /* Row gather tf.nn.embedding_lookup(ent_emb, ids) (models.py:176) restricted to the shard:
