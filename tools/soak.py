@@ -10,6 +10,8 @@ answers in one row, duplicates of the target).  Checked per case:
   * the pruned top-k of the filtered rows (k drawn from 1 - 128; logits never materialised by the library) == a stable sort of
     the masked rows of the mode's own score_all logits: ids and values, (score desc, id asc), for every query (cases whose
     logit matrix stays under 2^26 elements).
+  * every fourth case: the entity table cut at random rows into 2 - 3 shard handles, the exchange done by hand --
+    gathered e1 rows, summed targets, summed counts, merged top-k -- equal to the unsharded handle's ranks, tie counts and top-k.
 Prints one line per case and a summary; exits non-zero on the first mismatch."""
 import os
 import sys
@@ -95,16 +97,35 @@ def main():
             ev[:, :kk] = sv[:, :kk]; ei[:, :kk] = si[:, :kk]
             ei[ev == float("-inf")] = -1
             topk_ok = torch.equal(ti.to(torch.int64), ei) and torch.equal(tv, ev) and torch.equal(ng_k + 1, r32)
+        shards_ok = True
+        if c % 4 == 3 and E >= 8:
+            from coper_amd.sharding import merge_topk
+            cuts = sorted(set(int(x) for x in rng.integers(1, E, size=int(rng.integers(1, 3)))))
+            bounds = list(zip([0] + cuts, cuts + [E]))
+            ks = max(1, min(4, min(hi - lo for lo, hi in bounds)))
+            shs = [ConvE(md, device="cuda:0", score_mode="bf16x3", shard=b, band_audit_period=1).load_parameters(p).prepare() for b in bounds]
+            rows = sum(s_.gather_entities(q["e1"]) for s_ in shs)
+            hs = shs[-1].encode(q["e1"], q["rel"], e1_rows=rows)
+            tg = sum(s_.target_scores(hs, q["e2"]) for s_ in shs)
+            outs = [s_.rank_counts(hs, tg, q["e2"], q["filt_indptr"], q["filt_idx"], k=ks) for s_ in shs]
+            ng_f, ne_f, tv_f, ti_f = m.rank_counts(h2, m.target_scores(h2, q["e2"]), q["e2"], q["filt_indptr"], q["filt_idx"], k=ks)
+            tv_s, ti_s = merge_topk(torch.cat([o[2] for o in outs], dim=1), torch.cat([o[3] for o in outs], dim=1), ks)
+            fin = torch.isfinite(tv_f)
+            shards_ok = (torch.equal(hs, h2) and torch.equal(sum(o[0] for o in outs), ng_f) and torch.equal(sum(o[1] for o in outs), ne_f)
+                         and torch.equal(sum(o[0] for o in outs) + 1, r32) and torch.equal(tv_s, tv_f) and torch.equal(ti_s[fin], ti_f[fin])
+                         and all(s_.band_audit()[0] < 0.5 for s_ in shs))
+            for s_ in shs:
+                s_.close()
         torch.cuda.synchronize()
         ratio, pairs = m.band_audit()
         ok = (torch.equal(ranks, r32) and torch.equal(ranks_e, r32) and torch.equal(ne_e, ne32) and torch.equal(r2, r32) and torch.equal(ne2, ne32)
-              and torch.equal(h, h2) and torch.equal(h, h_e) and bool(torch.isfinite(h).all()) and ratio < 0.5 and topk_ok)
+              and torch.equal(h, h2) and torch.equal(h, h_e) and bool(torch.isfinite(h).all()) and ratio < 0.5 and topk_ok and shards_ok)
         worst = max(worst, ratio)
         print("case %3d  %-13s E=%-6d R=%-4d std=%-8.2g Q=%-5d nnz=%-7d  audit %.3f over %d pairs  %s" % (
             c, "d=%d" % md["ent_emb_size"], md["num_ent"], md["num_rel"], ent_std, Q, int(q["filt_indptr"][-1]), ratio, pairs, "ok" if ok else "MISMATCH"), flush=True)
         if not ok:
             bad = (ranks != r32).nonzero().flatten()[:8].tolist()
-            print("   first differing queries:", bad, "fused", ranks[bad].tolist(), "chain", r32[bad].tolist(), "top-k ok:", topk_ok)
+            print("   first differing queries:", bad, "fused", ranks[bad].tolist(), "chain", r32[bad].tolist(), "top-k ok:", topk_ok, "shards ok:", shards_ok)
             sys.exit(1)
         m.close(); m32.close()
     print("soak: %d cases, all ranks == the fp32 chain's on the same h; largest band audit %.3f; %.0f s" % (cases, worst, time.time() - t0))
