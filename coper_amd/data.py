@@ -306,12 +306,15 @@ def canonical_csr(indptr, idx):
     idx = np.asarray(idx, np.int64)
     if len(idx) < 2:
         return indptr, idx
-    down = np.diff(idx) < 0
+    down = idx[1:] < idx[:-1]                   # (one pass, no int64 temporary: this check is most of a pass's host marshalling)
     inner = indptr[1:-1]
-    inner = inner[(inner > 0) & (inner < len(idx))]
-    down[inner - 1] = False                     # steps across row boundaries do not count
-    if not down.any():
+    if len(inner) and (inner[0] <= 0 or inner[-1] >= len(idx)):      # (empty rows at either end; indptr is non-decreasing)
+        inner = inner[np.searchsorted(inner, 0, side="right"):np.searchsorted(inner, len(idx), side="left")]
+    inner = np.unique(inner) if len(inner) > 1 and np.any(inner[1:] == inner[:-1]) else inner      # (empty rows repeat a boundary)
+    # steps down across row boundaries do not count: in order iff every step down sits on a boundary
+    if np.count_nonzero(down) == np.count_nonzero(down[inner - 1]):
         return indptr, idx
+    down[inner - 1] = False
     out = idx.copy()
     for i in np.unique(np.searchsorted(indptr, np.nonzero(down)[0], side="right") - 1):
         out[indptr[i]:indptr[i + 1]] = np.sort(idx[indptr[i]:indptr[i + 1]], kind="stable")
