@@ -977,6 +977,34 @@ COPER_API int coper_band_audit_post(coper_handle* h, int32_t reset, uint32_t* ds
   return COPER_OK;
 }
 
+// The audit ACTS: host logic only -- the caller brings the two words it read with coper_band_audit or
+// received through coper_band_audit_post.
+COPER_API int coper_band_policy(coper_handle* h, float max_ratio, int64_t n_pairs, int32_t* action, float* kappa_now) {
+  if (!h) return COPER_EINVAL;
+  int act = COPER_BAND_KEEP;
+  if (h->band_consts && n_pairs > 0 && max_ratio == max_ratio && max_ratio > 0.5f) {
+    // widen so that the error just seen sits at or below a QUARTER of the new allowance: x2 for (0.5, 1), x 2^ceil(log2(4 ratio))
+    // from 1 on (the pass is then re-ranked under the new band by the caller); never beyond 2^20 (kappa = 1 is every pair)
+    float mult = 2.f;
+    if (max_ratio >= 1.f) {
+      act = COPER_BAND_RERANK;
+      mult = 4.f;
+      while (mult < 4.f * max_ratio && mult < 1048576.f) mult *= 2.f;
+    } else {
+      act = COPER_BAND_WIDENED;
+    }
+    float m = h->band_kappa_mult * mult;
+    const float base = h->cfg.rank_band_kappa > 0.f ? h->cfg.rank_band_kappa : COPER_BAND_KAPPA_DEFAULT;
+    if (base * m > 1.f) m = 1.f / base;
+    if (m < h->band_kappa_mult) m = h->band_kappa_mult;
+    h->band_kappa_mult = m;
+    h->band_launches = 0;      // the next count launch carries the audit again: the new band is checked at once
+  }
+  if (action) *action = act;
+  if (kappa_now) *kappa_now = h->band_consts ? band_kappa(h) : 0.f;
+  return COPER_OK;
+}
+
 COPER_API int coper_check_ids(coper_handle* h, int64_t* n_bad, void* stream) {
   if (!h || !n_bad) return COPER_EINVAL;
   *n_bad = 0;

@@ -104,6 +104,7 @@ struct coper_handle {
   void* Ef3 = nullptr;          //   the count kernel's image (bf16x3_chain.h): [2 n_eblk][NS][2][64] x 16 B, zero-filled first
   unsigned* band_consts = nullptr;   // [BAND_NCONST] float bits: [0] max |E_e|_2, [1] max |pred_bias| of the shard (exact band), [2] max |E element|,
                                      //   [3] the band audit's largest |x3 - chain| / (tau / 2), [4] its pair count (coper_band_audit)
+  float band_kappa_mult = 1.f;       // coper_band_policy: a power of two on top of the configured kappa (kept across coper_prepare)
   unsigned band_launches = 0;        // count launches since prepare (which of them the band audit rides on: kernels_score3_bf16.hip)
   int x3_ent_exp = 0;                // e_E: the entity planes hold E 2^e_E (split16.h; prepare)
   float x3_ent_absmax = 0.f;         //   the maximum it was chosen from (the shard's, or coper_config.x3_ent_absmax)

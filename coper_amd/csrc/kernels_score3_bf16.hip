@@ -898,7 +898,7 @@ int launch_band_consts(coper_handle* h, const float* ent, const float* bias, hip
 
 float band_kappa(const coper_handle* h) {
   const float k = h->cfg.rank_band_kappa;
-  return k > 0.f ? k : COPER_BAND_KAPPA_DEFAULT;
+  return (k > 0.f ? k : COPER_BAND_KAPPA_DEFAULT) * h->band_kappa_mult;     // (the multiplier: coper_band_policy)
 }
 
 int launch_band_setup(coper_handle* h, const float* hvec, const float* tgt, int64_t B, hipStream_t s) {
@@ -1169,13 +1169,25 @@ __device__ __forceinline__ void band_exact_body(const uint4* __restrict__ mask, 
       const bool last = it0 + 256 >= (ni < BE_ITEMS ? ni : BE_ITEMS);
       if (full || last) {
         const int n = s_n < BE_CAP ? s_n : BE_CAP;
+        const bool aud_round = A.audit && !audited && (wg & (int64_t)A.audit_wg_mask) == 0;
         for (int p = threadIdx.x; p < n; p += 256) {
           float sx = NAN, tx = 0.f;
-          const bool dec = band_decide(A, (int64_t)(s_p[p] >> 32), (int64_t)(s_p[p] & 0xFFFFFFFFull), sx, tx);
+          const int64_t pq = (int64_t)(s_p[p] >> 32), pe = (int64_t)(s_p[p] & 0xFFFFFFFFull);
+          bool dec = band_decide(A, pq, pe, sx, tx);
+          // Round 5: a query's own TARGET is always inside its band (it is the band's centre), so its pair is always listed --
+          // and audited like a decided one: the chain's logit of the target against the mode's.  A band too narrow to hold any
+          // competitor (nothing decided, nothing to audit: the audit was blind exactly when it mattered) still reports the error
+          // of every target the sampled workgroups see.  Counts are not touched.
+          if (!dec && aud_round && p < BE_AUDIT && pq < A.Bc && pe < A.n_local && A.dbg == 0 && pe + A.shard_lo == A.e2[pq]) {
+            if (A.tgt_x) tx = A.tgt_x[pq];
+            else { float unused = 0.f; exact_chain_pair(A.ent + pe * A.d, nullptr, A.hvec + pq * A.d, A.bias[pe], 0.f, A.d, tx, unused); }
+            sx = tx;
+            dec = true;
+          }
           if (p < BE_AUDIT) { s_sx[p] = dec ? sx : NAN; s_tx[p] = tx; }
         }
         __syncthreads();
-        if (A.audit && !audited && n > 0 && (wg & (int64_t)A.audit_wg_mask) == 0) {   // the first round of (a sample of) the workgroups
+        if (aud_round && n > 0) {   // the first round of (a sample of) the workgroups
           audited = true;
           const int na = n < BE_AUDIT ? n : BE_AUDIT;
           for (int g = (int)(threadIdx.x >> 6); g * 32 < na; g += 4) band_audit_group(A, s_p, s_sx, s_tx, g * 32, na, s_ae[threadIdx.x >> 6]);

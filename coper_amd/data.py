@@ -388,13 +388,19 @@ class EvalDataset(object):
             return None
         import weakref
         cache = self.__dict__.setdefault("_staged", {})
-        ent = cache.get(id(model))
+        key = id(model)
+        ent = cache.get(key)
         if ent is not None and ent[0]() is model:
             return ent[1]
         q = self.q
         ip, ix = canonical_csr(q["filt_indptr"], q["filt_idx"])
         sb = model.stage_persistent(q["e1"], q["rel"], q["e2"], ip, ix)
-        cache[id(model)] = (weakref.ref(model), sb)
+        # the entry (a pinned host buffer and int64 device arrays) goes when the model does: the callback drops it, unless the
+        # slot was taken over by a later model that got the same id()
+        def _drop(ref, cache=cache, key=key):
+            if cache.get(key, (None,))[0] is ref:
+                del cache[key]
+        cache[key] = (weakref.ref(model, _drop), sb)
         return sb
 
     def __iter__(self) -> Iterator[dict]:

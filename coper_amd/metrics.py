@@ -105,19 +105,25 @@ def ranking_and_hits(model, results_dir, data_iterator_handle, name, session=Non
         sb = data_iterator_handle.staged_for(model)
     if sb is not None:
         Q = sb["B"]
-        out = model.rank_pass_staged(sb)
-        sb["event"].synchronize()
-        ranks = out.numpy()
-        if Q and getattr(model, "score_mode", None) == "bf16x3":
+        x3 = Q and getattr(model, "score_mode", None) == "bf16x3"
+        for attempt in range(_MAX_RERANKS + 1):
+            out = model.rank_pass_staged(sb)
+            sb["event"].synchronize()
+            ranks = out.numpy()
+            if not x3:
+                break
             aud = sb["out_host"][Q:Q + 2].numpy()
-            _report_band_audit(float(aud[:1].view(np.float32)[0]), int(aud[1:2].view(np.uint32)[0]))
+            if _act_on_band_audit(model, float(aud[:1].view(np.float32)[0]), int(aud[1:2].view(np.uint32)[0])) != 2:
+                break
+        else:
+            raise RuntimeError("bf16x3 band audit: still above the band's allowance after %d re-ranked passes" % _MAX_RERANKS)
         return _finish(ranks, Q, results_dir, hits_to_compute, enable_write_to_file, return_ranks)
 
     # a plain list of batches with CSR filters: the encoder needs the ids only, so it is launched as soon as THEY are
     # concatenated, and the filters -- the bulk of the marshalling: concatenation, the canonical-order check, staging -- are
     # put together on the host while the device encodes (coper_encode + coper_rank give coper_encode_rank's bits)
-    if not hasattr(data_iterator_handle, "as_single_batch") and not isinstance(data_iterator_handle, (list, tuple)):
-        data_iterator_handle = list(data_iterator_handle)          # (an iterator of batches: drained once, like metrics.py:38-60)
+    # (only a source that already IS a list: a generator -- e.g. of the reference's dense e2_multi batches, 1.2 GB for the
+    # FB15k-237 test set -- is streamed through collect_batches below, one batch converted to CSR and dropped at a time)
     if ranker is None and isinstance(data_iterator_handle, (list, tuple)) and hasattr(model, "encode") and hasattr(model, "rank") \
             and 0 < sum(len(b["e1"]) for b in data_iterator_handle) <= max_chunk \
             and all("filt_indptr" in b for b in data_iterator_handle):
@@ -130,11 +136,15 @@ def ranking_and_hits(model, results_dir, data_iterator_handle, name, session=Non
         ip = np.concatenate([np.zeros(1, np.int64)] + [np.asarray(b["filt_indptr"], np.int64)[1:] + o for b, o in zip(bs, base)])
         ix = np.concatenate([np.asarray(b["filt_idx"], np.int64) for b in bs]) if base[-1] else np.zeros(0, np.int64)
         ip, ix = canonical_csr(ip, ix)
-        r, _ = model.rank(h, e2, ip, ix, filt_nnz=len(ix), want_equal=False)
-        ranks = r.cpu().numpy()
+        x3 = getattr(model, "score_mode", None) == "bf16x3" and hasattr(model, "band_audit")
+        for attempt in range(_MAX_RERANKS + 1):
+            r, _ = model.rank(h, e2, ip, ix, filt_nnz=len(ix), want_equal=False)
+            ranks = r.cpu().numpy()
+            if not x3 or _act_on_band_audit(model, *model.band_audit()) != 2:
+                break
+        else:
+            raise RuntimeError("bf16x3 band audit: still above the band's allowance after %d re-ranked passes" % _MAX_RERANKS)
         Q = len(e1)
-        if getattr(model, "score_mode", None) == "bf16x3" and hasattr(model, "band_audit"):
-            _report_band_audit(*model.band_audit())
         return _finish(ranks, Q, results_dir, hits_to_compute, enable_write_to_file, return_ranks)
 
     q = collect_batches(data_iterator_handle, device=getattr(model, "device", None))
@@ -145,24 +155,41 @@ def ranking_and_hits(model, results_dir, data_iterator_handle, name, session=Non
         ip = q["filt_indptr"][s:e + 1]
         chunk = dict(e1=q["e1"][s:e], e2=q["e2"][s:e], rel=q["rel"][s:e], filt_indptr=ip - ip[0],
                      filt_idx=q["filt_idx"][ip[0]:ip[-1]])
-        if ranker is not None:
-            r, _ = ranker.rank(chunk)
+        # bf16x3 mode: the run-time audit of the exact band (include/coper_hip.h: coper_band_audit) -- the largest error of the
+        # mode's logits on the pairs closest to the targets, relative to what the band allows; ranks are the fp32 chain's below 1.
+        # Acted on per chunk (coper_band_policy): above 0.5 the handle's kappa is widened, from 1.0 on the chunk is ranked again.
+        # (An entity-sharded ranker audits per shard handle: its ranks() owns that loop.)
+        x3 = ranker is None and getattr(model, "score_mode", None) == "bf16x3" and hasattr(model, "band_audit")
+        for attempt in range(_MAX_RERANKS + 1):
+            if ranker is not None:
+                r, _ = ranker.rank(chunk)
+            else:
+                r, _ = local_rank_pass(model, chunk)
+            if not x3 or _act_on_band_audit(model, *model.band_audit()) != 2:
+                break
         else:
-            r, _ = local_rank_pass(model, chunk)
+            raise RuntimeError("bf16x3 band audit: still above the band's allowance after %d re-ranked passes" % _MAX_RERANKS)
         ranks.append(r)
     ranks = torch.cat(ranks).cpu().numpy().astype(np.int64) if ranks else np.zeros(0, np.int64)
-    # bf16x3 mode: the run-time audit of the exact band (include/coper_hip.h: coper_band_audit) -- the largest error of the
-    # mode's logits on the pairs closest to the targets, relative to what the band allows; ranks are the fp32 chain's below 1
-    if Q and getattr(model, "score_mode", None) == "bf16x3" and hasattr(model, "band_audit"):
-        _report_band_audit(*model.band_audit())
     return _finish(ranks, Q, results_dir, hits_to_compute, enable_write_to_file, return_ranks)
 
 
-def _report_band_audit(ratio, n_pairs):
+_MAX_RERANKS = 4
+
+
+def _act_on_band_audit(model, ratio, n_pairs):
+    """The audit ACTS (include/coper_hip.h: coper_band_policy): ratio > 0.5 widens the handle's kappa for later passes, ratio >= 1
+    also has the caller rank the pass again (integer ranks are the contract, metrics.py:44-50).  Returns the action.  A pass that
+    carried no audit (n_pairs == 0: seven of eight short launches by default) leaves the last real measurement in place."""
+    if n_pairs <= 0:
+        return 0
     ranking_and_hits.last_band_audit = (ratio, n_pairs)
-    if ratio > 0.5:
+    action, kappa = model.band_policy(ratio, n_pairs) if hasattr(model, "band_policy") else (0, 0.0)
+    if action:
         logger.warning("bf16x3 band audit: |logit_x3 - logit_fp32| reached %.2f of the band's allowance on %d audited pairs; "
-                       "raise rank_band_kappa (ranks may differ from the fp32 chain's above 1.0)", ratio, n_pairs)
+                       "kappa widened to %.3g%s", ratio, n_pairs, kappa, "; this pass is ranked again" if action == 2 else "")
+        ranking_and_hits.band_actions = getattr(ranking_and_hits, "band_actions", 0) + 1
+    return action
 
 
 def _finish(ranks, count, results_dir, hits_to_compute, enable_write_to_file, return_ranks):

@@ -544,6 +544,13 @@ class ConvE(object):
         _lib.check(self._h, self._lib.coper_band_audit(self._h, 1 if reset else 0, C.byref(r), C.byref(n), self._stream()))
         return float(r.value), int(n.value)
 
+    def band_policy(self, ratio, n_pairs):
+        """coper_band_policy on the audit's two words: (action, kappa now in force).  action 0 = keep, 1 = the handle's kappa
+        was widened for later passes, 2 = widened AND the pass the words belong to must be ranked again."""
+        act, kap = C.c_int32(), C.c_float()
+        _lib.check(self._h, self._lib.coper_band_policy(self._h, float(ratio), int(n_pairs), C.byref(act), C.byref(kap)))
+        return int(act.value), float(kap.value)
+
     def check_ids(self):
         n = C.c_int64()
         _lib.check(self._h, self._lib.coper_check_ids(self._h, C.byref(n), self._stream()))

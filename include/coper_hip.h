@@ -259,8 +259,9 @@ COPER_API int coper_encode_rank(coper_handle* h, const int64_t* e1, const int64_
                                 const int64_t* e2, const int64_t* filt_indptr, const int64_t* filt_idx, int64_t filt_nnz,
                                 int64_t B, float* h_out, int32_t* ranks, int32_t* n_equal, void* stream);
 
-/* COPER_SCORE_BF16X3: the run-time audit of the exact band.  Every count launch re-scores the pairs its band walk decides (the
- * competitors closest to each target) with the mode's own arithmetic as well and keeps the largest
+/* COPER_SCORE_BF16X3: the run-time audit of the exact band.  An AUDITED count launch (coper_config.band_audit_period: by default
+ * the first after coper_prepare and every 8th, a sample of its workgroups, 128 pairs per round) re-scores pairs its band walk
+ * decides (the competitors closest to each target) with the mode's own arithmetic as well and keeps the largest
  *        |logit_x3 - logit_chain| / (tau_q / 2)      (tau_q / 2: the error the band allows one logit; see rank_band_kappa)
  * seen since the last reset, and the number of pairs audited (modulo 2^32).  A ratio below 1 on every audited pair is what
  * makes the mode's ranks the fp32 chain's; the library's tests assert <= 0.5, coper_amd.metrics.ranking_and_hits logs a
@@ -271,6 +272,25 @@ COPER_API int coper_band_audit(coper_handle* h, int32_t reset, float* max_ratio,
  * (device memory or PINNED, device-mapped host memory, like coper_copy_out_i32) behind the work already on the stream; a
  * host that waits for its ranks anyway reads them with the same wait.  COPER_ESTATE on a COPER_SCORE_F32 handle. */
 COPER_API int coper_band_audit_post(coper_handle* h, int32_t reset, uint32_t* dst2, void* stream);
+/* What a host DOES with the audit's two words (from coper_band_audit or coper_band_audit_post); host logic, no device work, no
+ * synchronisation.  The contract of the path is integer ranks (metrics.py:44-50), so a measured error near the band's allowance
+ * must not only be logged:
+ *   ratio <= 0.5 (or no pair audited)  *action = COPER_BAND_KEEP;
+ *   0.5 < ratio < 1                    the handle's kappa is doubled for every later pass         *action = COPER_BAND_WIDENED;
+ *   ratio >= 1                         kappa is multiplied by the power of two that puts the error seen at or below a quarter of
+ *                                      the new allowance, and the pass the words belong to must be ranked AGAIN by the caller
+ *                                      (same call, same arguments: its close comparisons now go to the fp32 chain)
+ *                                                                                                   *action = COPER_BAND_RERANK.
+ * After a change the next count launch carries the audit whatever band_audit_period says, so a re-ranked pass is checked against
+ * its new band at once.  The multiplier survives coper_prepare (it is a fact about the arithmetic, not about the weights);
+ * *kappa_now = the relative half-width now in force.  coper_amd.metrics.ranking_and_hits applies this after every pass.
+ * Sampling: with the default band_audit_period the first count launch after coper_prepare and every 8th from there are audited,
+ * on the first round of at most ~512 workgroups and 128 pairs per round -- a sample; band_audit_period = 1 audits every launch.
+ * No counterpart in the reference (it ranks materialised fp32 logits). */
+#define COPER_BAND_KEEP 0
+#define COPER_BAND_WIDENED 1
+#define COPER_BAND_RERANK 2
+COPER_API int coper_band_policy(coper_handle* h, float max_ratio, int64_t n_pairs, int32_t* action, float* kappa_now);
 
 /* Timing hook used by bench.py: average device time (ms) of the dominant kernel
  * (score_count) over the launches since the last reset, measured with hipEvents recorded on

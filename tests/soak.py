@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised soak of the fused pass (coper_encode_rank, x3 mode) against the fp32 chain on the same embeddings:
-    python tools/soak.py [cases] [seed]
+    python tests/soak.py [cases] [seed]
 Every case draws a model shape (d = 200 or 256, entity counts from a handful to tens of thousands, 2 - 600 relations, table
 scale from 1e-4 to 10), a batch (1 - 6,000 queries, relation skew, duplicate queries) and filters (empty to thousands of known
 answers in one row, duplicates of the target).  Checked per case:
@@ -12,6 +12,9 @@ answers in one row, duplicates of the target).  Checked per case:
     logit matrix stays under 2^26 elements).
   * every fourth case: the entity table cut at random rows into 2 - 3 shard handles, the exchange done by hand --
     gathered e1 rows, summed targets, summed counts, merged top-k -- equal to the unsharded handle's ranks, tie counts and top-k.
+  * on a sample of 24 queries per case: the fp32-exact ranker's logits == the C restatement of the chain (oracle/coper_oracle_chain.c)
+    bit for bit, and its ranks / tie counts == the C closed form of metrics.py:44-50 on them -- the checker itself is pinned to
+    the CPU oracle in every case (test infrastructure: this file lives under tests/ because it loads the oracle).
 Prints one line per case and a summary; exits non-zero on the first mismatch."""
 import os
 import sys
@@ -23,6 +26,23 @@ import torch
 
 from coper_amd import data as cdata
 from coper_amd.models import ConvE
+from oracle import coper_oracle as O
+
+
+def pinned_to_c_chain(p, h, q, m32, r32, ne32, n_sample=24):
+    """f32-mode logits / ranks / tie counts of a query sample == the C oracle's on the same h rows."""
+    Q = h.shape[0]
+    sel = np.unique(np.linspace(0, Q - 1, min(Q, n_sample)).astype(np.int64))
+    hs = h[torch.as_tensor(sel, device=h.device)].contiguous()
+    chain = O.score_chain(hs.cpu().numpy(), p["ent_emb"], p["pred_bias"])
+    if not np.array_equal(m32.score_all(hs).cpu().numpy(), chain):
+        return False
+    ip, ix = q["filt_indptr"], q["filt_idx"]
+    sip = np.zeros(len(sel) + 1, np.int64)
+    sip[1:] = np.cumsum(ip[sel + 1] - ip[sel])
+    six = np.concatenate([ix[ip[i]:ip[i + 1]] for i in sel]).astype(np.int64)
+    ng_c, ne_c = O.rank_counts_c(chain, q["e2"][sel], sip, six)
+    return bool(np.array_equal(r32.cpu().numpy()[sel], 1 + ng_c) and np.array_equal(ne32.cpu().numpy()[sel], ne_c))
 
 
 def draw_case(rng):
@@ -60,6 +80,8 @@ def draw_queries(md, Q, rng):
 
 
 def main():
+    import subprocess
+    subprocess.check_call(["make", "-C", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle")], stdout=subprocess.DEVNULL)
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     rng = np.random.default_rng(seed)
@@ -74,6 +96,7 @@ def main():
         ranks, _, h = m.rank_pass(q["e1"], q["rel"], q["e2"], q["filt_indptr"], q["filt_idx"], want_equal=False, want_h=True)
         ranks_e, ne_e, h_e = m.rank_pass(q["e1"], q["rel"], q["e2"], q["filt_indptr"], q["filt_idx"], want_equal=True, want_h=True)
         r32, ne32 = m32.rank(h, q["e2"], q["filt_indptr"], q["filt_idx"], want_equal=True)
+        pin_ok = pinned_to_c_chain(p, h, q, m32, r32, ne32)
         h2 = m.encode(q["e1"], q["rel"])
         r2, ne2 = m.rank(h2, q["e2"], q["filt_indptr"], q["filt_idx"], want_equal=True)
         topk_ok = True
@@ -119,16 +142,16 @@ def main():
         torch.cuda.synchronize()
         ratio, pairs = m.band_audit()
         ok = (torch.equal(ranks, r32) and torch.equal(ranks_e, r32) and torch.equal(ne_e, ne32) and torch.equal(r2, r32) and torch.equal(ne2, ne32)
-              and torch.equal(h, h2) and torch.equal(h, h_e) and bool(torch.isfinite(h).all()) and ratio < 0.5 and topk_ok and shards_ok)
+              and torch.equal(h, h2) and torch.equal(h, h_e) and bool(torch.isfinite(h).all()) and ratio < 0.5 and topk_ok and shards_ok and pin_ok)
         worst = max(worst, ratio)
         print("case %3d  %-13s E=%-6d R=%-4d std=%-8.2g Q=%-5d nnz=%-7d  audit %.3f over %d pairs  %s" % (
             c, "d=%d" % md["ent_emb_size"], md["num_ent"], md["num_rel"], ent_std, Q, int(q["filt_indptr"][-1]), ratio, pairs, "ok" if ok else "MISMATCH"), flush=True)
         if not ok:
             bad = (ranks != r32).nonzero().flatten()[:8].tolist()
-            print("   first differing queries:", bad, "fused", ranks[bad].tolist(), "chain", r32[bad].tolist(), "top-k ok:", topk_ok, "shards ok:", shards_ok)
+            print("   first differing queries:", bad, "fused", ranks[bad].tolist(), "chain", r32[bad].tolist(), "top-k ok:", topk_ok, "shards ok:", shards_ok, "C-oracle pin ok:", pin_ok)
             sys.exit(1)
         m.close(); m32.close()
-    print("soak: %d cases, all ranks == the fp32 chain's on the same h; largest band audit %.3f; %.0f s" % (cases, worst, time.time() - t0))
+    print("soak: %d cases, all ranks == the fp32 chain's on the same h (the chain pinned to the C oracle on a sample per case); largest band audit %.3f; %.0f s" % (cases, worst, time.time() - t0))
 
 
 if __name__ == "__main__":

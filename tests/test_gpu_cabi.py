@@ -314,3 +314,54 @@ def test_post_i32_next_copies_the_last_ranks_beside_the_next_grouping(Q):
     assert np.array_equal(host.numpy(), ranks.cpu().numpy())
     assert m._lib.coper_post_i32_next(m._h, None, 5, None) == 1
     m.close()
+
+
+def test_band_policy_widens_and_reranks_a_too_narrow_band():
+    """coper_band_policy: the audit ACTS.  A band a thousand times too narrow (rank_band_kappa = 1e-9, every
+    count launch audited) must still return the fp32 chain's ranks from `ranking_and_hits`: the first pass's audit reads far
+    above 1, the policy widens kappa by the power of two that covers the error seen and the pass is ranked again.  All three
+    routes of the drop-in ranker (dataset object, list of CSR batches, generator of the reference's dense-mask batches)."""
+    import ctypes
+    from coper_amd import _lib
+    from coper_amd.metrics import ranking_and_hits
+    from coper_amd.models import ConvE
+    md = cdata.model_descriptors("fb15k237_cpg", num_ent=3000, num_rel=40)
+    p = cdata.synthetic_params(md, 5)
+    q = cdata.synthetic_queries(md, 2048, seed=7)
+    m32 = ConvE(md, device="cuda:0", score_mode="f32").load_parameters(p).prepare()
+    want = ranking_and_hits(m32, None, cdata.EvalDataset(q, 512, md["num_ent"]), "f32", return_ranks=True)[3]
+    for route in ("dataset", "list", "dense_generator"):
+        m = ConvE(md, device="cuda:0", score_mode="bf16x3", rank_band_kappa=1e-9, band_audit_period=1).load_parameters(p).prepare()
+        ds = cdata.EvalDataset(q, 512, md["num_ent"], dense_mask=(route == "dense_generator"))
+        ranking_and_hits.band_actions = 0
+        if route == "dataset":
+            src = ds
+        elif route == "list":
+            src = list(ds)
+        else:
+            src = ({k: v for k, v in b.items() if k not in ("filt_indptr", "filt_idx")} for b in ds)
+        got = ranking_and_hits(m, None, src, route, return_ranks=True)[3]
+        assert np.array_equal(got, want), route
+        assert ranking_and_hits.band_actions >= 1, route          # the policy did act
+        act, kappa = m.band_policy(0.0, 0)                         # (no pairs: keep; reports the kappa now in force)
+        assert act == 0 and kappa >= 64e-9, (route, kappa)
+        # a second evaluation starts from the widened band: no re-rank needed, same ranks
+        ranking_and_hits.band_actions = 0
+        src2 = ds if route != "list" else list(ds)
+        got2 = ranking_and_hits(m, None, src2, route, return_ranks=True)[3]
+        assert np.array_equal(got2, want) and ranking_and_hits.last_band_audit[0] < 1.0
+        m.close()
+    # the C entry point as a foreign host binds it: thresholds and the multiplier's arithmetic
+    m = ConvE(md, device="cuda:0", score_mode="bf16x3").load_parameters(p).prepare()
+    act, kap = ctypes.c_int32(), ctypes.c_float()
+    for ratio, n, want_act, want_kappa in ((0.4, 100, 0, 1e-6), (0.7, 100, 1, 2e-6), (0.9, 0, 0, 2e-6), (3.0, 5, 2, 32e-6), (float("nan"), 5, 0, 32e-6)):
+        _lib.check(m._h, m._lib.coper_band_policy(m._h, ratio, n, ctypes.byref(act), ctypes.byref(kap)))
+        assert act.value == want_act and abs(kap.value / want_kappa - 1) < 1e-6, (ratio, act.value, kap.value)
+    m.prepare()                                                    # the multiplier is a fact about the arithmetic: it survives
+    _lib.check(m._h, m._lib.coper_band_policy(m._h, 0.0, 0, ctypes.byref(act), ctypes.byref(kap)))
+    assert abs(kap.value / 32e-6 - 1) < 1e-6
+    m32f = ConvE(md, device="cuda:0", score_mode="f32").load_parameters(p).prepare()
+    _lib.check(m32f._h, m32f._lib.coper_band_policy(m32f._h, 5.0, 10, ctypes.byref(act), ctypes.byref(kap)))
+    assert act.value == 0 and kap.value == 0.0                     # no band in the fp32-exact mode
+    for x in (m, m32, m32f):
+        x.close()

@@ -97,9 +97,11 @@ def _identity_ranker(E, B):
     return md, p, d
 
 
+@pytest.mark.parametrize("score_mode", ["f32", "bf16x3"])
 @pytest.mark.parametrize("E", [14, 257, 4099])
-def test_fused_ranker_reproduces_reference_ranking_and_hits(golden_dir, E):
-    """rank_*.npz hold the outputs of the REFERENCE'S OWN ranking_and_hits on (pred, e2, filter)."""
+def test_fused_ranker_reproduces_reference_ranking_and_hits(golden_dir, E, score_mode):
+    """rank_*.npz hold the outputs of the REFERENCE'S OWN ranking_and_hits on (pred, e2, filter) -- in both arithmetic modes:
+    the headline mode's count kernel + band walk (what bench.py times) sees the reference-held vectors too."""
     from coper_amd.metrics import hits_and_means
     g = np.load(os.path.join(golden_dir, "rank_E%d.npz" % E))
     pred, e2 = g["pred"], g["e2"]
@@ -108,12 +110,18 @@ def test_fused_ranker_reproduces_reference_ranking_and_hits(golden_dir, E):
     p["ent_emb"] = np.zeros((E, d), np.float32)
     p["ent_emb"][:, :B] = pred.T
     p["pred_bias"] = np.zeros(E, np.float32)
-    m = _model(md, p)
+    m = _model(md, p, score_mode=score_mode, **({"band_audit_period": 1} if score_mode == "bf16x3" else {}))
     h = torch.eye(B, d, device="cuda:0")
-    assert np.array_equal(m.score_all(h).cpu().numpy(), pred)
+    if score_mode == "f32":
+        assert np.array_equal(m.score_all(h).cpu().numpy(), pred)
+    else:   # the split carries 22 of a logit's 24 bits; the ranks below are nevertheless the reference's
+        assert np.abs(m.score_all(h).cpu().numpy() - pred).max() <= 2e-6 * np.abs(pred).max()
     ranks, ne = m.rank(h, e2, g["filt_indptr"], g["filt_idx"])
     ranks = ranks.cpu().numpy()
     assert np.array_equal(ranks, g["closed_form_rank"]) and not ne.cpu().numpy().any()
+    if score_mode == "bf16x3":
+        ratio, n_pairs = m.band_audit()
+        assert ratio <= 0.5, (ratio, n_pairs)
     mr, mrr, hits = hits_and_means(ranks, tuple(int(k) for k in g["ref_hits_k"]))
     assert mr == float(g["ref_mr"])
     assert abs(mrr - float(g["ref_mrr"])) <= 4e-16
@@ -121,7 +129,8 @@ def test_fused_ranker_reproduces_reference_ranking_and_hits(golden_dir, E):
     m.close()
 
 
-def test_fused_ranker_tie_band(golden_dir):
+@pytest.mark.parametrize("score_mode", ["f32", "bf16x3"])
+def test_fused_ranker_tie_band(golden_dir, score_mode):
     g = np.load(os.path.join(golden_dir, "rank_ties.npz"))
     pred, e2 = g["pred"], g["e2"]
     B, E = pred.shape
@@ -129,7 +138,7 @@ def test_fused_ranker_tie_band(golden_dir):
     p["ent_emb"] = np.zeros((E, d), np.float32)
     p["ent_emb"][:, :B] = pred.T
     p["pred_bias"] = np.zeros(E, np.float32)
-    m = _model(md, p)
+    m = _model(md, p, score_mode=score_mode)
     h = torch.eye(B, d, device="cuda:0")
     ranks, ne = m.rank(h, e2, g["filt_indptr"], g["filt_idx"])
     assert np.array_equal(ranks.cpu().numpy(), 1 + g["n_greater"])

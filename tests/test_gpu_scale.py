@@ -70,7 +70,25 @@ def _tables(kind, md, seed):
     return p
 
 
-def _check(md, p, Q, h_scale=1.0, seed=0, kappa=0.0):
+def _pin_to_c_chain(O, p, h, q, l32_rows, r32, ne32, n_sample=48):
+    """The checker behind the checker: at THIS operand scale, on a sample of the queries, the f32 mode's
+    logits are the C restatement of the fp32 chain bit for bit, and its ranks / tie counts are the C closed form of
+    metrics.py:44-50 on those logits -- no GPU arithmetic on the checking side."""
+    Q = h.shape[0]
+    sel = np.unique(np.linspace(0, Q - 1, min(Q, n_sample)).astype(np.int64))
+    hs = np.ascontiguousarray(h[torch.as_tensor(sel, device=h.device)].cpu().numpy())
+    chain = O.score_chain(hs, p["ent_emb"], p["pred_bias"])
+    assert np.array_equal(l32_rows(sel), chain), "f32-mode logits differ from the C chain at this scale"
+    ip, ix = q["filt_indptr"], q["filt_idx"]
+    sip = np.zeros(len(sel) + 1, np.int64)
+    sip[1:] = np.cumsum(ip[sel + 1] - ip[sel])
+    six = np.concatenate([ix[ip[i]:ip[i + 1]] for i in sel]) if len(sel) else np.zeros(0, np.int64)
+    ng_c, ne_c = O.rank_counts_c(chain, q["e2"][sel], sip, six)
+    assert np.array_equal(r32.cpu().numpy()[sel], 1 + ng_c), "f32-mode ranks differ from the C oracle's at this scale"
+    assert np.array_equal(ne32.cpu().numpy()[sel], ne_c)
+
+
+def _check(md, p, Q, h_scale=1.0, seed=0, kappa=0.0, O=None):
     m3 = _model(md, p, score_mode="bf16x3", rank_band_kappa=kappa)
     m32 = _model(md, p, score_mode="f32")
     q = cdata.synthetic_queries(md, Q, seed=seed)
@@ -92,6 +110,8 @@ def _check(md, p, Q, h_scale=1.0, seed=0, kappa=0.0):
     assert np.array_equal(r3.cpu().numpy(), r32.cpu().numpy()), "x3 ranks differ from the fp32 chain's"
     assert np.array_equal(ne3.cpu().numpy(), ne32.cpu().numpy())
     assert n_pairs > 0 and ratio <= AUDIT_BAR, (ratio, n_pairs)
+    if O is not None:     # ... and the f32 mode itself is pinned to the C oracle at this scale
+        _pin_to_c_chain(O, p, h, q, lambda sel: m32.score_all(h[torch.as_tensor(sel, device=h.device)].contiguous()).cpu().numpy(), r32, ne32)
     # the fused pass (coper_encode_rank) agrees when h is the model's own
     if h_scale == 1.0:
         rf, _ = m3.rank_pass(q["e1"], q["rel"], q["e2"], q["filt_indptr"], q["filt_idx"], want_equal=False)
@@ -123,21 +143,21 @@ def _check(md, p, Q, h_scale=1.0, seed=0, kappa=0.0):
 
 
 @pytest.mark.parametrize("kind", ["xavier", "xavier_bias", "n0.1", "n1e-2", "n1e-3", "rowspread", "clamp", "tiny"])
-def test_x3_ranks_equal_chain_at_every_table_scale_fb15k237(kind):
+def test_x3_ranks_equal_chain_at_every_table_scale_fb15k237(kind, oracle_chain):
     """FB15k-237's shapes (|E| = 14,541, d = 200, 474 relations): every query's rank and tie count."""
     md = cdata.model_descriptors("fb15k237_cpg")
     p = _tables(kind, md, 0)
-    rel, ratio, n = _check(md, p, 4096)
+    rel, ratio, n = _check(md, p, 4096, O=oracle_chain)
     print("fb15k237 %-12s max |s_x3 - s_chain| = %.3f of the band's allowance over %d logits; band audit %.3f over %d pairs; "
           "encoder max |h - h64| / max |h64| = %.2e" % (kind, rel, 384 * md["num_ent"], ratio, n, _check.last_h_rel))
 
 
 @pytest.mark.parametrize("h_scale", [1e-6, 1e-3, 1e3, 1e6])
-def test_x3_ranks_equal_chain_at_every_query_scale(h_scale):
+def test_x3_ranks_equal_chain_at_every_query_scale(h_scale, oracle_chain):
     """The query side: the same embeddings multiplied by a constant (a model whose FCBN gamma is that much larger / smaller)."""
     md = cdata.model_descriptors("fb15k237_cpg", num_ent=6000, num_rel=40)
     p = cdata.synthetic_params(md, 3)
-    _check(md, p, 1024, h_scale=h_scale, seed=5)
+    _check(md, p, 1024, h_scale=h_scale, seed=5, O=oracle_chain)
 
 
 def test_x3_mixed_query_magnitudes_in_one_batch():
@@ -162,7 +182,7 @@ def test_x3_mixed_query_magnitudes_in_one_batch():
 
 
 @pytest.mark.parametrize("kind", ["xavier10m", "n1e-3"])
-def test_x3_ranks_equal_chain_10m_shape_tables(kind):
+def test_x3_ranks_equal_chain_10m_shape_tables(kind, oracle_chain):
     """The 10M-entity config's shapes (d = 256, 16 x 16 image, r = 32) on a 300,000-row slice of the table, with the element
     scale the reference's initialiser gives the FULL 10M-row table (limit sqrt(6 / (10^7 + 256)) = 7.7e-4, models.py:205-208)."""
     md = cdata.model_descriptors("synth10m_cpg", num_ent=300000, num_rel=64)
@@ -175,7 +195,7 @@ def test_x3_ranks_equal_chain_10m_shape_tables(kind):
         p["pred_bias"] = np.zeros(E, np.float32)
     else:
         p["ent_emb"] = (rng.standard_normal((E, d)) * 1e-3).astype(np.float32)
-    rel, ratio, n = _check(md, p, 1024)
+    rel, ratio, n = _check(md, p, 1024, O=oracle_chain)
     print("10M-shape %-10s max |s_x3 - s_chain| = %.3f of the band's allowance; band audit %.3f over %d pairs" % (kind, rel, ratio, n))
 
 
