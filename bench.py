@@ -55,7 +55,9 @@ SCALE_WORKLOAD, SCALE_TOPK, HBM_REGIME_QUERIES = "synth10m_cpg", 10, 128
 # Ranks of the `scale` pass on ONE GPU holding all 10M entities (seed 0, Q = 4096, x3 mode with the scale-invariant fp16 split
 # and the exact band: round 4; entity rows ~ N(0, 0.1^2) as SURVEY 8(d) says, rounds 1 - 3 drew 0.3), measured on MI355X: every
 # entity sharding of the same table must reproduce them bit for bit (integer counts summed across shards).
-SCALE_EXPECTED = {"ranks_sha1": "41cfaa9fdcb7dd12be87a5db274136ce373d6540", "mean_rank": 4908718.644287109}
+# (round 5: the encoder's conv moved to the matrix cores -- h moves by ~1e-7 of its magnitude, a handful of the 4,096 ranks among
+# 10M entities by one place: the value below is the single-GPU pass of the round-5 arithmetic; round 4's was 41cfaa9f...)
+SCALE_EXPECTED = {"ranks_sha1": "0e327a86e98b02e13e2dcac9997a9697d6de1421", "mean_rank": 4908718.635253906}
 
 
 def _profile_entry(pattern, workload, Q, kernel, exact=None):

@@ -95,6 +95,7 @@ PROTOTYPES = {
     "coper_profile_read": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_I64)]),
     "coper_train_init": (C.c_int, [_P, C.POINTER(coper_train_config)]),
     "coper_train_step": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _P, _P]),
+    "coper_train_forward": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P]),
     "coper_train_grad": (C.c_int, [_P, C.c_char_p, _P, _I64, C.POINTER(_I64), C.POINTER(C.c_double), _P]),
     "coper_train_slot": (C.c_int, [_P, C.c_char_p, C.c_int32, _P, _I64, C.c_int32, C.POINTER(_I64), _P]),
     "coper_train_powers": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_I64), C.POINTER(C.c_double),

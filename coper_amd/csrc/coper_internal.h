@@ -106,6 +106,7 @@ struct coper_handle {
                                      //   [3] the band audit's largest |x3 - chain| / (tau / 2), [4] its pair count (coper_band_audit)
   float band_kappa_mult = 1.f;       // coper_band_policy: a power of two on top of the configured kappa (kept across coper_prepare)
   unsigned band_launches = 0;        // count launches since prepare (which of them the band audit rides on: kernels_score3_bf16.hip)
+  int img_exp = 0;                   // e_I: the fused encoder's image planes (compute_x_exp)
   int x3_ent_exp = 0;                // e_E: the entity planes hold E 2^e_E (split16.h; prepare)
   float x3_ent_absmax = 0.f;         //   the maximum it was chosen from (the shard's, or coper_config.x3_ent_absmax)
   const int32_t* stage_src = nullptr;   // coper_stage_ids_next: a batch to bring in beside the next encoder launch (stage_n > 0: pending)

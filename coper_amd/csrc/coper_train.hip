@@ -74,6 +74,8 @@ struct TrainState {
   // the other products (static dense layer, 1-vs-all scorer, dE of the dense scorer backward): two operand plane sets and
   // the split-K partial sums, grown on demand
   TgPlanes mmX, mmY;
+  int32_t* tg_exps = nullptr;    // [8] the exponents of the eight plane sets (train_gemm.h), in the order pX pXt pP1 pP3 pTn pTb mmX mmY
+  unsigned* tg_scratch = nullptr;   // [2] the absmax reduction of tg_pack (zero between packs)
   size_t mmX_cap = 0, mmY_cap = 0, mmP_cap = 0;
   float* mmP = nullptr;
   float *z0 = nullptr, *z1 = nullptr, *hv = nullptr, *dh = nullptr, *dz = nullptr, *ds = nullptr, *dx = nullptr, *dc = nullptr;
@@ -219,6 +221,8 @@ __global__ __launch_bounds__(256) void k_tr_col_sums(const float* __restrict__ m
 
 // BN statistics -> (mean, inv_std) used by forward and backward; moving statistics updated in place.
 // unbiased_moving: [TF-semantics] the fused 4-D kernel feeds the unbiased variance into the moving average.
+// unbiased_moving bit 1 (value 2): leave the moving statistics alone (coper_train_forward: a fetch without train_op runs none of
+// the UPDATE_OPS, models.py:194-200).
 __global__ void k_tr_bn_finish(const double* __restrict__ sums, int cols, double n, int use_batch, float momentum,
                                int unbiased_moving, float* __restrict__ mov_mean, float* __restrict__ mov_var,
                                float* __restrict__ mean_out, float* __restrict__ inv_out) {
@@ -230,7 +234,8 @@ __global__ void k_tr_bn_finish(const double* __restrict__ sums, int cols, double
     if (var < 0) var = 0;
     mean_out[c] = (float)mean;
     inv_out[c] = (float)(1.0 / sqrt(var + (double)BN_EPS));
-    const double var_m = unbiased_moving ? var * (n / (n - 1.0)) : var;
+    if (unbiased_moving & 2) return;
+    const double var_m = (unbiased_moving & 1) ? var * (n / (n - 1.0)) : var;
     mov_mean[c] = (float)((double)mov_mean[c] * momentum + mean * (1.0 - (double)momentum));
     mov_var[c] = (float)((double)mov_var[c] * momentum + var_m * (1.0 - (double)momentum));
   } else {
@@ -1017,8 +1022,8 @@ static int tg_matmul(coper_handle* h, TrainState* T, hipStream_t s, const MmView
       T->mmP_cap = np;
     }
   }
-  if ((rc = tg_pack(h, X.p, X.ri, X.ki, M, K, tg_rows_pad(M), X.rows_fast, T->mmX, s))) return rc;
-  if ((rc = tg_pack(h, Y.p, Y.ri, Y.ki, N, K, tg_rows_pad(N), Y.rows_fast, T->mmY, s))) return rc;
+  if ((rc = tg_pack(h, X.p, X.ri, X.ki, M, K, tg_rows_pad(M), X.rows_fast, T->mmX, s, T->tg_scratch))) return rc;
+  if ((rc = tg_pack(h, Y.p, Y.ri, Y.ki, N, K, tg_rows_pad(N), Y.rows_fast, T->mmY, s, T->tg_scratch))) return rc;
   return tg_gemm_nt(h, T->mmX, M, T->mmY, N, K, C, ci, cj, s, nsplit, T->mmP, sumsq);
 }
 
@@ -1042,6 +1047,8 @@ void train_destroy(coper_handle* h) {
       if (i < COPER_MAX_CTX) { (void)tracked_free(ch.u[i]); (void)tracked_free(ch.a[i]); (void)tracked_free(ch.du[i]); (void)tracked_free(ch.st[i]); }
     }
   (void)tracked_free(T->red);
+  if (T->tg_exps) (void)tracked_free(T->tg_exps);
+  if (T->tg_scratch) (void)tracked_free(T->tg_scratch);
   for (TgPlanes* pl : {&T->mmX, &T->mmY}) {
     if (pl->hi) (void)tracked_free(pl->hi);
     if (pl->lo) (void)tracked_free(pl->lo);
@@ -1138,14 +1145,44 @@ COPER_API int coper_train_init(coper_handle* h, const coper_train_config* cfg) {
   for (int i = 0; i < T->nhc; ++i) mx = h->cfg.ctx_conv[i] > mx ? h->cfg.ctx_conv[i] : mx;
   if ((rc = talloc(h, &T->bnst, (size_t)4 * mx))) return rc;
   if ((rc = talloc(h, &T->red, (size_t)(2 + 2 * mx * TR_COLSUM_SLICES + TG_SUMSQ_SLOTS)))) return rc;
+  if ((rc = talloc(h, &T->tg_exps, (size_t)8)) || (rc = talloc(h, &T->tg_scratch, (size_t)2))) return rc;
+  COPER_HIP_TRY(h, hipMemset(T->tg_exps, 0, 8 * sizeof(int32_t)));
+  COPER_HIP_TRY(h, hipMemset(T->tg_scratch, 0, 2 * sizeof(unsigned)));
+  {
+    TgPlanes* sets[8] = {&T->pX, &T->pXt, &T->pP1, &T->pP3, &T->pTn, &T->pTb, &T->mmX, &T->mmY};
+    for (int i = 0; i < 8; ++i) sets[i]->exp = T->tg_exps + i;
+  }
   return COPER_OK;
 }
 
-COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t* rel, const int32_t* lookup, const float* labels,
-                               int64_t B, int64_t L, float* loss_out, void* stream) {
+}  // extern "C"
+
+// logits of the train-mode forward for coper_train_forward: the fma chain of k_tr_score_loss (sampled) / S + bias (1-vs-all)
+__global__ __launch_bounds__(256) void k_tr_scores_out(const float* __restrict__ hv, const float* __restrict__ ent,
+                                                       const float* __restrict__ pred_bias, const int32_t* __restrict__ lookup,
+                                                       int64_t E, int d, int64_t L, float* __restrict__ out) {
+  const int64_t b = blockIdx.x;
+  for (int64_t l = threadIdx.x; l < L; l += 256) {
+    int64_t row = lookup[b * L + l];
+    if (row < 0 || row >= E) row = 0;
+    const float* er = ent + row * d;
+    float s = 0.f;
+    for (int k = 0; k < d; ++k) s = fmaf(hv[b * d + k], er[k], s);
+    out[b * L + l] = s + pred_bias[row];
+  }
+}
+__global__ __launch_bounds__(256) void k_tr_add_bias_out(const float* __restrict__ S, const float* __restrict__ pred_bias, int64_t E,
+                                                         int64_t total, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < total) out[i] = S[i] + pred_bias[i % E];
+}
+
+static int train_step_impl(coper_handle* h, const int64_t* e1, const int64_t* rel, const int32_t* lookup, const float* labels,
+                           int64_t B, int64_t L, float* loss_out, void* stream, const int apply, float* pred_out, float* h_out) {
   if (!h) return COPER_EINVAL;
   TrainState* T = (TrainState*)h->train;
   if (!T) return fail(h, COPER_ESTATE, "coper_train_step: call coper_train_init first");
+  const int nomov = apply ? 0 : 2;
   if (!e1 || !rel || !labels || B <= 0 || L <= 0 || B * L > 0x7fffffff)
     return fail(h, COPER_EINVAL, "coper_train_step: bad argument");
   const bool one_vs_all = lookup == nullptr;   // use_negative_sampling = False: labels are the dense e2_multi [B, |E|]
@@ -1155,7 +1192,7 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
   const Dims& dm = h->dm;
   hipStream_t s = (hipStream_t)stream;
   COPER_HIP_TRY(h, hipSetDevice(h->cfg.device));
-  h->prepared = false;   // the variables change: per-relation caches, fragment images and folded BN go stale
+  if (apply) h->prepared = false;   // the variables change: per-relation caches, fragment images and folded BN go stale
   const coper_train_config& tc = T->cfg;
   const int d = dm.d, r = dm.r, C = dm.C, P = dm.Ho * dm.Wo, isz = dm.in_h * dm.in_w, NT = dm.fh * dm.fw;   // NT: filter taps
   const int64_t F = dm.F, Fc = dm.F_conv;   // dense input width (F_conv + r under concat_rel), conv features
@@ -1268,7 +1305,7 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
       if (dm.ctx_bn) {
         double* cs = colsum_slice(3 + 4 * g + i);
         if (use_batch) hipLaunchKernelGGL(k_tr_col_sums, dim3(64), dim3(256), 0, s, ch.u[i], B, nj, cs);
-        hipLaunchKernelGGL(k_tr_bn_finish, dim3((nj + 63) / 64), dim3(64), 0, s, cs, nj, (double)B, use_batch, tc.batch_norm_momentum, 0,
+        hipLaunchKernelGGL(k_tr_bn_finish, dim3((nj + 63) / 64), dim3(64), 0, s, cs, nj, (double)B, use_batch, tc.batch_norm_momentum, 0 | nomov,
                            const_cast<float*>(h->params[pn + "/BatchNorm/moving_mean"].ptr),
                            const_cast<float*>(h->params[pn + "/BatchNorm/moving_variance"].ptr), ch.st[i], ch.st[i] + nj);
         ga = P_((pn + "/BatchNorm/gamma").c_str());
@@ -1303,7 +1340,7 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
   const int64_t nBF = B * Fc;
   if (use_batch) hipLaunchKernelGGL(k_tr_col_sums, dim3(256), dim3(256), 0, s, T->y, B * (int64_t)P, C, colsum);
   hipLaunchKernelGGL(k_tr_bn_finish, dim3((C + 63) / 64), dim3(64), 0, s, colsum, C, (double)B * P, use_batch,
-                     tc.batch_norm_momentum, 1, const_cast<float*>(h->params["Conv1BN/moving_mean"].ptr),
+                     tc.batch_norm_momentum, 1 | nomov, const_cast<float*>(h->params["Conv1BN/moving_mean"].ptr),
                      const_cast<float*>(h->params["Conv1BN/moving_variance"].ptr), mean1, inv1);
   hipLaunchKernelGGL(k_tr_bn1_fwd, dim3((unsigned)((nBF + 255) / 256)), dim3(256), 0, s, T->y, mean1, inv1, P_("Conv1BN/gamma"),
                      P_("Conv1BN/beta"), C, nBF, tc.seed, step, thr_h, ks_h, T->x);
@@ -1329,8 +1366,8 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
       // T[rho][b][k] = sum_f x[b][f] P[rho][f][k] on the bf16 matrix cores with split operands (train_gemm_bf16.hip): x and P
       // are packed into fragment planes (P as rows (rho, k) with f contracted), one GEMM of [B] x [r*d] outputs
       const int64_t nrk = (int64_t)rc_w * d;
-      if ((rc = tg_pack(h, xin, tg_idx(F), tg_idx(1), B, F, tg_rows_pad(B), false, T->pX, s))) return rc;
-      if ((rc = tg_pack(h, Wmat, tg_idx2(d, F * (int64_t)d, 1), tg_idx(d), nrk, F, tg_rows_pad(nrk), true, T->pP1, s))) return rc;
+      if ((rc = tg_pack(h, xin, tg_idx(F), tg_idx(1), B, F, tg_rows_pad(B), false, T->pX, s, T->tg_scratch))) return rc;
+      if ((rc = tg_pack(h, Wmat, tg_idx2(d, F * (int64_t)d, 1), tg_idx(d), nrk, F, tg_rows_pad(nrk), true, T->pP1, s, T->tg_scratch))) return rc;
       if ((rc = tg_gemm_split(h, T, s, T->pX, B, T->pP1, nrk, F, Tf, tg_idx(d), tg_idx2(d, nBd, 1)))) return rc;
     } else {
       // z0[B,d] = x[B,F] W[F,d]: 8 output tiles, K = F cut into slices
@@ -1342,7 +1379,7 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
                        cw, rc_w, cbv, gen ? P_(blast.c_str()) : nullptr, rc_b, d, nBd, tc.seed, step, thr_o, ks_o, T->z1);
   }
   if (use_batch) hipLaunchKernelGGL(k_tr_col_sums, dim3(64), dim3(256), 0, s, T->z1, B, d, colsum_slice(1));
-  hipLaunchKernelGGL(k_tr_bn_finish, dim3((d + 63) / 64), dim3(64), 0, s, colsum_slice(1), d, (double)B, use_batch, tc.batch_norm_momentum, 0,
+  hipLaunchKernelGGL(k_tr_bn_finish, dim3((d + 63) / 64), dim3(64), 0, s, colsum_slice(1), d, (double)B, use_batch, tc.batch_norm_momentum, 0 | nomov,
                      const_cast<float*>(h->params["FCBN/moving_mean"].ptr), const_cast<float*>(h->params["FCBN/moving_variance"].ptr),
                      mean2, inv2);
   hipLaunchKernelGGL(k_tr_fcbn_fwd, dim3((unsigned)((nBd + 255) / 256)), dim3(256), 0, s, T->z1, mean2, inv2, P_("FCBN/gamma"),
@@ -1358,6 +1395,8 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
     if ((rc = tg_matmul(h, T, s, MmView{T->hv, tg_idx(d), tg_idx(1), false}, B, MmView{ent, tg_idx(d), tg_idx(1), false}, dm.E, d, T->Sd,
                         tg_idx(dm.E), tg_idx(1))))
       return rc;
+    if (pred_out)
+      hipLaunchKernelGGL(k_tr_add_bias_out, dim3((unsigned)((B * dm.E + 255) / 256)), dim3(256), 0, s, T->Sd, P_("pred_bias"), dm.E, B * dm.E, pred_out);
     hipLaunchKernelGGL(k_tr_dense_loss, dim3(2048), dim3(256), 0, s, T->Sd, P_("pred_bias"), labels, dm.E, B * dm.E,
                        tc.label_smoothing_epsilon, (float)(1.0 / (double)dm.E), inv_BL, red);
   } else {
@@ -1365,6 +1404,13 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
                        dm.E, d, L, tc.label_smoothing_epsilon, (float)(1.0 / (double)dm.E), inv_BL, T->ds, red);
   }
   if (loss_out) hipLaunchKernelGGL(k_tr_store_loss, dim3(1), dim3(1), 0, s, red, 1.0 / ((double)B * (double)L), loss_out);
+  if (!one_vs_all && pred_out)
+    hipLaunchKernelGGL(k_tr_scores_out, dim3((unsigned)B), dim3(256), 0, s, T->hv, ent, P_("pred_bias"), lookup, dm.E, d, L, pred_out);
+  if (h_out) COPER_HIP_TRY(h, hipMemcpyAsync(h_out, T->hv, sizeof(float) * (size_t)nBd, hipMemcpyDeviceToDevice, s));
+  if (!apply) {      // coper_train_forward: nothing is differentiated, nothing updated, the step counter (dropout masks) stays
+    COPER_HIP_TRY(h, hipGetLastError());
+    return COPER_OK;
+  }
 
   // ---- backward
   std::string sumsq_done;   // the leaf whose squared gradient norm its own GEMM accumulates
@@ -1419,12 +1465,13 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
     // dx[b][f] = sum_(rho,k) dT[rho][b][k] P[rho][f][k]: two split-bf16 GEMMs, the [B, r*F] intermediate dz P2^T is never formed
     const int64_t nrk = (int64_t)rc_w * d;
     hipLaunchKernelGGL(k_tr_scale_rows, dim3((unsigned)((nBd + 255) / 256)), dim3(256), 0, s, T->dz, cw, rc_w, d, nBd, dTf);
-    if ((rc = tg_pack(h, xin, tg_idx(1), tg_idx(F), F, B, tg_rows_pad(F), true, T->pXt, s))) return rc;
-    if ((rc = tg_pack(h, dTf, tg_idx2(d, nBd, 1), tg_idx(d), nrk, B, tg_rows_pad(nrk), true, T->pTn, s))) return rc;
+    // (x and the projection were packed for the forward pass: the same tensors, the same powers of two -- no second reduction)
+    if ((rc = tg_pack(h, xin, tg_idx(1), tg_idx(F), F, B, tg_rows_pad(F), true, T->pXt, s, T->tg_scratch, T->pX.exp))) return rc;
+    if ((rc = tg_pack(h, dTf, tg_idx2(d, nBd, 1), tg_idx(d), nrk, B, tg_rows_pad(nrk), true, T->pTn, s, T->tg_scratch))) return rc;
     if ((rc = tg_gemm_nt(h, T->pXt, F, T->pTn, nrk, B, dW, tg_idx(d), tg_idx2(d, F * (int64_t)d, 1), s, 1, nullptr, ssq))) return rc;
     sumsq_done = wlast;   // the GEMM added |dP|^2 to the global-norm accumulator as it stored
-    if ((rc = tg_pack(h, dTf, tg_idx(d), tg_idx2(d, nBd, 1), B, nrk, tg_rows_pad(B), false, T->pTb, s))) return rc;
-    if ((rc = tg_pack(h, Wmat, tg_idx(d), tg_idx2(d, F * (int64_t)d, 1), F, nrk, tg_rows_pad(F), false, T->pP3, s))) return rc;
+    if ((rc = tg_pack(h, dTf, tg_idx(d), tg_idx2(d, nBd, 1), B, nrk, tg_rows_pad(B), false, T->pTb, s, T->tg_scratch, T->pTn.exp))) return rc;
+    if ((rc = tg_pack(h, Wmat, tg_idx(d), tg_idx2(d, F * (int64_t)d, 1), F, nrk, tg_rows_pad(F), false, T->pP3, s, T->tg_scratch, T->pP1.exp))) return rc;
     if ((rc = tg_gemm_split(h, T, s, T->pTb, B, T->pP3, F, nrk, dxin, tg_idx(F), tg_idx(1)))) return rc;
     hipLaunchKernelGGL(k_tr_dc_from_partials, dim3((unsigned)((B * rc_w + 3) / 4)), dim3(256), 0, s, T->dz, Tf, B, rc_w, d, dcw);
   } else {
@@ -1519,6 +1566,18 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
   T->b2p *= tc.beta2;
   T->step += 1;
   return COPER_OK;
+}
+
+extern "C" {
+
+COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t* rel, const int32_t* lookup, const float* labels,
+                               int64_t B, int64_t L, float* loss_out, void* stream) {
+  return train_step_impl(h, e1, rel, lookup, labels, B, L, loss_out, stream, 1, nullptr, nullptr);
+}
+
+COPER_API int coper_train_forward(coper_handle* h, const int64_t* e1, const int64_t* rel, const int32_t* lookup, const float* labels,
+                                  int64_t B, int64_t L, float* loss_out, float* pred_out, float* h_out, void* stream) {
+  return train_step_impl(h, e1, rel, lookup, labels, B, L, loss_out, stream, 0, pred_out, h_out);
 }
 
 COPER_API int coper_train_grad(coper_handle* h, const char* leaf_name, float* out, int64_t cap, int64_t* n, double* global_norm,

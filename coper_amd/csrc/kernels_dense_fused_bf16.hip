@@ -38,6 +38,10 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #ifndef COPER_FUSED_PBUDGET
 #define COPER_FUSED_PBUDGET 216
 #endif
+#ifndef COPER_FUSED_CONV_FMA
+#define COPER_FUSED_CONV_FMA 0      // 1: rounds 2 - 4's conv (fp32 fma chain on the vector unit) for A/B; 0: the conv on the matrix cores
+#endif
+
 
 // -DCOPER_FUSED_LO8 (round 4, measured, NOT the default): the weights' second term streamed as BYTES (split16.h: split8_q8 /
 // lo8_decode; 3 bytes per value instead of 4) and rebuilt as fp16 in front of the k-step's MFMAs, 20 vector instructions per
@@ -78,6 +82,7 @@ struct FusedConvArgs {
   const float* scale;
   const float* shift;
   int per_rel_conv, d, r, in_w, in_hw, Wo, img_stride, x_exp;
+  int img_exp;      // e_I: the image planes in LDS hold (e1 row | rel row) 2^e_I as fp16 hi + lo (round 5: the conv on the matrix cores)
 };
 
 // The dense finalize in this kernel's epilogue (round 4; one K slice only -- the workgroup's accumulators are then the whole
@@ -108,6 +113,63 @@ constexpr int FUSED_STAGE_WGS = 16;     // workgroups of the staging role (512 t
 // ---- prologue shared by both roles: the slice's rows of the tile's images -> LDS.
 // Two dependent latencies in all: the sorted row / relation ids of the wave's 16 queries (written by
 // k_rel_scatter), then every row piece of those queries in flight at once.
+// Round 5: the image is stored SPLIT -- per query a plane of fp16 hi and a plane of fp16 lo of (value 2^e_I), two values per dword
+// (PD = (img_stride - 1) / 2 dwords per plane, hi plane first; img_stride = 2 PD + 1 is odd: 16 queries read 16 banks) -- because
+// the conv runs on the matrix cores now (fused_conv_role): its B operand is eight fp16 values of a query's 3x3 window, taken
+// from these planes with four LDS reads.  Same LDS bytes as the fp32 image of rounds 2 - 4.
+#if !COPER_FUSED_CONV_FMA
+__device__ __forceinline__ void fused_load_images(unsigned* __restrict__ img, const FusedConvArgs& A, int start, int n,
+                                                  int t0, int t1) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int q0 = wave * 16;
+  if (q0 < n) {
+    int qi = q0 + (lane & 15);
+    if (qi > n - 1) qi = n - 1;
+    int my_row = A.sorted_row[start + qi], my_rid = A.sorted_rid[start + qi];
+#ifdef COPER_DBG_FUSED_NO_IMG
+    my_row = -1;
+#endif
+    const float* base = A.e1_rows ? A.e1_rows : A.ent;
+    const int len = t1 - t0, PD = (A.img_stride - 1) >> 1, eI = A.img_exp;     // (len, t0, d even: dense_fused_supported)
+    auto fetch2 = [&](const int row, const int rid, const int t) -> float2 {   // elements t, t + 1 of the query's (stacked) image
+      if (t >= t1) return make_float2(0.f, 0.f);
+      if (t < A.d) return row >= 0 ? *(const float2*)(base + (int64_t)row * A.d + t) : make_float2(0.f, 0.f);
+      return *(const float2*)(A.rel_emb + (int64_t)rid * A.r + (t - A.d));
+    };
+    auto put2 = [&](const int q, const int pp, const float2 x) {
+      unsigned short h0, l0, h1, l1;
+      split1_s16(x3_scale(x.x, eI), h0, l0);
+      split1_s16(x3_scale(x.y, eI), h1, l1);
+      img[q * A.img_stride + pp] = (unsigned)h0 | ((unsigned)h1 << 16);
+      img[q * A.img_stride + PD + pp] = (unsigned)l0 | ((unsigned)l1 << 16);
+    };
+    float2 v[16][2];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int row = __builtin_amdgcn_readlane(my_row, u), rid = __builtin_amdgcn_readlane(my_rid, u);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) v[u][h] = fetch2(row, rid, t0 + 2 * (lane + 64 * h));
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      if (q0 + u < n) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          if (2 * (lane + 64 * h) < len) put2(q0 + u, lane + 64 * h, v[u][h]);
+        if (lane == 0) img[(q0 + u) * A.img_stride + 2 * PD] = 0u;     // the pad dword (a window's unused third half may fall on it)
+      }
+    // rows longer than 256 values (not the shipped shapes): the rest, plainly
+    if (len > 256) {
+      for (int u = 0; u < 16 && q0 + u < n; ++u) {
+        const int row = __builtin_amdgcn_readlane(my_row, u), rid = __builtin_amdgcn_readlane(my_rid, u);
+        for (int pp = 128 + lane; 2 * pp < len; pp += 64) put2(q0 + u, pp, fetch2(row, rid, t0 + 2 * pp));
+      }
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+#else
 __device__ __forceinline__ void fused_load_images(float* __restrict__ img, const FusedConvArgs& A, int start, int n,
                                                   int t0, int t1) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -159,14 +221,20 @@ __device__ __forceinline__ void fused_load_images(float* __restrict__ img, const
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 }
+#endif
 
 // ---- matrix role.  Wave w (0..3) owns feature blocks w, w+4, ... of the NFB/4*4 "full" ones for every query
 // block, and -- when NFB is not a multiple of 4 (d = 200: 13 blocks) -- query blocks w, w+4 of the one left
 // over, so that every SIMD carries the same MFMA load to within one query block (dealing whole feature blocks
 // would leave one wave with 4 of 13).  All four waves then stream that last block's weight fragments; the
 // repeats hit L1/L2.
+#if COPER_FUSED_CONV_FMA
+typedef float fused_img_t;
+#else
+typedef unsigned fused_img_t;
+#endif
 template <int NFB, int NB, bool WNT>
-__device__ __forceinline__ void fused_matrix_role(const uint4* __restrict__ xring, float* __restrict__ img,
+__device__ __forceinline__ void fused_matrix_role(const uint4* __restrict__ xring, fused_img_t* __restrict__ img,
                                                   const uint4* __restrict__ Whi, const fused_wlo_t* __restrict__ Wlo,
                                                   const FusedConvArgs& A, int64_t relw, int start, int n, int fb0,
                                                   int nfb, int64_t ks32n, int64_t kb, int64_t ke, int t0, int t1,
@@ -234,13 +302,40 @@ __device__ __forceinline__ void fused_matrix_role(const uint4* __restrict__ xrin
     acc[0][0][2] += __uint_as_float(xb[0].x);                                                       \
   }
 #else
+  // Round 5: the x fragments of query block q + 1 are requested BEFORE the nine MFMAs of block q are issued (two register
+  // pairs, alternating).  Rounds 2 - 4 left the order to the compiler, which used one pair: ds_read x 2, wait, 9 MFMAs, ds_read x 2,
+  // wait ... -- every query block paid an LDS round trip with the matrix pipe idle (~110 of its ~250 cycles: the role ran at
+  // 31 cycles per MFMA, half the pipe's rate, on every shape -- profiles/r05a_encoder_ablations.txt, the NOCONV / NOW builds).
+  // __builtin_amdgcn_sched_group_barrier pins the issue order inside the step's basic block: 2 LDS reads (block q + 1), then
+  // the 3 NFULL MFMAs of block q.
+#ifdef COPER_DBG_FUSED_NO_XREAD      /* diagnostic: the B operands come from nowhere (no LDS read in the matrix role) */
+#define M_LD(i_) make_uint4((unsigned)lane, (unsigned)(i_), 0x3c003c00u, 0x3c003c00u)
+#else
+#define M_LD(i_) xb[i_]
+#endif
+#ifndef COPER_FUSED_XPF
+#define COPER_FUSED_XPF 2     // query blocks the x fragments are requested ahead of their MFMAs (1 or 2)
+#endif
+  // the blocks a wave consumes in one step, in order: 0 .. NB-1, then (NRQ > 0) its own block of the left-over feature block
+  constexpr int NV = NB + (NRQ > 0 ? 1 : 0), XPF = COPER_FUSED_XPF, XR = XPF + 1;
+  const int qr = wave < NB ? wave : NB - 1;
+#define M_LDV_H(v_) M_LD(((v_) < NB ? (v_) : qr) * 64)
+#define M_LDV_L(v_) M_LD((NB + ((v_) < NB ? (v_) : qr)) * 64)
 #define M_STEP(s2)                                                                                  \
   {                                                                                                 \
     FW_PRE((s2) % P)                                                                                \
     __builtin_amdgcn_s_barrier();                                                                   \
     const uint4* xb = xring + ((s2)&1) * XSTAGE + lane;                                             \
+    uint4 bhq[XR], blq[XR];                                                                         \
+    _Pragma("unroll") for (int v = 0; v < XPF && v < NV; ++v) { bhq[v] = M_LDV_H(v); blq[v] = M_LDV_L(v); } \
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 * (XPF < NV ? XPF : NV), 0);                      \
     _Pragma("unroll") for (int q = 0; q < NB; ++q) {                                                \
-      const uint4 bh = xb[q * 64], bl = xb[(NB + q) * 64];                                          \
+      if (q + XPF < NV) {                                                                           \
+        bhq[(q + XPF) % XR] = M_LDV_H(q + XPF); blq[(q + XPF) % XR] = M_LDV_L(q + XPF);             \
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                          \
+      }                                                                                             \
+      __builtin_amdgcn_sched_group_barrier(0x008, 3 * NFULL, 0);                                    \
+      const uint4 bh = bhq[q % XR], bl = blq[q % XR];                                               \
       _Pragma("unroll") for (int j = 0; j < NFULL; ++j)                                             \
           acc[j][q] = MFMA16_BF16(FW_LO((s2) % P, j), bh, acc[j][q]);                               \
       _Pragma("unroll") for (int j = 0; j < NFULL; ++j)                                             \
@@ -250,7 +345,9 @@ __device__ __forceinline__ void fused_matrix_role(const uint4* __restrict__ xrin
     }                                                                                               \
     _Pragma("unroll") for (int t = 0; t < NRQ; ++t) {                                               \
       const int q = wave + 4 * t < NB ? wave + 4 * t : NB - 1; /* past the tile: recompute, not stored */ \
-      const uint4 bh = xb[q * 64], bl = xb[(NB + q) * 64];                                          \
+      uint4 bh, bl;                                                                                 \
+      if (t == 0) { bh = bhq[NB % XR]; bl = blq[NB % XR]; }    /* (requested beside the last full blocks) */ \
+      else { bh = M_LD(q * 64); bl = M_LD((NB + q) * 64); }                                         \
       accr[t] = MFMA16_BF16(FW_LO((s2) % P, NFULL), bh, accr[t]);                                   \
       accr[t] = MFMA16_BF16(FW_HI((s2) % P, NFULL), bl, accr[t]);                                   \
       accr[t] = MFMA16_BF16(FW_HI((s2) % P, NFULL), bh, accr[t]);                                   \
@@ -379,6 +476,137 @@ __device__ __forceinline__ void fused_matrix_role(const uint4* __restrict__ xrin
 }
 
 // ---- conv role: conv wave cw (0..3) produces x fragments f = cw, cw+4
+#if !COPER_FUSED_CONV_FMA
+// Round 5: the 3x3 conv on the matrix cores.  Rounds 2 - 4 ran it as 72 fp32 FMAs per lane and output pixel (conv_x8) -- ~150
+// vector instructions per 16-query fragment and k-step with the split, 1,700 cycles per k-step for the eight fragments of a
+// 128-query tile (profiles/r05a_encoder_ablations.txt, NOMFMA build), against 1,250 for the dense layer's own MFMAs: the conv, not
+// the weight stream, bounded the static-weight shapes, and it shared every SIMD's issue with the matrix waves on all of them.
+// Here one output pixel of 16 queries x 32 channels is TWO v_mfma_f32_16x16x32_f16:
+//     D[channel m][query n] = b'[m] + sum_k A[m][k] B[k][n],   K = 32 slots holding the 27 products of the x3 arithmetic
+//         slots  0.. 7   tap_hi[t] img_hi[t]   t = 0..7      (lane group g = 0)
+//         slots  8..15   tap_hi[t] img_lo[t]                 (g = 1)
+//         slots 16..23   tap_lo[t] img_hi[t]                 (g = 2)
+//         slots 24..26   tap_hi[8] img_hi[8], tap_hi[8] img_lo[8], tap_lo[8] img_hi[8];  27..31 zero weights   (g = 3)
+// with tap' = conv_w scale (folded BN, conv_fold.h) 2^(e_x - e_I) and img' = image 2^e_I split into fp16 hi + lo (the planes
+// fused_load_images leaves in LDS), so that D = x 2^e_x as before: the bias enters as the C operand, ReLU and the split of x
+// follow on the 8 accumulator values of a lane.  The rows of the two MFMAs are channels 8 (m / 4) + 4 u + m % 4 (u = 0, 1): a lane's
+// eight outputs are then the channels 8 g .. 8 g + 7 of its query -- the B-operand layout of the dense layer's MFMAs, written
+// to the ring without a shuffle.  A lane's B operand: three ds_read2_b32 (the window's rows, its own plane) + one ds_read_b32
+// (tap 8 of the other plane), two v_alignbit per row for the window's column parity, two v_perm.  ~50 vector instructions and two
+// MFMAs per fragment and k-step instead of ~150; 60 fewer registers in this role (no taps).
+// Arithmetic: every product carries 22 bits (hi hi + hi lo + lo hi; lo lo dropped: 2^-22), fp32 accumulation inside the MFMA --
+// against the fp32 fma chain of rounds 2 - 4 this moves x by ~2^-22 of the pixel's magnitude, the size of the split x gets
+// anyway; tests/test_gpu_scale.py holds h to 1e-5 of float64 relative to its magnitude at every scale as before.
+// x (and with it h) remains a pure function of (e1, rel): a column of the MFMA sees only its own query's window.
+template <int NB>
+__device__ __forceinline__ void fused_conv_role(uint4* __restrict__ xring, unsigned* __restrict__ img,
+                                                const FusedConvArgs& A, int64_t relw, int start, int n, int64_t kb,
+                                                int64_t ke, int i_lo, int t0, int t1, int cw) {
+  constexpr int NFR = (NB + 3) / 4;
+  constexpr int XSTAGE = 2 * NB * 64;
+  const int lane = threadIdx.x & 63;
+  const int nk = (int)(ke - kb);
+  const int Wo = A.Wo, in_w = A.in_w, W2 = in_w >> 1;
+  const int g = lane >> 4, m = lane & 15;
+  const int PD = (A.img_stride - 1) >> 1;
+  // the A operands (the relation's folded taps, split) and the bias rows (loads in flight during the image prologue)
+  u32x4 aop[2];
+  f32x4 cop[2];
+  {
+    const float* wsrc = A.per_rel_conv ? A.conv_w + relw * (int64_t)(9 * 32) : A.conv_w;
+    const float* bsrc = A.per_rel_conv ? A.conv_b + relw * (int64_t)32 : A.conv_b;
+    const int te = A.x_exp - A.img_exp;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int ch = 8 * (m >> 2) + 4 * u + (m & 3);
+      const float sc = A.scale[ch];
+      unsigned short th[9], tl[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) split1_s16(x3_scale(wsrc[k * 32 + ch] * sc, te), th[k], tl[k]);
+      unsigned short sl[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) sl[k] = g == 2 ? tl[k] : th[k];
+      if (g == 3) {
+        sl[0] = th[8]; sl[1] = th[8]; sl[2] = tl[8];
+#pragma unroll
+        for (int k = 3; k < 8; ++k) sl[k] = 0;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) aop[u][k] = (unsigned)sl[2 * k] | ((unsigned)sl[2 * k + 1] << 16);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = 8 * g + 4 * u + i;
+        cop[u][i] = x3_scale(fmaf(bsrc[c], A.scale[c], A.shift[c]), A.x_exp);
+      }
+    }
+  }
+  fused_load_images(img, A, start, n, t0, t1);
+  // dword bases of this lane's query in each of the wave's fragments (padding lanes repeat the last query): own plane (hi for
+  // g = 0, 2, 3; lo for g = 1) and the other one (tap 8's second term, used by g = 3)
+  int qown[NFR], qoth[NFR];
+#pragma unroll
+  for (int t = 0; t < NFR; ++t) {
+    int qi = (cw + 4 * t) * 16 + m;
+    if (qi > n - 1) qi = n - 1;
+    qown[t] = qi * A.img_stride + (g == 1 ? PD : 0);
+    qoth[t] = qi * A.img_stride + (g == 1 ? 0 : PD);
+  }
+  int poff = (int)(kb - (int64_t)i_lo * Wo);   // pixel offset ci*in_w + cj of the NEXT conv step (values; a dword holds two)
+  int cj = poff;
+  for (int kk = 0; kk <= nk; ++kk) {
+    // kk = 0: x(0) before the first barrier; kk >= 1: barrier k = kk-1, then x(kk) while the matrix waves run k
+    if (kk > 0) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my x writes of step kk-1 have landed in LDS
+      __builtin_amdgcn_s_barrier();
+    }
+#ifdef COPER_DBG_FUSED_NO_CONV
+    if (kk < 1) {
+#else
+    if (kk < nk) {
+#endif
+      const int pd = poff >> 1;
+      const unsigned sh = (unsigned)(poff & 1) << 4;      // wave-uniform: the window starts in the low or the high half of a dword
+#pragma unroll
+      for (int t = 0; t < NFR; ++t) {
+        if (cw + 4 * t < NB) {   // wave-uniform
+          const unsigned* r = img + qown[t] + pd;
+          const unsigned d00 = r[0], d01 = r[1], d10 = r[W2], d11 = r[W2 + 1], d20 = r[2 * W2], d21 = r[2 * W2 + 1];
+          const unsigned o21 = img[qoth[t] + pd + 2 * W2 + 1];
+          const unsigned a01 = __builtin_amdgcn_alignbit(d01, d00, sh), a2 = d01 >> sh;
+          const unsigned b01 = __builtin_amdgcn_alignbit(d11, d10, sh), b2 = d11 >> sh;
+          const unsigned c01 = __builtin_amdgcn_alignbit(d21, d20, sh), c2 = d21 >> sh;
+          u32x4 bop;
+          bop[0] = a01;                                                  // taps 0, 1
+          bop[1] = __builtin_amdgcn_perm(b01, a2, 0x05040100u);          // taps 2, 3
+          bop[2] = __builtin_amdgcn_perm(b2, b01, 0x05040302u);          // taps 4, 5
+          bop[3] = c01;                                                  // taps 6, 7
+          if (g == 3) {                                                  // tap 8: [hi, lo], [hi, -]; the other slots meet zero weights
+            bop[0] = __builtin_amdgcn_perm(o21 >> sh, c2, 0x05040100u);
+            bop[1] = c2 & 0xffffu;
+          }
+          const f32x4 y0 = MFMA16_BF16(aop[0], bop, cop[0]);
+          const f32x4 y1 = MFMA16_BF16(aop[1], bop, cop[1]);
+          // ReLU: one v_med3_f32 per value (fmaxf compiles to two: it canonicalises its operand first).  NOT inline asm: the hardware
+          // does not interlock a vector instruction that reads an MFMA's result, the compiler's hazard recognizer pads the wait
+          // states for its own instructions only -- an asm v_max_f32 right behind the MFMA read stale registers (measured: h = 0).
+          float y[8];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            y[i] = __builtin_amdgcn_fmed3f(y0[i], 0.f, 3.0e38f);
+            y[4 + i] = __builtin_amdgcn_fmed3f(y1[i], 0.f, 3.0e38f);
+          }
+          uint4 h4, l4;
+          split8_pos_s16(y, h4, l4);
+          uint4* dst = xring + (kk & 1) * XSTAGE + (cw + 4 * t) * 64 + lane;
+          dst[0] = h4;
+          dst[NB * 64] = l4;
+        }
+      }
+      if (++cj == Wo) { cj = 0; poff += in_w - Wo + 1; } else { ++poff; }
+    }
+  }
+}
+#else
 template <int NB>
 __device__ __forceinline__ void fused_conv_role(uint4* __restrict__ xring, float* __restrict__ img,
                                                 const FusedConvArgs& A, int64_t relw, int start, int n, int64_t kb,
@@ -437,6 +665,7 @@ __device__ __forceinline__ void fused_conv_role(uint4* __restrict__ xring, float
     }
   }
 }
+#endif
 
 // (Round 2, measured and not kept: a persistent form -- one workgroup per CU walking the (tile, K slice) items round-robin
 // instead of a grid sized by the worst case, most of it empty workgroups -- took 0.24 ms where this launch takes 0.19
@@ -505,7 +734,11 @@ __global__ __launch_bounds__(512) void k_dense_fused_bf16x3(const uint4* __restr
   const unsigned long long dbg_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
   uint4* xring = fused_lds;                       // 2 stages x 16 slots x 1 KiB
+#if COPER_FUSED_CONV_FMA
   float* img = (float*)(fused_lds + 2 * 16 * 64);
+#else
+  unsigned* img = (unsigned*)(fused_lds + 2 * 16 * 64);
+#endif
   // pixel p = k-step index: the slice needs image rows i_lo .. i_hi + 2
   const int i_lo = (int)(kb / A.Wo);
   const int t0 = i_lo * A.in_w;
@@ -564,6 +797,9 @@ bool dense_fused_supported(const coper_handle* h, int nslices) {
   if (dm.F != dm.F_pad || dm.F != (int64_t)dm.Ho * dm.Wo * 32) return false;
   if (dm.gen_conv && !dm.gen_fc) return false;       // per-relation filters need single-relation tiles
   if (!(dm.nfb == 13 || dm.nfb == 8 || dm.nfb == 16)) return false;
+#if !COPER_FUSED_CONV_FMA
+  if ((dm.in_w & 1) || (dm.d & 1) || (dm.stacked && (dm.r & 1))) return false;   // the image planes hold two values per dword
+#endif
   int stride = fused_rows_max(dm, nslices) * dm.in_w;
   stride |= 1;
   size_t lds = (size_t)2 * 16 * 64 * sizeof(uint4) + (size_t)128 * stride * sizeof(float);
@@ -585,7 +821,7 @@ static void dense_fused_launch(coper_handle* h, const int64_t* e1, const int64_t
   A.rel_emb = dm.lookup ? nullptr : h->params["rel_emb"].ptr;
   A.conv_w = dm.gen_conv ? h->conv_w_rel : h->params["conv1_weights"].ptr;
   A.conv_b = dm.gen_conv ? h->conv_b_rel : h->params["conv1_bias"].ptr;
-  A.scale = h->conv_scale; A.shift = h->conv_shift; A.x_exp = h->x_exp;
+  A.scale = h->conv_scale; A.shift = h->conv_shift; A.x_exp = h->x_exp; A.img_exp = h->img_exp;
   A.per_rel_conv = dm.gen_conv ? 1 : 0;
   A.d = dm.d; A.r = dm.r; A.in_w = dm.in_w; A.in_hw = dm.in_h * dm.in_w; A.Wo = dm.Wo;
   A.img_stride = (fused_rows_max(dm, nslices) * dm.in_w) | 1;

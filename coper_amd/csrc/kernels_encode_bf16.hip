@@ -133,6 +133,12 @@ int compute_x_exp(coper_handle* h, unsigned* scratch, hipStream_t s) {
     COPER_HIP_TRY(h, hipStreamSynchronize(s));
   }
   const float in_max = dm.stacked ? fmaxf(h->x3_ent_absmax, rel_max) : h->x3_ent_absmax;
+  {   // e_I: the fused encoder's image planes hold (e1 row | rel row) 2^e_I with the largest input in [2^7, 2^8) -- the middle of
+      // fp16's window, eleven binades of full precision below it and eight above (kernels_dense_fused_bf16.hip, round 5)
+    unsigned ib;
+    memcpy(&ib, &in_max, sizeof ib);
+    h->img_exp = x3_exp_for_bits(ib) - 7;
+  }
   const int64_t Rc = dm.gen_conv ? dm.R : 1;
   hipLaunchKernelGGL(k_x_bound, dim3((unsigned)((Rc * dm.C + 255) / 256)), dim3(256), 0, s, cw, cb, h->conv_scale, h->conv_shift, Rc, dm.C,
                      dm.fh * dm.fw, in_max, scratch);

@@ -1,4 +1,7 @@
-// Split-bf16 GEMMs of the training step (train_gemm_bf16.hip): operand packing and C(i,j) = sum_k X(i,k) Y(j,k).
+// Split-16 GEMMs of the training step (train_gemm_bf16.hip; the file names are round 2's): operand packing and
+// C(i,j) = sum_k X(i,k) Y(j,k).  Round 5: the split is the inference path's SCALED fp16 split (split16.h) -- every packed operand
+// carries an exact power of two chosen from its own largest magnitude (gradients are 1e-6, activations 1e+1: nothing puts them in
+// fp16's window), 22 bits per value instead of the 16 of round 2's bf16 split: 5e-7 relative per product instead of 1.5e-5.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -18,6 +21,7 @@ inline TgIdx tg_idx2(int64_t seg, int64_t s_hi, int64_t s_lo) { return TgIdx{seg
 struct TgPlanes {
   uint4* hi = nullptr;
   uint4* lo = nullptr;
+  int32_t* exp = nullptr;   // device word: the planes hold X 2^exp (written by tg_pack, read by the GEMM's epilogue)
 };
 
 constexpr int TG_SUMSQ_SLOTS = 64;
@@ -31,8 +35,10 @@ inline size_t tg_plane_elems(int64_t rows, int64_t K) { return (size_t)(tg_rows_
 
 // X(row, k) = src[off(ri, row) + off(ki, k)] -> planes (rows zero-padded to R_pad, k to a multiple of 16).
 // rows_fast: consecutive rows are contiguous in memory (the pack reads along rows), else consecutive k are.
+// exp_from: another plane set packed from the SAME tensor earlier (its exponent is reused: no second pass for the maximum);
+// otherwise the largest |X| is reduced first (scratch: two device words)
 int tg_pack(coper_handle* h, const float* src, TgIdx ri, TgIdx ki, int64_t R, int64_t K, int64_t R_pad, bool rows_fast, TgPlanes out,
-            hipStream_t s);
+            hipStream_t s, unsigned* scratch, const int32_t* exp_from = nullptr);
 // C[off(ci, i) + off(cj, j)] = sum_k X(i, k) Y(j, k), i < M, j < N
 // nsplit > 1: K is cut into nsplit slices whose partial sums go to `part` ([nsplit][M][N] floats) and are summed in slice order
 // sumsq: when not null, the sum of the squares of the stored C is added by the storing kernel to the TG_SUMSQ_SLOTS device

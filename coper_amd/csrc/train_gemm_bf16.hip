@@ -12,32 +12,64 @@
 // inference path (k_pack_frag: any two-level strided view of an fp32 tensor -> [row block of 32][k-step][64 lanes] x 16 B,
 // transposing through LDS so that the reads follow the contiguous dimension), then k_gemm_nt_bf16x3 streams fragments
 // straight into the registers the MFMAs consume and stores C through a two-level strided view.
+// Round 5: the split is fp16 with one exact power of two per packed operand (split16.h; COPER_SPLIT_BF16 builds keep round 2's):
+// the planes hold X 2^e_X with max |X| 2^e_X in [2^14, 2^15), the epilogue multiplies by 2^-(e_X + e_Y).
 #include "coper_internal.h"
+#include "split16.h"
 #include "train_gemm.h"
 
 namespace coper {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-#define TG_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&(a), *(const bf16x8*)&(b), (c), 0, 0, 0)
+#define TG_MFMA(a, b, c) S16_MFMA32(a, b, c)
 
 __device__ __forceinline__ int64_t tg_off(const TgIdx& a, int64_t i) {
   return a.seg > 0 ? (i / a.seg) * a.s_hi + (i % a.seg) * a.s_lo : i * a.s_lo;
 }
 
-__device__ __forceinline__ void tg_split8(const float* v, uint4& hi, uint4& lo) {
-  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-  unsigned hw[4], lw[4];
+__device__ __forceinline__ void tg_split8(const float* v, int e, uint4& hi, uint4& lo) {
+  float w[8];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    bf16x2_t hp = {(__bf16)v[2 * j], (__bf16)v[2 * j + 1]};
-    float r0 = v[2 * j] - (float)hp[0], r1 = v[2 * j + 1] - (float)hp[1];
-    bf16x2_t lp = {(__bf16)r0, (__bf16)r1};
-    hw[j] = __builtin_bit_cast(unsigned, hp);
-    lw[j] = __builtin_bit_cast(unsigned, lp);
+  for (int j = 0; j < 8; ++j) w[j] = x3_scale(v[j], e);
+  split8_s16(w, hi, lo);
+}
+
+// The largest |X| of an operand, as an exponent: ONE launch.  Every view tg_pack is given is a permutation of a dense tensor, so
+// the maximum is taken over the `n` contiguous floats behind it (16-byte loads: 118 MB of projections in ~25 us); the last block
+// to finish (ticket in scratch[1]) turns the bits into the power of two, stores it for the pack and the GEMM, and leaves the two
+// scratch words zero for the next call.
+__global__ __launch_bounds__(256) void k_tg_absmax_exp(const float* __restrict__ src, int64_t n, unsigned* __restrict__ scratch,
+                                                       int32_t* __restrict__ exp_out) {
+  unsigned m = 0u;
+  const int64_t n4 = (((uintptr_t)src) & 15) == 0 ? n >> 2 : 0;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n4; e += (int64_t)gridDim.x * 256) {
+    const uint4 v = ((const uint4*)src)[e];
+    const unsigned a = v.x & 0x7fffffffu, b = v.y & 0x7fffffffu, c = v.z & 0x7fffffffu, d = v.w & 0x7fffffffu;
+    const unsigned ab = a > b ? a : b, cd = c > d ? c : d, x = ab > cd ? ab : cd;
+    m = x > m ? x : m;
   }
-  hi = make_uint4(hw[0], hw[1], hw[2], hw[3]);
-  lo = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+  for (int64_t e = 4 * n4 + (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    const unsigned b = __float_as_uint(src[e]) & 0x7fffffffu;
+    m = b > m ? b : m;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const unsigned t = __shfl_xor(m, o, 64); m = t > m ? t : m; }
+  __shared__ unsigned sm[4];
+  __shared__ int s_last;
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned w = sm[0] > sm[1] ? sm[0] : sm[1], w2 = sm[2] > sm[3] ? sm[2] : sm[3];
+    w = w > w2 ? w : w2;
+    if (w) atomicMax(scratch, w);
+    __threadfence();
+    s_last = atomicAdd(scratch + 1, 1u) == gridDim.x - 1 ? 1 : 0;
+    if (s_last) {
+      const unsigned all = atomicExch(scratch, 0u);     // (memory-side: coherent whatever XCD added)
+      *exp_out = x3_exp_for_bits(all);
+      scratch[1] = 0u;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -48,7 +80,8 @@ __device__ __forceinline__ void tg_split8(const float* v, uint4& hi, uint4& lo) 
 // ------------------------------------------------------------------------------------------------
 template <int MODE, int RT>
 __global__ __launch_bounds__(256) void k_pack_frag(const float* __restrict__ src, TgIdx ri, TgIdx ki, int64_t R, int64_t K,
-                                                   int KS16, int KST, uint4* __restrict__ hi, uint4* __restrict__ lo) {
+                                                   int KS16, int KST, uint4* __restrict__ hi, uint4* __restrict__ lo,
+                                                   const int32_t* __restrict__ exp_dev, int32_t* __restrict__ exp_copy) {
   // tile of RT rows x KT k (4096 elements): 32 x 128 when k is the contiguous direction, 128 x 32 when rows are (a
   // wave then reads 512 contiguous bytes per k instead of 128: the [rho][f][k] -> rows (rho, k) view of the projection
   // went from 70 to 5x us)
@@ -88,6 +121,8 @@ __global__ __launch_bounds__(256) void k_pack_frag(const float* __restrict__ src
     }
   }
   __syncthreads();
+  const int pe = *exp_dev;
+  if (exp_copy && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *exp_copy = pe;    // (a plane set packed with another set's exponent)
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
     const int f = t + 256 * p, blk = f >> 6, l = f & 63;          // 8 (row block, k-step) blocks of 64 lanes
@@ -99,7 +134,7 @@ __global__ __launch_bounds__(256) void k_pack_frag(const float* __restrict__ src
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = tile[row][kb + j];
     uint4 h4, l4;
-    tg_split8(v, h4, l4);
+    tg_split8(v, pe, h4, l4);
     const int64_t o = (((int64_t)blockIdx.y * (RT / 32) + rb) * KST + ks) * 64 + l;
     hi[o] = h4;
     lo[o] = l4;
@@ -116,17 +151,26 @@ static bool tg_vec_ok(const float* src, const TgIdx& fast, const TgIdx& slow, in
 }
 
 int tg_pack(coper_handle* h, const float* src, TgIdx ri, TgIdx ki, int64_t R, int64_t K, int64_t R_pad, bool rows_fast, TgPlanes out,
-            hipStream_t s) {
+            hipStream_t s, unsigned* scratch, const int32_t* exp_from) {
   const int KS16 = (int)((K + 15) / 16), KST = (int)tg_ks_stride(K);
+  if (!out.exp || !scratch) return fail(h, COPER_ESTATE, "tg_pack: plane set without an exponent word");
+  if (!exp_from) {       // (scratch is zero between calls: the reduction's last block resets it)
+    int64_t nb = (R * K + 256 * 16 - 1) / (256 * 16);
+    if (nb > 1024) nb = 1024;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(k_tg_absmax_exp, dim3((unsigned)nb), dim3(256), 0, s, src, R * K, scratch, out.exp);
+  }
+  const int32_t* pexp = exp_from ? exp_from : out.exp;
+  int32_t* pcopy = exp_from ? out.exp : nullptr;
   const bool vec = rows_fast ? tg_vec_ok(src, ri, ki, R) : tg_vec_ok(src, ki, ri, K);
   if (!rows_fast) {
     dim3 grid((unsigned)((KS16 + 7) / 8), (unsigned)(R_pad / 32));
-    if (vec) hipLaunchKernelGGL((k_pack_frag<2, 32>), grid, dim3(256), 0, s, src, ri, ki, R, K, KS16, KST, out.hi, out.lo);
-    else hipLaunchKernelGGL((k_pack_frag<0, 32>), grid, dim3(256), 0, s, src, ri, ki, R, K, KS16, KST, out.hi, out.lo);
+    if (vec) hipLaunchKernelGGL((k_pack_frag<2, 32>), grid, dim3(256), 0, s, src, ri, ki, R, K, KS16, KST, out.hi, out.lo, pexp, pcopy);
+    else hipLaunchKernelGGL((k_pack_frag<0, 32>), grid, dim3(256), 0, s, src, ri, ki, R, K, KS16, KST, out.hi, out.lo, pexp, pcopy);
   } else {
     dim3 grid((unsigned)((KS16 + 1) / 2), (unsigned)(R_pad / 128));   // R_pad is a multiple of TG_ROW_PAD = 128
-    if (vec) hipLaunchKernelGGL((k_pack_frag<3, 128>), grid, dim3(256), 0, s, src, ri, ki, R, K, KS16, KST, out.hi, out.lo);
-    else hipLaunchKernelGGL((k_pack_frag<1, 128>), grid, dim3(256), 0, s, src, ri, ki, R, K, KS16, KST, out.hi, out.lo);
+    if (vec) hipLaunchKernelGGL((k_pack_frag<3, 128>), grid, dim3(256), 0, s, src, ri, ki, R, K, KS16, KST, out.hi, out.lo, pexp, pcopy);
+    else hipLaunchKernelGGL((k_pack_frag<1, 128>), grid, dim3(256), 0, s, src, ri, ki, R, K, KS16, KST, out.hi, out.lo, pexp, pcopy);
   }
   COPER_HIP_TRY(h, hipGetLastError());
   return COPER_OK;
@@ -146,8 +190,10 @@ template <int TI, int TJ, int NBUF>
 __global__ __launch_bounds__(256) void k_gemm_nt_bf16x3(const uint4* __restrict__ Xhi, const uint4* __restrict__ Xlo,
                                                         const uint4* __restrict__ Yhi, const uint4* __restrict__ Ylo, int KS16_all, int KST,
                                                         float* __restrict__ C, TgIdx ci, TgIdx cj, int64_t M, int64_t N, int nsplit,
-                                                        float* __restrict__ part, double* __restrict__ sumsq, int cs) {
+                                                        float* __restrict__ part, double* __restrict__ sumsq, int cs,
+                                                        const int32_t* __restrict__ ex, const int32_t* __restrict__ ey) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int se = -(*ex + *ey);      // the accumulators carry 2^(e_X + e_Y)
   // 1-D grid, XCD-aware: workgroup L runs on XCD L % 8 as that XCD's (L / 8)-th workgroup.  The `cs` i tiles that share one
   // j tile's Y fragments are consecutive workgroups of ONE XCD, so its L2 fetches those fragments once (with i fastest in a
   // plain 3-D grid the four i tiles of the T / dx shapes sat on four XCDs: the 118 MB of projection planes crossed the
@@ -239,7 +285,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt_bf16x3(const uint4* __restrict_
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int64_t i = (ib0 + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          if (i < M) pz[i * N] = acc[a][b][r];
+          if (i < M) pz[i * N] = x3_scale(acc[a][b][r], se);
         }
         continue;
       }
@@ -248,8 +294,9 @@ __global__ __launch_bounds__(256) void k_gemm_nt_bf16x3(const uint4* __restrict_
       for (int r = 0; r < 16; ++r) {
         const int64_t i = (ib0 + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (i < M) {
-          C[tg_off(ci, i) + oj] = acc[a][b][r];
-          ss = fmaf(acc[a][b][r], acc[a][b][r], ss);
+          const float v = x3_scale(acc[a][b][r], se);
+          C[tg_off(ci, i) + oj] = v;
+          ss = fmaf(v, v, ss);
         }
       }
     }
@@ -305,7 +352,7 @@ int tg_split_k(int64_t M, int64_t N, int64_t K) {
 }
 
 void tg_launch_w128(const TgPlanes& X, int64_t M, const TgPlanes& Y, int64_t N, int KS16, int KST, float* C, TgIdx ci, TgIdx cj, hipStream_t s,
-                    int nsplit, float* part, double* sumsq);
+                    int nsplit, float* part, double* sumsq);     // (reads X.exp / Y.exp)
 
 int tg_gemm_nt(coper_handle* h, TgPlanes X, int64_t M, TgPlanes Y, int64_t N, int64_t K, float* C, TgIdx ci, TgIdx cj, hipStream_t s,
                int nsplit, float* part, double* sumsq) {
@@ -325,7 +372,7 @@ int tg_gemm_nt(coper_handle* h, TgPlanes X, int64_t M, TgPlanes Y, int64_t N, in
   const int cs = ti < 4 ? ti : 4;                       // i tiles of one j tile kept together on an XCD
   const int64_t nclu = (int64_t)((ti + cs - 1) / cs) * tj * nsplit;
   dim3 grid((unsigned)(8 * cs * ((nclu + 7) / 8)));
-  hipLaunchKernelGGL((k_gemm_nt_bf16x3<2, 2, 3>), grid, dim3(256), 0, s, X.hi, X.lo, Y.hi, Y.lo, KS16, KST, C, ci, cj, M, N, nsplit, part, sumsq, cs);
+  hipLaunchKernelGGL((k_gemm_nt_bf16x3<2, 2, 3>), grid, dim3(256), 0, s, X.hi, X.lo, Y.hi, Y.lo, KS16, KST, C, ci, cj, M, N, nsplit, part, sumsq, cs, X.exp, Y.exp);
   if (nsplit > 1)
     hipLaunchKernelGGL(k_tg_reduce, dim3((unsigned)((M * N + 255) / 256)), dim3(256), 0, s, part, nsplit, M, N, C, ci, cj, sumsq);
   COPER_HIP_TRY(h, hipGetLastError());

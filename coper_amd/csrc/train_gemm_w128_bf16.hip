@@ -10,14 +10,15 @@
 // Measured (MI355X, FB15k-237 step, 30 GFLOP each): T = x P 82 us + 19 us slice sum (four-wave kernel: 130), dP 95 (124),
 // dx 83 + 16 (139); main loop alone 68 us, without its loads 54 us (COPER_DBG_W128_NO_EPI / _NO_LOADS builds).
 // This file is built WITHOUT -amdgpu-mfma-vgpr-form: the accumulators must live in AGPRs.
+// Round 5: fp16 planes carrying one power of two per operand (train_gemm.h); the epilogue takes 2^(e_X + e_Y) out.
 #include "coper_internal.h"
+#include "split16.h"
 #include "train_gemm.h"
 
 namespace coper {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-#define TGW_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&(a), *(const bf16x8*)&(b), (c), 0, 0, 0)
+#define TGW_MFMA(a, b, c) S16_MFMA32(a, b, c)
 
 __device__ __forceinline__ int64_t tgw_off(const TgIdx& a, int64_t i) {
   return a.seg > 0 ? (i / a.seg) * a.s_hi + (i % a.seg) * a.s_lo : i * a.s_lo;
@@ -27,8 +28,10 @@ template <int NBUF>
 __global__ __launch_bounds__(256) void k_gemm_nt_w128_bf16x3(const uint4* __restrict__ Xhi, const uint4* __restrict__ Xlo,
                                                             const uint4* __restrict__ Yhi, const uint4* __restrict__ Ylo, int KS16_all, int KST,
                                                             float* __restrict__ C, TgIdx ci, TgIdx cj, int64_t M, int64_t N, int nsplit,
-                                                            float* __restrict__ part, double* __restrict__ sumsq, int cs) {
+                                                            float* __restrict__ part, double* __restrict__ sumsq, int cs,
+                                                            const int32_t* __restrict__ ex, const int32_t* __restrict__ ey) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int se = -(*ex + *ey);
   // a workgroup is four independent waves: the (up to) 4 i tiles of one (j tile, K slice), which share the Y fragments
   const int ti = (int)((M + 127) / 128), tj = (int)((N + 127) / 128), nic = (ti + 3) / 4;
   const int c = blockIdx.x;
@@ -129,8 +132,9 @@ __global__ __launch_bounds__(256) void k_gemm_nt_w128_bf16x3(const uint4* __rest
 #pragma unroll
       for (int b = 0; b < 4; ++b)
         if (i < M && jok[b]) {
-          pj[b][oi] = acc[a][b][r];
-          ss = fmaf(acc[a][b][r], acc[a][b][r], ss);
+          const float v = x3_scale(acc[a][b][r], se);
+          pj[b][oi] = v;
+          ss = fmaf(v, v, ss);
         }
     }
   }
@@ -147,7 +151,7 @@ void tg_launch_w128(const TgPlanes& X, int64_t M, const TgPlanes& Y, int64_t N, 
   const int ti = (int)((M + 127) / 128), tj = (int)((N + 127) / 128);
   const int64_t nclu = (int64_t)((ti + 3) / 4) * tj * nsplit;
   dim3 grid((unsigned)nclu);
-  hipLaunchKernelGGL((k_gemm_nt_w128_bf16x3<3>), grid, dim3(256), 0, s, X.hi, X.lo, Y.hi, Y.lo, KS16, KST, C, ci, cj, M, N, nsplit, part, sumsq, 4);
+  hipLaunchKernelGGL((k_gemm_nt_w128_bf16x3<3>), grid, dim3(256), 0, s, X.hi, X.lo, Y.hi, Y.lo, KS16, KST, C, ci, cj, M, N, nsplit, part, sumsq, 4, X.exp, Y.exp);
 }
 
 }  // namespace coper

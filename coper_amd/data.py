@@ -360,6 +360,37 @@ class SyntheticKGLoader(object):
         q = self._queries(dataset_type)
         return EvalDataset(q, batch_size, self.num_ent, dense_mask)
 
+    def train_samples(self):
+        """The synthetic train graph as the records a train TFRecord holds (data.py:481-489, 574-594): one per distinct (e1, rel)
+        of the synthetic "train" queries, with the union of their known-answer lists as its tails."""
+        q = self._queries("train")
+        key = q["e1"].astype(np.int64) * self.num_rel + q["rel"]
+        order = np.argsort(key, kind="stable")
+        uniq, first = np.unique(key[order], return_index=True)
+        bounds = list(first) + [len(order)]
+        e1, rel, indptr, idx = [], [], [0], []
+        for u in range(len(uniq)):
+            rows = order[bounds[u]:bounds[u + 1]]
+            tails = np.unique(np.concatenate([q["filt_idx"][q["filt_indptr"][i]:q["filt_indptr"][i + 1]] for i in rows] + [q["e2"][rows]]))
+            e1.append(int(q["e1"][rows[0]])); rel.append(int(q["rel"][rows[0]]))
+            idx.extend(int(t) for t in tails)
+            indptr.append(len(idx))
+        return dict(e1=np.asarray(e1, np.int64), rel=np.asarray(rel, np.int64), tail_indptr=np.asarray(indptr, np.int64),
+                    tail_idx=np.asarray(idx, np.int64))
+
+    def train_dataset(self, directory=None, batch_size=512, include_inv_relations=True, num_parallel_readers=None,
+                      num_parallel_batches=None, buffer_size=None, prefetch_buffer_size=None, prop_negatives=10.0,
+                      num_labels=100, cache=False, one_positive_label_per_sample=True, seed=0, device=None):
+        """The reference loader's `train_dataset` signature (data.py:89-100) over the synthetic graph; `num_labels=None` = 1-vs-all
+        labels (data.py:157-158); `device` (extra keyword): sample / densify on that device."""
+        samples = self.train_samples()
+        if num_labels is None:
+            return OneVsAllTrainDataset(samples, self.num_ent, batch_size, seed, device=device)
+        if device is not None:
+            return DeviceTrainDataset(samples, self.num_ent, batch_size, num_labels, seed, device=device,
+                                      one_positive_label_per_sample=one_positive_label_per_sample, prop_negatives=prop_negatives)
+        return TrainDataset(samples, self.num_ent, batch_size, num_labels, one_positive_label_per_sample, prop_negatives, seed)
+
 
 class EvalDataset(object):
     """Re-iterable batch source; exhausting it is the end-of-data signal the reference gets as
@@ -585,6 +616,77 @@ class DeviceTrainDataset(object):
             for v in b.values():
                 v.record_stream(cur)          # allocated on the side stream, consumed on the caller's
             yield b
+
+
+class OneVsAllTrainDataset(object):
+    """1-vs-all training batches: `train_dataset(..., num_labels=None)` (data.py:157-158 -> `_add_lookup_values`, :314-330;
+    selected by an empty `num_labels` in `config_nations_plain.yaml:22`, `config_umls_cpg.yaml:20`; `run_cpg.py:116` then builds the
+    model with `use_negative_sampling=False`).  One row per (e1, rel) RECORD of the train graph:
+        e1, rel int64 [B];  e2 = -1 (the train records carry 'None', data.py:485-489 -> `entity_ids['None'] = -1`, :333);
+        e2_multi float32 [B, |E|]: 1.0 at every known train tail of (e1, rel) (`tf.sparse_to_dense`, data.py:318-322);
+        lookup_values int32 [B, 0] (data.py:323).
+    Rows pass through the shuffle buffer of 1000 (data.py:160) and are batched; the record stream repeats (data.py:136).
+    `device`: the dense label matrix is built THERE from the CSR tail lists (one scatter of the batch's known tails into a zeroed
+    [B, |E|] tensor -- 30 MB per 512 x 14,541 batch never crosses PCIe) and the batch is a dict of device tensors that
+    `ConvE.train_step` takes as it is; without it, NumPy arrays in the reference's dtypes."""
+
+    def __init__(self, samples, num_ent, batch_size, seed=0, shuffle_buffer=1000, device=None):
+        self.num_ent, self.batch_size, self.shuffle_buffer = int(num_ent), int(batch_size), int(shuffle_buffer)
+        self.rng = np.random.default_rng(seed)
+        self.e1 = np.asarray(samples["e1"], np.int64)
+        self.rel = np.asarray(samples["rel"], np.int64)
+        self.ip = np.asarray(samples["tail_indptr"], np.int64)
+        self.tails = np.asarray(samples["tail_idx"], np.int64)
+        self.n_rec = len(self.e1)
+        if self.n_rec == 0:
+            raise ValueError("OneVsAllTrainDataset: the train graph has no (e1, rel) record")
+        self.device = torch.device(device) if device is not None else None
+        if self.device is not None:
+            self.d_e1 = torch.as_tensor(self.e1).to(self.device)
+            self.d_rel = torch.as_tensor(self.rel).to(self.device)
+            self.d_ip = torch.as_tensor(self.ip).to(self.device)
+            self.d_tails = torch.as_tensor(self.tails).to(self.device)
+
+    def _record_batches(self):
+        buf, pos = [], 0
+        while True:
+            while len(buf) < self.shuffle_buffer + self.batch_size:
+                buf.append(pos % self.n_rec)
+                pos += 1
+            js = self.rng.integers(0, 1 << 62, size=self.batch_size)
+            take = []
+            for t in range(self.batch_size):
+                j = int(js[t] % min(len(buf), self.shuffle_buffer))
+                take.append(buf[j])
+                buf[j] = buf[-1]
+                buf.pop()
+            yield np.asarray(take, np.int64)
+
+    def _host_batch(self, rec):
+        B = len(rec)
+        lab = np.zeros((B, self.num_ent), np.float32)
+        for i, r in enumerate(rec):
+            lab[i, self.tails[self.ip[r]:self.ip[r + 1]]] = 1.0
+        return dict(e1=self.e1[rec], rel=self.rel[rec], e2=np.full(B, -1, np.int64), e2_multi=lab,
+                    lookup_values=np.zeros((B, 0), np.int32))
+
+    def _device_batch(self, rec):
+        dev = self.device
+        B = len(rec)
+        r = torch.as_tensor(rec).to(dev)
+        lo, hi = self.d_ip[r], self.d_ip[r + 1]
+        n = hi - lo
+        owner = torch.repeat_interleave(torch.arange(B, device=dev), n)
+        base = torch.cumsum(n, 0) - n
+        src = lo[owner] + (torch.arange(int(owner.numel()), device=dev) - base[owner])
+        lab = torch.zeros((B, self.num_ent), dtype=torch.float32, device=dev)
+        lab[owner, self.d_tails[src]] = 1.0
+        return dict(e1=self.d_e1[r], rel=self.d_rel[r], e2=torch.full((B,), -1, dtype=torch.int64, device=dev), e2_multi=lab,
+                    lookup_values=torch.zeros((B, 0), dtype=torch.int32, device=dev))
+
+    def __iter__(self) -> Iterator[dict]:
+        for rec in self._record_batches():
+            yield self._host_batch(rec) if self.device is None else self._device_batch(rec)
 
 
 class TrainDataset(object):

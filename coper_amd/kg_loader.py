@@ -26,7 +26,7 @@ from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 
-from .data import DeviceTrainDataset, EvalDataset, TrainDataset
+from .data import DeviceTrainDataset, EvalDataset, OneVsAllTrainDataset, TrainDataset
 
 __all__ = ["TSVKGLoader"]
 
@@ -217,8 +217,8 @@ class TSVKGLoader(object):
                       num_labels=100, cache=False, one_positive_label_per_sample=True, seed=0, device=None):
         """`device` (extra keyword): sample on that device (`DeviceTrainDataset`: batches of device tensors; the
         both samplers) instead of on the host."""
-        if num_labels is None:
-            raise NotImplementedError("1-vs-all training labels (num_labels=None, data.py:155-156) are not built")
+        if num_labels is None:      # 1-vs-all labels (data.py:157-158, 314-330)
+            return OneVsAllTrainDataset(self.train_samples(include_inv_relations), self.num_ent, batch_size, seed, device=device)
         if device is not None:
             return DeviceTrainDataset(self.train_samples(include_inv_relations), self.num_ent, batch_size, num_labels, seed, device=device,
                                       one_positive_label_per_sample=one_positive_label_per_sample, prop_negatives=prop_negatives)
@@ -269,8 +269,6 @@ class TFRecordKGLoader(object):
         from . import tf_records
         if self.num_ent is None:
             self.maybe_create_tf_record_files(directory)
-        if num_labels is None:
-            raise NotImplementedError("1-vs-all training labels (num_labels=None, data.py:155-156) are not built")
         q = tf_records.read_split(directory or self.directory, "train", include_inv_relations)
         n = np.diff(q["filt_indptr"])
         sel = np.nonzero(n > 0)[0]
@@ -278,6 +276,8 @@ class TFRecordKGLoader(object):
         samples = dict(e1=q["e1"][sel], rel=q["rel"][sel],
                        tail_indptr=np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64),
                        tail_idx=np.concatenate(rows).astype(np.int64) if rows else np.zeros(0, np.int64))
+        if num_labels is None:      # 1-vs-all labels (data.py:157-158, 314-330)
+            return OneVsAllTrainDataset(samples, self.num_ent, batch_size, seed, device=device)
         if device is not None:
             return DeviceTrainDataset(samples, self.num_ent, batch_size, num_labels, seed, device=device,
                                       one_positive_label_per_sample=one_positive_label_per_sample, prop_negatives=prop_negatives)

@@ -151,12 +151,20 @@ class ConvE(object):
                     # every shard of one table scales its planes by the same power of two (include/coper_hip.h: x3_ent_absmax)
                     self.set_x3_ent_absmax(float(t.abs().max()) if t.numel() else 0.0)
                 t = t[lo:hi]
+            elif name == "ent_emb" and self.score_mode == "bf16x3" and getattr(self, "_x3_absmax", None) is not None:
+                # new rows for this shard alone: a table-wide maximum agreed for the OLD rows may no longer cover them (coper_prepare
+                # would refuse on this rank only while the others go on into collectives: ADVICE r4).  Back to the shard's own
+                # maximum; an EntityShardedRanker re-agrees on the table-wide one with its next chunk (sharding.py step 1)
+                _lib.check(self._h, self._lib.coper_set_x3_ent_absmax(self._h, 0.0))
+                self._x3_absmax = None
             t = t.to(device=self.device, dtype=torch.float32).contiguous()
             if t.numel() != int(np.prod(want)):
                 raise ValueError("parameter %s: got shape %s, need %s" % (name, tuple(t.shape), want))
             self._tensors[name] = t
             shape = (C.c_int64 * max(1, t.dim()))(*t.shape)
             _lib.check(self._h, self._lib.coper_set_param(self._h, name.encode(), _ptr(t), shape, t.dim()))
+        if "ent_emb" in params:
+            self._ent_absmax_cache = None
         self._prepared = False
         return self
 
@@ -523,9 +531,20 @@ class ConvE(object):
         return run
 
     def ent_absmax(self) -> float:
-        """The largest |ent_emb| element of the rows this handle holds."""
-        t = self._tensors.get("ent_emb")
-        return float(t.abs().max()) if t is not None and t.numel() else 0.0
+        """The largest |ent_emb| element of the rows this handle holds (one pass over the shard, kept until the rows change)."""
+        c = getattr(self, "_ent_absmax_cache", None)
+        if c is None:
+            t = self._tensors.get("ent_emb")
+            c = self._ent_absmax_cache = float(t.abs().max()) if t is not None and t.numel() else 0.0
+        return c
+
+    def owned_rows(self, ids):
+        """(ent_emb rows [n, d], pred_bias [n]) of GLOBAL ids this shard holds (sharding.py step 1): plain indexing of the registered
+        tensors -- no prepared state needed, so a shard whose weights were just reloaded can answer before it is prepared again."""
+        lo, hi = self.shard
+        ids = self._ids(ids)
+        loc = (ids - lo).clamp(0, max(0, hi - lo - 1))
+        return self._tensors["ent_emb"].index_select(0, loc), self._tensors["pred_bias"].index_select(0, loc)
 
     def set_x3_ent_absmax(self, absmax: float):
         """coper_set_x3_ent_absmax: the largest |ent_emb| element of the WHOLE table, for a handle that holds a shard of it
@@ -607,7 +626,32 @@ class ConvE(object):
             _lib.check(self._h, self._lib.coper_train_step(self._h, _ptr(e1), _ptr(rel), _ptr(lookup), _ptr(labels), B, L,
                                                            _ptr(self._train_loss), self._stream()))
         self._prepared = False       # caches are stale; the next inference call prepares again
+        self._ent_absmax_cache = None
         return self._train_loss
+
+    def train_forward(self, batch, want_predictions=False, want_h=False):
+        """The training-mode graph without the update (coper_train_forward): `session.run(model.loss | model.predictions_lookup |
+        model.predicted_e2_emb, {model.is_train: True, ...})` when `train_op` is not fetched (models.py:183-192).  Returns
+        (loss 1-element device tensor, predictions [B, L] or None, h [B, d] or None); nothing is updated."""
+        if getattr(self, "_train_loss", None) is None:
+            self.train_init()
+        e1, rel = self._ids(batch["e1"]), self._ids(batch["rel"])
+        lv = batch.get("lookup_values", None)
+        one_vs_all = lv is None or (hasattr(lv, "shape") and len(lv.shape) == 2 and lv.shape[1] == 0)
+        lookup = None if one_vs_all else self._ids(lv, torch.int32)
+        labels = batch["e2_multi"]
+        labels = (labels if isinstance(labels, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(labels)))
+        labels = labels.to(device=self.device, dtype=torch.float32).contiguous()
+        B, L = labels.shape
+        if (lookup is not None and tuple(lookup.shape) != (B, L)) or e1.numel() != B or rel.numel() != B:
+            raise ValueError("training batch: e1, rel [B]; lookup_values and e2_multi [B, L] (or e2_multi [B, num_ent] alone)")
+        loss = torch.zeros(1, device=self.device, dtype=torch.float32)
+        pred = torch.empty((B, L), device=self.device, dtype=torch.float32) if want_predictions else None
+        hv = torch.empty((B, self.ent_emb_size), device=self.device, dtype=torch.float32) if want_h else None
+        with torch.cuda.device(self.device):
+            _lib.check(self._h, self._lib.coper_train_forward(self._h, _ptr(e1), _ptr(rel), _ptr(lookup), _ptr(labels), B, L, _ptr(loss),
+                                                              _ptr(pred), _ptr(hv), self._stream()))
+        return loss, pred, hv
 
     def train_grad(self, leaf_name):
         """(gradient of the last step as a tensor copy, global gradient norm) -- test / diagnostics hook."""
@@ -742,8 +786,26 @@ class Session(object):
                     raise KeyError("fetch %r cannot be combined with train_op" % (n,))
             return out[0] if single else tuple(out)
         if is_train:
-            raise NotImplementedError("is_train=True without train_op: train-mode forward values (dropout, batch statistics) are "
-                                      "only produced inside the training step")
+            # the training-mode graph without train_op (models.py:183-192): dropout and batch statistics, nothing updated
+            loss, pred, hv = m.train_forward(batch, want_predictions=any(n in ("predictions_lookup", "predictions_all") for n in names),
+                                             want_h="predicted_e2_emb" in names)
+            lv = batch.get("lookup_values", None)
+            one_vs_all = lv is None or (hasattr(lv, "shape") and len(lv.shape) == 2 and lv.shape[1] == 0)
+            out = []
+            for f, n in zip(fl, names):
+                if n == "loss":
+                    out.append(float(loss.cpu()[0]))
+                elif n == "predictions_lookup" or (n == "predictions_all" and one_vs_all):
+                    out.append(pred.cpu().numpy())
+                elif n == "predicted_e2_emb":
+                    out.append(hv.cpu().numpy())
+                elif n in ("e1", "e2", "rel", "e2_multi", "lookup_values"):
+                    out.append(_host(batch[n]))
+                elif n is None and f is None:
+                    out.append(None)
+                else:
+                    raise KeyError("fetch %r is not served under is_train=True without train_op" % (n,))
+            return out[0] if single else tuple(out)
         cache = {}
 
         def h():

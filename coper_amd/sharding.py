@@ -8,8 +8,12 @@ The reference has no distributed code at all; the path sha
 * `EntityShardedRanker` -- large KGs (the 10M-entity config): rank g owns entity rows
   [g|E|/G, (g+1)|E|/G) of `ent_emb` / `pred_bias`.  Per chunk of B queries, THREE collectives
   (round 2 had four):
-    1. ONE all-reduce(sum) of the shard-local gathers of `ent_emb[e1]`, `ent_emb[e2]` and `pred_bias[e2]`
-       (each row has one owner, the rest contribute zeros: exact)                 [B, 2d + 1]  f32
+    1. ONE all-gather of the rows each rank OWNS among `ent_emb[e1]`, `ent_emb[e2]` (with `pred_bias[e2]` beside them), padded
+       to the largest share -- every row has one owner, so this moves each row once where rounds 2 - 4 all-reduced a zero-padded
+       [B, 2d + 1] (a ring all-reduce moves it twice) -- plus ONE header row per rank: the largest |ent_emb| element of its rows
+       and the power-of-two hint it has in force, from which every rank derives the table-wide maximum on EVERY chunk
+       (a shard whose weights were reloaded can no longer run on a stale hint while the others enter collectives: ADVICE r4)
+                                                                                [G, cap + 1, d + 1]  f32
     2. the encoder is split by relation (rank = rel mod G: a rank touches only its relations'
        generated dense weights); all-gather of the OWNED `h` rows, padded to the largest share
        (round 2 all-reduced a zero-padded [B, d]: G times the bytes)              [G, ceil-ish(B/G), d]  f32
@@ -29,7 +33,8 @@ Both take a *scorer* returning torch tensors on its own device.  `QueryShardedEv
     rank_counts(h, tgt [2, B], e2, filt_indptr, filt_idx, filt_nnz=, k=) -> (n_greater, n_equal[, topk_val, topk_idx])
 and, optionally, `ent_absmax()` / `set_x3_ent_absmax(v)`: the largest |ent_emb| element of the local rows and the setter of the
 table-wide one -- the bf16x3 mode scales every shard's planes by the same power of two so that its logits do not depend on the
-shard layout (include/coper_hip.h: x3_ent_absmax); the ranker all-reduces (MAX) it once at construction.
+shard layout (include/coper_hip.h: x3_ent_absmax); the ranker re-derives it from the header rows of step 1 on every chunk.
+Optional, for step 1 without touching the prepared state: `owned_rows(ids) -> ([n, d] rows, [n] biases)` of ids the shard holds.
 `coper_amd.models.ConvE` is the product scorer; the CPU `gloo` tests (tests/test_sharding_gloo.py) plug a test-only scorer in to
 exercise the exchange logic without a GPU -- the product never routes through anything else."""
 from __future__ import annotations
@@ -110,8 +115,13 @@ class EntityShardedRanker(object):
         self.world = dist.get_world_size(group) if self.dist else 1
         self.rank_id = dist.get_rank(group) if self.dist else 0
         self._plan = None      # the relation split of the last chunk (encode)
-        # one power of two for the entity planes of every shard (the x3 mode's logits are then the same bits whatever the layout)
-        if self.dist and hasattr(scorer, "ent_absmax") and hasattr(scorer, "set_x3_ent_absmax"):
+        self._rows_plan = None # the ownership split of the last chunk (step 1)
+        ne = getattr(scorer, "num_ent", None)
+        self.bounds = np.asarray([shard_bounds(ne, self.world, g)[0] for g in range(self.world)], np.int64) if ne else None
+        # one power of two for the entity planes of every shard (the x3 mode's logits are then the same bits whatever the layout):
+        # agreed at construction, and again from the header rows of step 1 on every chunk (a shard whose weights were reloaded)
+        self._absmax_ok = hasattr(scorer, "ent_absmax") and hasattr(scorer, "set_x3_ent_absmax")
+        if self.dist and self._absmax_ok:
             m = torch.as_tensor([float(scorer.ent_absmax())], dtype=torch.float32, device=getattr(scorer, "device", "cpu"))
             dist.all_reduce(m, op=dist.ReduceOp.MAX, group=self.group)
             scorer.set_x3_ent_absmax(float(m[0]))
@@ -121,14 +131,62 @@ class EntityShardedRanker(object):
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
-    def _gather_rows(self, e1, e2):
-        """step 1: (ent_emb[e1] [B,d], ent_emb[e2] [B,d], pred_bias[e2] [B]) from ONE all-reduce"""
+    def _owned(self, ids_np):
+        """(rows [n, d], biases [n]) of ids this shard holds"""
         sc = self.scorer
-        r1, r2, b2 = sc.gather_entities(e1), sc.gather_entities(e2), sc.gather_bias(e2)
-        d = r1.shape[1]
-        pack = torch.cat([r1, r2, b2.reshape(-1, 1)], dim=1)
-        self._allreduce(pack)
-        return pack[:, :d].contiguous(), pack[:, d:2 * d].contiguous(), pack[:, 2 * d].contiguous()
+        if hasattr(sc, "owned_rows"):
+            return sc.owned_rows(ids_np)
+        return sc.gather_entities(ids_np), sc.gather_bias(ids_np)
+
+    def _gather_rows(self, e1, e2):
+        """step 1: (ent_emb[e1] [B,d], ent_emb[e2] [B,d], pred_bias[e2] [B]) from ONE all-gather of the owned rows"""
+        sc = self.scorer
+        e1_np = np.asarray(e1.cpu() if isinstance(e1, torch.Tensor) else e1).astype(np.int64)
+        e2_np = np.asarray(e2.cpu() if isinstance(e2, torch.Tensor) else e2).astype(np.int64)
+        B = len(e1_np)
+        if not self.dist or self.bounds is None:
+            r1, r2, b2 = sc.gather_entities(e1_np), sc.gather_entities(e2_np), sc.gather_bias(e2_np)
+            if self.dist:      # (a scorer that does not say how many entities there are: the all-reduce of rounds 2 - 4)
+                d = r1.shape[1]
+                pack = torch.cat([r1, r2, b2.reshape(-1, 1)], dim=1)
+                self._allreduce(pack)
+                return pack[:, :d].contiguous(), pack[:, d:2 * d].contiguous(), pack[:, 2 * d].contiguous()
+            return r1, r2, b2
+        # who owns what is known to every rank (ids are replicated): the plan is kept for the chunk it was made for
+        plan = self._rows_plan
+        if plan is None or plan["B"] != B or not (np.array_equal(plan["e1"], e1_np) and np.array_equal(plan["e2"], e2_np)):
+            ids = np.concatenate([e1_np, e2_np])                                 # positions 0..B-1: e1, B..2B-1: e2
+            owner = np.clip(np.searchsorted(self.bounds, ids, side="right") - 1, 0, self.world - 1)
+            order = np.argsort(owner, kind="stable")
+            counts = np.bincount(owner, minlength=self.world)
+            cap = int(counts.max())
+            start = np.concatenate([[0], np.cumsum(counts)])
+            slot = np.empty(2 * B, np.int64)                                     # where position p sits in the gathered tensor
+            for g in range(self.world):
+                slot[order[start[g]:start[g + 1]]] = g * (cap + 1) + 1 + np.arange(counts[g])
+            mine = order[start[self.rank_id]:start[self.rank_id + 1]]
+            dev = getattr(sc, "device", "cpu")
+            plan = self._rows_plan = dict(B=B, e1=e1_np.copy(), e2=e2_np.copy(), cap=cap, mine_ids=ids[mine], n_mine=len(mine),
+                                          take1=torch.as_tensor(slot[:B], device=dev), take2=torch.as_tensor(slot[B:], device=dev))
+        cap = plan["cap"]
+        rows, bias = self._owned(plan["mine_ids"])
+        d = rows.shape[1]
+        buf = torch.zeros((cap + 1, d + 1), dtype=torch.float32, device=rows.device)
+        if self._absmax_ok:                                                      # the header row: [own maximum, hint in force]
+            buf[0, 0] = float(sc.ent_absmax())
+            buf[0, 1] = float(getattr(sc, "_x3_absmax", None) or 0.0)
+        if plan["n_mine"]:
+            buf[1:1 + plan["n_mine"], :d] = rows
+            buf[1:1 + plan["n_mine"], d] = bias
+        out = torch.empty((self.world * (cap + 1), d + 1), dtype=torch.float32, device=rows.device)
+        dist.all_gather_into_tensor(out, buf, group=self.group)
+        if self._absmax_ok:
+            head = out.view(self.world, cap + 1, d + 1)[:, 0, :2].cpu()          # (one small D2H per chunk: every rank sees the same values)
+            m = float(head[:, 0].max())
+            if m > 0.0 and bool((head[:, 1] != m).any()):                        # some rank runs on another hint (reloaded weights): all re-agree
+                sc.set_x3_ent_absmax(m)
+        g1, g2 = out.index_select(0, plan["take1"]), out.index_select(0, plan["take2"])
+        return g1[:, :d].contiguous(), g2[:, :d].contiguous(), g2[:, d].contiguous()
 
     def encode(self, e1, rel, rows=None):
         """step 2: h [B, d] on every rank; `rows` = ent_emb[e1] (step 1) or None to fetch them here"""

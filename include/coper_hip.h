@@ -343,6 +343,16 @@ COPER_API int coper_train_init(coper_handle* h, const coper_train_config* cfg);
  * (models.py:448-453). */
 COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t* rel, const int32_t* lookup,
                                const float* labels, int64_t B, int64_t L, float* loss_out, void* stream);
+/* The train-mode graph WITHOUT the update: what `session.run(model.loss)` or `session.run(model.predictions_lookup)` under
+ * `{model.is_train: True}` evaluate when `train_op` is not among the fetches (models.py:183-192: the loss and the likelihoods are
+ * plain tensors of the graph; the UPDATE_OPS and the optimizer hang off train_op only, models.py:194-200).  Same batch contract as
+ * coper_train_step; dropout with the masks the NEXT coper_train_step will draw (the step counter is not advanced), batch
+ * statistics when batch_norm_train_stats -- and nothing written: no variable, no BN moving statistic, no optimizer slot.
+ * loss_out: device float[1] or NULL; pred_out: device float [B, L] logits (predictions_lookup; [B, num_ent] with lookup == NULL)
+ * or NULL; h_out: device float [B, d] (predicted_e2_emb in training mode) or NULL.  Inference caches stay valid. */
+COPER_API int coper_train_forward(coper_handle* h, const int64_t* e1, const int64_t* rel, const int32_t* lookup,
+                                  const float* labels, int64_t B, int64_t L, float* loss_out, float* pred_out, float* h_out,
+                                  void* stream);
 /* Diagnostics: copies the (unclipped) gradient of the last step for a trainable leaf into `out` (device float
  * buffer of `cap` elements; may be NULL), returns its length in *n, and in *global_norm (optional, host) the
  * global gradient norm of the last step (synchronises). */

@@ -14,6 +14,21 @@ class OracleShardScorer(object):
         self.E = np.ascontiguousarray(params["ent_emb"][self.lo:self.hi])
         self.b = np.ascontiguousarray(params["pred_bias"][self.lo:self.hi])
         self.d = self.E.shape[1]
+        self.num_ent = int(md["num_ent"])          # (lets the ranker split step 1 by owner)
+        self._x3_absmax = None                     # the table-wide maximum the ranker agreed on (recorded, not used: fp32 arithmetic)
+        self.absmax_calls = []
+
+    def ent_absmax(self):
+        return float(np.abs(self.E).max()) if self.E.size else 0.0
+
+    def set_x3_ent_absmax(self, v):
+        self._x3_absmax = float(v)
+        self.absmax_calls.append(float(v))
+
+    def owned_rows(self, ids):
+        ids = np.asarray(ids)
+        assert ((ids >= self.lo) & (ids < self.hi)).all(), "step 1 asked a shard for rows it does not hold"
+        return torch.from_numpy(np.ascontiguousarray(self.E[ids - self.lo])), torch.from_numpy(np.ascontiguousarray(self.b[ids - self.lo]))
 
     def gather_entities(self, ids):
         ids = np.asarray(ids)

@@ -102,14 +102,27 @@ def _rel_err(a, b, floor):
 @pytest.mark.parametrize("train_stats,one_vs_all", [(True, False), (False, False), (True, True)])
 @pytest.mark.parametrize("name", sorted(_CASES))
 def test_train_step_matches_oracle(name, train_stats, one_vs_all):
+    """The table law of SURVEY 8(d) (sigma = 0.1).  Rounds 2 - 4 kept sigma = 0.3 here behind an environment variable: on the 0.1
+    table one fuzz case had an activation 6e-6 from a ReLU kink, inside the 1.5e-5 error of the bf16-split GEMMs, and passed or
+    failed with the run.  Round 5 moved those GEMMs to the scaled fp16 split (5e-7): the variable is gone."""
+    _train_step_case(name, train_stats, one_vs_all, "n0.1")
+
+
+@pytest.mark.parametrize("name", sorted(k for k in _CASES if not k.startswith("fuzz_")) + ["fuzz_00", "fuzz_d288"])
+def test_train_step_matches_oracle_from_the_reference_init(name):
+    """... and from the state the reference itself starts training in (models.py:205-214, 284-293: xavier-uniform tables and
+    projections, zero biases, BN at its defaults -- `data.reference_init_params`), where the embeddings are +-0.1 and smaller."""
+    _train_step_case(name, True, False, "reference")
+
+
+def _train_step_case(name, train_stats, one_vs_all, init):
     from coper_amd.models import ConvE
     from oracle import coper_train_oracle as T
     md = dict(cdata._COMMON)
     md.update(_CASES[name])
     md.update(batch_norm_train_stats=train_stats, batch_norm_momentum=0.9, hidden_dropout=0.3, output_dropout=0.2,
               label_smoothing_epsilon=0.1, learning_rate=0.003)
-    import os
-    p0 = cdata.synthetic_params(md, seed=21, ent_std=float(os.environ.get("COPER_TEST_ENT_STD", "0.3")))    # (0.1: DESIGN_LOG.md, round-4 log)
+    p0 = cdata.synthetic_params(md, seed=21, ent_std=0.1) if init == "n0.1" else cdata.reference_init_params(md, 21)
     B, L, seed = 48, 37, 5
     m = ConvE(md, device="cuda:0")
     m.load_parameters({k: torch.as_tensor(np.array(v, np.float32)) for k, v in p0.items()})
@@ -196,10 +209,12 @@ def test_train_rejects_unsupported_variants_and_order():
     m5.close()
 
 
-@pytest.mark.parametrize("variant", ["cpg_linear", "plain", "lookup", "cpg_mlp_bn"])
+@pytest.mark.parametrize("variant", ["cpg_linear", "plain", "lookup", "cpg_mlp_bn", "cpg_linear@reference_init", "plain@reference_init"])
 def test_training_loop_learns_a_small_graph(variant):
     """End to end: TrainDataset (the reference's one-positive-per-row sampler) -> train_step -> prepare ->
-    ranking_and_hits.  The loss falls and the filtered MRR on the training triples ends far above chance."""
+    ranking_and_hits.  The loss falls and the filtered MRR on the training triples ends far above chance -- also from the state
+    the reference starts in (`@reference_init`: xavier tables, zero biases, BN defaults; models.py:205-214, 284-293)."""
+    variant, _, init = variant.partition("@")
     from coper_amd.data import EvalDataset, TrainDataset
     from coper_amd.metrics import ranking_and_hits
     from coper_amd.models import ConvE
@@ -214,7 +229,7 @@ def test_training_loop_learns_a_small_graph(variant):
     rel = np.tile(np.arange(R), E)
     e2 = (e1 * np.array(mult)[rel] + np.array(off)[rel]) % E
     samples = dict(e1=e1, rel=rel, tail_indptr=np.arange(len(e1) + 1), tail_idx=e2.astype(np.int64))
-    p = cdata.synthetic_params(md, seed=4, ent_std=0.3)
+    p = cdata.reference_init_params(md, 4) if init else cdata.synthetic_params(md, seed=4, ent_std=0.3)
     m = ConvE(md, device="cuda:0").load_parameters(p)
 
     def mrr():
@@ -231,7 +246,7 @@ def test_training_loop_learns_a_small_graph(variant):
             losses.append(float(loss.cpu()[0]))
     after = mrr()
     assert np.isfinite(losses).all() and losses[-1] < 0.5 * losses[0], losses
-    assert before < 0.15 and after > 0.5 and after > 4 * before, (before, after, losses)
+    assert before < 0.15 and after > (0.3 if init else 0.5) and after > 4 * before, (before, after, losses)
     m.close()
 
 
@@ -509,4 +524,95 @@ def test_device_sampler_proportional_mode_on_the_gpu():
             assert set(lk[:lead].tolist()) <= set(t) and len(set(lk[:lead].tolist())) == lead and len(set(lk[lead:].tolist())) == L - lead
             assert np.array_equal(lab, np.array([float(v in t) for v in lk], np.float32)) and int(h["e2"][r]) == int(lk[0])
         assert np.isfinite(float(m.train_step(b).cpu()[0]))
+    m.close()
+
+
+@pytest.mark.parametrize("one_vs_all", [False, True])
+@pytest.mark.parametrize("name", ["cpg_linear", "plain", "cpg_mlp_bn", "lookup"])
+def test_train_forward_is_the_step_without_the_update(name, one_vs_all):
+    """coper_train_forward (round 5): `session.run((model.loss, model.predictions_lookup), {is_train: True})` without train_op
+    (models.py:183-192).  Its loss is bit-for-bit the loss the NEXT train_step reports on the same batch (same dropout masks,
+    same batch statistics); its logits reproduce that loss through the label-smoothed BCE of models.py:448-453; and nothing is
+    written: every variable, BN moving statistic and optimizer slot keeps its bits."""
+    from coper_amd.models import ConvE
+    md = dict(cdata._COMMON)
+    md.update(_CASES[name])
+    md.update(batch_norm_train_stats=True, batch_norm_momentum=0.9, hidden_dropout=0.3, output_dropout=0.2,
+              label_smoothing_epsilon=0.1, learning_rate=0.003)
+    p0 = cdata.synthetic_params(md, seed=8, ent_std=0.1)
+    m = ConvE(md, device="cuda:0")
+    m.load_parameters({k: torch.as_tensor(np.array(v, np.float32)) for k, v in p0.items()})
+    m.train_init(seed=11)
+    B, L = 40, 29
+    m.train_step(_batch(md, B, L, seed=1))                      # (slots and moving statistics away from their initial values)
+    batch = _batch(md, B, L, seed=2)
+    if one_vs_all:
+        dense = np.zeros((B, md["num_ent"]), np.float32)
+        np.put_along_axis(dense, batch["lookup_values"].astype(np.int64), batch["e2_multi"], axis=1)
+        batch = dict(e1=batch["e1"], rel=batch["rel"], e2_multi=dense, lookup_values=np.zeros((B, 0), np.int32))
+    before = {k: v.clone() for k, v in m._tensors.items()}
+    slots0, pow0 = m.optimizer_state()
+    sess = m.session()
+    fetched = sess.run((m.loss, m.predictions_lookup, m.predicted_e2_emb), {m.is_train: True, m.input_iterator_handle: [batch]})
+    loss_f, pred, hv = fetched
+    for k, v in m._tensors.items():
+        assert torch.equal(v, before[k]), k
+    slots1, pow1 = m.optimizer_state()
+    assert pow0 == pow1 and all(np.array_equal(a, b) for k in slots0 for a, b in zip(slots0[k], slots1[k]))
+    Lw = md["num_ent"] if one_vs_all else L
+    assert pred.shape == (B, Lw) and hv.shape == (B, md["ent_emb_size"])
+    # the logits are the scorer on the train-mode embedding
+    E = before["ent_emb"].double().cpu().numpy()
+    pb = before["pred_bias"].double().cpu().numpy()
+    if one_vs_all:
+        want = hv.astype(np.float64) @ E.T + pb[None, :]
+    else:
+        lk = batch["lookup_values"].astype(np.int64)
+        want = np.einsum("bd,bld->bl", hv.astype(np.float64), E[lk]) + pb[lk]
+    assert np.abs(pred - want).max() <= 1e-4 * max(1.0, np.abs(want).max())
+    # ... and the loss is models.py:448-453 on them
+    t = (1.0 - 0.1) * batch["e2_multi"].astype(np.float64) + 1.0 / md["num_ent"]
+    s = pred.astype(np.float64)
+    bce = np.maximum(s, 0) - s * t + np.log1p(np.exp(-np.abs(s)))
+    assert abs(loss_f - bce.mean()) <= 2e-5 * max(1.0, abs(bce.mean()))
+    # the step that follows draws the same masks and statistics: the same loss, bit for bit -- and it does update
+    loss_s = float(m.train_step(batch).cpu()[0])
+    assert loss_s == loss_f
+    assert not torch.equal(m._tensors["ent_emb"], before["ent_emb"])
+    m.close()
+
+
+def test_one_vs_all_training_through_the_loader():
+    """`config_nations_plain.yaml`-shaped training (plain ConvE, `num_labels` empty -> 1-vs-all labels, data.py:157-158,
+    314-330; run_cpg.py:116 builds the model with use_negative_sampling=False): loader.train_dataset(num_labels=None, device=)
+    -> dense e2_multi [B, |E|] built on the device -> the reference's own `session.run((loss, train_op), {is_train: True})`.
+    The loss falls and the filtered MRR on the train graph ends far above its start."""
+    from coper_amd.data import EvalDataset, OneVsAllTrainDataset, SyntheticKGLoader
+    from coper_amd.metrics import ranking_and_hits
+    from coper_amd.models import ConvE
+    md = cdata.model_descriptors("nations_cpg", ent_emb_size=40, rel_emb_size=40, emb_h=10, emb_w=4, context_rel_conv=None,
+                                 context_rel_out=None, conv_num_channels=8, num_ent=60, num_rel=8)
+    md.update(use_negative_sampling=False, batch_norm_train_stats=False, hidden_dropout=0.1, output_dropout=0.1,
+              label_smoothing_epsilon=0.1, learning_rate=0.003)
+    ld = SyntheticKGLoader("nations_plain_like", seed=1, queries=300, md=md)
+    ds = ld.train_dataset(None, batch_size=64, num_labels=None, device="cuda:0")
+    assert isinstance(ds, OneVsAllTrainDataset)
+    s = ld.train_samples()
+    p = cdata.reference_init_params(md, 3)                      # the reference's own starting point (models.py:205-214, 284-293)
+    m = ConvE(md, device="cuda:0").load_parameters(p)
+    # the training triples as an evaluation set: every (e1, rel, tail) with the record's other tails filtered
+    n = np.diff(s["tail_indptr"])
+    q = dict(e1=np.repeat(s["e1"], n), rel=np.repeat(s["rel"], n), e2=s["tail_idx"].astype(np.int64),
+             filt_indptr=np.concatenate([[0], np.cumsum(np.repeat(n, n))]).astype(np.int64),
+             filt_idx=np.concatenate([s["tail_idx"][s["tail_indptr"][i]:s["tail_indptr"][i + 1]] for i in range(len(n)) for _ in range(n[i])]).astype(np.int64))
+    mrr0 = ranking_and_hits(m, None, EvalDataset(q, 256, md["num_ent"]), "before")[1]
+    sess = m.session()
+    it = iter(ds)
+    losses = []
+    for step in range(400):
+        loss, _ = sess.run((m.loss, m.train_op), {m.is_train: True, m.input_iterator_handle: it})
+        losses.append(loss)
+    mrr1 = ranking_and_hits(m, None, EvalDataset(q, 256, md["num_ent"]), "after")[1]
+    assert np.mean(losses[-20:]) < 0.7 * np.mean(losses[:20]), (losses[:3], losses[-3:])
+    assert mrr1 > mrr0 + 0.1, (mrr0, mrr1)
     m.close()

@@ -323,3 +323,60 @@ def test_device_train_dataset_proportional_sampler_rules():
                     orders.add((i, tuple(lk[:3].tolist())))
         if prop == 2.0:
             assert len({i for i, _ in orders}) < len(orders)              # tails come in different orders on different visits
+
+
+def test_one_vs_all_train_dataset_contract(tmp_path, golden_dir):
+    """`train_dataset(..., num_labels=None)` (data.py:157-158 -> `_add_lookup_values`, :314-330): one row per (e1, rel) record,
+    dense 0/1 labels over all entities = the record's train tails, empty lookup, e2 = -1 ('None'); host and device-side builders
+    of the label matrix agree; the TSV and the synthetic loader both serve it."""
+    from coper_amd.data import OneVsAllTrainDataset, SyntheticKGLoader
+    from coper_amd.kg_loader import TSVKGLoader
+    rng = np.random.default_rng(3)
+    E, N = 61, 30
+    indptr, idx = [0], []
+    for i in range(N):
+        idx.extend(sorted(rng.choice(E, size=int(rng.integers(1, 7)), replace=False)))
+        indptr.append(len(idx))
+    s = dict(e1=rng.integers(0, E, N), rel=rng.integers(0, 4, N), tail_indptr=np.array(indptr), tail_idx=np.array(idx))
+    rec_of = {}
+    for i in range(N):
+        rec_of.setdefault((int(s["e1"][i]), int(s["rel"][i])), []).append(set(idx[indptr[i]:indptr[i + 1]]))
+    host = OneVsAllTrainDataset(s, E, batch_size=8, seed=4, shuffle_buffer=10)
+    dev = OneVsAllTrainDataset(s, E, batch_size=8, seed=4, shuffle_buffer=10, device="cpu")
+    seen = set()
+    for k, (bh, bd) in enumerate(zip(host, dev)):
+        if k == 12:
+            break
+        assert bh["e1"].dtype == np.int64 and bh["e2_multi"].dtype == np.float32 and bh["lookup_values"].dtype == np.int32
+        assert bh["e2_multi"].shape == (8, E) and bh["lookup_values"].shape == (8, 0) and (bh["e2"] == -1).all()
+        for key in ("e1", "rel", "e2", "e2_multi", "lookup_values"):
+            assert np.array_equal(bh[key], bd[key].numpy()), key
+        for i in range(8):
+            tails = set(np.nonzero(bh["e2_multi"][i])[0].tolist())
+            assert tails in rec_of[(int(bh["e1"][i]), int(bh["rel"][i]))]
+            assert set(np.unique(bh["e2_multi"][i]).tolist()) <= {0.0, 1.0}
+            seen.add((int(bh["e1"][i]), int(bh["rel"][i])))
+    assert len(seen) >= len(rec_of) - 2                    # the stream repeats and the buffer shuffles: every record comes by
+    # the loaders: num_labels=None selects it (config_nations_plain.yaml:22 leaves the key empty)
+    for f in ("train.txt", "dev.txt", "test.txt"):
+        shutil.copy(os.path.join(golden_dir, "kg_tsv", f), tmp_path)
+    ld = TSVKGLoader(str(tmp_path), "nell-995-test")
+    ld.assign_ids(write_files=True)
+    ld.maybe_create_tf_record_files(str(tmp_path), write_tfrecords=True)
+    ts = ld.train_samples()
+    tds = ld.train_dataset(None, batch_size=32, num_labels=None, seed=2)
+    assert isinstance(tds, OneVsAllTrainDataset)
+    tb = next(iter(tds))
+    assert tb["e2_multi"].shape == (32, ld.num_ent) and tb["lookup_values"].shape == (32, 0)
+    key = {(int(a), int(b)): i for i, (a, b) in enumerate(zip(ts["e1"], ts["rel"]))}
+    for i in range(32):
+        r = key[(int(tb["e1"][i]), int(tb["rel"][i]))]
+        assert np.array_equal(np.nonzero(tb["e2_multi"][i])[0], np.unique(ts["tail_idx"][ts["tail_indptr"][r]:ts["tail_indptr"][r + 1]]))
+    from coper_amd.kg_loader import TFRecordKGLoader       # ... and the loader over the reference's own preprocessed directory
+    assert isinstance(TFRecordKGLoader(str(tmp_path)).train_dataset(None, batch_size=8, num_labels=None), OneVsAllTrainDataset)
+    syn = SyntheticKGLoader("nations_cpg", queries=200)
+    ds = syn.train_dataset(None, batch_size=16, num_labels=None)
+    assert isinstance(ds, OneVsAllTrainDataset)
+    b = next(iter(ds))
+    assert b["e2_multi"].shape == (16, syn.num_ent) and b["lookup_values"].shape == (16, 0)
+    assert not isinstance(syn.train_dataset(None, batch_size=16, num_labels=10), OneVsAllTrainDataset)

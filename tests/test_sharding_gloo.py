@@ -42,6 +42,18 @@ def _worker(rank, world, port, mode, out_dir):
             q2 = dict(q, rel=(q["rel"] + 1) % md["num_rel"])     # ... which a chunk with other relations must not
             ranker.rank(q2)
             ranks, ne, tv, ti = ranker.rank(q, k=7)
+            # the table-wide maximum: agreed at construction (one value on every rank) ...
+            full = float(np.abs(p["ent_emb"]).max())
+            assert sc.absmax_calls == [np.float32(full)], sc.absmax_calls
+            # ... and re-agreed from the header rows of step 1 when ONE shard's rows change (a reload on one rank must
+            # neither leave it on a stale hint nor stall the others): rank 0 doubles its rows, every rank ends on the new maximum
+            if rank == 0:
+                sc.E = sc.E * np.float32(4.0)
+                sc._x3_absmax = None              # (what ConvE.load_parameters(global_rows=False) does with the old hint)
+            ranker.rank(q)
+            new_full = max(float(np.abs(p["ent_emb"][shard_bounds(md["num_ent"], world, 0)[0]:shard_bounds(md["num_ent"], world, 0)[1]]).max()) * 4.0,
+                           float(np.abs(p["ent_emb"][shard_bounds(md["num_ent"], world, 0)[1]:]).max()))
+            assert sc._x3_absmax == np.float32(new_full), (rank, sc._x3_absmax, new_full)
             np.save(os.path.join(out_dir, "tv_%d.npy" % rank), tv.numpy())
             np.save(os.path.join(out_dir, "ti_%d.npy" % rank), ti.numpy())
         elif mode == "entity_nosplit":

@@ -31,8 +31,26 @@ for i in range(K):
     loss = m.train_step(bs[i % 4])
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) * 1e3 / K
+# Roofline of the step: ALGORITHMIC work = what any implementation of models.py:186-200 + amsgrad.py:130-189 must do.
+#   bytes: AMSGrad reads p, g, m, v, v_hat and writes p, m, v, v_hat of EVERY trainable element each step (dense decay of all slots,
+#          amsgrad.py:141-159): 9 x 4 B per parameter; + the sampled rows gathered twice (forward, backward) B L d 4 B each;
+#   flops: generated dense layer: three products of 2 B r F d (T = x P, dP, dx; static layer: 2 B F d each), the scorer 2 B L d x 3.
+n_param = sum(int(np.prod(v.shape)) for k, v in m._tensors.items() if not k.endswith(("moving_mean", "moving_variance")))
+dm = cdata._dims(md)
+F, d, r = dm["F"], int(md["ent_emb_size"]), int(md["rel_emb_size"])
+gen = md.get("context_rel_out", None) is not None and not md.get("do_parameter_lookup", False)
+by = 9.0 * 4.0 * n_param + 2.0 * B * L * d * 4.0
+fl = 3.0 * 2.0 * B * (r if gen else 1) * F * d + 3.0 * 2.0 * B * L * d
+t_hbm, t_mfma = by / 8.0e12, fl / 2.5e15
+floor_ms = max(t_hbm, t_mfma) * 1e3
+roof = {"bound": "hbm" if t_hbm >= t_mfma else "mfma", "algorithmic_bytes": by, "algorithmic_flops": fl, "floor_ms": floor_ms,
+        "frac": floor_ms / ms, "achieved": (by / (ms * 1e-3) / 1e9) if t_hbm >= t_mfma else (fl / (ms * 1e-3) / 1e12),
+        "peak": 8000.0 if t_hbm >= t_mfma else 2500.0, "unit": "GB/s" if t_hbm >= t_mfma else "TFLOP/s",
+        "note": "whole step against the larger of its two floors (AMSGrad's dense slot traffic at 8 TB/s; the three dense-layer products "
+                "and the scorer at 2.5 PF -- the x3 arithmetic spends three hardware MFMAs per product); host clock over %d steps" % K}
 print(json.dumps({"metric": "training step", "workload": name, "B": B, "L": L, "ms_per_step": ms, "queries_per_s": B / ms * 1e3,
-                  "scored_pairs_per_s": B * L / ms * 1e3, "loss": float(loss.cpu()[0])}))
+                  "scored_pairs_per_s": B * L / ms * 1e3, "loss": float(loss.cpu()[0]), "dtype": "fp16x3", "trainable_parameters": n_param,
+                  "roofline": roof}))
 
 # the same step fed by the samplers: a synthetic train graph of this shape, one known tail list per (e1, rel)
 if "--with-sampler" in sys.argv:
