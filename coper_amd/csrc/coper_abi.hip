@@ -551,7 +551,7 @@ COPER_API int coper_prepare(coper_handle* h, void* stream) {
   h->x_exp = 0;
   h->band_launches = 0;
   if (h->enc_bf16) {
-    size_t plane = (size_t)h->Rw * dm.nfb * (dm.F_pad / 32) * 64 * 16;
+    size_t plane = (size_t)h->Rw * dm.nfb * w16_ks_stride(dm) * 64 * 16;
     dev_free((char**)&h->Wf16_hi); dev_free((char**)&h->Wf16_lo); dev_free((char**)&h->Wf8_lo);
     if (tracked_malloc(&h->Wf16_hi, plane) != hipSuccess || tracked_malloc(&h->Wf16_lo, plane) != hipSuccess)
       return fail(h, COPER_ENOMEM, "hipMalloc of the bf16 weight planes failed");

@@ -321,6 +321,19 @@ int launch_topk_pruned_bf16x3(coper_handle* h, const float* hvec, const float* t
 bool conv_bf16_supported(const Dims& dm);
 int launch_wfrag_to_bf16(coper_handle* h, const float* Wf, int64_t Rw, void* hi, void* lo, void* lo8, hipStream_t s);
 int compute_x_exp(coper_handle* h, unsigned* scratch, hipStream_t s);
+// k-steps (of 32) between two feature blocks of the 16-bit dense-weight image Wf16_{hi,lo}: [rel * nfb + fb][stride][64] x 16 B.
+// Round 5: ODD (F / 32 | 1: 145 for 144 at FB15k-237 shapes, +0.7 % memory).  The 26 streams of a workgroup and the 237 workgroups
+// of a pass are all at the same k-step at the same time; with feature blocks 144 KiB and relations 1,872 KiB apart they all sat at
+// the same offset inside every 4-KiB page of the image, i.e. on the same few memory channels.  Measured on the pass (same box,
+// three alternating runs): fused encoder 0.1729 -> 0.1687 ms, pass 0.5115 -> 0.5064 ms (-DCOPER_W_EVEN_STRIDE builds the old image).
+__host__ __device__ inline int64_t w16_ks_stride_n(int64_t ks32n) {
+#ifdef COPER_W_EVEN_STRIDE
+  return ks32n;
+#else
+  return ks32n | 1;
+#endif
+}
+inline int64_t w16_ks_stride(const Dims& dm) { return w16_ks_stride_n(dm.F_pad / 32); }
 int launch_conv_bf16(coper_handle* h, const int64_t* e1, const int64_t* rel, const float* e1_rows, int64_t B,
                      bool skip_big, hipStream_t s);
 int launch_dense_bf16(coper_handle* h, int64_t B, int nslices, bool small_only, hipStream_t s);

@@ -36,7 +36,12 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define COPER_FUSED_PMAX 3
 #endif
 #ifndef COPER_FUSED_PBUDGET
-#define COPER_FUSED_PBUDGET 216
+// Register budget that decides the weight prefetch depth P per tile size (fused_matrix_role).  Round 5: 216 -> 220, which gives
+// the 81..96-query tiles (six query blocks: 147 of the 237 tiles of an FB15k-237 pass) THREE k-steps of weights in flight
+// instead of two -- the launch is bound by what one CU keeps in flight (16 -> 24 KB per wave; its tiles all take ~200 us whatever
+// their size): fused encoder 0.1768 -> 0.1647 ms, pass 0.5115 -> 0.498 ms on one box (profiles/r05b_experiments.txt).  232 (seven
+// blocks too) needs the x fragments requested one block ahead instead of two to stay out of scratch, and measures no gain.
+#define COPER_FUSED_PBUDGET 220
 #endif
 #ifndef COPER_FUSED_CONV_FMA
 #define COPER_FUSED_CONV_FMA 0      // 1: rounds 2 - 4's conv (fp32 fma chain on the vector unit) for A/B; 0: the conv on the matrix cores
@@ -238,7 +243,7 @@ __device__ __forceinline__ void fused_matrix_role(const uint4* __restrict__ xrin
                                                   const uint4* __restrict__ Whi, const fused_wlo_t* __restrict__ Wlo,
                                                   const FusedConvArgs& A, int64_t relw, int start, int n, int fb0,
                                                   int nfb, int64_t ks32n, int64_t kb, int64_t ke, int t0, int t1,
-                                                  float* __restrict__ zdst, int d_pad16, int wave, const FusedFin& Fn) {
+                                                  float* __restrict__ zdst, int d_pad16, int wave, const FusedFin& Fn, int64_t ks32s) {
   constexpr int NFULL = NFB / 4;              // whole feature blocks per wave
   constexpr int REM = NFB % 4 ? 1 : 0;        // 1: one more block, shared by query block
   static_assert(NFB % 4 <= 1, "at most one left-over feature block");
@@ -254,7 +259,7 @@ __device__ __forceinline__ void fused_matrix_role(const uint4* __restrict__ xrin
   for (int j = 0; j < NW; ++j) {
     int fb = fb0 + (j < NFULL ? wave + 4 * j : 4 * NFULL);
     if (fb > nfb - 1) fb = nfb - 1;
-    int64_t o = ((relw * nfb + fb) * ks32n + kb) * 64;   // wave-uniform: scalar base + one shared lane offset
+    int64_t o = ((relw * nfb + fb) * ks32s + kb) * 64;   // wave-uniform: scalar base + one shared lane offset
     wp[j][0] = Whi + o;
     wp[j][1] = (const uint4*)(Wlo + o);
   }
@@ -317,7 +322,11 @@ __device__ __forceinline__ void fused_matrix_role(const uint4* __restrict__ xrin
 #define COPER_FUSED_XPF 2     // query blocks the x fragments are requested ahead of their MFMAs (1 or 2)
 #endif
   // the blocks a wave consumes in one step, in order: 0 .. NB-1, then (NRQ > 0) its own block of the left-over feature block
-  constexpr int NV = NB + (NRQ > 0 ? 1 : 0), XPF = COPER_FUSED_XPF, XR = XPF + 1;
+#ifndef COPER_FUSED_XBUDGET
+#define COPER_FUSED_XBUDGET 220    // tiles whose registers (at P = 3) exceed this request their x fragments ONE block ahead (8 registers less)
+#endif
+  constexpr int NV = NB + (NRQ > 0 ? 1 : 0);
+  constexpr int XPF = (P == 3 && (NFULL * NB + NRQ) * 4 + FW_WREG3 + 44 > COPER_FUSED_XBUDGET) ? 1 : COPER_FUSED_XPF, XR = XPF + 1;
   const int qr = wave < NB ? wave : NB - 1;
 #define M_LDV_H(v_) M_LD(((v_) < NB ? (v_) : qr) * 64)
 #define M_LDV_L(v_) M_LD((NB + ((v_) < NB ? (v_) : qr)) * 64)
@@ -475,6 +484,11 @@ __device__ __forceinline__ void fused_matrix_role(const uint4* __restrict__ xrin
   }
 }
 
+// (Round 5, measured and removed: the conv waves TOUCHING the weight stream ahead of the matrix waves -- one dword per 128-byte line
+// of the k-step four, six or ten steps on, an asm load into a reserved register nobody waits for -- so that the lines would sit in
+// the XCD's L2 when the matrix waves ask.  The launch got slower with every step of distance: fused encoder 0.165 -> 0.200 / 0.223 /
+// 0.266 ms at FB15k-237 shapes, WN18RR 0.040 -> 0.047, plain ConvE 0.233 -> 0.241: the touched lines are fetched again by the
+// non-temporal loads that follow (profiles/r05b_experiments.txt, F).)
 // ---- conv role: conv wave cw (0..3) produces x fragments f = cw, cw+4
 #if !COPER_FUSED_CONV_FMA
 // Round 5: the 3x3 conv on the matrix cores.  Rounds 2 - 4 ran it as 72 fp32 FMAs per lane and output pixel (conv_x8) -- ~150
@@ -686,7 +700,7 @@ __global__ __launch_bounds__(512) void k_dense_fused_bf16x3(const uint4* __restr
                                                             int nfb, int64_t ks32n, int nslices, int64_t Bcap,
                                                             int d_pad16, float* __restrict__ z_part, int n_big_cap, FusedFin Fn,
                                                             int n_tile_blocks, const int32_t* __restrict__ stage_src, int64_t stage_n,
-                                                            int64_t* __restrict__ stage_dst) {
+                                                            int64_t* __restrict__ stage_dst, int64_t ks32s) {
   extern __shared__ uint4 fused_lds[];
   // Staging role (coper_stage_ids_next): the workgroups behind the tile lists bring the NEXT pass's int32 batch in from pinned
   // host memory (PCIe reads) and widen it to the int64 arrays the ABI takes, while the tiles stream their weights.  A pass has
@@ -753,10 +767,10 @@ __global__ __launch_bounds__(512) void k_dense_fused_bf16x3(const uint4* __restr
   if (wave < 4) {                                                                                                      \
     if (WNT && !shared_w)                                                                                              \
       fused_matrix_role<NFB, NB_, TILE_WNT(true)>(xring, img, Whi, Wlo, A, relw, start, n, fb0, nfb, ks32n, kb, ke, t0, t1, zdst, \
-                                                  d_pad16, wave, Fn);                                                  \
+                                                  d_pad16, wave, Fn, ks32s);                                           \
     else                                                                                                               \
       fused_matrix_role<NFB, NB_, TILE_WNT(false)>(xring, img, Whi, Wlo, A, relw, start, n, fb0, nfb, ks32n, kb, ke, t0, t1, zdst, \
-                                                   d_pad16, wave, Fn);                                                 \
+                                                   d_pad16, wave, Fn, ks32s);                                          \
   } else                                                                                                               \
     fused_conv_role<NB_>(xring, img, A, relw, start, n, kb, ke, i_lo, t0, t1, wave - 4);
   switch (nb) {
@@ -838,7 +852,7 @@ static void dense_fused_launch(coper_handle* h, const int64_t* e1, const int64_t
   hipLaunchKernelGGL((k_dense_fused_bf16x3<NFB, WNT>), dim3((unsigned)(n_tile_blocks + n_stage), (unsigned)nslices, (unsigned)zgroups), dim3(512),
                      lds, s, (const uint4*)h->Wf16_hi, (const fused_wlo_t*)(FUSED_LO8 ? h->Wf8_lo : h->Wf16_lo), A, h->tiles, h->n_tiles, cap_small, dm.nfb,
                      dm.F_pad / 32, nslices, h->ws_queries, dm.d_pad16, h->z_part, (int)n_big_max, Fn, n_tile_blocks, h->stage_src,
-                     h->stage_n, h->stage_dst);
+                     h->stage_n, h->stage_dst, w16_ks_stride(dm));
   h->stage_n = 0;
 }
 

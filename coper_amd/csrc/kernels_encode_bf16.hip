@@ -34,7 +34,7 @@ __device__ __forceinline__ void split8_e(const float* v, uint4& hi, uint4& lo) {
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_wfrag_to_bf16(const float4* __restrict__ Wf, int64_t n_relfb, int64_t ks32n,
                                                        uint4* __restrict__ hi, uint4* __restrict__ lo, uint2* __restrict__ lo8, int nfb,
-                                                       const int32_t* __restrict__ w_exp) {
+                                                       const int32_t* __restrict__ w_exp, int64_t ks32s) {
   int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (relfb*ks32n + ks)*64 + lane
   if (j >= n_relfb * ks32n * 64) return;
   int l = (int)(j & 63);
@@ -51,16 +51,17 @@ __global__ __launch_bounds__(256) void k_wfrag_to_bf16(const float4* __restrict_
 #pragma unroll
   for (int t = 0; t < 8; ++t) v[t] = x3_scale(v[t], ew);
   uint4 h4, l4;
+  const int64_t jo = (relfb * ks32s + ks) * 64 + l;     // (ks32s: k-steps between two feature blocks of the image, coper_internal.h)
 #ifndef COPER_SPLIT_BF16
   if (lo8) {       // the second term in 8 bits (split16.h): the byte plane for the fused encoder, the same values as fp16 for the others
     uint2 b2;
     split8_q8(v, h4, l4, b2);
-    lo8[j] = b2;
+    lo8[jo] = b2;
   } else
 #endif
     split8_e(v, h4, l4);
-  hi[j] = h4;
-  lo[j] = l4;
+  hi[jo] = h4;
+  lo[jo] = l4;
 }
 
 // largest |W| of every relation's fragment image -> its power of two (split16.h): w_exp[rel] first accumulates the maximum's
@@ -91,7 +92,7 @@ int launch_wfrag_to_bf16(coper_handle* h, const float* Wf, int64_t Rw, void* hi,
   hipLaunchKernelGGL(k_w_absmax, dim3(64, (unsigned)Rw), dim3(256), 0, s, (const float4*)Wf, per_rel4, h->w_exp);
   hipLaunchKernelGGL(k_bits_to_exp, dim3((unsigned)((Rw + 255) / 256)), dim3(256), 0, s, h->w_exp, Rw);
   hipLaunchKernelGGL(k_wfrag_to_bf16, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float4*)Wf,
-                     Rw * dm.nfb, ks32n, (uint4*)hi, (uint4*)lo, (uint2*)lo8, dm.nfb, h->w_exp);
+                     Rw * dm.nfb, ks32n, (uint4*)hi, (uint4*)lo, (uint2*)lo8, dm.nfb, h->w_exp, w16_ks_stride(dm));
   COPER_HIP_TRY(h, hipGetLastError());
   return COPER_OK;
 }
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(256) void k_dense_small_bf16x3(const uint4* __restr
 #pragma unroll
   for (int a = 0; a < NFB; ++a) {
     int fb = fb0 + a < nfb ? fb0 + a : nfb - 1;
-    woff[a] = ((relw * nfb + fb) * ks32n) * 64 + lane;
+    woff[a] = ((relw * nfb + fb) * w16_ks_stride_n(ks32n)) * 64 + lane;
   }
   int64_t xoff[NQ];
 #pragma unroll
@@ -393,7 +394,7 @@ __device__ __forceinline__ void dense_big_body_bf16(uint4* __restrict__ ring, co
       int fbi = sl - plane * NFB;
       int fb = fb0 + fbi < nfb ? fb0 + fbi : nfb - 1;
       const uint4* base = plane ? Wlo : Whi;
-      src[i] = (const char*)(base + ((relw * nfb + fb) * ks32n + kb) * 64 + lane);
+      src[i] = (const char*)(base + ((relw * nfb + fb) * w16_ks_stride_n(ks32n) + kb) * 64 + lane);
       stride[i] = 1024;
     } else {
       int xs = sl - 2 * NFB;
@@ -562,7 +563,7 @@ __device__ __forceinline__ void dense_reg_body_bf16(uint4* __restrict__ ring, co
   for (int j = 0; j < NOWN; ++j) {
     int fb = fb0 + wave + 4 * j;
     if (fb > nfb - 1) fb = nfb - 1;
-    int64_t o = ((relw * nfb + fb) * ks32n + kb) * 64 + lane;
+    int64_t o = ((relw * nfb + fb) * w16_ks_stride_n(ks32n) + kb) * 64 + lane;
     wp[j][0] = Whi + o;
     wp[j][1] = Wlo + o;
   }

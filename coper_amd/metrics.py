@@ -122,8 +122,19 @@ def ranking_and_hits(model, results_dir, data_iterator_handle, name, session=Non
     # a plain list of batches with CSR filters: the encoder needs the ids only, so it is launched as soon as THEY are
     # concatenated, and the filters -- the bulk of the marshalling: concatenation, the canonical-order check, staging -- are
     # put together on the host while the device encodes (coper_encode + coper_rank give coper_encode_rank's bits)
-    # (only a source that already IS a list: a generator -- e.g. of the reference's dense e2_multi batches, 1.2 GB for the
-    # FB15k-237 test set -- is streamed through collect_batches below, one batch converted to CSR and dropped at a time)
+    # An iterator of batches is drained into a list only when its batches carry CSR filters (ids and short lists: a few MB for a
+    # whole evaluation set).  The reference's own batches carry a dense e2_multi [B, |E|] (30 MB each, 1.2 GB for the FB15k-237
+    # test set): those are streamed through collect_batches below, one batch converted to CSR and dropped at a time.
+    if not hasattr(data_iterator_handle, "as_single_batch") and not isinstance(data_iterator_handle, (list, tuple)):
+        it = iter(data_iterator_handle)
+        first = next(it, None)
+        if first is None:
+            data_iterator_handle = []
+        elif "filt_indptr" in first:
+            data_iterator_handle = [first] + list(it)
+        else:
+            import itertools
+            data_iterator_handle = itertools.chain([first], it)
     if ranker is None and isinstance(data_iterator_handle, (list, tuple)) and hasattr(model, "encode") and hasattr(model, "rank") \
             and 0 < sum(len(b["e1"]) for b in data_iterator_handle) <= max_chunk \
             and all("filt_indptr" in b for b in data_iterator_handle):
