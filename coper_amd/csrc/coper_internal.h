@@ -279,8 +279,8 @@ inline int topk_nseg(int64_t n_eblk) { return n_eblk < 4096 ? 8 : 1; }
 inline int topk_expand(const coper_handle* h) {
   const char* force = getenv("COPER_TOPK_EXPAND");             // A/B and tests: "1" / "2" (read per call; set it before the handle's first top-k call and keep it)
   if (h->cfg.score_mode == COPER_SCORE_F32) return 1;
-#if defined(COPER_SC3_MB) && COPER_SC3_MB != 4
-  return 1;                                                    // (A/B builds with 32-entity blocks per wave)
+#if (defined(COPER_SC3_MB) && COPER_SC3_MB != 4) || defined(COPER_SC3_ASM_LOADS)
+  return 1;                                                    // (A/B builds: 32-entity blocks per wave; loads inside the asm blocks -- no 64-entity form generated)
 #endif
   if (h->dm.KS16 != 13 && h->dm.KS16 != 16) return 1;          // (the 64-entity form is instantiated for d = 200 and 256 only: build time)
   if (force && (force[0] == '1' || force[0] == '2')) return force[0] - '0';

@@ -848,12 +848,20 @@ static void dense_fused_launch(coper_handle* h, const int64_t* e1, const int64_t
   }
   // a pending staging job (coper_stage_ids_next) rides in this launch: FUSED_STAGE_WGS more workgroups
   const int n_tile_blocks = (int)(n_big_max + n_small_max);
-  const int n_stage = h->stage_n > 0 ? FUSED_STAGE_WGS : 0;
+  // (a pass being captured into a hipGraph leaves a pending staging job to the next eager call, as coper_post_i32_next does: a
+  // replay would repeat the PCIe read with the pointers recorded at capture time and overwrite whatever staging buffer they name)
+  bool stage_now = h->stage_n > 0;
+  if (stage_now) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); stage_now = false; }
+    else if (cap != hipStreamCaptureStatusNone) stage_now = false;
+  }
+  const int n_stage = stage_now ? FUSED_STAGE_WGS : 0;
   hipLaunchKernelGGL((k_dense_fused_bf16x3<NFB, WNT>), dim3((unsigned)(n_tile_blocks + n_stage), (unsigned)nslices, (unsigned)zgroups), dim3(512),
                      lds, s, (const uint4*)h->Wf16_hi, (const fused_wlo_t*)(FUSED_LO8 ? h->Wf8_lo : h->Wf16_lo), A, h->tiles, h->n_tiles, cap_small, dm.nfb,
                      dm.F_pad / 32, nslices, h->ws_queries, dm.d_pad16, h->z_part, (int)n_big_max, Fn, n_tile_blocks, h->stage_src,
-                     h->stage_n, h->stage_dst, w16_ks_stride(dm));
-  h->stage_n = 0;
+                     stage_now ? h->stage_n : 0, h->stage_dst, w16_ks_stride(dm));
+  if (stage_now) h->stage_n = 0;
 }
 
 // the constant part of FusedFin, (re)written when the workspace or the parameters move (ensure_workspace / prepare)

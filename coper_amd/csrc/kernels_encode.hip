@@ -305,6 +305,64 @@ __global__ __launch_bounds__(HIST_BLOCK) void k_rel_scatter(const int64_t* __res
   }
 }
 
+// ONE relation key (static dense weights: plain ConvE): the counting sort is the identity -- perm[b] = b, one group of B queries cut
+// into ceil(B / 128) balanced tiles -- so nothing is counted or scanned (round 5).  The two-launch path spent 22 us of a plain-ConvE
+// pass having 20,480 threads add to ONE LDS counter and ONE global counter (k_rel_hist_scan: 22.1 us against 12.2 with 474 keys).
+// Same outputs as k_rel_hist_scan + k_rel_scatter (tile order: the rem larger tiles first); the blocks behind the main ones
+// carry a pending coper_post_i32_next job like k_rel_hist_scan's.
+__global__ __launch_bounds__(HIST_BLOCK) void k_rel_group_identity(const int64_t* __restrict__ rel, const int64_t* __restrict__ e1, int64_t B,
+                                                                    int64_t R_all, int have_e1_rows, int64_t shard_lo, int64_t n_local,
+                                                                    int64_t cap_small, int32_t* __restrict__ count, int32_t* __restrict__ offset,
+                                                                    int32_t* __restrict__ tiles, int32_t* __restrict__ n_tiles,
+                                                                    int32_t* __restrict__ perm, int32_t* __restrict__ sorted_row,
+                                                                    int32_t* __restrict__ sorted_rid, int32_t* __restrict__ inv_perm,
+                                                                    float* __restrict__ x3m, int n_main, const int32_t* __restrict__ post_src,
+                                                                    int64_t post_n, int32_t* __restrict__ post_dst) {
+  if ((int)blockIdx.x >= n_main) {
+    const int64_t nb = (int64_t)gridDim.x - n_main, b = (int64_t)blockIdx.x - n_main;
+    const bool vec = ((((uintptr_t)post_src) | ((uintptr_t)post_dst)) & 15) == 0;
+    const int64_t n4 = vec ? post_n / 4 : 0;
+    for (int64_t i = b * HIST_BLOCK + threadIdx.x; i < n4; i += nb * HIST_BLOCK) ((int4*)post_dst)[i] = ((const int4*)post_src)[i];
+    for (int64_t i = 4 * n4 + b * HIST_BLOCK + threadIdx.x; i < post_n; i += nb * HIST_BLOCK) post_dst[i] = post_src[i];
+    return;
+  }
+  const int64_t b = (int64_t)blockIdx.x * HIST_BLOCK + threadIdx.x;
+  if (b < B) {
+    int64_t rid = rel[b];
+    if (rid < 0 || rid >= R_all) rid = 0;
+    int64_t row;
+    if (have_e1_rows) row = b;
+    else { row = e1[b] - shard_lo; if (row < 0 || row >= n_local) row = -1; }
+    perm[b] = (int32_t)b;
+    inv_perm[b] = (int32_t)b;
+    sorted_row[b] = (int32_t)row;
+    sorted_rid[b] = (int32_t)rid;
+  }
+  if (blockIdx.x == 0) {
+    if (x3m) for (int i = threadIdx.x; i < 1024; i += HIST_BLOCK) x3m[i] = 0.f;
+    const int c = (int)B;
+    if (threadIdx.x == 0) {
+      count[0] = c;
+      count[R_all + 1] = 0;
+      offset[0] = 0; offset[1] = c;
+      n_tiles[0] = (c > 0 && c <= 32) ? 1 : 0;
+      n_tiles[1] = c > 32 ? (c + 127) / 128 : 0;
+      if (c > 0 && c <= 32) { tiles[0] = 0; tiles[1] = 0; tiles[2] = c; tiles[3] = 0; }
+    }
+    if (c > 32) {
+      const int nb = (c + 127) / 128, bsz = c / nb, rem = c % nb;
+      int32_t* tiles_big = tiles + 4 * cap_small;
+      for (int j = threadIdx.x; j < nb; j += HIST_BLOCK) {
+        int32_t* t = tiles_big + 4 * (int64_t)j;
+        t[0] = 0;
+        t[1] = j * bsz + (j < rem ? j : rem);
+        t[2] = bsz + (j < rem ? 1 : 0);
+        t[3] = nb > 1 ? 1 : 0;
+      }
+    }
+  }
+}
+
 // capacity of the small-tile list (one tile per relation key at most); the big list follows it
 static int64_t small_tile_cap(const coper_handle* h) { return (h->dm.gen_fc ? h->dm.R : 1) + 1; }
 
@@ -317,6 +375,23 @@ int launch_group_by_relation(coper_handle* h, const int64_t* e1, const int64_t* 
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); post_now = false; }
     else if (cap != hipStreamCaptureStatusNone) post_now = false;
+  }
+  static const bool no_identity = getenv("COPER_GROUP_NO_IDENTITY") != nullptr;     // A/B switch, read once
+  if (R == 1 && !no_identity) {
+    const unsigned nbm = (unsigned)((B + HIST_BLOCK - 1) / HIST_BLOCK);
+    unsigned npost = 0;
+    const int32_t* psrc = h->post_src; const int64_t pn = h->post_n; int32_t* pdst = h->post_dst;
+    if (pn > 0 && post_now) {
+      npost = (unsigned)((pn + 4 * HIST_BLOCK - 1) / (4 * HIST_BLOCK));
+      if (npost > 32) npost = 32;
+      h->post_n = 0;
+    }
+    hipLaunchKernelGGL(k_rel_group_identity, dim3(nbm + npost), dim3(HIST_BLOCK), 0, s, rel, e1, B, (int64_t)dm.R, have_e1_rows ? 1 : 0,
+                       (int64_t)h->cfg.shard_lo, dm.n_local, small_tile_cap(h), h->rel_count, h->rel_offset, h->tiles, h->n_tiles, h->perm,
+                       h->sorted_row, h->sorted_rid, h->inv_perm, h->x3m, (int)nbm, psrc, pn, pdst);
+    (void)tq;
+    COPER_HIP_TRY(h, hipGetLastError());
+    return COPER_OK;
   }
   if (post_now && !(R <= HIST_LDS_MAX && B > 4096)) {     // (a pending coper_post_i32_next rides in the two-launch path only)
     const int64_t pn = h->post_n;

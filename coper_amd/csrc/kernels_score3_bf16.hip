@@ -1385,9 +1385,11 @@ static int sc3_go(coper_handle* h, int64_t q0, int64_t Bc, int32_t* ng, float* g
 template <int NP, int TAIL>
 static int sc3_gm(coper_handle* h, int64_t q0, int64_t Bc, int32_t* ng, float* gmax, int64_t gm_stride, hipStream_t s) {
   if (!gmax) return sc3_go<NP, TAIL, 0>(h, q0, Bc, ng, gmax, gm_stride, s);
+#ifndef COPER_SC3_ASM_LOADS
   if constexpr (SC3_MB == 4 && (2 * NP + TAIL == 13 || 2 * NP + TAIL == 16)) {     // (64-entity maxima: topk_expand, coper_internal.h)
     if (topk_expand(h) == 2) return sc3_go<NP, TAIL, 2>(h, q0, Bc, ng, gmax, gm_stride, s);
   }
+#endif
   return sc3_go<NP, TAIL, 1>(h, q0, Bc, ng, gmax, gm_stride, s);
 }
 

@@ -51,8 +51,27 @@ def hits_and_means(ranks, hits_to_compute=(1, 3, 5, 10, 20)):
     # (np.mean of an integer array is the float64 sum over n; the sum of integers below 2^53 is exact in any order, so the
     # integer sum gives the same float64 -- at half the time)
     mr = (np.float64(ranks.sum(dtype=np.int64)) / n if ranks.dtype.kind in "iu" and ranks.dtype.itemsize <= 4 else np.mean(ranks)) if n else float("nan")
-    mrr = np.mean(1. / ranks) if n else float("nan")
+    if n and ranks.dtype.kind in "iu" and int(ranks.min()) >= 1 and int(ranks.max()) < (1 << 22):
+        # 1 / rank from a table (the same float64 quotients, gathered in the same order: np.mean sums the same array) -- a third of
+        # the time of 20,480 int -> float64 conversions and divisions
+        mrr = np.mean(_inverse_table(int(ranks.max()))[ranks])
+    else:
+        mrr = np.mean(1. / ranks) if n else float("nan")
     return mr, mrr, hits
+
+
+_INV = np.zeros(1)
+
+
+def _inverse_table(top):
+    """[0, 1/1, 1/2, ... 1/top] in float64 (grown on demand, kept)."""
+    global _INV
+    if len(_INV) <= top:
+        n = max(top + 1, 2 * len(_INV))
+        t = np.zeros(n)
+        t[1:] = 1. / np.arange(1, n)
+        _INV = t
+    return _INV
 
 
 def collect_batches(data_iterator_handle, device=None):

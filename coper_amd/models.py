@@ -315,7 +315,12 @@ class ConvE(object):
         B = sb["B"]
         if B == 0:
             return sb["out_host"][:0]
-        self.widen_ids(sb["pin"][:sb["total"]], out=sb["stage"][:sb["total"]])
+        # the int64 device arrays are a copy of the pinned buffer, which is a copy of the caller's arrays taken when the dataset was
+        # staged: nothing can have changed in either since the last pass, so only the FIRST pass brings the batch in (round 5:
+        # -20 us per call of ranking_and_hits on a dataset that is scored after every epoch, run_cpg.py:228-250)
+        if not sb.get("resident"):
+            self.widen_ids(sb["pin"][:sb["total"]], out=sb["stage"][:sb["total"]])
+            sb["resident"] = True
         e1, rel, e2, ip, ix = sb["views"]
         ranks = sb["ranks"][:B]
         _lib.check(self._h, self._lib.coper_encode_rank(self._h, _ptr(e1), _ptr(rel), None, _ptr(e2), _ptr(ip), _ptr(ix),

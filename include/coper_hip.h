@@ -98,7 +98,10 @@ typedef struct coper_config {
   /* COPER_SCORE_BF16X3: the entity planes hold ent_emb 2^e with e chosen so that this magnitude lands in [2^14, 2^15) of
    * fp16's range.  0 = the largest |ent_emb| element of the handle's own rows.  Entity shards of one table pass the table-wide
    * maximum (coper_amd/sharding.py all-reduces it) so that the mode's logits do not depend on the shard layout; a value below
-   * the shard's own maximum is refused by coper_prepare. */
+   * the shard's own maximum is refused by coper_prepare.  The same magnitude bounds the encoder's INPUT rows: rows handed in through
+   * `e1_rows` (an entity-sharded evaluation passes rows of other shards) must not exceed it in any element -- the conv activations'
+   * power of two and the fp16 image planes of the fused encoder are derived from it; larger elements are clamped to fp16's range
+   * and `h` saturates silently.  coper_amd/sharding.py keeps the table-wide maximum agreed on every chunk. */
   float x3_ent_absmax;
   /* COPER_SCORE_BF16X3: which count launches carry the band audit (coper_band_audit).  0 = the library default: the first
    * launch after coper_prepare and every 8th from there (+3 us per 0.5 ms pass), every launch of more than 2^31 logits;
@@ -168,7 +171,9 @@ COPER_API int coper_widen_ids(coper_handle* h, const int32_t* src, int64_t n, in
  * stream their weights (fewer tiles than CUs at the BASELINE shapes: they run on CUs that would idle), so the batch of pass
  * n + 1 arrives under pass n's kernels without a second stream.  dst must not be an array pass n itself reads (two staging
  * buffers, used alternately); configurations the fused encoder does not serve run the job as a launch of its own at the same
- * point.  Nothing is queued on a stream by this call; a later call replaces a job that has not run. */
+ * point.  Nothing is queued on a stream by this call; a later call replaces a job that has not run.  A pass that is being
+ * captured into a hipGraph leaves the job pending for the next eager call (a replay must not repeat a read with the pointers
+ * recorded at capture time). */
 COPER_API int coper_stage_ids_next(coper_handle* h, const int32_t* src, int64_t n, int64_t* dst);
 
 /* The way back: n int32 values (the ranks of a pass) from device memory to `dst`, which may be PINNED, device-mapped HOST
