@@ -358,7 +358,7 @@ COPER_API void coper_destroy(coper_handle* h) {
   dev_free(&h->rel_count_buf[0]); h->rel_count = nullptr; h->rel_count_buf[1] = nullptr; h->group_done = nullptr; dev_free(&h->rel_offset); h->rel_cursor = nullptr; dev_free(&h->perm); dev_free(&h->inv_perm); dev_free(&h->sorted_row); dev_free(&h->sorted_rid);
   dev_free(&h->tiles); dev_free(&h->n_tiles); dev_free(&h->blk_off); dev_free(&h->x_sorted); dev_free(&h->z_part);
   dev_free(&h->tgt_ws); dev_free(&h->h_ws); dev_free(&h->cnt_ws); dev_free(&h->hfrag_ws); dev_free(&h->logits_ws); dev_free(&h->row_of_ws);
-  dev_free(&h->gmax_ws); dev_free(&h->cand_blk_ws); dev_free(&h->cand_val_ws); dev_free(&h->cand_q_ws); dev_free(&h->cand_tau_ws); dev_free(&h->cand_sorted_ws); dev_free(&h->blk_cnt_ws); dev_free(&h->blk_off_ws);
+  dev_free(&h->tk_coarse_ws); dev_free(&h->gmax_ws); dev_free(&h->cand_blk_ws); dev_free(&h->cand_val_ws); dev_free(&h->cand_q_ws); dev_free(&h->cand_tau_ws); dev_free(&h->cand_sorted_ws); dev_free(&h->blk_cnt_ws); dev_free(&h->blk_off_ws);
   dev_free((char**)&h->Wf16_hi); dev_free((char**)&h->Wf16_lo); dev_free((char**)&h->Wf8_lo);
   dev_free((char**)&h->Ef16_hi); dev_free((char**)&h->Ef16_lo); dev_free((char**)&h->hfrag16_hi); dev_free((char**)&h->hfrag16_lo);
   dev_free((char**)&h->Erm16_hi); dev_free((char**)&h->Erm16_lo); dev_free((char**)&h->hrm16_hi); dev_free((char**)&h->hrm16_lo);
@@ -796,8 +796,13 @@ COPER_API int coper_rank_counts(coper_handle* h, const float* hvec, const float*
   if (pruned) {
     const size_t gneed = (size_t)(topk_gm_rows(h) * topk_chunk_queries(h->dm.n_eblk, B, h->gmax_max_floats));
     const size_t t64 = (size_t)((int64_t)k * B + filt_nnz), tneed = (size_t)XF * t64;
-    if (gneed > h->gmax_cap || tneed > h->cand_cap || (size_t)B > h->cand_tau_cap) {
+    const size_t cneed = topk_coarse_bytes(topk_gm_rows(h), topk_chunk_queries(h->dm.n_eblk, B, h->gmax_max_floats));
+    if (gneed > h->gmax_cap || tneed > h->cand_cap || (size_t)B > h->cand_tau_cap || cneed > h->tk_coarse_cap) {
       COPER_HIP_TRY(h, hipStreamSynchronize(s));
+      if (cneed > h->tk_coarse_cap) {
+        if ((rc = dev_alloc(h, &h->tk_coarse_ws, cneed))) return rc;
+        h->tk_coarse_cap = cneed;
+      }
       if (gneed > h->gmax_cap) {
         if ((rc = dev_alloc(h, &h->gmax_ws, gneed))) return rc;
         h->gmax_cap = gneed;

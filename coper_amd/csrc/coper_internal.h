@@ -156,6 +156,8 @@ struct coper_handle {
   float* cand_val_ws = nullptr;   // [k*B + nnz][32] their logits
   size_t cand_cap = 0;
   int32_t* cand_q_ws = nullptr;   // [k*B + nnz] the query of every candidate slot
+  char* tk_coarse_ws = nullptr;   // the threshold kernel's coarse level (topk_coarse_bytes)
+  size_t tk_coarse_cap = 0;
   uint32_t* cand_tau_ws = nullptr; // [B] selection threshold per query (ordered float bits; 0: none)
   size_t cand_tau_cap = 0;
   int32_t* cand_sorted_ws = nullptr;  // candidate slots grouped by entity block, 32-padded per block
@@ -268,6 +270,20 @@ inline int64_t topk_chunk_queries(int64_t n_eblk, int64_t B, int64_t cap_floats)
   if (qc < 128) qc = 128;
   const int64_t Bpad = (B + 127) / 128 * 128;
   return qc > Bpad ? Bpad : qc;
+}
+// The coarse level of the top-k threshold kernel (kernels_topk_bf16.hip: TK_GRP; round 5): one key per 16 visits of a thread, i.e.
+// 1/16 of the block maxima of a query chunk -- bytes of the scratch for G blocks x qs queries, for either strip width (4 x QV
+// queries, 512 / QV sub-ranges); 0: the block axis is too short for the route to pay.
+constexpr int64_t TK_COARSE_MIN_BLOCKS = 16384;
+inline size_t topk_coarse_bytes(int64_t G, int64_t qs) {
+  if (G < TK_COARSE_MIN_BLOCKS) return 0;
+  size_t need = 0;
+  for (int QV : {4, 8}) {
+    const int64_t SUB = 512 / QV, NG = ((G + SUB - 1) / SUB + 15) / 16, strips = (qs + 4 * QV - 1) / (4 * QV);
+    const size_t b = (size_t)strips * NG * 512 * 16;
+    need = b > need ? b : need;
+  }
+  return need;
 }
 // size of the block-grouped slot list: every block with candidates is padded to a multiple of 32
 // counters per block for the grouping of candidate slots: few blocks = many slots per block = contended atomics

@@ -93,6 +93,16 @@ __device__ __forceinline__ void tk_sweep_strided(const float4* __restrict__ col,
 }
 
 constexpr int TK_BIN = 64;   // block maxima per query that may share the threshold's upper 16 bits on the fast path
+// Round 5 -- the coarse seed (long block axes: the 10M-entity table and its shards).  The three sweeps above read every block
+// maximum three times (2.56 GB each for 4,096 queries against 10 M entities).  Instead: ONE sweep that only keeps the largest key
+// of every TK_GRP consecutive visits of a thread (1/16 of the data, written to `coarse`), an exact radix select of the m-th
+// largest COARSE key tau_c on that level (four passes over 1/16), and then only the groups whose coarse key reaches tau_c are
+// read again: the m-th largest maximum tau is >= tau_c (the m largest coarse keys are m maxima >= tau_c), so every block with a
+// maximum >= tau lies in such a group -- about m groups per query.  Their maxima >= tau_c go to an LDS list (TK_CL entries per
+// query) that is ranked (key desc, block asc) exactly as the bin list of the fast path was; a list that overflows (queries with
+// hundreds of known answers: m = k + their number) sends the strip down the three-sweep route.
+constexpr int TK_GRP = 16;   // visits per coarse key
+constexpr int TK_CL = 128;   // candidate-list entries per query on the coarse route (>= TK_BIN: the two routes share the lists)
 
 // Threshold + candidate blocks of a strip of NQS = 4 * QV queries (QV = 8: 32 queries; QV = 4: 16).
 // thread = (sub-range of the block axis, 4 queries); HCOPY histogram copies (sub-range % HCOPY) thin out same-bank
@@ -114,12 +124,36 @@ extern "C" __attribute__((visibility("default"))) int coper_dbg_tk_over() {
 }
 #endif
 
+// A thread's walk over the coarse keys it wrote (TK_GRP): eight 16-byte loads in flight per batch -- the walk is a handful of
+// groups per thread (10 on a 1.25 M-row shard, 77 on the 10M table), one load at a time it was a round trip per group and pass.
+template <typename F>
+__device__ __forceinline__ void tk_coarse_walk(const uint4* __restrict__ my, int64_t n_grp, F&& f) {
+  constexpr int D = 8;
+  int64_t jg = 0;
+  for (; jg + D <= n_grp; jg += D) {
+    uint4 v[D];
+#pragma unroll
+    for (int u = 0; u < D; ++u) v[u] = my[(jg + u) * TK_THREADS];
+#pragma unroll
+    for (int u = 0; u < D; ++u) f(jg + u, v[u]);
+  }
+  if (jg < n_grp) {
+    uint4 v[D];
+#pragma unroll
+    for (int u = 0; u < D; ++u) v[u] = my[(jg + u < n_grp ? jg + u : n_grp - 1) * TK_THREADS];
+#pragma unroll
+    for (int u = 0; u < D; ++u)
+      if (jg + u < n_grp) f(jg + u, v[u]);
+  }
+}
+
 template <int QV, int HCOPY>
 __global__ __launch_bounds__(TK_THREADS) void k_topk_threshold_emit(const float* __restrict__ gmax, int64_t G, int64_t Qs, int64_t q0,
                                                                     int64_t Bc, int k, const int64_t* __restrict__ indptr,
                                                                     int32_t* __restrict__ cand_blk, int32_t* __restrict__ cand_q,
                                                                     int32_t* __restrict__ blk_cnt, int nseg,
-                                                                    uint32_t* __restrict__ cand_tau, int pair_xcd) {
+                                                                    uint32_t* __restrict__ cand_tau, int pair_xcd,
+                                                                    uint4* __restrict__ coarse, int64_t NG) {
   constexpr int NQS = 4 * QV, SUB = TK_THREADS / QV;
   extern __shared__ uint32_t tk_lds[];
   uint32_t* hist = tk_lds;                               // [HCOPY][256 digits][NQS]
@@ -129,8 +163,8 @@ __global__ __launch_bounds__(TK_THREADS) void k_topk_threshold_emit(const float*
   uint32_t* s_bn = s_slot + NQS;                         // [NQS] fast path: entries of the bin list
   uint32_t* s_cgt = s_bn + NQS;                          // [SUB][NQS]   (general route)
   uint32_t* s_ceq = s_cgt + SUB * NQS;                   // [SUB][NQS]
-  uint32_t* s_bkey = s_ceq + SUB * NQS;                  // [NQS][TK_BIN]
-  int32_t* s_bg = (int32_t*)(s_bkey + NQS * TK_BIN);     // [NQS][TK_BIN]
+  uint32_t* s_bkey = s_ceq + SUB * NQS;                  // [NQS][TK_CL]   (fast path: TK_BIN of them)
+  int32_t* s_bg = (int32_t*)(s_bkey + NQS * TK_CL);      // [NQS][TK_CL]
   const int qv = threadIdx.x % QV, sr = threadIdx.x / QV;
   // 16-query strips are 64 B of a 128-B line of gmax: the two strips of a line go to workgroups 8 apart, i.e. to the same
   // XCD (workgroup w runs on XCD w % 8) -- one L2 then fetches the line once, where neighbouring workgroups (two XCDs)
@@ -232,6 +266,152 @@ __global__ __launch_bounds__(TK_THREADS) void k_topk_threshold_emit(const float*
     mask |= 0xFFu << shift;
     __syncthreads();
   };
+  // ---- the coarse route (see TK_GRP above)
+  bool coarse_done = false;
+  if (coarse) {
+    uint4* my = coarse + ((int64_t)strip * NG) * TK_THREADS + threadIdx.x;      // my group jg: my[jg * TK_THREADS]
+    const int64_t n_vis = (int64_t)sr < G ? (G - sr + SUB - 1) / SUB : 0;       // my visits: blocks sr, sr + SUB, ...
+    const int64_t n_grp = (n_vis + TK_GRP - 1) / TK_GRP;
+    {   // sweep 1: the largest key of every TK_GRP visits
+      uint32_t gm[4] = {0u, 0u, 0u, 0u};
+      int64_t gj = 0;
+      tk_sweep_strided(col, qs4, (int64_t)sr, (int64_t)SUB, G, [&](int64_t g, const float4& v4) {
+        const int64_t jg = ((g - sr) / SUB) / TK_GRP;
+        if (jg != gj) { my[gj * TK_THREADS] = make_uint4(gm[0], gm[1], gm[2], gm[3]); gm[0] = gm[1] = gm[2] = gm[3] = 0u; gj = jg; }
+        const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { const uint32_t key = tk_key(vv[c]); gm[c] = key > gm[c] ? key : gm[c]; }
+      });
+      if (n_vis > 0) my[gj * TK_THREADS] = make_uint4(gm[0], gm[1], gm[2], gm[3]);
+    }
+    // the m-th largest coarse key of every query: four radix digits over the keys this thread wrote itself
+    uint32_t cmask = 0;
+    for (int pass = 0; pass < 4; ++pass) {
+      const int shift = 24 - 8 * pass;
+      for (int j = threadIdx.x; j < HCOPY * 256 * NQS; j += TK_THREADS) hist[j] = 0;
+      __syncthreads();
+      uint32_t prefix[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) prefix[c] = s_prefix[4 * qv + c];
+      tk_coarse_walk(my, n_grp, [&](int64_t, const uint4& k4) {
+        const uint32_t kk[4] = {k4.x, k4.y, k4.z, k4.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if ((kk[c] & cmask) == prefix[c]) atomicAdd(&myhist[((kk[c] >> shift) & 255) * NQS + c], 1u);
+      });
+      __syncthreads();
+      if (threadIdx.x < NQS) {
+        const int qi = threadIdx.x;
+        const uint32_t rem = s_rem[qi];
+        if (rem > 0) {
+          uint32_t cum = 0;
+          int dg = 255;
+          for (; dg > 0; --dg) {
+            uint32_t cnt = 0;
+#pragma unroll
+            for (int hc = 0; hc < HCOPY; ++hc) cnt += hist[(hc * 256 + dg) * NQS + qi];
+            if (cum + cnt >= rem) break;
+            cum += cnt;
+          }
+          s_prefix[qi] |= (uint32_t)dg << shift;
+          s_rem[qi] = rem - cum;
+        }
+      }
+      cmask |= 0xFFu << shift;
+      __syncthreads();
+    }
+    // the groups that reach tau_c: their maxima >= tau_c into the query's list
+    {
+      uint32_t tauc[4];
+      bool live[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { tauc[c] = s_prefix[4 * qv + c]; live[c] = valid[c]; }
+      tk_coarse_walk(my, n_grp, [&](int64_t jg, const uint4& k4) {
+        const uint32_t kk[4] = {k4.x, k4.y, k4.z, k4.w};
+        bool q_[4], any = false;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { q_[c] = live[c] && kk[c] >= tauc[c]; any |= q_[c]; }
+        if (!any) return;
+        for (int u0 = 0; u0 < TK_GRP; u0 += 8) {      // the group's maxima again, eight loads in flight
+          float4 f8[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int64_t g = sr + (jg * TK_GRP + u0 + u) * (int64_t)SUB;
+            f8[u] = col[(g < G ? g : (int64_t)sr) * qs4];
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int64_t g = sr + (jg * TK_GRP + u0 + u) * (int64_t)SUB;
+            if (g >= G) continue;
+            const float vv[4] = {f8[u].x, f8[u].y, f8[u].z, f8[u].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              if (!q_[c]) continue;
+              const uint32_t key = tk_key(vv[c]);
+              if (key >= tauc[c]) {
+                const uint32_t i = atomicAdd(&s_bn[4 * qv + c], 1u);
+                if (i < (uint32_t)TK_CL) { s_bkey[(4 * qv + c) * TK_CL + i] = key; s_bg[(4 * qv + c) * TK_CL + i] = (int32_t)g; }
+              }
+            }
+          }
+        }
+      });
+    }
+    __syncthreads();
+    bool over_c = false;
+    if (threadIdx.x < NQS) over_c = s_bn[threadIdx.x] > (uint32_t)TK_CL;
+    if (!__syncthreads_or(over_c ? 1 : 0)) {
+      // rank the lists: entry e of query qi is candidate number `ahead` if ahead < m
+      for (int t = threadIdx.x; t < NQS * TK_CL; t += TK_THREADS) {
+        const int qi = t / TK_CL, e = t % TK_CL;
+        const int64_t ql = qs0 + qi;
+        const uint32_t nb = s_bn[qi];
+        if (ql >= Bc || (uint32_t)e >= nb) continue;
+        const int64_t qg = q0 + ql;
+        const int64_t beg = indptr[qg] - indptr[0];
+        const int64_t nslots = (int64_t)k + (indptr[qg + 1] - indptr[0] - beg);
+        const uint32_t m = (uint32_t)(nslots < G ? nslots : G);
+        const uint32_t key = s_bkey[qi * TK_CL + e];
+        const int32_t g = s_bg[qi * TK_CL + e];
+        uint32_t ahead = 0;
+        for (uint32_t t2 = 0; t2 < nb; ++t2) {
+          const uint32_t k2 = s_bkey[qi * TK_CL + t2];
+          ahead += (k2 > key || (k2 == key && s_bg[qi * TK_CL + t2] < g)) ? 1u : 0u;
+        }
+        if (ahead >= m) continue;
+        const int64_t o = (int64_t)k * qg + beg;
+        cand_blk[o + ahead] = key > kinf ? g : -1;       // blocks whose maximum is -inf hold nothing: their slots stay unused
+        if (ahead == m - 1) cand_tau[qg] = (nslots <= G && key > kinf) ? key : 0u;
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (!valid[c]) continue;
+        const int qi = 4 * qv + c;
+        const int64_t m = slots[c] < G ? slots[c] : G;
+        for (int64_t j = sr; j < slots[c]; j += SUB) {
+          cand_q[off[c] + j] = (int32_t)(q0 + qs0 + qi);
+          if (j >= m) cand_blk[off[c] + j] = -1;
+        }
+      }
+      coarse_done = true;
+    } else {
+      // a list overflowed: the strip takes the three-sweep route from the start
+      if (threadIdx.x < NQS) {
+        const int64_t ql = qs0 + threadIdx.x;
+        int64_t m64 = 0;
+        if (ql < Bc) {
+          m64 = (int64_t)k + (indptr[q0 + ql + 1] - indptr[q0 + ql]);
+          if (m64 > G) m64 = G;
+        }
+        s_prefix[threadIdx.x] = 0;
+        s_rem[threadIdx.x] = (uint32_t)m64;
+        s_slot[threadIdx.x] = 0;
+        s_bn[threadIdx.x] = 0;
+      }
+      __syncthreads();
+    }
+  }
+  if (!coarse_done) {
   radix_pass(0);
   radix_pass(1);
 
@@ -355,6 +535,7 @@ __global__ __launch_bounds__(TK_THREADS) void k_topk_threshold_emit(const float*
       }
     });
   }
+  }   // (!coarse_done)
   // ---- candidates are scored block by block: how many slots want block g (nseg counters per block thin out the
   // same-address atomics when there are few blocks)
   __threadfence_block();
@@ -389,7 +570,7 @@ __global__ __launch_bounds__(256) void k_topk_expand64(const int32_t* __restrict
 
 template <int QV, int HCOPY>
 constexpr size_t tk_emit_lds() {
-  return sizeof(uint32_t) * (HCOPY * 256 * 4 * QV + 4 * 4 * QV + 2 * (TK_THREADS / QV) * 4 * QV + 2 * 4 * QV * TK_BIN);
+  return sizeof(uint32_t) * (HCOPY * 256 * 4 * QV + 4 * 4 * QV + 2 * (TK_THREADS / QV) * 4 * QV + 2 * 4 * QV * TK_CL);
 }
 
 // ---- group the candidate slots by entity block: every block's slots padded to a multiple of 32 (one wave each)
@@ -687,8 +868,14 @@ static void tk_launch_emit(coper_handle* h, int64_t G, int64_t qs, int64_t q0, i
     (void)hipFuncSetAttribute((const void*)k_topk_threshold_emit<QV, HCOPY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done |= bit;
   }
+  // the coarse route (TK_GRP): long block axes, when the scratch was reserved for this (G, qs)
+  static const bool no_coarse = getenv("COPER_TK_NO_COARSE") != nullptr;     // A/B switch, read once
+  constexpr int64_t SUB = TK_THREADS / QV;
+  const int64_t NG = ((G + SUB - 1) / SUB + TK_GRP - 1) / TK_GRP, strips = qs / (4 * QV);
+  const size_t cbytes = (size_t)strips * NG * TK_THREADS * sizeof(uint4);
+  uint4* coarse = (!no_coarse && G >= TK_COARSE_MIN_BLOCKS && h->tk_coarse_ws && cbytes <= h->tk_coarse_cap) ? (uint4*)h->tk_coarse_ws : nullptr;
   hipLaunchKernelGGL((k_topk_threshold_emit<QV, HCOPY>), dim3((unsigned)(qs / (4 * QV))), dim3(TK_THREADS), lds, s, h->gmax_ws, G, qs, q0, bc,
-                     k, indptr, out_blk, out_q, out_cnt, topk_nseg(G), h->cand_tau_ws, tk_pair_xcd() ? 1 : 0);
+                     k, indptr, out_blk, out_q, out_cnt, topk_nseg(G), h->cand_tau_ws, tk_pair_xcd() ? 1 : 0, coarse, NG);
 }
 
 // strip width / histogram copies of the threshold kernel by shape

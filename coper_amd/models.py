@@ -372,6 +372,8 @@ class ConvE(object):
     def encode(self, e1, rel, e1_rows: Optional[torch.Tensor] = None):
         """predicted_e2_emb [B, d] (models.py:183)."""
         self._need_prepared()
+        if e1 is not None and not isinstance(e1, torch.Tensor) and not isinstance(rel, torch.Tensor):
+            e1, rel = self.stage_batch(e1, rel)          # host ids: one pinned int32 buffer, one launch (not two pageable copies)
         rel = self._ids(rel)
         e1 = self._ids(e1) if e1 is not None else None
         B = rel.numel()
@@ -452,6 +454,8 @@ class ConvE(object):
     def rank(self, h, e2, filt_indptr, filt_idx, filt_nnz=None, want_equal=True):
         """Filtered ranks int32 [B] (+ n_equal, or None with want_equal=False) on an unsharded model."""
         self._need_prepared()
+        if not any(isinstance(a, torch.Tensor) for a in (e2, filt_indptr, filt_idx)):
+            e2, filt_indptr, filt_idx = self.stage_batch(e2, filt_indptr, filt_idx)     # host batch: pinned int32 + one widening launch
         e2, ip, ix = self._ids(e2), self._ids(filt_indptr), self._ids(filt_idx)
         B = e2.numel()
         nnz = int(ix.numel()) if filt_nnz is None else int(filt_nnz)

@@ -237,22 +237,41 @@ class EntityShardedRanker(object):
         h = self.encode(chunk["e1"], chunk["rel"], rows=rows1)                    # step 2
         tx = sc.score_rows(h, rows2, bias2)          # the targets by the fp32 chain, on every rank from its own copy of the rows
         tgt = torch.stack([tx, tx])
-        out = sc.rank_counts(h, tgt, chunk["e2"], chunk["filt_indptr"], chunk["filt_idx"],
-                             filt_nnz=len(chunk["filt_idx"]), k=k)
-        ng, ne = out[0], out[1]
-        # step 3: ONE all-gather of the packed per-shard record: [ng<<32 | ne, k score bit patterns, k ids]
-        B = ng.shape[0]
-        rec = torch.empty((B, 1 + 2 * k), dtype=torch.int64, device=ng.device)
-        rec[:, 0] = (ng.to(torch.int64) << 32) | ne.to(torch.int64)
-        if k > 0:
-            rec[:, 1:1 + k] = out[2].contiguous().view(torch.int32).to(torch.int64)
-            rec[:, 1 + k:] = out[3]
-        if self.dist:
-            allrec = torch.empty((self.world * B, 1 + 2 * k), dtype=torch.int64, device=rec.device)
-            dist.all_gather_into_tensor(allrec, rec, group=self.group)           # concatenated along dim 0 (gloo + nccl)
-            allrec = allrec.view(self.world, B, 1 + 2 * k)
+        # step 3: ONE all-gather of the packed per-shard record: [ng<<32 | ne, k score bit patterns, k ids] per query, and one more
+        # row per rank: the words of its band audit (x3 scorers).  Every rank sees every rank's audit, so all of them apply the
+        # SAME policy (coper_band_policy on the largest ratio): widen kappa together, and -- from 1.0 on -- count the chunk again
+        # together (round 5; the unsharded ranker does the same in metrics.ranking_and_hits).  No extra collective.
+        audited = hasattr(sc, "band_audit") and hasattr(sc, "band_policy") and getattr(sc, "score_mode", None) == "bf16x3"
+        for attempt in range(5):
+            out = sc.rank_counts(h, tgt, chunk["e2"], chunk["filt_indptr"], chunk["filt_idx"],
+                                 filt_nnz=len(chunk["filt_idx"]), k=k)
+            ng, ne = out[0], out[1]
+            B = ng.shape[0]
+            rec = torch.zeros((B + 1, 1 + 2 * k), dtype=torch.int64, device=ng.device)
+            rec[:B, 0] = (ng.to(torch.int64) << 32) | ne.to(torch.int64)
+            if k > 0:
+                rec[:B, 1:1 + k] = out[2].contiguous().view(torch.int32).to(torch.int64)
+                rec[:B, 1 + k:] = out[3]
+            if audited:
+                ratio, n_pairs = sc.band_audit()
+                rec[B, 0] = (int(np.float32(ratio).view(np.uint32)) << 32) | (min(int(n_pairs), 0x7fffffff) & 0xffffffff)
+            if self.dist:
+                allrec = torch.empty((self.world * (B + 1), 1 + 2 * k), dtype=torch.int64, device=rec.device)
+                dist.all_gather_into_tensor(allrec, rec, group=self.group)           # concatenated along dim 0 (gloo + nccl)
+                allrec = allrec.view(self.world, B + 1, 1 + 2 * k)
+            else:
+                allrec = rec.view(1, B + 1, 1 + 2 * k)
+            if not audited:
+                break
+            words = allrec[:, B, 0].cpu().numpy()
+            ratios = (words >> 32).astype(np.uint32).view(np.float32)
+            pairs = int((words & 0xffffffff).sum())
+            action, _ = sc.band_policy(float(ratios.max()) if pairs else 0.0, pairs)
+            if action != 2:
+                break
         else:
-            allrec = rec.view(1, B, 1 + 2 * k)
+            raise RuntimeError("bf16x3 band audit: still above the band's allowance after 4 re-counted chunks")
+        allrec = allrec[:, :B, :]
         ng_tot = (allrec[:, :, 0] >> 32).sum(dim=0)
         ne_tot = (allrec[:, :, 0] & 0xFFFFFFFF).sum(dim=0)
         ranks = (1 + ng_tot).to(torch.int32)

@@ -357,6 +357,15 @@ def test_band_policy_widens_and_reranks_a_too_narrow_band():
         got2 = ranking_and_hits(m, None, src2, route, return_ranks=True)[3]
         assert np.array_equal(got2, want) and ranking_and_hits.last_band_audit[0] < 1.0
         m.close()
+    # the entity-sharded ranker applies the same policy on the audit words it exchanges with its records (one shard here: no
+    # process group; the two-rank form runs in tests/test_gpu_multirank.py)
+    from coper_amd.sharding import EntityShardedRanker
+    m = ConvE(md, device="cuda:0", score_mode="bf16x3", rank_band_kappa=1e-9, band_audit_period=1).load_parameters(p).prepare()
+    ranking_and_hits.band_actions = 0
+    got = ranking_and_hits(m, None, cdata.EvalDataset(q, 512, md["num_ent"]), "sharded", ranker=EntityShardedRanker(m), return_ranks=True)[3]
+    assert np.array_equal(got, want)
+    assert m.band_policy(0.0, 0)[1] >= 64e-9                      # (the ranker widened the handle's band)
+    m.close()
     # the C entry point as a foreign host binds it: thresholds and the multiplier's arithmetic
     m = ConvE(md, device="cuda:0", score_mode="bf16x3").load_parameters(p).prepare()
     act, kap = ctypes.c_int32(), ctypes.c_float()
