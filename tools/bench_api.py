@@ -18,7 +18,8 @@ torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
 print("ranking_and_hits (EvalDataset, 20480 queries): %.3f ms  %.2f M triples/s" % (dt * 1e3, 20480 / dt / 1e6), out[:2])
 # generic iterable of batches (no as_single_batch): the reference's batch contract with CSR filters
 batches = list(ds)
-t0 = time.perf_counter()
+for _ in range(3): ranking_and_hits(m, None, iter(batches), "test")      # (the first call allocates the pinned staging buffers)
+torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(10): out = ranking_and_hits(m, None, iter(batches), "test")
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
 print("ranking_and_hits (list of 512-batches): %.3f ms  %.2f M triples/s" % (dt * 1e3, 20480 / dt / 1e6))
