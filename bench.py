@@ -116,6 +116,7 @@ def parse_args():
                          "costs the stream a few microseconds of pipeline drain; 1 = every step)")
     ap.add_argument("--topk", type=int, default=0,
                     help="entity mode: also select and exchange the per-shard top-k of the filtered rows (SURVEY 8(e) step 3)")
+    ap.add_argument("--no-group-next", action="store_true", help="--h2d overlap with every pass sorting its own batch by relation (A/B against coper_group_next)")
     ap.add_argument("--no-post-next", action="store_true", help="--h2d overlap with the ranks copied out by a launch of their own behind every pass (A/B against coper_post_i32_next)")
     ap.add_argument("--h2d", choices=["overlap", "kernel", "sdma"], default="overlap",
                     help="how a pass's pinned int32 batch reaches the device: read over PCIe by extra workgroups of the PREVIOUS pass's "
@@ -590,6 +591,8 @@ def main():
                     model.widen_ids(pin, out=stages[c])
                     primed[0] = True
                 model.stage_next(pin, stages[1 - c])       # pass n + 1's batch: beside this pass's encoder launch
+                if not args.no_group_next:                 # ... where one more workgroup sorts it by relation (coper_group_next)
+                    model.group_next(views2[1 - c]["e1"], views2[1 - c]["rel"])
             elif args.h2d == "kernel":
                 model.widen_ids(pin, out=stages[c])        # one launch reads the pinned int32 batch over PCIe and writes int64 (coper_widen_ids)
             else:
@@ -756,7 +759,7 @@ def main():
                 "score_mode": "f32 (v_mfma_f32_32x32x2_f32, exact)" if args.score_mode == "f32" else
                 "bf16x3 = the x3 mode (API name kept): fp16 split since round 3, 3 x v_mfma_f32_16x16x32_f16 (two K = 16 steps each) per "
                 "pair of products, ~2^-22 rel.; exact band decided by the fp32 chain", "prepare_ms": round(prepare_ms, 2),
-                "inputs": ("SURVEY 8(d) region: every pass brings a batch of ids + CSR filters (int32 in pinned host memory, " + ({"overlap": "the NEXT pass's batch, read over PCIe and widened by extra workgroups of this pass's encoder launch: coper_stage_ids_next" + ("" if args.no_post_next else "; the ranks of a pass are posted to pinned host memory by extra blocks of the next pass's first launch: coper_post_i32_next"), "kernel": "read over PCIe and widened by one launch of coper_widen_ids in front of the pass", "sdma": "one copy-engine H2D, widened on the device"}[args.h2d]) + ") in and copies its int32 "
+                "inputs": ("SURVEY 8(d) region: every pass brings a batch of ids + CSR filters (int32 in pinned host memory, " + ({"overlap": "the NEXT pass's batch, read over PCIe and widened by extra workgroups of this pass's encoder launch: coper_stage_ids_next" + ("" if args.no_group_next else ", and sorted by relation by one more (coper_group_next: the pass starts with its encoder launch)") + ("" if args.no_post_next else "; the ranks of a pass are posted to pinned host memory by extra blocks of the next pass's first launch: coper_post_i32_next"), "kernel": "read over PCIe and widened by one launch of coper_widen_ids in front of the pass", "sdma": "one copy-engine H2D, widened on the device"}[args.h2d]) + ") in and copies its int32 "
                            "ranks back to pinned host memory (D2H), %d bytes per pass, inside the timed region; one stream"
                            % pcie_bytes) if pcie_step is not None
                 else "ids + CSR filters resident in HBM before the timed region",

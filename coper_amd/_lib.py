@@ -80,6 +80,7 @@ PROTOTYPES = {
     "coper_copy_out_i32": (C.c_int, [_P, _P, _I64, _P, _P]),
     "coper_stage_ids_next": (C.c_int, [_P, _P, _I64, _P]),
     "coper_post_i32_next": (C.c_int, [_P, _P, _I64, _P]),
+    "coper_group_next": (C.c_int, [_P, _P, _P, _I64, C.c_int32]),
     "coper_gather_entities": (C.c_int, [_P, _P, _I64, _P, _P]),
     "coper_encode": (C.c_int, [_P, _P, _P, _I64, _P, _P, _P]),
     "coper_score_all": (C.c_int, [_P, _P, _I64, _P, _I64, _P]),

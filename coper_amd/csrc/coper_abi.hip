@@ -164,6 +164,66 @@ static void dev_free(T** p) {
   if (*p) { (void)tracked_free(*p); *p = nullptr; }
 }
 
+// ---- grouping sets (coper_group_next) ----
+void group_snapshot_home(coper_handle* h) {
+  coper_handle::GroupSet& g = h->gset[0];
+  g.rel_count = h->rel_count; g.rel_offset = h->rel_offset; g.perm = h->perm; g.inv_perm = h->inv_perm; g.sorted_row = h->sorted_row;
+  g.sorted_rid = h->sorted_rid; g.tiles = h->tiles; g.n_tiles = h->n_tiles; g.x3m = h->x3m; g.fused_fin_dev = h->fused_fin_dev;
+  g.fused_fin_perm = h->fused_fin_perm;
+}
+
+void group_use_set(coper_handle* h, int i) {
+  if (h->gcur == i) return;
+  if (h->gcur == 0) group_snapshot_home(h);
+  const coper_handle::GroupSet& g = h->gset[i];
+  h->rel_count = g.rel_count; h->rel_offset = g.rel_offset; h->perm = g.perm; h->inv_perm = g.inv_perm; h->sorted_row = g.sorted_row;
+  h->sorted_rid = g.sorted_rid; h->tiles = g.tiles; h->n_tiles = g.n_tiles; h->x3m = g.x3m; h->fused_fin_dev = g.fused_fin_dev;
+  h->fused_fin_perm = g.fused_fin_perm;
+  h->gcur = i;
+}
+
+void group_sets_free(coper_handle* h) {
+  group_use_set(h, 0);
+  for (int i = 1; i < 3; ++i) {
+    coper_handle::GroupSet& g = h->gset[i];
+    if (g.slab) (void)tracked_free(g.slab);
+    if (g.fused_fin_dev) (void)tracked_free(g.fused_fin_dev);
+    g = coper_handle::GroupSet();
+  }
+  h->gnext.ride = false; h->gdone.done = false;
+}
+
+// sets 1 and 2 at the capacity of the workspace (which exists: the caller is a pass being enqueued), with their finalize constants
+int group_sets_ensure(coper_handle* h, hipStream_t s) {
+  if (h->gset[1].slab && h->gset[2].slab) return COPER_OK;
+  const Dims& dm = h->dm;
+  if (!h->perm || !h->x3m || h->ws_queries <= 0) return fail(h, COPER_ESTATE, "grouping sets: no workspace yet");
+  const int cur = h->gcur;
+  group_use_set(h, 0);
+  const size_t cap = (size_t)h->ws_queries, r2 = (size_t)dm.R + 2, nt = 4 * (cap / 32 + (size_t)dm.R + 4);
+  auto up4 = [](size_t n) { return (n + 3) & ~(size_t)3; };      // (16-byte pieces)
+  const size_t total = 2 * up4(r2) + 4 * up4(cap) + up4(nt) + 4 + (size_t)X3M_SLOTS;
+  for (int i = 1; i < 3; ++i) {
+    coper_handle::GroupSet& g = h->gset[i];
+    if (g.slab) continue;
+    if (tracked_malloc(&g.slab, total * sizeof(int32_t)) != hipSuccess) { (void)hipGetLastError(); return fail(h, COPER_ENOMEM, "hipMalloc failed (grouping set)"); }
+    COPER_HIP_TRY(h, hipMemsetAsync(g.slab, 0, total * sizeof(int32_t), s));
+    int32_t* p = g.slab;
+    g.rel_count = p; p += up4(r2);
+    g.rel_offset = p; p += up4(r2);
+    g.perm = p; p += up4(cap);
+    g.inv_perm = p; p += up4(cap);
+    g.sorted_row = p; p += up4(cap);
+    g.sorted_rid = p; p += up4(cap);
+    g.tiles = p; p += up4(nt);
+    g.n_tiles = p; p += 4;
+    g.x3m = (float*)p;
+  }
+  int rc = fused_fin_update(h, s);
+  group_use_set(h, cur);
+  return rc;
+}
+
 static int ensure_workspace(coper_handle* h, int64_t B, int64_t nnz, hipStream_t s) {
   const Dims& dm = h->dm;
   if (nnz > h->ws_nnz) h->ws_nnz = nnz;
@@ -175,6 +235,7 @@ static int ensure_workspace(coper_handle* h, int64_t B, int64_t nnz, hipStream_t
   }
   if (B <= h->ws_queries && h->perm) return COPER_OK;
   COPER_HIP_TRY(h, hipStreamSynchronize(s));
+  group_sets_free(h);           // (sized by the workspace; back on the home set before its arrays move)
   int64_t cap = B < 64 ? 64 : B;
   int rc;
   const int KSPLIT_MAX = 8;
@@ -217,6 +278,7 @@ static int ensure_workspace(coper_handle* h, int64_t B, int64_t nnz, hipStream_t
   }
   h->ws_queries = cap;
   h->ws_ksplit = KSPLIT_MAX;
+  group_snapshot_home(h);
   return fused_fin_update(h, s);        // (perm moved)
 }
 
@@ -352,6 +414,7 @@ COPER_API void coper_destroy(coper_handle* h) {
   (void)hipSetDevice(h->cfg.device);
   (void)hipDeviceSynchronize();
   train_destroy(h);
+  group_sets_free(h);
   dev_free(&h->conv_scale); dev_free(&h->conv_shift); dev_free(&h->fc_scale); dev_free(&h->fc_shift);
   dev_free(&h->conv_w_rel); dev_free(&h->conv_b_rel); dev_free(&h->fc_b_rel); dev_free(&h->Wf);
   dev_free(&h->Ef); dev_free(&h->bias_pad); dev_free(&h->ctx_tmp[0]); dev_free(&h->ctx_tmp[1]);
@@ -464,6 +527,8 @@ COPER_API int coper_prepare(coper_handle* h, void* stream) {
     if (!h->params[sp.name].set) return fail(h, COPER_EMISSING, "coper_prepare: parameter '" + sp.name + "' was never set");
   COPER_HIP_TRY(h, hipSetDevice(cfg.device));
   int rc;
+  group_use_set(h, 0);          // (x3m of the home set is re-allocated below; a grouping done ahead does not survive a prepare)
+  h->gnext.ride = false; h->gdone.done = false;
   if ((rc = dev_alloc(h, &h->conv_scale, dm.C)) || (rc = dev_alloc(h, &h->conv_shift, dm.C)) ||
       (rc = dev_alloc(h, &h->fc_scale, dm.d)) || (rc = dev_alloc(h, &h->fc_shift, dm.d)))
     return rc;
@@ -482,6 +547,7 @@ COPER_API int coper_prepare(coper_handle* h, void* stream) {
       return rc;
     COPER_HIP_TRY(h, hipMemsetAsync(h->x3s, 0, 4 * sizeof(int32_t), s));
     COPER_HIP_TRY(h, hipMemsetAsync(h->x3m, 0, X3M_SLOTS * sizeof(float), s));
+    group_snapshot_home(h);
     if ((rc = launch_band_consts(h, P("ent_emb"), P("pred_bias"), s))) return rc;
     {
       unsigned cb[BAND_NCONST];
@@ -643,11 +709,26 @@ COPER_API int coper_post_i32_next(coper_handle* h, const int32_t* src, int64_t n
   return COPER_OK;
 }
 
+COPER_API int coper_group_next(coper_handle* h, const int64_t* e1, const int64_t* rel, int64_t B, int32_t have_e1_rows) {
+  if (!h) return COPER_EINVAL;
+  if (B < 0 || (B > 0 && (!rel || (!e1 && !have_e1_rows)))) return fail(h, COPER_EINVAL, "coper_group_next: bad argument");
+  h->gnext.e1 = have_e1_rows ? nullptr : e1; h->gnext.rel = rel; h->gnext.B = B; h->gnext.rows = have_e1_rows ? 1 : 0;
+  h->gnext.pending = B > 0;
+  h->gnext.ride = false;
+  return COPER_OK;
+}
+
 COPER_API int coper_gather_entities(coper_handle* h, const int64_t* ids, int64_t B, float* out, void* stream) {
   COPER_REQUIRE_PREPARED(h);
   if (B == 0) return COPER_OK;
   if (!ids || !out || B < 0) return fail(h, COPER_EINVAL, "coper_gather_entities: bad argument");
   return launch_gather_entities(h, ids, B, out, (hipStream_t)stream);
+}
+
+static bool stream_is_capturing(hipStream_t s) {
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); return true; }
+  return cap != hipStreamCaptureStatusNone;
 }
 
 // grouping, conv and the dense layer up to the K-slice partials in z_part (everything of coper_encode but the finalize)
@@ -679,7 +760,19 @@ static int encode_partials(coper_handle* h, const int64_t* e1, const int64_t* re
 #endif
   if (ksplit > h->ws_ksplit) ksplit = h->ws_ksplit;
   *ksplit_out = ksplit;
+  // coper_group_next: a pass whose batch was sorted in the shadow of the last one (into set gnext.set) skips its grouping launches
+  bool pre = false;
   {
+    auto& g = h->gdone;
+    if (g.done) {
+      pre = g.rel == rel && g.e1 == (e1_rows ? nullptr : e1) && g.B == B && g.rows == (e1_rows ? 1 : 0) && h->gset[g.set].slab != nullptr &&
+            !stream_is_capturing(s);
+      g.done = false;          // (consumed or dropped: it was the NEXT pass's)
+    }
+    group_use_set(h, pre ? g.set : 0);
+  }
+  h->post_here = false;
+  if (!pre) {
     ScopedKernelTimer t(h, "group", s);
     if ((rc = launch_group_by_relation(h, e1, rel, e1_rows != nullptr, B, tq, s))) return rc;
   }
@@ -689,6 +782,20 @@ static int encode_partials(coper_handle* h, const int64_t* e1, const int64_t* re
 #else
     const bool fused = dense_fused_supported(h, ksplit);
 #endif
+    if (fused && h->gnext.pending && !stream_is_capturing(s)) {
+      if ((rc = group_sets_ensure(h, s))) return rc;
+      h->gnext.ride = true;
+    } else if (!fused) {
+      h->gnext.pending = false;     // (only the fused launch has the role)
+    }
+    if (pre && h->post_n > 0) {       // the job that rides in the grouping launch otherwise
+      if (fused) h->post_here = true;
+      else {
+        const int64_t pn = h->post_n;
+        h->post_n = 0;
+        if ((rc = launch_copy_i32(h, h->post_src, pn, h->post_dst, s))) return rc;
+      }
+    }
     if (!fused && h->stage_n > 0) {     // (a pending coper_stage_ids_next rides in the fused launch only)
       const int64_t n = h->stage_n;
       h->stage_n = 0;
@@ -706,6 +813,7 @@ static int encode_partials(coper_handle* h, const int64_t* e1, const int64_t* re
     }
     return COPER_OK;
   }
+  h->gnext.pending = false;
   if (h->stage_n > 0) {
     const int64_t n = h->stage_n;
     h->stage_n = 0;

@@ -115,6 +115,27 @@ struct coper_handle {
   const int32_t* post_src = nullptr;    // coper_post_i32_next: int32 results to copy out beside the next grouping launch (post_n > 0: pending)
   int64_t post_n = 0;
   int32_t* post_dst = nullptr;
+  bool post_here = false;               //   the pass being enqueued was grouped ahead (coper_group_next): the fused encoder launch carries the job
+  // coper_group_next: grouping arrays in sets.  Set 0 is HOME (the arrays below: every pass that groups itself, and every captured
+  // graph, uses it); sets 1 and 2 are written by the grouping role of a fused encoder launch for the NEXT pass while the running
+  // pass reads its own.  The fields perm / inv_perm / ... / x3m / fused_fin_dev always name the set of the pass being enqueued.
+  struct GroupSet {
+    int32_t* slab = nullptr;         // sets 1, 2: one allocation; set 0: unused (a snapshot of the home pointers)
+    int32_t* rel_count = nullptr; int32_t* rel_offset = nullptr; int32_t* perm = nullptr; int32_t* inv_perm = nullptr;
+    int32_t* sorted_row = nullptr; int32_t* sorted_rid = nullptr; int32_t* tiles = nullptr; int32_t* n_tiles = nullptr;
+    float* x3m = nullptr; void* fused_fin_dev = nullptr; const int32_t* fused_fin_perm = nullptr;
+  } gset[3];
+  int gcur = 0;                      // the set the fields name now
+  struct {
+    const int64_t* e1 = nullptr; const int64_t* rel = nullptr; int64_t B = 0; int rows = 0;
+    bool pending = false;            // registered, not yet launched
+    bool ride = false;               // the next fused encoder launch carries it (sets 1, 2 are allocated)
+  } gnext;
+  struct {                           // a grouping launched ahead into set `set`: the pass with exactly these ids skips its own
+    const int64_t* e1 = nullptr; const int64_t* rel = nullptr; int64_t B = 0; int rows = 0;
+    bool done = false;
+    int set = 0;
+  } gdone;
   void* fused_fin_dev = nullptr;     // FusedFinConst (kernels_dense_fused_bf16.hip): the fused encoder's finalize constants, in device memory
   const int32_t* fused_fin_perm = nullptr;   //   the workspace generation they were written for
   int32_t* w_exp = nullptr;          // [Rw] e_W per relation: the dense-weight planes hold W_r 2^e_W (split16.h; prepare)
@@ -358,6 +379,11 @@ int launch_dense_fused_bf16(coper_handle* h, const int64_t* e1, const int64_t* r
                             int nslices, float* h_fin, hipStream_t s);
 bool dense_fused_finalizes(const coper_handle* h, int nslices, const float* h_out);
 int fused_fin_update(coper_handle* h, hipStream_t s);
+// grouping sets (coper_group_next; coper_abi.hip)
+void group_snapshot_home(coper_handle* h);          // after the home arrays were (re)allocated
+void group_use_set(coper_handle* h, int i);         // point the fields at set i
+void group_sets_free(coper_handle* h);              // sets 1, 2 (back to home first)
+int group_sets_ensure(coper_handle* h, hipStream_t s);
 int launch_dense_finalize(coper_handle* h, const int64_t* rel, int64_t B, int ksplit, float* h_out, hipStream_t s);
 int launch_dense_finalize_pack(coper_handle* h, int64_t B, int ksplit, float* h_out, int32_t* cnt, int32_t cnt_base,
                                int32_t* cnt_eq, hipStream_t s);

@@ -14,6 +14,15 @@
 // kernel that still serves the <= 32-query tiles: x, and with it h[b], stays a pure function of (e1, rel).
 #include "bf16x3_chain.h"
 #include "coper_internal.h"
+#ifdef COPER_DBG_GROUP_CLK
+#include <hip/hip_runtime.h>
+__device__ unsigned long long g_group_clk[8];
+extern "C" __attribute__((visibility("default"))) int coper_dbg_group_clock(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_group_clk), sizeof(unsigned long long) * 8) == hipSuccess ? 0 : 1;
+}
+#define GROUP_CLK(i) do { __syncthreads(); if (threadIdx.x == 0) g_group_clk[i] = wall_clock64(); } while (0)
+#endif
+#include "group_body.h"
 #include "conv_fold.h"
 
 namespace coper {
@@ -698,39 +707,109 @@ __global__ __launch_bounds__(512) void k_dense_fused_bf16x3(const uint4* __restr
                                                             FusedConvArgs A, const int32_t* __restrict__ tiles,
                                                             const int32_t* __restrict__ n_tiles, int64_t cap_small,
                                                             int nfb, int64_t ks32n, int nslices, int64_t Bcap,
-                                                            int d_pad16, float* __restrict__ z_part, int n_big_cap, FusedFin Fn,
-                                                            int n_tile_blocks, const int32_t* __restrict__ stage_src, int64_t stage_n,
-                                                            int64_t* __restrict__ stage_dst, int64_t ks32s) {
+                                                            int d_pad16, float* __restrict__ z_part, FusedFin Fn,
+                                                            int n_special, const int32_t* __restrict__ stage_src, int64_t stage_n,
+                                                            int64_t* __restrict__ stage_dst, int64_t ks32s, GroupJob J, int n_group,
+                                                            const int32_t* __restrict__ post_src, int64_t post_n, int32_t* __restrict__ post_dst,
+                                                            int n_big_cap_old) {
   extern __shared__ uint4 fused_lds[];
-  // Staging role (coper_stage_ids_next): the workgroups behind the tile lists bring the NEXT pass's int32 batch in from pinned
+  // Staging role (coper_stage_ids_next): workgroups in front of the tile lists bring the NEXT pass's int32 batch in from pinned
   // host memory (PCIe reads) and widen it to the int64 arrays the ABI takes, while the tiles stream their weights.  A pass has
   // fewer relation tiles than the chip has CUs at the BASELINE shapes (237 of 256), so these land on CUs that would idle.
-  if ((int)blockIdx.x >= n_tile_blocks) {
+  // Grouping role (coper_group_next): ONE workgroup in front of them sorts the NEXT pass's batch by relation into a set of grouping
+  // arrays this pass does not read (group_body.h) -- the two grouping launches of that pass, done in this launch's shadow.
+  // Posting role (coper_post_i32_next): when the pass that runs was grouped ahead it has no grouping launch to carry the LAST
+  // pass's ranks out; the staging workgroups copy them.
+  // The special workgroups come FIRST in the grid: the tile lists are sized for the worst case (B / 33 + R blocks, most of which
+  // find no tile and leave), and on a launch of one workgroup per CU the dispatcher works through those one CU slot at a time --
+  // behind them the staging workgroups started ~140 us into a 165 us launch (measured when the grouping role was added).
+  if ((int)blockIdx.x < n_special) {
     if (blockIdx.y | blockIdx.z) return;
-    const int64_t nb = (int64_t)gridDim.x - n_tile_blocks, b = (int64_t)blockIdx.x - n_tile_blocks;
+    const int n_copy = n_special - n_group;                            // staging workgroups first, the grouping workgroup behind them:
+    if ((int)blockIdx.x >= n_copy) {                                   // when it runs they have all been dispatched, so it may wait for them
+      GROUP_CLK(0);
+      if (J.wait_for > 0) {
+        if (threadIdx.x == 0) {
+          while (__hip_atomic_load(J.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < J.wait_for) __builtin_amdgcn_s_sleep(16);
+          __hip_atomic_store(J.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+      }
+      GROUP_CLK(1);
+      group_role_body<512>(J, (int*)fused_lds);
+      GROUP_CLK(5);
+      return;
+    }
+    const int64_t nb = n_copy, b = (int64_t)blockIdx.x;
+    if (post_n > 0) {
+      const bool pvec = ((((uintptr_t)post_src) | ((uintptr_t)post_dst)) & 15) == 0;
+      const int64_t p4 = pvec ? post_n / 4 : 0;
+      for (int64_t i = b * 512 + threadIdx.x; i < p4; i += nb * 512) ((int4*)post_dst)[i] = ((const int4*)post_src)[i];
+      for (int64_t i = 4 * p4 + b * 512 + threadIdx.x; i < post_n; i += nb * 512) post_dst[i] = post_src[i];
+    }
     const bool vec = ((((uintptr_t)stage_src) | ((uintptr_t)stage_dst)) & 15) == 0;
     const int64_t n4 = vec ? stage_n / 4 : 0;
-    for (int64_t i = b * 512 + threadIdx.x; i < n4; i += nb * 512) {
+    auto copy4 = [&](int64_t lo, int64_t hi) {
+      for (int64_t i = lo + b * 512 + threadIdx.x; i < hi; i += nb * 512) {
+        const int4 v = ((const int4*)stage_src)[i];
+        longlong2* o = (longlong2*)(stage_dst + 4 * i);
+        o[0] = make_longlong2(v.x, v.y);
+        o[1] = make_longlong2(v.z, v.w);
+      }
+    };
+    // The grouping workgroup reads the FRONT of what this job stages (the id arrays it sorts): that part first, with stores and (on
+    // its side) loads that are coherent across the XCDs' L2s by themselves, then the signal.  (Release / acquire FENCES at agent
+    // scope write back and invalidate whole L2s: 128 waves of them stretched this launch from 165 to 240 us.)
+    const bool sig = n_group && J.wait_for > 0;
+    int64_t f4 = sig ? (J.front + 3) / 4 : 0;
+    if (f4 > n4 || f4 * 4 < J.front) f4 = 0;      // (an unaligned job: element by element below)
+    for (int64_t i = b * 512 + threadIdx.x; i < f4; i += nb * 512) {
       const int4 v = ((const int4*)stage_src)[i];
-      longlong2* o = (longlong2*)(stage_dst + 4 * i);
-      o[0] = make_longlong2(v.x, v.y);
-      o[1] = make_longlong2(v.z, v.w);
+      int64_t* o = stage_dst + 4 * i;
+      __hip_atomic_store(o + 0, (int64_t)v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(o + 1, (int64_t)v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(o + 2, (int64_t)v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(o + 3, (int64_t)v.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if (sig && f4 == 0)
+      for (int64_t i = b * 512 + threadIdx.x; i < J.front; i += nb * 512)
+        __hip_atomic_store(stage_dst + i, (int64_t)stage_src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (sig) {
+      __syncthreads();                              // (every wave's stores have been acknowledged)
+      if (threadIdx.x == 0) __hip_atomic_fetch_add(J.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    copy4(f4, n4);
     for (int64_t i = 4 * n4 + b * 512 + threadIdx.x; i < stage_n; i += nb * 512) stage_dst[i] = stage_src[i];
     return;
   }
-  // blockIdx.x < n_big_cap: the list of 33..128-query tiles; above it: the list of <= 32-query tiles (one per
-  // relation key at most) -- every tile of the batch is served by this one launch
-  int tile = blockIdx.x;
+  // One index over both tile lists, the real tiles FIRST and contiguous: the 33..128-query tiles (n_tiles[1] of them), then the
+  // <= 32-query tiles (n_tiles[0]); the grid holds B / 128 + min(R, B) + 1 blocks per slice -- an upper bound of their sum (a
+  // relation with c queries has at most c / 128 + 1 tiles) -- and the blocks beyond leave.  (Until round 5 each list had its own
+  // worst-case range, B / 33 + 1 and R: at plain ConvE 461 empty blocks stood between the 160 tiles of one K slice and those of
+  // the next, each needing a whole free CU for its LDS before the dispatcher could move on.)
+  int tile = (int)blockIdx.x - n_special;
   const int32_t* tl;
-  if (tile < n_big_cap) {
+#ifdef COPER_FUSED_OLD_GRID      // (A/B: each list in its own worst-case range)
+  if (tile < n_big_cap_old) {
     if (tile >= n_tiles[1]) return;
     tl = tiles + 4 * (cap_small + tile);
   } else {
-    tile -= n_big_cap;
+    tile -= n_big_cap_old;
     if (tile >= n_tiles[0]) return;
     tl = tiles + 4 * (int64_t)tile;
   }
+#else
+  {
+    const int nbig = n_tiles[1];
+    if (tile < nbig) {
+      tl = tiles + 4 * (cap_small + tile);
+    } else {
+      tile -= nbig;
+      if (tile >= n_tiles[0]) return;
+      tl = tiles + 4 * (int64_t)tile;
+    }
+  }
+#endif
 #ifdef COPER_DBG_FUSED_EXIT
   return;
 #endif
@@ -827,8 +906,6 @@ static void dense_fused_launch(coper_handle* h, const int64_t* e1, const int64_t
   FusedFin Fn;
   Fn.h_out = h_fin; Fn.c = (const FusedFinConst*)h->fused_fin_dev;
   int64_t cap_small = (dm.gen_fc ? dm.R : 1) + 1;
-  int64_t n_big_max = B / 33 + 1;
-  int64_t n_small_max = cap_small - 1 < B ? cap_small - 1 : B;
   FusedConvArgs A;
   A.e1_rows = e1_rows; A.sorted_row = h->sorted_row; A.sorted_rid = h->sorted_rid;
   A.ent = h->params["ent_emb"].ptr;
@@ -847,34 +924,83 @@ static void dense_fused_launch(coper_handle* h, const int64_t* e1, const int64_t
     attr_done |= bit;
   }
   // a pending staging job (coper_stage_ids_next) rides in this launch: FUSED_STAGE_WGS more workgroups
-  const int n_tile_blocks = (int)(n_big_max + n_small_max);
+#ifdef COPER_FUSED_OLD_GRID
+  const int n_big_cap_old = (int)(B / 33 + 1);
+  const int n_tile_blocks = n_big_cap_old + (int)(cap_small - 1 < B ? cap_small - 1 : B);
+#else
+  const int n_big_cap_old = 0;
+  const int n_tile_blocks = (int)(B / 128 + (cap_small - 1 < B ? cap_small - 1 : B) + 1);     // (an upper bound of the two tile lists together: see the kernel)
+#endif
   // (a pass being captured into a hipGraph leaves a pending staging job to the next eager call, as coper_post_i32_next does: a
   // replay would repeat the PCIe read with the pointers recorded at capture time and overwrite whatever staging buffer they name)
-  bool stage_now = h->stage_n > 0;
-  if (stage_now) {
+  bool capturing = false;
+  if (h->stage_n > 0 || h->post_n > 0 || h->gnext.ride) {
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); stage_now = false; }
-    else if (cap != hipStreamCaptureStatusNone) stage_now = false;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); capturing = true; }
+    else capturing = cap != hipStreamCaptureStatusNone;
   }
-  const int n_stage = stage_now ? FUSED_STAGE_WGS : 0;
-  hipLaunchKernelGGL((k_dense_fused_bf16x3<NFB, WNT>), dim3((unsigned)(n_tile_blocks + n_stage), (unsigned)nslices, (unsigned)zgroups), dim3(512),
+  const bool stage_now = h->stage_n > 0 && !capturing;
+  // a pass that was grouped ahead has no grouping launch for a pending coper_post_i32_next to ride in: the staging workgroups take it
+  bool post_now = h->post_n > 0 && h->post_here && !capturing;
+  h->post_here = false;
+  // coper_group_next: one more workgroup sorts the next pass's batch into the set this pass does not use
+  GroupJob J = {};
+  int n_group = 0;
+  if (h->gnext.ride && !capturing) {
+    const int64_t R = dm.gen_fc ? dm.R : 1;
+    const int t = h->gcur == 1 ? 2 : 1;
+    const coper_handle::GroupSet& g = h->gset[t];
+    if (g.slab && h->gnext.B <= h->ws_queries && group_role_lds_ints(R, 512) * sizeof(int) <= lds) {
+      J.B = h->gnext.B; J.R = R; J.R_all = dm.R; J.shard_lo = h->cfg.shard_lo; J.n_local = dm.n_local; J.cap_small = cap_small;
+      J.count = g.rel_count; J.offset = g.rel_offset; J.tiles = g.tiles; J.n_tiles = g.n_tiles; J.perm = g.perm;
+      J.sorted_row = g.sorted_row; J.sorted_rid = g.sorted_rid; J.inv_perm = g.inv_perm; J.x3m = g.x3m; J.x3m_slots = X3M_SLOTS;
+      J.use_rel = dm.gen_fc ? 1 : 0; J.have_e1_rows = h->gnext.rows;
+      // ids inside the batch this launch stages: the grouping workgroup waits for the staging workgroups (a ticket), then reads
+      // the device arrays like any other (one workgroup reading pinned host memory itself manages 0.65 GB/s: measured, 370 us)
+      auto in_stage = [&](const int64_t* p) { return stage_now && p && p + J.B > h->stage_dst && p < h->stage_dst + h->stage_n; };
+      J.rel64 = h->gnext.rel; J.e1_64 = h->gnext.e1;
+      J.ticket = h->group_done + 1;
+      J.wait_for = (in_stage(h->gnext.rel) || in_stage(h->gnext.e1)) ? FUSED_STAGE_WGS : 0;
+      J.front = 0;
+      if (in_stage(h->gnext.rel)) J.front = (h->gnext.rel + J.B) - h->stage_dst;
+      if (in_stage(h->gnext.e1) && (h->gnext.e1 + J.B) - h->stage_dst > J.front) J.front = (h->gnext.e1 + J.B) - h->stage_dst;
+      if (J.front > h->stage_n) J.front = h->stage_n;
+      n_group = 1;
+      h->gdone.e1 = h->gnext.e1; h->gdone.rel = h->gnext.rel; h->gdone.B = h->gnext.B; h->gdone.rows = h->gnext.rows;
+      h->gdone.done = true; h->gdone.set = t;
+    }
+  }
+  h->gnext.ride = false; h->gnext.pending = false;
+  const int n_stage = (stage_now || post_now) ? FUSED_STAGE_WGS : 0;
+  hipLaunchKernelGGL((k_dense_fused_bf16x3<NFB, WNT>), dim3((unsigned)(n_tile_blocks + n_group + n_stage), (unsigned)nslices, (unsigned)zgroups), dim3(512),
                      lds, s, (const uint4*)h->Wf16_hi, (const fused_wlo_t*)(FUSED_LO8 ? h->Wf8_lo : h->Wf16_lo), A, h->tiles, h->n_tiles, cap_small, dm.nfb,
-                     dm.F_pad / 32, nslices, h->ws_queries, dm.d_pad16, h->z_part, (int)n_big_max, Fn, n_tile_blocks, h->stage_src,
-                     stage_now ? h->stage_n : 0, h->stage_dst, w16_ks_stride(dm));
+                     dm.F_pad / 32, nslices, h->ws_queries, dm.d_pad16, h->z_part, Fn, n_group + n_stage, h->stage_src,
+                     stage_now ? h->stage_n : 0, h->stage_dst, w16_ks_stride(dm), J, n_group, h->post_src, post_now ? h->post_n : 0, h->post_dst, n_big_cap_old);
   if (stage_now) h->stage_n = 0;
+  if (post_now) h->post_n = 0;
 }
 
 // the constant part of FusedFin, (re)written when the workspace or the parameters move (ensure_workspace / prepare)
 int fused_fin_update(coper_handle* h, hipStream_t s) {
   const Dims& dm = h->dm;
   if (!h->enc_bf16 || !h->x3m || !h->perm) return COPER_OK;
-  FusedFinConst c;
-  c.perm = h->perm; c.fc_b = dm.gen_fc ? h->fc_b_rel : h->params["fc_bias"].ptr; c.scale = h->fc_scale; c.shift = h->fc_shift;
-  c.w_exp = h->w_exp; c.x3m = h->x3m; c.per_rel_bias = dm.gen_fc ? 1 : 0; c.x_exp = h->x_exp; c.d = dm.d; c.pad = 0;
-  if (!h->fused_fin_dev && tracked_malloc(&h->fused_fin_dev, sizeof c) != hipSuccess) return fail(h, COPER_ENOMEM, "hipMalloc failed (fused finalize constants)");
-  COPER_HIP_TRY(h, hipMemcpyAsync(h->fused_fin_dev, &c, sizeof c, hipMemcpyHostToDevice, s));
-  COPER_HIP_TRY(h, hipStreamSynchronize(s));      // (c is on the stack)
-  h->fused_fin_perm = h->perm;
+  const int cur = h->gcur;
+  group_use_set(h, 0);
+  // one block of constants per set of grouping arrays (coper_group_next): perm and x3m are the set's
+  for (int i = 0; i < 3; ++i) {
+    coper_handle::GroupSet& g = h->gset[i];
+    if (i > 0 && !g.slab) continue;
+    FusedFinConst c;
+    c.perm = i ? g.perm : h->perm; c.fc_b = dm.gen_fc ? h->fc_b_rel : h->params["fc_bias"].ptr; c.scale = h->fc_scale; c.shift = h->fc_shift;
+    c.w_exp = h->w_exp; c.x3m = i ? g.x3m : h->x3m; c.per_rel_bias = dm.gen_fc ? 1 : 0; c.x_exp = h->x_exp; c.d = dm.d; c.pad = 0;
+    void** dev = i ? &g.fused_fin_dev : &h->fused_fin_dev;
+    if (!*dev && tracked_malloc(dev, sizeof c) != hipSuccess) return fail(h, COPER_ENOMEM, "hipMalloc failed (fused finalize constants)");
+    COPER_HIP_TRY(h, hipMemcpyAsync(*dev, &c, sizeof c, hipMemcpyHostToDevice, s));
+    COPER_HIP_TRY(h, hipStreamSynchronize(s));      // (c is on the stack)
+    if (i) g.fused_fin_perm = g.perm; else h->fused_fin_perm = h->perm;
+  }
+  group_snapshot_home(h);
+  group_use_set(h, cur);
   return COPER_OK;
 }
 

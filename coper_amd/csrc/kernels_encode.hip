@@ -13,6 +13,7 @@
 //   finalize           sum K-splits in fixed order + fc bias (:410/:412) -> FCBN folded (:416-418)
 //                      -> ReLU (:419) -> h[perm[pos], d].
 #include "coper_internal.h"
+#include "group_body.h"
 
 namespace coper {
 
@@ -45,92 +46,6 @@ __global__ __launch_bounds__(HIST_BLOCK) void k_rel_hist(const int64_t* __restri
     __syncthreads();
     for (int k = threadIdx.x; k < R; k += HIST_BLOCK)
       if (sh[k]) atomicAdd(&count[k], sh[k]);
-  }
-}
-
-// single block: exclusive scan of the counts -> offsets, and the two tile lists:
-//   small tiles: one per relation group with 1..32 queries          (k_dense_small_f32)
-//   big tiles:   groups with > 32 queries cut into ceil(c/128) balanced tiles of <= 128 (k_dense_big_f32),
-//                emitted largest-first (by 16-query block count) so the hardware dispatcher, which hands
-//                out workgroups in index order, ends the launch on the cheapest tiles.
-// tiles[] = small list at [0, 4*cap_small), big list after it; n_tiles[0] = #small, n_tiles[1] = #big.
-__device__ __forceinline__ void rel_scan_tiles_body(const int32_t* count, int64_t R, int64_t cap_small,
-                                                    int32_t* offset, int32_t* __restrict__ tiles,
-                                                    int32_t* __restrict__ n_tiles) {
-  __shared__ int s_cnt[1024];
-  __shared__ int s_sml[1024];
-  __shared__ int carry_cnt, carry_sml;
-  __shared__ int cls_count[9], cls_base[9], cls_cursor[9];
-  if (threadIdx.x == 0) { carry_cnt = 0; carry_sml = 0; }
-  if (threadIdx.x < 9) { cls_count[threadIdx.x] = 0; cls_cursor[threadIdx.x] = 0; }
-  __syncthreads();
-  int32_t* tiles_big = tiles + 4 * cap_small;
-  // pass 1: offsets, small tiles, and the number of big tiles per size class
-  for (int64_t base = 0; base < R; base += 1024) {
-    int64_t rid = base + threadIdx.x;
-    int c = rid < R ? count[rid] : 0;
-    int ns = (c > 0 && c <= 32) ? 1 : 0;
-    // inclusive scan of (c, ns) over the 1024 threads: shuffles inside a wave, the 16 wave totals through LDS
-    // (two barriers; a Hillis-Steele scan over LDS took twenty)
-    {
-      int ic = c, is = ns;
-      const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const int a = __shfl_up(ic, off), b2 = __shfl_up(is, off);
-        if (lane >= off) { ic += a; is += b2; }
-      }
-      if (lane == 63) { s_cnt[wv] = ic; s_sml[wv] = is; }
-      __syncthreads();
-      int pc = 0, ps = 0;
-      for (int w2 = 0; w2 < wv; ++w2) { pc += s_cnt[w2]; ps += s_sml[w2]; }
-      __syncthreads();
-      s_cnt[threadIdx.x] = ic + pc;
-      s_sml[threadIdx.x] = is + ps;
-      __syncthreads();
-    }
-    int excl_c = carry_cnt + s_cnt[threadIdx.x] - c;
-    int excl_s = carry_sml + s_sml[threadIdx.x] - ns;
-    if (rid < R) {
-      offset[rid] = excl_c;
-      if (ns) {
-        int32_t* t = tiles + 4 * (int64_t)excl_s;
-        t[0] = (int32_t)rid; t[1] = excl_c; t[2] = c; t[3] = 0;
-      }
-      if (c > 32) {
-        int nb = (c + 127) / 128, bsz = c / nb, rem = c % nb;
-        if (rem) atomicAdd(&cls_count[(bsz + 1 + 15) >> 4], rem);
-        atomicAdd(&cls_count[(bsz + 15) >> 4], nb - rem);
-      }
-    }
-    __syncthreads();
-    if (threadIdx.x == 1023) { carry_cnt += s_cnt[1023]; carry_sml += s_sml[1023]; }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    int run = 0;
-    for (int k = 8; k >= 0; --k) { cls_base[k] = run; run += cls_count[k]; }
-    offset[R] = carry_cnt;
-    n_tiles[0] = carry_sml;
-    n_tiles[1] = run;
-  }
-  __syncthreads();
-  // pass 2: place the big tiles, class by class (order inside a class is irrelevant to the results)
-  for (int64_t rid = threadIdx.x; rid < R; rid += 1024) {
-    int c = count[rid];
-    if (c <= 32) continue;
-    int nb = (c + 127) / 128, bsz = c / nb, rem = c % nb;
-    int off = offset[rid];
-    for (int j = 0; j < nb; ++j) {
-      int sz = bsz + (j < rem ? 1 : 0);
-      int k = (sz + 15) >> 4;
-      int slot = cls_base[k] + atomicAdd(&cls_cursor[k], 1);
-      int32_t* t = tiles_big + 4 * (int64_t)slot;
-      t[0] = (int32_t)rid;
-      t[1] = off + j * bsz + (j < rem ? j : rem);
-      t[2] = sz;
-      t[3] = nb > 1 ? 1 : 0;   // the relation has several tiles: its weights are worth caching (k_dense_fused_bf16x3)
-    }
   }
 }
 

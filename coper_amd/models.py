@@ -249,6 +249,17 @@ class ConvE(object):
         self._stage_keep = (src, out)      # (the job is carried out later: keep both alive)
         _lib.check(self._h, self._lib.coper_stage_ids_next(self._h, C.c_void_p(src.data_ptr()), src.numel(), _ptr(out)))
 
+    def group_next(self, e1: Optional[torch.Tensor], rel: torch.Tensor, e1_rows: bool = False):
+        """coper_group_next: `e1` / `rel` (int64, device -- typically views of the staging array a `stage_next` job fills) are the id
+        arrays of the pass AFTER the next one; that batch is sorted by relation by one more workgroup of the next pass's encoder
+        launch, and the pass that then comes with exactly these tensors starts with its encoder.  Results never depend on it."""
+        if rel is None or rel.dtype != torch.int64 or not rel.is_contiguous() or rel.device != self.device:
+            raise ValueError("group_next: rel must be a contiguous int64 tensor on %s" % self.device)
+        if not e1_rows and (e1 is None or e1.dtype != torch.int64 or not e1.is_contiguous() or e1.device != self.device or e1.numel() != rel.numel()):
+            raise ValueError("group_next: e1 must be a contiguous int64 tensor of rel's size on %s" % self.device)
+        self._group_keep = (e1, rel)
+        _lib.check(self._h, self._lib.coper_group_next(self._h, None if e1_rows else _ptr(e1), _ptr(rel), rel.numel(), 1 if e1_rows else 0))
+
     def stage_batch(self, *arrays):
         """Host (NumPy) id arrays of one batch -> int64 tensors on the device through ONE pinned int32 buffer and one launch of
         coper_widen_ids (instead of one pageable H2D copy per array).  Arrays whose ids do not fit int32, and tensors, take

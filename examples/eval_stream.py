@@ -4,7 +4,8 @@
 Every pass scores one batch of (e1, rel, e2, known answers) queries against all entities (what `ranking_and_hits` does per
 `session.run`, `CoPER_ConvE/qa_cpg/metrics.py:38-57`).  The host keeps each batch as int32 in ONE pinned buffer; while pass n
 runs, extra workgroups of its encoder launch read pass n + 1's batch over PCIe (`ConvE.stage_next` = `coper_stage_ids_next`),
-and pass n's ranks leave for pinned host memory beside pass n + 1's first launch (`ConvE.post_next` = `coper_post_i32_next`).
+one more sorts it by relation (`ConvE.group_next` = `coper_group_next`: pass n + 1 starts with its encoder launch), and pass n's
+ranks leave for pinned host memory beside pass n + 1's first launch (`ConvE.post_next` = `coper_post_i32_next`).
 One stream, no copy engine, no launch that only moves data -- except in front of the first pass and behind the last one.
 
     python examples/eval_stream.py [--workload fb15k237_cpg] [--batches 6] [--queries 20480]"""
@@ -67,6 +68,7 @@ def main(argv=None):
         c = n & 1
         if n + 1 < args.batches:
             model.stage_next(packed[n + 1][0], stages[1 - c])          # batch n + 1: read beside this pass's encoder launch
+            model.group_next(views[1 - c]["e1"], views[1 - c]["rel"])  # ... and sorted by relation there: pass n + 1 starts with its encoder
         v = views[c]
         nnz = len(batches[n]["filt_idx"])
         r, _ = model.rank_pass(v["e1"], v["rel"], v["e2"], v["filt_indptr"], v["filt_idx"][:nnz], filt_nnz=nnz, want_equal=False,

@@ -189,6 +189,19 @@ COPER_API int coper_copy_out_i32(coper_handle* h, const int32_t* src, int64_t n,
  * a hipGraph leaves the job to the next eager one.  Nothing is queued by this call. */
 COPER_API int coper_post_i32_next(coper_handle* h, const int32_t* src, int64_t n, int32_t* dst);
 
+/* The NEXT pass's grouping, overlapped.  Every pass starts by sorting its batch by relation (the reference instead materialises
+ * per-query weights, models.py:350,412): two small launches that nothing else can overlap, 18 us of a 487 us pass at the BASELINE
+ * shapes.  This call registers the id arrays of the pass that will FOLLOW the next one enqueued on this handle -- device addresses
+ * (e1 / rel of that later coper_encode / coper_encode_rank call; have_e1_rows != 0: it will pass e1_rows, e1 is ignored), whose
+ * contents are either there already or are what a coper_stage_ids_next job registered for the same launch will write there.  One
+ * more workgroup of the next fused encoder launch then sorts that batch into a second set of grouping arrays while the relation
+ * tiles stream their weights; the following call with exactly these pointers and B (and ids unchanged in between) finds its
+ * grouping done and starts with its encoder launch (a pending coper_post_i32_next job rides there instead).  Any other call in
+ * between, a coper_prepare, a growing workspace or a pass captured into a hipGraph drops the prepared grouping: the pass then groups
+ * itself as always -- results never depend on it.  Configurations the fused encoder does not serve ignore the registration.
+ * Nothing is queued by this call; B == 0 cancels.  (h[b] is a function of (e1[b], rel[b]) alone either way.) */
+COPER_API int coper_group_next(coper_handle* h, const int64_t* e1, const int64_t* rel, int64_t B, int32_t have_e1_rows);
+
 /* Row gather tf.nn.embedding_lookup(ent_emb, ids) (models.py:176) restricted to the shard:
  * out[b,:] = ent_emb[ids[b]] if shard_lo <= ids[b] < shard_hi else 0.  (Multi-GPU: sum over
  * ranks = the full gather.)  out: [B, d]. */

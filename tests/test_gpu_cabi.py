@@ -283,6 +283,86 @@ def test_stage_ids_next_brings_the_next_batch_in_beside_the_encoder(workload):
     m.close()
 
 
+@pytest.mark.parametrize("workload,Q", [("fb15k237_cpg", 6000), ("fb15k237_cpg", 700), ("fb15k237_plain", 3000), ("wn18rr_cpg", 900)])
+def test_group_next_sorts_the_next_batch_beside_the_encoder(workload, Q):
+    """coper_group_next: a stream of DIFFERENT batches, each staged (coper_stage_ids_next) and sorted by relation (coper_group_next)
+    inside the previous pass's encoder launch, its ranks posted (coper_post_i32_next) in the next one's: every pass returns the ranks
+    a plain pass returns, only the first pass groups itself, and whatever breaks the chain (another batch in between, a withdrawn
+    registration, device-resident ids without a staging job, out-of-range ids) falls back or clamps exactly like the plain path."""
+    from coper_amd.models import ConvE
+    md = cdata.model_descriptors(workload, num_ent=4000)
+    p = cdata.synthetic_params(md, 5)
+    m = ConvE(md, device="cuda:0", score_mode="bf16x3").load_parameters(p).prepare()
+    keys = ("e1", "rel", "e2", "filt_indptr", "filt_idx")
+    qs = [cdata.synthetic_queries(md, Q, seed=40 + i) for i in range(5)]
+    base = [_encode_rank(m, q["e1"], q["rel"], q["e2"], q["filt_indptr"], q["filt_idx"], False) for q in qs]
+    pins, views = [], []
+    width = max(sum(int(np.asarray(q[k]).size) for k in keys) for q in qs)
+    stages = [torch.empty(width, dtype=torch.int64, device="cuda:0") for _ in range(2)]
+    for q in qs:
+        sizes = [int(np.asarray(q[k]).size) for k in keys]
+        offs = np.concatenate([[0], np.cumsum(sizes)])
+        pin = torch.empty(int(offs[-1]), dtype=torch.int32).pin_memory()
+        for k, o, n in zip(keys, offs, sizes):
+            pin[o:o + n].copy_(torch.as_tensor(np.asarray(q[k]).astype(np.int32)))
+        pins.append(pin)
+        views.append([{k: st[o:o + n] for k, o, n in zip(keys, offs, sizes)} for st in stages])
+    ranks = [torch.empty(Q, dtype=torch.int32, device="cuda:0") for _ in range(2)]
+    hosts = [torch.full((Q,), -1, dtype=torch.int32).pin_memory() for _ in qs]
+    m.profile(True)
+    m.profile_read("group")
+    m.widen_ids(pins[0], out=stages[0][:pins[0].numel()])
+    for i in range(len(qs)):
+        c = i & 1
+        if i + 1 < len(qs):
+            m.stage_next(pins[i + 1], stages[1 - c][:pins[i + 1].numel()])
+            m.group_next(views[i + 1][1 - c]["e1"], views[i + 1][1 - c]["rel"])
+        v = views[i][c]
+        r, _ = m.rank_pass(v["e1"], v["rel"], v["e2"], v["filt_indptr"], v["filt_idx"], want_equal=False, out=ranks[c])
+        m.post_next(r, hosts[i])
+    m.post_flush()
+    torch.cuda.synchronize()
+    for i in range(len(qs)):
+        assert np.array_equal(hosts[i].numpy(), base[i]), i
+    _, launches = m.profile_read("group")
+    assert launches == 1, launches                       # only the first pass sorted its own batch
+    # ids that are already on the device (no staging job): the role reads the int64 arrays
+    v0, v1 = views[0][0], views[1][1]
+    m.widen_ids(pins[0], out=stages[0][:pins[0].numel()]); m.widen_ids(pins[1], out=stages[1][:pins[1].numel()])
+    m.group_next(v1["e1"], v1["rel"])
+    r0, _ = m.rank_pass(v0["e1"], v0["rel"], v0["e2"], v0["filt_indptr"], v0["filt_idx"], want_equal=False)
+    r1, _ = m.rank_pass(v1["e1"], v1["rel"], v1["e2"], v1["filt_indptr"], v1["filt_idx"], want_equal=False)
+    assert np.array_equal(r0.cpu().numpy(), base[0]) and np.array_equal(r1.cpu().numpy(), base[1])
+    assert m.profile_read("group")[1] == 1
+    # a different batch in between drops the prepared grouping; a withdrawn registration prepares nothing
+    m.group_next(v1["e1"], v1["rel"])
+    r0, _ = m.rank_pass(v0["e1"], v0["rel"], v0["e2"], v0["filt_indptr"], v0["filt_idx"], want_equal=False)
+    r0b, _ = m.rank_pass(v0["e1"], v0["rel"], v0["e2"], v0["filt_indptr"], v0["filt_idx"], want_equal=False)
+    r1, _ = m.rank_pass(v1["e1"], v1["rel"], v1["e2"], v1["filt_indptr"], v1["filt_idx"], want_equal=False)
+    assert np.array_equal(r0b.cpu().numpy(), base[0]) and np.array_equal(r1.cpu().numpy(), base[1])
+    assert m.profile_read("group")[1] == 3
+    m.group_next(v1["e1"], v1["rel"])
+    assert m._lib.coper_group_next(m._h, None, None, 0, 0) == 0
+    r0, _ = m.rank_pass(v0["e1"], v0["rel"], v0["e2"], v0["filt_indptr"], v0["filt_idx"], want_equal=False)
+    r1, _ = m.rank_pass(v1["e1"], v1["rel"], v1["e2"], v1["filt_indptr"], v1["filt_idx"], want_equal=False)
+    assert np.array_equal(r1.cpu().numpy(), base[1]) and m.profile_read("group")[1] == 2
+    # out-of-range relation / entity ids: clamped and counted like the grouping kernels do (coper_check_ids)
+    bad = {k: t.clone() for k, t in v1.items()}
+    bad["rel"][3] = md["num_rel"] * 2 + 7 if "num_rel" in md else 10 ** 6
+    bad["rel"][5] = -4
+    ref, _ = m.rank_pass(bad["e1"], bad["rel"], bad["e2"], bad["filt_indptr"], bad["filt_idx"], want_equal=False)
+    ref = ref.cpu().numpy()
+    n_ref = m.check_ids() if hasattr(m, "check_ids") else None
+    m.group_next(bad["e1"], bad["rel"])
+    m.rank_pass(v0["e1"], v0["rel"], v0["e2"], v0["filt_indptr"], v0["filt_idx"], want_equal=False)
+    got, _ = m.rank_pass(bad["e1"], bad["rel"], bad["e2"], bad["filt_indptr"], bad["filt_idx"], want_equal=False)
+    assert np.array_equal(got.cpu().numpy(), ref)
+    if n_ref is not None:
+        assert m.check_ids() == n_ref
+    assert m._lib.coper_group_next(m._h, None, None, 5, 0) == 1
+    m.close()
+
+
 @pytest.mark.parametrize("Q", [6000, 700])      # the two-launch grouping (the job rides in its first launch) / the single-workgroup one (a launch of its own)
 def test_post_i32_next_copies_the_last_ranks_beside_the_next_grouping(Q):
     """coper_post_i32_next: the ranks of pass n, registered after it was queued, reach pinned host memory during pass n + 1 -- not

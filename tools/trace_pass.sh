@@ -2,15 +2,17 @@
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 rm -rf $R/gpurun_out/trace_pass
-rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/trace_pass -- python3 $R/bench.py --no-cpu-baseline --no-scale --no-extras --steps 20 --warmup 3 > $R/gpurun_out/trace_pass.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/trace_pass -- python3 $R/bench.py --no-cpu-baseline --no-scale --no-extras --steps 20 --warmup 3 $TRACE_ARGS > $R/gpurun_out/trace_pass.log 2>&1
 cd $R
 f=$(find gpurun_out/trace_pass -name "*kernel_trace.csv" | head -1); python3 - "$f" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-# passes start with the grouping kernel; take the last complete one
-idx = [i for i, r in enumerate(rows) if "k_rel_hist_scan" in r["Kernel_Name"]]
-a, b = idx[-2], idx[-1]
+# passes start with the grouping kernel -- or, grouped ahead (coper_group_next), with the encoder; take the last complete one
+tail = rows[-60:]
+first = "k_rel_hist_scan" if sum("k_rel_hist_scan" in r["Kernel_Name"] for r in tail) >= 3 else "k_dense_fused"
+idx = [i for i, r in enumerate(rows) if first in r["Kernel_Name"]]
+a, b = idx[-3], idx[-2]
 t0 = int(rows[a]["Start_Timestamp"])
 print("one pass of bench.py (FB15k-237-shaped, 20,480 queries), start offsets and durations in us:")
 for r in rows[a:b]:
