@@ -73,6 +73,9 @@ PROTOTYPES = {
     "coper_set_x3_ent_absmax": (C.c_int, [_P, C.c_float]),
     "coper_band_audit": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_float), C.POINTER(_I64), _P]),
     "coper_band_audit_post": (C.c_int, [_P, C.c_int32, _P, _P]),
+    "coper_post_ranks_audit": (C.c_int, [_P, _P, _I64, _P, C.c_int32, _P]),
+    "coper_pack_ids_i32": (C.c_int, [_P, _I64, _P, _P, _I64, _P]),
+    "coper_hits_means": (C.c_int, [_P, _I64, _P, C.c_int32, _P, _P, _P]),
     "coper_band_policy": (C.c_int, [_P, C.c_float, _I64, C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
     "coper_prepare": (C.c_int, [_P, _P]),
     "coper_reserve": (C.c_int, [_P, _I64, _I64, _P]),

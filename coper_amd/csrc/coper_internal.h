@@ -253,6 +253,7 @@ int launch_conv(coper_handle* h, const int64_t* e1, const int64_t* rel, const fl
                 hipStream_t s);
 int launch_dense(coper_handle* h, const int64_t* rel, int64_t B, int tq, int ksplit, float* h_out, hipStream_t s);
 int launch_copy_i32(coper_handle* h, const int32_t* src, int64_t n, int32_t* dst, hipStream_t s);
+int launch_copy_i32_audit(coper_handle* h, const int32_t* src, int64_t n, int32_t* dst, unsigned* audit, int reset, hipStream_t s);
 int launch_widen_ids(coper_handle* h, const int32_t* src, int64_t n, int64_t* dst, hipStream_t s);
 int launch_gather_entities(coper_handle* h, const int64_t* ids, int64_t B, float* out, hipStream_t s);
 

@@ -919,6 +919,32 @@ __global__ __launch_bounds__(256) void k_copy_i32(const int32_t* __restrict__ sr
   }
 }
 
+// the ranks of a pass AND the two words of its band audit (behind them in dst), the audit reset for the next pass: one launch for
+// what coper_copy_out_i32 + coper_band_audit_post do in two launches and a memset (coper_post_ranks_audit)
+__global__ __launch_bounds__(256) void k_copy_i32_audit(const int32_t* __restrict__ src, int64_t n, int32_t* __restrict__ dst,
+                                                        unsigned* __restrict__ audit, int reset) {
+  const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 + 4 <= n && ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0) {
+    *(int4*)(dst + i4) = *(const int4*)(src + i4);
+  } else {
+    for (int64_t i = i4; i < i4 + 4 && i < n; ++i) dst[i] = src[i];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    unsigned a0 = 0u, a1 = 0u;
+    if (audit) {
+      a0 = audit[0]; a1 = audit[1];
+      if (reset) { audit[0] = 0u; audit[1] = 0u; }
+    }
+    dst[n] = (int32_t)a0; dst[n + 1] = (int32_t)a1;
+  }
+}
+
+int launch_copy_i32_audit(coper_handle* h, const int32_t* src, int64_t n, int32_t* dst, unsigned* audit, int reset, hipStream_t s) {
+  hipLaunchKernelGGL(k_copy_i32_audit, dim3((unsigned)((n + 1023) / 1024 > 0 ? (n + 1023) / 1024 : 1)), dim3(256), 0, s, src, n, dst, audit, reset);
+  COPER_HIP_TRY(h, hipGetLastError());
+  return COPER_OK;
+}
+
 int launch_copy_i32(coper_handle* h, const int32_t* src, int64_t n, int32_t* dst, hipStream_t s) {
   hipLaunchKernelGGL(k_copy_i32, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s, src, n, dst);
   COPER_HIP_TRY(h, hipGetLastError());

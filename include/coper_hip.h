@@ -290,6 +290,11 @@ COPER_API int coper_band_audit(coper_handle* h, int32_t reset, float* max_ratio,
  * (device memory or PINNED, device-mapped host memory, like coper_copy_out_i32) behind the work already on the stream; a
  * host that waits for its ranks anyway reads them with the same wait.  COPER_ESTATE on a COPER_SCORE_F32 handle. */
 COPER_API int coper_band_audit_post(coper_handle* h, int32_t reset, uint32_t* dst2, void* stream);
+/* coper_copy_out_i32 and coper_band_audit_post in ONE launch: the n int32 ranks of a pass to dst[0, n) and the audit's two words to
+ * dst[n], dst[n + 1] (zeros on a handle without a band), the audit reset for the next pass when reset != 0.  dst: n + 2 int32,
+ * device or pinned host memory.  What `ranking_and_hits` fetches per `session.run` (metrics.py:40-43) plus the audit, behind the
+ * pass's last kernel. */
+COPER_API int coper_post_ranks_audit(coper_handle* h, const int32_t* ranks, int64_t n, int32_t* dst, int32_t reset, void* stream);
 /* What a host DOES with the audit's two words (from coper_band_audit or coper_band_audit_post); host logic, no device work, no
  * synchronisation.  The contract of the path is integer ranks (metrics.py:44-50), so a measured error near the band's allowance
  * must not only be logged:
@@ -313,6 +318,19 @@ COPER_API int coper_band_policy(coper_handle* h, float max_ratio, int64_t n_pair
 /* Timing hook used by bench.py: average device time (ms) of the dominant kernel
  * (score_count) over the launches since the last reset, measured with hipEvents recorded on
  * the launch stream.  enable != 0 turns per-launch event recording on. */
+/* Host only: n int64 ids narrowed to int32 into dst (the pinned staging buffer coper_widen_ids / coper_stage_ids_next read), checked on
+ * the way: *status bit 0 = a value does not fit int32 (the caller then passes int64 arrays the ordinary way), bit 1 (with a CSR
+ * indptr of n_rows rows over this array, indptr[0] = 0, indptr[n_rows] = n) = a row is not ascending (the filter contract of
+ * coper_rank / coper_encode_rank: the caller sorts such rows first).  One pass instead of three over the bulk of a batch's host
+ * marshalling (metrics.py:40-45 feeds placeholders; here the feed is the staging buffer). */
+COPER_API int coper_pack_ids_i32(const int64_t* src, int64_t n, int32_t* dst, const int64_t* indptr, int64_t n_rows, int32_t* status);
+
+/* Host only: the metrics of a pass's ranks as the reference computes them (metrics.py:53-57, 65-76): mean rank and mean reciprocal
+ * rank as float64 means (the same summation order as numpy's np.mean, so the values are the ones the reference's expressions
+ * give), hits[k] = the fraction of ranks <= levels[k].  ranks start at 1 (metrics.py:50); EINVAL otherwise and for n == 0. */
+COPER_API int coper_hits_means(const int32_t* ranks, int64_t n, const int32_t* levels, int32_t n_levels, double* mean_rank, double* mrr,
+                               double* hits);
+
 /* Ids are validated on the device and clamped, never trusted: returns in *n_bad the number of
  * out-of-range relation ids seen by coper_encode since the last call (synchronises the stream). */
 COPER_API int coper_check_ids(coper_handle* h, int64_t* n_bad, void* stream);

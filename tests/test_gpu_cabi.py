@@ -196,6 +196,48 @@ def test_host_batches_are_staged_through_one_pinned_buffer():
     m.close()
 
 
+def test_list_route_of_ranking_and_hits_stages_the_filter_with_native_checks():
+    """`ranking_and_hits` on a plain list of CSR batches (coper_amd/metrics.py; the reference's loop, metrics.py:38-60): targets and
+    filter go through ConvE.stage_csr -- narrowing, range check and rows-ascending check in one native pass (coper_pack_ids_i32) --,
+    ranks and audit come back through one launch (coper_post_ranks_audit), the metrics from coper_hits_means.  Same results as the
+    dataset route; batches with an UNSORTED filter row or an id beyond int32 take the general route and give the same ranks / the
+    same id report as before."""
+    from coper_amd.models import ConvE
+    from coper_amd.metrics import ranking_and_hits
+    md = cdata.model_descriptors("fb15k237_cpg", num_ent=3000, num_rel=20)
+    m = ConvE(md, device="cuda:0", score_mode="bf16x3").load_parameters(cdata.synthetic_params(md, 1)).prepare()
+    q = cdata.synthetic_queries(md, 3000, seed=77)
+    ds = cdata.EvalDataset(q, 512, md["num_ent"])
+    want = ranking_and_hits(m, None, ds, "dataset", return_ranks=True)
+    batches = list(ds)
+    calls = []
+    orig = m.stage_csr
+    m.stage_csr = lambda *a: (calls.append(orig(*a)), calls[-1])[1]
+    got = ranking_and_hits(m, None, batches, "list", return_ranks=True)
+    assert calls and calls[-1] is not None                                   # the native route served it
+    assert got[0] == want[0] and got[1] == want[1] and got[2] == want[2] and np.array_equal(got[3], want[3])
+    got = ranking_and_hits(m, None, batches[:1], "one batch", return_ranks=True)
+    assert np.array_equal(got[3], want[3][:512]) and calls[-1] is not None
+    # a filter row out of order: the general route sorts it (same ranks: the mask is a set)
+    rev = [dict(b) for b in batches]
+    b0 = rev[2]
+    ip = np.asarray(b0["filt_indptr"])
+    r = int(np.argmax(np.diff(ip)))
+    assert ip[r + 1] - ip[r] >= 2
+    ix = np.array(b0["filt_idx"], np.int64)
+    ix[ip[r]:ip[r + 1]] = ix[ip[r]:ip[r + 1]][::-1]
+    b0["filt_idx"] = ix
+    got = ranking_and_hits(m, None, rev, "unsorted", return_ranks=True)
+    assert calls[-1] is None and np.array_equal(got[3], want[3])
+    # no known answers at all
+    empty = [dict(b, filt_indptr=np.zeros(len(b["e1"]) + 1, np.int64), filt_idx=np.zeros(0, np.int64)) for b in batches[:2]]
+    got = ranking_and_hits(m, None, empty, "no filter", return_ranks=True)
+    ref, _ = m.rank_pass(np.concatenate([b["e1"] for b in empty]), np.concatenate([b["rel"] for b in empty]),
+                         np.concatenate([b["e2"] for b in empty]), np.zeros(1025, np.int64), np.zeros(0, np.int64), want_equal=False)
+    assert calls[-1] is not None and np.array_equal(got[3], ref.cpu().numpy())
+    m.close()
+
+
 def test_band_audit_and_table_exponent_through_the_c_abi():
     """coper_band_audit / coper_band_audit_post / coper_set_x3_ent_absmax as a foreign host binds them (include/coper_hip.h):
     every count launch audited (band_audit_period = 1), the ratio read with a synchronisation and posted to pinned memory

@@ -200,3 +200,80 @@ def test_generated_asm_regions_are_up_to_date(tmp_path):
     subprocess.run([sys.executable, os.path.join(root, "tools", "gen_sc3_region_asm.py"), str(tmp_path), "--with-loads"], check=True, capture_output=True)
     for name in ("sc3_region_asm_ld.inc", "sc3_region_asm_gm_ld.inc"):
         assert os.path.getsize(os.path.join(str(tmp_path), name)) > 10000
+
+
+def test_hits_means_native_equals_numpy_bit_for_bit():
+    """coper_hits_means (host code of the library; metrics.hits_and_means takes it for int32 ranks): mean rank, MRR and Hits@k are
+    the float64 values the reference's NumPy expressions give (metrics.py:53-57, 65-76) -- np.mean's summation order included:
+    pairwise inside chunks of np.getbufsize() elements -- for sizes around every boundary of that order; ranks below 1 are refused
+    and take the NumPy route."""
+    import ctypes as C
+    from coper_amd import _lib, metrics
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    levels = (1, 3, 5, 10, 20)
+    for n in (1, 7, 8, 9, 127, 128, 129, 1023, 8191, 8192, 8193, 16384, 20480, 70001):
+        for top in (3, 14542, 5_000_000, 40_000_000):
+            r = rng.integers(1, top, n).astype(np.int32)
+            mr, mrr, hits = metrics.hits_and_means(r, levels)
+            r64 = r.astype(np.int64)
+            assert mr == np.mean(r64) and mrr == np.mean(1. / r64), (n, top)
+            for k in levels:
+                assert hits[k] == np.mean(np.where(r64 <= k, 1.0, 0.0))
+            assert (mr, mrr, hits) == metrics.hits_and_means(r64, levels)          # the NumPy route of the same function
+    r = rng.integers(1, 100, 50).astype(np.int32)
+    mr, mrr = C.c_double(), C.c_double()
+    lv = (C.c_int32 * 2)(1, 10)
+    hv = (C.c_double * 2)()
+    assert lib.coper_hits_means(C.c_void_p(r.ctypes.data), 50, lv, 2, C.byref(mr), C.byref(mrr), hv) == 0
+    assert hv[1] == np.count_nonzero(r <= 10) / 50
+    r[3] = 0
+    assert lib.coper_hits_means(C.c_void_p(r.ctypes.data), 50, lv, 2, C.byref(mr), C.byref(mrr), hv) == 1
+    assert lib.coper_hits_means(C.c_void_p(r.ctypes.data), 0, lv, 2, C.byref(mr), C.byref(mrr), hv) == 1
+    with np.errstate(divide="ignore"):
+        assert metrics.hits_and_means(r, levels)[1] == np.inf                      # (what np.mean(1. / ranks) gives for a rank of 0)
+
+
+def test_pack_ids_i32_checks_range_and_row_order():
+    """coper_pack_ids_i32 (host code): the narrowing copy into the staging buffer reports ids beyond int32 and filter rows that
+    are not ascending -- what `canonical_csr` and `stage_batch` establish with NumPy passes -- and nothing else."""
+    import ctypes as C
+    from coper_amd import _lib
+    from coper_amd.data import canonical_csr
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+
+    def pack(a, ip=None):
+        a = np.ascontiguousarray(a, np.int64)
+        out = np.full(a.size, -7, np.int32)
+        st = C.c_int32(-1)
+        rc = lib.coper_pack_ids_i32(C.c_void_p(a.ctypes.data), a.size, C.c_void_p(out.ctypes.data),
+                                    C.c_void_p(ip.ctypes.data) if ip is not None else None, len(ip) - 1 if ip is not None else 0, C.byref(st))
+        return rc, st.value, out
+
+    for trial in range(200):
+        B = int(rng.integers(1, 40))
+        lens = rng.integers(0, 9, B)
+        ip = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        rows = [np.sort(rng.integers(0, 50, n)) for n in lens]
+        if trial % 3 == 1 and lens.max() >= 2:                       # one row out of order somewhere
+            r = int(np.argmax(lens))
+            rows[r] = rows[r][::-1].copy()
+            if np.all(rows[r][1:] >= rows[r][:-1]):
+                rows[r][0] = rows[r][-1] + 1
+        ix = np.concatenate(rows).astype(np.int64) if ip[-1] else np.zeros(0, np.int64)
+        rc, st, out = pack(ix, ip)
+        assert rc == 0 and np.array_equal(out, ix.astype(np.int32))
+        _, fixed = canonical_csr(ip, ix)
+        assert bool(st & 2) == (not np.array_equal(fixed, ix)), (trial, st)
+        assert not (st & 1)
+    big = np.array([1, 2 ** 31 - 1, -2 ** 31, 5], np.int64)
+    assert pack(big)[:2] == (0, 0)
+    for v in (2 ** 31, -2 ** 31 - 1, 2 ** 40, -2 ** 62):
+        b2 = big.copy(); b2[2] = v
+        assert pack(b2)[:2] == (0, 1), v
+    # malformed row pointers are refused, not read
+    ix = np.arange(6, dtype=np.int64)
+    for bad_ip in ([0, 3, 5], [1, 3, 6], [0, 7, 6], [0, 4, 3, 6]):
+        assert pack(ix, np.asarray(bad_ip, np.int64))[0] == 1, bad_ip
+    assert pack(np.zeros(0, np.int64), np.zeros(4, np.int64))[:2] == (0, 0)      # empty rows only
