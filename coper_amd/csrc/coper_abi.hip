@@ -529,7 +529,7 @@ COPER_API int coper_prepare(coper_handle* h, void* stream) {
   COPER_HIP_TRY(h, hipSetDevice(cfg.device));
   int rc;
   group_use_set(h, 0);          // (x3m of the home set is re-allocated below; a grouping done ahead does not survive a prepare)
-  h->gnext.ride = false; h->gdone.done = false;
+  h->gnext.pending = false; h->gnext.ride = false; h->gdone.done = false;
   if ((rc = dev_alloc(h, &h->conv_scale, dm.C)) || (rc = dev_alloc(h, &h->conv_shift, dm.C)) ||
       (rc = dev_alloc(h, &h->fc_scale, dm.d)) || (rc = dev_alloc(h, &h->fc_shift, dm.d)))
     return rc;
