@@ -113,7 +113,7 @@ def test_bench_finds_the_committed_pmc_summaries():
     h = {}
     bench.pmc_traffic(h, "synth10m_cpg", 128, "coper::k_score_count3_bf16x3", exact="coper::k_score_count3_bf16x3<8, 0, 2, 0>")
     assert 1.0e10 < h["traffic"] < 1.15e10        # the 10M x 256 table read once: PMC bytes within 1.1x of the algorithmic 10.28 GB
-    assert "r05c" in h["traffic_source"]          # (the newest committed collection)
+    assert "r05d" in h["traffic_source"]          # (the newest committed collection)
     for wl, Q in (("fb15k237_plain", 20480), ("wn18rr_cpg", 3072)):      # round 5: counter traffic of the encoder on the other configs too
         t = {}
         bench.pmc_traffic(t, wl, Q, "coper::k_dense_fused_bf16x3")
