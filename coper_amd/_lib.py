@@ -74,6 +74,10 @@ PROTOTYPES = {
     "coper_band_audit": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_float), C.POINTER(_I64), _P]),
     "coper_band_audit_post": (C.c_int, [_P, C.c_int32, _P, _P]),
     "coper_post_ranks_audit": (C.c_int, [_P, _P, _I64, _P, C.c_int32, _P]),
+    "coper_pack_owned_rows": (C.c_int, [_P, _P, _I64, _I64, C.c_float, C.c_float, _P, _P]),
+    "coper_unpack_rows": (C.c_int, [_P, _P, _P, _P, _I64, _P, _P, _P, _P]),
+    "coper_pack_shard_record": (C.c_int, [_P, _P, _P, _P, _P, _I64, C.c_int32, C.c_int32, _P, _P]),
+    "coper_merge_shard_records": (C.c_int, [_P, _P, C.c_int32, _I64, C.c_int32, _P, _P, _P, _P, _P]),
     "coper_pack_ids_i32": (C.c_int, [_P, _I64, _P, _P, _I64, _P]),
     "coper_hits_means": (C.c_int, [_P, _I64, _P, C.c_int32, _P, _P, _P]),
     "coper_band_policy": (C.c_int, [_P, C.c_float, _I64, C.POINTER(C.c_int32), C.POINTER(C.c_float)]),

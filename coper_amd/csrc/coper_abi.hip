@@ -1096,6 +1096,40 @@ COPER_API int coper_post_ranks_audit(coper_handle* h, const int32_t* ranks, int6
   return launch_copy_i32_audit(h, ranks, n, dst, h->band_consts ? h->band_consts + 3 : nullptr, reset, (hipStream_t)stream);
 }
 
+// ---- step 1 of the entity-sharded exchange (coper_amd/sharding.py): the owned rows packed for the all-gather, the gathered rows handed out ----
+COPER_API int coper_pack_owned_rows(coper_handle* h, const int64_t* local_rows, int64_t n, int64_t cap, float hdr0, float hdr1, float* buf,
+                                    void* stream) {
+  if (!h || n < 0 || cap < n || !buf || (n > 0 && !local_rows)) return fail(h, COPER_EINVAL, "coper_pack_owned_rows: bad argument");
+  auto e = h->params.find("ent_emb"), b = h->params.find("pred_bias");
+  if (e == h->params.end() || b == h->params.end() || !e->second.set || !b->second.set)
+    return fail(h, COPER_EMISSING, "coper_pack_owned_rows: ent_emb / pred_bias were never set");
+  return launch_pack_owned_rows(h, e->second.ptr, b->second.ptr, local_rows, n, cap, hdr0, hdr1, buf, (hipStream_t)stream);
+}
+
+COPER_API int coper_unpack_rows(coper_handle* h, const float* gathered, const int64_t* take1, const int64_t* take2, int64_t B, float* rows1,
+                                float* rows2, float* bias2, void* stream) {
+  if (!h || B < 0 || (B > 0 && (!gathered || !take1 || !take2 || !rows1 || !rows2 || !bias2))) return fail(h, COPER_EINVAL, "coper_unpack_rows: bad argument");
+  if (B == 0) return COPER_OK;
+  return launch_unpack_rows(h, gathered, take1, take2, B, rows1, rows2, bias2, (hipStream_t)stream);
+}
+
+// ---- step 3 of the entity-sharded exchange (coper_amd/sharding.py): the per-shard record packed, the gathered records merged ----
+COPER_API int coper_pack_shard_record(coper_handle* h, const int32_t* n_greater, const int32_t* n_equal, const float* topk_val,
+                                      const int64_t* topk_idx, int64_t B, int32_t k, int32_t reset_audit, int64_t* rec, void* stream) {
+  if (!h || B < 0 || k < 0 || !rec || (B > 0 && (!n_greater || !n_equal)) || (B > 0 && k > 0 && (!topk_val || !topk_idx)))
+    return fail(h, COPER_EINVAL, "coper_pack_shard_record: bad argument");
+  return launch_pack_shard_record(h, n_greater, n_equal, topk_val, topk_idx, B, k, h->band_consts ? h->band_consts + 3 : nullptr, reset_audit, rec,
+                                  (hipStream_t)stream);
+}
+
+COPER_API int coper_merge_shard_records(coper_handle* h, const int64_t* all_rec, int32_t world, int64_t B, int32_t k, int32_t* ranks,
+                                        int32_t* n_equal, float* cand_val, int64_t* cand_idx, void* stream) {
+  if (!h || world < 1 || B < 0 || k < 0 || (B > 0 && (!all_rec || !ranks)) || (B > 0 && k > 0 && (!cand_val || !cand_idx)))
+    return fail(h, COPER_EINVAL, "coper_merge_shard_records: bad argument");
+  if (B == 0) return COPER_OK;
+  return launch_merge_shard_records(h, all_rec, world, B, k, ranks, n_equal, cand_val, cand_idx, (hipStream_t)stream);
+}
+
 // ---- host marshalling of a batch: int64 ids -> the int32 staging buffer, checked on the way ----
 // One pass over an id array on the host: narrowed to int32 into dst (typically the pinned buffer coper_widen_ids reads) while the
 // two things the staging path must know are checked -- every value fits int32 (status bit 0 otherwise), and, with a CSR indptr,

@@ -253,6 +253,14 @@ int launch_conv(coper_handle* h, const int64_t* e1, const int64_t* rel, const fl
                 hipStream_t s);
 int launch_dense(coper_handle* h, const int64_t* rel, int64_t B, int tq, int ksplit, float* h_out, hipStream_t s);
 int launch_copy_i32(coper_handle* h, const int32_t* src, int64_t n, int32_t* dst, hipStream_t s);
+int launch_pack_owned_rows(coper_handle* h, const float* ent, const float* bias, const int64_t* loc, int64_t n, int64_t cap, float hdr0, float hdr1,
+                           float* buf, hipStream_t s);
+int launch_unpack_rows(coper_handle* h, const float* all, const int64_t* take1, const int64_t* take2, int64_t B, float* g1, float* g2, float* b2,
+                       hipStream_t s);
+int launch_pack_shard_record(coper_handle* h, const int32_t* ng, const int32_t* ne, const float* tv, const int64_t* ti, int64_t B, int k,
+                             unsigned* audit, int reset, int64_t* rec, hipStream_t s);
+int launch_merge_shard_records(coper_handle* h, const int64_t* all, int world, int64_t B, int k, int32_t* ranks, int32_t* ne, float* vals,
+                               int64_t* ids, hipStream_t s);
 int launch_copy_i32_audit(coper_handle* h, const int32_t* src, int64_t n, int32_t* dst, unsigned* audit, int reset, hipStream_t s);
 int launch_widen_ids(coper_handle* h, const int32_t* src, int64_t n, int64_t* dst, hipStream_t s);
 int launch_gather_entities(coper_handle* h, const int64_t* ids, int64_t B, float* out, hipStream_t s);

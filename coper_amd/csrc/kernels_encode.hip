@@ -951,6 +951,139 @@ int launch_copy_i32(coper_handle* h, const int32_t* src, int64_t n, int32_t* dst
   return COPER_OK;
 }
 
+// ---- step 1 of the entity-sharded exchange: the rows a shard OWNS among ent_emb[e1], ent_emb[e2] packed for the all-gather, and
+// the gathered rows handed out to the queries -- one launch each for what were ~7 and ~5 torch launches per chunk ----
+// buf[cap + 1][d + 1]: row 0 = the header { hdr0, hdr1, 0... }, row 1 + i = { ent_emb[loc[i]][0..d), pred_bias[loc[i]] }, zero beyond n
+__global__ __launch_bounds__(256) void k_pack_owned_rows(const float* __restrict__ ent, const float* __restrict__ bias, const int64_t* __restrict__ loc,
+                                                         int64_t n, int64_t cap, int d, int64_t n_local, float hdr0, float hdr1,
+                                                         float* __restrict__ buf) {
+  const int W = d + 1;
+  const int64_t total = (cap + 1) * W;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / W;
+    const int c = (int)(i - r * W);
+    float v = 0.f;
+    if (r == 0) v = c == 0 ? hdr0 : c == 1 ? hdr1 : 0.f;
+    else if (r - 1 < n) {
+      int64_t row = loc[r - 1];
+      row = row < 0 ? 0 : row >= n_local ? n_local - 1 : row;
+      v = c < d ? ent[row * d + c] : bias[row];
+    }
+    buf[i] = v;
+  }
+}
+
+// g1[b] = all[take1[b]][0..d), g2[b] = all[take2[b]][0..d), b2[b] = all[take2[b]][d]
+__global__ __launch_bounds__(256) void k_unpack_rows(const float* __restrict__ all, const int64_t* __restrict__ take1, const int64_t* __restrict__ take2,
+                                                     int64_t B, int d, float* __restrict__ g1, float* __restrict__ g2, float* __restrict__ b2) {
+  const int W = d + 1;
+  const int64_t total = B * (2 * (int64_t)d + 1);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t b = i / (2 * d + 1);
+    const int c = (int)(i - b * (2 * d + 1));
+    if (c < d) g1[b * d + c] = all[take1[b] * W + c];
+    else if (c < 2 * d) g2[b * d + (c - d)] = all[take2[b] * W + (c - d)];
+    else b2[b] = all[take2[b] * W + d];
+  }
+}
+
+int launch_pack_owned_rows(coper_handle* h, const float* ent, const float* bias, const int64_t* loc, int64_t n, int64_t cap, float hdr0, float hdr1,
+                           float* buf, hipStream_t s) {
+  const int64_t total = (cap + 1) * (h->dm.d + 1);
+  int64_t nb = (total + 255) / 256;
+  if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(k_pack_owned_rows, dim3((unsigned)nb), dim3(256), 0, s, ent, bias, loc, n, cap, h->dm.d, h->dm.n_local, hdr0, hdr1, buf);
+  COPER_HIP_TRY(h, hipGetLastError());
+  return COPER_OK;
+}
+
+int launch_unpack_rows(coper_handle* h, const float* all, const int64_t* take1, const int64_t* take2, int64_t B, float* g1, float* g2, float* b2,
+                       hipStream_t s) {
+  const int64_t total = B * (2 * (int64_t)h->dm.d + 1);
+  int64_t nb = (total + 255) / 256;
+  if (nb > 8192) nb = 8192;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(k_unpack_rows, dim3((unsigned)nb), dim3(256), 0, s, all, take1, take2, B, h->dm.d, g1, g2, b2);
+  COPER_HIP_TRY(h, hipGetLastError());
+  return COPER_OK;
+}
+
+// ---- the entity-sharded exchange's record (coper_amd/sharding.py, step 3) packed and merged on the device ----
+// rec[B + 1][1 + 2 k] int64: row b = { n_greater << 32 | n_equal, the k top scores' float bits, the k ids }, row B = the
+// shard's band-audit words { ratio bits << 32 | pairs } (read from the handle and reset: no host round trip).  One launch for
+// what were ~10 torch launches and a synchronising audit read per chunk.
+__global__ __launch_bounds__(256) void k_pack_shard_record(const int32_t* __restrict__ ng, const int32_t* __restrict__ ne,
+                                                           const float* __restrict__ tv, const int64_t* __restrict__ ti, int64_t B, int k,
+                                                           unsigned* __restrict__ audit, int reset, int64_t* __restrict__ rec) {
+  const int W = 1 + 2 * k;
+  const int64_t n = (B + 1) * W;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t b = i / W;
+    const int c = (int)(i - b * W);
+    int64_t v = 0;
+    if (b < B) {
+      if (c == 0) v = ((int64_t)ng[b] << 32) | (int64_t)(uint32_t)ne[b];
+      else if (c <= k) v = (int64_t)(int32_t)__float_as_uint(tv[b * k + (c - 1)]);      // (sign-extended, as .view(int32).to(int64) gives)
+      else v = ti[b * k + (c - 1 - k)];
+    } else if (c == 0 && audit) {
+      const unsigned a0 = audit[0], a1 = audit[1];
+      v = ((int64_t)a0 << 32) | (int64_t)(a1 > 0x7fffffffu ? 0x7fffffffu : a1);
+      if (reset) { audit[0] = 0u; audit[1] = 0u; }
+    }
+    rec[i] = v;
+  }
+}
+
+// all[world][B + 1][1 + 2 k] -> ranks = 1 + sum of n_greater, n_equal summed, the candidates side by side: vals / ids [B][world k]
+__global__ __launch_bounds__(256) void k_merge_shard_records(const int64_t* __restrict__ all, int world, int64_t B, int k,
+                                                             int32_t* __restrict__ ranks, int32_t* __restrict__ ne,
+                                                             float* __restrict__ vals, int64_t* __restrict__ ids) {
+  const int W = 1 + 2 * k;
+  const int64_t per = (int64_t)world * k + 1;          // work items per query: the counts, then every (shard, j)
+  const int64_t n = B * per;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t b = i / per;
+    const int64_t r = i - b * per;
+    if (r == 0) {
+      int64_t g = 0, e = 0;
+      for (int w = 0; w < world; ++w) {
+        const int64_t v = all[((int64_t)w * (B + 1) + b) * W];
+        g += v >> 32;
+        e += v & 0xFFFFFFFFll;
+      }
+      ranks[b] = (int32_t)(1 + g);
+      if (ne) ne[b] = (int32_t)e;
+    } else {
+      const int64_t wj = r - 1;
+      const int w = (int)(wj / k), j = (int)(wj - (int64_t)w * k);
+      const int64_t* row = all + ((int64_t)w * (B + 1) + b) * W;
+      vals[b * ((int64_t)world * k) + wj] = __uint_as_float((uint32_t)row[1 + j]);
+      ids[b * ((int64_t)world * k) + wj] = row[1 + k + j];
+    }
+  }
+}
+
+int launch_pack_shard_record(coper_handle* h, const int32_t* ng, const int32_t* ne, const float* tv, const int64_t* ti, int64_t B, int k,
+                             unsigned* audit, int reset, int64_t* rec, hipStream_t s) {
+  const int64_t n = (B + 1) * (1 + 2 * (int64_t)k);
+  int64_t nb = (n + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(k_pack_shard_record, dim3((unsigned)nb), dim3(256), 0, s, ng, ne, tv, ti, B, k, audit, reset, rec);
+  COPER_HIP_TRY(h, hipGetLastError());
+  return COPER_OK;
+}
+
+int launch_merge_shard_records(coper_handle* h, const int64_t* all, int world, int64_t B, int k, int32_t* ranks, int32_t* ne, float* vals,
+                               int64_t* ids, hipStream_t s) {
+  const int64_t n = B * ((int64_t)world * k + 1);
+  int64_t nb = (n + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(k_merge_shard_records, dim3((unsigned)nb), dim3(256), 0, s, all, world, B, k, ranks, ne, vals, ids);
+  COPER_HIP_TRY(h, hipGetLastError());
+  return COPER_OK;
+}
+
 int launch_widen_ids(coper_handle* h, const int32_t* src, int64_t n, int64_t* dst, hipStream_t s) {
   hipLaunchKernelGGL(k_widen_ids, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s, src, n, dst);
   COPER_HIP_TRY(h, hipGetLastError());

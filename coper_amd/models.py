@@ -497,6 +497,28 @@ class ConvE(object):
             return ng, ne, tv, ti
         return ng, ne
 
+    def pack_shard_record(self, ng, ne, tv=None, ti=None, reset_audit=True):
+        """coper_pack_shard_record: the int64 record [B + 1, 1 + 2 k] this shard contributes to the exchange's all-gather (counts, top-k,
+        and -- last row -- its band-audit words, read and reset on the device)."""
+        B = int(ng.numel())
+        k = int(tv.shape[1]) if tv is not None else 0
+        rec = torch.empty((B + 1, 1 + 2 * k), dtype=torch.int64, device=self.device)
+        _lib.check(self._h, self._lib.coper_pack_shard_record(self._h, _ptr(ng), _ptr(ne), _ptr(tv.contiguous()) if k else None,
+                                                              _ptr(ti.contiguous()) if k else None, B, k, 1 if reset_audit else 0, _ptr(rec), self._stream()))
+        return rec
+
+    def merge_shard_records(self, allrec, world, B, k):
+        """coper_merge_shard_records: (ranks int32 [B], n_equal int32 [B], cand_val f32 [B, world k] or None, cand_idx int64 or None)
+        from the gathered records [world, B + 1, 1 + 2 k]."""
+        allrec = allrec.contiguous()
+        ranks = torch.empty((B,), dtype=torch.int32, device=self.device)
+        ne = torch.empty((B,), dtype=torch.int32, device=self.device)
+        vals = torch.empty((B, world * k), dtype=torch.float32, device=self.device) if k else None
+        ids = torch.empty((B, world * k), dtype=torch.int64, device=self.device) if k else None
+        _lib.check(self._h, self._lib.coper_merge_shard_records(self._h, _ptr(allrec), int(world), int(B), int(k), _ptr(ranks), _ptr(ne),
+                                                                _ptr(vals), _ptr(ids), self._stream()))
+        return ranks, ne, vals, ids
+
     def rank(self, h, e2, filt_indptr, filt_idx, filt_nnz=None, want_equal=True):
         """Filtered ranks int32 [B] (+ n_equal, or None with want_equal=False) on an unsharded model."""
         self._need_prepared()
@@ -600,6 +622,25 @@ class ConvE(object):
         ids = self._ids(ids)
         loc = (ids - lo).clamp(0, max(0, hi - lo - 1))
         return self._tensors["ent_emb"].index_select(0, loc), self._tensors["pred_bias"].index_select(0, loc)
+
+    def pack_owned_rows(self, local_rows: torch.Tensor, cap: int, hdr0: float, hdr1: float):
+        """coper_pack_owned_rows: the [cap + 1, d + 1] buffer this shard contributes to step 1's all-gather (header row, then the
+        rows / biases at `local_rows` -- int64 device tensor of shard-local row numbers --, zeros up to cap): one launch."""
+        buf = torch.empty((cap + 1, self.ent_emb_size + 1), dtype=torch.float32, device=self.device)
+        n = int(local_rows.numel())
+        _lib.check(self._h, self._lib.coper_pack_owned_rows(self._h, _ptr(local_rows) if n else None, n, int(cap), float(hdr0), float(hdr1),
+                                                            _ptr(buf), self._stream()))
+        return buf
+
+    def unpack_rows(self, gathered: torch.Tensor, take1: torch.Tensor, take2: torch.Tensor):
+        """coper_unpack_rows: (ent_emb[e1] [B, d], ent_emb[e2] [B, d], pred_bias[e2] [B]) out of step 1's gathered buffer: one launch."""
+        B, d = int(take1.numel()), self.ent_emb_size
+        g1 = torch.empty((B, d), dtype=torch.float32, device=self.device)
+        g2 = torch.empty((B, d), dtype=torch.float32, device=self.device)
+        b2 = torch.empty((B,), dtype=torch.float32, device=self.device)
+        _lib.check(self._h, self._lib.coper_unpack_rows(self._h, _ptr(gathered), _ptr(take1), _ptr(take2), B, _ptr(g1), _ptr(g2), _ptr(b2),
+                                                        self._stream()))
+        return g1, g2, b2
 
     def set_x3_ent_absmax(self, absmax: float):
         """coper_set_x3_ent_absmax: the largest |ent_emb| element of the WHOLE table, for a handle that holds a shard of it

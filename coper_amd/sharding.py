@@ -169,22 +169,32 @@ class EntityShardedRanker(object):
             plan = self._rows_plan = dict(B=B, e1=e1_np.copy(), e2=e2_np.copy(), cap=cap, mine_ids=ids[mine], n_mine=len(mine),
                                           take1=torch.as_tensor(slot[:B], device=dev), take2=torch.as_tensor(slot[B:], device=dev))
         cap = plan["cap"]
-        rows, bias = self._owned(plan["mine_ids"])
-        d = rows.shape[1]
-        buf = torch.zeros((cap + 1, d + 1), dtype=torch.float32, device=rows.device)
-        if self._absmax_ok:                                                      # the header row: [own maximum, hint in force]
-            buf[0, 0] = float(sc.ent_absmax())
-            buf[0, 1] = float(getattr(sc, "_x3_absmax", None) or 0.0)
-        if plan["n_mine"]:
-            buf[1:1 + plan["n_mine"], :d] = rows
-            buf[1:1 + plan["n_mine"], d] = bias
-        out = torch.empty((self.world * (cap + 1), d + 1), dtype=torch.float32, device=rows.device)
+        native = hasattr(sc, "pack_owned_rows") and hasattr(sc, "unpack_rows") and hasattr(sc, "shard")
+        hdr = (float(sc.ent_absmax()), float(getattr(sc, "_x3_absmax", None) or 0.0)) if self._absmax_ok else (0.0, 0.0)
+        if native:           # header + owned rows + zero padding: one launch (the shard-local row numbers are kept with the plan)
+            if "loc" not in plan:
+                plan["loc"] = torch.as_tensor(plan["mine_ids"] - int(sc.shard[0]), dtype=torch.int64).to(sc.device)
+            buf = sc.pack_owned_rows(plan["loc"], cap, hdr[0], hdr[1])
+            d = buf.shape[1] - 1
+        else:
+            rows, bias = self._owned(plan["mine_ids"])
+            d = rows.shape[1]
+            buf = torch.zeros((cap + 1, d + 1), dtype=torch.float32, device=rows.device)
+            if self._absmax_ok:                                                  # the header row: [own maximum, hint in force]
+                buf[0, 0] = hdr[0]
+                buf[0, 1] = hdr[1]
+            if plan["n_mine"]:
+                buf[1:1 + plan["n_mine"], :d] = rows
+                buf[1:1 + plan["n_mine"], d] = bias
+        out = torch.empty((self.world * (cap + 1), d + 1), dtype=torch.float32, device=buf.device)
         dist.all_gather_into_tensor(out, buf, group=self.group)
         if self._absmax_ok:
             head = out.view(self.world, cap + 1, d + 1)[:, 0, :2].cpu()          # (one small D2H per chunk: every rank sees the same values)
             m = float(head[:, 0].max())
             if m > 0.0 and bool((head[:, 1] != m).any()):                        # some rank runs on another hint (reloaded weights): all re-agree
                 sc.set_x3_ent_absmax(m)
+        if native:
+            return sc.unpack_rows(out, plan["take1"], plan["take2"])
         g1, g2 = out.index_select(0, plan["take1"]), out.index_select(0, plan["take2"])
         return g1[:, :d].contiguous(), g2[:, :d].contiguous(), g2[:, d].contiguous()
 
@@ -247,14 +257,18 @@ class EntityShardedRanker(object):
                                  filt_nnz=len(chunk["filt_idx"]), k=k)
             ng, ne = out[0], out[1]
             B = ng.shape[0]
-            rec = torch.zeros((B + 1, 1 + 2 * k), dtype=torch.int64, device=ng.device)
-            rec[:B, 0] = (ng.to(torch.int64) << 32) | ne.to(torch.int64)
-            if k > 0:
-                rec[:B, 1:1 + k] = out[2].contiguous().view(torch.int32).to(torch.int64)
-                rec[:B, 1 + k:] = out[3]
-            if audited:
-                ratio, n_pairs = sc.band_audit()
-                rec[B, 0] = (int(np.float32(ratio).view(np.uint32)) << 32) | (min(int(n_pairs), 0x7fffffff) & 0xffffffff)
+            native = hasattr(sc, "pack_shard_record") and hasattr(sc, "merge_shard_records")
+            if native:       # one launch: counts, top-k and the audit words (read and reset on the device: no host round trip here)
+                rec = sc.pack_shard_record(ng, ne, out[2] if k > 0 else None, out[3] if k > 0 else None, reset_audit=True)
+            else:
+                rec = torch.zeros((B + 1, 1 + 2 * k), dtype=torch.int64, device=ng.device)
+                rec[:B, 0] = (ng.to(torch.int64) << 32) | ne.to(torch.int64)
+                if k > 0:
+                    rec[:B, 1:1 + k] = out[2].contiguous().view(torch.int32).to(torch.int64)
+                    rec[:B, 1 + k:] = out[3]
+                if audited:
+                    ratio, n_pairs = sc.band_audit()
+                    rec[B, 0] = (int(np.float32(ratio).view(np.uint32)) << 32) | (min(int(n_pairs), 0x7fffffff) & 0xffffffff)
             if self.dist:
                 allrec = torch.empty((self.world * (B + 1), 1 + 2 * k), dtype=torch.int64, device=rec.device)
                 dist.all_gather_into_tensor(allrec, rec, group=self.group)           # concatenated along dim 0 (gloo + nccl)
@@ -271,14 +285,20 @@ class EntityShardedRanker(object):
                 break
         else:
             raise RuntimeError("bf16x3 band audit: still above the band's allowance after 4 re-counted chunks")
-        allrec = allrec[:, :B, :]
-        ng_tot = (allrec[:, :, 0] >> 32).sum(dim=0)
-        ne_tot = (allrec[:, :, 0] & 0xFFFFFFFF).sum(dim=0)
-        ranks = (1 + ng_tot).to(torch.int32)
-        if k == 0:
-            return ranks, ne_tot.to(torch.int32)
-        vals = allrec[:, :, 1:1 + k].to(torch.int32).view(torch.float32).permute(1, 0, 2).reshape(B, -1)
-        ids = allrec[:, :, 1 + k:].permute(1, 0, 2).reshape(B, -1)
+        if native:           # one launch: the summed counts and the candidates side by side
+            ranks, ne_i, vals, ids = sc.merge_shard_records(allrec, self.world, B, k)
+            if k == 0:
+                return ranks, ne_i
+            ne_tot = ne_i
+        else:
+            allrec = allrec[:, :B, :]
+            ng_tot = (allrec[:, :, 0] >> 32).sum(dim=0)
+            ne_tot = (allrec[:, :, 0] & 0xFFFFFFFF).sum(dim=0)
+            ranks = (1 + ng_tot).to(torch.int32)
+            if k == 0:
+                return ranks, ne_tot.to(torch.int32)
+            vals = allrec[:, :, 1:1 + k].to(torch.int32).view(torch.float32).permute(1, 0, 2).reshape(B, -1)
+            ids = allrec[:, :, 1 + k:].permute(1, 0, 2).reshape(B, -1)
         if self.world == 1:      # one shard: its list is already in (score desc, id asc) order
             return ranks, ne_tot.to(torch.int32), vals.contiguous(), ids.contiguous()
         tv, ti = merge_topk(vals, ids, k)

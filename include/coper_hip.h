@@ -318,6 +318,29 @@ COPER_API int coper_band_policy(coper_handle* h, float max_ratio, int64_t n_pair
 /* Timing hook used by bench.py: average device time (ms) of the dominant kernel
  * (score_count) over the launches since the last reset, measured with hipEvents recorded on
  * the launch stream.  enable != 0 turns per-launch event recording on. */
+/* Step 1 of the entity-sharded exchange (coper_amd/sharding.py): every rank needs ent_emb[e1], ent_emb[e2] and pred_bias[e2] of the chunk
+ * (models.py:176, :437); each row lives on one shard.  coper_pack_owned_rows writes what THIS shard owns for the all-gather --
+ * buf[cap + 1][d + 1] float: row 0 = the header { hdr0, hdr1, 0... } (the shard's largest |ent_emb| and the table-wide maximum in
+ * force: how the ranks keep ONE power of two for their entity planes), row 1 + i = { ent_emb[local_rows[i]], pred_bias[local_rows[i]] }
+ * from the registered parameter tensors (no prepared state needed), zeros up to cap -- and coper_unpack_rows hands the gathered rows
+ * out: rows1[b] = gathered[take1[b]][0, d), rows2[b] = gathered[take2[b]][0, d), bias2[b] = gathered[take2[b]][d].  One launch each. */
+COPER_API int coper_pack_owned_rows(coper_handle* h, const int64_t* local_rows, int64_t n, int64_t cap, float hdr0, float hdr1, float* buf,
+                                    void* stream);
+COPER_API int coper_unpack_rows(coper_handle* h, const float* gathered, const int64_t* take1, const int64_t* take2, int64_t B, float* rows1,
+                                float* rows2, float* bias2, void* stream);
+
+/* Step 3 of the entity-sharded exchange (coper_amd/sharding.py; north_star's one collective of counts + top-k): the record a shard
+ * contributes, packed by ONE launch -- rec[B + 1][1 + 2 k] int64: row b = { n_greater << 32 | n_equal, the k top scores' float bits
+ * (sign-extended int32), the k global ids } from coper_rank_counts' outputs; row B = the shard's band-audit words
+ * { ratio bits << 32 | min(pairs, 2^31 - 1) } read on the device (and reset when reset_audit != 0: no host round trip; zeros on a
+ * handle without a band) -- and, after the all-gather, the merge of all_rec[world][B + 1][1 + 2 k] by one more: ranks = 1 + the
+ * summed n_greater (metrics.py:50), n_equal summed (may be NULL), the candidates side by side cand_val / cand_idx [B][world k]
+ * (shard-major; the global top-k is their (score desc, id asc) selection).  Integer sums: bit-equal to the single-GPU ranks. */
+COPER_API int coper_pack_shard_record(coper_handle* h, const int32_t* n_greater, const int32_t* n_equal, const float* topk_val,
+                                      const int64_t* topk_idx, int64_t B, int32_t k, int32_t reset_audit, int64_t* rec, void* stream);
+COPER_API int coper_merge_shard_records(coper_handle* h, const int64_t* all_rec, int32_t world, int64_t B, int32_t k, int32_t* ranks,
+                                        int32_t* n_equal, float* cand_val, int64_t* cand_idx, void* stream);
+
 /* Host only: n int64 ids narrowed to int32 into dst (the pinned staging buffer coper_widen_ids / coper_stage_ids_next read), checked on
  * the way: *status bit 0 = a value does not fit int32 (the caller then passes int64 arrays the ordinary way), bit 1 (with a CSR
  * indptr of n_rows rows over this array, indptr[0] = 0, indptr[n_rows] = n) = a row is not ascending (the filter contract of

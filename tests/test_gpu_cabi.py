@@ -238,6 +238,86 @@ def test_list_route_of_ranking_and_hits_stages_the_filter_with_native_checks():
     m.close()
 
 
+@pytest.mark.parametrize("k", [0, 1, 10])
+def test_shard_record_pack_and_merge_match_the_tensor_formulation(k):
+    """coper_pack_shard_record / coper_merge_shard_records (step 3 of the entity-sharded exchange) against the torch expressions
+    they replace in coper_amd/sharding.py: the same int64 record (counts, score bits, ids, audit row) and, from records of three
+    shards, the same ranks, tie counts and candidate lists."""
+    from coper_amd.models import ConvE
+    md = cdata.model_descriptors("fb15k237_cpg", num_ent=3000, num_rel=20)
+    m = ConvE(md, device="cuda:0", score_mode="bf16x3", band_audit_period=1).load_parameters(cdata.synthetic_params(md, 1)).prepare()
+    q = cdata.synthetic_queries(md, 700, seed=5)
+    m.rank_pass(q["e1"], q["rel"], q["e2"], q["filt_indptr"], q["filt_idx"], want_equal=False)     # (leaves a real audit behind)
+    g = torch.Generator(device="cuda:0").manual_seed(3)
+    world, B = 3, 701
+    recs, parts = [], []
+    for w in range(world):
+        ng = torch.randint(0, 2 ** 31 - 1, (B,), generator=g, device="cuda:0", dtype=torch.int64).to(torch.int32)
+        ne = torch.randint(0, 50, (B,), generator=g, device="cuda:0", dtype=torch.int64).to(torch.int32)
+        tv = torch.randn((B, k), generator=g, device="cuda:0") if k else None
+        if k:
+            tv[5, 0] = float("-inf"); tv[7, k - 1] = -0.0
+        ti = torch.randint(-1, 10 ** 7, (B, k), generator=g, device="cuda:0", dtype=torch.int64) if k else None
+        want = torch.zeros((B + 1, 1 + 2 * k), dtype=torch.int64, device="cuda:0")
+        want[:B, 0] = (ng.to(torch.int64) << 32) | ne.to(torch.int64)
+        if k:
+            want[:B, 1:1 + k] = tv.contiguous().view(torch.int32).to(torch.int64)
+            want[:B, 1 + k:] = ti
+        if w == 0:
+            ratio, pairs = m.band_audit(reset=False)
+            assert pairs > 0
+            want[B, 0] = (int(np.float32(ratio).view(np.uint32)) << 32) | (min(int(pairs), 0x7fffffff) & 0xffffffff)
+        rec = m.pack_shard_record(ng, ne, tv, ti, reset_audit=True)
+        assert torch.equal(rec, want), (w, k)
+        if w == 0:
+            assert m.band_audit(reset=False) == (0.0, 0)                 # read and reset on the device
+        recs.append(rec); parts.append((ng, ne))
+    allrec = torch.stack(recs)
+    ranks, ne_tot, vals, ids = m.merge_shard_records(allrec, world, B, k)
+    a = allrec[:, :B, :]
+    assert torch.equal(ranks, (1 + (a[:, :, 0] >> 32).sum(dim=0)).to(torch.int32))
+    assert torch.equal(ne_tot, (a[:, :, 0] & 0xFFFFFFFF).sum(dim=0).to(torch.int32))
+    if k:
+        wv = a[:, :, 1:1 + k].to(torch.int32).view(torch.float32).permute(1, 0, 2).reshape(B, -1)
+        wi = a[:, :, 1 + k:].permute(1, 0, 2).reshape(B, -1)
+        assert torch.equal(vals.view(torch.int32), wv.contiguous().view(torch.int32)) and torch.equal(ids, wi)
+    else:
+        assert vals is None and ids is None
+    m.close()
+
+
+def test_owned_rows_pack_and_unpack_match_the_tensor_formulation():
+    """coper_pack_owned_rows / coper_unpack_rows (step 1 of the entity-sharded exchange) against the indexing expressions they
+    replace in coper_amd/sharding.py, on a model that holds a SHARD of the table."""
+    from coper_amd.models import ConvE
+    md = cdata.model_descriptors("fb15k237_cpg", num_ent=3000, num_rel=20)
+    p = cdata.synthetic_params(md, 1)
+    lo, hi = 1000, 2200
+    m = ConvE(md, device="cuda:0", score_mode="bf16x3", shard=(lo, hi)).load_parameters(p).prepare()
+    rng = np.random.default_rng(2)
+    d = md["ent_emb_size"]
+    for n, cap in ((0, 0), (0, 5), (1, 1), (37, 37), (500, 777)):
+        ids = rng.integers(lo, hi, n)
+        loc = torch.as_tensor(ids - lo, dtype=torch.int64, device="cuda:0")
+        buf = m.pack_owned_rows(loc, cap, 0.625, 1.5)
+        rows, bias = m.owned_rows(ids)
+        want = torch.zeros((cap + 1, d + 1), device="cuda:0")
+        want[0, 0], want[0, 1] = 0.625, 1.5
+        if n:
+            want[1:1 + n, :d] = rows
+            want[1:1 + n, d] = bias
+        assert torch.equal(buf, want), (n, cap)
+    world, cap, B = 3, 40, 129
+    g = torch.Generator(device="cuda:0").manual_seed(0)
+    out = torch.randn((world * (cap + 1), d + 1), generator=g, device="cuda:0")
+    t1 = torch.randint(0, world * (cap + 1), (B,), generator=g, device="cuda:0")
+    t2 = torch.randint(0, world * (cap + 1), (B,), generator=g, device="cuda:0")
+    g1, g2, b2 = m.unpack_rows(out, t1, t2)
+    w1, w2 = out.index_select(0, t1), out.index_select(0, t2)
+    assert torch.equal(g1, w1[:, :d]) and torch.equal(g2, w2[:, :d]) and torch.equal(b2, w2[:, d])
+    m.close()
+
+
 def test_band_audit_and_table_exponent_through_the_c_abi():
     """coper_band_audit / coper_band_audit_post / coper_set_x3_ent_absmax as a foreign host binds them (include/coper_hip.h):
     every count launch audited (band_audit_period = 1), the ratio read with a synchronisation and posted to pinned memory
