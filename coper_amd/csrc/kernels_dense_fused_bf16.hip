@@ -106,6 +106,20 @@ struct FusedConvArgs {
 // FB15k-237-shaped pass.  h_out == NULL: partial sums to z_part as before.
 // (The constant part lives in device memory, written at prepare: as kernel arguments its nine words pushed the main loop's
 // scalar registers into spills -- the kernel ran 19 us longer to save a 14 us launch.)
+#ifdef COPER_DBG_FUSED_CLOCK
+// phase stamps of a workgroup (wave 0: matrix role, wave 4: conv role), read with coper_dbg_fused_phases
+__device__ unsigned long long g_fused_ph[8 * 2048];
+extern "C" __attribute__((visibility("default"))) int coper_dbg_fused_phases(unsigned long long* out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fused_ph), sizeof(unsigned long long) * 8 * (n < 2048 ? n : 2048)) == hipSuccess ? 0 : 1;
+}
+#define FUSED_PH(i_)                                                                                            \
+  do {                                                                                                          \
+    const int w_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                              \
+    if ((threadIdx.x & 63) == 0 && w_ < 2048) g_fused_ph[8 * w_ + (i_)] = __builtin_amdgcn_s_memrealtime();     \
+  } while (0)
+#else
+#define FUSED_PH(i_) do { } while (0)
+#endif
 struct FusedFinConst {
   const int32_t* perm; const float* fc_b; const float* scale; const float* shift; const int32_t* w_exp; float* x3m;
   int per_rel_bias, x_exp, d, pad;
@@ -293,7 +307,12 @@ __device__ __forceinline__ void fused_matrix_role(const uint4* __restrict__ xrin
 #pragma unroll
   for (int t = 0; t < P; ++t)
     if (t < nk) W_ISSUE(t, t);      // the weight stream starts before anything else
+  // (Round 5, late, -DCOPER_DBG_FUSED_CLOCK phases: the images stand in LDS 9 us (WN18RR) to 15 us (FB15k-237) after the workgroup's
+  //  start -- three dependent round trips, tile -> ids -> rows, while every workgroup of the launch asks for its first 300 KB.
+  //  Requesting the rows BEFORE the weights, or by the conv waves alone: the same 9 / 15 us, or worse; see DESIGN_LOG.md.)
+  if (wave == 0) FUSED_PH(0);
   fused_load_images(img, A, start, n, t0, t1);
+  if (wave == 0) FUSED_PH(1);
   f32x4 acc[NFULL][NB], accr[NRQ > 0 ? NRQ : 1];
 #pragma unroll
   for (int j = 0; j < NFULL; ++j)
@@ -387,6 +406,7 @@ __device__ __forceinline__ void fused_matrix_role(const uint4* __restrict__ xrin
       W_ISSUE(s2 % P, kn < nk ? kn : 0);
 #endif
     }
+    if (k0 == 0 && wave == 0) FUSED_PH(2);      // (the first 2 P steps done)
   }
   // remaining nk % 2P steps
 #pragma unroll
@@ -400,6 +420,7 @@ __device__ __forceinline__ void fused_matrix_role(const uint4* __restrict__ xrin
   }
 #undef M_STEP
 #undef W_ISSUE
+  if (wave == 0) FUSED_PH(3);
 #ifdef COPER_DBG_FUSED_NO_STORE
   if (acc[0][0][0] != 1.2345f) return;
 #endif
@@ -564,6 +585,7 @@ __device__ __forceinline__ void fused_conv_role(uint4* __restrict__ xring, unsig
     }
   }
   fused_load_images(img, A, start, n, t0, t1);
+  if (cw == 0) FUSED_PH(5);
   // dword bases of this lane's query in each of the wave's fragments (padding lanes repeat the last query): own plane (hi for
   // g = 0, 2, 3; lo for g = 1) and the other one (tap 8's second term, used by g = 3)
   int qown[NFR], qoth[NFR];
