@@ -482,6 +482,15 @@ def test_group_next_sorts_the_next_batch_beside_the_encoder(workload, Q):
     if n_ref is not None:
         assert m.check_ids() == n_ref
     assert m._lib.coper_group_next(m._h, None, None, 5, 0) == 1
+    # the pass that follows hands its entity rows over itself (e1_rows: what the entity-sharded ranker's encoder gets)
+    rows0, rows1 = m.gather_entities(v0["e1"]), m.gather_entities(v1["e1"])
+    plain1, _ = m.rank_pass(None, v1["rel"], v1["e2"], v1["filt_indptr"], v1["filt_idx"], want_equal=False, e1_rows=rows1)
+    assert np.array_equal(plain1.cpu().numpy(), base[1])
+    m.profile_read("group")
+    m.group_next(None, v1["rel"], e1_rows=True)
+    m.rank_pass(None, v0["rel"], v0["e2"], v0["filt_indptr"], v0["filt_idx"], want_equal=False, e1_rows=rows0)
+    got1, _ = m.rank_pass(None, v1["rel"], v1["e2"], v1["filt_indptr"], v1["filt_idx"], want_equal=False, e1_rows=rows1)
+    assert np.array_equal(got1.cpu().numpy(), base[1]) and m.profile_read("group")[1] == 1
     m.close()
 
 
