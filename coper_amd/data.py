@@ -415,24 +415,43 @@ class EvalDataset(object):
         """The whole dataset marshalled once for `model` (ConvE.stage_persistent: canonical CSR, int32 in pinned memory, device
         buffers): `ranking_and_hits` scores the same evaluation set after every epoch (run_cpg.py:18-35, 228-250) and pays
         the host-side marshalling once.  One entry per model, dropped with it; None when the model has no such path."""
+        out = self.staged_chunks_for(model, None)
+        return out[0] if out else None
+
+    def staged_chunks_for(self, model, max_chunk=None):
+        """`staged_for` for sets of any size: the dataset cut into ceil(Q / max_chunk) chunks of (nearly) equal size, each marshalled
+        once (its own pinned buffer, device arrays and rank buffer) -- FB15k-237's test set is 40,932 queries with both directions,
+        more than one device pass takes.  The list (one entry when max_chunk is None or the set fits); None when the model has no
+        such path or an id does not fit int32."""
         if not hasattr(model, "stage_persistent"):
             return None
         import weakref
         cache = self.__dict__.setdefault("_staged", {})
-        key = id(model)
+        key = (id(model), None if max_chunk is None else int(max_chunk))
         ent = cache.get(key)
         if ent is not None and ent[0]() is model:
             return ent[1]
         q = self.q
+        Q = len(q["e1"])
         ip, ix = canonical_csr(q["filt_indptr"], q["filt_idx"])
-        sb = model.stage_persistent(q["e1"], q["rel"], q["e2"], ip, ix)
-        # the entry (a pinned host buffer and int64 device arrays) goes when the model does: the callback drops it, unless the
+        ip = np.asarray(ip)
+        n_chunks = 1 if (max_chunk is None or Q <= max_chunk) else -(-Q // int(max_chunk))
+        size = -(-Q // n_chunks) if Q else 0
+        sbs = []
+        for c in range(n_chunks):
+            lo, hi = c * size, min(Q, (c + 1) * size)
+            cip = ip[lo:hi + 1]
+            sb = model.stage_persistent(q["e1"][lo:hi], q["rel"][lo:hi], q["e2"][lo:hi], cip - cip[0], ix[cip[0]:cip[-1]])
+            if sb is None:
+                return None
+            sbs.append(sb)
+        # the entries (pinned host buffers and int64 device arrays) go when the model does: the callback drops them, unless the
         # slot was taken over by a later model that got the same id()
         def _drop(ref, cache=cache, key=key):
             if cache.get(key, (None,))[0] is ref:
                 del cache[key]
-        cache[key] = (weakref.ref(model, _drop), sb)
-        return sb
+        cache[key] = (weakref.ref(model, _drop), sbs)
+        return sbs
 
     def __iter__(self) -> Iterator[dict]:
         q = self.q

@@ -142,24 +142,41 @@ def ranking_and_hits(model, results_dir, data_iterator_handle, name, session=Non
 
     # an evaluation set that is scored again and again (after every epoch, run_cpg.py:228-250) is marshalled once: int32 in
     # pinned memory, canonical CSR, device buffers (EvalDataset.staged_for); a pass is then three asynchronous calls and one wait
-    sb = None
-    if ranker is None and hasattr(data_iterator_handle, "staged_for") and hasattr(model, "rank_pass_staged") \
-            and getattr(data_iterator_handle, "num_queries", max_chunk + 1) <= max_chunk:
-        sb = data_iterator_handle.staged_for(model)
-    if sb is not None:
-        Q = sb["B"]
+    # Sets larger than one device pass (`max_chunk` queries; FB15k-237's test set with both directions is 40,932) are cut into equal
+    # chunks, each staged once; their passes are queued back to back on one stream -- the next chunk's sort by relation inside the
+    # running chunk's encoder launch (coper_group_next: its ids are resident) -- and waited for once.
+    sbs = None
+    if ranker is None and hasattr(model, "rank_pass_staged"):
+        if hasattr(data_iterator_handle, "staged_chunks_for"):
+            sbs = data_iterator_handle.staged_chunks_for(model, max_chunk)
+        elif hasattr(data_iterator_handle, "staged_for") and getattr(data_iterator_handle, "num_queries", max_chunk + 1) <= max_chunk:
+            sb = data_iterator_handle.staged_for(model)
+            sbs = [sb] if sb is not None else None
+    if sbs:
+        Q = sum(sb["B"] for sb in sbs)
         x3 = Q and getattr(model, "score_mode", None) == "bf16x3"
+        todo = [i for i, sb in enumerate(sbs) if sb["B"]]
         for attempt in range(_MAX_RERANKS + 1):
-            out = model.rank_pass_staged(sb)
-            sb["event"].synchronize()
-            ranks = out.numpy()
-            if not x3:
+            for j, i in enumerate(todo):
+                nxt = sbs[todo[j + 1]] if j + 1 < len(todo) else None
+                if nxt is not None and nxt.get("resident") and hasattr(model, "group_next"):
+                    model.group_next(nxt["views"][0], nxt["views"][1])
+                model.rank_pass_staged(sbs[i])
+            if todo:
+                sbs[todo[-1]]["event"].synchronize()          # (one stream: the last chunk's event covers them all)
+            again = []
+            if x3:
+                for i in todo:
+                    aud = sbs[i]["out_host"][sbs[i]["B"]:sbs[i]["B"] + 2].numpy()
+                    if _act_on_band_audit(model, float(aud[:1].view(np.float32)[0]), int(aud[1:2].view(np.uint32)[0])) == 2:
+                        again.append(i)
+            if not again:
                 break
-            aud = sb["out_host"][Q:Q + 2].numpy()
-            if _act_on_band_audit(model, float(aud[:1].view(np.float32)[0]), int(aud[1:2].view(np.uint32)[0])) != 2:
-                break
+            todo = again
         else:
             raise RuntimeError("bf16x3 band audit: still above the band's allowance after %d re-ranked passes" % _MAX_RERANKS)
+        parts = [sb["out_host"][:sb["B"]].numpy() for sb in sbs]
+        ranks = parts[0] if len(parts) == 1 else np.concatenate(parts)
         return _finish(ranks, Q, results_dir, hits_to_compute, enable_write_to_file, return_ranks)
 
     # a plain list of batches with CSR filters: the encoder needs the ids only, so it is launched as soon as THEY are

@@ -209,6 +209,14 @@ def test_list_route_of_ranking_and_hits_stages_the_filter_with_native_checks():
     q = cdata.synthetic_queries(md, 3000, seed=77)
     ds = cdata.EvalDataset(q, 512, md["num_ent"])
     want = ranking_and_hits(m, None, ds, "dataset", return_ranks=True)
+    # a set larger than one device pass: equal chunks staged once, their passes queued back to back (the second call has the next
+    # chunk's sort by relation done inside the running chunk's encoder launch: coper_group_next)
+    for rep in range(3):
+        m.profile(True); m.profile_read("group")
+        got = ranking_and_hits(m, None, ds, "chunks", max_chunk=1000, return_ranks=True)
+        assert got[0] == want[0] and got[1] == want[1] and got[2] == want[2] and np.array_equal(got[3], want[3]), rep
+        assert m.profile_read("group")[1] == (3 if rep == 0 else 1), rep          # three chunks of 1,000
+        m.profile(False)
     batches = list(ds)
     calls = []
     orig = m.stage_csr
