@@ -8,7 +8,7 @@ one more sorts it by relation (`ConvE.group_next` = `coper_group_next`: pass n +
 ranks leave for pinned host memory beside pass n + 1's first launch (`ConvE.post_next` = `coper_post_i32_next`).
 One stream, no copy engine, no launch that only moves data -- except in front of the first pass and behind the last one.
 
-    python examples/eval_stream.py [--workload fb15k237_cpg] [--batches 6] [--queries 20480]"""
+    python examples/eval_stream.py [--workload fb15k237_cpg] [--batches 6] [--queries 20480] [--score-mode bf16x3|f32]"""
 import argparse
 import os
 import sys
@@ -43,11 +43,12 @@ def main(argv=None):
     ap.add_argument("--workload", default="fb15k237_cpg")
     ap.add_argument("--batches", type=int, default=6)
     ap.add_argument("--queries", type=int, default=None)
+    ap.add_argument("--score-mode", choices=["f32", "bf16x3"], default="bf16x3", help="bf16x3: the headline mode (ranks of the fp32 chain); f32: bit-exact logits")
     args = ap.parse_args(argv)
     md = cdata.model_descriptors(args.workload)
     Q = args.queries or cdata.CONFIGS[args.workload]["queries"]
     dev = torch.device("cuda", 0)
-    model = ConvE(md, device=dev).load_parameters(cdata.synthetic_params(md, 0)).prepare()
+    model = ConvE(md, device=dev, score_mode=args.score_mode).load_parameters(cdata.synthetic_params(md, 0)).prepare()
     batches = [cdata.synthetic_queries(md, Q, seed=s) for s in range(args.batches)]
     cap = max(len(b["filt_idx"]) for b in batches)
     packed = [pack(b, cap) for b in batches]
@@ -61,21 +62,26 @@ def main(argv=None):
     b0 = batches[0]
     model.rank_pass(b0["e1"], b0["rel"], b0["e2"], b0["filt_indptr"], b0["filt_idx"], want_equal=False)    # (warm-up: code objects, workspaces)
 
-    torch.cuda.synchronize(dev)
+    def stream():
+        model.widen_ids(packed[0][0], out=stages[0])                   # the first batch has no pass to arrive beside
+        for n in range(args.batches):
+            c = n & 1
+            if n + 1 < args.batches:
+                model.stage_next(packed[n + 1][0], stages[1 - c])          # batch n + 1: read beside this pass's encoder launch
+                model.group_next(views[1 - c]["e1"], views[1 - c]["rel"])  # ... and sorted by relation there: pass n + 1 starts with its encoder
+            v = views[c]
+            nnz = len(batches[n]["filt_idx"])
+            r, _ = model.rank_pass(v["e1"], v["rel"], v["e2"], v["filt_indptr"], v["filt_idx"][:nnz], filt_nnz=nnz, want_equal=False,
+                                   out=ranks_dev[c])
+            model.post_next(r, ranks_host[n])                          # ranks n: out beside pass n + 1's first launch
+        model.post_flush()                                             # ... and the last ones by a launch of their own
+        torch.cuda.synchronize(dev)
+
+    stream()                                                           # (the first run allocates the second set of grouping arrays)
+    for h in ranks_host:
+        h.fill_(-1)
     t0 = time.perf_counter()
-    model.widen_ids(packed[0][0], out=stages[0])                       # the first batch has no pass to arrive beside
-    for n in range(args.batches):
-        c = n & 1
-        if n + 1 < args.batches:
-            model.stage_next(packed[n + 1][0], stages[1 - c])          # batch n + 1: read beside this pass's encoder launch
-            model.group_next(views[1 - c]["e1"], views[1 - c]["rel"])  # ... and sorted by relation there: pass n + 1 starts with its encoder
-        v = views[c]
-        nnz = len(batches[n]["filt_idx"])
-        r, _ = model.rank_pass(v["e1"], v["rel"], v["e2"], v["filt_indptr"], v["filt_idx"][:nnz], filt_nnz=nnz, want_equal=False,
-                               out=ranks_dev[c])
-        model.post_next(r, ranks_host[n])                              # ranks n: out beside pass n + 1's first launch
-    model.post_flush()                                                 # ... and the last ones by a launch of their own
-    torch.cuda.synchronize(dev)
+    stream()
     dt = time.perf_counter() - t0
 
     for n, b in enumerate(batches):                                    # the same ranks as one pass at a time, nothing overlapped
