@@ -783,11 +783,13 @@ static int encode_partials(coper_handle* h, const int64_t* e1, const int64_t* re
 #else
     const bool fused = dense_fused_supported(h, ksplit);
 #endif
-    if (fused && h->gnext.pending && !stream_is_capturing(s)) {
+    // a coper_group_next registration is for THIS call only: it rides in the fused launch below or is dropped (a captured pass, a
+    // configuration without the fused encoder) -- never kept for a later call, whose caller may have freed the arrays it names
+    const bool want_group = h->gnext.pending;
+    h->gnext.pending = false;
+    if (fused && want_group && !stream_is_capturing(s)) {
       if ((rc = group_sets_ensure(h, s))) return rc;
       h->gnext.ride = true;
-    } else if (!fused) {
-      h->gnext.pending = false;     // (only the fused launch has the role)
     }
     if (pre && h->post_n > 0) {       // the job that rides in the grouping launch otherwise
       if (fused) h->post_here = true;

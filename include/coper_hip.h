@@ -198,7 +198,8 @@ COPER_API int coper_post_i32_next(coper_handle* h, const int32_t* src, int64_t n
  * tiles stream their weights; the following call with exactly these pointers and B (and ids unchanged in between) finds its
  * grouping done and starts with its encoder launch (a pending coper_post_i32_next job rides there instead).  Any other call in
  * between, a coper_prepare, a growing workspace or a pass captured into a hipGraph drops the prepared grouping: the pass then groups
- * itself as always -- results never depend on it.  Configurations the fused encoder does not serve ignore the registration.
+ * itself as always -- results never depend on it.  The registration is for the NEXT encode / encode_rank call only: a call that
+ * cannot carry it (captured into a hipGraph, a configuration the fused encoder does not serve) drops it.
  * Nothing is queued by this call; B == 0 cancels.  (h[b] is a function of (e1[b], rel[b]) alone either way.) */
 COPER_API int coper_group_next(coper_handle* h, const int64_t* e1, const int64_t* rel, int64_t B, int32_t have_e1_rows);
 
