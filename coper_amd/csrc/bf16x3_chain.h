@@ -192,7 +192,10 @@ __device__ __forceinline__ void exact_chain_pair(const float* __restrict__ er, c
     if (tr) t_out = exact_chain(tr, hr, bias_t, d);
     return;
   }
-  constexpr int CB = 5;
+#ifndef COPER_CHAIN_CB
+#define COPER_CHAIN_CB 5
+#endif
+  constexpr int CB = COPER_CHAIN_CB;     // k-steps of 8 values requested per round trip
   float s = bias_e, t = bias_t;
   const float4* e4 = (const float4*)er;
   const float4* t4 = (const float4*)(tr ? tr : er);
