@@ -182,6 +182,14 @@ __device__ __forceinline__ float exact_chain(const float* __restrict__ er, const
 // The same chain for the two logits of a comparison -- entity row `er` and target row `tr` (may be NULL: t_out untouched)
 // against one query row -- with the loads of CB k-steps of 8 issued before their fmas: a lane that walks a chain alone is
 // latency-bound on its row loads (25 dependent round trips to L2 at d = 200 took 25 us per chain; in batches of five: 5).
+#ifndef COPER_CHAIN_CB
+#define COPER_CHAIN_CB 5
+#endif
+// CB: k-steps of 8 values requested per round trip (5: the band walk of small tables, the tail kernels; 3: the band walk of a large
+// table or shard, which decides hundreds of thousands of pairs, one per lane -- there residency counts for more than round trips:
+// 10 M x 256, 4,096 queries: 44.1 -> 43.85 ms, a rank of eight 6.43 -> 6.37 ms; 8: slower everywhere).  The order of the chain's
+// fused multiply-adds does not depend on it.
+template <int CB = COPER_CHAIN_CB>
 __device__ __forceinline__ void exact_chain_pair(const float* __restrict__ er, const float* __restrict__ tr, const float* __restrict__ hr,
                                                  float bias_e, float bias_t, int d, float& s_out, float& t_out) {
   const int KS = (d + 7) >> 3;
@@ -192,10 +200,6 @@ __device__ __forceinline__ void exact_chain_pair(const float* __restrict__ er, c
     if (tr) t_out = exact_chain(tr, hr, bias_t, d);
     return;
   }
-#ifndef COPER_CHAIN_CB
-#define COPER_CHAIN_CB 5
-#endif
-  constexpr int CB = COPER_CHAIN_CB;     // k-steps of 8 values requested per round trip
   float s = bias_e, t = bias_t;
   const float4* e4 = (const float4*)er;
   const float4* t4 = (const float4*)(tr ? tr : er);

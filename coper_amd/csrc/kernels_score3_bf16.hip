@@ -964,6 +964,7 @@ struct BandArgs {
 };
 
 // returns true when the pair was decided by the chain; sx_out / tx_out: the chain's logits of the competitor and of the target
+template <int CB = COPER_CHAIN_CB>
 __device__ __forceinline__ bool band_decide(const BandArgs& A, const int64_t q, const int64_t e, float& sx_out, float& tx_out) {
   if (q >= A.Bc || e >= A.n_local || A.dbg == 1) return false;
   const int64_t eg = e + A.shard_lo, tq = A.e2[q];
@@ -991,11 +992,11 @@ __device__ __forceinline__ bool band_decide(const BandArgs& A, const int64_t q, 
   float sx, tx = 0.f;
   if (A.tgt_x) {
     tx = A.tgt_x[q];
-    exact_chain_pair(A.ent + e * A.d, nullptr, hr, A.bias[e], 0.f, A.d, sx, tx);
+    exact_chain_pair<CB>(A.ent + e * A.d, nullptr, hr, A.bias[e], 0.f, A.d, sx, tx);
   } else {
     const int64_t trow = tq - A.shard_lo;
-    if (trow >= 0 && trow < A.n_local) exact_chain_pair(A.ent + e * A.d, A.ent + trow * A.d, hr, A.bias[e], A.bias[trow], A.d, sx, tx);
-    else exact_chain_pair(A.ent + e * A.d, nullptr, hr, A.bias[e], 0.f, A.d, sx, tx);
+    if (trow >= 0 && trow < A.n_local) exact_chain_pair<CB>(A.ent + e * A.d, A.ent + trow * A.d, hr, A.bias[e], A.bias[trow], A.d, sx, tx);
+    else exact_chain_pair<CB>(A.ent + e * A.d, nullptr, hr, A.bias[e], 0.f, A.d, sx, tx);
   }
   if (sx > tx) atomicAdd(&A.ng[q], 1);
   else if (A.ne && sx == tx) atomicAdd(&A.ne[q], 1);
@@ -1104,6 +1105,7 @@ __device__ __forceinline__ void band_audit_group(const BandArgs& A, const unsign
 // units give ~90 (one walk) and 290 workgroups instead of 73
 constexpr int BE_CAP = 4096, BE_ITEMS = 2048, BE_UPW = COPER_BE_UPW;
 constexpr int BE_AUDIT = 128;     // pairs of a round the audit re-scores, 32 per wave (a workgroup walks ~90 at FB15k-237 shapes: all of them)
+template <int CB = COPER_CHAIN_CB>
 __device__ __forceinline__ void band_exact_body(const uint4* __restrict__ mask, const unsigned long long* __restrict__ summ, const int64_t n_units,
                                                 const unsigned rows4 /* rows per tile x 4 waves */, const BandArgs& A, const int64_t wg) {
   constexpr int MB = SC3_MB, NW = 2 * MB;      // 32-bit mask words per lane and row of a wave
@@ -1173,7 +1175,7 @@ __device__ __forceinline__ void band_exact_body(const uint4* __restrict__ mask, 
         for (int p = threadIdx.x; p < n; p += 256) {
           float sx = NAN, tx = 0.f;
           const int64_t pq = (int64_t)(s_p[p] >> 32), pe = (int64_t)(s_p[p] & 0xFFFFFFFFull);
-          bool dec = band_decide(A, pq, pe, sx, tx);
+          bool dec = band_decide<CB>(A, pq, pe, sx, tx);
           // Round 5: a query's own TARGET is always inside its band (it is the band's centre), so its pair is always listed --
           // and audited like a decided one: the chain's logit of the target against the mode's.  A band too narrow to hold any
           // competitor (nothing decided, nothing to audit: the audit was blind exactly when it mattered) still reports the error
@@ -1222,7 +1224,7 @@ __device__ __forceinline__ void band_exact_body(const uint4* __restrict__ mask, 
             const int V = 32 * (c % MB) + (31 - p);
             const int b = V / (4 * MB), m2 = (V >> 2) % MB, j = V & 3;
             float sx_u, tx_u;
-            band_decide(A, (int64_t)tile * 128 + 16 * b + (l & 15), (int64_t)(eb + c / MB) * (16 * MB) + 16 * m2 + 4 * (l >> 4) + j, sx_u, tx_u);
+            band_decide<CB>(A, (int64_t)tile * 128 + 16 * b + (l & 15), (int64_t)(eb + c / MB) * (16 * MB) + 16 * m2 + 4 * (l >> 4) + j, sx_u, tx_u);
           }
         }
       }
@@ -1230,9 +1232,10 @@ __device__ __forceinline__ void band_exact_body(const uint4* __restrict__ mask, 
   }
 }
 
+template <int CB>
 __global__ __launch_bounds__(256) void k_band_exact(const uint4* __restrict__ mask, const unsigned long long* __restrict__ summ, int64_t n_units,
                                                     unsigned rows4, BandArgs A) {
-  band_exact_body(mask, summ, n_units, rows4, A, blockIdx.x);
+  band_exact_body<CB>(mask, summ, n_units, rows4, A, blockIdx.x);
 }
 
 // k_filter_excess_bf16x3 -- the CSR entries beyond the first TL_OWN_ENTRIES of a 32-query block (real KGs hold (e1, rel) pairs
@@ -1469,7 +1472,12 @@ int score_count3_chunk_bf16x3(coper_handle* h, int64_t q0, int64_t Bc, const flo
         hipLaunchKernelGGL(k_band_excess_bf16x3<16>, dim3(n_band + FX_GRID), dim3(256), 0, s, (const uint4*)h->mask_ws, summ, n_units,
                            (unsigned)(rows_per_tile * 4), A, (int)n_band, F);
     } else {
-      hipLaunchKernelGGL(k_band_exact, dim3(n_band), dim3(256), 0, s, (const uint4*)h->mask_ws, summ, n_units, (unsigned)(rows_per_tile * 4), A);
+      // large tables / shards: hundreds of thousands of pairs, one per lane -- three k-steps per round trip keep more walks resident
+      // (bf16x3_chain.h: exact_chain_pair); the same chain, the same decisions
+      if (h->dm.n_local >= 500000)
+        hipLaunchKernelGGL(k_band_exact<3>, dim3(n_band), dim3(256), 0, s, (const uint4*)h->mask_ws, summ, n_units, (unsigned)(rows_per_tile * 4), A);
+      else
+        hipLaunchKernelGGL(k_band_exact<COPER_CHAIN_CB>, dim3(n_band), dim3(256), 0, s, (const uint4*)h->mask_ws, summ, n_units, (unsigned)(rows_per_tile * 4), A);
     }
     COPER_HIP_TRY(h, hipGetLastError());
   }
