@@ -1472,10 +1472,13 @@ int score_count3_chunk_bf16x3(coper_handle* h, int64_t q0, int64_t Bc, const flo
         hipLaunchKernelGGL(k_band_excess_bf16x3<16>, dim3(n_band + FX_GRID), dim3(256), 0, s, (const uint4*)h->mask_ws, summ, n_units,
                            (unsigned)(rows_per_tile * 4), A, (int)n_band, F);
     } else {
+#ifndef COPER_BAND_CB_LARGE
+#define COPER_BAND_CB_LARGE 3
+#endif
       // large tables / shards: hundreds of thousands of pairs, one per lane -- three k-steps per round trip keep more walks resident
       // (bf16x3_chain.h: exact_chain_pair); the same chain, the same decisions
       if (h->dm.n_local >= 500000)
-        hipLaunchKernelGGL(k_band_exact<3>, dim3(n_band), dim3(256), 0, s, (const uint4*)h->mask_ws, summ, n_units, (unsigned)(rows_per_tile * 4), A);
+        hipLaunchKernelGGL(k_band_exact<COPER_BAND_CB_LARGE>, dim3(n_band), dim3(256), 0, s, (const uint4*)h->mask_ws, summ, n_units, (unsigned)(rows_per_tile * 4), A);
       else
         hipLaunchKernelGGL(k_band_exact<COPER_CHAIN_CB>, dim3(n_band), dim3(256), 0, s, (const uint4*)h->mask_ws, summ, n_units, (unsigned)(rows_per_tile * 4), A);
     }
