@@ -101,6 +101,12 @@ hipError_t tracked_free(void* p) {
 
 ScopedKernelTimer::ScopedKernelTimer(coper_handle* h_, const char* n, hipStream_t s_) : h(h_), name(n), s(s_) {
   if (!h->profile) return;
+  {   // a pass being captured into a hipGraph is not timed: events recorded into a capture cannot be read back (found by a test that
+      // left the profile on while capturing: hipEventElapsedTime -> invalid resource handle at the next coper_profile_read)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (cap != hipStreamCaptureStatusNone) return;
+  }
   e0 = timer_event(h);
   e1 = timer_event(h);
   if (!e0 || !e1) { e0 = e1 = nullptr; return; }

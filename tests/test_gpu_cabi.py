@@ -490,6 +490,22 @@ def test_group_next_sorts_the_next_batch_beside_the_encoder(workload, Q):
     if n_ref is not None:
         assert m.check_ids() == n_ref
     assert m._lib.coper_group_next(m._h, None, None, 5, 0) == 1
+    # a pass captured into a hipGraph neither carries a registration nor consumes a prepared grouping: the registration made before
+    # the capture is dropped, replays and eager passes around them return the plain ranks
+    if Q <= 3000:
+        qd = {k: np.asarray(t.cpu()) for k, t in v1.items()}
+        m.group_next(v1["e1"], v1["rel"])
+        run = m.capture_rank_pass(Q, len(qd["filt_idx"]) + 8, want_equal=False)
+        for _ in range(2):
+            got = run(qd["e1"], qd["rel"], qd["e2"], qd["filt_indptr"], qd["filt_idx"])[0].cpu().numpy()
+            assert np.array_equal(got, base[1])
+        r1, _ = m.rank_pass(v1["e1"], v1["rel"], v1["e2"], v1["filt_indptr"], v1["filt_idx"], want_equal=False)
+        assert np.array_equal(r1.cpu().numpy(), base[1])
+        m.group_next(v1["e1"], v1["rel"])                      # prepared by an eager pass, then a replay in between, then the consumer
+        m.rank_pass(v0["e1"], v0["rel"], v0["e2"], v0["filt_indptr"], v0["filt_idx"], want_equal=False)
+        got = run(qd["e1"], qd["rel"], qd["e2"], qd["filt_indptr"], qd["filt_idx"])[0].cpu().numpy()
+        r1, _ = m.rank_pass(v1["e1"], v1["rel"], v1["e2"], v1["filt_indptr"], v1["filt_idx"], want_equal=False)
+        assert np.array_equal(got, base[1]) and np.array_equal(r1.cpu().numpy(), base[1])
     # the pass that follows hands its entity rows over itself (e1_rows: what the entity-sharded ranker's encoder gets)
     rows0, rows1 = m.gather_entities(v0["e1"]), m.gather_entities(v1["e1"])
     plain1, _ = m.rank_pass(None, v1["rel"], v1["e2"], v1["filt_indptr"], v1["filt_idx"], want_equal=False, e1_rows=rows1)
