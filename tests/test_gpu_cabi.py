@@ -506,6 +506,26 @@ def test_group_next_sorts_the_next_batch_beside_the_encoder(workload, Q):
         got = run(qd["e1"], qd["rel"], qd["e2"], qd["filt_indptr"], qd["filt_idx"])[0].cpu().numpy()
         r1, _ = m.rank_pass(v1["e1"], v1["rel"], v1["e2"], v1["filt_indptr"], v1["filt_idx"], want_equal=False)
         assert np.array_equal(got, base[1]) and np.array_equal(r1.cpu().numpy(), base[1])
+    # a prepared grouping does not survive coper_prepare or a growing workspace (the second sets are sized by it): the consumer groups
+    # itself, and the chain works again afterwards
+    m.profile(True); m.profile_read("group")
+    m.group_next(v1["e1"], v1["rel"])
+    m.rank_pass(v0["e1"], v0["rel"], v0["e2"], v0["filt_indptr"], v0["filt_idx"], want_equal=False)
+    m._prepared = False
+    m.prepare()
+    r1, _ = m.rank_pass(v1["e1"], v1["rel"], v1["e2"], v1["filt_indptr"], v1["filt_idx"], want_equal=False)
+    assert np.array_equal(r1.cpu().numpy(), base[1]) and m.profile_read("group")[1] == 2
+    m.group_next(v1["e1"], v1["rel"])
+    m.rank_pass(v0["e1"], v0["rel"], v0["e2"], v0["filt_indptr"], v0["filt_idx"], want_equal=False)
+    qbig = cdata.synthetic_queries(md, 2 * Q + 300, seed=91)
+    rbig, _ = m.rank_pass(qbig["e1"], qbig["rel"], qbig["e2"], qbig["filt_indptr"], qbig["filt_idx"], want_equal=False)     # (the workspace grows)
+    r1, _ = m.rank_pass(v1["e1"], v1["rel"], v1["e2"], v1["filt_indptr"], v1["filt_idx"], want_equal=False)
+    assert np.array_equal(r1.cpu().numpy(), base[1])
+    m.profile_read("group")
+    m.group_next(v1["e1"], v1["rel"])
+    r0, _ = m.rank_pass(v0["e1"], v0["rel"], v0["e2"], v0["filt_indptr"], v0["filt_idx"], want_equal=False)
+    r1, _ = m.rank_pass(v1["e1"], v1["rel"], v1["e2"], v1["filt_indptr"], v1["filt_idx"], want_equal=False)
+    assert np.array_equal(r0.cpu().numpy(), base[0]) and np.array_equal(r1.cpu().numpy(), base[1]) and m.profile_read("group")[1] == 1
     # the pass that follows hands its entity rows over itself (e1_rows: what the entity-sharded ranker's encoder gets)
     rows0, rows1 = m.gather_entities(v0["e1"]), m.gather_entities(v1["e1"])
     plain1, _ = m.rank_pass(None, v1["rel"], v1["e2"], v1["filt_indptr"], v1["filt_idx"], want_equal=False, e1_rows=rows1)
