@@ -1312,11 +1312,12 @@ static int train_step_impl(coper_handle* h, const int64_t* e1, const int64_t* re
     if (!one_vs_all && dense_scorer_bwd) add(T->Sd, sizeof(float) * B * dm.E);
     hipLaunchKernelGGL(k_tr_zero_list, dim3(256, (unsigned)zl.n), dim3(256), 0, s, zl);
   }
+  // (a coper_group_next registration, or a grouping prepared ahead, was for an evaluation pass: a training step drops both)
+  h->gnext.pending = false; h->gnext.ride = false; h->gdone.done = false;
   if (lk) {
     // group the batch by relation (perm / rel_offset / rel_count of the inference path): the table gradient is
     // written per present relation, never zero-filled (1.75 GB at FB15k-237 shapes)
     if ((rc = coper_reserve(h, B, 0, stream))) return rc;
-    h->gnext.pending = false; h->gnext.ride = false; h->gdone.done = false;      // (a coper_group_next registration was for an evaluation pass)
     group_use_set(h, 0);
     if ((rc = launch_group_by_relation(h, e1, rel, false, B, 32, s))) return rc;
   }

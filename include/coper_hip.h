@@ -182,7 +182,7 @@ COPER_API int coper_stage_ids_next(coper_handle* h, const int32_t* src, int64_t 
 COPER_API int coper_copy_out_i32(coper_handle* h, const int32_t* src, int64_t n, int32_t* dst, void* stream);
 
 /* The same copy, overlapped: registers (src, n, dst) as a job the NEXT call on this handle that groups a batch by relation
- * (coper_encode, coper_encode_rank, a training step) carries out beside its first launch, on that call's stream: the ranks of pass
+ * (coper_encode, coper_encode_rank, a training step of a parameter-lookup model) carries out beside its first launch, on that call's stream: the ranks of pass
  * n reach the host under pass n + 1's histogram instead of through a launch of their own behind pass n.  src must stay
  * unchanged until then (it is: the next pass writes its ranks in its third launch); the last pass of a loop is followed by
  * coper_copy_out_i32.  A later registration replaces a job that has not run; n == 0 cancels; a call that is being captured into

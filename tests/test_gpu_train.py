@@ -616,3 +616,47 @@ def test_one_vs_all_training_through_the_loader():
     assert np.mean(losses[-20:]) < 0.7 * np.mean(losses[:20]), (losses[:3], losses[-3:])
     assert mrr1 > mrr0 + 0.1, (mrr0, mrr1)
     m.close()
+
+
+def test_training_steps_between_streamed_evaluation_passes():
+    """An evaluation stream interrupted by training steps (run_cpg.py:211-250: train, then evaluate, then train on): a registration
+    made with coper_group_next and a grouping prepared ahead do not survive a training step, ranks registered with
+    coper_post_i32_next leave with the next call that sorts a batch by relation (the step itself for a parameter-lookup model, the
+    next evaluation pass otherwise), and the evaluation passes around the steps return what plain passes return on the weights of
+    the moment."""
+    from coper_amd.models import ConvE
+    for case in ("cpg_linear", "lookup"):
+        md = dict(cdata._COMMON)
+        md.update(_CASES[case])
+        md.update(batch_norm_train_stats=True, batch_norm_momentum=0.9, hidden_dropout=0.3, output_dropout=0.2,
+                  label_smoothing_epsilon=0.1, learning_rate=0.003)
+        p0 = cdata.synthetic_params(md, seed=8, ent_std=0.1)
+        m = ConvE(md, device="cuda:0", score_mode="bf16x3")
+        m.load_parameters({k: torch.as_tensor(np.array(v, np.float32)) for k, v in p0.items()})
+        m.train_init(seed=11)
+        Q = 300
+        qa, qb = cdata.synthetic_queries(md, Q, seed=5), cdata.synthetic_queries(md, Q, seed=6)
+        da = {k: torch.as_tensor(np.asarray(v)).to("cuda:0") for k, v in qa.items()}
+        db = {k: torch.as_tensor(np.asarray(v)).to("cuda:0") for k, v in qb.items()}
+
+        def plain(d):
+            return m.rank_pass(d["e1"], d["rel"], d["e2"], d["filt_indptr"], d["filt_idx"], want_equal=False)[0].cpu().numpy()
+
+        host = torch.full((Q,), -1, dtype=torch.int32).pin_memory()
+        ranks = torch.empty(Q, dtype=torch.int32, device="cuda:0")
+        for rep in range(3):
+            want_a = plain(da)
+            m.group_next(db["e1"], db["rel"])                      # B is announced as the pass after the next one ...
+            r, _ = m.rank_pass(da["e1"], da["rel"], da["e2"], da["filt_indptr"], da["filt_idx"], want_equal=False, out=ranks)
+            m.post_next(r, host)
+            m.group_next(da["e1"], da["rel"])                      # ... and one more registration that no evaluation pass will carry
+            m.train_step(_batch(md, 40, 29, seed=20 + rep))        # the weights move
+            torch.cuda.synchronize()
+            if case == "lookup":                                   # (its step sorted its batch: the ranks left beside that launch)
+                assert np.array_equal(host.numpy(), want_a), rep
+            got_b, _ = m.rank_pass(db["e1"], db["rel"], db["e2"], db["filt_indptr"], db["filt_idx"], want_equal=False)
+            got_b = got_b.cpu().numpy()
+            assert np.array_equal(host.numpy(), want_a), (case, rep)
+            assert np.array_equal(got_b, plain(db)), (case, rep)   # (on the NEW weights: nothing of the old grouping or planes was used)
+            host.fill_(-1)
+        m.close()
