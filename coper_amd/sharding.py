@@ -141,6 +141,9 @@ class EntityShardedRanker(object):
     def _gather_rows(self, e1, e2):
         """step 1: (ent_emb[e1] [B,d], ent_emb[e2] [B,d], pred_bias[e2] [B]) from ONE all-gather of the owned rows"""
         sc = self.scorer
+        # (ids are compared BY VALUE with the cached plan's: a device tensor costs a synchronising copy per chunk -- pass NumPy arrays.
+        #  Identity + torch's version counter would not do: the library's own kernels write id buffers through raw pointers
+        #  (coper_widen_ids, coper_stage_ids_next), which no counter sees)
         e1_np = np.asarray(e1.cpu() if isinstance(e1, torch.Tensor) else e1).astype(np.int64)
         e2_np = np.asarray(e2.cpu() if isinstance(e2, torch.Tensor) else e2).astype(np.int64)
         B = len(e1_np)
