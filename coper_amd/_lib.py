@@ -15,6 +15,7 @@ COPER_ABI_VERSION = 3
 COPER_MAX_CTX = 8
 
 SCORE_F32, SCORE_BF16X3 = 0, 1
+RANK_STALE = -(1 << 30)      # COPER_RANK_STALE (include/coper_hip.h)
 
 STATUS = {0: "COPER_OK", 1: "COPER_EINVAL", 2: "COPER_EMISSING", 3: "COPER_ESHAPE", 4: "COPER_EHIP",
           5: "COPER_ESTATE", 6: "COPER_ENOMEM", 7: "COPER_EUNSUPPORTED"}
@@ -43,7 +44,7 @@ class coper_config(C.Structure):
         ("context_rel_use_batch_norm", C.c_int32), ("bn_epsilon", C.c_float),
         ("shard_lo", C.c_int64), ("shard_hi", C.c_int64),
         ("score_mode", C.c_int32), ("rank_band_kappa", C.c_float), ("x3_ent_absmax", C.c_float),
-        ("band_audit_period", C.c_int32), ("reserved", C.c_int32 * 4),
+        ("band_audit_period", C.c_int32), ("role", C.c_int32), ("reserved", C.c_int32 * 3),
     ]
 
 
@@ -98,6 +99,7 @@ PROTOTYPES = {
     "coper_rank": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P]),
     "coper_encode_rank": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P]),
     "coper_check_ids": (C.c_int, [_P, C.POINTER(_I64), _P]),
+    "coper_stale_passes": (C.c_int, [_P, C.POINTER(_I64), _P]),
     "coper_live_device_bytes": (_I64, []),
     "coper_profile_enable": (C.c_int, [_P, C.c_int]),
     "coper_profile_read": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_I64)]),
@@ -148,8 +150,11 @@ def check(handle, rc):
         raise CoperError(rc, text.decode() if text else "")
 
 
+ROLE_BOTH, ROLE_ENCODE, ROLE_SCORE = 0, 1, 2     # coper_role
+
+
 def make_config(md, device=0, shard=None, score_mode=SCORE_F32, bn_epsilon=1e-3, rank_band_kappa=0.0, x3_ent_absmax=0.0,
-                band_audit_period=0):
+                band_audit_period=0, role=ROLE_BOTH):
     """model_descriptors dict (models.py:98-130 keys) -> coper_config."""
     cfg = coper_config()
     cfg.abi_version = COPER_ABI_VERSION
@@ -187,4 +192,5 @@ def make_config(md, device=0, shard=None, score_mode=SCORE_F32, bn_epsilon=1e-3,
     cfg.rank_band_kappa = float(rank_band_kappa)     # 0: the library default (include/coper_hip.h)
     cfg.x3_ent_absmax = float(x3_ent_absmax)         # 0: the handle's own rows; entity shards pass the table-wide maximum
     cfg.band_audit_period = int(band_audit_period)   # 0: the library default (first count launch, then every 8th)
+    cfg.role = int(role)                             # 0: encoder and scorer (every handle before round 6)
     return cfg

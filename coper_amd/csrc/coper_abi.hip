@@ -197,7 +197,8 @@ void group_sets_free(coper_handle* h) {
     if (g.fused_fin_dev) (void)tracked_free(g.fused_fin_dev);
     g = coper_handle::GroupSet();
   }
-  h->gnext.ride = false; h->gdone.done = false;
+  h->pipe.invalidate_grouping();
+  h->pass_chk = nullptr;
 }
 
 // sets 1 and 2 at the capacity of the workspace (which exists: the caller is a pass being enqueued), with their finalize constants
@@ -209,7 +210,7 @@ int group_sets_ensure(coper_handle* h, hipStream_t s) {
   group_use_set(h, 0);
   const size_t cap = (size_t)h->ws_queries, r2 = (size_t)dm.R + 2, nt = 4 * (cap / 32 + (size_t)dm.R + 4);
   auto up4 = [](size_t n) { return (n + 3) & ~(size_t)3; };      // (16-byte pieces)
-  const size_t total = 2 * up4(r2) + 4 * up4(cap) + up4(nt) + 4 + (size_t)X3M_SLOTS;
+  const size_t total = 2 * up4(r2) + 4 * up4(cap) + up4(nt) + 4 + (size_t)X3M_SLOTS + 2 * GROUP_CHK_WORDS;
   for (int i = 1; i < 3; ++i) {
     coper_handle::GroupSet& g = h->gset[i];
     if (g.slab) continue;
@@ -224,7 +225,8 @@ int group_sets_ensure(coper_handle* h, hipStream_t s) {
     g.sorted_rid = p; p += up4(cap);
     g.tiles = p; p += up4(nt);
     g.n_tiles = p; p += 4;
-    g.x3m = (float*)p;
+    g.x3m = (float*)p; p += X3M_SLOTS;       // (a multiple of four words: the check words below are 8-byte aligned)
+    g.chk = (int64_t*)p;
   }
   int rc = fused_fin_update(h, s);
   group_use_set(h, cur);
@@ -242,6 +244,11 @@ static int ensure_workspace(coper_handle* h, int64_t B, int64_t nnz, hipStream_t
   }
   if (B <= h->ws_queries && h->perm) return COPER_OK;
   COPER_HIP_TRY(h, hipStreamSynchronize(s));
+  if (h->group_done) {          // (the device counter of coper_stale_passes lives in the slab replaced below)
+    int32_t v = 0;
+    COPER_HIP_TRY(h, hipMemcpy(&v, h->group_done + 2, sizeof v, hipMemcpyDeviceToHost));
+    h->stale_passes_host += v;
+  }
   group_sets_free(h);           // (sized by the workspace; back on the home set before its arrays move)
   int64_t cap = B < 64 ? 64 : B;
   int rc;
@@ -357,6 +364,8 @@ COPER_API int coper_create(const coper_config* cfg, coper_handle** out) {
   if (cfg->shard_lo < 0 || cfg->shard_hi > dm.E || cfg->shard_lo >= cfg->shard_hi) return bad("entity shard [lo,hi) out of range");
   if (cfg->score_mode != COPER_SCORE_F32 && cfg->score_mode != COPER_SCORE_BF16X3)
     return bad("score_mode: COPER_SCORE_F32 or COPER_SCORE_BF16X3");
+  if (cfg->role != COPER_ROLE_BOTH && cfg->role != COPER_ROLE_ENCODE && cfg->role != COPER_ROLE_SCORE)
+    return bad("role: COPER_ROLE_BOTH, COPER_ROLE_ENCODE or COPER_ROLE_SCORE");
   // models.py:360: e1 stacked on the reshaped relation only for plain ConvE
   dm.stacked = !dm.gen_conv && !dm.gen_fc && !dm.lookup;
   dm.in_h = dm.emb_h; dm.in_w = dm.emb_w;
@@ -535,7 +544,7 @@ COPER_API int coper_prepare(coper_handle* h, void* stream) {
   COPER_HIP_TRY(h, hipSetDevice(cfg.device));
   int rc;
   group_use_set(h, 0);          // (x3m of the home set is re-allocated below; a grouping done ahead does not survive a prepare)
-  h->gnext.pending = false; h->gnext.ride = false; h->gdone.done = false;
+  h->pipe.invalidate_grouping();
   if ((rc = dev_alloc(h, &h->conv_scale, dm.C)) || (rc = dev_alloc(h, &h->conv_shift, dm.C)) ||
       (rc = dev_alloc(h, &h->fc_scale, dm.d)) || (rc = dev_alloc(h, &h->fc_shift, dm.d)))
     return rc;
@@ -575,6 +584,12 @@ COPER_API int coper_prepare(coper_handle* h, void* stream) {
     }
   }
 
+  const bool role_enc = cfg.role != COPER_ROLE_SCORE, role_score = cfg.role != COPER_ROLE_ENCODE;
+  h->enc_bf16 = false;
+  h->x_exp = 0;
+  h->band_launches = 0;
+  h->Rw = 0;
+  if (role_enc) {      // ---- the encoder's derived state (a COPER_ROLE_SCORE handle has none: no generator evaluated, no W_r cached)
   // scratch for generator hidden activations: R * max_hidden (+ 2 * max_hidden for the folded BN)
   int max_hidden = 1;
   for (int i = 0; i < cfg.n_ctx_conv; ++i) max_hidden = cfg.ctx_conv[i] > max_hidden ? cfg.ctx_conv[i] : max_hidden;
@@ -621,8 +636,6 @@ COPER_API int coper_prepare(coper_handle* h, void* stream) {
     if ((rc = launch_gen_dense_frag(h, nullptr, 1, 0, P("fc_weights"), 1, h->Wf, s))) return rc;
   }
   h->enc_bf16 = cfg.score_mode != COPER_SCORE_F32 && conv_bf16_supported(dm);
-  h->x_exp = 0;
-  h->band_launches = 0;
   if (h->enc_bf16) {
     size_t plane = (size_t)h->Rw * dm.nfb * w16_ks_stride(dm) * 64 * 16;
     dev_free((char**)&h->Wf16_hi); dev_free((char**)&h->Wf16_lo); dev_free((char**)&h->Wf8_lo);
@@ -639,8 +652,10 @@ COPER_API int coper_prepare(coper_handle* h, void* stream) {
     COPER_HIP_TRY(h, hipStreamSynchronize(s));
     dev_free(&h->Wf);  // the fp32 image was only the staging form
   }
-  // entity table image(s)
-  if (cfg.score_mode == COPER_SCORE_F32) {
+  }                    // ---- (role_enc)
+  // entity table image(s) (a COPER_ROLE_ENCODE handle has none)
+  if (!role_score) {
+  } else if (cfg.score_mode == COPER_SCORE_F32) {
     if ((rc = dev_alloc(h, &h->Ef, (size_t)dm.n_eblk * dm.KS * 64 * 4)) || (rc = dev_alloc(h, &h->bias_pad, (size_t)dm.n_eblk * 32)))
       return rc;
     if ((rc = launch_entity_frag(h, P("ent_emb"), P("pred_bias"), s))) return rc;
@@ -670,7 +685,7 @@ COPER_API int coper_prepare(coper_handle* h, void* stream) {
     const int64_t share = (int64_t)(prop.totalGlobalMem / 32 / sizeof(float));
     h->gmax_max_floats = share > ((int64_t)1 << 28) ? share : ((int64_t)1 << 28);
   }
-  if (cfg.score_mode == COPER_SCORE_F32 && (rc = score_kernels_init(h))) return rc;
+  if (role_score && cfg.score_mode == COPER_SCORE_F32 && (rc = score_kernels_init(h))) return rc;
   if ((rc = fused_fin_update(h, s))) return rc;       // (parameters / exponents moved)
   h->prepared = true;
   return COPER_OK;
@@ -686,6 +701,15 @@ COPER_API int coper_reserve(coper_handle* h, int64_t max_queries, int64_t max_fi
   do {                                                                                      \
     if (!(h)) return COPER_EINVAL;                                                          \
     if (!(h)->prepared) return fail((h), COPER_ESTATE, "coper_prepare has not been called"); \
+  } while (0)
+// coper_config.role: the entry points of the other role are refused, loudly (their derived buffers do not exist)
+#define COPER_REQUIRE_ENCODER(h)                                                                                                   \
+  do {                                                                                                                             \
+    if ((h)->cfg.role == COPER_ROLE_SCORE) return fail((h), COPER_ESTATE, "the handle was created with COPER_ROLE_SCORE: no encoder"); \
+  } while (0)
+#define COPER_REQUIRE_SCORER(h)                                                                                                     \
+  do {                                                                                                                              \
+    if ((h)->cfg.role == COPER_ROLE_ENCODE) return fail((h), COPER_ESTATE, "the handle was created with COPER_ROLE_ENCODE: no scorer"); \
   } while (0)
 
 COPER_API int coper_copy_out_i32(coper_handle* h, const int32_t* src, int64_t n, int32_t* dst, void* stream) {
@@ -705,23 +729,24 @@ COPER_API int coper_widen_ids(coper_handle* h, const int32_t* src, int64_t n, in
 COPER_API int coper_stage_ids_next(coper_handle* h, const int32_t* src, int64_t n, int64_t* dst) {
   if (!h) return COPER_EINVAL;
   if (n < 0 || (n > 0 && (!src || !dst))) return fail(h, COPER_EINVAL, "coper_stage_ids_next: bad argument");
-  h->stage_src = src; h->stage_n = n; h->stage_dst = dst;
+  h->pipe.stage.src = src; h->pipe.stage.n = n; h->pipe.stage.dst = dst;
   return COPER_OK;
 }
 
 COPER_API int coper_post_i32_next(coper_handle* h, const int32_t* src, int64_t n, int32_t* dst) {
   if (!h) return COPER_EINVAL;
   if (n < 0 || (n > 0 && (!src || !dst))) return fail(h, COPER_EINVAL, "coper_post_i32_next: bad argument");
-  h->post_src = src; h->post_n = n; h->post_dst = dst;
+  h->pipe.post.src = src; h->pipe.post.n = n; h->pipe.post.dst = dst;
   return COPER_OK;
 }
 
 COPER_API int coper_group_next(coper_handle* h, const int64_t* e1, const int64_t* rel, int64_t B, int32_t have_e1_rows) {
   if (!h) return COPER_EINVAL;
   if (B < 0 || (B > 0 && (!rel || (!e1 && !have_e1_rows)))) return fail(h, COPER_EINVAL, "coper_group_next: bad argument");
-  h->gnext.e1 = have_e1_rows ? nullptr : e1; h->gnext.rel = rel; h->gnext.B = B; h->gnext.rows = have_e1_rows ? 1 : 0;
-  h->gnext.pending = B > 0;
-  h->gnext.ride = false;
+  auto& g = h->pipe.gnext;
+  g.e1 = have_e1_rows ? nullptr : e1; g.rel = rel; g.B = B; g.rows = have_e1_rows ? 1 : 0;
+  g.pending = B > 0;
+  g.ride = false;
   return COPER_OK;
 }
 
@@ -742,7 +767,8 @@ static bool stream_is_capturing(hipStream_t s) {
 // h_x3: where the x3 encoder may write finished h rows when its launch can finalize them itself (dense_fused_finalizes);
 // *finalized says whether it did (the caller then skips its finalize launch)
 static int encode_partials(coper_handle* h, const int64_t* e1, const int64_t* rel, int64_t B, const float* e1_rows, hipStream_t s,
-                           int* ksplit_out, float* h_out_f32_path, float* h_x3 = nullptr, bool* finalized = nullptr) {
+                           int* ksplit_out, float* h_out_f32_path, float* h_x3 = nullptr, bool* finalized = nullptr,
+                           bool consume_prepared = false) {
   if (finalized) *finalized = false;
   const Dims& dm = h->dm;
   int rc;
@@ -767,18 +793,17 @@ static int encode_partials(coper_handle* h, const int64_t* e1, const int64_t* re
 #endif
   if (ksplit > h->ws_ksplit) ksplit = h->ws_ksplit;
   *ksplit_out = ksplit;
-  // coper_group_next: a pass whose batch was sorted in the shadow of the last one (into set gnext.set) skips its grouping launches
+  // coper_group_next: a pass whose batch was sorted in the shadow of the last one skips its grouping launches.  Only a pass that
+  // writes ranks (consume_prepared: coper_encode_rank) may run on such a grouping: its tiles check it against the live ids and the
+  // kernel that presets its rank counters acts on the verdict (group_body.h: the guard).  Whatever else comes next drops it.
   bool pre = false;
   {
-    auto& g = h->gdone;
-    if (g.done) {
-      pre = g.rel == rel && g.e1 == (e1_rows ? nullptr : e1) && g.B == B && g.rows == (e1_rows ? 1 : 0) && h->gset[g.set].slab != nullptr &&
-            !stream_is_capturing(s);
-      g.done = false;          // (consumed or dropped: it was the NEXT pass's)
-    }
-    group_use_set(h, pre ? g.set : 0);
+    int set = 0;
+    pre = h->pipe.take_prepared(e1, rel, B, e1_rows ? 1 : 0, &set) && consume_prepared && h->gset[set].slab != nullptr && !stream_is_capturing(s);
+    group_use_set(h, pre ? set : 0);
+    h->pass_chk = pre ? h->gset[set].chk : nullptr;
   }
-  h->post_here = false;
+  h->pipe.post.here = false;
   if (!pre) {
     ScopedKernelTimer t(h, "group", s);
     if ((rc = launch_group_by_relation(h, e1, rel, e1_rows != nullptr, B, tq, s))) return rc;
@@ -791,24 +816,21 @@ static int encode_partials(coper_handle* h, const int64_t* e1, const int64_t* re
 #endif
     // a coper_group_next registration is for THIS call only: it rides in the fused launch below or is dropped (a captured pass, a
     // configuration without the fused encoder) -- never kept for a later call, whose caller may have freed the arrays it names
-    const bool want_group = h->gnext.pending;
-    h->gnext.pending = false;
+    const bool want_group = h->pipe.gnext.pending;
+    h->pipe.gnext.pending = false;
     if (fused && want_group && !stream_is_capturing(s)) {
       if ((rc = group_sets_ensure(h, s))) return rc;
-      h->gnext.ride = true;
+      h->pipe.gnext.ride = true;
     }
-    if (pre && h->post_n > 0) {       // the job that rides in the grouping launch otherwise
-      if (fused) h->post_here = true;
-      else {
-        const int64_t pn = h->post_n;
-        h->post_n = 0;
-        if ((rc = launch_copy_i32(h, h->post_src, pn, h->post_dst, s))) return rc;
+    if (pre && h->pipe.post.n > 0) {       // the job that rides in the grouping launch otherwise
+      if (fused) h->pipe.post.here = true;
+      else if (const int64_t pn = h->pipe.take_post()) {
+        if ((rc = launch_copy_i32(h, h->pipe.post.src, pn, h->pipe.post.dst, s))) return rc;
       }
     }
-    if (!fused && h->stage_n > 0) {     // (a pending coper_stage_ids_next rides in the fused launch only)
-      const int64_t n = h->stage_n;
-      h->stage_n = 0;
-      if ((rc = launch_widen_ids(h, h->stage_src, n, h->stage_dst, s))) return rc;
+    if (!fused) {                           // (a pending coper_stage_ids_next rides in the fused launch only)
+      if (const int64_t n = h->pipe.take_stage())
+        if ((rc = launch_widen_ids(h, h->pipe.stage.src, n, h->pipe.stage.dst, s))) return rc;
     }
     if (fused) {   // one launch serves every tile: conv, BN, ReLU and the dense layer (kernels_dense_fused_bf16.hip)
       ScopedKernelTimer t(h, "dense", s);
@@ -822,12 +844,9 @@ static int encode_partials(coper_handle* h, const int64_t* e1, const int64_t* re
     }
     return COPER_OK;
   }
-  h->gnext.pending = false;
-  if (h->stage_n > 0) {
-    const int64_t n = h->stage_n;
-    h->stage_n = 0;
-    if ((rc = launch_widen_ids(h, h->stage_src, n, h->stage_dst, s))) return rc;
-  }
+  h->pipe.gnext.pending = false;
+  if (const int64_t n = h->pipe.take_stage())
+    if ((rc = launch_widen_ids(h, h->pipe.stage.src, n, h->pipe.stage.dst, s))) return rc;
   if ((rc = launch_conv(h, e1, rel, e1_rows, B, s))) return rc;
   return launch_dense(h, rel, B, tq, ksplit, h_out_f32_path, s);   // fp32 mode: finalize included
 }
@@ -835,6 +854,7 @@ static int encode_partials(coper_handle* h, const int64_t* e1, const int64_t* re
 COPER_API int coper_encode(coper_handle* h, const int64_t* e1, const int64_t* rel, int64_t B, const float* e1_rows,
                  float* h_out, void* stream) {
   COPER_REQUIRE_PREPARED(h);
+  COPER_REQUIRE_ENCODER(h);
   if (B == 0) return COPER_OK;  // empty batch: nothing to do (the reference's session.run on an empty batch returns [0,d])
   if (!rel || !h_out || B < 0 || (!e1 && !e1_rows)) return fail(h, COPER_EINVAL, "coper_encode: bad argument");
   if (B > 0x7fffffff) return fail(h, COPER_EINVAL, "coper_encode: batch too large");
@@ -848,6 +868,7 @@ COPER_API int coper_encode(coper_handle* h, const int64_t* e1, const int64_t* re
 
 COPER_API int coper_score_all(coper_handle* h, const float* hvec, int64_t B, float* logits, int64_t ld, void* stream) {
   COPER_REQUIRE_PREPARED(h);
+  COPER_REQUIRE_SCORER(h);
   if (B == 0) return COPER_OK;
   if (!hvec || !logits || B < 0 || ld < h->dm.n_local) return fail(h, COPER_EINVAL, "coper_score_all: bad argument");
   hipStream_t s = (hipStream_t)stream;
@@ -859,6 +880,7 @@ COPER_API int coper_score_all(coper_handle* h, const float* hvec, int64_t B, flo
 COPER_API int coper_score_lookup(coper_handle* h, const float* hvec, const int32_t* lookup, int64_t B, int64_t L, float* out,
                        void* stream) {
   COPER_REQUIRE_PREPARED(h);
+  COPER_REQUIRE_SCORER(h);
   if (B == 0 || L == 0) return COPER_OK;  // eval batches carry lookup_values of shape [B, 0] (data.py:205-213)
   if (!hvec || !lookup || !out || B < 0 || L < 0) return fail(h, COPER_EINVAL, "coper_score_lookup: bad argument");
   hipStream_t s = (hipStream_t)stream;
@@ -870,6 +892,7 @@ COPER_API int coper_score_lookup(coper_handle* h, const float* hvec, const int32
 
 COPER_API int coper_target_scores(coper_handle* h, const float* hvec, const int64_t* e2, int64_t B, float* tgt, void* stream) {
   COPER_REQUIRE_PREPARED(h);
+  COPER_REQUIRE_SCORER(h);
   if (B == 0) return COPER_OK;
   if (!hvec || !e2 || !tgt || B < 0) return fail(h, COPER_EINVAL, "coper_target_scores: bad argument");
   hipStream_t s = (hipStream_t)stream;
@@ -896,6 +919,7 @@ COPER_API int coper_rank_counts(coper_handle* h, const float* hvec, const float*
                       const int64_t* filt_indptr, const int64_t* filt_idx, int64_t filt_nnz, int64_t B, int32_t k,
                       int32_t* n_greater, int32_t* n_equal, float* topk_val, int64_t* topk_idx, void* stream) {
   COPER_REQUIRE_PREPARED(h);
+  COPER_REQUIRE_SCORER(h);
   if (B == 0) return COPER_OK;
   if (!hvec || !tgt || !e2 || !filt_indptr || !n_greater || B < 0 || filt_nnz < 0 ||
       (filt_nnz > 0 && !filt_idx))
@@ -983,6 +1007,7 @@ COPER_API int coper_rank_counts(coper_handle* h, const float* hvec, const float*
 COPER_API int coper_rank(coper_handle* h, const float* hvec, const int64_t* e2, const int64_t* filt_indptr,
                const int64_t* filt_idx, int64_t filt_nnz, int64_t B, int32_t* ranks, int32_t* n_equal, void* stream) {
   COPER_REQUIRE_PREPARED(h);
+  COPER_REQUIRE_SCORER(h);
   if (B == 0) return COPER_OK;
   if (!ranks || B < 0) return fail(h, COPER_EINVAL, "coper_rank: bad argument");
   if (h->dm.n_local != h->dm.E) return fail(h, COPER_ESTATE, "coper_rank needs the whole table; sharded handles use coper_target_scores + coper_rank_counts");
@@ -1019,6 +1044,8 @@ COPER_API int coper_encode_rank(coper_handle* h, const int64_t* e1, const int64_
                                 const int64_t* filt_indptr, const int64_t* filt_idx, int64_t filt_nnz, int64_t B, float* h_out,
                                 int32_t* ranks, int32_t* n_equal, void* stream) {
   COPER_REQUIRE_PREPARED(h);
+  COPER_REQUIRE_ENCODER(h);
+  COPER_REQUIRE_SCORER(h);
   if (B == 0) return COPER_OK;
   if (!rel || !e2 || !filt_indptr || !ranks || B < 0 || filt_nnz < 0 || (!e1 && !e1_rows) || (filt_nnz > 0 && !filt_idx))
     return fail(h, COPER_EINVAL, "coper_encode_rank: bad argument");
@@ -1026,6 +1053,7 @@ COPER_API int coper_encode_rank(coper_handle* h, const int64_t* e1, const int64_
   if (h->dm.n_local != h->dm.E) return fail(h, COPER_ESTATE, "coper_encode_rank needs the whole table (see coper_rank)");
   hipStream_t s = (hipStream_t)stream;
   int rc, ksplit = 1;
+  struct ClearChk { coper_handle* h; ~ClearChk() { h->pass_chk = nullptr; } } clear_chk{h};   // (the guard's verdict belongs to this call's launches only)
   // the embedding is needed in fp32 either way: the fp32-exact mode scores from it, the bf16x3 mode's exact band re-scores from it
   if ((rc = ensure_rank_workspace(h, B, filt_nnz, h_out == nullptr, s))) return rc;
   float* hv = h_out ? h_out : h->h_ws;
@@ -1037,7 +1065,7 @@ COPER_API int coper_encode_rank(coper_handle* h, const int64_t* e1, const int64_
   // bf16x3: the finalize writes h straight into the planes the rank kernels read (and the fp32 rows the exact band needs) and
   // presets the counters, which accumulate into `ranks` from 1: no pack, zero or finish launch
   bool finalized = false;
-  if ((rc = encode_partials(h, e1, rel, B, e1_rows, s, &ksplit, nullptr, hv, &finalized))) return rc;
+  if ((rc = encode_partials(h, e1, rel, B, e1_rows, s, &ksplit, nullptr, hv, &finalized, true))) return rc;
   if (!n_equal && tail_fused_supported(h)) {
     // ranks only (what the reference computes): finalize, targets, the band and the filter correction in ONE launch
     // (kernels_tail_bf16.hip) that leaves ranks = 1 - (known answers above the band); the count kernel and the exact
@@ -1243,9 +1271,13 @@ COPER_HOST_INLINE int hits_means_body(const int32_t* ranks, int64_t n, const int
     for (int64_t i = 0; i < n; ++i) c += ranks[i] <= lv;
     hits[k] = (double)c / (double)n;
   }
-  if ((int64_t)tab.size() <= (int64_t)hi && hi < (1 << 24)) {
+  // (the table pays when it is small beside the ranks it serves: at most 2^20 entries -- 8 MB per thread, the NumPy fallback's cap
+  //  is 2^22 -- and at most four per rank; ADVICE r5: 4,096 ranks of a 10M-entity evaluation filled 80 MB to save 4,096 divisions)
+  if ((int64_t)tab.size() <= (int64_t)hi && hi < (1 << 20) && (int64_t)hi <= 4 * n) {
     const size_t old_n = tab.size() < 1 ? 1 : tab.size();
-    tab.resize((size_t)hi + 1 > 2 * old_n ? (size_t)hi + 1 : 2 * old_n);
+    size_t want = (size_t)hi + 1 > 2 * old_n ? (size_t)hi + 1 : 2 * old_n;
+    if (want > ((size_t)1 << 20)) want = (size_t)1 << 20;
+    tab.resize(want);
     tab[0] = 0.;
     for (size_t v = old_n; v < tab.size(); ++v) tab[v] = 1.0 / (double)v;
   }
@@ -1309,6 +1341,20 @@ COPER_API int coper_band_policy(coper_handle* h, float max_ratio, int64_t n_pair
   }
   if (action) *action = act;
   if (kappa_now) *kappa_now = h->band_consts ? band_kappa(h) : 0.f;
+  return COPER_OK;
+}
+
+COPER_API int coper_stale_passes(coper_handle* h, int64_t* n_passes, void* stream) {
+  if (!h || !n_passes) return COPER_EINVAL;
+  *n_passes = h->stale_passes_host;
+  h->stale_passes_host = 0;
+  if (!h->group_done) return COPER_OK;
+  hipStream_t s = (hipStream_t)stream;
+  int32_t v = 0;
+  COPER_HIP_TRY(h, hipMemcpyAsync(&v, h->group_done + 2, sizeof v, hipMemcpyDeviceToHost, s));
+  COPER_HIP_TRY(h, hipMemsetAsync(h->group_done + 2, 0, sizeof v, s));
+  COPER_HIP_TRY(h, hipStreamSynchronize(s));
+  *n_passes += v;
   return COPER_OK;
 }
 

@@ -63,6 +63,9 @@ constexpr float COPER_BAND_KAPPA_DEFAULT = 1e-6f;
 #endif
 constexpr int COPER_TOPK_PRUNED_MAX = 128;   // largest k served by the block-maxima top-k (bf16x3); above: logits chunks
 constexpr int BAND_NCONST = 8;
+// the check words of a grouping prepared ahead (group_body.h: the guard), 64-bit each
+enum { GROUP_CHK_REL = 0, GROUP_CHK_E1 = 1, GROUP_CHK_PERM = 2, GROUP_CHK_LO = 3, GROUP_CHK_NLOCAL = 4, GROUP_CHK_RALL = 5,
+       GROUP_CHK_STALE = 6, GROUP_CHK_WORDS = 8 };
 constexpr int EBLK_ALIGN = 16;  // entity blocks consumed per workgroup iteration in score_count (8 waves x 2)
 
 struct Timer {
@@ -109,13 +112,6 @@ struct coper_handle {
   int img_exp = 0;                   // e_I: the fused encoder's image planes (compute_x_exp)
   int x3_ent_exp = 0;                // e_E: the entity planes hold E 2^e_E (split16.h; prepare)
   float x3_ent_absmax = 0.f;         //   the maximum it was chosen from (the shard's, or coper_config.x3_ent_absmax)
-  const int32_t* stage_src = nullptr;   // coper_stage_ids_next: a batch to bring in beside the next encoder launch (stage_n > 0: pending)
-  int64_t stage_n = 0;
-  int64_t* stage_dst = nullptr;
-  const int32_t* post_src = nullptr;    // coper_post_i32_next: int32 results to copy out beside the next grouping launch (post_n > 0: pending)
-  int64_t post_n = 0;
-  int32_t* post_dst = nullptr;
-  bool post_here = false;               //   the pass being enqueued was grouped ahead (coper_group_next): the fused encoder launch carries the job
   // coper_group_next: grouping arrays in sets.  Set 0 is HOME (the arrays below: every pass that groups itself, and every captured
   // graph, uses it); sets 1 and 2 are written by the grouping role of a fused encoder launch for the NEXT pass while the running
   // pass reads its own.  The fields perm / inv_perm / ... / x3m / fused_fin_dev always name the set of the pass being enqueued.
@@ -124,18 +120,44 @@ struct coper_handle {
     int32_t* rel_count = nullptr; int32_t* rel_offset = nullptr; int32_t* perm = nullptr; int32_t* inv_perm = nullptr;
     int32_t* sorted_row = nullptr; int32_t* sorted_rid = nullptr; int32_t* tiles = nullptr; int32_t* n_tiles = nullptr;
     float* x3m = nullptr; void* fused_fin_dev = nullptr; const int32_t* fused_fin_perm = nullptr;
+    int64_t* chk = nullptr;          // sets 1, 2: [GROUP_CHK_WORDS] what the grouping role sorted (group_body.h: the guard of a prepared grouping)
   } gset[3];
   int gcur = 0;                      // the set the fields name now
-  struct {
-    const int64_t* e1 = nullptr; const int64_t* rel = nullptr; int64_t B = 0; int rows = 0;
-    bool pending = false;            // registered, not yet launched
-    bool ride = false;               // the next fused encoder launch carries it (sets 1, 2 are allocated)
-  } gnext;
-  struct {                           // a grouping launched ahead into set `set`: the pass with exactly these ids skips its own
-    const int64_t* e1 = nullptr; const int64_t* rel = nullptr; int64_t B = 0; int rows = 0;
-    bool done = false;
-    int set = 0;
-  } gdone;
+  // The jobs a host registers for a LATER launch of this handle, and the grouping a launch prepared ahead: ONE owner, one
+  // invalidation rule (the drop rules used to be spread over five places).
+  //   stage  (coper_stage_ids_next): a batch to bring in beside the next fused encoder launch            n > 0: pending
+  //   post   (coper_post_i32_next):  int32 results to copy out beside the next pass's first launch       n > 0: pending
+  //   gnext  (coper_group_next):     id arrays of the pass AFTER the next one, to be sorted inside the next fused encoder launch
+  //   gdone: a grouping launched ahead into set `set`; the pass that comes with exactly these pointers consumes it -- and CHECKS it
+  //          on the device against the live ids (pass_chk below)
+  // Lifetimes: stage / post name buffers the caller owns and stay pending until a launch carries them (an eager pass, or post_flush /
+  // a launch of their own where no launch can carry them); gnext is for the NEXT encode / encode_rank call only; gdone is for the
+  // call after that only.  invalidate_grouping() -- coper_prepare, a training step, a growing workspace, freed grouping sets -- drops
+  // gnext and gdone together; nothing else does.
+  struct PassPipeline {
+    struct { const int32_t* src = nullptr; int64_t n = 0; int64_t* dst = nullptr; } stage;
+    struct { const int32_t* src = nullptr; int64_t n = 0; int32_t* dst = nullptr;
+             bool here = false; } post;  // here: the pass being enqueued was grouped ahead, its fused encoder launch carries the job
+    struct { const int64_t* e1 = nullptr; const int64_t* rel = nullptr; int64_t B = 0; int rows = 0;
+             bool pending = false;       // registered, not yet launched
+             bool ride = false; } gnext; // the fused encoder launch being enqueued carries it (sets 1, 2 are allocated)
+    struct { const int64_t* e1 = nullptr; const int64_t* rel = nullptr; int64_t B = 0; int rows = 0;
+             bool done = false; int set = 0; } gdone;
+    void invalidate_grouping() { gnext.pending = false; gnext.ride = false; gdone.done = false; }
+    // the next call's view of a grouping prepared ahead: consumed (true) or dropped -- never kept for a later call
+    bool take_prepared(const int64_t* e1, const int64_t* rel, int64_t B, int rows, int* set) {
+      const bool hit = gdone.done && gdone.rel == rel && gdone.e1 == (rows ? nullptr : e1) && gdone.B == B && gdone.rows == rows;
+      gdone.done = false;
+      *set = hit ? gdone.set : 0;
+      return hit;
+    }
+    int64_t take_stage() { const int64_t n = stage.n; stage.n = 0; return n; }
+    int64_t take_post() { const int64_t n = post.n; post.n = 0; return n; }
+  } pipe;
+  // the pass being enqueued runs on a grouping prepared ahead: the set's check words (its tiles compare the live ids with what was
+  // sorted; the kernels that preset the rank counters read the verdict); nullptr: the pass grouped itself
+  int64_t* pass_chk = nullptr;
+  int64_t stale_passes_host = 0;     // coper_stale_passes: what the device counter (group_done + 2) held when a growing workspace replaced it
   void* fused_fin_dev = nullptr;     // FusedFinConst (kernels_dense_fused_bf16.hip): the fused encoder's finalize constants, in device memory
   const int32_t* fused_fin_perm = nullptr;   //   the workspace generation they were written for
   int32_t* w_exp = nullptr;          // [Rw] e_W per relation: the dense-weight planes hold W_r 2^e_W (split16.h; prepare)

@@ -1097,6 +1097,7 @@ extern "C" {
 COPER_API int coper_train_init(coper_handle* h, const coper_train_config* cfg) {
   if (!h || !cfg) return COPER_EINVAL;
   if (cfg->abi_version != COPER_ABI_VERSION) return fail(h, COPER_EINVAL, "coper_train_init: ABI version mismatch");
+  if (h->cfg.role != COPER_ROLE_BOTH) return fail(h, COPER_ESTATE, "coper_train_init: training needs a COPER_ROLE_BOTH handle");
   const Dims& dm = h->dm;
   if (h->cfg.shard_lo != 0 || h->cfg.shard_hi != dm.E)
     return fail(h, COPER_EUNSUPPORTED, "coper_train_init: training needs the whole entity table on the handle");
@@ -1313,7 +1314,7 @@ static int train_step_impl(coper_handle* h, const int64_t* e1, const int64_t* re
     hipLaunchKernelGGL(k_tr_zero_list, dim3(256, (unsigned)zl.n), dim3(256), 0, s, zl);
   }
   // (a coper_group_next registration, or a grouping prepared ahead, was for an evaluation pass: a training step drops both)
-  h->gnext.pending = false; h->gnext.ride = false; h->gdone.done = false;
+  h->pipe.invalidate_grouping();
   if (lk) {
     // group the batch by relation (perm / rel_offset / rel_count of the inference path): the table gradient is
     // written per present relation, never zero-filled (1.75 GB at FB15k-237 shapes)

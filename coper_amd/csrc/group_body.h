@@ -112,6 +112,35 @@ __device__ __forceinline__ void rel_scan_tiles_body(const int32_t* count, int64_
 // outputs as k_rel_group_single / k_rel_group_identity (the order inside a relation group is whatever the LDS cursors hand out:
 // h[b] does not depend on it).  The ids are the int64 device arrays of that pass; when a staging job of the same launch is
 // still bringing them in, the caller waits for its workgroups first (ticket / wait_for).
+// The guard of a prepared grouping.  The grouping role leaves what it sorted in GROUP_CHK_WORDS 64-bit words
+// of its set; the tiles of the pass that CONSUMES the set compare every query's live ids with its sorted_row / sorted_rid
+// (group_chk_issue / group_chk_verdict: the id arrays at the registered addresses may have been rewritten between the two launches -- the natural
+// mistake with two staging buffers) and raise GROUP_CHK_STALE; the kernel that presets the pass's rank counters then writes
+// COPER_RANK_STALE into every rank instead of 1 (a stale grouping never reaches the ranks) and counts the pass (coper_stale_passes).
+// (the word indices GROUP_CHK_*: coper_internal.h)
+
+// one lane's query of a consuming tile: sorted position `pos`, what the set holds for it (row, rid).  Ids are read past the XCD's L2
+// (the arrays may have been written by a staging job of the launch before: the same coherent loads the grouping role uses).
+__device__ __forceinline__ void group_chk_issue(const int64_t* __restrict__ chk, int pos, int64_t& live_rel, int64_t& live_e1) {
+  const int64_t* rel64 = (const int64_t*)chk[GROUP_CHK_REL];
+  const int64_t* e1_64 = (const int64_t*)chk[GROUP_CHK_E1];
+  const int32_t* perm = (const int32_t*)chk[GROUP_CHK_PERM];
+  const int b = perm[pos];
+  live_rel = __hip_atomic_load(rel64 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  live_e1 = e1_64 ? __hip_atomic_load(e1_64 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+}
+__device__ __forceinline__ void group_chk_verdict(int64_t* __restrict__ chk, int64_t live_rel, int64_t live_e1, int row, int rid) {
+  int64_t r = live_rel;
+  if (r < 0 || r >= chk[GROUP_CHK_RALL]) r = 0;
+  bool bad = (int)r != rid;
+  if (chk[GROUP_CHK_E1]) {
+    int64_t lr = live_e1 - chk[GROUP_CHK_LO];
+    if (lr < 0 || lr >= chk[GROUP_CHK_NLOCAL]) lr = -1;
+    bad |= (int)lr != row;
+  }
+  if (bad) atomicOr((int*)(chk + GROUP_CHK_STALE), 1);
+}
+
 struct GroupJob {
   const int64_t* rel64; const int64_t* e1_64;
   int32_t* ticket; int wait_for, pad2;     // the staging workgroups of the launch that bring the ids in (0: they are resident)
@@ -119,6 +148,7 @@ struct GroupJob {
   int64_t B, R, R_all, shard_lo, n_local, cap_small;
   int32_t* count; int32_t* offset; int32_t* tiles; int32_t* n_tiles; int32_t* perm; int32_t* sorted_row; int32_t* sorted_rid; int32_t* inv_perm;
   float* x3m;
+  int64_t* chk;                            // the set's check words (GROUP_CHK_*), written here, read by the consuming pass
   int use_rel, have_e1_rows, x3m_slots, pad;
 };
 
@@ -132,6 +162,10 @@ template <int NT>
 __device__ __forceinline__ void group_role_body(const GroupJob& J, int* __restrict__ lds) {
   const int64_t B = J.B;
   if (J.x3m) for (int i = threadIdx.x; i < J.x3m_slots; i += NT) J.x3m[i] = 0.f;
+  if (J.chk && threadIdx.x == 0) {
+    J.chk[GROUP_CHK_REL] = (int64_t)J.rel64; J.chk[GROUP_CHK_E1] = J.have_e1_rows ? 0 : (int64_t)J.e1_64; J.chk[GROUP_CHK_PERM] = (int64_t)J.perm;
+    J.chk[GROUP_CHK_LO] = J.shard_lo; J.chk[GROUP_CHK_NLOCAL] = J.n_local; J.chk[GROUP_CHK_RALL] = J.R_all; J.chk[GROUP_CHK_STALE] = 0;
+  }
   // (ids a staging job of this launch wrote: loads that do not trust a line the XCD's L2 may hold from the last pass)
   const bool coh = J.wait_for > 0;
   auto ld_id = [&](const int64_t* p) -> int64_t { return coh ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p; };

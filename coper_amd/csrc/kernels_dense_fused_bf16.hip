@@ -97,6 +97,7 @@ struct FusedConvArgs {
   const float* shift;
   int per_rel_conv, d, r, in_w, in_hw, Wo, img_stride, x_exp;
   int img_exp;      // e_I: the image planes in LDS hold (e1 row | rel row) 2^e_I as fp16 hi + lo (round 5: the conv on the matrix cores)
+  int64_t* chk;     // the pass runs on a grouping prepared ahead (coper_group_next): its check words (group_body.h), else nullptr
 };
 
 // The dense finalize in this kernel's epilogue (round 4; one K slice only -- the workgroup's accumulators are then the whole
@@ -154,6 +155,16 @@ __device__ __forceinline__ void fused_load_images(unsigned* __restrict__ img, co
     int qi = q0 + (lane & 15);
     if (qi > n - 1) qi = n - 1;
     int my_row = A.sorted_row[start + qi], my_rid = A.sorted_rid[start + qi];
+    // a grouping prepared ahead is CHECKED by the pass that consumes it (group_body.h): every query's live (e1, rel) against what was
+    // sorted -- once per query (K slice 0, feature group 0), its loads issued with the ones above and below, the verdict at the end
+#ifdef COPER_DBG_NO_GROUP_CHK      // (A/B of the guard's cost: tools/ab_bench.sh)
+    const bool chk = false;
+#else
+    const bool chk = A.chk != nullptr && (blockIdx.y | blockIdx.z) == 0;
+#endif
+    int64_t live_rel = 0, live_e1 = 0;
+    const int chk_row = my_row, chk_rid = my_rid;
+    if (chk) group_chk_issue(A.chk, start + qi, live_rel, live_e1);
 #ifdef COPER_DBG_FUSED_NO_IMG
     my_row = -1;
 #endif
@@ -193,6 +204,7 @@ __device__ __forceinline__ void fused_load_images(unsigned* __restrict__ img, co
         for (int pp = 128 + lane; 2 * pp < len; pp += 64) put2(q0 + u, pp, fetch2(row, rid, t0 + 2 * pp));
       }
     }
+    if (chk) group_chk_verdict(A.chk, live_rel, live_e1, chk_row, chk_rid);
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -634,11 +646,13 @@ __device__ __forceinline__ void fused_conv_role(uint4* __restrict__ xring, unsig
           // ReLU: one v_med3_f32 per value (fmaxf compiles to two: it canonicalises its operand first).  NOT inline asm: the hardware
           // does not interlock a vector instruction that reads an MFMA's result, the compiler's hazard recognizer pads the wait
           // states for its own instructions only -- an asm v_max_f32 right behind the MFMA read stale registers (measured: h = 0).
+          // (the upper bound is fp16's largest finite value: activations of e1_rows beyond the agreed x3_ent_absmax saturate, as in
+          //  round 4, instead of leaving v_cvt_pk_f16_f32 as inf and h as NaN rows -- ADVICE r5; in-range values: the same bits)
           float y[8];
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            y[i] = __builtin_amdgcn_fmed3f(y0[i], 0.f, 3.0e38f);
-            y[4 + i] = __builtin_amdgcn_fmed3f(y1[i], 0.f, 3.0e38f);
+            y[i] = __builtin_amdgcn_fmed3f(y0[i], 0.f, 65504.f);
+            y[4 + i] = __builtin_amdgcn_fmed3f(y1[i], 0.f, 65504.f);
           }
           uint4 h4, l4;
           split8_pos_s16(y, h4, l4);
@@ -752,7 +766,15 @@ __global__ __launch_bounds__(512) void k_dense_fused_bf16x3(const uint4* __restr
       GROUP_CLK(0);
       if (J.wait_for > 0) {
         if (threadIdx.x == 0) {
-          while (__hip_atomic_load(J.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < J.wait_for) __builtin_amdgcn_s_sleep(16);
+          // (bounded: ~1 s.  A ticket that never arrives -- it cannot, the staging workgroups stand in front of this one in the
+          //  grid -- would leave this workgroup sorting ids that are not there yet; the pass that consumes the sorting checks
+          //  it against the live ids and reports it stale: group_body.h)
+          for (int spin = 0; spin < (1 << 21) && __hip_atomic_load(J.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < J.wait_for; ++spin)
+            __builtin_amdgcn_s_sleep(16);
+          // (round 6, ADVICE r5: the hand-over is a release / acquire pair at agent scope -- ONE per staging workgroup and one here,
+          //  +1 us per pass measured; round 5 relied on relaxed atomics, write-through stores and in-order dispatch alone.  The
+          //  release / acquire FENCES in every wave that round 5 had tried first stretched the launch from 165 to 240 us.)
+          (void)__hip_atomic_load(J.ticket, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
           __hip_atomic_store(J.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
@@ -798,7 +820,7 @@ __global__ __launch_bounds__(512) void k_dense_fused_bf16x3(const uint4* __restr
         __hip_atomic_store(stage_dst + i, (int64_t)stage_src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (sig) {
       __syncthreads();                              // (every wave's stores have been acknowledged)
-      if (threadIdx.x == 0) __hip_atomic_fetch_add(J.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (threadIdx.x == 0) __hip_atomic_fetch_add(J.ticket, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
     copy4(f4, n4);
     for (int64_t i = 4 * n4 + b * 512 + threadIdx.x; i < stage_n; i += nb * 512) stage_dst[i] = stage_src[i];
@@ -938,6 +960,7 @@ static void dense_fused_launch(coper_handle* h, const int64_t* e1, const int64_t
   A.per_rel_conv = dm.gen_conv ? 1 : 0;
   A.d = dm.d; A.r = dm.r; A.in_w = dm.in_w; A.in_hw = dm.in_h * dm.in_w; A.Wo = dm.Wo;
   A.img_stride = (fused_rows_max(dm, nslices) * dm.in_w) | 1;
+  A.chk = h->pass_chk;
   size_t lds = (size_t)2 * 16 * 64 * sizeof(uint4) + (size_t)128 * A.img_stride * sizeof(float);
   static uint64_t attr_done = 0;   // per instantiation, one bit per device: always the hardware maximum
   const uint64_t bit = 1ull << (h->cfg.device & 63);
@@ -955,51 +978,53 @@ static void dense_fused_launch(coper_handle* h, const int64_t* e1, const int64_t
 #endif
   // (a pass being captured into a hipGraph leaves a pending staging job to the next eager call, as coper_post_i32_next does: a
   // replay would repeat the PCIe read with the pointers recorded at capture time and overwrite whatever staging buffer they name)
+  coper_handle::PassPipeline& pp = h->pipe;
   bool capturing = false;
-  if (h->stage_n > 0 || h->post_n > 0 || h->gnext.ride) {
+  if (pp.stage.n > 0 || pp.post.n > 0 || pp.gnext.ride) {
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); capturing = true; }
     else capturing = cap != hipStreamCaptureStatusNone;
   }
-  const bool stage_now = h->stage_n > 0 && !capturing;
+  const bool stage_now = pp.stage.n > 0 && !capturing;
   // a pass that was grouped ahead has no grouping launch for a pending coper_post_i32_next to ride in: the staging workgroups take it
-  bool post_now = h->post_n > 0 && h->post_here && !capturing;
-  h->post_here = false;
+  bool post_now = pp.post.n > 0 && pp.post.here && !capturing;
+  pp.post.here = false;
   // coper_group_next: one more workgroup sorts the next pass's batch into the set this pass does not use
   GroupJob J = {};
   int n_group = 0;
-  if (h->gnext.ride && !capturing) {
+  if (pp.gnext.ride && !capturing) {
     const int64_t R = dm.gen_fc ? dm.R : 1;
     const int t = h->gcur == 1 ? 2 : 1;
     const coper_handle::GroupSet& g = h->gset[t];
-    if (g.slab && h->gnext.B <= h->ws_queries && group_role_lds_ints(R, 512) * sizeof(int) <= lds) {
-      J.B = h->gnext.B; J.R = R; J.R_all = dm.R; J.shard_lo = h->cfg.shard_lo; J.n_local = dm.n_local; J.cap_small = cap_small;
+    if (g.slab && pp.gnext.B <= h->ws_queries && group_role_lds_ints(R, 512) * sizeof(int) <= lds) {
+      J.B = pp.gnext.B; J.R = R; J.R_all = dm.R; J.shard_lo = h->cfg.shard_lo; J.n_local = dm.n_local; J.cap_small = cap_small;
       J.count = g.rel_count; J.offset = g.rel_offset; J.tiles = g.tiles; J.n_tiles = g.n_tiles; J.perm = g.perm;
       J.sorted_row = g.sorted_row; J.sorted_rid = g.sorted_rid; J.inv_perm = g.inv_perm; J.x3m = g.x3m; J.x3m_slots = X3M_SLOTS;
-      J.use_rel = dm.gen_fc ? 1 : 0; J.have_e1_rows = h->gnext.rows;
+      J.chk = g.chk;
+      J.use_rel = dm.gen_fc ? 1 : 0; J.have_e1_rows = pp.gnext.rows;
       // ids inside the batch this launch stages: the grouping workgroup waits for the staging workgroups (a ticket), then reads
       // the device arrays like any other (one workgroup reading pinned host memory itself manages 0.65 GB/s: measured, 370 us)
-      auto in_stage = [&](const int64_t* p) { return stage_now && p && p + J.B > h->stage_dst && p < h->stage_dst + h->stage_n; };
-      J.rel64 = h->gnext.rel; J.e1_64 = h->gnext.e1;
+      auto in_stage = [&](const int64_t* p) { return stage_now && p && p + J.B > pp.stage.dst && p < pp.stage.dst + pp.stage.n; };
+      J.rel64 = pp.gnext.rel; J.e1_64 = pp.gnext.e1;
       J.ticket = h->group_done + 1;
-      J.wait_for = (in_stage(h->gnext.rel) || in_stage(h->gnext.e1)) ? FUSED_STAGE_WGS : 0;
+      J.wait_for = (in_stage(pp.gnext.rel) || in_stage(pp.gnext.e1)) ? FUSED_STAGE_WGS : 0;
       J.front = 0;
-      if (in_stage(h->gnext.rel)) J.front = (h->gnext.rel + J.B) - h->stage_dst;
-      if (in_stage(h->gnext.e1) && (h->gnext.e1 + J.B) - h->stage_dst > J.front) J.front = (h->gnext.e1 + J.B) - h->stage_dst;
-      if (J.front > h->stage_n) J.front = h->stage_n;
+      if (in_stage(pp.gnext.rel)) J.front = (pp.gnext.rel + J.B) - pp.stage.dst;
+      if (in_stage(pp.gnext.e1) && (pp.gnext.e1 + J.B) - pp.stage.dst > J.front) J.front = (pp.gnext.e1 + J.B) - pp.stage.dst;
+      if (J.front > pp.stage.n) J.front = pp.stage.n;
       n_group = 1;
-      h->gdone.e1 = h->gnext.e1; h->gdone.rel = h->gnext.rel; h->gdone.B = h->gnext.B; h->gdone.rows = h->gnext.rows;
-      h->gdone.done = true; h->gdone.set = t;
+      pp.gdone.e1 = pp.gnext.e1; pp.gdone.rel = pp.gnext.rel; pp.gdone.B = pp.gnext.B; pp.gdone.rows = pp.gnext.rows;
+      pp.gdone.done = true; pp.gdone.set = t;
     }
   }
-  h->gnext.ride = false; h->gnext.pending = false;
+  pp.gnext.ride = false; pp.gnext.pending = false;
   const int n_stage = (stage_now || post_now) ? FUSED_STAGE_WGS : 0;
   hipLaunchKernelGGL((k_dense_fused_bf16x3<NFB, WNT>), dim3((unsigned)(n_tile_blocks + n_group + n_stage), (unsigned)nslices, (unsigned)zgroups), dim3(512),
                      lds, s, (const uint4*)h->Wf16_hi, (const fused_wlo_t*)(FUSED_LO8 ? h->Wf8_lo : h->Wf16_lo), A, h->tiles, h->n_tiles, cap_small, dm.nfb,
-                     dm.F_pad / 32, nslices, h->ws_queries, dm.d_pad16, h->z_part, Fn, n_group + n_stage, h->stage_src,
-                     stage_now ? h->stage_n : 0, h->stage_dst, w16_ks_stride(dm), J, n_group, h->post_src, post_now ? h->post_n : 0, h->post_dst, n_big_cap_old);
-  if (stage_now) h->stage_n = 0;
-  if (post_now) h->post_n = 0;
+                     dm.F_pad / 32, nslices, h->ws_queries, dm.d_pad16, h->z_part, Fn, n_group + n_stage, pp.stage.src,
+                     stage_now ? pp.stage.n : 0, pp.stage.dst, w16_ks_stride(dm), J, n_group, pp.post.src, post_now ? pp.post.n : 0, pp.post.dst, n_big_cap_old);
+  if (stage_now) pp.take_stage();
+  if (post_now) pp.take_post();
 }
 
 // the constant part of FusedFin, (re)written when the workspace or the parameters move (ensure_workspace / prepare)

@@ -285,7 +285,7 @@ int launch_group_by_relation(coper_handle* h, const int64_t* e1, const int64_t* 
                              hipStream_t s) {
   const Dims& dm = h->dm;
   int64_t R = dm.gen_fc ? dm.R : 1;
-  bool post_now = h->post_n > 0;
+  bool post_now = h->pipe.post.n > 0;
   if (post_now) {      // (a pass being captured into a hipGraph leaves the job to the next eager call: a replay must not repeat it)
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); post_now = false; }
@@ -295,11 +295,11 @@ int launch_group_by_relation(coper_handle* h, const int64_t* e1, const int64_t* 
   if (R == 1 && !no_identity) {
     const unsigned nbm = (unsigned)((B + HIST_BLOCK - 1) / HIST_BLOCK);
     unsigned npost = 0;
-    const int32_t* psrc = h->post_src; const int64_t pn = h->post_n; int32_t* pdst = h->post_dst;
+    const int32_t* psrc = h->pipe.post.src; const int64_t pn = h->pipe.post.n; int32_t* pdst = h->pipe.post.dst;
     if (pn > 0 && post_now) {
       npost = (unsigned)((pn + 4 * HIST_BLOCK - 1) / (4 * HIST_BLOCK));
       if (npost > 32) npost = 32;
-      h->post_n = 0;
+      h->pipe.take_post();
     }
     hipLaunchKernelGGL(k_rel_group_identity, dim3(nbm + npost), dim3(HIST_BLOCK), 0, s, rel, e1, B, (int64_t)dm.R, have_e1_rows ? 1 : 0,
                        (int64_t)h->cfg.shard_lo, dm.n_local, small_tile_cap(h), h->rel_count, h->rel_offset, h->tiles, h->n_tiles, h->perm,
@@ -309,9 +309,8 @@ int launch_group_by_relation(coper_handle* h, const int64_t* e1, const int64_t* 
     return COPER_OK;
   }
   if (post_now && !(R <= HIST_LDS_MAX && B > 4096)) {     // (a pending coper_post_i32_next rides in the two-launch path only)
-    const int64_t pn = h->post_n;
-    h->post_n = 0;
-    int rc0 = launch_copy_i32(h, h->post_src, pn, h->post_dst, s);
+    const int64_t pn = h->pipe.take_post();
+    int rc0 = launch_copy_i32(h, h->pipe.post.src, pn, h->pipe.post.dst, s);
     if (rc0) return rc0;
   }
   // rel_count (= rel_count_buf[0]) holds the counts of the last call; rel_count_buf[1] is the accumulation buffer of the
@@ -332,11 +331,11 @@ int launch_group_by_relation(coper_handle* h, const int64_t* e1, const int64_t* 
   if (R <= HIST_LDS_MAX) {
     // two launches: histogram + scan (last block), scatter.  A pending coper_post_i32_next rides in the first one.
     unsigned npost = 0;
-    const int32_t* psrc = h->post_src; const int64_t pn = h->post_n; int32_t* pdst = h->post_dst;
+    const int32_t* psrc = h->pipe.post.src; const int64_t pn = h->pipe.post.n; int32_t* pdst = h->pipe.post.dst;
     if (pn > 0 && post_now) {
       npost = (unsigned)((pn + 4 * HIST_BLOCK - 1) / (4 * HIST_BLOCK));
       if (npost > 32) npost = 32;
-      h->post_n = 0;
+      h->pipe.take_post();
     }
     hipLaunchKernelGGL(k_rel_hist_scan, dim3(nb + npost), dim3(HIST_BLOCK), sizeof(int32_t) * (size_t)R, s, rel, B, dm.gen_fc ? 1 : 0, R,
                        (int64_t)dm.R, h->rel_count_buf[1], h->rel_count, h->group_done, small_tile_cap(h), h->rel_offset, h->tiles,

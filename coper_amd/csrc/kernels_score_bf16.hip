@@ -34,14 +34,20 @@ __global__ __launch_bounds__(256) void k_rows_to_frag_bf16(const float* __restri
                                                            uint4* __restrict__ f3, int query_side,
                                                            int64_t total, int32_t* __restrict__ cnt, int32_t cnt_base,
                                                            int32_t* __restrict__ cnt_eq, int fixed_exp,
-                                                           const float* __restrict__ x3m, int32_t* __restrict__ x3s) {
+                                                           const float* __restrict__ x3m, int32_t* __restrict__ x3s,
+                                                           const int32_t* __restrict__ stale, int32_t* __restrict__ stale_count) {
   int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (blk*KS16 + ks)*64 + l
   // the power of two of this operand class (split16.h): the table's (prepare), or the packed batch's -- reduced here from the
   // block maxima k_absmax_publish / k_finalize_h_publish left, and published by block 0 for the kernels that follow
   __shared__ float s_red[4];
   const int e2x = x3m ? x3_batch_exp(x3m, fixed_exp, x3s, s_red) : fixed_exp;
   // optional: preset the rank counters of the pass this packing opens (saves a launch on the ranking path)
-  if (cnt && j < n_rows) { cnt[j] = cnt_base; if (cnt_eq) cnt_eq[j] = 0; }
+  // (a pass on a grouping prepared ahead whose ids had changed since -- group_body.h: the guard -- gets COPER_RANK_STALE in every rank)
+  if (cnt) {
+    const bool is_stale = stale != nullptr && *stale != 0;
+    if (j < n_rows) { cnt[j] = is_stale ? COPER_RANK_STALE : cnt_base; if (cnt_eq) cnt_eq[j] = 0; }
+    if (is_stale && j == 0) atomicAdd(stale_count, 1);
+  }
   if (j >= total) return;
   int l = (int)(j & 63);
   int64_t rest = j >> 6;
@@ -70,7 +76,8 @@ int launch_rows_to_frag_bf16(coper_handle* h, const float* src, int64_t n_rows, 
   int64_t total = n_blk * dm.KS16 * 64;
   hipLaunchKernelGGL(k_rows_to_frag_bf16, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, n_rows, dm.d,
                      dm.KS16, hi, lo, rm_hi, rm_lo, f3, query_side ? 1 : 0, total, h->preset_cnt, h->count_base, h->preset_eq,
-                     h->x3_ent_exp, query_side ? h->x3m : nullptr, h->x3s);
+                     h->x3_ent_exp, query_side ? h->x3m : nullptr, h->x3s,
+                     h->preset_cnt && h->pass_chk ? (const int32_t*)(h->pass_chk + GROUP_CHK_STALE) : nullptr, h->group_done ? h->group_done + 2 : nullptr);
   if (h->preset_cnt) h->counts_preset = h->preset_cnt;
   h->preset_cnt = nullptr;
   h->preset_eq = nullptr;

@@ -201,7 +201,8 @@ __global__ __launch_bounds__(64 * TL_WAVES, KS <= 13 ? 3 : 2) void k_finalize_ta
     const uint4* __restrict__ Ehi, const uint4* __restrict__ Elo, const float* __restrict__ bias_pad, int64_t n_local,
     const int64_t* __restrict__ e2, const int64_t* __restrict__ indptr, const int64_t* __restrict__ idx, float* __restrict__ tgt,
     float kappa, const unsigned* __restrict__ band_consts, const float* __restrict__ x3m, int ent_exp, int32_t* __restrict__ x3s,
-    float2* __restrict__ tband, int32_t* __restrict__ ranks, int32_t* __restrict__ heavy) {
+    float2* __restrict__ tband, int32_t* __restrict__ ranks, int32_t* __restrict__ heavy, const int32_t* __restrict__ stale,
+    int32_t* __restrict__ stale_count) {
   __shared__ uint4 s_bh[KS][64], s_bl[KS][64];   // the block's B-operand fragments (hi / lo), shared by the waves
   __shared__ int64_t s_e[TL_WAVES][32];
   __shared__ int s_corr[32];
@@ -360,7 +361,12 @@ __global__ __launch_bounds__(64 * TL_WAVES, KS <= 13 ? 3 : 2) void k_finalize_ta
   }
   TL_STAMP(4);
   __syncthreads();
-  if (wave == 0 && half == 0 && live) ranks[q] = 1 - s_corr[i];
+  // a pass that ran on a grouping prepared ahead whose ids had changed since (group_body.h: the guard; `stale` is the verdict of the
+  // encoder launch in front of this one): every rank is written as COPER_RANK_STALE -- what the count and band launches add keeps it
+  // negative -- and the pass is counted (coper_stale_passes)
+  const bool is_stale = stale != nullptr && *stale != 0;
+  if (wave == 0 && half == 0 && live) ranks[q] = is_stale ? COPER_RANK_STALE : 1 - s_corr[i];
+  if (is_stale && blk == 0 && threadIdx.x == 0) atomicAdd(stale_count, 1);
   TL_STAMP(5);
 }
 
@@ -416,7 +422,8 @@ int launch_finalize_targets_filter_bf16x3(coper_handle* h, int64_t B, int ksplit
   hipLaunchKernelGGL(k_finalize_targets_filter_bf16x3<KS_>, dim3(grid), dim3(64 * TL_WAVES), 0, s, B, dm.d, (const float*)h_out,   \
                      (uint4*)h->hf3_ws, (const uint4*)h->Erm16_hi, (const uint4*)h->Erm16_lo,                                       \
                      h->bias_pad, dm.n_local, e2, indptr, idx, tgt, band_kappa(h), h->band_consts, h->x3m, h->x3_ent_exp, h->x3s,   \
-                     (float2*)h->tband_ws, ranks, h->heavy_ws)
+                     (float2*)h->tband_ws, ranks, h->heavy_ws, h->pass_chk ? (const int32_t*)(h->pass_chk + GROUP_CHK_STALE) : nullptr, \
+                     h->group_done + 2)
   if (dm.KS16 == 13) { TL_GO(13); } else { TL_GO(16); }
 #undef TL_GO
   COPER_HIP_TRY(h, hipGetLastError());

@@ -166,10 +166,23 @@ def ranking_and_hits(model, results_dir, data_iterator_handle, name, session=Non
                 sbs[todo[-1]]["event"].synchronize()          # (one stream: the last chunk's event covers them all)
             again = []
             if x3:
+                # ONE policy call per round of passes: every chunk of the round was audited under the same kappa, and
+                # coper_band_policy multiplies the handle's kappa cumulatively -- per chunk, two chunks at ratio 1.2 widened 8 x 8.
+                # The largest ratio and the summed pairs decide; the chunks whose own ratio reached 1 are ranked again.
+                auds = []
                 for i in todo:
                     aud = sbs[i]["out_host"][sbs[i]["B"]:sbs[i]["B"] + 2].numpy()
-                    if _act_on_band_audit(model, float(aud[:1].view(np.float32)[0]), int(aud[1:2].view(np.uint32)[0])) == 2:
-                        again.append(i)
+                    auds.append((i, float(aud[:1].view(np.float32)[0]), int(aud[1:2].view(np.uint32)[0])))
+                seen = [a for a in auds if a[2] > 0]
+                if seen and _act_on_band_audit(model, max(a[1] for a in seen), sum(a[2] for a in seen)) == 2:
+                    again = [a[0] for a in seen if a[1] >= 1.0]
+            # the guard of a grouping prepared ahead (include/coper_hip.h: coper_group_next): a pass whose ids were rewritten between
+            # the launch that sorted them and the pass itself comes back with COPER_RANK_STALE in every rank -- ranked again
+            for i in todo:
+                if i not in again and int(sbs[i]["out_host"][:sbs[i]["B"]].min()) < 1:
+                    again.append(i)
+                    ranking_and_hits.stale_passes = getattr(ranking_and_hits, "stale_passes", 0) + 1
+            again.sort()
             if not again:
                 break
             todo = again
@@ -240,26 +253,33 @@ def ranking_and_hits(model, results_dir, data_iterator_handle, name, session=Non
     q = collect_batches(data_iterator_handle, device=getattr(model, "device", None))
     Q = len(q["e1"])
     ranks = []
-    for s in range(0, Q, max_chunk):
-        e = min(Q, s + max_chunk)
-        ip = q["filt_indptr"][s:e + 1]
-        chunk = dict(e1=q["e1"][s:e], e2=q["e2"][s:e], rel=q["rel"][s:e], filt_indptr=ip - ip[0],
-                     filt_idx=q["filt_idx"][ip[0]:ip[-1]])
-        # bf16x3 mode: the run-time audit of the exact band (include/coper_hip.h: coper_band_audit) -- the largest error of the
-        # mode's logits on the pairs closest to the targets, relative to what the band allows; ranks are the fp32 chain's below 1.
-        # Acted on per chunk (coper_band_policy): above 0.5 the handle's kappa is widened, from 1.0 on the chunk is ranked again.
-        # (An entity-sharded ranker audits per shard handle: its ranks() owns that loop.)
-        x3 = ranker is None and getattr(model, "score_mode", None) == "bf16x3" and hasattr(model, "band_audit")
-        for attempt in range(_MAX_RERANKS + 1):
-            if ranker is not None:
-                r, _ = ranker.rank(chunk)
+
+    def chunks():
+        for s in range(0, Q, max_chunk):
+            e = min(Q, s + max_chunk)
+            ip = q["filt_indptr"][s:e + 1]
+            yield dict(e1=q["e1"][s:e], e2=q["e2"][s:e], rel=q["rel"][s:e], filt_indptr=ip - ip[0], filt_idx=q["filt_idx"][ip[0]:ip[-1]])
+
+    if ranker is not None and hasattr(ranker, "rank_stream"):
+        # an entity-sharded ranker owns its loop (sharding.py: plans one chunk ahead, steps 1 - 2 of the next chunk beside this one's
+        # count launch, the band audit of every shard handle acted on per window of chunks)
+        ranks = [res[0] for res in ranker.rank_stream(chunks())]
+    else:
+        for chunk in chunks():
+            # bf16x3 mode: the run-time audit of the exact band (include/coper_hip.h: coper_band_audit) -- the largest error of the
+            # mode's logits on the pairs closest to the targets, relative to what the band allows; ranks are the fp32 chain's below 1.
+            # Acted on per chunk (coper_band_policy): above 0.5 the handle's kappa is widened, from 1.0 on the chunk is ranked again.
+            x3 = ranker is None and getattr(model, "score_mode", None) == "bf16x3" and hasattr(model, "band_audit")
+            for attempt in range(_MAX_RERANKS + 1):
+                if ranker is not None:
+                    r, _ = ranker.rank(chunk)
+                else:
+                    r, _ = local_rank_pass(model, chunk)
+                if not x3 or _act_on_band_audit(model, *model.band_audit()) != 2:
+                    break
             else:
-                r, _ = local_rank_pass(model, chunk)
-            if not x3 or _act_on_band_audit(model, *model.band_audit()) != 2:
-                break
-        else:
-            raise RuntimeError("bf16x3 band audit: still above the band's allowance after %d re-ranked passes" % _MAX_RERANKS)
-        ranks.append(r)
+                raise RuntimeError("bf16x3 band audit: still above the band's allowance after %d re-ranked passes" % _MAX_RERANKS)
+            ranks.append(r)
     ranks = torch.cat(ranks).cpu().numpy().astype(np.int64) if ranks else np.zeros(0, np.int64)
     return _finish(ranks, Q, results_dir, hits_to_compute, enable_write_to_file, return_ranks)
 

@@ -72,7 +72,8 @@ def _host(v):
 
 
 class ConvE(object):
-    def __init__(self, model_descriptors: dict, device=None, shard=None, score_mode="f32", rank_band_kappa=0.0, band_audit_period=0):
+    def __init__(self, model_descriptors: dict, device=None, shard=None, score_mode="f32", rank_band_kappa=0.0, band_audit_period=0,
+                 role="both"):
         md = dict(model_descriptors)
         # required keys, as models.py:99-105,119-130 reads them
         for key in ("use_negative_sampling", "label_smoothing_epsilon", "num_ent", "num_rel", "ent_emb_size",
@@ -98,8 +99,11 @@ class ConvE(object):
             raise ValueError("score_mode: 'f32' (exact-f32 MFMA) or 'bf16x3' (split-bf16 operands, 3 bf16 MFMAs per product)")
         mode = {"f32": _lib.SCORE_F32, "bf16x3": _lib.SCORE_BF16X3}[score_mode]
         self.score_mode = score_mode
+        if role not in ("both", "encode", "score"):
+            raise ValueError("role: 'both', 'encode' (no entity planes; encode only) or 'score' (no generated weights; scoring only)")
+        self.role = role
         cfg = _lib.make_config(md, device=self.device.index or 0, shard=self.shard, score_mode=mode, rank_band_kappa=rank_band_kappa,
-                               band_audit_period=band_audit_period)
+                               band_audit_period=band_audit_period, role={"both": _lib.ROLE_BOTH, "encode": _lib.ROLE_ENCODE, "score": _lib.ROLE_SCORE}[role])
         h = C.c_void_p()
         rc = self._lib.coper_create(C.byref(cfg), C.byref(h))
         if rc != 0:
@@ -685,6 +689,13 @@ class ConvE(object):
     def check_ids(self):
         n = C.c_int64()
         _lib.check(self._h, self._lib.coper_check_ids(self._h, C.byref(n), self._stream()))
+        return n.value
+
+    def stale_passes(self):
+        """coper_stale_passes: rank passes since the last call that ran on a grouping prepared ahead (`group_next`) whose id arrays had
+        been rewritten in between -- their ranks were all written as RANK_STALE (negative) and must be ranked again by a plain call."""
+        n = C.c_int64()
+        _lib.check(self._h, self._lib.coper_stale_passes(self._h, C.byref(n), self._stream()))
         return n.value
 
     def profile(self, enable=True):

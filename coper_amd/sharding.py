@@ -106,30 +106,78 @@ class QueryShardedEvaluator(object):
         return torch.cat(rs), torch.cat(nes)
 
 
-class EntityShardedRanker(object):
-    """Entity-sharded ranking; see the module docstring for the three exchange steps."""
+class _ChunkPlan(object):
+    """Host-side plan of one chunk: who owns which row (step 1), which rank encodes which query (step 2).  Every rank derives
+    the same plan from the replicated ids; all index tensors travel to the device in ONE pinned buffer / one copy."""
+    __slots__ = ("B", "cap1", "n_mine", "mine_ids", "cap2", "n_enc", "ints", "off", "dev", "split")
 
-    def __init__(self, scorer, group=None, split_encoder=True):
+
+class EntityShardedRanker(object):
+    """Entity-sharded ranking; see the module docstring for the three exchange steps.
+
+    `scorer` holds the rank's entity rows and runs step 3 (targets, fused score + count, top-k); `encoder` -- by default the
+    same object -- runs the rank's share of step 2.  Given a SECOND handle for the encoder (coper_config.role: one handle per
+    role, no derived buffer held twice), `rank_stream` issues steps 1 - 2 of chunk n + 1 on a side stream, with their two
+    collectives on a communicator of their own, BEFORE chunk n's count launch: they run under its 5.5 ms instead of in front of
+    the next one.
+
+    `rank(chunk)` is one chunk, checked before it returns (two small D2H reads: the header row of step 1, the audit words of
+    step 3).  `rank_stream(chunks)` is the evaluation loop: plans are made one chunk ahead while the device works, nothing is
+    read back inside a chunk -- the header comparison and the audit words stay on the device and are read ONCE per window of
+    chunks; a window whose check fails (a shard reloaded its rows; a band too narrow) is ranked again chunk by chunk."""
+
+    def __init__(self, scorer, group=None, split_encoder=True, encoder=None, emulate_world=None, overlap=None):
         self.scorer, self.group, self.split_encoder = scorer, group, split_encoder
+        self.encoder = encoder if encoder is not None else scorer
         self.dist = dist.is_initialized()      # a process group of ONE rank still runs its collectives (RCCL on one GPU)
         self.world = dist.get_world_size(group) if self.dist else 1
         self.rank_id = dist.get_rank(group) if self.dist else 0
-        self._plan = None      # the relation split of the last chunk (encode)
-        self._rows_plan = None # the ownership split of the last chunk (step 1)
+        # emulate_world = (G, g): ONE rank's work of a G-rank job without the other ranks (bench.py's `scale.projected`): the plans,
+        # launches and buffers of rank g, every all-gather replaced by a local copy of the own share into all G slots -- the other
+        # ranks' rows read as this rank's, so the VALUES mean nothing; the work per chunk is the rank's own
+        self.emulated = emulate_world is not None
+        if self.emulated:
+            self.world, self.rank_id, self.dist = int(emulate_world[0]), int(emulate_world[1]), True
         ne = getattr(scorer, "num_ent", None)
+        self.num_ent = int(ne) if ne else None
         self.bounds = np.asarray([shard_bounds(ne, self.world, g)[0] for g in range(self.world)], np.int64) if ne else None
+        self.device = torch.device(getattr(scorer, "device", "cpu"))
+        self.cuda = self.device.type == "cuda"
+        # steps 1 - 2 of the next chunk beside this chunk's count launch: needs a handle of its own for the encoder (the two would
+        # race on one handle's workspace) and a communicator of its own (one communicator runs its collectives in issue order)
+        # (overlap=False: everything on one stream and one communicator, in program order -- the A/B switch, and the fallback should two
+        #  communicators in flight at once ever misbehave on a node: they are issued in the same order on every rank)
+        self.overlap = bool(self.cuda and self.encoder is not self.scorer and self.dist) if overlap is None else bool(overlap and self.cuda and self.encoder is not self.scorer)
+        self.side = torch.cuda.Stream(device=self.device) if self.overlap else None
+        self.side_group = group
+        if self.overlap and self.world > 1 and not self.emulated:
+            self.side_group = dist.new_group(ranks=dist.get_process_group_ranks(group) if group is not None else None)
+        self._pins, self._pin_i = [None] * 4, 0
         # one power of two for the entity planes of every shard (the x3 mode's logits are then the same bits whatever the layout):
         # agreed at construction, and again from the header rows of step 1 on every chunk (a shard whose weights were reloaded)
         self._absmax_ok = hasattr(scorer, "ent_absmax") and hasattr(scorer, "set_x3_ent_absmax")
         if self.dist and self._absmax_ok:
-            m = torch.as_tensor([float(scorer.ent_absmax())], dtype=torch.float32, device=getattr(scorer, "device", "cpu"))
-            dist.all_reduce(m, op=dist.ReduceOp.MAX, group=self.group)
-            scorer.set_x3_ent_absmax(float(m[0]))
+            m = torch.as_tensor([float(scorer.ent_absmax())], dtype=torch.float32, device=self.device)
+            if not self.emulated:
+                dist.all_reduce(m, op=dist.ReduceOp.MAX, group=self.group)
+            self._set_absmax(float(m[0]))
+
+    # ------------------------------------------------------------------------------------------------ small helpers
+    def _set_absmax(self, m):
+        self.scorer.set_x3_ent_absmax(m)
+        if self.encoder is not self.scorer and hasattr(self.encoder, "set_x3_ent_absmax"):
+            self.encoder.set_x3_ent_absmax(m)
 
     def _allreduce(self, t):
-        if self.dist:
+        if self.dist and not self.emulated:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
+
+    def _all_gather(self, out, buf, group):
+        if self.emulated:
+            out.view(self.world, -1).copy_(buf.reshape(1, -1).expand(self.world, -1))
+        else:
+            dist.all_gather_into_tensor(out, buf, group=group)
 
     def _owned(self, ids_np):
         """(rows [n, d], biases [n]) of ids this shard holds"""
@@ -138,174 +186,287 @@ class EntityShardedRanker(object):
             return sc.owned_rows(ids_np)
         return sc.gather_entities(ids_np), sc.gather_bias(ids_np)
 
-    def _gather_rows(self, e1, e2):
-        """step 1: (ent_emb[e1] [B,d], ent_emb[e2] [B,d], pred_bias[e2] [B]) from ONE all-gather of the owned rows"""
+    @staticmethod
+    def _host_ids(a):
+        # (host copies of the ids drive the plans: pass NumPy arrays -- a device tensor costs a synchronising copy per chunk)
+        return np.ascontiguousarray(np.asarray(a.cpu() if isinstance(a, torch.Tensor) else a).astype(np.int64, copy=False))
+
+    def _hdr(self):
         sc = self.scorer
-        # (ids are compared BY VALUE with the cached plan's: a device tensor costs a synchronising copy per chunk -- pass NumPy arrays.
-        #  Identity + torch's version counter would not do: the library's own kernels write id buffers through raw pointers
-        #  (coper_widen_ids, coper_stage_ids_next), which no counter sees)
-        e1_np = np.asarray(e1.cpu() if isinstance(e1, torch.Tensor) else e1).astype(np.int64)
-        e2_np = np.asarray(e2.cpu() if isinstance(e2, torch.Tensor) else e2).astype(np.int64)
-        B = len(e1_np)
-        if not self.dist or self.bounds is None:
-            r1, r2, b2 = sc.gather_entities(e1_np), sc.gather_entities(e2_np), sc.gather_bias(e2_np)
-            if self.dist:      # (a scorer that does not say how many entities there are: the all-reduce of rounds 2 - 4)
-                d = r1.shape[1]
-                pack = torch.cat([r1, r2, b2.reshape(-1, 1)], dim=1)
-                self._allreduce(pack)
-                return pack[:, :d].contiguous(), pack[:, d:2 * d].contiguous(), pack[:, 2 * d].contiguous()
-            return r1, r2, b2
-        # who owns what is known to every rank (ids are replicated): the plan is kept for the chunk it was made for
-        plan = self._rows_plan
-        if plan is None or plan["B"] != B or not (np.array_equal(plan["e1"], e1_np) and np.array_equal(plan["e2"], e2_np)):
-            ids = np.concatenate([e1_np, e2_np])                                 # positions 0..B-1: e1, B..2B-1: e2
-            owner = np.clip(np.searchsorted(self.bounds, ids, side="right") - 1, 0, self.world - 1)
+        return (float(sc.ent_absmax()), float(getattr(sc, "_x3_absmax", None) or 0.0)) if self._absmax_ok else (0.0, 0.0)
+
+    # ------------------------------------------------------------------------------------------------ the plan (host only)
+    def plan(self, chunk):
+        """Everything the host contributes to a chunk, vectorised (no loop over ranks), no device call: `rank_stream` makes the
+        plan of chunk n + 1 while chunk n runs.  Ids outside [0, num_ent) are refused here (ValueError) -- rounds 2 - 4 gathered
+        zero rows for them, round 5 silently ranked such a query against a clamped entity; the reference's gather
+        raises InvalidArgumentError."""
+        e1, e2, rel = self._host_ids(chunk["e1"]), self._host_ids(chunk["e2"]), self._host_ids(chunk["rel"])
+        B, G, g = len(e1), self.world, self.rank_id
+        if len(e2) != B or len(rel) != B:
+            raise ValueError("chunk: e1, e2, rel of one length")
+        pl = _ChunkPlan()
+        pl.B, pl.split = B, bool(self.split_encoder and G > 1)
+        parts = []
+        if self.bounds is not None and self.dist:
+            ids = np.concatenate([e1, e2])                                       # positions 0..B-1: e1, B..2B-1: e2
+            if B and (int(ids.min()) < 0 or int(ids.max()) >= self.num_ent):
+                raise ValueError("entity id outside [0, %d) in e1 / e2" % self.num_ent)
+            owner = np.searchsorted(self.bounds, ids, side="right") - 1
             order = np.argsort(owner, kind="stable")
-            counts = np.bincount(owner, minlength=self.world)
-            cap = int(counts.max())
+            counts = np.bincount(owner, minlength=G)
             start = np.concatenate([[0], np.cumsum(counts)])
+            cap = int(counts.max()) if B else 0
+            so = owner[order]
             slot = np.empty(2 * B, np.int64)                                     # where position p sits in the gathered tensor
-            for g in range(self.world):
-                slot[order[start[g]:start[g + 1]]] = g * (cap + 1) + 1 + np.arange(counts[g])
-            mine = order[start[self.rank_id]:start[self.rank_id + 1]]
-            dev = getattr(sc, "device", "cpu")
-            plan = self._rows_plan = dict(B=B, e1=e1_np.copy(), e2=e2_np.copy(), cap=cap, mine_ids=ids[mine], n_mine=len(mine),
-                                          take1=torch.as_tensor(slot[:B], device=dev), take2=torch.as_tensor(slot[B:], device=dev))
-        cap = plan["cap"]
-        native = hasattr(sc, "pack_owned_rows") and hasattr(sc, "unpack_rows") and hasattr(sc, "shard")
-        hdr = (float(sc.ent_absmax()), float(getattr(sc, "_x3_absmax", None) or 0.0)) if self._absmax_ok else (0.0, 0.0)
-        if native:           # header + owned rows + zero padding: one launch (the shard-local row numbers are kept with the plan)
-            if "loc" not in plan:
-                plan["loc"] = torch.as_tensor(plan["mine_ids"] - int(sc.shard[0]), dtype=torch.int64).to(sc.device)
-            buf = sc.pack_owned_rows(plan["loc"], cap, hdr[0], hdr[1])
-            d = buf.shape[1] - 1
+            slot[order] = so * (cap + 1) + 1 + (np.arange(2 * B) - start[so])
+            mine = order[start[g]:start[g + 1]]
+            pl.cap1, pl.n_mine, pl.mine_ids = cap, len(mine), ids[mine]
+            parts += [("take1", slot[:B]), ("take2", slot[B:]), ("loc", pl.mine_ids - int(self.bounds[g]))]
         else:
-            rows, bias = self._owned(plan["mine_ids"])
-            d = rows.shape[1]
-            buf = torch.zeros((cap + 1, d + 1), dtype=torch.float32, device=rows.device)
-            if self._absmax_ok:                                                  # the header row: [own maximum, hint in force]
-                buf[0, 0] = hdr[0]
-                buf[0, 1] = hdr[1]
-            if plan["n_mine"]:
-                buf[1:1 + plan["n_mine"], :d] = rows
-                buf[1:1 + plan["n_mine"], d] = bias
-        out = torch.empty((self.world * (cap + 1), d + 1), dtype=torch.float32, device=buf.device)
-        dist.all_gather_into_tensor(out, buf, group=self.group)
-        if self._absmax_ok:
-            head = out.view(self.world, cap + 1, d + 1)[:, 0, :2].cpu()          # (one small D2H per chunk: every rank sees the same values)
-            m = float(head[:, 0].max())
-            if m > 0.0 and bool((head[:, 1] != m).any()):                        # some rank runs on another hint (reloaded weights): all re-agree
-                sc.set_x3_ent_absmax(m)
-        if native:
-            return sc.unpack_rows(out, plan["take1"], plan["take2"])
-        g1, g2 = out.index_select(0, plan["take1"]), out.index_select(0, plan["take2"])
-        return g1[:, :d].contiguous(), g2[:, :d].contiguous(), g2[:, d].contiguous()
-
-    def encode(self, e1, rel, rows=None):
-        """step 2: h [B, d] on every rank; `rows` = ent_emb[e1] (step 1) or None to fetch them here"""
-        sc = self.scorer
-        if rows is None:
-            rows = self._allreduce(sc.gather_entities(e1))
-        # (host copies of the ids drive the split: pass NumPy arrays -- device tensors cost a synchronising copy each per chunk)
-        rel_np = np.asarray(rel.cpu() if isinstance(rel, torch.Tensor) else rel)
-        e1_np = np.asarray(e1.cpu() if isinstance(e1, torch.Tensor) else e1)
-        B = len(rel_np)
-        if self.world == 1 or not self.split_encoder:
-            h = sc.encode(e1_np, rel_np, e1_rows=rows)
-            if self.world == 1 and self.dist:          # one rank: the gather of a single share (keeps the RCCL path exercised)
-                out = torch.empty_like(h)
-                dist.all_gather_into_tensor(out, h.contiguous(), group=self.group)
-                h = out
-            return h
-        # the relation split is known to every rank (ids are replicated): shares, their order, the largest one.  An evaluation
-        # set is scored pass after pass: the plan (host argsort / bincount, four small H2D copies) is kept for the chunk it
-        # was made for and reused while the relation ids compare equal (a 20 us check against ~200 us of planning and syncs)
-        plan = self._plan
-        if plan is None or plan["B"] != B or not np.array_equal(plan["rel"], rel_np):
-            owner = rel_np % self.world
+            pl.cap1, pl.n_mine, pl.mine_ids = 0, 0, None
+        if pl.split:
+            owner = rel % G
             order = np.argsort(owner, kind="stable")
-            counts = np.bincount(owner, minlength=self.world)
-            cap = int(counts.max())
-            mine = order[int(counts[:self.rank_id].sum()):int(counts[:self.rank_id + 1].sum())]
-            take = np.concatenate([g * cap + np.arange(counts[g]) for g in range(self.world)])
-            dev = rows.device
-            plan = self._plan = dict(B=B, rel=rel_np.copy(), cap=cap, mine=mine, sel=torch.as_tensor(mine, device=dev),
-                                     order=torch.as_tensor(order, device=dev), take=torch.as_tensor(take, device=dev))
-        cap, mine = plan["cap"], plan["mine"]
-        buf = torch.zeros((cap, rows.shape[1]), dtype=torch.float32, device=rows.device)
-        if len(mine):
-            buf[:len(mine)] = sc.encode(e1_np[mine], rel_np[mine], e1_rows=rows.index_select(0, plan["sel"]).contiguous())
-        out = torch.empty((self.world * cap, rows.shape[1]), dtype=torch.float32, device=rows.device)
-        dist.all_gather_into_tensor(out, buf, group=self.group)
-        # share g sits at rows [g cap, g cap + counts[g]); `order` lists the queries share by share
-        h = torch.empty((B, rows.shape[1]), dtype=torch.float32, device=rows.device)
-        h.index_copy_(0, plan["order"], out.index_select(0, plan["take"]))
-        return h
+            counts = np.bincount(owner, minlength=G)
+            start = np.concatenate([[0], np.cumsum(counts)])
+            cap = int(counts.max()) if B else 0
+            so = owner[order]
+            mine = order[start[g]:start[g + 1]]
+            pl.cap2, pl.n_enc = cap, len(mine)
+            # share g sits at rows [g cap, g cap + counts[g]) of the gathered h; `order` lists the queries share by share
+            parts += [("sel", mine), ("order", order), ("take", so * cap + (np.arange(B) - start[so])), ("rel_mine", rel[mine])]
+        else:
+            pl.cap2, pl.n_enc = B, B
+            parts += [("rel_all", rel)]
+        pl.off, n = {}, 0
+        for name, a in parts:
+            pl.off[name] = (n, n + len(a))
+            n += len(a)
+        if self.cuda:       # one pinned buffer (a small ring: the copy of the plan before last may still be in flight), one H2D
+            i = self._pin_i = (self._pin_i + 1) % len(self._pins)
+            if self._pins[i] is None or self._pins[i].numel() < max(1, n):
+                self._pins[i] = torch.empty(max(1, n) * 2, dtype=torch.int64).pin_memory()
+            pl.ints = self._pins[i][:n]
+            host = pl.ints.numpy()
+        else:
+            pl.ints = torch.empty(n, dtype=torch.int64)
+            host = pl.ints.numpy()
+        for name, a in parts:
+            lo, hi = pl.off[name]
+            host[lo:hi] = a
+        pl.dev = None
+        return pl
 
-    def rank(self, chunk, k=0):
-        """Returns (ranks, n_equal) int32 [B]; with k > 0 also the global top-k of the filtered rows
-        (topk_val f32 [B,k], topk_idx int64 [B,k]), merged from the per-shard top-k in (score desc, id asc) order."""
+    def _dev(self, pl, name):
+        if pl.dev is None:
+            pl.dev = pl.ints.to(self.device, non_blocking=True) if self.cuda else pl.ints
+        lo, hi = pl.off[name]
+        return pl.dev[lo:hi]
+
+    # ------------------------------------------------------------------------------------------------ steps 1 and 2
+    def _steps12(self, pl, chunk, group):
+        """(h [B, d], ent_emb[e2] [B, d], pred_bias[e2] [B], header state [2] or None) on the current stream.  The header state --
+        {table-wide maximum seen in the header rows, 1.0 when some rank runs on another hint} -- stays on the device."""
+        sc, enc, G, B = self.scorer, self.encoder, self.world, pl.B
+        hdr_state = None
+        if pl.mine_ids is None:      # not distributed, or a scorer that does not say how many entities there are (the all-reduce of rounds 2 - 4)
+            e1, e2 = self._host_ids(chunk["e1"]), self._host_ids(chunk["e2"])
+            rows1, rows2, bias2 = sc.gather_entities(e1), sc.gather_entities(e2), sc.gather_bias(e2)
+            if self.dist:
+                d = rows1.shape[1]
+                pack = torch.cat([rows1, rows2, bias2.reshape(-1, 1)], dim=1)
+                self._allreduce(pack)
+                rows1, rows2, bias2 = pack[:, :d].contiguous(), pack[:, d:2 * d].contiguous(), pack[:, 2 * d].contiguous()
+        else:
+            cap = pl.cap1
+            native = hasattr(sc, "pack_owned_rows") and hasattr(sc, "unpack_rows") and hasattr(sc, "shard")
+            hdr = self._hdr()
+            if native:           # header + owned rows + zero padding: one launch
+                buf = sc.pack_owned_rows(self._dev(pl, "loc"), cap, hdr[0], hdr[1])
+                d = buf.shape[1] - 1
+            else:
+                rows, bias = self._owned(pl.mine_ids)
+                d = rows.shape[1]
+                buf = torch.zeros((cap + 1, d + 1), dtype=torch.float32, device=rows.device)
+                buf[0, 0], buf[0, 1] = hdr[0], hdr[1]                            # the header row: [own maximum, hint in force]
+                if pl.n_mine:
+                    buf[1:1 + pl.n_mine, :d] = rows
+                    buf[1:1 + pl.n_mine, d] = bias
+            out = torch.empty((G * (cap + 1), d + 1), dtype=torch.float32, device=buf.device)
+            self._all_gather(out, buf, group)
+            if self._absmax_ok:
+                head = out.view(G, cap + 1, d + 1)[:, 0, :2]
+                m = head[:, 0].max()
+                hdr_state = torch.stack([m, ((head[:, 1] != m).any() & (m > 0)).to(torch.float32)])
+            if native:
+                rows1, rows2, bias2 = sc.unpack_rows(out, self._dev(pl, "take1"), self._dev(pl, "take2"))
+            else:
+                g1, g2 = out.index_select(0, self._dev(pl, "take1")), out.index_select(0, self._dev(pl, "take2"))
+                rows1, rows2, bias2 = g1[:, :d].contiguous(), g2[:, :d].contiguous(), g2[:, d].contiguous()
+        # step 2
+        if not pl.split:
+            h = enc.encode(None, self._dev(pl, "rel_all"), e1_rows=rows1)
+            if G == 1 and self.dist:          # one rank: the gather of a single share (keeps the RCCL path exercised)
+                out = torch.empty_like(h)
+                self._all_gather(out, h.contiguous(), group)
+                h = out
+        else:
+            d = rows1.shape[1]
+            buf = torch.zeros((pl.cap2, d), dtype=torch.float32, device=rows1.device)
+            if pl.n_enc:
+                buf[:pl.n_enc] = enc.encode(None, self._dev(pl, "rel_mine"), e1_rows=rows1.index_select(0, self._dev(pl, "sel")).contiguous())
+            out = torch.empty((G * pl.cap2, d), dtype=torch.float32, device=rows1.device)
+            self._all_gather(out, buf, group)
+            h = torch.empty((B, d), dtype=torch.float32, device=rows1.device)
+            h.index_copy_(0, self._dev(pl, "order"), out.index_select(0, self._dev(pl, "take")))
+        return h, rows2, bias2, hdr_state
+
+    # ------------------------------------------------------------------------------------------------ step 3
+    def _audited(self):
         sc = self.scorer
-        rows1, rows2, bias2 = self._gather_rows(chunk["e1"], chunk["e2"])        # step 1
-        h = self.encode(chunk["e1"], chunk["rel"], rows=rows1)                    # step 2
+        return hasattr(sc, "band_audit") and hasattr(sc, "band_policy") and getattr(sc, "score_mode", None) == "bf16x3"
+
+    def _step3(self, chunk, h, rows2, bias2, k):
+        """The gathered records [G, B + 1, 1 + 2 k] (device) of one count over the rank's rows: ONE all-gather of the packed
+        per-shard record [ng << 32 | ne, k score bit patterns, k ids] per query, and one more row per rank: the words of its band
+        audit (x3 scorers) -- every rank sees every rank's audit, so all of them apply the SAME policy without another collective."""
+        sc = self.scorer
         tx = sc.score_rows(h, rows2, bias2)          # the targets by the fp32 chain, on every rank from its own copy of the rows
         tgt = torch.stack([tx, tx])
-        # step 3: ONE all-gather of the packed per-shard record: [ng<<32 | ne, k score bit patterns, k ids] per query, and one more
-        # row per rank: the words of its band audit (x3 scorers).  Every rank sees every rank's audit, so all of them apply the
-        # SAME policy (coper_band_policy on the largest ratio): widen kappa together, and -- from 1.0 on -- count the chunk again
-        # together (round 5; the unsharded ranker does the same in metrics.ranking_and_hits).  No extra collective.
-        audited = hasattr(sc, "band_audit") and hasattr(sc, "band_policy") and getattr(sc, "score_mode", None) == "bf16x3"
-        for attempt in range(5):
-            out = sc.rank_counts(h, tgt, chunk["e2"], chunk["filt_indptr"], chunk["filt_idx"],
-                                 filt_nnz=len(chunk["filt_idx"]), k=k)
-            ng, ne = out[0], out[1]
-            B = ng.shape[0]
-            native = hasattr(sc, "pack_shard_record") and hasattr(sc, "merge_shard_records")
-            if native:       # one launch: counts, top-k and the audit words (read and reset on the device: no host round trip here)
-                rec = sc.pack_shard_record(ng, ne, out[2] if k > 0 else None, out[3] if k > 0 else None, reset_audit=True)
-            else:
-                rec = torch.zeros((B + 1, 1 + 2 * k), dtype=torch.int64, device=ng.device)
-                rec[:B, 0] = (ng.to(torch.int64) << 32) | ne.to(torch.int64)
-                if k > 0:
-                    rec[:B, 1:1 + k] = out[2].contiguous().view(torch.int32).to(torch.int64)
-                    rec[:B, 1 + k:] = out[3]
-                if audited:
-                    ratio, n_pairs = sc.band_audit()
-                    rec[B, 0] = (int(np.float32(ratio).view(np.uint32)) << 32) | (min(int(n_pairs), 0x7fffffff) & 0xffffffff)
-            if self.dist:
-                allrec = torch.empty((self.world * (B + 1), 1 + 2 * k), dtype=torch.int64, device=rec.device)
-                dist.all_gather_into_tensor(allrec, rec, group=self.group)           # concatenated along dim 0 (gloo + nccl)
-                allrec = allrec.view(self.world, B + 1, 1 + 2 * k)
-            else:
-                allrec = rec.view(1, B + 1, 1 + 2 * k)
-            if not audited:
-                break
-            words = allrec[:, B, 0].cpu().numpy()
-            ratios = (words >> 32).astype(np.uint32).view(np.float32)
-            pairs = int((words & 0xffffffff).sum())
-            action, _ = sc.band_policy(float(ratios.max()) if pairs else 0.0, pairs)
-            if action != 2:
-                break
+        # (`e2_dev`: the targets' ids already on the device -- the plans read chunk["e2"] on the host)
+        out = sc.rank_counts(h, tgt, chunk.get("e2_dev", chunk["e2"]), chunk["filt_indptr"], chunk["filt_idx"], filt_nnz=len(chunk["filt_idx"]), k=k)
+        ng, ne = out[0], out[1]
+        B = ng.shape[0]
+        if hasattr(sc, "pack_shard_record"):     # one launch: counts, top-k and the audit words (read and reset on the device)
+            rec = sc.pack_shard_record(ng, ne, out[2] if k > 0 else None, out[3] if k > 0 else None, reset_audit=True)
         else:
-            raise RuntimeError("bf16x3 band audit: still above the band's allowance after 4 re-counted chunks")
-        if native:           # one launch: the summed counts and the candidates side by side
-            ranks, ne_i, vals, ids = sc.merge_shard_records(allrec, self.world, B, k)
+            rec = torch.zeros((B + 1, 1 + 2 * k), dtype=torch.int64, device=ng.device)
+            rec[:B, 0] = (ng.to(torch.int64) << 32) | ne.to(torch.int64)
+            if k > 0:
+                rec[:B, 1:1 + k] = out[2].contiguous().view(torch.int32).to(torch.int64)
+                rec[:B, 1 + k:] = out[3]
+            if self._audited():
+                ratio, n_pairs = sc.band_audit()
+                rec[B, 0] = (int(np.float32(ratio).view(np.uint32)) << 32) | (min(int(n_pairs), 0x7fffffff) & 0xffffffff)
+        if self.dist:
+            allrec = torch.empty((self.world * (B + 1), 1 + 2 * k), dtype=torch.int64, device=rec.device)
+            self._all_gather(allrec, rec, self.group)                            # concatenated along dim 0 (gloo + nccl)
+            return allrec.view(self.world, B + 1, 1 + 2 * k)
+        return rec.view(1, B + 1, 1 + 2 * k)
+
+    def _merge(self, allrec, B, k):
+        sc = self.scorer
+        if hasattr(sc, "merge_shard_records"):   # one launch: the summed counts and the candidates side by side
+            ranks, ne_tot, vals, ids = sc.merge_shard_records(allrec, self.world, B, k)
             if k == 0:
-                return ranks, ne_i
-            ne_tot = ne_i
+                return ranks, ne_tot
         else:
-            allrec = allrec[:, :B, :]
-            ng_tot = (allrec[:, :, 0] >> 32).sum(dim=0)
-            ne_tot = (allrec[:, :, 0] & 0xFFFFFFFF).sum(dim=0)
-            ranks = (1 + ng_tot).to(torch.int32)
+            rec = allrec[:, :B, :]
+            ranks = (1 + (rec[:, :, 0] >> 32).sum(dim=0)).to(torch.int32)
+            ne_tot = (rec[:, :, 0] & 0xFFFFFFFF).sum(dim=0).to(torch.int32)
             if k == 0:
-                return ranks, ne_tot.to(torch.int32)
-            vals = allrec[:, :, 1:1 + k].to(torch.int32).view(torch.float32).permute(1, 0, 2).reshape(B, -1)
-            ids = allrec[:, :, 1 + k:].permute(1, 0, 2).reshape(B, -1)
+                return ranks, ne_tot
+            vals = rec[:, :, 1:1 + k].to(torch.int32).view(torch.float32).permute(1, 0, 2).reshape(B, -1)
+            ids = rec[:, :, 1 + k:].permute(1, 0, 2).reshape(B, -1)
         if self.world == 1:      # one shard: its list is already in (score desc, id asc) order
             return ranks, ne_tot.to(torch.int32), vals.contiguous(), ids.contiguous()
         tv, ti = merge_topk(vals, ids, k)
         return ranks, ne_tot.to(torch.int32), tv, ti
+
+    @staticmethod
+    def _audit_words(words):
+        """(largest ratio, pairs in all, per-rank ratios) of the audit words [.., G] (host int64 array)"""
+        ratios = (words >> 32).astype(np.uint32).view(np.float32)
+        return ratios, (words & 0xffffffff)
+
+    # ------------------------------------------------------------------------------------------------ one chunk, checked
+    def rank(self, chunk, k=0):
+        """Returns (ranks, n_equal) int32 [B]; with k > 0 also the global top-k of the filtered rows
+        (topk_val f32 [B,k], topk_idx int64 [B,k]), merged from the per-shard top-k in (score desc, id asc) order."""
+        pl = self.plan(chunk)
+        B = pl.B
+        h, rows2, bias2, hdr_state = self._steps12(pl, chunk, self.group)
+        if hdr_state is not None:
+            st = hdr_state.cpu()                     # (one small D2H per chunk: every rank sees the same values)
+            if float(st[1]) != 0.0:                  # some rank runs on another hint (reloaded weights): all re-agree, h is encoded again
+                self._set_absmax(float(st[0]))
+                h, rows2, bias2, _ = self._steps12(pl, chunk, self.group)
+        audited = self._audited()
+        for attempt in range(5):
+            allrec = self._step3(chunk, h, rows2, bias2, k)
+            if not audited:
+                break
+            ratios, pairs = self._audit_words(allrec[:, B, 0].cpu().numpy())
+            n_pairs = int(pairs.sum())
+            action, _ = self.scorer.band_policy(float(ratios.max()) if n_pairs else 0.0, n_pairs)
+            if action != 2:
+                break
+        else:
+            raise RuntimeError("bf16x3 band audit: still above the band's allowance after 4 re-counted chunks")
+        return self._merge(allrec, B, k)
+
+    # ------------------------------------------------------------------------------------------------ the evaluation loop
+    def rank_stream(self, chunks, k=0, window=8):
+        """Generator over `chunks` (an iterable of chunk dicts: e1 / rel / e2 host arrays, the CSR filter on the host or the
+        device): yields what `rank` returns for each, in order.  Per chunk the host only plans (one chunk ahead) and enqueues;
+        header comparisons and audit words are read once per `window` chunks, and the results of a window are yielded after its
+        check -- a window that fails it is ranked again chunk by chunk with `rank` (every rank takes the same decision: the words
+        are the same on all of them)."""
+        it = iter(chunks)
+        main = torch.cuda.current_stream(self.device) if self.cuda else None
+        audited = self._audited()
+
+        def issue12(chunk):
+            pl = self.plan(chunk)                                  # host work: overlaps whatever the device is doing
+            if self.overlap:
+                self.side.wait_stream(main)                        # (the parameters / the last set_absmax are stream-ordered on main)
+                with torch.cuda.stream(self.side):
+                    res = self._steps12(pl, chunk, self.side_group)
+                    ev = torch.cuda.Event()
+                    ev.record(self.side)
+                for t in res[:3]:
+                    t.record_stream(main)
+                if res[3] is not None:
+                    res[3].record_stream(main)
+                return chunk, pl, res, ev
+            return chunk, pl, self._steps12(pl, chunk, self.group), None
+
+        nxt_chunk = next(it, None)
+        nxt = issue12(nxt_chunk) if nxt_chunk is not None else None
+        pending = []
+        while nxt is not None:
+            chunk, pl, (h, rows2, bias2, hdr_state), ev = nxt
+            # steps 1 - 2 of the FOLLOWING chunk first: with a side stream they run under this chunk's count launch
+            nxt_chunk = next(it, None)
+            nxt = issue12(nxt_chunk) if nxt_chunk is not None else None
+            if ev is not None:
+                main.wait_event(ev)
+            allrec = self._step3(chunk, h, rows2, bias2, k)
+            pending.append((chunk, pl.B, allrec, hdr_state, self._merge(allrec, pl.B, k)))
+            if len(pending) >= window or nxt is None:
+                redo_all, redo = False, set()
+                states = [p[3] for p in pending if p[3] is not None]
+                words = [p[2][:, p[1], 0] for p in pending] if audited else []
+                if states or words:                                 # ONE wait per window (two small copies behind the same work)
+                    st = torch.stack(states).cpu().numpy() if states else None
+                    wd = torch.stack(words).cpu().numpy() if words else None
+                    if st is not None and (st[:, 1] != 0).any():
+                        self._set_absmax(float(st[:, 0].max()))
+                        redo_all = True
+                    if wd is not None and not redo_all:
+                        ratios, pairs = self._audit_words(wd)       # [n, G]
+                        n_pairs = int(pairs.sum())
+                        action, _ = self.scorer.band_policy(float(ratios.max()) if n_pairs else 0.0, n_pairs)
+                        if action == 2:
+                            redo = {i for i in range(len(pending)) if float(ratios[i].max()) >= 1.0}
+                if (redo_all or redo) and nxt is not None and self.overlap:
+                    main.wait_stream(self.side)                     # (the chunk issued ahead ran on the old planes / hint: issued again below)
+                for i, p in enumerate(pending):
+                    yield self.rank(p[0], k=k) if (redo_all or i in redo) else p[4]
+                if redo_all and nxt is not None:
+                    nxt = issue12(nxt[0])
+                pending = []
 
 
 def merge_topk(vals, ids, k):

@@ -107,8 +107,18 @@ typedef struct coper_config {
    * launch after coper_prepare and every 8th from there (+3 us per 0.5 ms pass), every launch of more than 2^31 logits;
    * n > 0: every n-th launch; negative: never.  Launches recorded into a hipGraph carry the audit only with n = 1. */
   int32_t band_audit_period;
-  int32_t reserved[4];
+  /* What the handle is built for (round 6; 0 = COPER_ROLE_BOTH = every earlier caller).  An entity-sharded evaluation runs the
+   * rank's share of the encoder and its count over the rank's entity rows on TWO streams (coper_amd/sharding.py: steps 1 - 2 of
+   * chunk n + 1 under chunk n's count launch), which one handle's workspace cannot serve: it creates one handle per role over the
+   * SAME parameter tensors.  COPER_ROLE_ENCODE builds no entity planes (4 x |E_local| d 2 + |E_local| d 4 bytes) and refuses the
+   * scoring entry points; COPER_ROLE_SCORE evaluates no generator and caches no W_r (R2 F d 4 bytes: 12.8 GB for the 10M-entity
+   * config) and refuses coper_encode / coper_encode_rank / training.  Everything both roles derive (folded BN, the band constants,
+   * the powers of two of split16.h) is the same values on both. */
+  int32_t role;                 /* coper_role */
+  int32_t reserved[3];
 } coper_config;
+
+typedef enum coper_role { COPER_ROLE_BOTH = 0, COPER_ROLE_ENCODE = 1, COPER_ROLE_SCORE = 2 } coper_role;
 
 typedef struct coper_handle coper_handle;
 
@@ -195,12 +205,21 @@ COPER_API int coper_post_i32_next(coper_handle* h, const int32_t* src, int64_t n
  * (e1 / rel of that later coper_encode / coper_encode_rank call; have_e1_rows != 0: it will pass e1_rows, e1 is ignored), whose
  * contents are either there already or are what a coper_stage_ids_next job registered for the same launch will write there.  One
  * more workgroup of the next fused encoder launch then sorts that batch into a second set of grouping arrays while the relation
- * tiles stream their weights; the following call with exactly these pointers and B (and ids unchanged in between) finds its
- * grouping done and starts with its encoder launch (a pending coper_post_i32_next job rides there instead).  Any other call in
- * between, a coper_prepare, a growing workspace or a pass captured into a hipGraph drops the prepared grouping: the pass then groups
- * itself as always -- results never depend on it.  The registration is for the NEXT encode / encode_rank call only: a call that
- * cannot carry it (captured into a hipGraph, a configuration the fused encoder does not serve) drops it.
- * Nothing is queued by this call; B == 0 cancels.  (h[b] is a function of (e1[b], rel[b]) alone either way.) */
+ * tiles stream their weights; the following coper_encode_rank call with exactly these pointers and B finds its grouping done and
+ * starts with its encoder launch (a pending coper_post_i32_next job rides there instead).  Any other call in between (coper_encode
+ * included: only a pass that writes ranks may run on a prepared grouping), a coper_prepare, a training step, a growing workspace
+ * or a pass captured into a hipGraph drops the prepared grouping: the pass then groups itself as always.  The registration is for
+ * the NEXT encode / encode_rank call only: a call that cannot carry it (captured into a hipGraph, a configuration the fused
+ * encoder does not serve) drops it.  Nothing is queued by this call; B == 0 cancels.
+ * THE GUARD.  The pointers identify the batch, not its contents: if the ids at those addresses are rewritten between the launch
+ * that sorted them and the pass that consumes the sorting (the natural mistake with two staging buffers), that pass would encode
+ * the ids that WERE there and rank them against the new e2 / filters.  So the consuming pass checks on the device: every tile
+ * of its encoder launch compares the live (e1, rel) of each of its queries with what was sorted -- every query exactly once, its
+ * loads beside the tile's own first loads -- and on ANY difference the pass's ranks are all written as COPER_RANK_STALE (negative:
+ * no consumer can mistake them for ranks, which start at 1; n_equal / h of that call are undefined) and the pass is counted
+ * (coper_stale_passes).  The caller ranks such a batch again with a plain call; coper_amd.metrics.ranking_and_hits and
+ * bench.py do.  A stale grouping never reaches the ranks; a grouping that is not stale is never reported (tests/test_gpu_pipeline.py:
+ * random interleavings of every registration, pass, prepare, training step, capture and workspace growth, ids rewritten at random). */
 COPER_API int coper_group_next(coper_handle* h, const int64_t* e1, const int64_t* rel, int64_t B, int32_t have_e1_rows);
 
 /* Row gather tf.nn.embedding_lookup(ent_emb, ids) (models.py:176) restricted to the shard:
@@ -358,6 +377,12 @@ COPER_API int coper_hits_means(const int32_t* ranks, int64_t n, const int32_t* l
 /* Ids are validated on the device and clamped, never trusted: returns in *n_bad the number of
  * out-of-range relation ids seen by coper_encode since the last call (synchronises the stream). */
 COPER_API int coper_check_ids(coper_handle* h, int64_t* n_bad, void* stream);
+
+/* The rank written for EVERY query of a coper_encode_rank pass that ran on a grouping prepared ahead (coper_group_next) whose id
+ * arrays had been rewritten since: see "THE GUARD" there.  Whatever the count and band launches add to it stays negative. */
+#define COPER_RANK_STALE (-(1 << 30))
+/* Passes since the last call whose prepared grouping was found stale (synchronises the stream; the counter restarts at 0). */
+COPER_API int coper_stale_passes(coper_handle* h, int64_t* n_passes, void* stream);
 
 /* Device memory (bytes) currently held by all handles of this process: every allocation of the library is entered in a
  * ledger.  Returns to its previous value when a handle is destroyed (tests/test_gpu_train.py checks exactly that).  The

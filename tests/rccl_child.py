@@ -42,6 +42,20 @@ def main():
         assert torch.equal(tv, tv0) and torch.equal(ti, ti0), mode
         ranks2, ne2 = er.rank(q, k=0)
         assert torch.equal(ranks2, r0) and torch.equal(ne2, ne0)
+        # round 6: the evaluation loop with one handle per role (coper_config.role) -- steps 1 - 2 of chunk n + 1 on a side stream and
+        # a second RCCL communicator under chunk n's count launch; three different chunks, window of two, the first chunk's results
+        qs = [q] + [cdata.synthetic_queries(md, 500 + 40 * i, seed=30 + i) for i in range(2)]
+        want = [er.rank(c, k=10) for c in qs]
+        ms = ConvE(md, device=dev, score_mode=mode, role="score").load_parameters(p).prepare()
+        me = ConvE(md, device=dev, score_mode=mode, role="encode").load_parameters(p).prepare()
+        er2 = EntityShardedRanker(ms, encoder=me)
+        assert er2.overlap and er2.side is not None
+        for rep in range(2):
+            got = list(er2.rank_stream(iter(qs), k=10, window=2))
+            for a, b in zip(got, want):
+                for x, y in zip(a, b):
+                    assert torch.equal(x, y), (mode, rep)
+        ms.close(); me.close()
         qe = QueryShardedEvaluator(m)
         r3, ne3 = qe.rank(q)                            # all-gather of the int32 ranks
         assert torch.equal(r3, r0) and torch.equal(ne3, ne0), mode

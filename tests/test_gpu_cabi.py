@@ -635,3 +635,49 @@ def test_band_policy_widens_and_reranks_a_too_narrow_band():
     assert act.value == 0 and kap.value == 0.0                     # no band in the fp32-exact mode
     for x in (m, m32, m32f):
         x.close()
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "f32"])
+def test_one_handle_per_role(mode):
+    """coper_config.role (round 6): a COPER_ROLE_ENCODE handle and a COPER_ROLE_SCORE handle over the same parameter tensors give
+    the bits of a handle that is both; each refuses the other role's entry points with COPER_ESTATE; each holds only its own
+    derived buffers (coper_live_device_bytes)."""
+    from coper_amd import _lib
+    from coper_amd.models import ConvE
+    md = cdata.model_descriptors("fb15k237_cpg", num_ent=6000, num_rel=60)
+    p = {k: torch.as_tensor(v).to("cuda:0") for k, v in cdata.synthetic_params(md, 2).items()}
+    q = cdata.synthetic_queries(md, 900, seed=3)
+    lib = _lib.load()
+    base = lib.coper_live_device_bytes()
+    both = ConvE(md, device="cuda:0", score_mode=mode).load_parameters(p).prepare()
+    n_both = lib.coper_live_device_bytes() - base
+    enc = ConvE(md, device="cuda:0", score_mode=mode, role="encode").load_parameters(p).prepare()
+    n_enc = lib.coper_live_device_bytes() - base - n_both
+    sco = ConvE(md, device="cuda:0", score_mode=mode, role="score").load_parameters(p).prepare()
+    n_sco = lib.coper_live_device_bytes() - base - n_both - n_enc
+    assert 0 < n_enc < n_both and 0 < n_sco < n_both and n_enc + n_sco < 1.1 * n_both, (n_both, n_enc, n_sco)
+    h0 = both.encode(q["e1"], q["rel"])
+    h1 = enc.encode(q["e1"], q["rel"])
+    assert torch.equal(h0, h1)
+    r0, ne0 = both.rank(h0, q["e2"], q["filt_indptr"], q["filt_idx"])
+    r1, ne1 = sco.rank(h1, q["e2"], q["filt_indptr"], q["filt_idx"])
+    assert torch.equal(r0, r1) and torch.equal(ne0, ne1)
+    assert torch.equal(both.score_all(h0[:64]), sco.score_all(h0[:64]))
+    tgt = sco.target_scores(h0, q["e2"])
+    a = both.rank_counts(h0, both.target_scores(h0, q["e2"]), q["e2"], q["filt_indptr"], q["filt_idx"], k=7)
+    b = sco.rank_counts(h0, tgt, q["e2"], q["filt_indptr"], q["filt_idx"], k=7)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    rows = both.gather_entities(q["e1"])
+    assert torch.equal(enc.gather_entities(q["e1"]), rows) and torch.equal(sco.gather_entities(q["e1"]), rows)
+    assert torch.equal(enc.encode(None, torch.as_tensor(q["rel"]).to("cuda:0"), e1_rows=rows), h0)
+    for bad in (lambda: enc.score_all(h0[:4]), lambda: enc.rank(h0, q["e2"], q["filt_indptr"], q["filt_idx"]),
+                lambda: enc.rank_pass(q["e1"], q["rel"], q["e2"], q["filt_indptr"], q["filt_idx"]),
+                lambda: sco.encode(q["e1"], q["rel"]), lambda: sco.rank_pass(q["e1"], q["rel"], q["e2"], q["filt_indptr"], q["filt_idx"]),
+                lambda: sco.train_init()):
+        with pytest.raises(_lib.CoperError) as e:
+            bad()
+        assert e.value.code == 5, e.value
+    for m in (both, enc, sco):
+        m.close()
+    assert lib.coper_live_device_bytes() == base

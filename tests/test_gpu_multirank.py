@@ -19,12 +19,12 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run_bench(extra, timeout=600):
+def _run_bench(extra, timeout=600, world=2):
     import torch
-    backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    backend = "nccl" if torch.cuda.device_count() >= world else "gloo"
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", backend, "--steps", "3",
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--dist-backend", backend, "--steps", "3",
                           "--warmup", "1", "--no-cpu-baseline", "--launch-timeout", str(timeout - 60)] + extra, env=env, capture_output=True, text=True, timeout=timeout)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-6000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -68,3 +68,21 @@ def test_bench_two_ranks_three_times_back_to_back():
         assert line["n_gpus"] == 2 and line["value"] > 0
         ranks.append((line["config"]["mean_rank"], line["config"]["mrr"]))
     assert ranks[0] == ranks[1] == ranks[2]
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_bench_scale_block_at_the_target_world_size(world):
+    """the entity-sharded path at north_star's own world size with the REAL kernels.  On a one-GPU box the
+    ranks share the GPU and talk over gloo (8 x (a 1.25 M-row shard's planes + the rank's W_r cache) fits 288 GB); with >= `world`
+    GPUs they get one each over RCCL.  1.25 M-row (2.5 M-row) shards, the `rel mod world` encoder split, k_band_exact<3> on shards,
+    the 8-row (4-row) all-gather layouts -- and the ranks of every chunk must be the single-GPU ranks bit for bit (SHA-1)."""
+    from bench import SCALE_EXPECTED
+    line, backend = _run_bench([], timeout=900, world=world)
+    assert line["n_gpus"] == world and line["value"] > 0
+    assert line["config"]["parallelism"] == "query-sharded x%d" % world
+    sc = line["scale"]
+    assert sc["n_gpus"] == world
+    assert sc["config"]["parallelism"].startswith("entity-sharded x%d (%d rows per rank)" % (world, 10_000_000 // world))
+    assert sc["ranks_independent_of_world"] is True
+    assert sc["ranks_sha1"] == SCALE_EXPECTED["ranks_sha1"]
+    assert abs(sc["mean_rank"] - SCALE_EXPECTED["mean_rank"]) < 1e-6

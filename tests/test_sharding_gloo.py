@@ -56,6 +56,31 @@ def _worker(rank, world, port, mode, out_dir):
             assert sc._x3_absmax == np.float32(new_full), (rank, sc._x3_absmax, new_full)
             np.save(os.path.join(out_dir, "tv_%d.npy" % rank), tv.numpy())
             np.save(os.path.join(out_dir, "ti_%d.npy" % rank), ti.numpy())
+        elif mode == "entity_stream":
+            # the evaluation loop (round 6): five DIFFERENT chunks through rank_stream -- plans rebuilt per chunk, one chunk ahead, the
+            # header / audit words read once per window of two -- equal, chunk by chunk, to rank() on the same chunk; a hint dropped on
+            # ONE rank (what a reload does) fails the first window's check: every rank re-agrees, the window is ranked again, same ranks
+            sc = OracleShardScorer(p, md, shard_bounds(md["num_ent"], world, rank))
+            ranker = EntityShardedRanker(sc)
+            qs = [cdata.synthetic_queries(md, 30 + 3 * i, seed=20 + i, mean_filter=3.0, max_filter=12) for i in range(5)]
+            want = [ranker.rank(c, k=5) for c in qs]
+            if rank == world - 1:
+                sc._x3_absmax = None
+            got = list(ranker.rank_stream(iter(qs), k=5, window=2))
+            assert len(got) == len(want)
+            for a, b in zip(got, want):
+                for x, y in zip(a, b):
+                    assert torch.equal(x, y)
+            assert sc._x3_absmax == np.float32(np.abs(p["ent_emb"]).max())
+            assert list(ranker.rank_stream([], k=0)) == []
+            # ids outside the table are refused when the chunk is planned (the reference's gather raises InvalidArgumentError)
+            bad = dict(qs[0], e2=np.where(np.arange(len(qs[0]["e2"])) == 3, md["num_ent"], qs[0]["e2"]))
+            try:
+                ranker.rank(bad)
+                raise AssertionError("an entity id beyond the table was accepted")
+            except ValueError:
+                pass
+            ranks, ne = ranker.rank(q)
         elif mode == "entity_nosplit":
             sc = OracleShardScorer(p, md, shard_bounds(md["num_ent"], world, rank))
             ranks, ne = EntityShardedRanker(sc, split_encoder=False).rank(q)
@@ -78,7 +103,7 @@ def _expected():
     return ranks.numpy(), ne.numpy()
 
 
-@pytest.mark.parametrize("mode,world", [("entity", 2), ("entity", 3), ("entity", 4), ("entity_nosplit", 2), ("query", 2), ("query", 3)])
+@pytest.mark.parametrize("mode,world", [("entity", 2), ("entity", 3), ("entity", 4), ("entity_stream", 2), ("entity_stream", 3), ("entity_nosplit", 2), ("query", 2), ("query", 3)])
 def test_sharded_ranks_equal_single_process(tmp_path, oracle_chain, mode, world):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, mode, str(tmp_path)), nprocs=world, join=True)
