@@ -304,7 +304,9 @@ def run_scale_blocks(ctx, args):
     # side stream under chunk n's count launch (--no-scale-overlap: one stream, program order)
     model = ConvE(md, device=ctx.device, shard=shard, score_mode="bf16x3", role="score")
     model.load_parameters(params, global_rows=False)
-    enc = ConvE(md, device=ctx.device, shard=shard, score_mode="bf16x3", role="encode")
+    # (the encoder is split by relation: rank g encodes the queries with rel mod world == g and holds the generated weights of those
+    #  relations only -- coper_config.rel_mod_*: 12.8 GB / world)
+    enc = ConvE(md, device=ctx.device, shard=shard, score_mode="bf16x3", role="encode", rel_mod=(ctx.world, ctx.rank) if ctx.world > 1 else None)
     enc.load_parameters(params, global_rows=False)
     ranker = EntityShardedRanker(model, encoder=enc, overlap=not args.no_scale_overlap)       # (before prepare: the ranks agree on the entity planes' power of two first)
     t0 = time.perf_counter()
@@ -409,7 +411,7 @@ def run_scale_blocks(ctx, args):
         params_g, _ = device_params(md, 0, ctx.device, shard_g)
         mg = ConvE(md, device=ctx.device, shard=shard_g, score_mode="bf16x3", role="score")
         mg.load_parameters(params_g, global_rows=False)
-        eg = ConvE(md, device=ctx.device, shard=shard_g, score_mode="bf16x3", role="encode")
+        eg = ConvE(md, device=ctx.device, shard=shard_g, score_mode="bf16x3", role="encode", rel_mod=(G, 0))
         eg.load_parameters(params_g, global_rows=False)
         rg = EntityShardedRanker(mg, encoder=eg, emulate_world=(G, 0), overlap=not args.no_scale_overlap)
         mg.prepare()

@@ -44,7 +44,7 @@ class coper_config(C.Structure):
         ("context_rel_use_batch_norm", C.c_int32), ("bn_epsilon", C.c_float),
         ("shard_lo", C.c_int64), ("shard_hi", C.c_int64),
         ("score_mode", C.c_int32), ("rank_band_kappa", C.c_float), ("x3_ent_absmax", C.c_float),
-        ("band_audit_period", C.c_int32), ("role", C.c_int32), ("reserved", C.c_int32 * 3),
+        ("band_audit_period", C.c_int32), ("role", C.c_int32), ("rel_mod_world", C.c_int32), ("rel_mod_rank", C.c_int32), ("reserved", C.c_int32 * 1),
     ]
 
 
@@ -154,7 +154,7 @@ ROLE_BOTH, ROLE_ENCODE, ROLE_SCORE = 0, 1, 2     # coper_role
 
 
 def make_config(md, device=0, shard=None, score_mode=SCORE_F32, bn_epsilon=1e-3, rank_band_kappa=0.0, x3_ent_absmax=0.0,
-                band_audit_period=0, role=ROLE_BOTH):
+                band_audit_period=0, role=ROLE_BOTH, rel_mod=None):
     """model_descriptors dict (models.py:98-130 keys) -> coper_config."""
     cfg = coper_config()
     cfg.abi_version = COPER_ABI_VERSION
@@ -193,4 +193,6 @@ def make_config(md, device=0, shard=None, score_mode=SCORE_F32, bn_epsilon=1e-3,
     cfg.x3_ent_absmax = float(x3_ent_absmax)         # 0: the handle's own rows; entity shards pass the table-wide maximum
     cfg.band_audit_period = int(band_audit_period)   # 0: the library default (first count launch, then every 8th)
     cfg.role = int(role)                             # 0: encoder and scorer (every handle before round 6)
+    if rel_mod is not None:                          # (G, g): generated dense weights of the relations r with r mod G == g only
+        cfg.rel_mod_world, cfg.rel_mod_rank = int(rel_mod[0]), int(rel_mod[1])
     return cfg

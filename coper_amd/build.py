@@ -63,14 +63,6 @@ def build_library(force=False, verbose=False, extra_flags=(), out=None, jobs=4):
     hdr_t = max(os.path.getmtime(p) for p in headers + [os.path.abspath(__file__)])
     base = [_hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-fvisibility=hidden", "-Wall",
             "-Wno-unused-function", "-DCOPER_BUILD", *extra_flags]
-    if any(f.startswith("-DCOPER_SC3_ASM_LOADS") for f in extra_flags):
-        # the count kernel's regions with their loads inside the asm blocks (a measured, non-default build option): its two
-        # generated includes (4,186 lines) are written on demand instead of being kept in the tree
-        gen = os.path.join(HERE, "..", "build", "gen")
-        os.makedirs(gen, exist_ok=True)
-        subprocess.check_call([sys.executable, os.path.join(HERE, "..", "tools", "gen_sc3_region_asm.py"), gen, "--with-loads"],
-                              stdout=subprocess.DEVNULL)
-        base += ["-I" + gen]
     todo, objs = [], []
     for src in SOURCES:
         sp = os.path.join(CSRC, src)

@@ -37,7 +37,7 @@ namespace coper {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// (the 16-bit type of the split -- fp16, or bf16 in COPER_SPLIT_BF16 builds -- is split16.h's business)
+// (the 16-bit type of the split -- fp16 -- is split16.h's business)
 #define BX3_MFMA32(a, b, c) S16_MFMA32(a, b, c)
 #define BX3_MFMA16(a, b, c) S16_MFMA16(a, b, c)
 

@@ -366,6 +366,8 @@ COPER_API int coper_create(const coper_config* cfg, coper_handle** out) {
     return bad("score_mode: COPER_SCORE_F32 or COPER_SCORE_BF16X3");
   if (cfg->role != COPER_ROLE_BOTH && cfg->role != COPER_ROLE_ENCODE && cfg->role != COPER_ROLE_SCORE)
     return bad("role: COPER_ROLE_BOTH, COPER_ROLE_ENCODE or COPER_ROLE_SCORE");
+  if (cfg->rel_mod_world < 0 || (cfg->rel_mod_world > 1 && (cfg->rel_mod_rank < 0 || cfg->rel_mod_rank >= cfg->rel_mod_world)))
+    return bad("rel_mod_world >= 0 and 0 <= rel_mod_rank < rel_mod_world");
   // models.py:360: e1 stacked on the reshaped relation only for plain ConvE
   dm.stacked = !dm.gen_conv && !dm.gen_fc && !dm.lookup;
   dm.in_h = dm.emb_h; dm.in_w = dm.emb_w;
@@ -438,7 +440,7 @@ COPER_API void coper_destroy(coper_handle* h) {
   dev_free(&h->tiles); dev_free(&h->n_tiles); dev_free(&h->blk_off); dev_free(&h->x_sorted); dev_free(&h->z_part);
   dev_free(&h->tgt_ws); dev_free(&h->h_ws); dev_free(&h->cnt_ws); dev_free(&h->hfrag_ws); dev_free(&h->logits_ws); dev_free(&h->row_of_ws);
   dev_free(&h->tk_coarse_ws); dev_free(&h->gmax_ws); dev_free(&h->cand_blk_ws); dev_free(&h->cand_val_ws); dev_free(&h->cand_q_ws); dev_free(&h->cand_tau_ws); dev_free(&h->cand_sorted_ws); dev_free(&h->blk_cnt_ws); dev_free(&h->blk_off_ws);
-  dev_free((char**)&h->Wf16_hi); dev_free((char**)&h->Wf16_lo); dev_free((char**)&h->Wf8_lo);
+  dev_free((char**)&h->Wf16_hi); dev_free((char**)&h->Wf16_lo);
   dev_free((char**)&h->Ef16_hi); dev_free((char**)&h->Ef16_lo); dev_free((char**)&h->hfrag16_hi); dev_free((char**)&h->hfrag16_lo);
   dev_free((char**)&h->Erm16_hi); dev_free((char**)&h->Erm16_lo); dev_free((char**)&h->hrm16_hi); dev_free((char**)&h->hrm16_lo);
   dev_free((char**)&h->Ef3); dev_free((char**)&h->hf3_ws); dev_free((char**)&h->mask_ws); dev_free(&h->band_consts); dev_free(&h->tband_ws); dev_free(&h->x3s); dev_free(&h->x3m); dev_free(&h->w_exp); dev_free((char**)&h->fused_fin_dev);
@@ -489,6 +491,7 @@ COPER_API int coper_set_param(coper_handle* h, const char* leaf_name, const void
   it->second.shape = got;
   it->second.set = true;
   h->prepared = false;
+  train_params_changed(h);
   return COPER_OK;
 }
 
@@ -616,8 +619,16 @@ COPER_API int coper_prepare(coper_handle* h, void* stream) {
   }
   int64_t ksteps = dm.F_pad / 16;
   size_t per_rel = (size_t)dm.nfb * ksteps * 64 * 4;  // floats
-  h->Rw = dm.gen_fc ? dm.R : 1;
+  // coper_config.rel_mod_*: weight sets of the relations r with r % G == g only, relation r at slot r / G (ceil(R / G) slots on
+  // every rank: a relation id the handle does not hold still indexes inside the planes; it is counted, kernels_dense_fused_bf16.hip)
+  const int w_div = cfg.rel_mod_world > 1 ? cfg.rel_mod_world : 1, w_rem = w_div > 1 ? cfg.rel_mod_rank : 0;
+  if (w_div > 1 && (!dm.gen_fc || dm.lookup || cfg.score_mode == COPER_SCORE_F32))
+    return fail(h, COPER_EUNSUPPORTED, "rel_mod_world > 1: COPER_SCORE_BF16X3 with generated dense weights (context_rel_out) only");
+  h->w_div = w_div; h->w_rem = w_rem;
+  const int64_t n_own = w_div > 1 ? (dm.R > w_rem ? (dm.R - w_rem + w_div - 1) / w_div : 0) : dm.R;
+  h->Rw = dm.gen_fc ? (w_div > 1 ? (dm.R + w_div - 1) / w_div : dm.R) : 1;
   if ((rc = dev_alloc(h, &h->Wf, per_rel * h->Rw))) return rc;
+  float* ctx_sel = nullptr;       // the generator contexts of the held relations, compacted (freed behind the synchronize below)
   if (dm.gen_fc) {
     if ((rc = dev_alloc(h, &h->fc_b_rel, (size_t)dm.R * dm.d))) return rc;
     if (dm.lookup) {
@@ -630,27 +641,54 @@ COPER_API int coper_prepare(coper_handle* h, void* stream) {
       if ((rc = launch_gen_small(h, ctx, dm.R, K, P(buf), dm.d, nullptr, nullptr, false, h->fc_b_rel, s))) return rc;
       if ((rc = run_generator_hidden(h, "fc_weights", cfg.n_ctx_out, cfg.ctx_out, &ctx, &K, s))) return rc;
       snprintf(buf, sizeof buf, "fc_weights/CPG/Projection%d", cfg.n_ctx_out);
-      if ((rc = launch_gen_dense_frag(h, ctx, dm.R, K, P(buf), 0, h->Wf, s))) return rc;
+      if (w_div > 1) {      // slot i = relation w_rem + i w_div: the same context row, the same sum -- W_r is the same bits at any G
+        if ((rc = dev_alloc(h, &ctx_sel, (size_t)h->Rw * K))) return rc;
+        COPER_HIP_TRY(h, hipMemsetAsync(ctx_sel, 0, sizeof(float) * (size_t)h->Rw * K, s));
+        if (n_own > 0)
+          COPER_HIP_TRY(h, hipMemcpy2DAsync(ctx_sel, sizeof(float) * K, ctx + (size_t)w_rem * K, sizeof(float) * (size_t)w_div * K, sizeof(float) * K,
+                                            (size_t)n_own, hipMemcpyDeviceToDevice, s));
+        ctx = ctx_sel;
+      }
+      if ((rc = launch_gen_dense_frag(h, ctx, h->Rw, K, P(buf), 0, h->Wf, s))) return rc;
     }
   } else {
     if ((rc = launch_gen_dense_frag(h, nullptr, 1, 0, P("fc_weights"), 1, h->Wf, s))) return rc;
   }
   h->enc_bf16 = cfg.score_mode != COPER_SCORE_F32 && conv_bf16_supported(dm);
+  if (w_div > 1 && !h->enc_bf16) {
+    dev_free(&ctx_sel);
+    return fail(h, COPER_EUNSUPPORTED, "rel_mod_world > 1: the configuration is not served by the 16-bit encoder");
+  }
   if (h->enc_bf16) {
     size_t plane = (size_t)h->Rw * dm.nfb * w16_ks_stride(dm) * 64 * 16;
-    dev_free((char**)&h->Wf16_hi); dev_free((char**)&h->Wf16_lo); dev_free((char**)&h->Wf8_lo);
+    dev_free((char**)&h->Wf16_hi); dev_free((char**)&h->Wf16_lo);
     if (tracked_malloc(&h->Wf16_hi, plane) != hipSuccess || tracked_malloc(&h->Wf16_lo, plane) != hipSuccess)
       return fail(h, COPER_ENOMEM, "hipMalloc of the bf16 weight planes failed");
-#if defined(COPER_FUSED_LO8) && !defined(COPER_SPLIT_BF16)      /* experiment: kernels_dense_fused_bf16.hip */
-    if (tracked_malloc(&h->Wf8_lo, plane / 2) != hipSuccess)
-      return fail(h, COPER_ENOMEM, "hipMalloc of the 8-bit weight plane failed");
-#endif
     // powers of two of the encoder's operands (split16.h): e_W per relation from its own largest |W|, e_x from a bound on x
-    if ((rc = dev_alloc(h, &h->w_exp, (size_t)h->Rw))) return rc;
-    if ((rc = launch_wfrag_to_bf16(h, h->Wf, h->Rw, h->Wf16_hi, h->Wf16_lo, h->Wf8_lo, s))) return rc;
+    if (w_div > 1) {       // e_W is looked up by RELATION ID everywhere; the conversion works on slots: computed there, scattered to the ids
+      int32_t* by_slot = nullptr;
+      if ((rc = dev_alloc(h, &h->w_exp, (size_t)dm.R)) || (rc = dev_alloc(h, &by_slot, (size_t)h->Rw))) return rc;
+      COPER_HIP_TRY(h, hipMemsetAsync(h->w_exp, 0, sizeof(int32_t) * (size_t)dm.R, s));
+      int32_t* by_id = h->w_exp;
+      h->w_exp = by_slot;
+      rc = launch_wfrag_to_bf16(h, h->Wf, h->Rw, h->Wf16_hi, h->Wf16_lo, s);
+      h->w_exp = by_id;
+      if (!rc && n_own > 0 &&
+          hipMemcpy2DAsync(by_id + w_rem, sizeof(int32_t) * (size_t)w_div, by_slot, sizeof(int32_t), sizeof(int32_t), (size_t)n_own,
+                           hipMemcpyDeviceToDevice, s) != hipSuccess)
+        rc = fail(h, COPER_EHIP, "hipMemcpy2DAsync (e_W by relation id)");
+      hipError_t e = hipStreamSynchronize(s);
+      dev_free(&by_slot);
+      if (rc) return rc;
+      COPER_HIP_TRY(h, e);
+    } else {
+      if ((rc = dev_alloc(h, &h->w_exp, (size_t)h->Rw))) return rc;
+      if ((rc = launch_wfrag_to_bf16(h, h->Wf, h->Rw, h->Wf16_hi, h->Wf16_lo, s))) return rc;
+    }
     if ((rc = compute_x_exp(h, h->band_consts + 5, s))) return rc;
     COPER_HIP_TRY(h, hipStreamSynchronize(s));
     dev_free(&h->Wf);  // the fp32 image was only the staging form
+    dev_free(&ctx_sel);
   }
   }                    // ---- (role_enc)
   // entity table image(s) (a COPER_ROLE_ENCODE handle has none)
@@ -783,14 +821,10 @@ static int encode_partials(coper_handle* h, const int64_t* e1, const int64_t* re
   // 237 of them on 256 CUs: fused encoder 0.184 vs 0.189 ms, and half the partial sums for the tail kernel to read: pass
   // 0.526 vs 0.534 ms); 2,000 relations (the 10M-entity config, ~1,000 tiles of ~4 queries) 2 > 1 (1.00 vs 1.30 ms);
   // 22 relations 8 > 4 > 3 > 2; one shared weight (plain ConvE) 3 > 4 > 8 > 2.
-#ifdef COPER_KSPLIT
-  int ksplit = ksteps >= 64 ? COPER_KSPLIT : 1;
-#else
   int ksplit = 1;
   // (the fp32 encoder -- conv kernel, x through HBM, k_dense_big_f32 -- keeps two slices there: 0.455 vs 0.515 ms)
   const int mid = h->enc_bf16 ? 1 : 2;
   if (ksteps >= 64) ksplit = !dm.gen_fc ? 3 : dm.R >= 1024 ? 2 : dm.R >= 256 ? mid : dm.R >= 32 ? 4 : 8;
-#endif
   if (ksplit > h->ws_ksplit) ksplit = h->ws_ksplit;
   *ksplit_out = ksplit;
   // coper_group_next: a pass whose batch was sorted in the shadow of the last one skips its grouping launches.  Only a pass that
@@ -809,11 +843,7 @@ static int encode_partials(coper_handle* h, const int64_t* e1, const int64_t* re
     if ((rc = launch_group_by_relation(h, e1, rel, e1_rows != nullptr, B, tq, s))) return rc;
   }
   if (h->enc_bf16) {
-#ifdef COPER_NO_FUSED_DENSE
-    const bool fused = false;
-#else
     const bool fused = dense_fused_supported(h, ksplit);
-#endif
     // a coper_group_next registration is for THIS call only: it rides in the fused launch below or is dropped (a captured pass, a
     // configuration without the fused encoder) -- never kept for a later call, whose caller may have freed the arrays it names
     const bool want_group = h->pipe.gnext.pending;
@@ -832,6 +862,8 @@ static int encode_partials(coper_handle* h, const int64_t* e1, const int64_t* re
       if (const int64_t n = h->pipe.take_stage())
         if ((rc = launch_widen_ids(h, h->pipe.stage.src, n, h->pipe.stage.dst, s))) return rc;
     }
+    if (!fused && h->w_div > 1)
+      return fail(h, COPER_EUNSUPPORTED, "rel_mod_world > 1: the configuration is not served by the fused encoder");
     if (fused) {   // one launch serves every tile: conv, BN, ReLU and the dense layer (kernels_dense_fused_bf16.hip)
       ScopedKernelTimer t(h, "dense", s);
       if (finalized) *finalized = dense_fused_finalizes(h, ksplit, h_x3);

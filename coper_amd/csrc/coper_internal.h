@@ -9,6 +9,50 @@
 
 #include "../../include/coper_hip.h"
 
+// ---- build switches (round 6: pruned) -------------------------------------------------------------------------------------------
+// The kernels keep ONE family of compile-time switches: the ablation / clock-stamp set COPER_DBG_* that the measurements of
+// DESIGN_LOG.md were made with (a stage removed, a clock stamped per workgroup).  They exist in DIAGNOSTIC builds only: without
+// -DCOPER_DIAG every one of them is undefined here, whatever the command line says, so the product library is one program.
+// (tools/ab_build.py passes -DCOPER_DIAG with them.)  The variant builds that rounds 2 - 5 measured and rejected -- the bf16 split,
+// the fp32-FMA conv of the fused encoder, loads inside the count kernel's asm blocks, buffer loads, the 8-bit second term, the
+// old grid layouts ... -- are gone from the sources; their numbers are in DESIGN_LOG.md.  What remains besides are named tunables
+// with ONE shipped value (`#ifndef X / #define X value`: COPER_SC3_MB, COPER_TL_WAVES, COPER_FUSED_PBUDGET, ...).
+#ifndef COPER_DIAG
+#undef COPER_DBG_CLOCK
+#undef COPER_DBG_DENSE_NO_DMA
+#undef COPER_DBG_DENSE_NO_MFMA
+#undef COPER_DBG_FUSED_CLOCK
+#undef COPER_DBG_FUSED_EXIT
+#undef COPER_DBG_FUSED_NO_CONV
+#undef COPER_DBG_FUSED_NO_IMG
+#undef COPER_DBG_FUSED_NO_MFMA
+#undef COPER_DBG_FUSED_NO_STORE
+#undef COPER_DBG_FUSED_NO_W
+#undef COPER_DBG_FUSED_NO_XREAD
+#undef COPER_DBG_GROUP_CLK
+#undef COPER_DBG_NO_EPILOGUE
+#undef COPER_DBG_NO_GLOADS
+#undef COPER_DBG_NO_GROUP_CHK
+#undef COPER_DBG_NO_LDS
+#undef COPER_DBG_REG_NO_BAR
+#undef COPER_DBG_REG_NO_MFMA
+#undef COPER_DBG_REG_NO_X
+#undef COPER_DBG_SC3_DUMMY_LDS
+#undef COPER_DBG_SC3_EPI_R0
+#undef COPER_DBG_SC3_HALF_LDS
+#undef COPER_DBG_SC3_LOADS_FIRST
+#undef COPER_DBG_SC3_NO_BAND
+#undef COPER_DBG_SC3_NO_EPI
+#undef COPER_DBG_SC3_ONE_LDS
+#undef COPER_DBG_SC3_SKIP_GL
+#undef COPER_DBG_SC3_SKIP_LDS
+#undef COPER_DBG_TK_OVER
+#undef COPER_DBG_TL_CLOCK
+#undef COPER_DBG_TL_NOGATHER
+#undef COPER_DBG_W128_NO_EPI
+#undef COPER_DBG_W128_NO_LOADS
+#endif
+
 namespace coper {
 
 // every device allocation of the library goes through these two: a process-wide ledger (pointer -> bytes) behind
@@ -53,14 +97,10 @@ struct Dims {
 // half-width of the exact band of the x3 ranker, relative to |h_q| max|E_e| + max|bias| (per logit; a comparison of two
 // logits gets twice that).  The largest error of the mode's logits against the fp32 chain measured over 3e8 logits of the
 // FB15k-237-shaped pass (tools/rank_decomp.py): fp16 split 1.8e-7 |h_q||E_e| (rms 1.2e-8) -- the fp32 chain itself is
-// 2.3e-7 from float64 --; bf16 split (COPER_SPLIT_BF16 builds) 3.3e-6 (rms 3.1e-7).  The defaults keep a factor 5 (3) above
+// 2.3e-7 from float64 --; round 2's bf16 split: 3.3e-6 (rms 3.1e-7).  The default keeps a factor 5 above
 // the worst case seen, 80 (30) sigma.  coper_config.rank_band_kappa overrides them; the proven worst case of the split and
 // of fp32 accumulation in any order is 3 * 2^-22 (2^-16) + 2 (3 * 16 KS16 + 1) 2^-24 ~ 7.5e-5 (1.2e-4) at d = 200.
-#ifdef COPER_SPLIT_BF16
-constexpr float COPER_BAND_KAPPA_DEFAULT = 1e-5f;
-#else
 constexpr float COPER_BAND_KAPPA_DEFAULT = 1e-6f;
-#endif
 constexpr int COPER_TOPK_PRUNED_MAX = 128;   // largest k served by the block-maxima top-k (bf16x3); above: logits chunks
 constexpr int BAND_NCONST = 8;
 // the check words of a grouping prepared ahead (group_body.h: the guard), 64-bit each
@@ -98,7 +138,6 @@ struct coper_handle {
   float* bias_pad = nullptr;    // [n_eblk*32], -inf padded
   void* Wf16_hi = nullptr;      // COPER_SCORE_BF16X3: dense weights as hi / lo bf16 planes (16x16x32 fragment order)
   void* Wf16_lo = nullptr;
-  void* Wf8_lo = nullptr;       // (-DCOPER_FUSED_LO8 only) the second term as bytes (split16.h: split8_q8); Wf16_lo then holds the same values
   bool enc_bf16 = false;        // encoder runs in bf16x3 (needs 3x3 filters, C % 8 == 0)
   void* Ef16_hi = nullptr;      // COPER_SCORE_BF16X3: entity table hi / lo bf16 planes, fragment-major
   void* Ef16_lo = nullptr;      //   [n_eblk][KS16][64] x 16 B
@@ -160,7 +199,8 @@ struct coper_handle {
   int64_t stale_passes_host = 0;     // coper_stale_passes: what the device counter (group_done + 2) held when a growing workspace replaced it
   void* fused_fin_dev = nullptr;     // FusedFinConst (kernels_dense_fused_bf16.hip): the fused encoder's finalize constants, in device memory
   const int32_t* fused_fin_perm = nullptr;   //   the workspace generation they were written for
-  int32_t* w_exp = nullptr;          // [Rw] e_W per relation: the dense-weight planes hold W_r 2^e_W (split16.h; prepare)
+  int32_t* w_exp = nullptr;          // [R or 1] e_W per relation id: the dense-weight planes hold W_r 2^e_W (split16.h; prepare)
+  int w_div = 1, w_rem = 0;          // coper_config.rel_mod_*: the weight planes hold the relations r with r % w_div == w_rem, relation r at slot r / w_div
   int x_exp = 0;                     // e_x: the conv activations enter the dense layer as x 2^e_x (from a bound; prepare)
   int32_t* x3s = nullptr;            // [4] the packed batch's exponents: [0] e_h, [1] e_E + e_h (bf16x3_chain.h)
   float* x3m = nullptr;              // [X3M_SLOTS] per-block maxima of the h rows being packed (bf16x3_chain.h)
@@ -247,6 +287,7 @@ namespace coper {
 
 int fail(coper_handle* h, int code, const std::string& msg);
 void train_destroy(coper_handle* h);   // coper_train.hip
+void train_params_changed(coper_handle* h);
 int hip_fail(coper_handle* h, hipError_t e, const char* what);
 
 #define COPER_HIP_TRY(h, expr)                                    \
@@ -347,8 +388,8 @@ inline int topk_nseg(int64_t n_eblk) { return n_eblk < 4096 ? 8 : 1; }
 inline int topk_expand(const coper_handle* h) {
   const char* force = getenv("COPER_TOPK_EXPAND");             // A/B and tests: "1" / "2" (read per call; set it before the handle's first top-k call and keep it)
   if (h->cfg.score_mode == COPER_SCORE_F32) return 1;
-#if (defined(COPER_SC3_MB) && COPER_SC3_MB != 4) || defined(COPER_SC3_ASM_LOADS)
-  return 1;                                                    // (A/B builds: 32-entity blocks per wave; loads inside the asm blocks -- no 64-entity form generated)
+#if defined(COPER_SC3_MB) && COPER_SC3_MB != 4
+  return 1;                                                    // (A/B builds with another block count per wave: no 64-entity form generated)
 #endif
   if (h->dm.KS16 != 13 && h->dm.KS16 != 16) return 1;          // (the 64-entity form is instantiated for d = 200 and 256 only: build time)
   if (force && (force[0] == '1' || force[0] == '2')) return force[0] - '0';
@@ -387,19 +428,15 @@ int launch_topk_pruned_bf16x3(coper_handle* h, const float* hvec, const float* t
                               int64_t* topk_idx, hipStream_t s);
 // kernels_encode_bf16.hip
 bool conv_bf16_supported(const Dims& dm);
-int launch_wfrag_to_bf16(coper_handle* h, const float* Wf, int64_t Rw, void* hi, void* lo, void* lo8, hipStream_t s);
+int launch_wfrag_to_bf16(coper_handle* h, const float* Wf, int64_t Rw, void* hi, void* lo, hipStream_t s);
 int compute_x_exp(coper_handle* h, unsigned* scratch, hipStream_t s);
 // k-steps (of 32) between two feature blocks of the 16-bit dense-weight image Wf16_{hi,lo}: [rel * nfb + fb][stride][64] x 16 B.
 // Round 5: ODD (F / 32 | 1: 145 for 144 at FB15k-237 shapes, +0.7 % memory).  The 26 streams of a workgroup and the 237 workgroups
 // of a pass are all at the same k-step at the same time; with feature blocks 144 KiB and relations 1,872 KiB apart they all sat at
 // the same offset inside every 4-KiB page of the image, i.e. on the same few memory channels.  Measured on the pass (same box,
-// three alternating runs): fused encoder 0.1729 -> 0.1687 ms, pass 0.5115 -> 0.5064 ms (-DCOPER_W_EVEN_STRIDE builds the old image).
+// three alternating runs): fused encoder 0.1729 -> 0.1687 ms, pass 0.5115 -> 0.5064 ms.
 __host__ __device__ inline int64_t w16_ks_stride_n(int64_t ks32n) {
-#ifdef COPER_W_EVEN_STRIDE
-  return ks32n;
-#else
   return ks32n | 1;
-#endif
 }
 inline int64_t w16_ks_stride(const Dims& dm) { return w16_ks_stride_n(dm.F_pad / 32); }
 int launch_conv_bf16(coper_handle* h, const int64_t* e1, const int64_t* rel, const float* e1_rows, int64_t B,

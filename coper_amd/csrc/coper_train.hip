@@ -74,7 +74,21 @@ struct TrainState {
   // the other products (static dense layer, 1-vs-all scorer, dE of the dense scorer backward): two operand plane sets and
   // the split-K partial sums, grown on demand
   TgPlanes mmX, mmY;
-  int32_t* tg_exps = nullptr;    // [8] the exponents of the eight plane sets (train_gemm.h), in the order pX pXt pP1 pP3 pTn pTb mmX mmY
+  int32_t* tg_exps = nullptr;    // [8 + TR_EXP_CACHE] the exponents of the eight plane sets (train_gemm.h), in the order pX pXt pP1 pP3 pTn pTb mmX mmY,
+                                 //   then the words tg_matmul hands out per operand tensor within a step (exp_cache)
+  // the largest |W| of the dense weights (the last projection of the fc_weights generator / the static fc_weights), as the OPTIMIZER
+  // left it: k_tr_amsgrad folds |p_new| of that leaf into TG_MAX_SLOTS slots while it writes it, the packs of the next step reduce
+  // the slots -- the 118 MB pass that used to find the maximum (53 us of a 1.25 ms step) is gone.  Two sets: a step reads [wmax_cur],
+  // its optimizer pass writes [wmax_cur ^ 1] (zeroed by the step's zero list).  Valid only from one train step to the next of this
+  // handle with no coper_set_param in between (the tensors are the caller's: include/coper_hip.h, coper_train_step)
+  unsigned* xmax = nullptr;      // TG_MAX_SLOTS: max x as k_tr_bn1_fwd wrote it;  dtmax: max |dT| as k_tr_scale_rows wrote it (zeroed per step)
+  unsigned* dtmax = nullptr;
+  unsigned* wmax[2] = {nullptr, nullptr};
+  int wmax_cur = 0;
+  bool wmax_valid = false;
+  // tg_matmul: the exponent of an operand tensor packed earlier in THIS step (x, the static W, dz and S are each packed for two
+  // products): (tensor, its word).  Cleared at the start of a step and where a kernel rewrites a tensor in place.
+  std::vector<std::pair<const float*, int32_t*>> exp_cache;
   unsigned* tg_scratch = nullptr;   // [2] the absmax reduction of tg_pack (zero between packs)
   size_t mmX_cap = 0, mmY_cap = 0, mmP_cap = 0;
   float* mmP = nullptr;
@@ -105,7 +119,7 @@ struct MmView {
   bool rows_fast;   // consecutive rows contiguous in memory (else consecutive k)
 };
 static int tg_matmul(coper_handle* h, TrainState* T, hipStream_t s, const MmView& X, int64_t M, const MmView& Y, int64_t N, int64_t K,
-                     float* C, TgIdx ci, TgIdx cj, double* sumsq = nullptr);
+                     float* C, TgIdx ci, TgIdx cj, double* sumsq = nullptr, const unsigned* x_slots = nullptr, const unsigned* y_slots = nullptr);
 
 // ------------------------------------------------------------------------------------------------
 // forward kernels
@@ -163,7 +177,7 @@ __global__ __launch_bounds__(256) void k_tr_conv_fwd(const int64_t* __restrict__
 // per-column sums of a [rows, cols] matrix in double: out[0..cols) = sum, out[cols..2cols) = sum of squares
 // (partial sums by row chunk, then atomics on doubles: order-dependent only in the last bits of a double)
 // everything the step accumulates into with atomics, zeroed by ONE launch (was a dozen memsets of ~5 us each)
-constexpr int TR_ZERO_MAX = 12;
+constexpr int TR_ZERO_MAX = 16;
 constexpr int TR_COLSUM_SLICES = 20;   // column-sum scratch: one slice per use within a step (see colsum_slice)
 struct ZeroList {
   void* p[TR_ZERO_MAX];
@@ -245,16 +259,36 @@ __global__ void k_tr_bn_finish(const double* __restrict__ sums, int cols, double
 }
 
 // x = keep * relu(bn(y)) / (1 - rate)     (elementwise over [B, P, C]; flat index = the dropout counter)
+// the largest |value| a workgroup of 256 wrote -> one of TG_MAX_SLOTS slots (train_gemm.h: tg_pack's max_slots): the elementwise
+// kernel that PRODUCES a GEMM operand leaves its maximum behind, so that the pack needs no pass of its own over the tensor (round 6)
+__device__ __forceinline__ void tr_block_max_to_slot(float v_abs, unsigned* __restrict__ slots) {
+  unsigned m = __float_as_uint(v_abs);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const unsigned u = __shfl_xor(m, o, 64); m = u > m ? u : m; }
+  __shared__ unsigned s_bm[4];
+  if ((threadIdx.x & 63) == 0) s_bm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned a = s_bm[0] > s_bm[1] ? s_bm[0] : s_bm[1], b = s_bm[2] > s_bm[3] ? s_bm[2] : s_bm[3], w = a > b ? a : b;
+    if (w) atomicMax(slots + (blockIdx.x & (TG_MAX_SLOTS - 1)), w);
+  }
+}
+
 __global__ __launch_bounds__(256) void k_tr_bn1_fwd(const float* __restrict__ y, const float* __restrict__ mean,
                                                     const float* __restrict__ inv, const float* __restrict__ gamma,
                                                     const float* __restrict__ beta, int C, int64_t total, uint32_t seed,
-                                                    uint32_t step, uint32_t thr, float keep_scale, float* __restrict__ x) {
+                                                    uint32_t step, uint32_t thr, float keep_scale, float* __restrict__ x,
+                                                    unsigned* __restrict__ max_slots) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= total) return;
-  const int c = (int)(i % C);
-  float v = (y[i] - mean[c]) * inv[c] * gamma[c] + beta[c];
-  v = v > 0.f ? v : 0.f;
-  x[i] = dropout_keep_u32(seed, step, 1u, (uint32_t)i, thr) ? v * keep_scale : 0.f;
+  float out = 0.f;
+  if (i < total) {
+    const int c = (int)(i % C);
+    float v = (y[i] - mean[c]) * inv[c] * gamma[c] + beta[c];
+    v = v > 0.f ? v : 0.f;
+    out = dropout_keep_u32(seed, step, 1u, (uint32_t)i, thr) ? v * keep_scale : 0.f;
+    x[i] = out;
+  }
+  if (max_slots) tr_block_max_to_slot(out, max_slots);       // (x >= 0)
 }
 
 // z1 = keep * (z0 + bias_b) / (1 - rate).  Static: z0 from the GEMM, bias_b = fc_bias[k].  Generated:
@@ -330,6 +364,70 @@ __global__ __launch_bounds__(256) void k_tr_score_loss(const float* __restrict__
     __syncthreads();
   }
   if (threadIdx.x == 0) atomicAdd(loss_acc, part[0]);
+}
+
+// The sampled scorer forward AND its backward w.r.t. h in ONE pass over the gathered rows (round 6; the dense-scorer route):
+//   s[b,l] = pred_bias[row] + E[row] . h[b];  loss;  ds[b,l] = (sigmoid(s) - t) / (B L);  dh[b,:] = sum_l ds[b,l] E[row,:]
+// ds of a row is a function of that row alone, so the row that was just gathered for its score is still in registers when its
+// contribution to dh is known: k_tr_score_loss + k_tr_dh_gather4 read the 410 MB of gathered rows (512 x 1000 x 200) twice, 61 + 45 us.
+// A wave owns a row slot: lane q (< d / 4) holds four features of the row as one 16-byte load (a row is ONE coalesced request),
+// eight rows in flight per wave; the score is a butterfly sum over the wave.  The four waves' partial dh meet in LDS in wave order.
+__global__ __launch_bounds__(256) void k_tr_score_loss_dh(const float* __restrict__ hv, const float* __restrict__ ent,
+                                                          const float* __restrict__ pred_bias, const int32_t* __restrict__ lookup,
+                                                          const float* __restrict__ labels, int64_t E, int d, int64_t L, float ls_eps,
+                                                          float inv_E, float inv_BL, float* __restrict__ ds, float* __restrict__ dh,
+                                                          double* __restrict__ loss_acc) {
+  __shared__ float4 s_dh[4][64];
+  __shared__ double s_loss[4];
+  const int64_t b = blockIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, d4 = d >> 2;
+  const bool on = lane < d4;
+  const float4 h4 = on ? *(const float4*)(hv + b * d + 4 * lane) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const int32_t* lk = lookup + b * L;
+  const float* lab = labels + b * L;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  double loss = 0.0;
+  for (int64_t l0 = wave; l0 < L; l0 += 32) {           // rows l0, l0 + 4, ..., l0 + 28 of this wave
+    int64_t row[8];
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int64_t l = l0 + 4 * u;
+      row[u] = l < L ? lk[l] : 0;
+      if (row[u] < 0 || row[u] >= E) row[u] = 0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = on ? *(const float4*)(ent + row[u] * d + 4 * lane) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int64_t l = l0 + 4 * u;
+      float p = fmaf(h4.w, v[u].w, fmaf(h4.z, v[u].z, fmaf(h4.y, v[u].y, h4.x * v[u].x)));
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) p += __shfl_xor(p, o, 64);        // every lane holds the sum (same value: one order)
+      if (l < L) {
+        const float sc = p + pred_bias[row[u]];
+        const float t = (1.f - ls_eps) * lab[l] + inv_E;                                    // models.py:450
+        const float g = (1.f / (1.f + expf(-sc)) - t) * inv_BL;
+        if (lane == 0) {
+          loss += (double)(fmaxf(sc, 0.f) - sc * t + log1pf(expf(-fabsf(sc))));              // sigmoid cross-entropy with logits
+          ds[b * L + l] = g;
+        }
+        acc.x = fmaf(g, v[u].x, acc.x); acc.y = fmaf(g, v[u].y, acc.y); acc.z = fmaf(g, v[u].z, acc.z); acc.w = fmaf(g, v[u].w, acc.w);
+      }
+    }
+  }
+  s_dh[wave][lane] = acc;
+  if (lane == 0) s_loss[wave] = loss;
+  __syncthreads();
+  if (wave == 0) {
+    if (on) {
+      float4 o = s_dh[0][lane];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) { const float4 q = s_dh[w][lane]; o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w; }
+      *(float4*)(dh + b * d + 4 * lane) = o;
+    }
+    if (lane == 0) atomicAdd(loss_acc, ((s_loss[0] + s_loss[1]) + (s_loss[2] + s_loss[3])));
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -694,12 +792,19 @@ __global__ __launch_bounds__(256) void k_tr_fc_post_bwd(float* __restrict__ dz, 
 
 // dT[rho][b,k] = c[b,rho] dz[b,k]   (operand of the batched weight-gradient GEMM dP[rho] = x^T dT[rho])
 __global__ __launch_bounds__(256) void k_tr_scale_rows(const float* __restrict__ dz, const float* __restrict__ c, int r, int d,
-                                                       int64_t total, float* __restrict__ dT) {
+                                                       int64_t total, float* __restrict__ dT, unsigned* __restrict__ max_slots) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= total) return;
-  const int64_t b = i / d;
-  const float g = dz[i];
-  for (int rho = 0; rho < r; ++rho) dT[(int64_t)rho * total + i] = c[b * r + rho] * g;
+  float mx = 0.f;
+  if (i < total) {
+    const int64_t b = i / d;
+    const float g = dz[i];
+    for (int rho = 0; rho < r; ++rho) {
+      const float v = c[b * r + rho] * g;
+      dT[(int64_t)rho * total + i] = v;
+      mx = fmaxf(mx, fabsf(v));
+    }
+  }
+  if (max_slots) tr_block_max_to_slot(mx, max_slots);
 }
 
 // dx[b,f] = sum_rho c[b,rho] dA[b,rho*F+f];  dc[b,rho] += sum_f x[b,f] dA[b,rho*F+f]
@@ -900,6 +1005,7 @@ __global__ __launch_bounds__(256) void k_tr_scatter_rows(const float* __restrict
 
 // every trainable tensor in one launch (blockIdx.y = tensor): the small ones would otherwise cost a launch each
 constexpr int TR_MAX_PARAMS = 40;
+constexpr int TR_EXP_CACHE = 8;
 struct TrainTensors {
   float* p[TR_MAX_PARAMS];
   float* g[TR_MAX_PARAMS];
@@ -911,6 +1017,8 @@ struct TrainTensors {
   // per-key count; a row with count 0 has gradient 0 whatever the buffer holds
   int64_t rowlen[TR_MAX_PARAMS];
   const int32_t* rowcnt[TR_MAX_PARAMS];
+  unsigned* wmax;     // TG_MAX_SLOTS slots for max |p_new| of tensor wmax_of (-1: none)
+  int wmax_of;
 };
 
 __global__ __launch_bounds__(256) void k_tr_sumsq(TrainTensors tt, int skip, double* __restrict__ acc) {
@@ -980,6 +1088,7 @@ __global__ __launch_bounds__(256) void k_tr_amsgrad(TrainTensors tt, const doubl
   // row-count test that only the looked-up tables need) the pass ran at 5.4 TB/s
   if (!rc && (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)vh) & 15) == 0) {
     const int64_t n4 = n >> 2;
+    unsigned pmx = 0u;       // the largest |p_new| this thread wrote (bit pattern): the next step's packs take their power of two from it
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
       const float4 g4 = ((const float4*)g)[i];
       float4 m4 = ((const float4*)m)[i], v4 = ((const float4*)v)[i], h4 = ((const float4*)vh)[i], p4 = ((const float4*)p)[i];
@@ -992,6 +1101,8 @@ __global__ __launch_bounds__(256) void k_tr_amsgrad(TrainTensors tt, const doubl
         const float vhi = fmaxf(gh[j], vi);
         gm[j] = mi; gv[j] = vi; gh[j] = vhi;
         gp[j] -= lr_t * mi / (sqrtf(vhi) + eps);
+        const unsigned pb = __float_as_uint(gp[j]) & 0x7fffffffu;
+        pmx = pb > pmx ? pb : pmx;
       }
       ((float4*)m)[i] = m4; ((float4*)v)[i] = v4; ((float4*)vh)[i] = h4; ((float4*)p)[i] = p4;
     }
@@ -1001,7 +1112,15 @@ __global__ __launch_bounds__(256) void k_tr_amsgrad(TrainTensors tt, const doubl
       const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
       const float vhi = fmaxf(vh[i], vi);
       m[i] = mi; v[i] = vi; vh[i] = vhi;
-      p[i] -= lr_t * mi / (sqrtf(vhi) + eps);
+      const float pn = p[i] - lr_t * mi / (sqrtf(vhi) + eps);
+      p[i] = pn;
+      const unsigned pb = __float_as_uint(pn) & 0x7fffffffu;
+      pmx = pb > pmx ? pb : pmx;
+    }
+    if (tt.wmax && tt.wmax_of == (int)blockIdx.y) {     // one atomic per wave, spread over the slots (8 per slot at 2,048 workgroups)
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { const unsigned u = __shfl_xor(pmx, o, 64); pmx = u > pmx ? u : pmx; }
+      if ((threadIdx.x & 63) == 0 && pmx) atomicMax(tt.wmax + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & (TG_MAX_SLOTS - 1)), pmx);
     }
     return;
   }
@@ -1032,7 +1151,7 @@ static int tg_gemm_split(coper_handle* h, TrainState* T, hipStream_t s, TgPlanes
 }
 
 static int tg_matmul(coper_handle* h, TrainState* T, hipStream_t s, const MmView& X, int64_t M, const MmView& Y, int64_t N, int64_t K,
-                     float* C, TgIdx ci, TgIdx cj, double* sumsq) {
+                     float* C, TgIdx ci, TgIdx cj, double* sumsq, const unsigned* x_slots, const unsigned* y_slots) {
   int rc;
   const size_t nx = tg_plane_elems(M, K), ny = tg_plane_elems(N, K);
   const int nsplit = tg_split_k(M, N, K);
@@ -1052,13 +1171,34 @@ static int tg_matmul(coper_handle* h, TrainState* T, hipStream_t s, const MmView
       T->mmP_cap = np;
     }
   }
-  if ((rc = tg_pack(h, X.p, X.ri, X.ki, M, K, tg_rows_pad(M), X.rows_fast, T->mmX, s, T->tg_scratch))) return rc;
-  if ((rc = tg_pack(h, Y.p, Y.ri, Y.ki, N, K, tg_rows_pad(N), Y.rows_fast, T->mmY, s, T->tg_scratch))) return rc;
-  return tg_gemm_nt(h, T->mmX, M, T->mmY, N, K, C, ci, cj, s, nsplit, T->mmP, sumsq);
+  // an operand tensor packed earlier in this step keeps its power of two (its own word from the pool behind the plane sets' eight):
+  // no second pass for the maximum.  A tensor with producer-side maxima (slots) needs no pass at all.
+  TgPlanes px = T->mmX, py = T->mmY;
+  auto pack = [&](const MmView& V, int64_t rows, TgPlanes& pl, const unsigned* slots) -> int {
+    const int32_t* from = nullptr;
+    for (auto& e : T->exp_cache)
+      if (e.first == V.p) from = e.second;
+    if (from) {
+      pl.exp = const_cast<int32_t*>(from);
+      return tg_pack(h, V.p, V.ri, V.ki, rows, K, tg_rows_pad(rows), V.rows_fast, pl, s, T->tg_scratch, from);
+    }
+    if ((int)T->exp_cache.size() < TR_EXP_CACHE) {
+      pl.exp = T->tg_exps + 8 + T->exp_cache.size();
+      T->exp_cache.emplace_back(V.p, pl.exp);
+    }
+    return tg_pack(h, V.p, V.ri, V.ki, rows, K, tg_rows_pad(rows), V.rows_fast, pl, s, T->tg_scratch, nullptr, slots);
+  };
+  if ((rc = pack(X, M, px, x_slots)) || (rc = pack(Y, N, py, y_slots))) return rc;
+  return tg_gemm_nt(h, px, M, py, N, K, C, ci, cj, s, nsplit, T->mmP, sumsq);
 }
 
 
 }  // namespace
+
+// coper_set_param: whatever the optimizer's last pass knew about the parameters (TrainState::wmax) no longer describes them
+void train_params_changed(coper_handle* h) {
+  if (h->train) ((TrainState*)h->train)->wmax_valid = false;
+}
 
 void train_destroy(coper_handle* h) {
   TrainState* T = (TrainState*)h->train;
@@ -1079,6 +1219,8 @@ void train_destroy(coper_handle* h) {
   (void)tracked_free(T->red);
   if (T->tg_exps) (void)tracked_free(T->tg_exps);
   if (T->tg_scratch) (void)tracked_free(T->tg_scratch);
+  for (unsigned* w : {T->wmax[0], T->wmax[1], T->xmax, T->dtmax})
+    if (w) (void)tracked_free(w);
   for (TgPlanes* pl : {&T->mmX, &T->mmY}) {
     if (pl->hi) (void)tracked_free(pl->hi);
     if (pl->lo) (void)tracked_free(pl->lo);
@@ -1176,8 +1318,13 @@ COPER_API int coper_train_init(coper_handle* h, const coper_train_config* cfg) {
   for (int i = 0; i < T->nhc; ++i) mx = h->cfg.ctx_conv[i] > mx ? h->cfg.ctx_conv[i] : mx;
   if ((rc = talloc(h, &T->bnst, (size_t)4 * mx))) return rc;
   if ((rc = talloc(h, &T->red, (size_t)(2 + 2 * mx * TR_COLSUM_SLICES + TG_SUMSQ_SLOTS)))) return rc;
-  if ((rc = talloc(h, &T->tg_exps, (size_t)8)) || (rc = talloc(h, &T->tg_scratch, (size_t)2))) return rc;
-  COPER_HIP_TRY(h, hipMemset(T->tg_exps, 0, 8 * sizeof(int32_t)));
+  if ((rc = talloc(h, &T->tg_exps, (size_t)(8 + TR_EXP_CACHE))) || (rc = talloc(h, &T->tg_scratch, (size_t)2)) ||
+      (rc = talloc(h, &T->wmax[0], (size_t)TG_MAX_SLOTS)) || (rc = talloc(h, &T->wmax[1], (size_t)TG_MAX_SLOTS)) ||
+      (rc = talloc(h, &T->xmax, (size_t)TG_MAX_SLOTS)) || (rc = talloc(h, &T->dtmax, (size_t)TG_MAX_SLOTS)))
+    return rc;
+  COPER_HIP_TRY(h, hipMemset(T->tg_exps, 0, (8 + TR_EXP_CACHE) * sizeof(int32_t)));
+  COPER_HIP_TRY(h, hipMemset(T->wmax[0], 0, TG_MAX_SLOTS * sizeof(unsigned)));
+  COPER_HIP_TRY(h, hipMemset(T->wmax[1], 0, TG_MAX_SLOTS * sizeof(unsigned)));
   COPER_HIP_TRY(h, hipMemset(T->tg_scratch, 0, 2 * sizeof(unsigned)));
   {
     TgPlanes* sets[8] = {&T->pX, &T->pXt, &T->pP1, &T->pP3, &T->pTn, &T->pTb, &T->mmX, &T->mmY};
@@ -1294,6 +1441,9 @@ static int train_step_impl(coper_handle* h, const int64_t* e1, const int64_t* re
 
   // ---- zero what is accumulated by atomics: one launch
   const bool dense_scorer_bwd = (double)B * (double)dm.E * 4.0 <= 512.0 * 1024 * 1024 && dm.E <= 0x7fffffff;
+  // the sampled scorer's forward also leaves dh (k_tr_score_loss_dh: one pass over the gathered rows instead of two); coper_train_forward
+  // takes the same kernel -- its loss is the following step's bit for bit
+  const bool fused_dh = !one_vs_all && dense_scorer_bwd && (d & 3) == 0 && d >= 16 && d <= 256 && (((uintptr_t)T->find("ent_emb")->p) & 15) == 0;
   if (!one_vs_all && dense_scorer_bwd && B * dm.E > T->capS) {
     COPER_HIP_TRY(h, hipStreamSynchronize(s));
     if ((rc = talloc(h, &T->Sd, (size_t)(B * dm.E)))) return rc;
@@ -1311,8 +1461,14 @@ static int train_step_impl(coper_handle* h, const int64_t* e1, const int64_t* re
     else if (gen) add(G_(blast.c_str()), sizeof(float) * rc_b * d);
     else add(G_("fc_bias"), sizeof(float) * d);
     if (!one_vs_all && dense_scorer_bwd) add(T->Sd, sizeof(float) * B * dm.E);
+    if (apply) add(T->wmax[T->wmax_cur ^ 1], sizeof(unsigned) * TG_MAX_SLOTS);      // what this step's optimizer pass fills for the next step
+    add(T->xmax, sizeof(unsigned) * TG_MAX_SLOTS);
+    add(T->dtmax, sizeof(unsigned) * TG_MAX_SLOTS);
     hipLaunchKernelGGL(k_tr_zero_list, dim3(256, (unsigned)zl.n), dim3(256), 0, s, zl);
   }
+  T->exp_cache.clear();
+  // the dense weights' maximum as the last step's optimizer pass left it (TrainState::wmax), when it is known to describe them
+  const unsigned* w_slots = T->wmax_valid ? T->wmax[T->wmax_cur] : nullptr;
   // (a coper_group_next registration, or a grouping prepared ahead, was for an evaluation pass: a training step drops both)
   h->pipe.invalidate_grouping();
   if (lk) {
@@ -1377,7 +1533,8 @@ static int train_step_impl(coper_handle* h, const int64_t* e1, const int64_t* re
                      tc.batch_norm_momentum, 1 | nomov, const_cast<float*>(h->params["Conv1BN/moving_mean"].ptr),
                      const_cast<float*>(h->params["Conv1BN/moving_variance"].ptr), mean1, inv1);
   hipLaunchKernelGGL(k_tr_bn1_fwd, dim3((unsigned)((nBF + 255) / 256)), dim3(256), 0, s, T->y, mean1, inv1, P_("Conv1BN/gamma"),
-                     P_("Conv1BN/beta"), C, nBF, tc.seed, step, thr_h, ks_h, T->x);
+                     P_("Conv1BN/beta"), C, nBF, tc.seed, step, thr_h, ks_h, T->x, T->xmax);
+  const unsigned* x_slots = cat ? nullptr : T->xmax;      // (concat_rel: the dense layer's input is another tensor)
   if (cat) hipLaunchKernelGGL(k_tr_concat, dim3((unsigned)((B * F + 255) / 256)), dim3(256), 0, s, T->x, T->c, Fc, r, B * F, T->xc);
   const float* xin = cat ? T->xc : T->x;   // [B, F]
   float* dxin = cat ? T->dxc : T->dx;
@@ -1400,13 +1557,13 @@ static int train_step_impl(coper_handle* h, const int64_t* e1, const int64_t* re
       // T[rho][b][k] = sum_f x[b][f] P[rho][f][k] on the bf16 matrix cores with split operands (train_gemm_bf16.hip): x and P
       // are packed into fragment planes (P as rows (rho, k) with f contracted), one GEMM of [B] x [r*d] outputs
       const int64_t nrk = (int64_t)rc_w * d;
-      if ((rc = tg_pack(h, xin, tg_idx(F), tg_idx(1), B, F, tg_rows_pad(B), false, T->pX, s, T->tg_scratch))) return rc;
-      if ((rc = tg_pack(h, Wmat, tg_idx2(d, F * (int64_t)d, 1), tg_idx(d), nrk, F, tg_rows_pad(nrk), true, T->pP1, s, T->tg_scratch))) return rc;
+      if ((rc = tg_pack(h, xin, tg_idx(F), tg_idx(1), B, F, tg_rows_pad(B), false, T->pX, s, T->tg_scratch, nullptr, x_slots))) return rc;
+      if ((rc = tg_pack(h, Wmat, tg_idx2(d, F * (int64_t)d, 1), tg_idx(d), nrk, F, tg_rows_pad(nrk), true, T->pP1, s, T->tg_scratch, nullptr, w_slots))) return rc;
       if ((rc = tg_gemm_split(h, T, s, T->pX, B, T->pP1, nrk, F, Tf, tg_idx(d), tg_idx2(d, nBd, 1)))) return rc;
     } else {
       // z0[B,d] = x[B,F] W[F,d]: 8 output tiles, K = F cut into slices
       if ((rc = tg_matmul(h, T, s, MmView{xin, tg_idx(F), tg_idx(1), false}, B, MmView{Wmat, tg_idx(1), tg_idx(d), true}, d, F, T->z0,
-                          tg_idx(d), tg_idx(1))))
+                          tg_idx(d), tg_idx(1), nullptr, x_slots, w_slots)))
         return rc;
     }
     hipLaunchKernelGGL(k_tr_fc_post, dim3((unsigned)((nBd + 255) / 256)), dim3(256), 0, s, gen ? Tf : T->z0, gen ? nullptr : P_("fc_bias"),
@@ -1431,8 +1588,13 @@ static int train_step_impl(coper_handle* h, const int64_t* e1, const int64_t* re
       return rc;
     if (pred_out)
       hipLaunchKernelGGL(k_tr_add_bias_out, dim3((unsigned)((B * dm.E + 255) / 256)), dim3(256), 0, s, T->Sd, P_("pred_bias"), dm.E, B * dm.E, pred_out);
+    for (size_t i = 0; i < T->exp_cache.size(); ++i)      // (the loss kernel rewrites S in place: its power of two as an OUTPUT operand is gone)
+      if (T->exp_cache[i].first == T->Sd) T->exp_cache[i].first = nullptr;
     hipLaunchKernelGGL(k_tr_dense_loss, dim3(2048), dim3(256), 0, s, T->Sd, P_("pred_bias"), labels, dm.E, B * dm.E,
                        tc.label_smoothing_epsilon, (float)(1.0 / (double)dm.E), inv_BL, red);
+  } else if (fused_dh) {
+    hipLaunchKernelGGL(k_tr_score_loss_dh, dim3((unsigned)B), dim3(256), 0, s, T->hv, ent, P_("pred_bias"), lookup, labels, dm.E, d, L,
+                       tc.label_smoothing_epsilon, (float)(1.0 / (double)dm.E), inv_BL, T->ds, T->dh, red);
   } else {
     hipLaunchKernelGGL(k_tr_score_loss, dim3((unsigned)B), dim3(256), sizeof(float) * d, s, T->hv, ent, P_("pred_bias"), lookup, labels,
                        dm.E, d, L, tc.label_smoothing_epsilon, (float)(1.0 / (double)dm.E), inv_BL, T->ds, red);
@@ -1466,7 +1628,9 @@ static int train_step_impl(coper_handle* h, const int64_t* e1, const int64_t* re
                         G_("ent_emb"), tg_idx(d), tg_idx(1))))
       return rc;
     // dh by the gather (a [d,B] = [d,|E|] x [|E|,B] GEMM has 8 output tiles and a long K: slower than the gather)
-    if ((d & 3) == 0 && d >= 16 && d <= 1024 && (((uintptr_t)ent | (uintptr_t)T->dh) & 15) == 0)
+    if (fused_dh) {
+      // (dh was written by the scorer's forward launch: k_tr_score_loss_dh)
+    } else if ((d & 3) == 0 && d >= 16 && d <= 1024 && (((uintptr_t)ent | (uintptr_t)T->dh) & 15) == 0)
       hipLaunchKernelGGL(k_tr_dh_gather4, dim3((unsigned)B), dim3(256), sizeof(float4) * (size_t)(256 / (d >> 2)) * (d >> 2), s, ent, lookup,
                          T->ds, dm.E, d, L, T->dh);
     else
@@ -1498,10 +1662,10 @@ static int train_step_impl(coper_handle* h, const int64_t* e1, const int64_t* re
     // dT[rho][b,:] = cw[b,rho] dz[b,:];  dP[rho][f][k] = sum_b x[b][f] dT[rho][b][k]  and
     // dx[b][f] = sum_(rho,k) dT[rho][b][k] P[rho][f][k]: two split-bf16 GEMMs, the [B, r*F] intermediate dz P2^T is never formed
     const int64_t nrk = (int64_t)rc_w * d;
-    hipLaunchKernelGGL(k_tr_scale_rows, dim3((unsigned)((nBd + 255) / 256)), dim3(256), 0, s, T->dz, cw, rc_w, d, nBd, dTf);
+    hipLaunchKernelGGL(k_tr_scale_rows, dim3((unsigned)((nBd + 255) / 256)), dim3(256), 0, s, T->dz, cw, rc_w, d, nBd, dTf, T->dtmax);
     // (x and the projection were packed for the forward pass: the same tensors, the same powers of two -- no second reduction)
     if ((rc = tg_pack(h, xin, tg_idx(1), tg_idx(F), F, B, tg_rows_pad(F), true, T->pXt, s, T->tg_scratch, T->pX.exp))) return rc;
-    if ((rc = tg_pack(h, dTf, tg_idx2(d, nBd, 1), tg_idx(d), nrk, B, tg_rows_pad(nrk), true, T->pTn, s, T->tg_scratch))) return rc;
+    if ((rc = tg_pack(h, dTf, tg_idx2(d, nBd, 1), tg_idx(d), nrk, B, tg_rows_pad(nrk), true, T->pTn, s, T->tg_scratch, nullptr, T->dtmax))) return rc;
     if ((rc = tg_gemm_nt(h, T->pXt, F, T->pTn, nrk, B, dW, tg_idx(d), tg_idx2(d, F * (int64_t)d, 1), s, 1, nullptr, ssq))) return rc;
     sumsq_done = wlast;   // the GEMM added |dP|^2 to the global-norm accumulator as it stored
     if ((rc = tg_pack(h, dTf, tg_idx(d), tg_idx2(d, nBd, 1), B, nrk, tg_rows_pad(B), false, T->pTb, s, T->tg_scratch, T->pTn.exp))) return rc;
@@ -1588,6 +1752,17 @@ static int train_step_impl(coper_handle* h, const int64_t* e1, const int64_t* re
     tt.rowlen[i] = table ? F * d : 1;
     tt.rowcnt[i] = table ? h->rel_count : nullptr;
   }
+  // the dense weights' largest |p_new| for the next step's packs (k_tr_amsgrad's 16-byte path only: it is the one that carries it)
+  tt.wmax = nullptr; tt.wmax_of = -1;
+  {
+    const std::string wname = lk ? std::string() : (gen ? wlast : std::string("fc_weights"));
+    for (int i = 0; i < np && !wname.empty(); ++i)
+      if (T->tp[i].name == wname && !tt.rowcnt[i] &&
+          ((((uintptr_t)tt.p[i]) | ((uintptr_t)tt.g[i]) | ((uintptr_t)tt.m[i]) | ((uintptr_t)tt.v[i]) | ((uintptr_t)tt.vh[i])) & 15) == 0) {
+        tt.wmax = T->wmax[T->wmax_cur ^ 1];
+        tt.wmax_of = i;
+      }
+  }
   int skip = -1;
   for (int i = 0; i < np; ++i)
     if (!sumsq_done.empty() && T->tp[i].name == sumsq_done) skip = i;
@@ -1599,6 +1774,8 @@ static int train_step_impl(coper_handle* h, const int64_t* e1, const int64_t* re
   T->b1p *= tc.beta1;
   T->b2p *= tc.beta2;
   T->step += 1;
+  T->wmax_cur ^= 1;
+  T->wmax_valid = tt.wmax != nullptr;
   return COPER_OK;
 }
 

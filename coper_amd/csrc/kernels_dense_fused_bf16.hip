@@ -35,12 +35,6 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   { (c) = MFMA16_BF16(alo, bhi, c); (c) = MFMA16_BF16(ahi, blo, c); (c) = MFMA16_BF16(ahi, bhi, c); }
 
 
-#ifndef COPER_FUSED_TAIL
-#define COPER_FUSED_TAIL 0
-#endif
-#ifndef COPER_FUSED_DUMMY
-#define COPER_FUSED_DUMMY 0
-#endif
 #ifndef COPER_FUSED_PMAX
 #define COPER_FUSED_PMAX 3
 #endif
@@ -52,38 +46,17 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // blocks too) needs the x fragments requested one block ahead instead of two to stay out of scratch, and measures no gain.
 #define COPER_FUSED_PBUDGET 220
 #endif
-#ifndef COPER_FUSED_CONV_FMA
-#define COPER_FUSED_CONV_FMA 0      // 1: rounds 2 - 4's conv (fp32 fma chain on the vector unit) for A/B; 0: the conv on the matrix cores
-#endif
 
 
-// -DCOPER_FUSED_LO8 (round 4, measured, NOT the default): the weights' second term streamed as BYTES (split16.h: split8_q8 /
-// lo8_decode; 3 bytes per value instead of 4) and rebuilt as fp16 in front of the k-step's MFMAs, 20 vector instructions per
-// fragment.  25 % fewer bytes bought nothing -- 0.1764 ms against 0.173 - 0.182: the kernel's compute side (conv waves and
-// matrix waves sharing the SIMDs' issue) needs the same 0.17 ms as the 4-byte stream (DESIGN_LOG.md, ablations) -- and the
-// 19 - 20 bits it leaves of every weight cost 0.2 % of the queries their float64-equal rank (99.64 -> 99.44 % at FB15k-237).
-// The default build's text is untouched: the weight registers are reached through the FW_* macros below.
-#if defined(COPER_FUSED_LO8) && !defined(COPER_SPLIT_BF16)
-#define FUSED_LO8 1
-typedef uint2 fused_wlo_t;
-typedef unsigned fused_wlo_reg __attribute__((ext_vector_type(2)));
-#define FW_DECL u32x4 W[P][NW]; fused_wlo_reg WL[P][NW]
-#define FW_HI(s_, j_) W[s_][j_]
-#define FW_LO(s_, j_) wl[j_]                          /* the k-step's decoded fragments (FW_PRE) */
-#define FW_LO_RAW(s_, j_) WL[s_][j_]
-#define FW_PRE(s_) u32x4 wl[NW]; _Pragma("unroll") for (int j = 0; j < NW; ++j) wl[j] = lo8_decode(WL[s_][j], W[s_][j]);
-#define FW_WREG3 (3 * NW * 6 + NW * 4)
-#else
-#define FUSED_LO8 0
-typedef uint4 fused_wlo_t;
-typedef u32x4 fused_wlo_reg;
+// (Round 4 measured the weights' second term streamed as BYTES -- 3 bytes per value instead of 4, rebuilt as fp16 in front of the
+// k-step's MFMAs: 25 % fewer bytes bought nothing, 0.1764 ms against 0.173 - 0.182, and cost 0.2 % of the queries their
+// float64-equal rank; the build switch is gone, the story is in DESIGN_LOG.md.)
 #define FW_DECL u32x4 W[P][NW][2]
 #define FW_HI(s_, j_) W[s_][j_][0]
 #define FW_LO(s_, j_) W[s_][j_][1]
 #define FW_LO_RAW(s_, j_) W[s_][j_][1]
 #define FW_PRE(s_)
 #define FW_WREG3 (3 * NW * 8)
-#endif
 
 struct FusedConvArgs {
   const float* e1_rows;
@@ -98,6 +71,8 @@ struct FusedConvArgs {
   int per_rel_conv, d, r, in_w, in_hw, Wo, img_stride, x_exp;
   int img_exp;      // e_I: the image planes in LDS hold (e1 row | rel row) 2^e_I as fp16 hi + lo (round 5: the conv on the matrix cores)
   int64_t* chk;     // the pass runs on a grouping prepared ahead (coper_group_next): its check words (group_body.h), else nullptr
+  int w_div, w_rem; // coper_config.rel_mod_*: the weight planes hold relation r at slot r / w_div, for r % w_div == w_rem only
+  int32_t* bad;     //   ... a tile of another relation is counted here (coper_check_ids) and runs on the slot's weights
 };
 
 // The dense finalize in this kernel's epilogue (round 4; one K slice only -- the workgroup's accumulators are then the whole
@@ -146,7 +121,6 @@ constexpr int FUSED_STAGE_WGS = 16;     // workgroups of the staging role (512 t
 // (PD = (img_stride - 1) / 2 dwords per plane, hi plane first; img_stride = 2 PD + 1 is odd: 16 queries read 16 banks) -- because
 // the conv runs on the matrix cores now (fused_conv_role): its B operand is eight fp16 values of a query's 3x3 window, taken
 // from these planes with four LDS reads.  Same LDS bytes as the fp32 image of rounds 2 - 4.
-#if !COPER_FUSED_CONV_FMA
 __device__ __forceinline__ void fused_load_images(unsigned* __restrict__ img, const FusedConvArgs& A, int start, int n,
                                                   int t0, int t1) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -209,74 +183,17 @@ __device__ __forceinline__ void fused_load_images(unsigned* __restrict__ img, co
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 }
-#else
-__device__ __forceinline__ void fused_load_images(float* __restrict__ img, const FusedConvArgs& A, int start, int n,
-                                                  int t0, int t1) {
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int q0 = wave * 16;
-  if (q0 < n) {
-    int qi = q0 + (lane & 15);
-    if (qi > n - 1) qi = n - 1;
-    int my_row = A.sorted_row[start + qi], my_rid = A.sorted_rid[start + qi];
-#ifdef COPER_DBG_FUSED_NO_IMG
-    my_row = -1;
-#endif
-    const float* base = A.e1_rows ? A.e1_rows : A.ent;
-    const int len = t1 - t0;
-    float v[16][2];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int row = __builtin_amdgcn_readlane(my_row, u), rid = __builtin_amdgcn_readlane(my_rid, u);
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int t = t0 + lane + 64 * h;
-        float x = 0.f;
-        if (t < t1) {
-          if (t < A.d) x = row >= 0 ? base[(int64_t)row * A.d + t] : 0.f;
-          else x = A.rel_emb[(int64_t)rid * A.r + (t - A.d)];
-        }
-        v[u][h] = x;
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 16; ++u)
-      if (q0 + u < n) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-          if (lane + 64 * h < len) img[(q0 + u) * A.img_stride + lane + 64 * h] = v[u][h];
-      }
-    // rows longer than 128 floats (not the shipped shapes): the rest, plainly
-    if (len > 128) {
-      for (int u = 0; u < 16 && q0 + u < n; ++u) {
-        const int row = __builtin_amdgcn_readlane(my_row, u), rid = __builtin_amdgcn_readlane(my_rid, u);
-        for (int t = t0 + 128 + lane; t < t1; t += 64) {
-          float x;
-          if (t < A.d) x = row >= 0 ? base[(int64_t)row * A.d + t] : 0.f;
-          else x = A.rel_emb[(int64_t)rid * A.r + (t - A.d)];
-          img[(q0 + u) * A.img_stride + (t - t0)] = x;
-        }
-      }
-    }
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-}
-#endif
 
 // ---- matrix role.  Wave w (0..3) owns feature blocks w, w+4, ... of the NFB/4*4 "full" ones for every query
 // block, and -- when NFB is not a multiple of 4 (d = 200: 13 blocks) -- query blocks w, w+4 of the one left
 // over, so that every SIMD carries the same MFMA load to within one query block (dealing whole feature blocks
 // would leave one wave with 4 of 13).  All four waves then stream that last block's weight fragments; the
 // repeats hit L1/L2.
-#if COPER_FUSED_CONV_FMA
-typedef float fused_img_t;
-#else
 typedef unsigned fused_img_t;
-#endif
 template <int NFB, int NB, bool WNT>
 __device__ __forceinline__ void fused_matrix_role(const uint4* __restrict__ xring, fused_img_t* __restrict__ img,
-                                                  const uint4* __restrict__ Whi, const fused_wlo_t* __restrict__ Wlo,
-                                                  const FusedConvArgs& A, int64_t relw, int start, int n, int fb0,
+                                                  const uint4* __restrict__ Whi, const uint4* __restrict__ Wlo,
+                                                  const FusedConvArgs& A, int64_t relw, int64_t relw_w, int start, int n, int fb0,
                                                   int nfb, int64_t ks32n, int64_t kb, int64_t ke, int t0, int t1,
                                                   float* __restrict__ zdst, int d_pad16, int wave, const FusedFin& Fn, int64_t ks32s) {
   constexpr int NFULL = NFB / 4;              // whole feature blocks per wave
@@ -294,7 +211,7 @@ __device__ __forceinline__ void fused_matrix_role(const uint4* __restrict__ xrin
   for (int j = 0; j < NW; ++j) {
     int fb = fb0 + (j < NFULL ? wave + 4 * j : 4 * NFULL);
     if (fb > nfb - 1) fb = nfb - 1;
-    int64_t o = ((relw * nfb + fb) * ks32s + kb) * 64;   // wave-uniform: scalar base + one shared lane offset
+    int64_t o = ((relw_w * nfb + fb) * ks32s + kb) * 64;   // wave-uniform: scalar base + one shared lane offset (relw_w: the relation's slot)
     wp[j][0] = Whi + o;
     wp[j][1] = (const uint4*)(Wlo + o);
   }
@@ -313,7 +230,7 @@ __device__ __forceinline__ void fused_matrix_role(const uint4* __restrict__ xrin
   {                                                                                                    \
     _Pragma("unroll") for (int j = 0; j < NW; ++j) {                                                   \
       FW_HI(s, j) = FUSED_W_LOAD((const u32x4*)(wp[j][0] + (int64_t)(kk)*64) + lane);                 \
-      FW_LO_RAW(s, j) = FUSED_W_LOAD((const fused_wlo_reg*)((const fused_wlo_t*)wp[j][1] + (int64_t)(kk)*64) + lane); \
+      FW_LO_RAW(s, j) = FUSED_W_LOAD((const u32x4*)((const uint4*)wp[j][1] + (int64_t)(kk)*64) + lane); \
     }                                                                                                  \
   }
 #pragma unroll
@@ -532,7 +449,6 @@ __device__ __forceinline__ void fused_matrix_role(const uint4* __restrict__ xrin
 // 0.266 ms at FB15k-237 shapes, WN18RR 0.040 -> 0.047, plain ConvE 0.233 -> 0.241: the touched lines are fetched again by the
 // non-temporal loads that follow (profiles/r05b_experiments.txt, F).)
 // ---- conv role: conv wave cw (0..3) produces x fragments f = cw, cw+4
-#if !COPER_FUSED_CONV_FMA
 // Round 5: the 3x3 conv on the matrix cores.  Rounds 2 - 4 ran it as 72 fp32 FMAs per lane and output pixel (conv_x8) -- ~150
 // vector instructions per 16-query fragment and k-step with the split, 1,700 cycles per k-step for the eight fragments of a
 // 128-query tile (profiles/r05a_encoder_ablations.txt, NOMFMA build), against 1,250 for the dense layer's own MFMAs: the conv, not
@@ -665,66 +581,6 @@ __device__ __forceinline__ void fused_conv_role(uint4* __restrict__ xring, unsig
     }
   }
 }
-#else
-template <int NB>
-__device__ __forceinline__ void fused_conv_role(uint4* __restrict__ xring, float* __restrict__ img,
-                                                const FusedConvArgs& A, int64_t relw, int start, int n, int64_t kb,
-                                                int64_t ke, int i_lo, int t0, int t1, int cw) {
-  constexpr int NFR = (NB + 3) / 4;
-  constexpr int XSTAGE = 2 * NB * 64;
-  const int lane = threadIdx.x & 63;
-  const int nk = (int)(ke - kb);
-  const int Wo = A.Wo, in_w = A.in_w;
-  // folded taps of this lane's channel octet (loads in flight during the image prologue)
-  const int g = lane >> 4;
-  float tap[9][8], bs[8];
-  {
-    const float* wsrc = A.per_rel_conv ? A.conv_w + relw * (int64_t)(9 * 32) : A.conv_w;
-    const float* bsrc = A.per_rel_conv ? A.conv_b + relw * (int64_t)32 : A.conv_b;
-    conv_fold_taps(wsrc, bsrc, A.scale, A.shift, 32, 8 * g, A.x_exp, tap, bs);
-  }
-  fused_load_images(img, A, start, n, t0, t1);
-  // image rows of this lane's query in each of the wave's fragments (padding lanes repeat the last query)
-  const float* qimg[NFR];
-#pragma unroll
-  for (int t = 0; t < NFR; ++t) {
-    int qi = (cw + 4 * t) * 16 + (lane & 15);
-    if (qi > n - 1) qi = n - 1;
-    qimg[t] = img + qi * A.img_stride;
-  }
-  int poff = (int)(kb - (int64_t)i_lo * Wo);   // pixel offset ci*in_w + cj of the NEXT conv step
-  int cj = poff;
-  for (int kk = 0; kk <= nk; ++kk) {
-    // kk = 0: x(0) before the first barrier; kk >= 1: barrier k = kk-1, then x(kk) while the matrix waves run k
-    if (kk > 0) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my x writes of step kk-1 have landed in LDS
-      __builtin_amdgcn_s_barrier();
-    }
-#ifdef COPER_DBG_FUSED_NO_CONV
-    if (kk < 1) {
-#else
-    if (kk < nk) {
-#endif
-#pragma unroll
-      for (int t = 0; t < NFR; ++t) {
-        if (cw + 4 * t < NB) {   // wave-uniform
-          const float* r0 = qimg[t] + poff;
-          float w[9] = {r0[0], r0[1], r0[2], r0[in_w], r0[in_w + 1], r0[in_w + 2],
-                        r0[2 * in_w], r0[2 * in_w + 1], r0[2 * in_w + 2]};
-          float y[8];
-          conv_x8(w, tap, bs, y);
-          uint4 h4, l4;
-          split8_bf16(y, h4, l4);
-          uint4* dst = xring + (kk & 1) * XSTAGE + (cw + 4 * t) * 64 + lane;
-          dst[0] = h4;
-          dst[NB * 64] = l4;
-        }
-      }
-      if (++cj == Wo) { cj = 0; poff += in_w - Wo + 1; } else { ++poff; }
-    }
-  }
-}
-#endif
 
 // (Round 2, measured and not kept: a persistent form -- one workgroup per CU walking the (tile, K slice) items round-robin
 // instead of a grid sized by the worst case, most of it empty workgroups -- took 0.24 ms where this launch takes 0.19
@@ -739,7 +595,7 @@ extern "C" __attribute__((visibility("default"))) int coper_dbg_fused_clock(unsi
 #endif
 
 template <int NFB, bool WNT>
-__global__ __launch_bounds__(512) void k_dense_fused_bf16x3(const uint4* __restrict__ Whi, const fused_wlo_t* __restrict__ Wlo,
+__global__ __launch_bounds__(512) void k_dense_fused_bf16x3(const uint4* __restrict__ Whi, const uint4* __restrict__ Wlo,
                                                             FusedConvArgs A, const int32_t* __restrict__ tiles,
                                                             const int32_t* __restrict__ n_tiles, int64_t cap_small,
                                                             int nfb, int64_t ks32n, int nslices, int64_t Bcap,
@@ -833,16 +689,6 @@ __global__ __launch_bounds__(512) void k_dense_fused_bf16x3(const uint4* __restr
   // the next, each needing a whole free CU for its LDS before the dispatcher could move on.)
   int tile = (int)blockIdx.x - n_special;
   const int32_t* tl;
-#ifdef COPER_FUSED_OLD_GRID      // (A/B: each list in its own worst-case range)
-  if (tile < n_big_cap_old) {
-    if (tile >= n_tiles[1]) return;
-    tl = tiles + 4 * (cap_small + tile);
-  } else {
-    tile -= n_big_cap_old;
-    if (tile >= n_tiles[0]) return;
-    tl = tiles + 4 * (int64_t)tile;
-  }
-#else
   {
     const int nbig = n_tiles[1];
     if (tile < nbig) {
@@ -853,13 +699,17 @@ __global__ __launch_bounds__(512) void k_dense_fused_bf16x3(const uint4* __restr
       tl = tiles + 4 * (int64_t)tile;
     }
   }
-#endif
 #ifdef COPER_DBG_FUSED_EXIT
   return;
 #endif
   const int slice = blockIdx.y;
   const int fb0 = blockIdx.z * NFB;
   const int64_t relw = __builtin_amdgcn_readfirstlane(tl[0]);
+  int64_t relw_w = relw;         // the relation's slot in the weight planes
+  if (A.w_div > 1) {
+    relw_w = (int)relw / A.w_div;
+    if ((int)relw - (int)relw_w * A.w_div != A.w_rem && threadIdx.x == 0 && (blockIdx.y | blockIdx.z) == 0) atomicAdd(A.bad, (int)tl[2]);
+  }
   const int start = __builtin_amdgcn_readfirstlane(tl[1]);
   const int n = __builtin_amdgcn_readfirstlane(tl[2]);
   const bool shared_w = __builtin_amdgcn_readfirstlane(tl[3]) != 0;
@@ -871,28 +721,20 @@ __global__ __launch_bounds__(512) void k_dense_fused_bf16x3(const uint4* __restr
   const unsigned long long dbg_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
   uint4* xring = fused_lds;                       // 2 stages x 16 slots x 1 KiB
-#if COPER_FUSED_CONV_FMA
-  float* img = (float*)(fused_lds + 2 * 16 * 64);
-#else
   unsigned* img = (unsigned*)(fused_lds + 2 * 16 * 64);
-#endif
   // pixel p = k-step index: the slice needs image rows i_lo .. i_hi + 2
   const int i_lo = (int)(kb / A.Wo);
   const int t0 = i_lo * A.in_w;
   int t1 = ((int)((ke - 1) / A.Wo) + 3) * A.in_w;
   if (t1 > A.in_hw) t1 = A.in_hw;
-#ifdef COPER_FUSED_NO_TILE_POLICY   // A/B: the launch-level choice only
-#define TILE_WNT(x_) WNT
-#else
 #define TILE_WNT(x_) (x_)
-#endif
 #define BODY(NB_)                                                                                                      \
   if (wave < 4) {                                                                                                      \
     if (WNT && !shared_w)                                                                                              \
-      fused_matrix_role<NFB, NB_, TILE_WNT(true)>(xring, img, Whi, Wlo, A, relw, start, n, fb0, nfb, ks32n, kb, ke, t0, t1, zdst, \
+      fused_matrix_role<NFB, NB_, TILE_WNT(true)>(xring, img, Whi, Wlo, A, relw, relw_w, start, n, fb0, nfb, ks32n, kb, ke, t0, t1, zdst, \
                                                   d_pad16, wave, Fn, ks32s);                                           \
     else                                                                                                               \
-      fused_matrix_role<NFB, NB_, TILE_WNT(false)>(xring, img, Whi, Wlo, A, relw, start, n, fb0, nfb, ks32n, kb, ke, t0, t1, zdst, \
+      fused_matrix_role<NFB, NB_, TILE_WNT(false)>(xring, img, Whi, Wlo, A, relw, relw_w, start, n, fb0, nfb, ks32n, kb, ke, t0, t1, zdst, \
                                                    d_pad16, wave, Fn, ks32s);                                          \
   } else                                                                                                               \
     fused_conv_role<NB_>(xring, img, A, relw, start, n, kb, ke, i_lo, t0, t1, wave - 4);
@@ -934,9 +776,7 @@ bool dense_fused_supported(const coper_handle* h, int nslices) {
   if (dm.F != dm.F_pad || dm.F != (int64_t)dm.Ho * dm.Wo * 32) return false;
   if (dm.gen_conv && !dm.gen_fc) return false;       // per-relation filters need single-relation tiles
   if (!(dm.nfb == 13 || dm.nfb == 8 || dm.nfb == 16)) return false;
-#if !COPER_FUSED_CONV_FMA
   if ((dm.in_w & 1) || (dm.d & 1) || (dm.stacked && (dm.r & 1))) return false;   // the image planes hold two values per dword
-#endif
   int stride = fused_rows_max(dm, nslices) * dm.in_w;
   stride |= 1;
   size_t lds = (size_t)2 * 16 * 64 * sizeof(uint4) + (size_t)128 * stride * sizeof(float);
@@ -961,6 +801,7 @@ static void dense_fused_launch(coper_handle* h, const int64_t* e1, const int64_t
   A.d = dm.d; A.r = dm.r; A.in_w = dm.in_w; A.in_hw = dm.in_h * dm.in_w; A.Wo = dm.Wo;
   A.img_stride = (fused_rows_max(dm, nslices) * dm.in_w) | 1;
   A.chk = h->pass_chk;
+  A.w_div = h->w_div; A.w_rem = h->w_rem; A.bad = h->rel_count + dm.R + 1;
   size_t lds = (size_t)2 * 16 * 64 * sizeof(uint4) + (size_t)128 * A.img_stride * sizeof(float);
   static uint64_t attr_done = 0;   // per instantiation, one bit per device: always the hardware maximum
   const uint64_t bit = 1ull << (h->cfg.device & 63);
@@ -969,13 +810,8 @@ static void dense_fused_launch(coper_handle* h, const int64_t* e1, const int64_t
     attr_done |= bit;
   }
   // a pending staging job (coper_stage_ids_next) rides in this launch: FUSED_STAGE_WGS more workgroups
-#ifdef COPER_FUSED_OLD_GRID
-  const int n_big_cap_old = (int)(B / 33 + 1);
-  const int n_tile_blocks = n_big_cap_old + (int)(cap_small - 1 < B ? cap_small - 1 : B);
-#else
   const int n_big_cap_old = 0;
   const int n_tile_blocks = (int)(B / 128 + (cap_small - 1 < B ? cap_small - 1 : B) + 1);     // (an upper bound of the two tile lists together: see the kernel)
-#endif
   // (a pass being captured into a hipGraph leaves a pending staging job to the next eager call, as coper_post_i32_next does: a
   // replay would repeat the PCIe read with the pointers recorded at capture time and overwrite whatever staging buffer they name)
   coper_handle::PassPipeline& pp = h->pipe;
@@ -1020,7 +856,7 @@ static void dense_fused_launch(coper_handle* h, const int64_t* e1, const int64_t
   pp.gnext.ride = false; pp.gnext.pending = false;
   const int n_stage = (stage_now || post_now) ? FUSED_STAGE_WGS : 0;
   hipLaunchKernelGGL((k_dense_fused_bf16x3<NFB, WNT>), dim3((unsigned)(n_tile_blocks + n_group + n_stage), (unsigned)nslices, (unsigned)zgroups), dim3(512),
-                     lds, s, (const uint4*)h->Wf16_hi, (const fused_wlo_t*)(FUSED_LO8 ? h->Wf8_lo : h->Wf16_lo), A, h->tiles, h->n_tiles, cap_small, dm.nfb,
+                     lds, s, (const uint4*)h->Wf16_hi, (const uint4*)h->Wf16_lo, A, h->tiles, h->n_tiles, cap_small, dm.nfb,
                      dm.F_pad / 32, nslices, h->ws_queries, dm.d_pad16, h->z_part, Fn, n_group + n_stage, pp.stage.src,
                      stage_now ? pp.stage.n : 0, pp.stage.dst, w16_ks_stride(dm), J, n_group, pp.post.src, post_now ? pp.post.n : 0, pp.post.dst, n_big_cap_old);
   if (stage_now) pp.take_stage();

@@ -33,7 +33,7 @@ __device__ __forceinline__ void split8_e(const float* v, uint4& hi, uint4& lo) {
 // -> two bf16 planes in the 16x16x32 layout:  W16[(rel*nfb + fb)*ks32n + ks][lane] = 8 bf16.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_wfrag_to_bf16(const float4* __restrict__ Wf, int64_t n_relfb, int64_t ks32n,
-                                                       uint4* __restrict__ hi, uint4* __restrict__ lo, uint2* __restrict__ lo8, int nfb,
+                                                       uint4* __restrict__ hi, uint4* __restrict__ lo, int nfb,
                                                        const int32_t* __restrict__ w_exp, int64_t ks32s) {
   int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (relfb*ks32n + ks)*64 + lane
   if (j >= n_relfb * ks32n * 64) return;
@@ -52,14 +52,7 @@ __global__ __launch_bounds__(256) void k_wfrag_to_bf16(const float4* __restrict_
   for (int t = 0; t < 8; ++t) v[t] = x3_scale(v[t], ew);
   uint4 h4, l4;
   const int64_t jo = (relfb * ks32s + ks) * 64 + l;     // (ks32s: k-steps between two feature blocks of the image, coper_internal.h)
-#ifndef COPER_SPLIT_BF16
-  if (lo8) {       // the second term in 8 bits (split16.h): the byte plane for the fused encoder, the same values as fp16 for the others
-    uint2 b2;
-    split8_q8(v, h4, l4, b2);
-    lo8[jo] = b2;
-  } else
-#endif
-    split8_e(v, h4, l4);
+  split8_e(v, h4, l4);
   hi[jo] = h4;
   lo[jo] = l4;
 }
@@ -83,7 +76,7 @@ __global__ void k_bits_to_exp(int32_t* __restrict__ w_exp, int64_t n) {
   if (i < n) w_exp[i] = x3_exp_for_bits((unsigned)w_exp[i]);
 }
 
-int launch_wfrag_to_bf16(coper_handle* h, const float* Wf, int64_t Rw, void* hi, void* lo, void* lo8, hipStream_t s) {
+int launch_wfrag_to_bf16(coper_handle* h, const float* Wf, int64_t Rw, void* hi, void* lo, hipStream_t s) {
   const Dims& dm = h->dm;
   int64_t ks32n = dm.F_pad / 32;
   int64_t total = Rw * dm.nfb * ks32n * 64;
@@ -92,7 +85,7 @@ int launch_wfrag_to_bf16(coper_handle* h, const float* Wf, int64_t Rw, void* hi,
   hipLaunchKernelGGL(k_w_absmax, dim3(64, (unsigned)Rw), dim3(256), 0, s, (const float4*)Wf, per_rel4, h->w_exp);
   hipLaunchKernelGGL(k_bits_to_exp, dim3((unsigned)((Rw + 255) / 256)), dim3(256), 0, s, h->w_exp, Rw);
   hipLaunchKernelGGL(k_wfrag_to_bf16, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float4*)Wf,
-                     Rw * dm.nfb, ks32n, (uint4*)hi, (uint4*)lo, (uint2*)lo8, dm.nfb, h->w_exp, w16_ks_stride(dm));
+                     Rw * dm.nfb, ks32n, (uint4*)hi, (uint4*)lo, dm.nfb, h->w_exp, w16_ks_stride(dm));
   COPER_HIP_TRY(h, hipGetLastError());
   return COPER_OK;
 }

@@ -73,7 +73,6 @@ struct SC3 {
   uint4 a0[2][PD][MB], a1[2][PD][MB];                     // entity fragments: two sets of PD steps, [m2]; reg 0 / reg 1 of the step
   uint4 q0[4], q1[4];                                     // query fragments of four consecutive regions (ring)
   f32x4 biasv[2][MB];                                     // [M][m2]
-  f32x4 braw[2][MB];                                      // (COPER_SC3_ASM_LOADS) pred_bias as loaded: scaled into biasv at the top of the half-row
   float thi[NB], tlo[NB];
   int cg[NB];
   unsigned mk[2 * MB], mg[2 * MB];                        // (logit >= t_lo) / (logit > t_hi): word MB M + (V >> 5), value V at bit 31 - (V & 31)
@@ -92,80 +91,21 @@ __device__ __forceinline__ uint4 sc3_lds_hi(const uint4 __attribute__((address_s
 }
 
 // Entity fragments: global loads from a 64-bit vector address per stream; constants beyond the 13-bit immediate cost a v_add_co /
-// v_addc pair and the wait states of their carry (58 loads per half-row).  Round 4 tried BUFFER loads instead (-DCOPER_SC3_BUFFER_LOADS:
+// v_addc pair and the wait states of their carry (58 loads per half-row).  Round 4 tried BUFFER loads instead (the build switch is gone:
 // a resource descriptor per row in four scalar registers, the lane's 16-byte slot as the one vector offset, the register's place
 // inside the row as a scalar offset: `s_movk` + `buffer_load`, no vector instruction, wait states 29 -> 7 per half-row): 0.2645
 // against 0.2551 ms on the same box, three alternating runs -- the address arithmetic is not what the loads cost.
-#ifndef COPER_SC3_BUFFER_LOADS     /* the shipped form */
 struct sc3_rsrc_t { const char* p; };
 __device__ __forceinline__ sc3_rsrc_t sc3_make_rsrc(const void* p) { return sc3_rsrc_t{(const char*)p}; }
 __device__ __forceinline__ uint4 sc3_bload(const sc3_rsrc_t r, const int voff, const int soff) { return *(const uint4*)(r.p + soff + voff); }
-#else
-typedef __amdgpu_buffer_rsrc_t sc3_rsrc_t;
-// (raw buffers: no stride, 2 GiB of records -- every offset used lies inside a row's 2 BLK_REGS KiB; 0x00020000: 32-bit data format)
-__device__ __forceinline__ sc3_rsrc_t sc3_make_rsrc(const void* p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7FFFFFFE, 0x00020000); }
-__device__ __forceinline__ uint4 sc3_bload(const sc3_rsrc_t r, const int voff, const int soff) {
-  const sc3_u4n v = __builtin_bit_cast(sc3_u4n, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
-  return make_uint4(v.x, v.y, v.z, v.w);
-}
-#endif
 struct SC3Ptrs {
   sc3_rsrc_t ra;               // this row's two entity blocks: block M, 16-row block m2, step t, register w at byte
   sc3_rsrc_t rn;               //   ((M BLK_REGS + (m2 NS + t) 2 + w) 64 + lane) 16;   rn: the next row's block 0
   int voff;                    // lane * 16
   const uint4* hl;       // the query tile in LDS, lane included
   const uint4 __attribute__((address_space(3)))* hl_hi;    // ... its part beyond 64 KiB (an LDS pointer the compiler cannot fold back)
-  unsigned lds[3];             // (COPER_SC3_ASM_LOADS) LDS byte address of the lane's slot in register 0, 4096, 8192 of the tile
 };
 
-#ifdef COPER_SC3_ASM_LOADS
-// The loads of a region written as instructions (sc3_region_asm_ld.inc; tools/microbench/mfma_load_mix.hip: behind the region's
-// last MFMAs they cost the matrix pipe 3 %, in front of the region -- where the compiler puts them -- 21 %).  The compiler does
-// not see them, so it does not wait for them either: every region starts with an s_waitcnt written here.  The counters count in
-// order and every load of the row loop is one of these (pred_bias included: sc3_load_bias), so "at most n younger loads
-// outstanding" is exact; anything else the compiler issues in between (mask and maxima stores) only makes a wait stricter.
-//   LDS:    region R reads the query fragments of region R + SC3_LD behind its last MFMAs -> at its top the reads of regions
-//           R - SC3_LD + 1 .. R - 1 may be outstanding: lgkmcnt(2 (SC3_LD - 1));
-//   global: the eight regions of step s load the entity fragments of step s + PD -> at the top of a step the loads of steps
-//           s - PD + 1 .. s - 1 may be outstanding: vmcnt(8 (PD - 1)), first region of the step only.
-// s_waitcnt's immediate (gfx9 encoding): vmcnt [3:0] and [15:14], expcnt [6:4] (7: no wait), lgkmcnt [11:8]
-#define SC3_WAITENC(vm, lg) (((vm) & 15) | (7 << 4) | (((lg) & 15) << 8) | ((((vm) >> 4) & 3) << 14))
-template <int NP, int TAIL, int PD, int M, int s, int b>
-struct SC3Ld {
-  static constexpr int MB = SC3_MB, NS = NP + TAIL, NR = NS * 8, G = (NS + PD - 1) / PD;
-  static_assert(MB == 4, "one entity-fragment load per region: 2 MB = 8 registers per step");
-  static constexpr int PA = (G & 1) ? M : 0, PA_NEXT = (PA + G) & 1;                   // (as in sc3_region)
-  static constexpr int m2 = b >> 1, wh = b & 1, tk = s + PD, u = tk - NS;
-  static constexpr bool this_block = tk < NS;                                          // else: step u of the next block ...
-  static constexpr bool next_row = !this_block && M == 1;                              // ... which is block 0 of the next row
-  static constexpr int set = this_block ? ((PA + tk / PD) & 1) : PA_NEXT, slot = this_block ? tk % PD : u;
-  static constexpr int BLKB = MB * NS * 2 * 1024;                                      // bytes of one entity block's registers
-  static constexpr int goff = this_block ? M * BLKB + ((m2 * NS + tk) * 2 + wh) * 1024 : (M == 0 ? BLKB : 0) + ((m2 * NS + u) * 2 + wh) * 1024;
-  static constexpr int glit = goff & ~4095, gimm = goff & 4095;                        // page (a v_add_u32 literal), 12-bit immediate
-  static constexpr int R = s * 8 + b, R2 = (R + SC3_LD) % NR, s2 = R2 / 8, b2 = R2 % 8, ring = (R + SC3_LD) & 3;
-  static constexpr int i0 = ((b2 * NS + s2) * 2) * 64;                                 // register 0 of region R2 (register 1: + 64)
-  static constexpr int lbase = i0 / 4096, lo0 = (i0 % 4096) * 16, lo1 = lo0 + 1024;    // (a ds_read offset holds 16 bits)
-  static_assert(lbase < 3 && lo1 < 65536, "three LDS bases");
-  static constexpr int wc = SC3_WAITENC(b == 0 ? 8 * (PD - 1) : 63, 2 * (SC3_LD - 1));
-};
-typedef unsigned sc3_u4w __attribute__((ext_vector_type(4)));
-#define SC3_QW(x) (*(sc3_u4w*)&(x))
-template <class L, class ST>
-__device__ __forceinline__ uint4& sc3_ld_gd(ST& S) {
-  if constexpr (L::wh == 0) return S.a0[L::set][L::slot][L::m2];
-  else return S.a1[L::set][L::slot][L::m2];
-}
-// the loads of a region in front of it (regions the compiler schedules: step 0)
-template <class L, class ST>
-__device__ __forceinline__ void sc3_ld_issue(ST& S, const SC3Ptrs& X) {
-  unsigned gt;
-  const char* GS = L::next_row ? X.rn.p : X.ra.p;
-  asm volatile("v_add_u32 %1, %3, %2\n\tglobal_load_dwordx4 %0, %1, %4 offset:%5"
-               : "=&v"(SC3_QW(sc3_ld_gd<L>(S))), "=&v"(gt) : "v"(X.voff), "n"(L::glit), "s"(GS), "n"(L::gimm));
-  asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"
-               : "=&v"(SC3_QW(S.q0[L::ring])), "=&v"(SC3_QW(S.q1[L::ring])) : "v"(X.lds[L::lbase]), "n"(L::lo0), "n"(L::lo1));
-}
-#endif
 
 // what follows the comparisons of value V: every 32 values the word pair gives the counts, every 8 (top-k launches) the block
 // maximum is reduced across lanes and stored, the row's last value stores the band words that carry a bit
@@ -304,26 +244,6 @@ template <int NP, int TAIL, int PD, int GM, int M>
 __device__ __forceinline__ void sc3_load_bias(SC3<NP, TAIL, PD, GM>& S, const float* __restrict__ bias_pad, const int64_t blk, const int lane) {
   sc3_load_bias_<NP, TAIL, PD, GM, M>(S, (const float4*)(bias_pad + blk * (16 * SC3_MB) + 4 * (lane >> 4)), std::make_integer_sequence<int, SC3_MB>{});
 }
-#ifdef COPER_SC3_ASM_LOADS
-// the same rows as loaded (no scale yet: the values arrive later): START = the tile's first row, loads the compiler sees
-template <int NP, int TAIL, int PD, int GM, int M, bool START>
-__device__ __forceinline__ void sc3_load_braw(SC3<NP, TAIL, PD, GM>& S, const float* __restrict__ bias_pad, const int64_t blk, const int lane) {
-  static_assert(SC3_MB == 4, "four quads");
-  const f32x4* bp = (const f32x4*)(bias_pad + blk * (16 * SC3_MB) + 4 * (lane >> 4));
-  if constexpr (START) {
-    S.braw[M][0] = bp[0]; S.braw[M][1] = bp[4]; S.braw[M][2] = bp[8]; S.braw[M][3] = bp[12];
-  } else {
-    asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:64\n\t"
-                 "global_load_dwordx4 %2, %4, off offset:128\n\tglobal_load_dwordx4 %3, %4, off offset:192"
-                 : "=&v"(S.braw[M][0]), "=&v"(S.braw[M][1]), "=&v"(S.braw[M][2]), "=&v"(S.braw[M][3]) : "v"(bp));
-  }
-}
-template <int NP, int TAIL, int PD, int GM, int M, int... m2>
-__device__ __forceinline__ void sc3_scale_bias(SC3<NP, TAIL, PD, GM>& S, std::integer_sequence<int, m2...>) {
-  ((S.biasv[M][m2] = f32x4{x3_scale(S.braw[M][m2][0], S.sexp), x3_scale(S.braw[M][m2][1], S.sexp), x3_scale(S.braw[M][m2][2], S.sexp),
-                           x3_scale(S.braw[M][m2][3], S.sexp)}), ...);
-}
-#endif
 
 // the instructions of region (step s, column block b) on the MB accumulator chains of block M, chains interleaved
 template <int NP, int TAIL, int PD, int GM, int M, int s, int b, int sa, int sl, int rs, bool tail, int... m2>
@@ -372,23 +292,6 @@ __device__ __forceinline__ void sc3_region_asm(SC3<NP, TAIL, PD, GM>& S, const S
   float sc;
   typedef unsigned sc3_u4 __attribute__((ext_vector_type(4)));     // (a HIP uint4 is a struct: not a register operand)
 #define SC3_Q(x) (*(const sc3_u4*)&(x))
-#ifdef COPER_SC3_ASM_LOADS
-  static_assert(GM != 2, "COPER_SC3_ASM_LOADS: the generator writes no blocks with 64-entity maxima");
-  typedef SC3Ld<NP, TAIL, PD, M, s, b> L;
-  uint4& GD = sc3_ld_gd<L>(S);
-  uint4& QD0 = S.q0[L::ring];
-  uint4& QD1 = S.q1[L::ring];
-  const char* GS = L::next_row ? X.rn.p : X.ra.p;
-  const unsigned LA = X.lds[L::lbase];
-  unsigned gt;
-  if constexpr (GM) {
-    constexpr int vm = v0 & 7;
-    static_assert(!(cnt == 3 && vm == 7), "the maximum of a group is stored after the block: it must not hold the next group's first pair");
-#include "sc3_region_asm_gm_ld.inc"
-  } else {
-#include "sc3_region_asm_ld.inc"
-  }
-#else
   if constexpr (GM) {       // top-k launches: block maxima folded in (even values wait in S.px, odd ones fold the pair into S.mx)
     constexpr int vm = v0 & sc3_gmask(GM);
     static_assert(!(cnt == 3 && vm == sc3_gmask(GM)), "the maximum of a group is stored after the block: it must not hold the next group's first pair");
@@ -400,7 +303,6 @@ __device__ __forceinline__ void sc3_region_asm(SC3<NP, TAIL, PD, GM>& S, const S
   } else {
 #include "sc3_region_asm.inc"
   }
-#endif
 #undef SC3_Q
   sc3_value_tail<NP, TAIL, PD, GM, 1 - M, v0>(S, lane, store_ok, gm_row, gm_col, mask_row);
   if constexpr (cnt > 1) sc3_value_tail<NP, TAIL, PD, GM, 1 - M, v0 + 1>(S, lane, store_ok, gm_row, gm_col, mask_row);
@@ -427,9 +329,7 @@ __device__ __forceinline__ void sc3_slot(SC3<NP, TAIL, PD, GM>& S, float* sc, co
 #ifndef COPER_DBG_SC3_NO_EPI
   sc3_slot_pieces<NP, TAIL, PD, GM, 1 - M, v0, cnt, I * PP>(S, sc, lane, store_ok, gm_row, gm_col, mask_row, std::make_integer_sequence<int, PP>{});
 #endif
-#ifndef COPER_SC3_NO_SLOT_FENCE
   SC3_FENCE();
-#endif
 }
 
 template <int NP, int TAIL, int PD, int GM, int M, int s, int b, int sa, int sl, int rs, bool tail, int v0, int cnt, int PP, int... I>
@@ -451,37 +351,6 @@ __device__ __forceinline__ void sc3_region(SC3<NP, TAIL, PD, GM>& S, const SC3Pt
   constexpr int PA = (G & 1) ? M : 0;        // entity-fragment set of this block's step 0
   constexpr int PA_NEXT = (PA + G) & 1;      // ... of the next block's step 0
   constexpr int sa = (PA + s / PD) & 1, sl = s % PD, tk = s + PD;
-#ifdef COPER_SC3_ASM_LOADS
-  {
-    typedef SC3Ld<NP, TAIL, PD, M, s, b> L;
-    constexpr int R = s * 8 + b, rs = R & 3;
-    constexpr int c0 = b * CH / 8, c1 = (b + 1) * CH / 8, v0 = s * CH + c0;
-    constexpr int cnt = v0 >= NV ? 0 : (v0 + (c1 - c0) > NV ? NV - v0 : c1 - c0);
-    if constexpr (MB == 4 && s > 0 && cnt >= 1 && cnt <= 3 && (v0 >> 5) == ((v0 + cnt - 1) >> 5) && !(GM && cnt == 3 && (v0 & sc3_gmask(GM)) == sc3_gmask(GM))) {
-      sc3_region_asm<NP, TAIL, PD, GM, M, s, b, sa, sl, rs, tail, v0, cnt>(S, X, lane, prev_valid, gm_row, gm_col, mask_row);
-      SC3_FENCE();
-      return;
-    }
-    // a region the compiler schedules (step 0, whose chains start from pred_bias): the wait -- tied to the registers it is for,
-    // so that nothing that reads them moves above it -- then the loads in front
-#define SC3_T(x) "+v"(SC3_QW(x))
-    asm volatile("s_waitcnt %10"
-                 : SC3_T(S.q0[rs]), SC3_T(S.q1[rs]), SC3_T(S.a0[sa][sl][0]), SC3_T(S.a0[sa][sl][1]), SC3_T(S.a0[sa][sl][2]), SC3_T(S.a0[sa][sl][3]),
-                   SC3_T(S.a1[sa][sl][0]), SC3_T(S.a1[sa][sl][1]), SC3_T(S.a1[sa][sl][2]), SC3_T(S.a1[sa][sl][3])
-                 : "n"(L::wc));
-#undef SC3_T
-    if constexpr (R == 0) {     // pred_bias of this half-row: loaded a row ago, behind the same wait (volatile asm keeps its place)
-      asm volatile("" : "+v"(S.braw[M][0]), "+v"(S.braw[M][1]), "+v"(S.braw[M][2]), "+v"(S.braw[M][3]));
-      sc3_scale_bias<NP, TAIL, PD, GM, M>(S, std::make_integer_sequence<int, MB>{});
-    }
-    sc3_ld_issue<L>(S, X);
-    SC3_FENCE();
-    sc3_mfmas<NP, TAIL, PD, GM, M, s, b, sa, sl, rs, tail>(S, std::make_integer_sequence<int, MB>{});
-    if constexpr (cnt > 0) sc3_values<NP, TAIL, PD, GM, 1 - M, v0>(S, lane, prev_valid, gm_row, gm_col, mask_row, std::make_integer_sequence<int, cnt>{});
-    SC3_FENCE();
-    return;
-  }
-#endif
 #ifndef COPER_DBG_SC3_SKIP_GL
   if constexpr (b < 2 * MB) {
     constexpr int m2 = b >> 1, wh = b & 1;
@@ -536,8 +405,7 @@ __device__ __forceinline__ void sc3_region(SC3<NP, TAIL, PD, GM>& S, const SC3Pt
   // epilogue of the other block: this step's chunk of CH values is dealt to the eight regions in order
   constexpr int c0 = b * CH / 8, c1 = (b + 1) * CH / 8, v0 = s * CH + c0;
   constexpr int cnt = v0 >= NV ? 0 : (v0 + (c1 - c0) > NV ? NV - v0 : c1 - c0);
-#ifndef COPER_SC3_INTERLEAVED     /* the shipped form: the region's MFMAs, then whole values */
-#if !defined(COPER_SC3_NO_ASM_REGION) && !defined(COPER_DBG_SC3_NO_EPI) && !defined(COPER_DBG_SC3_NO_BAND) && !defined(COPER_DBG_SC3_EPI_R0) && !defined(COPER_SPLIT_BF16)
+#if !defined(COPER_DBG_SC3_NO_EPI) && !defined(COPER_DBG_SC3_NO_BAND) && !defined(COPER_DBG_SC3_EPI_R0)
   if constexpr (MB == 4 && s > 0 && cnt >= 1 && cnt <= 3 && (v0 >> 5) == ((v0 + cnt - 1) >> 5) && !(GM && cnt == 3 && (v0 & sc3_gmask(GM)) == sc3_gmask(GM))) {
     sc3_region_asm<NP, TAIL, PD, GM, M, s, b, sa, sl, rs, tail, v0, cnt>(S, X, lane, prev_valid, gm_row, gm_col, mask_row);
     SC3_FENCE();
@@ -551,19 +419,6 @@ __device__ __forceinline__ void sc3_region(SC3<NP, TAIL, PD, GM>& S, const SC3Pt
   if constexpr (cnt > 0) sc3_values<NP, TAIL, PD, GM, 1 - M, v0>(S, lane, prev_valid, gm_row, gm_col, mask_row, std::make_integer_sequence<int, cnt>{});
 #endif
   SC3_FENCE();
-#else
-  // experiment (tools/ab_build.py IL=-DCOPER_SC3_INTERLEAVED): one MFMA, one piece of the other block's epilogue, barrier --
-  // slot by slot.  tools/microbench/mfma_valu_mix.hip says clumps of 5 vector instructions cost ~12 % against the same
-  // instructions spread one behind each MFMA; this form spreads them, but the compiler answers the barriers with 37 - 53
-  // spilled registers and more wait states: 0.295 against 0.276 ms.  Not the default.
-  constexpr int NM = tail ? 2 * MB : 3 * MB;
-  constexpr int PP = cnt == 0 ? 0 : (2 * cnt + NM - 1) / NM;          // pieces behind one MFMA (1 for every d > 32)
-  constexpr int NSLOT = NM;
-  float sc[cnt > 0 ? cnt : 1];
-  SC3_FENCE();       // (the region's loads stay in front of its first MFMA)
-  sc3_slots<NP, TAIL, PD, GM, M, s, b, sa, sl, rs, tail, v0, cnt, PP>(S, sc, lane, prev_valid, gm_row, gm_col, mask_row,
-                                                                       std::make_integer_sequence<int, NSLOT>{});
-#endif
 }
 
 template <int NP, int TAIL, int PD, int GM, int M, int s>
@@ -580,11 +435,7 @@ __device__ __forceinline__ void sc3_step(SC3<NP, TAIL, PD, GM>& S, const SC3Ptrs
   sc3_region<NP, TAIL, PD, GM, M, s, 7>(S, X, lane, prev_valid, gm_row, gm_col, mask_row);
   if constexpr (s == 0) {
     // pred_bias of this block in the NEXT row: the chains have consumed biasv[M] (program order)
-#ifdef COPER_SC3_ASM_LOADS
-    sc3_load_braw<NP, TAIL, PD, GM, M, false>(S, bias_pad, bias_blk_next, lane);
-#else
     sc3_load_bias<NP, TAIL, PD, GM, M>(S, bias_pad, bias_blk_next, lane);
-#endif
     SC3_FENCE();
   }
 }
@@ -645,10 +496,6 @@ __global__ __launch_bounds__(256, 1) void k_score_count3_bf16x3(const uint4* __r
   // rows_per_tile + 1/3 long: workgroups that cross into a new tile get fewer rows)
   int64_t r_begin, r_end;
   {
-#ifdef COPER_SC3_EVEN_SPLIT
-    r_begin = total_rows * blockIdx.x / gridDim.x;
-    r_end = total_rows * (blockIdx.x + 1) / gridDim.x;
-#else
 #ifndef COPER_SC3_TILE_COST
 #define COPER_SC3_TILE_COST 16
 #endif
@@ -662,7 +509,6 @@ __global__ __launch_bounds__(256, 1) void k_score_count3_bf16x3(const uint4* __r
     };
     r_begin = row_at(total_u * blockIdx.x / gridDim.x);
     r_end = blockIdx.x + 1 == gridDim.x ? total_rows : row_at(total_u * (blockIdx.x + 1) / gridDim.x);
-#endif
   }
   if (rows_per_item > 0) {
     const int64_t n_tiles = total_rows / rows_per_tile;
@@ -697,9 +543,6 @@ __global__ __launch_bounds__(256, 1) void k_score_count3_bf16x3(const uint4* __r
     const int64_t row = r % rows_per_tile;
     const int64_t eb = (row * 4 + wave) * 2;
     if (tile != cur_tile) {   // workgroup-uniform: (re)start of the pipeline
-#ifdef COPER_SC3_ASM_LOADS
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the last row's look-ahead loads (the compiler does not know them)
-#endif
       __syncthreads();
       const uint4* sh = Hf3 + tile * (TILE_REGS * 64);
       {
@@ -734,13 +577,8 @@ __global__ __launch_bounds__(256, 1) void k_score_count3_bf16x3(const uint4* __r
       for (int i = 0; i < 2 * MB; ++i) { S.mk[i] = 0u; S.mg[i] = 0u; }
       // entity fragments of block 0's first PD steps, pred_bias of both blocks, "previous block" accumulators that count nothing
       sc3_prologue_a<NP, TAIL, PD, GM>(S, Ef3 + eb * BLK_REGS * 64 + lane, std::make_integer_sequence<int, PD>{});
-#ifdef COPER_SC3_ASM_LOADS
-      sc3_load_braw<NP, TAIL, PD, GM, 0, true>(S, bias_pad, eb, lane);
-      sc3_load_braw<NP, TAIL, PD, GM, 1, true>(S, bias_pad, eb + 1, lane);
-#else
       sc3_load_bias<NP, TAIL, PD, GM, 0>(S, bias_pad, eb, lane);
       sc3_load_bias<NP, TAIL, PD, GM, 1>(S, bias_pad, eb + 1, lane);
-#endif
 #pragma unroll
       for (int b = 0; b < NB; ++b)
 #pragma unroll
@@ -761,27 +599,14 @@ __global__ __launch_bounds__(256, 1) void k_score_count3_bf16x3(const uint4* __r
     const int64_t eb_next = has_next ? (((r + 1) % rows_per_tile) * 4 + wave) * 2 : eb;     // past the end: re-read this row's blocks
     const int64_t gm_col = cur_tile * 128;
     SC3Ptrs X;
-#ifdef COPER_SC3_ASM_LOADS
-    {   // the rows' bases as scalar registers whatever the compiler thinks of their uniformity (the loads' "s" operands)
-      const uint64_t pa = (uint64_t)(Ef3 + eb * BLK_REGS * 64), pn = (uint64_t)(Ef3 + eb_next * BLK_REGS * 64);
-      X.ra = sc3_make_rsrc((const void*)(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(pa >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)pa)));
-      X.rn = sc3_make_rsrc((const void*)(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(pn >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)pn)));
-    }
-#else
     X.ra = sc3_make_rsrc(Ef3 + eb * BLK_REGS * 64);
     X.rn = sc3_make_rsrc(Ef3 + eb_next * BLK_REGS * 64);
-#endif
     X.voff = lane * 16;
     X.hl = hl3 + lane;
     {
       unsigned hi_off = (unsigned)(uintptr_t)((const uint4 __attribute__((address_space(3)))*)(hl3 + lane + 4096));
       asm volatile("" : "+v"(hi_off));     // opaque: otherwise the second base is re-derived from the first with an add per read
       X.hl_hi = (const uint4 __attribute__((address_space(3)))*)(uintptr_t)hi_off;
-#ifdef COPER_SC3_ASM_LOADS
-      X.lds[0] = hi_off - 65536u; X.lds[1] = hi_off; X.lds[2] = hi_off + 65536u;
-      asm volatile("" : "+v"(X.lds[0]));         // (opaque, as hi_off: a base is a register, not an add in front of every block)
-      if constexpr (TILE_REGS > 128) asm volatile("" : "+v"(X.lds[2]));
-#endif
     }
     uint4* mask_cur = mask + ((cur_tile * rows_per_tile + row) * 4 + wave) * MW;
     // block 0 (epilogue of the previous row's block 1 beside it: its last value completes that row's mask), then block 1
@@ -1388,11 +1213,9 @@ static int sc3_go(coper_handle* h, int64_t q0, int64_t Bc, int32_t* ng, float* g
 template <int NP, int TAIL>
 static int sc3_gm(coper_handle* h, int64_t q0, int64_t Bc, int32_t* ng, float* gmax, int64_t gm_stride, hipStream_t s) {
   if (!gmax) return sc3_go<NP, TAIL, 0>(h, q0, Bc, ng, gmax, gm_stride, s);
-#ifndef COPER_SC3_ASM_LOADS
   if constexpr (SC3_MB == 4 && (2 * NP + TAIL == 13 || 2 * NP + TAIL == 16)) {     // (64-entity maxima: topk_expand, coper_internal.h)
     if (topk_expand(h) == 2) return sc3_go<NP, TAIL, 2>(h, q0, Bc, ng, gmax, gm_stride, s);
   }
-#endif
   return sc3_go<NP, TAIL, 1>(h, q0, Bc, ng, gmax, gm_stride, s);
 }
 
@@ -1417,12 +1240,8 @@ int score_count3_chunk_bf16x3(coper_handle* h, int64_t q0, int64_t Bc, const flo
     ScopedKernelTimer t(h, "score_count", s);
     switch (h->dm.KS16) {
 #define SC3_CASE(KS_) case KS_: rc = sc3_gm<(KS_) / 2, (KS_) & 1>(h, q0, Bc, ng, gmax, gm_stride, s); break;
-#ifdef COPER_SC3_ONLY_KS    /* quick experiment builds: one instantiation */
-      SC3_CASE(COPER_SC3_ONLY_KS)
-#else
       SC3_CASE(1) SC3_CASE(2) SC3_CASE(3) SC3_CASE(4) SC3_CASE(5) SC3_CASE(6) SC3_CASE(7) SC3_CASE(8) SC3_CASE(9) SC3_CASE(10)
       SC3_CASE(11) SC3_CASE(12) SC3_CASE(13) SC3_CASE(14) SC3_CASE(15) SC3_CASE(16) SC3_CASE(17) SC3_CASE(18) SC3_CASE(19) SC3_CASE(20)
-#endif
 #undef SC3_CASE
       default: rc = fail(h, COPER_EUNSUPPORTED, "score_count3: ent_emb_size beyond 320");
     }

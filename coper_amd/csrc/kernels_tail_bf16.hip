@@ -254,10 +254,6 @@ __global__ __launch_bounds__(64 * TL_WAVES, KS <= 13 ? 3 : 2) void k_finalize_ta
   static_assert(TL_WAVES == 4, "x3_batch_exp: 256 threads");
   int eh, sexp;
   int32_t x3l[2];                         // (what x3s holds once block 0 has published: this kernel must not read it back)
-#ifdef COPER_TL_H_AFTER_EXP      /* the round-4 form before this one: the h rows requested after the exponent's reduction */
-  eh = x3_batch_exp(x3m, ent_exp, x3s, &s_n2[0][0]); sexp = eh + ent_exp; x3l[0] = eh; x3l[1] = sexp;
-  __syncthreads();                        // (s_n2 served as the reduction's scratch)
-#endif
   {
     const bool vec_ok = (d & 3) == 0 && (((uintptr_t)h_rows) & 15) == 0;
     constexpr int NKW = (KS + TL_WAVES - 1) / TL_WAVES;      // k-steps of a wave
@@ -278,10 +274,8 @@ __global__ __launch_bounds__(64 * TL_WAVES, KS <= 13 ? 3 : 2) void k_finalize_ta
         }
       }
     }
-#ifndef COPER_TL_H_AFTER_EXP
     eh = x3_batch_exp(x3m, ent_exp, x3s, &s_n2[0][0]); sexp = eh + ent_exp; x3l[0] = eh; x3l[1] = sexp;
     __syncthreads();                        // (s_n2 served as the reduction's scratch)
-#endif
     float n2 = 0.f;
 #pragma unroll
     for (int u = 0; u < NKW; ++u) {

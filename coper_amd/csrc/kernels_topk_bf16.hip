@@ -205,13 +205,9 @@ __global__ __launch_bounds__(TK_THREADS) void k_topk_threshold_emit(const float*
       slots[c] = (int64_t)k + (indptr[qg + 1] - indptr[0] - beg);
     }
   }
-  // a sweep whose result does not depend on the visiting order (COPER_TK_BLOCKED_SWEEPS: A/B build with contiguous ranges)
+  // a sweep whose result does not depend on the visiting order (contiguous ranges were the A/B form of round 4)
   auto sweep_any_order = [&](auto&& f) {
-#ifdef COPER_TK_BLOCKED_SWEEPS
-    tk_sweep(col, qs4, g_lo, g_hi, f);
-#else
     tk_sweep_strided(col, qs4, (int64_t)sr, (int64_t)SUB, G, f);
-#endif
   };
   uint32_t* myhist = hist + (sr % HCOPY) * 256 * NQS + 4 * qv;
   uint32_t mask = 0;

@@ -7,8 +7,8 @@
 //   fp16 (5-bit exponent, 11-bit significand): hi + lo carries 22-23 significant bits (error <= 2^-22 |x|) while lo is a
 //        NORMAL fp16, i.e. 2^-3 <= |x| < 65,504; below that lo is subnormal and the error is 2^-25 ABSOLUTE (gfx950's fp16
 //        MFMA keeps subnormal inputs: measured, tools/microbench/mfma_shape.hip).
-// Round 3 measured what the 8 missing bits cost (tools/rank_decomp.py): the split is fp16 (COPER_SPLIT_BF16 builds the
-// round-2 arithmetic for A/B).
+// Round 3 measured what the 8 missing bits cost (tools/rank_decomp.py): the split is fp16 (round 2's bf16 arithmetic was a
+// build option until round 6: DESIGN_LOG.md).
 //
 // Round 4: the split is SCALE-INVARIANT.  fp16's 22 bits only exist in a window of magnitudes, and nothing about the model
 // puts its operands there: the reference initialises ent_emb with xavier_initializer (models.py:205-208: +-0.02 for
@@ -28,34 +28,21 @@
 
 namespace coper {
 
-#ifdef COPER_SPLIT_BF16
-typedef __bf16 s16_t;
-#define S16_NAME "bf16"
-#define S16_MFMA32_BUILTIN __builtin_amdgcn_mfma_f32_32x32x16_bf16
-#define S16_MFMA16_BUILTIN __builtin_amdgcn_mfma_f32_16x16x32_bf16
-__device__ __forceinline__ float s16_clamp(float v) { return v; }
-#else
 typedef _Float16 s16_t;
 #define S16_NAME "fp16"
 #define S16_MFMA32_BUILTIN __builtin_amdgcn_mfma_f32_32x32x16_f16
 #define S16_MFMA16_BUILTIN __builtin_amdgcn_mfma_f32_16x16x32_f16
 __device__ __forceinline__ float s16_clamp(float v) { return __builtin_fminf(__builtin_fmaxf(v, -65504.f), 65504.f); }   // (NaN stays NaN)
-#endif
 typedef s16_t s16x8 __attribute__((ext_vector_type(8)));
 
 // exponent e with  maxabs * 2^e  in [2^14, 2^15)  (0 for zero / non-finite maxima); |e| <= X3_EXP_CLAMP
 constexpr int X3_EXP_CLAMP = 60;
 __host__ __device__ __forceinline__ int x3_exp_for_bits(unsigned bits) {   // bits of a non-negative float
-#ifdef COPER_SPLIT_BF16
-  (void)bits;
-  return 0;                                   // (bf16 carries fp32's exponent range: nothing to move)
-#else
   const int be = (int)((bits >> 23) & 255u);
   if ((bits & 0x7fffffffu) == 0u || be == 255) return 0;
   // normal: maxabs in [2^(be-127), 2^(be-126));  subnormal maxima are treated like the smallest normal
   const int e = 14 - ((be ? be : 1) - 127);
   return e > X3_EXP_CLAMP ? X3_EXP_CLAMP : (e < -X3_EXP_CLAMP ? -X3_EXP_CLAMP : e);
-#endif
 }
 // v * 2^e, exact (v_ldexp_f32)
 __device__ __forceinline__ float x3_scale(float v, int e) { return __builtin_ldexpf(v, e); }
@@ -86,16 +73,6 @@ __device__ __forceinline__ void split8_s16(const float* v, uint4& hi, uint4& lo)
 // split8_s16's.  12 vector instructions per 8 values where the compiler's form of split8_s16 takes 40.
 __device__ __forceinline__ void split8_pos_s16(const float* v, uint4& hi, uint4& lo) {
   unsigned hw[4], lw[4];
-#ifdef COPER_SPLIT_BF16
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float a = v[2 * j], b = v[2 * j + 1];
-    s16x2 hp = {(s16_t)a, (s16_t)b};
-    s16x2 lp = {(s16_t)(a - (float)hp[0]), (s16_t)(b - (float)hp[1])};
-    hw[j] = __builtin_bit_cast(unsigned, hp);
-    lw[j] = __builtin_bit_cast(unsigned, lp);
-  }
-#else
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const float a = v[2 * j], b = v[2 * j + 1];
@@ -103,68 +80,9 @@ __device__ __forceinline__ void split8_pos_s16(const float* v, uint4& hi, uint4&
     asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lw[j]) : "v"(hw[j]), "v"(a));
     asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lw[j]) : "v"(hw[j]), "v"(b));
   }
-#endif
   hi = make_uint4(hw[0], hw[1], hw[2], hw[3]);
   lo = make_uint4(lw[0], lw[1], lw[2], lw[3]);
 }
-#ifndef COPER_SPLIT_BF16
-// ---- the dense weights' second term in 8 bits (round 4 experiment, -DCOPER_FUSED_LO8: the fused encoder then streams 3 bytes per
-// value instead of 4; measured and not shipped, see kernels_dense_fused_bf16.hip).
-// lo = x - hi lies within half an ulp of hi: |lo| <= 2^(E - 26) with E the biased exponent of the fp16 hi (hi = 1.m 2^(E - 15)).
-// It is kept as  q = rne(lo / 2^(E - 33)), an integer in [-128, 127] (+128, exactly half an ulp, is clamped), and the term that
-// enters the matrix cores is  lo' = q 2^(E - 33)  -- exactly an fp16, rebuilt from the byte and hi's own exponent bits by
-// lo8_decode below.  hi + lo' carries 19 - 20 significant bits of every value whatever its magnitude (|x - hi - lo'| <=
-// 2^(E - 34) <= 2^-19 |x|).  E < 19 (|hi| < 2^-11 of the class maximum after the power-of-two scaling above): lo' = 0.
-// The fp16 lo plane the other dense kernels read holds the same lo', so that h stays one function of (e1, rel) whichever
-// kernel serves a tile.
-__device__ __forceinline__ void split8_q8(const float* v, uint4& hi, uint4& lo16, uint2& lo8) {
-  unsigned hw[4], lw[4], bw[2] = {0u, 0u};
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    unsigned short hb[2], lb[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const float a = s16_clamp(v[2 * j + u]);
-      const s16_t h = (s16_t)a;
-      hb[u] = __builtin_bit_cast(unsigned short, h);
-      const int E = (hb[u] >> 10) & 31;
-      float q = 0.f;
-      if (E >= 19 && E < 31) {
-        q = __builtin_rintf(__builtin_ldexpf(a - (float)h, 33 - E));
-        q = __builtin_fminf(__builtin_fmaxf(q, -128.f), 127.f);
-      }
-      const s16_t l = (s16_t)__builtin_ldexpf(q, E - 33);      // (exact: 8 bits, a normal fp16 or zero)
-      lb[u] = __builtin_bit_cast(unsigned short, l);
-      bw[j >> 1] |= (unsigned)((int)q + 128) << (8 * (2 * (j & 1) + u));
-    }
-    hw[j] = (unsigned)hb[0] | ((unsigned)hb[1] << 16);
-    lw[j] = (unsigned)lb[0] | ((unsigned)lb[1] << 16);
-  }
-  hi = make_uint4(hw[0], hw[1], hw[2], hw[3]);
-  lo16 = make_uint4(lw[0], lw[1], lw[2], lw[3]);
-  lo8 = make_uint2(bw[0], bw[1]);
-}
-// 8 bytes + the 8 hi values they belong to -> the 8 fp16 lo' values (16 bytes), five vector instructions per pair:
-//   v_perm_b32    0x64XX 0x64YY: the fp16 numbers 1024 + byte (1024's ulp is 1)
-//   v_pk_add_f16  - 1152 = -(1024 + 128): q, exactly
-//   v_and_b32     hi's exponent fields;  v_pk_sub_u16 (clamp)  - 18: the exponent field of 2^(E - 33), 0 below E = 19
-//   v_pk_mul_f16  q 2^(E - 33): exact (8 bits times a power of two, normal)
-typedef unsigned short lo8_u16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned lo8_u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned lo8_u32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ lo8_u32x4 lo8_decode(const lo8_u32x2 b, const lo8_u32x4 hi) {
-  lo8_u32x4 out;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const unsigned t = __builtin_amdgcn_perm(0x64646464u, b[j >> 1], (j & 1) ? 0x04030402u : 0x04010400u);
-    const s16x2 q = __builtin_bit_cast(s16x2, t) + (s16x2){(s16_t)-1152.f, (s16_t)-1152.f};
-    const lo8_u16x2 e = __builtin_bit_cast(lo8_u16x2, hi[j] & 0x7C007C00u);
-    const lo8_u16x2 sc = __builtin_elementwise_sub_sat(e, (lo8_u16x2){0x4800, 0x4800});
-    out[j] = __builtin_bit_cast(unsigned, q * __builtin_bit_cast(s16x2, sc));
-  }
-  return out;
-}
-#endif
 
 // one value -> its two 16-bit patterns
 __device__ __forceinline__ void split1_s16(float v, unsigned short& hi, unsigned short& lo) {

@@ -37,8 +37,12 @@ inline size_t tg_plane_elems(int64_t rows, int64_t K) { return (size_t)(tg_rows_
 // rows_fast: consecutive rows are contiguous in memory (the pack reads along rows), else consecutive k are.
 // exp_from: another plane set packed from the SAME tensor earlier (its exponent is reused: no second pass for the maximum);
 // otherwise the largest |X| is reduced first (scratch: two device words)
+// max_slots: TG_MAX_SLOTS device words whose maximum is the bit pattern of the operand's largest |X| -- left by the kernel that
+// PRODUCED the tensor (the optimizer's pass over the dense weights: coper_train.hip) -- the pack reduces them itself: no pass
+// over the tensor for its maximum at all
+constexpr int TG_MAX_SLOTS = 1024;
 int tg_pack(coper_handle* h, const float* src, TgIdx ri, TgIdx ki, int64_t R, int64_t K, int64_t R_pad, bool rows_fast, TgPlanes out,
-            hipStream_t s, unsigned* scratch, const int32_t* exp_from = nullptr);
+            hipStream_t s, unsigned* scratch, const int32_t* exp_from = nullptr, const unsigned* max_slots = nullptr);
 // C[off(ci, i) + off(cj, j)] = sum_k X(i, k) Y(j, k), i < M, j < N
 // nsplit > 1: K is cut into nsplit slices whose partial sums go to `part` ([nsplit][M][N] floats) and are summed in slice order
 // sumsq: when not null, the sum of the squares of the stored C is added by the storing kernel to the TG_SUMSQ_SLOTS device

@@ -12,7 +12,7 @@
 // inference path (k_pack_frag: any two-level strided view of an fp32 tensor -> [row block of 32][k-step][64 lanes] x 16 B,
 // transposing through LDS so that the reads follow the contiguous dimension), then k_gemm_nt_bf16x3 streams fragments
 // straight into the registers the MFMAs consume and stores C through a two-level strided view.
-// Round 5: the split is fp16 with one exact power of two per packed operand (split16.h; COPER_SPLIT_BF16 builds keep round 2's):
+// Round 5: the split is fp16 with one exact power of two per packed operand (split16.h; round 2's was bf16):
 // the planes hold X 2^e_X with max |X| 2^e_X in [2^14, 2^15), the epilogue multiplies by 2^-(e_X + e_Y).
 #include "coper_internal.h"
 #include "split16.h"
@@ -42,14 +42,29 @@ __global__ __launch_bounds__(256) void k_tg_absmax_exp(const float* __restrict__
                                                        int32_t* __restrict__ exp_out) {
   unsigned m = 0u;
   const int64_t n4 = (((uintptr_t)src) & 15) == 0 ? n >> 2 : 0;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n4; e += (int64_t)gridDim.x * 256) {
+  // eight independent 16-byte loads in flight per thread (round 6: the loop carried ONE -- 118 MB of projections took 59 us,
+  // 2 TB/s, and the 13 - 30 MB operands 18 - 32 us each: 137 us of a 1.25 ms step went into five of these launches)
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  for (; e + 7 * stride < n4; e += 8 * stride) {
+    uint4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = ((const uint4*)src)[e + u * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const unsigned a = v[u].x & 0x7fffffffu, b = v[u].y & 0x7fffffffu, c = v[u].z & 0x7fffffffu, d = v[u].w & 0x7fffffffu;
+      const unsigned ab = a > b ? a : b, cd = c > d ? c : d, x = ab > cd ? ab : cd;
+      m = x > m ? x : m;
+    }
+  }
+  for (; e < n4; e += stride) {
     const uint4 v = ((const uint4*)src)[e];
     const unsigned a = v.x & 0x7fffffffu, b = v.y & 0x7fffffffu, c = v.z & 0x7fffffffu, d = v.w & 0x7fffffffu;
     const unsigned ab = a > b ? a : b, cd = c > d ? c : d, x = ab > cd ? ab : cd;
     m = x > m ? x : m;
   }
-  for (int64_t e = 4 * n4 + (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
-    const unsigned b = __float_as_uint(src[e]) & 0x7fffffffu;
+  for (int64_t e1 = 4 * n4 + (int64_t)blockIdx.x * 256 + threadIdx.x; e1 < n; e1 += stride) {
+    const unsigned b = __float_as_uint(src[e1]) & 0x7fffffffu;
     m = b > m ? b : m;
   }
 #pragma unroll
@@ -81,7 +96,8 @@ __global__ __launch_bounds__(256) void k_tg_absmax_exp(const float* __restrict__
 template <int MODE, int RT>
 __global__ __launch_bounds__(256) void k_pack_frag(const float* __restrict__ src, TgIdx ri, TgIdx ki, int64_t R, int64_t K,
                                                    int KS16, int KST, uint4* __restrict__ hi, uint4* __restrict__ lo,
-                                                   const int32_t* __restrict__ exp_dev, int32_t* __restrict__ exp_copy) {
+                                                   const int32_t* __restrict__ exp_dev, int32_t* __restrict__ exp_copy,
+                                                   const unsigned* __restrict__ max_slots) {
   // tile of RT rows x KT k (4096 elements): 32 x 128 when k is the contiguous direction, 128 x 32 when rows are (a
   // wave then reads 512 contiguous bytes per k instead of 128: the [rho][f][k] -> rows (rho, k) view of the projection
   // went from 70 to 5x us)
@@ -120,8 +136,23 @@ __global__ __launch_bounds__(256) void k_pack_frag(const float* __restrict__ src
       tile[row][kk] = v.x; tile[row + 1][kk] = v.y; tile[row + 2][kk] = v.z; tile[row + 3][kk] = v.w;
     }
   }
+  // the operand's power of two: a word another pack left, or -- max_slots -- the maximum its producer left in TG_MAX_SLOTS slots
+  __shared__ unsigned s_mx[4];
+  if (max_slots) {
+    unsigned mx = 0u;
+    for (int i = t; i < TG_MAX_SLOTS; i += 256) { const unsigned v = max_slots[i]; mx = v > mx ? v : mx; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned u = __shfl_xor(mx, o, 64); mx = u > mx ? u : mx; }
+    if ((t & 63) == 0) s_mx[t >> 6] = mx;
+  }
   __syncthreads();
-  const int pe = *exp_dev;
+  int pe;
+  if (max_slots) {
+    const unsigned a = s_mx[0] > s_mx[1] ? s_mx[0] : s_mx[1], b = s_mx[2] > s_mx[3] ? s_mx[2] : s_mx[3];
+    pe = x3_exp_for_bits(a > b ? a : b);
+  } else {
+    pe = *exp_dev;
+  }
   if (exp_copy && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *exp_copy = pe;    // (a plane set packed with another set's exponent)
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
@@ -151,26 +182,28 @@ static bool tg_vec_ok(const float* src, const TgIdx& fast, const TgIdx& slow, in
 }
 
 int tg_pack(coper_handle* h, const float* src, TgIdx ri, TgIdx ki, int64_t R, int64_t K, int64_t R_pad, bool rows_fast, TgPlanes out,
-            hipStream_t s, unsigned* scratch, const int32_t* exp_from) {
+            hipStream_t s, unsigned* scratch, const int32_t* exp_from, const unsigned* max_slots) {
   const int KS16 = (int)((K + 15) / 16), KST = (int)tg_ks_stride(K);
   if (!out.exp || !scratch) return fail(h, COPER_ESTATE, "tg_pack: plane set without an exponent word");
-  if (!exp_from) {       // (scratch is zero between calls: the reduction's last block resets it)
-    int64_t nb = (R * K + 256 * 16 - 1) / (256 * 16);
-    if (nb > 1024) nb = 1024;
+  if (!exp_from && !max_slots) {       // (scratch is zero between calls: the reduction's last block resets it)
+    // (at most 512 workgroups: every one ends on two atomics on one line -- a thousand of them took longer than the reduction)
+    int64_t nb = (R * K + 256 * 32 - 1) / (256 * 32);
+    if (nb > 512) nb = 512;
     if (nb < 1) nb = 1;
     hipLaunchKernelGGL(k_tg_absmax_exp, dim3((unsigned)nb), dim3(256), 0, s, src, R * K, scratch, out.exp);
   }
   const int32_t* pexp = exp_from ? exp_from : out.exp;
-  int32_t* pcopy = exp_from ? out.exp : nullptr;
+  int32_t* pcopy = (exp_from || max_slots) ? out.exp : nullptr;
+  if (exp_from) max_slots = nullptr;
   const bool vec = rows_fast ? tg_vec_ok(src, ri, ki, R) : tg_vec_ok(src, ki, ri, K);
   if (!rows_fast) {
     dim3 grid((unsigned)((KS16 + 7) / 8), (unsigned)(R_pad / 32));
-    if (vec) hipLaunchKernelGGL((k_pack_frag<2, 32>), grid, dim3(256), 0, s, src, ri, ki, R, K, KS16, KST, out.hi, out.lo, pexp, pcopy);
-    else hipLaunchKernelGGL((k_pack_frag<0, 32>), grid, dim3(256), 0, s, src, ri, ki, R, K, KS16, KST, out.hi, out.lo, pexp, pcopy);
+    if (vec) hipLaunchKernelGGL((k_pack_frag<2, 32>), grid, dim3(256), 0, s, src, ri, ki, R, K, KS16, KST, out.hi, out.lo, pexp, pcopy, max_slots);
+    else hipLaunchKernelGGL((k_pack_frag<0, 32>), grid, dim3(256), 0, s, src, ri, ki, R, K, KS16, KST, out.hi, out.lo, pexp, pcopy, max_slots);
   } else {
     dim3 grid((unsigned)((KS16 + 1) / 2), (unsigned)(R_pad / 128));   // R_pad is a multiple of TG_ROW_PAD = 128
-    if (vec) hipLaunchKernelGGL((k_pack_frag<3, 128>), grid, dim3(256), 0, s, src, ri, ki, R, K, KS16, KST, out.hi, out.lo, pexp, pcopy);
-    else hipLaunchKernelGGL((k_pack_frag<1, 128>), grid, dim3(256), 0, s, src, ri, ki, R, K, KS16, KST, out.hi, out.lo, pexp, pcopy);
+    if (vec) hipLaunchKernelGGL((k_pack_frag<3, 128>), grid, dim3(256), 0, s, src, ri, ki, R, K, KS16, KST, out.hi, out.lo, pexp, pcopy, max_slots);
+    else hipLaunchKernelGGL((k_pack_frag<1, 128>), grid, dim3(256), 0, s, src, ri, ki, R, K, KS16, KST, out.hi, out.lo, pexp, pcopy, max_slots);
   }
   COPER_HIP_TRY(h, hipGetLastError());
   return COPER_OK;

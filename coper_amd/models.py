@@ -73,7 +73,7 @@ def _host(v):
 
 class ConvE(object):
     def __init__(self, model_descriptors: dict, device=None, shard=None, score_mode="f32", rank_band_kappa=0.0, band_audit_period=0,
-                 role="both"):
+                 role="both", rel_mod=None):
         md = dict(model_descriptors)
         # required keys, as models.py:99-105,119-130 reads them
         for key in ("use_negative_sampling", "label_smoothing_epsilon", "num_ent", "num_rel", "ent_emb_size",
@@ -103,7 +103,9 @@ class ConvE(object):
             raise ValueError("role: 'both', 'encode' (no entity planes; encode only) or 'score' (no generated weights; scoring only)")
         self.role = role
         cfg = _lib.make_config(md, device=self.device.index or 0, shard=self.shard, score_mode=mode, rank_band_kappa=rank_band_kappa,
-                               band_audit_period=band_audit_period, role={"both": _lib.ROLE_BOTH, "encode": _lib.ROLE_ENCODE, "score": _lib.ROLE_SCORE}[role])
+                               band_audit_period=band_audit_period, role={"both": _lib.ROLE_BOTH, "encode": _lib.ROLE_ENCODE, "score": _lib.ROLE_SCORE}[role],
+                               rel_mod=rel_mod)
+        self.rel_mod = (int(rel_mod[0]), int(rel_mod[1])) if rel_mod is not None else None
         h = C.c_void_p()
         rc = self._lib.coper_create(C.byref(cfg), C.byref(h))
         if rc != 0:

@@ -147,7 +147,11 @@ class EntityShardedRanker(object):
         # race on one handle's workspace) and a communicator of its own (one communicator runs its collectives in issue order)
         # (overlap=False: everything on one stream and one communicator, in program order -- the A/B switch, and the fallback should two
         #  communicators in flight at once ever misbehave on a node: they are issued in the same order on every rank)
-        self.overlap = bool(self.cuda and self.encoder is not self.scorer and self.dist) if overlap is None else bool(overlap and self.cuda and self.encoder is not self.scorer)
+        #  Default: on from two ranks on.  With ONE rank holding the whole table it costs more than it hides (measured, 10M x 256:
+        #  46.8 -> 48.6 ms per chunk -- the count launch deals its rows so that the workgroups of an XCD stream one stretch of the
+        #  table together, and a second kernel taking CUs in the middle of it breaks that up; on a 1.25 M-row shard 7.04 -> 6.82 ms)
+        two = self.cuda and self.encoder is not self.scorer
+        self.overlap = bool(two and self.dist and self.world > 1) if overlap is None else bool(overlap and two)
         self.side = torch.cuda.Stream(device=self.device) if self.overlap else None
         self.side_group = group
         if self.overlap and self.world > 1 and not self.emulated:

@@ -115,7 +115,17 @@ typedef struct coper_config {
    * config) and refuses coper_encode / coper_encode_rank / training.  Everything both roles derive (folded BN, the band constants,
    * the powers of two of split16.h) is the same values on both. */
   int32_t role;                 /* coper_role */
-  int32_t reserved[3];
+  /* The generated dense weights W_r of the relations r with r mod rel_mod_world == rel_mod_rank ONLY (round 6; 0 or 1 = all of
+   * them).  An entity-sharded evaluation splits its encoder by relation -- rank g of G encodes the queries whose relation id is
+   * g mod G (coper_amd/sharding.py step 2) -- so its encoder handle needs R2 / G weight sets, not R2: 1.6 GB instead of 12.8 GB per
+   * rank for the 10M-entity config at G = 8.  Everything small that is derived per relation (conv filters, biases, the powers
+   * of two of split16.h) is still built for every relation, from the same values: h[b] is the same bits as on a handle that holds
+   * all weight sets.  A query whose relation the handle does not hold is encoded with another relation's weights and COUNTED
+   * (coper_check_ids).  COPER_SCORE_BF16X3 with generated dense weights (context_rel_out) on the fused encoder only:
+   * COPER_EUNSUPPORTED from coper_prepare otherwise; no training. */
+  int32_t rel_mod_world;
+  int32_t rel_mod_rank;
+  int32_t reserved[1];
 } coper_config;
 
 typedef enum coper_role { COPER_ROLE_BOTH = 0, COPER_ROLE_ENCODE = 1, COPER_ROLE_SCORE = 2 } coper_role;
@@ -425,7 +435,11 @@ COPER_API int coper_train_init(coper_handle* h, const coper_train_config* cfg);
  * e1, rel int64 [B]; lookup int32 [B,L] (obj_lookup_values); labels float [B,L] (e2_multi for the looked-up
  * entities).  lookup == NULL with L == num_ent is 1-vs-all training (use_negative_sampling = False, run_cpg.py:116:
  * labels are the dense e2_multi [B, num_ent], models.py:159-162).  loss_out: device float[1], the batch loss
- * (models.py:448-453). */
+ * (models.py:448-453).
+ * The registered tensors ARE the variables and the step keeps facts about them from one step to the next (round 6: the largest
+ * magnitude of the dense weights, noted by the optimizer's pass as it writes them, is what the next step's operand packing scales
+ * by).  A caller that changes parameter CONTENTS between steps by other means than this call registers the tensor again
+ * (coper_set_param on the same pointer is enough; coper_amd.ConvE.load_parameters does) -- as coper_prepare asks for inference. */
 COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t* rel, const int32_t* lookup,
                                const float* labels, int64_t B, int64_t L, float* loss_out, void* stream);
 /* The train-mode graph WITHOUT the update: what `session.run(model.loss)` or `session.run(model.predictions_lookup)` under

@@ -681,3 +681,61 @@ def test_one_handle_per_role(mode):
     for m in (both, enc, sco):
         m.close()
     assert lib.coper_live_device_bytes() == base
+
+
+@pytest.mark.parametrize("workload,G", [("fb15k237_cpg", 3), ("synth10m_cpg", 8), ("wn18rr_cpg", 4)])
+def test_generated_weights_of_the_held_relations_only(workload, G):
+    """coper_config.rel_mod_* (round 6): an encoder handle that holds the generated dense weights of the relations r with
+    r mod G == g only -- what rank g of an entity-sharded evaluation encodes -- gives the bits of a handle that holds them all,
+    in 1 / G of the weight memory; a query of another relation is counted by coper_check_ids; what the option does not serve is
+    refused by coper_prepare."""
+    from coper_amd import _lib
+    from coper_amd.models import ConvE
+    md = cdata.model_descriptors(workload, num_ent=3000)
+    if workload == "synth10m_cpg":
+        md["num_rel"] = 203                                      # (not a multiple of G: the last slots of some ranks stay empty)
+    p = {k: torch.as_tensor(v).to("cuda:0") for k, v in cdata.synthetic_params(md, 7).items()}
+    q = cdata.synthetic_queries(md, 1500, seed=8)
+    lib = _lib.load()
+    import gc
+    gc.collect()
+    base = lib.coper_live_device_bytes()
+    full = ConvE(md, device="cuda:0", score_mode="bf16x3", role="encode").load_parameters(p).prepare()
+    n_full = lib.coper_live_device_bytes() - base
+    h_full = full.encode(q["e1"], q["rel"])
+    rows = full.gather_entities(q["e1"])
+    for g in range(G):
+        part = ConvE(md, device="cuda:0", score_mode="bf16x3", role="encode", rel_mod=(G, g)).load_parameters(p)
+        before = lib.coper_live_device_bytes()
+        part.prepare()
+        n_part = lib.coper_live_device_bytes() - before
+        assert n_part < n_full * (1.0 / G + 0.15), (g, n_part, n_full)
+        mine = np.nonzero(q["rel"] % G == g)[0]
+        sel = torch.as_tensor(mine).to("cuda:0")
+        h = part.encode(q["e1"][mine], q["rel"][mine])
+        assert torch.equal(h, h_full[sel]), g
+        assert part.check_ids() == 0
+        h2 = part.encode(None, torch.as_tensor(q["rel"][mine]).to("cuda:0"), e1_rows=rows[sel].contiguous())     # (what sharding.py's step 2 calls)
+        assert torch.equal(h2, h_full[sel]), g
+        if g == 0:
+            other = np.nonzero(q["rel"] % G != g)[0][:37]
+            part.encode(q["e1"][other], q["rel"][other])
+            assert part.check_ids() == len(other)
+        part.close()
+    full.close()
+    assert lib.coper_live_device_bytes() == base
+    # refused: the fp32-exact mode, a static dense layer
+    bad = ConvE(md, device="cuda:0", score_mode="f32", rel_mod=(G, 0)).load_parameters(p)
+    with pytest.raises(_lib.CoperError) as e:
+        bad.prepare()
+    assert e.value.code == 7
+    bad.close()
+    mdp = cdata.model_descriptors("fb15k237_plain", num_ent=500)
+    bad = ConvE(mdp, device="cuda:0", score_mode="bf16x3", rel_mod=(2, 1)).load_parameters(cdata.synthetic_params(mdp, 1))
+    with pytest.raises(_lib.CoperError) as e:
+        bad.prepare()
+    assert e.value.code == 7
+    bad.close()
+    with pytest.raises(_lib.CoperError):
+        ConvE(md, device="cuda:0", score_mode="bf16x3", rel_mod=(4, 4))
+    assert lib.coper_live_device_bytes() == base

@@ -81,6 +81,37 @@ def test_synth10m_full_size(oracle_chain, mode):
         ev, ei = torch.topk(row, K)                                          # ties at the top are not expected here
         assert torch.equal(ev, tv[b]) and torch.equal(ei, ti[b])
     del xrows
+    # (1b) round 6: the same ranks pinned to the C RESTATEMENT of the fp32 chain directly -- no second HIP handle
+    # in the argument.  Eight of the sampled queries: their 10M logits by oracle_score_chain (oracle/coper_oracle_chain.c, fmaf in
+    # the documented order) block-wise over the device-drawn table copied to the host, the closed form of metrics.py:44-50 on them.
+    from concurrent.futures import ThreadPoolExecutor
+    pin = sample[::5][:8]
+    hp = np.ascontiguousarray(h[torch.as_tensor(pin).cuda()].cpu().numpy())
+    tq = q["e2"][pin]
+    tx_c = np.array([O.score_chain(hp[i:i + 1], ent[int(tq[i]):int(tq[i]) + 1].cpu().numpy(), bias[int(tq[i]):int(tq[i]) + 1].cpu().numpy())[0, 0]
+                     for i in range(len(pin))], np.float32)
+    ng_c, ne_c = np.zeros(len(pin), np.int64), np.zeros(len(pin), np.int64)
+    BLK = 1_000_000
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        for lo in range(0, E, BLK):
+            hi = min(E, lo + BLK)
+            Eb, bb = ent[lo:hi].cpu().numpy(), bias[lo:hi].cpu().numpy()
+
+            def one(i):
+                row = O.score_chain(hp[i:i + 1], Eb, bb)[0]                 # (ctypes releases the GIL: eight chains side by side)
+                f = ix[ip[pin[i]]:ip[pin[i] + 1]]
+                f = f[(f >= lo) & (f < hi)] - lo
+                keep = np.ones(hi - lo, bool)
+                keep[f] = False
+                if lo <= tq[i] < hi:
+                    keep[tq[i] - lo] = False
+                row = row[keep]
+                return int((row > tx_c[i]).sum()), int((row == tx_c[i]).sum())
+            for i, (g_, e_) in enumerate(ex.map(one, range(len(pin)))):
+                ng_c[i] += g_
+                ne_c[i] += e_
+    assert np.array_equal(tx_c, tgt[1, torch.as_tensor(pin).cuda()].cpu().numpy())            # the exact-chain targets, bit for bit
+    assert np.array_equal(1 + ng_c, ranks_np[pin]) and np.array_equal(ne_c, ne.cpu().numpy()[pin]), (1 + ng_c, ranks_np[pin])
     # (2) logits on sampled columns against the fp64 oracle; fp32 mode: bit-equal to the documented chain
     cols = np.unique(np.concatenate([np.random.default_rng(1).integers(0, E, 3000), q["e2"][sample], q["e1"][sample]]))
     cols_t = torch.as_tensor(cols).cuda()

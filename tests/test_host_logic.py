@@ -187,19 +187,13 @@ def test_bench_self_launch_propagates_a_failing_rank():
 
 def test_generated_asm_regions_are_up_to_date(tmp_path):
     """coper_amd/csrc/sc3_region_asm{,_gm,_gm64}.inc are generated (tools/gen_sc3_region_asm.py) and committed: the committed files must be
-    what the generator writes today.  The pair of the COPER_SC3_ASM_LOADS build option (loads inside the blocks) is written on demand by
-    coper_amd/build.py (`--with-loads`) and not kept in the tree."""
+    what the generator writes today."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     subprocess.run([sys.executable, os.path.join(root, "tools", "gen_sc3_region_asm.py"), str(tmp_path)], check=True, capture_output=True)
     for name in ("sc3_region_asm.inc", "sc3_region_asm_gm.inc", "sc3_region_asm_gm64.inc"):
         assert open(os.path.join(str(tmp_path), name)).read() == open(os.path.join(root, "coper_amd", "csrc", name)).read(), name
-    assert not os.path.exists(os.path.join(str(tmp_path), "sc3_region_asm_ld.inc"))
-    assert not os.path.exists(os.path.join(root, "coper_amd", "csrc", "sc3_region_asm_ld.inc"))
-    subprocess.run([sys.executable, os.path.join(root, "tools", "gen_sc3_region_asm.py"), str(tmp_path), "--with-loads"], check=True, capture_output=True)
-    for name in ("sc3_region_asm_ld.inc", "sc3_region_asm_gm_ld.inc"):
-        assert os.path.getsize(os.path.join(str(tmp_path), name)) > 10000
 
 
 def test_hits_means_native_equals_numpy_bit_for_bit():

@@ -13,6 +13,8 @@ if args and args[0] == "--only":
 for spec in args:
     tag, _, flags = spec.partition("=")
     flags = [f for f in flags.split(",") if f]
+    if any(f.startswith("-DCOPER_DBG_") for f in flags) and "-DCOPER_DIAG" not in flags:
+        flags.append("-DCOPER_DIAG")            # (the ablation switches exist in diagnostic builds only: csrc/coper_internal.h)
     out = os.path.join(build.HERE, "..", "build", "ab", "lib_%s.so" % tag)
     if only is None:
         build.build_library(force=True, extra_flags=flags, out=out)
