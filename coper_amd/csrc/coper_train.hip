@@ -366,70 +366,6 @@ __global__ __launch_bounds__(256) void k_tr_score_loss(const float* __restrict__
   if (threadIdx.x == 0) atomicAdd(loss_acc, part[0]);
 }
 
-// The sampled scorer forward AND its backward w.r.t. h in ONE pass over the gathered rows (round 6; the dense-scorer route):
-//   s[b,l] = pred_bias[row] + E[row] . h[b];  loss;  ds[b,l] = (sigmoid(s) - t) / (B L);  dh[b,:] = sum_l ds[b,l] E[row,:]
-// ds of a row is a function of that row alone, so the row that was just gathered for its score is still in registers when its
-// contribution to dh is known: k_tr_score_loss + k_tr_dh_gather4 read the 410 MB of gathered rows (512 x 1000 x 200) twice, 61 + 45 us.
-// A wave owns a row slot: lane q (< d / 4) holds four features of the row as one 16-byte load (a row is ONE coalesced request),
-// eight rows in flight per wave; the score is a butterfly sum over the wave.  The four waves' partial dh meet in LDS in wave order.
-__global__ __launch_bounds__(256) void k_tr_score_loss_dh(const float* __restrict__ hv, const float* __restrict__ ent,
-                                                          const float* __restrict__ pred_bias, const int32_t* __restrict__ lookup,
-                                                          const float* __restrict__ labels, int64_t E, int d, int64_t L, float ls_eps,
-                                                          float inv_E, float inv_BL, float* __restrict__ ds, float* __restrict__ dh,
-                                                          double* __restrict__ loss_acc) {
-  __shared__ float4 s_dh[4][64];
-  __shared__ double s_loss[4];
-  const int64_t b = blockIdx.x;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, d4 = d >> 2;
-  const bool on = lane < d4;
-  const float4 h4 = on ? *(const float4*)(hv + b * d + 4 * lane) : make_float4(0.f, 0.f, 0.f, 0.f);
-  const int32_t* lk = lookup + b * L;
-  const float* lab = labels + b * L;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  double loss = 0.0;
-  for (int64_t l0 = wave; l0 < L; l0 += 32) {           // rows l0, l0 + 4, ..., l0 + 28 of this wave
-    int64_t row[8];
-    float4 v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int64_t l = l0 + 4 * u;
-      row[u] = l < L ? lk[l] : 0;
-      if (row[u] < 0 || row[u] >= E) row[u] = 0;
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = on ? *(const float4*)(ent + row[u] * d + 4 * lane) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int64_t l = l0 + 4 * u;
-      float p = fmaf(h4.w, v[u].w, fmaf(h4.z, v[u].z, fmaf(h4.y, v[u].y, h4.x * v[u].x)));
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) p += __shfl_xor(p, o, 64);        // every lane holds the sum (same value: one order)
-      if (l < L) {
-        const float sc = p + pred_bias[row[u]];
-        const float t = (1.f - ls_eps) * lab[l] + inv_E;                                    // models.py:450
-        const float g = (1.f / (1.f + expf(-sc)) - t) * inv_BL;
-        if (lane == 0) {
-          loss += (double)(fmaxf(sc, 0.f) - sc * t + log1pf(expf(-fabsf(sc))));              // sigmoid cross-entropy with logits
-          ds[b * L + l] = g;
-        }
-        acc.x = fmaf(g, v[u].x, acc.x); acc.y = fmaf(g, v[u].y, acc.y); acc.z = fmaf(g, v[u].z, acc.z); acc.w = fmaf(g, v[u].w, acc.w);
-      }
-    }
-  }
-  s_dh[wave][lane] = acc;
-  if (lane == 0) s_loss[wave] = loss;
-  __syncthreads();
-  if (wave == 0) {
-    if (on) {
-      float4 o = s_dh[0][lane];
-#pragma unroll
-      for (int w = 1; w < 4; ++w) { const float4 q = s_dh[w][lane]; o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w; }
-      *(float4*)(dh + b * d + 4 * lane) = o;
-    }
-    if (lane == 0) atomicAdd(loss_acc, ((s_loss[0] + s_loss[1]) + (s_loss[2] + s_loss[3])));
-  }
-}
-
 // ------------------------------------------------------------------------------------------------
 // backward kernels
 // ------------------------------------------------------------------------------------------------
@@ -1441,9 +1377,9 @@ static int train_step_impl(coper_handle* h, const int64_t* e1, const int64_t* re
 
   // ---- zero what is accumulated by atomics: one launch
   const bool dense_scorer_bwd = (double)B * (double)dm.E * 4.0 <= 512.0 * 1024 * 1024 && dm.E <= 0x7fffffff;
-  // the sampled scorer's forward also leaves dh (k_tr_score_loss_dh: one pass over the gathered rows instead of two); coper_train_forward
-  // takes the same kernel -- its loss is the following step's bit for bit
-  const bool fused_dh = !one_vs_all && dense_scorer_bwd && (d & 3) == 0 && d >= 16 && d <= 256 && (((uintptr_t)T->find("ent_emb")->p) & 15) == 0;
+  // (Round 6 tried the sampled scorer's forward and dh in ONE pass over the gathered rows -- a wave per row, the score a butterfly
+  //  sum over its lanes: 242 us against 61 + 45 for the two kernels.  Thirty-two sequential iterations per wave, each with two
+  //  dependent round trips and eight six-step cross-lane sums, are latency end to end; removed.)
   if (!one_vs_all && dense_scorer_bwd && B * dm.E > T->capS) {
     COPER_HIP_TRY(h, hipStreamSynchronize(s));
     if ((rc = talloc(h, &T->Sd, (size_t)(B * dm.E)))) return rc;
@@ -1542,6 +1478,7 @@ static int train_step_impl(coper_handle* h, const int64_t* e1, const int64_t* re
   const float* cw = nh ? T->chain[0].v[nh] : T->c;   // [B, rc_w]
   const float* cbv = nh ? T->chain[1].v[nh] : T->c;  // [B, rc_b]
   const float* Wmat = gen ? P_(wlast.c_str()) : P_("fc_weights");   // row-major [rc_w * F, d] (generated) or [F, d] (static)
+  bool p3_packed = false;        // the projection's second view (rows f) was packed with its first
   const int64_t nBd = B * d;
   float* Tf = T->A;                 // T[rho][b][k]
   float* dTf = T->A + (size_t)rc_w * nBd;
@@ -1558,7 +1495,13 @@ static int train_step_impl(coper_handle* h, const int64_t* e1, const int64_t* re
       // are packed into fragment planes (P as rows (rho, k) with f contracted), one GEMM of [B] x [r*d] outputs
       const int64_t nrk = (int64_t)rc_w * d;
       if ((rc = tg_pack(h, xin, tg_idx(F), tg_idx(1), B, F, tg_rows_pad(B), false, T->pX, s, T->tg_scratch, nullptr, x_slots))) return rc;
-      if ((rc = tg_pack(h, Wmat, tg_idx2(d, F * (int64_t)d, 1), tg_idx(d), nrk, F, tg_rows_pad(nrk), true, T->pP1, s, T->tg_scratch, nullptr, w_slots))) return rc;
+      // the projection is an operand of two products, contracted over f here and over (rho, k) in dx: a training step packs BOTH
+      // views from one read (tg_pack_both: 118 MB read once instead of twice, one launch instead of two)
+      if (apply && (d & 3) == 0 && (((uintptr_t)Wmat) & 15) == 0) {
+        if ((rc = tg_pack_both(h, Wmat, tg_idx(d), tg_idx2(d, F * (int64_t)d, 1), F, nrk, T->pP3, T->pP1, s, T->tg_scratch, w_slots))) return rc;
+        p3_packed = true;
+      } else if ((rc = tg_pack(h, Wmat, tg_idx2(d, F * (int64_t)d, 1), tg_idx(d), nrk, F, tg_rows_pad(nrk), true, T->pP1, s, T->tg_scratch, nullptr, w_slots)))
+        return rc;
       if ((rc = tg_gemm_split(h, T, s, T->pX, B, T->pP1, nrk, F, Tf, tg_idx(d), tg_idx2(d, nBd, 1)))) return rc;
     } else {
       // z0[B,d] = x[B,F] W[F,d]: 8 output tiles, K = F cut into slices
@@ -1592,9 +1535,6 @@ static int train_step_impl(coper_handle* h, const int64_t* e1, const int64_t* re
       if (T->exp_cache[i].first == T->Sd) T->exp_cache[i].first = nullptr;
     hipLaunchKernelGGL(k_tr_dense_loss, dim3(2048), dim3(256), 0, s, T->Sd, P_("pred_bias"), labels, dm.E, B * dm.E,
                        tc.label_smoothing_epsilon, (float)(1.0 / (double)dm.E), inv_BL, red);
-  } else if (fused_dh) {
-    hipLaunchKernelGGL(k_tr_score_loss_dh, dim3((unsigned)B), dim3(256), 0, s, T->hv, ent, P_("pred_bias"), lookup, labels, dm.E, d, L,
-                       tc.label_smoothing_epsilon, (float)(1.0 / (double)dm.E), inv_BL, T->ds, T->dh, red);
   } else {
     hipLaunchKernelGGL(k_tr_score_loss, dim3((unsigned)B), dim3(256), sizeof(float) * d, s, T->hv, ent, P_("pred_bias"), lookup, labels,
                        dm.E, d, L, tc.label_smoothing_epsilon, (float)(1.0 / (double)dm.E), inv_BL, T->ds, red);
@@ -1628,9 +1568,7 @@ static int train_step_impl(coper_handle* h, const int64_t* e1, const int64_t* re
                         G_("ent_emb"), tg_idx(d), tg_idx(1))))
       return rc;
     // dh by the gather (a [d,B] = [d,|E|] x [|E|,B] GEMM has 8 output tiles and a long K: slower than the gather)
-    if (fused_dh) {
-      // (dh was written by the scorer's forward launch: k_tr_score_loss_dh)
-    } else if ((d & 3) == 0 && d >= 16 && d <= 1024 && (((uintptr_t)ent | (uintptr_t)T->dh) & 15) == 0)
+    if ((d & 3) == 0 && d >= 16 && d <= 1024 && (((uintptr_t)ent | (uintptr_t)T->dh) & 15) == 0)
       hipLaunchKernelGGL(k_tr_dh_gather4, dim3((unsigned)B), dim3(256), sizeof(float4) * (size_t)(256 / (d >> 2)) * (d >> 2), s, ent, lookup,
                          T->ds, dm.E, d, L, T->dh);
     else
@@ -1669,7 +1607,7 @@ static int train_step_impl(coper_handle* h, const int64_t* e1, const int64_t* re
     if ((rc = tg_gemm_nt(h, T->pXt, F, T->pTn, nrk, B, dW, tg_idx(d), tg_idx2(d, F * (int64_t)d, 1), s, 1, nullptr, ssq))) return rc;
     sumsq_done = wlast;   // the GEMM added |dP|^2 to the global-norm accumulator as it stored
     if ((rc = tg_pack(h, dTf, tg_idx(d), tg_idx2(d, nBd, 1), B, nrk, tg_rows_pad(B), false, T->pTb, s, T->tg_scratch, T->pTn.exp))) return rc;
-    if ((rc = tg_pack(h, Wmat, tg_idx(d), tg_idx2(d, F * (int64_t)d, 1), F, nrk, tg_rows_pad(F), false, T->pP3, s, T->tg_scratch, T->pP1.exp))) return rc;
+    if (!p3_packed && (rc = tg_pack(h, Wmat, tg_idx(d), tg_idx2(d, F * (int64_t)d, 1), F, nrk, tg_rows_pad(F), false, T->pP3, s, T->tg_scratch, T->pP1.exp))) return rc;
     if ((rc = tg_gemm_split(h, T, s, T->pTb, B, T->pP3, F, nrk, dxin, tg_idx(F), tg_idx(1)))) return rc;
     hipLaunchKernelGGL(k_tr_dc_from_partials, dim3((unsigned)((B * rc_w + 3) / 4)), dim3(256), 0, s, T->dz, Tf, B, rc_w, d, dcw);
   } else {

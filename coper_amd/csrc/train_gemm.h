@@ -43,6 +43,10 @@ inline size_t tg_plane_elems(int64_t rows, int64_t K) { return (size_t)(tg_rows_
 constexpr int TG_MAX_SLOTS = 1024;
 int tg_pack(coper_handle* h, const float* src, TgIdx ri, TgIdx ki, int64_t R, int64_t K, int64_t R_pad, bool rows_fast, TgPlanes out,
             hipStream_t s, unsigned* scratch, const int32_t* exp_from = nullptr, const unsigned* max_slots = nullptr);
+// Both views of one tensor from ONE read: view A = rows i (ri) contracted over k (ki) into `a`; view B = rows k contracted over i into
+// `b` (the operand of the product that contracts the other index).  ki must be 16-byte loadable (unit stride, multiples of four).
+int tg_pack_both(coper_handle* h, const float* src, TgIdx ri, TgIdx ki, int64_t R, int64_t K, TgPlanes a, TgPlanes b, hipStream_t s,
+                 unsigned* scratch, const unsigned* max_slots = nullptr);
 // C[off(ci, i) + off(cj, j)] = sum_k X(i, k) Y(j, k), i < M, j < N
 // nsplit > 1: K is cut into nsplit slices whose partial sums go to `part` ([nsplit][M][N] floats) and are summed in slice order
 // sumsq: when not null, the sum of the squares of the stored C is added by the storing kernel to the TG_SUMSQ_SLOTS device

@@ -181,6 +181,107 @@ static bool tg_vec_ok(const float* src, const TgIdx& fast, const TgIdx& slow, in
   return true;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Both views of ONE tensor from one read (round 6: the generated dense layer's projection P is an operand of two of its three
+// GEMMs, contracted over a different index in each -- 118 MB read by two pack launches, 64 + 60 us of a 1.2 ms step):
+//   view A: rows i (ri), contraction k (ki)  -> planes A [ceil(R / 32)][KST_A][64]        (what k_pack_frag<2, 32> writes)
+//   view B: rows k,      contraction i       -> planes B [ceil(K / 32) padded][KST_B][64]  (the transposed operand)
+// A workgroup loads a 32 x 128 tile (32 rows i, 128 consecutive k, four per thread as one 16-byte load) into LDS and emits the
+// eight (row block, k-step) fragment blocks of view A and the eight (4 row blocks of k) x (2 k-steps of i) blocks of view B.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack_frag_both(const float* __restrict__ src, TgIdx ri, TgIdx ki, int64_t R, int64_t K,
+                                                        int KS16_A, int KST_A, uint4* __restrict__ ahi, uint4* __restrict__ alo,
+                                                        int KS16_B, int KST_B, uint4* __restrict__ bhi, uint4* __restrict__ blo,
+                                                        const int32_t* __restrict__ exp_dev, int32_t* __restrict__ exp_a,
+                                                        int32_t* __restrict__ exp_b, const unsigned* __restrict__ max_slots) {
+  constexpr int RT = 32, KT = 128;
+  __shared__ float tile[RT][KT + 1];
+  const int64_t row0 = (int64_t)blockIdx.y * RT, k0 = (int64_t)blockIdx.x * KT;
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int e = t + 256 * i, row = e / (KT / 4), kk = (e % (KT / 4)) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row0 + row < R && k0 + kk < K) v = *(const float4*)(src + tg_off(ri, row0 + row) + tg_off(ki, k0 + kk));   // (K % 4 == 0: host)
+    tile[row][kk] = v.x; tile[row][kk + 1] = v.y; tile[row][kk + 2] = v.z; tile[row][kk + 3] = v.w;
+  }
+  __shared__ unsigned s_mx[4];
+  if (max_slots) {
+    unsigned mx = 0u;
+    for (int i = t; i < TG_MAX_SLOTS; i += 256) { const unsigned v = max_slots[i]; mx = v > mx ? v : mx; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned u = __shfl_xor(mx, o, 64); mx = u > mx ? u : mx; }
+    if ((t & 63) == 0) s_mx[t >> 6] = mx;
+  }
+  __syncthreads();
+  int pe;
+  if (max_slots) {
+    const unsigned a = s_mx[0] > s_mx[1] ? s_mx[0] : s_mx[1], b = s_mx[2] > s_mx[3] ? s_mx[2] : s_mx[3];
+    pe = x3_exp_for_bits(a > b ? a : b);
+  } else {
+    pe = *exp_dev;
+  }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && t == 0) { *exp_a = pe; *exp_b = pe; }
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int f = t + 256 * p, blk = f >> 6, l = f & 63;
+    // view A: row block blockIdx.y, k-steps 8 blockIdx.x + blk
+    {
+      const int64_t ks = (int64_t)blockIdx.x * (KT / 16) + blk;
+      if (ks < KS16_A) {
+        const int row = l & 31, kb = 16 * blk + 8 * (l >> 5);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = tile[row][kb + j];
+        uint4 h4, l4;
+        tg_split8(v, pe, h4, l4);
+        const int64_t o = ((int64_t)blockIdx.y * KST_A + ks) * 64 + l;
+        ahi[o] = h4;
+        alo[o] = l4;
+      }
+    }
+    // view B: rows are the k of this tile (four blocks of 32), the contraction runs over the tile's 32 rows i (two k-steps)
+    {
+      const int rb = blk >> 1, ksl = blk & 1;
+      const int64_t ks = (int64_t)blockIdx.y * (RT / 16) + ksl;
+      if (ks < KS16_B) {
+        const int col = 32 * rb + (l & 31), ib = 16 * ksl + 8 * (l >> 5);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = tile[ib + j][col];
+        uint4 h4, l4;
+        tg_split8(v, pe, h4, l4);
+        const int64_t o = (((int64_t)blockIdx.x * (KT / 32) + rb) * KST_B + ks) * 64 + l;
+        bhi[o] = h4;
+        blo[o] = l4;
+      }
+    }
+  }
+}
+
+// view A = (ri rows, ki contraction) into `a`, view B = the transposed operand into `b` (rows K padded to TG_ROW_PAD by the caller's
+// allocation: tg_plane_elems).  The exponent: max_slots, or one reduction pass (scratch); both plane sets get it.
+int tg_pack_both(coper_handle* h, const float* src, TgIdx ri, TgIdx ki, int64_t R, int64_t K, TgPlanes a, TgPlanes b, hipStream_t s,
+                 unsigned* scratch, const unsigned* max_slots) {
+  if (!a.exp || !b.exp || !scratch) return fail(h, COPER_ESTATE, "tg_pack_both: plane set without an exponent word");
+  if (!tg_vec_ok(src, ki, ri, K)) return fail(h, COPER_ESTATE, "tg_pack_both: the contraction index of view A must be 16-byte loadable");
+  if (!max_slots) {
+    int64_t nb = (R * K + 256 * 32 - 1) / (256 * 32);
+    if (nb > 512) nb = 512;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(k_tg_absmax_exp, dim3((unsigned)nb), dim3(256), 0, s, src, R * K, scratch, a.exp);
+  }
+  const int KS16_A = (int)((K + 15) / 16), KST_A = (int)tg_ks_stride(K), KS16_B = (int)((R + 15) / 16), KST_B = (int)tg_ks_stride(R);
+  // rows of view B beyond K (up to its TG_ROW_PAD padding) and k-steps beyond KS16 are never read by the GEMM's stores, but its
+  // loads touch whole row blocks: the tile grid covers them (bounds-checked loads write zeros)
+  dim3 grid((unsigned)(tg_rows_pad(K) / 128), (unsigned)(tg_rows_pad(R) / 32));
+  hipLaunchKernelGGL(k_pack_frag_both, grid, dim3(256), 0, s, src, ri, ki, R, K, KS16_A, KST_A, a.hi, a.lo, KS16_B, KST_B, b.hi, b.lo, a.exp,
+                     a.exp, b.exp, max_slots);
+  COPER_HIP_TRY(h, hipGetLastError());
+  return COPER_OK;
+}
+
+
 int tg_pack(coper_handle* h, const float* src, TgIdx ri, TgIdx ki, int64_t R, int64_t K, int64_t R_pad, bool rows_fast, TgPlanes out,
             hipStream_t s, unsigned* scratch, const int32_t* exp_from, const unsigned* max_slots) {
   const int KS16 = (int)((K + 15) / 16), KST = (int)tg_ks_stride(K);
