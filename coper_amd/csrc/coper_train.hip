@@ -1025,9 +1025,7 @@ __global__ __launch_bounds__(256) void k_tr_amsgrad(TrainTensors tt, const doubl
   if (!rc && (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)vh) & 15) == 0) {
     const int64_t n4 = n >> 2;
     unsigned pmx = 0u;       // the largest |p_new| this thread wrote (bit pattern): the next step's packs take their power of two from it
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-      const float4 g4 = ((const float4*)g)[i];
-      float4 m4 = ((const float4*)m)[i], v4 = ((const float4*)v)[i], h4 = ((const float4*)vh)[i], p4 = ((const float4*)p)[i];
+    auto upd4 = [&](const float4& g4, float4& m4, float4& v4, float4& h4, float4& p4) {
       float* gm = (float*)&m4; float* gv = (float*)&v4; float* gh = (float*)&h4; float* gp = (float*)&p4; const float* gg = (const float*)&g4;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -1040,6 +1038,23 @@ __global__ __launch_bounds__(256) void k_tr_amsgrad(TrainTensors tt, const doubl
         const unsigned pb = __float_as_uint(gp[j]) & 0x7fffffffu;
         pmx = pb > pmx ? pb : pmx;
       }
+    };
+    const int64_t st = (int64_t)gridDim.x * 256;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    // two elements-of-four per thread and trip: ten 16-byte loads in flight (round 6: five reached 4.9 TB/s on the 1.17 GB of a step)
+    for (; i + st < n4; i += 2 * st) {
+      const float4 ga = ((const float4*)g)[i], gb = ((const float4*)g)[i + st];
+      float4 ma = ((const float4*)m)[i], va = ((const float4*)v)[i], ha = ((const float4*)vh)[i], pa = ((const float4*)p)[i];
+      float4 mb = ((const float4*)m)[i + st], vb = ((const float4*)v)[i + st], hb = ((const float4*)vh)[i + st], pb4 = ((const float4*)p)[i + st];
+      upd4(ga, ma, va, ha, pa);
+      upd4(gb, mb, vb, hb, pb4);
+      ((float4*)m)[i] = ma; ((float4*)v)[i] = va; ((float4*)vh)[i] = ha; ((float4*)p)[i] = pa;
+      ((float4*)m)[i + st] = mb; ((float4*)v)[i + st] = vb; ((float4*)vh)[i + st] = hb; ((float4*)p)[i + st] = pb4;
+    }
+    for (; i < n4; i += st) {
+      const float4 g4 = ((const float4*)g)[i];
+      float4 m4 = ((const float4*)m)[i], v4 = ((const float4*)v)[i], h4 = ((const float4*)vh)[i], p4 = ((const float4*)p)[i];
+      upd4(g4, m4, v4, h4, p4);
       ((float4*)m)[i] = m4; ((float4*)v)[i] = v4; ((float4*)vh)[i] = h4; ((float4*)p)[i] = p4;
     }
     for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {

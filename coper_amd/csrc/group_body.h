@@ -85,21 +85,10 @@ __device__ __forceinline__ void rel_scan_tiles_body_t(const int32_t* count, int6
     if (c <= 32) continue;
     int nb = (c + 127) / 128, bsz = c / nb, rem = c % nb;
     int off = offset[rid];
-    // (round 6) the tiles of ONE relation sit next to each other in their size class (one reservation per class instead of one per
-    // tile): the fused encoder deals consecutive list entries to one XCD when a weight set is read by several tiles, so that its L2
-    // fetches the set once (k_dense_fused_bf16x3: the XCD-chunked tile index)
-    const int k_hi = (bsz + 1 + 15) >> 4, k_lo = (bsz + 15) >> 4;
-    int base_hi = 0, base_lo = 0;
-    if (rem && k_hi == k_lo) {
-      base_hi = cls_base[k_hi] + atomicAdd(&cls_cursor[k_hi], nb);
-      base_lo = base_hi + rem;
-    } else {
-      if (rem) base_hi = cls_base[k_hi] + atomicAdd(&cls_cursor[k_hi], rem);
-      base_lo = cls_base[k_lo] + atomicAdd(&cls_cursor[k_lo], nb - rem);
-    }
     for (int j = 0; j < nb; ++j) {
       int sz = bsz + (j < rem ? 1 : 0);
-      int slot = j < rem ? base_hi + j : base_lo + (j - rem);
+      int k = (sz + 15) >> 4;
+      int slot = cls_base[k] + atomicAdd(&cls_cursor[k], 1);
       int32_t* t = tiles_big + 4 * (int64_t)slot;
       t[0] = (int32_t)rid;
       t[1] = off + j * bsz + (j < rem ? j : rem);

@@ -602,8 +602,7 @@ __global__ __launch_bounds__(512) void k_dense_fused_bf16x3(const uint4* __restr
                                                             int d_pad16, float* __restrict__ z_part, FusedFin Fn,
                                                             int n_special, const int32_t* __restrict__ stage_src, int64_t stage_n,
                                                             int64_t* __restrict__ stage_dst, int64_t ks32s, GroupJob J, int n_group,
-                                                            const int32_t* __restrict__ post_src, int64_t post_n, int32_t* __restrict__ post_dst,
-                                                            int xcd_chunks) {
+                                                            const int32_t* __restrict__ post_src, int64_t post_n, int32_t* __restrict__ post_dst) {
   extern __shared__ uint4 fused_lds[];
   // Staging role (coper_stage_ids_next): workgroups in front of the tile lists bring the NEXT pass's int32 batch in from pinned
   // host memory (PCIe reads) and widen it to the int64 arrays the ABI takes, while the tiles stream their weights.  A pass has
@@ -691,18 +690,6 @@ __global__ __launch_bounds__(512) void k_dense_fused_bf16x3(const uint4* __restr
   const int32_t* tl;
   {
     const int nbig = n_tiles[1];
-    if (xcd_chunks) {
-      // Weight sets read by several tiles (K slices: WN18RR's three tiles per relation, the 10M config): consecutive list entries --
-      // the tiles of one relation (group_body.h) -- go to ONE XCD, whose L2 then fetches the set's K slice once: workgroups are
-      // handed to the XCDs round-robin in grid order, so entry c CH + k is taken by the workgroup 8 k + c of its K slice's row
-      // (CH = ceil(T / 8); the grid row is padded to a multiple of eight).  Round 5 dealt entry t to XCD t mod 8: the three tiles
-      // of a relation on three XCDs, 155.9 MB fetched per launch for 45.5 MB of weights at WN18RR shapes.
-      const int T = nbig + n_tiles[0], CH = (T + 7) >> 3;
-      const int c = tile & 7, k = tile >> 3;
-      if (k >= CH) return;
-      tile = c * CH + k;
-      if (tile >= T) return;
-    }
     if (tile < nbig) {
       tl = tiles + 4 * (cap_small + tile);
     } else {
@@ -822,10 +809,11 @@ static void dense_fused_launch(coper_handle* h, const int64_t* e1, const int64_t
     attr_done |= bit;
   }
   // a pending staging job (coper_stage_ids_next) rides in this launch: FUSED_STAGE_WGS more workgroups
-  // (XCD-chunked tile index: launches whose weight sets are read by several tiles -- several K slices of generated weights)
-  const int xcd_chunks = (nslices > 1 && dm.gen_fc) ? 1 : 0;
-  int n_tile_blocks = (int)(B / 128 + (cap_small - 1 < B ? cap_small - 1 : B) + 1);     // (an upper bound of the two tile lists together: see the kernel)
-  if (xcd_chunks) n_tile_blocks = (n_tile_blocks + 7) / 8 * 8;      // (the chunked index runs over 8 ceil(T / 8) entries)
+  // (Round 6 measured the tiles of one relation dealt to ONE XCD -- an XCD-chunked tile index for launches with several K slices:
+  //  the encoder's HBM traffic at WN18RR shapes fell from 156 to 94 - 100 MB and the pass got 9 - 12 us slower, profiles/r06_wn_xcd.txt:
+  //  the launch is one round of workgroups bound by its prologue and the matrix pipe, and the deal below ends every K slice's row
+  //  on its smallest tiles.  Removed.)
+  const int n_tile_blocks = (int)(B / 128 + (cap_small - 1 < B ? cap_small - 1 : B) + 1);     // (an upper bound of the two tile lists together: see the kernel)
   // (a pass being captured into a hipGraph leaves a pending staging job to the next eager call, as coper_post_i32_next does: a
   // replay would repeat the PCIe read with the pointers recorded at capture time and overwrite whatever staging buffer they name)
   coper_handle::PassPipeline& pp = h->pipe;
@@ -872,7 +860,7 @@ static void dense_fused_launch(coper_handle* h, const int64_t* e1, const int64_t
   hipLaunchKernelGGL((k_dense_fused_bf16x3<NFB, WNT>), dim3((unsigned)(n_tile_blocks + n_group + n_stage), (unsigned)nslices, (unsigned)zgroups), dim3(512),
                      lds, s, (const uint4*)h->Wf16_hi, (const uint4*)h->Wf16_lo, A, h->tiles, h->n_tiles, cap_small, dm.nfb,
                      dm.F_pad / 32, nslices, h->ws_queries, dm.d_pad16, h->z_part, Fn, n_group + n_stage, pp.stage.src,
-                     stage_now ? pp.stage.n : 0, pp.stage.dst, w16_ks_stride(dm), J, n_group, pp.post.src, post_now ? pp.post.n : 0, pp.post.dst, xcd_chunks);
+                     stage_now ? pp.stage.n : 0, pp.stage.dst, w16_ks_stride(dm), J, n_group, pp.post.src, post_now ? pp.post.n : 0, pp.post.dst);
   if (stage_now) pp.take_stage();
   if (post_now) pp.take_post();
 }
