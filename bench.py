@@ -308,7 +308,7 @@ def run_scale_blocks(ctx, args):
     #  relations only -- coper_config.rel_mod_*: 12.8 GB / world)
     enc = ConvE(md, device=ctx.device, shard=shard, score_mode="bf16x3", role="encode", rel_mod=(ctx.world, ctx.rank) if ctx.world > 1 else None)
     enc.load_parameters(params, global_rows=False)
-    ranker = EntityShardedRanker(model, encoder=enc, overlap=not args.no_scale_overlap)       # (before prepare: the ranks agree on the entity planes' power of two first)
+    ranker = EntityShardedRanker(model, encoder=enc, overlap=False if args.no_scale_overlap else None)       # (None: from two ranks on; before prepare: the ranks agree on the entity planes' power of two first)
     t0 = time.perf_counter()
     model.prepare()
     enc.prepare()
@@ -413,7 +413,7 @@ def run_scale_blocks(ctx, args):
         mg.load_parameters(params_g, global_rows=False)
         eg = ConvE(md, device=ctx.device, shard=shard_g, score_mode="bf16x3", role="encode", rel_mod=(G, 0))
         eg.load_parameters(params_g, global_rows=False)
-        rg = EntityShardedRanker(mg, encoder=eg, emulate_world=(G, 0), overlap=not args.no_scale_overlap)
+        rg = EntityShardedRanker(mg, encoder=eg, emulate_world=(G, 0), overlap=False if args.no_scale_overlap else None)
         mg.prepare()
         eg.prepare()
         mg.reserve(Q, nnz_max)
@@ -784,6 +784,7 @@ def main():
         model.post_flush()
         torch.cuda.synchronize(device)
         assert np.array_equal(out_host.numpy(), ranks_np)
+        assert model.stale_passes() == 0     # (the guard of coper_group_next: no timed pass ran on a sorting its ids had outlived)
     assert np.array_equal(res[0].cpu().numpy(), ranks_np)
     kern = {}
     for k in KERNELS:

@@ -21,8 +21,6 @@ from typing import Callable, List, Optional, Sequence
 import numpy as np
 import torch
 
-from . import _lib
-
 __all__ = ["RankStream"]
 
 KEYS = ("e1", "rel", "e2", "filt_indptr", "filt_idx")
@@ -57,7 +55,8 @@ class RankStream(object):
         host = pin.numpy()
         for a, o in zip(arrs, offs):
             host[o:o + a.size] = a
-        return dict(pin=pin[:int(offs[-1])], offs=offs, sizes=sizes, B=B, nnz=nnz)
+        # (and pinned memory for the ranks of this batch: allocated once per packed batch, not per run)
+        return dict(pin=pin[:int(offs[-1])], offs=offs, sizes=sizes, B=B, nnz=nnz, host=torch.empty(max(1, B), dtype=torch.int32).pin_memory())
 
     def _views(self, c: int, pk: dict):
         st = self.stages[c]
@@ -69,7 +68,7 @@ class RankStream(object):
         disturb the stream)."""
         m = self.model
         packed = [b if "pin" in b else self.pack(b) for b in batches]
-        hosts = [torch.empty(max(1, pk["B"]), dtype=torch.int32).pin_memory() for pk in packed]
+        hosts = [pk["host"] for pk in packed]
         live = [n for n, pk in enumerate(packed) if pk["B"] > 0]
         first = True
         for j, n in enumerate(live):
@@ -94,8 +93,8 @@ class RankStream(object):
         for n, pk in enumerate(packed):
             r = hosts[n][:pk["B"]].numpy()
             if pk["B"] and int(r.min()) < 1:                                         # the guard fired: rank this batch again, plainly
-                if int(r.max()) != _lib.RANK_STALE and int(r.max()) >= 1:
-                    raise RuntimeError("RankStream: pass %d returned ranks below 1 that are not COPER_RANK_STALE" % n)
+                if int(r.max()) >= 1:          # (a stale pass has EVERY rank at COPER_RANK_STALE + its counts: all negative)
+                    raise RuntimeError("RankStream: pass %d returned a mixture of ranks and values below 1" % n)
                 self.stale_passes += 1
                 host = pk["pin"].numpy()
                 arrs = [host[o:o + s].astype(np.int64) for o, s in zip(pk["offs"], pk["sizes"])]

@@ -10,6 +10,8 @@ grouping prepared ahead is consumed by pointer identity.  Two things are tested 
     graph replays / a growing workspace, with the staged ids rewritten at random points: every pass's ranks are those of an
     un-pipelined handle on the ids that are in the array at that moment -- or all COPER_RANK_STALE, and that only when the array
     really changed after its sorting was launched (no false alarms, no wrong ranks)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -401,7 +403,8 @@ def _run_sequences(md, p, Q, n_seq, n_ops, seed, train=False):
 def test_random_interleavings_of_the_pass_pipeline(workload, Q, seed):
     md = cdata.model_descriptors(workload, num_ent=2500)
     p = cdata.synthetic_params(md, 6)
-    n_stale = _run_sequences(md, p, Q, n_seq=230, n_ops=24, seed=seed)
+    # (COPER_PIPELINE_SEQS: a longer soak of the same test -- profiles/r06_pipeline_soak.txt ran 4 x 5,000 sequences)
+    n_stale = _run_sequences(md, p, Q, n_seq=int(os.environ.get("COPER_PIPELINE_SEQS", "230")), n_ops=24, seed=seed)
     assert n_stale > 0          # (the sequences do rewrite arrays behind their sorting: the guard was exercised, not just idle)
 
 

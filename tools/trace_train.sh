@@ -17,7 +17,8 @@ tot = 0
 for r in step:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     tot += e - s
-    print("%8.1f  %7.1f us  grid %-8s %s" % ((s - t0) / 1e3, (e - s) / 1e3, r.get("Grid_Size_X", "?"), r["Kernel_Name"].split("(")[0][-60:]))
+    name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+    print("%8.1f  %7.1f us  grid %-8s %s" % ((s - t0) / 1e3, (e - s) / 1e3, r.get("Grid_Size_X", "?"), name[-60:]))
 print("span %.1f us, kernels %.1f us" % ((int(step[-1]["End_Timestamp"]) - t0) / 1e3, tot / 1e3))
 PY
 tail -1 gpurun_out/trace_train.log
