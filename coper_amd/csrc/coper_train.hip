@@ -83,6 +83,7 @@ struct TrainState {
   // handle with no coper_set_param in between (the tensors are the caller's: include/coper_hip.h, coper_train_step)
   unsigned* xmax = nullptr;      // TG_MAX_SLOTS: max x as k_tr_bn1_fwd wrote it;  dtmax: max |dT| as k_tr_scale_rows wrote it (zeroed per step)
   unsigned* dtmax = nullptr;
+  unsigned* smax = nullptr;      // TG_MAX_SLOTS: max |S| as k_tr_build_S wrote it
   unsigned* wmax[2] = {nullptr, nullptr};
   int wmax_cur = 0;
   bool wmax_valid = false;
@@ -472,16 +473,49 @@ __global__ __launch_bounds__(256) void k_tr_dh_gather4(const float* __restrict__
 }
 
 // dense route of the scorer backward (small entity tables): S[b, lookup[b,l]] += ds[b,l], dbias[lookup] += ds;
-// then dE = S^T h and dh = S E are two library GEMMs instead of B*L*d float atomics
-__global__ __launch_bounds__(256) void k_tr_scatter_ds(const int32_t* __restrict__ lookup, const float* __restrict__ ds, int64_t E,
-                                                       int64_t L, int64_t total, float* __restrict__ S, float* __restrict__ dbias) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= total) return;
-  int64_t row = lookup[i];
-  if (row < 0 || row >= E) row = 0;
-  const float g = ds[i];
-  atomicAdd(&S[(i / L) * E + row], g);
-  atomicAdd(&dbias[row], g);
+// then dE = S^T h is a GEMM instead of B*L*d float atomics.
+// Round 6: S is built ROW BY ROW in LDS -- a workgroup per query zeroes a stretch of its row in LDS (<= TR_S_CHUNK columns),
+// adds its L sampled gradients with LDS atomics, writes the stretch out coalesced and keeps its largest magnitude for the pack of S
+// (tg_pack's max_slots) -- instead of B L float atomics into a zero-filled 30 MB matrix, a pass over it for its maximum and a
+// zeroing launch share: k_tr_scatter_ds 54 us + k_tg_absmax_exp 18 + the zero list's 30 MB at FB15k-237 shapes.  dbias = the column
+// sums of S (k_tr_col_sums_add).  Duplicate ids of a row add in the order the LDS serves them, as the global atomics did.
+constexpr int TR_S_CHUNK = 32768;      // columns per LDS stretch (128 KB)
+__global__ __launch_bounds__(256) void k_tr_build_S(const int32_t* __restrict__ lookup, const float* __restrict__ ds, int64_t E, int64_t L,
+                                                    float* __restrict__ S, unsigned* __restrict__ max_slots) {
+  extern __shared__ float s_row[];
+  const int64_t b = blockIdx.x;
+  const int32_t* lk = lookup + b * L;
+  const float* g = ds + b * L;
+  float mx = 0.f;
+  for (int64_t c0 = 0; c0 < E; c0 += TR_S_CHUNK) {
+    const int n = (int)(E - c0 < TR_S_CHUNK ? E - c0 : TR_S_CHUNK);
+    for (int i = threadIdx.x; i < n; i += 256) s_row[i] = 0.f;
+    __syncthreads();
+    for (int64_t l = threadIdx.x; l < L; l += 256) {
+      int64_t row = lk[l];
+      if (row < 0 || row >= E) row = 0;
+      if (row >= c0 && row < c0 + n) atomicAdd(&s_row[row - c0], g[l]);
+    }
+    __syncthreads();
+    float* out = S + b * E + c0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+      const float v = s_row[i];
+      out[i] = v;
+      mx = fmaxf(mx, fabsf(v));
+    }
+    __syncthreads();
+  }
+  tr_block_max_to_slot(mx, max_slots);
+}
+
+// out[c] += sum over rows of S[row, c]: row stretches of 64 per workgroup row, one float atomic per (stretch, column)
+__global__ __launch_bounds__(256) void k_tr_col_sums_add(const float* __restrict__ S, int64_t rows, int64_t cols, float* __restrict__ out) {
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  const int64_t r0 = (int64_t)blockIdx.y * 64, r1 = r0 + 64 < rows ? r0 + 64 : rows;
+  float a = 0.f;
+  for (int64_t r = r0; r < r1; ++r) a += S[r * cols + c];
+  if (a != 0.f) atomicAdd(&out[c], a);
 }
 
 // 1-vs-all training (lookup == NULL, models.py:159-162,434-437): S holds the logits h E^T from a GEMM; add the bias,
@@ -1170,7 +1204,7 @@ void train_destroy(coper_handle* h) {
   (void)tracked_free(T->red);
   if (T->tg_exps) (void)tracked_free(T->tg_exps);
   if (T->tg_scratch) (void)tracked_free(T->tg_scratch);
-  for (unsigned* w : {T->wmax[0], T->wmax[1], T->xmax, T->dtmax})
+  for (unsigned* w : {T->wmax[0], T->wmax[1], T->xmax, T->dtmax, T->smax})
     if (w) (void)tracked_free(w);
   for (TgPlanes* pl : {&T->mmX, &T->mmY}) {
     if (pl->hi) (void)tracked_free(pl->hi);
@@ -1271,7 +1305,8 @@ COPER_API int coper_train_init(coper_handle* h, const coper_train_config* cfg) {
   if ((rc = talloc(h, &T->red, (size_t)(2 + 2 * mx * TR_COLSUM_SLICES + TG_SUMSQ_SLOTS)))) return rc;
   if ((rc = talloc(h, &T->tg_exps, (size_t)(8 + TR_EXP_CACHE))) || (rc = talloc(h, &T->tg_scratch, (size_t)2)) ||
       (rc = talloc(h, &T->wmax[0], (size_t)TG_MAX_SLOTS)) || (rc = talloc(h, &T->wmax[1], (size_t)TG_MAX_SLOTS)) ||
-      (rc = talloc(h, &T->xmax, (size_t)TG_MAX_SLOTS)) || (rc = talloc(h, &T->dtmax, (size_t)TG_MAX_SLOTS)))
+      (rc = talloc(h, &T->xmax, (size_t)TG_MAX_SLOTS)) || (rc = talloc(h, &T->dtmax, (size_t)TG_MAX_SLOTS)) ||
+      (rc = talloc(h, &T->smax, (size_t)TG_MAX_SLOTS)))
     return rc;
   COPER_HIP_TRY(h, hipMemset(T->tg_exps, 0, (8 + TR_EXP_CACHE) * sizeof(int32_t)));
   COPER_HIP_TRY(h, hipMemset(T->wmax[0], 0, TG_MAX_SLOTS * sizeof(unsigned)));
@@ -1411,10 +1446,11 @@ static int train_step_impl(coper_handle* h, const int64_t* e1, const int64_t* re
     if (lk) add(G_("fc_bias"), sizeof(float) * T->find("fc_bias")->n);
     else if (gen) add(G_(blast.c_str()), sizeof(float) * rc_b * d);
     else add(G_("fc_bias"), sizeof(float) * d);
-    if (!one_vs_all && dense_scorer_bwd) add(T->Sd, sizeof(float) * B * dm.E);
+    // (the dense S of the sampled scorer's backward is written whole by k_tr_build_S: nothing to zero)
     if (apply) add(T->wmax[T->wmax_cur ^ 1], sizeof(unsigned) * TG_MAX_SLOTS);      // what this step's optimizer pass fills for the next step
     add(T->xmax, sizeof(unsigned) * TG_MAX_SLOTS);
     add(T->dtmax, sizeof(unsigned) * TG_MAX_SLOTS);
+    add(T->smax, sizeof(unsigned) * TG_MAX_SLOTS);
     hipLaunchKernelGGL(k_tr_zero_list, dim3(256, (unsigned)zl.n), dim3(256), 0, s, zl);
   }
   T->exp_cache.clear();
@@ -1576,11 +1612,18 @@ static int train_step_impl(coper_handle* h, const int64_t* e1, const int64_t* re
                         T->dh, tg_idx(d), tg_idx(1))))
       return rc;
   } else if (dense_scorer_bwd) {
-    hipLaunchKernelGGL(k_tr_scatter_ds, dim3((unsigned)((B * L + 255) / 256)), dim3(256), 0, s, lookup, T->ds, dm.E, L, B * L, T->Sd,
-                       G_("pred_bias"));
+    {
+      const size_t lds_s = sizeof(float) * (size_t)(dm.E < TR_S_CHUNK ? dm.E : TR_S_CHUNK);
+      // (the kernel also holds 16 bytes of static LDS: asking for the whole 160 KB as dynamic is refused, and so is the launch after it)
+      if (lds_s > 64 * 1024)
+        COPER_HIP_TRY(h, hipFuncSetAttribute((const void*)k_tr_build_S, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
+      hipLaunchKernelGGL(k_tr_build_S, dim3((unsigned)B), dim3(256), lds_s, s, lookup, T->ds, dm.E, L, T->Sd, T->smax);
+      hipLaunchKernelGGL(k_tr_col_sums_add, dim3((unsigned)((dm.E + 255) / 256), (unsigned)((B + 63) / 64)), dim3(256), 0, s, T->Sd, B, dm.E,
+                         G_("pred_bias"));
+    }
     // dE[E,d] = S^T h  (overwrites the zeroed gradient; the e1-row contributions are added after it)
     if ((rc = tg_matmul(h, T, s, MmView{T->Sd, tg_idx(1), tg_idx(dm.E), true}, dm.E, MmView{T->hv, tg_idx(1), tg_idx(d), true}, d, B,
-                        G_("ent_emb"), tg_idx(d), tg_idx(1))))
+                        G_("ent_emb"), tg_idx(d), tg_idx(1), nullptr, T->smax)))
       return rc;
     // dh by the gather (a [d,B] = [d,|E|] x [|E|,B] GEMM has 8 output tiles and a long K: slower than the gather)
     if ((d & 3) == 0 && d >= 16 && d <= 1024 && (((uintptr_t)ent | (uintptr_t)T->dh) & 15) == 0)

@@ -955,7 +955,7 @@ int launch_copy_i32(coper_handle* h, const int32_t* src, int64_t n, int32_t* dst
 // buf[cap + 1][d + 1]: row 0 = the header { hdr0, hdr1, 0... }, row 1 + i = { ent_emb[loc[i]][0..d), pred_bias[loc[i]] }, zero beyond n
 __global__ __launch_bounds__(256) void k_pack_owned_rows(const float* __restrict__ ent, const float* __restrict__ bias, const int64_t* __restrict__ loc,
                                                          int64_t n, int64_t cap, int d, int64_t n_local, float hdr0, float hdr1,
-                                                         float* __restrict__ buf) {
+                                                         float* __restrict__ buf, int32_t* __restrict__ bad) {
   const int W = d + 1;
   const int64_t total = (cap + 1) * W;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -964,9 +964,14 @@ __global__ __launch_bounds__(256) void k_pack_owned_rows(const float* __restrict
     float v = 0.f;
     if (r == 0) v = c == 0 ? hdr0 : c == 1 ? hdr1 : 0.f;
     else if (r - 1 < n) {
-      int64_t row = loc[r - 1];
-      row = row < 0 ? 0 : row >= n_local ? n_local - 1 : row;
-      v = c < d ? ent[row * d + c] : bias[row];
+      // a row number outside the shard: a ZERO row (what coper_gather_entities hands out for an id the shard does not hold) and one
+      // more bad id for coper_check_ids -- round 5 clamped it to a real entity, silently
+      const int64_t row = loc[r - 1];
+      if (row < 0 || row >= n_local) {
+        if (c == 0 && bad) atomicAdd(bad, 1);
+      } else {
+        v = c < d ? ent[row * d + c] : bias[row];
+      }
     }
     buf[i] = v;
   }
@@ -991,7 +996,8 @@ int launch_pack_owned_rows(coper_handle* h, const float* ent, const float* bias,
   const int64_t total = (cap + 1) * (h->dm.d + 1);
   int64_t nb = (total + 255) / 256;
   if (nb > 8192) nb = 8192;
-  hipLaunchKernelGGL(k_pack_owned_rows, dim3((unsigned)nb), dim3(256), 0, s, ent, bias, loc, n, cap, h->dm.d, h->dm.n_local, hdr0, hdr1, buf);
+  hipLaunchKernelGGL(k_pack_owned_rows, dim3((unsigned)nb), dim3(256), 0, s, ent, bias, loc, n, cap, h->dm.d, h->dm.n_local, hdr0, hdr1, buf,
+                     h->rel_count ? h->rel_count + h->dm.R + 1 : nullptr);
   COPER_HIP_TRY(h, hipGetLastError());
   return COPER_OK;
 }

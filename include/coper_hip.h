@@ -352,7 +352,8 @@ COPER_API int coper_band_policy(coper_handle* h, float max_ratio, int64_t n_pair
  * (models.py:176, :437); each row lives on one shard.  coper_pack_owned_rows writes what THIS shard owns for the all-gather --
  * buf[cap + 1][d + 1] float: row 0 = the header { hdr0, hdr1, 0... } (the shard's largest |ent_emb| and the table-wide maximum in
  * force: how the ranks keep ONE power of two for their entity planes), row 1 + i = { ent_emb[local_rows[i]], pred_bias[local_rows[i]] }
- * from the registered parameter tensors (no prepared state needed), zeros up to cap -- and coper_unpack_rows hands the gathered rows
+ * from the registered parameter tensors (no prepared state needed; a row number outside [0, n_local) gives a zero row and is counted
+ * by coper_check_ids once the handle has a workspace), zeros up to cap -- and coper_unpack_rows hands the gathered rows
  * out: rows1[b] = gathered[take1[b]][0, d), rows2[b] = gathered[take2[b]][0, d), bias2[b] = gathered[take2[b]][d].  One launch each. */
 COPER_API int coper_pack_owned_rows(coper_handle* h, const int64_t* local_rows, int64_t n, int64_t cap, float hdr0, float hdr1, float* buf,
                                     void* stream);

@@ -671,6 +671,13 @@ def test_one_handle_per_role(mode):
     rows = both.gather_entities(q["e1"])
     assert torch.equal(enc.gather_entities(q["e1"]), rows) and torch.equal(sco.gather_entities(q["e1"]), rows)
     assert torch.equal(enc.encode(None, torch.as_tensor(q["rel"]).to("cuda:0"), e1_rows=rows), h0)
+    # step 1's pack on either handle (parameter tensors only); a row number outside the shard is a zero row, never a clamped entity
+    loc = torch.as_tensor([5, md["num_ent"] + 3, 17, -2], dtype=torch.int64, device="cuda:0")
+    buf = sco.pack_owned_rows(loc, 6, 1.5, 2.5)
+    assert torch.equal(buf, enc.pack_owned_rows(loc, 6, 1.5, 2.5))
+    assert buf[0, 0].item() == 1.5 and buf[0, 1].item() == 2.5
+    assert torch.equal(buf[1, :-1], p["ent_emb"][5]) and torch.equal(buf[3, :-1], p["ent_emb"][17]) and buf[1, -1] == p["pred_bias"][5]
+    assert not buf[2].any() and not buf[4].any() and not buf[5:].any()
     for bad in (lambda: enc.score_all(h0[:4]), lambda: enc.rank(h0, q["e2"], q["filt_indptr"], q["filt_idx"]),
                 lambda: enc.rank_pass(q["e1"], q["rel"], q["e2"], q["filt_indptr"], q["filt_idx"]),
                 lambda: sco.encode(q["e1"], q["rel"]), lambda: sco.rank_pass(q["e1"], q["rel"], q["e2"], q["filt_indptr"], q["filt_idx"]),

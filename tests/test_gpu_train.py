@@ -44,6 +44,12 @@ _CASES = {
                      context_rel_conv=None, context_rel_out=[]),
     "cpg_linear_c32": dict(num_ent=157, num_rel=4, ent_emb_size=80, rel_emb_size=4, emb_h=10, emb_w=8, conv_num_channels=32,
                            context_rel_conv=None, context_rel_out=[]),
+    # entity tables whose row of the dense scorer backward does not fit 64 KB of LDS, and not one LDS stretch either (k_tr_build_S:
+    # 20,011 entities = 78 KB in one stretch; 41,003 = two stretches of <= 32,768 columns -- WN18RR has 40,943)
+    "cpg_linear_e20k": dict(num_ent=20011, num_rel=6, ent_emb_size=40, rel_emb_size=8, emb_h=10, emb_w=4, conv_num_channels=8,
+                            context_rel_conv=None, context_rel_out=[]),
+    "plain_e41k": dict(num_ent=41003, num_rel=6, ent_emb_size=40, rel_emb_size=40, emb_h=10, emb_w=4, conv_num_channels=8,
+                       context_rel_conv=None, context_rel_out=None),
 }
 
 

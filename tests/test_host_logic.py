@@ -271,3 +271,44 @@ def test_pack_ids_i32_checks_range_and_row_order():
     for bad_ip in ([0, 3, 5], [1, 3, 6], [0, 7, 6], [0, 4, 3, 6]):
         assert pack(ix, np.asarray(bad_ip, np.int64))[0] == 1, bad_ip
     assert pack(np.zeros(0, np.int64), np.zeros(4, np.int64))[:2] == (0, 0)      # empty rows only
+
+
+def test_entity_sharded_plan_and_the_emulated_rank(oracle_chain):
+    """coper_amd.sharding (round 6): the host plan of a chunk -- owners, slots, the relation split, all in one buffer -- against a
+    plain restatement, ids outside the table refused; and `emulate_world` (bench.py's scale.projected: ONE rank's work of a G-rank
+    job, every all-gather a local copy) runs the whole exchange without a process group."""
+    import numpy as np
+    import torch
+    from coper_amd import data as cdata
+    from coper_amd.sharding import EntityShardedRanker, shard_bounds
+    from tests.oracle_scorer import OracleShardScorer
+    md = dict(cdata._COMMON, num_ent=203, num_rel=12, ent_emb_size=32, rel_emb_size=8, emb_h=4, emb_w=8, conv_num_channels=4,
+              context_rel_conv=None, context_rel_out=[])
+    p = cdata.synthetic_params(md, seed=11)
+    G, g = 4, 1
+    sc = OracleShardScorer(p, md, shard_bounds(md["num_ent"], G, g))
+    er = EntityShardedRanker(sc, emulate_world=(G, g))
+    assert er.world == G and er.rank_id == g and not er.overlap
+    q = cdata.synthetic_queries(md, 37, seed=3, mean_filter=2.0, max_filter=8)
+    pl = er.plan(q)
+    ids = np.concatenate([q["e1"], q["e2"]])
+    bounds = [shard_bounds(md["num_ent"], G, r) for r in range(G)]
+    owner = np.array([next(r for r, (lo, hi) in enumerate(bounds) if lo <= i < hi) for i in ids])
+    counts = np.bincount(owner, minlength=G)
+    assert pl.cap1 == counts.max() and pl.n_mine == counts[g]
+    assert np.array_equal(pl.mine_ids, ids[owner == g])                                   # stable: in batch order
+    take = np.concatenate([er._dev(pl, "take1").numpy(), er._dev(pl, "take2").numpy()])
+    seen = np.zeros(G, int)
+    for pos, o in enumerate(owner):                                                       # position p sits behind its owner's header row, in order
+        assert take[pos] == o * (pl.cap1 + 1) + 1 + seen[o]
+        seen[o] += 1
+    rel = np.asarray(q["rel"])
+    assert np.array_equal(er._dev(pl, "sel").numpy(), np.nonzero(rel % G == g)[0]) and pl.n_enc == int((rel % G == g).sum())
+    assert pl.cap2 == np.bincount(rel % G, minlength=G).max()
+    for key, bad in (("e1", -1), ("e2", md["num_ent"])):
+        qb = dict(q)
+        qb[key] = np.where(np.arange(len(q[key])) == 5, bad, q[key])
+        with pytest.raises(ValueError):
+            er.plan(qb)
+    out = list(er.rank_stream([q, cdata.synthetic_queries(md, 20, seed=4, mean_filter=2.0, max_filter=8)], k=3, window=2))
+    assert len(out) == 2 and out[0][0].shape == (37,) and out[1][2].shape == (20, 3)

@@ -1,50 +1,40 @@
-"""ONE rank's compute of an 8-rank pass of the 10M-entity config (bench.py's scale.projected), alone in a process so that a
-rocprofv3 --kernel-trace --stats run shows where its time goes:  rocprofv3 --kernel-trace --stats -d out -- python3 tools/rank_step_probe.py"""
-import os, sys, time
+"""ONE rank's work of an 8-rank evaluation of the 10M-entity config (bench.py's scale.projected), alone in a process so that a
+rocprofv3 --kernel-trace --stats run shows where its time goes:
+    rocprofv3 --kernel-trace --stats -d out -- python3 tools/rank_step_probe.py          (G=8 K=10 OVERLAP=1 in the environment)
+Round 6: the rank runs through EntityShardedRanker.rank_stream itself (emulate_world: plans rebuilt per chunk, every launch of the
+exchange, one handle per role, steps 1 - 2 of the next chunk on the side stream), the all-gathers replaced by local copies."""
+import itertools, os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from coper_amd import data as cdata
 from coper_amd.models import ConvE
-from coper_amd.sharding import shard_bounds
+from coper_amd.sharding import EntityShardedRanker, shard_bounds
 
-G = int(os.environ.get("G", "8")); K = int(os.environ.get("K", "10"))
+G = int(os.environ.get("G", "8")); K = int(os.environ.get("K", "10")); OVERLAP = os.environ.get("OVERLAP", "1") != "0"
+N = int(os.environ.get("CHUNKS", "12"))
 dev = torch.device("cuda:0")
 md = cdata.model_descriptors("synth10m_cpg")
-Q, d = 4096, int(md["ent_emb_size"])
-q = cdata.synthetic_queries(md, Q, seed=0)
+Q = 4096
+qs = [cdata.synthetic_queries(md, Q, seed=s) for s in range(4)]
 shard = shard_bounds(md["num_ent"], G, 0)
 params, _ = bench.device_params(md, 0, dev, shard)
-m = ConvE(md, device=dev, shard=shard, score_mode="bf16x3")
-m.load_parameters(params, global_rows=False); m.prepare(); m.reserve(Q, len(q["filt_idx"]))
-dq = {n: torch.as_tensor(v).to(dev) for n, v in q.items()}
-mine = np.nonzero(q["rel"] % G == 0)[0]
-sel = torch.as_tensor(mine, device=dev)
-rows1 = torch.randn((Q, d), device=dev) * 0.1; rows2 = torch.randn((Q, d), device=dev) * 0.1
-bias2 = torch.zeros(Q, device=dev); hfull = torch.randn((Q, d), device=dev).abs()
-def step(k=K):
-    ts = [time.perf_counter()]
-    def mark():
-        if os.environ.get("SYNC"):
-            torch.cuda.synchronize(); ts.append(time.perf_counter())
-    r1, r2, b2 = m.gather_entities(dq["e1"]), m.gather_entities(dq["e2"]), m.gather_bias(dq["e2"]); mark()
-    hloc = m.encode(q["e1"][mine], q["rel"][mine], e1_rows=rows1.index_select(0, sel).contiguous()); mark()
-    hfull.index_copy_(0, sel, hloc)
-    tx = m.score_rows(hfull, rows2, bias2); mark()
-    out = m.rank_counts(hfull, torch.stack([tx, tx]), dq["e2"], dq["filt_indptr"], dq["filt_idx"], filt_nnz=len(q["filt_idx"]), k=k); mark()
-    return ts
-for _ in range(3): step()
+ms = ConvE(md, device=dev, shard=shard, score_mode="bf16x3", role="score").load_parameters(params, global_rows=False)
+me = ConvE(md, device=dev, shard=shard, score_mode="bf16x3", role="encode", rel_mod=(G, 0)).load_parameters(params, global_rows=False)
+er = EntityShardedRanker(ms, encoder=me, emulate_world=(G, 0), overlap=OVERLAP)
+ms.prepare(); me.prepare()
+ms.reserve(Q, max(len(q["filt_idx"]) for q in qs)); me.reserve(Q, 0)
+chunks = []
+for q in qs:
+    dq = {n: torch.as_tensor(q[n]).to(dev) for n in ("e2", "filt_indptr", "filt_idx")}
+    chunks.append(dict(e1=q["e1"], rel=q["rel"], e2=q["e2"], e2_dev=dq["e2"], filt_indptr=dq["filt_indptr"], filt_idx=dq["filt_idx"]))
+list(er.rank_stream(chunks, k=K, window=4))
 torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(10): step()
-torch.cuda.synchronize(); print("rank step (k=%d): %.3f ms" % (K, (time.perf_counter() - t0) * 100))
-os.environ["SYNC"] = "1"
-acc = np.zeros(4)
-for _ in range(5):
-    ts = step(); acc += np.diff(ts)
-print("with a synchronize after each part: gathers %.3f  encode %.3f  targets %.3f  rank_counts %.3f ms" % tuple(acc / 5 * 1e3))
-del os.environ["SYNC"]
-for k in (0,):
-    for _ in range(2): step(k)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(10): step(k)
-    torch.cuda.synchronize(); print("rank step (k=%d): %.3f ms" % (k, (time.perf_counter() - t0) * 100))
+list(er.rank_stream(itertools.islice(itertools.cycle(chunks), N), k=K, window=4))
+torch.cuda.synchronize()
+print("one rank of %d, %d chunks of %d queries through rank_stream (overlap %s, top-%d): %.3f ms per chunk" % (G, N, Q, er.overlap, K, (time.perf_counter() - t0) / N * 1e3))
+# the host's share alone: the plans
+t0 = time.perf_counter()
+for c in itertools.islice(itertools.cycle(chunks), 40):
+    er.plan(c)
+print("host plan of a chunk: %.3f ms" % ((time.perf_counter() - t0) / 40 * 1e3))
