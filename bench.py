@@ -129,6 +129,7 @@ def parse_args():
                     help="self-launched ranks (--gpus N from a plain shell) are stopped after this many seconds")
     ap.add_argument("--no-scale", action="store_true", help="skip the 10M-entity blocks (scale, HBM-regime roofline)")
     ap.add_argument("--no-extras", action="store_true", help="main line only: no f32 comparison, PCIe-inclusive loop, 10M blocks")
+    ap.add_argument("--scale-side-communicator", action="store_true", help="scale block: the side stream's two collectives on a communicator of their own (EntityShardedRanker(side_communicator=True))")
     ap.add_argument("--no-scale-overlap", action="store_true", help="scale block: steps 1 - 2 of the next chunk on the count launch's own stream (A/B against the side stream)")
     ap.add_argument("--scale-steps", type=int, default=None, help="timed passes of the scale block (default min(steps, 10))")
     ap.add_argument("--per-rank-of", type=int, default=8,
@@ -308,7 +309,7 @@ def run_scale_blocks(ctx, args):
     #  relations only -- coper_config.rel_mod_*: 12.8 GB / world)
     enc = ConvE(md, device=ctx.device, shard=shard, score_mode="bf16x3", role="encode", rel_mod=(ctx.world, ctx.rank) if ctx.world > 1 else None)
     enc.load_parameters(params, global_rows=False)
-    ranker = EntityShardedRanker(model, encoder=enc, overlap=False if args.no_scale_overlap else None)       # (None: from two ranks on; before prepare: the ranks agree on the entity planes' power of two first)
+    ranker = EntityShardedRanker(model, encoder=enc, overlap=False if args.no_scale_overlap else None, side_communicator=args.scale_side_communicator)       # (None: from two ranks on; before prepare: the ranks agree on the entity planes' power of two first)
     t0 = time.perf_counter()
     model.prepare()
     enc.prepare()
@@ -392,7 +393,7 @@ def run_scale_blocks(ctx, args):
         if not blk["ranks_independent_of_world"]:
             blk["parity_violation"] = ("entity-sharded ranks at world=%d differ from the single-GPU ranks of the same KG: sha1 %s != %s, "
                                        "mean rank %.6f != %.6f" % (ctx.world, sha, exp["ranks_sha1"], blk["mean_rank"], exp["mean_rank"]))
-    blk["config"]["overlap"] = ("steps 1 - 2 of chunk n + 1 on a side stream / second communicator under chunk n's count launch" if ranker.overlap
+    blk["config"]["overlap"] = ("steps 1 - 2 of chunk n + 1 on a side stream under chunk n's count launch" if ranker.overlap
                                 else "one stream, program order")
     out["scale"] = blk
     model.close()

@@ -117,16 +117,15 @@ class EntityShardedRanker(object):
 
     `scorer` holds the rank's entity rows and runs step 3 (targets, fused score + count, top-k); `encoder` -- by default the
     same object -- runs the rank's share of step 2.  Given a SECOND handle for the encoder (coper_config.role: one handle per
-    role, no derived buffer held twice), `rank_stream` issues steps 1 - 2 of chunk n + 1 on a side stream, with their two
-    collectives on a communicator of their own, BEFORE chunk n's count launch: they run under its 5.5 ms instead of in front of
-    the next one.
+    role, no derived buffer held twice), `rank_stream` issues steps 1 - 2 of chunk n + 1 on a side stream BEFORE chunk n's
+    count launch: they run under its 5.5 ms instead of in front of the next one.
 
     `rank(chunk)` is one chunk, checked before it returns (two small D2H reads: the header row of step 1, the audit words of
     step 3).  `rank_stream(chunks)` is the evaluation loop: plans are made one chunk ahead while the device works, nothing is
     read back inside a chunk -- the header comparison and the audit words stay on the device and are read ONCE per window of
     chunks; a window whose check fails (a shard reloaded its rows; a band too narrow) is ranked again chunk by chunk."""
 
-    def __init__(self, scorer, group=None, split_encoder=True, encoder=None, emulate_world=None, overlap=None):
+    def __init__(self, scorer, group=None, split_encoder=True, encoder=None, emulate_world=None, overlap=None, side_communicator=False):
         self.scorer, self.group, self.split_encoder = scorer, group, split_encoder
         self.encoder = encoder if encoder is not None else scorer
         self.dist = dist.is_initialized()      # a process group of ONE rank still runs its collectives (RCCL on one GPU)
@@ -153,8 +152,14 @@ class EntityShardedRanker(object):
         two = self.cuda and self.encoder is not self.scorer
         self.overlap = bool(two and self.dist and self.world > 1) if overlap is None else bool(overlap and two)
         self.side = torch.cuda.Stream(device=self.device) if self.overlap else None
+        # The side stream's two collectives run on the SAME communicator by default: torch hands a communicator's collectives to one
+        # internal stream in issue order -- [side] gather rows (n + 1), gather h (n + 1), [main] gather records (n) -- the same order on
+        # every rank, and the first two have long finished when the count launch the third waits for ends.  side_communicator=True gives
+        # them a communicator of their own (dist.new_group): two communicators with kernels in flight at once is the textbook way to
+        # hang a node if their issue order ever differed between ranks; it does not here, but nothing in this build could run it on
+        # eight GPUs, so it is opt-in.
         self.side_group = group
-        if self.overlap and self.world > 1 and not self.emulated:
+        if side_communicator and self.overlap and self.world > 1 and not self.emulated:
             self.side_group = dist.new_group(ranks=dist.get_process_group_ranks(group) if group is not None else None)
         self._pins, self._pin_i = [None] * 4, 0
         # one power of two for the entity planes of every shard (the x3 mode's logits are then the same bits whatever the layout):

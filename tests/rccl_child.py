@@ -48,7 +48,7 @@ def main():
         want = [er.rank(c, k=10) for c in qs]
         ms = ConvE(md, device=dev, score_mode=mode, role="score").load_parameters(p).prepare()
         me = ConvE(md, device=dev, score_mode=mode, role="encode").load_parameters(p).prepare()
-        er2 = EntityShardedRanker(ms, encoder=me, overlap=True)      # (default: off with one rank)
+        er2 = EntityShardedRanker(ms, encoder=me, overlap=True, side_communicator=True)      # (default: off with one rank)
         assert er2.overlap and er2.side is not None
         for rep in range(2):
             got = list(er2.rank_stream(iter(qs), k=10, window=2))

@@ -77,7 +77,8 @@ def test_bench_scale_block_at_the_target_world_size(world):
     GPUs they get one each over RCCL.  1.25 M-row (2.5 M-row) shards, the `rel mod world` encoder split, k_band_exact<3> on shards,
     the 8-row (4-row) all-gather layouts -- and the ranks of every chunk must be the single-GPU ranks bit for bit (SHA-1)."""
     from bench import SCALE_EXPECTED
-    line, backend = _run_bench([], timeout=900, world=world)
+    # (world 4 also with the side stream's collectives on a communicator of their own: the opt-in form)
+    line, backend = _run_bench(["--scale-side-communicator"] if world == 4 else [], timeout=900, world=world)
     assert line["n_gpus"] == world and line["value"] > 0
     assert line["config"]["parallelism"] == "query-sharded x%d" % world
     sc = line["scale"]
