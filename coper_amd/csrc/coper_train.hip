@@ -198,20 +198,47 @@ __global__ __launch_bounds__(256) void k_tr_zero_list(ZeroList zl) {
   for (size_t i = tail0 + t * 4; i < bytes; i += stride * 4) *(uint32_t*)(base + i) = 0;
 }
 
-__global__ __launch_bounds__(256) void k_tr_col_sums(const float* __restrict__ m, int64_t rows, int cols, double* __restrict__ out) {
+constexpr int TR_CS_SLOTS = 16;   // copies of a column-sum slice that many workgroups add to (workgroup w: copy w % slots)
+// ... folded into copy 0 by a launch of one workgroup (k_tr_fold_slots), so readers see one slice.  (Round 6 also tried the fold by the
+// LAST workgroup of the adding launch -- a ticket behind a __threadfence: every workgroup then waits for its own stores to drain
+// before the ticket, 140 us against 12 for k_tr_bn1_bwd_sums -- and the fold in every reading workgroup: + 10 us on 9,216 of them.)
+__global__ __launch_bounds__(256) void k_tr_fold_slots(double* __restrict__ base, int n2, int nslots) {
+  for (int j = threadIdx.x; j < n2; j += 256) {
+    double v[TR_CS_SLOTS];
+#pragma unroll
+    for (int z = 0; z < TR_CS_SLOTS; ++z) v[z] = z < nslots ? base[(size_t)z * n2 + j] : 0.0;
+    double a = 0;
+#pragma unroll
+    for (int z = 0; z < TR_CS_SLOTS; ++z) a += v[z];
+    base[j] = a;
+  }
+}
+__global__ __launch_bounds__(256) void k_tr_col_sums(const float* __restrict__ m, int64_t rows, int cols, double* __restrict__ out, int nslots) {
   // per-column sum and sum of squares in double; a block reduces its row lanes in LDS and issues ONE atomic pair per
-  // column (many blocks adding to the same few addresses are contention-bound: 14x slower per add)
+  // column (many blocks adding to the same few addresses are contention-bound: 14x slower per add -- 1024 workgroups on the 64
+  // addresses of Conv1BN's statistics took 33 us for a 3 us read, so those go to TR_CS_SLOTS copies of the slice)
   __shared__ double sh[2][256];
+  out += (size_t)(blockIdx.x % nslots) * 2 * cols;
   if (cols <= 256) {
     const int cpt = 256 / cols;                         // row lanes per column
     const int col = threadIdx.x % cols, rl = threadIdx.x / cols;
     double s = 0, q = 0;
-    if (rl < cpt)
-      for (int64_t rr = (int64_t)blockIdx.x * cpt + rl; rr < rows; rr += (int64_t)gridDim.x * cpt) {
+    if (rl < cpt) {
+      const int64_t st = (int64_t)gridDim.x * cpt;
+      int64_t rr = (int64_t)blockIdx.x * cpt + rl;
+      for (; rr + 3 * st < rows; rr += 4 * st) {          // four loads in flight, added in row order
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = m[(rr + u * st) * cols + col];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s += (double)v[u]; q += (double)v[u] * v[u]; }
+      }
+      for (; rr < rows; rr += st) {
         const double v = m[rr * cols + col];
         s += v;
         q += v * v;
       }
+    }
     sh[0][threadIdx.x] = s;
     sh[1][threadIdx.x] = q;
     __syncthreads();
@@ -310,6 +337,36 @@ __global__ __launch_bounds__(256) void k_tr_fc_post(const float* __restrict__ z0
   } else {
     v = z0[i] + fc_bias[k];
   }
+  z1[i] = dropout_keep_u32(seed, step, 2u, (uint32_t)i, thr) ? v * keep_scale : 0.f;
+}
+
+// the generated dense layer straight from the K slices of its product (tg_gemm_nt: leave_slices): T[rho][b, k] = the slices of
+// part[z][b][rho d + k] added in slice order -- what k_tg_reduce stores, kept for the backward pass -- and z1 as k_tr_fc_post forms it.
+// One kernel instead of two, the 13 MB of T written once and not read back (round 6: 39.8 us -> the slices' 65 MB at stream rate).
+template <int NS>
+__global__ __launch_bounds__(256) void k_tr_fc_post_slices(const float* __restrict__ part, const float* __restrict__ cw, int rw,
+                                                           const float* __restrict__ cb, const float* __restrict__ Pb, int rb, int d,
+                                                           int64_t total, uint32_t seed, uint32_t step, uint32_t thr, float keep_scale,
+                                                           float* __restrict__ Tf, float* __restrict__ z1) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int k = (int)(i % d);
+  const int64_t b = i / d;
+  const int64_t N = (int64_t)rw * d, MN = (total / d) * N;
+  const float* p = part + b * N + k;
+  float v = 0.f;
+#pragma unroll 4
+  for (int rho = 0; rho < rw; ++rho) {
+    float t[NS];
+#pragma unroll
+    for (int z = 0; z < NS; ++z) t[z] = p[(int64_t)z * MN + (int64_t)rho * d];
+    float a = 0.f;
+#pragma unroll
+    for (int z = 0; z < NS; ++z) a += t[z];
+    Tf[(int64_t)rho * total + i] = a;
+    v = fmaf(cw[b * rw + rho], a, v);
+  }
+  for (int rho = 0; rho < rb; ++rho) v = fmaf(cb[b * rb + rho], Pb[rho * d + k], v);
   z1[i] = dropout_keep_u32(seed, step, 2u, (uint32_t)i, thr) ? v * keep_scale : 0.f;
 }
 
@@ -514,8 +571,37 @@ __global__ __launch_bounds__(256) void k_tr_col_sums_add(const float* __restrict
   if (c >= cols) return;
   const int64_t r0 = (int64_t)blockIdx.y * 64, r1 = r0 + 64 < rows ? r0 + 64 : rows;
   float a = 0.f;
-  for (int64_t r = r0; r < r1; ++r) a += S[r * cols + c];
+  int64_t r = r0;
+  for (; r + 8 <= r1; r += 8) {          // eight loads in flight (one at a time, a 64-row stretch was 64 dependent round trips: 17 - 20 us)
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = S[(r + u) * cols + c];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a += v[u];
+  }
+  for (; r < r1; ++r) a += S[r * cols + c];
   if (a != 0.f) atomicAdd(&out[c], a);
+}
+
+// out[i, j] += sum over rows b of w[b, i] v[b, j]   (a [ni x B] x [B x nj] product with a short ni: the generated dense bias'
+// projection gradient dPb[rho, k] = sum_b c[b, rho] dz0[b, k]): a workgroup per (i, stretch of 64 rows), a thread per j
+__global__ __launch_bounds__(256) void k_tr_wsum_rows_add(const float* __restrict__ w, const float* __restrict__ v, int64_t rows, int ni, int nj,
+                                                          float* __restrict__ out) {
+  const int i = blockIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.y * 64, r1 = r0 + 64 < rows ? r0 + 64 : rows;
+  for (int j = threadIdx.x; j < nj; j += 256) {
+    float a = 0.f;
+    int64_t r = r0;
+    for (; r + 8 <= r1; r += 8) {
+      float x[8], c[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { x[u] = v[(r + u) * nj + j]; c[u] = w[(r + u) * ni + i]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a = fmaf(c[u], x[u], a);
+    }
+    for (; r < r1; ++r) a = fmaf(w[r * ni + i], v[r * nj + j], a);
+    atomicAdd(&out[(int64_t)i * nj + j], a);
+  }
 }
 
 // 1-vs-all training (lookup == NULL, models.py:159-162,434-437): S holds the logits h E^T from a GEMM; add the bias,
@@ -751,7 +837,8 @@ __global__ __launch_bounds__(256) void k_tr_fc_post_bwd(float* __restrict__ dz, 
   }
   __syncthreads();
   if (Pb) {
-    for (int idx = threadIdx.x; idx < r * d; idx += 256) atomicAdd(&dPb[idx], c[b * r + idx / d] * row[idx % d]);
+    // (dPb[rho, k] = sum_b c[b, rho] dz0[b, k] is a small product of its own behind this kernel since round 6: B workgroups adding
+    //  r d values each to the same r d addresses took 32 us)
     for (int rho = threadIdx.x; rho < r; rho += 256) {
       float a = 0.f;
       for (int k = 0; k < d; ++k) a = fmaf(row[k], Pb[rho * d + k], a);
@@ -804,8 +891,9 @@ __global__ __launch_bounds__(256) void k_tr_bn1_bwd_sums(float* __restrict__ dx,
                                                          const float* __restrict__ mean, const float* __restrict__ inv,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta, int C,
                                                          int64_t total, uint32_t seed, uint32_t step, uint32_t thr,
-                                                         float keep_scale, double* __restrict__ sums) {
+                                                         float keep_scale, double* __restrict__ sums, int nslots) {
   __shared__ double s1[256], s2[256];
+  sums += (size_t)(blockIdx.x % nslots) * 2 * C;      // (TR_CS_SLOTS copies: k_tr_col_sums)
   if (256 % C != 0) {
     // channel counts that do not divide the workgroup: a thread meets every channel, so the channel sums are built in LDS
     // (C <= 256 doubles per array) with one LDS atomic pair per element, then added to the global sums
@@ -830,10 +918,28 @@ __global__ __launch_bounds__(256) void k_tr_bn1_bwd_sums(float* __restrict__ dx,
   }
   double a1 = 0, a2 = 0;
   // grid-stride: 256 % C == 0, so a thread stays on one channel and the channel sums are built in registers
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int c = (int)(i % C);
-    const float yh = (y[i] - mean[c]) * inv[c];
-    const float act = yh * gamma[c] + beta[c];
+  const int64_t st = (int64_t)gridDim.x * 256;
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int c = (int)(i % C);
+  const float mc = mean[c], ic = inv[c], gc = gamma[c], bc = beta[c];
+  for (; i + 3 * st < total; i += 4 * st) {          // four load pairs in flight (one at a time: 20 dependent round trips, 40 us)
+    float yv[4], dv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { yv[u] = y[i + u * st]; dv[u] = dx[i + u * st]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float yh = (yv[u] - mc) * ic;
+      const float act = yh * gc + bc;
+      float g = dropout_keep_u32(seed, step, 1u, (uint32_t)(i + u * st), thr) ? dv[u] * keep_scale : 0.f;
+      if (!(act > 0.f)) g = 0.f;
+      dx[i + u * st] = g;
+      a1 += g;
+      a2 += (double)g * yh;
+    }
+  }
+  for (; i < total; i += st) {
+    const float yh = (y[i] - mc) * ic;
+    const float act = yh * gc + bc;
     float g = dropout_keep_u32(seed, step, 1u, (uint32_t)i, thr) ? dx[i] * keep_scale : 0.f;
     if (!(act > 0.f)) g = 0.f;
     dx[i] = g;
@@ -873,39 +979,40 @@ __global__ __launch_bounds__(256) void k_tr_bn1_bwd_apply(float* __restrict__ dx
   }
 }
 
-// conv backward, one workgroup per query: dK, dkb (block-reduced, then atomics), d(img) -> rows of dE / drel_emb
+// conv backward, one workgroup per query: the query's filter / bias gradients dK_ps[b], dkb_ps[b] (reduced by the caller: through the
+// generators / tables, or -- static filters -- by column sums), d(img) -> rows of dE / drel_emb
 __global__ __launch_bounds__(256) void k_tr_conv_bwd(const float* __restrict__ dy, const float* __restrict__ img_all,
                                                      const float* __restrict__ K, const int64_t* __restrict__ e1,
                                                      const int64_t* __restrict__ rel, int64_t E, int64_t R, int d, int r,
                                                      int in_h, int in_w, int stacked, int C, int Ho, int Wo,
-                                                     float* __restrict__ dK, float* __restrict__ dkb,
                                                      float* __restrict__ dE, float* __restrict__ drel,
                                                      const float* __restrict__ K_ps, float* __restrict__ dK_ps,
                                                      float* __restrict__ dkb_ps, int fh, int fw) {
-  extern __shared__ float lds[];  // img[isz] | g[P*C] | taps[fh*fw*C]
-  const int isz = in_h * in_w, P = Ho * Wo, nt = fh * fw;
+  extern __shared__ float lds[];  // img[isz] | g[P][C + 1] | taps[fh*fw*C]
+  // (round 6: a pixel's C gradients are C + 1 words apart -- the image-gradient loop below has every lane on another PIXEL and the
+  //  same channel: with a stride of C = 32 words all 64 lanes sat on one LDS bank, 45 of this kernel's 60 us)
+  const int isz = in_h * in_w, P = Ho * Wo, nt = fh * fw, CS = C + 1;
   float* img = lds;
   float* g = img + isz;
-  float* taps = g + P * C;
+  float* taps = g + P * CS;
   const int64_t b = blockIdx.x;
   for (int t = threadIdx.x; t < isz; t += 256) img[t] = img_all[b * isz + t];
-  for (int t = threadIdx.x; t < P * C; t += 256) g[t] = dy[b * (int64_t)P * C + t];
+  for (int t = threadIdx.x; t < P * C; t += 256) g[(t / C) * CS + (t % C)] = dy[b * (int64_t)P * C + t];
   const float* Ksrc = K_ps ? K_ps + b * (int64_t)nt * C : K;
   for (int t = threadIdx.x; t < nt * C; t += 256) taps[t] = Ksrc[t];
   __syncthreads();
   // filter and bias gradients: entry (tap, c) = sum_p img[p + tap offset] * g[p, c]
-  // (per-sample filters: written per sample, reduced through the generator / table afterwards)
   for (int idx = threadIdx.x; idx < (nt + 1) * C; idx += 256) {
     const int cc = idx % C, tap = idx / C;
     float a = 0.f;
     if (tap < nt) {
       const int u = tap / fw, v = tap % fw;
       for (int i = 0; i < Ho; ++i)
-        for (int j = 0; j < Wo; ++j) a = fmaf(img[(i + u) * in_w + j + v], g[(i * Wo + j) * C + cc], a);
-      if (dK_ps) dK_ps[b * (int64_t)nt * C + tap * C + cc] = a; else atomicAdd(&dK[tap * C + cc], a);
+        for (int j = 0; j < Wo; ++j) a = fmaf(img[(i + u) * in_w + j + v], g[(i * Wo + j) * CS + cc], a);
+      dK_ps[b * (int64_t)nt * C + tap * C + cc] = a;
     } else {
-      for (int p = 0; p < P; ++p) a += g[p * C + cc];
-      if (dkb_ps) dkb_ps[b * C + cc] = a; else atomicAdd(&dkb[cc], a);
+      for (int p = 0; p < P; ++p) a += g[p * CS + cc];
+      dkb_ps[b * C + cc] = a;
     }
   }
   // image gradient (full correlation), scattered to the embedding rows
@@ -922,7 +1029,7 @@ __global__ __launch_bounds__(256) void k_tr_conv_bwd(const float* __restrict__ d
       for (int v = 0; v < fw; ++v) {
         const int j = jj - v;
         if (j < 0 || j >= Wo) continue;
-        const float* gp = g + (i * Wo + j) * C;
+        const float* gp = g + (i * Wo + j) * CS;
         const float* tp = taps + (u * fw + v) * C;
         for (int cc = 0; cc < C; ++cc) a = fmaf(gp[cc], tp[cc], a);
       }
@@ -1122,17 +1229,20 @@ __global__ __launch_bounds__(256) void k_tr_amsgrad(TrainTensors tt, const doubl
 __global__ void k_tr_store_loss(const double* __restrict__ acc, double inv_BL, float* __restrict__ out) { out[0] = (float)(acc[0] * inv_BL); }
 
 // GEMM on planes packed by the caller, K cut into slices when the output has few tiles (the partial-sum pool grows on demand)
+// slices_left: when not null and K was cut, the partial sums stay in T->mmP ([*slices_left][M][N]) for the caller's next kernel and C is
+// not written (*slices_left = 1: C holds the product)
 static int tg_gemm_split(coper_handle* h, TrainState* T, hipStream_t s, TgPlanes X, int64_t M, TgPlanes Y, int64_t N, int64_t K, float* C,
-                         TgIdx ci, TgIdx cj) {
+                         TgIdx ci, TgIdx cj, int* slices_left = nullptr) {
   int rc;
   const int nsplit = tg_split_k(M, N, K);
+  if (slices_left) *slices_left = nsplit > 1 && nsplit <= 8 ? nsplit : 1;
   const size_t np = nsplit > 1 ? (size_t)nsplit * M * N : 0;
   if (np > T->mmP_cap) {
     COPER_HIP_TRY(h, hipStreamSynchronize(s));
     if ((rc = talloc(h, &T->mmP, np))) return rc;
     T->mmP_cap = np;
   }
-  return tg_gemm_nt(h, X, M, Y, N, K, C, ci, cj, s, nsplit, T->mmP);
+  return tg_gemm_nt(h, X, M, Y, N, K, C, ci, cj, s, nsplit, T->mmP, nullptr, slices_left && *slices_left > 1);
 }
 
 static int tg_matmul(coper_handle* h, TrainState* T, hipStream_t s, const MmView& X, int64_t M, const MmView& Y, int64_t N, int64_t K,
@@ -1302,7 +1412,7 @@ COPER_API int coper_train_init(coper_handle* h, const coper_train_config* cfg) {
   for (int i = 0; i < T->nh; ++i) mx = h->cfg.ctx_out[i] > mx ? h->cfg.ctx_out[i] : mx;
   for (int i = 0; i < T->nhc; ++i) mx = h->cfg.ctx_conv[i] > mx ? h->cfg.ctx_conv[i] : mx;
   if ((rc = talloc(h, &T->bnst, (size_t)4 * mx))) return rc;
-  if ((rc = talloc(h, &T->red, (size_t)(2 + 2 * mx * TR_COLSUM_SLICES + TG_SUMSQ_SLOTS)))) return rc;
+  if ((rc = talloc(h, &T->red, (size_t)(2 + 2 * mx * TR_COLSUM_SLICES + TG_SUMSQ_SLOTS + 2 * TR_CS_SLOTS * 2 * mx)))) return rc;
   if ((rc = talloc(h, &T->tg_exps, (size_t)(8 + TR_EXP_CACHE))) || (rc = talloc(h, &T->tg_scratch, (size_t)2)) ||
       (rc = talloc(h, &T->wmax[0], (size_t)TG_MAX_SLOTS)) || (rc = talloc(h, &T->wmax[1], (size_t)TG_MAX_SLOTS)) ||
       (rc = talloc(h, &T->xmax, (size_t)TG_MAX_SLOTS)) || (rc = talloc(h, &T->dtmax, (size_t)TG_MAX_SLOTS)) ||
@@ -1403,9 +1513,10 @@ static int train_step_impl(coper_handle* h, const int64_t* e1, const int64_t* re
           return rc;
       }
     }
-    if (dm.gen_conv && ((rc = talloc(h, &T->Kt, (size_t)cb * NT * C)) || (rc = talloc(h, &T->Kbv, (size_t)cb * C)) ||
-                        (rc = talloc(h, &T->dKs, (size_t)cb * NT * C)) || (rc = talloc(h, &T->dkbs, (size_t)cb * C))))
-      return rc;
+    if (dm.gen_conv && ((rc = talloc(h, &T->Kt, (size_t)cb * NT * C)) || (rc = talloc(h, &T->Kbv, (size_t)cb * C)))) return rc;
+    // per-query filter / bias gradients: what the generators and tables reduce (gen_conv), and -- round 6 -- what the STATIC filters'
+    // gradients are summed from (512 workgroups adding to the same 320 addresses were 50 of k_tr_conv_bwd's 60 us)
+    if ((rc = talloc(h, &T->dKs, (size_t)cb * NT * C)) || (rc = talloc(h, &T->dkbs, (size_t)cb * C))) return rc;
     T->capB = cb; T->capL = cl;
   }
   auto P_ = [&](const char* n) -> float* { return T->find(n)->p; };
@@ -1420,7 +1531,10 @@ static int train_step_impl(coper_handle* h, const int64_t* e1, const int64_t* re
   double* red = T->red;         // [0] loss, [1] sumsq, then TR_COLSUM_SLICES slices of 2 mx column sums, one per use
   auto colsum_slice = [&](int i) { return red + 2 + (size_t)i * 2 * mx; };
   double* ssq = red + 2 + (size_t)2 * mx * TR_COLSUM_SLICES;   // TG_SUMSQ_SLOTS partial sums of the squared gradient norm   // 0 Conv1BN, 1 FCBN, 2 Conv1BN backward, 3 + 4 g + i chains
-  double* colsum = colsum_slice(0);
+  // ... then two slices in TR_CS_SLOTS copies each (Conv1BN's statistics and its backward sums: thousands of workgroups add to them)
+  auto cs_slots = [&](int j) { return ssq + TG_SUMSQ_SLOTS + (size_t)j * TR_CS_SLOTS * 2 * mx; };
+  const int cs_n = TR_CS_SLOTS;
+  double* colsum;
   const uint32_t thr_h = dropout_threshold24(tc.hidden_dropout), thr_o = dropout_threshold24(tc.output_dropout);
   const float ks_h = 1.f / (1.f - tc.hidden_dropout), ks_o = 1.f / (1.f - tc.output_dropout);
   const uint32_t step = T->step;
@@ -1440,7 +1554,7 @@ static int train_step_impl(coper_handle* h, const int64_t* e1, const int64_t* re
     ZeroList zl;
     zl.n = 0;
     auto add = [&](void* p, size_t bytes) { if (p && bytes && zl.n < TR_ZERO_MAX) { zl.p[zl.n] = p; zl.bytes[zl.n] = bytes; ++zl.n; } };
-    add(red, sizeof(double) * (2 + (size_t)2 * mx * TR_COLSUM_SLICES + TG_SUMSQ_SLOTS));
+    add(red, sizeof(double) * (2 + (size_t)2 * mx * TR_COLSUM_SLICES + TG_SUMSQ_SLOTS + (size_t)2 * TR_CS_SLOTS * 2 * mx));
     for (const char* nm : {"ent_emb", "rel_emb", "conv1_weights", "conv1_bias", "pred_bias"})
       if (T->find(nm)) add(G_(nm), sizeof(float) * T->find(nm)->n);
     if (lk) add(G_("fc_bias"), sizeof(float) * T->find("fc_bias")->n);
@@ -1481,7 +1595,7 @@ static int train_step_impl(coper_handle* h, const int64_t* e1, const int64_t* re
       const float *ga = nullptr, *be = nullptr;
       if (dm.ctx_bn) {
         double* cs = colsum_slice(3 + 4 * g + i);
-        if (use_batch) hipLaunchKernelGGL(k_tr_col_sums, dim3(64), dim3(256), 0, s, ch.u[i], B, nj, cs);
+        if (use_batch) hipLaunchKernelGGL(k_tr_col_sums, dim3(64), dim3(256), 0, s, ch.u[i], B, nj, cs, 1);
         hipLaunchKernelGGL(k_tr_bn_finish, dim3((nj + 63) / 64), dim3(64), 0, s, cs, nj, (double)B, use_batch, tc.batch_norm_momentum, 0 | nomov,
                            const_cast<float*>(h->params[pn + "/BatchNorm/moving_mean"].ptr),
                            const_cast<float*>(h->params[pn + "/BatchNorm/moving_variance"].ptr), ch.st[i], ch.st[i] + nj);
@@ -1515,8 +1629,11 @@ static int train_step_impl(coper_handle* h, const int64_t* e1, const int64_t* re
                      dm.gen_conv ? nullptr : P_("conv1_bias"), dm.E, dm.R, d, r, dm.in_h, dm.in_w, dm.stacked ? 1 : 0, C, dm.Ho, dm.Wo, T->img,
                      ((gen || cat) && !genc) ? T->c : nullptr, T->y, K_ps, kb_ps, dm.fh, dm.fw);
   const int64_t nBF = B * Fc;
-  if (use_batch) hipLaunchKernelGGL(k_tr_col_sums, dim3(256), dim3(256), 0, s, T->y, B * (int64_t)P, C, colsum);
-  hipLaunchKernelGGL(k_tr_bn_finish, dim3((C + 63) / 64), dim3(64), 0, s, colsum, C, (double)B * P, use_batch,
+  if (use_batch) {
+    hipLaunchKernelGGL(k_tr_col_sums, dim3(1024), dim3(256), 0, s, T->y, B * (int64_t)P, C, cs_slots(0), cs_n);
+    hipLaunchKernelGGL(k_tr_fold_slots, dim3(1), dim3(256), 0, s, cs_slots(0), 2 * C, cs_n);
+  }
+  hipLaunchKernelGGL(k_tr_bn_finish, dim3((C + 63) / 64), dim3(64), 0, s, cs_slots(0), C, (double)B * P, use_batch,
                      tc.batch_norm_momentum, 1 | nomov, const_cast<float*>(h->params["Conv1BN/moving_mean"].ptr),
                      const_cast<float*>(h->params["Conv1BN/moving_variance"].ptr), mean1, inv1);
   hipLaunchKernelGGL(k_tr_bn1_fwd, dim3((unsigned)((nBF + 255) / 256)), dim3(256), 0, s, T->y, mean1, inv1, P_("Conv1BN/gamma"),
@@ -1534,6 +1651,7 @@ static int train_step_impl(coper_handle* h, const int64_t* e1, const int64_t* re
   float* Tf = T->A;                 // T[rho][b][k]
   float* dTf = T->A + (size_t)rc_w * nBd;
   constexpr int LK_NSL = 4;      // F slices of the looked-up dense layer (deterministic partial sums)
+  int t_slices = 1;              // K slices of the generated dense layer's product left for k_tr_fc_post_slices
   if (lk) {
     // z0[b] = x[b] W[rel[b]]: one pass over the looked-up rows (B * F * d * 4 bytes)
     hipLaunchKernelGGL(k_tr_lookup_fwd, dim3((unsigned)B, LK_NSL), dim3(256), sizeof(float) * (size_t)((F + LK_NSL - 1) / LK_NSL + 1), s, T->x,
@@ -1553,17 +1671,28 @@ static int train_step_impl(coper_handle* h, const int64_t* e1, const int64_t* re
         p3_packed = true;
       } else if ((rc = tg_pack(h, Wmat, tg_idx2(d, F * (int64_t)d, 1), tg_idx(d), nrk, F, tg_rows_pad(nrk), true, T->pP1, s, T->tg_scratch, nullptr, w_slots)))
         return rc;
-      if ((rc = tg_gemm_split(h, T, s, T->pX, B, T->pP1, nrk, F, Tf, tg_idx(d), tg_idx2(d, nBd, 1)))) return rc;
+      if ((rc = tg_gemm_split(h, T, s, T->pX, B, T->pP1, nrk, F, Tf, tg_idx(d), tg_idx2(d, nBd, 1), &t_slices))) return rc;
     } else {
       // z0[B,d] = x[B,F] W[F,d]: 8 output tiles, K = F cut into slices
       if ((rc = tg_matmul(h, T, s, MmView{xin, tg_idx(F), tg_idx(1), false}, B, MmView{Wmat, tg_idx(1), tg_idx(d), true}, d, F, T->z0,
                           tg_idx(d), tg_idx(1), nullptr, x_slots, w_slots)))
         return rc;
     }
-    hipLaunchKernelGGL(k_tr_fc_post, dim3((unsigned)((nBd + 255) / 256)), dim3(256), 0, s, gen ? Tf : T->z0, gen ? nullptr : P_("fc_bias"),
-                       cw, rc_w, cbv, gen ? P_(blast.c_str()) : nullptr, rc_b, d, nBd, tc.seed, step, thr_o, ks_o, T->z1);
+    if (t_slices > 1) {
+#define COPER_FC_SLICES(NS)                                                                                                              \
+  case NS:                                                                                                                               \
+    hipLaunchKernelGGL(k_tr_fc_post_slices<NS>, dim3((unsigned)((nBd + 255) / 256)), dim3(256), 0, s, T->mmP, cw, rc_w, cbv,            \
+                       P_(blast.c_str()), rc_b, d, nBd, tc.seed, step, thr_o, ks_o, Tf, T->z1);                                          \
+    break;
+      switch (t_slices) {
+        COPER_FC_SLICES(2) COPER_FC_SLICES(3) COPER_FC_SLICES(4) COPER_FC_SLICES(5) COPER_FC_SLICES(6) COPER_FC_SLICES(7) COPER_FC_SLICES(8)
+      }
+#undef COPER_FC_SLICES
+    } else
+      hipLaunchKernelGGL(k_tr_fc_post, dim3((unsigned)((nBd + 255) / 256)), dim3(256), 0, s, gen ? Tf : T->z0, gen ? nullptr : P_("fc_bias"),
+                         cw, rc_w, cbv, gen ? P_(blast.c_str()) : nullptr, rc_b, d, nBd, tc.seed, step, thr_o, ks_o, T->z1);
   }
-  if (use_batch) hipLaunchKernelGGL(k_tr_col_sums, dim3(64), dim3(256), 0, s, T->z1, B, d, colsum_slice(1));
+  if (use_batch) hipLaunchKernelGGL(k_tr_col_sums, dim3(64), dim3(256), 0, s, T->z1, B, d, colsum_slice(1), 1);
   hipLaunchKernelGGL(k_tr_bn_finish, dim3((d + 63) / 64), dim3(64), 0, s, colsum_slice(1), d, (double)B, use_batch, tc.batch_norm_momentum, 0 | nomov,
                      const_cast<float*>(h->params["FCBN/moving_mean"].ptr), const_cast<float*>(h->params["FCBN/moving_variance"].ptr),
                      mean2, inv2);
@@ -1653,6 +1782,8 @@ static int train_step_impl(coper_handle* h, const int64_t* e1, const int64_t* re
   hipLaunchKernelGGL(k_tr_fc_post_bwd, dim3((unsigned)B), dim3(256), sizeof(float) * d, s, T->dz, cbv,
                      gen ? P_(blast.c_str()) : nullptr, rc_b, d, tc.seed, step, thr_o, ks_o,
                      gen ? nullptr : G_("fc_bias"), gen ? G_(blast.c_str()) : nullptr, dcb);
+  if (gen)      // (into the zeroed gradient: 8 atomics per address)
+    hipLaunchKernelGGL(k_tr_wsum_rows_add, dim3((unsigned)rc_b, (unsigned)((B + 63) / 64)), dim3(256), 0, s, cbv, T->dz, B, rc_b, d, G_(blast.c_str()));
   float* dW = gen ? G_(wlast.c_str()) : G_("fc_weights");
   if (gen) {
     // dT[rho][b,:] = cw[b,rho] dz[b,:];  dP[rho][f][k] = sum_b x[b][f] dT[rho][b][k]  and
@@ -1704,17 +1835,22 @@ static int train_step_impl(coper_handle* h, const int64_t* e1, const int64_t* re
     }
   };
   if (gen) { chain_backward(0, nh); chain_backward(1, nh); }
-  colsum = colsum_slice(2);
-  hipLaunchKernelGGL(k_tr_bn1_bwd_sums, dim3((unsigned)((nBF + 255) / 256 < 1024 ? (nBF + 255) / 256 : 1024)), dim3(256), 0, s, T->dx, T->y, mean1, inv1, P_("Conv1BN/gamma"),
-                     P_("Conv1BN/beta"), C, nBF, tc.seed, step, thr_h, ks_h, colsum);
+  colsum = cs_slots(1);
+  hipLaunchKernelGGL(k_tr_bn1_bwd_sums, dim3((unsigned)((nBF + 255) / 256 < 2048 ? (nBF + 255) / 256 : 2048)), dim3(256), 0, s, T->dx, T->y, mean1, inv1, P_("Conv1BN/gamma"),
+                     P_("Conv1BN/beta"), C, nBF, tc.seed, step, thr_h, ks_h, colsum, cs_n);
+  hipLaunchKernelGGL(k_tr_fold_slots, dim3(1), dim3(256), 0, s, colsum, 2 * C, cs_n);
   hipLaunchKernelGGL(k_tr_bn1_bwd_apply, dim3((unsigned)((nBF + 255) / 256)), dim3(256), 0, s, T->dx, T->y, mean1, inv1, P_("Conv1BN/gamma"),
                      colsum, C, nBF, (double)B * P, use_batch, G_("Conv1BN/gamma"), G_("Conv1BN/beta"));
-  size_t lds_cb = sizeof(float) * (size_t)(isz + (size_t)P * C + NT * C);
+  size_t lds_cb = sizeof(float) * (size_t)(isz + (size_t)P * (C + 1) + NT * C);
   if (lds_cb > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_tr_conv_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipLaunchKernelGGL(k_tr_conv_bwd, dim3((unsigned)B), dim3(256), lds_cb, s, T->dx, T->img, dm.gen_conv ? nullptr : P_("conv1_weights"), e1, rel,
-                     dm.E, dm.R, d, r, dm.in_h, dm.in_w, dm.stacked ? 1 : 0, C, dm.Ho, dm.Wo, dm.gen_conv ? nullptr : G_("conv1_weights"),
-                     dm.gen_conv ? nullptr : G_("conv1_bias"), G_("ent_emb"), dm.lookup ? nullptr : G_("rel_emb"), K_ps,
-                     dm.gen_conv ? T->dKs : nullptr, dm.gen_conv ? T->dkbs : nullptr, dm.fh, dm.fw);
+                     dm.E, dm.R, d, r, dm.in_h, dm.in_w, dm.stacked ? 1 : 0, C, dm.Ho, dm.Wo, G_("ent_emb"),
+                     dm.lookup ? nullptr : G_("rel_emb"), K_ps, T->dKs, T->dkbs, dm.fh, dm.fw);
+  if (!dm.gen_conv) {      // static filters: their gradients are the column sums of the per-query ones (added to the zeroed gradients)
+    hipLaunchKernelGGL(k_tr_col_sums_add, dim3((unsigned)((NT * C + 255) / 256), (unsigned)((B + 63) / 64)), dim3(256), 0, s, T->dKs, B,
+                       (int64_t)NT * C, G_("conv1_weights"));
+    hipLaunchKernelGGL(k_tr_col_sums_add, dim3(1, (unsigned)((B + 63) / 64)), dim3(256), 0, s, T->dkbs, B, (int64_t)C, G_("conv1_bias"));
+  }
   if (genc) {
     // per-sample filter gradients -> last projections and contexts, then back through the conv generators
     hipLaunchKernelGGL(k_tr_small_mm_tn, dim3((unsigned)(((int64_t)rc_cw * NT * C + 255) / 256)), dim3(256), 0, s, ccw, T->dKs, B, rc_cw, NT * C,

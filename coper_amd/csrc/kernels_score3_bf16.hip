@@ -159,7 +159,8 @@ __device__ __forceinline__ void sc3_value_tail(SC3<NP, TAIL, PD, GM>& S, const i
 template <int NP, int TAIL, int PD, int GM, int M, int V>
 __device__ __forceinline__ void sc3_value(SC3<NP, TAIL, PD, GM>& S, const int lane, const bool store_ok, float* __restrict__ gm_row,
                                           const int64_t gm_col, uint4* __restrict__ mask_row) {
-  constexpr int MB = SC3_MB, NV = 32 * MB;
+  constexpr int MB = SC3_MB;
+  [[maybe_unused]] constexpr int NV = 32 * MB;
   constexpr int b = V / (4 * MB), m2 = (V >> 2) % MB, j = V & 3, w = MB * M + (V >> 5);
 #ifdef COPER_DBG_SC3_EPI_R0   /* ablation: one value per column block keeps the chains alive, the epilogue nearly free */
   if constexpr ((V & 7) != 0) return;

@@ -52,7 +52,8 @@ int tg_pack_both(coper_handle* h, const float* src, TgIdx ri, TgIdx ki, int64_t 
 // sumsq: when not null, the sum of the squares of the stored C is added by the storing kernel to the TG_SUMSQ_SLOTS device
 // doubles at sumsq (a workgroup adds to slot (its index) % TG_SUMSQ_SLOTS: thousands of atomics on one address serialise)
 int tg_gemm_nt(coper_handle* h, TgPlanes X, int64_t M, TgPlanes Y, int64_t N, int64_t K, float* C, TgIdx ci, TgIdx cj, hipStream_t s,
-               int nsplit = 1, float* part = nullptr, double* sumsq = nullptr);
+               int nsplit = 1, float* part = nullptr, double* sumsq = nullptr, bool leave_slices = false);
+// (leave_slices: with nsplit > 1 the partial sums stay in `part` and C is not written -- the caller's next kernel adds them, in slice order)
 // slices that fill the chip when the output has few 128 x 128 tiles and K is long (1: no split)
 int tg_split_k(int64_t M, int64_t N, int64_t K);
 

@@ -489,7 +489,7 @@ void tg_launch_w128(const TgPlanes& X, int64_t M, const TgPlanes& Y, int64_t N, 
                     int nsplit, float* part, double* sumsq);     // (reads X.exp / Y.exp)
 
 int tg_gemm_nt(coper_handle* h, TgPlanes X, int64_t M, TgPlanes Y, int64_t N, int64_t K, float* C, TgIdx ci, TgIdx cj, hipStream_t s,
-               int nsplit, float* part, double* sumsq) {
+               int nsplit, float* part, double* sumsq, bool leave_slices) {
   const int KS16 = (int)((K + 15) / 16), KST = (int)tg_ks_stride(K);
   if (nsplit < 1 || !part) nsplit = 1;
   // workgroup tiles of 128 x 128 (rows of both plane sets are padded to TG_ROW_PAD).  A 128 x 256 tile (64 x 128 per wave,
@@ -497,7 +497,7 @@ int tg_gemm_nt(coper_handle* h, TgPlanes X, int64_t M, TgPlanes Y, int64_t N, in
   // (4608 x 6400 x 512): one k-step of prefetch does not cover the fill latency.
   if (tg_use_w128(M, N, K) && ci.seg == 0) {   // (two-level row views of C: the four-wave kernel)
     tg_launch_w128(X, M, Y, N, KS16, KST, C, ci, cj, s, nsplit, part, sumsq);
-    if (nsplit > 1)
+    if (nsplit > 1 && !leave_slices)
       hipLaunchKernelGGL(k_tg_reduce, dim3((unsigned)((M * N + 255) / 256)), dim3(256), 0, s, part, nsplit, M, N, C, ci, cj, sumsq);
     COPER_HIP_TRY(h, hipGetLastError());
     return COPER_OK;
@@ -507,7 +507,7 @@ int tg_gemm_nt(coper_handle* h, TgPlanes X, int64_t M, TgPlanes Y, int64_t N, in
   const int64_t nclu = (int64_t)((ti + cs - 1) / cs) * tj * nsplit;
   dim3 grid((unsigned)(8 * cs * ((nclu + 7) / 8)));
   hipLaunchKernelGGL((k_gemm_nt_bf16x3<2, 2, 3>), grid, dim3(256), 0, s, X.hi, X.lo, Y.hi, Y.lo, KS16, KST, C, ci, cj, M, N, nsplit, part, sumsq, cs, X.exp, Y.exp);
-  if (nsplit > 1)
+  if (nsplit > 1 && !leave_slices)
     hipLaunchKernelGGL(k_tg_reduce, dim3((unsigned)((M * N + 255) / 256)), dim3(256), 0, s, part, nsplit, M, N, C, ci, cj, sumsq);
   COPER_HIP_TRY(h, hipGetLastError());
   return COPER_OK;
