@@ -18,6 +18,7 @@
 // old grid layouts ... -- are gone from the sources; their numbers are in DESIGN_LOG.md.  What remains besides are named tunables
 // with ONE shipped value (`#ifndef X / #define X value`: COPER_SC3_MB, COPER_TL_WAVES, COPER_FUSED_PBUDGET, ...).
 #ifndef COPER_DIAG
+#undef COPER_DBG_AMSGRAD_NO_NT
 #undef COPER_DBG_CLOCK
 #undef COPER_DBG_DENSE_NO_DMA
 #undef COPER_DBG_DENSE_NO_MFMA

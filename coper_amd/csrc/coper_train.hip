@@ -424,6 +424,124 @@ __global__ __launch_bounds__(256) void k_tr_score_loss(const float* __restrict__
   if (threadIdx.x == 0) atomicAdd(loss_acc, part[0]);
 }
 
+// The sampled scorer of a training step in ONE pass over the gathered rows (round 6): scores, loss, ds AND dh = sum_l ds E[row].
+// k_tr_score_loss + k_tr_dh_gather4 each read the B L rows of d floats (410 MB at 512 x 1000 x 200: 61 + 45 us); sigmoid
+// cross-entropy is elementwise, so ds[b, l] is known as soon as row l's score is, while the row is still in registers.
+// k_tr_dh_gather4's layout: a thread owns four features (one 16-byte load) of one of 256 / (d / 4) row slots, SF_U rows per
+// slot and batch; the next batch's rows are requested before this batch is touched.  Per batch: every thread's four-term
+// share of its rows' dot products -> LDS; one thread per row adds the d / 4 shares in feature order, forms loss and ds;
+// every thread adds ds x its registers to its dh share.  (An earlier fused form -- a wave per row, butterfly sums -- was
+// latency end to end: 242 us.)
+#ifndef COPER_SF_U
+#define COPER_SF_U 12
+#endif
+constexpr int SF_U = COPER_SF_U;      // rows per slot and batch
+constexpr int SF_MAX_L = 8192;       // lookup entries of a query held in LDS (32 KB)
+__global__ __launch_bounds__(256) void k_tr_score_loss_dh(const float* __restrict__ hv, const float* __restrict__ ent,
+                                                          const float* __restrict__ pred_bias, const int32_t* __restrict__ lookup,
+                                                          const float* __restrict__ labels, int64_t E, int d, int L, float ls_eps,
+                                                          float inv_E, float inv_BL, float* __restrict__ ds, float* __restrict__ dh,
+                                                          double* __restrict__ loss_acc) {
+  extern __shared__ float4 sf_lds[];   // float4 [slots][d4] (the slots' dh shares at the end) | float part[RB][d4 + 1] | float g[RB] | int ids[L]
+  __shared__ double red[256];
+  const int64_t b = blockIdx.x;
+  const int d4 = d >> 2, slots = 256 / d4 > 32 ? 32 : 256 / d4, RB = SF_U * slots, PS = d4 + 1;      // (RB <= 256)
+  // threads that share a row's sum of partial products (a power of two, neighbours in a wave)
+  const int tpr = 256 / RB >= 8 ? 8 : (256 / RB >= 4 ? 4 : (256 / RB >= 2 ? 2 : 1));
+  float* part = (float*)(sf_lds + slots * d4);
+  float* gsh = part + RB * PS;
+  int* ids = (int*)(gsh + RB);
+  const int slot = threadIdx.x / d4, q4 = threadIdx.x - slot * d4;
+  const bool live = slot < slots;
+  // the query's rows, range-checked once (a row id is read by the thread that loads the row, by the thread that scores it, ...)
+  for (int l = threadIdx.x; l < L; l += 256) {
+    const int32_t row = lookup[b * L + l];
+    ids[l] = (row < 0 || row >= E) ? 0 : row;
+  }
+  const float4 h4 = live ? *(const float4*)(hv + b * d + 4 * q4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  double lacc = 0.0;
+  float4 va[SF_U], vb[SF_U];
+  // (every load of the loop is unconditional, with clamped indices, and issued in ONE order -- this batch's label and bias, then the
+  //  next batch's rows: the vector-memory counter retires in order, so a wait for a load issued after the prefetch would drain it,
+  //  and a load under a branch makes the compiler wait for everything)
+#define SF_FETCH(l0_, dst_)                                                                   \
+  {                                                                                           \
+    _Pragma("unroll") for (int u = 0; u < SF_U; ++u) {                                        \
+      const int l = (l0_) + u * slots + slot;                                                 \
+      const int64_t row = ids[l < L ? l : L - 1];                                             \
+      dst_[u] = *(const float4*)(ent + row * d + 4 * qc);                                     \
+    }                                                                                         \
+  }
+  const int qc = live ? q4 : 0;                                  // (threads past the last slot load, and drop, a valid address)
+  const int sr = threadIdx.x / tpr, sj = threadIdx.x % tpr;      // scoring: row sr of the batch, share sj of its partial products
+  const int q_lo = (int)((int64_t)d4 * sj / tpr), q_hi = (int)((int64_t)d4 * (sj + 1) / tpr);
+#define SF_BATCH(l0_, cur_, nxt_)                                                             \
+  {                                                                                           \
+    const int lb = (l0_);                                                                     \
+    const bool on = sr < RB && lb + sr < L;    /* (uniform over the tpr neighbours of a row) */ \
+    const int lc = lb + sr < L ? lb + sr : L - 1;                                             \
+    const float lab = labels[b * L + lc], pb = pred_bias[ids[lc]];                            \
+    SF_FETCH(lb + RB, nxt_);                                                                  \
+    if (live) {                                                                               \
+      _Pragma("unroll") for (int u = 0; u < SF_U; ++u) {                                      \
+        float pz = h4.x * cur_[u].x;                                                          \
+        pz = fmaf(h4.y, cur_[u].y, pz); pz = fmaf(h4.z, cur_[u].z, pz); pz = fmaf(h4.w, cur_[u].w, pz); \
+        part[(u * slots + slot) * PS + q4] = pz;                                              \
+      }                                                                                       \
+    }                                                                                         \
+    __syncthreads();                                                                          \
+    float sc = 0.f;                                                                           \
+    if (on) {                                                                                 \
+      const float* pr = part + sr * PS;                                                       \
+      for (int q = q_lo; q < q_hi; ++q) sc += pr[q];                                          \
+    }                                                                                         \
+    for (int o = 1; o < tpr; o <<= 1) sc += __shfl_xor(sc, o, 64);   /* (the same sum in every neighbour) */ \
+    if (on && sj == 0) {                                                                      \
+      sc += pb;                                                                               \
+      const float t = (1.f - ls_eps) * lab + inv_E;                    /* models.py:450 */    \
+      const float as = fabsf(sc);                                                             \
+      lacc += (double)(fmaxf(sc, 0.f) - sc * t + log1pf(expf(-as)));   /* sigmoid cross-entropy with logits */ \
+      const float sg = 1.f / (1.f + expf(-sc));                                               \
+      const float g = (sg - t) * inv_BL;                                                      \
+      ds[b * L + lb + sr] = g;                                                                \
+      gsh[sr] = g;                                                                            \
+    }                                                                                         \
+    __syncthreads();                                                                          \
+    if (live) {                                                                               \
+      _Pragma("unroll") for (int u = 0; u < SF_U; ++u)                                        \
+        if (lb + u * slots + slot < L) {                                                      \
+          const float g = gsh[u * slots + slot];                                              \
+          acc.x = fmaf(g, cur_[u].x, acc.x); acc.y = fmaf(g, cur_[u].y, acc.y);               \
+          acc.z = fmaf(g, cur_[u].z, acc.z); acc.w = fmaf(g, cur_[u].w, acc.w);               \
+        }                                                                                     \
+    }                                                                                         \
+  }
+  SF_FETCH(0, va);
+  for (int l0 = 0; l0 < L; l0 += 2 * RB) {
+    SF_BATCH(l0, va, vb);
+    if (l0 + RB < L) SF_BATCH(l0 + RB, vb, va);      // (uniform)
+  }
+#undef SF_BATCH
+#undef SF_FETCH
+  if (live) sf_lds[slot * d4 + q4] = acc;
+  red[threadIdx.x] = lacc;
+  __syncthreads();
+  if (live && slot == 0) {
+    for (int s2 = 1; s2 < slots; ++s2) {   // fixed order
+      const float4 o = sf_lds[s2 * d4 + q4];
+      acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+    }
+    *(float4*)(dh + b * d + 4 * q4) = acc;
+  }
+  if (threadIdx.x == 0) {      // (the loss terms, in thread order)
+    double a = 0.0;
+    for (int t = 0; t < 256; ++t) a += red[t];
+    atomicAdd(loss_acc, a);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // backward kernels
 // ------------------------------------------------------------------------------------------------
@@ -1007,10 +1125,17 @@ __global__ __launch_bounds__(256) void k_tr_conv_bwd(const float* __restrict__ d
     float a = 0.f;
     if (tap < nt) {
       const int u = tap / fw, v = tap % fw;
-      for (int i = 0; i < Ho; ++i)
-        for (int j = 0; j < Wo; ++j) a = fmaf(img[(i + u) * in_w + j + v], g[(i * Wo + j) * CS + cc], a);
+      // (the trip counts are run-time values: without the unrolls every iteration waits out its own two LDS reads -- with two
+      //  waves per SIMD this kernel was LDS latency end to end, 31 us)
+      for (int i = 0; i < Ho; ++i) {
+        const float* ir = img + (i + u) * in_w + v;
+        const float* gr = g + (i * Wo) * CS + cc;
+#pragma unroll 6
+        for (int j = 0; j < Wo; ++j) a = fmaf(ir[j], gr[j * CS], a);
+      }
       dK_ps[b * (int64_t)nt * C + tap * C + cc] = a;
     } else {
+#pragma unroll 8
       for (int p = 0; p < P; ++p) a += g[p * CS + cc];
       dkb_ps[b * C + cc] = a;
     }
@@ -1031,6 +1156,7 @@ __global__ __launch_bounds__(256) void k_tr_conv_bwd(const float* __restrict__ d
         if (j < 0 || j >= Wo) continue;
         const float* gp = g + (i * Wo + j) * CS;
         const float* tp = taps + (u * fw + v) * C;
+#pragma unroll 8
         for (int cc = 0; cc < C; ++cc) a = fmaf(gp[cc], tp[cc], a);
       }
     }
@@ -1183,15 +1309,28 @@ __global__ __launch_bounds__(256) void k_tr_amsgrad(TrainTensors tt, const doubl
     const int64_t st = (int64_t)gridDim.x * 256;
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     // two elements-of-four per thread and trip: ten 16-byte loads in flight (round 6: five reached 4.9 TB/s on the 1.17 GB of a step)
+    // the three slot streams (m, v, v_hat: read once and written once per step, 0.78 GB of the 1.17) with the non-temporal policy:
+    // they pass the caches without displacing the gradient the products just wrote and the parameter the packs read next
+    // (round 6 A/B, three workloads: - 25 ... - 35 us per step)
+#ifndef COPER_DBG_AMSGRAD_NO_NT
+    typedef float f4v __attribute__((ext_vector_type(4)));
+#define AMS_LD(p_, i_) ([&] { const f4v t = __builtin_nontemporal_load((const f4v*)(p_) + (i_)); return make_float4(t.x, t.y, t.z, t.w); }())
+#define AMS_ST(p_, i_, v_) __builtin_nontemporal_store(f4v{(v_).x, (v_).y, (v_).z, (v_).w}, (f4v*)(p_) + (i_))
+#else
+#define AMS_LD(p_, i_) (((const float4*)(p_))[i_])
+#define AMS_ST(p_, i_, v_) (((float4*)(p_))[i_] = (v_))
+#endif
     for (; i + st < n4; i += 2 * st) {
       const float4 ga = ((const float4*)g)[i], gb = ((const float4*)g)[i + st];
-      float4 ma = ((const float4*)m)[i], va = ((const float4*)v)[i], ha = ((const float4*)vh)[i], pa = ((const float4*)p)[i];
-      float4 mb = ((const float4*)m)[i + st], vb = ((const float4*)v)[i + st], hb = ((const float4*)vh)[i + st], pb4 = ((const float4*)p)[i + st];
+      float4 ma = AMS_LD(m, i), va = AMS_LD(v, i), ha = AMS_LD(vh, i), pa = ((const float4*)p)[i];
+      float4 mb = AMS_LD(m, i + st), vb = AMS_LD(v, i + st), hb = AMS_LD(vh, i + st), pb4 = ((const float4*)p)[i + st];
       upd4(ga, ma, va, ha, pa);
       upd4(gb, mb, vb, hb, pb4);
-      ((float4*)m)[i] = ma; ((float4*)v)[i] = va; ((float4*)vh)[i] = ha; ((float4*)p)[i] = pa;
-      ((float4*)m)[i + st] = mb; ((float4*)v)[i + st] = vb; ((float4*)vh)[i + st] = hb; ((float4*)p)[i + st] = pb4;
+      AMS_ST(m, i, ma); AMS_ST(v, i, va); AMS_ST(vh, i, ha); ((float4*)p)[i] = pa;
+      AMS_ST(m, i + st, mb); AMS_ST(v, i + st, vb); AMS_ST(vh, i + st, hb); ((float4*)p)[i + st] = pb4;
     }
+#undef AMS_LD
+#undef AMS_ST
     for (; i < n4; i += st) {
       const float4 g4 = ((const float4*)g)[i];
       float4 m4 = ((const float4*)m)[i], v4 = ((const float4*)v)[i], h4 = ((const float4*)vh)[i], p4 = ((const float4*)p)[i];
@@ -1699,6 +1838,10 @@ static int train_step_impl(coper_handle* h, const int64_t* e1, const int64_t* re
   hipLaunchKernelGGL(k_tr_fcbn_fwd, dim3((unsigned)((nBd + 255) / 256)), dim3(256), 0, s, T->z1, mean2, inv2, P_("FCBN/gamma"),
                      P_("FCBN/beta"), d, nBd, T->hv);
   const float inv_BL = (float)(1.0 / ((double)B * (double)L));
+  // a training step over a sampled lookup whose dE goes through the dense S matrix: scores, loss, ds and dh from one pass over the rows
+  // (coper_train_forward takes the same kernel: its loss is the step's, bit for bit; the dh it leaves in the workspace is not used)
+  const bool score_dh_fused = !one_vs_all && dense_scorer_bwd && (d & 3) == 0 && d >= 16 && d <= 1024 && L >= 1 && L <= SF_MAX_L &&
+                              (((uintptr_t)ent | (uintptr_t)T->dh | (uintptr_t)T->hv) & 15) == 0;
   if (one_vs_all) {
     if (B * dm.E > T->capS) {
       COPER_HIP_TRY(h, hipStreamSynchronize(s));
@@ -1715,6 +1858,12 @@ static int train_step_impl(coper_handle* h, const int64_t* e1, const int64_t* re
       if (T->exp_cache[i].first == T->Sd) T->exp_cache[i].first = nullptr;
     hipLaunchKernelGGL(k_tr_dense_loss, dim3(2048), dim3(256), 0, s, T->Sd, P_("pred_bias"), labels, dm.E, B * dm.E,
                        tc.label_smoothing_epsilon, (float)(1.0 / (double)dm.E), inv_BL, red);
+  } else if (score_dh_fused) {
+    const int d4 = d >> 2, slots = 256 / d4 > 32 ? 32 : 256 / d4, RB = SF_U * slots;
+    hipLaunchKernelGGL(k_tr_score_loss_dh, dim3((unsigned)B), dim3(256),
+                       sizeof(float4) * (size_t)slots * d4 + sizeof(float) * (size_t)RB * (d4 + 2) + sizeof(int) * (size_t)L, s, T->hv, ent,
+                       P_("pred_bias"), lookup, labels, dm.E, d, (int)L, tc.label_smoothing_epsilon, (float)(1.0 / (double)dm.E), inv_BL, T->ds,
+                       T->dh, red);
   } else {
     hipLaunchKernelGGL(k_tr_score_loss, dim3((unsigned)B), dim3(256), sizeof(float) * d, s, T->hv, ent, P_("pred_bias"), lookup, labels,
                        dm.E, d, L, tc.label_smoothing_epsilon, (float)(1.0 / (double)dm.E), inv_BL, T->ds, red);
@@ -1755,7 +1904,9 @@ static int train_step_impl(coper_handle* h, const int64_t* e1, const int64_t* re
                         G_("ent_emb"), tg_idx(d), tg_idx(1), nullptr, T->smax)))
       return rc;
     // dh by the gather (a [d,B] = [d,|E|] x [|E|,B] GEMM has 8 output tiles and a long K: slower than the gather)
-    if ((d & 3) == 0 && d >= 16 && d <= 1024 && (((uintptr_t)ent | (uintptr_t)T->dh) & 15) == 0)
+    if (score_dh_fused) {
+      // (dh came with the scores: k_tr_score_loss_dh)
+    } else if ((d & 3) == 0 && d >= 16 && d <= 1024 && (((uintptr_t)ent | (uintptr_t)T->dh) & 15) == 0)
       hipLaunchKernelGGL(k_tr_dh_gather4, dim3((unsigned)B), dim3(256), sizeof(float4) * (size_t)(256 / (d >> 2)) * (d >> 2), s, ent, lookup,
                          T->ds, dm.E, d, L, T->dh);
     else
