@@ -6,40 +6,40 @@ launch of at least `--min-us` against its ALGORITHMIC work at FB15k-237 CoPER sh
 
     tools/train_kernel_roofline.py profiles/r06_train_trace.txt [--json out.json]
 
-bytes against 8 TB/s, flops against the 2.5 PF of the 16-bit matrix cores (the x3 arithmetic spends three hardware products per
-product: `hw_frac` = 3 x frac is what the matrix pipe sees)."""
+bytes against 8 TB/s, flops against the 2.5 PF of the 16-bit matrix cores.  The x3 arithmetic spends three hardware products per
+product: for those kernels `frac` prices the hardware products (what the matrix pipe sees), `alg_frac` the algorithm's flops."""
 import json
 import re
 import sys
 
 B, L, d, r, C = 512, 1000, 200, 32, 32
-F = 18 * 18 * C                     # 10368
+F = 8 * 18 * C                      # 4608: the 10 x 20 image under a 3 x 3 VALID conv, 32 channels
 E = 14541
 N_PARAM = 32436293
-P_ELEMS = r * F * d                 # the projection of the fc_weights generator
+P_ELEMS = r * F * d                 # the projection of the fc_weights generator (29.5 M of the 32.4 M parameters)
 HBM, MFMA = 8.0e12, 2.5e15
 
-# kernel -> list of (what, bytes, flops) for its successive launches in a step (the last entry repeats)
+# kernel -> list of (what, bytes, flops, hardware products per product) for its successive launches in a step (the last entry repeats)
 WORK = {
-    "k_tr_amsgrad": [("AMSGrad + clip: p, g, m, v, v_hat read, p, m, v, v_hat written, every trainable element", 9 * 4 * N_PARAM, 0)],
-    "k_gemm_nt_w128_bf16x3": [("T = x P   [B] x [r d], K = F", 4 * (B * F + P_ELEMS + r * B * d), 2.0 * B * r * F * d),
-                              ("dP = x^T dT   [F] x [r d], K = B", 4 * (B * F + r * B * d + P_ELEMS), 2.0 * B * r * F * d),
-                              ("dx = dT P^T   [B] x [F], K = r d", 4 * (r * B * d + P_ELEMS + B * F), 2.0 * B * r * F * d)],
-    "k_gemm_nt_bf16x3": [("dE = S^T h   [E] x [d], K = B", 4 * (B * E + B * d + E * d), 2.0 * B * E * d)],
-    "k_pack_frag_both": [("both 16-bit views of the projection from one read: 118 MB in, 2 x 118 MB out", 4 * P_ELEMS * 3, 0)],
-    "k_tr_score_loss": [("sampled scorer forward: B L rows of d floats gathered (L2-resident table), loss, ds", 4 * B * L * d, 2.0 * B * L * d)],
-    "k_tr_dh_gather4": [("dh = sum_l ds E[row]: the same B L rows gathered again", 4 * B * L * d, 2.0 * B * L * d)],
-    "k_tr_conv_bwd": [("conv backward: dx [B, F] read, image gradients and filter gradients", 4 * (B * F + B * 20 * 20), 2.0 * 2 * B * F * 9)],
-    "k_tr_bn1_bwd_sums": [("BN1 backward sums: y and dx read, dx (ReLU / dropout applied) written", 4 * 3 * B * F, 0)],
-    "k_tr_bn1_bwd_apply": [("BN1 backward apply: y, dx read, dx written", 4 * 3 * B * F, 0)],
-    "k_tr_fc_post_bwd": [("dropout / bias backward of the dense layer, dc_b: dz [B, d], the bias projection", 4 * (2 * B * d + r * d), 2.0 * B * r * d)],
-    "k_tr_fc_post": [("z0 = sum_rho c T[rho] + bias: the forward partials T [r, B, d] read", 4 * (r * B * d + B * d), 2.0 * B * r * d)],
-    "k_tg_reduce": [("split-K partial sums added in slice order", 4 * 2 * B * r * d * 2, 0), ("split-K partial sums (dx)", 4 * 3 * B * F, 0)],
-    "k_tr_col_sums": [("BN1 batch statistics: y [B P, C] read", 4 * B * F, 0), ("FCBN batch statistics", 4 * B * d, 0)],
-    "k_tr_col_sums_add": [("dbias = column sums of S [B, E]", 4 * B * E, 0)],
-    "k_tr_build_S": [("S rows built in LDS, written once", 4 * (B * E + 2 * B * L), 0)],
-    "k_tr_conv_fwd": [("conv forward: images gathered, y [B, F] written", 4 * (B * F + B * 20 * 20), 2.0 * B * F * 9)],
-    "k_tr_bn1_fwd": [("BN1 + ReLU + dropout: y read, x written", 4 * 2 * B * F, 0)],
+    "k_tr_amsgrad": [("AMSGrad + clip: p, g, m, v, v_hat read, p, m, v, v_hat written, every trainable element", 9 * 4 * N_PARAM, 0, 1)],
+    "k_gemm_nt_w128_bf16x3": [("T = x P   [B] x [r d], K = F (five K slices)", 4 * (B * F + P_ELEMS + 5 * r * B * d), 2.0 * B * r * F * d, 3),
+                              ("dP = x^T dT   [F] x [r d], K = B", 4 * (B * F + r * B * d + P_ELEMS), 2.0 * B * r * F * d, 3),
+                              ("dx = dT P^T   [B] x [F], K = r d (seven K slices)", 4 * (r * B * d + P_ELEMS + 7 * B * F), 2.0 * B * r * F * d, 3)],
+    "k_gemm_nt_bf16x3": [("dE = S^T h   [E] x [d], K = B", 4 * (B * E + B * d + E * d), 2.0 * B * E * d, 3)],
+    "k_pack_frag_both": [("both 16-bit views of the projection from one read: 118 MB in, 2 x 118 MB out", 4 * P_ELEMS * 3, 0, 1)],
+    "k_tr_score_loss_dh": [("sampled scorer, forward and dh: B L rows of d floats gathered ONCE (table resident in L2 / MALL), loss, ds", 4 * B * L * d, 4.0 * B * L * d, 1)],
+    "k_tr_conv_bwd": [("conv backward: dx [B, F] read, image gradients and per-query filter gradients", 4 * (B * F + B * 200 + B * 320), 2.0 * 2 * B * F * 9, 1)],
+    "k_tr_bn1_bwd_sums": [("BN1 backward sums: y and dx read, dx (ReLU / dropout applied) written", 4 * 3 * B * F, 0, 1)],
+    "k_tr_bn1_bwd_apply": [("BN1 backward apply: y, dx read, dx written", 4 * 3 * B * F, 0, 1)],
+    "k_tr_fc_post_slices": [("z1 and T from the five K slices of x P: 5 x [B, r d] read, T [r, B, d] and z1 written", 4 * (6 * r * B * d + B * d), 2.0 * B * r * d, 1)],
+    "k_tr_fc_post_bwd": [("dropout / bias backward of the dense layer: dz [B, d]", 4 * 3 * B * d, 0, 1)],
+    "k_tg_reduce": [("the seven K slices of dx added in slice order", 4 * 8 * B * F, 0, 1)],
+    "k_tr_col_sums": [("BN1 batch statistics: y [B P, C] read", 4 * B * F, 0, 1), ("FCBN batch statistics", 4 * B * d, 0, 1)],
+    "k_tr_col_sums_add": [("dbias = column sums of S [B, E]", 4 * B * E, 0, 1)],
+    "k_tr_build_S": [("S rows built in LDS, written once", 4 * (B * E + 2 * B * L), 0, 1)],
+    "k_tr_conv_fwd": [("conv forward: images gathered, y [B, F] written", 4 * (B * F + B * 200), 2.0 * B * F * 9, 1)],
+    "k_tr_bn1_fwd": [("BN1 + ReLU + dropout: y read, x written", 4 * 2 * B * F, 0, 1)],
+    "k_pack_frag": [("an operand's two fp16 planes from its fp32 values", 0, 0, 1)],
 }
 
 
@@ -63,20 +63,23 @@ def main(argv):
         seen[base] = k + 1
         if base not in WORK or us < min_us:
             continue
-        what, by, fl = WORK[base][min(k, len(WORK[base]) - 1)]
-        t_hbm, t_mfma = by / HBM * 1e6, fl / MFMA * 1e6
-        bound = "mfma" if t_mfma > t_hbm else "hbm"
-        floor = max(t_hbm, t_mfma)
+        what, by, fl, prod = WORK[base][min(k, len(WORK[base]) - 1)]
+        if by == 0 and fl == 0:
+            continue
+        t_hbm, t_alg, t_hw = by / HBM * 1e6, fl / MFMA * 1e6, prod * fl / MFMA * 1e6
+        bound = "mfma" if t_hw > t_hbm else "hbm"
+        floor = max(t_hbm, t_hw)
         e = {"kernel": name, "us": us, "what": what, "bound": bound, "floor_us": round(floor, 1), "frac": round(floor / us, 3),
-             "achieved": round(fl / us / 1e6, 1) if bound == "mfma" else round(by / us / 1e3, 1), "unit": "TFLOP/s" if bound == "mfma" else "GB/s"}
-        if bound == "mfma" and "x3" in name:
-            e["hw_frac"] = round(3 * floor / us, 3)
+             "achieved": round(prod * fl / us / 1e6, 1) if bound == "mfma" else round(by / us / 1e3, 1), "unit": "TFLOP/s" if bound == "mfma" else "GB/s"}
+        if prod > 1:      # the x3 arithmetic: three hardware products per product -- `frac` prices the hardware products, `alg_frac` the algorithm's
+            e["alg_frac"] = round(max(t_hbm, t_alg) / us, 3)
+            e["hardware_products"] = prod
         rows.append(e)
     rows.sort(key=lambda e: -e["us"])
     print("%-34s %8s %6s %9s %6s  %s" % ("kernel", "us", "bound", "floor us", "frac", "algorithmic work"))
     for e in rows:
         print("%-34s %8.1f %6s %9.1f %6.3f  %s%s" % (e["kernel"][:34], e["us"], e["bound"], e["floor_us"], e["frac"], e["what"],
-                                                 "  [hardware products: %.2f of the pipe]" % e["hw_frac"] if "hw_frac" in e else ""))
+                                                 "  [x%d hardware products; algorithmic %.2f]" % (e["hardware_products"], e["alg_frac"]) if "alg_frac" in e else ""))
     covered = sum(e["us"] for e in rows)
     print("launches listed: %.1f us of %.1f us of kernels in the step" % (covered, total))
     if out_json:
