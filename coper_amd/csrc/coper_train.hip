@@ -74,7 +74,7 @@ struct TrainState {
   // the other products (static dense layer, 1-vs-all scorer, dE of the dense scorer backward): two operand plane sets and
   // the split-K partial sums, grown on demand
   TgPlanes mmX, mmY;
-  int32_t* tg_exps = nullptr;    // [8 + TR_EXP_CACHE] the exponents of the eight plane sets (train_gemm.h), in the order pX pXt pP1 pP3 pTn pTb mmX mmY,
+  int32_t* tg_exps = nullptr;    // [10 + TR_EXP_CACHE] the exponents of the ten plane sets (train_gemm.h), in the order pX pXt pP1 pP3 pTn pTb mmX mmY mmX2 mmY2,
                                  //   then the words tg_matmul hands out per operand tensor within a step (exp_cache)
   // the largest |W| of the dense weights (the last projection of the fc_weights generator / the static fc_weights), as the OPTIMIZER
   // left it: k_tr_amsgrad folds |p_new| of that leaf into TG_MAX_SLOTS slots while it writes it, the packs of the next step reduce
@@ -90,8 +90,15 @@ struct TrainState {
   // tg_matmul: the exponent of an operand tensor packed earlier in THIS step (x, the static W, dz and S are each packed for two
   // products): (tensor, its word).  Cleared at the start of a step and where a kernel rewrites a tensor in place.
   std::vector<std::pair<const float*, int32_t*>> exp_cache;
-  unsigned* tg_scratch = nullptr;   // [2] the absmax reduction of tg_pack (zero between packs)
+  unsigned* tg_scratch = nullptr;   // [2] the absmax reduction of tg_pack (zero between packs); [2..3]: the side stream's
+  // round 6: a step is not one chain -- the projection's packs do not need the conv, the scorer's backward does not need the dense
+  // layer's.  Those stretches run on a side stream of the state's own, forked from and joined to the caller's stream by events
+  // (under capture they become branches of the graph).  side[0]: the packs in front, the scorer's backward; side[1]: the dP product.
+  hipStream_t side[2] = {nullptr, nullptr};
+  hipEvent_t ev_fork[3] = {nullptr, nullptr, nullptr}, ev_join[3] = {nullptr, nullptr, nullptr};
   size_t mmX_cap = 0, mmY_cap = 0, mmP_cap = 0;
+  TgPlanes mmX2, mmY2;               // tg_matmul's operand planes on the side stream (TrainState::side[0])
+  size_t mmX2_cap = 0, mmY2_cap = 0;
   float* mmP = nullptr;
   float *z0 = nullptr, *z1 = nullptr, *hv = nullptr, *dh = nullptr, *dz = nullptr, *ds = nullptr, *dx = nullptr, *dc = nullptr;
   double* red = nullptr;     // reduction scratch: [0] loss, [1] grad sumsq (total, written by the optimizer kernel), [2..] BN sums, then TG_SUMSQ_SLOTS partial sumsq
@@ -1390,15 +1397,21 @@ static int tg_matmul(coper_handle* h, TrainState* T, hipStream_t s, const MmView
   const size_t nx = tg_plane_elems(M, K), ny = tg_plane_elems(N, K);
   const int nsplit = tg_split_k(M, N, K);
   const size_t np = nsplit > 1 ? (size_t)nsplit * M * N : 0;
-  if (nx > T->mmX_cap || ny > T->mmY_cap || np > T->mmP_cap) {
+  const bool on_side = T->side[0] && s == T->side[0];      // (the caller made sure that no K slices are needed there: one partial-sum pool)
+  TgPlanes& MX = on_side ? T->mmX2 : T->mmX;
+  TgPlanes& MY = on_side ? T->mmY2 : T->mmY;
+  size_t& capX = on_side ? T->mmX2_cap : T->mmX_cap;
+  size_t& capY = on_side ? T->mmY2_cap : T->mmY_cap;
+  if (on_side && nsplit > 1) return fail(h, COPER_ESTATE, "tg_matmul: a product with K slices on the side stream");
+  if (nx > capX || ny > capY || np > T->mmP_cap) {
     COPER_HIP_TRY(h, hipStreamSynchronize(s));
-    if (nx > T->mmX_cap) {
-      if ((rc = talloc(h, &T->mmX.hi, nx)) || (rc = talloc(h, &T->mmX.lo, nx))) return rc;
-      T->mmX_cap = nx;
+    if (nx > capX) {
+      if ((rc = talloc(h, &MX.hi, nx)) || (rc = talloc(h, &MX.lo, nx))) return rc;
+      capX = nx;
     }
-    if (ny > T->mmY_cap) {
-      if ((rc = talloc(h, &T->mmY.hi, ny)) || (rc = talloc(h, &T->mmY.lo, ny))) return rc;
-      T->mmY_cap = ny;
+    if (ny > capY) {
+      if ((rc = talloc(h, &MY.hi, ny)) || (rc = talloc(h, &MY.lo, ny))) return rc;
+      capY = ny;
     }
     if (np > T->mmP_cap) {
       if ((rc = talloc(h, &T->mmP, np))) return rc;
@@ -1407,20 +1420,21 @@ static int tg_matmul(coper_handle* h, TrainState* T, hipStream_t s, const MmView
   }
   // an operand tensor packed earlier in this step keeps its power of two (its own word from the pool behind the plane sets' eight):
   // no second pass for the maximum.  A tensor with producer-side maxima (slots) needs no pass at all.
-  TgPlanes px = T->mmX, py = T->mmY;
+  TgPlanes px = MX, py = MY;
+  unsigned* const scratch = on_side ? T->tg_scratch + 2 : T->tg_scratch;
   auto pack = [&](const MmView& V, int64_t rows, TgPlanes& pl, const unsigned* slots) -> int {
     const int32_t* from = nullptr;
     for (auto& e : T->exp_cache)
       if (e.first == V.p) from = e.second;
     if (from) {
       pl.exp = const_cast<int32_t*>(from);
-      return tg_pack(h, V.p, V.ri, V.ki, rows, K, tg_rows_pad(rows), V.rows_fast, pl, s, T->tg_scratch, from);
+      return tg_pack(h, V.p, V.ri, V.ki, rows, K, tg_rows_pad(rows), V.rows_fast, pl, s, scratch, from);
     }
     if ((int)T->exp_cache.size() < TR_EXP_CACHE) {
-      pl.exp = T->tg_exps + 8 + T->exp_cache.size();
+      pl.exp = T->tg_exps + 10 + T->exp_cache.size();
       T->exp_cache.emplace_back(V.p, pl.exp);
     }
-    return tg_pack(h, V.p, V.ri, V.ki, rows, K, tg_rows_pad(rows), V.rows_fast, pl, s, T->tg_scratch, nullptr, slots);
+    return tg_pack(h, V.p, V.ri, V.ki, rows, K, tg_rows_pad(rows), V.rows_fast, pl, s, scratch, nullptr, slots);
   };
   if ((rc = pack(X, M, px, x_slots)) || (rc = pack(Y, N, py, y_slots))) return rc;
   return tg_gemm_nt(h, px, M, py, N, K, C, ci, cj, s, nsplit, T->mmP, sumsq);
@@ -1453,9 +1467,15 @@ void train_destroy(coper_handle* h) {
   (void)tracked_free(T->red);
   if (T->tg_exps) (void)tracked_free(T->tg_exps);
   if (T->tg_scratch) (void)tracked_free(T->tg_scratch);
+  for (hipStream_t& st : T->side)
+    if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); st = nullptr; }
+  for (int i = 0; i < 3; ++i) {
+    if (T->ev_fork[i]) (void)hipEventDestroy(T->ev_fork[i]);
+    if (T->ev_join[i]) (void)hipEventDestroy(T->ev_join[i]);
+  }
   for (unsigned* w : {T->wmax[0], T->wmax[1], T->xmax, T->dtmax, T->smax})
     if (w) (void)tracked_free(w);
-  for (TgPlanes* pl : {&T->mmX, &T->mmY}) {
+  for (TgPlanes* pl : {&T->mmX, &T->mmY, &T->mmX2, &T->mmY2}) {
     if (pl->hi) (void)tracked_free(pl->hi);
     if (pl->lo) (void)tracked_free(pl->lo);
   }
@@ -1552,18 +1572,28 @@ COPER_API int coper_train_init(coper_handle* h, const coper_train_config* cfg) {
   for (int i = 0; i < T->nhc; ++i) mx = h->cfg.ctx_conv[i] > mx ? h->cfg.ctx_conv[i] : mx;
   if ((rc = talloc(h, &T->bnst, (size_t)4 * mx))) return rc;
   if ((rc = talloc(h, &T->red, (size_t)(2 + 2 * mx * TR_COLSUM_SLICES + TG_SUMSQ_SLOTS + 2 * TR_CS_SLOTS * 2 * mx)))) return rc;
-  if ((rc = talloc(h, &T->tg_exps, (size_t)(8 + TR_EXP_CACHE))) || (rc = talloc(h, &T->tg_scratch, (size_t)2)) ||
+  if ((rc = talloc(h, &T->tg_exps, (size_t)(10 + TR_EXP_CACHE))) || (rc = talloc(h, &T->tg_scratch, (size_t)4)) ||
       (rc = talloc(h, &T->wmax[0], (size_t)TG_MAX_SLOTS)) || (rc = talloc(h, &T->wmax[1], (size_t)TG_MAX_SLOTS)) ||
       (rc = talloc(h, &T->xmax, (size_t)TG_MAX_SLOTS)) || (rc = talloc(h, &T->dtmax, (size_t)TG_MAX_SLOTS)) ||
       (rc = talloc(h, &T->smax, (size_t)TG_MAX_SLOTS)))
     return rc;
-  COPER_HIP_TRY(h, hipMemset(T->tg_exps, 0, (8 + TR_EXP_CACHE) * sizeof(int32_t)));
+  COPER_HIP_TRY(h, hipMemset(T->tg_exps, 0, (10 + TR_EXP_CACHE) * sizeof(int32_t)));
   COPER_HIP_TRY(h, hipMemset(T->wmax[0], 0, TG_MAX_SLOTS * sizeof(unsigned)));
   COPER_HIP_TRY(h, hipMemset(T->wmax[1], 0, TG_MAX_SLOTS * sizeof(unsigned)));
-  COPER_HIP_TRY(h, hipMemset(T->tg_scratch, 0, 2 * sizeof(unsigned)));
+  COPER_HIP_TRY(h, hipMemset(T->tg_scratch, 0, 4 * sizeof(unsigned)));
   {
-    TgPlanes* sets[8] = {&T->pX, &T->pXt, &T->pP1, &T->pP3, &T->pTn, &T->pTb, &T->mmX, &T->mmY};
-    for (int i = 0; i < 8; ++i) sets[i]->exp = T->tg_exps + i;
+    static const bool one_stream = getenv("COPER_TRAIN_ONE_STREAM") != nullptr;   // A/B switch: the step as one chain
+    if (!one_stream) {
+      for (hipStream_t& st : T->side) COPER_HIP_TRY(h, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+      for (int i = 0; i < 3; ++i) {
+        COPER_HIP_TRY(h, hipEventCreateWithFlags(&T->ev_fork[i], hipEventDisableTiming));
+        COPER_HIP_TRY(h, hipEventCreateWithFlags(&T->ev_join[i], hipEventDisableTiming));
+      }
+    }
+  }
+  {
+    TgPlanes* sets[10] = {&T->pX, &T->pXt, &T->pP1, &T->pP3, &T->pTn, &T->pTb, &T->mmX, &T->mmY, &T->mmX2, &T->mmY2};
+    for (int i = 0; i < 10; ++i) sets[i]->exp = T->tg_exps + i;
   }
   return COPER_OK;
 }
@@ -1605,6 +1635,24 @@ static int train_step_impl(coper_handle* h, const int64_t* e1, const int64_t* re
   const Dims& dm = h->dm;
   hipStream_t s = (hipStream_t)stream;
   COPER_HIP_TRY(h, hipSetDevice(h->cfg.device));
+  // the side streams (TrainState::side): fork(i, k) lets side[k] start behind everything queued on s so far, join(i) lets s go on
+  // behind what side[k] was given since.  Whatever leaves this function early joins what it forked (SideJoin).
+  struct SideJoin {
+    TrainState* T; hipStream_t s; int on[3] = {-1, -1, -1};
+    void fork(int i, int k) {
+      (void)hipEventRecord(T->ev_fork[i], s);
+      (void)hipStreamWaitEvent(T->side[k], T->ev_fork[i], 0);
+      on[i] = k;
+    }
+    void join(int i) {
+      if (on[i] < 0) return;
+      (void)hipEventRecord(T->ev_join[i], T->side[on[i]]);
+      (void)hipStreamWaitEvent(s, T->ev_join[i], 0);
+      on[i] = -1;
+    }
+    ~SideJoin() { for (int i = 0; i < 3; ++i) join(i); }
+  } sj{T, s};
+  const bool two_streams = T->side[0] != nullptr;
   if (apply) h->prepared = false;   // the variables change: per-relation caches, fragment images and folded BN go stale
   const coper_train_config& tc = T->cfg;
   const int d = dm.d, r = dm.r, C = dm.C, P = dm.Ho * dm.Wo, isz = dm.in_h * dm.in_w, NT = dm.fh * dm.fw;   // NT: filter taps
@@ -1805,6 +1853,8 @@ static int train_step_impl(coper_handle* h, const int64_t* e1, const int64_t* re
       if ((rc = tg_pack(h, xin, tg_idx(F), tg_idx(1), B, F, tg_rows_pad(B), false, T->pX, s, T->tg_scratch, nullptr, x_slots))) return rc;
       // the projection is an operand of two products, contracted over f here and over (rho, k) in dx: a training step packs BOTH
       // views from one read (tg_pack_both: 118 MB read once instead of twice, one launch instead of two)
+      // (round 6 also ran this pack on a side stream beside the conv / Conv1BN launches in front of it: the stream takes the memory
+      //  system, k_tr_bn1_fwd beside it 38 us for 9 -- 5 us gained, not kept)
       if (apply && (d & 3) == 0 && (((uintptr_t)Wmat) & 15) == 0) {
         if ((rc = tg_pack_both(h, Wmat, tg_idx(d), tg_idx2(d, F * (int64_t)d, 1), F, nrk, T->pP3, T->pP1, s, T->tg_scratch, w_slots))) return rc;
         p3_packed = true;
@@ -1890,6 +1940,12 @@ static int train_step_impl(coper_handle* h, const int64_t* e1, const int64_t* re
                         T->dh, tg_idx(d), tg_idx(1))))
       return rc;
   } else if (dense_scorer_bwd) {
+    // the scorer's backward (S, dbias, dE = S^T h: ~70 us of launches that need ds and h only) beside the dense layer's: on the side
+    // stream (tg_matmul packs into a second pair of plane sets there) when dE needs no K slices (the partial-sum pool is the dx
+    // product's); joined in front of the conv backward, which adds the e1 rows to dE
+    const bool sb_side = two_streams && score_dh_fused && tg_split_k(dm.E, d, B) == 1;
+    hipStream_t const s_main = s;
+    if (sb_side) { sj.fork(1, 0); s = T->side[0]; }
     {
       const size_t lds_s = sizeof(float) * (size_t)(dm.E < TR_S_CHUNK ? dm.E : TR_S_CHUNK);
       // (the kernel also holds 16 bytes of static LDS: asking for the whole 160 KB as dynamic is refused, and so is the launch after it)
@@ -1903,6 +1959,7 @@ static int train_step_impl(coper_handle* h, const int64_t* e1, const int64_t* re
     if ((rc = tg_matmul(h, T, s, MmView{T->Sd, tg_idx(1), tg_idx(dm.E), true}, dm.E, MmView{T->hv, tg_idx(1), tg_idx(d), true}, d, B,
                         G_("ent_emb"), tg_idx(d), tg_idx(1), nullptr, T->smax)))
       return rc;
+    s = s_main;
     // dh by the gather (a [d,B] = [d,|E|] x [|E|,B] GEMM has 8 output tiles and a long K: slower than the gather)
     if (score_dh_fused) {
       // (dh came with the scores: k_tr_score_loss_dh)
@@ -1944,11 +2001,15 @@ static int train_step_impl(coper_handle* h, const int64_t* e1, const int64_t* re
     // (x and the projection were packed for the forward pass: the same tensors, the same powers of two -- no second reduction)
     if ((rc = tg_pack(h, xin, tg_idx(1), tg_idx(F), F, B, tg_rows_pad(F), true, T->pXt, s, T->tg_scratch, T->pX.exp))) return rc;
     if ((rc = tg_pack(h, dTf, tg_idx2(d, nBd, 1), tg_idx(d), nrk, B, tg_rows_pad(nrk), true, T->pTn, s, T->tg_scratch, nullptr, T->dtmax))) return rc;
-    if ((rc = tg_gemm_nt(h, T->pXt, F, T->pTn, nrk, B, dW, tg_idx(d), tg_idx2(d, F * (int64_t)d, 1), s, 1, nullptr, ssq))) return rc;
-    sumsq_done = wlast;   // the GEMM added |dP|^2 to the global-norm accumulator as it stored
     if ((rc = tg_pack(h, dTf, tg_idx(d), tg_idx2(d, nBd, 1), B, nrk, tg_rows_pad(B), false, T->pTb, s, T->tg_scratch, T->pTn.exp))) return rc;
     if (!p3_packed && (rc = tg_pack(h, Wmat, tg_idx(d), tg_idx2(d, F * (int64_t)d, 1), F, nrk, tg_rows_pad(F), false, T->pP3, s, T->tg_scratch, T->pP1.exp))) return rc;
     if ((rc = tg_gemm_split(h, T, s, T->pTb, B, T->pP3, F, nrk, dxin, tg_idx(F), tg_idx(1)))) return rc;
+    // the dP product's result is read by the optimizer only: BEHIND the dx product, on the second side stream, beside the dozen short
+    // launches between here and the optimizer (slice sum, Conv1BN and conv backward, the generators' chains).  (Beside the dx product
+    // itself the two took 211 us for 100 + 84: a SIMD holds one wave of either.)
+    if (two_streams) sj.fork(2, 1);
+    if ((rc = tg_gemm_nt(h, T->pXt, F, T->pTn, nrk, B, dW, tg_idx(d), tg_idx2(d, F * (int64_t)d, 1), two_streams ? T->side[1] : s, 1, nullptr, ssq))) return rc;
+    sumsq_done = wlast;   // the GEMM added |dP|^2 to the global-norm accumulator as it stored
     hipLaunchKernelGGL(k_tr_dc_from_partials, dim3((unsigned)((B * rc_w + 3) / 4)), dim3(256), 0, s, T->dz, Tf, B, rc_w, d, dcw);
   } else {
     // static dense layer (plain ConvE): dW[F,d] = x^T dz and dx[B,F] = dz W^T
@@ -1994,6 +2055,7 @@ static int train_step_impl(coper_handle* h, const int64_t* e1, const int64_t* re
                      colsum, C, nBF, (double)B * P, use_batch, G_("Conv1BN/gamma"), G_("Conv1BN/beta"));
   size_t lds_cb = sizeof(float) * (size_t)(isz + (size_t)P * (C + 1) + NT * C);
   if (lds_cb > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_tr_conv_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  sj.join(1);      // (dE = S^T h is stored: the conv backward adds the e1 rows to it)
   hipLaunchKernelGGL(k_tr_conv_bwd, dim3((unsigned)B), dim3(256), lds_cb, s, T->dx, T->img, dm.gen_conv ? nullptr : P_("conv1_weights"), e1, rel,
                      dm.E, dm.R, d, r, dm.in_h, dm.in_w, dm.stacked ? 1 : 0, C, dm.Ho, dm.Wo, G_("ent_emb"),
                      dm.lookup ? nullptr : G_("rel_emb"), K_ps, T->dKs, T->dkbs, dm.fh, dm.fw);
@@ -2049,6 +2111,7 @@ static int train_step_impl(coper_handle* h, const int64_t* e1, const int64_t* re
   int skip = -1;
   for (int i = 0; i < np; ++i)
     if (!sumsq_done.empty() && T->tp[i].name == sumsq_done) skip = i;
+  sj.join(2);      // (dP and its squared norm)
   hipLaunchKernelGGL(k_tr_sumsq, dim3(512, (unsigned)np), dim3(256), 0, s, tt, skip, ssq);
   const float lr_t = (float)((double)tc.learning_rate * std::sqrt(1.0 - T->b2p) / (1.0 - T->b1p));
   hipLaunchKernelGGL(k_tr_amsgrad, dim3(2048, (unsigned)np), dim3(256), 0, s, tt, ssq, red + 1, tc.clip_norm, lr_t, tc.beta1, tc.beta2,
