@@ -666,3 +666,58 @@ def test_training_steps_between_streamed_evaluation_passes():
             assert np.array_equal(got_b, plain(db)), (case, rep)   # (on the NEW weights: nothing of the old grouping or planes was used)
             host.fill_(-1)
         m.close()
+
+
+_SIDE_CHILD = r"""
+import json, sys
+import numpy as np, torch
+sys.path.insert(0, %(root)r)
+from tests.test_gpu_train import _run_few_steps
+print("RESULT " + json.dumps(_run_few_steps(%(names)r)))
+"""
+
+
+def _run_few_steps(names):
+    """Three training steps of each case from seeded variables: the losses and every variable afterwards (as lists)."""
+    from coper_amd.models import ConvE
+    out = {}
+    for name in names:
+        md = dict(cdata._COMMON)
+        md.update(_CASES[name])
+        md.update(batch_norm_train_stats=True, batch_norm_momentum=0.9, hidden_dropout=0.3, output_dropout=0.2, label_smoothing_epsilon=0.1,
+                  learning_rate=0.003)
+        p0 = cdata.synthetic_params(md, seed=33, ent_std=0.1)
+        m = ConvE(md, device="cuda:0")
+        m.load_parameters({k: torch.as_tensor(np.array(v, np.float32)) for k, v in p0.items()})
+        m.train_init(seed=9)
+        losses = [float(m.train_step(_batch(md, 96, 53, seed=300 + i)).cpu()[0]) for i in range(3)]
+        out[name] = dict(losses=losses, variables={k: m._tensors[k].cpu().numpy().reshape(-1).astype(np.float64).tolist() for k in sorted(p0)})
+        m.close()
+    return out
+
+
+def test_side_streams_change_the_schedule_only():
+    """Round 6: a step forks the scorer's backward and the dP product onto side streams of the training state.  A fresh process with
+    COPER_TRAIN_ONE_STREAM=1 runs the same steps as one chain: the same losses and variables (up to the order of the step's float
+    atomics, which neither schedule fixes)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = ["cpg_wide", "plain_wide", "lookup", "cpg_conv_mlp", "cpg_linear_e20k"]
+    env = dict(os.environ, COPER_TRAIN_ONE_STREAM="1")
+    child = subprocess.run([sys.executable, "-c", _SIDE_CHILD % dict(root=root, names=names)], env=env, capture_output=True, text=True, timeout=600)
+    assert child.returncode == 0, child.stderr[-4000:]
+    one = json.loads([ln for ln in child.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+    assert "COPER_TRAIN_ONE_STREAM" not in os.environ
+    two = _run_few_steps(names)
+    for name in names:
+        for a, b in zip(one[name]["losses"], two[name]["losses"]):
+            assert abs(a - b) <= 1e-6 * max(1.0, abs(a)), (name, a, b)
+        bias_gap = 0.0
+        if "conv1_bias" in one[name]["variables"]:
+            bias_gap = np.abs(np.array(one[name]["variables"]["conv1_bias"]) - np.array(two[name]["variables"]["conv1_bias"])).max()
+        for k, va in one[name]["variables"].items():
+            if k == "conv1_bias":      # exact gradient 0 under batch-statistics BN: its steps are rounding noise (see _train_step_case)
+                continue
+            va, vb = np.array(va), np.array(two[name]["variables"][k])
+            tol = 1e-5 * max(1.0, np.abs(va).max()) + (bias_gap if k == "Conv1BN/moving_mean" else 0.0)
+            assert np.abs(va - vb).max() <= tol, (name, k, np.abs(va - vb).max(), tol)
