@@ -440,7 +440,10 @@ COPER_API int coper_train_init(coper_handle* h, const coper_train_config* cfg);
  * The registered tensors ARE the variables and the step keeps facts about them from one step to the next (round 6: the largest
  * magnitude of the dense weights, noted by the optimizer's pass as it writes them, is what the next step's operand packing scales
  * by).  A caller that changes parameter CONTENTS between steps by other means than this call registers the tensor again
- * (coper_set_param on the same pointer is enough; coper_amd.ConvE.load_parameters does) -- as coper_prepare asks for inference. */
+ * (coper_set_param on the same pointer is enough; coper_amd.ConvE.load_parameters does) -- as coper_prepare asks for inference.
+ * Ordering: to the caller the step is one sequence of launches on `stream`.  Inside, two stretches that do not depend on the chain
+ * beside them (the scorer's backward; the projection gradient's product) run on streams of the training state's own, forked from
+ * `stream` and joined to it by events before the call returns -- nothing of the step is left outside `stream`'s order. */
 COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t* rel, const int32_t* lookup,
                                const float* labels, int64_t B, int64_t L, float* loss_out, void* stream);
 /* The train-mode graph WITHOUT the update: what `session.run(model.loss)` or `session.run(model.predictions_lookup)` under
