@@ -452,7 +452,7 @@ __global__ __launch_bounds__(256) void k_tr_score_loss_dh(const float* __restric
   extern __shared__ float4 sf_lds[];   // float4 [slots][d4] (the slots' dh shares at the end) | float part[RB][d4 + 1] | float g[RB] | int ids[L]
   __shared__ double red[256];
   const int64_t b = blockIdx.x;
-  const int d4 = d >> 2, slots = 256 / d4 > 32 ? 32 : 256 / d4, RB = SF_U * slots, PS = d4 + 1;      // (RB <= 256)
+  const int d4 = d >> 2, slots = 256 / d4 > 256 / SF_U ? 256 / SF_U : 256 / d4, RB = SF_U * slots, PS = d4 + 1;      // (RB <= 256: a thread per row of a batch)
   // threads that share a row's sum of partial products (a power of two, neighbours in a wave)
   const int tpr = 256 / RB >= 8 ? 8 : (256 / RB >= 4 ? 4 : (256 / RB >= 2 ? 2 : 1));
   float* part = (float*)(sf_lds + slots * d4);
@@ -1909,7 +1909,7 @@ static int train_step_impl(coper_handle* h, const int64_t* e1, const int64_t* re
     hipLaunchKernelGGL(k_tr_dense_loss, dim3(2048), dim3(256), 0, s, T->Sd, P_("pred_bias"), labels, dm.E, B * dm.E,
                        tc.label_smoothing_epsilon, (float)(1.0 / (double)dm.E), inv_BL, red);
   } else if (score_dh_fused) {
-    const int d4 = d >> 2, slots = 256 / d4 > 32 ? 32 : 256 / d4, RB = SF_U * slots;
+    const int d4 = d >> 2, slots = 256 / d4 > 256 / SF_U ? 256 / SF_U : 256 / d4, RB = SF_U * slots;
     hipLaunchKernelGGL(k_tr_score_loss_dh, dim3((unsigned)B), dim3(256),
                        sizeof(float4) * (size_t)slots * d4 + sizeof(float) * (size_t)RB * (d4 + 2) + sizeof(int) * (size_t)L, s, T->hv, ent,
                        P_("pred_bias"), lookup, labels, dm.E, d, (int)L, tc.label_smoothing_epsilon, (float)(1.0 / (double)dm.E), inv_BL, T->ds,

@@ -121,7 +121,14 @@ def test_train_step_matches_oracle_from_the_reference_init(name):
     _train_step_case(name, True, False, "reference")
 
 
-def _train_step_case(name, train_stats, one_vs_all, init):
+@pytest.mark.parametrize("name,L", [("cpg_linear", 700), ("plain", 301), ("cpg_wide", 1000), ("fuzz_d288", 259)])
+def test_train_step_matches_oracle_with_long_lookups(name, L):
+    """Lookups longer than a workgroup (k_tr_score_loss_dh takes the rows of a query in batches of <= 256, a thread per row of the
+    batch when it scores them: at d = 40 a batch is 252 rows, at d = 200 60) -- the sampled cases above have L = 37."""
+    _train_step_case(name, True, False, "n0.1", B=24, L=L, steps=2)
+
+
+def _train_step_case(name, train_stats, one_vs_all, init, B=48, L=37, steps=3):
     from coper_amd.models import ConvE
     from oracle import coper_train_oracle as T
     md = dict(cdata._COMMON)
@@ -129,7 +136,7 @@ def _train_step_case(name, train_stats, one_vs_all, init):
     md.update(batch_norm_train_stats=train_stats, batch_norm_momentum=0.9, hidden_dropout=0.3, output_dropout=0.2,
               label_smoothing_epsilon=0.1, learning_rate=0.003)
     p0 = cdata.synthetic_params(md, seed=21, ent_std=0.1) if init == "n0.1" else cdata.reference_init_params(md, 21)
-    B, L, seed = 48, 37, 5
+    seed = 5
     m = ConvE(md, device="cuda:0")
     m.load_parameters({k: torch.as_tensor(np.array(v, np.float32)) for k, v in p0.items()})
     m.train_init(seed=seed)
@@ -138,7 +145,7 @@ def _train_step_case(name, train_stats, one_vs_all, init):
     # the wide and the random-shape cases restart the oracle from the device's variables before every step, so that each step is held to the
     # step-0 bounds (the other cases let the two trajectories run free and bound the Adam-amplified drift instead)
     sync = name.endswith("_wide") or name.startswith("fuzz_")
-    for step in range(3):
+    for step in range(steps):
         batch = _batch(md, B, L, seed=100 + step)
         if sync and step > 0:
             for k in ref:
