@@ -189,30 +189,46 @@ static bool tg_vec_ok(const float* src, const TgIdx& fast, const TgIdx& slow, in
 // A workgroup loads a 32 x 128 tile (32 rows i, 128 consecutive k, four per thread as one 16-byte load) into LDS and emits the
 // eight (row block, k-step) fragment blocks of view A and the eight (4 row blocks of k) x (2 k-steps of i) blocks of view B.
 // ------------------------------------------------------------------------------------------------
+// Round 6: a workgroup takes PB_TPW row blocks one after the other (the next block's loads are requested before this one's fragments
+// are formed; the reduction of the 1,024 maximum slots -- 4 KB per workgroup, a shuffle sum and a barrier -- once per workgroup).
+constexpr int PB_TPW = 4;
 __global__ __launch_bounds__(256) void k_pack_frag_both(const float* __restrict__ src, TgIdx ri, TgIdx ki, int64_t R, int64_t K,
                                                         int KS16_A, int KST_A, uint4* __restrict__ ahi, uint4* __restrict__ alo,
                                                         int KS16_B, int KST_B, uint4* __restrict__ bhi, uint4* __restrict__ blo,
                                                         const int32_t* __restrict__ exp_dev, int32_t* __restrict__ exp_a,
-                                                        int32_t* __restrict__ exp_b, const unsigned* __restrict__ max_slots) {
+                                                        int32_t* __restrict__ exp_b, const unsigned* __restrict__ max_slots, int n_rb) {
   constexpr int RT = 32, KT = 128;
-  __shared__ float tile[RT][KT + 1];
-  const int64_t row0 = (int64_t)blockIdx.y * RT, k0 = (int64_t)blockIdx.x * KT;
+  __shared__ float tile[2][RT][KT + 1];
+  const int64_t k0 = (int64_t)blockIdx.x * KT;
   const int t = threadIdx.x;
+  const int rb0 = blockIdx.y * PB_TPW, rb1 = rb0 + PB_TPW < n_rb ? rb0 + PB_TPW : n_rb;
+  float4 v[4];
+  auto fetch = [&](int rb) {
+    const int64_t row0 = (int64_t)rb * RT;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int e = t + 256 * i, row = e / (KT / 4), kk = (e % (KT / 4)) * 4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row0 + row < R && k0 + kk < K) v = *(const float4*)(src + tg_off(ri, row0 + row) + tg_off(ki, k0 + kk));   // (K % 4 == 0: host)
-    tile[row][kk] = v.x; tile[row][kk + 1] = v.y; tile[row][kk + 2] = v.z; tile[row][kk + 3] = v.w;
-  }
+    for (int i = 0; i < 4; ++i) {
+      const int e = t + 256 * i, row = e / (KT / 4), kk = (e % (KT / 4)) * 4;
+      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row0 + row < R && k0 + kk < K) v[i] = *(const float4*)(src + tg_off(ri, row0 + row) + tg_off(ki, k0 + kk));   // (K % 4 == 0: host)
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = t + 256 * i, row = e / (KT / 4), kk = (e % (KT / 4)) * 4;
+      tile[buf][row][kk] = v[i].x; tile[buf][row][kk + 1] = v[i].y; tile[buf][row][kk + 2] = v[i].z; tile[buf][row][kk + 3] = v[i].w;
+    }
+  };
+  fetch(rb0);
   __shared__ unsigned s_mx[4];
   if (max_slots) {
     unsigned mx = 0u;
-    for (int i = t; i < TG_MAX_SLOTS; i += 256) { const unsigned v = max_slots[i]; mx = v > mx ? v : mx; }
+    for (int i = t; i < TG_MAX_SLOTS; i += 256) { const unsigned w = max_slots[i]; mx = w > mx ? w : mx; }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const unsigned u = __shfl_xor(mx, o, 64); mx = u > mx ? u : mx; }
     if ((t & 63) == 0) s_mx[t >> 6] = mx;
   }
+  stash(0);
   __syncthreads();
   int pe;
   if (max_slots) {
@@ -222,39 +238,47 @@ __global__ __launch_bounds__(256) void k_pack_frag_both(const float* __restrict_
     pe = *exp_dev;
   }
   if (blockIdx.x == 0 && blockIdx.y == 0 && t == 0) { *exp_a = pe; *exp_b = pe; }
+  for (int rb = rb0; rb < rb1; ++rb) {
+    const int buf = (rb - rb0) & 1;
+    if (rb + 1 < rb1) fetch(rb + 1);
 #pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    const int f = t + 256 * p, blk = f >> 6, l = f & 63;
-    // view A: row block blockIdx.y, k-steps 8 blockIdx.x + blk
-    {
-      const int64_t ks = (int64_t)blockIdx.x * (KT / 16) + blk;
-      if (ks < KS16_A) {
-        const int row = l & 31, kb = 16 * blk + 8 * (l >> 5);
-        float v[8];
+    for (int p = 0; p < 2; ++p) {
+      const int f = t + 256 * p, blk = f >> 6, l = f & 63;
+      // view A: row block rb, k-steps 8 blockIdx.x + blk
+      {
+        const int64_t ks = (int64_t)blockIdx.x * (KT / 16) + blk;
+        if (ks < KS16_A) {
+          const int row = l & 31, kb = 16 * blk + 8 * (l >> 5);
+          float w[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = tile[row][kb + j];
-        uint4 h4, l4;
-        tg_split8(v, pe, h4, l4);
-        const int64_t o = ((int64_t)blockIdx.y * KST_A + ks) * 64 + l;
-        ahi[o] = h4;
-        alo[o] = l4;
+          for (int j = 0; j < 8; ++j) w[j] = tile[buf][row][kb + j];
+          uint4 h4, l4;
+          tg_split8(w, pe, h4, l4);
+          const int64_t o = ((int64_t)rb * KST_A + ks) * 64 + l;
+          ahi[o] = h4;
+          alo[o] = l4;
+        }
+      }
+      // view B: rows are the k of this tile (four blocks of 32), the contraction runs over the tile's 32 rows i (two k-steps)
+      {
+        const int rbb = blk >> 1, ksl = blk & 1;
+        const int64_t ks = (int64_t)rb * (RT / 16) + ksl;
+        if (ks < KS16_B) {
+          const int col = 32 * rbb + (l & 31), ib = 16 * ksl + 8 * (l >> 5);
+          float w[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) w[j] = tile[buf][ib + j][col];
+          uint4 h4, l4;
+          tg_split8(w, pe, h4, l4);
+          const int64_t o = (((int64_t)blockIdx.x * (KT / 32) + rbb) * KST_B + ks) * 64 + l;
+          bhi[o] = h4;
+          blo[o] = l4;
+        }
       }
     }
-    // view B: rows are the k of this tile (four blocks of 32), the contraction runs over the tile's 32 rows i (two k-steps)
-    {
-      const int rb = blk >> 1, ksl = blk & 1;
-      const int64_t ks = (int64_t)blockIdx.y * (RT / 16) + ksl;
-      if (ks < KS16_B) {
-        const int col = 32 * rb + (l & 31), ib = 16 * ksl + 8 * (l >> 5);
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = tile[ib + j][col];
-        uint4 h4, l4;
-        tg_split8(v, pe, h4, l4);
-        const int64_t o = (((int64_t)blockIdx.x * (KT / 32) + rb) * KST_B + ks) * 64 + l;
-        bhi[o] = h4;
-        blo[o] = l4;
-      }
+    if (rb + 1 < rb1) {
+      stash(buf ^ 1);      // (the other buffer: its readers finished before the barrier at the end of the previous trip)
+      __syncthreads();
     }
   }
 }
@@ -274,9 +298,10 @@ int tg_pack_both(coper_handle* h, const float* src, TgIdx ri, TgIdx ki, int64_t 
   const int KS16_A = (int)((K + 15) / 16), KST_A = (int)tg_ks_stride(K), KS16_B = (int)((R + 15) / 16), KST_B = (int)tg_ks_stride(R);
   // rows of view B beyond K (up to its TG_ROW_PAD padding) and k-steps beyond KS16 are never read by the GEMM's stores, but its
   // loads touch whole row blocks: the tile grid covers them (bounds-checked loads write zeros)
-  dim3 grid((unsigned)(tg_rows_pad(K) / 128), (unsigned)(tg_rows_pad(R) / 32));
+  const int n_rb = (int)(tg_rows_pad(R) / 32);
+  dim3 grid((unsigned)(tg_rows_pad(K) / 128), (unsigned)((n_rb + PB_TPW - 1) / PB_TPW));
   hipLaunchKernelGGL(k_pack_frag_both, grid, dim3(256), 0, s, src, ri, ki, R, K, KS16_A, KST_A, a.hi, a.lo, KS16_B, KST_B, b.hi, b.lo, a.exp,
-                     a.exp, b.exp, max_slots);
+                     a.exp, b.exp, max_slots, n_rb);
   COPER_HIP_TRY(h, hipGetLastError());
   return COPER_OK;
 }

@@ -413,4 +413,5 @@ def test_random_interleavings_with_training_steps():
     md.update(_TRAIN_MD)
     md.update(batch_norm_train_stats=True, batch_norm_momentum=0.9, learning_rate=0.003, use_negative_sampling=True)
     p = cdata.synthetic_params(md, seed=8, ent_std=0.1)
-    _run_sequences(md, p, 400, n_seq=80, n_ops=24, seed=9, train=True)
+    # (COPER_PIPELINE_TRAIN_SEQS: the same as a soak -- round 6's training step forks onto side streams of its own)
+    _run_sequences(md, p, 400, n_seq=int(os.environ.get("COPER_PIPELINE_TRAIN_SEQS", "80")), n_ops=24, seed=int(os.environ.get("COPER_PIPELINE_TRAIN_SEED", "9")), train=True)
