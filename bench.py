@@ -86,6 +86,37 @@ def _profile_entry(pattern, workload, Q, kernel, exact=None):
     return None, None
 
 
+def run_train_lines(budget_s=150.0):
+    """SURVEY 8(f)-1 beside the line: the training step (B = 512 queries x L = 1000 sampled entities: forward, backward, clip,
+    AMSGrad) of the three shipped model shapes, each timed by `tools/bench_train.py` in a child process of its own (a fresh
+    training state; this process has finished its timed regions).  Reported, not part of `value`.  Skipped under a profiler
+    (the children would be traced too) and when the budget runs out."""
+    import subprocess
+    if any(k.startswith(("ROCPROF", "ROCP_TOOL")) for k in os.environ):
+        return None
+    res, t0 = {}, time.time()
+    for w in ("fb15k237_cpg", "wn18rr_cpg", "fb15k237_plain"):
+        left = budget_s - (time.time() - t0)
+        if left < 25:
+            break
+        try:
+            cp = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_train.py"), w], capture_output=True, text=True,
+                                timeout=min(90.0, left))
+            lines = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")]
+            if cp.returncode == 0 and lines:
+                d = json.loads(lines[-1])
+                res[w] = {"ms_per_step": d["ms_per_step"], "B": d["B"], "L": d["L"], "trainable_parameters": d["trainable_parameters"],
+                          "floor_ms": d["roofline"]["floor_ms"], "frac_of_floor": d["roofline"]["frac"], "bound": d["roofline"]["bound"]}
+            else:
+                res[w] = {"error": (cp.stderr or cp.stdout)[-300:]}
+        except Exception as e:      # (a timeout, a missing file: the line goes out without this entry)
+            res[w] = {"error": repr(e)[:300]}
+    if res:
+        res["how"] = ("tools/bench_train.py per workload in a child process: host clock over 20 steps after 3, synthetic batches resident on the "
+                      "device; floor = the larger of AMSGrad's slot traffic at 8 TB/s and the step's products at 2.5 PF")
+    return res
+
+
 def pmc_traffic(entry, workload, Q, kernel, exact=None):
     """HBM bytes per launch of `kernel`: NOT measured in this run -- replayed from the committed PMC summary of the
     same command (separate --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied); provenance recorded."""
@@ -129,6 +160,7 @@ def parse_args():
                     help="self-launched ranks (--gpus N from a plain shell) are stopped after this many seconds")
     ap.add_argument("--no-scale", action="store_true", help="skip the 10M-entity blocks (scale, HBM-regime roofline)")
     ap.add_argument("--no-extras", action="store_true", help="main line only: no f32 comparison, PCIe-inclusive loop, 10M blocks")
+    ap.add_argument("--no-train-lines", action="store_true", help="skip the training-step block (three child processes, ~10 s each)")
     ap.add_argument("--scale-side-communicator", action="store_true", help="scale block: the side stream's two collectives on a communicator of their own (EntityShardedRanker(side_communicator=True))")
     ap.add_argument("--no-scale-overlap", action="store_true", help="scale block: steps 1 - 2 of the next chunk on the count launch's own stream (A/B against the side stream)")
     ap.add_argument("--scale-steps", type=int, default=None, help="timed passes of the scale block (default min(steps, 10))")
@@ -836,6 +868,10 @@ def main():
             out["config"]["band_audit"] = band_audit
         if api:
             out["api"] = api
+        if extras and world == 1 and not entity_mode and args.workload == "fb15k237_cpg" and not args.no_train_lines:
+            tr = run_train_lines()
+            if tr:
+                out["train"] = tr
         out["config"]["synthetic_law"] = "ent_emb ~ N(0, 0.1^2) (SURVEY 8(d); rounds 1 - 3: 0.3), pred_bias ~ N(0, 0.1^2)"
         cnt = np.bincount(q["rel"])
         dm = cdata._dims(md)

@@ -1639,15 +1639,17 @@ static int train_step_impl(coper_handle* h, const int64_t* e1, const int64_t* re
   // behind what side[k] was given since.  Whatever leaves this function early joins what it forked (SideJoin).
   struct SideJoin {
     TrainState* T; hipStream_t s; int on[3] = {-1, -1, -1};
+    hipError_t err = hipSuccess;      // the first failure of an event call (checked where the step ends)
+    void note(hipError_t e) { if (e != hipSuccess && err == hipSuccess) err = e; }
     void fork(int i, int k) {
-      (void)hipEventRecord(T->ev_fork[i], s);
-      (void)hipStreamWaitEvent(T->side[k], T->ev_fork[i], 0);
+      note(hipEventRecord(T->ev_fork[i], s));
+      note(hipStreamWaitEvent(T->side[k], T->ev_fork[i], 0));
       on[i] = k;
     }
     void join(int i) {
       if (on[i] < 0) return;
-      (void)hipEventRecord(T->ev_join[i], T->side[on[i]]);
-      (void)hipStreamWaitEvent(s, T->ev_join[i], 0);
+      note(hipEventRecord(T->ev_join[i], T->side[on[i]]));
+      note(hipStreamWaitEvent(s, T->ev_join[i], 0));
       on[i] = -1;
     }
     ~SideJoin() { for (int i = 0; i < 3; ++i) join(i); }
@@ -2112,6 +2114,8 @@ static int train_step_impl(coper_handle* h, const int64_t* e1, const int64_t* re
   for (int i = 0; i < np; ++i)
     if (!sumsq_done.empty() && T->tp[i].name == sumsq_done) skip = i;
   sj.join(2);      // (dP and its squared norm)
+  sj.join(1);
+  if (sj.err != hipSuccess) return fail(h, COPER_EHIP, "coper_train_step: an event call of the side streams failed");
   hipLaunchKernelGGL(k_tr_sumsq, dim3(512, (unsigned)np), dim3(256), 0, s, tt, skip, ssq);
   const float lr_t = (float)((double)tc.learning_rate * std::sqrt(1.0 - T->b2p) / (1.0 - T->b1p));
   hipLaunchKernelGGL(k_tr_amsgrad, dim3(2048, (unsigned)np), dim3(256), 0, s, tt, ssq, red + 1, tc.clip_norm, lr_t, tc.beta1, tc.beta2,
