@@ -81,6 +81,8 @@ PROTOTYPES = {
     "coper_merge_shard_records": (C.c_int, [_P, _P, C.c_int32, _I64, C.c_int32, _P, _P, _P, _P, _P]),
     "coper_pack_ids_i32": (C.c_int, [_P, _I64, _P, _P, _I64, _P]),
     "coper_hits_means": (C.c_int, [_P, _I64, _P, C.c_int32, _P, _P, _P]),
+    "coper_sample_train_batch": (C.c_int, [C.c_int32, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, C.c_int32, C.c_double, _I64, C.c_uint64,
+                                           C.c_uint64, _P, _P, _P, _P, _P, _P]),
     "coper_band_policy": (C.c_int, [_P, C.c_float, _I64, C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
     "coper_prepare": (C.c_int, [_P, _P]),
     "coper_reserve": (C.c_int, [_P, _I64, _I64, _P]),

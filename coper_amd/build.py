@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libcoper_hip.so")
 SOURCES = ["coper_abi.hip", "kernels_prepare.hip", "kernels_encode.hip", "kernels_score.hip", "kernels_score_bf16.hip", "kernels_score3_bf16.hip", "kernels_tail_bf16.hip",
-           "kernels_encode_bf16.hip", "kernels_dense_fused_bf16.hip", "kernels_topk_bf16.hip", "coper_train.hip", "train_gemm_bf16.hip", "train_gemm_w128_bf16.hip"]
+           "kernels_encode_bf16.hip", "kernels_dense_fused_bf16.hip", "kernels_topk_bf16.hip", "coper_train.hip", "train_gemm_bf16.hip", "train_gemm_w128_bf16.hip", "sampler.hip"]
 
 
 def _hipcc():

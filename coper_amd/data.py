@@ -484,7 +484,10 @@ class DeviceTrainDataset(object):
     them as they are."""
 
     def __init__(self, samples, num_ent, batch_size, num_labels=100, seed=0, shuffle_buffer=1000, device="cuda:0",
-                 one_positive_label_per_sample=True, prop_negatives=10.0):
+                 one_positive_label_per_sample=True, prop_negatives=10.0, native=None):
+        """native: build the batch with the library's sampler kernel (`coper_sample_train_batch`: one launch, nothing read back;
+        round 6) -- the default on a GPU when num_labels <= 2048; False: the torch-op construction of rounds 2 - 5 (the only one on
+        the CPU; the same distribution, another random stream)."""
         self.num_ent, self.batch_size, self.num_labels = int(num_ent), int(batch_size), int(num_labels)
         self.one_pos, self.prop = bool(one_positive_label_per_sample), float(prop_negatives)
         if self.num_labels > self.num_ent:
@@ -510,6 +513,18 @@ class DeviceTrainDataset(object):
         self.d_rel = torch.as_tensor(np.asarray(samples["rel"], np.int64)).to(self.device)
         self.d_ip = torch.as_tensor(ip).to(self.device)
         self.d_tails = torch.as_tensor(self.row_tail).to(self.device)
+        self._k = k
+        can_native = self.device.type == "cuda" and self.num_labels <= 2048 and self.num_ent < 2 ** 31
+        if native and not can_native:
+            raise ValueError("DeviceTrainDataset(native=True) needs a GPU, num_labels <= 2048 and num_ent < 2^31")
+        self.native = can_native if native is None else bool(native)
+        self._seed, self._batch_no = int(seed) & (2 ** 64 - 1), 0
+        if self.native:
+            from . import _lib
+            self._lib = _lib.load()
+            # the batch's record ids (and positives) travel through a ring of pinned buffers: one asynchronous copy per batch
+            self._pins = [torch.empty(2 * self.batch_size, dtype=torch.int64).pin_memory() for _ in range(4)]
+            self._pin_ev = [None] * 4
 
     def _negatives(self, B, n=None):
         """[B, n] int64 (n = L - 1 by default): per row the first n entries of a fresh uniform permutation of the entities = an ordered uniform
@@ -535,7 +550,43 @@ class DeviceTrainDataset(object):
         keys = torch.rand((B, E), device=dev, generator=self.gen)
         return torch.argsort(keys, dim=1)[:, :n]
 
+    def _native_batch(self, ids):
+        """One launch of `coper_sample_train_batch` on the current stream.  ids: rows (one positive per row) or records (proportional)."""
+        dev, L, B = self.device, self.num_labels, len(ids)
+        slot = self._batch_no % len(self._pins)
+        if self._pin_ev[slot] is not None:
+            self._pin_ev[slot].synchronize()          # (the copy that read this buffer four batches ago: long done)
+        pin = self._pins[slot]
+        host = pin.numpy()
+        if self.one_pos:
+            rec = self.row_rec[ids]
+            host[:B] = rec
+            host[B:2 * B] = self.row_tail[ids]
+        else:
+            rec = np.asarray(ids, np.int64)
+            host[:B] = rec
+        staged = torch.empty(2 * B, dtype=torch.int64, device=dev)
+        staged.copy_(pin[:2 * B], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        self._pin_ev[slot] = ev
+        out = dict(e1=torch.empty(B, dtype=torch.int64, device=dev), rel=torch.empty(B, dtype=torch.int64, device=dev),
+                   e2=torch.empty(B, dtype=torch.int64, device=dev), lookup_values=torch.empty((B, L), dtype=torch.int32, device=dev),
+                   e2_multi=torch.empty((B, L), dtype=torch.float32, device=dev))
+        rc = self._lib.coper_sample_train_batch(
+            dev.index or 0, staged.data_ptr(), staged.data_ptr() + 8 * B if self.one_pos else None, self.d_e1.data_ptr(), self.d_rel.data_ptr(),
+            self.d_ip.data_ptr(), self.d_tails.data_ptr(), B, L, self.num_ent, 0 if self.one_pos else 1, self.prop, int(self._k[rec].max()),
+            self._seed, self._batch_no, out["e1"].data_ptr(), out["rel"].data_ptr(), out["e2"].data_ptr(), out["lookup_values"].data_ptr(),
+            out["e2_multi"].data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+        if rc != 0:
+            raise RuntimeError("coper_sample_train_batch failed with status %d" % rc)
+        # (`staged` is freed with this frame: the caching allocator hands its memory out again in THIS stream's order, behind the launch)
+        self._batch_no += 1
+        return out
+
     def _device_batch(self, rows):
+        if self.native:
+            return self._native_batch(rows)
         dev, E, L, B = self.device, self.num_ent, self.num_labels, len(rows)
         rows_d = torch.as_tensor(rows).to(dev)
         rec = torch.as_tensor(self.row_rec[rows]).to(dev)
@@ -556,6 +607,8 @@ class DeviceTrainDataset(object):
         """data.py:228-277: per record the tails in a fresh random order, then the head of a fresh permutation of ALL entities;
         num_positives_needed = int(L / (1 + prop_negatives)); a record with more tails than that keeps L - min(|E|, L - needed)
         of them.  Labels = membership in the tail list; e2 = the first tail of the shuffled order."""
+        if self.native:
+            return self._native_batch(recs)
         dev, E, L, B = self.device, self.num_ent, self.num_labels, len(recs)
         rec = torch.as_tensor(recs).to(dev)
         lo, hi = self.d_ip[rec], self.d_ip[rec + 1]

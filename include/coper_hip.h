@@ -385,6 +385,25 @@ COPER_API int coper_pack_ids_i32(const int64_t* src, int64_t n, int32_t* dst, co
 COPER_API int coper_hits_means(const int32_t* ranks, int64_t n, const int32_t* levels, int32_t n_levels, double* mean_rank, double* mrr,
                                double* hits);
 
+/* One training batch of the reference's samplers (CoPER_ConvE/qa_cpg/data.py:228-311), built on the device by ONE launch (round 6).
+ * Replaces what `train_dataset(...)`'s map function does per record on 32 tf.data threads (data.py:93-94, 138-156).  All pointers are
+ * device memory on `device`:
+ *   rec int64 [B]: the (e1, rel) record of each row of the batch (the host keeps the record stream, its shuffle buffer and the batching:
+ *     data.py:136-160 on ids only); pos_tail int64 [B]: the row's positive (one positive per row: data.py:278-311; NULL when proportional);
+ *   rec_e1, rec_rel int64 [n_rec]; tail_indptr int64 [n_rec + 1], tail_idx int64: the known train tails of every record (CSR);
+ *   max_tails: the longest tail list among the batch's records (sizes the workgroups' hash set of known tails);
+ *   proportional != 0: data.py:228-277 with prop_negatives -- the first `lead` of the record's tails in a fresh random order, then sampled
+ *     entities; lead = the number of tails when that is <= int(L / (1 + prop_negatives)), L - min(num_ent, L - that) otherwise;
+ * out: e1, rel, e2 int64 [B]; lookup int32 [B, L] (obj_lookup_values); labels float [B, L] (e2_multi: 1 where the looked-up entity is a
+ *   known tail of the record -- a sampled "negative" that is one is supervised as positive, as the reference comments).
+ * The sampled entities of a row are the head of a fresh uniform permutation of all entities (an ordered uniform sample without
+ * replacement), a function of (seed, batch, row) alone.  L <= 2048, num_ent < 2^31 (the lookup's dtype); EUNSUPPORTED otherwise.
+ * Asynchronous on `stream`; no handle: the sampler knows nothing of the model. */
+COPER_API int coper_sample_train_batch(int32_t device, const int64_t* rec, const int64_t* pos_tail, const int64_t* rec_e1,
+                                       const int64_t* rec_rel, const int64_t* tail_indptr, const int64_t* tail_idx, int64_t B, int64_t L,
+                                       int64_t num_ent, int32_t proportional, double prop_negatives, int64_t max_tails, uint64_t seed,
+                                       uint64_t batch, int64_t* e1, int64_t* rel, int64_t* e2, int32_t* lookup, float* labels, void* stream);
+
 /* Ids are validated on the device and clamped, never trusted: returns in *n_bad the number of
  * out-of-range relation ids seen by coper_encode since the last call (synchronises the stream). */
 COPER_API int coper_check_ids(coper_handle* h, int64_t* n_bad, void* stream);
