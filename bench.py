@@ -100,13 +100,17 @@ def run_train_lines(budget_s=150.0):
         if left < 25:
             break
         try:
-            cp = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_train.py"), w], capture_output=True, text=True,
+            fed = ["512", "1000", "--with-sampler"] if w == "fb15k237_cpg" else []      # (... and the loop fed by the device samplers, once)
+            cp = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_train.py"), w] + fed, capture_output=True, text=True,
                                 timeout=min(90.0, left))
-            lines = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")]
+            lines = [json.loads(ln) for ln in cp.stdout.splitlines() if ln.startswith("{")]
             if cp.returncode == 0 and lines:
-                d = json.loads(lines[-1])
+                d = lines[0]
                 res[w] = {"ms_per_step": d["ms_per_step"], "B": d["B"], "L": d["L"], "trainable_parameters": d["trainable_parameters"],
                           "floor_ms": d["roofline"]["floor_ms"], "frac_of_floor": d["roofline"]["frac"], "bound": d["roofline"]["bound"]}
+                for x in lines[1:]:
+                    if "sampler" in x:
+                        res[w].setdefault("fed_by_device_sampler_ms_per_step", {})[x["sampler"]] = x["ms_per_step"]
             else:
                 res[w] = {"error": (cp.stderr or cp.stdout)[-300:]}
         except Exception as e:      # (a timeout, a missing file: the line goes out without this entry)
