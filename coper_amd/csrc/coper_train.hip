@@ -1012,13 +1012,29 @@ __global__ __launch_bounds__(256) void k_tr_dc_from_partials(const float* __rest
 
 // Conv1BN backward, pass 1: g = dx * keep/(1-rate) through the ReLU; per-channel sums of g and g*yhat
 // (dbeta, dgamma).  g overwrites dx.
-__global__ __launch_bounds__(256) void k_tr_bn1_bwd_sums(float* __restrict__ dx, const float* __restrict__ y,
+// NS > 0 (round 6): dx arrives as the NS K slices of its product (tg_gemm_nt: leave_slices), added here in slice order -- the slice sum's
+// launch, its store of dx and this kernel's read of it are gone.
+template <int NS>
+__global__ __launch_bounds__(256) void k_tr_bn1_bwd_sums(float* __restrict__ dx, const float* __restrict__ part, const float* __restrict__ y,
                                                          const float* __restrict__ mean, const float* __restrict__ inv,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta, int C,
                                                          int64_t total, uint32_t seed, uint32_t step, uint32_t thr,
                                                          float keep_scale, double* __restrict__ sums, int nslots) {
   __shared__ double s1[256], s2[256];
   sums += (size_t)(blockIdx.x % nslots) * 2 * C;      // (TR_CS_SLOTS copies: k_tr_col_sums)
+  auto dx_in = [&](int64_t i) -> float {
+    if constexpr (NS == 0) {
+      return dx[i];
+    } else {
+      float t[NS];
+#pragma unroll
+      for (int z = 0; z < NS; ++z) t[z] = part[(int64_t)z * total + i];
+      float a = 0.f;
+#pragma unroll
+      for (int z = 0; z < NS; ++z) a += t[z];      // slice order, as k_tg_reduce
+      return a;
+    }
+  };
   if (256 % C != 0) {
     // channel counts that do not divide the workgroup: a thread meets every channel, so the channel sums are built in LDS
     // (C <= 256 doubles per array) with one LDS atomic pair per element, then added to the global sums
@@ -1028,7 +1044,7 @@ __global__ __launch_bounds__(256) void k_tr_bn1_bwd_sums(float* __restrict__ dx,
       const int c = (int)(i % C);
       const float yh = (y[i] - mean[c]) * inv[c];
       const float act = yh * gamma[c] + beta[c];
-      float g = dropout_keep_u32(seed, step, 1u, (uint32_t)i, thr) ? dx[i] * keep_scale : 0.f;
+      float g = dropout_keep_u32(seed, step, 1u, (uint32_t)i, thr) ? dx_in(i) * keep_scale : 0.f;
       if (!(act > 0.f)) g = 0.f;
       dx[i] = g;
       atomicAdd(&s1[c], (double)g);
@@ -1050,7 +1066,7 @@ __global__ __launch_bounds__(256) void k_tr_bn1_bwd_sums(float* __restrict__ dx,
   for (; i + 3 * st < total; i += 4 * st) {          // four load pairs in flight (one at a time: 20 dependent round trips, 40 us)
     float yv[4], dv[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { yv[u] = y[i + u * st]; dv[u] = dx[i + u * st]; }
+    for (int u = 0; u < 4; ++u) { yv[u] = y[i + u * st]; dv[u] = dx_in(i + u * st); }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const float yh = (yv[u] - mc) * ic;
@@ -1065,7 +1081,7 @@ __global__ __launch_bounds__(256) void k_tr_bn1_bwd_sums(float* __restrict__ dx,
   for (; i < total; i += st) {
     const float yh = (y[i] - mc) * ic;
     const float act = yh * gc + bc;
-    float g = dropout_keep_u32(seed, step, 1u, (uint32_t)i, thr) ? dx[i] * keep_scale : 0.f;
+    float g = dropout_keep_u32(seed, step, 1u, (uint32_t)i, thr) ? dx_in(i) * keep_scale : 0.f;
     if (!(act > 0.f)) g = 0.f;
     dx[i] = g;
     a1 += g;
@@ -1841,6 +1857,7 @@ static int train_step_impl(coper_handle* h, const int64_t* e1, const int64_t* re
   float* dTf = T->A + (size_t)rc_w * nBd;
   constexpr int LK_NSL = 4;      // F slices of the looked-up dense layer (deterministic partial sums)
   int t_slices = 1;              // K slices of the generated dense layer's product left for k_tr_fc_post_slices
+  int dx_slices = 1;             // K slices of the dx product left for k_tr_bn1_bwd_sums
   if (lk) {
     // z0[b] = x[b] W[rel[b]]: one pass over the looked-up rows (B * F * d * 4 bytes)
     hipLaunchKernelGGL(k_tr_lookup_fwd, dim3((unsigned)B, LK_NSL), dim3(256), sizeof(float) * (size_t)((F + LK_NSL - 1) / LK_NSL + 1), s, T->x,
@@ -2005,7 +2022,8 @@ static int train_step_impl(coper_handle* h, const int64_t* e1, const int64_t* re
     if ((rc = tg_pack(h, dTf, tg_idx2(d, nBd, 1), tg_idx(d), nrk, B, tg_rows_pad(nrk), true, T->pTn, s, T->tg_scratch, nullptr, T->dtmax))) return rc;
     if ((rc = tg_pack(h, dTf, tg_idx(d), tg_idx2(d, nBd, 1), B, nrk, tg_rows_pad(B), false, T->pTb, s, T->tg_scratch, T->pTn.exp))) return rc;
     if (!p3_packed && (rc = tg_pack(h, Wmat, tg_idx(d), tg_idx2(d, F * (int64_t)d, 1), F, nrk, tg_rows_pad(F), false, T->pP3, s, T->tg_scratch, T->pP1.exp))) return rc;
-    if ((rc = tg_gemm_split(h, T, s, T->pTb, B, T->pP3, F, nrk, dxin, tg_idx(F), tg_idx(1)))) return rc;
+    // (the K slices of dx stay in the partial-sum pool for k_tr_bn1_bwd_sums when dx IS the conv features' gradient: no concat_rel)
+    if ((rc = tg_gemm_split(h, T, s, T->pTb, B, T->pP3, F, nrk, dxin, tg_idx(F), tg_idx(1), cat ? nullptr : &dx_slices))) return rc;
     // the dP product's result is read by the optimizer only: BEHIND the dx product, on the second side stream, beside the dozen short
     // launches between here and the optimizer (slice sum, Conv1BN and conv backward, the generators' chains).  (Beside the dx product
     // itself the two took 211 us for 100 + 84: a SIMD holds one wave of either.)
@@ -2050,8 +2068,18 @@ static int train_step_impl(coper_handle* h, const int64_t* e1, const int64_t* re
   };
   if (gen) { chain_backward(0, nh); chain_backward(1, nh); }
   colsum = cs_slots(1);
-  hipLaunchKernelGGL(k_tr_bn1_bwd_sums, dim3((unsigned)((nBF + 255) / 256 < 2048 ? (nBF + 255) / 256 : 2048)), dim3(256), 0, s, T->dx, T->y, mean1, inv1, P_("Conv1BN/gamma"),
-                     P_("Conv1BN/beta"), C, nBF, tc.seed, step, thr_h, ks_h, colsum, cs_n);
+  {
+    const dim3 g1((unsigned)((nBF + 255) / 256 < 2048 ? (nBF + 255) / 256 : 2048));
+#define COPER_BN1_SUMS(NS)                                                                                                                \
+  case NS:                                                                                                                                \
+    hipLaunchKernelGGL(k_tr_bn1_bwd_sums<NS>, g1, dim3(256), 0, s, T->dx, NS ? T->mmP : nullptr, T->y, mean1, inv1, P_("Conv1BN/gamma"), \
+                       P_("Conv1BN/beta"), C, nBF, tc.seed, step, thr_h, ks_h, colsum, cs_n);                                             \
+    break;
+    switch (dx_slices > 1 ? dx_slices : 0) {
+      COPER_BN1_SUMS(0) COPER_BN1_SUMS(2) COPER_BN1_SUMS(3) COPER_BN1_SUMS(4) COPER_BN1_SUMS(5) COPER_BN1_SUMS(6) COPER_BN1_SUMS(7) COPER_BN1_SUMS(8)
+    }
+#undef COPER_BN1_SUMS
+  }
   hipLaunchKernelGGL(k_tr_fold_slots, dim3(1), dim3(256), 0, s, colsum, 2 * C, cs_n);
   hipLaunchKernelGGL(k_tr_bn1_bwd_apply, dim3((unsigned)((nBF + 255) / 256)), dim3(256), 0, s, T->dx, T->y, mean1, inv1, P_("Conv1BN/gamma"),
                      colsum, C, nBF, (double)B * P, use_batch, G_("Conv1BN/gamma"), G_("Conv1BN/beta"));
