@@ -10,12 +10,16 @@
 //     dense: static z0 = x W (one GEMM); generated z[b] = sum_rho ctx[b,rho] (x[b] P[rho]) -- the FACTORED form: r
 //            independent [B,F]x[F,d] products (one strided-batched GEMM), the [B,F,d] weight tensor of
 //            models.py:70,412 is never formed; g_lookup: one pass over the looked-up [F,d] rows  (k_tr_lookup_*)
-//     + dense bias, dropout, FCBN, ReLU -> h [B, d]                                   k_tr_fc_post, k_tr_fcbn_fwd
-//     sampled scorer s[b,l] = h[b] . ent_emb[lookup[b,l]] + pred_bias[...] (k_tr_score_loss) or 1-vs-all (GEMM)
+//     + dense bias, dropout, FCBN, ReLU -> h [B, d]                                   k_tr_fc_post(_slices), k_tr_fcbn_fwd
+//     sampled scorer s[b,l] = h[b] . ent_emb[lookup[b,l]] + pred_bias[...] and the loss: k_tr_score_loss_dh (round 6: with ds and
+//     dh = sum_l ds E[lookup] from the same pass over the gathered rows; k_tr_score_loss where d % 4 != 0) or 1-vs-all (GEMM)
 //   backward: the transposes of the above (dense: dP[rho] = x^T (ctx[:,rho] . dz) batched, dA = dz P2^T one GEMM, then
 //   the contraction with ctx / x); embedding-row gradients by float atomics or, when B*|E| is small, through a dense
-//   d(loss)/d(logits) matrix and one GEMM.  Every GEMM is the split-bf16 MFMA kernel of train_gemm_bf16.hip (no library).
+//   d(loss)/d(logits) matrix and one GEMM.  Every GEMM is the split-fp16 MFMA kernel of train_gemm_bf16.hip (no library).
 //   optimiser: tf.clip_by_global_norm + AMSGrad (amsgrad.py:130-159), one launch each over all tensors.
+//   Schedule (round 6): the scorer's backward and the dP product run on two side streams of the training state, forked from and
+//   joined to the caller's stream by events (train_step_impl: SideJoin); K slices of the few-tile products are added by the
+//   kernels that consume them (k_tr_fc_post_slices, k_tr_bn1_bwd_sums<NS>), not by a launch of their own.
 #include <cmath>
 #include <cstring>
 
