@@ -23,13 +23,13 @@ HBM, MFMA = 8.0e12, 2.5e15
 WORK = {
     "k_tr_amsgrad": [("AMSGrad + clip: p, g, m, v, v_hat read, p, m, v, v_hat written, every trainable element", 9 * 4 * N_PARAM, 0, 1)],
     "k_gemm_nt_w128_bf16x3": [("T = x P   [B] x [r d], K = F (five K slices)", 4 * (B * F + P_ELEMS + 5 * r * B * d), 2.0 * B * r * F * d, 3),
-                              ("dP = x^T dT   [F] x [r d], K = B", 4 * (B * F + r * B * d + P_ELEMS), 2.0 * B * r * F * d, 3),
-                              ("dx = dT P^T   [B] x [F], K = r d (seven K slices)", 4 * (r * B * d + P_ELEMS + 7 * B * F), 2.0 * B * r * F * d, 3)],
+                              ("dx = dT P^T   [B] x [F], K = r d (seven K slices)", 4 * (r * B * d + P_ELEMS + 7 * B * F), 2.0 * B * r * F * d, 3),
+                              ("dP = x^T dT   [F] x [r d], K = B (launched behind dx since round 6)", 4 * (B * F + r * B * d + P_ELEMS), 2.0 * B * r * F * d, 3)],
     "k_gemm_nt_bf16x3": [("dE = S^T h   [E] x [d], K = B", 4 * (B * E + B * d + E * d), 2.0 * B * E * d, 3)],
     "k_pack_frag_both": [("both 16-bit views of the projection from one read: 118 MB in, 2 x 118 MB out", 4 * P_ELEMS * 3, 0, 1)],
     "k_tr_score_loss_dh": [("sampled scorer, forward and dh: B L rows of d floats gathered ONCE (table resident in L2 / MALL), loss, ds", 4 * B * L * d, 4.0 * B * L * d, 1)],
     "k_tr_conv_bwd": [("conv backward: dx [B, F] read, image gradients and per-query filter gradients", 4 * (B * F + B * 200 + B * 320), 2.0 * 2 * B * F * 9, 1)],
-    "k_tr_bn1_bwd_sums": [("BN1 backward sums: y and dx read, dx (ReLU / dropout applied) written", 4 * 3 * B * F, 0, 1)],
+    "k_tr_bn1_bwd_sums": [("BN1 backward sums: y and the seven K slices of dx read, dx (ReLU / dropout applied) written", 4 * 9 * B * F, 0, 1)],
     "k_tr_bn1_bwd_apply": [("BN1 backward apply: y, dx read, dx written", 4 * 3 * B * F, 0, 1)],
     "k_tr_fc_post_slices": [("z1 and T from the five K slices of x P: 5 x [B, r d] read, T [r, B, d] and z1 written", 4 * (6 * r * B * d + B * d), 2.0 * B * r * d, 1)],
     "k_tr_fc_post_bwd": [("dropout / bias backward of the dense layer: dz [B, d]", 4 * 3 * B * d, 0, 1)],
