@@ -189,6 +189,7 @@ __global__ __launch_bounds__(256) void k_tr_conv_fwd(const int64_t* __restrict__
 // per-column sums of a [rows, cols] matrix in double: out[0..cols) = sum, out[cols..2cols) = sum of squares
 // (partial sums by row chunk, then atomics on doubles: order-dependent only in the last bits of a double)
 // everything the step accumulates into with atomics, zeroed by ONE launch (was a dozen memsets of ~5 us each)
+constexpr int TR_LK_NSL = 4;     // F slices of the looked-up dense layer's forward (partial sums in T->dx)
 constexpr int TR_ZERO_MAX = 16;
 constexpr int TR_COLSUM_SLICES = 20;   // column-sum scratch: one slice per use within a step (see colsum_slice)
 struct ZeroList {
@@ -1695,7 +1696,10 @@ static int train_step_impl(coper_handle* h, const int64_t* e1, const int64_t* re
     COPER_HIP_TRY(h, hipStreamSynchronize(s));
     int64_t cb = B > T->capB ? B : T->capB, cl = (!one_vs_all && L > T->capL) ? L : (T->capL > 0 ? T->capL : 1);
     if ((rc = talloc(h, &T->img, (size_t)cb * isz)) || (rc = talloc(h, &T->y, (size_t)cb * F)) ||
-        (rc = talloc(h, &T->x, (size_t)cb * F)) || (rc = talloc(h, &T->dx, (size_t)cb * F)) ||
+        (rc = talloc(h, &T->x, (size_t)cb * F)) ||
+        // (dx doubles as the looked-up dense layer's scratch: TR_LK_NSL partial sums of [B, d] -- more than [B, F] where F < 4 d: a fuzz
+        //  shape of round 6, d = 77 with three channels, wrote past the end of it)
+        (rc = talloc(h, &T->dx, (size_t)cb * (size_t)(F > (int64_t)TR_LK_NSL * d ? F : (int64_t)TR_LK_NSL * d))) ||
         (rc = talloc(h, &T->c, (size_t)cb * r)) || (rc = talloc(h, &T->dc, (size_t)cb * r)) ||
         (rc = talloc(h, &T->z0, (size_t)cb * d)) || (rc = talloc(h, &T->z1, (size_t)cb * d)) ||
         (rc = talloc(h, &T->hv, (size_t)cb * d)) || (rc = talloc(h, &T->dh, (size_t)cb * d)) ||
@@ -1859,13 +1863,13 @@ static int train_step_impl(coper_handle* h, const int64_t* e1, const int64_t* re
   const int64_t nBd = B * d;
   float* Tf = T->A;                 // T[rho][b][k]
   float* dTf = T->A + (size_t)rc_w * nBd;
-  constexpr int LK_NSL = 4;      // F slices of the looked-up dense layer (deterministic partial sums)
+  constexpr int LK_NSL = TR_LK_NSL;      // F slices of the looked-up dense layer (deterministic partial sums)
   int t_slices = 1;              // K slices of the generated dense layer's product left for k_tr_fc_post_slices
   int dx_slices = 1;             // K slices of the dx product left for k_tr_bn1_bwd_sums
   if (lk) {
     // z0[b] = x[b] W[rel[b]]: one pass over the looked-up rows (B * F * d * 4 bytes)
     hipLaunchKernelGGL(k_tr_lookup_fwd, dim3((unsigned)B, LK_NSL), dim3(256), sizeof(float) * (size_t)((F + LK_NSL - 1) / LK_NSL + 1), s, T->x,
-                       P_("fc_weights"), rel, dm.R, F, d, LK_NSL, B, T->dx /* scratch: [NSL][B][d] fits in [B][F] */);
+                       P_("fc_weights"), rel, dm.R, F, d, LK_NSL, B, T->dx /* scratch: [NSL][B][d], allocated for it */);
     hipLaunchKernelGGL(k_tr_lookup_post, dim3((unsigned)((nBd + 255) / 256)), dim3(256), 0, s, T->dx, LK_NSL, P_("fc_bias"), rel, dm.R, d, nBd,
                        tc.seed, step, thr_o, ks_o, T->z1);
   } else {

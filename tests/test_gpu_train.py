@@ -29,6 +29,10 @@ _CASES = {
     # looked-up conv filters with a STATIC dense layer (models.py:217-228 with context_rel_out None)
     "lookup_conv_static_fc": dict(num_ent=211, num_rel=6, ent_emb_size=40, rel_emb_size=1, emb_h=10, emb_w=4, conv_num_channels=8,
                                   context_rel_conv=[], context_rel_out=None, do_parameter_lookup=True),
+    # a looked-up dense layer whose input is NARROWER than four outputs (F = 5 * 9 * 3 = 135 < 4 * 77): its forward keeps four partial sums
+    # of [B, d] in the workspace that also holds dx [B, F] -- until round 6 sized for dx alone (found by the 96-shape fuzz run)
+    "lookup_narrow_F": dict(num_ent=130, num_rel=6, ent_emb_size=77, rel_emb_size=1, emb_h=7, emb_w=11, conv_num_channels=3,
+                            context_rel_conv=[], context_rel_out=[], do_parameter_lookup=True),
     "cpg_linear_concat": dict(num_ent=211, num_rel=6, ent_emb_size=40, rel_emb_size=8, emb_h=10, emb_w=4, conv_num_channels=8,
                               context_rel_conv=None, context_rel_out=[], concat_rel=True),
     "plain_concat": dict(num_ent=211, num_rel=6, ent_emb_size=40, rel_emb_size=40, emb_h=10, emb_w=4, conv_num_channels=8,
@@ -84,7 +88,8 @@ def _fuzz_cases(n):
     return out
 
 
-_CASES.update(_fuzz_cases(12))
+import os as _os
+_CASES.update(_fuzz_cases(int(_os.environ.get("COPER_TRAIN_FUZZ", "12"))))      # (COPER_TRAIN_FUZZ=96: the same tests as a soak of random shapes)
 
 
 def _batch(md, B, L, seed):
