@@ -186,3 +186,11 @@ def test_the_c_abi_refuses_what_it_cannot_do():
     assert lib.coper_sample_train_batch(*args(4096, 100000)) == 7        # COPER_EUNSUPPORTED: L beyond the LDS plan
     assert lib.coper_sample_train_batch(*args(8, 4)) == 1                # COPER_EINVAL: more labels than entities (data.py:146-147)
     assert lib.coper_sample_train_batch(*args(8, 100, pos=False)) == 1   # one positive per row needs the positives
+
+
+def test_sampler_soak_short():
+    """tests/sampler_soak.py: random graphs, label counts, batch sizes and samplers; every row by the construction rules."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "sampler_soak.py"), "120", "9"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "every row by the construction rules" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
