@@ -2172,6 +2172,17 @@ COPER_API int coper_train_step(coper_handle* h, const int64_t* e1, const int64_t
   return train_step_impl(h, e1, rel, lookup, labels, B, L, loss_out, stream, 1, nullptr, nullptr);
 }
 
+namespace coper {
+namespace {
+// coper_train_grad on a looked-up table: rows of relations the last batch did not hold are never written by the step (the optimizer and
+// the global norm skip them by their count) -- the copy handed out shows them as the zeros they are
+__global__ __launch_bounds__(256) void k_tr_zero_absent_rows(float* __restrict__ out, const int32_t* __restrict__ rowcnt, int64_t rowlen, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    if (rowcnt[i / rowlen] == 0) out[i] = 0.f;
+}
+}  // namespace
+}  // namespace coper
+
 COPER_API int coper_train_forward(coper_handle* h, const int64_t* e1, const int64_t* rel, const int32_t* lookup, const float* labels,
                                   int64_t B, int64_t L, float* loss_out, float* pred_out, float* h_out, void* stream) {
   return train_step_impl(h, e1, rel, lookup, labels, B, L, loss_out, stream, 0, pred_out, h_out);
@@ -2188,6 +2199,12 @@ COPER_API int coper_train_grad(coper_handle* h, const char* leaf_name, float* ou
   if (out) {
     if (cap < t->n) return fail(h, COPER_EINVAL, "coper_train_grad: output buffer too small");
     COPER_HIP_TRY(h, hipMemcpyAsync(out, t->g, sizeof(float) * t->n, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    if (h->dm.lookup && h->dm.gen_fc && t->name == "fc_weights" && h->rel_count && T->step > 0) {
+      const int64_t rowlen = h->dm.F * (int64_t)h->dm.d;
+      hipLaunchKernelGGL(k_tr_zero_absent_rows, dim3((unsigned)((t->n + 255) / 256 < 4096 ? (t->n + 255) / 256 : 4096)), dim3(256), 0, (hipStream_t)stream, out,
+                         h->rel_count, rowlen, t->n);
+      COPER_HIP_TRY(h, hipGetLastError());
+    }
   }
   if (global_norm) {
     COPER_HIP_TRY(h, hipStreamSynchronize((hipStream_t)stream));

@@ -477,7 +477,9 @@ COPER_API int coper_train_forward(coper_handle* h, const int64_t* e1, const int6
                                   void* stream);
 /* Diagnostics: copies the (unclipped) gradient of the last step for a trainable leaf into `out` (device float
  * buffer of `cap` elements; may be NULL), returns its length in *n, and in *global_norm (optional, host) the
- * global gradient norm of the last step (synchronises). */
+ * global gradient norm of the last step (synchronises).  Call it before anything regroups a batch by relation (an evaluation pass): the
+ * looked-up dense table's rows of relations the last batch did not hold are not written by a step -- optimizer and norm skip them by the
+ * batch's relation counts -- and are handed out as the zeros they stand for by those same counts. */
 COPER_API int coper_train_grad(coper_handle* h, const char* leaf_name, float* out, int64_t cap, int64_t* n,
                                double* global_norm, void* stream);
 

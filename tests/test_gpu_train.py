@@ -133,6 +133,30 @@ def test_train_step_matches_oracle_with_long_lookups(name, L):
     _train_step_case(name, True, False, "n0.1", B=24, L=L, steps=2)
 
 
+def _shape_cases():
+    n = int(_os.environ.get("COPER_TRAIN_SHAPE_FUZZ", "10"))      # (COPER_TRAIN_SHAPE_FUZZ=200: a soak of batch shapes)
+    rng = np.random.default_rng(77)
+    names = ["cpg_linear", "plain", "cpg_mlp_bn", "lookup", "cpg_conv_fc", "lookup_narrow_F", "cpg_linear_c32", "fuzz_03", "fuzz_06", "fuzz_d288"]
+    out = []
+    for i in range(n):
+        B = int(rng.choice([2, 3, 5, 17, 31, 64, 65, 100, 129]))
+        L = int(rng.choice([1, 2, 5, 36, 63, 64, 65, 130, 251, 252, 253, 256, 257, 505, 1001]))
+        # (batch statistics over 2 - 5 samples are ill-conditioned -- FCBN of two samples is +-1 whatever they were: rounding differences of
+        #  the step come back amplified past the tolerances that hold from 8 samples on; those batches take the moving statistics)
+        out.append((names[i % len(names)], B, L, bool(rng.random() < 0.7) and B >= 8))
+    return out
+
+
+@pytest.mark.parametrize("name,B,L,train_stats", _shape_cases())
+def test_train_step_matches_oracle_over_batch_shapes(name, B, L, train_stats):
+    """Batch shapes around every grain of the step's kernels: 2 ... 129 queries, 1 ... 1,001 lookup entries (a batch of the fused scorer is
+    60 - 252 rows, a workgroup 256 threads, a GEMM tile 128 rows)."""
+    md = _CASES[name]
+    if L > md["num_ent"]:
+        L = md["num_ent"]
+    _train_step_case(name, train_stats, False, "n0.1", B=B, L=L, steps=2)
+
+
 def _train_step_case(name, train_stats, one_vs_all, init, B=48, L=37, steps=3):
     from coper_amd.models import ConvE
     from oracle import coper_train_oracle as T
