@@ -47,7 +47,10 @@ def _random_case(seed):
     return variant, md, Q
 
 
-@pytest.mark.parametrize("seed", range(60))
+import os as _os
+
+
+@pytest.mark.parametrize("seed", range(int(_os.environ.get("COPER_EVAL_FUZZ", "60"))))      # (COPER_EVAL_FUZZ=600: the same test as a soak)
 def test_random_shapes_against_oracle(oracle_chain, seed):
     from coper_amd.models import ConvE
     O = oracle_chain
