@@ -126,10 +126,11 @@ def test_train_step_matches_oracle_from_the_reference_init(name):
     _train_step_case(name, True, False, "reference")
 
 
-@pytest.mark.parametrize("name,L", [("cpg_linear", 700), ("plain", 301), ("cpg_wide", 1000), ("fuzz_d288", 259)])
+@pytest.mark.parametrize("name,L", [("cpg_linear", 700), ("plain", 301), ("cpg_wide", 1000), ("fuzz_d288", 259), ("cpg_linear", 9000), ("lookup", 8193)])
 def test_train_step_matches_oracle_with_long_lookups(name, L):
     """Lookups longer than a workgroup (k_tr_score_loss_dh takes the rows of a query in batches of <= 256, a thread per row of the
-    batch when it scores them: at d = 40 a batch is 252 rows, at d = 200 60) -- the sampled cases above have L = 37."""
+    batch when it scores them: at d = 40 a batch is 252 rows, at d = 200 60) -- the sampled cases above have L = 37.  Beyond 8,192 entries
+    the row ids no longer fit the kernel's LDS plan: the two-kernel path of rounds 1 - 5 takes those."""
     _train_step_case(name, True, False, "n0.1", B=24, L=L, steps=2)
 
 
