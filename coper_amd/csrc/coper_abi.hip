@@ -56,8 +56,20 @@ static std::mutex g_ledger_mu;
 static std::unordered_map<void*, size_t> g_ledger;
 static int64_t g_ledger_bytes = 0;
 
+// COPER_DBG_REDZONE=<bytes> (round 6): every allocation of the library is followed by that many bytes of 0xA5; when it is freed the
+// bytes are read back and a changed one ends the process with the allocation's size -- a kernel that writes past the end of a
+// workspace fails the first test that frees it instead of whichever test owns the neighbouring memory (found the way this was built:
+// a workspace of the training step sized for one of its two uses, overrun for 12 rounds of tests that happened not to notice).
+static size_t redzone_bytes() {
+  static const char* rz = getenv("COPER_DBG_REDZONE");
+  static const size_t n = rz ? (size_t)strtoull(rz, nullptr, 0) : 0;
+  return n;
+}
+
 hipError_t tracked_malloc_impl(void** p, size_t bytes) {
-  const hipError_t e = hipMalloc(p, bytes);
+  const size_t rz = redzone_bytes();
+  const hipError_t e = hipMalloc(p, bytes + rz);
+  if (e == hipSuccess && *p && rz) (void)hipMemset((char*)*p + bytes, 0xA5, rz);
   // COPER_DBG_POISON=<byte>: every allocation of the library starts filled with that byte (0xFF: NaN patterns) -- a kernel that
   // reads workspace nobody wrote shows up as a wrong result in the first test that runs, not in whichever test inherits a
   // predecessor's memory (tools/README.md)
@@ -88,12 +100,29 @@ hipError_t tracked_malloc_impl(void** p, size_t bytes) {
 
 hipError_t tracked_free(void* p) {
   if (!p) return hipSuccess;
+  size_t bytes = 0;
+  bool known = false;
   {
     std::lock_guard<std::mutex> lk(g_ledger_mu);
     auto it = g_ledger.find(p);
     if (it != g_ledger.end()) {
+      bytes = it->second;
+      known = true;
       g_ledger_bytes -= (int64_t)it->second;
       g_ledger.erase(it);
+    }
+  }
+  const size_t rz = redzone_bytes();
+  if (known && rz) {
+    std::vector<unsigned char> tail(rz);
+    if (hipDeviceSynchronize() == hipSuccess && hipMemcpy(tail.data(), (char*)p + bytes, rz, hipMemcpyDeviceToHost) == hipSuccess) {
+      for (size_t i = 0; i < rz; ++i)
+        if (tail[i] != 0xA5) {
+          fprintf(stderr, "[coper] COPER_DBG_REDZONE: byte %zu behind an allocation of %zu bytes was overwritten (0x%02x)\n", i, bytes, tail[i]);
+          abort();
+        }
+    } else {
+      (void)hipGetLastError();
     }
   }
   return hipFree(p);
